@@ -1,0 +1,175 @@
+/*
+ * tlcgnn.h -- C ABI of libtlcgnn_hip.so: the MI355X (gfx950) implementation of TLC-GNN / PDGNN's
+ * per-edge topological-feature hot path (vicinity subgraph -> extended persistence diagram ->
+ * persistence image -> link-prediction forward).
+ *
+ * The reference (pkuyzy/TLC-GNN) has no FFI layer of its own: its boundary is a set of Python call
+ * signatures.  Each entry point below names the reference interface (file:line under /root/reference)
+ * that it replaces; INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in signatures (`stream` is a hipStream_t
+ *     passed as void*, NULL = the default stream);
+ *   - pointers prefixed d_ are DEVICE pointers, h_ are HOST pointers;
+ *   - the caller allocates every buffer; the library keeps nothing beyond the call except the
+ *     `tlc_graph` handle (which owns a device copy of the CSR and the kernels' scratch);
+ *   - every call is stream-ordered and asynchronous unless stated otherwise; outputs are fully
+ *     overwritten (zero rows are written explicitly, mirroring `pi_sg = np.zeros(...)`,
+ *     sg2dgm/riccidist2dgm.py:363);
+ *   - return value: TLC_OK or a TLC_ERR_* code for API misuse / runtime failure.  Per-pair conditions
+ *     that the reference swallows into a zero row (`except BaseException`, riccidist2dgm.py:352-357)
+ *     are reported in the per-pair status byte, never as a return code.
+ */
+#ifndef TLCGNN_H
+#define TLCGNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- return codes ------------------------------------------------------------------------------ */
+#define TLC_OK                 0
+#define TLC_ERR_INVALID_ARG    1
+#define TLC_ERR_HIP            2   /* a HIP runtime call failed; see tlc_last_error() */
+#define TLC_ERR_NO_DEVICE      3
+#define TLC_ERR_UNSUPPORTED    4   /* e.g. graph too large for the LDS-resident vicinity bitmaps */
+#define TLC_ERR_OUT_OF_MEMORY  5
+
+/* ---- per-pair status byte (the reference's swallowed exception classes) ---------- */
+#define TLC_ST_OK              0   /* row computed (may still be all zero: d(u,v) > hop)            */
+#define TLC_ST_MISSING_NODE    1   /* KeyError: endpoint has no edge (graph is built from edges)    */
+#define TLC_ST_DISCONNECTED    2   /* AssertionError: vicinity empty or not connected (:318)        */
+#define TLC_ST_ZERO_RANGE      3   /* ZeroDivisionError: all filtration values 0 (:54)              */
+#define TLC_ST_NO_TREE_EDGE    4   /* IndexError: single-node vicinity (accelerated_PD.py:122)      */
+
+/* ---- variant flags (one kernel family serves the TLC-GNN and the PDGNN forks) ---- */
+#define TLC_KEEP_ZERO_PERS   0x01u /* Knowledge_Distillation/accelerated_PD.py:68-69,108-109,169-170 */
+#define TLC_INCLUDE_ROOTS    0x02u /* Knowledge_Distillation/data_utils_LP.py:111                    */
+#define TLC_NORM_EPS         0x04u /* divide by (max + 1e-10): data_utils_LP.py:64                   */
+#define TLC_PI_ORD0_EXT1     0x08u /* image over Ord0 ++ Ext1 only: data_utils_GC.py:155-163         */
+#define TLC_NO_EXT1          0x10u /* extended_flag=False: riccidist2dgm.py:323-326                  */
+
+typedef struct tlc_graph tlc_graph;   /* opaque: device CSR + scratch, bound to one device */
+
+/* ---- library ------------------------------------------------------------------------------------ */
+const char* tlc_version(void);
+const char* tlc_last_error(void);          /* thread-local text of the last TLC_ERR_* */
+int  tlc_device_count(void);
+
+/* ---- P1: graph2pi.__init__ (sg2dgm/riccidist2dgm.py:216-226) ------------------------------------
+ * Symmetric CSR of the weighted graph: node ids 0..n_nodes-1, h_w[e] = kappa_e + 1 (must be > 0),
+ * both directions present.  Nodes with an empty row are "missing" (TLC_ST_MISSING_NODE), exactly as
+ * the reference's graph is built from edges only (loaddatas.py:88-92).  Synchronous (uploads). */
+int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const int32_t* h_col, const double* h_w,
+                     int device, tlc_graph** out);
+int tlc_graph_destroy(tlc_graph* g);
+
+/* ---- P2-P9: graph2pi.get_pimg_for_all_edges (sg2dgm/riccidist2dgm.py:348-370) ------------------
+ * For every pair (u,v): S = ball_hop(u) & ball_hop(v) on the unweighted graph (:311-316), induced
+ * subgraph, filtration f = (d(x,u)+d(x,v)) / max with node-sourced weighted shortest paths (:20-61),
+ * perturbed keys + two union-find passes + spanning-tree cycle swap (accelerated_PD.py:6-178),
+ * res x res Gaussian persistence image (PersistenceImager.pyx:352-388).
+ *   d_pairs      int32[n_pairs,2]
+ *   d_out_pi     float64[n_pairs, res*res], row-major [birth_bin*res + pers_bin]
+ *   d_out_status uint8[n_pairs] (may be NULL)
+ * hop >= 1; res in 1..8. */
+int tlc_pd_pi_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags,
+                    int res, double* d_out_pi, uint8_t* d_out_status, void* stream);
+
+/* Same pipeline, stopping after the filtration (used by tests and by the PDGNN 'filtration' mode,
+ * Knowledge_Distillation/data_utils_LP.py:105-200 mode='filtration'):
+ *   d_node_offs  int64[n_pairs+1]  (caller-provided capacity layout: slot i holds up to
+ *                                   node_offs[i+1]-node_offs[i] nodes)
+ *   d_out_ids    int32[cap]  ascending node ids of S;  d_out_f float64[cap];  d_out_n int32[n_pairs]
+ * A vicinity larger than its slot sets d_out_n[i] = -(size). */
+int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags,
+                            const int64_t* d_node_offs, int32_t* d_out_ids, double* d_out_f,
+                            int32_t* d_out_n, uint8_t* d_out_status, void* stream);
+
+/* Counters of the last tlc_pd_pi_batch on this handle (synchronises the stream):
+ * h_out[0..7] = pairs in tier small / medium / large, rows non-zero, sum |S|, sum induced edges,
+ *               sources that needed the exact tie fallback, reserved. */
+int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream);
+
+/* ---- P6-P8: perturb_filter_function / Union_find / Accelerate_PD ---------------------------------
+ * (sg2dgm/accelerated_PD.py:6-178 and the Knowledge_Distillation fork, selected by TLC_KEEP_ZERO_PERS)
+ * Batch of n_graphs independent graphs with caller-supplied filtration values.
+ *   d_node_offs int64[n_graphs+1], d_edge_offs int64[n_graphs+1]
+ *   d_edges     int32[sum m, 2] local node ids;  d_f float64[sum n]
+ * Outputs (slot of graph g starts at node_offs[g] resp. edge_offs[g]):
+ *   d_pd_up    float64[sum n, 2]  Ord0 points   (ascending pass, :46-68)
+ *   d_pd_down  float64[sum n, 2]  Rel1 points   (descending pass, :83-109)
+ *   d_pd_one   float64[sum m, 2]  Ext1 points   (:115-178)
+ *   d_ext0     float64[n_graphs, 2]  [min f, max f] (:110)
+ *   d_counts   int32[n_graphs, 4] = {#up, #down, #one, #connected components}
+ *   d_edge_rank int32[sum m] (may be NULL): >= 0: position among the Pos edges, in descending-pass
+ *               order (:109); < 0: -(position among the Neg edges)-1 (:99). */
+int tlc_pd_from_filtration(int32_t n_graphs, const int64_t* d_node_offs, const int64_t* d_edge_offs,
+                           const int32_t* d_edges, const double* d_f, uint32_t flags,
+                           double* d_pd_up, double* d_pd_down, double* d_pd_one, double* d_ext0,
+                           int32_t* d_counts, int32_t* d_edge_rank, void* stream);
+
+/* ---- P9: PersistenceImager(resolution=res).transform (sg2dgm/PersistenceImager.pyx:352-388) -------
+ * isotropic sigma=1 Gaussian, ranges [0,1]^2, linear-ramp weight (:9-30), birth-death input (skew=True).
+ *   d_offs int64[n_dgms+1];  d_pts float64[sum k, 2];  d_out float64[n_dgms, res*res] */
+int tlc_pi_raster(int32_t n_dgms, const int64_t* d_offs, const double* d_pts, int res, double* d_out,
+                  void* stream);
+
+/* ---- M1-M3: TLCGNN forward (baselines/TLCGNN.py:19-62) ------------------------------------------- */
+
+/* gcn_norm of GCNConv(cached=True) (in-tree spec: Knowledge_Distillation/PD_conv.py:35-70): add the
+ * remaining self loops (w=1), deg = scatter_add(w, target), norm = d^-1/2[src] * w * d^-1/2[dst];
+ * result as CSR by target row, sources ascending inside a row.
+ *   d_edge_index int64[2,n_edges] (row 0 = source, row 1 = target), existing self loops keep w=1 once
+ *   d_rowptr int32[n_nodes+1]; d_col int32[n_edges+n_nodes]; d_val float32[n_edges+n_nodes]
+ *   d_nnz int32[1]: entries actually written (<= n_edges+n_nodes) */
+int tlc_gcn_norm_csr(int32_t n_nodes, int64_t n_edges, const int64_t* d_edge_index,
+                     int32_t* d_rowptr, int32_t* d_col, float* d_val, int32_t* d_nnz, void* stream);
+
+/* C[M,N] = A[M,K] @ B[K,N] (+bias[N]) (optional ReLU), fp32 in / fp32 accumulate on the f32 MFMA.
+ * The dense projection x @ W of GCNConv (PD_conv.py:179-181). Row-major, leading dims = N/K. */
+int tlc_gemm_f32(int32_t M, int32_t N, int32_t K, const float* d_A, const float* d_B, const float* d_bias,
+                 int relu, float* d_C, void* stream);
+
+/* Y[n,k] = act( CSR(rowptr,col,val) @ X[n,k] + bias[k] ): the propagate/scatter-add of GCNConv
+ * (PD_conv.py:183-188; message_passing.py:275-293 aggr='add'), act = ReLU if relu!=0. */
+int tlc_spmm_csr_f32(int32_t n_rows, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
+                     const float* d_X, int32_t k, const float* d_bias, int relu, float* d_Y, void* stream);
+
+/* emb.renorm_(2, 0, 1) (TLCGNN.py:48): rows with L2 norm > 1 are scaled by 1/(norm + 1e-7), in place. */
+int tlc_renorm_rows_f32(int32_t n_rows, int32_t k, float* d_emb, void* stream);
+
+/* Net.decode after the renorm (TLCGNN.py:52-61), one fused pass per pair:
+ *   h = LeakyReLU_0.2( W1 @ [ (emb[u]-emb[v])^2 || PI ] + b1 );  d = clamp(|W2 @ h + b2|, 0, 40);
+ *   prob = 1 / (exp(d - 2) + 1)
+ *   d_pairs int32[n_pairs,2]; d_emb float32[n_nodes,emb_dim]; d_pi float64[n_pairs,pi_dim] (cast to
+ *   float32 on load, as torch.Tensor(PI) does); d_W1 float32[pi_dim, emb_dim+pi_dim] (torch Linear
+ *   layout [out,in]); d_b1[pi_dim]; d_W2 float32[pi_dim]; d_b2 float32[1]; d_prob float32[n_pairs] */
+int tlc_lp_decode_fused(int64_t n_pairs, const int32_t* d_pairs, const float* d_emb, int32_t emb_dim,
+                        const double* d_pi, int32_t pi_dim, const float* d_W1, const float* d_b1,
+                        const float* d_W2, const float* d_b2, float* d_prob, void* stream);
+
+/* ---- M4-M6: PDGNN layer forward (Knowledge_Distillation/gat_conv.py:113-216) ----------------------
+ * One GATConv(heads=1, new_node_feat, use_edge_attn) layer on a block-diagonal batch of graphs whose
+ * edges are given as CSR BY TARGET (self loops already added, gat_conv.py:146-160):
+ *   x_l = X @ Wl^T (no bias);  alpha = x_l . att;  per edge j->i: a = softmax_i(leaky_relu(alpha_j+alpha_i)),
+ *   m = leaky_relu(Wij @ [x_i || x_j]) * a;  out_i = [ sum m || (min m + max m) ] + bias  (:166-172,202-216)
+ *   d_X float32[n, c_in]; d_Wl float32[c_out, c_in]; d_att float32[c_out]; d_Wij float32[c_out, 2*c_out];
+ *   d_bias float32[2*c_out]; d_out float32[n, 2*c_out]; prelu_slope < 0 disables the fused PReLU. */
+int tlc_gat_layer_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_src,
+                      const float* d_X, int32_t c_in, int32_t c_out,
+                      const float* d_Wl, const float* d_att, const float* d_Wij, const float* d_bias,
+                      float prelu_slope, float* d_out, void* stream);
+
+/* Edge head of Teacher_Model.forward (Teacher_model.py:54-59): for every non-self-loop edge e=(s,t):
+ *   pd[e] = W6 @ prelu(W5 @ [x[s] || x[t]] + b5) + b6   -> float32[n_edges,2] */
+int tlc_edge_head_fwd(int64_t n_edges, const int32_t* d_src, const int32_t* d_dst, const float* d_X,
+                      int32_t c, const float* d_W5, const float* d_b5, int32_t hidden, float prelu_slope,
+                      const float* d_W6, const float* d_b6, float* d_pd, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TLCGNN_H */

@@ -1,0 +1,134 @@
+"""CPU: the oracle (oracle/tlc_oracle.c) against the golden vectors captured from the imported reference.
+
+This is what pins the oracle (task §3): every fixture under tests/golden/ was produced by
+tests/golden/make_golden.py running the reference's own Python single-threaded.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from helpers import same_multiset, ragged_slice, rel_err, csr_from_golden
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_pi_kat_g1():
+    d = np.load(os.path.join(G, "pi_kat.npz"))
+    out = oracle.pi_raster([0, len(d["pd"])], d["pd"], 5)[0]
+    # the reference's printed vector has 4 decimals
+    assert np.abs(out - d["gt_4dp"]).max() < 6e-5
+    # and the fp64 row of the reference itself (scipy erfc vs libm erfc: a few ulp)
+    assert rel_err(out, d["ref_fp64"]).max() < 1e-13
+
+
+def test_pi_random_g2():
+    d = np.load(os.path.join(G, "pi_random.npz"))
+    out = oracle.pi_raster(d["offs"], d["pts"], 5)
+    ref = d["out"]
+    # tolerance stated by north_star: 1e-5 relative; the oracle is ~1e-13 (absolute floor for all-zero rows)
+    assert np.abs(out - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    nz = np.abs(ref) > 1e-9
+    assert rel_err(out[nz], ref[nz]).max() < 1e-10
+    for res in (3, 7):
+        o = oracle.pi_raster(d["offs"][:21], d["pts"][: d["offs"][20]], res)
+        r = d["out_res%d" % res]
+        assert np.abs(o - r).max() <= 1e-12 * max(1.0, np.abs(r).max())
+
+
+@pytest.mark.parametrize("fork", ["tlc", "kd"])
+def test_pd_from_filtration_g3(fork):
+    d = np.load(os.path.join(G, "pd_from_f.npz"))
+    node_offs = d["f_offs"]
+    edge_offs = d["e_offs"]
+    flags = oracle.KEEP_ZERO_PERS if fork == "kd" else 0
+    r = oracle.pd_from_filtration(node_offs, edge_offs, d["edges"], d["f"], flags)
+    B = len(d["n"])
+    for g in range(B):
+        no, eo = node_offs[g], edge_offs[g]
+        n, m = int(d["n"][g]), int(edge_offs[g + 1] - eo)
+        c = r["counts"][g]
+        up = r["up"][no:no + c[0]]
+        down = r["down"][no:no + c[1]]
+        one = r["one"][eo:eo + c[2]]
+        ext0 = r["ext0"][g]
+        if fork == "tlc":
+            pd0 = np.concatenate([up, ext0[None, :], down, ext0[None, ::-1]])
+            assert same_multiset(pd0, ragged_slice(d["tlc_pd0"], d["tlc_pd0_offs"], g)), g
+            assert same_multiset(one, ragged_slice(d["tlc_pd1"], d["tlc_pd1_offs"], g)), g
+            assert int(d["npos"][g]) == m - n + 1 and int(d["nneg"][g]) == n - 1
+            rank = r["edge_rank"][eo:eo + m]
+            assert (rank >= 0).sum() == d["npos"][g] and (rank < 0).sum() == d["nneg"][g]
+        else:
+            assert same_multiset(up, ragged_slice(d["kd_ord0"], d["kd_ord0_offs"], g)), g
+            assert same_multiset(ext0[None, :], ragged_slice(d["kd_ext0"], d["kd_ext0_offs"], g)), g
+            assert same_multiset(down, ragged_slice(d["kd_rel1"], d["kd_rel1_offs"], g)), g
+            assert same_multiset(one, ragged_slice(d["kd_ext1"], d["kd_ext1_offs"], g)), g
+            assert c[0] == n - 1 and c[1] == n - 1 and c[2] == m - n + 1
+        assert c[3] == 1
+
+
+def test_filtration_g4():
+    d = np.load(os.path.join(G, "filtration.npz"))
+    rowptr, col, w = csr_from_golden(d)
+    for hop in (1, 2, 3):
+        sel = np.nonzero(d["hop"] == hop)[0]
+        pairs = d["pairs"][sel]
+        offs, ids, f, n, m, st = oracle.vicinity_filtration(rowptr, col, w, pairs, hop)
+        for k, gi in enumerate(sel):
+            ref_ids = ragged_slice(d["ids"], d["offs"], gi)
+            ref_f = ragged_slice(d["f"], d["offs"], gi)
+            assert n[k] == len(ref_ids)
+            assert np.array_equal(ids[offs[k]:offs[k] + n[k]], ref_ids)
+            # bit-exact: node-sourced shortest paths in the reference's summation order
+            assert np.array_equal(f[offs[k]:offs[k] + n[k]], ref_f), (hop, k)
+
+
+@pytest.mark.parametrize("hop", [1, 2, 3])
+def test_end_to_end_g5(hop):
+    d = np.load(os.path.join(G, "e2e.npz"))
+    rowptr, col, w = csr_from_golden(d)
+    out, st, _ = oracle.pd_pi_batch(rowptr, col, w, d["pairs"], hop, n_threads=1)
+    ref = d["pi_hop%d" % hop]
+    assert np.array_equal(st.astype(np.int64), d["cls_hop%d" % hop])
+    assert np.array_equal(out == 0, ref == 0)          # zero rows (and zero pixels) are exactly zero
+    nz = ref != 0
+    assert rel_err(out[nz], ref[nz]).max() < 1e-10     # north_star bound is 1e-5
+    # the thread pool changes nothing (no shared mutable state, unlike the reference's ThreadPool)
+    out2, st2, used = oracle.pd_pi_batch(rowptr, col, w, d["pairs"], hop, n_threads=4)
+    assert np.array_equal(out, out2) and np.array_equal(st, st2)
+
+
+def test_pubmed_sample():
+    p = os.path.join(G, "pubmed_sample.npz")
+    d = np.load(p)
+    from tlc_gnn_amd import synth
+    n, e, k, hop, _ = synth.shaped_graph("PubMed")
+    rowptr, col, w = synth.edges_to_csr(n, e, k)
+    out, st, _ = oracle.pd_pi_batch(rowptr, col, w, d["pairs"], 2, n_threads=0)
+    ref = d["pi"]
+    assert (st == 0).all()
+    nz = ref != 0
+    assert np.array_equal(out == 0, ref == 0)
+    assert rel_err(out[nz], ref[nz]).max() < 1e-10
+
+
+def test_kd_gc_g6():
+    d = np.load(os.path.join(G, "kd_gc.npz"))
+    r = oracle.pd_from_filtration(d["f_offs"], d["e_offs"], d["edges"], d["f"], oracle.KEEP_ZERO_PERS)
+    for g in range(len(d["n"])):
+        no, eo = d["f_offs"][g], d["e_offs"][g]
+        c = r["counts"][g]
+        up = r["up"][no:no + c[0]]
+        one = r["one"][eo:eo + c[2]]
+        assert same_multiset(up, ragged_slice(d["ord0"], d["ord0_offs"], g))
+        assert same_multiset(one, ragged_slice(d["ext1"], d["ext1_offs"], g))
+        # PI over Ord0 ++ Ext1 (data_utils_GC.py:155-163), PI0 / PI1 separately
+        pts = np.concatenate([up, one])
+        pi = oracle.pi_raster([0, len(pts)], pts, 5)[0]
+        assert np.abs(pi - d["pi"][g]).max() < 1e-12
+        if len(up):
+            assert np.abs(oracle.pi_raster([0, len(up)], up, 5)[0] - d["pi0"][g]).max() < 1e-12
+        if len(one):
+            assert np.abs(oracle.pi_raster([0, len(one)], one, 5)[0] - d["pi1"][g]).max() < 1e-12
