@@ -1,0 +1,221 @@
+"""GPU: the HIP PD/PI path (through the C ABI) against the CPU oracle and the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import same_multiset, ragged_slice, rel_err, csr_from_golden
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+def _dev(torch, a, dtype):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def test_pi_raster_goldens(torch_cuda):
+    torch = torch_cuda
+    from tlc_gnn_amd import engine
+    d = np.load(os.path.join(G, "pi_kat.npz"))
+    out = engine.pi_raster(_dev(torch, [0, len(d["pd"])], torch.int64), _dev(torch, d["pd"], torch.float64), 5).cpu().numpy()[0]
+    assert np.abs(out - d["gt_4dp"]).max() < 6e-5          # the reference's own printed known-answer vector
+    assert rel_err(out, d["ref_fp64"]).max() < 1e-9         # north_star tolerance: 1e-5 relative
+    d = np.load(os.path.join(G, "pi_random.npz"))
+    out = engine.pi_raster(_dev(torch, d["offs"], torch.int64), _dev(torch, d["pts"], torch.float64), 5).cpu().numpy()
+    ref = d["out"]
+    assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    nz = np.abs(ref) > 1e-9
+    assert rel_err(out[nz], ref[nz]).max() < 1e-8
+    for res in (3, 7):
+        o = engine.pi_raster(_dev(torch, d["offs"][:21], torch.int64), _dev(torch, d["pts"][: d["offs"][20]], torch.float64), res).cpu().numpy()
+        r = d["out_res%d" % res]
+        assert np.abs(o - r).max() <= 1e-11 * max(1.0, np.abs(r).max())
+
+
+@pytest.mark.parametrize("fork", ["tlc", "kd"])
+def test_pd_from_filtration_golden(torch_cuda, fork):
+    torch = torch_cuda
+    from tlc_gnn_amd import engine
+    d = np.load(os.path.join(G, "pd_from_f.npz"))
+    flags = engine.KEEP_ZERO_PERS if fork == "kd" else 0
+    r = engine.pd_from_filtration(_dev(torch, d["f_offs"], torch.int64), _dev(torch, d["e_offs"], torch.int64),
+                                  _dev(torch, d["edges"], torch.int32), _dev(torch, d["f"], torch.float64), flags)
+    r = {k: v.cpu().numpy() for k, v in r.items()}
+    node_offs, edge_offs = d["f_offs"], d["e_offs"]
+    for g in range(len(d["n"])):
+        no, eo = node_offs[g], edge_offs[g]
+        n, m = int(d["n"][g]), int(edge_offs[g + 1] - eo)
+        c = r["counts"][g]
+        up, down, one = r["up"][no:no + c[0]], r["down"][no:no + c[1]], r["one"][eo:eo + c[2]]
+        ext0 = r["ext0"][g]
+        if fork == "tlc":
+            pd0 = np.concatenate([up, ext0[None, :], down, ext0[None, ::-1]])
+            assert same_multiset(pd0, ragged_slice(d["tlc_pd0"], d["tlc_pd0_offs"], g)), g     # bit-exact
+            assert same_multiset(one, ragged_slice(d["tlc_pd1"], d["tlc_pd1_offs"], g)), g
+            rank = r["edge_rank"][eo:eo + m]
+            assert (rank >= 0).sum() == d["npos"][g] and (rank < 0).sum() == d["nneg"][g]
+            assert sorted(rank[rank >= 0].tolist()) == list(range(int(d["npos"][g])))
+        else:
+            assert same_multiset(up, ragged_slice(d["kd_ord0"], d["kd_ord0_offs"], g)), g
+            assert same_multiset(ext0[None, :], ragged_slice(d["kd_ext0"], d["kd_ext0_offs"], g)), g
+            assert same_multiset(down, ragged_slice(d["kd_rel1"], d["kd_rel1_offs"], g)), g
+            assert same_multiset(one, ragged_slice(d["kd_ext1"], d["kd_ext1_offs"], g)), g
+        assert c[3] == 1
+
+
+def test_filtration_golden_bit_exact(torch_cuda):
+    torch = torch_cuda
+    from tlc_gnn_amd import engine
+    d = np.load(os.path.join(G, "filtration.npz"))
+    rowptr, col, w = csr_from_golden(d)
+    g = engine.DeviceGraph(rowptr, col, w)
+    for hop in (1, 2, 3):
+        sel = np.nonzero(d["hop"] == hop)[0]
+        pairs = _dev(torch, d["pairs"][sel], torch.int32)
+        offs, ids, f, n, st = [t.cpu().numpy() for t in g.vicinity_filtration(pairs, hop)]
+        for k, gi in enumerate(sel):
+            ref_ids = ragged_slice(d["ids"], d["offs"], gi)
+            ref_f = ragged_slice(d["f"], d["offs"], gi)
+            assert n[k] == len(ref_ids), (hop, k)
+            assert np.array_equal(ids[offs[k]:offs[k] + n[k]], ref_ids)
+            assert np.array_equal(f[offs[k]:offs[k] + n[k]], ref_f), (hop, k)   # bit-exact f
+    g.close()
+
+
+@pytest.mark.parametrize("hop", [1, 2, 3])
+def test_end_to_end_golden(torch_cuda, hop):
+    torch = torch_cuda
+    from tlc_gnn_amd import engine
+    d = np.load(os.path.join(G, "e2e.npz"))
+    rowptr, col, w = csr_from_golden(d)
+    g = engine.DeviceGraph(rowptr, col, w)
+    out, st = g.pd_pi_batch(_dev(torch, d["pairs"], torch.int32), hop)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    ref = d["pi_hop%d" % hop]
+    assert np.array_equal(st.astype(np.int64), d["cls_hop%d" % hop])        # the reference's exception classes
+    assert np.array_equal(out == 0, ref == 0)
+    nz = ref != 0
+    assert rel_err(out[nz], ref[nz]).max() < 1e-8                           # north_star: 1e-5 relative
+    g.close()
+
+
+def test_pubmed_sample_vs_reference(torch_cuda):
+    torch = torch_cuda
+    from tlc_gnn_amd import engine, synth
+    d = np.load(os.path.join(G, "pubmed_sample.npz"))
+    n, e, k, hop, _ = synth.shaped_graph("PubMed")
+    rowptr, col, w = synth.edges_to_csr(n, e, k)
+    g = engine.DeviceGraph(rowptr, col, w)
+    out, st = g.pd_pi_batch(_dev(torch, d["pairs"], torch.int32), 2)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    ref = d["pi"]
+    assert (st == 0).all()
+    nz = ref != 0
+    assert np.array_equal(out == 0, ref == 0)
+    assert rel_err(out[nz], ref[nz]).max() < 1e-8
+    g.close()
+
+
+def test_full_pubmed_batch_vs_oracle(torch_cuda):
+    """BASELINE configs[1] at full size: all train-positive pairs of the PubMed-shaped graph, hop 2."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    n, e, k, hop, _ = synth.shaped_graph("PubMed")
+    rowptr, col, w = synth.edges_to_csr(n, e, k)
+    g = engine.DeviceGraph(rowptr, col, w)
+    rs = np.random.RandomState(7)
+    pairs = e[rs.permutation(len(e))[:37676]].astype(np.int32)
+    out, st = g.pd_pi_batch(_dev(torch, pairs, torch.int32), 2)
+    out2, st2 = g.pd_pi_batch(_dev(torch, pairs, torch.int32), 2)
+    assert torch.equal(out, out2) and torch.equal(st, st2)                  # deterministic, bit for bit
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, 2, n_threads=0)
+    assert np.array_equal(st, rst)
+    assert np.array_equal(out == 0, ref == 0)
+    nz = ref != 0
+    assert rel_err(out[nz], ref[nz]).max() < 1e-8
+    stats = g.stats()
+    assert stats["tier_small"] + stats["tier_medium"] + stats["tier_large"] + stats["tier_huge"] == len(pairs)
+    g.close()
+
+
+def test_ties_take_the_exact_fallback(torch_cuda):
+    """All-equal weights: every shortest path is tied, the chain walk must hand over to the node-sourced
+    Bellman-Ford and still match the oracle bit for bit (filtration) / 1e-8 (image)."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    n = 600
+    e = synth.holme_kim_edges(n, 2400, triad_p=0.5, seed=11)
+    kappa = np.round(np.random.RandomState(3).uniform(-0.5, 0.9, size=len(e)), 1)   # one decimal: many exact ties
+    rowptr, col, w = synth.edges_to_csr(n, e, kappa)
+    g = engine.DeviceGraph(rowptr, col, w)
+    pairs = e[:500].astype(np.int32)
+    for hop in (1, 2):
+        offs, ids, f, nn, st = [t.cpu().numpy() for t in g.vicinity_filtration(_dev(torch, pairs, torch.int32), hop)]
+        o_offs, o_ids, o_f, o_n, o_m, o_st = oracle.vicinity_filtration(rowptr, col, w, pairs, hop)
+        assert np.array_equal(nn, o_n) and np.array_equal(st, o_st)
+        for k in range(len(pairs)):
+            assert np.array_equal(f[offs[k]:offs[k] + nn[k]], o_f[o_offs[k]:o_offs[k] + o_n[k]]), (hop, k)
+        out, st = g.pd_pi_batch(_dev(torch, pairs, torch.int32), hop)
+        ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, hop, n_threads=0)
+        out = out.cpu().numpy()
+        assert np.array_equal(st.cpu().numpy(), rst)
+        nz = ref != 0
+        assert np.array_equal(out == 0, ref == 0)
+        assert rel_err(out[nz], ref[nz]).max() < 1e-8
+    assert g.stats()["tie_fallback_sources"] > 0
+    g.close()
+
+
+def test_variant_flags_vs_oracle(torch_cuda):
+    torch = torch_cuda
+    from tlc_gnn_amd import engine
+    from oracle import oracle
+    d = np.load(os.path.join(G, "e2e.npz"))
+    rowptr, col, w = csr_from_golden(d)
+    g = engine.DeviceGraph(rowptr, col, w)
+    pairs = d["pairs"].astype(np.int32)
+    for flags in (engine.INCLUDE_ROOTS | engine.NORM_EPS, engine.KEEP_ZERO_PERS | engine.PI_ORD0_EXT1, engine.NO_EXT1):
+        for hop in (1, 2):
+            out, st = g.pd_pi_batch(_dev(torch, pairs, torch.int32), hop, flags=flags)
+            ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, hop, flags=flags, n_threads=0)
+            out = out.cpu().numpy()
+            assert np.array_equal(st.cpu().numpy(), rst), (flags, hop)
+            nz = ref != 0
+            assert np.array_equal(out == 0, ref == 0), (flags, hop)
+            assert rel_err(out[nz], ref[nz]).max() < 1e-8
+    # other resolutions
+    for res in (3, 8):
+        out, st = g.pd_pi_batch(_dev(torch, pairs, torch.int32), 2, res=res)
+        ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, 2, res=res, n_threads=0)
+        out = out.cpu().numpy()
+        nz = ref != 0
+        assert np.array_equal(out == 0, ref == 0)
+        assert rel_err(out[nz], ref[nz]).max() < 1e-8
+    g.close()
+
+
+def test_empty_and_degenerate_batches(torch_cuda):
+    torch = torch_cuda
+    from tlc_gnn_amd import engine
+    rowptr = np.array([0, 1, 2, 2], dtype=np.int32)      # 0-1 edge, node 2 isolated
+    col = np.array([1, 0], dtype=np.int32)
+    w = np.array([1.5, 1.5])
+    g = engine.DeviceGraph(rowptr, col, w)
+    out, st = g.pd_pi_batch(torch.zeros((0, 2), dtype=torch.int32, device="cuda"), 1)
+    assert out.shape == (0, 25)
+    pairs = torch.tensor([[0, 1], [0, 2], [2, 2], [0, 0], [5, 0], [-1, 1]], dtype=torch.int32, device="cuda")
+    out, st = g.pd_pi_batch(pairs, 1)
+    assert (out == 0).all()
+    assert st.cpu().tolist() == [3, 1, 1, 3, 1, 1]      # ZeroDivision / KeyError classes of the reference
+    g.close()

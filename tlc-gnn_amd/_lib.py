@@ -1,0 +1,111 @@
+"""ctypes binding of libtlcgnn_hip.so (the C ABI of include/tlcgnn.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every compute call goes through the C ABI
+with raw device pointers.  There is NO CPU fallback: if the HIP library is missing or no GPU is visible,
+the product path raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtlcgnn_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+OK = 0
+ERRORS = {1: "TLC_ERR_INVALID_ARG", 2: "TLC_ERR_HIP", 3: "TLC_ERR_NO_DEVICE", 4: "TLC_ERR_UNSUPPORTED",
+          5: "TLC_ERR_OUT_OF_MEMORY"}
+
+ST_OK, ST_MISSING_NODE, ST_DISCONNECTED, ST_ZERO_RANGE, ST_NO_TREE_EDGE, ST_TOO_LARGE = range(6)
+KEEP_ZERO_PERS, INCLUDE_ROOTS, NORM_EPS, PI_ORD0_EXT1, NO_EXT1 = 0x1, 0x2, 0x4, 0x8, 0x10
+
+# every symbol include/tlcgnn.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "tlc_version", "tlc_last_error", "tlc_device_count", "tlc_graph_create", "tlc_graph_destroy",
+    "tlc_pd_pi_batch", "tlc_vicinity_filtration", "tlc_pd_pi_batch_stats", "tlc_pd_from_filtration",
+    "tlc_pi_raster", "tlc_gcn_norm_csr", "tlc_gemm_f32", "tlc_spmm_csr_f32", "tlc_renorm_rows_f32",
+    "tlc_lp_decode_fused", "tlc_gat_layer_fwd", "tlc_edge_head_fwd",
+]
+
+
+class TlcError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 into tlc-gnn_amd/libtlcgnn_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise TlcError("building libtlcgnn_hip.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TlcError("libtlcgnn_hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the product path)")
+        L = C.CDLL(LIB_PATH)
+        L.tlc_version.restype = C.c_char_p
+        L.tlc_last_error.restype = C.c_char_p
+        L.tlc_graph_create.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.tlc_graph_destroy.argtypes = [C.c_void_p]
+        L.tlc_pd_pi_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+        L.tlc_vicinity_filtration.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tlc_pd_pi_batch_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tlc_pd_from_filtration.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 7
+        L.tlc_pi_raster.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        if hasattr(L, "tlc_gcn_norm_csr"):
+            L.tlc_gcn_norm_csr.argtypes = [C.c_int32, C.c_int64] + [C.c_void_p] * 6
+            L.tlc_gemm_f32.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p]
+            L.tlc_spmm_csr_f32.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_int, C.c_void_p,
+                                                                            C.c_void_p]
+            L.tlc_renorm_rows_f32.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+            L.tlc_lp_decode_fused.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        if hasattr(L, "tlc_gat_layer_fwd"):
+            L.tlc_gat_layer_fwd.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                            C.c_void_p]
+            L.tlc_edge_head_fwd.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                            C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != OK:
+        msg = lib().tlc_last_error().decode("utf-8", "replace")
+        raise TlcError("%s: %s (%s)" % (what or "libtlcgnn_hip", ERRORS.get(rc, rc), msg))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise TlcError("no MI355X/HIP device visible: the TLC-GNN hot path has no CPU fallback")
+    return torch
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous()
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,407 @@
+// api.hip -- host side of the C ABI (include/tlcgnn.h): handle, workspaces, launch orchestration.
+//
+// tlc_pd_pi_batch on a chunk of pairs:
+//   COUNT (vicinity sizes) -> exclusive scan + tier binning -> [one 48-byte read-back: arena size and tier
+//   counts] -> FILL (induced subgraphs into the arena) -> one PD kernel per size tier, the tiers running
+//   concurrently on side streams so that the few large subgraphs overlap the many small ones.
+#include <stdarg.h>
+
+#include <algorithm>
+#include <new>
+
+#include "tlc_common.h"
+#include "tlc_kernels.h"
+
+// ---- error text ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void tlc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* tlc_last_error(void) { return g_err; }
+extern "C" const char* tlc_version(void) { return "tlcgnn-hip 0.1.0 (gfx950)"; }
+extern "C" int tlc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+#define TLC_CHUNK_PAIRS (1 << 20)
+#define TLC_N_SIDE 3
+
+struct HostSync {
+    long long total_entries;
+    int tier_count[TLC_N_TIERS];
+    int pad[2];
+    unsigned long long stats[2];
+};
+
+struct tlc_graph {
+    int device;
+    int n_nodes;
+    long long nnz;
+    int nw;
+    int *d_rowptr, *d_col;
+    double* d_w;
+    // per-chunk workspace
+    size_t cap_pairs;
+    int *hdr_n, *hdr_m2, *hdr_lu, *hdr_lv, *tier_list;
+    long long* edge_off;
+    // small device block: [0..3] tier counts, [4] work counter, [8..] see below
+    int* d_ctl;
+    long long* d_block_sums;   // 1024
+    long long* d_totals;       // 1
+    unsigned long long* d_stats;  // 2
+    HostSync* h_sync;          // pinned
+    // arena
+    size_t cap_entries;
+    unsigned* A_dir;
+    double* A_lw;
+    // vicinity scratch
+    int vic_slots;
+    int vic_hop_cap;           // frontiers allocated for hop >= 3 ?
+    int* vic_scratch;
+    long long vic_stride;
+    size_t vic_lds;
+    // HUGE tier scratch
+    int huge_slots;
+    unsigned char* huge_scratch;
+    size_t huge_stride;
+    hipStream_t side[TLC_N_SIDE];
+    hipEvent_t ev_fork, ev_join[TLC_N_SIDE];
+    long long last_stats[8];
+};
+
+static int ensure_pairs(tlc_graph* g, size_t n) {
+    if (n <= g->cap_pairs) return TLC_OK;
+    hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
+    g->hdr_n = g->hdr_m2 = g->hdr_lu = g->hdr_lv = g->tier_list = nullptr;
+    g->edge_off = nullptr;
+    g->cap_pairs = 0;
+    TLC_HIP_CHECK(hipMalloc(&g->hdr_n, n * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&g->hdr_m2, n * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&g->hdr_lu, n * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&g->hdr_lv, n * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&g->tier_list, n * TLC_N_TIERS * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&g->edge_off, (n + 1) * sizeof(long long)));
+    g->cap_pairs = n;
+    return TLC_OK;
+}
+
+static int ensure_arena(tlc_graph* g, size_t entries) {
+    if (entries <= g->cap_entries) return TLC_OK;
+    size_t want = std::max(entries + entries / 4, (size_t)1 << 16);
+    hipFree(g->A_dir); hipFree(g->A_lw);
+    g->A_dir = nullptr; g->A_lw = nullptr; g->cap_entries = 0;
+    TLC_HIP_CHECK(hipMalloc(&g->A_dir, want * sizeof(unsigned)));
+    TLC_HIP_CHECK(hipMalloc(&g->A_lw, want * sizeof(double)));
+    g->cap_entries = want;
+    return TLC_OK;
+}
+
+static int ensure_vic_scratch(tlc_graph* g, int hop) {
+    const int need_front = hop >= 3 ? 1 : 0;
+    if (g->vic_scratch && g->vic_hop_cap >= need_front) return TLC_OK;
+    hipFree(g->vic_scratch);
+    g->vic_scratch = nullptr;
+    // slot = [frontA | frontB | ids | lrow]; the frontiers are only touched for hop >= 3
+    g->vic_stride = 4ll * g->n_nodes + 16;
+    TLC_HIP_CHECK(hipMalloc(&g->vic_scratch, (size_t)g->vic_slots * g->vic_stride * sizeof(int)));
+    g->vic_hop_cap = 1;
+    return TLC_OK;
+}
+
+static int ensure_huge(tlc_graph* g) {
+    if (g->huge_scratch) return TLC_OK;
+    const int nmax = std::min(g->n_nodes, 65535);
+    const long long mmax = g->nnz / 2 + 1;
+    g->huge_stride = tlc_huge_slot_bytes(nmax, (int)mmax);
+    g->huge_slots = 64;
+    TLC_HIP_CHECK(hipMalloc(&g->huge_scratch, g->huge_stride * (size_t)g->huge_slots));
+    return TLC_OK;
+}
+
+extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const int32_t* h_col, const double* h_w,
+                                int device, tlc_graph** out) {
+    TLC_REQUIRE(out != nullptr, "out is null");
+    *out = nullptr;
+    TLC_REQUIRE(n_nodes > 0 && h_rowptr && h_col && h_w, "null graph arrays or n_nodes <= 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        tlc_set_error("no HIP device visible");
+        return TLC_ERR_NO_DEVICE;
+    }
+    TLC_REQUIRE(device >= 0 && device < ndev, "device index out of range");
+    const long long nnz = h_rowptr[n_nodes];
+    TLC_REQUIRE(h_rowptr[0] == 0 && nnz >= 0, "rowptr must start at 0");
+    for (int i = 0; i < n_nodes; ++i) TLC_REQUIRE(h_rowptr[i + 1] >= h_rowptr[i], "rowptr not monotone");
+    for (long long j = 0; j < nnz; ++j) {
+        TLC_REQUIRE(h_col[j] >= 0 && h_col[j] < n_nodes, "column index out of range");
+        TLC_REQUIRE(h_w[j] > 0.0, "edge weights (kappa+1) must be > 0");
+    }
+    const int nw = (n_nodes + 31) / 32;
+    const size_t lds = ((size_t)3 * nw + 4) * 4;
+    if (lds > 160 * 1024) {
+        tlc_set_error("graph has %d nodes: the vicinity bitmaps (%zu B) exceed the 160 KiB LDS of a CU", n_nodes, lds);
+        return TLC_ERR_UNSUPPORTED;
+    }
+    TLC_HIP_CHECK(hipSetDevice(device));
+    tlc_graph* g = new (std::nothrow) tlc_graph();
+    if (!g) return TLC_ERR_OUT_OF_MEMORY;
+    memset(g, 0, sizeof(*g));
+    g->device = device; g->n_nodes = n_nodes; g->nnz = nnz; g->nw = nw; g->vic_lds = lds;
+    int rc = TLC_OK;
+    auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
+#define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
+    CK(hipMalloc(&g->d_rowptr, (size_t)(n_nodes + 1) * sizeof(int)));
+    CK(hipMalloc(&g->d_col, (size_t)std::max(nnz, 1ll) * sizeof(int)));
+    CK(hipMalloc(&g->d_w, (size_t)std::max(nnz, 1ll) * sizeof(double)));
+    CK(hipMemcpy(g->d_rowptr, h_rowptr, (size_t)(n_nodes + 1) * sizeof(int), hipMemcpyHostToDevice));
+    CK(hipMemcpy(g->d_col, h_col, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    CK(hipMemcpy(g->d_w, h_w, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+    CK(hipMalloc(&g->d_ctl, 64 * sizeof(int)));
+    CK(hipMalloc(&g->d_block_sums, 1024 * sizeof(long long)));
+    CK(hipMalloc(&g->d_totals, 2 * sizeof(long long)));
+    CK(hipMalloc(&g->d_stats, 2 * sizeof(unsigned long long)));
+    CK(hipHostMalloc((void**)&g->h_sync, sizeof(HostSync), hipHostMallocDefault));
+    for (int k = 0; k < TLC_N_SIDE; ++k) {
+        CK(hipStreamCreateWithFlags(&g->side[k], hipStreamNonBlocking));
+        CK(hipEventCreateWithFlags(&g->ev_join[k], hipEventDisableTiming));
+    }
+    CK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+#undef CK
+    // concurrent vicinity workgroups worth launching: LDS-bound per CU, 256 CUs
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    int per_cu = (int)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds, 1));
+    if (per_cu < 1) per_cu = 1;
+    g->vic_slots = cus * per_cu;
+    (void)rc;
+    *out = g;
+    return TLC_OK;
+}
+
+extern "C" int tlc_graph_destroy(tlc_graph* g) {
+    if (!g) return TLC_OK;
+    hipSetDevice(g->device);
+    hipDeviceSynchronize();
+    hipFree(g->d_rowptr); hipFree(g->d_col); hipFree(g->d_w);
+    hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
+    hipFree(g->d_ctl); hipFree(g->d_block_sums); hipFree(g->d_totals); hipFree(g->d_stats);
+    if (g->h_sync) hipHostFree(g->h_sync);
+    hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch);
+    for (int k = 0; k < TLC_N_SIDE; ++k) {
+        if (g->side[k]) hipStreamDestroy(g->side[k]);
+        if (g->ev_join[k]) hipEventDestroy(g->ev_join[k]);
+    }
+    if (g->ev_fork) hipEventDestroy(g->ev_fork);
+    delete g;
+    return TLC_OK;
+}
+
+// one chunk (<= TLC_CHUNK_PAIRS pairs)
+static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop, uint32_t flags, int res,
+                     double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
+                     double* d_out_f, int32_t* d_out_n, int pi_enabled, hipStream_t s) {
+    int rc;
+    if ((rc = ensure_pairs(g, (size_t)n_pairs)) != TLC_OK) return rc;
+    if ((rc = ensure_vic_scratch(g, hop)) != TLC_OK) return rc;
+    TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl, 0, 64 * sizeof(int), s));
+    TLC_HIP_CHECK(hipMemsetAsync(g->d_stats, 0, 2 * sizeof(unsigned long long), s));
+
+    TlcVicParams vp;
+    memset(&vp, 0, sizeof(vp));
+    vp.n_nodes = g->n_nodes; vp.nw = g->nw; vp.rowptr = g->d_rowptr; vp.col = g->d_col; vp.w = g->d_w;
+    vp.pairs = d_pairs; vp.n_pairs = n_pairs; vp.hop = hop; vp.flags = flags; vp.res = res;
+    vp.work_counter = g->d_ctl + 4;
+    vp.scratch = g->vic_scratch; vp.scratch_stride = g->vic_stride;
+    vp.hdr_n = g->hdr_n; vp.hdr_m2 = g->hdr_m2; vp.hdr_lu = g->hdr_lu; vp.hdr_lv = g->hdr_lv;
+    vp.out_pi = d_out_pi; vp.out_status = d_out_status; vp.out_n = d_out_n;
+    vp.edge_off = g->edge_off; vp.A_dir = nullptr; vp.A_lw = nullptr;
+    vp.ids_off = (const long long*)d_ids_off; vp.out_ids = d_out_ids;
+
+    static bool lds_attr = false;
+    if (!lds_attr && g->vic_lds > 64 * 1024) {
+        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
+        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
+        lds_attr = true;
+    }
+    const int vgrid = std::min(n_pairs, g->vic_slots);
+    hipLaunchKernelGGL(tlc_vicinity_kernel<false>, dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
+    TLC_HIP_CHECK(hipGetLastError());
+
+    // exclusive scan of the induced entry counts + tier binning
+    const int nb = (n_pairs + 1023) / 1024;
+    hipLaunchKernelGGL(tlc_scan_block_sums, dim3(nb), dim3(1024), 0, s, (const int*)g->hdr_m2, n_pairs, g->d_block_sums);
+    hipLaunchKernelGGL(tlc_scan_top, dim3(1), dim3(1024), 0, s, g->d_block_sums, nb, g->d_totals);
+    TlcScanParams sp;
+    sp.n_pairs = n_pairs; sp.hdr_n = g->hdr_n; sp.hdr_m2 = g->hdr_m2; sp.block_sums = g->d_block_sums;
+    sp.edge_off = g->edge_off; sp.tier_count = g->d_ctl; sp.tier_list = g->tier_list;
+    hipLaunchKernelGGL(tlc_scan_down, dim3(nb), dim3(1024), 0, s, sp);
+    TLC_HIP_CHECK(hipGetLastError());
+    TLC_HIP_CHECK(hipMemcpyAsync(&g->h_sync->total_entries, g->d_totals, sizeof(long long), hipMemcpyDeviceToHost, s));
+    TLC_HIP_CHECK(hipMemcpyAsync(g->h_sync->tier_count, g->d_ctl, TLC_N_TIERS * sizeof(int), hipMemcpyDeviceToHost, s));
+    TLC_HIP_CHECK(hipStreamSynchronize(s));
+    const long long total = g->h_sync->total_entries;
+    int tc[TLC_N_TIERS];
+    for (int t = 0; t < TLC_N_TIERS; ++t) tc[t] = g->h_sync->tier_count[t];
+    if ((rc = ensure_arena(g, (size_t)total)) != TLC_OK) return rc;
+    if (tc[TLC_TIER_HUGE] > 0 && (rc = ensure_huge(g)) != TLC_OK) return rc;
+
+    const int todo = tc[0] + tc[1] + tc[2] + tc[3];
+    if (todo > 0) {
+        TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl + 4, 0, sizeof(int), s));
+        vp.A_dir = g->A_dir; vp.A_lw = g->A_lw;
+        hipLaunchKernelGGL(tlc_vicinity_kernel<true>, dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
+        TLC_HIP_CHECK(hipGetLastError());
+
+        TlcPdParams pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.hdr_n = g->hdr_n; pp.hdr_m2 = g->hdr_m2; pp.hdr_lu = g->hdr_lu; pp.hdr_lv = g->hdr_lv;
+        pp.edge_off = g->edge_off; pp.A_dir = g->A_dir; pp.A_lw = g->A_lw;
+        pp.flags = flags; pp.res = res; pp.out_pi = d_out_pi; pp.out_status = d_out_status;
+        pp.ids_off = (const long long*)d_ids_off; pp.out_f = d_out_f; pp.out_n = d_out_n; pp.pi_enabled = pi_enabled;
+        pp.huge_scratch = g->huge_scratch; pp.huge_stride = (long long)g->huge_stride;
+        pp.huge_nmax = std::min(g->n_nodes, 65535); pp.huge_mmax = (int)(g->nnz / 2 + 1); pp.huge_slots = g->huge_slots;
+        pp.stats = g->d_stats;
+        // fork: heavy tiers first, each on its own stream; the small tier stays on the caller's stream
+        TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s));
+        const int order[3] = {TLC_TIER_HUGE, TLC_TIER_LARGE, TLC_TIER_MEDIUM};
+        bool used[TLC_N_SIDE] = {false, false, false};
+        for (int k = 0; k < 3; ++k) {
+            const int t = order[k];
+            if (tc[t] <= 0) continue;
+            TLC_HIP_CHECK(hipStreamWaitEvent(g->side[k], g->ev_fork, 0));
+            pp.tier_list = g->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
+            if ((rc = tlc_launch_pd_tier(t, pp, g->side[k])) != TLC_OK) return rc;
+            TLC_HIP_CHECK(hipEventRecord(g->ev_join[k], g->side[k]));
+            used[k] = true;
+        }
+        pp.tier_list = g->tier_list + (size_t)TLC_TIER_SMALL * n_pairs; pp.tier_count = tc[TLC_TIER_SMALL];
+        if ((rc = tlc_launch_pd_tier(TLC_TIER_SMALL, pp, s)) != TLC_OK) return rc;
+        for (int k = 0; k < 3; ++k)
+            if (used[k]) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_join[k], 0));
+    }
+    for (int t = 0; t < TLC_N_TIERS; ++t) g->last_stats[t] += tc[t];
+    g->last_stats[4] += total;
+    g->last_stats[6] += 1;
+    return TLC_OK;
+}
+
+static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags, int res,
+                     double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
+                     double* d_out_f, int32_t* d_out_n, int pi_enabled, void* stream) {
+    TLC_REQUIRE(g != nullptr, "graph handle is null");
+    TLC_REQUIRE(n_pairs >= 0, "n_pairs < 0");
+    TLC_REQUIRE(hop >= 1 && hop <= 64, "hop must be in 1..64");
+    TLC_REQUIRE(res >= 1 && res <= 8, "res must be in 1..8");
+    TLC_REQUIRE(n_pairs == 0 || d_pairs != nullptr, "pairs is null");
+    TLC_HIP_CHECK(hipSetDevice(g->device));
+    memset(g->last_stats, 0, sizeof(g->last_stats));
+    hipStream_t s = (hipStream_t)stream;
+    for (int64_t off = 0; off < n_pairs; off += TLC_CHUNK_PAIRS) {
+        const int cnt = (int)std::min<int64_t>(TLC_CHUNK_PAIRS, n_pairs - off);
+        // NOTE: ids_off is indexed by the global pair index, the kernels index by chunk-local index
+        int rc = run_chunk(g, d_pairs + 2 * off, cnt, hop, flags, res,
+                           d_out_pi ? d_out_pi + (size_t)off * res * res : nullptr,
+                           d_out_status ? d_out_status + off : nullptr,
+                           d_ids_off ? d_ids_off + off : nullptr, d_out_ids, d_out_f,
+                           d_out_n ? d_out_n + off : nullptr, pi_enabled, s);
+        if (rc != TLC_OK) return rc;
+        if (off + TLC_CHUNK_PAIRS < n_pairs) {
+            // the arena and the headers are reused by the next chunk
+            TLC_HIP_CHECK(hipStreamSynchronize(s));
+            TLC_HIP_CHECK(hipMemcpy(g->h_sync->stats, g->d_stats, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            g->last_stats[5] += (long long)g->h_sync->stats[0];
+        }
+    }
+    return TLC_OK;
+}
+
+extern "C" int tlc_pd_pi_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags, int res,
+                               double* d_out_pi, uint8_t* d_out_status, void* stream) {
+    TLC_REQUIRE(n_pairs == 0 || d_out_pi != nullptr, "out_pi is null");
+    return run_batch(g, d_pairs, n_pairs, hop, flags, res, d_out_pi, d_out_status, nullptr, nullptr, nullptr, nullptr, 1,
+                     stream);
+}
+
+extern "C" int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags,
+                                       const int64_t* d_node_offs, int32_t* d_out_ids, double* d_out_f, int32_t* d_out_n,
+                                       uint8_t* d_out_status, void* stream) {
+    TLC_REQUIRE(d_node_offs && d_out_ids && d_out_f && d_out_n, "null output");
+    return run_batch(g, d_pairs, n_pairs, hop, flags, 5, nullptr, d_out_status, d_node_offs, d_out_ids, d_out_f, d_out_n, 0,
+                     stream);
+}
+
+extern "C" int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream) {
+    TLC_REQUIRE(g && h_out, "null argument");
+    TLC_HIP_CHECK(hipSetDevice(g->device));
+    TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    TLC_HIP_CHECK(hipMemcpy(g->h_sync->stats, g->d_stats, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) h_out[k] = g->last_stats[k];
+    h_out[5] += (long long)g->h_sync->stats[0];
+    return TLC_OK;
+}
+
+// ---- tlc_pd_from_filtration ----------------------------------------------------------------------------------------
+extern "C" int tlc_pd_from_filtration(int32_t n_graphs, const int64_t* d_node_offs, const int64_t* d_edge_offs,
+                                      const int32_t* d_edges, const double* d_f, uint32_t flags, double* d_pd_up,
+                                      double* d_pd_down, double* d_pd_one, double* d_ext0, int32_t* d_counts,
+                                      int32_t* d_edge_rank, void* stream) {
+    TLC_REQUIRE(n_graphs >= 0, "n_graphs < 0");
+    if (n_graphs == 0) return TLC_OK;
+    TLC_REQUIRE(d_node_offs && d_edge_offs && d_f && d_pd_up && d_pd_down && d_pd_one && d_ext0 && d_counts, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int* d_tier = nullptr;   // [4 counts | 4*n lists]
+    TLC_HIP_CHECK(hipMalloc(&d_tier, ((size_t)TLC_N_TIERS * n_graphs + 8) * sizeof(int)));
+    int rc = TLC_OK;
+    int tc[TLC_N_TIERS] = {0, 0, 0, 0};
+    long long tail[2] = {0, 0};
+    unsigned char* huge = nullptr;
+    do {
+        if (hipMemsetAsync(d_tier, 0, 8 * sizeof(int), s) != hipSuccess) { rc = TLC_ERR_HIP; break; }
+        if ((rc = tlc_launch_pdf_bin(n_graphs, (const long long*)d_node_offs, (const long long*)d_edge_offs, d_tier, d_tier + 8, s))) break;
+        if (hipMemcpyAsync(tc, d_tier, sizeof(tc), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = TLC_ERR_HIP; break; }
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = TLC_ERR_HIP; break; }
+        TlcPdfParams p;
+        memset(&p, 0, sizeof(p));
+        p.node_offs = (const long long*)d_node_offs; p.edge_offs = (const long long*)d_edge_offs;
+        p.edges = d_edges; p.f = d_f; p.flags = flags;
+        p.pd_up = d_pd_up; p.pd_down = d_pd_down; p.pd_one = d_pd_one; p.ext0 = d_ext0; p.counts = d_counts;
+        p.edge_rank = d_edge_rank;
+        if (tc[TLC_TIER_HUGE] > 0) {
+            // size the scratch by the largest graph: bounded by the totals
+            if (hipMemcpy(&tail[0], d_node_offs + n_graphs, sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(&tail[1], d_edge_offs + n_graphs, sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) { rc = TLC_ERR_HIP; break; }
+            if (tail[0] > 65535 * (long long)n_graphs) {}
+            p.huge_nmax = (int)std::min<long long>(tail[0], 65535);
+            p.huge_mmax = (int)std::min<long long>(tail[1] + 1, 0x7fffffff);
+            p.huge_stride = (long long)tlc_huge_slot_bytes(p.huge_nmax, p.huge_mmax);
+            p.huge_slots = std::min(tc[TLC_TIER_HUGE], 32);
+            if (hipMalloc(&huge, (size_t)p.huge_stride * p.huge_slots) != hipSuccess) { tlc_set_error("HUGE scratch alloc failed"); rc = TLC_ERR_OUT_OF_MEMORY; break; }
+            p.huge_scratch = huge;
+        }
+        for (int t = TLC_N_TIERS - 1; t >= 0 && rc == TLC_OK; --t) {
+            p.list = d_tier + 8 + (size_t)t * n_graphs; p.count = tc[t];
+            rc = tlc_launch_pdf_tier(t, p, s);
+        }
+    } while (0);
+    if (rc == TLC_ERR_HIP) tlc_set_error("tlc_pd_from_filtration: HIP runtime call failed: %s", hipGetErrorString(hipGetLastError()));
+    // the temporaries must outlive the kernels
+    hipStreamSynchronize(s);
+    hipFree(d_tier);
+    if (huge) hipFree(huge);
+    return rc;
+}
+
+extern "C" int tlc_pi_raster(int32_t n_dgms, const int64_t* d_offs, const double* d_pts, int res, double* d_out,
+                             void* stream) {
+    TLC_REQUIRE(n_dgms >= 0, "n_dgms < 0");
+    TLC_REQUIRE(res >= 1 && res <= 8, "res must be in 1..8");
+    if (n_dgms == 0) return TLC_OK;
+    TLC_REQUIRE(d_offs && d_out, "null pointer");
+    return tlc_launch_pi_raster(n_dgms, (const long long*)d_offs, d_pts, res, d_out, stream);
+}

@@ -1,0 +1,869 @@
+// pd_pipeline.hip -- P5..P9 of the hot path on one vicinity subgraph per workgroup.
+//
+//   P5  filtration.build_fv           sg2dgm/riccidist2dgm.py:20-61     (node-sourced shortest paths, normalise)
+//   P6  perturb_filter_function       sg2dgm/accelerated_PD.py:6-23     (fp64 keys, no FMA contraction)
+//   P7  Union_find                    sg2dgm/accelerated_PD.py:26-113   (two sorted passes, elder rule)
+//   P8  Accelerate_PD                 sg2dgm/accelerated_PD.py:115-178  (spanning-tree cycle swap)
+//   P9  PersistenceImager.transform   sg2dgm/PersistenceImager.pyx:352-388
+//
+// All per-subgraph state (distances, keys, union-find parents, tree parents, diagram points, image
+// table) is staged in LDS; the size tier picks the workgroup width and the LDS footprint (tlc_kernels.h).
+// The HUGE tier runs the same code on a per-workgroup HBM scratch slot.
+//
+// Exactness of the filtration: the reference's distance from x to a root r is the minimum
+// over paths of the LEFT-TO-RIGHT fp64 sum starting at x.  We run one root-sourced Bellman-Ford per root
+// (lanes over directed entries, ds_min_u64 on the bit patterns), mark the entries that are tight within
+// 1e-10 relative, and let one lane per node x walk its tight chain towards the root accumulating the
+// weights in the reference's order.  If every node on the chain has exactly one tight successor, every
+// other path is longer by far more than any rounding error, so the chain's sum IS the reference value.
+// Otherwise (exact or near ties) that source falls back to a Bellman-Ford sourced at x itself, which
+// converges to the same minimum by monotonicity of fp64 addition.  Compile with -ffp-contract=off.
+#include "tlc_common.h"
+#include "tlc_kernels.h"
+
+#define TLC_INF_BITS 0x7FF0000000000000ull
+#define TLC_NONE16 0xFFFFu
+
+namespace {
+
+typedef unsigned long long ull;
+
+__host__ __device__ constexpr size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ constexpr int pow2ceil(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+__host__ __device__ constexpr size_t smax(size_t a, size_t b) { return a > b ? a : b; }
+
+// Region layout of one subgraph's state; constexpr for the LDS tiers, evaluated at run time for HUGE.
+struct Layout {
+    size_t o_f, o_dir, o_lw, o_x, o_amb, o_par, o_mark, o_pn, o_pts, o_ctl, total;
+};
+__host__ __device__ constexpr Layout make_layout(int NM, int MM, bool lwl, int idxb, size_t min_table = 0) {
+    Layout L{};
+    size_t o = 0;
+    L.o_f = o;    o += al16((size_t)(NM + 2) * 8);                      // BF distances from u, then f (+min,max)
+    L.o_dir = o;  o += al16((size_t)2 * MM * 4);                        // directed entries src<<16|dst
+    L.o_lw = o;   o += lwl ? al16((size_t)2 * MM * 8) : 0;              // entry weights (dir|lw also host the PI table)
+    if (o - L.o_dir < min_table) o = L.o_dir + al16(min_table);         // the image table needs >= 1 point
+    L.o_x = o;    o += al16(smax((size_t)NM * 8 + (size_t)4 * NM * 4,   // [dist from v | cnt/nxt x2]
+                                 (size_t)pow2ceil(MM) * 12));           // or [sort keys | sort payload]
+    L.o_amb = o;  o += al16((size_t)NM * idxb);                         // tie-fallback list, then union-find parents
+    L.o_par = o;  o += al16((size_t)NM * idxb);                         // spanning-tree parents
+    L.o_mark = o; o += al16((size_t)NM * idxb);                         // path stamps
+    L.o_pn = o;   o += al16((size_t)MM * 4);                            // Pos from the front, Neg from the back
+    L.o_pts = o;  o += al16((size_t)(MM + 2) * 4);                      // diagram points (birth node<<16 | death node)
+    L.o_ctl = o;  o += 256;
+    L.total = o;
+    return L;
+}
+
+template <typename idx_t>
+struct Mem {
+    double* f;
+    unsigned* dir;
+    double* lw;
+    ull* dv;
+    unsigned *cntU, *nxtU, *cntV, *nxtV;
+    ull* keyS;
+    unsigned* valS;
+    idx_t *amb, *comp, *par, *mark;
+    unsigned *pn, *pts;
+    int* ctl;      // [0] changed [1] namb [2] npts [3] npos [4] nneg [5] progress [6] n_up [7] n_down
+    double* red;   // 16 doubles for block reductions
+    int* wcnt;     // 16 ints for block compaction
+    unsigned char* table;  // PI table: spans dir (+lw)
+    size_t table_bytes;
+};
+
+template <typename idx_t>
+__device__ __forceinline__ Mem<idx_t> carve(unsigned char* base, const Layout& L, int NM, int MM, bool lwl) {
+    Mem<idx_t> m;
+    m.f = (double*)(base + L.o_f);
+    m.dir = (unsigned*)(base + L.o_dir);
+    m.lw = (double*)(base + L.o_lw);
+    m.dv = (ull*)(base + L.o_x);
+    m.cntU = (unsigned*)(base + L.o_x + (size_t)NM * 8);
+    m.nxtU = m.cntU + NM;
+    m.cntV = m.nxtU + NM;
+    m.nxtV = m.cntV + NM;
+    m.keyS = (ull*)(base + L.o_x);
+    m.valS = (unsigned*)(base + L.o_x + (size_t)pow2ceil(MM) * 8);
+    m.amb = (idx_t*)(base + L.o_amb);
+    m.comp = m.amb;
+    m.par = (idx_t*)(base + L.o_par);
+    m.mark = (idx_t*)(base + L.o_mark);
+    m.pn = (unsigned*)(base + L.o_pn);
+    m.pts = (unsigned*)(base + L.o_pts);
+    m.ctl = (int*)(base + L.o_ctl);
+    m.red = (double*)(base + L.o_ctl + 64);
+    m.wcnt = (int*)(base + L.o_ctl + 192);
+    m.table = base + L.o_dir;
+    m.table_bytes = L.o_x - L.o_dir;
+    return m;
+}
+
+// ---- block helpers (W threads) -------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ double block_max(double v, double* red) {
+    v = tlc_wave_max_f64(v);
+    if (W == 64) return v;
+    if (tlc_lane() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = red[0];
+#pragma unroll
+    for (int k = 1; k < W / 64; ++k) r = red[k] > r ? red[k] : r;
+    __syncthreads();
+    return r;
+}
+template <int W>
+__device__ __forceinline__ double block_min(double v, double* red) {
+    v = tlc_wave_min_f64(v);
+    if (W == 64) return v;
+    if (tlc_lane() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = red[0];
+#pragma unroll
+    for (int k = 1; k < W / 64; ++k) r = red[k] < r ? red[k] : r;
+    __syncthreads();
+    return r;
+}
+
+// monotone map double -> u64 (ascending); ~key gives descending order
+__device__ __forceinline__ ull f64_key(double x) {
+    const ull b = (ull)__double_as_longlong(x);
+    return b ^ ((b >> 63) ? ~0ull : (1ull << 63));
+}
+
+// perturb_filter_function (accelerated_PD.py:18-21); evaluated in exactly this association, no FMA
+__device__ __forceinline__ double key_asc(double fa, double fb) {
+    const double hi = fa > fb ? fa : fb, lo = fa < fb ? fa : fb;
+    return hi + (lo + 1.0) * 1e-6;
+}
+__device__ __forceinline__ double key_desc(double fa, double fb) {
+    const double hi = fa > fb ? fa : fb, lo = fa < fb ? fa : fb;
+    return lo - (101.0 - hi) * 1e-6;
+}
+
+// ---- Bellman-Ford over the directed entries: dist = min over paths of the fp64 sum accumulated from the source --
+template <int W, bool TWO, class LWF>
+__device__ __forceinline__ void bellman_ford(ull* d0, ull* d1, const unsigned* dir, int m2, int n, LWF LW, int* ctl) {
+    const int tid = threadIdx.x;
+    for (int iter = 0; iter <= n; ++iter) {
+        if (tid == 0) ctl[0] = 0;
+        __syncthreads();
+        int ch = 0;
+        for (int j = tid; j < m2; j += W) {
+            const unsigned e = dir[j];
+            const int a = e >> 16, b = e & 0xffffu;
+            const double w = LW(j);
+            {
+                const double c = __longlong_as_double((long long)d0[a]) + w;
+                const ull cb = (ull)__double_as_longlong(c);
+                const ull old = atomicMin(&d0[b], cb);
+                ch |= (cb < old);
+            }
+            if (TWO) {
+                const double c = __longlong_as_double((long long)d1[a]) + w;
+                const ull cb = (ull)__double_as_longlong(c);
+                const ull old = atomicMin(&d1[b], cb);
+                ch |= (cb < old);
+            }
+        }
+        if (ch) ctl[0] = 1;
+        __syncthreads();
+        const int any = ctl[0];
+        __syncthreads();
+        if (!any) break;
+    }
+}
+
+// ---- bitonic sort of (key u64, payload u32), ascending by key, P a power of two ------------------------------------
+template <int W>
+__device__ __forceinline__ void bitonic_sort(ull* key, unsigned* val, int P) {
+    const int tid = threadIdx.x;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += W) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int x = i | j;
+                const bool up = ((i & k) == 0);
+                const ull ki = key[i], kx = key[x];
+                if ((ki > kx) == up && ki != kx) {
+                    key[i] = kx; key[x] = ki;
+                    const unsigned vi = val[i], vx = val[x];
+                    val[i] = vx; val[x] = vi;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename idx_t>
+__device__ __forceinline__ int uf_find(idx_t* comp, int p) {
+    // path halving exactly as accelerated_PD.py:53-58
+    int c = comp[p];
+    while (p != c) {
+        const int g = comp[c];
+        comp[p] = (idx_t)g;
+        p = g;
+        c = comp[p];
+    }
+    return p;
+}
+
+// Where the serial passes put the diagram points.  Only thread 0 calls these.
+// Batch path: node-index pairs into LDS (every PD coordinate is a copy of some f[node]).
+struct PtsSink {
+    unsigned* pts;
+    int np, n_up, n_down, n_one;
+    __device__ __forceinline__ void up(const double*, int birth, int death) { pts[np++] = ((unsigned)birth << 16) | (unsigned)death; ++n_up; }
+    __device__ __forceinline__ void ext0(const double*, int mn, int mx) { pts[np++] = ((unsigned)mn << 16) | (unsigned)mx; }
+    __device__ __forceinline__ void down(const double*, int, int) {}
+    __device__ __forceinline__ void one(const double*, int birth, int death) { pts[np++] = ((unsigned)birth << 16) | (unsigned)death; ++n_one; }
+    static constexpr bool want_down = false;
+};
+// tlc_pd_from_filtration: values straight to the caller's arrays.
+struct GlobalSink {
+    double *pd_up, *pd_down, *pd_one, *e0;
+    int np, n_up, n_down, n_one;
+    __device__ __forceinline__ void up(const double* f, int b, int d) { pd_up[2 * n_up] = f[b]; pd_up[2 * n_up + 1] = f[d]; ++n_up; }
+    __device__ __forceinline__ void ext0(const double* f, int mn, int mx) { e0[0] = f[mn]; e0[1] = f[mx]; }
+    __device__ __forceinline__ void down(const double* f, int b, int d) { pd_down[2 * n_down] = f[b]; pd_down[2 * n_down + 1] = f[d]; ++n_down; }
+    __device__ __forceinline__ void one(const double* f, int b, int d) { pd_one[2 * n_one] = f[b]; pd_one[2 * n_one + 1] = f[d]; ++n_one; }
+    static constexpr bool want_down = true;
+};
+
+// The two union-find passes on a subgraph whose f[0..n) is final (f[n] = min, f[n+1] = max).
+// valS[0..m) holds one payload per undirected edge: the packed endpoints a<<16|b (EID=false) or an edge id into
+// M.dir[] (EID=true).  On return ctl[3] = #Pos, ctl[4] = #Neg, pn[] = Pos from the front / Neg from the back
+// (payloads, in descending-pass order).
+template <int W, typename idx_t, bool EID, class Sink>
+__device__ __forceinline__ void pd_stages(Mem<idx_t>& M, Sink& sink, int n, int m, int P, unsigned flags, int MMcap) {
+    const int tid = threadIdx.x;
+    const bool keep0 = (flags & TLC_KEEP_ZERO_PERS) != 0;
+    double* f = M.f;
+    auto ends = [&](unsigned v) -> unsigned { return EID ? M.dir[v] : v; };
+    // ---- ascending keys ----------------------------------------------------------------------------------------------
+    for (int e = tid; e < P; e += W) {
+        if (e < m) {
+            const unsigned ab = ends(M.valS[e]);
+            M.keyS[e] = f64_key(key_asc(f[ab >> 16], f[ab & 0xffffu]));
+        } else {
+            M.keyS[e] = ~0ull;
+            M.valS[e] = 0u;
+        }
+    }
+    for (int i = tid; i < n; i += W) M.comp[i] = (idx_t)i;
+    __syncthreads();
+    bitonic_sort<W>(M.keyS, M.valS, P);
+    // ---- ascending union-find pass (accelerated_PD.py:46-68) ---------------------------------------------------------
+    if (tid == 0) {
+        for (int e = 0; e < m; ++e) {
+            const unsigned ab = ends(M.valS[e]);
+            const int a = ab >> 16, b = ab & 0xffffu;
+            const int pa = uf_find(M.comp, a), pb = uf_find(M.comp, b);
+            if (pa != pb) {
+                const int small = (f[pa] <= f[pb]) ? pa : pb, large = pa + pb - small;     // :63-64
+                const int maxn = (f[a] > f[b]) ? a : b;                                    // :65
+                if (keep0 || f[large] < f[maxn]) sink.up(f, large, maxn);                  // :66-67
+                M.comp[large] = (idx_t)small;
+            }
+        }
+        sink.ext0(f, n, n + 1);                                                            // [min, max]  (:110)
+    }
+    __syncthreads();
+    // ---- descending keys, same edges (:70-77) -------------------------------------------------------------------------
+    for (int e = tid; e < m; e += W) {
+        const unsigned ab = ends(M.valS[e]);
+        M.keyS[e] = ~f64_key(key_desc(f[ab >> 16], f[ab & 0xffffu]));
+    }
+    for (int i = tid; i < n; i += W) M.comp[i] = (idx_t)i;
+    __syncthreads();
+    bitonic_sort<W>(M.keyS, M.valS, P);
+    // ---- descending pass (:83-109): Pos / Neg classification (+ Rel1 points) ------------------------------------------
+    if (tid == 0) {
+        int npos = 0, nneg = 0;
+        for (int e = 0; e < m; ++e) {
+            const unsigned val = M.valS[e];
+            const unsigned ab = ends(val);
+            const int a = ab >> 16, b = ab & 0xffffu;
+            const int pa = uf_find(M.comp, a), pb = uf_find(M.comp, b);
+            if (pa != pb) {
+                M.pn[MMcap - 1 - nneg] = val;
+                ++nneg;
+                const int small = (f[pa] <= f[pb]) ? pa : pb, large = pa + pb - small;     // :101-102
+                if (Sink::want_down) {
+                    const int minn = (f[a] < f[b]) ? a : b;                                // :103-104
+                    if (keep0 || f[small] > f[minn]) sink.down(f, small, minn);            // :105-106
+                }
+                M.comp[small] = (idx_t)large;
+            } else {
+                M.pn[npos++] = val;
+            }
+        }
+        M.ctl[3] = npos; M.ctl[4] = nneg;
+    }
+    __syncthreads();
+}
+
+// Accelerate_PD (accelerated_PD.py:115-178).  Requires ctl[4] (#Neg) >= 1.
+template <int W, typename idx_t, bool EID, class Sink>
+__device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, unsigned flags, int MMcap) {
+    const int tid = threadIdx.x;
+    const bool keep0 = (flags & TLC_KEEP_ZERO_PERS) != 0;
+    const idx_t NONE = (idx_t)~(idx_t)0;
+    const int npos = M.ctl[3], nneg = M.ctl[4];
+    double* f = M.f;
+    auto ends = [&](unsigned v) -> unsigned { return EID ? M.dir[v] : v; };
+    // spanning tree of the Neg edges rooted at the first endpoint of the first Neg edge (:119-125)
+    for (int i = tid; i < n; i += W) { M.par[i] = NONE; M.mark[i] = 0; }
+    __syncthreads();
+    const int root = ends(M.pn[MMcap - 1]) >> 16;
+    if (tid == 0) M.par[root] = (idx_t)root;
+    __syncthreads();
+    for (int round = 0; round <= n; ++round) {
+        if (tid == 0) M.ctl[5] = 0;
+        __syncthreads();
+        int prog = 0;
+        for (int k = tid; k < nneg; k += W) {
+            const unsigned ab = ends(M.pn[MMcap - 1 - k]);
+            const int a = ab >> 16, b = ab & 0xffffu;
+            const idx_t pa = M.par[a], pb = M.par[b];
+            if (pa != NONE && pb == NONE) { M.par[b] = (idx_t)a; prog = 1; }
+            else if (pb != NONE && pa == NONE) { M.par[a] = (idx_t)b; prog = 1; }
+        }
+        if (prog) M.ctl[5] = 1;
+        __syncthreads();
+        const int any = M.ctl[5];
+        __syncthreads();
+        if (!any) break;
+    }
+    if (tid == 0) {
+        unsigned stamp = 0;
+        for (int pi = 0; pi < npos; ++pi) {
+            const unsigned pq = ends(M.pn[pi]);
+            const int p = pq >> 16, q = pq & 0xffffu;
+            if (M.par[p] == NONE || M.par[q] == NONE) continue;   // other component: callers gate on connectivity
+            if (++stamp == (unsigned)NONE) {                      // stamp space of idx_t exhausted: start over
+                for (int i = 0; i < n; ++i) M.mark[i] = 0;
+                stamp = 1;
+            }
+            for (int a = p; a != root; a = M.par[a]) M.mark[a] = (idx_t)stamp;   // path_0 (:131-144)
+            int meet = root;
+            for (int a = q; a != root; a = M.par[a]) {                           // path_1 until it joins path_0
+                if (M.mark[a] == (idx_t)stamp) { meet = a; break; }
+            }
+            // Loop = symmetric difference of the two root paths (:149-151); first maximum of 'asc' (:155-159)
+            int best = -1, side = 0;
+            double bestv = 0.0;
+            for (int a = p; a != meet; a = M.par[a]) {
+                const double v = key_asc(f[a], f[M.par[a]]);
+                if (best < 0 || v > bestv) { best = a; bestv = v; side = 0; }
+            }
+            for (int a = q; a != meet; a = M.par[a]) {
+                const double v = key_asc(f[a], f[M.par[a]]);
+                if (best < 0 || v > bestv) { best = a; bestv = v; side = 1; }
+            }
+            if (best < 0) continue;
+            const int bp = M.par[best];
+            const int hin = (f[best] > f[bp]) ? best : bp;                       // large_value  (:160)
+            const int lon = (f[p] < f[q]) ? p : q;                               // low_value    (:162)
+            if (keep0 || f[hin] > f[lon]) sink.one(f, lon, hin);                 // :164-165
+            // evert the path so that (p,q) replaces the removed tree edge (:168-176)
+            int node = side == 0 ? p : q, nodec = side == 0 ? q : p;
+            while (nodec != best) {
+                const int tp = M.par[node];
+                M.par[node] = (idx_t)nodec;
+                nodec = node;
+                node = tp;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// PersistenceImager.transform (PersistenceImager.pyx:352-388) over points first..last: Gaussian sigma=1 on [0,1]^2,
+// linear-ramp weight.  Phase A: one lane per (point, grid line) evaluates the normal CDF into an LDS table; phase B:
+// one lane per pixel sums w * dPhi_b * dPhi_p over the points in diagram order (the factored form of the reference's
+// 4-term inclusion-exclusion).  `get(k, b, d)` yields the k-th (birth, death).  Returns this thread's
+// pixel value (threads >= res*res carry `acc` through unchanged).
+template <int W, class Get>
+__device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get get, int first, int last, int res,
+                                           double acc) {
+    const int tid = threadIdx.x;
+    const int G = res + 1, stride = 2 * G + 1;
+    int batch = (int)(table_bytes / ((size_t)stride * 8));
+    if (batch > W) batch = W;
+    const double pixel = 1.0 / (double)res;
+    const double step = ((1.0 + pixel) - 0.0) / (double)(res + 1);       // _create_mesh (:302-314)
+    const double inv_s2 = 0.70710678118654752440;
+    for (int b0 = first; b0 < last; b0 += batch) {
+        const int nb = (last - b0) < batch ? (last - b0) : batch;
+        for (int t = tid; t < nb * stride; t += W) {
+            const int pt = t / stride, g = t - pt * stride;
+            double b, d;
+            get(b0 + pt, b, d);
+            const double pers = d - b;                                         // skew (:367-368)
+            const double wgt = pers < 0.0 ? 0.0 : (pers > 1.0 ? 1.0 : pers);   // linear_ramp (:9-30)
+            double val;
+            if (g == 2 * G) val = wgt;
+            else if (wgt == 0.0) val = 0.0;
+            else {
+                const double x = (g < G) ? ((double)g * step - b) : ((double)(g - G) * step - pers);
+                val = 0.5 * erfc(-x * inv_s2);                                 // _norm_cdf (:54-60)
+            }
+            tbl[t] = val;
+        }
+        __syncthreads();
+        if (tid < res * res) {
+            const int pi = tid / res, pj = tid - pi * res;
+            for (int pt = 0; pt < nb; ++pt) {
+                const double* r = tbl + pt * stride;
+                const double wgt = r[2 * G];
+                if (wgt != 0.0) acc += wgt * ((r[pi + 1] - r[pi]) * (r[G + pj + 1] - r[G + pj]));
+            }
+        }
+        __syncthreads();
+    }
+    return acc;
+}
+
+}  // namespace
+
+// ======================================================================================================================
+// Batch kernel: one workgroup per vicinity subgraph of one size tier.
+// ======================================================================================================================
+template <int NM, int MM, int W, bool LWL, bool HUGE>
+__global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
+    typedef unsigned short idx_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x;
+    unsigned char* base;
+    Layout L;
+    int NMr, MMr;
+    if constexpr (HUGE) {
+        NMr = p.huge_nmax; MMr = p.huge_mmax;
+        L = make_layout(NMr, MMr, false, sizeof(idx_t), TLC_HUGE_MIN_TABLE);
+        base = p.huge_scratch + (size_t)blockIdx.x * p.huge_stride;
+    } else {
+        NMr = NM; MMr = MM;
+        constexpr Layout Lc = make_layout(NM, MM, LWL, sizeof(idx_t));
+        L = Lc;
+        base = lds_raw;
+    }
+    Mem<idx_t> M = carve<idx_t>(base, L, NMr, MMr, LWL);
+    const int res = p.res, res2 = res * res;
+
+    for (int wi = blockIdx.x; wi < p.tier_count; wi += gridDim.x) {
+        const int i = p.tier_list[wi];
+        const int n = p.hdr_n[i], m2 = p.hdr_m2[i], lu = p.hdr_lu[i], lv = p.hdr_lv[i];
+        const long long eo = p.edge_off[i];
+        const int m = m2 >> 1;
+        const bool far = (lu < 0);        // u in S <=> v in S <=> d(u,v) <= hop  
+        int status = TLC_ST_OK;
+        // ---- stage the subgraph ------------------------------------------------------------------------------------
+        for (int j = tid; j < m2; j += W) {
+            M.dir[j] = p.A_dir[eo + j];
+            if (LWL) M.lw[j] = p.A_lw[eo + j];
+        }
+        ull* du = (ull*)M.f;
+        for (int k = tid; k < n; k += W) { du[k] = TLC_INF_BITS; M.dv[k] = TLC_INF_BITS; }
+        if (tid == 0) M.ctl[1] = 0;
+        __syncthreads();
+        const double* glw = p.A_lw + eo;
+        auto LW = [&](int j) -> double { return LWL ? M.lw[j] : glw[j]; };
+
+        if (!far) {
+            // ---- P5: filtration.build_fv, weighted branch, descriptor 'sum' (riccidist2dgm.py:20-61) ------------------
+            if (tid == 0) { du[lu] = 0ull; M.dv[lv] = 0ull; }
+            __syncthreads();
+            bellman_ford<W, true>(du, M.dv, M.dir, m2, n, LW, M.ctl);
+            // assert one connected component (:318): everything must be reachable from u
+            double dmx = 0.0;
+            int unreach = 0;
+            for (int k = tid; k < n; k += W) {
+                const ull a = du[k], b = M.dv[k];
+                unreach |= (a == TLC_INF_BITS);
+                const double da = __longlong_as_double((long long)a), db = __longlong_as_double((long long)b);
+                if (a != TLC_INF_BITS && da > dmx) dmx = da;
+                if (b != TLC_INF_BITS && db > dmx) dmx = db;
+            }
+            dmx = block_max<W>(dmx, M.red);
+            const double un = block_max<W>(unreach ? 1.0 : 0.0, M.red);
+            if (un != 0.0) status = TLC_ST_DISCONNECTED;
+            if (status == TLC_ST_OK) {
+                // tight entries: a -> b lies on a (near-)shortest path from a to the root
+                const double tol = 1e-10 * (1.0 + dmx);
+                for (int k = tid; k < n; k += W) { M.cntU[k] = 0u; M.cntV[k] = 0u; }
+                __syncthreads();
+                for (int j = tid; j < m2; j += W) {
+                    const unsigned e = M.dir[j];
+                    const int a = e >> 16, b = e & 0xffffu;
+                    const double w = LW(j);
+                    if (a != lu) {
+                        const double s = (w + __longlong_as_double((long long)du[b])) - __longlong_as_double((long long)du[a]);
+                        if (s <= tol) { atomicAdd(&M.cntU[a], 1u); M.nxtU[a] = (unsigned)j; }
+                    }
+                    if (a != lv) {
+                        const double s = (w + __longlong_as_double((long long)M.dv[b])) - __longlong_as_double((long long)M.dv[a]);
+                        if (s <= tol) { atomicAdd(&M.cntV[a], 1u); M.nxtV[a] = (unsigned)j; }
+                    }
+                }
+                __syncthreads();
+                // chain walks: sum the weights from x towards the root, left to right (:29-30, :34-35).
+                // f aliases du, which is dead from here on: the walks only read cnt/nxt/dir/lw.
+                for (int x0 = 0; x0 < n; x0 += W) {
+                    const int x = x0 + tid;
+                    double fr = 0.0;
+                    bool amb = false;
+                    if (x < n && x != lu && x != lv) {
+                        double d1 = 0.0, d2 = 0.0;
+                        int a = x, steps = 0;
+                        while (a != lu) {
+                            if (M.cntU[a] != 1u || ++steps > n) { amb = true; break; }
+                            const int j = (int)M.nxtU[a];
+                            d1 = d1 + LW(j);
+                            a = (int)(M.dir[j] & 0xffffu);
+                        }
+                        a = x; steps = 0;
+                        while (!amb && a != lv) {
+                            if (M.cntV[a] != 1u || ++steps > n) { amb = true; break; }
+                            const int j = (int)M.nxtV[a];
+                            d2 = d2 + LW(j);
+                            a = (int)(M.dir[j] & 0xffffu);
+                        }
+                        fr = d1 + d2;                                     // 'sum' = dist_1 + dist_2 (:49)
+                    }
+                    if (x < n) {
+                        if (amb) M.amb[atomicAdd(&M.ctl[1], 1)] = (idx_t)x;
+                        else M.f[x] = fr;
+                    }
+                }
+                __syncthreads();
+                // exact fallback for sources with (near-)tied paths: Bellman-Ford sourced at x itself
+                const int namb = M.ctl[1];
+                for (int q = 0; q < namb; ++q) {
+                    const int x = M.amb[q];
+                    for (int k = tid; k < n; k += W) M.dv[k] = TLC_INF_BITS;
+                    __syncthreads();
+                    if (tid == 0) M.dv[x] = 0ull;
+                    __syncthreads();
+                    bellman_ford<W, false>(M.dv, M.dv, M.dir, m2, n, LW, M.ctl);
+                    if (tid == 0)
+                        M.f[x] = __longlong_as_double((long long)M.dv[lu]) + __longlong_as_double((long long)M.dv[lv]);
+                    __syncthreads();
+                }
+                if (namb && tid == 0 && p.stats) atomicAdd(&p.stats[0], (ull)namb);
+                // normalise (:50-56): plain division by the maximum
+                double mx = 0.0;
+                for (int k = tid; k < n; k += W) mx = M.f[k] > mx ? M.f[k] : mx;
+                mx = block_max<W>(mx, M.red);
+                double scaler = mx;
+                if (p.flags & TLC_NORM_EPS) scaler = mx + 1e-10;          // data_utils_LP.py:64
+                else if (mx == 0.0) status = TLC_ST_ZERO_RANGE;           // ZeroDivisionError (:54)
+                if (status == TLC_ST_OK)
+                    for (int k = tid; k < n; k += W) M.f[k] = M.f[k] / scaler;
+                __syncthreads();
+            }
+        } else {
+            // d(u,v) > hop: every distance is the sentinel 100 (:31-37) => f == 200/200; only connectivity matters
+            if (tid == 0) du[0] = 0ull;
+            __syncthreads();
+            bellman_ford<W, false>(du, du, M.dir, m2, n, LW, M.ctl);
+            int unreach = 0;
+            for (int k = tid; k < n; k += W) unreach |= (du[k] == TLC_INF_BITS);
+            const double un = block_max<W>(unreach ? 1.0 : 0.0, M.red);
+            if (un != 0.0) status = TLC_ST_DISCONNECTED;
+            __syncthreads();
+            const double one = (p.flags & TLC_NORM_EPS) ? (200.0 / (200.0 + 1e-10)) : (200.0 / 200.0);
+            for (int k = tid; k < n; k += W) M.f[k] = one;
+            __syncthreads();
+        }
+        // optional filtration output (tlc_vicinity_filtration)
+        if (p.out_f) {
+            const long long no = p.ids_off[i];
+            const long long cap = p.ids_off[i + 1] - no;
+            if (n <= cap) {
+                for (int k = tid; k < n; k += W) p.out_f[no + k] = (status == TLC_ST_OK) ? M.f[k] : 0.0;
+                if (tid == 0) p.out_n[i] = n;
+            } else if (tid == 0) p.out_n[i] = -n;
+        }
+        double acc = 0.0;
+        if (p.pi_enabled && status == TLC_ST_OK && far) {
+            // constant f: no strict pair, [1,1] has persistence 0 => weight 0 => exact zero image;
+            // IndexError for a single node (accelerated_PD.py:122)
+            if (n == 1 && !(p.flags & TLC_NO_EXT1)) status = TLC_ST_NO_TREE_EDGE;
+        } else if (p.pi_enabled && status == TLC_ST_OK) {
+            // ---- undirected edge list: directed entries with src < dst, in CSR order (deterministic compaction) ------
+            {
+                int run = 0;
+                for (int j0 = 0; j0 < m2; j0 += W) {
+                    const int j = j0 + tid;
+                    unsigned e = 0;
+                    bool keep = false;
+                    if (j < m2) { e = M.dir[j]; keep = (e >> 16) < (e & 0xffffu); }
+                    const ull mk = __ballot(keep);
+                    int off;
+                    if (W == 64) {
+                        off = run + __popcll(mk & tlc_lanemask_lt());
+                        run += __popcll(mk);
+                    } else {
+                        if (tlc_lane() == 0) M.wcnt[tid >> 6] = __popcll(mk);
+                        __syncthreads();
+                        int before = 0, tot = 0;
+#pragma unroll
+                        for (int k = 0; k < W / 64; ++k) {
+                            const int c = M.wcnt[k];
+                            if (k < (tid >> 6)) before += c;
+                            tot += c;
+                        }
+                        off = run + before + __popcll(mk & tlc_lanemask_lt());
+                        run += tot;
+                        __syncthreads();
+                    }
+                    // keyS/valS alias dv/cnt/nxt, which are dead by now
+                    if (keep) M.valS[off] = e;
+                }
+                __syncthreads();
+            }
+            // min / max of f as two extra "nodes" n, n+1 for the [min,max] point (accelerated_PD.py:28-38,110)
+            {
+                double mn = 99999999.0, mx = -99999999.0;
+                for (int k = tid; k < n; k += W) { const double v = M.f[k]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+                mn = block_min<W>(mn, M.red);
+                mx = block_max<W>(mx, M.red);
+                if (tid == 0) { M.f[n] = mn; M.f[n + 1] = mx; }
+                __syncthreads();
+            }
+            const int P = pow2ceil(m < 2 ? 2 : m);
+            PtsSink sink{M.pts, 0, 0, 0, 0};
+            pd_stages<W, idx_t, false>(M, sink, n, m, P, p.flags, MMr);
+            if (!(p.flags & TLC_NO_EXT1)) {
+                if (M.ctl[4] == 0) status = TLC_ST_NO_TREE_EDGE;          // list(Nodes)[0] -> IndexError (:122)
+                else ext1_stage<W, idx_t, false>(M, sink, n, p.flags, MMr);
+            }
+            if (tid == 0) { M.ctl[2] = sink.np; M.ctl[6] = sink.n_up; }
+            __syncthreads();
+            if (status == TLC_ST_OK) {
+                const int np = M.ctl[2], n_up = M.ctl[6];
+                auto get = [&](int k, double& b, double& d) {
+                    const unsigned bd = M.pts[k];
+                    b = M.f[bd >> 16];
+                    d = M.f[bd & 0xffffu];
+                };
+                // transform(np.array(PD_zero + PD_one)) (riccidist2dgm.py:327-328); Rel1 and [max,min] have negative
+                // persistence => weight 0 (PersistenceImager.pyx:23-24), so they are never materialised here
+                if (p.flags & TLC_PI_ORD0_EXT1) {
+                    acc = pi_stage<W>((double*)M.table, M.table_bytes, get, 0, n_up, res, acc);
+                    acc = pi_stage<W>((double*)M.table, M.table_bytes, get, n_up + 1, np, res, acc);
+                } else {
+                    acc = pi_stage<W>((double*)M.table, M.table_bytes, get, 0, np, res, acc);
+                }
+            }
+        }
+        if (status != TLC_ST_OK) acc = 0.0;
+        if (p.out_pi && tid < res2) p.out_pi[(size_t)i * res2 + tid] = acc;
+        if (p.out_status && tid == 0) p.out_status[i] = (unsigned char)status;
+        __syncthreads();
+    }
+}
+
+// ======================================================================================================================
+// tlc_pd_from_filtration: caller-supplied graphs and filtration values; diagrams written out as values.
+// ======================================================================================================================
+template <int NM, int MM, int W, bool HUGE>
+__global__ __launch_bounds__(W) void tlc_pdf_tier_kernel(TlcPdfParams p) {
+    typedef unsigned short idx_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x;
+    unsigned char* base;
+    Layout L;
+    int NMr, MMr;
+    if constexpr (HUGE) {
+        NMr = p.huge_nmax; MMr = p.huge_mmax;
+        L = make_layout(NMr, MMr, false, sizeof(idx_t), TLC_HUGE_MIN_TABLE);
+        base = p.huge_scratch + (size_t)blockIdx.x * p.huge_stride;
+    } else {
+        NMr = NM; MMr = MM;
+        constexpr Layout Lc = make_layout(NM, MM, false, sizeof(idx_t));
+        L = Lc;
+        base = lds_raw;
+    }
+    Mem<idx_t> M = carve<idx_t>(base, L, NMr, MMr, false);
+    for (int wi = blockIdx.x; wi < p.count; wi += gridDim.x) {
+        const int g = p.list[wi];
+        const long long no = p.node_offs[g], eo = p.edge_offs[g];
+        const int n = (int)(p.node_offs[g + 1] - no), m = (int)(p.edge_offs[g + 1] - eo);
+        double mn = 99999999.0, mx = -99999999.0;
+        for (int k = tid; k < n; k += W) {
+            const double v = p.f[no + k];
+            M.f[k] = v;
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+        }
+        mn = block_min<W>(mn, M.red);
+        mx = block_max<W>(mx, M.red);
+        if (tid == 0) { M.f[n] = mn; M.f[n + 1] = mx; }
+        for (int e = tid; e < m; e += W) {
+            M.dir[e] = ((unsigned)p.edges[2 * (eo + e)] << 16) | (unsigned)p.edges[2 * (eo + e) + 1];
+            M.valS[e] = (unsigned)e;
+        }
+        __syncthreads();
+        GlobalSink sink{p.pd_up + 2 * no, p.pd_down + 2 * no, p.pd_one + 2 * eo, p.ext0 + 2 * (size_t)g, 0, 0, 0, 0};
+        const int P = pow2ceil(m < 2 ? 2 : m);
+        pd_stages<W, idx_t, true>(M, sink, n, m, P, p.flags, MMr);
+        const int npos = M.ctl[3], nneg = M.ctl[4];
+        if (!(p.flags & TLC_NO_EXT1) && nneg > 0) ext1_stage<W, idx_t, true>(M, sink, n, p.flags, MMr);
+        if (tid == 0) {
+            p.counts[4 * (size_t)g + 0] = sink.n_up;
+            p.counts[4 * (size_t)g + 1] = sink.n_down;
+            p.counts[4 * (size_t)g + 2] = sink.n_one;
+            p.counts[4 * (size_t)g + 3] = n - nneg;
+        }
+        if (p.edge_rank) {
+            for (int k = tid; k < npos; k += W) p.edge_rank[eo + M.pn[k]] = k;
+            for (int k = tid; k < nneg; k += W) p.edge_rank[eo + M.pn[MMr - 1 - k]] = -k - 1;
+        }
+        __syncthreads();
+    }
+}
+
+// tier binning for tlc_pd_from_filtration
+__global__ void tlc_pdf_bin_kernel(int n_graphs, const long long* node_offs, const long long* edge_offs, int* tier_count,
+                                   int* tier_list) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_graphs) return;
+    const long long n = node_offs[g + 1] - node_offs[g], m = edge_offs[g + 1] - edge_offs[g];
+    int tier = TLC_TIER_HUGE;
+    if (n <= 0) tier = -1;
+    else if (n <= TLC_S_NMAX && m <= TLC_S_MMAX) tier = TLC_TIER_SMALL;
+    else if (n <= TLC_M_NMAX && m <= TLC_M_MMAX) tier = TLC_TIER_MEDIUM;
+    else if (n <= TLC_L_NMAX && m <= TLC_L_MMAX) tier = TLC_TIER_LARGE;
+    if (tier >= 0) {
+        const int pos = atomicAdd(&tier_count[tier], 1);
+        tier_list[(size_t)tier * n_graphs + pos] = g;
+    }
+}
+
+// ======================================================================================================================
+// tlc_pi_raster: one wavefront per diagram, points streamed from HBM in table-sized batches.
+// ======================================================================================================================
+__global__ __launch_bounds__(64) void tlc_pi_raster_kernel(int n_dgms, const long long* __restrict__ offs,
+                                                           const double* __restrict__ pts, int res,
+                                                           double* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) double tbl[64 * 17];
+    const int tid = threadIdx.x;
+    for (int d = blockIdx.x; d < n_dgms; d += gridDim.x) {
+        const long long o = offs[d];
+        const int k = (int)(offs[d + 1] - o);
+        auto get = [&](int i, double& b, double& dd) {
+            b = pts[2 * (o + i)];
+            dd = pts[2 * (o + i) + 1];
+        };
+        const double acc = pi_stage<64>(tbl, sizeof(tbl), get, 0, k, res, 0.0);
+        if (tid < res * res) out[(size_t)d * res * res + tid] = acc;
+        __syncthreads();
+    }
+}
+
+// ---- host launchers ------------------------------------------------------------------------------------------------------
+size_t tlc_huge_slot_bytes(int nmax, int mmax) { return al16(make_layout(nmax, mmax, false, 2, TLC_HUGE_MIN_TABLE).total); }
+
+template <class K>
+static int set_lds_limit(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return TLC_OK;
+}
+
+int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (p.tier_count <= 0) return TLC_OK;
+    switch (tier) {
+        case TLC_TIER_SMALL: {
+            constexpr Layout L = make_layout(TLC_S_NMAX, TLC_S_MMAX, true, 2);
+            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_S_NMAX, TLC_S_MMAX, 64, true, false>), dim3(p.tier_count), dim3(64),
+                               L.total, s, p);
+            break;
+        }
+        case TLC_TIER_MEDIUM: {
+            constexpr Layout L = make_layout(TLC_M_NMAX, TLC_M_MMAX, true, 2);
+            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, true, false>), dim3(p.tier_count),
+                               dim3(256), L.total, s, p);
+            break;
+        }
+        case TLC_TIER_LARGE: {
+            constexpr Layout L = make_layout(TLC_L_NMAX, TLC_L_MMAX, false, 2);
+            int rc = set_lds_limit(tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, 512, false, false>, L.total);
+            if (rc) return rc;
+            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, 512, false, false>), dim3(p.tier_count),
+                               dim3(512), L.total, s, p);
+            break;
+        }
+        case TLC_TIER_HUGE: {
+            if (p.huge_slots <= 0 || !p.huge_scratch) { tlc_set_error("HUGE tier without scratch"); return TLC_ERR_INVALID_ARG; }
+            const int grid = p.tier_count < p.huge_slots ? p.tier_count : p.huge_slots;
+            hipLaunchKernelGGL((tlc_pd_tier_kernel<0, 0, 256, false, true>), dim3(grid), dim3(256), 0, s, p);
+            break;
+        }
+        default:
+            tlc_set_error("bad tier");
+            return TLC_ERR_INVALID_ARG;
+    }
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
+int tlc_launch_pdf_tier(int tier, const TlcPdfParams& p, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (p.count <= 0) return TLC_OK;
+    switch (tier) {
+        case TLC_TIER_SMALL: {
+            constexpr Layout L = make_layout(TLC_S_NMAX, TLC_S_MMAX, false, 2);
+            hipLaunchKernelGGL((tlc_pdf_tier_kernel<TLC_S_NMAX, TLC_S_MMAX, 64, false>), dim3(p.count), dim3(64), L.total, s, p);
+            break;
+        }
+        case TLC_TIER_MEDIUM: {
+            constexpr Layout L = make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2);
+            hipLaunchKernelGGL((tlc_pdf_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, false>), dim3(p.count), dim3(256), L.total, s, p);
+            break;
+        }
+        case TLC_TIER_LARGE: {
+            constexpr Layout L = make_layout(TLC_L_NMAX, TLC_L_MMAX, false, 2);
+            int rc = set_lds_limit(tlc_pdf_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, 512, false>, L.total);
+            if (rc) return rc;
+            hipLaunchKernelGGL((tlc_pdf_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, 512, false>), dim3(p.count), dim3(512), L.total, s, p);
+            break;
+        }
+        case TLC_TIER_HUGE: {
+            if (p.huge_slots <= 0 || !p.huge_scratch) { tlc_set_error("HUGE tier without scratch"); return TLC_ERR_INVALID_ARG; }
+            const int grid = p.count < p.huge_slots ? p.count : p.huge_slots;
+            hipLaunchKernelGGL((tlc_pdf_tier_kernel<0, 0, 256, true>), dim3(grid), dim3(256), 0, s, p);
+            break;
+        }
+        default:
+            tlc_set_error("bad tier");
+            return TLC_ERR_INVALID_ARG;
+    }
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
+int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long* edge_offs, int* tier_count,
+                       int* tier_list, void* stream) {
+    if (n_graphs <= 0) return TLC_OK;
+    hipLaunchKernelGGL(tlc_pdf_bin_kernel, dim3((n_graphs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_graphs,
+                       node_offs, edge_offs, tier_count, tier_list);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
+int tlc_launch_pi_raster(int n_dgms, const long long* offs, const double* pts, int res, double* out, void* stream) {
+    if (n_dgms <= 0) return TLC_OK;
+    const int grid = n_dgms < 65536 ? n_dgms : 65536;
+    hipLaunchKernelGGL(tlc_pi_raster_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, n_dgms, offs, pts, res, out);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}

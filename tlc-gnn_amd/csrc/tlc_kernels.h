@@ -1,0 +1,138 @@
+// tlc_kernels.h -- kernel parameter blocks and tier constants shared by the .hip files and the host API.
+#pragma once
+#include <stdint.h>
+
+// per-pair status beyond the public ones: vicinity does not fit the packed 16-bit local ids
+#define TLC_ST_TOO_LARGE 5
+
+// Size tiers of the PD kernel (nodes / undirected edges of the vicinity subgraph).
+//   SMALL : one wavefront per subgraph, all state in ~6.5 KB of LDS   (>= 16 waves per CU)
+//   MEDIUM: 256 threads per subgraph, ~51 KB of LDS                    (3 workgroups per CU)
+//   LARGE : 512 threads per subgraph, ~140 KB of LDS, weights stay in HBM/L2 (1 workgroup per CU)
+//   HUGE  : 256 threads per subgraph, state in a per-workgroup HBM scratch slot (any size < 65536 nodes)
+#define TLC_TIER_SMALL 0
+#define TLC_TIER_MEDIUM 1
+#define TLC_TIER_LARGE 2
+#define TLC_TIER_HUGE 3
+#define TLC_N_TIERS 4
+
+#define TLC_S_NMAX 64
+#define TLC_S_MMAX 128
+#define TLC_M_NMAX 512
+#define TLC_M_MMAX 1024
+#define TLC_L_NMAX 2048
+#define TLC_L_MMAX 4096
+#define TLC_HUGE_MIN_TABLE 16384  /* bytes reserved for the image table in a HUGE scratch slot */
+
+struct TlcVicParams {
+    // graph (device CSR)
+    int n_nodes;
+    int nw;  // bitmap words = ceil(n_nodes / 32)
+    const int* rowptr;
+    const int* col;
+    const double* w;
+    // batch
+    const int* pairs;
+    int n_pairs;
+    int hop;
+    unsigned flags;
+    int res;
+    int* work_counter;
+    // per-workgroup scratch slot: 4 * n_nodes + 1 ints (two frontiers, id list, row offsets)
+    int* scratch;
+    long long scratch_stride;
+    // per-pair header
+    int* hdr_n;
+    int* hdr_m2;
+    int* hdr_lu;
+    int* hdr_lv;
+    // finished-in-COUNT outputs
+    double* out_pi;
+    unsigned char* out_status;
+    int* out_n;  // optional (tlc_vicinity_filtration)
+    // FILL
+    const long long* edge_off;
+    unsigned* A_dir;
+    double* A_lw;
+    const long long* ids_off;  // optional id output (tlc_vicinity_filtration)
+    int* out_ids;
+};
+
+struct TlcScanParams {
+    int n_pairs;
+    const int* hdr_n;
+    const int* hdr_m2;
+    const long long* block_sums;
+    long long* edge_off;
+    int* tier_count;  // [TLC_N_TIERS]
+    int* tier_list;   // [TLC_N_TIERS][n_pairs]
+};
+
+struct TlcPdParams {
+    // batch mode inputs (arena written by the FILL pass)
+    const int* tier_list;  // pair indices of this tier
+    int tier_count;
+    const int* hdr_n;
+    const int* hdr_m2;
+    const int* hdr_lu;
+    const int* hdr_lv;
+    const long long* edge_off;
+    const unsigned* A_dir;
+    const double* A_lw;
+    unsigned flags;
+    int res;
+    // outputs
+    double* out_pi;             // [n_pairs, res*res]
+    unsigned char* out_status;  // may be null
+    // optional filtration output (tlc_vicinity_filtration)
+    const long long* ids_off;
+    double* out_f;
+    int* out_n;
+    int pi_enabled;
+    // HUGE tier: per-workgroup scratch in HBM
+    unsigned char* huge_scratch;
+    long long huge_stride;
+    int huge_nmax;
+    int huge_mmax;
+    int huge_slots;
+    // statistics: [0] sources that took the exact tie fallback
+    unsigned long long* stats;
+};
+
+// PD from a caller-supplied filtration (tlc_pd_from_filtration)
+struct TlcPdfParams {
+    const int* list;  // graph indices of this tier
+    int count;
+    const long long* node_offs;
+    const long long* edge_offs;
+    const int* edges;  // int32[sum m, 2]
+    const double* f;
+    unsigned flags;
+    double* pd_up;
+    double* pd_down;
+    double* pd_one;
+    double* ext0;
+    int* counts;
+    int* edge_rank;
+    unsigned char* huge_scratch;
+    long long huge_stride;
+    int huge_nmax;
+    int huge_mmax;
+    int huge_slots;
+};
+
+#ifdef __HIPCC__
+template <bool FILL>
+__global__ void tlc_vicinity_kernel(TlcVicParams p);
+__global__ void tlc_scan_block_sums(const int* m2, int n_pairs, long long* block_sums);
+__global__ void tlc_scan_top(long long* block_sums, int n_blocks, long long* totals);
+__global__ void tlc_scan_down(TlcScanParams p);
+#endif
+
+// host-side launchers implemented next to their kernels
+int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream);
+int tlc_launch_pdf_tier(int tier, const TlcPdfParams& p, void* stream);
+int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long* edge_offs, int* tier_count,
+                       int* tier_list, void* stream);
+size_t tlc_huge_slot_bytes(int nmax, int mmax);
+int tlc_launch_pi_raster(int n_dgms, const long long* offs, const double* pts, int res, double* out, void* stream);

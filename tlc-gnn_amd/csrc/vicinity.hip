@@ -1,0 +1,348 @@
+// vicinity.hip -- P4 of the hot path: S = ball_hop(u) & ball_hop(v) and the induced weighted subgraph.
+//
+// Replaces sg2dgm_accelerate's BFS + set intersection + graph.subgraph (sg2dgm/riccidist2dgm.py:311-316).
+//
+// One wavefront per pair (64-thread workgroups, pairs dequeued from an atomic counter so that the
+// heavy-tailed vicinity sizes balance).  The two balls live as N-bit bitmaps in LDS (3 * N/8 bytes per
+// wave: ball(u), ball(v) -> S, and the per-word popcount prefix that turns a set bit into a local id),
+// so membership tests never leave the CU; CSR rows are read with one lane per short row and with the
+// whole wave (coalesced) for rows of >= 32 entries.
+//
+// Two passes over a batch (no device-side allocation, no overflow path):
+//   COUNT  writes |S|, the number of induced directed entries and the local ids of u and v per pair,
+//          and finishes the pairs that need no further work (missing endpoint, empty vicinity);
+//   FILL   (after an exclusive scan sized the arena) writes the induced subgraph of every remaining
+//          pair as packed directed entries (src<<16 | dst, local ids ascending by node id) + fp64 weights.
+#include "tlc_common.h"
+#include "tlc_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ bool bit_test(const unsigned* bits, int b) { return (bits[b >> 5] >> (b & 31)) & 1u; }
+
+// Set the bits of every neighbour of every node in list[0..count); optionally append newly set nodes to
+// `next` (global scratch) through the LDS counter *s_cnt.
+__device__ __forceinline__ void expand_rows(const int* __restrict__ list, int count, unsigned* bits,
+                                            const int* __restrict__ rowptr, const int* __restrict__ col,
+                                            int* next, int* s_cnt) {
+    const int lane = tlc_lane();
+    for (int base = 0; base < count; base += TLC_WAVE) {
+        const int k = base + lane;
+        int beg = 0, end = 0;
+        if (k < count) {
+            const int a = list[k];
+            beg = rowptr[a];
+            end = rowptr[a + 1];
+        }
+        const bool big = (end - beg) >= 32;
+        if (!big) {
+            for (int j = beg; j < end; ++j) {
+                const int b = col[j];
+                const unsigned bit = 1u << (b & 31);
+                const unsigned old = atomicOr(&bits[b >> 5], bit);
+                if (next && !(old & bit)) next[atomicAdd(s_cnt, 1)] = b;
+            }
+        }
+        unsigned long long mask = __ballot(big);
+        while (mask) {
+            const int L = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int bb = __shfl(beg, L, 64), ee = __shfl(end, L, 64);
+            for (int j = bb + lane; j < ee; j += TLC_WAVE) {
+                const int b = col[j];
+                const unsigned bit = 1u << (b & 31);
+                const unsigned old = atomicOr(&bits[b >> 5], bit);
+                if (next && !(old & bit)) next[atomicAdd(s_cnt, 1)] = b;
+            }
+        }
+    }
+}
+
+// nx.bfs_edges(graph, root, depth_limit=hop) as a bitmap (riccidist2dgm.py:311-314)
+__device__ __forceinline__ void mark_ball(unsigned* bits, int root, int hop, const TlcVicParams& p, int* frontA,
+                                          int* frontB, int* s_cnt) {
+    const int lane = tlc_lane();
+    if (lane == 0) atomicOr(&bits[root >> 5], 1u << (root & 31));
+    const int rb = p.rowptr[root], re = p.rowptr[root + 1];
+    // level 0: the only frontier node is the root; the next frontier is its CSR row itself
+    for (int j = rb + lane; j < re; j += TLC_WAVE) {
+        const int b = p.col[j];
+        atomicOr(&bits[b >> 5], 1u << (b & 31));
+    }
+    const int* list = p.col + rb;
+    int count = re - rb;
+    for (int level = 1; level < hop; ++level) {
+        const bool last = (level == hop - 1);
+        int* next = last ? nullptr : ((level & 1) ? frontA : frontB);
+        if (lane == 0) *s_cnt = 0;
+        __syncthreads();
+        expand_rows(list, count, bits, p.rowptr, p.col, next, s_cnt);
+        __syncthreads();
+        if (last) break;
+        list = next;
+        count = *s_cnt;
+        __syncthreads();
+        if (count == 0) break;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int local_id(const unsigned* S, const unsigned* pref, int b) {
+    const int w = b >> 5;
+    return (int)pref[w] + __popc(S[w] & ((1u << (b & 31)) - 1u));
+}
+
+// Walk the CSR rows of ids[0..n).  WRITE=false: ldeg[k] = induced degree of row k (if ldeg), returns the
+// wave-uniform total.  WRITE=true: row k's entries go to dir/lw starting at lrow[k].
+template <bool WRITE>
+__device__ __forceinline__ int induced_rows(const int* __restrict__ ids, int n, const unsigned* S, const unsigned* pref,
+                                            const TlcVicParams& p, int* ldeg_or_lrow, unsigned* dir, double* lw) {
+    const int lane = tlc_lane();
+    int total = 0;
+    for (int base = 0; base < n; base += TLC_WAVE) {
+        const int k = base + lane;
+        int beg = 0, end = 0, t = 0;
+        if (k < n) {
+            const int a = ids[k];
+            beg = p.rowptr[a];
+            end = p.rowptr[a + 1];
+            if (WRITE) t = ldeg_or_lrow[k];
+        }
+        const bool big = (end - beg) >= 32;
+        int cnt = 0;
+        if (!big) {
+            for (int j = beg; j < end; ++j) {
+                const int b = p.col[j];
+                if (bit_test(S, b)) {
+                    if (WRITE) {
+                        dir[t + cnt] = ((unsigned)k << 16) | (unsigned)local_id(S, pref, b);
+                        lw[t + cnt] = p.w[j];
+                    }
+                    ++cnt;
+                }
+            }
+        }
+        unsigned long long mask = __ballot(big);
+        while (mask) {
+            const int L = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int bb = __shfl(beg, L, 64), ee = __shfl(end, L, 64), tt = __shfl(t, L, 64);
+            const int kk = base + L;
+            int run = 0;
+            for (int j0 = bb; j0 < ee; j0 += TLC_WAVE) {
+                const int j = j0 + lane;
+                int b = -1;
+                bool in = false;
+                if (j < ee) {
+                    b = p.col[j];
+                    in = bit_test(S, b);
+                }
+                const unsigned long long m = __ballot(in);
+                if (WRITE && in) {
+                    const int pos = tt + run + __popcll(m & tlc_lanemask_lt());
+                    dir[pos] = ((unsigned)kk << 16) | (unsigned)local_id(S, pref, b);
+                    lw[pos] = p.w[j];
+                }
+                run += __popcll(m);
+            }
+            if (lane == L) cnt = run;
+        }
+        if (!WRITE) {
+            if (ldeg_or_lrow && k < n) ldeg_or_lrow[k] = cnt;
+            total += tlc_wave_sum_i32(cnt);
+        }
+    }
+    return total;
+}
+
+}  // namespace
+
+template <bool FILL>
+__global__ __launch_bounds__(TLC_WAVE) void tlc_vicinity_kernel(TlcVicParams p) {
+    extern __shared__ unsigned lds[];
+    unsigned* bitsU = lds;
+    unsigned* bitsV = lds + p.nw;   // becomes S
+    unsigned* pref = lds + 2 * p.nw;
+    int* s_cnt = (int*)(lds + 3 * p.nw);
+    const int lane = tlc_lane();
+    int* slot = p.scratch + (size_t)blockIdx.x * p.scratch_stride;
+    int* frontA = slot;
+    int* frontB = slot + p.n_nodes;
+    int* ids = slot + 2 * (size_t)p.n_nodes;     // ascending node ids of S
+    int* lrow = slot + 3 * (size_t)p.n_nodes;    // FILL: induced degree, then row offsets (n+1)
+    const int res2 = p.res * p.res;
+
+    for (;;) {
+        int i = 0;
+        if (lane == 0) i = atomicAdd(p.work_counter, 1);
+        i = __shfl(i, 0, 64);
+        if (i >= p.n_pairs) break;
+        const int u = p.pairs[2 * (size_t)i], v = p.pairs[2 * (size_t)i + 1];
+        if (FILL) {
+            if (p.hdr_n[i] <= 0) continue;    // finished by the COUNT pass
+        } else {
+            // KeyError on dict_node (riccidist2dgm.py:353): ids the edge-built graph does not contain
+            bool missing = u < 0 || v < 0 || u >= p.n_nodes || v >= p.n_nodes;
+            if (!missing) missing = (p.rowptr[u + 1] == p.rowptr[u]) || (p.rowptr[v + 1] == p.rowptr[v]);
+            if (missing) {
+                if (lane == 0) {
+                    p.hdr_n[i] = 0; p.hdr_m2[i] = 0; p.hdr_lu[i] = -1; p.hdr_lv[i] = -1;
+                    if (p.out_status) p.out_status[i] = TLC_ST_MISSING_NODE;
+                    if (p.out_n) p.out_n[i] = 0;
+                }
+                if (p.out_pi) for (int c = lane; c < res2; c += TLC_WAVE) p.out_pi[(size_t)i * res2 + c] = 0.0;
+                continue;
+            }
+        }
+        // ---- the two balls -------------------------------------------------------------------------
+        for (int w = lane; w < 2 * p.nw; w += TLC_WAVE) lds[w] = 0u;
+        __syncthreads();
+        mark_ball(bitsV, v, p.hop, p, frontA, frontB, s_cnt);
+        mark_ball(bitsU, u, p.hop, p, frontA, frontB, s_cnt);
+        if ((p.flags & TLC_INCLUDE_ROOTS) && lane == 0) {   // data_utils_LP.py:111  nodes + [u, v]
+            bitsU[u >> 5] |= 1u << (u & 31); bitsV[u >> 5] |= 1u << (u & 31);
+            bitsU[v >> 5] |= 1u << (v & 31); bitsV[v >> 5] |= 1u << (v & 31);
+        }
+        __syncthreads();
+        // ---- S = ball(u) & ball(v)  (:315), per-word popcount prefix -----------------------------------
+        int carry = 0;
+        for (int base = 0; base < p.nw; base += TLC_WAVE) {
+            const int w = base + lane;
+            unsigned s = 0;
+            if (w < p.nw) {
+                s = bitsU[w] & bitsV[w];
+                bitsV[w] = s;
+            }
+            const int pc = __popc(s);
+            const int inc = tlc_wave_iscan_i32(pc);
+            if (w < p.nw) pref[w] = (unsigned)(carry + inc - pc);
+            carry += __shfl(inc, 63, 64);
+        }
+        const int n = carry;
+        __syncthreads();
+        const unsigned* S = bitsV;
+        if (!FILL) {
+            int lu = -1, lv = -1;
+            if (n > 0) {
+                if (bit_test(S, u)) lu = local_id(S, pref, u);
+                if (bit_test(S, v)) lv = local_id(S, pref, v);
+            }
+            if (n == 0 || n > 65535) {
+                // n == 0: AssertionError, zero connected components (:318).  n > 65535 does not fit the packed
+                // local ids: reported as its own status so that it cannot pass silently.
+                if (lane == 0) {
+                    p.hdr_n[i] = 0; p.hdr_m2[i] = 0; p.hdr_lu[i] = lu; p.hdr_lv[i] = lv;
+                    if (p.out_status) p.out_status[i] = (n == 0) ? TLC_ST_DISCONNECTED : TLC_ST_TOO_LARGE;
+                    if (p.out_n) p.out_n[i] = (n == 0) ? 0 : -n;
+                }
+                if (p.out_pi) for (int c = lane; c < res2; c += TLC_WAVE) p.out_pi[(size_t)i * res2 + c] = 0.0;
+                continue;
+            }
+            if (lane == 0) { p.hdr_lu[i] = lu; p.hdr_lv[i] = lv; }
+        }
+        // ---- ascending id list of S ---------------------------------------------------------------------
+        for (int w = lane; w < p.nw; w += TLC_WAVE) {
+            unsigned s = S[w];
+            int o = (int)pref[w];
+            while (s) {
+                const int b = __builtin_ctz(s);
+                s &= s - 1;
+                ids[o++] = (w << 5) + b;
+            }
+        }
+        __syncthreads();
+        if (FILL && p.out_ids) {
+            const long long no = p.ids_off[i];
+            const long long cap = p.ids_off[i + 1] - no;
+            if (n <= cap) for (int k = lane; k < n; k += TLC_WAVE) p.out_ids[no + k] = ids[k];
+        }
+        // ---- induced subgraph (graph.subgraph(nodes), :316) -------------------------------------------------
+        if (!FILL) {
+            const int m2 = induced_rows<false>(ids, n, S, pref, p, nullptr, nullptr, nullptr);
+            if (lane == 0) { p.hdr_n[i] = n; p.hdr_m2[i] = m2; }
+        } else {
+            induced_rows<false>(ids, n, S, pref, p, lrow, nullptr, nullptr);
+            __syncthreads();
+            int run = 0;
+            for (int base = 0; base < n; base += TLC_WAVE) {
+                const int k = base + lane;
+                const int d = k < n ? lrow[k] : 0;
+                const int inc = tlc_wave_iscan_i32(d);
+                if (k < n) lrow[k] = run + inc - d;
+                run += __shfl(inc, 63, 64);
+            }
+            __syncthreads();
+            const long long eo = p.edge_off[i];
+            induced_rows<true>(ids, n, S, pref, p, lrow, p.A_dir + eo, p.A_lw + eo);
+        }
+        __syncthreads();
+    }
+}
+
+template __global__ void tlc_vicinity_kernel<false>(TlcVicParams);
+template __global__ void tlc_vicinity_kernel<true>(TlcVicParams);
+
+// ---- exclusive scan of the per-pair sizes + tier binning ---------------------------------------------------------
+// Three small kernels (block sums, scan of the block sums, downsweep); n_pairs per chunk is <= 2^20.
+#define SCAN_BLOCK 1024
+
+__global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_block_sums(const int* __restrict__ m2, int n_pairs,
+                                                                  long long* __restrict__ block_sums) {
+    __shared__ long long s[SCAN_BLOCK / TLC_WAVE];
+    const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    long long v = i < n_pairs ? (long long)m2[i] : 0;
+    v = tlc_wave_sum_i64(v);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int k = 0; k < SCAN_BLOCK / TLC_WAVE; ++k) t += s[k];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_top(long long* __restrict__ block_sums, int n_blocks,
+                                                           long long* __restrict__ totals) {
+    // n_blocks <= 1024: one thread per block sum, Hillis-Steele in LDS
+    __shared__ long long s[SCAN_BLOCK];
+    const int t = threadIdx.x;
+    const long long own = t < n_blocks ? block_sums[t] : 0;
+    s[t] = own;
+    __syncthreads();
+    for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
+        const long long a = t >= o ? s[t - o] : 0;
+        __syncthreads();
+        s[t] += a;
+        __syncthreads();
+    }
+    if (t < n_blocks) block_sums[t] = s[t] - own;
+    if (t == SCAN_BLOCK - 1) totals[0] = s[t];
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_down(TlcScanParams p) {
+    __shared__ long long s[SCAN_BLOCK];
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * SCAN_BLOCK + t;
+    const int n = i < p.n_pairs ? p.hdr_n[i] : 0;
+    const long long own = i < p.n_pairs ? (long long)p.hdr_m2[i] : 0;
+    s[t] = own;
+    __syncthreads();
+    for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
+        const long long a = t >= o ? s[t - o] : 0;
+        __syncthreads();
+        s[t] += a;
+        __syncthreads();
+    }
+    if (i < p.n_pairs) {
+        p.edge_off[i] = p.block_sums[blockIdx.x] + s[t] - own;
+        if (n > 0) {
+            const int m = (int)(own >> 1);
+            int tier = TLC_TIER_HUGE;
+            if (n <= TLC_S_NMAX && m <= TLC_S_MMAX) tier = TLC_TIER_SMALL;
+            else if (n <= TLC_M_NMAX && m <= TLC_M_MMAX) tier = TLC_TIER_MEDIUM;
+            else if (n <= TLC_L_NMAX && m <= TLC_L_MMAX) tier = TLC_TIER_LARGE;
+            const int pos = atomicAdd(&p.tier_count[tier], 1);
+            p.tier_list[(size_t)tier * p.n_pairs + pos] = i;
+        }
+    }
+}

@@ -1,0 +1,127 @@
+"""Device-side entry points of the PD/PI path: thin, typed wrappers over the C ABI (include/tlcgnn.h).
+
+Everything here takes/returns torch CUDA tensors (device memory + stream plumbing only) and calls
+libtlcgnn_hip.so through ctypes.  The reference-named drop-ins (sg2dgm/, baselines/, Knowledge_Distillation/)
+are built on these.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KEEP_ZERO_PERS, INCLUDE_ROOTS, NORM_EPS, PI_ORD0_EXT1, NO_EXT1  # noqa: F401
+
+
+class DeviceGraph:
+    """graph2pi.__init__ (sg2dgm/riccidist2dgm.py:216-226): weighted graph resident on one GPU.
+
+    rowptr/col/w: symmetric CSR (numpy), w = kappa + 1 > 0.
+    """
+
+    def __init__(self, rowptr, col, w, device=None):
+        torch = _lib.require_gpu()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        self.n_nodes = len(rowptr) - 1
+        self.nnz = int(rowptr[-1])
+        h = C.c_void_p()
+        rc = _lib.lib().tlc_graph_create(C.c_int32(self.n_nodes), rowptr.ctypes.data_as(C.c_void_p),
+                                         col.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p),
+                                         C.c_int(self.device), C.byref(h))
+        _lib.check(rc, "tlc_graph_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().tlc_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- P2-P9 -------------------------------------------------------------------------------------------
+    def pd_pi_batch(self, pairs, hop, flags=0, res=5, out=None, status=None):
+        """pairs: int32 CUDA tensor [E,2] -> (pi float64[E,res*res], status uint8[E]) on the current stream."""
+        import torch
+        assert pairs.is_cuda and pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2
+        pairs = pairs.contiguous()
+        E = pairs.shape[0]
+        if out is None:
+            out = torch.empty((E, res * res), dtype=torch.float64, device=pairs.device)
+        if status is None:
+            status = torch.empty((E,), dtype=torch.uint8, device=pairs.device)
+        rc = _lib.lib().tlc_pd_pi_batch(self._h, _lib.ptr(pairs), C.c_int64(E), C.c_int(hop), C.c_uint32(flags),
+                                        C.c_int(res), _lib.ptr(out), _lib.ptr(status), _lib.stream_ptr())
+        _lib.check(rc, "tlc_pd_pi_batch")
+        return out, status
+
+    def stats(self):
+        out = (C.c_int64 * 8)()
+        rc = _lib.lib().tlc_pd_pi_batch_stats(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr())
+        _lib.check(rc, "tlc_pd_pi_batch_stats")
+        v = list(out)
+        return {"tier_small": v[0], "tier_medium": v[1], "tier_large": v[2], "tier_huge": v[3],
+                "induced_entries": v[4], "tie_fallback_sources": v[5], "chunks": v[6]}
+
+    def vicinity_filtration(self, pairs, hop, flags=0, cap=None):
+        """-> (node_offs int64[E+1], ids int32[E*cap], f float64[E*cap], n int32[E], status uint8[E])"""
+        import torch
+        pairs = pairs.contiguous()
+        E = pairs.shape[0]
+        cap = self.n_nodes if cap is None else int(cap)
+        dev = pairs.device
+        offs = torch.arange(E + 1, dtype=torch.int64, device=dev) * cap
+        ids = torch.zeros(max(E * cap, 1), dtype=torch.int32, device=dev)
+        f = torch.zeros(max(E * cap, 1), dtype=torch.float64, device=dev)
+        n = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
+        st = torch.zeros(max(E, 1), dtype=torch.uint8, device=dev)
+        rc = _lib.lib().tlc_vicinity_filtration(self._h, _lib.ptr(pairs), C.c_int64(E), C.c_int(hop), C.c_uint32(flags),
+                                                _lib.ptr(offs), _lib.ptr(ids), _lib.ptr(f), _lib.ptr(n), _lib.ptr(st),
+                                                _lib.stream_ptr())
+        _lib.check(rc, "tlc_vicinity_filtration")
+        return offs, ids, f, n[:E], st[:E]
+
+
+def pd_from_filtration(node_offs, edge_offs, edges, f, flags=0, want_rank=True):
+    """Batched perturb_filter_function + Union_find + Accelerate_PD (sg2dgm/accelerated_PD.py:6-178).
+
+    All arguments CUDA tensors: node_offs/edge_offs int64[B+1], edges int32[sum m,2], f float64[sum n].
+    Returns dict(up, down, one, ext0, counts, edge_rank) of CUDA tensors (layout: include/tlcgnn.h).
+    """
+    torch = _lib.require_gpu()
+    dev = f.device
+    B = node_offs.numel() - 1
+    sn, sm = int(f.numel()), int(edges.shape[0])
+    up = torch.zeros((max(sn, 1), 2), dtype=torch.float64, device=dev)
+    down = torch.zeros((max(sn, 1), 2), dtype=torch.float64, device=dev)
+    one = torch.zeros((max(sm, 1), 2), dtype=torch.float64, device=dev)
+    ext0 = torch.zeros((max(B, 1), 2), dtype=torch.float64, device=dev)
+    counts = torch.zeros((max(B, 1), 4), dtype=torch.int32, device=dev)
+    rank = torch.zeros(max(sm, 1), dtype=torch.int32, device=dev) if want_rank else None
+    edges = edges.contiguous()
+    rc = _lib.lib().tlc_pd_from_filtration(C.c_int32(B), _lib.ptr(node_offs.contiguous()), _lib.ptr(edge_offs.contiguous()),
+                                           _lib.ptr(edges), _lib.ptr(f.contiguous()), C.c_uint32(flags), _lib.ptr(up),
+                                           _lib.ptr(down), _lib.ptr(one), _lib.ptr(ext0), _lib.ptr(counts),
+                                           _lib.ptr(rank), _lib.stream_ptr())
+    _lib.check(rc, "tlc_pd_from_filtration")
+    return dict(up=up, down=down, one=one, ext0=ext0[:B], counts=counts[:B], edge_rank=None if rank is None else rank[:sm])
+
+
+def pi_raster(offs, pts, res=5):
+    """Batched PersistenceImager(resolution=res).transform (sg2dgm/PersistenceImager.pyx:352-388).
+
+    offs int64[B+1], pts float64[sum k, 2] (birth, death) CUDA tensors -> float64[B, res*res].
+    """
+    torch = _lib.require_gpu()
+    B = offs.numel() - 1
+    out = torch.empty((max(B, 1), res * res), dtype=torch.float64, device=offs.device)
+    pts = pts.contiguous()
+    rc = _lib.lib().tlc_pi_raster(C.c_int32(B), _lib.ptr(offs.contiguous()), _lib.ptr(pts) if pts.numel() else None,
+                                  C.c_int(res), _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "tlc_pi_raster")
+    return out[:B]
