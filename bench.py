@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- persistence-images/sec + LP-forward edges/sec on the PubMed-shaped synthetic graph (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W            (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (N>1)
+
+One "step" = one pass of the hot path over one batch per GPU:
+  leg 1  PD/PI : all 37 676 train-positive pairs (hop 2) -> 5x5 persistence images        (tlc_pd_pi_batch)
+  leg 2  LP fwd: TLCGNN encode (2-layer GCN) + fused decode over 2*37 676 = 75 352 pairs, image rows resident in HBM
+Inputs are resident in HBM before the timed region.  Weak scaling: every rank owns a full batch (its own permutation of
+the training pairs, the small CSR replicated, no data-path collective for leg 1; the encoder of leg 2 is node-row
+sharded with one RCCL all-gather per layer).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def build_workload(rank, seed=1234):
+    """PubMed-shaped graph, the reference's split of the positives (loaddatas.py:38-53: same RNG stream up to the
+    shuffle of the positives), training graph = graph minus val/test positives (TLCGNN.py:88-100)."""
+    from tlc_gnn_amd import synth
+    n, edges, kappa, hop, n_feat = synth.shaped_graph("PubMed", seed=seed)
+    np.random.seed(seed)
+    order = np.lexsort((edges[:, 1], edges[:, 0]))          # sp.triu(adj).nonzero(): row-major order of (x, y), x < y
+    pos = edges[order].copy()
+    np.random.shuffle(pos)
+    m_pos = len(pos)
+    n_val, n_test = int(m_pos * 0.05), int(m_pos * 0.1)
+    train = pos[n_val + n_test:]
+    # training graph: curvature is an input of the path; seeded stand-in on the surviving edges
+    key = {(int(a), int(b)): float(k) for (a, b), k in zip(edges.tolist(), kappa.tolist())}
+    tr_sorted = train[np.lexsort((train[:, 1], train[:, 0]))]
+    tr_kappa = np.array([key[(int(a), int(b))] for a, b in tr_sorted.tolist()])
+    rowptr, col, w = synth.edges_to_csr(n, tr_sorted, tr_kappa)
+    rs = np.random.RandomState(seed + 1000 * rank)
+    pi_pairs = train.copy()
+    if rank > 0:                                             # weak scaling: same work, different order/orientation
+        pi_pairs = pi_pairs[rs.permutation(len(pi_pairs))]
+        pi_pairs = pi_pairs[:, ::-1] if rank % 2 else pi_pairs
+    # negatives for the decode: uniformly sampled non-adjacent pairs, as many as positives (TLCGNN.py:29-32)
+    adj = set(map(tuple, tr_sorted.tolist()))
+    neg = []
+    while len(neg) < len(train):
+        a, b = rs.randint(0, n, size=2 * len(train)), rs.randint(0, n, size=2 * len(train))
+        for x, y in zip(a.tolist(), b.tolist()):
+            if x != y and (min(x, y), max(x, y)) not in adj:
+                neg.append((x, y))
+                if len(neg) == len(train):
+                    break
+    neg = np.array(neg, dtype=np.int64)
+    x = synth.synthetic_features(n, n_feat, seed=seed)
+    return dict(n=n, hop=hop, n_feat=n_feat, rowptr=rowptr, col=col, w=w, train_edges=tr_sorted,
+                pi_pairs=np.ascontiguousarray(pi_pairs, dtype=np.int32), neg=neg, x=x)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from tlc_gnn_amd import engine, ops, dist as tdist, _lib
+    from tlc_gnn_amd.baselines import TLCGNN
+
+    rank, local_rank, world = tdist.env_world()
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    wl = build_workload(rank)
+    n, hop = wl["n"], wl["hop"]
+    g = engine.DeviceGraph(wl["rowptr"], wl["col"], wl["w"], device=local_rank)
+    pi_pairs = torch.from_numpy(wl["pi_pairs"]).to(dev)
+    E = pi_pairs.shape[0]
+    pi_out = torch.empty((E, 25), dtype=torch.float64, device=dev)
+    pi_status = torch.empty(E, dtype=torch.uint8, device=dev)
+
+    # ---- LP leg setup: model, graph operator, decode tables (all resident before the timed region) ---------------------
+    torch.manual_seed(1234)
+    model = TLCGNN.Net(None, wl["n_feat"], 2, PI=None)
+    for mod in (model.linear, model.linear_1):                       # weights_init of pipelines.py:42-46 (xavier on Linear)
+        torch.nn.init.xavier_uniform_(mod.weight)
+        torch.nn.init.zeros_(mod.bias)
+    model = model.to(dev).eval()
+    te = wl["train_edges"]
+    edge_index = torch.from_numpy(np.concatenate([te, te[:, ::-1]]).T.copy()).long().to(dev)
+    rowptr_n, col_n, val_n = ops.gcn_norm_csr(edge_index, n)          # cached=True: one-off
+    enc = tdist.ShardedGCNEncoder(rowptr_n, col_n, val_n, n, world, rank,
+                                  gemm=lambda a, b: ops.gemm(a, b),
+                                  spmm=lambda rp, c, v, xx, bias, relu: ops.spmm(rp, c, v, xx, bias=bias, relu=relu))
+    x_local = torch.from_numpy(wl["x"][enc.lo:enc.hi]).to(dev).contiguous()
+    dec_pairs_np = np.concatenate([wl["pi_pairs"].astype(np.int64), wl["neg"]]).astype(np.int32)
+    dec_pairs = torch.from_numpy(dec_pairs_np).to(dev)
+    dec_pi, _ = g.pd_pi_batch(dec_pairs, hop)                         # image rows of the decode batch: resident
+    w1, b1 = model.conv1.weight.detach(), model.conv1.bias.detach()
+    w2, b2 = model.conv2.weight.detach(), model.conv2.bias.detach()
+    l1w, l1b = model.linear_1.weight.detach(), model.linear_1.bias.detach()
+    l2w, l2b = model.linear.weight.detach(), model.linear.bias.detach()
+    prob = torch.empty(dec_pairs.shape[0], dtype=torch.float32, device=dev)
+
+    def leg_pi():
+        g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)
+
+    def leg_lp():
+        emb = enc.encode(x_local, w1, b1, w2, b2)
+        ops.renorm_rows_(emb)
+        ops.lp_decode(dec_pairs, emb, dec_pi, l1w, l1b, l2w, l2b, out=prob)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        leg_pi()
+        leg_lp()
+    g.set_timing(True)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    ktimes = {k: [] for k in engine.DeviceGraph.KERNELS}
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record()
+        leg_pi()
+        ev[s][1].record()
+        leg_lp()
+        ev[s][2].record()
+        for k, v in g.timings().items():          # HIP events on the streams the kernels ran on (synchronises: part of the step)
+            ktimes[k].append(v)
+    barrier()
+    wall = time.perf_counter() - t0
+    t_pi = sum(ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)) * 1e-3
+    t_lp = sum(ev[s][1].elapsed_time(ev[s][2]) for s in range(args.steps)) * 1e-3
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([wall, t_pi, t_lp], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, t_pi, t_lp = [float(v) for v in t.tolist()]
+
+    if rank == 0:
+        stats = g.stats()
+        n_sz, m2_sz = g.sizes(E)
+        tiers = engine.tier_of(n_sz, m2_sz)
+        bytes_pp = engine.algorithmic_bytes(wl["rowptr"], wl["col"], wl["pi_pairs"], hop)
+        kavg = {k: float(np.mean([x for x in v if x >= 0])) if any(x >= 0 for x in v) else -1.0 for k, v in ktimes.items()}
+        dom = max(kavg, key=lambda k: kavg[k])
+        if dom.startswith("pd_tier"):
+            dom_bytes = float(bytes_pp[tiers == dom].sum())
+            dom_units = int((tiers == dom).sum())
+        else:
+            dom_bytes, dom_units = float(bytes_pp.sum()), E
+        achieved = dom_bytes / (kavg[dom] * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "persistence-images/sec + LP-forward edges/sec, PubMed-scale, 1/2/4/8 GPU",
+            "value": world * E * args.steps / t_pi,
+            "unit": "persistence-images/sec",
+            "lp_forward_edges_per_sec": world * dec_pairs.shape[0] * args.steps / t_lp,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "pi_ms_per_step": t_pi / args.steps * 1e3, "lp_ms_per_step": t_lp / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "PubMed-shaped synthetic graph (N=19717, M=44324, F=500, seed 1234), hop=2; per GPU: "
+                                   "PI-A = all %d train-positive pairs -> 5x5 persistence images, then TLCGNN forward "
+                                   "(GCN 500->100->16 encode + fused decode of %d pairs, image rows resident)" % (E, dec_pairs.shape[0]),
+                       "pairs_per_gpu": E, "decode_pairs_per_gpu": int(dec_pairs.shape[0]),
+                       "parallelism": "pair shards per GPU (no collective); encoder node-row sharded, 1 all-gather per layer",
+                       "vicinity_tiers": {k: int(v) for k, v in stats.items() if k.startswith("tier")},
+                       "tie_fallback_sources": int(stats["tie_fallback_sources"])},
+            "roofline": {"bound": "hbm", "kernel": dom, "kernel_ms": kavg[dom], "units_per_launch": dom_units,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic},
+            "roofline_chain": {"bound": "hbm", "algorithmic_bytes_per_pi": float(bytes_pp.mean()),
+                               "achieved": float(bytes_pp.sum()) * world * args.steps / t_pi / 1e9, "peak": HBM_PEAK_GBS * world,
+                               "unit": "GB/s", "frac": float(bytes_pp.sum()) * args.steps / t_pi / 1e9 / HBM_PEAK_GBS},
+            "kernel_ms": kavg,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # the CPU restatement (oracle/tlc_oracle.c, a port of the reference's algorithm) on this box's host cores,
+            # same batch, bounded sample.  A reported baseline, not a target.
+            from oracle import oracle
+            sample = wl["pi_pairs"][: min(E, 20000)]
+            oracle.pd_pi_batch(wl["rowptr"], wl["col"], wl["w"], sample[:256], hop, n_threads=0)    # warm up / build
+            c0 = time.perf_counter()
+            ref, rst, used = oracle.pd_pi_batch(wl["rowptr"], wl["col"], wl["w"], sample, hop, n_threads=0)
+            cdt = time.perf_counter() - c0
+            out["cpu_baseline"] = {"value": len(sample) / cdt, "unit": "persistence-images/sec", "cores": int(used),
+                                   "kind": "port", "sample": "first %d pairs of the same PI-A batch, OpenMP over pairs, "
+                                   "%.2f s wall" % (len(sample), cdt)}
+            got = pi_out[: len(sample)].cpu().numpy()
+            nz = ref != 0
+            out["cpu_baseline"]["max_rel_diff_vs_gpu"] = float((np.abs(got[nz] - ref[nz]) / np.abs(ref[nz])).max()) if nz.any() else 0.0
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

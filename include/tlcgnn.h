@@ -89,9 +89,21 @@ int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int64_t n_pair
                             int32_t* d_out_n, uint8_t* d_out_status, void* stream);
 
 /* Counters of the last tlc_pd_pi_batch on this handle (synchronises the stream):
- * h_out[0..7] = pairs in tier small / medium / large, rows non-zero, sum |S|, sum induced edges,
- *               sources that needed the exact tie fallback, reserved. */
+ * h_out[0..3] = pairs in tier small / medium / large / huge, [4] = induced directed entries (arena size),
+ * [5] = sources that needed the exact tie fallback, [6] = chunks, [7] reserved. */
 int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream);
+
+/* Measurement helpers used by bench.py (no reference counterpart: the reference only prints time.time() deltas,
+ * riccidist2dgm.py:349-350).  set_timing(1) makes every later tlc_pd_pi_batch bracket each of its kernels with HIP
+ * events on the stream that kernel runs on; timings() returns the last chunk's durations in ms:
+ * h_ms[0..6] = COUNT, scan+binning, FILL, PD tier SMALL, MEDIUM, LARGE, HUGE (-1 = not launched).  Synchronises.
+ * sizes(): per pair of the last chunk, |S| and the induced directed entry count.
+ * algorithmic_bytes(): SURVEY.md 8(d) per-pair byte model, evaluated on the HOST CSR (pure accounting). */
+int tlc_pd_pi_batch_set_timing(tlc_graph* g, int enable);
+int tlc_pd_pi_batch_timings(tlc_graph* g, double* h_ms, void* stream);
+int tlc_pd_pi_batch_sizes(tlc_graph* g, int32_t* h_n, int32_t* h_m2, int64_t cap, void* stream);
+int tlc_pd_pi_algorithmic_bytes(int32_t n_nodes, const int32_t* h_rowptr, const int32_t* h_col, const int32_t* h_pairs,
+                                int64_t n_pairs, int hop, int res, double* h_out_bytes);
 
 /* ---- P6-P8: perturb_filter_function / Union_find / Accelerate_PD ---------------------------------
  * (sg2dgm/accelerated_PD.py:6-178 and the Knowledge_Distillation fork, selected by TLC_KEEP_ZERO_PERS)
@@ -157,11 +169,13 @@ int tlc_lp_decode_fused(int64_t n_pairs, const int32_t* d_pairs, const float* d_
  *   x_l = X @ Wl^T (no bias);  alpha = x_l . att;  per edge j->i: a = softmax_i(leaky_relu(alpha_j+alpha_i)),
  *   m = leaky_relu(Wij @ [x_i || x_j]) * a;  out_i = [ sum m || (min m + max m) ] + bias  (:166-172,202-216)
  *   d_X float32[n, c_in]; d_Wl float32[c_out, c_in]; d_att float32[c_out]; d_Wij float32[c_out, 2*c_out];
- *   d_bias float32[2*c_out]; d_out float32[n, 2*c_out]; prelu_slope < 0 disables the fused PReLU. */
+ *   d_bias float32[2*c_out]; d_out float32[n, 2*c_out]; prelu_slope < 0 disables the fused PReLU.
+ *   d_work float32[n * (3*c_out + 1)]: caller-provided scratch (per node: x_l, the two lin_ij half-projections, alpha).
+ *   c_out in {8,16,32,64}. */
 int tlc_gat_layer_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_src,
                       const float* d_X, int32_t c_in, int32_t c_out,
                       const float* d_Wl, const float* d_att, const float* d_Wij, const float* d_bias,
-                      float prelu_slope, float* d_out, void* stream);
+                      float prelu_slope, float* d_work, float* d_out, void* stream);
 
 /* Edge head of Teacher_Model.forward (Teacher_model.py:54-59): for every non-self-loop edge e=(s,t):
  *   pd[e] = W6 @ prelu(W5 @ [x[s] || x[t]] + b5) + b6   -> float32[n_edges,2] */

@@ -1,0 +1,138 @@
+"""GPU: TLCGNN link-prediction forward (HIP, through the C ABI / the drop-in classes) against the pure-torch fp32
+restatement of oracle/lp_forward_ref.py.  Tolerance: 1e-5 relative (north_star), with an absolute floor of 1e-6."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import torch
+    assert torch.cuda.is_available()
+    from tlc_gnn_amd import synth
+    n, m, F_ = 1500, 5200, 233
+    edges = synth.holme_kim_edges(n, m, triad_p=0.4, seed=3)
+    x = torch.from_numpy(synth.synthetic_features(n, F_, seed=3))
+    ei = torch.from_numpy(np.concatenate([edges, edges[:, ::-1]]).T.copy()).long()
+    # a few self loops and a duplicate edge: gcn_norm must treat them like add_remaining_self_loops does
+    ei = torch.cat([ei, torch.tensor([[5, 9, 9], [5, 9, 9]]), ei[:, :3]], dim=1)
+    return torch, n, F_, x, ei
+
+
+def _close(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs()
+    return bool((err <= ATOL + RTOL * b.abs()).all()), float((err / (b.abs() + ATOL)).max())
+
+
+def test_gcn_norm_csr(setup):
+    torch, n, F_, x, ei = setup
+    from tlc_gnn_amd import ops
+    from oracle import lp_forward_ref as ref
+    rowptr, col, val = ops.gcn_norm_csr(ei.cuda(), n)
+    rei, norm = ref.gcn_norm(ei, n)
+    dense_ref = torch.zeros(n, n, dtype=torch.float64)
+    dense_ref.index_put_((rei[1], rei[0]), norm.double(), accumulate=True)
+    rp, c, v = rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().double().numpy()
+    dense = np.zeros((n, n))
+    for i in range(n):
+        assert np.all(np.diff(c[rp[i]:rp[i + 1]]) >= 0)         # sources ascending inside a row
+        np.add.at(dense[i], c[rp[i]:rp[i + 1]], v[rp[i]:rp[i + 1]])
+    assert np.abs(dense - dense_ref.numpy()).max() < 1e-6
+    assert len(c) == rei.shape[1]
+
+
+@pytest.mark.parametrize("shape", [(1500, 233, 100), (1500, 100, 16), (77, 5, 3), (130, 64, 128), (1, 1, 1)])
+def test_gemm_f32_mfma(setup, shape):
+    torch = setup[0]
+    from tlc_gnn_amd import ops
+    M, K, N = shape
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    out = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), relu=True)
+    ref = torch.relu(a.double() @ b.double() + bias.double())
+    err = (out.cpu().double() - ref).abs().max().item()
+    scale = (a.abs().double() @ b.abs().double()).max().item()
+    assert err <= 1e-6 * scale + 1e-6          # fp32 fma chain: ~1e-7 * sum|a b| (guide, FP32-input MFMA numerics)
+    # asymmetric check of the C layout: A = I picks rows of B
+    eye = torch.eye(K)
+    out = ops.gemm(eye.cuda(), b.cuda())
+    assert torch.equal(out.cpu(), b)
+
+
+def test_encode_decode_vs_torch_reference(setup):
+    torch, n, F_, x, ei = setup
+    from tlc_gnn_amd.baselines import TLCGNN
+    from tlc_gnn_amd.data import Data
+    from oracle import lp_forward_ref as ref
+    torch.manual_seed(1234)
+    E = 4000
+    rs = np.random.RandomState(5)
+    pairs = rs.randint(0, n, size=(E, 2))
+    PI = rs.uniform(0, 0.3, size=(E, 25))
+    PI[::7] = 0.0
+    data = Data(x=x.clone(), edge_index=ei.clone(), y=torch.zeros(n), total_edges=pairs,
+                total_edges_y=torch.from_numpy((rs.rand(E) < 0.5).astype(np.int64)),
+                train_pos=1000, train_neg=1500, val_pos=300, val_neg=300, test_pos=450, test_neg=450)
+    model = TLCGNN.Net(data, F_, 2, PI=PI)
+    with torch.no_grad():
+        model.conv1.bias.uniform_(-0.1, 0.1)      # reference init is zeros; exercise the bias path
+        model.conv2.bias.uniform_(-0.1, 0.1)
+        model.conv2.weight.mul_(3.0)              # push some embedding rows over norm 1 so that renorm acts
+    model = model.cuda().eval()
+    data = data.to("cuda")
+    with torch.no_grad():
+        emb = model.encode(data)
+    w1, b1 = model.conv1.weight.detach().cpu(), model.conv1.bias.detach().cpu()
+    w2, b2 = model.conv2.weight.detach().cpu(), model.conv2.bias.detach().cpu()
+    emb_ref = ref.tlcgnn_encode(x, ei, w1, b1, w2, b2)
+    ok, worst = _close(emb, emb_ref)
+    assert ok, worst
+    assert (emb_ref.norm(dim=1) > 1).any() and (emb_ref.norm(dim=1) < 1).any()
+    for typ, sl in (("val", slice(2500, 3100)), ("test", slice(3100, None))):
+        emb_in = emb.clone()
+        prob, y = model.decode(data, emb_in, typ)
+        emb_r = emb_ref.clone()
+        prob_ref = ref.tlcgnn_decode(emb_r, torch.from_numpy(pairs[sl]), torch.from_numpy(PI[sl]),
+                                     model.linear_1.weight.detach().cpu(), model.linear_1.bias.detach().cpu(),
+                                     model.linear.weight.detach().cpu(), model.linear.bias.detach().cpu())
+        ok, worst = _close(prob, prob_ref)
+        assert ok, (typ, worst)
+        ok, worst = _close(emb_in, emb_r)              # renorm_ acted in place, like the reference
+        assert ok, worst
+        assert torch.equal(y.cpu(), data.total_edges_y[sl].float().cpu())
+    # train: same RNG stream as the reference's np.random.randint
+    np.random.seed(77)
+    prob, y = model.decode(data, emb.clone(), "train")
+    np.random.seed(77)
+    index = np.random.randint(0, 1500, 1000)
+    sel = np.concatenate([np.arange(1000), 1000 + index])
+    prob_ref = ref.tlcgnn_decode(emb_ref.clone(), torch.from_numpy(pairs[sel]), torch.from_numpy(PI[sel]),
+                                 model.linear_1.weight.detach().cpu(), model.linear_1.bias.detach().cpu(),
+                                 model.linear.weight.detach().cpu(), model.linear.bias.detach().cpu())
+    ok, worst = _close(prob, prob_ref)
+    assert ok, worst
+    assert prob.shape[0] == 2000 and y.shape[0] == 2000
+
+
+def test_decode_generic_dims(setup):
+    torch = setup[0]
+    from tlc_gnn_amd import ops
+    from oracle import lp_forward_ref as ref
+    g = torch.Generator().manual_seed(0)
+    n, D, P, E = 50, 8, 9, 333
+    emb = torch.randn(n, D, generator=g) * 0.3
+    pairs = torch.randint(0, n, (E, 2), generator=g)
+    pi = torch.rand(E, P, generator=g, dtype=torch.float64)
+    w1, b1 = torch.randn(P, D + P, generator=g) * 0.3, torch.randn(P, generator=g) * 0.1
+    w2, b2 = torch.randn(1, P, generator=g) * 0.3, torch.randn(1, generator=g) * 0.1
+    emb_d = ops.renorm_rows_(emb.cuda())
+    out = ops.lp_decode(pairs.int().cuda(), emb_d, pi.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+    r = ref.tlcgnn_decode(emb.clone(), pairs, pi, w1, b1, w2, b2)
+    ok, worst = _close(out, r)
+    assert ok, worst

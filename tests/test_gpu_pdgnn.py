@@ -1,0 +1,87 @@
+"""GPU: PDGNN layer / teacher forward (HIP) against the pure-torch restatement (oracle/lp_forward_ref.py)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL, ATOL = 1e-5, 2e-6
+
+
+def _close(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs()
+    return bool((err <= ATOL + RTOL * b.abs()).all()), float((err / (b.abs() + ATOL)).max())
+
+
+def _batch_from_golden(torch, n_graphs=40):
+    d = np.load(os.path.join(G, "kd_gc.npz"))
+    xs, eis, gptr, eptr = [], [], [0], [0]
+    for g in range(n_graphs):
+        no, eo = d["f_offs"][g], d["e_offs"][g]
+        n = int(d["n"][g])
+        e = d["edges"][eo:d["e_offs"][g + 1]]
+        both = np.concatenate([e, e[:, ::-1]])                        # both directions, as PyG stores undirected graphs
+        eis.append(both + gptr[-1])
+        xs.append(d["f"][no:no + n])
+        gptr.append(gptr[-1] + n)
+        eptr.append(eptr[-1] + len(both))
+    x = torch.tensor(np.concatenate(xs), dtype=torch.float32).view(-1, 1)
+    ei = torch.tensor(np.concatenate(eis).T.copy(), dtype=torch.int64)
+    n = x.shape[0]
+    loops = torch.arange(n, dtype=torch.int64)
+    ei_full = torch.cat([ei, torch.stack([loops, loops])], dim=1)     # add_self_loops at the end (train_Teacher_Model.py:43-44)
+    return x, ei_full, torch.tensor(gptr), torch.tensor(eptr)
+
+
+def test_gat_layer_and_teacher_forward():
+    import torch
+    from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
+    from oracle import lp_forward_ref as ref
+    from oracle import oracle
+    torch.manual_seed(7)
+    x, ei, gptr, eptr = _batch_from_golden(torch)
+    model = Teacher_Model(type='GAT').eval()
+    with torch.no_grad():
+        for conv in (model.DIM0_Model.conv1, model.DIM0_Model.conv2, model.DIM0_Model.conv3, model.DIM0_Model.conv4):
+            conv.bias.uniform_(-0.2, 0.2)
+            torch.nn.init.xavier_uniform_(conv.lin_ij.weight)
+    params = {"prelu": torch.tensor(0.1)}
+    for name in ("conv1", "conv2", "conv3", "conv4"):
+        c = getattr(model.DIM0_Model, name)
+        params[name] = {"lin_l": c.lin_l.weight.detach().clone(), "att_l": c.att_l.detach().reshape(-1).clone(),
+                        "lin_ij": c.lin_ij.weight.detach().clone(), "bias": c.bias.detach().clone()}
+    params.update(lin5_w=model.lin5.weight.detach().clone(), lin5_b=model.lin5.bias.detach().clone(),
+                  lin6_w=model.lin6.weight.detach().clone(), lin6_b=model.lin6.bias.detach().clone())
+    # single layer
+    from tlc_gnn_amd import ops
+    model = model.cuda()
+    xc, eic = x.cuda(), ei.cuda()
+    c1 = model.DIM0_Model.conv1
+    with torch.no_grad():
+        out1 = c1(xc, eic)
+    p = params["conv1"]
+    r1 = ref.gat_conv(x, ei, p["lin_l"], p["att_l"], p["lin_ij"], p["bias"])
+    ok, worst = _close(out1, r1)
+    assert ok, worst
+    # whole teacher forward, batched block-diagonally (H4: evaluate_time loops graph by graph in the reference)
+    with torch.no_grad():
+        pd_hat, img, *_ = model(xc, eic, None, compute_loss=False, grad_PI=False, graph_ptr=gptr.cuda(), edge_ptr=eptr.cuda())
+    xr, pd_ref = ref.teacher_forward(x, ei, params)
+    ok, worst = _close(pd_hat, pd_ref)
+    assert ok, worst
+    # image per graph == CPU raster of the reference-restated diagram (fp32 points cast to fp64)
+    ref_img = oracle.pi_raster(eptr.numpy(), pd_ref.double().numpy(), 5)
+    got = img.cpu().numpy()
+    assert np.abs(got - ref_img).max() <= 1e-5 * max(1.0, np.abs(ref_img).max())
+    # unbatched call == the reference's per-graph call (one image for the whole input)
+    with torch.no_grad():
+        g0 = slice(int(gptr[0]), int(gptr[1]))
+        m0 = int(eptr[1])
+        n0 = int(gptr[1])
+        ei0 = torch.cat([ei[:, :m0], torch.stack([torch.arange(n0), torch.arange(n0)])], dim=1)
+        pd0, img0, *_ = model(x[g0].cuda(), ei0.cuda(), None, compute_loss=False, grad_PI=False)
+    ok, worst = _close(pd0, pd_ref[:m0])
+    assert ok, worst
+    assert img0.shape == (25,)

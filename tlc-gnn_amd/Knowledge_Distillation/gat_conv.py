@@ -1,0 +1,70 @@
+"""Drop-in for the reference's Knowledge_Distillation/gat_conv.py ("the PDGNN layer", README.md:70), forward only.
+
+  GATConv.__init__ :62-104, forward :113-181, message :183-200, aggregate :202-216.
+
+Tensor input, heads=1, new_node_feat=True, use_edge_attn=True, add_self_loops=True (what Teacher_model.py:182-189 builds)
+run as two HIP kernels behind `tlc_gat_layer_fwd` (include/tlcgnn.h); other configurations raise.
+"""
+import math
+
+import torch
+from torch.nn import Linear, Parameter
+
+from .. import ops
+
+
+def glorot(tensor):
+    if tensor is not None:
+        stdv = math.sqrt(6.0 / (tensor.size(-2) + tensor.size(-1)))
+        tensor.data.uniform_(-stdv, stdv)
+
+
+class GATConv(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, double_input=False, new_node_feat=True, use_edge_attn=True, heads=1,
+                 concat=True, negative_slope=0.2, dropout=0., add_self_loops=True, bias=True, **kwargs):
+        super(GATConv, self).__init__()
+        if not isinstance(in_channels, int) or heads != 1 or not new_node_feat or not use_edge_attn or not add_self_loops \
+                or not bias or abs(negative_slope - 0.2) > 1e-12:
+            raise NotImplementedError("GATConv (HIP): only the PDGNN configuration is implemented: int in_channels, heads=1, "
+                                      "new_node_feat, use_edge_attn, add_self_loops, bias, negative_slope=0.2")
+        if concat:
+            # the reference's concat=True path views [N,1,2C] as [-1, C] and then adds a 2C bias (:166-172): a shape error
+            raise NotImplementedError("GATConv (HIP): concat=True is not usable in the reference either; use concat=False")
+        self.in_channels, self.out_channels, self.heads, self.concat = in_channels, out_channels, heads, concat
+        self.negative_slope, self.dropout, self.add_self_loops = negative_slope, dropout, add_self_loops
+        self.new_node_feat, self.use_edge_attn = new_node_feat, use_edge_attn
+        self.lin_ij = Linear(2 * out_channels, out_channels, bias=False)                        # :80-81
+        self.lin_l = Linear((2 if double_input else 1) * in_channels, heads * out_channels, bias=False)   # :83-86
+        self.lin_r = self.lin_l
+        self.att_l = Parameter(torch.Tensor(1, heads, out_channels))
+        self.att_r = Parameter(torch.Tensor(1, heads, out_channels))                            # unused on the tensor path (:135-136)
+        self.bias = Parameter(torch.Tensor(2 * out_channels))                                   # :99-101
+        self._csr_key, self._csr = None, None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot(self.lin_l.weight)
+        glorot(self.att_l)
+        glorot(self.att_r)
+        self.bias.data.zero_()
+
+    def _csr_by_target(self, edge_index, n):
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), n)
+        if self._csr_key != key:
+            # remove_self_loops + add_self_loops (:146-152) and grouping by target == the structure gcn_norm builds
+            rowptr, col, _ = ops.gcn_norm_csr(edge_index, n)
+            self._csr_key, self._csr = key, (rowptr, col)
+        return self._csr
+
+    def forward(self, x, edge_index, size=None, return_attention_weights=None, prelu_slope=-1.0, csr=None):
+        if not isinstance(x, torch.Tensor) or size is not None or return_attention_weights is not None:
+            raise NotImplementedError("GATConv (HIP): tensor input, size=None, return_attention_weights=None only")
+        assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("GATConv (HIP): attention dropout in training mode is not implemented (forward/eval only)")
+        rowptr, col = csr if csr is not None else self._csr_by_target(edge_index, x.shape[0])
+        return ops.gat_layer(rowptr, col, x, self.lin_l.weight.detach(), self.att_l.detach().reshape(-1),
+                             self.lin_ij.weight.detach(), self.bias.detach(), prelu_slope=prelu_slope)
+
+    def __repr__(self):
+        return '{}({}, {}, heads={})'.format(self.__class__.__name__, self.in_channels, self.out_channels, self.heads)

@@ -22,7 +22,8 @@ KEEP_ZERO_PERS, INCLUDE_ROOTS, NORM_EPS, PI_ORD0_EXT1, NO_EXT1 = 0x1, 0x2, 0x4, 
 # every symbol include/tlcgnn.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "tlc_version", "tlc_last_error", "tlc_device_count", "tlc_graph_create", "tlc_graph_destroy",
-    "tlc_pd_pi_batch", "tlc_vicinity_filtration", "tlc_pd_pi_batch_stats", "tlc_pd_from_filtration",
+    "tlc_pd_pi_batch", "tlc_vicinity_filtration", "tlc_pd_pi_batch_stats", "tlc_pd_pi_batch_set_timing",
+    "tlc_pd_pi_batch_timings", "tlc_pd_pi_batch_sizes", "tlc_pd_pi_algorithmic_bytes", "tlc_pd_from_filtration",
     "tlc_pi_raster", "tlc_gcn_norm_csr", "tlc_gemm_f32", "tlc_spmm_csr_f32", "tlc_renorm_rows_f32",
     "tlc_lp_decode_fused", "tlc_gat_layer_fwd", "tlc_edge_head_fwd",
 ]
@@ -63,6 +64,10 @@ def lib():
         L.tlc_vicinity_filtration.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.tlc_pd_pi_batch_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tlc_pd_pi_batch_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.tlc_pd_pi_batch_timings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tlc_pd_pi_batch_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.tlc_pd_pi_algorithmic_bytes.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         L.tlc_pd_from_filtration.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 7
         L.tlc_pi_raster.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         if hasattr(L, "tlc_gcn_norm_csr"):
@@ -77,7 +82,7 @@ def lib():
         if hasattr(L, "tlc_gat_layer_fwd"):
             L.tlc_gat_layer_fwd.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
-                                            C.c_void_p]
+                                            C.c_void_p, C.c_void_p]
             L.tlc_edge_head_fwd.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p]

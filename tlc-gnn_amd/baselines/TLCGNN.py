@@ -1,0 +1,178 @@
+"""Drop-in for the reference's baselines/TLCGNN.py: same names, arguments and results; the forward runs on
+hand-written HIP kernels through the C ABI (include/tlcgnn.h).
+
+Reference: /root/reference/baselines/TLCGNN.py
+  Net.__init__ :10-18, Net.encode :19-26, Net.decode :27-62, call :71-111.
+GCNConv is third-party in the reference (torch-geometric==1.6.1); its in-tree specification is
+Knowledge_Distillation/PD_conv.py:35-70 (gcn_norm) and :146-148,179-188 (weight [in,out] glorot, bias zeros,
+x @ W, add-aggregate at the target, + bias).
+
+Forward only: encode/decode produce the link probabilities; the optimiser loop of pipelines.py is out of scope.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from ..loaddatas import get_edges_split, compute_persistence_image
+
+
+class GCNConv(torch.nn.Module):
+    """GCNConv(in, out, cached=True) forward: gcn_norm (cached) -> x @ W (f32 MFMA) -> normalised add-aggregate
+    (row-owned CSR SpMM) + bias, optional fused ReLU."""
+
+    def __init__(self, in_channels, out_channels, cached=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.cached = in_channels, out_channels, cached
+        self.weight = torch.nn.Parameter(torch.empty(in_channels, out_channels))
+        self.bias = torch.nn.Parameter(torch.empty(out_channels))
+        self._cache = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # glorot(weight), zeros(bias): PD_conv.py:146-148
+        stdv = math.sqrt(6.0 / (self.weight.size(-2) + self.weight.size(-1)))
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
+            self.bias.zero_()
+        self._cache = None
+
+    def norm_csr(self, edge_index, num_nodes):
+        if self._cache is None or not self.cached:
+            self._cache = ops.gcn_norm_csr(edge_index, num_nodes)
+        return self._cache
+
+    def forward(self, x, edge_index, relu=False):
+        rowptr, col, val = self.norm_csr(edge_index, x.shape[0])
+        with torch.no_grad():
+            xw = ops.gemm(x, self.weight.detach())
+            return ops.spmm(rowptr, col, val, xw, bias=self.bias.detach(), relu=relu)
+
+
+class Net(torch.nn.Module):
+    def __init__(self, data, num_features, num_classes, PI, dimension=5):
+        super(Net, self).__init__()
+        self.conv1 = GCNConv(num_features, 100, cached=True)
+        self.conv2 = GCNConv(100, 16, cached=True)
+        self.PI = PI                                    # float64 [n_pairs, dimension**2]: numpy (reference) or CUDA tensor
+        self.leakyrelu = torch.nn.LeakyReLU(0.2, True)
+        self.linear = torch.nn.Linear(dimension * dimension, 1, bias=True)
+        self.linear_1 = torch.nn.Linear(dimension * dimension + 16, dimension * dimension, bias=True)
+        self._pi_dev = None
+        self._pairs_dev = None
+
+    # device-resident copies of the per-pair tables (the reference re-uploads a slice on every decode, TLCGNN.py:52-53)
+    def _tables(self, data, device):
+        if self._pi_dev is None or self._pi_dev.device != device:
+            pi = self.PI
+            if not isinstance(pi, torch.Tensor):
+                pi = torch.from_numpy(np.ascontiguousarray(pi, dtype=np.float64))
+            self._pi_dev = pi.to(device=device, dtype=torch.float64).reshape(pi.shape[0], -1).contiguous()
+            te = data.total_edges
+            if not isinstance(te, torch.Tensor):
+                te = torch.from_numpy(np.ascontiguousarray(te, dtype=np.int64))
+            self._pairs_dev = te.to(device=device, dtype=torch.int32).contiguous()
+        return self._pi_dev, self._pairs_dev
+
+    def encode(self, data):
+        # can set p = 0.8 for Cora and Citeseer, the results can be higher   (reference comment, TLCGNN.py:20)
+        x, edge_index = data.x, data.edge_index
+        x = F.dropout(x, p=0.5, training=self.training)
+        x = self.conv1(x, edge_index, relu=not self.training)          # ReLU fused into the aggregate in eval mode
+        if self.training:
+            x = F.dropout(F.relu(x), p=0.5, training=True)
+        x = self.conv2(x, edge_index, relu=True)
+        return x
+
+    def decode(self, data, emb, type="train"):
+        device = emb.device
+        pi_all, pairs_all = self._tables(data, device)
+        tp, tn, vp, vn = data.train_pos, data.train_neg, data.val_pos, data.val_neg
+        if type == 'train':
+            index = np.random.randint(0, tn, tp)                       # same RNG call as TLCGNN.py:31
+            idx = torch.cat((torch.arange(tp, device=device),
+                             tp + torch.from_numpy(index).to(device)))
+            edges_y = torch.cat((data.total_edges_y[:tp], data.total_edges_y[tp:tp + tn][torch.from_numpy(index).to(data.total_edges_y.device)]))
+            total_edges = pairs_all[idx].contiguous()
+            PI = pi_all[idx].contiguous()
+        elif type == 'val':
+            total_edges = pairs_all[tp + tn:tp + tn + vp + vn]
+            edges_y = data.total_edges_y[tp + tn:tp + tn + vp + vn]
+            PI = pi_all[tp + tn:tp + tn + vp + vn]
+        elif type == 'test':
+            total_edges = pairs_all[tp + tn + vp + vn:]
+            edges_y = data.total_edges_y[tp + tn + vp + vn:]
+            PI = pi_all[tp + tn + vp + vn:]
+        else:
+            raise ValueError("type must be 'train', 'val' or 'test'")
+        # linear to gather edge features
+        emb = ops.renorm_rows_(emb)                                    # emb.renorm_(2,0,1), in place (:48)
+        prob = ops.lp_decode(total_edges, emb, PI, self.linear_1.weight.detach(), self.linear_1.bias.detach(),
+                             self.linear.weight.detach(), self.linear.bias.detach())
+        return prob, edges_y.float()
+
+
+def num(strings):
+    try:
+        return int(strings)
+    except ValueError:
+        return float(strings)
+
+
+def call(data, name, num_features, num_classes, data_cnt):
+    # to generate data and models  (TLCGNN.py:71-111)
+    if name in ['PPI']:
+        val_prop = 0.2
+        test_prop = 0.2
+    else:
+        val_prop = 0.05
+        test_prop = 0.1
+    train_edges, train_edges_false, val_edges, val_edges_false, test_edges, test_edges_false = get_edges_split(
+        data, val_prop=val_prop, test_prop=test_prop)
+    total_edges = np.concatenate((train_edges, train_edges_false, val_edges, val_edges_false, test_edges, test_edges_false))
+    data.train_pos, data.train_neg = len(train_edges), len(train_edges_false)
+    data.val_pos, data.val_neg = len(val_edges), len(val_edges_false)
+    data.test_pos, data.test_neg = len(test_edges), len(test_edges_false)
+    data.total_edges = total_edges
+    data.total_edges_y = torch.cat((torch.ones(len(train_edges)), torch.zeros(len(train_edges_false)),
+                                    torch.ones(len(val_edges)), torch.zeros(len(val_edges_false)),
+                                    torch.ones(len(test_edges)), torch.zeros(len(test_edges_false)))).long()
+
+    # delete val_pos and test_pos (both directions; a pair that is absent is a self loop) -- :88-100
+    data.edge_index = remove_pairs_both_directions(data.edge_index, np.concatenate((val_edges, test_edges)))
+
+    hop = 2 if name in ["PubMed"] else 1
+    if name in ['PPI']:
+        f1 = compute_persistence_image(data, train_edges, train_edges_false, val_edges, val_edges_false, test_edges,
+                                       test_edges_false, name + "_" + str(data_cnt), hop=hop)
+    else:
+        f1 = compute_persistence_image(data, train_edges, train_edges_false, val_edges, val_edges_false, test_edges,
+                                       test_edges_false, name, hop=hop)
+    if not torch.cuda.is_available():
+        raise RuntimeError("TLCGNN.call: no MI355X visible; the HIP forward has no CPU fallback")
+    device = torch.device('cuda')
+    model, data = Net(data, num_features, num_classes, PI=f1).to(device), data.to(device)
+    return model, data
+
+
+def remove_pairs_both_directions(edge_index, pairs):
+    """edge_list.remove(e); edge_list.remove(e[::-1]) for every val/test positive that is present (:88-100),
+    without the O(E^2) Python list scans: removes the FIRST occurrence of each direction, keeps order."""
+    ei = edge_index.cpu().numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index)
+    ei = ei.astype(np.int64)
+    src, dst = ei[0], ei[1]
+    keep = np.ones(ei.shape[1], dtype=bool)
+    first = {}
+    for i in range(ei.shape[1] - 1, -1, -1):
+        first.setdefault((int(src[i]), int(dst[i])), []).append(i)      # stacks of positions, earliest on top
+    for a, b in np.asarray(pairs).reshape(-1, 2).tolist():
+        st = first.get((a, b))
+        if st:
+            keep[st.pop()] = False
+            st2 = first.get((b, a))
+            if not st2:
+                raise ValueError("list.remove(x): x not in list")        # what the reference raises
+            keep[st2.pop()] = False
+    return torch.from_numpy(ei[:, keep]).long()

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <new>
+#include <vector>
 
 #include "tlc_common.h"
 #include "tlc_kernels.h"
@@ -72,6 +73,12 @@ struct tlc_graph {
     hipStream_t side[TLC_N_SIDE];
     hipEvent_t ev_fork, ev_join[TLC_N_SIDE];
     long long last_stats[8];
+    unsigned long long* d_phase;   // diagnostics: [TLC_N_TIERS][16] cycle counters, null unless enabled
+    // optional per-kernel timing (tlc_pd_pi_batch_set_timing): events bracket each launch on its own stream
+    int timing;
+    hipEvent_t ev_t[16];           // 0/1 count, 2/3 scan, 4/5 fill, 6+2t / 7+2t tier t
+    int ev_used[8];
+    int last_n_pairs;
 };
 
 static int ensure_pairs(tlc_graph* g, size_t n) {
@@ -171,6 +178,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
         CK(hipEventCreateWithFlags(&g->ev_join[k], hipEventDisableTiming));
     }
     CK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+    for (int k = 0; k < 16; ++k) CK(hipEventCreate(&g->ev_t[k]));
 #undef CK
     // concurrent vicinity workgroups worth launching: LDS-bound per CU, 256 CUs
     hipDeviceProp_t prop;
@@ -192,12 +200,13 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
     hipFree(g->d_ctl); hipFree(g->d_block_sums); hipFree(g->d_totals); hipFree(g->d_stats);
     if (g->h_sync) hipHostFree(g->h_sync);
-    hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch);
+    hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch); hipFree(g->d_phase);
     for (int k = 0; k < TLC_N_SIDE; ++k) {
         if (g->side[k]) hipStreamDestroy(g->side[k]);
         if (g->ev_join[k]) hipEventDestroy(g->ev_join[k]);
     }
     if (g->ev_fork) hipEventDestroy(g->ev_fork);
+    for (int k = 0; k < 16; ++k) if (g->ev_t[k]) hipEventDestroy(g->ev_t[k]);
     delete g;
     return TLC_OK;
 }
@@ -230,17 +239,25 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         lds_attr = true;
     }
     const int vgrid = std::min(n_pairs, g->vic_slots);
+    memset(g->ev_used, 0, sizeof(g->ev_used));
+    g->last_n_pairs = n_pairs;
+#define T0(k, st) do { if (g->timing) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k)], st)); } } while (0)
+#define T1(k, st) do { if (g->timing) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k) + 1], st)); g->ev_used[k] = 1; } } while (0)
+    T0(0, s);
     hipLaunchKernelGGL(tlc_vicinity_kernel<false>, dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
+    T1(0, s);
     TLC_HIP_CHECK(hipGetLastError());
 
     // exclusive scan of the induced entry counts + tier binning
     const int nb = (n_pairs + 1023) / 1024;
+    T0(1, s);
     hipLaunchKernelGGL(tlc_scan_block_sums, dim3(nb), dim3(1024), 0, s, (const int*)g->hdr_m2, n_pairs, g->d_block_sums);
     hipLaunchKernelGGL(tlc_scan_top, dim3(1), dim3(1024), 0, s, g->d_block_sums, nb, g->d_totals);
     TlcScanParams sp;
     sp.n_pairs = n_pairs; sp.hdr_n = g->hdr_n; sp.hdr_m2 = g->hdr_m2; sp.block_sums = g->d_block_sums;
     sp.edge_off = g->edge_off; sp.tier_count = g->d_ctl; sp.tier_list = g->tier_list;
     hipLaunchKernelGGL(tlc_scan_down, dim3(nb), dim3(1024), 0, s, sp);
+    T1(1, s);
     TLC_HIP_CHECK(hipGetLastError());
     TLC_HIP_CHECK(hipMemcpyAsync(&g->h_sync->total_entries, g->d_totals, sizeof(long long), hipMemcpyDeviceToHost, s));
     TLC_HIP_CHECK(hipMemcpyAsync(g->h_sync->tier_count, g->d_ctl, TLC_N_TIERS * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -255,7 +272,9 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     if (todo > 0) {
         TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl + 4, 0, sizeof(int), s));
         vp.A_dir = g->A_dir; vp.A_lw = g->A_lw;
+        T0(2, s);
         hipLaunchKernelGGL(tlc_vicinity_kernel<true>, dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
+        T1(2, s);
         TLC_HIP_CHECK(hipGetLastError());
 
         TlcPdParams pp;
@@ -276,15 +295,23 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
             if (tc[t] <= 0) continue;
             TLC_HIP_CHECK(hipStreamWaitEvent(g->side[k], g->ev_fork, 0));
             pp.tier_list = g->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
+            pp.phase_cycles = g->d_phase ? g->d_phase + 16 * t : nullptr;
+            T0(3 + t, g->side[k]);
             if ((rc = tlc_launch_pd_tier(t, pp, g->side[k])) != TLC_OK) return rc;
+            T1(3 + t, g->side[k]);
             TLC_HIP_CHECK(hipEventRecord(g->ev_join[k], g->side[k]));
             used[k] = true;
         }
         pp.tier_list = g->tier_list + (size_t)TLC_TIER_SMALL * n_pairs; pp.tier_count = tc[TLC_TIER_SMALL];
+        pp.phase_cycles = g->d_phase ? g->d_phase + 16 * TLC_TIER_SMALL : nullptr;
+        if (tc[TLC_TIER_SMALL] > 0) T0(3 + TLC_TIER_SMALL, s);
         if ((rc = tlc_launch_pd_tier(TLC_TIER_SMALL, pp, s)) != TLC_OK) return rc;
+        if (tc[TLC_TIER_SMALL] > 0) T1(3 + TLC_TIER_SMALL, s);
         for (int k = 0; k < 3; ++k)
             if (used[k]) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_join[k], 0));
     }
+#undef T0
+#undef T1
     for (int t = 0; t < TLC_N_TIERS; ++t) g->last_stats[t] += tc[t];
     g->last_stats[4] += total;
     g->last_stats[6] += 1;
@@ -404,4 +431,99 @@ extern "C" int tlc_pi_raster(int32_t n_dgms, const int64_t* d_offs, const double
     if (n_dgms == 0) return TLC_OK;
     TLC_REQUIRE(d_offs && d_out, "null pointer");
     return tlc_launch_pi_raster(n_dgms, (const long long*)d_offs, d_pts, res, d_out, stream);
+}
+
+// ---- diagnostics (not part of include/tlcgnn.h): per-phase cycle counters of the PD tier kernels -------------------
+extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out /* [4][16] or null */) {
+    TLC_REQUIRE(g != nullptr, "null graph");
+    TLC_HIP_CHECK(hipSetDevice(g->device));
+    TLC_HIP_CHECK(hipDeviceSynchronize());
+    if (h_out && g->d_phase) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_phase, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (enable && !g->d_phase) TLC_HIP_CHECK(hipMalloc(&g->d_phase, 64 * sizeof(unsigned long long)));
+    if (g->d_phase) TLC_HIP_CHECK(hipMemset(g->d_phase, 0, 64 * sizeof(unsigned long long)));
+    if (!enable && g->d_phase) { hipFree(g->d_phase); g->d_phase = nullptr; }
+    return TLC_OK;
+}
+
+// ---- measurement helpers (declared in include/tlcgnn.h) ----------------------------------------------------------------
+extern "C" int tlc_pd_pi_batch_set_timing(tlc_graph* g, int enable) {
+    TLC_REQUIRE(g != nullptr, "null graph");
+    g->timing = enable ? 1 : 0;
+    return TLC_OK;
+}
+
+// h_ms[0..6] = COUNT, scan+binning, FILL, tier SMALL, MEDIUM, LARGE, HUGE kernel durations (ms, -1 = not launched) of the
+// LAST chunk of the last tlc_pd_pi_batch, from HIP events recorded on the stream each kernel ran on.  Synchronises.
+extern "C" int tlc_pd_pi_batch_timings(tlc_graph* g, double* h_ms, void* stream) {
+    TLC_REQUIRE(g && h_ms, "null argument");
+    TLC_HIP_CHECK(hipSetDevice(g->device));
+    TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    for (int k = 0; k < 7; ++k) {
+        h_ms[k] = -1.0;
+        if (g->timing && g->ev_used[k]) {
+            TLC_HIP_CHECK(hipEventSynchronize(g->ev_t[2 * k + 1]));
+            float ms = 0.f;
+            TLC_HIP_CHECK(hipEventElapsedTime(&ms, g->ev_t[2 * k], g->ev_t[2 * k + 1]));
+            h_ms[k] = (double)ms;
+        }
+    }
+    return TLC_OK;
+}
+
+// vicinity sizes of the last chunk: h_n[i] = |S| (0 for pairs finished early), h_m2[i] = induced directed entries
+extern "C" int tlc_pd_pi_batch_sizes(tlc_graph* g, int32_t* h_n, int32_t* h_m2, int64_t cap, void* stream) {
+    TLC_REQUIRE(g && h_n && h_m2, "null argument");
+    TLC_HIP_CHECK(hipSetDevice(g->device));
+    TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    const size_t k = (size_t)std::min<int64_t>(cap, g->last_n_pairs);
+    if (k) {
+        TLC_HIP_CHECK(hipMemcpy(h_n, g->hdr_n, k * sizeof(int), hipMemcpyDeviceToHost));
+        TLC_HIP_CHECK(hipMemcpy(h_m2, g->hdr_m2, k * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return TLC_OK;
+}
+
+// Algorithmic HBM bytes per pair, host-side accounting on the host CSR:
+//   8 [pair] + sum_{x in B_{hop-1}(u) U B_{hop-1}(v)} (8 + 4 deg x) + sum_{x in S} (8 + 12 deg x) + 8 res^2
+extern "C" int tlc_pd_pi_algorithmic_bytes(int32_t n_nodes, const int32_t* h_rowptr, const int32_t* h_col, const int32_t* h_pairs,
+                                           int64_t n_pairs, int hop, int res, double* h_out_bytes) {
+    TLC_REQUIRE(n_nodes > 0 && h_rowptr && h_col && h_out_bytes && (n_pairs == 0 || h_pairs), "null argument");
+    std::vector<int> su(n_nodes, 0), sv(n_nodes, 0), sx(n_nodes, 0), fr(n_nodes), nx(n_nodes), ball(n_nodes);
+    int ep = 0;
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        const int u = h_pairs[2 * i], v = h_pairs[2 * i + 1];
+        double b = 8.0 + 8.0 * res * res;
+        if (u < 0 || v < 0 || u >= n_nodes || v >= n_nodes || h_rowptr[u + 1] == h_rowptr[u] || h_rowptr[v + 1] == h_rowptr[v]) {
+            h_out_bytes[i] = b;
+            continue;
+        }
+        ++ep;
+        int n_ball = 0;
+        for (int side = 0; side < 2; ++side) {
+            const int root = side ? v : u;
+            std::vector<int>& st = side ? sv : su;
+            int nf = 1;
+            fr[0] = root; st[root] = ep;
+            if (side == 0) ball[n_ball++] = root;
+            for (int d = 0; d < hop && nf > 0; ++d) {
+                int nn = 0;
+                for (int k = 0; k < nf; ++k) {
+                    const int a = fr[k];
+                    if (sx[a] != ep) { sx[a] = ep; b += 8.0 + 4.0 * (h_rowptr[a + 1] - h_rowptr[a]); }
+                    for (int j = h_rowptr[a]; j < h_rowptr[a + 1]; ++j) {
+                        const int c = h_col[j];
+                        if (st[c] != ep) { st[c] = ep; nx[nn++] = c; if (side == 0) ball[n_ball++] = c; }
+                    }
+                }
+                std::copy(nx.begin(), nx.begin() + nn, fr.begin());
+                nf = nn;
+            }
+        }
+        for (int k = 0; k < n_ball; ++k) {
+            const int a = ball[k];
+            if (sv[a] == ep) b += 8.0 + 12.0 * (h_rowptr[a + 1] - h_rowptr[a]);
+        }
+        h_out_bytes[i] = b;
+    }
+    return TLC_OK;
 }

@@ -1,0 +1,187 @@
+// gat_forward.hip -- M4..M6: the PDGNN layer and edge head, forward only.
+//
+//   tlc_gat_layer_fwd   GATConv(heads=1, concat=False, new_node_feat, use_edge_attn) on a block-diagonal batch
+//                       (Knowledge_Distillation/gat_conv.py:113-216; gather/scatter: message_passing.py:124-183,275-293)
+//   tlc_edge_head_fwd   lin6(prelu(lin5([x_src || x_dst])))  (Knowledge_Distillation/Teacher_model.py:54-59)
+//
+// The reference evaluates lin_ij on the concatenation [x_i || x_j] for every edge (gat_conv.py:193-194): an
+// [E, 2C] x [2C, C] product.  Because lin_ij has no bias, W_ij [x_i || x_j] = W_ij[:, :C] x_i + W_ij[:, C:] x_j, so the
+// two halves are projected ONCE PER NODE (kernel 1, together with lin_l and the attention logit) and the per-edge work
+// collapses to leaky_relu(P_i + Q_j) * softmax weight.  The three scatters (sum, min, max at the target,
+// gat_conv.py:216) become one pass over a CSR row per target: every output row has one owner, no atomics.
+#include "tlc_common.h"
+
+namespace {
+
+// kernel 1: per node  x_l = Wl x,  alpha = x_l . att,  P = Wij[:, :C] x_l,  Q = Wij[:, C:] x_l
+// work layout per node: [x_l (C) | P (C) | Q (C) | alpha (1)]   (stride 3C+1)
+template <int C>
+__global__ __launch_bounds__(256) void gat_node_kernel(int n, const float* __restrict__ X, int c_in, const float* __restrict__ Wl,
+                                                       const float* __restrict__ att, const float* __restrict__ Wij,
+                                                       float* __restrict__ work) {
+    extern __shared__ float sm[];
+    float* sWl = sm;                       // [C][c_in]
+    float* sWij = sm + C * c_in;           // [C][2C]
+    float* sXl = sWij + C * 2 * C;         // [256/C nodes][C]
+    for (int t = threadIdx.x; t < C * c_in; t += 256) sWl[t] = Wl[t];
+    for (int t = threadIdx.x; t < C * 2 * C; t += 256) sWij[t] = Wij[t];
+    __syncthreads();
+    constexpr int NPB = 256 / C;           // nodes per block
+    const int ln = threadIdx.x / C, c = threadIdx.x % C;
+    for (int base = blockIdx.x * NPB; base < n; base += gridDim.x * NPB) {
+        const int i = base + ln;
+        float xl = 0.0f;
+        if (i < n) {
+            const float* xr = X + (size_t)i * c_in;
+            const float* wr = sWl + c * c_in;
+            for (int k = 0; k < c_in; ++k) xl += wr[k] * xr[k];
+        }
+        sXl[ln * C + c] = xl;
+        // alpha = (x_l * att_l).sum(-1)  (gat_conv.py:135): reduce over the C lanes of this node
+        float a = xl * att[c];
+#pragma unroll
+        for (int o = C / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        __syncthreads();
+        if (i < n) {
+            const float* xs = sXl + ln * C;
+            const float* wr = sWij + c * 2 * C;
+            float p = 0.0f, q = 0.0f;
+#pragma unroll 8
+            for (int k = 0; k < C; ++k) {
+                p += wr[k] * xs[k];          // target half:  x_i
+                q += wr[C + k] * xs[k];      // source half:  x_j
+            }
+            float* w = work + (size_t)i * (3 * C + 1);
+            w[c] = xl;
+            w[C + c] = p;
+            w[2 * C + c] = q;
+            if (c == 0) w[3 * C] = a;
+        }
+        __syncthreads();
+    }
+}
+
+// kernel 2: one group of C lanes per target node
+template <int C>
+__global__ __launch_bounds__(256) void gat_aggregate_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ src,
+                                                            const float* __restrict__ work, const float* __restrict__ bias,
+                                                            float prelu_slope, float* __restrict__ out) {
+    constexpr int S = 3 * C + 1;
+    const int i = (blockIdx.x * 256 + threadIdx.x) / C, c = threadIdx.x % C;
+    if (i >= n) return;
+    const int b = rowptr[i], e = rowptr[i + 1];
+    const float ai = work[(size_t)i * S + 3 * C];
+    const float pi = work[(size_t)i * S + C + c];
+    // softmax over the incoming edges (torch_geometric.utils.softmax: subtract the segment max)
+    float mx = -INFINITY;
+    for (int j = b; j < e; ++j) {
+        float t = work[(size_t)src[j] * S + 3 * C] + ai;      // alpha_j + alpha_i  (gat_conv.py:184)
+        t = t > 0.0f ? t : 0.2f * t;                          // leaky_relu(negative_slope=0.2) (:185)
+        mx = t > mx ? t : mx;
+    }
+    float den = 0.0f, sum = 0.0f, mn = INFINITY, mxv = -INFINITY;
+    for (int j = b; j < e; ++j) {
+        const float* wj = work + (size_t)src[j] * S;
+        float t = wj[3 * C] + ai;
+        t = t > 0.0f ? t : 0.2f * t;
+        const float ex = expf(t - mx);
+        den += ex;
+        float m = pi + wj[2 * C + c];                         // lin_ij([x_i || x_j]) (:193-194)
+        m = m > 0.0f ? m : 0.2f * m;                          // leaky_relu (:195)
+        m *= ex;                                              // * alpha (:198-200), normalised below
+        sum += m;
+        mn = m < mn ? m : mn;
+        mxv = m > mxv ? m : mxv;
+    }
+    float o_sum = 0.0f, o_mm = 0.0f;                          // empty segment: scatter leaves zeros
+    if (e > b) {
+        const float inv = 1.0f / (den + 1e-16f);
+        o_sum = sum * inv;
+        o_mm = mn * inv + mxv * inv;                          // scatter min + scatter max (:216)
+    }
+    o_sum += bias[c];                                         // mean over the single head, + bias (:166-172)
+    o_mm += bias[C + c];
+    if (prelu_slope >= 0.0f) {                                // F.prelu(x, 0.1) between layers (Teacher_model.py:219-227)
+        o_sum = o_sum > 0.0f ? o_sum : prelu_slope * o_sum;
+        o_mm = o_mm > 0.0f ? o_mm : prelu_slope * o_mm;
+    }
+    out[(size_t)i * 2 * C + c] = o_sum;
+    out[(size_t)i * 2 * C + C + c] = o_mm;
+}
+
+// edge head: one thread per edge; W5 / W6 staged in LDS
+__global__ __launch_bounds__(256) void edge_head_kernel(long long n_edges, const int* __restrict__ src, const int* __restrict__ dst,
+                                                        const float* __restrict__ X, int c, const float* __restrict__ W5,
+                                                        const float* __restrict__ b5, int hidden, float slope,
+                                                        const float* __restrict__ W6, const float* __restrict__ b6,
+                                                        float* __restrict__ pd) {
+    extern __shared__ float sm[];
+    float* sW5 = sm;                       // [hidden][2c]
+    float* sW6 = sm + hidden * 2 * c;      // [2][hidden]
+    for (int t = threadIdx.x; t < hidden * 2 * c; t += 256) sW5[t] = W5[t];
+    for (int t = threadIdx.x; t < 2 * hidden; t += 256) sW6[t] = W6[t];
+    __syncthreads();
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_edges) return;
+    const float* xs = X + (size_t)src[e] * c;
+    const float* xd = X + (size_t)dst[e] * c;
+    float o0 = b6[0], o1 = b6[1];
+    for (int h = 0; h < hidden; ++h) {
+        const float* wr = sW5 + h * 2 * c;
+        float v = b5[h];
+        for (int k = 0; k < c; ++k) v += wr[k] * xs[k];
+        for (int k = 0; k < c; ++k) v += wr[c + k] * xd[k];
+        v = v > 0.0f ? v : slope * v;                          // F.prelu(x, 0.1) (Teacher_model.py:57)
+        o0 += sW6[h] * v;
+        o1 += sW6[hidden + h] * v;
+    }
+    pd[2 * e] = o0;
+    pd[2 * e + 1] = o1;
+}
+
+template <int C>
+int launch_gat(int n, const int* rowptr, const int* src, const float* X, int c_in, const float* Wl, const float* att,
+               const float* Wij, const float* bias, float slope, float* work, float* out, hipStream_t s) {
+    const size_t lds = ((size_t)C * c_in + (size_t)C * 2 * C + 256) * sizeof(float);
+    if (lds > 64 * 1024) { tlc_set_error("tlc_gat_layer_fwd: c_in too large for the LDS-staged weights"); return TLC_ERR_UNSUPPORTED; }
+    constexpr int NPB = 256 / C;
+    int grid = (n + NPB - 1) / NPB;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(gat_node_kernel<C>, dim3(grid), dim3(256), lds, s, n, X, c_in, Wl, att, Wij, work);
+    hipLaunchKernelGGL(gat_aggregate_kernel<C>, dim3((unsigned)(((size_t)n * C + 255) / 256)), dim3(256), 0, s, n, rowptr, src,
+                       (const float*)work, bias, slope, out);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
+}  // namespace
+
+extern "C" int tlc_gat_layer_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_src, const float* d_X, int32_t c_in,
+                                 int32_t c_out, const float* d_Wl, const float* d_att, const float* d_Wij, const float* d_bias,
+                                 float prelu_slope, float* d_work, float* d_out, void* stream) {
+    TLC_REQUIRE(n_nodes >= 0 && c_in > 0, "bad sizes");
+    TLC_REQUIRE(c_out == 8 || c_out == 16 || c_out == 32 || c_out == 64, "c_out must be 8, 16, 32 or 64");
+    if (n_nodes == 0) return TLC_OK;
+    TLC_REQUIRE(d_rowptr && d_src && d_X && d_Wl && d_att && d_Wij && d_bias && d_work && d_out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    switch (c_out) {
+        case 8: return launch_gat<8>(n_nodes, d_rowptr, d_src, d_X, c_in, d_Wl, d_att, d_Wij, d_bias, prelu_slope, d_work, d_out, s);
+        case 16: return launch_gat<16>(n_nodes, d_rowptr, d_src, d_X, c_in, d_Wl, d_att, d_Wij, d_bias, prelu_slope, d_work, d_out, s);
+        case 32: return launch_gat<32>(n_nodes, d_rowptr, d_src, d_X, c_in, d_Wl, d_att, d_Wij, d_bias, prelu_slope, d_work, d_out, s);
+        default: return launch_gat<64>(n_nodes, d_rowptr, d_src, d_X, c_in, d_Wl, d_att, d_Wij, d_bias, prelu_slope, d_work, d_out, s);
+    }
+}
+
+extern "C" int tlc_edge_head_fwd(int64_t n_edges, const int32_t* d_src, const int32_t* d_dst, const float* d_X, int32_t c,
+                                 const float* d_W5, const float* d_b5, int32_t hidden, float prelu_slope, const float* d_W6,
+                                 const float* d_b6, float* d_pd, void* stream) {
+    TLC_REQUIRE(n_edges >= 0 && c > 0 && hidden > 0, "bad sizes");
+    if (n_edges == 0) return TLC_OK;
+    TLC_REQUIRE(d_src && d_dst && d_X && d_W5 && d_b5 && d_W6 && d_b6 && d_pd, "null pointer");
+    const size_t lds = ((size_t)hidden * 2 * c + 2 * (size_t)hidden) * sizeof(float);
+    TLC_REQUIRE(lds <= 64 * 1024, "edge head weights do not fit LDS");
+    hipLaunchKernelGGL(edge_head_kernel, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), lds, (hipStream_t)stream,
+                       (long long)n_edges, d_src, d_dst, d_X, c, d_W5, d_b5, hidden, prelu_slope, d_W6, d_b6, d_pd);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}

@@ -22,6 +22,16 @@
 #include "tlc_kernels.h"
 
 #define TLC_INF_BITS 0x7FF0000000000000ull
+// diagnostics: accumulate the cycles thread 0 spent since the previous stamp into phase slot k (only when the
+// caller passed a phase_cycles buffer; tools/phase_profile.py)
+#define TLC_STAMP(k)                                                                 \
+    do {                                                                             \
+        if (pc && threadIdx.x == 0) {                                    \
+            const unsigned long long _t = clock64();                                 \
+            atomicAdd(&pc[(k)], _t - t_prev);                            \
+            t_prev = _t;                                                             \
+        }                                                                            \
+    } while (0)
 #define TLC_NONE16 0xFFFFu
 
 namespace {
@@ -241,7 +251,8 @@ struct GlobalSink {
 // M.dir[] (EID=true).  On return ctl[3] = #Pos, ctl[4] = #Neg, pn[] = Pos from the front / Neg from the back
 // (payloads, in descending-pass order).
 template <int W, typename idx_t, bool EID, class Sink>
-__device__ __forceinline__ void pd_stages(Mem<idx_t>& M, Sink& sink, int n, int m, int P, unsigned flags, int MMcap) {
+__device__ __forceinline__ void pd_stages(Mem<idx_t>& M, Sink& sink, int n, int m, int P, unsigned flags, int MMcap,
+                                          ull* pc, ull& t_prev) {
     const int tid = threadIdx.x;
     const bool keep0 = (flags & TLC_KEEP_ZERO_PERS) != 0;
     double* f = M.f;
@@ -259,6 +270,7 @@ __device__ __forceinline__ void pd_stages(Mem<idx_t>& M, Sink& sink, int n, int 
     for (int i = tid; i < n; i += W) M.comp[i] = (idx_t)i;
     __syncthreads();
     bitonic_sort<W>(M.keyS, M.valS, P);
+    TLC_STAMP(5);
     // ---- ascending union-find pass (accelerated_PD.py:46-68) ---------------------------------------------------------
     if (tid == 0) {
         for (int e = 0; e < m; ++e) {
@@ -275,6 +287,7 @@ __device__ __forceinline__ void pd_stages(Mem<idx_t>& M, Sink& sink, int n, int 
         sink.ext0(f, n, n + 1);                                                            // [min, max]  (:110)
     }
     __syncthreads();
+    TLC_STAMP(6);
     // ---- descending keys, same edges (:70-77) -------------------------------------------------------------------------
     for (int e = tid; e < m; e += W) {
         const unsigned ab = ends(M.valS[e]);
@@ -283,6 +296,7 @@ __device__ __forceinline__ void pd_stages(Mem<idx_t>& M, Sink& sink, int n, int 
     for (int i = tid; i < n; i += W) M.comp[i] = (idx_t)i;
     __syncthreads();
     bitonic_sort<W>(M.keyS, M.valS, P);
+    TLC_STAMP(7);
     // ---- descending pass (:83-109): Pos / Neg classification (+ Rel1 points) ------------------------------------------
     if (tid == 0) {
         int npos = 0, nneg = 0;
@@ -307,11 +321,13 @@ __device__ __forceinline__ void pd_stages(Mem<idx_t>& M, Sink& sink, int n, int 
         M.ctl[3] = npos; M.ctl[4] = nneg;
     }
     __syncthreads();
+    TLC_STAMP(8);
 }
 
 // Accelerate_PD (accelerated_PD.py:115-178).  Requires ctl[4] (#Neg) >= 1.
 template <int W, typename idx_t, bool EID, class Sink>
-__device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, unsigned flags, int MMcap) {
+__device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, unsigned flags, int MMcap, ull* pc,
+                                           ull& t_prev) {
     const int tid = threadIdx.x;
     const bool keep0 = (flags & TLC_KEEP_ZERO_PERS) != 0;
     const idx_t NONE = (idx_t)~(idx_t)0;
@@ -341,6 +357,7 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
         __syncthreads();
         if (!any) break;
     }
+    TLC_STAMP(9);
     if (tid == 0) {
         unsigned stamp = 0;
         for (int pi = 0; pi < npos; ++pi) {
@@ -383,6 +400,7 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
         }
     }
     __syncthreads();
+    TLC_STAMP(10);
 }
 
 // PersistenceImager.transform (PersistenceImager.pyx:352-388) over points first..last: Gaussian sigma=1 on [0,1]^2,
@@ -464,6 +482,9 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
         const int m = m2 >> 1;
         const bool far = (lu < 0);        // u in S <=> v in S <=> d(u,v) <= hop  
         int status = TLC_ST_OK;
+        ull* pc = p.phase_cycles;
+        ull t_prev = pc ? clock64() : 0ull;
+        const ull t_begin = t_prev;
         // ---- stage the subgraph ------------------------------------------------------------------------------------
         for (int j = tid; j < m2; j += W) {
             M.dir[j] = p.A_dir[eo + j];
@@ -480,7 +501,9 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
             // ---- P5: filtration.build_fv, weighted branch, descriptor 'sum' (riccidist2dgm.py:20-61) ------------------
             if (tid == 0) { du[lu] = 0ull; M.dv[lv] = 0ull; }
             __syncthreads();
+            TLC_STAMP(0);
             bellman_ford<W, true>(du, M.dv, M.dir, m2, n, LW, M.ctl);
+            TLC_STAMP(1);
             // assert one connected component (:318): everything must be reachable from u
             double dmx = 0.0;
             int unreach = 0;
@@ -543,6 +566,7 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
                     }
                 }
                 __syncthreads();
+                TLC_STAMP(2);
                 // exact fallback for sources with (near-)tied paths: Bellman-Ford sourced at x itself
                 const int namb = M.ctl[1];
                 for (int q = 0; q < namb; ++q) {
@@ -557,6 +581,7 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
                     __syncthreads();
                 }
                 if (namb && tid == 0 && p.stats) atomicAdd(&p.stats[0], (ull)namb);
+                TLC_STAMP(3);
                 // normalise (:50-56): plain division by the maximum
                 double mx = 0.0;
                 for (int k = tid; k < n; k += W) mx = M.f[k] > mx ? M.f[k] : mx;
@@ -640,10 +665,11 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
             }
             const int P = pow2ceil(m < 2 ? 2 : m);
             PtsSink sink{M.pts, 0, 0, 0, 0};
-            pd_stages<W, idx_t, false>(M, sink, n, m, P, p.flags, MMr);
+            TLC_STAMP(4);
+            pd_stages<W, idx_t, false>(M, sink, n, m, P, p.flags, MMr, pc, t_prev);
             if (!(p.flags & TLC_NO_EXT1)) {
                 if (M.ctl[4] == 0) status = TLC_ST_NO_TREE_EDGE;          // list(Nodes)[0] -> IndexError (:122)
-                else ext1_stage<W, idx_t, false>(M, sink, n, p.flags, MMr);
+                else ext1_stage<W, idx_t, false>(M, sink, n, p.flags, MMr, pc, t_prev);
             }
             if (tid == 0) { M.ctl[2] = sink.np; M.ctl[6] = sink.n_up; }
             __syncthreads();
@@ -664,6 +690,8 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
                 }
             }
         }
+        TLC_STAMP(11);
+        if (pc && tid == 0) { atomicAdd(&pc[12], clock64() - t_begin); atomicMax(&pc[13], clock64() - t_begin); atomicAdd(&pc[14], 1ull); }
         if (status != TLC_ST_OK) acc = 0.0;
         if (p.out_pi && tid < res2) p.out_pi[(size_t)i * res2 + tid] = acc;
         if (p.out_status && tid == 0) p.out_status[i] = (unsigned char)status;
@@ -714,9 +742,10 @@ __global__ __launch_bounds__(W) void tlc_pdf_tier_kernel(TlcPdfParams p) {
         __syncthreads();
         GlobalSink sink{p.pd_up + 2 * no, p.pd_down + 2 * no, p.pd_one + 2 * eo, p.ext0 + 2 * (size_t)g, 0, 0, 0, 0};
         const int P = pow2ceil(m < 2 ? 2 : m);
-        pd_stages<W, idx_t, true>(M, sink, n, m, P, p.flags, MMr);
+        ull* pc = nullptr; ull t_prev = 0;
+        pd_stages<W, idx_t, true>(M, sink, n, m, P, p.flags, MMr, pc, t_prev);
         const int npos = M.ctl[3], nneg = M.ctl[4];
-        if (!(p.flags & TLC_NO_EXT1) && nneg > 0) ext1_stage<W, idx_t, true>(M, sink, n, p.flags, MMr);
+        if (!(p.flags & TLC_NO_EXT1) && nneg > 0) ext1_stage<W, idx_t, true>(M, sink, n, p.flags, MMr, pc, t_prev);
         if (tid == 0) {
             p.counts[4 * (size_t)g + 0] = sink.n_up;
             p.counts[4 * (size_t)g + 1] = sink.n_down;

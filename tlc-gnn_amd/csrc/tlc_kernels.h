@@ -97,6 +97,8 @@ struct TlcPdParams {
     int huge_slots;
     // statistics: [0] sources that took the exact tie fallback
     unsigned long long* stats;
+    // diagnostics (null in production): per tier 16 accumulated cycle counts of thread 0, see pd_pipeline.hip
+    unsigned long long* phase_cycles;
 };
 
 // PD from a caller-supplied filtration (tlc_pd_from_filtration)

@@ -333,16 +333,26 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_down(TlcScanParams p) {
         s[t] += a;
         __syncthreads();
     }
+    int tier = -1;
     if (i < p.n_pairs) {
         p.edge_off[i] = p.block_sums[blockIdx.x] + s[t] - own;
         if (n > 0) {
             const int m = (int)(own >> 1);
-            int tier = TLC_TIER_HUGE;
+            tier = TLC_TIER_HUGE;
             if (n <= TLC_S_NMAX && m <= TLC_S_MMAX) tier = TLC_TIER_SMALL;
             else if (n <= TLC_M_NMAX && m <= TLC_M_MMAX) tier = TLC_TIER_MEDIUM;
             else if (n <= TLC_L_NMAX && m <= TLC_L_MMAX) tier = TLC_TIER_LARGE;
-            const int pos = atomicAdd(&p.tier_count[tier], 1);
-            p.tier_list[(size_t)tier * p.n_pairs + pos] = i;
         }
+    }
+    // wave-aggregated append: one atomic per wave and tier
+#pragma unroll
+    for (int tt = 0; tt < TLC_N_TIERS; ++tt) {
+        const unsigned long long mk = __ballot(tier == tt);
+        if (mk == 0) continue;
+        int base = 0;
+        const int leader = __builtin_ctzll(mk);
+        if (tlc_lane() == leader) base = atomicAdd(&p.tier_count[tt], __popcll(mk));
+        base = __shfl(base, leader, 64);
+        if (tier == tt) p.tier_list[(size_t)tt * p.n_pairs + base + __popcll(mk & tlc_lanemask_lt())] = i;
     }
 }

@@ -68,6 +68,25 @@ class DeviceGraph:
         return {"tier_small": v[0], "tier_medium": v[1], "tier_large": v[2], "tier_huge": v[3],
                 "induced_entries": v[4], "tie_fallback_sources": v[5], "chunks": v[6]}
 
+    # ---- measurement helpers (bench.py) -----------------------------------------------------------------------
+    KERNELS = ["vicinity_count", "scan_bin", "vicinity_fill", "pd_tier_small", "pd_tier_medium", "pd_tier_large", "pd_tier_huge"]
+
+    def set_timing(self, on=True):
+        _lib.check(_lib.lib().tlc_pd_pi_batch_set_timing(self._h, C.c_int(1 if on else 0)), "set_timing")
+
+    def timings(self):
+        """ms per kernel of the last batch (HIP events on the stream each kernel ran on); -1 = not launched."""
+        out = (C.c_double * 8)()
+        _lib.check(_lib.lib().tlc_pd_pi_batch_timings(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr()), "timings")
+        return dict(zip(self.KERNELS, list(out)[:7]))
+
+    def sizes(self, n_pairs):
+        n = np.zeros(n_pairs, dtype=np.int32)
+        m2 = np.zeros(n_pairs, dtype=np.int32)
+        _lib.check(_lib.lib().tlc_pd_pi_batch_sizes(self._h, n.ctypes.data_as(C.c_void_p), m2.ctypes.data_as(C.c_void_p),
+                                                    C.c_int64(n_pairs), _lib.stream_ptr()), "sizes")
+        return n, m2
+
     def vicinity_filtration(self, pairs, hop, flags=0, cap=None):
         """-> (node_offs int64[E+1], ids int32[E*cap], f float64[E*cap], n int32[E], status uint8[E])"""
         import torch
@@ -125,3 +144,32 @@ def pi_raster(offs, pts, res=5):
                                   C.c_int(res), _lib.ptr(out), _lib.stream_ptr())
     _lib.check(rc, "tlc_pi_raster")
     return out[:B]
+
+
+# size tiers of the PD kernel (csrc/tlc_kernels.h)
+TIER_LIMITS = [("pd_tier_small", 64, 128), ("pd_tier_medium", 512, 1024), ("pd_tier_large", 2048, 4096)]
+
+
+def tier_of(n, m2):
+    """tier name per pair from (|S|, induced directed entries), mirroring tlc_scan_down; '' for pairs finished early."""
+    n = np.asarray(n)
+    m = np.asarray(m2) // 2
+    out = np.full(n.shape, "pd_tier_huge", dtype=object)
+    for name, nm, mm in reversed(TIER_LIMITS):
+        out[(n <= nm) & (m <= mm)] = name
+    out[n <= 0] = ""
+    return out
+
+
+def algorithmic_bytes(rowptr, col, pairs, hop, res=5):
+    """SURVEY.md 8(d) byte model per pair (host-side accounting through the C ABI; no GPU needed)."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    out = np.zeros(len(pairs), dtype=np.float64)
+    rc = _lib.lib().tlc_pd_pi_algorithmic_bytes(C.c_int32(len(rowptr) - 1), rowptr.ctypes.data_as(C.c_void_p),
+                                                col.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p),
+                                                C.c_int64(len(pairs)), C.c_int(hop), C.c_int(res),
+                                                out.ctypes.data_as(C.c_void_p))
+    _lib.check(rc, "tlc_pd_pi_algorithmic_bytes")
+    return out

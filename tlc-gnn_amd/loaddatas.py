@@ -1,0 +1,115 @@
+"""Drop-in for the path-facing part of the reference's loaddatas.py (/root/reference/loaddatas.py).
+
+  get_edges_split :26-35, get_adj_split :38-54, compute_persistence_image :56-103, compute_ricci_curvature :105-123.
+
+`compute_persistence_image` is the caller of the hot path: it fixes the order of the six
+pair lists, builds the graph FROM EDGES ONLY (isolated nodes are "missing"), takes weights kappa+1 and calls
+graph2pi(...).get_pimg_for_all_edges(hop, norm=True, extended_flag=True, resolution=5, descriptor='sum').
+Dataset download (`loaddatas`) and the Ollivier-Ricci solver are out of scope: curvature is an INPUT here
+(`data.ricci_list`, the reference's sorted [u, v, kappa] list).
+"""
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+from .sg2dgm import riccidist2dgm as sg2dgm
+
+
+def _edge_index_numpy(edge_index):
+    try:
+        import torch
+        if isinstance(edge_index, torch.Tensor):
+            return edge_index.detach().cpu().numpy()
+    except ImportError:  # pragma: no cover
+        pass
+    return np.asarray(edge_index)
+
+
+def get_edges_split(data, val_prop=0.2, test_prop=0.2, seed=1234):
+    """loaddatas.py:26-35: adjacency of the graph on nodes 0..len(data.y)-1 -> get_adj_split."""
+    n = len(data.y)
+    ei = _edge_index_numpy(data.edge_index).astype(np.int64)
+    # nx.Graph().add_edges_from + nx.adjacency_matrix: symmetric 0/1 matrix (a self loop is a single diagonal 1)
+    a = sp.coo_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(n, n)).tocsr()
+    a = ((a + a.T) > 0).astype(np.int64)
+    return get_adj_split(sp.csr_matrix(a), val_prop=val_prop, test_prop=test_prop, seed=seed)
+
+
+def get_adj_split(adj, val_prop=0.05, test_prop=0.1, seed=1234):
+    """loaddatas.py:38-54, statement for statement (same RNG stream, same orders).
+
+    Like the reference this materialises the dense complement `1. - adj.toarray()` (N x N float64): fine for the
+    plumbing-sized graphs it is tested on, 3.1 GB for PubMed -- replacing it is SURVEY.md §8(f) item 2.
+    """
+    np.random.seed(seed)  # get tp edges
+    x, y = sp.triu(adj).nonzero()
+    pos_edges = np.array(list(zip(x, y)))
+    np.random.shuffle(pos_edges)
+    # get tn edges
+    x, y = sp.triu(sp.csr_matrix(1. - adj.toarray())).nonzero()
+    neg_edges = np.array(list(zip(x, y)))
+    np.random.shuffle(neg_edges)
+
+    m_pos = len(pos_edges)
+    n_val = int(m_pos * val_prop)
+    n_test = int(m_pos * test_prop)
+    val_edges, test_edges, train_edges = pos_edges[:n_val], pos_edges[n_val:n_test + n_val], pos_edges[n_test + n_val:]
+    val_edges_false, test_edges_false = neg_edges[:n_val], neg_edges[n_val:n_test + n_val]
+    train_edges_false = np.concatenate([neg_edges, val_edges, test_edges], axis=0)
+    return train_edges, train_edges_false, val_edges, val_edges_false, test_edges, test_edges_false
+
+
+def compute_ricci_curvature(data):
+    """loaddatas.py:105-123 calls the third-party GraphRicciCurvature (Sinkhorn, alpha=0.5); that solver is the
+    step BEFORE the path.  Here the curvature must be supplied as `data.ricci_list`:
+    the reference's format, a sorted list of [u, v, kappa] holding both directions of every edge."""
+    ricci = getattr(data, "ricci_list", None)
+    if ricci is None:
+        raise NotImplementedError(
+            "compute_ricci_curvature: supply data.ricci_list ([[u, v, kappa], ...], both directions, sorted); the "
+            "Ollivier-Ricci solver is not part of the accelerated path (tlc_gnn_amd.synth.synthetic_curvature makes a "
+            "seeded stand-in)")
+    return ricci
+
+
+def compute_persistence_image(data, train_edges, train_edges_false, val_edges, val_edges_false, test_edges,
+                              test_edges_false, data_name, hop=1, cache_dir='./data/TLCGNN'):
+    """loaddatas.py:56-103.  Returns float64 [n_pairs, 25] (numpy, like the reference)."""
+    import torch
+    if data_name == "photo":
+        data_name = "Photo"
+    if data_name == "computers":
+        data_name = "Computers"
+
+    filename = os.path.join(cache_dir, data_name + '.npy') if cache_dir else None
+    if filename and os.path.exists(filename):
+        return np.load(filename)
+    total_edges = np.concatenate(
+        (train_edges, train_edges_false, val_edges, val_edges_false, test_edges, test_edges_false))
+    data.train_pos, data.train_neg = len(train_edges), len(train_edges_false)
+    data.val_pos, data.val_neg = len(val_edges), len(val_edges_false)
+    data.test_pos, data.test_neg = len(test_edges), len(test_edges_false)
+    data.total_edges = total_edges
+
+    # delete val_pos and test_pos (:73-86) -- a no-op when TLCGNN.call already did it
+    from .baselines.TLCGNN import remove_pairs_both_directions
+    data.edge_index = remove_pairs_both_directions(data.edge_index, np.concatenate((val_edges, test_edges)))
+    ei = data.edge_index.cpu().numpy()
+    ei = ei[:, ei[0] != ei[1]]                                   # remove_self_loops (:86,90)
+    data.edge_index = torch.from_numpy(ei).long()
+
+    # generate graph for computing persistence diagram: edges only, so isolated nodes do not exist (:88-92)
+    edges = ei.T
+    print(len(set(map(tuple, np.sort(edges, axis=1).tolist()))))  # len(g.edges()) (:93)
+
+    ricci_cur = compute_ricci_curvature(data)
+
+    # compute sg2dgm and save in a dict
+    pi = sg2dgm.graph2pi(edges, ricci_curv=ricci_cur)
+    pi.get_pimg_for_all_edges(total_edges, cores=16, hop=hop, norm=True, extended_flag=True,
+                              resolution=5, descriptor='sum')
+    if filename:
+        os.makedirs(os.path.dirname(filename), exist_ok=True)    # the reference never creates it and np.save fails
+        np.save(filename, pi.pi_sg)
+    return pi.pi_sg

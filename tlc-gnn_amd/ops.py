@@ -1,0 +1,120 @@
+"""Typed wrappers over the LP-forward / PDGNN entry points of the C ABI (include/tlcgnn.h).
+
+torch tensors in, torch tensors out; every call enqueues hand-written HIP kernels on the current stream.
+Forward only (no autograd): the path in scope is the link-prediction FORWARD.
+"""
+import ctypes as C
+
+from . import _lib
+
+
+def _f32(t):
+    import torch
+    assert t.is_cuda and t.dtype == torch.float32, "expected a float32 CUDA tensor"
+    return t.contiguous()
+
+
+def gcn_norm_csr(edge_index, num_nodes):
+    """gcn_norm of GCNConv(cached=True) (Knowledge_Distillation/PD_conv.py:35-70) as CSR by target.
+
+    edge_index: int64 CUDA [2,E] (row 0 source, row 1 target).  Returns (rowptr int32[N+1], col int32[nnz], val f32[nnz]).
+    """
+    torch = _lib.require_gpu()
+    assert edge_index.is_cuda and edge_index.dtype == torch.int64 and edge_index.shape[0] == 2
+    ei = edge_index.contiguous()
+    E = ei.shape[1]
+    dev = ei.device
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(E + num_nodes, dtype=torch.int32, device=dev)
+    val = torch.empty(E + num_nodes, dtype=torch.float32, device=dev)
+    nnz = torch.zeros(1, dtype=torch.int32, device=dev)
+    rc = _lib.lib().tlc_gcn_norm_csr(C.c_int32(num_nodes), C.c_int64(E), _lib.ptr(ei), _lib.ptr(rowptr), _lib.ptr(col),
+                                     _lib.ptr(val), _lib.ptr(nnz), _lib.stream_ptr())
+    _lib.check(rc, "tlc_gcn_norm_csr")
+    k = int(nnz.item())
+    return rowptr, col[:k].contiguous(), val[:k].contiguous()
+
+
+def gemm(a, b, bias=None, relu=False, out=None):
+    """C = A @ B (+bias)(ReLU) on the f32 MFMA; A [M,K], B [K,N<=128] float32 CUDA."""
+    torch = _lib.require_gpu()
+    a, b = _f32(a), _f32(b)
+    M, K = a.shape
+    K2, N = b.shape
+    assert K == K2
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    rc = _lib.lib().tlc_gemm_f32(C.c_int32(M), C.c_int32(N), C.c_int32(K), _lib.ptr(a), _lib.ptr(b),
+                                 _lib.ptr(_f32(bias)) if bias is not None else None, C.c_int(1 if relu else 0),
+                                 _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "tlc_gemm_f32")
+    return out
+
+
+def spmm(rowptr, col, val, x, bias=None, relu=False, out=None):
+    """Y = act(CSR @ X + bias): the normalised scatter-add of GCNConv as a row-owned gather."""
+    torch = _lib.require_gpu()
+    x = _f32(x)
+    n = rowptr.numel() - 1
+    k = x.shape[1]
+    if out is None:
+        out = torch.empty((n, k), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().tlc_spmm_csr_f32(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.ptr(x), C.c_int32(k),
+                                     _lib.ptr(_f32(bias)) if bias is not None else None, C.c_int(1 if relu else 0),
+                                     _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "tlc_spmm_csr_f32")
+    return out
+
+
+def renorm_rows_(emb):
+    """emb.renorm_(2, 0, 1) in place (baselines/TLCGNN.py:48)."""
+    emb_c = _f32(emb)
+    assert emb_c.data_ptr() == emb.data_ptr(), "renorm_rows_ needs a contiguous tensor (in place)"
+    rc = _lib.lib().tlc_renorm_rows_f32(C.c_int32(emb.shape[0]), C.c_int32(emb.shape[1]), _lib.ptr(emb), _lib.stream_ptr())
+    _lib.check(rc, "tlc_renorm_rows_f32")
+    return emb
+
+
+def lp_decode(pairs, emb, pi, w1, b1, w2, b2, out=None):
+    """Fused Net.decode tail (baselines/TLCGNN.py:52-61).  pairs int32 [E,2], emb f32 [N,D], pi f64 [E,P]."""
+    torch = _lib.require_gpu()
+    assert pairs.dtype == torch.int32 and pi.dtype == torch.float64
+    E = pairs.shape[0]
+    if out is None:
+        out = torch.empty(E, dtype=torch.float32, device=emb.device)
+    rc = _lib.lib().tlc_lp_decode_fused(C.c_int64(E), _lib.ptr(pairs.contiguous()), _lib.ptr(_f32(emb)), C.c_int32(emb.shape[1]),
+                                        _lib.ptr(pi.contiguous()), C.c_int32(pi.shape[1]), _lib.ptr(_f32(w1)), _lib.ptr(_f32(b1)),
+                                        _lib.ptr(_f32(w2).reshape(-1)), _lib.ptr(_f32(b2)), _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "tlc_lp_decode_fused")
+    return out
+
+
+def gat_layer(rowptr, src, x, wl, att, wij, bias, prelu_slope=-1.0, out=None):
+    """One PDGNN layer (Knowledge_Distillation/gat_conv.py:113-216) on a CSR-by-target batch."""
+    torch = _lib.require_gpu()
+    x = _f32(x)
+    n, c_in = x.shape
+    c_out = wl.shape[0]
+    if out is None:
+        out = torch.empty((n, 2 * c_out), dtype=torch.float32, device=x.device)
+    work = torch.empty(max(n, 1) * (3 * c_out + 1), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().tlc_gat_layer_fwd(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(src), _lib.ptr(x), C.c_int32(c_in),
+                                      C.c_int32(c_out), _lib.ptr(_f32(wl)), _lib.ptr(_f32(att).reshape(-1)), _lib.ptr(_f32(wij)),
+                                      _lib.ptr(_f32(bias)), C.c_float(prelu_slope), _lib.ptr(work), _lib.ptr(out),
+                                      _lib.stream_ptr())
+    _lib.check(rc, "tlc_gat_layer_fwd")
+    return out
+
+
+def edge_head(src, dst, x, w5, b5, prelu_slope, w6, b6, out=None):
+    """Edge head of Teacher_Model.forward (Knowledge_Distillation/Teacher_model.py:54-59) -> f32 [E,2]."""
+    torch = _lib.require_gpu()
+    x = _f32(x)
+    E = src.numel()
+    if out is None:
+        out = torch.empty((E, 2), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().tlc_edge_head_fwd(C.c_int64(E), _lib.ptr(src), _lib.ptr(dst), _lib.ptr(x), C.c_int32(x.shape[1]),
+                                      _lib.ptr(_f32(w5)), _lib.ptr(_f32(b5)), C.c_int32(w5.shape[0]), C.c_float(prelu_slope),
+                                      _lib.ptr(_f32(w6)), _lib.ptr(_f32(b6)), _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "tlc_edge_head_fwd")
+    return out

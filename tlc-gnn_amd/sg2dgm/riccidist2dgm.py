@@ -1,0 +1,124 @@
+"""Drop-in for the accelerated path of the reference's sg2dgm/riccidist2dgm.py.
+
+  graph2pi.__init__ :216-226, get_pimg_for_one_edge :348-357, get_pimg_for_all_edges :362-370,
+  sg2dgm_accelerate :310-329, filtration.build_fv :20-61.
+
+The whole per-pair pipeline (vicinity -> filtration -> extended persistence -> persistence image) runs as
+hand-written HIP kernels behind `tlc_pd_pi_batch` (include/tlcgnn.h).  Only the accelerated path is provided; the
+dionysus path (graph2dgm, sg2pimg, get_pimg) is never called by the reference's pipeline and is not reproduced.
+"""
+import numpy as np
+
+from .. import engine, _lib
+
+
+def _edge_array(g):
+    """edges of a networkx-like graph (anything with .edges()) or an [M,2] array, in iteration order."""
+    if hasattr(g, "edges") and callable(getattr(g, "edges")):
+        e = [(a, b) for a, b in g.edges()]
+        return np.array(e, dtype=np.int64).reshape(-1, 2)
+    return np.asarray(g, dtype=np.int64).reshape(-1, 2)
+
+
+class graph2pi():
+    def __init__(self, g, ricci_curv):
+        # nx.convert_node_labels_to_integers(g, label_attribute="old_label") + dict_node (:217-220):
+        # labels in first-seen order.  Relabelling only permutes ties; diagrams are compared as multisets.
+        edges = _edge_array(g)
+        self.dict_node = {}
+        for a, b in edges.tolist():
+            if a not in self.dict_node:
+                self.dict_node[a] = len(self.dict_node)
+            if b not in self.dict_node:
+                self.dict_node[b] = len(self.dict_node)
+        n = len(self.dict_node)
+        self.n_nodes = n
+        # ricci_curv: [[u, v, kappa], ...] with both directions (:221-226); edge weight = kappa + 1
+        self.ricci_curv = {}
+        for i in ricci_curv:
+            if int(i[0]) not in self.dict_node or int(i[1]) not in self.dict_node:
+                continue          # curvature entry of an edge that is not in this graph (e.g. a removed val/test positive)
+            u, v = self.dict_node[int(i[0])], self.dict_node[int(i[1])]
+            self.ricci_curv[(u, v)] = float(i[2])
+            self.ricci_curv[(v, u)] = float(i[2])
+        und = {}
+        for a, b in edges.tolist():
+            u, v = self.dict_node[a], self.dict_node[b]
+            if u == v:
+                continue
+            und[(min(u, v), max(u, v))] = True
+        src = np.array([k[0] for k in und] + [k[1] for k in und], dtype=np.int64)
+        dst = np.array([k[1] for k in und] + [k[0] for k in und], dtype=np.int64)
+        try:
+            w = np.array([self.ricci_curv[(int(a), int(b))] + 1 for a, b in zip(src, dst)], dtype=np.float64)
+        except KeyError as e:
+            raise KeyError("graph2pi: edge %s has no curvature entry" % (e,))
+        order = np.lexsort((dst, src))
+        src, dst, w = src[order], dst[order], w[order]
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(rowptr, src + 1, 1)
+        self._csr = (np.cumsum(rowptr).astype(np.int32), dst.astype(np.int32), np.ascontiguousarray(w))
+        self._dev = None
+        self.pi_sg = None
+        self.cnt_compute = 0
+        self.status = None
+
+    def _device_graph(self):
+        if self._dev is None:
+            self._dev = engine.DeviceGraph(*self._csr)
+        return self._dev
+
+    def _map_pairs(self, total_edges):
+        te = np.asarray(total_edges).reshape(-1, 2)
+        get = self.dict_node.get
+        return np.array([[get(int(a), -1), get(int(b), -1)] for a, b in te.tolist()], dtype=np.int32).reshape(-1, 2)
+
+    def get_pimg_for_all_edges(self, total_edges, cores, hop=2, norm=True, extended_flag=False, resolution=5, descriptor='min'):
+        """Fills self.pi_sg (float64 [n_pairs, resolution**2]) and self.cnt_compute like :362-370.
+
+        `cores` is accepted for signature compatibility (the reference's ThreadPool is GIL-bound and racy; here every
+        pair is one independent wavefront/workgroup).  `norm` is ignored exactly as the reference ignores it (:353
+        hard-wires norm=True).  Only descriptor='sum' -- the one the pipeline uses (loaddatas.py:101) -- is implemented.
+        """
+        if descriptor != 'sum':
+            raise NotImplementedError("graph2pi: only descriptor='sum' is implemented on the HIP path")
+        import torch
+        dev_graph = self._device_graph()
+        pairs = torch.from_numpy(self._map_pairs(total_edges)).cuda()
+        flags = 0 if extended_flag else _lib.NO_EXT1
+        out, status = dev_graph.pd_pi_batch(pairs, hop, flags=flags, res=resolution)
+        self.pi_sg = out.cpu().numpy()
+        self.status = status.cpu().numpy()
+        self.cnt_compute = int((self.status == _lib.ST_OK).sum())
+        return self.pi_sg
+
+    def get_pimg_for_one_edge(self, u, v, hop=2, norm=True, extended_flag=False, resolution=5, descriptor='min', cnt=0):
+        """:348-357 -- one row; every failure class of the reference gives zeros."""
+        row = self.get_pimg_for_all_edges([[u, v]], 1, hop=hop, norm=True, extended_flag=extended_flag,
+                                          resolution=resolution, descriptor=descriptor)[0]
+        return row
+
+    def sg2dgm_accelerate(self, u, v, hop, extended_flag=False, descriptor="seal", resolution=5, norm=False, cnt=0):
+        """:310-329 with already-relabelled ids (u, v are NEW labels, as in the reference); returns [res,res].
+
+        Raises the reference's exception classes for the four zero-row conditions.  norm=True only.
+        """
+        if not norm:
+            raise NotImplementedError("sg2dgm_accelerate: only norm=True (what get_pimg_for_one_edge passes) is implemented")
+        if descriptor != 'sum':
+            raise NotImplementedError("only descriptor='sum' is implemented on the HIP path")
+        import torch
+        pairs = torch.tensor([[int(u), int(v)]], dtype=torch.int32, device="cuda")
+        out, st = self._device_graph().pd_pi_batch(pairs, hop, flags=0 if extended_flag else _lib.NO_EXT1, res=resolution)
+        st = int(st.item())
+        if st == _lib.ST_MISSING_NODE:
+            raise KeyError((u, v))
+        if st == _lib.ST_DISCONNECTED:
+            raise AssertionError()
+        if st == _lib.ST_ZERO_RANGE:
+            raise ZeroDivisionError("float division by zero")
+        if st == _lib.ST_NO_TREE_EDGE:
+            raise IndexError("list index out of range")
+        if st != _lib.ST_OK:
+            raise RuntimeError("vicinity too large for the packed local ids (status %d)" % st)
+        return out.cpu().numpy().reshape(resolution, resolution)

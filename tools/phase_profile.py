@@ -1,0 +1,27 @@
+"""Per-phase cycle shares of the PD tier kernels (diagnostic: thread 0's clock64 deltas, summed over workgroups)."""
+import ctypes as C, sys
+import numpy as np, torch
+sys.path.insert(0, ".")
+from tlc_gnn_amd import engine, synth, _lib
+
+NAMES = ["load", "bellman-ford", "tight+chain", "tie fallback", "normalise+edges", "sort asc", "uf asc", "sort desc",
+         "uf desc", "tree bfs", "ext1 serial", "image", "TOTAL", "max per wg", "n wg"]
+n, e, k, hop, _ = synth.shaped_graph("PubMed")
+rowptr, col, w = synth.edges_to_csr(n, e, k)
+g = engine.DeviceGraph(rowptr, col, w)
+rs = np.random.RandomState(7)
+pairs = torch.as_tensor(e[rs.permutation(len(e))[:37676]].astype(np.int32)).cuda()
+L = _lib.lib()
+L.tlc_debug_phase_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+g.pd_pi_batch(pairs, 2)
+L.tlc_debug_phase_profile(g._h, 1, None)
+g.pd_pi_batch(pairs, 2)
+buf = (C.c_uint64 * 64)()
+L.tlc_debug_phase_profile(g._h, 0, C.cast(buf, C.c_void_p))
+a = np.array(list(buf), dtype=np.float64).reshape(4, 16)
+for t, tn in enumerate(["small", "medium", "large", "huge"]):
+    if a[t, 14] == 0:
+        continue
+    print("tier %s: %d workgroups, mean %.0f cycles, max %.0f cycles" % (tn, a[t, 14], a[t, 12] / a[t, 14], a[t, 13]))
+    for i in range(12):
+        print("   %-16s %6.2f %%   mean %9.0f" % (NAMES[i], 100 * a[t, i] / max(a[t, 12], 1), a[t, i] / a[t, 14]))
