@@ -1,0 +1,122 @@
+"""CPU: host logic, the C-ABI library surface, generators, sharding helpers (no GPU compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from tlc_gnn_amd import _lib
+    L = _lib.lib()
+    header = open(os.path.join(ROOT, "include", "tlcgnn.h")).read()
+    declared = sorted(set(re.findall(r"\b(tlc_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations parsed"
+    for sym in declared:
+        assert hasattr(L, sym), "libtlcgnn_hip.so does not export %s" % sym
+    assert sorted(_lib.SYMBOLS) == declared
+    assert L.tlc_version().startswith(b"tlcgnn-hip")
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from tlc_gnn_amd import engine, _lib
+    rowptr = np.array([0, 1, 2], dtype=np.int32)
+    with pytest.raises(_lib.TlcError):
+        engine.DeviceGraph(rowptr, np.array([1, 0], dtype=np.int32), np.array([1.0, 1.0]))
+    # the C ABI itself reports "no device" instead of computing on the CPU
+    h = C.c_void_p()
+    col = np.array([1, 0], dtype=np.int32)
+    w = np.array([1.0, 1.0])
+    rc = _lib.lib().tlc_graph_create(C.c_int32(2), rowptr.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
+                                     w.ctypes.data_as(C.c_void_p), C.c_int(0), C.byref(h))
+    assert rc == 3 and not h.value          # TLC_ERR_NO_DEVICE
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "tlc-gnn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("no oracle", ""), "%s mentions the oracle" % f
+
+
+def test_get_adj_split_matches_reference_golden_g7():
+    import scipy.sparse as sp
+    from tlc_gnn_amd import loaddatas
+    d = np.load(os.path.join(G, "adj_split.npz"))
+    n, edges = int(d["n_nodes"]), d["edges"]
+    a = sp.coo_matrix((np.ones(len(edges)), (edges[:, 0], edges[:, 1])), shape=(n, n))
+    parts = loaddatas.get_adj_split(sp.csr_matrix(a + a.T), val_prop=0.05, test_prop=0.1, seed=1234)
+    names = ["train_edges", "train_edges_false", "val_edges", "val_edges_false", "test_edges", "test_edges_false"]
+    for name, p in zip(names, parts):
+        assert np.array_equal(np.asarray(p), d[name]), name
+
+
+def test_remove_pairs_both_directions_like_list_remove():
+    import torch
+    from tlc_gnn_amd.baselines.TLCGNN import remove_pairs_both_directions
+    ei = torch.tensor([[0, 1, 1, 2, 0, 1, 3, 2], [1, 0, 2, 1, 1, 0, 2, 3]])
+    out = remove_pairs_both_directions(ei, np.array([[0, 1], [2, 3], [7, 7]]))
+    # reference: edge_list.remove([0,1]); edge_list.remove([1,0]) removes the FIRST occurrences only
+    ref = np.array(ei).T.tolist()
+    for e in ([0, 1], [2, 3]):
+        ref.remove(e)
+        ref.remove(e[::-1])
+    assert out.T.tolist() == ref
+
+
+def test_synthetic_generator_is_deterministic_and_shaped():
+    from tlc_gnn_amd import synth
+    n, e, k, hop, f = synth.shaped_graph("PubMed", scale=0.05)
+    n2, e2, k2, _, _ = synth.shaped_graph("PubMed", scale=0.05)
+    assert np.array_equal(e, e2) and np.array_equal(k, k2)
+    assert len(np.unique(e, axis=0)) == len(e) and (e[:, 0] < e[:, 1]).all()
+    rowptr, col, w = synth.edges_to_csr(n, e, k)
+    assert rowptr[-1] == 2 * len(e) and (w > 0).all()
+    ricci = synth.synthetic_curvature(e)
+    assert len(ricci) == 2 * len(e) and ricci == sorted(ricci)
+
+
+def test_algorithmic_bytes_model_matches_oracle_accounting():
+    from tlc_gnn_amd import synth, engine
+    from oracle import oracle
+    n, e, k, hop, _ = synth.shaped_graph("PubMed", scale=0.1)
+    rowptr, col, w = synth.edges_to_csr(n, e, k)
+    pairs = np.concatenate([e[:300], np.random.RandomState(0).randint(0, n, size=(100, 2))]).astype(np.int32)
+    b = engine.algorithmic_bytes(rowptr, col, pairs, 2)
+    tot, sn, sm = oracle.algorithmic_bytes(rowptr, col, pairs, 2)
+    assert abs(b.sum() - tot) < 1e-6
+    assert (b >= 8 + 200).all()
+
+
+def test_tier_classification_mirrors_kernel_constants():
+    from tlc_gnn_amd import engine
+    hdr = open(os.path.join(ROOT, "tlc-gnn_amd", "csrc", "tlc_kernels.h")).read()
+    vals = {k: int(v) for k, v in re.findall(r"#define (TLC_[SML]_[NM]MAX) (\d+)", hdr)}
+    assert engine.TIER_LIMITS == [("pd_tier_small", vals["TLC_S_NMAX"], vals["TLC_S_MMAX"]),
+                                  ("pd_tier_medium", vals["TLC_M_NMAX"], vals["TLC_M_MMAX"]),
+                                  ("pd_tier_large", vals["TLC_L_NMAX"], vals["TLC_L_MMAX"])]
+    t = engine.tier_of(np.array([0, 10, 64, 65, 512, 513, 3000]), np.array([0, 20, 256, 10, 2048, 10, 10]))
+    assert t.tolist() == ["", "pd_tier_small", "pd_tier_small", "pd_tier_medium", "pd_tier_medium", "pd_tier_large", "pd_tier_huge"]
+
+
+def test_shard_helpers():
+    from tlc_gnn_amd import dist as tdist
+    for n, w in ((10, 3), (19717, 8), (5, 8), (0, 2)):
+        b = [tdist.shard_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+    cost = np.array([1, 1, 1, 100, 1, 1, 1, 1])
+    bounds = tdist.shard_pairs_by_cost(cost, 2)
+    assert bounds[0] == 0 and bounds[-1] == len(cost) and 0 < bounds[1] < len(cost)
