@@ -270,13 +270,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
 
     const int todo = tc[0] + tc[1] + tc[2] + tc[3];
     if (todo > 0) {
-        TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl + 4, 0, sizeof(int), s));
         vp.A_dir = g->A_dir; vp.A_lw = g->A_lw;
-        T0(2, s);
-        hipLaunchKernelGGL(tlc_vicinity_kernel<true>, dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
-        T1(2, s);
-        TLC_HIP_CHECK(hipGetLastError());
-
         TlcPdParams pp;
         memset(&pp, 0, sizeof(pp));
         pp.hdr_n = g->hdr_n; pp.hdr_m2 = g->hdr_m2; pp.hdr_lu = g->hdr_lu; pp.hdr_lv = g->hdr_lv;
@@ -286,28 +280,52 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         pp.huge_scratch = g->huge_scratch; pp.huge_stride = (long long)g->huge_stride;
         pp.huge_nmax = std::min(g->n_nodes, 65535); pp.huge_mmax = (int)(g->nnz / 2 + 1); pp.huge_slots = g->huge_slots;
         pp.stats = g->d_stats;
-        // fork: heavy tiers first, each on its own stream; the small tier stays on the caller's stream
-        TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s));
-        const int order[3] = {TLC_TIER_HUGE, TLC_TIER_LARGE, TLC_TIER_MEDIUM};
         bool used[TLC_N_SIDE] = {false, false, false};
-        for (int k = 0; k < 3; ++k) {
-            const int t = order[k];
-            if (tc[t] <= 0) continue;
+        auto launch_side = [&](int k, int t) -> int {
+            TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s));
             TLC_HIP_CHECK(hipStreamWaitEvent(g->side[k], g->ev_fork, 0));
             pp.tier_list = g->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
             pp.phase_cycles = g->d_phase ? g->d_phase + 16 * t : nullptr;
             T0(3 + t, g->side[k]);
-            if ((rc = tlc_launch_pd_tier(t, pp, g->side[k])) != TLC_OK) return rc;
+            int r = tlc_launch_pd_tier(t, pp, g->side[k]);
+            if (r != TLC_OK) return r;
             T1(3 + t, g->side[k]);
             TLC_HIP_CHECK(hipEventRecord(g->ev_join[k], g->side[k]));
             used[k] = true;
+            return TLC_OK;
+        };
+        // 1. the heavy tiers first: their subgraphs are filled by a small early pass so that the long serial tails of the
+        //    largest vicinities start as soon as possible and overlap everything else
+        const int heavy = tc[TLC_TIER_LARGE] + tc[TLC_TIER_HUGE];
+        if (heavy > 0) {
+            T0(2, s);
+            for (int t = TLC_TIER_LARGE; t <= TLC_TIER_HUGE; ++t) {
+                if (tc[t] <= 0) continue;
+                TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl + 4, 0, sizeof(int), s));
+                vp.fill_mode = 1; vp.fill_list = g->tier_list + (size_t)t * n_pairs; vp.fill_count = tc[t];
+                hipLaunchKernelGGL(tlc_vicinity_kernel<true>, dim3(std::min(tc[t], g->vic_slots)), dim3(TLC_WAVE), g->vic_lds, s, vp);
+                TLC_HIP_CHECK(hipGetLastError());
+                if ((rc = launch_side(t == TLC_TIER_HUGE ? 0 : 1, t)) != TLC_OK) return rc;
+            }
         }
-        pp.tier_list = g->tier_list + (size_t)TLC_TIER_SMALL * n_pairs; pp.tier_count = tc[TLC_TIER_SMALL];
-        pp.phase_cycles = g->d_phase ? g->d_phase + 16 * TLC_TIER_SMALL : nullptr;
-        if (tc[TLC_TIER_SMALL] > 0) T0(3 + TLC_TIER_SMALL, s);
-        if ((rc = tlc_launch_pd_tier(TLC_TIER_SMALL, pp, s)) != TLC_OK) return rc;
-        if (tc[TLC_TIER_SMALL] > 0) T1(3 + TLC_TIER_SMALL, s);
-        for (int k = 0; k < 3; ++k)
+        // 2. everything else
+        if (tc[TLC_TIER_SMALL] + tc[TLC_TIER_MEDIUM] > 0) {
+            TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl + 4, 0, sizeof(int), s));
+            vp.fill_mode = heavy > 0 ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
+            if (heavy == 0) T0(2, s);
+            hipLaunchKernelGGL(tlc_vicinity_kernel<true>, dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
+            T1(2, s);
+            TLC_HIP_CHECK(hipGetLastError());
+            if (tc[TLC_TIER_MEDIUM] > 0 && (rc = launch_side(2, TLC_TIER_MEDIUM)) != TLC_OK) return rc;
+            pp.tier_list = g->tier_list + (size_t)TLC_TIER_SMALL * n_pairs; pp.tier_count = tc[TLC_TIER_SMALL];
+            pp.phase_cycles = g->d_phase ? g->d_phase + 16 * TLC_TIER_SMALL : nullptr;
+            if (tc[TLC_TIER_SMALL] > 0) T0(3 + TLC_TIER_SMALL, s);
+            if ((rc = tlc_launch_pd_tier(TLC_TIER_SMALL, pp, s)) != TLC_OK) return rc;
+            if (tc[TLC_TIER_SMALL] > 0) T1(3 + TLC_TIER_SMALL, s);
+        } else if (heavy > 0) {
+            T1(2, s);
+        }
+        for (int k = 0; k < TLC_N_SIDE; ++k)
             if (used[k]) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_join[k], 0));
     }
 #undef T0

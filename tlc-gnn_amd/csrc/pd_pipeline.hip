@@ -47,22 +47,42 @@ __host__ __device__ constexpr int pow2ceil(int x) {
 __host__ __device__ constexpr size_t smax(size_t a, size_t b) { return a > b ? a : b; }
 
 // Region layout of one subgraph's state; constexpr for the LDS tiers, evaluated at run time for HUGE.
+// Regions are aliased by phase:
+//   x region : [dist from v | tight-successor tables]  (filtration)
+//              [sort keys u64 | sort payload u32]       (the three sorts)
+//              [first/hook u32 | best u32 | comp2 | tree bits | R bits] in the key half between the sorts (MST passes),
+//              then [edge rank of each node's parent edge u32] (cycle swap)
+//   dir region: directed entries, then [undirected edges (lo<<16|hi in rank space) | ascending rank of every edge],
+//              then (with lw) the image table
 struct Layout {
-    size_t o_f, o_dir, o_lw, o_x, o_amb, o_par, o_mark, o_pn, o_pts, o_ctl, total;
+    size_t o_f, o_dir, o_lw, o_x, o_vals, o_amb, o_par, o_mark, o_pn, o_pts, o_ctl, total;
+    int P;   // capacity of the sort buffers (power of two >= max(NM, MM))
 };
+__host__ __device__ constexpr size_t aux_bytes(int NM, int MM, int idxb) {
+    return (size_t)NM * 8 + al16((size_t)NM * idxb) + 2 * al16((size_t)((MM + 31) / 32) * 4);
+}
 __host__ __device__ constexpr Layout make_layout(int NM, int MM, bool lwl, int idxb, size_t min_table = 0) {
     Layout L{};
     size_t o = 0;
-    L.o_f = o;    o += al16((size_t)(NM + 2) * 8);                      // BF distances from u, then f (+min,max)
-    L.o_dir = o;  o += al16((size_t)2 * MM * 4);                        // directed entries src<<16|dst
+    L.P = pow2ceil(NM > MM ? NM : MM);
+    L.o_f = o;    o += al16((size_t)(NM + 2) * 8);                      // BF distances from u, then f
+    L.o_dir = o;  o += al16((size_t)2 * MM * 4);                        // directed entries | later: edges + asc ranks
     L.o_lw = o;   o += lwl ? al16((size_t)2 * MM * 8) : 0;              // entry weights (dir|lw also host the PI table)
     if (o - L.o_dir < min_table) o = L.o_dir + al16(min_table);         // the image table needs >= 1 point
-    L.o_x = o;    o += al16(smax((size_t)NM * 8 + (size_t)4 * NM * 4,   // [dist from v | cnt/nxt x2]
-                                 (size_t)pow2ceil(MM) * 12));           // or [sort keys | sort payload]
+    const size_t keys = al16(smax((size_t)L.P * 8, aux_bytes(NM, MM, idxb)));
+    L.o_x = o;
+    L.o_vals = o + keys;
+    o += al16(smax((size_t)NM * 8 + (size_t)4 * NM * 4, keys + (size_t)L.P * 4));
+    // the cycle swap re-uses everything from o_x up to o_pn: par, key, mark (u32) and two u64 tables per node
+    {
+        const size_t have = (o - L.o_x) + 3 * al16((size_t)NM * idxb);
+        const size_t need = (size_t)NM * 28 + 16;
+        if (have < need) o += al16(need - have);
+    }
     L.o_amb = o;  o += al16((size_t)NM * idxb);                         // tie-fallback list, then union-find parents
     L.o_par = o;  o += al16((size_t)NM * idxb);                         // spanning-tree parents
-    L.o_mark = o; o += al16((size_t)NM * idxb);                         // path stamps
-    L.o_pn = o;   o += al16((size_t)MM * 4);                            // Pos from the front, Neg from the back
+    L.o_mark = o; o += al16((size_t)NM * idxb);                         // node ranks, then path stamps
+    L.o_pn = o;   o += al16((size_t)MM * 4);                            // Pos from the front, Neg from the back (edge ids)
     L.o_pts = o;  o += al16((size_t)(MM + 2) * 4);                      // diagram points (birth node<<16 | death node)
     L.o_ctl = o;  o += 256;
     L.total = o;
@@ -72,19 +92,26 @@ __host__ __device__ constexpr Layout make_layout(int NM, int MM, bool lwl, int i
 template <typename idx_t>
 struct Mem {
     double* f;
-    unsigned* dir;
+    unsigned* dir;     // phase 1: directed entries; afterwards ends[e] = lo<<16|hi (rank space)
+    unsigned* arank;   // ascending-sort position of edge e
     double* lw;
     ull* dv;
     unsigned *cntU, *nxtU, *cntV, *nxtV;
     ull* keyS;
     unsigned* valS;
+    // MST-pass scratch inside the key half of the sort buffers
+    unsigned *first, *best;
+    idx_t* comp2;
+    unsigned *tbits, *rbits;
+    unsigned* ekey;    // cycle swap: ascending rank of the edge (node, parent[node])
     idx_t *amb, *comp, *par, *mark;
     unsigned *pn, *pts;
-    int* ctl;      // [0] changed [1] namb [2] npts [3] npos [4] nneg [5] progress [6] n_up [7] n_down
+    int* ctl;      // [0] flag [1] namb [2] npts [3] npos [4] nneg [5] flag2 [6] n_up [7] n_down [8] n_one
     double* red;   // 16 doubles for block reductions
     int* wcnt;     // 16 ints for block compaction
     unsigned char* table;  // PI table: spans dir (+lw)
     size_t table_bytes;
+    int P;
 };
 
 template <typename idx_t>
@@ -92,6 +119,7 @@ __device__ __forceinline__ Mem<idx_t> carve(unsigned char* base, const Layout& L
     Mem<idx_t> m;
     m.f = (double*)(base + L.o_f);
     m.dir = (unsigned*)(base + L.o_dir);
+    m.arank = m.dir + MM;
     m.lw = (double*)(base + L.o_lw);
     m.dv = (ull*)(base + L.o_x);
     m.cntU = (unsigned*)(base + L.o_x + (size_t)NM * 8);
@@ -99,7 +127,13 @@ __device__ __forceinline__ Mem<idx_t> carve(unsigned char* base, const Layout& L
     m.cntV = m.nxtU + NM;
     m.nxtV = m.cntV + NM;
     m.keyS = (ull*)(base + L.o_x);
-    m.valS = (unsigned*)(base + L.o_x + (size_t)pow2ceil(MM) * 8);
+    m.valS = (unsigned*)(base + L.o_vals);
+    m.first = (unsigned*)(base + L.o_x);
+    m.best = m.first + NM;
+    m.comp2 = (idx_t*)(base + L.o_x + (size_t)NM * 8);
+    m.tbits = (unsigned*)(base + L.o_x + (size_t)NM * 8 + al16((size_t)NM * sizeof(idx_t)));
+    m.rbits = m.tbits + al16((size_t)((MM + 31) / 32) * 4) / 4;
+    m.ekey = m.first;
     m.amb = (idx_t*)(base + L.o_amb);
     m.comp = m.amb;
     m.par = (idx_t*)(base + L.o_par);
@@ -111,6 +145,7 @@ __device__ __forceinline__ Mem<idx_t> carve(unsigned char* base, const Layout& L
     m.wcnt = (int*)(base + L.o_ctl + 192);
     m.table = base + L.o_dir;
     m.table_bytes = L.o_x - L.o_dir;
+    m.P = L.P;
     return m;
 }
 
@@ -224,183 +259,475 @@ __device__ __forceinline__ int uf_find(idx_t* comp, int p) {
     return p;
 }
 
-// Where the serial passes put the diagram points.  Only thread 0 calls these.
-// Batch path: node-index pairs into LDS (every PD coordinate is a copy of some f[node]).
+__device__ __forceinline__ double key_to_f64(ull k) {
+    const ull b = (k >> 63) ? (k ^ (1ull << 63)) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// W-thread barrier-separated "did any thread set the flag" on ctl[slot]
+template <int W>
+__device__ __forceinline__ bool block_any(bool v, int* ctl, int slot) {
+    if (W == 64) return __ballot(v) != 0ull;
+    if (threadIdx.x == 0) ctl[slot] = 0;
+    __syncthreads();
+    if (v) ctl[slot] = 1;
+    __syncthreads();
+    const int r = ctl[slot];
+    __syncthreads();
+    return r != 0;
+}
+
+// pointer jumping until every node points at its root
+template <int W, typename idx_t>
+__device__ __forceinline__ void flatten(idx_t* comp, int n, int* ctl) {
+    for (int it = 0; it < 32; ++it) {
+        bool ch = false;
+        for (int y = threadIdx.x; y < n; y += W) {
+            const int c = comp[y];
+            const int cc = comp[c];
+            if (cc != c) { comp[y] = (idx_t)cc; ch = true; }
+        }
+        __syncthreads();
+        if (!block_any<W>(ch, ctl, 0)) break;
+    }
+}
+
+// Where the diagram points go.  Counters live in LDS (ctl[6..8], ctl[2]) so that parallel and serial code share them.
+// Batch path: node-index pairs (rank space) into LDS: every PD coordinate is a copy of some f[node].
 struct PtsSink {
     unsigned* pts;
-    int np, n_up, n_down, n_one;
-    __device__ __forceinline__ void up(const double*, int birth, int death) { pts[np++] = ((unsigned)birth << 16) | (unsigned)death; ++n_up; }
-    __device__ __forceinline__ void ext0(const double*, int mn, int mx) { pts[np++] = ((unsigned)mn << 16) | (unsigned)mx; }
+    int* ctl;
+    static constexpr bool want_down = false, is_global = false;
+    __device__ __forceinline__ void up(const double*, int b, int d) { pts[ctl[2]++] = ((unsigned)b << 16) | (unsigned)d; ctl[6]++; }
+    __device__ __forceinline__ void ext0(const double*, int mn, int mx) { pts[ctl[2]++] = ((unsigned)mn << 16) | (unsigned)mx; }
     __device__ __forceinline__ void down(const double*, int, int) {}
-    __device__ __forceinline__ void one(const double*, int birth, int death) { pts[np++] = ((unsigned)birth << 16) | (unsigned)death; ++n_one; }
-    static constexpr bool want_down = false;
+    __device__ __forceinline__ void one_at(const double*, int slot, int, int b, int d) { pts[slot] = ((unsigned)b << 16) | (unsigned)d; }
 };
 // tlc_pd_from_filtration: values straight to the caller's arrays.
 struct GlobalSink {
     double *pd_up, *pd_down, *pd_one, *e0;
-    int np, n_up, n_down, n_one;
-    __device__ __forceinline__ void up(const double* f, int b, int d) { pd_up[2 * n_up] = f[b]; pd_up[2 * n_up + 1] = f[d]; ++n_up; }
+    int* ctl;
+    static constexpr bool want_down = true, is_global = true;
+    __device__ __forceinline__ void up(const double* f, int b, int d) { const int k = ctl[6]++; pd_up[2 * k] = f[b]; pd_up[2 * k + 1] = f[d]; }
     __device__ __forceinline__ void ext0(const double* f, int mn, int mx) { e0[0] = f[mn]; e0[1] = f[mx]; }
-    __device__ __forceinline__ void down(const double* f, int b, int d) { pd_down[2 * n_down] = f[b]; pd_down[2 * n_down + 1] = f[d]; ++n_down; }
-    __device__ __forceinline__ void one(const double* f, int b, int d) { pd_one[2 * n_one] = f[b]; pd_one[2 * n_one + 1] = f[d]; ++n_one; }
-    static constexpr bool want_down = true;
+    __device__ __forceinline__ void down(const double* f, int b, int d) { const int k = ctl[7]++; pd_down[2 * k] = f[b]; pd_down[2 * k + 1] = f[d]; }
+    __device__ __forceinline__ void one_at(const double* f, int, int k, int b, int d) { pd_one[2 * k] = f[b]; pd_one[2 * k + 1] = f[d]; }
 };
 
-// The two union-find passes on a subgraph whose f[0..n) is final (f[n] = min, f[n+1] = max).
-// valS[0..m) holds one payload per undirected edge: the packed endpoints a<<16|b (EID=false) or an edge id into
-// M.dir[] (EID=true).  On return ctl[3] = #Pos, ctl[4] = #Neg, pn[] = Pos from the front / Neg from the back
-// (payloads, in descending-pass order).
-template <int W, typename idx_t, bool EID, class Sink>
-__device__ __forceinline__ void pd_stages(Mem<idx_t>& M, Sink& sink, int n, int m, int P, unsigned flags, int MMcap,
-                                          ull* pc, ull& t_prev) {
+// ---- relabel the nodes by ascending f (stable for ties) and move the edges to rank space -------------------------------
+// After this f[0] = min, f[n-1] = max, every comparison of f values between nodes is an index comparison, and
+// ends[e] = lo<<16 | hi with lo < hi the two ranks of edge e.  M.mark holds rank[node] until the cycle swap reuses it.
+template <int W, typename idx_t>
+__device__ __forceinline__ void relabel_by_rank(Mem<idx_t>& M, int n, int m) {
     const int tid = threadIdx.x;
-    const bool keep0 = (flags & TLC_KEEP_ZERO_PERS) != 0;
-    double* f = M.f;
-    auto ends = [&](unsigned v) -> unsigned { return EID ? M.dir[v] : v; };
-    // ---- ascending keys ----------------------------------------------------------------------------------------------
+    const int Pn = pow2ceil(n < 2 ? 2 : n);
+    for (int i = tid; i < Pn; i += W) {
+        M.keyS[i] = i < n ? f64_key(M.f[i]) : ~0ull;
+        M.valS[i] = (unsigned)i;
+    }
+    __syncthreads();
+    bitonic_sort<W>(M.keyS, M.valS, Pn);
+    for (int r = tid; r < n; r += W) {
+        M.f[r] = key_to_f64(M.keyS[r]);
+        M.mark[M.valS[r]] = (idx_t)r;
+    }
+    __syncthreads();
+    for (int e = tid; e < m; e += W) {
+        const unsigned ab = M.dir[e];
+        const unsigned ra = M.mark[ab >> 16], rb = M.mark[ab & 0xffffu];
+        M.dir[e] = ra < rb ? ((ra << 16) | rb) : ((rb << 16) | ra);
+    }
+    __syncthreads();
+}
+
+// sort the m edges by the ascending (DESC=false) or descending (DESC=true) perturbed key; valS[pos] = edge id
+template <int W, typename idx_t, bool DESC>
+__device__ __forceinline__ void sort_edges(Mem<idx_t>& M, int m) {
+    const int tid = threadIdx.x;
+    const int P = pow2ceil(m < 2 ? 2 : m);
     for (int e = tid; e < P; e += W) {
         if (e < m) {
-            const unsigned ab = ends(M.valS[e]);
-            M.keyS[e] = f64_key(key_asc(f[ab >> 16], f[ab & 0xffffu]));
+            const unsigned ab = M.dir[e];
+            const double flo = M.f[ab >> 16], fhi = M.f[ab & 0xffffu];
+            M.keyS[e] = DESC ? ~f64_key(key_desc(flo, fhi)) : f64_key(key_asc(flo, fhi));
         } else {
             M.keyS[e] = ~0ull;
-            M.valS[e] = 0u;
         }
+        M.valS[e] = (unsigned)e;
     }
-    for (int i = tid; i < n; i += W) M.comp[i] = (idx_t)i;
     __syncthreads();
     bitonic_sort<W>(M.keyS, M.valS, P);
-    TLC_STAMP(5);
-    // ---- ascending union-find pass (accelerated_PD.py:46-68) ---------------------------------------------------------
-    if (tid == 0) {
-        for (int e = 0; e < m; ++e) {
-            const unsigned ab = ends(M.valS[e]);
-            const int a = ab >> 16, b = ab & 0xffffu;
-            const int pa = uf_find(M.comp, a), pb = uf_find(M.comp, b);
-            if (pa != pb) {
-                const int small = (f[pa] <= f[pb]) ? pa : pb, large = pa + pb - small;     // :63-64
-                const int maxn = (f[a] > f[b]) ? a : b;                                    // :65
-                if (keep0 || f[large] < f[maxn]) sink.up(f, large, maxn);                  // :66-67
-                M.comp[large] = (idx_t)small;
-            }
+}
+
+// ---- one filtration pass as a minimum-spanning-forest computation in sorted-position order -----------------------------
+// The reference runs Kruskal over the sorted simplices with the elder rule (accelerated_PD.py:46-68 ascending, :83-109
+// descending).  Which edges join two components (the "Neg"/tree edges) depends only on the total order, so they are found
+// with Boruvka rounds (every component picks its earliest outgoing edge: atomicMin on the sorted position), all lanes busy.
+// The elder-rule PAIRS additionally depend on the merge order, but only through the component minima (maxima):
+//   * the first edge (in sorted order) at a node y whose other endpoint is older attaches the singleton {y} to a component
+//     that already holds an older vertex; the pair it emits has zero persistence and it never changes a component's
+//     oldest vertex, nor can it bridge two components earlier than the reference would (no other edge at y precedes it);
+//     all of these are applied at once ("pre-merge"), leaving one basin per local extremum;
+//   * Boruvka started from the basins yields the remaining tree edges R (|R| = #basins - 1, a handful);
+//   * only R is replayed serially, in sorted order, with the reference's elder rule.
+// WANT_PAIRS=false: tree bits only (batch path, descending pass: only the Pos/Neg split and #Neg are consumed).
+template <int W, typename idx_t, bool DESC, bool WANT_PAIRS, class Sink>
+__device__ __forceinline__ void mst_pass(Mem<idx_t>& M, Sink& sink, int n, int m, unsigned flags) {
+    const int tid = threadIdx.x;
+    const bool keep0 = (flags & TLC_KEEP_ZERO_PERS) != 0;
+    const unsigned INF = 0xFFFFFFFFu;
+    const int nwords = (m + 31) >> 5;
+    const unsigned* ord = M.valS;
+    const unsigned* ends = M.dir;
+    double* f = M.f;
+    for (int w = tid; w < nwords; w += W) { M.tbits[w] = 0u; M.rbits[w] = 0u; }
+    if (WANT_PAIRS) {
+        for (int y = tid; y < n; y += W) M.first[y] = INF;
+        __syncthreads();
+        for (int pos = tid; pos < m; pos += W) {
+            const unsigned ab = ends[ord[pos]];
+            atomicMin(&M.first[ab >> 16], (unsigned)pos);
+            atomicMin(&M.first[ab & 0xffffu], (unsigned)pos);
         }
-        sink.ext0(f, n, n + 1);                                                            // [min, max]  (:110)
-    }
-    __syncthreads();
-    TLC_STAMP(6);
-    // ---- descending keys, same edges (:70-77) -------------------------------------------------------------------------
-    for (int e = tid; e < m; e += W) {
-        const unsigned ab = ends(M.valS[e]);
-        M.keyS[e] = ~f64_key(key_desc(f[ab >> 16], f[ab & 0xffffu]));
-    }
-    for (int i = tid; i < n; i += W) M.comp[i] = (idx_t)i;
-    __syncthreads();
-    bitonic_sort<W>(M.keyS, M.valS, P);
-    TLC_STAMP(7);
-    // ---- descending pass (:83-109): Pos / Neg classification (+ Rel1 points) ------------------------------------------
-    if (tid == 0) {
-        int npos = 0, nneg = 0;
-        for (int e = 0; e < m; ++e) {
-            const unsigned val = M.valS[e];
-            const unsigned ab = ends(val);
-            const int a = ab >> 16, b = ab & 0xffffu;
-            const int pa = uf_find(M.comp, a), pb = uf_find(M.comp, b);
-            if (pa != pb) {
-                M.pn[MMcap - 1 - nneg] = val;
-                ++nneg;
-                const int small = (f[pa] <= f[pb]) ? pa : pb, large = pa + pb - small;     // :101-102
-                if (Sink::want_down) {
-                    const int minn = (f[a] < f[b]) ? a : b;                                // :103-104
-                    if (keep0 || f[small] > f[minn]) sink.down(f, small, minn);            // :105-106
+        __syncthreads();
+        // pre-merge: y joins the older endpoint of its first edge (ascending: the lower rank; descending: the higher)
+        int npre = 0;
+        for (int y0 = 0; y0 < n; y0 += W) {
+            const int y = y0 + tid;
+            int c = y;
+            bool pre = false;
+            if (y < n) {
+                const unsigned p = M.first[y];
+                if (p != INF) {
+                    const unsigned ab = ends[ord[p]];
+                    const int lo = ab >> 16, hi = ab & 0xffffu;
+                    if (DESC ? (lo == y) : (hi == y)) {
+                        c = DESC ? hi : lo;
+                        pre = true;
+                        atomicOr(&M.tbits[p >> 5], 1u << (p & 31));
+                    }
                 }
-                M.comp[small] = (idx_t)large;
-            } else {
-                M.pn[npos++] = val;
+                M.comp[y] = (idx_t)c;
+            }
+            if (Sink::is_global && keep0) {
+                // the Knowledge_Distillation fork keeps these zero-persistence pairs (:68-69 / :108-109): [f[y], f[y]]
+                const ull mk = __ballot(pre);
+                int off;
+                if (W == 64) {
+                    off = npre + __popcll(mk & tlc_lanemask_lt());
+                    npre += __popcll(mk);
+                } else {
+                    if (tlc_lane() == 0) M.wcnt[tid >> 6] = __popcll(mk);
+                    __syncthreads();
+                    int before = 0, tot = 0;
+#pragma unroll
+                    for (int k = 0; k < W / 64; ++k) {
+                        const int cc = M.wcnt[k];
+                        if (k < (tid >> 6)) before += cc;
+                        tot += cc;
+                    }
+                    off = npre + before + __popcll(mk & tlc_lanemask_lt());
+                    npre += tot;
+                    __syncthreads();
+                }
+                if (pre) {
+                    if constexpr (Sink::is_global) {
+                        double* dst = DESC ? sink.pd_down : sink.pd_up;
+                        dst[2 * off] = f[y];
+                        dst[2 * off + 1] = f[y];
+                    }
+                }
             }
         }
-        M.ctl[3] = npos; M.ctl[4] = nneg;
+        __syncthreads();
+        if (Sink::is_global && keep0 && tid == 0) M.ctl[DESC ? 7 : 6] = npre;
+        flatten<W>(M.comp, n, M.ctl);
+        for (int y = tid; y < n; y += W) M.comp2[y] = M.comp[y];
+    } else {
+        for (int y = tid; y < n; y += W) M.comp2[y] = (idx_t)y;
     }
     __syncthreads();
-    TLC_STAMP(8);
+    // ---- Boruvka rounds on comp2 (kept flat: comp2[y] is y's root) ---------------------------------------------------
+    unsigned* hook = M.first;
+    for (int round = 0; round < 40; ++round) {
+        for (int y = tid; y < n; y += W) { M.best[y] = INF; hook[y] = INF; }
+        __syncthreads();
+        bool found = false;
+        for (int pos = tid; pos < m; pos += W) {
+            if ((M.tbits[pos >> 5] >> (pos & 31)) & 1u) continue;
+            const unsigned ab = ends[ord[pos]];
+            const int ra = M.comp2[ab >> 16], rb = M.comp2[ab & 0xffffu];
+            if (ra != rb) {
+                atomicMin(&M.best[ra], (unsigned)pos);
+                atomicMin(&M.best[rb], (unsigned)pos);
+                found = true;
+            }
+        }
+        __syncthreads();
+        if (!block_any<W>(found, M.ctl, 0)) break;
+        for (int y = tid; y < n; y += W) {
+            const unsigned pos = M.best[y];
+            if (pos == INF || M.comp2[y] != y) continue;
+            const unsigned ab = ends[ord[pos]];
+            const int ra = M.comp2[ab >> 16], rb = M.comp2[ab & 0xffffu];
+            const int other = (ra == y) ? rb : ra;
+            atomicOr(&M.tbits[pos >> 5], 1u << (pos & 31));
+            if (WANT_PAIRS) atomicOr(&M.rbits[pos >> 5], 1u << (pos & 31));
+            // unique positions => the pick graph has only 2-cycles; the larger root of a mutual pick hooks
+            if (M.best[other] != pos || y > other) hook[y] = (unsigned)other;
+        }
+        __syncthreads();
+        for (int y = tid; y < n; y += W)
+            if (hook[y] != INF) M.comp2[y] = (idx_t)hook[y];
+        __syncthreads();
+        flatten<W>(M.comp2, n, M.ctl);
+    }
+    // ---- replay the few remaining tree edges with the elder rule -------------------------------------------------------
+    if (WANT_PAIRS) {
+        if (tid == 0) {
+            for (int w = 0; w < nwords; ++w) {
+                unsigned bits = M.rbits[w];
+                while (bits) {
+                    const int pos = (w << 5) + __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const unsigned ab = ends[ord[pos]];
+                    const int lo = ab >> 16, hi = ab & 0xffffu;
+                    const int pa = uf_find(M.comp, lo), pb = uf_find(M.comp, hi);
+                    if (pa == pb) continue;
+                    const int small = pa < pb ? pa : pb, large = pa + pb - small;      // rank order == f order
+                    if (!DESC) {
+                        // :63-68  the younger root `large` dies at the higher endpoint of the edge
+                        if (keep0 || f[large] < f[hi]) sink.up(f, large, hi);
+                        M.comp[large] = (idx_t)small;
+                    } else {
+                        // :101-107  the root with the smaller f dies at the lower endpoint
+                        if (Sink::want_down && (keep0 || f[small] > f[lo])) sink.down(f, small, lo);
+                        M.comp[small] = (idx_t)large;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- Pos / Neg lists from the tree bits of the descending pass, in descending-pass order (:99,109) --------------------
+template <int W, typename idx_t>
+__device__ __forceinline__ void split_pos_neg(Mem<idx_t>& M, int m, int MMcap) {
+    const int tid = threadIdx.x;
+    int npos = 0, nneg = 0;
+    for (int p0 = 0; p0 < m; p0 += W) {
+        const int pos = p0 + tid;
+        bool isneg = false, valid = pos < m;
+        unsigned eid = 0;
+        if (valid) {
+            isneg = (M.tbits[pos >> 5] >> (pos & 31)) & 1u;
+            eid = M.valS[pos];
+        }
+        const ull mp = __ballot(valid && !isneg), mn = __ballot(valid && isneg);
+        int offp, offn;
+        if (W == 64) {
+            offp = npos + __popcll(mp & tlc_lanemask_lt());
+            offn = nneg + __popcll(mn & tlc_lanemask_lt());
+            npos += __popcll(mp);
+            nneg += __popcll(mn);
+        } else {
+            if (tlc_lane() == 0) { M.wcnt[tid >> 6] = __popcll(mp); M.wcnt[8 + (tid >> 6)] = __popcll(mn); }
+            __syncthreads();
+            int bp = 0, bn = 0, tp = 0, tn = 0;
+#pragma unroll
+            for (int k = 0; k < W / 64; ++k) {
+                const int cp = M.wcnt[k], cn = M.wcnt[8 + k];
+                if (k < (tid >> 6)) { bp += cp; bn += cn; }
+                tp += cp; tn += cn;
+            }
+            offp = npos + bp + __popcll(mp & tlc_lanemask_lt());
+            offn = nneg + bn + __popcll(mn & tlc_lanemask_lt());
+            npos += tp; nneg += tn;
+            __syncthreads();
+        }
+        if (valid) {
+            if (isneg) M.pn[MMcap - 1 - offn] = eid;
+            else M.pn[offp] = eid;
+        }
+    }
+    if (tid == 0) { M.ctl[3] = npos; M.ctl[4] = nneg; }
+    __syncthreads();
 }
 
 // Accelerate_PD (accelerated_PD.py:115-178).  Requires ctl[4] (#Neg) >= 1.
-template <int W, typename idx_t, bool EID, class Sink>
-__device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, unsigned flags, int MMcap, ull* pc,
+//
+// Tree state per node (u32 arrays carved from the dead sort / union-find regions): par[x], key[x] = ascending rank of the
+// edge (x, par x), mark[x] = stamp of the last walk through x, pmP[x] / pmQ[x] = (running maximum rank+1, child endpoint
+// of that edge) of the p- resp. q-walk on arrival at x.  Every tree edge carries the ascending rank of its key, so "the
+// first maximum of 'asc' over the loop" (:155-159) is an integer maximum.
+// The loop of a Pos edge (p,q) is found by TWO LANES of one wavefront walking up from p and from q in the same instruction
+// stream.  A step is: publish the running maximum at the next node, then ds_wrxchg the stamp there; the exchange returns
+// the other walk's stamp exactly once, at the lowest common ancestor (two lanes hitting the same word in one instruction
+// are serialised by the LDS, so simultaneous arrival is detected too).  One LDS round trip per step, no second pass over
+// the loop, cost per Pos edge ~ cycle length instead of the two root paths of :131-148.  The path eversion that swaps the
+// edges (:168-176) runs on lane 0.
+template <int W, typename idx_t, class Sink>
+__device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, unsigned flags, int MMcap, int NMcap, ull* pc,
                                            ull& t_prev) {
     const int tid = threadIdx.x;
     const bool keep0 = (flags & TLC_KEEP_ZERO_PERS) != 0;
-    const idx_t NONE = (idx_t)~(idx_t)0;
+    const unsigned NONE = 0xffffffffu;
     const int npos = M.ctl[3], nneg = M.ctl[4];
+    const unsigned* ends = M.dir;
     double* f = M.f;
-    auto ends = [&](unsigned v) -> unsigned { return EID ? M.dir[v] : v; };
-    // spanning tree of the Neg edges rooted at the first endpoint of the first Neg edge (:119-125)
-    for (int i = tid; i < n; i += W) { M.par[i] = NONE; M.mark[i] = 0; }
+    unsigned* par = (unsigned*)M.keyS;
+    unsigned* key = par + NMcap;
+    unsigned* mark = key + NMcap;
+    ull* pmP = (ull*)(mark + NMcap + (NMcap & 1));
+    ull* pmQ = pmP + NMcap;
+    // spanning tree of the Neg edges (:119-125).  Any root gives the same diagram; rank 0 (a root of the vicinity) keeps
+    // the tree shallow.  If rank 0 is not incident to a Neg edge (disconnected input) fall back to the reference's choice.
+    // (the Neg list in M.pn and the edge tables in M.dir are outside the regions re-used here)
     __syncthreads();
-    const int root = ends(M.pn[MMcap - 1]) >> 16;
-    if (tid == 0) M.par[root] = (idx_t)root;
+    for (int i = tid; i < n; i += W) { par[i] = NONE; key[i] = 0u; mark[i] = 0u; }
+    __syncthreads();
+    int root = 0;
+    {
+        const unsigned ab = ends[M.pn[MMcap - 1]];
+        bool has0 = false;
+        for (int k = tid; k < nneg; k += W) has0 |= ((ends[M.pn[MMcap - 1 - k]] >> 16) == 0u);
+        if (!block_any<W>(has0, M.ctl, 5)) root = ab >> 16;
+    }
+    if (tid == 0) par[root] = (unsigned)root;
     __syncthreads();
     for (int round = 0; round <= n; ++round) {
-        if (tid == 0) M.ctl[5] = 0;
-        __syncthreads();
-        int prog = 0;
+        bool prog = false;
         for (int k = tid; k < nneg; k += W) {
-            const unsigned ab = ends(M.pn[MMcap - 1 - k]);
+            const unsigned eid = M.pn[MMcap - 1 - k];
+            const unsigned ab = ends[eid];
             const int a = ab >> 16, b = ab & 0xffffu;
-            const idx_t pa = M.par[a], pb = M.par[b];
-            if (pa != NONE && pb == NONE) { M.par[b] = (idx_t)a; prog = 1; }
-            else if (pb != NONE && pa == NONE) { M.par[a] = (idx_t)b; prog = 1; }
+            const unsigned pa = par[a], pb = par[b];
+            if (pa != NONE && pb == NONE) { par[b] = (unsigned)a; key[b] = M.arank[eid]; prog = true; }
+            else if (pb != NONE && pa == NONE) { par[a] = (unsigned)b; key[a] = M.arank[eid]; prog = true; }
         }
-        if (prog) M.ctl[5] = 1;
         __syncthreads();
-        const int any = M.ctl[5];
-        __syncthreads();
-        if (!any) break;
+        if (!block_any<W>(prog, M.ctl, 5)) break;
     }
     TLC_STAMP(9);
-    if (tid == 0) {
+    if (tid < 64) {                                                 // first wavefront; lanes 0 and 1 walk
+        const int lane = tid;
+        const bool walker = lane < 2;
+        const bool qside = (lane & 1) != 0;
+        ull* pmMine = qside ? pmQ : pmP;
+        const ull* pmTheirs = qside ? pmP : pmQ;
         unsigned stamp = 0;
+        // the per-query operands do not depend on the tree: fetch them one query ahead, off the dependent chain
+        unsigned n_eid = npos > 0 ? M.pn[0] : 0u;
+        unsigned n_pq = npos > 0 ? ends[n_eid] : 0u;
+        unsigned n_ar = npos > 0 ? M.arank[n_eid] : 0u;
+        int n_out = 0;                         // points emitted by this stage (wave-uniform)
+        const int out0 = M.ctl[2];
         for (int pi = 0; pi < npos; ++pi) {
-            const unsigned pq = ends(M.pn[pi]);
-            const int p = pq >> 16, q = pq & 0xffffu;
-            if (M.par[p] == NONE || M.par[q] == NONE) continue;   // other component: callers gate on connectivity
-            if (++stamp == (unsigned)NONE) {                      // stamp space of idx_t exhausted: start over
-                for (int i = 0; i < n; ++i) M.mark[i] = 0;
-                stamp = 1;
+            const unsigned pq = n_pq, ar = n_ar;
+            if (pi + 1 < npos) {
+                n_eid = M.pn[pi + 1];
+                n_pq = ends[n_eid];
+                n_ar = M.arank[n_eid];
             }
-            for (int a = p; a != root; a = M.par[a]) M.mark[a] = (idx_t)stamp;   // path_0 (:131-144)
-            int meet = root;
-            for (int a = q; a != root; a = M.par[a]) {                           // path_1 until it joins path_0
-                if (M.mark[a] == (idx_t)stamp) { meet = a; break; }
+            const int p = pq >> 16, q = pq & 0xffffu;              // f[p] <= f[q]: low_value = f[p] (:162)
+            int cur = qside ? q : p;
+            unsigned pcur = par[cur], kcur = key[cur];
+            if (__ballot(pcur == NONE) != 0ull) continue;          // other component (callers gate on connectivity)
+            stamp += 2;
+            if (stamp >= 0xfffffff0u) {                            // stamp space exhausted: start over
+                for (int i = lane; i < n; i += 64) mark[i] = 0u;
+                stamp = 2;
             }
-            // Loop = symmetric difference of the two root paths (:149-151); first maximum of 'asc' (:155-159)
-            int best = -1, side = 0;
-            double bestv = 0.0;
-            for (int a = p; a != meet; a = M.par[a]) {
-                const double v = key_asc(f[a], f[M.par[a]]);
-                if (best < 0 || v > bestv) { best = a; bestv = v; side = 0; }
+            const unsigned mine = stamp + (qside ? 1u : 0u), theirs = stamp + (qside ? 0u : 1u);
+            unsigned mx = 0;                   // rank + 1 of the heaviest edge this walk has crossed (0 = none)
+            unsigned arg = 0;                  // child endpoint of that edge
+            if (walker) { mark[cur] = mine; pmMine[cur] = 0ull; }
+            unsigned res_k = 0, res_a = 0, res_s = 0;
+            for (;;) {
+                bool found = false;
+                if (walker && cur != root) {
+                    if (kcur + 1u > mx) { mx = kcur + 1u; arg = (unsigned)cur; }
+                    const int nxt = (int)pcur;
+                    pmMine[nxt] = ((ull)mx << 32) | (ull)arg;               // publish before taking the stamp
+                    const unsigned old = atomicExch(&mark[nxt], mine);      // ds_wrxchg_rtn_b32
+                    const unsigned pn = par[nxt], kn = key[nxt];
+                    if (old == theirs) {
+                        found = true;
+                        const ull o = pmTheirs[nxt];
+                        const unsigned ok = (unsigned)(o >> 32), oa = (unsigned)(o & 0xffffffffull);
+                        if (mx >= ok) { res_k = mx; res_a = arg; res_s = qside ? 1u : 0u; }
+                        else { res_k = ok; res_a = oa; res_s = qside ? 0u : 1u; }
+                    } else {
+                        cur = nxt; pcur = pn; kcur = kn;
+                    }
+                }
+                const ull fm = __ballot(found);
+                if (fm) {
+                    const int fl = __builtin_ctzll(fm);
+                    res_k = __builtin_amdgcn_readlane(res_k, fl);
+                    res_a = __builtin_amdgcn_readlane(res_a, fl);
+                    res_s = __builtin_amdgcn_readlane(res_s, fl);
+                    break;
+                }
             }
-            for (int a = q; a != meet; a = M.par[a]) {
-                const double v = key_asc(f[a], f[M.par[a]]);
-                if (best < 0 || v > bestv) { best = a; bestv = v; side = 1; }
+            if (res_k == 0) continue;
+            const int best = (int)res_a;
+            const int bp = (int)par[best];
+            const int hin = best > bp ? best : bp;                                // large_value  (:160)
+            // low_value > = large_value is dropped by the TLC fork (:164).  The batch path defers that test: a point with
+            // zero persistence has weight 0 in the image, so it may stay in the list.
+            bool emit = true;
+            if (Sink::is_global && !keep0) emit = f[hin] > f[p];
+            if (emit) {
+                if (lane == 0) sink.one_at(f, out0 + n_out, n_out, p, hin);
+                ++n_out;
             }
-            if (best < 0) continue;
-            const int bp = M.par[best];
-            const int hin = (f[best] > f[bp]) ? best : bp;                       // large_value  (:160)
-            const int lon = (f[p] < f[q]) ? p : q;                               // low_value    (:162)
-            if (keep0 || f[hin] > f[lon]) sink.one(f, lon, hin);                 // :164-165
-            // evert the path so that (p,q) replaces the removed tree edge (:168-176)
-            int node = side == 0 ? p : q, nodec = side == 0 ? q : p;
-            while (nodec != best) {
-                const int tp = M.par[node];
-                M.par[node] = (idx_t)nodec;
-                nodec = node;
-                node = tp;
+            if (lane == 0) {
+                // evert the path so that (p,q) replaces the removed tree edge (:168-176)
+                int node = res_s == 0 ? p : q, nodec = res_s == 0 ? q : p;
+                unsigned kin = ar;
+                while (nodec != best) {
+                    const unsigned pp = par[node], kk = key[node];
+                    par[node] = (unsigned)nodec;
+                    key[node] = kin;
+                    nodec = node;
+                    node = (int)pp;
+                    kin = kk;
+                }
             }
         }
+        if (lane == 0) { M.ctl[2] = out0 + n_out; M.ctl[8] = n_out; }
     }
     __syncthreads();
     TLC_STAMP(10);
+}
+
+// All PD stages on a subgraph whose f[0..n) is final and whose m undirected edges sit in M.dir[0..m) as node-id pairs.
+template <int W, typename idx_t, class Sink>
+__device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, int m, unsigned flags, int MMcap, int NMcap,
+                                            ull* pc, ull& t_prev) {
+    relabel_by_rank<W>(M, n, m);
+    sort_edges<W, idx_t, false>(M, m);
+    for (int pos = threadIdx.x; pos < m; pos += W) M.arank[M.valS[pos]] = (unsigned)pos;
+    __syncthreads();
+    TLC_STAMP(5);
+    mst_pass<W, idx_t, false, true>(M, sink, n, m, flags);
+    if (threadIdx.x == 0) sink.ext0(M.f, 0, n - 1);                  // [min, max]  (:110)
+    __syncthreads();
+    TLC_STAMP(6);
+    sort_edges<W, idx_t, true>(M, m);
+    TLC_STAMP(7);
+    if (Sink::want_down) mst_pass<W, idx_t, true, true>(M, sink, n, m, flags);
+    else mst_pass<W, idx_t, true, false>(M, sink, n, m, flags);
+    split_pos_neg<W>(M, m, MMcap);
+    TLC_STAMP(8);
+    int status = TLC_ST_OK;
+    if (!(flags & TLC_NO_EXT1)) {
+        if (M.ctl[4] == 0) status = TLC_ST_NO_TREE_EDGE;              // list(Nodes)[0] -> IndexError (:122)
+        else ext1_stage<W>(M, sink, n, flags, MMcap, NMcap, pc, t_prev);
+    }
+    return status;
 }
 
 // PersistenceImager.transform (PersistenceImager.pyx:352-388) over points first..last: Gaussian sigma=1 on [0,1]^2,
@@ -412,9 +739,15 @@ template <int W, class Get>
 __device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get get, int first, int last, int res,
                                            double acc) {
     const int tid = threadIdx.x;
-    const int G = res + 1, stride = 2 * G + 1;
+    const int G = res + 1, stride = 2 * G + 1, res2 = res * res;
     int batch = (int)(table_bytes / ((size_t)stride * 8));
     if (batch > W) batch = W;
+    // phase B layout: S slices of the point list per pixel; thread = slice * res^2 + pixel
+    const int S = W / res2 > 0 ? W / res2 : 1;
+    const int sl = tid / res2, pix = tid - sl * res2;
+    const int pi = pix / res, pj = pix - pi * res;
+    const double acc_in = acc;
+    acc = 0.0;
     const double pixel = 1.0 / (double)res;
     const double step = ((1.0 + pixel) - 0.0) / (double)(res + 1);       // _create_mesh (:302-314)
     const double inv_s2 = 0.70710678118654752440;
@@ -436,9 +769,8 @@ __device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get 
             tbl[t] = val;
         }
         __syncthreads();
-        if (tid < res * res) {
-            const int pi = tid / res, pj = tid - pi * res;
-            for (int pt = 0; pt < nb; ++pt) {
+        if (tid < res2 * S) {
+            for (int pt = sl; pt < nb; pt += S) {
                 const double* r = tbl + pt * stride;
                 const double wgt = r[2 * G];
                 if (wgt != 0.0) acc += wgt * ((r[pi + 1] - r[pi]) * (r[G + pj + 1] - r[G + pj]));
@@ -446,7 +778,18 @@ __device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get 
         }
         __syncthreads();
     }
-    return acc;
+    if (S > 1) {
+        // fold the S point-slices of every pixel in a fixed order (deterministic)
+        if (tid < res2 * S) tbl[tid] = acc;
+        __syncthreads();
+        if (tid < res2) {
+            double t = 0.0;
+            for (int s = 0; s < S; ++s) t += tbl[s * res2 + tid];
+            acc = t;
+        }
+        __syncthreads();
+    }
+    return acc + acc_in;
 }
 
 }  // namespace
@@ -649,30 +992,16 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
                         run += tot;
                         __syncthreads();
                     }
-                    // keyS/valS alias dv/cnt/nxt, which are dead by now
-                    if (keep) M.valS[off] = e;
+                    // in place: off <= j, and every lane of this chunk has read its entry already
+                    if (keep) M.dir[off] = e;
                 }
                 __syncthreads();
             }
-            // min / max of f as two extra "nodes" n, n+1 for the [min,max] point (accelerated_PD.py:28-38,110)
-            {
-                double mn = 99999999.0, mx = -99999999.0;
-                for (int k = tid; k < n; k += W) { const double v = M.f[k]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-                mn = block_min<W>(mn, M.red);
-                mx = block_max<W>(mx, M.red);
-                if (tid == 0) { M.f[n] = mn; M.f[n + 1] = mx; }
-                __syncthreads();
-            }
-            const int P = pow2ceil(m < 2 ? 2 : m);
-            PtsSink sink{M.pts, 0, 0, 0, 0};
-            TLC_STAMP(4);
-            pd_stages<W, idx_t, false>(M, sink, n, m, P, p.flags, MMr, pc, t_prev);
-            if (!(p.flags & TLC_NO_EXT1)) {
-                if (M.ctl[4] == 0) status = TLC_ST_NO_TREE_EDGE;          // list(Nodes)[0] -> IndexError (:122)
-                else ext1_stage<W, idx_t, false>(M, sink, n, p.flags, MMr, pc, t_prev);
-            }
-            if (tid == 0) { M.ctl[2] = sink.np; M.ctl[6] = sink.n_up; }
+            if (tid == 0) { M.ctl[2] = 0; M.ctl[6] = 0; M.ctl[7] = 0; M.ctl[8] = 0; }
             __syncthreads();
+            PtsSink sink{M.pts, M.ctl};
+            TLC_STAMP(4);
+            status = pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev);
             if (status == TLC_ST_OK) {
                 const int np = M.ctl[2], n_up = M.ctl[6];
                 auto get = [&](int k, double& b, double& d) {
@@ -725,31 +1054,27 @@ __global__ __launch_bounds__(W) void tlc_pdf_tier_kernel(TlcPdfParams p) {
         const int g = p.list[wi];
         const long long no = p.node_offs[g], eo = p.edge_offs[g];
         const int n = (int)(p.node_offs[g + 1] - no), m = (int)(p.edge_offs[g + 1] - eo);
-        double mn = 99999999.0, mx = -99999999.0;
-        for (int k = tid; k < n; k += W) {
-            const double v = p.f[no + k];
-            M.f[k] = v;
-            mn = v < mn ? v : mn;
-            mx = v > mx ? v : mx;
-        }
-        mn = block_min<W>(mn, M.red);
-        mx = block_max<W>(mx, M.red);
-        if (tid == 0) { M.f[n] = mn; M.f[n + 1] = mx; }
-        for (int e = tid; e < m; e += W) {
+        for (int k = tid; k < n; k += W) M.f[k] = p.f[no + k];
+        for (int e = tid; e < m; e += W)
             M.dir[e] = ((unsigned)p.edges[2 * (eo + e)] << 16) | (unsigned)p.edges[2 * (eo + e) + 1];
-            M.valS[e] = (unsigned)e;
+        if (tid == 0) { M.ctl[2] = 0; M.ctl[3] = 0; M.ctl[4] = 0; M.ctl[6] = 0; M.ctl[7] = 0; M.ctl[8] = 0; }
+        __syncthreads();
+        GlobalSink sink{p.pd_up + 2 * no, p.pd_down + 2 * no, p.pd_one + 2 * eo, p.ext0 + 2 * (size_t)g, M.ctl};
+        ull* pc = nullptr;
+        ull t_prev = 0;
+        if (m > 0) {
+            pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev);
+        } else if (tid == 0) {
+            double mn = 99999999.0, mx = -99999999.0;
+            for (int k = 0; k < n; ++k) { mn = M.f[k] < mn ? M.f[k] : mn; mx = M.f[k] > mx ? M.f[k] : mx; }
+            sink.e0[0] = mn; sink.e0[1] = mx;
         }
         __syncthreads();
-        GlobalSink sink{p.pd_up + 2 * no, p.pd_down + 2 * no, p.pd_one + 2 * eo, p.ext0 + 2 * (size_t)g, 0, 0, 0, 0};
-        const int P = pow2ceil(m < 2 ? 2 : m);
-        ull* pc = nullptr; ull t_prev = 0;
-        pd_stages<W, idx_t, true>(M, sink, n, m, P, p.flags, MMr, pc, t_prev);
         const int npos = M.ctl[3], nneg = M.ctl[4];
-        if (!(p.flags & TLC_NO_EXT1) && nneg > 0) ext1_stage<W, idx_t, true>(M, sink, n, p.flags, MMr, pc, t_prev);
         if (tid == 0) {
-            p.counts[4 * (size_t)g + 0] = sink.n_up;
-            p.counts[4 * (size_t)g + 1] = sink.n_down;
-            p.counts[4 * (size_t)g + 2] = sink.n_one;
+            p.counts[4 * (size_t)g + 0] = M.ctl[6];
+            p.counts[4 * (size_t)g + 1] = M.ctl[7];
+            p.counts[4 * (size_t)g + 2] = M.ctl[8];
             p.counts[4 * (size_t)g + 3] = n - nneg;
         }
         if (p.edge_rank) {

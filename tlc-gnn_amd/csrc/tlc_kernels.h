@@ -56,6 +56,11 @@ struct TlcVicParams {
     double* A_lw;
     const long long* ids_off;  // optional id output (tlc_vicinity_filtration)
     int* out_ids;
+    // FILL scheduling: 0 = every pair, 1 = only the pairs in fill_list[0..fill_count) (the heavy tiers go first so that
+    // their long serial tails start early), 2 = every pair that is NOT in a heavy tier
+    int fill_mode;
+    const int* fill_list;
+    int fill_count;
 };
 
 struct TlcScanParams {

@@ -176,10 +176,15 @@ __global__ __launch_bounds__(TLC_WAVE) void tlc_vicinity_kernel(TlcVicParams p) 
         int i = 0;
         if (lane == 0) i = atomicAdd(p.work_counter, 1);
         i = __shfl(i, 0, 64);
-        if (i >= p.n_pairs) break;
+        if (FILL && p.fill_mode == 1) {
+            if (i >= p.fill_count) break;
+            i = p.fill_list[i];
+        } else if (i >= p.n_pairs) break;
         const int u = p.pairs[2 * (size_t)i], v = p.pairs[2 * (size_t)i + 1];
         if (FILL) {
-            if (p.hdr_n[i] <= 0) continue;    // finished by the COUNT pass
+            const int hn = p.hdr_n[i];
+            if (hn <= 0) continue;    // finished by the COUNT pass
+            if (p.fill_mode == 2 && (hn > TLC_M_NMAX || (p.hdr_m2[i] >> 1) > TLC_M_MMAX)) continue;   // filled by the early pass
         } else {
             // KeyError on dict_node (riccidist2dgm.py:353): ids the edge-built graph does not contain
             bool missing = u < 0 || v < 0 || u >= p.n_nodes || v >= p.n_nodes;
