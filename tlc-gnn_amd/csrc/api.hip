@@ -60,6 +60,10 @@ struct tlc_graph {
     size_t cap_entries;
     unsigned* A_dir;
     double* A_lw;
+    // fixed-size slots of the SMALL tier (written by the COUNT pass)
+    size_t cap_small;
+    unsigned* S_dir;
+    double* S_lw;
     // vicinity scratch
     int vic_slots;
     int vic_hop_cap;           // frontiers allocated for hop >= 3 ?
@@ -108,6 +112,16 @@ static int ensure_arena(tlc_graph* g, size_t entries) {
     return TLC_OK;
 }
 
+static int ensure_small(tlc_graph* g, size_t n_pairs) {
+    if (n_pairs <= g->cap_small) return TLC_OK;
+    hipFree(g->S_dir); hipFree(g->S_lw);
+    g->S_dir = nullptr; g->S_lw = nullptr; g->cap_small = 0;
+    TLC_HIP_CHECK(hipMalloc(&g->S_dir, n_pairs * (2 * TLC_S_MMAX) * sizeof(unsigned)));
+    TLC_HIP_CHECK(hipMalloc(&g->S_lw, n_pairs * (2 * TLC_S_MMAX) * sizeof(double)));
+    g->cap_small = n_pairs;
+    return TLC_OK;
+}
+
 static int ensure_vic_scratch(tlc_graph* g, int hop) {
     const int need_front = hop >= 3 ? 1 : 0;
     if (g->vic_scratch && g->vic_hop_cap >= need_front) return TLC_OK;
@@ -149,7 +163,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
         TLC_REQUIRE(h_w[j] > 0.0, "edge weights (kappa+1) must be > 0");
     }
     const int nw = (n_nodes + 31) / 32;
-    const size_t lds = ((size_t)3 * nw + 4) * 4;
+    const size_t lds = ((size_t)3 * ((nw + 3) & ~3) + 4 + 16) * 4;
     if (lds > 160 * 1024) {
         tlc_set_error("graph has %d nodes: the vicinity bitmaps (%zu B) exceed the 160 KiB LDS of a CU", n_nodes, lds);
         return TLC_ERR_UNSUPPORTED;
@@ -184,7 +198,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    int per_cu = (int)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds, 1));
+    int per_cu = (int)std::min<size_t>(20, (160 * 1024) / std::max<size_t>(lds + 64, 1));
     if (per_cu < 1) per_cu = 1;
     g->vic_slots = cus * per_cu;
     (void)rc;
@@ -200,7 +214,7 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
     hipFree(g->d_ctl); hipFree(g->d_block_sums); hipFree(g->d_totals); hipFree(g->d_stats);
     if (g->h_sync) hipHostFree(g->h_sync);
-    hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch); hipFree(g->d_phase);
+    hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->S_dir); hipFree(g->S_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch); hipFree(g->d_phase);
     for (int k = 0; k < TLC_N_SIDE; ++k) {
         if (g->side[k]) hipStreamDestroy(g->side[k]);
         if (g->ev_join[k]) hipEventDestroy(g->ev_join[k]);
@@ -218,6 +232,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     int rc;
     if ((rc = ensure_pairs(g, (size_t)n_pairs)) != TLC_OK) return rc;
     if ((rc = ensure_vic_scratch(g, hop)) != TLC_OK) return rc;
+    if ((rc = ensure_small(g, (size_t)n_pairs)) != TLC_OK) return rc;
     TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl, 0, 64 * sizeof(int), s));
     TLC_HIP_CHECK(hipMemsetAsync(g->d_stats, 0, 2 * sizeof(unsigned long long), s));
 
@@ -231,11 +246,13 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     vp.out_pi = d_out_pi; vp.out_status = d_out_status; vp.out_n = d_out_n;
     vp.edge_off = g->edge_off; vp.A_dir = nullptr; vp.A_lw = nullptr;
     vp.ids_off = (const long long*)d_ids_off; vp.out_ids = d_out_ids;
+    vp.small_dir = g->S_dir; vp.small_lw = g->S_lw;
 
     static bool lds_attr = false;
     if (!lds_attr && g->vic_lds > 64 * 1024) {
-        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
-        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
+        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
+        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
+        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
         lds_attr = true;
     }
     const int vgrid = std::min(n_pairs, g->vic_slots);
@@ -244,18 +261,18 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
 #define T0(k, st) do { if (g->timing) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k)], st)); } } while (0)
 #define T1(k, st) do { if (g->timing) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k) + 1], st)); g->ev_used[k] = 1; } } while (0)
     T0(0, s);
-    hipLaunchKernelGGL(tlc_vicinity_kernel<false>, dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
+    hipLaunchKernelGGL((tlc_vicinity_kernel<false, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
     T1(0, s);
     TLC_HIP_CHECK(hipGetLastError());
 
     // exclusive scan of the induced entry counts + tier binning
     const int nb = (n_pairs + 1023) / 1024;
     T0(1, s);
-    hipLaunchKernelGGL(tlc_scan_block_sums, dim3(nb), dim3(1024), 0, s, (const int*)g->hdr_m2, n_pairs, g->d_block_sums);
+    hipLaunchKernelGGL(tlc_scan_block_sums, dim3(nb), dim3(1024), 0, s, (const int*)g->hdr_n, (const int*)g->hdr_m2, n_pairs, 1, g->d_block_sums);
     hipLaunchKernelGGL(tlc_scan_top, dim3(1), dim3(1024), 0, s, g->d_block_sums, nb, g->d_totals);
     TlcScanParams sp;
     sp.n_pairs = n_pairs; sp.hdr_n = g->hdr_n; sp.hdr_m2 = g->hdr_m2; sp.block_sums = g->d_block_sums;
-    sp.edge_off = g->edge_off; sp.tier_count = g->d_ctl; sp.tier_list = g->tier_list;
+    sp.edge_off = g->edge_off; sp.tier_count = g->d_ctl; sp.tier_list = g->tier_list; sp.small_arena = 1;
     hipLaunchKernelGGL(tlc_scan_down, dim3(nb), dim3(1024), 0, s, sp);
     T1(1, s);
     TLC_HIP_CHECK(hipGetLastError());
@@ -275,6 +292,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         memset(&pp, 0, sizeof(pp));
         pp.hdr_n = g->hdr_n; pp.hdr_m2 = g->hdr_m2; pp.hdr_lu = g->hdr_lu; pp.hdr_lv = g->hdr_lv;
         pp.edge_off = g->edge_off; pp.A_dir = g->A_dir; pp.A_lw = g->A_lw;
+        pp.small_dir = g->S_dir; pp.small_lw = g->S_lw;
         pp.flags = flags; pp.res = res; pp.out_pi = d_out_pi; pp.out_status = d_out_status;
         pp.ids_off = (const long long*)d_ids_off; pp.out_f = d_out_f; pp.out_n = d_out_n; pp.pi_enabled = pi_enabled;
         pp.huge_scratch = g->huge_scratch; pp.huge_stride = (long long)g->huge_stride;
@@ -294,35 +312,31 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
             used[k] = true;
             return TLC_OK;
         };
-        // 1. the heavy tiers first: their subgraphs are filled by a small early pass so that the long serial tails of the
+        // 0. the SMALL tier needs nothing more: its subgraphs were written by the COUNT pass
+        if (tc[TLC_TIER_SMALL] > 0 && (rc = launch_side(0, TLC_TIER_SMALL)) != TLC_OK) return rc;
+        // 1. the heavy tiers next: their subgraphs are filled by a small early pass so that the long serial tails of the
         //    largest vicinities start as soon as possible and overlap everything else
         const int heavy = tc[TLC_TIER_LARGE] + tc[TLC_TIER_HUGE];
-        if (heavy > 0) {
-            T0(2, s);
-            for (int t = TLC_TIER_LARGE; t <= TLC_TIER_HUGE; ++t) {
-                if (tc[t] <= 0) continue;
-                TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl + 4, 0, sizeof(int), s));
-                vp.fill_mode = 1; vp.fill_list = g->tier_list + (size_t)t * n_pairs; vp.fill_count = tc[t];
-                hipLaunchKernelGGL(tlc_vicinity_kernel<true>, dim3(std::min(tc[t], g->vic_slots)), dim3(TLC_WAVE), g->vic_lds, s, vp);
-                TLC_HIP_CHECK(hipGetLastError());
-                if ((rc = launch_side(t == TLC_TIER_HUGE ? 0 : 1, t)) != TLC_OK) return rc;
-            }
-        }
-        // 2. everything else
-        if (tc[TLC_TIER_SMALL] + tc[TLC_TIER_MEDIUM] > 0) {
-            TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl + 4, 0, sizeof(int), s));
-            vp.fill_mode = heavy > 0 ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
-            if (heavy == 0) T0(2, s);
-            hipLaunchKernelGGL(tlc_vicinity_kernel<true>, dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
-            T1(2, s);
+        T0(2, s);
+        for (int t = TLC_TIER_HUGE; t >= TLC_TIER_LARGE; --t) {
+            if (tc[t] <= 0) continue;
+            vp.fill_mode = 1; vp.fill_list = g->tier_list + (size_t)t * n_pairs; vp.fill_count = tc[t];
+            // the heavy vicinities get 8 wavefronts each (hop <= 2), so that their many long CSR rows are in flight together
+            if (hop <= 2)
+                hipLaunchKernelGGL((tlc_vicinity_kernel<true, 512>), dim3(std::min(tc[t], g->vic_slots)), dim3(512), g->vic_lds, s, vp);
+            else
+                hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(std::min(tc[t], g->vic_slots)), dim3(TLC_WAVE), g->vic_lds, s, vp);
             TLC_HIP_CHECK(hipGetLastError());
-            if (tc[TLC_TIER_MEDIUM] > 0 && (rc = launch_side(2, TLC_TIER_MEDIUM)) != TLC_OK) return rc;
-            pp.tier_list = g->tier_list + (size_t)TLC_TIER_SMALL * n_pairs; pp.tier_count = tc[TLC_TIER_SMALL];
-            pp.phase_cycles = g->d_phase ? g->d_phase + 16 * TLC_TIER_SMALL : nullptr;
-            if (tc[TLC_TIER_SMALL] > 0) T0(3 + TLC_TIER_SMALL, s);
-            if ((rc = tlc_launch_pd_tier(TLC_TIER_SMALL, pp, s)) != TLC_OK) return rc;
-            if (tc[TLC_TIER_SMALL] > 0) T1(3 + TLC_TIER_SMALL, s);
-        } else if (heavy > 0) {
+            if ((rc = launch_side(1, t)) != TLC_OK) return rc;
+        }
+        // 2. the MEDIUM tier
+        if (tc[TLC_TIER_MEDIUM] > 0) {
+            vp.fill_mode = heavy > 0 ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
+            hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
+            TLC_HIP_CHECK(hipGetLastError());
+            T1(2, s);
+            if ((rc = launch_side(2, TLC_TIER_MEDIUM)) != TLC_OK) return rc;
+        } else {
             T1(2, s);
         }
         for (int k = 0; k < TLC_N_SIDE; ++k)

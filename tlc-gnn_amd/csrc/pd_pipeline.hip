@@ -829,15 +829,18 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
         ull t_prev = pc ? clock64() : 0ull;
         const ull t_begin = t_prev;
         // ---- stage the subgraph ------------------------------------------------------------------------------------
+        const bool in_small = (NM == TLC_S_NMAX && !HUGE && p.small_dir != nullptr);
+        const unsigned* adir = in_small ? p.small_dir + (size_t)i * (2 * TLC_S_MMAX) : p.A_dir + eo;
+        const double* alw = in_small ? p.small_lw + (size_t)i * (2 * TLC_S_MMAX) : p.A_lw + eo;
         for (int j = tid; j < m2; j += W) {
-            M.dir[j] = p.A_dir[eo + j];
-            if (LWL) M.lw[j] = p.A_lw[eo + j];
+            M.dir[j] = adir[j];
+            if (LWL) M.lw[j] = alw[j];
         }
         ull* du = (ull*)M.f;
         for (int k = tid; k < n; k += W) { du[k] = TLC_INF_BITS; M.dv[k] = TLC_INF_BITS; }
         if (tid == 0) M.ctl[1] = 0;
         __syncthreads();
-        const double* glw = p.A_lw + eo;
+        const double* glw = alw;
         auto LW = [&](int j) -> double { return LWL ? M.lw[j] : glw[j]; };
 
         if (!far) {

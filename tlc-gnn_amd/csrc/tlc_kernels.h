@@ -61,6 +61,9 @@ struct TlcVicParams {
     int fill_mode;
     const int* fill_list;
     int fill_count;
+    // fixed-size slots (2*TLC_S_MMAX entries per pair) for the vicinities of the SMALL tier, written by the COUNT pass
+    unsigned* small_dir;
+    double* small_lw;
 };
 
 struct TlcScanParams {
@@ -71,6 +74,7 @@ struct TlcScanParams {
     long long* edge_off;
     int* tier_count;  // [TLC_N_TIERS]
     int* tier_list;   // [TLC_N_TIERS][n_pairs]
+    int small_arena;
 };
 
 struct TlcPdParams {
@@ -84,6 +88,8 @@ struct TlcPdParams {
     const long long* edge_off;
     const unsigned* A_dir;
     const double* A_lw;
+    const unsigned* small_dir;   // SMALL tier: fixed-size slots written by the COUNT pass (null: use the arena)
+    const double* small_lw;
     unsigned flags;
     int res;
     // outputs
@@ -129,9 +135,9 @@ struct TlcPdfParams {
 };
 
 #ifdef __HIPCC__
-template <bool FILL>
+template <bool FILL, int BW>
 __global__ void tlc_vicinity_kernel(TlcVicParams p);
-__global__ void tlc_scan_block_sums(const int* m2, int n_pairs, long long* block_sums);
+__global__ void tlc_scan_block_sums(const int* hn, const int* m2, int n_pairs, int small_arena, long long* block_sums);
 __global__ void tlc_scan_top(long long* block_sums, int n_blocks, long long* totals);
 __global__ void tlc_scan_down(TlcScanParams p);
 #endif

@@ -18,6 +18,30 @@
 
 namespace {
 
+// exclusive scan of one int per thread over a BW-thread workgroup (BW multiple of 64); *total = sum.  `xw` is an LDS array
+// of BW/64 ints.  All threads must call.
+template <int BW>
+__device__ __forceinline__ int block_escan_i32(int v, int* xw, int* total) {
+    const int inc = tlc_wave_iscan_i32(v);
+    if (BW == 64) {
+        *total = __shfl(inc, 63, 64);
+        return inc - v;
+    }
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (tlc_lane() == 63) xw[wv] = inc;
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < BW / 64; ++k) {
+        const int c = xw[k];
+        if (k < wv) before += c;
+        tot += c;
+    }
+    *total = tot;
+    return before + inc - v;
+}
+
 __device__ __forceinline__ bool bit_test(const unsigned* bits, int b) { return (bits[b >> 5] >> (b & 31)) & 1u; }
 
 // Set the bits of every neighbour of every node in list[0..count); optionally append newly set nodes to
@@ -94,12 +118,12 @@ __device__ __forceinline__ int local_id(const unsigned* S, const unsigned* pref,
 
 // Walk the CSR rows of ids[0..n).  WRITE=false: ldeg[k] = induced degree of row k (if ldeg), returns the
 // wave-uniform total.  WRITE=true: row k's entries go to dir/lw starting at lrow[k].
-template <bool WRITE>
+template <bool WRITE, int BW>
 __device__ __forceinline__ int induced_rows(const int* __restrict__ ids, int n, const unsigned* S, const unsigned* pref,
-                                            const TlcVicParams& p, int* ldeg_or_lrow, unsigned* dir, double* lw) {
+                                            const TlcVicParams& p, int* ldeg_or_lrow, unsigned* dir, double* lw, int* xw) {
     const int lane = tlc_lane();
     int total = 0;
-    for (int base = 0; base < n; base += TLC_WAVE) {
+    for (int base = (int)(threadIdx.x >> 6) * TLC_WAVE; base < n; base += BW) {
         const int k = base + lane;
         int beg = 0, end = 0, t = 0;
         if (k < n) {
@@ -149,81 +173,149 @@ __device__ __forceinline__ int induced_rows(const int* __restrict__ ids, int n, 
         }
         if (!WRITE) {
             if (ldeg_or_lrow && k < n) ldeg_or_lrow[k] = cnt;
-            total += tlc_wave_sum_i32(cnt);
+            total += cnt;
         }
     }
-    return total;
+    if (WRITE) return 0;
+    int tot = 0;
+    block_escan_i32<BW>(total, xw, &tot);
+    return tot;
 }
 
 }  // namespace
 
-template <bool FILL>
-__global__ __launch_bounds__(TLC_WAVE) void tlc_vicinity_kernel(TlcVicParams p) {
-    extern __shared__ unsigned lds[];
-    unsigned* bitsU = lds;
-    unsigned* bitsV = lds + p.nw;   // becomes S
-    unsigned* pref = lds + 2 * p.nw;
-    int* s_cnt = (int*)(lds + 3 * p.nw);
+// Both balls at once for hop <= 2 (the only values the reference uses, TLCGNN.py:102): the two root rows are read
+// together and their concatenation is the level-1 frontier, so the pair pays ONE chain of dependent global loads
+// (root rows -> neighbour rows) instead of two.
+template <int BW>
+__device__ __forceinline__ void mark_two_balls_hop2(unsigned* bitsU, unsigned* bitsV, int u, int v, int hop, const TlcVicParams& p) {
     const int lane = tlc_lane();
+    const int ub = p.rowptr[u], ue = p.rowptr[u + 1], vb = p.rowptr[v], ve = p.rowptr[v + 1];
+    const int du = ue - ub, dv = ve - vb, tot = du + dv;
+    if (threadIdx.x == 0) {
+        atomicOr(&bitsU[u >> 5], 1u << (u & 31));
+        atomicOr(&bitsV[v >> 5], 1u << (v & 31));
+    }
+    for (int base = (int)(threadIdx.x >> 6) * TLC_WAVE; base < tot; base += BW) {
+        const int k = base + lane;
+        int beg = 0, end = 0;
+        unsigned* bits = bitsU;
+        if (k < tot) {
+            const bool isu = k < du;
+            const int a = p.col[isu ? ub + k : vb + (k - du)];
+            bits = isu ? bitsU : bitsV;
+            atomicOr(&bits[a >> 5], 1u << (a & 31));
+            if (hop >= 2) { beg = p.rowptr[a]; end = p.rowptr[a + 1]; }
+        }
+        if (hop < 2) continue;
+        const bool big = (end - beg) >= 32;
+        if (!big) {
+            for (int j = beg; j < end; ++j) {
+                const int b = p.col[j];
+                atomicOr(&bits[b >> 5], 1u << (b & 31));
+            }
+        }
+        unsigned long long mask = __ballot(big);
+        while (mask) {
+            const int L = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int bb = __shfl(beg, L, 64), ee = __shfl(end, L, 64);
+            unsigned* wb = ((base + L) < du) ? bitsU : bitsV;
+            for (int j = bb + lane; j < ee; j += TLC_WAVE) {
+                const int b = p.col[j];
+                atomicOr(&wb[b >> 5], 1u << (b & 31));
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <bool FILL, int BW>
+__global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    const int nw4 = (p.nw + 3) & ~3;          // bitmaps padded to 16 bytes
+    unsigned* bitsU = lds;
+    unsigned* bitsV = lds + nw4;   // becomes S
+    unsigned* pref = lds + 2 * nw4;
+    int* s_cnt = (int*)(lds + 3 * nw4);
+    int* xw = s_cnt + 4;                       // BW/64 ints for the block scans
+    const int lane = tlc_lane();
+    const int tid = threadIdx.x;
     int* slot = p.scratch + (size_t)blockIdx.x * p.scratch_stride;
     int* frontA = slot;
     int* frontB = slot + p.n_nodes;
     int* ids = slot + 2 * (size_t)p.n_nodes;     // ascending node ids of S
-    int* lrow = slot + 3 * (size_t)p.n_nodes;    // FILL: induced degree, then row offsets (n+1)
+    int* lrow = slot + 3 * (size_t)p.n_nodes;    // induced degree, then row offsets
     const int res2 = p.res * p.res;
+    const int wpl = (p.nw + BW - 1) / BW;      // bitmap words per thread (contiguous chunk)
 
-    for (;;) {
-        int i = 0;
-        if (lane == 0) i = atomicAdd(p.work_counter, 1);
-        i = __shfl(i, 0, 64);
-        if (FILL && p.fill_mode == 1) {
-            if (i >= p.fill_count) break;
-            i = p.fill_list[i];
-        } else if (i >= p.n_pairs) break;
+    // static striding over the pairs: a single global work counter saturates at ~90 dequeues/us (MI355X_MICROARCH.md,
+    // "dequeue"), which would cap this kernel at ~0.4 ms per 37k pairs; consecutive pairs land on different workgroups,
+    // so hub-heavy runs of the pair list are spread out anyway
+    const int n_work = (FILL && p.fill_mode == 1) ? p.fill_count : p.n_pairs;
+    for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const int i = (FILL && p.fill_mode == 1) ? p.fill_list[wi] : wi;
         const int u = p.pairs[2 * (size_t)i], v = p.pairs[2 * (size_t)i + 1];
         if (FILL) {
             const int hn = p.hdr_n[i];
             if (hn <= 0) continue;    // finished by the COUNT pass
-            if (p.fill_mode == 2 && (hn > TLC_M_NMAX || (p.hdr_m2[i] >> 1) > TLC_M_MMAX)) continue;   // filled by the early pass
+            const int hm = p.hdr_m2[i] >> 1;
+            if (p.small_dir && hn <= TLC_S_NMAX && hm <= TLC_S_MMAX) continue;                         // written by COUNT
+            if (p.fill_mode == 2 && (hn > TLC_M_NMAX || hm > TLC_M_MMAX)) continue;                    // filled by the early pass
         } else {
             // KeyError on dict_node (riccidist2dgm.py:353): ids the edge-built graph does not contain
             bool missing = u < 0 || v < 0 || u >= p.n_nodes || v >= p.n_nodes;
             if (!missing) missing = (p.rowptr[u + 1] == p.rowptr[u]) || (p.rowptr[v + 1] == p.rowptr[v]);
             if (missing) {
-                if (lane == 0) {
+                if (tid == 0) {
                     p.hdr_n[i] = 0; p.hdr_m2[i] = 0; p.hdr_lu[i] = -1; p.hdr_lv[i] = -1;
                     if (p.out_status) p.out_status[i] = TLC_ST_MISSING_NODE;
                     if (p.out_n) p.out_n[i] = 0;
                 }
-                if (p.out_pi) for (int c = lane; c < res2; c += TLC_WAVE) p.out_pi[(size_t)i * res2 + c] = 0.0;
+                if (p.out_pi) for (int c = tid; c < res2; c += BW) p.out_pi[(size_t)i * res2 + c] = 0.0;
                 continue;
             }
         }
         // ---- the two balls -------------------------------------------------------------------------
-        for (int w = lane; w < 2 * p.nw; w += TLC_WAVE) lds[w] = 0u;
+        {
+            uint4* z = reinterpret_cast<uint4*>(lds);
+            for (int w = tid; w < (2 * nw4) / 4; w += BW) z[w] = make_uint4(0u, 0u, 0u, 0u);
+        }
         __syncthreads();
-        mark_ball(bitsV, v, p.hop, p, frontA, frontB, s_cnt);
-        mark_ball(bitsU, u, p.hop, p, frontA, frontB, s_cnt);
-        if ((p.flags & TLC_INCLUDE_ROOTS) && lane == 0) {   // data_utils_LP.py:111  nodes + [u, v]
+        if (p.hop <= 2) {
+            mark_two_balls_hop2<BW>(bitsU, bitsV, u, v, p.hop, p);
+        } else if (BW == 64) {                              // generic depth: single-wavefront workgroups only (host enforces)
+            mark_ball(bitsV, v, p.hop, p, frontA, frontB, s_cnt);
+            mark_ball(bitsU, u, p.hop, p, frontA, frontB, s_cnt);
+        }
+        if ((p.flags & TLC_INCLUDE_ROOTS) && tid == 0) {   // data_utils_LP.py:111  nodes + [u, v]
             bitsU[u >> 5] |= 1u << (u & 31); bitsV[u >> 5] |= 1u << (u & 31);
             bitsU[v >> 5] |= 1u << (v & 31); bitsV[v >> 5] |= 1u << (v & 31);
         }
         __syncthreads();
-        // ---- S = ball(u) & ball(v)  (:315), per-word popcount prefix -----------------------------------
-        int carry = 0;
-        for (int base = 0; base < p.nw; base += TLC_WAVE) {
-            const int w = base + lane;
-            unsigned s = 0;
-            if (w < p.nw) {
-                s = bitsU[w] & bitsV[w];
-                bitsV[w] = s;
-            }
-            const int pc = __popc(s);
-            const int inc = tlc_wave_iscan_i32(pc);
-            if (w < p.nw) pref[w] = (unsigned)(carry + inc - pc);
-            carry += __shfl(inc, 63, 64);
+        // ---- S = ball(u) & ball(v)  (:315), popcount prefix and the ascending id list in one sweep: every lane owns a
+        //      contiguous chunk of bitmap words, one wave scan links the chunks
+        const int w0 = tid * wpl < p.nw ? tid * wpl : p.nw, w1 = (w0 + wpl) < p.nw ? (w0 + wpl) : p.nw;
+        int mycnt = 0;
+        for (int w = w0; w < w1; ++w) {
+            const unsigned s = bitsU[w] & bitsV[w];
+            bitsV[w] = s;
+            mycnt += __popc(s);
         }
-        const int n = carry;
+        int n = 0;
+        const int excl = block_escan_i32<BW>(mycnt, xw, &n);
+        {
+            int o = excl;
+            for (int w = w0; w < w1; ++w) {
+                unsigned s = bitsV[w];
+                pref[w] = (unsigned)o;
+                while (s) {
+                    const int b = __builtin_ctz(s);
+                    s &= s - 1;
+                    ids[o++] = (w << 5) + b;
+                }
+            }
+        }
         __syncthreads();
         const unsigned* S = bitsV;
         if (!FILL) {
@@ -233,69 +325,82 @@ __global__ __launch_bounds__(TLC_WAVE) void tlc_vicinity_kernel(TlcVicParams p) 
                 if (bit_test(S, v)) lv = local_id(S, pref, v);
             }
             if (n == 0 || n > 65535) {
-                // n == 0: AssertionError, zero connected components (:318).  n > 65535 does not fit the packed
-                // local ids: reported as its own status so that it cannot pass silently.
-                if (lane == 0) {
+                // n == 0: AssertionError, zero connected components (:318).  n > 65535 does not fit the packed local ids:
+                // reported as its own status so that it cannot pass silently.
+                if (tid == 0) {
                     p.hdr_n[i] = 0; p.hdr_m2[i] = 0; p.hdr_lu[i] = lu; p.hdr_lv[i] = lv;
                     if (p.out_status) p.out_status[i] = (n == 0) ? TLC_ST_DISCONNECTED : TLC_ST_TOO_LARGE;
                     if (p.out_n) p.out_n[i] = (n == 0) ? 0 : -n;
                 }
-                if (p.out_pi) for (int c = lane; c < res2; c += TLC_WAVE) p.out_pi[(size_t)i * res2 + c] = 0.0;
+                if (p.out_pi) for (int c = tid; c < res2; c += BW) p.out_pi[(size_t)i * res2 + c] = 0.0;
                 continue;
             }
-            if (lane == 0) { p.hdr_lu[i] = lu; p.hdr_lv[i] = lv; }
+            if (tid == 0) { p.hdr_lu[i] = lu; p.hdr_lv[i] = lv; }
         }
-        // ---- ascending id list of S ---------------------------------------------------------------------
-        for (int w = lane; w < p.nw; w += TLC_WAVE) {
-            unsigned s = S[w];
-            int o = (int)pref[w];
-            while (s) {
-                const int b = __builtin_ctz(s);
-                s &= s - 1;
-                ids[o++] = (w << 5) + b;
+        if (p.out_ids && (FILL || p.small_dir)) {
+            // id output of tlc_vicinity_filtration: by whichever pass finishes the pair's subgraph
+            const bool mine = FILL ? true : (n <= TLC_S_NMAX);
+            if (mine) {
+                const long long no = p.ids_off[i];
+                const long long cap = p.ids_off[i + 1] - no;
+                if (n <= cap) for (int k = tid; k < n; k += BW) p.out_ids[no + k] = ids[k];
             }
-        }
-        __syncthreads();
-        if (FILL && p.out_ids) {
-            const long long no = p.ids_off[i];
-            const long long cap = p.ids_off[i + 1] - no;
-            if (n <= cap) for (int k = lane; k < n; k += TLC_WAVE) p.out_ids[no + k] = ids[k];
         }
         // ---- induced subgraph (graph.subgraph(nodes), :316) -------------------------------------------------
+        const int m2 = induced_rows<false, BW>(ids, n, S, pref, p, lrow, nullptr, nullptr, xw);
+        bool write = FILL;
+        unsigned* wdir = nullptr;
+        double* wlw = nullptr;
         if (!FILL) {
-            const int m2 = induced_rows<false>(ids, n, S, pref, p, nullptr, nullptr, nullptr);
-            if (lane == 0) { p.hdr_n[i] = n; p.hdr_m2[i] = m2; }
+            if (tid == 0) { p.hdr_n[i] = n; p.hdr_m2[i] = m2; }
+            // small vicinities are finished right here: fixed-size slot, no second kernel pass over this pair
+            if (p.small_dir && n <= TLC_S_NMAX && (m2 >> 1) <= TLC_S_MMAX) {
+                write = true;
+                wdir = p.small_dir + (size_t)i * (2 * TLC_S_MMAX);
+                wlw = p.small_lw + (size_t)i * (2 * TLC_S_MMAX);
+            }
         } else {
-            induced_rows<false>(ids, n, S, pref, p, lrow, nullptr, nullptr);
+            const long long eo = p.edge_off[i];
+            wdir = p.A_dir + eo;
+            wlw = p.A_lw + eo;
+        }
+        if (write) {
             __syncthreads();
             int run = 0;
-            for (int base = 0; base < n; base += TLC_WAVE) {
-                const int k = base + lane;
+            for (int base = 0; base < n; base += BW) {
+                const int k = base + tid;
                 const int d = k < n ? lrow[k] : 0;
-                const int inc = tlc_wave_iscan_i32(d);
-                if (k < n) lrow[k] = run + inc - d;
-                run += __shfl(inc, 63, 64);
+                int tot = 0;
+                const int ex = block_escan_i32<BW>(d, xw, &tot);
+                if (k < n) lrow[k] = run + ex;
+                run += tot;
             }
             __syncthreads();
-            const long long eo = p.edge_off[i];
-            induced_rows<true>(ids, n, S, pref, p, lrow, p.A_dir + eo, p.A_lw + eo);
+            induced_rows<true, BW>(ids, n, S, pref, p, lrow, wdir, wlw, xw);
         }
         __syncthreads();
     }
 }
 
-template __global__ void tlc_vicinity_kernel<false>(TlcVicParams);
-template __global__ void tlc_vicinity_kernel<true>(TlcVicParams);
+template __global__ void tlc_vicinity_kernel<false, 64>(TlcVicParams);
+template __global__ void tlc_vicinity_kernel<true, 64>(TlcVicParams);
+template __global__ void tlc_vicinity_kernel<true, 512>(TlcVicParams);
 
 // ---- exclusive scan of the per-pair sizes + tier binning ---------------------------------------------------------
 // Three small kernels (block sums, scan of the block sums, downsweep); n_pairs per chunk is <= 2^20.
 #define SCAN_BLOCK 1024
 
-__global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_block_sums(const int* __restrict__ m2, int n_pairs,
-                                                                  long long* __restrict__ block_sums) {
+__device__ __forceinline__ long long arena_entries(int n, int m2, int small_arena) {
+    if (n <= 0) return 0;
+    if (small_arena && n <= TLC_S_NMAX && (m2 >> 1) <= TLC_S_MMAX) return 0;
+    return (long long)m2;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_block_sums(const int* __restrict__ hn, const int* __restrict__ m2, int n_pairs,
+                                                                  int small_arena, long long* __restrict__ block_sums) {
     __shared__ long long s[SCAN_BLOCK / TLC_WAVE];
     const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    long long v = i < n_pairs ? (long long)m2[i] : 0;
+    long long v = i < n_pairs ? arena_entries(hn[i], m2[i], small_arena) : 0;
     v = tlc_wave_sum_i64(v);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -329,7 +434,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_down(TlcScanParams p) {
     const int t = threadIdx.x;
     const int i = blockIdx.x * SCAN_BLOCK + t;
     const int n = i < p.n_pairs ? p.hdr_n[i] : 0;
-    const long long own = i < p.n_pairs ? (long long)p.hdr_m2[i] : 0;
+    const int m2v = i < p.n_pairs ? p.hdr_m2[i] : 0;
+    const long long own = i < p.n_pairs ? arena_entries(n, m2v, p.small_arena) : 0;
     s[t] = own;
     __syncthreads();
     for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
@@ -342,7 +448,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_down(TlcScanParams p) {
     if (i < p.n_pairs) {
         p.edge_off[i] = p.block_sums[blockIdx.x] + s[t] - own;
         if (n > 0) {
-            const int m = (int)(own >> 1);
+            const int m = m2v >> 1;
             tier = TLC_TIER_HUGE;
             if (n <= TLC_S_NMAX && m <= TLC_S_MMAX) tier = TLC_TIER_SMALL;
             else if (n <= TLC_M_NMAX && m <= TLC_M_MMAX) tier = TLC_TIER_MEDIUM;
