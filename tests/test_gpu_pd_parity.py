@@ -223,3 +223,48 @@ def test_empty_and_degenerate_batches(torch_cuda):
     assert np.array_equal(out == 0, ref == 0)
     assert rel_err(out[ref != 0], ref[ref != 0]).max() < 1e-8
     g.close()
+
+
+def test_huge_tier_and_photo_shaped_hop1(torch_cuda):
+    """Dense graph (Photo-shaped core): hop-1 vicinities with thousands of nodes / >4096 edges take the HUGE tier
+    (state in an HBM scratch slot) and the LARGE tier; both must match the oracle."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    n = 3000
+    e = synth.holme_kim_edges(n, 90000, triad_p=0.6, seed=13)        # mean degree 60, hubs in the hundreds
+    kappa = synth.curvature_array(e, seed=13)
+    rowptr, col, w = synth.edges_to_csr(n, e, kappa)
+    deg = np.diff(rowptr)
+    hubs = np.argsort(-deg)[:12]
+    pairs = np.array([[a, b] for a in hubs[:6] for b in hubs[6:]] + e[:150].tolist(), dtype=np.int32)
+    g = engine.DeviceGraph(rowptr, col, w)
+    for hop in (1, 2):
+        sel = pairs if hop == 1 else pairs[:6]
+        out, st = g.pd_pi_batch(_dev(torch, sel, torch.int32), hop)
+        stats = g.stats()
+        ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, sel, hop, n_threads=0)
+        out = out.cpu().numpy()
+        assert np.array_equal(st.cpu().numpy(), rst), hop
+        nz = ref != 0
+        assert np.array_equal(out == 0, ref == 0)
+        assert rel_err(out[nz], ref[nz]).max() < 1e-8
+        if hop == 2:
+            assert stats["tier_huge"] > 0, stats
+    # the same sizes through tlc_pd_from_filtration (HUGE tier of the pdf kernel)
+    offs, ids, f, nn, mm, sst = oracle.vicinity_filtration(rowptr, col, w, pairs[:3], 2)
+    for k in range(3):
+        S = ids[offs[k]:offs[k] + nn[k]]
+        fv = f[offs[k]:offs[k] + nn[k]]
+        loc = -np.ones(n, dtype=np.int64); loc[S] = np.arange(len(S))
+        mask = (loc[e[:, 0]] >= 0) & (loc[e[:, 1]] >= 0)
+        le = np.stack([loc[e[mask, 0]], loc[e[mask, 1]]], axis=1).astype(np.int32)
+        r = engine.pd_from_filtration(_dev(torch, [0, len(S)], torch.int64), _dev(torch, [0, len(le)], torch.int64),
+                                      _dev(torch, le, torch.int32), _dev(torch, fv, torch.float64), 0)
+        o = oracle.pd_from_filtration([0, len(S)], [0, len(le)], le, fv, 0)
+        c, oc = r["counts"][0].cpu().numpy(), o["counts"][0]
+        assert np.array_equal(c, oc)
+        assert same_multiset(r["up"][:c[0]].cpu().numpy(), o["up"][:oc[0]])
+        assert same_multiset(r["down"][:c[1]].cpu().numpy(), o["down"][:oc[1]])
+        assert same_multiset(r["one"][:c[2]].cpu().numpy(), o["one"][:oc[2]])
+    g.close()

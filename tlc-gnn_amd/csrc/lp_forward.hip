@@ -90,9 +90,11 @@ __global__ void gcn_val_kernel(int n_nodes, const int* __restrict__ rowptr, cons
 
 // ======================================================================================================================
 // f32 MFMA GEMM: C[M,N] = A[M,K] @ B[K,N] (+bias)(ReLU).  N <= 128.
-// Workgroup = 4 waves = 128 rows; each wave owns 32 rows x NT 32-column tiles (v_mfma_f32_32x32x2_f32, exact f32).
-// A and B K-chunks are staged through LDS with coalesced 16-byte loads; LDS rows are padded by one word so that
-// the MFMA operand reads (32 consecutive rows, same k) hit 32 different banks.
+// Workgroup = 4 waves = 128 rows x NT*32 columns: every wave owns 32 rows x all NT column tiles
+// (v_mfma_f32_32x32x2_f32, exact f32).  K-chunks of 32 are staged through LDS with coalesced 16-byte loads; the loads of
+// chunk k+1 are issued into registers before the MFMAs of chunk k and written to LDS after them (register prefetch), so
+// the HBM/L2 latency hides under the matrix pipe.  LDS rows are padded by one word: the operand reads (32 consecutive
+// rows, same k) hit 32 different banks.
 // ======================================================================================================================
 #define GEMM_BM 128
 #define GEMM_KC 32
@@ -102,64 +104,107 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
                                                        const float* __restrict__ B, const float* __restrict__ bias, int relu,
                                                        float* __restrict__ C) {
     constexpr int NP = NT * 32;
+    constexpr int NTH = NT;                           // every wave owns 32 rows x all column tiles
+    constexpr int BQ = (GEMM_KC * NP) / (256 * 4);    // float4 loads of B per thread and chunk
     __shared__ float As[GEMM_BM][GEMM_KC + 1];
     __shared__ float Bs[GEMM_KC][NP + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = wave, cg = 0;
     const int row0 = blockIdx.x * GEMM_BM;
-    f32x16 acc[NT];
+    const bool vecA = (K % 4) == 0, vecB = (N % 4) == 0;
+    f32x16 acc[NTH];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NTH; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    for (int k0 = 0; k0 < K; k0 += GEMM_KC) {
-        // A tile: 128 x 32 floats; thread -> (row = idx / 8, 4 consecutive k)
-        for (int idx = tid; idx < GEMM_BM * (GEMM_KC / 4); idx += 256) {
+    float4 ra[4], rb[BQ > 0 ? BQ : 1];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                 // A tile: 128 x 32 floats = 1024 float4, 4 per thread
+            const int idx = tid + q * 256;
             const int r = idx >> 3, kq = (idx & 7) * 4;
             const int gr = row0 + r, gk = k0 + kq;
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gr < M) {
                 const float* src = A + (size_t)gr * K + gk;
-                if (gk + 3 < K && ((((size_t)gr * K + gk) & 3) == 0)) {
-                    const float4 q = *reinterpret_cast<const float4*>(src);
-                    v0 = q.x; v1 = q.y; v2 = q.z; v3 = q.w;
-                } else {
-                    if (gk < K) v0 = src[0];
-                    if (gk + 1 < K) v1 = src[1];
-                    if (gk + 2 < K) v2 = src[2];
-                    if (gk + 3 < K) v3 = src[3];
+                if (vecA && gk + 3 < K) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (gk < K) v.x = src[0];
+                    if (gk + 1 < K) v.y = src[1];
+                    if (gk + 2 < K) v.z = src[2];
+                    if (gk + 3 < K) v.w = src[3];
                 }
             }
-            As[r][kq] = v0; As[r][kq + 1] = v1; As[r][kq + 2] = v2; As[r][kq + 3] = v3;
+            ra[q] = v;
         }
-        // B tile: 32 x NP
-        for (int idx = tid; idx < GEMM_KC * NP; idx += 256) {
-            const int kk = idx / NP, c = idx - kk * NP;
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) {                // B tile: 32 x NP floats
+            const int idx = tid + q * 256;
+            const int kk = idx / (NP / 4), c = (idx - kk * (NP / 4)) * 4;
             const int gk = k0 + kk;
-            Bs[kk][c] = (gk < K && c < N) ? B[(size_t)gk * N + c] : 0.0f;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gk < K) {
+                const float* src = B + (size_t)gk * N + c;
+                if (vecB && c + 3 < N) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (c < N) v.x = src[0];
+                    if (c + 1 < N) v.y = src[1];
+                    if (c + 2 < N) v.z = src[2];
+                    if (c + 3 < N) v.w = src[3];
+                }
+            }
+            rb[q] = v;
         }
-        __syncthreads();
-        const int ar = wave * 32 + (lane & 31), kh = lane >> 5;
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256;
+            const int r = idx >> 3, kq = (idx & 7) * 4;
+            As[r][kq] = ra[q].x; As[r][kq + 1] = ra[q].y; As[r][kq + 2] = ra[q].z; As[r][kq + 3] = ra[q].w;
+        }
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) {
+            const int idx = tid + q * 256;
+            const int kk = idx / (NP / 4), c = (idx - kk * (NP / 4)) * 4;
+            Bs[kk][c] = rb[q].x; Bs[kk][c + 1] = rb[q].y; Bs[kk][c + 2] = rb[q].z; Bs[kk][c + 3] = rb[q].w;
+        }
+    };
+
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    const int ar = rg * 32 + (lane & 31), kh = lane >> 5;
+    for (int k0 = 0; k0 < K; k0 += GEMM_KC) {
+        const bool more = (k0 + GEMM_KC) < K;
+        if (more) load_chunk(k0 + GEMM_KC);           // in flight during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < GEMM_KC; ks += 2) {
             const float a = As[ar][ks + kh];              // A[i = lane&31][k = lane>>5]
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float b = Bs[ks + kh][t * 32 + (lane & 31)];   // B[k = lane>>5][j = lane&31]
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            for (int t = 0; t < NTH; ++t) {
+                const int tile = cg * NTH + t;
+                if (tile < NT) {
+                    const float b = Bs[ks + kh][tile * 32 + (lane & 31)];   // B[k = lane>>5][j = lane&31]
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
             }
         }
+        __syncthreads();
+        if (more) store_chunk();
         __syncthreads();
     }
     // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int c = t * 32 + (lane & 31);
-        if (c >= N) continue;
+    for (int t = 0; t < NTH; ++t) {
+        const int tile = cg * NTH + t;
+        const int c = tile * 32 + (lane & 31);
+        if (tile >= NT || c >= N) continue;
         const float bv = bias ? bias[c] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int row = row0 + rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < M) {
                 float v = acc[t][r] + bv;
                 if (relu) v = v > 0.0f ? v : 0.0f;
@@ -170,8 +215,43 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
 }
 
 // ======================================================================================================================
-// CSR SpMM: Y[i,:] = act(sum_j val[j] * X[col[j],:] + bias).  G lanes per row (G = 16/32/64), rows per wave = 64/G.
+// CSR SpMM: Y[i,:] = act(sum_j val[j] * X[col[j],:] + bias).  Each row is owned by G lanes, every lane covering 4 adjacent
+// feature columns with 16-byte gathers; 8 neighbour rows are in flight per lane (hub rows of the graph have hundreds of
+// entries and would otherwise serialise on the gather latency).  k % 4 == 0; k <= 4*G.
 // ======================================================================================================================
+template <int G>
+__global__ __launch_bounds__(256) void spmm_csr_v4_kernel(int n_rows, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                          const float* __restrict__ val, const float* __restrict__ X, int k,
+                                                          const float* __restrict__ bias, int relu, float* __restrict__ Y) {
+    const int gid = (blockIdx.x * 256 + threadIdx.x) / G, gl = threadIdx.x % G;
+    if (gid >= n_rows) return;
+    const int c = gl * 4;
+    if (c >= k) return;
+    const int b = rowptr[gid], e = rowptr[gid + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j = b;
+    for (; j + 8 <= e; j += 8) {
+        float4 x[8];
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u] = val[j + u];
+            x[u] = *reinterpret_cast<const float4*>(X + (size_t)col[j + u] * k + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u] * x[u].x; acc.y += v[u] * x[u].y; acc.z += v[u] * x[u].z; acc.w += v[u] * x[u].w; }
+    }
+    for (; j < e; ++j) {
+        const float v = val[j];
+        const float4 x = *reinterpret_cast<const float4*>(X + (size_t)col[j] * k + c);
+        acc.x += v * x.x; acc.y += v * x.y; acc.z += v * x.z; acc.w += v * x.w;
+    }
+    if (bias) { acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3]; }
+    if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    *reinterpret_cast<float4*>(Y + (size_t)gid * k + c) = acc;
+}
+
+// scalar fallback (k not a multiple of 4): G lanes per row, one column per lane and pass
 template <int G>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                        const float* __restrict__ val, const float* __restrict__ X, int k,
@@ -326,7 +406,18 @@ extern "C" int tlc_spmm_csr_f32(int32_t n_rows, const int32_t* d_rowptr, const i
     if (n_rows == 0) return TLC_OK;
     TLC_REQUIRE(d_rowptr && d_col && d_val && d_X && d_Y, "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (k <= 16) {
+    const bool vec = (k % 4) == 0 && k <= 256 && ((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_Y)) & 15) == 0;
+    if (vec && k <= 16) {
+        hipLaunchKernelGGL(spmm_csr_v4_kernel<4>, dim3((unsigned)(((size_t)n_rows * 4 + 255) / 256)), dim3(256), 0, s, n_rows, d_rowptr, d_col, d_val, d_X, k, d_bias, relu, d_Y);
+    } else if (vec && k <= 32) {
+        hipLaunchKernelGGL(spmm_csr_v4_kernel<8>, dim3((unsigned)(((size_t)n_rows * 8 + 255) / 256)), dim3(256), 0, s, n_rows, d_rowptr, d_col, d_val, d_X, k, d_bias, relu, d_Y);
+    } else if (vec && k <= 64) {
+        hipLaunchKernelGGL(spmm_csr_v4_kernel<16>, dim3((unsigned)(((size_t)n_rows * 16 + 255) / 256)), dim3(256), 0, s, n_rows, d_rowptr, d_col, d_val, d_X, k, d_bias, relu, d_Y);
+    } else if (vec && k <= 128) {
+        hipLaunchKernelGGL(spmm_csr_v4_kernel<32>, dim3((unsigned)(((size_t)n_rows * 32 + 255) / 256)), dim3(256), 0, s, n_rows, d_rowptr, d_col, d_val, d_X, k, d_bias, relu, d_Y);
+    } else if (vec) {
+        hipLaunchKernelGGL(spmm_csr_v4_kernel<64>, dim3((unsigned)(((size_t)n_rows * 64 + 255) / 256)), dim3(256), 0, s, n_rows, d_rowptr, d_col, d_val, d_X, k, d_bias, relu, d_Y);
+    } else if (k <= 16) {
         hipLaunchKernelGGL(spmm_csr_kernel<16>, dim3((n_rows * 16 + 255) / 256), dim3(256), 0, s, n_rows, d_rowptr, d_col, d_val, d_X, k, d_bias, relu, d_Y);
     } else if (k <= 32) {
         hipLaunchKernelGGL(spmm_csr_kernel<32>, dim3((n_rows * 32 + 255) / 256), dim3(256), 0, s, n_rows, d_rowptr, d_col, d_val, d_X, k, d_bias, relu, d_Y);
