@@ -177,6 +177,13 @@ int tlc_gat_layer_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d
                       const float* d_Wl, const float* d_att, const float* d_Wij, const float* d_bias,
                       float prelu_slope, float* d_work, float* d_out, void* stream);
 
+/* MessagePassing.aggregate (Knowledge_Distillation/message_passing.py:275-293): torch_scatter.scatter(inputs, index, dim=0,
+ * dim_size=n_out, reduce) with reduce 0 = sum, 1 = mean, 2 = min, 3 = max; empty segments give 0, as torch_scatter does.
+ *   d_index int64[n_src]; d_src float32[n_src,k]; d_out float32[n_out,k]; d_count_work int32[n_out] (not needed for sum).
+ * Float atomics: the summation order is not fixed (same as the reference's scatter kernels). */
+int tlc_scatter_f32(int64_t n_src, const int64_t* d_index, const float* d_src, int32_t k, int reduce, int32_t n_out,
+                    float* d_out, int32_t* d_count_work, void* stream);
+
 /* Edge head of Teacher_Model.forward (Teacher_model.py:54-59): for every non-self-loop edge e=(s,t):
  *   pd[e] = W6 @ prelu(W5 @ [x[s] || x[t]] + b5) + b6   -> float32[n_edges,2] */
 int tlc_edge_head_fwd(int64_t n_edges, const int32_t* d_src, const int32_t* d_dst, const float* d_X,

@@ -268,3 +268,25 @@ def test_huge_tier_and_photo_shaped_hop1(torch_cuda):
         assert same_multiset(r["down"][:c[1]].cpu().numpy(), o["down"][:oc[1]])
         assert same_multiset(r["one"][:c[2]].cpu().numpy(), o["one"][:oc[2]])
     g.close()
+
+
+def test_more_than_one_chunk_of_pairs(torch_cuda):
+    """> 2^20 pairs: the batch is processed in chunks that reuse the handle's workspace; rows must not depend on it."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine
+    d = np.load(os.path.join(G, "e2e.npz"))
+    rowptr, col, w = csr_from_golden(d)
+    g = engine.DeviceGraph(rowptr, col, w)
+    base = d["pairs"].astype(np.int32)
+    reps = (1 << 20) // len(base) + 2
+    pairs = np.tile(base, (reps, 1))
+    assert len(pairs) > (1 << 20)
+    out, st = g.pd_pi_batch(_dev(torch, pairs, torch.int32), 2)
+    ref = torch.from_numpy(d["pi_hop2"])
+    one = out[: len(base)].cpu()
+    assert rel_err(one.numpy()[ref.numpy() != 0], ref.numpy()[ref.numpy() != 0]).max() < 1e-8
+    tiled = out.view(reps, len(base), 25)
+    assert bool((tiled == tiled[0:1]).all())                      # every repetition bit-identical to the first
+    assert bool((st.view(reps, len(base)) == st[: len(base)].view(1, -1)).all())
+    assert g.stats()["chunks"] == 2
+    g.close()

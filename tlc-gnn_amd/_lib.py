@@ -25,7 +25,7 @@ SYMBOLS = [
     "tlc_pd_pi_batch", "tlc_vicinity_filtration", "tlc_pd_pi_batch_stats", "tlc_pd_pi_batch_set_timing",
     "tlc_pd_pi_batch_timings", "tlc_pd_pi_batch_sizes", "tlc_pd_pi_algorithmic_bytes", "tlc_pd_from_filtration",
     "tlc_pi_raster", "tlc_gcn_norm_csr", "tlc_gemm_f32", "tlc_spmm_csr_f32", "tlc_renorm_rows_f32",
-    "tlc_lp_decode_fused", "tlc_gat_layer_fwd", "tlc_edge_head_fwd",
+    "tlc_lp_decode_fused", "tlc_gat_layer_fwd", "tlc_scatter_f32", "tlc_edge_head_fwd",
 ]
 
 
@@ -83,6 +83,8 @@ def lib():
             L.tlc_gat_layer_fwd.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
+            L.tlc_scatter_f32.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
             L.tlc_edge_head_fwd.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p]

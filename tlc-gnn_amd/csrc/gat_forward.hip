@@ -9,6 +9,8 @@
 // two halves are projected ONCE PER NODE (kernel 1, together with lin_l and the attention logit) and the per-edge work
 // collapses to leaky_relu(P_i + Q_j) * softmax weight.  The three scatters (sum, min, max at the target,
 // gat_conv.py:216) become one pass over a CSR row per target: every output row has one owner, no atomics.
+#include <algorithm>
+
 #include "tlc_common.h"
 
 namespace {
@@ -154,7 +156,68 @@ int launch_gat(int n, const int* rowptr, const int* src, const float* X, int c_i
     return TLC_OK;
 }
 
+// ---- generic scatter (message_passing.py:275-293 -> torch_scatter.scatter, reduce sum / mean / min / max) ----------------
+// float atomics at the memory side; min / max order floats through their monotone integer image.
+__device__ __forceinline__ int f32_ord(float x) {
+    const int b = __float_as_int(x);
+    return b >= 0 ? b : (b ^ 0x7fffffff);
+}
+__device__ __forceinline__ float ord_f32(int o) { return __int_as_float(o >= 0 ? o : (o ^ 0x7fffffff)); }
+
+__global__ void scatter_init_kernel(long long n, int reduce, float* __restrict__ out, int* __restrict__ cnt, long long n_rows) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        if (reduce == 2) reinterpret_cast<int*>(out)[t] = 0x7fffffff;          // +max of the ordered image
+        else if (reduce == 3) reinterpret_cast<int*>(out)[t] = (int)0x80000000;
+        else out[t] = 0.0f;
+    }
+    if (cnt && t < n_rows) cnt[t] = 0;
+}
+__global__ void scatter_kernel(long long n_src, const long long* __restrict__ index, const float* __restrict__ src, int k, int reduce,
+                               int n_out, float* __restrict__ out, int* __restrict__ cnt) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_src * k) return;
+    const long long e = t / k;
+    const int c = (int)(t - e * k);
+    const long long i = index[e];
+    if (i < 0 || i >= n_out) return;
+    const float v = src[t];
+    float* dst = out + i * k + c;
+    if (reduce <= 1) atomicAdd(dst, v);
+    else if (reduce == 2) atomicMin(reinterpret_cast<int*>(dst), f32_ord(v));
+    else atomicMax(reinterpret_cast<int*>(dst), f32_ord(v));
+    if (cnt && c == 0) atomicAdd(&cnt[i], 1);
+}
+__global__ void scatter_finish_kernel(long long n, int k, int reduce, float* __restrict__ out, const int* __restrict__ cnt) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int c = cnt[t / k];
+    if (reduce == 1) out[t] = c > 0 ? out[t] / (float)c : 0.0f;
+    else out[t] = c > 0 ? ord_f32(reinterpret_cast<int*>(out)[t]) : 0.0f;      // empty segments stay 0 (torch_scatter)
+}
+
 }  // namespace
+
+extern "C" int tlc_scatter_f32(int64_t n_src, const int64_t* d_index, const float* d_src, int32_t k, int reduce, int32_t n_out,
+                               float* d_out, int32_t* d_count_work, void* stream) {
+    TLC_REQUIRE(n_src >= 0 && k > 0 && n_out >= 0 && reduce >= 0 && reduce <= 3, "bad arguments");
+    if (n_out == 0) return TLC_OK;
+    TLC_REQUIRE(d_out && (n_src == 0 || (d_index && d_src)), "null pointer");
+    TLC_REQUIRE(reduce == 0 || d_count_work, "mean / min / max need the int32[n_out] count workspace");
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)n_out * k;
+    int* cnt = reduce == 0 ? nullptr : d_count_work;
+    hipLaunchKernelGGL(scatter_init_kernel, dim3((unsigned)((std::max<long long>(total, n_out) + 255) / 256)), dim3(256), 0, s, total, reduce,
+                       d_out, cnt, (long long)n_out);
+    if (n_src > 0)
+        hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((n_src * k + 255) / 256)), dim3(256), 0, s, (long long)n_src,
+                           (const long long*)d_index, d_src, k, reduce, n_out, d_out, cnt);
+    if (reduce != 0)
+        hipLaunchKernelGGL(scatter_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, k, reduce, d_out,
+                           (const int*)cnt);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
 
 extern "C" int tlc_gat_layer_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_src, const float* d_X, int32_t c_in,
                                  int32_t c_out, const float* d_Wl, const float* d_att, const float* d_Wij, const float* d_bias,

@@ -118,3 +118,27 @@ def edge_head(src, dst, x, w5, b5, prelu_slope, w6, b6, out=None):
                                       _lib.ptr(_f32(w6)), _lib.ptr(_f32(b6)), _lib.ptr(out), _lib.stream_ptr())
     _lib.check(rc, "tlc_edge_head_fwd")
     return out
+
+
+REDUCE = {"add": 0, "sum": 0, "mean": 1, "min": 2, "max": 3}
+
+
+def scatter(src, index, dim_size, reduce="sum"):
+    """torch_scatter.scatter(src, index, dim=0, dim_size=dim_size, reduce=...) (message_passing.py:292).
+
+    src float32 CUDA [E, ...] (trailing dims flattened), index int64 CUDA [E] -> [dim_size, ...]; empty segments are 0."""
+    torch = _lib.require_gpu()
+    src = _f32(src)
+    E = src.shape[0]
+    tail = tuple(src.shape[1:])
+    k = 1
+    for d in tail:
+        k *= int(d)
+    k = max(k, 1)
+    out = torch.empty((dim_size,) + tail, dtype=torch.float32, device=src.device)
+    r = REDUCE[reduce]
+    cnt = torch.empty(max(dim_size, 1), dtype=torch.int32, device=src.device) if r != 0 else None
+    rc = _lib.lib().tlc_scatter_f32(C.c_int64(E), _lib.ptr(index.contiguous()), _lib.ptr(src), C.c_int32(k), C.c_int(r),
+                                    C.c_int32(dim_size), _lib.ptr(out), _lib.ptr(cnt), _lib.stream_ptr())
+    _lib.check(rc, "tlc_scatter_f32")
+    return out
