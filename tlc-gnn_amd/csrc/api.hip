@@ -187,8 +187,11 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     CK(hipMalloc(&g->d_totals, 2 * sizeof(long long)));
     CK(hipMalloc(&g->d_stats, 2 * sizeof(unsigned long long)));
     CK(hipHostMalloc((void**)&g->h_sync, sizeof(HostSync), hipHostMallocDefault));
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     for (int k = 0; k < TLC_N_SIDE; ++k) {
-        CK(hipStreamCreateWithFlags(&g->side[k], hipStreamNonBlocking));
+        // side[1] carries the heavy tiers (the critical path): highest priority
+        CK(hipStreamCreateWithPriority(&g->side[k], hipStreamNonBlocking, k == 1 ? prio_hi : prio_lo));
         CK(hipEventCreateWithFlags(&g->ev_join[k], hipEventDisableTiming));
     }
     CK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
@@ -312,10 +315,8 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
             used[k] = true;
             return TLC_OK;
         };
-        // 0. the SMALL tier needs nothing more: its subgraphs were written by the COUNT pass
-        if (tc[TLC_TIER_SMALL] > 0 && (rc = launch_side(0, TLC_TIER_SMALL)) != TLC_OK) return rc;
-        // 1. the heavy tiers next: their subgraphs are filled by a small early pass so that the long serial tails of the
-        //    largest vicinities start as soon as possible and overlap everything else
+        // 1. the heavy tiers first: their subgraphs are filled by a small early pass (8 wavefronts per pair) so that the
+        //    long serial tails of the largest vicinities start as soon as possible and overlap everything else
         const int heavy = tc[TLC_TIER_LARGE] + tc[TLC_TIER_HUGE];
         T0(2, s);
         for (int t = TLC_TIER_HUGE; t >= TLC_TIER_LARGE; --t) {
@@ -329,6 +330,9 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
             TLC_HIP_CHECK(hipGetLastError());
             if ((rc = launch_side(1, t)) != TLC_OK) return rc;
         }
+        // 0. the SMALL tier needs nothing more (its subgraphs were written by the COUNT pass); it is submitted after the
+        //    heavy chain so that its many workgroups do not delay that chain's start
+        if (tc[TLC_TIER_SMALL] > 0 && (rc = launch_side(0, TLC_TIER_SMALL)) != TLC_OK) return rc;
         // 2. the MEDIUM tier
         if (tc[TLC_TIER_MEDIUM] > 0) {
             vp.fill_mode = heavy > 0 ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;

@@ -611,6 +611,9 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
     }
     TLC_STAMP(9);
     if (tid < 64) {                                                 // first wavefront; lanes 0 and 1 walk
+        // this wave carries the critical serial chain of the batch: let it win issue arbitration against the other
+        // kernels' waves that share the SIMD
+        __builtin_amdgcn_s_setprio(3);
         const int lane = tid;
         const bool walker = lane < 2;
         const bool qside = (lane & 1) != 0;
@@ -698,6 +701,7 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
             }
         }
         if (lane == 0) { M.ctl[2] = out0 + n_out; M.ctl[8] = n_out; }
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     TLC_STAMP(10);
