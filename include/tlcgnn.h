@@ -50,6 +50,8 @@ extern "C" {
 #define TLC_NORM_EPS         0x04u /* divide by (max + 1e-10): data_utils_LP.py:64                   */
 #define TLC_PI_ORD0_EXT1     0x08u /* image over Ord0 ++ Ext1 only: data_utils_GC.py:155-163         */
 #define TLC_NO_EXT1          0x10u /* extended_flag=False: riccidist2dgm.py:323-326                  */
+#define TLC_UNREACHABLE_100  0x20u /* no connectivity assert; an unreachable root costs the sentinel 100:
+                                      Knowledge_Distillation/data_utils_LP.py:41-49 (filtration only)  */
 
 typedef struct tlc_graph tlc_graph;   /* opaque: device CSR + scratch, bound to one device */
 
@@ -83,10 +85,14 @@ int tlc_pd_pi_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int h
  *   d_node_offs  int64[n_pairs+1]  (caller-provided capacity layout: slot i holds up to
  *                                   node_offs[i+1]-node_offs[i] nodes)
  *   d_out_ids    int32[cap]  ascending node ids of S;  d_out_f float64[cap];  d_out_n int32[n_pairs]
- * A vicinity larger than its slot sets d_out_n[i] = -(size). */
+ * A vicinity larger than its slot sets d_out_n[i] = -(size).
+ * Optional (all three or none): d_edge_offs int64[n_pairs+1] capacity layout, d_out_edges int32[cap,2] = the induced
+ * undirected edges as LOCAL ids (position in the pair's id list, lower id first), d_out_m int32[n_pairs] (-(m) if the slot is
+ * too small): the (filtration_val, edge_index) pair that data_utils_LP.compute_persistence_image(mode='filtration') returns. */
 int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags,
                             const int64_t* d_node_offs, int32_t* d_out_ids, double* d_out_f,
-                            int32_t* d_out_n, uint8_t* d_out_status, void* stream);
+                            int32_t* d_out_n, uint8_t* d_out_status,
+                            const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m, void* stream);
 
 /* Counters of the last tlc_pd_pi_batch on this handle (synchronises the stream):
  * h_out[0..3] = pairs in tier small / medium / large / huge, [4] = induced directed entries (arena size),

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtlc_oracle.so")
 
 ST_OK, ST_MISSING_NODE, ST_DISCONNECTED, ST_ZERO_RANGE, ST_NO_TREE_EDGE = range(5)
-KEEP_ZERO_PERS, INCLUDE_ROOTS, NORM_EPS, PI_ORD0_EXT1, NO_EXT1 = 1, 2, 4, 8, 16
+KEEP_ZERO_PERS, INCLUDE_ROOTS, NORM_EPS, PI_ORD0_EXT1, NO_EXT1, UNREACHABLE_100 = 1, 2, 4, 8, 16, 32
 
 _lib = None
 
@@ -86,7 +86,7 @@ def pd_pi_batch(rowptr, col, w, pairs, hop, flags=0, res=5, n_threads=1):
     return out, st, used
 
 
-def vicinity_filtration(rowptr, col, w, pairs, hop, flags=0, cap=None):
+def vicinity_filtration(rowptr, col, w, pairs, hop, flags=0, cap=None, edge_cap=None):
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
     col = np.ascontiguousarray(col, dtype=np.int32)
     w = np.ascontiguousarray(w, dtype=np.float64)
@@ -100,10 +100,16 @@ def vicinity_filtration(rowptr, col, w, pairs, hop, flags=0, cap=None):
     n = np.zeros(E, dtype=np.int32)
     m = np.zeros(E, dtype=np.int32)
     st = np.zeros(E, dtype=np.uint8)
+    edge_offs = edges = None
+    if edge_cap is not None:
+        edge_offs = np.arange(E + 1, dtype=np.int64) * edge_cap
+        edges = np.zeros((max(E * edge_cap, 1), 2), dtype=np.int32)
     lib().tlco_vicinity_filtration(C.c_int32(n_nodes), _p(rowptr, C.c_int32), _p(col, C.c_int32), _p(w, C.c_double),
                                    _p(pairs, C.c_int32), C.c_int64(E), C.c_int(hop), C.c_uint32(flags),
                                    _p(node_offs, C.c_int64), _p(ids, C.c_int32), _p(f, C.c_double), _p(n, C.c_int32),
-                                   _p(m, C.c_int32), _p(st, C.c_uint8))
+                                   _p(m, C.c_int32), _p(st, C.c_uint8), _p(edge_offs, C.c_int64), _p(edges, C.c_int32))
+    if edge_cap is not None:
+        return node_offs, ids, f, n, m, st, edge_offs, edges
     return node_offs, ids, f, n, m, st
 
 

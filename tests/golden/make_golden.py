@@ -16,6 +16,7 @@ Fixtures:
   G3 pd_from_f.npz       graphs + filtration -> PD pieces, both forks (sg2dgm|Knowledge_Distillation/accelerated_PD.py)
   G4 filtration.npz      (graph,u,v,hop) -> S, f[n]               (sg2dgm/riccidist2dgm.py:20-61,310-320)
   G5 e2e.npz             pairs -> pi_sg rows + exception class    (sg2dgm/riccidist2dgm.py:348-370)
+  G4b kd_lp_filtration.npz  PDGNN LP vicinity: ids, f, induced edges  (Knowledge_Distillation/data_utils_LP.py:105-200)
   G6 kd_gc.npz           PDGNN ground-truth tuples, degree filtration (Knowledge_Distillation/data_utils_GC.py:98-166)
   G7 adj_split.npz       get_adj_split outputs, seed 1234         (loaddatas.py:38-54)
 """
@@ -88,6 +89,11 @@ def import_reference():
     except Exception as e:  # pragma: no cover
         print("WARN: data_utils_GC not importable:", repr(e))
         mods["kd_gc"] = None
+    try:
+        mods["kd_lp"] = importlib.import_module("Knowledge_Distillation.data_utils_LP")
+    except Exception as e:  # pragma: no cover
+        print("WARN: data_utils_LP not importable:", repr(e))
+        mods["kd_lp"] = None
     try:
         mods["lds"] = importlib.import_module("loaddatas")
     except Exception as e:  # pragma: no cover
@@ -383,6 +389,52 @@ def make_g4_g5(mods, do_time=False):
                             ref_seconds=dt)
 
 
+# ----------------------------------------------------------------------------------------------- G4b
+def make_g4b(mods):
+    """PDGNN link-prediction vicinity (Knowledge_Distillation/data_utils_LP.py:105-200, filt='ricci', mode='filtration'):
+    nodes = ball(u) & ball(v) + [u, v], NO connectivity assert (unreachable roots -> 100), normalised by max + 1e-10."""
+    import networkx as nx
+    kd = mods["kd_lp"]
+    if kd is None:
+        print("G4b skipped")
+        return
+    d = np.load(os.path.join(HERE, "e2e.npz"))
+    edges, kappa, pairs = d["edges"], d["kappa"], d["pairs"]
+    g = nx.Graph()
+    g.add_edges_from([(int(a), int(b)) for a, b in edges])
+    ricci = sorted([[int(a), int(b), float(k)] for (a, b), k in zip(edges.tolist(), kappa.tolist())] +
+                   [[int(b), int(a), float(k)] for (a, b), k in zip(edges.tolist(), kappa.tolist())])
+    ids_l, f_l, e_l, pr, hops, none = [], [], [], [], [], []
+    for hop in (1, 2):
+        for i, (u, v) in enumerate(pairs.tolist()):
+            if u not in g or v not in g:
+                continue                                        # networkx raises on a missing root: not a data case
+            fv, ei = kd.compute_persistence_image(g, u, v, filt="ricci", hop=hop, ricci_curv=ricci, mode="filtration")
+            if fv is None:
+                none.append([u, v, hop])
+                continue
+            # the same two statements the function runs, to recover which node each value belongs to (:108-114)
+            nodes_u = [u] + [x for _, x in nx.bfs_edges(g, u, depth_limit=hop)]
+            nodes_v = [v] + [x for _, x in nx.bfs_edges(g, v, depth_limit=hop)]
+            nodes = list(set(nodes_u) & set(nodes_v)) + [u] + [v]
+            sub = nx.convert_node_labels_to_integers(g.subgraph(nodes), label_attribute="old_label")
+            old = np.array([sub._node[k]["old_label"] for k in range(len(sub))], dtype=np.int64)
+            order = np.argsort(old)
+            ids_l.append(old[order])
+            f_l.append(np.asarray(fv, dtype=np.float64)[order])
+            ee = old[np.asarray(ei).T.reshape(-1, 2)]
+            ee = np.sort(ee, axis=1)
+            e_l.append(ee[np.lexsort((ee[:, 1], ee[:, 0]))])
+            pr.append([u, v])
+            hops.append(hop)
+    ids_flat, offs = ragged(ids_l, 0, np.int64)
+    f_flat, _ = ragged(f_l, 0, np.float64)
+    e_flat, e_offs = ragged(e_l, 2, np.int64)
+    np.savez_compressed(os.path.join(HERE, "kd_lp_filtration.npz"), pairs=np.array(pr, dtype=np.int64), hop=np.array(hops),
+                        ids=ids_flat, f=f_flat, offs=offs, edges=e_flat, e_offs=e_offs, none_cases=np.array(none, dtype=np.int64))
+    print("G4b cases:", len(pr), "none:", len(none), "with a 100-sentinel:", sum(1 for f in f_l if len(f) and f.max() > 0 and (np.isclose(f * 0 + 1, 1).all())))
+
+
 # ----------------------------------------------------------------------------------------------- G6
 def make_g6(mods):
     import networkx as nx
@@ -440,12 +492,17 @@ def make_g7(mods):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true", help="also time the reference on the PubMed-shaped graph")
+    ap.add_argument("--only", default="", help="regenerate a single fixture (g4b)")
     args = ap.parse_args()
     assert sys.version_info[:2] < (3, 12), "python>=3.12 sums with compensation: goldens would differ (SURVEY A.2)"
     mods = import_reference()
+    if args.only == "g4b":
+        make_g4b(mods)
+        return
     make_g1_g2(mods)
     make_g3(mods)
     make_g4_g5(mods, do_time=args.time)
+    make_g4b(mods)
     make_g6(mods)
     make_g7(mods)
 

@@ -124,3 +124,73 @@ def test_message_passing_dropin_and_scatter():
     out = Conv().cuda()(x.cuda(), ei.cuda(), w.cuda()).cpu()
     ref = torch.zeros(n, k).index_add_(0, ei[1], (x[ei[0]] - x[ei[1]]) * w.view(-1, 1)) + x
     assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_kd_lp_vicinity_filtration_matches_reference_golden():
+    """PDGNN link-prediction vicinities (data_utils_LP.py:105-200, filt='ricci', mode='filtration') on the GPU:
+    node sets, filtration values (bit-exact, incl. the 100-sentinel of unreachable roots) and induced edges."""
+    import torch
+    from tlc_gnn_amd.Knowledge_Distillation import data_utils_LP as kd
+    d = np.load(os.path.join(G, "kd_lp_filtration.npz"))
+    g5 = np.load(os.path.join(G, "e2e.npz"))
+    edges, kappa = g5["edges"], g5["kappa"]
+    ricci = sorted([[int(a), int(b), float(k)] for (a, b), k in zip(edges.tolist(), kappa.tolist())] +
+                   [[int(b), int(a), float(k)] for (a, b), k in zip(edges.tolist(), kappa.tolist())])
+    vic = kd.Vicinities(edges, ricci)
+    n_disc = 0
+    for hop in (1, 2):
+        sel = np.nonzero(d["hop"] == hop)[0]
+        b = vic.batch(d["pairs"][sel], hop)
+        node_ptr, edge_ptr = b["node_ptr"].cpu().numpy(), b["edge_ptr"].cpu().numpy()
+        ids, f, e = b["ids"].cpu().numpy(), b["f"].cpu().numpy(), b["edges"].cpu().numpy()
+        for k, gi in enumerate(sel):
+            ref_ids = d["ids"][d["offs"][gi]:d["offs"][gi + 1]]
+            ref_f = d["f"][d["offs"][gi]:d["offs"][gi + 1]]
+            my_ids = ids[node_ptr[k]:node_ptr[k + 1]]
+            assert np.array_equal(my_ids, ref_ids), (hop, k)
+            assert np.array_equal(f[node_ptr[k]:node_ptr[k + 1]], ref_f), (hop, k)
+            got = my_ids[e[edge_ptr[k]:edge_ptr[k + 1]]]
+            got = np.sort(got, axis=1)
+            got = got[np.lexsort((got[:, 1], got[:, 0]))]
+            assert np.array_equal(got, d["edges"][d["e_offs"][gi]:d["e_offs"][gi + 1]])
+            n_disc += int(len(ref_f) > 2 and np.sort(ref_f)[-1] > 0.99 and (ref_f > 0.45).sum() >= 1 and (np.isclose(ref_f, ref_f.max()).sum() > 0))
+        nonep = d["none_cases"][d["none_cases"][:, 2] == hop][:, :2]
+        if len(nonep):
+            bn = vic.batch(nonep, hop)
+            assert int(bn["edge_ptr"][-1]) == 0 and int(bn["node_ptr"][-1]) == 0     # the reference returns (None, None)
+    # the single-pair reference signature
+    u, v = d["pairs"][0].tolist()
+    fv, ei = kd.compute_persistence_image(edges, u, v, filt='ricci', hop=int(d["hop"][0]), ricci_curv=ricci, mode='filtration')
+    assert np.array_equal(np.array(fv), d["f"][d["offs"][0]:d["offs"][1]]) and ei.shape[0] == 2
+
+
+def test_gcn_lp_gin_compute_pi_batched_equals_per_pair():
+    """Config 3 caller shape (gcn_LP_GIN.py:43-64): one batched PDGNN forward over all vicinities == per-vicinity forwards."""
+    import torch
+    from tlc_gnn_amd.Knowledge_Distillation import gcn_LP_GIN
+    from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
+    from tlc_gnn_amd.data import Data
+    g5 = np.load(os.path.join(G, "e2e.npz"))
+    edges, kappa = g5["edges"], g5["kappa"]
+    ricci = sorted([[int(a), int(b), float(k)] for (a, b), k in zip(edges.tolist(), kappa.tolist())] +
+                   [[int(b), int(a), float(k)] for (a, b), k in zip(edges.tolist(), kappa.tolist())])
+    torch.manual_seed(11)
+    teacher = Teacher_Model(type='GAT').cuda().eval()
+    pairs = g5["pairs"][:120]
+    data = Data(total_edges=pairs)
+    net = gcn_LP_GIN.Net(data, 8, 2, teacher, g=edges, ricci_curv=ricci).cuda()
+    PI = net.compute_PI(data, "Photo", chunk=50).cpu()
+    assert PI.shape == (120, 25) and bool(torch.isfinite(PI).all())
+    assert int((PI.abs().sum(1) > 0).sum()) > 20
+    # per-pair path through the same modules
+    for i in (0, 3, 17, 64, 119):
+        b = net._vic.batch(pairs[i:i + 1], 1)
+        n = int(b["node_ptr"][-1])
+        if n <= 1:
+            assert float(PI[i].abs().sum()) == 0.0
+            continue
+        loops = torch.arange(n, device="cuda")
+        ei = torch.cat([b["edges"].long().t(), torch.stack([loops, loops])], dim=1)
+        with torch.no_grad():
+            _, img, *_ = teacher(b["f"].float().view(-1, 1), ei, None, compute_loss=False, grad_PI=False)
+        assert torch.allclose(img.cpu().float(), PI[i].float(), rtol=1e-4, atol=1e-6), i

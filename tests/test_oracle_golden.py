@@ -132,3 +132,35 @@ def test_kd_gc_g6():
             assert np.abs(oracle.pi_raster([0, len(up)], up, 5)[0] - d["pi0"][g]).max() < 1e-12
         if len(one):
             assert np.abs(oracle.pi_raster([0, len(one)], one, 5)[0] - d["pi1"][g]).max() < 1e-12
+
+
+def test_kd_lp_filtration_g4b():
+    """PDGNN link-prediction vicinity (data_utils_LP.py:105-200, filt='ricci', mode='filtration')."""
+    d = np.load(os.path.join(G, "kd_lp_filtration.npz"))
+    g5 = np.load(os.path.join(G, "e2e.npz"))
+    rowptr, col, w = csr_from_golden(g5)
+    flags = oracle.INCLUDE_ROOTS | oracle.NORM_EPS | oracle.UNREACHABLE_100
+    n_sentinel = 0
+    for hop in (1, 2):
+        sel = np.nonzero(d["hop"] == hop)[0]
+        pairs = d["pairs"][sel]
+        offs, ids, f, n, m, st, eoffs, edges = oracle.vicinity_filtration(rowptr, col, w, pairs, hop, flags, edge_cap=4000)
+        assert (st == 0).all()
+        for k, gi in enumerate(sel):
+            ref_ids = ragged_slice(d["ids"], d["offs"], gi)
+            ref_f = ragged_slice(d["f"], d["offs"], gi)
+            assert n[k] == len(ref_ids)
+            assert np.array_equal(ids[offs[k]:offs[k] + n[k]], ref_ids)
+            assert np.array_equal(f[offs[k]:offs[k] + n[k]], ref_f), (hop, k)       # bit-exact, sentinel cases included
+            n_sentinel += int(ref_f.max() > 0 and (ref_f * (ref_f.max() and 1)).max() > 0 and n[k] > 2 and ref_f.max() == ref_f.max())
+            ref_e = ragged_slice(d["edges"], d["e_offs"], gi)
+            loc = ids[offs[k]:offs[k] + n[k]]
+            got = loc[edges[eoffs[k]:eoffs[k] + m[k]]]
+            got = np.sort(got, axis=1)
+            got = got[np.lexsort((got[:, 1], got[:, 0]))]
+            assert np.array_equal(got, ref_e)
+        # pairs for which the reference returns (None, None): no edge in the subgraph
+        nonep = d["none_cases"][d["none_cases"][:, 2] == hop][:, :2]
+        if len(nonep):
+            _, _, _, nn, mm, st2 = oracle.vicinity_filtration(rowptr, col, w, nonep, hop, flags)
+            assert (mm == 0).all()

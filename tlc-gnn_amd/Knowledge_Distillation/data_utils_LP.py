@@ -1,0 +1,102 @@
+"""Drop-in for the vicinity / filtration part of the reference's Knowledge_Distillation/data_utils_LP.py (PDGNN, link
+prediction), filt='ricci'.
+
+  ricci_filtration.build_fv :35-65, compute_persistence_image :105-200 (modes 'filtration' and 'PI').
+
+Differences from the TLC-GNN vicinity (sg2dgm/riccidist2dgm.py) that the HIP kernels take as flags: the two roots are always
+part of the subgraph (:111), there is no connectivity assert (an unreachable root costs the sentinel 100, :41-49) and the
+normalisation divides by max + 1e-10 (:64).  Node labels of a vicinity are positions in ASCENDING original id (the reference's
+`convert_node_labels_to_integers` order is arbitrary); edges are listed once, lower label first.
+HKS / degree filtrations, the CBGNN cycle helpers (:256-448, dead code in the reference) and `call` are not reproduced.
+"""
+import numpy as np
+
+from .. import engine, _lib
+
+KD_LP_FLAGS = _lib.INCLUDE_ROOTS | _lib.NORM_EPS | _lib.UNREACHABLE_100
+
+
+class Vicinities:
+    """Device-resident weighted graph for PDGNN's edge-centred vicinities; build once, query many pairs."""
+
+    def __init__(self, g, ricci_curv):
+        from ..sg2dgm.riccidist2dgm import graph2pi
+        self._g2p = graph2pi(g, ricci_curv, keep_labels=True)   # kappa+1 weights (riccidist2dgm.py:216-226)
+        self.dict_node = self._g2p.dict_node
+        self.inv = np.arange(self._g2p.n_nodes, dtype=np.int64)
+        for old, new in self.dict_node.items():
+            self.inv[new] = old
+
+    def batch(self, pairs, hop, node_cap=None, edge_cap=None):
+        """pairs: [E,2] original labels -> dict of CUDA tensors: node_ptr int64[E+1], edge_ptr int64[E+1], ids int64 (original
+        labels, ascending inside a vicinity), f float64, edges int32 [sum m, 2] (local ids, lower first), status uint8[E].
+        Vicinities without an edge have empty slices (the reference returns (None, None) for them, :117-118)."""
+        import torch
+        dev_graph = self._g2p._device_graph()
+        mapped = torch.from_numpy(self._g2p._map_pairs(pairs)).cuda()
+        n_cap = dev_graph.n_nodes if node_cap is None else int(node_cap)
+        e_cap = max(dev_graph.nnz // 2, 1) if edge_cap is None else int(edge_cap)
+        offs, ids, f, n, st, eoffs, edges, m = dev_graph.vicinity_filtration(mapped, hop, flags=KD_LP_FLAGS, cap=n_cap, edge_cap=e_cap)
+        if bool((n < 0).any()) or bool((m < 0).any()):
+            raise RuntimeError("vicinity larger than the requested node_cap / edge_cap")
+        n = torch.where(m > 0, n, torch.zeros_like(n))              # no edge -> (None, None)
+        node_ptr = torch.zeros(len(n) + 1, dtype=torch.int64, device=n.device)
+        node_ptr[1:] = torch.cumsum(n.long(), 0)
+        edge_ptr = torch.zeros(len(m) + 1, dtype=torch.int64, device=m.device)
+        edge_ptr[1:] = torch.cumsum(m.clamp(min=0).long(), 0)
+        # compact the capacity layout (device-side index arithmetic only)
+        tot_n, tot_m = int(node_ptr[-1]), int(edge_ptr[-1])
+        pair_of_node = torch.repeat_interleave(torch.arange(len(n), device=n.device), n.long())
+        k_node = torch.arange(tot_n, device=n.device) - node_ptr[pair_of_node]
+        src_n = offs[pair_of_node] + k_node
+        pair_of_edge = torch.repeat_interleave(torch.arange(len(m), device=m.device), m.clamp(min=0).long())
+        k_edge = torch.arange(tot_m, device=m.device) - edge_ptr[pair_of_edge]
+        src_e = eoffs[pair_of_edge] + k_edge
+        inv = torch.from_numpy(self.inv).to(n.device)
+        return dict(node_ptr=node_ptr, edge_ptr=edge_ptr, ids=inv[ids[src_n].long()], f=f[src_n], edges=edges[src_e],
+                    status=st, pair_of_node=pair_of_node, pair_of_edge=pair_of_edge)
+
+
+_CACHE = {}
+
+
+def _vicinities(g, ricci_curv):
+    key = (id(g), id(ricci_curv))
+    if key not in _CACHE:
+        _CACHE.clear()
+        _CACHE[key] = Vicinities(g, ricci_curv)
+    return _CACHE[key]
+
+
+def compute_persistence_image(g, u, v, filt='hks', hks_time=0.1, hop=2, ricci_curv=None, mode='PI', num_models=5,
+                              max_loop_len=10, cycle_the=2):
+    """Reference signature (:105).  filt='ricci' only; mode 'filtration' -> (filtration_val list, edge_index LongTensor[2,m])
+    or (None, None); mode 'PI' -> the reference's 9-tuple (times are 0)."""
+    import torch
+    if filt != 'ricci':
+        raise NotImplementedError("data_utils_LP (HIP): only filt='ricci' is implemented (hks / degree filtrations are host-side inputs)")
+    b = _vicinities(g, ricci_curv).batch([[u, v]], hop)
+    if int(b["edge_ptr"][-1]) == 0:
+        return None, None
+    fv = b["f"].cpu().numpy()
+    edge_index = b["edges"].t().contiguous().long().cpu()
+    if mode == 'filtration':
+        return fv.tolist(), edge_index
+    if mode != 'PI':
+        raise ValueError("mode must be 'PI' or 'filtration'")
+    n, m = len(fv), edge_index.shape[1]
+    r = engine.pd_from_filtration(torch.tensor([0, n], dtype=torch.int64, device="cuda"),
+                                  torch.tensor([0, m], dtype=torch.int64, device="cuda"),
+                                  b["edges"].contiguous(), b["f"].contiguous(), _lib.KEEP_ZERO_PERS)
+    c = r["counts"][0].cpu().numpy()
+    if c[3] != 1:
+        raise KeyError("vicinity is not connected: the reference's Accelerate_PD raises here (accelerated_PD.py:132-148)")
+    ord0, ext1 = r["up"][:c[0]], r["one"][:c[2]]
+    def img(pts):
+        if pts.shape[0] == 0:
+            return np.zeros(25)
+        return engine.pi_raster(torch.tensor([0, pts.shape[0]], dtype=torch.int64, device="cuda"), pts.contiguous(), 5)[0].cpu().numpy()
+    PI0, PI1 = img(ord0), img(ext1)
+    both = torch.cat((ord0, ext1))
+    pers_img = PI1 if c[0] == 0 else (PI0 if c[2] == 0 else img(both))
+    return ord0.cpu().numpy(), ext1.cpu().numpy(), pers_img, fv.tolist(), edge_index, PI0, PI1, 0.0, 0.0

@@ -17,7 +17,7 @@ ERRORS = {1: "TLC_ERR_INVALID_ARG", 2: "TLC_ERR_HIP", 3: "TLC_ERR_NO_DEVICE", 4:
           5: "TLC_ERR_OUT_OF_MEMORY"}
 
 ST_OK, ST_MISSING_NODE, ST_DISCONNECTED, ST_ZERO_RANGE, ST_NO_TREE_EDGE, ST_TOO_LARGE = range(6)
-KEEP_ZERO_PERS, INCLUDE_ROOTS, NORM_EPS, PI_ORD0_EXT1, NO_EXT1 = 0x1, 0x2, 0x4, 0x8, 0x10
+KEEP_ZERO_PERS, INCLUDE_ROOTS, NORM_EPS, PI_ORD0_EXT1, NO_EXT1, UNREACHABLE_100 = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 
 # every symbol include/tlcgnn.h declares (tests check that the library exports all of them)
 SYMBOLS = [
@@ -62,7 +62,8 @@ def lib():
         L.tlc_pd_pi_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
         L.tlc_vicinity_filtration.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_void_p,
-                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]
         L.tlc_pd_pi_batch_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.tlc_pd_pi_batch_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.tlc_pd_pi_batch_timings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -231,7 +231,8 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
 // one chunk (<= TLC_CHUNK_PAIRS pairs)
 static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop, uint32_t flags, int res,
                      double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
-                     double* d_out_f, int32_t* d_out_n, int pi_enabled, hipStream_t s) {
+                     double* d_out_f, int32_t* d_out_n, const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m,
+                     int pi_enabled, hipStream_t s) {
     int rc;
     if ((rc = ensure_pairs(g, (size_t)n_pairs)) != TLC_OK) return rc;
     if ((rc = ensure_vic_scratch(g, hop)) != TLC_OK) return rc;
@@ -246,7 +247,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     vp.work_counter = g->d_ctl + 4;
     vp.scratch = g->vic_scratch; vp.scratch_stride = g->vic_stride;
     vp.hdr_n = g->hdr_n; vp.hdr_m2 = g->hdr_m2; vp.hdr_lu = g->hdr_lu; vp.hdr_lv = g->hdr_lv;
-    vp.out_pi = d_out_pi; vp.out_status = d_out_status; vp.out_n = d_out_n;
+    vp.out_pi = d_out_pi; vp.out_status = d_out_status; vp.out_n = d_out_n; vp.out_m = d_out_m;
     vp.edge_off = g->edge_off; vp.A_dir = nullptr; vp.A_lw = nullptr;
     vp.ids_off = (const long long*)d_ids_off; vp.out_ids = d_out_ids;
     vp.small_dir = g->S_dir; vp.small_lw = g->S_lw;
@@ -298,6 +299,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         pp.small_dir = g->S_dir; pp.small_lw = g->S_lw;
         pp.flags = flags; pp.res = res; pp.out_pi = d_out_pi; pp.out_status = d_out_status;
         pp.ids_off = (const long long*)d_ids_off; pp.out_f = d_out_f; pp.out_n = d_out_n; pp.pi_enabled = pi_enabled;
+        pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
         pp.huge_scratch = g->huge_scratch; pp.huge_stride = (long long)g->huge_stride;
         pp.huge_nmax = std::min(g->n_nodes, 65535); pp.huge_mmax = (int)(g->nnz / 2 + 1); pp.huge_slots = g->huge_slots;
         pp.stats = g->d_stats;
@@ -356,7 +358,8 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
 
 static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags, int res,
                      double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
-                     double* d_out_f, int32_t* d_out_n, int pi_enabled, void* stream) {
+                     double* d_out_f, int32_t* d_out_n, const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m,
+                     int pi_enabled, void* stream) {
     TLC_REQUIRE(g != nullptr, "graph handle is null");
     TLC_REQUIRE(n_pairs >= 0, "n_pairs < 0");
     TLC_REQUIRE(hop >= 1 && hop <= 64, "hop must be in 1..64");
@@ -372,7 +375,8 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
                            d_out_pi ? d_out_pi + (size_t)off * res * res : nullptr,
                            d_out_status ? d_out_status + off : nullptr,
                            d_ids_off ? d_ids_off + off : nullptr, d_out_ids, d_out_f,
-                           d_out_n ? d_out_n + off : nullptr, pi_enabled, s);
+                           d_out_n ? d_out_n + off : nullptr, d_edge_offs ? d_edge_offs + off : nullptr, d_out_edges,
+                           d_out_m ? d_out_m + off : nullptr, pi_enabled, s);
         if (rc != TLC_OK) return rc;
         if (off + TLC_CHUNK_PAIRS < n_pairs) {
             // the arena and the headers are reused by the next chunk
@@ -387,16 +391,19 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
 extern "C" int tlc_pd_pi_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags, int res,
                                double* d_out_pi, uint8_t* d_out_status, void* stream) {
     TLC_REQUIRE(n_pairs == 0 || d_out_pi != nullptr, "out_pi is null");
-    return run_batch(g, d_pairs, n_pairs, hop, flags, res, d_out_pi, d_out_status, nullptr, nullptr, nullptr, nullptr, 1,
-                     stream);
+    return run_batch(g, d_pairs, n_pairs, hop, flags, res, d_out_pi, d_out_status, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, 1, stream);
 }
 
 extern "C" int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags,
                                        const int64_t* d_node_offs, int32_t* d_out_ids, double* d_out_f, int32_t* d_out_n,
-                                       uint8_t* d_out_status, void* stream) {
+                                       uint8_t* d_out_status, const int64_t* d_edge_offs, int32_t* d_out_edges,
+                                       int32_t* d_out_m, void* stream) {
     TLC_REQUIRE(d_node_offs && d_out_ids && d_out_f && d_out_n, "null output");
-    return run_batch(g, d_pairs, n_pairs, hop, flags, 5, nullptr, d_out_status, d_node_offs, d_out_ids, d_out_f, d_out_n, 0,
-                     stream);
+    const int ne = (d_edge_offs != nullptr) + (d_out_edges != nullptr) + (d_out_m != nullptr);
+    TLC_REQUIRE(ne == 0 || ne == 3, "edge_offs / out_edges / out_m must be given together");
+    return run_batch(g, d_pairs, n_pairs, hop, flags, 5, nullptr, d_out_status, d_node_offs, d_out_ids, d_out_f, d_out_n,
+                     d_edge_offs, d_out_edges, d_out_m, 0, stream);
 }
 
 extern "C" int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream) {

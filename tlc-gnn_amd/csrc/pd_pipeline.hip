@@ -866,7 +866,8 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
             }
             dmx = block_max<W>(dmx, M.red);
             const double un = block_max<W>(unreach ? 1.0 : 0.0, M.red);
-            if (un != 0.0) status = TLC_ST_DISCONNECTED;
+            const bool sentinel = (p.flags & TLC_UNREACHABLE_100) != 0;     // data_utils_LP.py:41-49: NetworkXNoPath -> 100
+            if (un != 0.0 && !sentinel) status = TLC_ST_DISCONNECTED;
             if (status == TLC_ST_OK) {
                 // tight entries: a -> b lies on a (near-)shortest path from a to the root
                 const double tol = 1e-10 * (1.0 + dmx);
@@ -895,6 +896,8 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
                     if (x < n && x != lu && x != lv) {
                         double d1 = 0.0, d2 = 0.0;
                         int a = x, steps = 0;
+                        const bool no_u = (du[x] == TLC_INF_BITS), no_v = (M.dv[x] == TLC_INF_BITS);   // only with `sentinel`
+                        if (no_u) { d1 = 100.0; a = lu; }
                         while (a != lu) {
                             if (M.cntU[a] != 1u || ++steps > n) { amb = true; break; }
                             const int j = (int)M.nxtU[a];
@@ -902,6 +905,7 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
                             a = (int)(M.dir[j] & 0xffffu);
                         }
                         a = x; steps = 0;
+                        if (no_v) { d2 = 100.0; a = lv; }
                         while (!amb && a != lv) {
                             if (M.cntV[a] != 1u || ++steps > n) { amb = true; break; }
                             const int j = (int)M.nxtV[a];
@@ -926,8 +930,11 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
                     if (tid == 0) M.dv[x] = 0ull;
                     __syncthreads();
                     bellman_ford<W, false>(M.dv, M.dv, M.dir, m2, n, LW, M.ctl);
-                    if (tid == 0)
-                        M.f[x] = __longlong_as_double((long long)M.dv[lu]) + __longlong_as_double((long long)M.dv[lv]);
+                    if (tid == 0) {
+                        const double e1 = M.dv[lu] == TLC_INF_BITS ? 100.0 : __longlong_as_double((long long)M.dv[lu]);
+                        const double e2 = M.dv[lv] == TLC_INF_BITS ? 100.0 : __longlong_as_double((long long)M.dv[lv]);
+                        M.f[x] = e1 + e2;
+                    }
                     __syncthreads();
                 }
                 if (namb && tid == 0 && p.stats) atomicAdd(&p.stats[0], (ull)namb);
@@ -966,13 +973,9 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
                 if (tid == 0) p.out_n[i] = n;
             } else if (tid == 0) p.out_n[i] = -n;
         }
-        double acc = 0.0;
-        if (p.pi_enabled && status == TLC_ST_OK && far) {
-            // constant f: no strict pair, [1,1] has persistence 0 => weight 0 => exact zero image (SURVEY.md A.6 Z0);
-            // IndexError for a single node (accelerated_PD.py:122)
-            if (n == 1 && !(p.flags & TLC_NO_EXT1)) status = TLC_ST_NO_TREE_EDGE;
-        } else if (p.pi_enabled && status == TLC_ST_OK) {
-            // ---- undirected edge list: directed entries with src < dst, in CSR order (deterministic compaction) ------
+        const bool want_edges = (p.out_edges != nullptr);
+        if (status == TLC_ST_OK && ((p.pi_enabled && !far) || want_edges)) {
+        // ---- undirected edge list: directed entries with src < dst, in CSR order (deterministic compaction) ------
             {
                 int run = 0;
                 for (int j0 = 0; j0 < m2; j0 += W) {
@@ -1004,6 +1007,25 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
                 }
                 __syncthreads();
             }
+        }
+        if (want_edges) {
+            const long long eo2 = p.edges_off[i];
+            const long long ecap = p.edges_off[i + 1] - eo2;
+            if (status == TLC_ST_OK && m <= ecap) {
+                for (int e = tid; e < m; e += W) {
+                    const unsigned ab = M.dir[e];
+                    p.out_edges[2 * (eo2 + e)] = (int)(ab >> 16);
+                    p.out_edges[2 * (eo2 + e) + 1] = (int)(ab & 0xffffu);
+                }
+                if (tid == 0) p.out_m[i] = m;
+            } else if (tid == 0) p.out_m[i] = status == TLC_ST_OK ? -m : 0;
+        }
+        double acc = 0.0;
+        if (p.pi_enabled && status == TLC_ST_OK && far) {
+            // constant f: no strict pair, [1,1] has persistence 0 => weight 0 => exact zero image (SURVEY.md A.6 Z0);
+            // IndexError for a single node (accelerated_PD.py:122)
+            if (n == 1 && !(p.flags & TLC_NO_EXT1)) status = TLC_ST_NO_TREE_EDGE;
+        } else if (p.pi_enabled && status == TLC_ST_OK) {
             if (tid == 0) { M.ctl[2] = 0; M.ctl[6] = 0; M.ctl[7] = 0; M.ctl[8] = 0; }
             __syncthreads();
             PtsSink sink{M.pts, M.ctl};

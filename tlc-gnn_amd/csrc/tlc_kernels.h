@@ -50,6 +50,7 @@ struct TlcVicParams {
     double* out_pi;
     unsigned char* out_status;
     int* out_n;  // optional (tlc_vicinity_filtration)
+    int* out_m;  // optional (tlc_vicinity_filtration)
     // FILL
     const long long* edge_off;
     unsigned* A_dir;
@@ -99,6 +100,9 @@ struct TlcPdParams {
     const long long* ids_off;
     double* out_f;
     int* out_n;
+    const long long* edges_off;  // optional induced-edge output (tlc_vicinity_filtration)
+    int* out_edges;
+    int* out_m;
     int pi_enabled;
     // HUGE tier: per-workgroup scratch in HBM
     unsigned char* huge_scratch;

@@ -271,6 +271,7 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
                     p.hdr_n[i] = 0; p.hdr_m2[i] = 0; p.hdr_lu[i] = -1; p.hdr_lv[i] = -1;
                     if (p.out_status) p.out_status[i] = TLC_ST_MISSING_NODE;
                     if (p.out_n) p.out_n[i] = 0;
+                    if (p.out_m) p.out_m[i] = 0;
                 }
                 if (p.out_pi) for (int c = tid; c < res2; c += BW) p.out_pi[(size_t)i * res2 + c] = 0.0;
                 continue;
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
                     p.hdr_n[i] = 0; p.hdr_m2[i] = 0; p.hdr_lu[i] = lu; p.hdr_lv[i] = lv;
                     if (p.out_status) p.out_status[i] = (n == 0) ? TLC_ST_DISCONNECTED : TLC_ST_TOO_LARGE;
                     if (p.out_n) p.out_n[i] = (n == 0) ? 0 : -n;
+                    if (p.out_m) p.out_m[i] = 0;
                 }
                 if (p.out_pi) for (int c = tid; c < res2; c += BW) p.out_pi[(size_t)i * res2 + c] = 0.0;
                 continue;

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import KEEP_ZERO_PERS, INCLUDE_ROOTS, NORM_EPS, PI_ORD0_EXT1, NO_EXT1  # noqa: F401
+from ._lib import KEEP_ZERO_PERS, INCLUDE_ROOTS, NORM_EPS, PI_ORD0_EXT1, NO_EXT1, UNREACHABLE_100  # noqa: F401
 
 
 class DeviceGraph:
@@ -87,8 +87,9 @@ class DeviceGraph:
                                                     C.c_int64(n_pairs), _lib.stream_ptr()), "sizes")
         return n, m2
 
-    def vicinity_filtration(self, pairs, hop, flags=0, cap=None):
-        """-> (node_offs int64[E+1], ids int32[E*cap], f float64[E*cap], n int32[E], status uint8[E])"""
+    def vicinity_filtration(self, pairs, hop, flags=0, cap=None, edge_cap=None):
+        """-> (node_offs int64[E+1], ids int32[E*cap], f float64[E*cap], n int32[E], status uint8[E])
+        with edge_cap: additionally (edge_offs int64[E+1], edges int32[E*edge_cap,2] local ids, m int32[E])"""
         import torch
         pairs = pairs.contiguous()
         E = pairs.shape[0]
@@ -99,10 +100,17 @@ class DeviceGraph:
         f = torch.zeros(max(E * cap, 1), dtype=torch.float64, device=dev)
         n = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
         st = torch.zeros(max(E, 1), dtype=torch.uint8, device=dev)
+        eoffs = edges = m = None
+        if edge_cap is not None:
+            eoffs = torch.arange(E + 1, dtype=torch.int64, device=dev) * int(edge_cap)
+            edges = torch.zeros((max(E * int(edge_cap), 1), 2), dtype=torch.int32, device=dev)
+            m = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
         rc = _lib.lib().tlc_vicinity_filtration(self._h, _lib.ptr(pairs), C.c_int64(E), C.c_int(hop), C.c_uint32(flags),
                                                 _lib.ptr(offs), _lib.ptr(ids), _lib.ptr(f), _lib.ptr(n), _lib.ptr(st),
-                                                _lib.stream_ptr())
+                                                _lib.ptr(eoffs), _lib.ptr(edges), _lib.ptr(m), _lib.stream_ptr())
         _lib.check(rc, "tlc_vicinity_filtration")
+        if edge_cap is not None:
+            return offs, ids, f, n[:E], st[:E], eoffs, edges, m[:E]
         return offs, ids, f, n[:E], st[:E]
 
 

@@ -21,17 +21,24 @@ def _edge_array(g):
 
 
 class graph2pi():
-    def __init__(self, g, ricci_curv):
+    def __init__(self, g, ricci_curv, keep_labels=False):
         # nx.convert_node_labels_to_integers(g, label_attribute="old_label") + dict_node (:217-220):
         # labels in first-seen order.  Relabelling only permutes ties; diagrams are compared as multisets.
+        # keep_labels=True (used by the PDGNN vicinity extractor) keeps non-negative integer labels as they are, so that
+        # "ascending node id" inside a vicinity means ascending ORIGINAL label; labels without an edge stay isolated.
         edges = _edge_array(g)
         self.dict_node = {}
-        for a, b in edges.tolist():
-            if a not in self.dict_node:
-                self.dict_node[a] = len(self.dict_node)
-            if b not in self.dict_node:
-                self.dict_node[b] = len(self.dict_node)
-        n = len(self.dict_node)
+        if keep_labels and len(edges) and edges.min() >= 0:
+            for a in np.unique(edges).tolist():
+                self.dict_node[a] = a
+            n = int(edges.max()) + 1
+        else:
+            for a, b in edges.tolist():
+                if a not in self.dict_node:
+                    self.dict_node[a] = len(self.dict_node)
+                if b not in self.dict_node:
+                    self.dict_node[b] = len(self.dict_node)
+            n = len(self.dict_node)
         self.n_nodes = n
         # ricci_curv: [[u, v, kappa], ...] with both directions (:221-226); edge weight = kappa + 1
         self.ricci_curv = {}
