@@ -194,3 +194,35 @@ def test_gcn_lp_gin_compute_pi_batched_equals_per_pair():
         with torch.no_grad():
             _, img, *_ = teacher(b["f"].float().view(-1, 1), ei, None, compute_loss=False, grad_PI=False)
         assert torch.allclose(img.cpu().float(), PI[i].float(), rtol=1e-4, atol=1e-6), i
+
+
+def test_data_utils_gc_dropin_matches_reference_golden_g6():
+    """Config 5 ground truth (data_utils_GC.py:98-166, degree filtration): Ord0, Ext1, PI, PI0, PI1 per graph."""
+    import torch
+    from tlc_gnn_amd.Knowledge_Distillation import data_utils_GC as gc
+    from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
+    from helpers import same_multiset
+    d = np.load(os.path.join(G, "kd_gc.npz"))
+    graphs = []
+    for g in range(len(d["n"])):
+        graphs.append((int(d["n"][g]), d["edges"][d["e_offs"][g]:d["e_offs"][g + 1]]))
+    graphs.insert(5, (4, np.array([[0, 1], [2, 3]])))            # disconnected -> (None, None) like :101-103
+    res = gc.compute_persistence_image_batch(graphs, filt='degree')
+    assert res[5] == (None, None)
+    res_ref = res[:5] + res[6:]
+    for g, r in enumerate(res_ref):
+        d0, d1, img, fv, ei, pi0, pi1, _, _ = r
+        assert np.array_equal(np.array(fv), d["f"][d["f_offs"][g]:d["f_offs"][g + 1]])          # the degree filtration itself
+        assert same_multiset(d0, d["ord0"][d["ord0_offs"][g]:d["ord0_offs"][g + 1]])
+        assert same_multiset(d1, d["ext1"][d["ext1_offs"][g]:d["ext1_offs"][g + 1]])
+        for got, ref in ((img, d["pi"][g]), (pi0, d["pi0"][g]), (pi1, d["pi1"][g])):
+            assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    one = gc.compute_persistence_image(graphs[0], filt='degree', mode='PI')
+    assert np.abs(one[2] - d["pi"][0]).max() < 1e-9
+    # evaluate_time as one batched forward
+    torch.manual_seed(5)
+    model = Teacher_Model(type='GAT').cuda().eval()
+    img, kept = gc.evaluate_batch(model, res)
+    assert img.shape == (len(graphs) - 1, 25) and 5 not in kept and bool(torch.isfinite(img).all())
+    img1, _ = gc.evaluate_batch(model, [res[0]])
+    assert torch.allclose(img1[0], img[0], rtol=1e-4, atol=1e-7)
