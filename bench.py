@@ -156,6 +156,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, t_pi, t_lp = [float(v) for v in t.tolist()]
 
+    # auxiliary (untimed region, single pass): the negative sweep of loaddatas.py:44-53 is dominated by pairs with
+    # d(u,v) > hop; report the throughput on 2^20 uniformly random pairs (PI-C of SURVEY.md 8d) next to the headline
+    sweep = None
+    if rank == 0:
+        g.set_timing(False)
+        rsw = np.random.RandomState(99)
+        sw_pairs = torch.from_numpy(rsw.randint(0, n, size=(1 << 20, 2)).astype(np.int32)).to(dev)
+        sw_out = torch.empty((1 << 20, 25), dtype=torch.float64, device=dev)
+        sw_st = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+        g.pd_pi_batch(sw_pairs, hop, out=sw_out, status=sw_st)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        g.pd_pi_batch(sw_pairs, hop, out=sw_out, status=sw_st)
+        torch.cuda.synchronize()
+        sdt = time.perf_counter() - c0
+        sweep = {"pairs": 1 << 20, "pairs_per_sec": (1 << 20) / sdt, "nonzero_rows": int((sw_out.abs().sum(1) > 0).sum()),
+                 "note": "uniformly random pairs, hop 2, one pass; not part of `value`"}
+        del sw_out, sw_pairs, sw_st
+        g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)      # restore the headline batch's header for sizes()/stats()
+        torch.cuda.synchronize()
     if rank == 0:
         stats = g.stats()
         n_sz, m2_sz = g.sizes(E)
@@ -200,6 +220,7 @@ def main():
                                "achieved": float(bytes_pp.sum()) * world * args.steps / t_pi / 1e9, "peak": HBM_PEAK_GBS * world,
                                "unit": "GB/s", "frac": float(bytes_pp.sum()) * args.steps / t_pi / 1e9 / HBM_PEAK_GBS},
             "kernel_ms": kavg,
+            "sweep": sweep,
         }
         if world == 1 and not args.no_cpu_baseline:
             # the CPU restatement (oracle/tlc_oracle.c, a port of the reference's algorithm) on this box's host cores,

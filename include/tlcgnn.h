@@ -16,6 +16,8 @@
  *   - every call is stream-ordered and asynchronous unless stated otherwise; outputs are fully
  *     overwritten (zero rows are written explicitly, mirroring `pi_sg = np.zeros(...)`,
  *     sg2dgm/riccidist2dgm.py:363);
+ *   - a tlc_graph handle owns mutable scratch: calls on the SAME handle must not overlap (use one handle per
+ *     host thread / per concurrent stream); different handles are independent;
  *   - return value: TLC_OK or a TLC_ERR_* code for API misuse / runtime failure.  Per-pair conditions
  *     that the reference swallows into a zero row (`except BaseException`, riccidist2dgm.py:352-357)
  *     are reported in the per-pair status byte, never as a return code.

@@ -50,7 +50,7 @@ struct tlc_graph {
     size_t cap_pairs;
     int *hdr_n, *hdr_m2, *hdr_lu, *hdr_lv, *tier_list;
     long long* edge_off;
-    // small device block: [0..3] tier counts, [4] work counter, [8..] see below
+    // small device block: [0..3] tier counts
     int* d_ctl;
     long long* d_block_sums;   // 1024
     long long* d_totals;       // 1
@@ -244,7 +244,6 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     memset(&vp, 0, sizeof(vp));
     vp.n_nodes = g->n_nodes; vp.nw = g->nw; vp.rowptr = g->d_rowptr; vp.col = g->d_col; vp.w = g->d_w;
     vp.pairs = d_pairs; vp.n_pairs = n_pairs; vp.hop = hop; vp.flags = flags; vp.res = res;
-    vp.work_counter = g->d_ctl + 4;
     vp.scratch = g->vic_scratch; vp.scratch_stride = g->vic_stride;
     vp.hdr_n = g->hdr_n; vp.hdr_m2 = g->hdr_m2; vp.hdr_lu = g->hdr_lu; vp.hdr_lv = g->hdr_lv;
     vp.out_pi = d_out_pi; vp.out_status = d_out_status; vp.out_n = d_out_n; vp.out_m = d_out_m;

@@ -37,7 +37,6 @@ struct TlcVicParams {
     int hop;
     unsigned flags;
     int res;
-    int* work_counter;
     // per-workgroup scratch slot: 4 * n_nodes + 1 ints (two frontiers, id list, row offsets)
     int* scratch;
     long long scratch_stride;

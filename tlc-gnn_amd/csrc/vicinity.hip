@@ -239,7 +239,6 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
     unsigned* pref = lds + 2 * nw4;
     int* s_cnt = (int*)(lds + 3 * nw4);
     int* xw = s_cnt + 4;                       // BW/64 ints for the block scans
-    const int lane = tlc_lane();
     const int tid = threadIdx.x;
     int* slot = p.scratch + (size_t)blockIdx.x * p.scratch_stride;
     int* frontA = slot;
