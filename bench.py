@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (same guide: 64 FLOP/clk/SIMD)
 
 
 def build_workload(rank, seed=1234):
@@ -176,6 +177,35 @@ def main():
         del sw_out, sw_pairs, sw_st
         g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)      # restore the headline batch's header for sizes()/stats()
         torch.cuda.synchronize()
+    # auxiliary (untimed): the LP leg's two bounded kernels on their own -- the feature GEMM against the f32 MFMA peak and
+    # the scatter-add SpMM against HBM (north_star); torch events on the current stream, which is where ops.* enqueue
+    lp_roof = None
+    if rank == 0:
+        def _avg_us(fn, reps=20):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e3
+        Mr, Kf, Nh = x_local.shape[0], x_local.shape[1], w1.shape[1]
+        xw = torch.empty((Mr, Nh), dtype=torch.float32, device=dev)
+        us_g = _avg_us(lambda: ops.gemm(x_local, w1, out=xw))
+        hfull = torch.empty((n, Nh), dtype=torch.float32, device=dev).normal_()
+        yfull = torch.empty((n, Nh), dtype=torch.float32, device=dev)
+        us_s = _avg_us(lambda: ops.spmm(rowptr_n, col_n, val_n, hfull, bias=b1, relu=True, out=yfull))
+        nnz = int(col_n.shape[0])
+        spmm_bytes = nnz * (Nh * 4 + 8) + n * (Nh * 4 + 4)            # gathered rows + col/val + output rows + rowptr
+        lp_roof = {"feature_gemm": {"bound": "mfma", "shape_mkn": [int(Mr), int(Kf), int(Nh)], "kernel_us": us_g,
+                                    "achieved": 2.0 * Mr * Kf * Nh / us_g / 1e6, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": 2.0 * Mr * Kf * Nh / us_g / 1e6 / MFMA_F32_PEAK_TFLOPS, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"},
+                   "scatter_add_spmm": {"bound": "hbm", "rows": int(n), "nnz": nnz, "k": int(Nh), "kernel_us": us_s,
+                                        "achieved": spmm_bytes / us_s / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": spmm_bytes / us_s / 1e3 / HBM_PEAK_GBS}}
+        del xw, hfull, yfull
     if rank == 0:
         stats = g.stats()
         n_sz, m2_sz = g.sizes(E)
@@ -220,6 +250,7 @@ def main():
                                "achieved": float(bytes_pp.sum()) * world * args.steps / t_pi / 1e9, "peak": HBM_PEAK_GBS * world,
                                "unit": "GB/s", "frac": float(bytes_pp.sum()) * args.steps / t_pi / 1e9 / HBM_PEAK_GBS},
             "kernel_ms": kavg,
+            "roofline_lp": lp_roof,
             "sweep": sweep,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -12,8 +12,8 @@
 // gather over a CSR sorted by target so that every output row has one owner: no atomics, bitwise
 // reproducible, and the bias/activation fuse into the same pass.
 #include "tlc_common.h"
+#include <stdlib.h>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ======================================================================================================================
 // gcn_norm -> CSR by target
@@ -62,17 +62,21 @@ __global__ void gcn_fill_kernel(long long n_edges, const long long* __restrict__
     if (r != c && r >= 0 && c >= 0 && r < n_nodes && c < n_nodes) col[rowptr[c] + atomicAdd(&cursor[c], 1)] = (int)r;
 }
 
-// one thread per target row: append the self loop, sort the sources ascending (rows are short), write the norm
-__global__ void gcn_finish_kernel(int n_nodes, const int* __restrict__ rowptr, int* __restrict__ col, float* __restrict__ val) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per target row: the self loop joins the sources and the row is rank-sorted ascending out of place (every
+// lane counts the entries below its own; hub rows would serialise an in-place sort on the global-memory latency)
+__global__ __launch_bounds__(256) void gcn_finish_kernel(int n_nodes, const int* __restrict__ rowptr, const int* __restrict__ raw,
+                                                         int* __restrict__ col) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (c >= n_nodes) return;
-    const int b = rowptr[c], e = rowptr[c + 1];
-    col[e - 1] = c;                                    // add_remaining_self_loops: one loop per node, weight 1
-    for (int i = b + 1; i < e; ++i) {                  // insertion sort
-        const int x = col[i];
-        int j = i - 1;
-        while (j >= b && col[j] > x) { col[j + 1] = col[j]; --j; }
-        col[j + 1] = x;
+    const int b = rowptr[c], d = rowptr[c + 1] - b;     // entry d-1 is the self loop (add_remaining_self_loops, weight 1)
+    for (int i = lane; i < d; i += 64) {
+        const int vi = i < d - 1 ? raw[b + i] : c;
+        int rank = 0;
+        for (int j = 0; j < d; ++j) {
+            const int vj = j < d - 1 ? raw[b + j] : c;
+            rank += (vj < vi) || (vj == vi && j < i);
+        }
+        col[b + rank] = vi;
     }
 }
 __global__ void gcn_val_kernel(int n_nodes, const int* __restrict__ rowptr, const int* __restrict__ col, float* __restrict__ val) {
@@ -89,129 +93,215 @@ __global__ void gcn_val_kernel(int n_nodes, const int* __restrict__ rowptr, cons
 }
 
 // ======================================================================================================================
-// f32 MFMA GEMM: C[M,N] = A[M,K] @ B[K,N] (+bias)(ReLU).  N <= 128.
-// Workgroup = 4 waves = 128 rows x NT*32 columns: every wave owns 32 rows x all NT column tiles
-// (v_mfma_f32_32x32x2_f32, exact f32).  K-chunks of 32 are staged through LDS with coalesced 16-byte loads; the loads of
-// chunk k+1 are issued into registers before the MFMAs of chunk k and written to LDS after them (register prefetch), so
-// the HBM/L2 latency hides under the matrix pipe.  LDS rows are padded by one word: the operand reads (32 consecutive
-// rows, same k) hit 32 different banks.
+// f32 MFMA GEMM, 16x16x4 tiles: C[M,N] = A[M,K] @ B[K,N] (+bias)(ReLU).  N <= 128.
+// Workgroup = 80 rows x NT*16 columns (PubMed: 19717 rows -> 247 workgroups, one per CU in a single round; N=100 pads to
+// 112, not 128).  Wave w of a group of four owns row tile w across all NT column tiles; the fifth row tile is split by
+// columns over the four waves.  KS such groups split every K chunk between them (two waves per SIMD) and are summed
+// through LDS at the end.  K runs in chunks of KC through double-buffered LDS with two chunks of global loads in flight
+// in registers (one chunk of MFMAs is shorter than an HBM round trip).
+// k is permuted inside every 16-block (lane group g = lane/16 takes k = 4g+s at step s; a sum over k does not care), so a
+// lane's four A operands are contiguous: one ds_read_b128 from rows of stride KC+8 words (conflict-free for b128's lane
+// groups); B stays row-major with stride NP+4 (4 rows apart = 16 banks apart for the two halves of a ds_read_b32).
+// Loads are buffer loads: rows past M, k past K and columns past N fall outside the descriptor and read as zeros, so the
+// pipeline has no branches and the compiler can count the loads in flight (vmcnt(n) instead of vmcnt(0)).
 // ======================================================================================================================
-#define GEMM_BM 128
-#define GEMM_KC 32
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define G16_BM 80
 
-template <int NT>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A,
-                                                       const float* __restrict__ B, const float* __restrict__ bias, int relu,
-                                                       float* __restrict__ C) {
-    constexpr int NP = NT * 32;
-    constexpr int NTH = NT;                           // every wave owns 32 rows x all column tiles
-    constexpr int BQ = (GEMM_KC * NP) / (256 * 4);    // float4 loads of B per thread and chunk
-    __shared__ float As[GEMM_BM][GEMM_KC + 1];
-    __shared__ float Bs[GEMM_KC][NP + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rg = wave, cg = 0;
-    const int row0 = blockIdx.x * GEMM_BM;
-    const bool vecA = (K % 4) == 0, vecB = (N % 4) == 0;
-    f32x16 acc[NTH];
-#pragma unroll
-    for (int t = 0; t < NTH; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+template <int NT, int KC>
+struct G16Layout {
+    static constexpr int NP = NT * 16, SB = NP + 4, AS = KC + 8;
+    static constexpr int A_WORDS = G16_BM * AS, B_WORDS = KC * SB;
+    static constexpr int STAGE_WORDS = 2 * (A_WORDS + B_WORDS), C_WORDS = G16_BM * SB;
+    static constexpr int LDS_BYTES = 4 * (STAGE_WORDS > C_WORDS ? STAGE_WORDS : C_WORDS);
+};
 
-    float4 ra[4], rb[BQ > 0 ? BQ : 1];
-    auto load_chunk = [&](int k0) {
+template <int NT, bool VEC, int KS, int KC>
+__global__ __launch_bounds__(256 * KS) void gemm16_f32_kernel(int M, int N, int K, const float* __restrict__ A,
+                                                              const float* __restrict__ B, const float* __restrict__ bias, int relu,
+                                                              float* __restrict__ C) {
+    using L = G16Layout<NT, KC>;
+    constexpr int TH = 256 * KS;
+    constexpr int NP = L::NP, SB = L::SB, AS = L::AS;
+    constexpr int XT = (NT + 3) / 4;                        // column tiles of the fifth row tile per wave
+    constexpr int NB = NT + XT;
+    constexpr int A4 = G16_BM * KC / 4, B4 = KC * NP / 4;   // float4 slots of the A and B tiles of one chunk
+    constexpr int AQ = (A4 + TH - 1) / TH, BQ = (B4 + TH - 1) / TH;
+    constexpr int A_WORDS = L::A_WORDS, B_WORDS = L::B_WORDS;
+    constexpr int NBLK = KC / 16 / KS;                      // 16-k blocks per wave and chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;                                 // [2][A_WORDS]
+    float* const Bs = smem + 2 * A_WORDS;                   // [2][B_WORDS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, ks = tid >> 8;
+    const int l16 = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * G16_BM;
+
+    f32x4 acc[NB];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                 // A tile: 128 x 32 floats = 1024 float4, 4 per thread
-            const int idx = tid + q * 256;
-            const int r = idx >> 3, kq = (idx & 7) * 4;
-            const int gr = row0 + r, gk = k0 + kq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gr < M) {
-                const float* src = A + (size_t)gr * K + gk;
-                if (vecA && gk + 3 < K) v = *reinterpret_cast<const float4*>(src);
-                else {
-                    if (gk < K) v.x = src[0];
-                    if (gk + 1 < K) v.y = src[1];
-                    if (gk + 2 < K) v.z = src[2];
-                    if (gk + 3 < K) v.w = src[3];
-                }
+    for (int t = 0; t < NB; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int xcol[XT];                                           // clamped: a wave without a real extra tile repeats the last one
+#pragma unroll
+    for (int x = 0; x < XT; ++x) xcol[x] = (wave * XT + x < NT ? wave * XT + x : NT - 1) * 16;
+
+    // The A descriptor covers only this workgroup's rows: no 4 GiB limit on A, and rows past M are out of range.
+    const int rows_here = min(G16_BM, M - row0);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (size_t)row0 * K), 0, rows_here * K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, K * N * 4, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+    u32x4 ra[2][AQ], rb[2][BQ];                             // two chunks in flight
+    auto load_chunk = [&](int k0, int set) {
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            const int idx = tid + q * TH;
+            const int r = idx / (KC / 4), gk = k0 + (idx % (KC / 4)) * 4;
+            const int off = (r * K + gk) * 4;
+            if (VEC) {
+                ra[set][q] = __builtin_amdgcn_raw_buffer_load_b128(rsA, idx < A4 && gk < K ? off : OOB, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    ra[set][q][j] = __builtin_amdgcn_raw_buffer_load_b32(rsA, idx < A4 && gk + j < K ? off + 4 * j : OOB, 0, 0);
             }
-            ra[q] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < BQ; ++q) {                // B tile: 32 x NP floats
-            const int idx = tid + q * 256;
-            const int kk = idx / (NP / 4), c = (idx - kk * (NP / 4)) * 4;
-            const int gk = k0 + kk;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gk < K) {
-                const float* src = B + (size_t)gk * N + c;
-                if (vecB && c + 3 < N) v = *reinterpret_cast<const float4*>(src);
-                else {
-                    if (c < N) v.x = src[0];
-                    if (c + 1 < N) v.y = src[1];
-                    if (c + 2 < N) v.z = src[2];
-                    if (c + 3 < N) v.w = src[3];
-                }
-            }
-            rb[q] = v;
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = tid + q * 256;
-            const int r = idx >> 3, kq = (idx & 7) * 4;
-            As[r][kq] = ra[q].x; As[r][kq + 1] = ra[q].y; As[r][kq + 2] = ra[q].z; As[r][kq + 3] = ra[q].w;
         }
 #pragma unroll
         for (int q = 0; q < BQ; ++q) {
-            const int idx = tid + q * 256;
+            const int idx = tid + q * TH;
             const int kk = idx / (NP / 4), c = (idx - kk * (NP / 4)) * 4;
-            Bs[kk][c] = rb[q].x; Bs[kk][c + 1] = rb[q].y; Bs[kk][c + 2] = rb[q].z; Bs[kk][c + 3] = rb[q].w;
+            const int gk = k0 + kk, off = (gk * N + c) * 4;
+            if (VEC) {
+                rb[set][q] = __builtin_amdgcn_raw_buffer_load_b128(rsB, idx < B4 && gk < K && c < N ? off : OOB, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    rb[set][q][j] = __builtin_amdgcn_raw_buffer_load_b32(rsB, idx < B4 && gk < K && c + j < N ? off + 4 * j : OOB, 0, 0);
+            }
+        }
+    };
+    auto store_chunk = [&](int buf, int set) {
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            const int idx = tid + q * TH;
+            const int r = idx / (KC / 4), kq = (idx % (KC / 4)) * 4;
+            if (idx < A4) *reinterpret_cast<u32x4*>(&As[buf * A_WORDS + r * AS + kq]) = ra[set][q];
+        }
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) {
+            const int idx = tid + q * TH;
+            const int kk = idx / (NP / 4), c = (idx - kk * (NP / 4)) * 4;
+            if (idx < B4) *reinterpret_cast<u32x4*>(&Bs[buf * B_WORDS + kk * SB + c]) = rb[set][q];
+        }
+    };
+    // operands of one 16-k block: read ahead of the MFMAs of the block before it
+    struct Ops { f32x4 a0, a1; float b[4][NB]; };
+    const int a0_off = (wave * 16 + l16) * AS + g * 4, a1_off = (64 + l16) * AS + g * 4;
+    auto read_block = [&](Ops& o, int buf, int kb) {
+        o.a0 = *reinterpret_cast<const f32x4*>(&As[buf * A_WORDS + a0_off + kb * 16]);
+        o.a1 = *reinterpret_cast<const f32x4*>(&As[buf * A_WORDS + a1_off + kb * 16]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float* brow = &Bs[buf * B_WORDS + (kb * 16 + g * 4 + s) * SB + l16];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o.b[s][t] = brow[t * 16];
+#pragma unroll
+            for (int x = 0; x < XT; ++x) o.b[s][NT + x] = brow[xcol[x]];
+        }
+    };
+    auto mfma_block = [&](const Ops& o) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0[s], o.b[s][t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int x = 0; x < XT; ++x) acc[NT + x] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1[s], o.b[s][NT + x], acc[NT + x], 0, 0, 0);
         }
     };
 
-    load_chunk(0);
-    store_chunk();
+    // Iteration ch (parity p): LDS buffer p holds chunk ch, register set p^1 holds chunk ch+1 (in flight), set p is free
+    // and takes chunk ch+2.  Chunk count rounded up to even; chunks past K load zeros.  Every load, store and barrier is
+    // unconditional (the compiler then counts the loads in flight: vmcnt(n), not vmcnt(0)).
+    const int nchunks = ((K + KC - 1) / KC + 1) & ~1;
+    auto step = [&](int ch, int p) {
+        load_chunk((ch + 2) * KC, p);
+        Ops o[2];
+        read_block(o[0], p, ks * NBLK);
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+            if (i + 1 < NBLK) read_block(o[(i + 1) & 1], p, ks * NBLK + i + 1);
+            __builtin_amdgcn_sched_barrier(0);              // keep the reads ahead of the matrix pipe
+            mfma_block(o[i & 1]);
+        }
+        store_chunk(p ^ 1, p ^ 1);
+        __syncthreads();
+    };
+    load_chunk(0, 0);
+    load_chunk(KC, 1);
+    store_chunk(0, 0);
     __syncthreads();
-    const int ar = rg * 32 + (lane & 31), kh = lane >> 5;
-    for (int k0 = 0; k0 < K; k0 += GEMM_KC) {
-        const bool more = (k0 + GEMM_KC) < K;
-        if (more) load_chunk(k0 + GEMM_KC);           // in flight during the MFMAs below
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        step(ch, 0);
+        step(ch + 1, 1);
+    }
+    // accumulators -> LDS tile (C/D layout of 16x16x4: col = lane&15, row = 4*(lane>>4) + reg), summed over the k-split
+    // wave groups, then streamed out as whole rows
+    float* const Cs = smem;
+    auto tile_rows = [&](auto&& fn) {
 #pragma unroll
-        for (int ks = 0; ks < GEMM_KC; ks += 2) {
-            const float a = As[ar][ks + kh];              // A[i = lane&31][k = lane>>5]
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int t = 0; t < NTH; ++t) {
-                const int tile = cg * NTH + t;
-                if (tile < NT) {
-                    const float b = Bs[ks + kh][tile * 32 + (lane & 31)];   // B[k = lane>>5][j = lane&31]
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-                }
-            }
+            for (int r = 0; r < 4; ++r) fn(acc[t][r], (wave * 16 + 4 * g + r) * SB + t * 16 + l16);
+#pragma unroll
+        for (int x = 0; x < XT; ++x)
+            if (wave * XT + x < NT)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fn(acc[NT + x][r], (64 + 4 * g + r) * SB + xcol[x] + l16);
+    };
+#pragma unroll
+    for (int part = KS - 1; part >= 0; --part) {
+        if (ks == part) {
+            if (part == KS - 1) tile_rows([&](float v, int off) { Cs[off] = v; });
+            else tile_rows([&](float v, int off) { Cs[off] += v; });
         }
         __syncthreads();
-        if (more) store_chunk();
-        __syncthreads();
     }
-    // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int t = 0; t < NTH; ++t) {
-        const int tile = cg * NTH + t;
-        const int c = tile * 32 + (lane & 31);
-        if (tile >= NT || c >= N) continue;
-        const float bv = bias ? bias[c] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < M) {
-                float v = acc[t][r] + bv;
-                if (relu) v = v > 0.0f ? v : 0.0f;
-                C[(size_t)row * N + c] = v;
+    if (VEC) {
+        const int n4 = N >> 2;
+        for (int idx = tid; idx < G16_BM * n4; idx += TH) {
+            const int r = idx / n4, c = (idx - r * n4) * 4;
+            if (row0 + r >= M) break;
+            float4 v = *reinterpret_cast<const float4*>(&Cs[r * SB + c]);
+            if (bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
             }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(C + (size_t)(row0 + r) * N + c) = v;
+        }
+    } else {
+        for (int idx = tid; idx < G16_BM * N; idx += TH) {
+            const int r = idx / N, c = idx - r * N;
+            if (row0 + r >= M) break;
+            float v = Cs[r * SB + c] + (bias ? bias[c] : 0.0f);
+            if (relu) v = fmaxf(v, 0.f);
+            C[(size_t)(row0 + r) * N + c] = v;
         }
     }
+}
+
+template <int NT, bool VEC, int KS, int KC>
+static hipError_t gemm16_launch(int M, int N, int K, const float* A, const float* B, const float* bias, int relu, float* C, hipStream_t s) {
+    static bool attr_set[64] = {};                          // dynamic LDS opt-in, once per kernel and device
+    auto kern = gemm16_f32_kernel<NT, VEC, KS, KC>;
+    constexpr int lds = G16Layout<NT, KC>::LDS_BYTES;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((M + G16_BM - 1) / G16_BM), dim3(256 * KS), lds, s, M, N, K, A, B, bias, relu, C);
+    return hipGetLastError();
 }
 
 // ======================================================================================================================
@@ -219,36 +309,86 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
 // feature columns with 16-byte gathers; 8 neighbour rows are in flight per lane (hub rows of the graph have hundreds of
 // entries and would otherwise serialise on the gather latency).  k % 4 == 0; k <= 4*G.
 // ======================================================================================================================
+#define SPMM_HUB 32
+#define SPMM_CAP 2048
 template <int G>
 __global__ __launch_bounds__(256) void spmm_csr_v4_kernel(int n_rows, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                           const float* __restrict__ val, const float* __restrict__ X, int k,
                                                           const float* __restrict__ bias, int relu, float* __restrict__ Y) {
-    const int gid = (blockIdx.x * 256 + threadIdx.x) / G, gl = threadIdx.x % G;
-    if (gid >= n_rows) return;
+    constexpr int NG = 256 / G;                         // rows (lane groups) per workgroup
+    __shared__ int s_col[NG * SPMM_HUB];                // per group: the indices/values of its own row
+    __shared__ float s_val[NG * SPMM_HUB];
+    __shared__ int h_col[SPMM_CAP];                     // hub rows: one chunk of the row, staged by the whole workgroup
+    __shared__ float h_val[SPMM_CAP];
+    __shared__ int hub_rows[NG];
+    __shared__ int n_hub;
+    __shared__ float4 part[NG][G];
+    const int tid = threadIdx.x, grp = tid / G, gl = tid % G;
+    // rows are dealt to workgroups round-robin (row = grp * gridDim.x + blockIdx.x): hub rows with neighbouring ids
+    // (old nodes of a preferential-attachment graph, degree-sorted inputs) land in different workgroups
+    const int row = grp * gridDim.x + blockIdx.x;
     const int c = gl * 4;
-    if (c >= k) return;
-    const int b = rowptr[gid], e = rowptr[gid + 1];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int j = b;
-    for (; j + 8 <= e; j += 8) {
-        float4 x[8];
-        float v[8];
+    const bool lane_ok = c < k;
+    if (tid == 0) n_hub = 0;
+    __syncthreads();
+    int b = 0, e = 0;
+    if (row < n_rows) { b = rowptr[row]; e = rowptr[row + 1]; }
+    const int d = e - b;
+    // rows above SPMM_HUB entries are left to the whole workgroup below: one lane group walking a hub row alone
+    // (dozens of dependent gather rounds) would be the tail of the launch
+    const bool hub = d > SPMM_HUB;
+    if (hub && gl == 0) hub_rows[atomicAdd(&n_hub, 1)] = row;
+    if (!hub)
+        for (int i = gl; i < d; i += G) { s_col[grp * SPMM_HUB + i] = col[b + i]; s_val[grp * SPMM_HUB + i] = val[b + i]; }
+    __syncthreads();
+    auto finish = [&](float4 acc, int r) {
+        if (bias) { acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3]; }
+        if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        *reinterpret_cast<float4*>(Y + (size_t)r * k + c) = acc;
+    };
+    // staged entries j0, j0+step, ... < j1, eight gathers in flight per round: a gather depends on one global round
+    // trip (the X row); the tail round is predicated (entries past j1 re-read the round's first row and are zeroed)
+    auto gather = [&](float4 acc, const int* sc, const float* sv, int j0, int j1, int step) {
+        for (int j = j0; j < j1; j += 8 * step) {
+            float4 x[8];
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            v[u] = val[j + u];
-            x[u] = *reinterpret_cast<const float4*>(X + (size_t)col[j + u] * k + c);
+            for (int u = 0; u < 8; ++u) {
+                const int jj = j + u * step;
+                const bool ok = jj < j1;
+                const int js = ok ? jj : j;
+                v[u] = ok ? sv[js] : 0.0f;
+                x[u] = *reinterpret_cast<const float4*>(X + (size_t)sc[js] * k + c);
+                if (!ok) x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u] * x[u].x; acc.y += v[u] * x[u].y; acc.z += v[u] * x[u].z; acc.w += v[u] * x[u].w; }
         }
+        return acc;
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < n_rows && !hub && lane_ok) finish(gather(zero4, s_col + grp * SPMM_HUB, s_val + grp * SPMM_HUB, 0, d, 1), row);
+    const int nh = n_hub;
+    for (int h = 0; h < nh; ++h) {                      // hub row: group g takes entries g, g+NG, ...; fixed-order sum
+        const int r = hub_rows[h];
+        const int hb = rowptr[r], he = rowptr[r + 1];
+        float4 acc = zero4;
+        for (int cb = hb; cb < he; cb += SPMM_CAP) {
+            const int cn = min(SPMM_CAP, he - cb);
+            __syncthreads();                            // the previous chunk / row is done with h_col, h_val and part
+            for (int i = tid; i < cn; i += 256) { h_col[i] = col[cb + i]; h_val[i] = val[cb + i]; }
+            __syncthreads();
+            if (lane_ok) acc = gather(acc, h_col, h_val, grp, cn, NG);
+        }
+        part[grp][gl] = acc;
+        __syncthreads();
+        if (grp == 0 && lane_ok) {
+            float4 t = part[0][gl];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { acc.x += v[u] * x[u].x; acc.y += v[u] * x[u].y; acc.z += v[u] * x[u].z; acc.w += v[u] * x[u].w; }
+            for (int q = 1; q < NG; ++q) { const float4 p = part[q][gl]; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }
+            finish(t, r);
+        }
     }
-    for (; j < e; ++j) {
-        const float v = val[j];
-        const float4 x = *reinterpret_cast<const float4*>(X + (size_t)col[j] * k + c);
-        acc.x += v * x.x; acc.y += v * x.y; acc.z += v * x.z; acc.w += v * x.w;
-    }
-    if (bias) { acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3]; }
-    if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-    *reinterpret_cast<float4*>(Y + (size_t)gid * k + c) = acc;
 }
 
 // scalar fallback (k not a multiple of 4): G lanes per row, one column per lane and pass
@@ -362,16 +502,16 @@ extern "C" int tlc_gcn_norm_csr(int32_t n_nodes, int64_t n_edges, const int64_t*
     TLC_REQUIRE(n_nodes > 0 && n_edges >= 0, "bad sizes");
     TLC_REQUIRE(d_rowptr && d_col && d_val && (n_edges == 0 || d_edge_index), "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    int* tmp = nullptr;   // [cnt n | cursor n]
-    TLC_HIP_CHECK(hipMalloc(&tmp, 2 * (size_t)n_nodes * sizeof(int)));
+    int* tmp = nullptr;   // [cnt n | cursor n | unsorted col n_edges + n]
+    TLC_HIP_CHECK(hipMalloc(&tmp, (3 * (size_t)n_nodes + (size_t)n_edges) * sizeof(int)));
     int rc = TLC_OK;
     do {
         if (hipMemsetAsync(tmp, 0, 2 * (size_t)n_nodes * sizeof(int), s) != hipSuccess) { rc = TLC_ERR_HIP; break; }
         const int eb = (int)((n_edges + 255) / 256), nb = (n_nodes + 255) / 256;
         if (n_edges) hipLaunchKernelGGL(gcn_count_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, tmp);
         hipLaunchKernelGGL(gcn_scan_kernel, dim3(1), dim3(1024), 0, s, n_nodes, (const int*)tmp, d_rowptr, d_nnz);
-        if (n_edges) hipLaunchKernelGGL(gcn_fill_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, (const int*)d_rowptr, tmp + n_nodes, d_col);
-        hipLaunchKernelGGL(gcn_finish_kernel, dim3(nb), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, d_col, d_val);
+        if (n_edges) hipLaunchKernelGGL(gcn_fill_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, (const int*)d_rowptr, tmp + n_nodes, tmp + 2 * (size_t)n_nodes);
+        hipLaunchKernelGGL(gcn_finish_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)(tmp + 2 * (size_t)n_nodes), d_col);
         hipLaunchKernelGGL(gcn_val_kernel, dim3(nb), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)d_col, d_val);
         if (hipGetLastError() != hipSuccess) { rc = TLC_ERR_HIP; break; }
     } while (0);
@@ -388,14 +528,22 @@ extern "C" int tlc_gemm_f32(int32_t M, int32_t N, int32_t K, const float* d_A, c
     if (M == 0) return TLC_OK;
     TLC_REQUIRE(d_A && d_B && d_C, "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((M + GEMM_BM - 1) / GEMM_BM), block(256);
-    const int nt = (N + 31) / 32;
-    switch (nt) {
-        case 1: hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, block, 0, s, M, N, K, d_A, d_B, d_bias, relu, d_C); break;
-        case 2: hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, block, 0, s, M, N, K, d_A, d_B, d_bias, relu, d_C); break;
-        case 3: hipLaunchKernelGGL(gemm_f32_kernel<3>, grid, block, 0, s, M, N, K, d_A, d_B, d_bias, relu, d_C); break;
-        default: hipLaunchKernelGGL(gemm_f32_kernel<4>, grid, block, 0, s, M, N, K, d_A, d_B, d_bias, relu, d_C); break;
+    TLC_REQUIRE((long long)K * N * 4 < (1ll << 31) && (long long)G16_BM * K * 4 < (1ll << 31), "K too large for the 32-bit buffer offsets");
+    const bool vec = (K % 4) == 0 && (N % 4) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(d_A) | reinterpret_cast<uintptr_t>(d_B) | reinterpret_cast<uintptr_t>(d_C) |
+                       reinterpret_cast<uintptr_t>(d_bias)) & 15) == 0;
+    hipError_t le = hipSuccess;
+#define TLC_G16(NT_)                                                                              \
+    case NT_:                                                                                     \
+        le = vec ? gemm16_launch<NT_, true, 2, 32>(M, N, K, d_A, d_B, d_bias, relu, d_C, s)       \
+                 : gemm16_launch<NT_, false, 2, 32>(M, N, K, d_A, d_B, d_bias, relu, d_C, s);     \
+        break;
+    switch ((N + 15) / 16) {
+        TLC_G16(1) TLC_G16(2) TLC_G16(3) TLC_G16(4) TLC_G16(5) TLC_G16(6) TLC_G16(7) TLC_G16(8)
+        default: break;
     }
+#undef TLC_G16
+    TLC_HIP_CHECK(le);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }
