@@ -54,7 +54,7 @@ struct tlc_graph {
     int* d_ctl;
     long long* d_block_sums;   // 1024
     long long* d_totals;       // 1
-    unsigned long long* d_stats;  // 2
+    unsigned long long* d_stats;  // [0] tie-fallback sources, [2] (as int) LARGE workgroups started
     HostSync* h_sync;          // pinned
     // arena
     size_t cap_entries;
@@ -77,7 +77,7 @@ struct tlc_graph {
     hipStream_t side[TLC_N_SIDE];
     hipEvent_t ev_fork, ev_join[TLC_N_SIDE];
     long long last_stats[8];
-    unsigned long long* d_phase;   // diagnostics: [TLC_N_TIERS][16] cycle counters, null unless enabled
+    unsigned long long* d_phase;   // diagnostics: [TLC_N_TIERS][32] cycle counters, null unless enabled
     // optional per-kernel timing (tlc_pd_pi_batch_set_timing): events bracket each launch on its own stream
     int timing;
     hipEvent_t ev_t[16];           // 0/1 count, 2/3 scan, 4/5 fill, 6+2t / 7+2t tier t
@@ -185,7 +185,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     CK(hipMalloc(&g->d_ctl, 64 * sizeof(int)));
     CK(hipMalloc(&g->d_block_sums, 1024 * sizeof(long long)));
     CK(hipMalloc(&g->d_totals, 2 * sizeof(long long)));
-    CK(hipMalloc(&g->d_stats, 2 * sizeof(unsigned long long)));
+    CK(hipMalloc(&g->d_stats, 4 * sizeof(unsigned long long)));
     CK(hipHostMalloc((void**)&g->h_sync, sizeof(HostSync), hipHostMallocDefault));
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -229,6 +229,14 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
 }
 
 // one chunk (<= TLC_CHUNK_PAIRS pairs)
+// one wavefront that returns when *counter >= target or after max_ticks of the 100 MHz wall clock
+__global__ void tlc_wait_started(const int* counter, int target, long long max_ticks) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && wall_clock64() - t0 < max_ticks)
+        __builtin_amdgcn_s_sleep(8);
+}
+
 static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop, uint32_t flags, int res,
                      double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
                      double* d_out_f, int32_t* d_out_n, const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m,
@@ -238,7 +246,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     if ((rc = ensure_vic_scratch(g, hop)) != TLC_OK) return rc;
     if ((rc = ensure_small(g, (size_t)n_pairs)) != TLC_OK) return rc;
     TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl, 0, 64 * sizeof(int), s));
-    TLC_HIP_CHECK(hipMemsetAsync(g->d_stats, 0, 2 * sizeof(unsigned long long), s));
+    TLC_HIP_CHECK(hipMemsetAsync(g->d_stats, 0, 4 * sizeof(unsigned long long), s));
 
     TlcVicParams vp;
     memset(&vp, 0, sizeof(vp));
@@ -302,12 +310,13 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         pp.huge_scratch = g->huge_scratch; pp.huge_stride = (long long)g->huge_stride;
         pp.huge_nmax = std::min(g->n_nodes, 65535); pp.huge_mmax = (int)(g->nnz / 2 + 1); pp.huge_slots = g->huge_slots;
         pp.stats = g->d_stats;
+        pp.started = (int*)(g->d_stats + 2);
         bool used[TLC_N_SIDE] = {false, false, false};
         auto launch_side = [&](int k, int t) -> int {
             TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s));
             TLC_HIP_CHECK(hipStreamWaitEvent(g->side[k], g->ev_fork, 0));
             pp.tier_list = g->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
-            pp.phase_cycles = g->d_phase ? g->d_phase + 16 * t : nullptr;
+            pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
             T0(3 + t, g->side[k]);
             int r = tlc_launch_pd_tier(t, pp, g->side[k]);
             if (r != TLC_OK) return r;
@@ -330,6 +339,15 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
                 hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(std::min(tc[t], g->vic_slots)), dim3(TLC_WAVE), g->vic_lds, s, vp);
             TLC_HIP_CHECK(hipGetLastError());
             if ((rc = launch_side(1, t)) != TLC_OK) return rc;
+        }
+        // A LARGE workgroup needs nearly all of a CU's LDS.  If the many small workgroups of the other tiers reach the CUs
+        // first, the dispatcher cannot place it until those kernels drain (measured: the whole LARGE tier, the critical
+        // path of the batch, starts ~0.35 ms late).  So the main stream -- and with it the SMALL fork and the MEDIUM fill --
+        // is held until the LARGE workgroups report themselves resident; the wait is bounded (50 us).
+        if (tc[TLC_TIER_LARGE] > 0) {
+            hipLaunchKernelGGL(tlc_wait_started, dim3(1), dim3(TLC_WAVE), 0, s, (const int*)pp.started,
+                               std::min(tc[TLC_TIER_LARGE], 192), 5000ll);
+            TLC_HIP_CHECK(hipGetLastError());
         }
         // 0. the SMALL tier needs nothing more (its subgraphs were written by the COUNT pass); it is submitted after the
         //    heavy chain so that its many workgroups do not delay that chain's start
@@ -476,13 +494,13 @@ extern "C" int tlc_pi_raster(int32_t n_dgms, const int64_t* d_offs, const double
 }
 
 // ---- diagnostics (not part of include/tlcgnn.h): per-phase cycle counters of the PD tier kernels -------------------
-extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out /* [4][16] or null */) {
+extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out /* [4][32] or null */) {
     TLC_REQUIRE(g != nullptr, "null graph");
     TLC_HIP_CHECK(hipSetDevice(g->device));
     TLC_HIP_CHECK(hipDeviceSynchronize());
-    if (h_out && g->d_phase) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_phase, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (enable && !g->d_phase) TLC_HIP_CHECK(hipMalloc(&g->d_phase, 64 * sizeof(unsigned long long)));
-    if (g->d_phase) TLC_HIP_CHECK(hipMemset(g->d_phase, 0, 64 * sizeof(unsigned long long)));
+    if (h_out && g->d_phase) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_phase, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (enable && !g->d_phase) TLC_HIP_CHECK(hipMalloc(&g->d_phase, 128 * sizeof(unsigned long long)));
+    if (g->d_phase) TLC_HIP_CHECK(hipMemset(g->d_phase, 0, 128 * sizeof(unsigned long long)));
     if (!enable && g->d_phase) { hipFree(g->d_phase); g->d_phase = nullptr; }
     return TLC_OK;
 }

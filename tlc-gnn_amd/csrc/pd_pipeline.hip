@@ -22,16 +22,21 @@
 #include "tlc_kernels.h"
 
 #define TLC_INF_BITS 0x7FF0000000000000ull
-// diagnostics: accumulate the cycles thread 0 spent since the previous stamp into phase slot k (only when the
-// caller passed a phase_cycles buffer; tools/phase_profile.py)
+// diagnostics (make PHASE_DEBUG=1; tools/phase_profile.py): accumulate the cycles thread 0 spent since the previous stamp
+// into phase slot k.  Compiled out by default: the counters cost registers in every tier kernel.
+#ifdef TLC_PHASE_DEBUG
 #define TLC_STAMP(k)                                                                 \
     do {                                                                             \
-        if (pc && threadIdx.x == 0) {                                    \
+        if (pc && threadIdx.x == 0) {                                                \
             const unsigned long long _t = clock64();                                 \
-            atomicAdd(&pc[(k)], _t - t_prev);                            \
+            atomicAdd(&pc[(k)], _t - t_prev);                                        \
+            ph[(k)] += _t - t_prev;                                                  \
             t_prev = _t;                                                             \
         }                                                                            \
     } while (0)
+#else
+#define TLC_STAMP(k) do { } while (0)
+#endif
 #define TLC_NONE16 0xFFFFu
 
 namespace {
@@ -55,7 +60,7 @@ __host__ __device__ constexpr size_t smax(size_t a, size_t b) { return a > b ? a
 //   dir region: directed entries, then [undirected edges (lo<<16|hi in rank space) | ascending rank of every edge],
 //              then (with lw) the image table
 struct Layout {
-    size_t o_f, o_dir, o_lw, o_x, o_vals, o_amb, o_par, o_mark, o_pn, o_pts, o_ctl, total;
+    size_t o_f, o_dir, o_lw, o_x, o_vals, o_amb, o_par, o_mark, o_pn, o_pts, o_ctl, o_rec, total;
     int P;   // capacity of the sort buffers (power of two >= max(NM, MM))
 };
 __host__ __device__ constexpr size_t aux_bytes(int NM, int MM, int idxb) {
@@ -76,7 +81,7 @@ __host__ __device__ constexpr Layout make_layout(int NM, int MM, bool lwl, int i
     // the cycle swap re-uses everything from o_x up to o_pn: par, key, mark (u32) and two u64 tables per node
     {
         const size_t have = (o - L.o_x) + 3 * al16((size_t)NM * idxb);
-        const size_t need = (size_t)NM * 28 + 16;
+        const size_t need = (size_t)(NM + 1) * 28 + 16;     // one spare node slot for the idle walker
         if (have < need) o += al16(need - have);
     }
     L.o_amb = o;  o += al16((size_t)NM * idxb);                         // tie-fallback list, then union-find parents
@@ -85,6 +90,9 @@ __host__ __device__ constexpr Layout make_layout(int NM, int MM, bool lwl, int i
     L.o_pn = o;   o += al16((size_t)MM * 4);                            // Pos from the front, Neg from the back (edge ids)
     L.o_pts = o;  o += al16((size_t)(MM + 2) * 4);                      // diagram points (birth node<<16 | death node)
     L.o_ctl = o;  o += 256;
+    // cycle swap: the two walks' path records, [2][65] nodes + [2][65] keys (the entry weights are dead by then)
+    if (lwl && (size_t)2 * MM * 8 >= 1280) L.o_rec = L.o_lw;
+    else { L.o_rec = o; o += 1280; }
     L.total = o;
     return L;
 }
@@ -109,6 +117,7 @@ struct Mem {
     int* ctl;      // [0] flag [1] namb [2] npts [3] npos [4] nneg [5] flag2 [6] n_up [7] n_down [8] n_one
     double* red;   // 16 doubles for block reductions
     int* wcnt;     // 16 ints for block compaction
+    unsigned* rec; // cycle swap: path records of the two walks
     unsigned char* table;  // PI table: spans dir (+lw)
     size_t table_bytes;
     int P;
@@ -143,6 +152,7 @@ __device__ __forceinline__ Mem<idx_t> carve(unsigned char* base, const Layout& L
     m.ctl = (int*)(base + L.o_ctl);
     m.red = (double*)(base + L.o_ctl + 64);
     m.wcnt = (int*)(base + L.o_ctl + 192);
+    m.rec = (unsigned*)(base + L.o_rec);
     m.table = base + L.o_dir;
     m.table_bytes = L.o_x - L.o_dir;
     m.P = L.P;
@@ -557,8 +567,8 @@ __device__ __forceinline__ void split_pos_neg(Mem<idx_t>& M, int m, int MMcap) {
 
 // Accelerate_PD (accelerated_PD.py:115-178).  Requires ctl[4] (#Neg) >= 1.
 //
-// Tree state per node (u32 arrays carved from the dead sort / union-find regions): par[x], key[x] = ascending rank of the
-// edge (x, par x), mark[x] = stamp of the last walk through x, pmP[x] / pmQ[x] = (running maximum rank+1, child endpoint
+// Tree state per node (u32 arrays carved from the dead sort / union-find regions): par[x], key[x] = (ascending rank + 1)
+// << 8 of the edge (x, par x), mark[x] = stamp of the last walk through x, pmP[x] / pmQ[x] = (running maximum rank+1, child endpoint
 // of that edge) of the p- resp. q-walk on arrival at x.  Every tree edge carries the ascending rank of its key, so "the
 // first maximum of 'asc' over the loop" (:155-159) is an integer maximum.
 // The loop of a Pos edge (p,q) is found by TWO LANES of one wavefront walking up from p and from q in the same instruction
@@ -569,18 +579,19 @@ __device__ __forceinline__ void split_pos_neg(Mem<idx_t>& M, int m, int MMcap) {
 // edges (:168-176) runs on lane 0.
 template <int W, typename idx_t, class Sink>
 __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, unsigned flags, int MMcap, int NMcap, ull* pc,
-                                           ull& t_prev) {
+                                           ull& t_prev, ull* ph) {
     const int tid = threadIdx.x;
     const bool keep0 = (flags & TLC_KEEP_ZERO_PERS) != 0;
     const unsigned NONE = 0xffffffffu;
     const int npos = M.ctl[3], nneg = M.ctl[4];
     const unsigned* ends = M.dir;
     double* f = M.f;
+    const int NS = NMcap + 1;                  // slot NMcap is a spare node: the target of an idle walker's LDS traffic
     unsigned* par = (unsigned*)M.keyS;
-    unsigned* key = par + NMcap;
-    unsigned* mark = key + NMcap;
-    ull* pmP = (ull*)(mark + NMcap + (NMcap & 1));
-    ull* pmQ = pmP + NMcap;
+    unsigned* key = par + NS;
+    unsigned* mark = key + NS;
+    ull* pmP = (ull*)(mark + NS + (NS & 1));
+    ull* pmQ = pmP + NS;
     // spanning tree of the Neg edges (:119-125).  Any root gives the same diagram; rank 0 (a root of the vicinity) keeps
     // the tree shallow.  If rank 0 is not incident to a Neg edge (disconnected input) fall back to the reference's choice.
     // (the Neg list in M.pn and the edge tables in M.dir are outside the regions re-used here)
@@ -603,80 +614,123 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
             const unsigned ab = ends[eid];
             const int a = ab >> 16, b = ab & 0xffffu;
             const unsigned pa = par[a], pb = par[b];
-            if (pa != NONE && pb == NONE) { par[b] = (unsigned)a; key[b] = M.arank[eid]; prog = true; }
-            else if (pb != NONE && pa == NONE) { par[a] = (unsigned)b; key[a] = M.arank[eid]; prog = true; }
+            if (pa != NONE && pb == NONE) { par[b] = (unsigned)a; key[b] = (M.arank[eid] + 1u) << 8; prog = true; }
+            else if (pb != NONE && pa == NONE) { par[a] = (unsigned)b; key[a] = (M.arank[eid] + 1u) << 8; prog = true; }
         }
         __syncthreads();
         if (!block_any<W>(prog, M.ctl, 5)) break;
     }
+    // above the root sits the spare slot, its own parent, behind edges of key 0: a walk that passes the root keeps
+    // stepping in place there, so a step needs no "at the root" case
+    if (tid == 0) { par[root] = (unsigned)NMcap; key[root] = 0u; par[NMcap] = (unsigned)NMcap; key[NMcap] = 0u; mark[NMcap] = 0u; }
+    __syncthreads();
     TLC_STAMP(9);
     if (tid < 64) {                                                 // first wavefront; lanes 0 and 1 walk
         // this wave carries the critical serial chain of the batch: let it win issue arbitration against the other
         // kernels' waves that share the SIMD
         __builtin_amdgcn_s_setprio(3);
         const int lane = tid;
-        const bool walker = lane < 2;
         const bool qside = (lane & 1) != 0;
         ull* pmMine = qside ? pmQ : pmP;
         const ull* pmTheirs = qside ? pmP : pmQ;
+        // path records: (key << 32 | node) of the edge crossed at step s of either walk (slot 64 = spare); a swap then
+        // re-parents its whole path in one parallel step instead of one dependent LDS round trip per node
+        ull* rec = (ull*)M.rec + (qside ? 65 : 0);
         unsigned stamp = 0;
-        // the per-query operands do not depend on the tree: fetch them one query ahead, off the dependent chain
-        unsigned n_eid = npos > 0 ? M.pn[0] : 0u;
-        unsigned n_pq = npos > 0 ? ends[n_eid] : 0u;
-        unsigned n_ar = npos > 0 ? M.arank[n_eid] : 0u;
+        // the per-query operands do not depend on the tree: the edge id is fetched two queries ahead and its endpoints
+        // and rank one query ahead, so that no load of this chain is ever waited for inside a query
+        unsigned eid1 = npos > 1 ? M.pn[1] : 0u;                   // edge id of query pi+1
+        unsigned n_pq = 0u, n_ar = 0u;                             // endpoints / ascending rank of query pi
+        if (npos > 0) { const unsigned e0 = M.pn[0]; n_pq = ends[e0]; n_ar = (M.arank[e0] + 1u) << 8; }
+        // ... and so are the walkers' first nodes, read under the previous query's swap (patched if it touched them)
+        int n_cur = qside ? (int)(n_pq & 0xffffu) : (int)(n_pq >> 16);
+        unsigned n_pcur = par[n_cur], n_kcur = key[n_cur];
         int n_out = 0;                         // points emitted by this stage (wave-uniform)
         const int out0 = M.ctl[2];
+#ifdef TLC_PHASE_DEBUG
+        ull dbg_a = 0, dbg_b = 0, dbg_c = 0, dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0;
+#define DBG_T(v) v = clock64()
+#else
+#define DBG_T(v)
+#endif
         for (int pi = 0; pi < npos; ++pi) {
+            DBG_T(dbg_t0);
             const unsigned pq = n_pq, ar = n_ar;
-            if (pi + 1 < npos) {
-                n_eid = M.pn[pi + 1];
-                n_pq = ends[n_eid];
-                n_ar = M.arank[n_eid];
-            }
+            int cur = n_cur;
+            unsigned pcur = n_pcur, kcur = n_kcur;
+            if (pi + 1 < npos) { n_pq = ends[eid1]; n_ar = (M.arank[eid1] + 1u) << 8; }
+            if (pi + 2 < npos) eid1 = M.pn[pi + 2];
             const int p = pq >> 16, q = pq & 0xffffu;              // f[p] <= f[q]: low_value = f[p] (:162)
-            int cur = qside ? q : p;
-            unsigned pcur = par[cur], kcur = key[cur];
-            if (__ballot(pcur == NONE) != 0ull) continue;          // other component (callers gate on connectivity)
-            stamp += 2;
-            if (stamp >= 0xfffffff0u) {                            // stamp space exhausted: start over
-                for (int i = lane; i < n; i += 64) mark[i] = 0u;
-                stamp = 2;
-            }
-            const unsigned mine = stamp + (qside ? 1u : 0u), theirs = stamp + (qside ? 0u : 1u);
-            unsigned mx = 0;                   // rank + 1 of the heaviest edge this walk has crossed (0 = none)
-            unsigned arg = 0;                  // child endpoint of that edge
-            if (walker) { mark[cur] = mine; pmMine[cur] = 0ull; }
-            unsigned res_k = 0, res_a = 0, res_s = 0;
-            for (;;) {
-                bool found = false;
-                if (walker && cur != root) {
-                    if (kcur + 1u > mx) { mx = kcur + 1u; arg = (unsigned)cur; }
-                    const int nxt = (int)pcur;
-                    pmMine[nxt] = ((ull)mx << 32) | (ull)arg;               // publish before taking the stamp
-                    const unsigned old = atomicExch(&mark[nxt], mine);      // ds_wrxchg_rtn_b32
-                    const unsigned pn = par[nxt], kn = key[nxt];
-                    if (old == theirs) {
-                        found = true;
-                        const ull o = pmTheirs[nxt];
-                        const unsigned ok = (unsigned)(o >> 32), oa = (unsigned)(o & 0xffffffffull);
-                        if (mx >= ok) { res_k = mx; res_a = arg; res_s = qside ? 1u : 0u; }
-                        else { res_k = ok; res_a = oa; res_s = qside ? 0u : 1u; }
-                    } else {
-                        cur = nxt; pcur = pn; kcur = kn;
+            // winner's record: hi = (max rank + 1) << 8 | step of that edge, lo = child << 16 | parent (ranks are unique,
+            // so comparing hi words compares ranks)
+            unsigned res_hi = 0, res_lo = 0;
+            unsigned res_s = 0;                // side of the winner: 0 = p-walk, 1 = q-walk
+            // Shortest loop first: p and q under the same parent (more than half of the queries of a hub-centred vicinity).
+            // Both walkers already hold their parent and key, so the answer needs no LDS traffic at all.
+            const unsigned pcP = __builtin_amdgcn_readlane(pcur, 0), pcQ = __builtin_amdgcn_readlane(pcur, 1);
+            if (pcP == pcQ && pcP != NONE) {
+                const unsigned kP = __builtin_amdgcn_readlane(kcur, 0), kQ = __builtin_amdgcn_readlane(kcur, 1);
+                res_s = kQ > kP ? 1u : 0u;
+                res_hi = res_s ? kQ : kP;                              // step 0
+                res_lo = ((unsigned)(res_s ? q : p) << 16) | pcP;
+            } else if (__ballot(lane < 2 && pcur == NONE) == 0ull) {   // else other component (callers gate on connectivity)
+                stamp += 2;
+                if (stamp >= 0xfffffff0u) {                        // stamp space exhausted: start over
+                    for (int i = lane; i < n; i += 64) mark[i] = 0u;
+                    stamp = 2;
+                }
+                int fl = 0;
+                DBG_T(dbg_t1);
+                if (lane < 2) {
+                    // The walk is straight-line code for both lanes; the only branch in a step is the uniform exit.
+                    const unsigned mine = stamp + (qside ? 1u : 0u), theirs = stamp + (qside ? 0u : 1u);
+                    unsigned mx_hi = 0, mx_lo = 0;                 // heaviest edge this walk has crossed (0 = none)
+                    unsigned step = 0, o_hi, o_lo;
+                    mark[cur] = mine;
+                    pmMine[cur] = 0ull;
+                    for (;;) {
+                        const unsigned c_hi = kcur | (step < 255u ? step : 255u);
+                        const bool upd = c_hi > mx_hi;
+                        mx_hi = upd ? c_hi : mx_hi;
+                        mx_lo = upd ? (((unsigned)cur << 16) | pcur) : mx_lo;
+                        rec[step < 64u ? step : 64u] = ((unsigned long long)kcur << 32) | (unsigned)cur;
+                        pmMine[pcur] = ((unsigned long long)mx_hi << 32) | mx_lo;  // publish before taking the stamp
+                        unsigned old = atomicExch(&mark[pcur], mine);              // ds_wrxchg_rtn_b32
+                        unsigned pn = par[pcur], kn = key[pcur];
+                        const unsigned long long o = pmTheirs[pcur];               // only meaningful at the meeting node
+                        o_hi = (unsigned)(o >> 32);
+                        o_lo = (unsigned)o;
+                        // one LDS round trip per step: without this the compiler sinks the reads below the test on `old`
+                        asm volatile("" : "+v"(old), "+v"(pn), "+v"(kn), "+v"(o_hi), "+v"(o_lo));
+                        const ull fm = __ballot(old == theirs);
+                        if (fm) { fl = __builtin_ctzll(fm); break; }
+                        cur = (int)pcur;
+                        pcur = pn;
+                        kcur = kn;
+                        ++step;
                     }
+                    const bool mwin = mx_hi >= o_hi;
+                    res_hi = mwin ? mx_hi : o_hi;
+                    res_lo = mwin ? mx_lo : o_lo;
+                    res_s = (mwin ? qside : !qside) ? 1u : 0u;
                 }
-                const ull fm = __ballot(found);
-                if (fm) {
-                    const int fl = __builtin_ctzll(fm);
-                    res_k = __builtin_amdgcn_readlane(res_k, fl);
-                    res_a = __builtin_amdgcn_readlane(res_a, fl);
-                    res_s = __builtin_amdgcn_readlane(res_s, fl);
-                    break;
-                }
+                DBG_T(dbg_t2);
+#ifdef TLC_PHASE_DEBUG
+                dbg_a += dbg_t1 - dbg_t0; dbg_b += dbg_t2 - dbg_t1;
+#endif
+                fl = __builtin_amdgcn_readfirstlane(fl);           // lanes 0 and 1 agree; the rest follow lane 0
+                res_hi = __builtin_amdgcn_readlane(res_hi, fl);
+                res_lo = __builtin_amdgcn_readlane(res_lo, fl);
+                res_s = __builtin_amdgcn_readlane(res_s, fl);
             }
-            if (res_k == 0) continue;
-            const int best = (int)res_a;
-            const int bp = (int)par[best];
+            // the next query's first nodes: issued ahead of the swap's writes, patched below if the swap touched them
+            const int np_ = (int)(n_pq >> 16), nq_ = (int)(n_pq & 0xffffu);
+            n_cur = qside ? nq_ : np_;
+            n_pcur = par[n_cur];
+            n_kcur = key[n_cur];
+            if (res_hi == 0u) continue;
+            const int best = (int)(res_lo >> 16), bp = (int)(res_lo & 0xffffu);
+            const unsigned bstep = res_hi & 0xffu;
             const int hin = best > bp ? best : bp;                                // large_value  (:160)
             // low_value > = large_value is dropped by the TLC fork (:164).  The batch path defers that test: a point with
             // zero persistence has weight 0 in the image, so it may stay in the list.
@@ -686,20 +740,55 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
                 if (lane == 0) sink.one_at(f, out0 + n_out, n_out, p, hin);
                 ++n_out;
             }
-            if (lane == 0) {
-                // evert the path so that (p,q) replaces the removed tree edge (:168-176)
-                int node = res_s == 0 ? p : q, nodec = res_s == 0 ? q : p;
-                unsigned kin = ar;
-                while (nodec != best) {
-                    const unsigned pp = par[node], kk = key[node];
-                    par[node] = (unsigned)nodec;
-                    key[node] = kin;
-                    nodec = node;
-                    node = (int)pp;
-                    kin = kk;
+            // evert the path so that (p,q) replaces the removed tree edge (:168-176): node x_i of the winner's walk gets
+            // x_{i-1} as parent (x_{-1} = the other endpoint) and inherits the key of the edge below it
+            if (bstep < 64u) {
+                const ull* rr = (const ull*)M.rec + (res_s ? 65 : 0);
+                // x_0 is an endpoint of the query and needs no record; most swaps end there
+                unsigned xi = 0xffffffffu, xprev = 0, kprev = 0;
+                if (lane == 0) { xi = (unsigned)(res_s == 0 ? p : q); xprev = (unsigned)(res_s == 0 ? q : p); kprev = ar; }
+                if (bstep != 0u && lane != 0 && (unsigned)lane <= bstep) {
+                    const ull r1 = rr[lane], r0 = rr[lane - 1];
+                    xi = (unsigned)r1;
+                    xprev = (unsigned)r0;
+                    kprev = (unsigned)(r0 >> 32);
                 }
+                if (xi != 0xffffffffu) { par[xi] = xprev; key[xi] = kprev; }
+                // a first node of the next query that sits on the everted path takes its new parent from that lane
+                const ull tp = __ballot(xi == (unsigned)np_), tq = __ballot(xi == (unsigned)nq_);
+                if (tp) {
+                    const int l = __builtin_ctzll(tp);
+                    const unsigned v = __builtin_amdgcn_readlane(xprev, l), k2 = __builtin_amdgcn_readlane(kprev, l);
+                    if (!qside) { n_pcur = v; n_kcur = k2; }
+                }
+                if (tq) {
+                    const int l = __builtin_ctzll(tq);
+                    const unsigned v = __builtin_amdgcn_readlane(xprev, l), k2 = __builtin_amdgcn_readlane(kprev, l);
+                    if (qside) { n_pcur = v; n_kcur = k2; }
+                }
+            } else {
+                if (lane == 0) {
+                    int node = res_s == 0 ? p : q, nodec = res_s == 0 ? q : p;
+                    unsigned kin = ar;
+                    while (nodec != best) {
+                        const unsigned pp = par[node], kk = key[node];
+                        par[node] = (unsigned)nodec;
+                        key[node] = kin;
+                        nodec = node;
+                        node = (int)pp;
+                        kin = kk;
+                    }
+                }
+                n_pcur = par[n_cur];
+                n_kcur = key[n_cur];
             }
+#ifdef TLC_PHASE_DEBUG
+            dbg_c += clock64() - dbg_t2;
+#endif
         }
+#ifdef TLC_PHASE_DEBUG
+        if (pc && lane == 0) { atomicAdd(&pc[15], dbg_a); atomicAdd(&pc[30], dbg_b); atomicAdd(&pc[31], dbg_c); }
+#endif
         if (lane == 0) { M.ctl[2] = out0 + n_out; M.ctl[8] = n_out; }
         __builtin_amdgcn_s_setprio(0);
     }
@@ -710,7 +799,7 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
 // All PD stages on a subgraph whose f[0..n) is final and whose m undirected edges sit in M.dir[0..m) as node-id pairs.
 template <int W, typename idx_t, class Sink>
 __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, int m, unsigned flags, int MMcap, int NMcap,
-                                            ull* pc, ull& t_prev) {
+                                            ull* pc, ull& t_prev, ull* ph) {
     relabel_by_rank<W>(M, n, m);
     sort_edges<W, idx_t, false>(M, m);
     for (int pos = threadIdx.x; pos < m; pos += W) M.arank[M.valS[pos]] = (unsigned)pos;
@@ -729,7 +818,7 @@ __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, i
     int status = TLC_ST_OK;
     if (!(flags & TLC_NO_EXT1)) {
         if (M.ctl[4] == 0) status = TLC_ST_NO_TREE_EDGE;              // list(Nodes)[0] -> IndexError (:122)
-        else ext1_stage<W>(M, sink, n, flags, MMcap, NMcap, pc, t_prev);
+        else ext1_stage<W>(M, sink, n, flags, MMcap, NMcap, pc, t_prev, ph);
     }
     return status;
 }
@@ -822,6 +911,8 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
     Mem<idx_t> M = carve<idx_t>(base, L, NMr, MMr, LWL);
     const int res = p.res, res2 = res * res;
 
+    // this workgroup is resident: tell the launcher's gate (api.hip, tlc_wait_started)
+    if (NM == TLC_L_NMAX && !HUGE && p.started && tid == 0) atomicAdd(p.started, 1);
     for (int wi = blockIdx.x; wi < p.tier_count; wi += gridDim.x) {
         const int i = p.tier_list[wi];
         const int n = p.hdr_n[i], m2 = p.hdr_m2[i], lu = p.hdr_lu[i], lv = p.hdr_lv[i];
@@ -829,9 +920,16 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
         const int m = m2 >> 1;
         const bool far = (lu < 0);        // u in S <=> v in S <=> d(u,v) <= hop  
         int status = TLC_ST_OK;
+#ifdef TLC_PHASE_DEBUG
         ull* pc = p.phase_cycles;
         ull t_prev = pc ? clock64() : 0ull;
+        ull ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const ull t_begin = t_prev;
+#else
+        ull* pc = nullptr;
+        ull t_prev = 0ull;
+        ull* ph = nullptr;
+#endif
         // ---- stage the subgraph ------------------------------------------------------------------------------------
         const bool in_small = (NM == TLC_S_NMAX && !HUGE && p.small_dir != nullptr);
         const unsigned* adir = in_small ? p.small_dir + (size_t)i * (2 * TLC_S_MMAX) : p.A_dir + eo;
@@ -1030,7 +1128,7 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
             __syncthreads();
             PtsSink sink{M.pts, M.ctl};
             TLC_STAMP(4);
-            status = pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev);
+            status = pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph);
             if (status == TLC_ST_OK) {
                 const int np = M.ctl[2], n_up = M.ctl[6];
                 auto get = [&](int k, double& b, double& d) {
@@ -1049,7 +1147,17 @@ __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
             }
         }
         TLC_STAMP(11);
-        if (pc && tid == 0) { atomicAdd(&pc[12], clock64() - t_begin); atomicMax(&pc[13], clock64() - t_begin); atomicAdd(&pc[14], 1ull); }
+#ifdef TLC_PHASE_DEBUG
+        if (pc && tid == 0) {
+            const ull tot = clock64() - t_begin;
+            atomicAdd(&pc[12], tot);
+            atomicAdd(&pc[14], 1ull);
+            if (atomicMax(&pc[13], tot) < tot) {          // slowest workgroup so far: its own phase split, n and m
+                for (int k = 0; k < 12; ++k) pc[16 + k] = ph[k];
+                pc[28] = (ull)n; pc[29] = (ull)m;
+            }
+        }
+#endif
         if (status != TLC_ST_OK) acc = 0.0;
         if (p.out_pi && tid < res2) p.out_pi[(size_t)i * res2 + tid] = acc;
         if (p.out_status && tid == 0) p.out_status[i] = (unsigned char)status;
@@ -1091,8 +1199,9 @@ __global__ __launch_bounds__(W) void tlc_pdf_tier_kernel(TlcPdfParams p) {
         GlobalSink sink{p.pd_up + 2 * no, p.pd_down + 2 * no, p.pd_one + 2 * eo, p.ext0 + 2 * (size_t)g, M.ctl};
         ull* pc = nullptr;
         ull t_prev = 0;
+        ull* ph = nullptr;
         if (m > 0) {
-            pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev);
+            pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph);
         } else if (tid == 0) {
             double mn = 99999999.0, mx = -99999999.0;
             for (int k = 0; k < n; ++k) { mn = M.f[k] < mn ? M.f[k] : mn; mx = M.f[k] > mx ? M.f[k] : mx; }

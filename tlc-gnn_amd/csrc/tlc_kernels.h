@@ -113,6 +113,7 @@ struct TlcPdParams {
     unsigned long long* stats;
     // diagnostics (null in production): per tier 16 accumulated cycle counts of thread 0, see pd_pipeline.hip
     unsigned long long* phase_cycles;
+    int* started;      // LARGE tier: workgroups that have begun (the launcher holds the small tiers back until then)
 };
 
 // PD from a caller-supplied filtration (tlc_pd_from_filtration)

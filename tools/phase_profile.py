@@ -16,12 +16,14 @@ L.tlc_debug_phase_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 g.pd_pi_batch(pairs, 2)
 L.tlc_debug_phase_profile(g._h, 1, None)
 g.pd_pi_batch(pairs, 2)
-buf = (C.c_uint64 * 64)()
+buf = (C.c_uint64 * 128)()
 L.tlc_debug_phase_profile(g._h, 0, C.cast(buf, C.c_void_p))
-a = np.array(list(buf), dtype=np.float64).reshape(4, 16)
+a = np.array(list(buf), dtype=np.float64).reshape(4, 32)
 for t, tn in enumerate(["small", "medium", "large", "huge"]):
     if a[t, 14] == 0:
         continue
     print("tier %s: %d workgroups, mean %.0f cycles, max %.0f cycles" % (tn, a[t, 14], a[t, 12] / a[t, 14], a[t, 13]))
     for i in range(12):
-        print("   %-16s %6.2f %%   mean %9.0f" % (NAMES[i], 100 * a[t, i] / max(a[t, 12], 1), a[t, i] / a[t, 14]))
+        print("   %-16s %6.2f %%   mean %9.0f   slowest wg %9.0f" % (NAMES[i], 100 * a[t, i] / max(a[t, 12], 1), a[t, i] / a[t, 14], a[t, 16 + i]))
+    print("   slowest wg: n=%d m=%d" % (a[t, 28], a[t, 29]))
+    print("   ext1 split (sum over wgs): pre-walk %.0f  walk %.0f  post %.0f  (ext1 total %.0f)" % (a[t, 15], a[t, 30], a[t, 31], a[t, 10]))
