@@ -45,7 +45,11 @@ def test_gcn_norm_csr(setup):
     assert len(c) == rei.shape[1]
 
 
-@pytest.mark.parametrize("shape", [(1500, 233, 100), (1500, 100, 16), (77, 5, 3), (130, 64, 128), (1, 1, 1)])
+# vectorised (K, N multiples of 4) and element-wise load paths, K a multiple of the 32-chunk or not, odd chunk counts,
+# row counts around the 80-row tile, every column-tile count of the 16x16x4 kernel
+@pytest.mark.parametrize("shape", [(1500, 233, 100), (1500, 100, 16), (77, 5, 3), (130, 64, 128), (1, 1, 1), (19717, 500, 100),
+                                   (2708, 1433, 7), (80, 32, 16), (81, 33, 17), (79, 96, 48), (161, 31, 65), (400, 768, 80),
+                                   (333, 160, 112), (5, 4, 4)])
 def test_gemm_f32_mfma(setup, shape):
     torch = setup[0]
     from tlc_gnn_amd import ops
@@ -136,3 +140,29 @@ def test_decode_generic_dims(setup):
     r = ref.tlcgnn_decode(emb.clone(), pairs, pi, w1, b1, w2, b2)
     ok, worst = _close(out, r)
     assert ok, worst
+
+
+def test_spmm_hub_rows_and_clustered_hubs(setup):
+    """Rows longer than the per-group limit (32) go through the cooperative hub path; one row is longer than its 2048-entry
+    staging chunk; hubs have neighbouring ids (they must not serialise in one workgroup); k covers every lane-group width."""
+    torch = setup[0]
+    from tlc_gnn_amd import ops
+    rs = np.random.RandomState(5)
+    n = 6000
+    deg = rs.randint(1, 9, size=n)
+    deg[:40] = rs.randint(33, 400, size=40)          # clustered hubs
+    deg[7] = 5000                                    # longer than one staging chunk
+    deg[n - 1] = 70
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = np.concatenate([np.sort(rs.choice(n, size=d, replace=False)) for d in deg]).astype(np.int32)
+    val = rs.randn(len(col)).astype(np.float32)
+    for k in (4, 16, 24, 64, 100, 128, 200, 7, 33):
+        x = torch.from_numpy(rs.randn(n, k).astype(np.float32))
+        bias = torch.from_numpy(rs.randn(k).astype(np.float32))
+        y = ops.spmm(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda(), x.cuda(),
+                     bias=bias.cuda(), relu=True)
+        A = torch.sparse_csr_tensor(torch.from_numpy(rowptr).long(), torch.from_numpy(col).long(), torch.from_numpy(val).double(), (n, n))
+        ref = torch.relu(A @ x.double() + bias.double())
+        mag = torch.sparse_csr_tensor(torch.from_numpy(rowptr).long(), torch.from_numpy(col).long(), torch.from_numpy(np.abs(val)).double(), (n, n)) @ x.abs().double()
+        err = (y.cpu().double() - ref).abs()
+        assert bool((err <= ATOL + RTOL * (mag + bias.abs().double())).all()), (k, float(err.max()))

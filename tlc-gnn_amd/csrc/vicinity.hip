@@ -60,11 +60,20 @@ __device__ __forceinline__ void expand_rows(const int* __restrict__ list, int co
         }
         const bool big = (end - beg) >= 32;
         if (!big) {
-            for (int j = beg; j < end; ++j) {
-                const int b = col[j];
-                const unsigned bit = 1u << (b & 31);
-                const unsigned old = atomicOr(&bits[b >> 5], bit);
-                if (next && !(old & bit)) next[atomicAdd(s_cnt, 1)] = b;
+            // eight entries per round trip (a load-use loop would pay one global latency per entry)
+            for (int j0 = beg; j0 < end; j0 += 8) {
+                int bb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) bb[q] = col[j0 + q < end ? j0 + q : beg];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (j0 + q < end) {
+                        const int b = bb[q];
+                        const unsigned bit = 1u << (b & 31);
+                        const unsigned old = atomicOr(&bits[b >> 5], bit);
+                        if (next && !(old & bit)) next[atomicAdd(s_cnt, 1)] = b;
+                    }
+                }
             }
         }
         unsigned long long mask = __ballot(big);
@@ -135,14 +144,25 @@ __device__ __forceinline__ int induced_rows(const int* __restrict__ ids, int n, 
         const bool big = (end - beg) >= 32;
         int cnt = 0;
         if (!big) {
-            for (int j = beg; j < end; ++j) {
-                const int b = p.col[j];
-                if (bit_test(S, b)) {
-                    if (WRITE) {
-                        dir[t + cnt] = ((unsigned)k << 16) | (unsigned)local_id(S, pref, b);
-                        lw[t + cnt] = p.w[j];
+            // eight entries (and, when writing, their weights) per round trip
+            for (int j0 = beg; j0 < end; j0 += 8) {
+                int bb[8];
+                double ww[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = j0 + q < end ? j0 + q : beg;
+                    bb[q] = p.col[j];
+                    if (WRITE) ww[q] = p.w[j];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (j0 + q < end && bit_test(S, bb[q])) {
+                        if (WRITE) {
+                            dir[t + cnt] = ((unsigned)k << 16) | (unsigned)local_id(S, pref, bb[q]);
+                            lw[t + cnt] = ww[q];
+                        }
+                        ++cnt;
                     }
-                    ++cnt;
                 }
             }
         }
@@ -210,9 +230,13 @@ __device__ __forceinline__ void mark_two_balls_hop2(unsigned* bitsU, unsigned* b
         if (hop < 2) continue;
         const bool big = (end - beg) >= 32;
         if (!big) {
-            for (int j = beg; j < end; ++j) {
-                const int b = p.col[j];
-                atomicOr(&bits[b >> 5], 1u << (b & 31));
+            for (int j0 = beg; j0 < end; j0 += 8) {         // eight entries per round trip
+                int bb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) bb[q] = p.col[j0 + q < end ? j0 + q : beg];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (j0 + q < end) atomicOr(&bits[bb[q] >> 5], 1u << (bb[q] & 31));
             }
         }
         unsigned long long mask = __ballot(big);
