@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the auxiliary random-pair sweep (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -160,7 +161,7 @@ def main():
     # auxiliary (untimed region, single pass): the negative sweep of loaddatas.py:44-53 is dominated by pairs with
     # d(u,v) > hop; report the throughput on 2^20 uniformly random pairs (PI-C of SURVEY.md 8d) next to the headline
     sweep = None
-    if rank == 0:
+    if rank == 0 and not args.no_sweep:
         g.set_timing(False)
         rsw = np.random.RandomState(99)
         sw_pairs = torch.from_numpy(rsw.randint(0, n, size=(1 << 20, 2)).astype(np.int32)).to(dev)

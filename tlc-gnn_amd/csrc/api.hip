@@ -190,8 +190,10 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     for (int k = 0; k < TLC_N_SIDE; ++k) {
-        // side[1] carries the heavy tiers (the critical path): highest priority
-        CK(hipStreamCreateWithPriority(&g->side[k], hipStreamNonBlocking, k == 1 ? prio_hi : prio_lo));
+        // side[1] carries the heavy tiers (the critical path): highest priority; side[2] (MEDIUM, the second longest
+        // chain) sits between it and side[0] (SMALL, which only has to finish before the other two do)
+        const int prio = k == 1 ? prio_hi : (k == 2 ? (prio_lo + prio_hi) / 2 : prio_lo);
+        CK(hipStreamCreateWithPriority(&g->side[k], hipStreamNonBlocking, prio));
         CK(hipEventCreateWithFlags(&g->ev_join[k], hipEventDisableTiming));
     }
     CK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
