@@ -207,6 +207,21 @@ def main():
                                         "achieved": spmm_bytes / us_s / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": spmm_bytes / us_s / 1e3 / HBM_PEAK_GBS}}
         del xw, hfull, yfull
+        # the stand-alone PI raster (tlc_pi_raster = PersistenceImager.transform) on diagrams shaped like this batch's:
+        # one diagram per pair with as many points as the vicinity has edges (Ord0 + ext0 + Ext1 points), values in [0,1]
+        n_sz_r, m2_sz_r = g.sizes(E)
+        kpts = np.maximum(m2_sz_r // 2, 1).astype(np.int64)
+        offs_r = torch.from_numpy(np.concatenate([[0], np.cumsum(kpts)])).to(dev)
+        gen = torch.Generator(device=dev).manual_seed(7)
+        bd = torch.rand((int(kpts.sum()), 2), generator=gen, device=dev, dtype=torch.float64)
+        bd[:, 1] = bd[:, 0] + bd[:, 1] * (1.0 - bd[:, 0])                     # death >= birth
+        us_r = _avg_us(lambda: engine.pi_raster(offs_r, bd, 5), reps=5)
+        raster_bytes = 16.0 * float(kpts.sum()) + 8.0 * 25 * E + 8.0 * (E + 1)
+        lp_roof["pi_raster"] = {"bound": "hbm", "diagrams": int(E), "points": int(kpts.sum()), "kernel_us": us_r,
+                                "achieved": raster_bytes / us_r / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": raster_bytes / us_r / 1e3 / HBM_PEAK_GBS,
+                                "note": "fp64 erfc issue-bound: 2*(res+1) CDF evaluations per point"}
+        del bd, offs_r
     if rank == 0:
         stats = g.stats()
         n_sz, m2_sz = g.sizes(E)
