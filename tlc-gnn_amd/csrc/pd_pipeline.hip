@@ -235,11 +235,51 @@ __device__ __forceinline__ void bellman_ford(ull* d0, ull* d1, const unsigned* d
 }
 
 // ---- bitonic sort of (key u64, payload u32), ascending by key, P a power of two ------------------------------------
+// One compare-exchange of the bitonic network between lanes l and l^J of a wavefront (element i = base + lane against
+// i^J).  Same rule as the LDS pass below: the pair is swapped iff (key_lo > key_hi) == up, equal keys stay put.
+template <int J>
+__device__ __forceinline__ void bitonic_lane_step(ull& kk, unsigned& vv, bool up) {
+    const ull ok = __shfl_xor(kk, J, 64);
+    const unsigned ov = __shfl_xor(vv, J, 64);
+    const bool lo = (tlc_lane() & J) == 0;
+    const ull klo = lo ? kk : ok, khi = lo ? ok : kk;
+    if (((klo > khi) == up) && (klo != khi)) { kk = ok; vv = ov; }
+}
+// sub-stages j = JMAX, JMAX/2, ..., 1 of stage k on one 64-element block held one element per lane
+template <int JMAX>
+__device__ __forceinline__ void bitonic_lane_tail(ull& kk, unsigned& vv, bool up) {
+    if (JMAX >= 32) bitonic_lane_step<32>(kk, vv, up);
+    if (JMAX >= 16) bitonic_lane_step<16>(kk, vv, up);
+    if (JMAX >= 8) bitonic_lane_step<8>(kk, vv, up);
+    if (JMAX >= 4) bitonic_lane_step<4>(kk, vv, up);
+    if (JMAX >= 2) bitonic_lane_step<2>(kk, vv, up);
+    bitonic_lane_step<1>(kk, vv, up);
+}
+
+// Bitonic sort of (key, payload) pairs in LDS, P a power of two.  Every compare-exchange whose partners sit in the same
+// 64-element block (j <= 32) runs in registers with cross-lane moves; only the sub-stages with j >= 64 go through LDS
+// with a barrier each: P = 1024 needs 15 barriers instead of 55, P <= 64 one.
 template <int W>
 __device__ __forceinline__ void bitonic_sort(ull* key, unsigned* val, int P) {
-    const int tid = threadIdx.x;
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NWV = W / 64;
+    const int nblk = (P + 63) >> 6;
+    // stages k = 2 .. min(P, 64): entirely inside a block
+    for (int b = wave; b < nblk; b += NWV) {
+        const int i = b * 64 + lane;
+        ull kk = i < P ? key[i] : 0ull;
+        unsigned vv = i < P ? val[i] : 0u;
+        if (P >= 2) bitonic_lane_tail<1>(kk, vv, (i & 2) == 0);
+        if (P >= 4) bitonic_lane_tail<2>(kk, vv, (i & 4) == 0);
+        if (P >= 8) bitonic_lane_tail<4>(kk, vv, (i & 8) == 0);
+        if (P >= 16) bitonic_lane_tail<8>(kk, vv, (i & 16) == 0);
+        if (P >= 32) bitonic_lane_tail<16>(kk, vv, (i & 32) == 0);
+        if (P >= 64) bitonic_lane_tail<32>(kk, vv, (i & 64) == 0);
+        if (i < P) { key[i] = kk; val[i] = vv; }
+    }
+    __syncthreads();
+    for (int k = 128; k <= P; k <<= 1) {
+        for (int j = k >> 1; j >= 64; j >>= 1) {
             for (int t = tid; t < (P >> 1); t += W) {
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const int x = i | j;
@@ -253,6 +293,14 @@ __device__ __forceinline__ void bitonic_sort(ull* key, unsigned* val, int P) {
             }
             __syncthreads();
         }
+        for (int b = wave; b < nblk; b += NWV) {
+            const int i = b * 64 + lane;
+            ull kk = key[i];
+            unsigned vv = val[i];
+            bitonic_lane_tail<32>(kk, vv, (i & k) == 0);
+            key[i] = kk; val[i] = vv;
+        }
+        __syncthreads();
     }
 }
 
@@ -703,11 +751,11 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
                         // one LDS round trip per step: without this the compiler sinks the reads below the test on `old`
                         asm volatile("" : "+v"(old), "+v"(pn), "+v"(kn), "+v"(o_hi), "+v"(o_lo));
                         const ull fm = __ballot(old == theirs);
-                        if (fm) { fl = __builtin_ctzll(fm); break; }
-                        cur = (int)pcur;
+                        cur = (int)pcur;                                           // (unused once the walks have met)
                         pcur = pn;
                         kcur = kn;
                         ++step;
+                        if (fm) { fl = __builtin_ctzll(fm); break; }               // the step's only branch
                     }
                     const bool mwin = mx_hi >= o_hi;
                     res_hi = mwin ? mx_hi : o_hi;
