@@ -687,7 +687,7 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
         unsigned stamp = 0;
         // the per-query operands do not depend on the tree: the edge id is fetched two queries ahead and its endpoints
         // and rank one query ahead, so that no load of this chain is ever waited for inside a query
-        unsigned eid1 = npos > 1 ? M.pn[1] : 0u;                   // edge id of query pi+1
+        unsigned eid1 = npos > 0 ? M.pn[npos > 1 ? 1 : 0] : 0u;     // edge id of query pi+1
         unsigned n_pq = 0u, n_ar = 0u;                             // endpoints / ascending rank of query pi
         if (npos > 0) { const unsigned e0 = M.pn[0]; n_pq = ends[e0]; n_ar = (M.arank[e0] + 1u) << 8; }
         // ... and so are the walkers' first nodes, read under the previous query's swap (patched if it touched them)
@@ -706,22 +706,16 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
             const unsigned pq = n_pq, ar = n_ar;
             int cur = n_cur;
             unsigned pcur = n_pcur, kcur = n_kcur;
-            if (pi + 1 < npos) { n_pq = ends[eid1]; n_ar = (M.arank[eid1] + 1u) << 8; }
-            if (pi + 2 < npos) eid1 = M.pn[pi + 2];
+            // (unconditional: past the end they re-read the last query's operands, which nobody uses)
+            n_pq = ends[eid1];
+            n_ar = (M.arank[eid1] + 1u) << 8;
+            eid1 = M.pn[pi + 2 < npos ? pi + 2 : npos - 1];
             const int p = pq >> 16, q = pq & 0xffffu;              // f[p] <= f[q]: low_value = f[p] (:162)
             // winner's record: hi = (max rank + 1) << 8 | step of that edge, lo = child << 16 | parent (ranks are unique,
             // so comparing hi words compares ranks)
             unsigned res_hi = 0, res_lo = 0;
             unsigned res_s = 0;                // side of the winner: 0 = p-walk, 1 = q-walk
-            // Shortest loop first: p and q under the same parent (more than half of the queries of a hub-centred vicinity).
-            // Both walkers already hold their parent and key, so the answer needs no LDS traffic at all.
-            const unsigned pcP = __builtin_amdgcn_readlane(pcur, 0), pcQ = __builtin_amdgcn_readlane(pcur, 1);
-            if (pcP == pcQ && pcP != NONE) {
-                const unsigned kP = __builtin_amdgcn_readlane(kcur, 0), kQ = __builtin_amdgcn_readlane(kcur, 1);
-                res_s = kQ > kP ? 1u : 0u;
-                res_hi = res_s ? kQ : kP;                              // step 0
-                res_lo = ((unsigned)(res_s ? q : p) << 16) | pcP;
-            } else if (__ballot(lane < 2 && pcur == NONE) == 0ull) {   // else other component (callers gate on connectivity)
+            if (__ballot(lane < 2 && pcur == NONE) == 0ull) {      // else other component (callers gate on connectivity)
                 stamp += 2;
                 if (stamp >= 0xfffffff0u) {                        // stamp space exhausted: start over
                     for (int i = lane; i < n; i += 64) mark[i] = 0u;
@@ -792,28 +786,21 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
             // x_{i-1} as parent (x_{-1} = the other endpoint) and inherits the key of the edge below it
             if (bstep < 64u) {
                 const ull* rr = (const ull*)M.rec + (res_s ? 65 : 0);
-                // x_0 is an endpoint of the query and needs no record; most swaps end there
-                unsigned xi = 0xffffffffu, xprev = 0, kprev = 0;
-                if (lane == 0) { xi = (unsigned)(res_s == 0 ? p : q); xprev = (unsigned)(res_s == 0 ? q : p); kprev = ar; }
-                if (bstep != 0u && lane != 0 && (unsigned)lane <= bstep) {
-                    const ull r1 = rr[lane], r0 = rr[lane - 1];
-                    xi = (unsigned)r1;
-                    xprev = (unsigned)r0;
-                    kprev = (unsigned)(r0 >> 32);
-                }
-                if (xi != 0xffffffffu) { par[xi] = xprev; key[xi] = kprev; }
+                const bool mine_i = (unsigned)lane <= bstep;
+                const int li = mine_i ? lane : 0;
+                const ull r1 = rr[li], r0 = rr[li > 0 ? li - 1 : 0];           // (same round trip as the two reads above)
+                const unsigned xi = mine_i ? (unsigned)r1 : 0xffffffffu;
+                const unsigned xprev = lane ? (unsigned)r0 : (unsigned)(res_s == 0 ? q : p);
+                const unsigned kprev = lane ? (unsigned)(r0 >> 32) : ar;
+                if (mine_i) { par[xi] = xprev; key[xi] = kprev; }
                 // a first node of the next query that sits on the everted path takes its new parent from that lane
                 const ull tp = __ballot(xi == (unsigned)np_), tq = __ballot(xi == (unsigned)nq_);
-                if (tp) {
-                    const int l = __builtin_ctzll(tp);
-                    const unsigned v = __builtin_amdgcn_readlane(xprev, l), k2 = __builtin_amdgcn_readlane(kprev, l);
-                    if (!qside) { n_pcur = v; n_kcur = k2; }
-                }
-                if (tq) {
-                    const int l = __builtin_ctzll(tq);
-                    const unsigned v = __builtin_amdgcn_readlane(xprev, l), k2 = __builtin_amdgcn_readlane(kprev, l);
-                    if (qside) { n_pcur = v; n_kcur = k2; }
-                }
+                const int lp = __builtin_ctzll(tp | (1ull << 63)), lq = __builtin_ctzll(tq | (1ull << 63));
+                const unsigned vp = __builtin_amdgcn_readlane(xprev, lp), kp2 = __builtin_amdgcn_readlane(kprev, lp);
+                const unsigned vq = __builtin_amdgcn_readlane(xprev, lq), kq2 = __builtin_amdgcn_readlane(kprev, lq);
+                const bool usep = tp != 0ull && !qside, useq = tq != 0ull && qside;
+                n_pcur = usep ? vp : (useq ? vq : n_pcur);
+                n_kcur = usep ? kp2 : (useq ? kq2 : n_kcur);
             } else {
                 if (lane == 0) {
                     int node = res_s == 0 ? p : q, nodec = res_s == 0 ? q : p;
