@@ -123,7 +123,8 @@ int tlc_pd_pi_algorithmic_bytes(int32_t n_nodes, const int32_t* h_rowptr, const 
  *   d_pd_down  float64[sum n, 2]  Rel1 points   (descending pass, :83-109)
  *   d_pd_one   float64[sum m, 2]  Ext1 points   (:115-178)
  *   d_ext0     float64[n_graphs, 2]  [min f, max f] (:110)
- *   d_counts   int32[n_graphs, 4] = {#up, #down, #one, #connected components}
+ *   d_counts   int32[n_graphs, 4] = {#up, #down, #one, #connected components}; all four -1 for a graph with more than
+ *              65 535 nodes or 2^24-2 edges (not computed)
  *   d_edge_rank int32[sum m] (may be NULL): >= 0: position among the Pos edges, in descending-pass
  *               order (:109); < 0: -(position among the Neg edges)-1 (:99). */
 int tlc_pd_from_filtration(int32_t n_graphs, const int64_t* d_node_offs, const int64_t* d_edge_offs,

@@ -350,3 +350,26 @@ def test_cycle_swap_long_loops_vs_oracle(torch_cuda, flags):
         c = ref["counts"][g]
         for key, base, k in (("up", no, c[0]), ("down", no, c[1]), ("one", eo, c[2])):
             assert same_multiset(got[key][base:base + k], ref[key][base:base + k]), (g, key, gs[g][0])   # bit-exact
+
+
+def test_pd_from_filtration_rejects_oversized_graph(torch_cuda):
+    """More than 65 535 nodes do not fit the packed local ids: the graph is skipped and says so (counts row = -1); its
+    neighbours in the batch are still computed."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine
+    from oracle import oracle
+    n_big = 70000
+    big = np.stack([np.arange(n_big - 1), np.arange(1, n_big)], 1)
+    tri = np.array([[0, 1], [1, 2], [0, 2]])
+    node_offs = np.array([0, 3, 3 + n_big, 6 + n_big], dtype=np.int64)
+    edge_offs = np.array([0, 3, 3 + len(big), 6 + len(big)], dtype=np.int64)
+    edges = np.concatenate([tri, big, tri]).astype(np.int32)
+    f = np.concatenate([[0.1, 0.5, 0.9], np.linspace(0, 1, n_big), [0.3, 0.2, 0.7]])
+    got = engine.pd_from_filtration(_dev(torch, node_offs, torch.int64), _dev(torch, edge_offs, torch.int64),
+                                    _dev(torch, edges, torch.int32), _dev(torch, f, torch.float64), 0)
+    c = got["counts"].cpu().numpy()
+    assert (c[1] == -1).all()
+    ref = oracle.pd_from_filtration(node_offs[[0, 1]], edge_offs[[0, 1]], tri.astype(np.int32), f[:3], 0)
+    assert np.array_equal(c[0], ref["counts"][0])
+    assert same_multiset(got["one"].cpu().numpy()[:c[0][2]], ref["one"][:c[0][2]])
+    assert c[2][2] == 1 and c[2][3] == 1

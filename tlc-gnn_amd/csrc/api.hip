@@ -310,7 +310,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         pp.ids_off = (const long long*)d_ids_off; pp.out_f = d_out_f; pp.out_n = d_out_n; pp.pi_enabled = pi_enabled;
         pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
         pp.huge_scratch = g->huge_scratch; pp.huge_stride = (long long)g->huge_stride;
-        pp.huge_nmax = std::min(g->n_nodes, 65535); pp.huge_mmax = (int)(g->nnz / 2 + 1); pp.huge_slots = g->huge_slots;
+        pp.huge_nmax = std::min(g->n_nodes, TLC_MAX_SUBGRAPH_NODES); pp.huge_mmax = (int)std::min<long long>(g->nnz / 2 + 1, TLC_MAX_SUBGRAPH_EDGES); pp.huge_slots = g->huge_slots;
         pp.stats = g->d_stats;
         pp.started = (int*)(g->d_stats + 2);
         bool used[TLC_N_SIDE] = {false, false, false};
@@ -452,7 +452,7 @@ extern "C" int tlc_pd_from_filtration(int32_t n_graphs, const int64_t* d_node_of
     unsigned char* huge = nullptr;
     do {
         if (hipMemsetAsync(d_tier, 0, 8 * sizeof(int), s) != hipSuccess) { rc = TLC_ERR_HIP; break; }
-        if ((rc = tlc_launch_pdf_bin(n_graphs, (const long long*)d_node_offs, (const long long*)d_edge_offs, d_tier, d_tier + 8, s))) break;
+        if ((rc = tlc_launch_pdf_bin(n_graphs, (const long long*)d_node_offs, (const long long*)d_edge_offs, d_counts, d_tier, d_tier + 8, s))) break;
         if (hipMemcpyAsync(tc, d_tier, sizeof(tc), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = TLC_ERR_HIP; break; }
         if (hipStreamSynchronize(s) != hipSuccess) { rc = TLC_ERR_HIP; break; }
         TlcPdfParams p;
@@ -465,9 +465,8 @@ extern "C" int tlc_pd_from_filtration(int32_t n_graphs, const int64_t* d_node_of
             // size the scratch by the largest graph: bounded by the totals
             if (hipMemcpy(&tail[0], d_node_offs + n_graphs, sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess ||
                 hipMemcpy(&tail[1], d_edge_offs + n_graphs, sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) { rc = TLC_ERR_HIP; break; }
-            if (tail[0] > 65535 * (long long)n_graphs) {}
             p.huge_nmax = (int)std::min<long long>(tail[0], 65535);
-            p.huge_mmax = (int)std::min<long long>(tail[1] + 1, 0x7fffffff);
+            p.huge_mmax = (int)std::min<long long>(tail[1] + 1, TLC_MAX_SUBGRAPH_EDGES);
             p.huge_stride = (long long)tlc_huge_slot_bytes(p.huge_nmax, p.huge_mmax);
             p.huge_slots = std::min(tc[TLC_TIER_HUGE], 32);
             if (hipMalloc(&huge, (size_t)p.huge_stride * p.huge_slots) != hipSuccess) { tlc_set_error("HUGE scratch alloc failed"); rc = TLC_ERR_OUT_OF_MEMORY; break; }

@@ -716,11 +716,7 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
             unsigned res_hi = 0, res_lo = 0;
             unsigned res_s = 0;                // side of the winner: 0 = p-walk, 1 = q-walk
             if (__ballot(lane < 2 && pcur == NONE) == 0ull) {      // else other component (callers gate on connectivity)
-                stamp += 2;
-                if (stamp >= 0xfffffff0u) {                        // stamp space exhausted: start over
-                    for (int i = lane; i < n; i += 64) mark[i] = 0u;
-                    stamp = 2;
-                }
+                stamp += 2;                                        // < 2^26: at most 2^24 Pos edges per subgraph (the key packing)
                 int fl = 0;
                 DBG_T(dbg_t1);
                 if (lane < 2) {
@@ -1260,12 +1256,17 @@ __global__ __launch_bounds__(W) void tlc_pdf_tier_kernel(TlcPdfParams p) {
 
 // tier binning for tlc_pd_from_filtration
 __global__ void tlc_pdf_bin_kernel(int n_graphs, const long long* node_offs, const long long* edge_offs, int* tier_count,
-                                   int* tier_list) {
+                                   int* tier_list, int* counts) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_graphs) return;
     const long long n = node_offs[g + 1] - node_offs[g], m = edge_offs[g + 1] - edge_offs[g];
     int tier = TLC_TIER_HUGE;
     if (n <= 0) tier = -1;
+    else if (n > TLC_MAX_SUBGRAPH_NODES || m > TLC_MAX_SUBGRAPH_EDGES) {
+        // does not fit the packed node ids / edge ranks: reported through the counts row, never computed wrongly
+        tier = -1;
+        for (int c = 0; c < 4; ++c) counts[4 * (size_t)g + c] = -1;
+    }
     else if (n <= TLC_S_NMAX && m <= TLC_S_MMAX) tier = TLC_TIER_SMALL;
     else if (n <= TLC_M_NMAX && m <= TLC_M_MMAX) tier = TLC_TIER_MEDIUM;
     else if (n <= TLC_L_NMAX && m <= TLC_L_MMAX) tier = TLC_TIER_LARGE;
@@ -1378,11 +1379,11 @@ int tlc_launch_pdf_tier(int tier, const TlcPdfParams& p, void* stream) {
     return TLC_OK;
 }
 
-int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long* edge_offs, int* tier_count,
+int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long* edge_offs, int* counts, int* tier_count,
                        int* tier_list, void* stream) {
     if (n_graphs <= 0) return TLC_OK;
     hipLaunchKernelGGL(tlc_pdf_bin_kernel, dim3((n_graphs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_graphs,
-                       node_offs, edge_offs, tier_count, tier_list);
+                       node_offs, edge_offs, tier_count, tier_list, counts);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }

@@ -14,6 +14,9 @@
 #define TLC_TIER_MEDIUM 1
 #define TLC_TIER_LARGE 2
 #define TLC_TIER_HUGE 3
+// hard limits of one subgraph: local node ids are packed in 16 bits, edge ranks + 1 in 24
+#define TLC_MAX_SUBGRAPH_NODES 65535
+#define TLC_MAX_SUBGRAPH_EDGES ((1 << 24) - 2)
 #define TLC_N_TIERS 4
 
 #define TLC_S_NMAX 64
@@ -149,7 +152,7 @@ __global__ void tlc_scan_down(TlcScanParams p);
 // host-side launchers implemented next to their kernels
 int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream);
 int tlc_launch_pdf_tier(int tier, const TlcPdfParams& p, void* stream);
-int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long* edge_offs, int* tier_count,
+int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long* edge_offs, int* counts, int* tier_count,
                        int* tier_list, void* stream);
 size_t tlc_huge_slot_bytes(int nmax, int mmax);
 int tlc_launch_pi_raster(int n_dgms, const long long* offs, const double* pts, int res, double* out, void* stream);

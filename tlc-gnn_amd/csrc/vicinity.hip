@@ -377,6 +377,17 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
         unsigned* wdir = nullptr;
         double* wlw = nullptr;
         if (!FILL) {
+            if ((m2 >> 1) > TLC_MAX_SUBGRAPH_EDGES) {            // edge ranks are packed in 24 bits (pd_pipeline.hip, cycle swap)
+                if (tid == 0) {
+                    p.hdr_n[i] = 0; p.hdr_m2[i] = 0;
+                    if (p.out_status) p.out_status[i] = TLC_ST_TOO_LARGE;
+                    if (p.out_n) p.out_n[i] = -n;
+                    if (p.out_m) p.out_m[i] = 0;
+                }
+                if (p.out_pi) for (int c = tid; c < res2; c += BW) p.out_pi[(size_t)i * res2 + c] = 0.0;
+                __syncthreads();
+                continue;
+            }
             if (tid == 0) { p.hdr_n[i] = n; p.hdr_m2[i] = m2; }
             // small vicinities are finished right here: fixed-size slot, no second kernel pass over this pair
             if (p.small_dir && n <= TLC_S_NMAX && (m2 >> 1) <= TLC_S_MMAX) {
