@@ -670,6 +670,10 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
     }
     // above the root sits the spare slot, its own parent, behind edges of key 0: a walk that passes the root keeps
     // stepping in place there, so a step needs no "at the root" case
+    // nodes the tree did not reach (disconnected input): only then does a query have to test its endpoints
+    bool unreached = false;
+    for (int i = tid; i < n; i += W) unreached |= (par[i] == NONE);
+    const bool any_unreached = block_any<W>(unreached, M.ctl, 5);
     if (tid == 0) { par[root] = (unsigned)NMcap; key[root] = 0u; par[NMcap] = (unsigned)NMcap; key[NMcap] = 0u; mark[NMcap] = 0u; }
     __syncthreads();
     TLC_STAMP(9);
@@ -691,7 +695,8 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
         unsigned n_pq = 0u, n_ar = 0u;                             // endpoints / ascending rank of query pi
         if (npos > 0) { const unsigned e0 = M.pn[0]; n_pq = ends[e0]; n_ar = (M.arank[e0] + 1u) << 8; }
         // ... and so are the walkers' first nodes, read under the previous query's swap (patched if it touched them)
-        int n_cur = qside ? (int)(n_pq & 0xffffu) : (int)(n_pq >> 16);
+        const unsigned side_shift = qside ? 0u : 16u;           // a walker's first node: p in the high, q in the low half
+        int n_cur = (int)((n_pq >> side_shift) & 0xffffu);
         unsigned n_pcur = par[n_cur], n_kcur = key[n_cur];
         int n_out = 0;                         // points emitted by this stage (wave-uniform)
         const int out0 = M.ctl[2];
@@ -715,13 +720,13 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
             // so comparing hi words compares ranks)
             unsigned res_hi = 0, res_lo = 0;
             unsigned res_s = 0;                // side of the winner: 0 = p-walk, 1 = q-walk
-            if (__ballot(lane < 2 && pcur == NONE) == 0ull) {      // else other component (callers gate on connectivity)
+            if (!any_unreached || __ballot(lane < 2 && pcur == NONE) == 0ull) {   // else other component (:274 of the oracle)
                 stamp += 2;                                        // < 2^26: at most 2^24 Pos edges per subgraph (the key packing)
                 int fl = 0;
                 DBG_T(dbg_t1);
                 if (lane < 2) {
                     // The walk is straight-line code for both lanes; the only branch in a step is the uniform exit.
-                    const unsigned mine = stamp + (qside ? 1u : 0u), theirs = stamp + (qside ? 0u : 1u);
+                    const unsigned mine = stamp + (unsigned)(lane & 1), theirs = stamp + (unsigned)((lane & 1) ^ 1);
                     unsigned mx_hi = 0, mx_lo = 0;                 // heaviest edge this walk has crossed (0 = none)
                     unsigned step = 0, o_hi, o_lo;
                     mark[cur] = mine;
@@ -750,7 +755,7 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
                     const bool mwin = mx_hi >= o_hi;
                     res_hi = mwin ? mx_hi : o_hi;
                     res_lo = mwin ? mx_lo : o_lo;
-                    res_s = (mwin ? qside : !qside) ? 1u : 0u;
+                    res_s = (unsigned)(lane & 1) ^ (mwin ? 0u : 1u);
                 }
                 DBG_T(dbg_t2);
 #ifdef TLC_PHASE_DEBUG
@@ -761,12 +766,9 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
                 res_lo = __builtin_amdgcn_readlane(res_lo, fl);
                 res_s = __builtin_amdgcn_readlane(res_s, fl);
             }
-            // the next query's first nodes: issued ahead of the swap's writes, patched below if the swap touched them
-            const int np_ = (int)(n_pq >> 16), nq_ = (int)(n_pq & 0xffffu);
-            n_cur = qside ? nq_ : np_;
-            n_pcur = par[n_cur];
-            n_kcur = key[n_cur];
-            if (res_hi == 0u) continue;
+            // the next query's first nodes (their parent and key are read after the swap's writes, below)
+            n_cur = (int)((n_pq >> side_shift) & 0xffffu);
+            if (res_hi == 0u) { n_pcur = par[n_cur]; n_kcur = key[n_cur]; continue; }
             const int best = (int)(res_lo >> 16), bp = (int)(res_lo & 0xffffu);
             const unsigned bstep = res_hi & 0xffu;
             const int hin = best > bp ? best : bp;                                // large_value  (:160)
@@ -784,19 +786,11 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
                 const ull* rr = (const ull*)M.rec + (res_s ? 65 : 0);
                 const bool mine_i = (unsigned)lane <= bstep;
                 const int li = mine_i ? lane : 0;
-                const ull r1 = rr[li], r0 = rr[li > 0 ? li - 1 : 0];           // (same round trip as the two reads above)
+                const ull r1 = rr[li], r0 = rr[li > 0 ? li - 1 : 0];
                 const unsigned xi = mine_i ? (unsigned)r1 : 0xffffffffu;
                 const unsigned xprev = lane ? (unsigned)r0 : (unsigned)(res_s == 0 ? q : p);
                 const unsigned kprev = lane ? (unsigned)(r0 >> 32) : ar;
                 if (mine_i) { par[xi] = xprev; key[xi] = kprev; }
-                // a first node of the next query that sits on the everted path takes its new parent from that lane
-                const ull tp = __ballot(xi == (unsigned)np_), tq = __ballot(xi == (unsigned)nq_);
-                const int lp = __builtin_ctzll(tp | (1ull << 63)), lq = __builtin_ctzll(tq | (1ull << 63));
-                const unsigned vp = __builtin_amdgcn_readlane(xprev, lp), kp2 = __builtin_amdgcn_readlane(kprev, lp);
-                const unsigned vq = __builtin_amdgcn_readlane(xprev, lq), kq2 = __builtin_amdgcn_readlane(kprev, lq);
-                const bool usep = tp != 0ull && !qside, useq = tq != 0ull && qside;
-                n_pcur = usep ? vp : (useq ? vq : n_pcur);
-                n_kcur = usep ? kp2 : (useq ? kq2 : n_kcur);
             } else {
                 if (lane == 0) {
                     int node = res_s == 0 ? p : q, nodec = res_s == 0 ? q : p;
@@ -810,9 +804,10 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
                         kin = kk;
                     }
                 }
-                n_pcur = par[n_cur];
-                n_kcur = key[n_cur];
             }
+            // LDS executes in order: these reads see the swap; their latency hides under the next query's set-up
+            n_pcur = par[n_cur];
+            n_kcur = key[n_cur];
 #ifdef TLC_PHASE_DEBUG
             dbg_c += clock64() - dbg_t2;
 #endif
