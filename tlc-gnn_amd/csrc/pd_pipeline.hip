@@ -917,7 +917,7 @@ __device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get 
 // Batch kernel: one workgroup per vicinity subgraph of one size tier.
 // ======================================================================================================================
 template <int NM, int MM, int W, bool LWL, bool HUGE>
-__global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {
+__global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : 1)) void tlc_pd_tier_kernel(TlcPdParams p) {
     typedef unsigned short idx_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x;
@@ -1312,8 +1312,8 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             break;
         }
         case TLC_TIER_MEDIUM: {
-            constexpr Layout L = make_layout(TLC_M_NMAX, TLC_M_MMAX, true, 2);
-            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, true, false>), dim3(p.tier_count),
+            constexpr Layout L = make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2);
+            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, false, false>), dim3(p.tier_count),
                                dim3(256), L.total, s, p);
             break;
         }
