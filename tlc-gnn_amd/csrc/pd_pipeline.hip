@@ -917,7 +917,7 @@ __device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get 
 // Batch kernel: one workgroup per vicinity subgraph of one size tier.
 // ======================================================================================================================
 template <int NM, int MM, int W, bool LWL, bool HUGE>
-__global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : 1)) void tlc_pd_tier_kernel(TlcPdParams p) {
+__global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W == 64 ? 4 : 1))) void tlc_pd_tier_kernel(TlcPdParams p) {
     typedef unsigned short idx_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x;
