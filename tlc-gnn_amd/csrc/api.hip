@@ -163,7 +163,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
         TLC_REQUIRE(h_w[j] > 0.0, "edge weights (kappa+1) must be > 0");
     }
     const int nw = (n_nodes + 31) / 32;
-    const size_t lds = ((size_t)3 * ((nw + 3) & ~3) + 4 + 16) * 4;
+    const size_t lds = ((size_t)5 * ((nw + 3) & ~3) / 2 + 4 + 16) * 4;   // two bitmaps + a 16-bit prefix per bitmap word
     if (lds > 160 * 1024) {
         tlc_set_error("graph has %d nodes: the vicinity bitmaps (%zu B) exceed the 160 KiB LDS of a CU", n_nodes, lds);
         return TLC_ERR_UNSUPPORTED;
@@ -203,7 +203,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    int per_cu = (int)std::min<size_t>(20, (160 * 1024) / std::max<size_t>(lds + 64, 1));
+    int per_cu = (int)std::min<size_t>(28, (160 * 1024) / std::max<size_t>(lds + 64, 1));
     if (per_cu < 1) per_cu = 1;
     g->vic_slots = cus * per_cu;
     (void)rc;

@@ -120,7 +120,7 @@ __device__ __forceinline__ void mark_ball(unsigned* bits, int root, int hop, con
     __syncthreads();
 }
 
-__device__ __forceinline__ int local_id(const unsigned* S, const unsigned* pref, int b) {
+__device__ __forceinline__ int local_id(const unsigned* S, const unsigned short* pref, int b) {
     const int w = b >> 5;
     return (int)pref[w] + __popc(S[w] & ((1u << (b & 31)) - 1u));
 }
@@ -128,7 +128,7 @@ __device__ __forceinline__ int local_id(const unsigned* S, const unsigned* pref,
 // Walk the CSR rows of ids[0..n).  WRITE=false: ldeg[k] = induced degree of row k (if ldeg), returns the
 // wave-uniform total.  WRITE=true: row k's entries go to dir/lw starting at lrow[k].
 template <bool WRITE, int BW>
-__device__ __forceinline__ int induced_rows(const int* __restrict__ ids, int n, const unsigned* S, const unsigned* pref,
+__device__ __forceinline__ int induced_rows(const int* __restrict__ ids, int n, const unsigned* S, const unsigned short* pref,
                                             const TlcVicParams& p, int* ldeg_or_lrow, unsigned* dir, double* lw, int* xw) {
     const int lane = tlc_lane();
     int total = 0;
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
     const int nw4 = (p.nw + 3) & ~3;          // bitmaps padded to 16 bytes
     unsigned* bitsU = lds;
     unsigned* bitsV = lds + nw4;   // becomes S
-    unsigned* pref = lds + 2 * nw4;
-    int* s_cnt = (int*)(lds + 3 * nw4);
+    unsigned short* pref = (unsigned short*)(lds + 2 * nw4);   // 16 bits: a vicinity has at most 65 535 nodes
+    int* s_cnt = (int*)(lds + 2 * nw4 + nw4 / 2);
     int* xw = s_cnt + 4;                       // BW/64 ints for the block scans
     const int tid = threadIdx.x;
     int* slot = p.scratch + (size_t)blockIdx.x * p.scratch_stride;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
             int o = excl;
             for (int w = w0; w < w1; ++w) {
                 unsigned s = bitsV[w];
-                pref[w] = (unsigned)o;
+                pref[w] = (unsigned short)o;
                 while (s) {
                     const int b = __builtin_ctz(s);
                     s &= s - 1;
