@@ -7,7 +7,7 @@ python bench.py --steps 10 --warmup 3 > gpurun_out/bench_$R.json 2> gpurun_out/b
 cat gpurun_out/bench_$R.json
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sweep > gpurun_out/prof/kt.log 2>&1
 cp $(find gpurun_out/prof/kt -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_bench_kernel_stats.csv
-python tools/timeline.py gpurun_out/prof/kt -3 > gpurun_out/${R}_bench_timeline.txt
+python tools/timeline.py gpurun_out/prof/kt 6 > gpurun_out/${R}_bench_timeline.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > gpurun_out/prof/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > gpurun_out/prof/pmc_write.log 2>&1
 head -14 gpurun_out/${R}_bench_kernel_stats.csv
