@@ -177,8 +177,11 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
     CK(hipMalloc(&g->d_rowptr, (size_t)(n_nodes + 1) * sizeof(int)));
-    CK(hipMalloc(&g->d_col, (size_t)std::max(nnz, 1ll) * sizeof(int)));
-    CK(hipMalloc(&g->d_w, (size_t)std::max(nnz, 1ll) * sizeof(double)));
+    // 8 entries of zero padding: the vicinity kernels read short rows with 16-byte loads that may run past a row's end
+    CK(hipMalloc(&g->d_col, ((size_t)nnz + 8) * sizeof(int)));
+    CK(hipMalloc(&g->d_w, ((size_t)nnz + 8) * sizeof(double)));
+    CK(hipMemset(g->d_col + nnz, 0, 8 * sizeof(int)));
+    CK(hipMemset(g->d_w + nnz, 0, 8 * sizeof(double)));
     CK(hipMemcpy(g->d_rowptr, h_rowptr, (size_t)(n_nodes + 1) * sizeof(int), hipMemcpyHostToDevice));
     CK(hipMemcpy(g->d_col, h_col, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
     CK(hipMemcpy(g->d_w, h_w, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));

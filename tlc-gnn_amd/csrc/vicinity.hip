@@ -44,6 +44,29 @@ __device__ __forceinline__ int block_escan_i32(int v, int* xw, int* total) {
 
 __device__ __forceinline__ bool bit_test(const unsigned* bits, int b) { return (bits[b >> 5] >> (b & 31)) & 1u; }
 
+// A lane that scans its own short CSR row costs the texture addresser one cycle per load, whatever the load's width: the
+// row scans are bound by that rate (64 scattered lanes = 64 cycles per wave instruction), so they fetch 16 bytes per
+// load from 4-byte aligned addresses (global memory is in unaligned-access mode; the CSR arrays carry 8 padding entries).
+struct __attribute__((packed, aligned(4))) TlcI4 { int v[4]; };
+struct __attribute__((packed, aligned(4))) TlcI2 { int x, y; };
+struct __attribute__((packed, aligned(8))) TlcD2 { double v[2]; };
+__device__ __forceinline__ void load_row8(const int* __restrict__ col, int j0, int (&bb)[8]) {
+    const TlcI4 a = *reinterpret_cast<const TlcI4*>(col + j0), b = *reinterpret_cast<const TlcI4*>(col + j0 + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { bb[q] = a.v[q]; bb[4 + q] = b.v[q]; }
+}
+__device__ __forceinline__ void load_row8w(const double* __restrict__ w, int j0, double (&ww)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const TlcD2 d = *reinterpret_cast<const TlcD2*>(w + j0 + 2 * q);
+        ww[2 * q] = d.v[0]; ww[2 * q + 1] = d.v[1];
+    }
+}
+__device__ __forceinline__ void row_bounds(const int* __restrict__ rowptr, int a, int& beg, int& end) {
+    const TlcI2 r = *reinterpret_cast<const TlcI2*>(rowptr + a);
+    beg = r.x; end = r.y;
+}
+
 // Set the bits of every neighbour of every node in list[0..count); optionally append newly set nodes to
 // `next` (global scratch) through the LDS counter *s_cnt.
 __device__ __forceinline__ void expand_rows(const int* __restrict__ list, int count, unsigned* bits,
@@ -55,16 +78,14 @@ __device__ __forceinline__ void expand_rows(const int* __restrict__ list, int co
         int beg = 0, end = 0;
         if (k < count) {
             const int a = list[k];
-            beg = rowptr[a];
-            end = rowptr[a + 1];
+            row_bounds(rowptr, a, beg, end);
         }
         const bool big = (end - beg) >= 32;
         if (!big) {
             // eight entries per round trip (a load-use loop would pay one global latency per entry)
             for (int j0 = beg; j0 < end; j0 += 8) {
                 int bb[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) bb[q] = col[j0 + q < end ? j0 + q : beg];
+                load_row8(col, j0, bb);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (j0 + q < end) {
@@ -137,8 +158,7 @@ __device__ __forceinline__ int induced_rows(const int* __restrict__ ids, int n, 
         int beg = 0, end = 0, t = 0;
         if (k < n) {
             const int a = ids[k];
-            beg = p.rowptr[a];
-            end = p.rowptr[a + 1];
+            row_bounds(p.rowptr, a, beg, end);
             if (WRITE) t = ldeg_or_lrow[k];
         }
         const bool big = (end - beg) >= 32;
@@ -148,12 +168,8 @@ __device__ __forceinline__ int induced_rows(const int* __restrict__ ids, int n, 
             for (int j0 = beg; j0 < end; j0 += 8) {
                 int bb[8];
                 double ww[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int j = j0 + q < end ? j0 + q : beg;
-                    bb[q] = p.col[j];
-                    if (WRITE) ww[q] = p.w[j];
-                }
+                load_row8(p.col, j0, bb);
+                if (WRITE) load_row8w(p.w, j0, ww);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (j0 + q < end && bit_test(S, bb[q])) {
@@ -225,15 +241,14 @@ __device__ __forceinline__ void mark_two_balls_hop2(unsigned* bitsU, unsigned* b
             const int a = p.col[isu ? ub + k : vb + (k - du)];
             bits = isu ? bitsU : bitsV;
             atomicOr(&bits[a >> 5], 1u << (a & 31));
-            if (hop >= 2) { beg = p.rowptr[a]; end = p.rowptr[a + 1]; }
+            if (hop >= 2) row_bounds(p.rowptr, a, beg, end);
         }
         if (hop < 2) continue;
         const bool big = (end - beg) >= 32;
         if (!big) {
             for (int j0 = beg; j0 < end; j0 += 8) {         // eight entries per round trip
                 int bb[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) bb[q] = p.col[j0 + q < end ? j0 + q : beg];
+                load_row8(p.col, j0, bb);
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                     if (j0 + q < end) atomicOr(&bits[bb[q] >> 5], 1u << (bb[q] & 31));
