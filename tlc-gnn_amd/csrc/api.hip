@@ -256,6 +256,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     TlcVicParams vp;
     memset(&vp, 0, sizeof(vp));
     vp.n_nodes = g->n_nodes; vp.nw = g->nw; vp.rowptr = g->d_rowptr; vp.col = g->d_col; vp.w = g->d_w;
+    vp.dbg = g->d_phase ? g->d_phase + 32 * TLC_TIER_HUGE : nullptr;   // (diagnostics share the HUGE tier's counter row)
     vp.pairs = d_pairs; vp.n_pairs = n_pairs; vp.hop = hop; vp.flags = flags; vp.res = res;
     vp.scratch = g->vic_scratch; vp.scratch_stride = g->vic_stride;
     vp.hdr_n = g->hdr_n; vp.hdr_m2 = g->hdr_m2; vp.hdr_lu = g->hdr_lu; vp.hdr_lv = g->hdr_lv;

@@ -67,6 +67,7 @@ struct TlcVicParams {
     // fixed-size slots (2*TLC_S_MMAX entries per pair) for the vicinities of the SMALL tier, written by the COUNT pass
     unsigned* small_dir;
     double* small_lw;
+    unsigned long long* dbg;   // PHASE_DEBUG builds: per-phase cycle sums of the COUNT pass (null otherwise)
 };
 
 struct TlcScanParams {

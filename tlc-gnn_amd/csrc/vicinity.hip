@@ -146,6 +146,62 @@ __device__ __forceinline__ int local_id(const unsigned* S, const unsigned short*
     return (int)pref[w] + __popc(S[w] & ((1u << (b & 31)) - 1u));
 }
 
+// One wavefront's batch of rows (lane = row k with CSR range [beg, end), empty for idle lanes): counts the entries whose
+// column is in S and, with WRITE, stores them as (k << 16 | local id, weight) from offset t on.  Short rows are scanned
+// by their own lane, rows of >= 32 entries by the whole wavefront.  Returns the lane's induced degree.
+template <bool WRITE>
+__device__ __forceinline__ int induced_batch(int k, int kbase, int beg, int end, int t, const unsigned* S,
+                                             const unsigned short* pref, const TlcVicParams& p, unsigned* dir, double* lw) {
+    const int lane = tlc_lane();
+    const bool big = (end - beg) >= 32;
+    int cnt = 0;
+    if (!big) {
+        // eight entries (and, when writing, their weights) per round trip
+        for (int j0 = beg; j0 < end; j0 += 8) {
+            int bb[8];
+            double ww[8];
+            load_row8(p.col, j0, bb);
+            if (WRITE) load_row8w(p.w, j0, ww);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (j0 + q < end && bit_test(S, bb[q])) {
+                    if (WRITE) {
+                        dir[t + cnt] = ((unsigned)k << 16) | (unsigned)local_id(S, pref, bb[q]);
+                        lw[t + cnt] = ww[q];
+                    }
+                    ++cnt;
+                }
+            }
+        }
+    }
+    unsigned long long mask = __ballot(big);
+    while (mask) {
+        const int L = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int bb = __shfl(beg, L, 64), ee = __shfl(end, L, 64), tt = __shfl(t, L, 64);
+        const int kk = kbase + L;
+        int run = 0;
+        for (int j0 = bb; j0 < ee; j0 += TLC_WAVE) {
+            const int j = j0 + lane;
+            int b = -1;
+            bool in = false;
+            if (j < ee) {
+                b = p.col[j];
+                in = bit_test(S, b);
+            }
+            const unsigned long long m = __ballot(in);
+            if (WRITE && in) {
+                const int pos = tt + run + __popcll(m & tlc_lanemask_lt());
+                dir[pos] = ((unsigned)kk << 16) | (unsigned)local_id(S, pref, b);
+                lw[pos] = p.w[j];
+            }
+            run += __popcll(m);
+        }
+        if (lane == L) cnt = run;
+    }
+    return cnt;
+}
+
 // Walk the CSR rows of ids[0..n).  WRITE=false: ldeg[k] = induced degree of row k (if ldeg), returns the
 // wave-uniform total.  WRITE=true: row k's entries go to dir/lw starting at lrow[k].
 template <bool WRITE, int BW>
@@ -161,52 +217,7 @@ __device__ __forceinline__ int induced_rows(const int* __restrict__ ids, int n, 
             row_bounds(p.rowptr, a, beg, end);
             if (WRITE) t = ldeg_or_lrow[k];
         }
-        const bool big = (end - beg) >= 32;
-        int cnt = 0;
-        if (!big) {
-            // eight entries (and, when writing, their weights) per round trip
-            for (int j0 = beg; j0 < end; j0 += 8) {
-                int bb[8];
-                double ww[8];
-                load_row8(p.col, j0, bb);
-                if (WRITE) load_row8w(p.w, j0, ww);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if (j0 + q < end && bit_test(S, bb[q])) {
-                        if (WRITE) {
-                            dir[t + cnt] = ((unsigned)k << 16) | (unsigned)local_id(S, pref, bb[q]);
-                            lw[t + cnt] = ww[q];
-                        }
-                        ++cnt;
-                    }
-                }
-            }
-        }
-        unsigned long long mask = __ballot(big);
-        while (mask) {
-            const int L = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const int bb = __shfl(beg, L, 64), ee = __shfl(end, L, 64), tt = __shfl(t, L, 64);
-            const int kk = base + L;
-            int run = 0;
-            for (int j0 = bb; j0 < ee; j0 += TLC_WAVE) {
-                const int j = j0 + lane;
-                int b = -1;
-                bool in = false;
-                if (j < ee) {
-                    b = p.col[j];
-                    in = bit_test(S, b);
-                }
-                const unsigned long long m = __ballot(in);
-                if (WRITE && in) {
-                    const int pos = tt + run + __popcll(m & tlc_lanemask_lt());
-                    dir[pos] = ((unsigned)kk << 16) | (unsigned)local_id(S, pref, b);
-                    lw[pos] = p.w[j];
-                }
-                run += __popcll(m);
-            }
-            if (lane == L) cnt = run;
-        }
+        const int cnt = induced_batch<WRITE>(k, base, beg, end, t, S, pref, p, dir, lw);
         if (!WRITE) {
             if (ldeg_or_lrow && k < n) ldeg_or_lrow[k] = cnt;
             total += cnt;
@@ -291,7 +302,15 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
     // "dequeue"), which would cap this kernel at ~0.4 ms per 37k pairs; consecutive pairs land on different workgroups,
     // so hub-heavy runs of the pair list are spread out anyway
     const int n_work = (FILL && p.fill_mode == 1) ? p.fill_count : p.n_pairs;
+#ifdef TLC_PHASE_DEBUG
+#define VSTAMP(k) do { if (!FILL && p.dbg && tid == 0) { const unsigned long long _t = clock64(); atomicAdd(&p.dbg[k], _t - vt); vt = _t; } } while (0)
+#else
+#define VSTAMP(k) do { } while (0)
+#endif
     for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+#ifdef TLC_PHASE_DEBUG
+        unsigned long long vt = clock64();
+#endif
         const int i = (FILL && p.fill_mode == 1) ? p.fill_list[wi] : wi;
         const int u = p.pairs[2 * (size_t)i], v = p.pairs[2 * (size_t)i + 1];
         if (FILL) {
@@ -332,6 +351,7 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
             bitsU[v >> 5] |= 1u << (v & 31); bitsV[v >> 5] |= 1u << (v & 31);
         }
         __syncthreads();
+        VSTAMP(0);
         // ---- S = ball(u) & ball(v)  (:315), popcount prefix and the ascending id list in one sweep: every lane owns a
         //      contiguous chunk of bitmap words, one wave scan links the chunks
         const int w0 = tid * wpl < p.nw ? tid * wpl : p.nw, w1 = (w0 + wpl) < p.nw ? (w0 + wpl) : p.nw;
@@ -356,6 +376,7 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
             }
         }
         __syncthreads();
+        VSTAMP(1);
         const unsigned* S = bitsV;
         if (!FILL) {
             int lu = -1, lv = -1;
@@ -387,7 +408,20 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
             }
         }
         // ---- induced subgraph (graph.subgraph(nodes), :316) -------------------------------------------------
-        const int m2 = induced_rows<false, BW>(ids, n, S, pref, p, lrow, nullptr, nullptr, xw);
+        // A vicinity of <= 64 nodes is one row per lane of a single wavefront: the row bounds and induced degrees stay in
+        // registers between the counting and the writing pass (no row-offset hand-off through global scratch, no second
+        // read of the id list and the row pointers); 9 of 10 pairs take this path in COUNT.
+        const bool reg_rows = (BW == 64) && n <= TLC_WAVE;
+        int rb = 0, re = 0, rcnt = 0;
+        int m2;
+        if (reg_rows) {
+            if (tid < n) row_bounds(p.rowptr, ids[tid], rb, re);
+            rcnt = induced_batch<false>(tid, 0, rb, re, 0, S, pref, p, nullptr, nullptr);
+            m2 = tlc_wave_sum_i32(rcnt);
+        } else {
+            m2 = induced_rows<false, BW>(ids, n, S, pref, p, lrow, nullptr, nullptr, xw);
+        }
+        VSTAMP(2);
         bool write = FILL;
         unsigned* wdir = nullptr;
         double* wlw = nullptr;
@@ -415,7 +449,10 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
             wdir = p.A_dir + eo;
             wlw = p.A_lw + eo;
         }
-        if (write) {
+        if (write && reg_rows) {
+            const int t0 = tlc_wave_iscan_i32(rcnt) - rcnt;
+            induced_batch<true>(tid, 0, rb, re, t0, S, pref, p, wdir, wlw);
+        } else if (write) {
             __syncthreads();
             int run = 0;
             for (int base = 0; base < n; base += BW) {
@@ -430,6 +467,10 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
             induced_rows<true, BW>(ids, n, S, pref, p, lrow, wdir, wlw, xw);
         }
         __syncthreads();
+        VSTAMP(3);
+#ifdef TLC_PHASE_DEBUG
+        if (!FILL && p.dbg && tid == 0) atomicAdd(&p.dbg[4], 1ull);
+#endif
     }
 }
 

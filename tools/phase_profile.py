@@ -27,3 +27,7 @@ for t, tn in enumerate(["small", "medium", "large", "huge"]):
         print("   %-16s %6.2f %%   mean %9.0f   slowest wg %9.0f" % (NAMES[i], 100 * a[t, i] / max(a[t, 12], 1), a[t, i] / a[t, 14], a[t, 16 + i]))
     print("   slowest wg: n=%d m=%d" % (a[t, 28], a[t, 29]))
     print("   ext1 split (sum over wgs): pre-walk %.0f  walk %.0f  post %.0f  (ext1 total %.0f)" % (a[t, 15], a[t, 30], a[t, 31], a[t, 10]))
+
+c = a[3]
+if c[4] > 0:
+    print("COUNT pass: %d pairs; mean cycles per pair: balls %.0f | S sweep + id list %.0f | induced count %.0f | small-tier write %.0f" % (c[4], c[0] / c[4], c[1] / c[4], c[2] / c[4], c[3] / c[4]))
