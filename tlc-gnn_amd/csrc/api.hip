@@ -127,10 +127,12 @@ static int ensure_vic_scratch(tlc_graph* g, int hop) {
     if (g->vic_scratch && g->vic_hop_cap >= need_front) return TLC_OK;
     hipFree(g->vic_scratch);
     g->vic_scratch = nullptr;
-    // slot = [frontA | frontB | ids | lrow]; the frontiers are only touched for hop >= 3
-    g->vic_stride = 4ll * g->n_nodes + 16;
+    // slot = [ids | lrow | frontA | frontB]: the id list and the row offsets of one vicinity (at most 65 535 nodes, whatever
+    // the graph's size), and for hop >= 3 the two BFS frontiers (up to n_nodes each)
+    const long long cap = std::min<long long>(g->n_nodes, TLC_MAX_SUBGRAPH_NODES + 1);
+    g->vic_stride = 2 * cap + (need_front ? 2ll * g->n_nodes : 0) + 16;
     TLC_HIP_CHECK(hipMalloc(&g->vic_scratch, (size_t)g->vic_slots * g->vic_stride * sizeof(int)));
-    g->vic_hop_cap = 1;
+    g->vic_hop_cap = need_front;
     return TLC_OK;
 }
 

@@ -291,10 +291,11 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
     int* xw = s_cnt + 4;                       // BW/64 ints for the block scans
     const int tid = threadIdx.x;
     int* slot = p.scratch + (size_t)blockIdx.x * p.scratch_stride;
-    int* frontA = slot;
-    int* frontB = slot + p.n_nodes;
-    int* ids = slot + 2 * (size_t)p.n_nodes;     // ascending node ids of S
-    int* lrow = slot + 3 * (size_t)p.n_nodes;    // induced degree, then row offsets
+    const int cap = p.n_nodes < TLC_MAX_SUBGRAPH_NODES + 1 ? p.n_nodes : TLC_MAX_SUBGRAPH_NODES + 1;
+    int* ids = slot;                             // ascending node ids of S (a vicinity has at most 65 535 nodes)
+    int* lrow = slot + cap;                      // induced degree, then row offsets
+    int* frontA = slot + 2 * (size_t)cap;        // BFS frontiers: hop >= 3 only (the host allocates them then)
+    int* frontB = frontA + p.n_nodes;
     const int res2 = p.res * p.res;
     const int wpl = (p.nw + BW - 1) / BW;      // bitmap words per thread (contiguous chunk)
 
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
             for (int w = w0; w < w1; ++w) {
                 unsigned s = bitsV[w];
                 pref[w] = (unsigned short)o;
-                while (s) {
+                while (s && n <= TLC_MAX_SUBGRAPH_NODES) {          // (an oversized vicinity is rejected below; its list has no room)
                     const int b = __builtin_ctz(s);
                     s &= s - 1;
                     ids[o++] = (w << 5) + b;
