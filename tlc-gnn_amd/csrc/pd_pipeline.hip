@@ -917,7 +917,12 @@ __device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get 
 // Batch kernel: one workgroup per vicinity subgraph of one size tier.
 // ======================================================================================================================
 template <int NM, int MM, int W, bool LWL, bool HUGE>
+#ifdef TLC_PHASE_DEBUG
+__global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {       // (the counters need the registers)
+#else
+// 128 VGPRs for the SMALL and MEDIUM tiers: four wavefronts per SIMD (16 resp. 4 workgroups per CU)
 __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W == 64 ? 4 : 1))) void tlc_pd_tier_kernel(TlcPdParams p) {
+#endif
     typedef unsigned short idx_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x;
