@@ -835,6 +835,10 @@ __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, i
     if (threadIdx.x == 0) sink.ext0(M.f, 0, n - 1);                  // [min, max]  (:110)
     __syncthreads();
     TLC_STAMP(6);
+    // A connected vicinity with n - 1 edges is a tree (30 % of a PubMed batch): every edge is a Neg edge, there is no Pos
+    // edge and no 1-dimensional point, and the descending pass would only add Rel1 points, which weigh 0 in the image.
+    // (The batch path is entered for connected vicinities only; tlc_pd_from_filtration reports Rel1 and takes the long way.)
+    if (!Sink::is_global && m == n - 1) return TLC_ST_OK;
     sort_edges<W, idx_t, true>(M, m);
     TLC_STAMP(7);
     if (Sink::want_down) mst_pass<W, idx_t, true, true>(M, sink, n, m, flags);

@@ -17,3 +17,8 @@ for name in ("pd_tier_small", "pd_tier_medium", "pd_tier_large"):
     if name == "pd_tier_medium":
         for nc, mc in ((128, 256), (192, 384), (256, 512), (384, 768)):
             print("   n<=%d & m<=%d: %.1f%%  (sum m share %.1f%%)" % (nc, mc, 100 * ((n <= nc) & (m <= mc)).mean(), 100 * m[(n <= nc) & (m <= mc)].sum() / m.sum()))
+m_all = m2 // 2
+ok = nn > 0
+print("trees (m == n-1): %.1f%% of all pairs; by tier:" % (100 * (m_all[ok] == nn[ok] - 1).mean()),
+      {t: round(100 * float(((m_all == nn - 1) & (tiers == t)).sum()) / max(1, int((tiers == t).sum())), 1) for t in ("pd_tier_small", "pd_tier_medium", "pd_tier_large")})
+print("m - n + 1 (number of Pos edges) percentiles over small tier:", np.percentile((m_all - nn + 1)[tiers == "pd_tier_small"], [10, 25, 50, 75, 90]))
