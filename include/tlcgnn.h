@@ -45,6 +45,8 @@ extern "C" {
 #define TLC_ST_DISCONNECTED    2   /* AssertionError: vicinity empty or not connected (:318)        */
 #define TLC_ST_ZERO_RANGE      3   /* ZeroDivisionError: all filtration values 0 (:54)              */
 #define TLC_ST_NO_TREE_EDGE    4   /* IndexError: single-node vicinity (accelerated_PD.py:122)      */
+#define TLC_ST_TOO_LARGE       5   /* not a reference class: the vicinity has more than 65 535 nodes or
+                                      2^24-2 edges (packed local ids / edge ranks); zero row, never silent */
 
 /* ---- variant flags (one kernel family serves the TLC-GNN and the PDGNN forks) ---- */
 #define TLC_KEEP_ZERO_PERS   0x01u /* Knowledge_Distillation/accelerated_PD.py:68-69,108-109,169-170 */

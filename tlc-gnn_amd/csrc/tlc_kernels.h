@@ -3,11 +3,13 @@
 #include <stdint.h>
 
 // per-pair status beyond the public ones: vicinity does not fit the packed 16-bit local ids
+#ifndef TLC_ST_TOO_LARGE
 #define TLC_ST_TOO_LARGE 5
+#endif
 
 // Size tiers of the PD kernel (nodes / undirected edges of the vicinity subgraph).
 //   SMALL : one wavefront per subgraph, all state in ~6.5 KB of LDS   (>= 16 waves per CU)
-//   MEDIUM: 256 threads per subgraph, ~51 KB of LDS                    (3 workgroups per CU)
+//   MEDIUM: 256 threads per subgraph, ~36 KB of LDS, 128 VGPRs         (4 workgroups per CU)
 //   LARGE : 512 threads per subgraph, ~140 KB of LDS, weights stay in HBM/L2 (1 workgroup per CU)
 //   HUGE  : 256 threads per subgraph, state in a per-workgroup HBM scratch slot (any size < 65536 nodes)
 #define TLC_TIER_SMALL 0
