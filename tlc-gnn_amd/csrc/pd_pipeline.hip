@@ -720,7 +720,7 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
             // so comparing hi words compares ranks)
             unsigned res_hi = 0, res_lo = 0;
             unsigned res_s = 0;                // side of the winner: 0 = p-walk, 1 = q-walk
-            if (!any_unreached || __ballot(lane < 2 && pcur == NONE) == 0ull) {   // else other component (:274 of the oracle)
+            if (!any_unreached || __ballot(lane < 2 && pcur == NONE) == 0ull) {   // else other component (the reference raises KeyError)
                 stamp += 2;                                        // < 2^26: at most 2^24 Pos edges per subgraph (the key packing)
                 int fl = 0;
                 DBG_T(dbg_t1);
