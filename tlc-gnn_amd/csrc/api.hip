@@ -11,6 +11,8 @@
 #include <vector>
 
 #include "tlc_common.h"
+#include <atomic>
+#include <chrono>
 #include "tlc_kernels.h"
 
 // ---- error text ------------------------------------------------------------------------------------------
@@ -37,6 +39,10 @@ struct HostSync {
     int tier_count[TLC_N_TIERS];
     int pad[2];
     unsigned long long stats[2];
+    // written by tlc_publish_sizes straight into this (pinned, device-mapped) block; seq last, after a system-scope fence
+    volatile long long pub_total;
+    volatile int pub_tier[TLC_N_TIERS];
+    volatile unsigned pub_seq;
 };
 
 struct tlc_graph {
@@ -56,6 +62,8 @@ struct tlc_graph {
     long long* d_totals;       // 1
     unsigned long long* d_stats;  // [0] tie-fallback sources, [2] (as int) LARGE workgroups started
     HostSync* h_sync;          // pinned
+    HostSync* h_sync_dev;      // the same block as the device sees it
+    unsigned pub_seq;          // sequence number of the last size publication
     // arena
     size_t cap_entries;
     unsigned* A_dir;
@@ -187,11 +195,13 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     CK(hipMemcpy(g->d_rowptr, h_rowptr, (size_t)(n_nodes + 1) * sizeof(int), hipMemcpyHostToDevice));
     CK(hipMemcpy(g->d_col, h_col, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
     CK(hipMemcpy(g->d_w, h_w, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
-    CK(hipMalloc(&g->d_ctl, 64 * sizeof(int)));
+    CK(hipMalloc(&g->d_ctl, (64 + 1024) * sizeof(int)));   // counters, then the scan's per-block flags
     CK(hipMalloc(&g->d_block_sums, 1024 * sizeof(long long)));
     CK(hipMalloc(&g->d_totals, 2 * sizeof(long long)));
     CK(hipMalloc(&g->d_stats, 4 * sizeof(unsigned long long)));
-    CK(hipHostMalloc((void**)&g->h_sync, sizeof(HostSync), hipHostMallocDefault));
+    CK(hipHostMalloc((void**)&g->h_sync, sizeof(HostSync), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(g->h_sync, 0, sizeof(HostSync));
+    CK(hipHostGetDevicePointer((void**)&g->h_sync_dev, g->h_sync, 0));
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     for (int k = 0; k < TLC_N_SIDE; ++k) {
@@ -252,7 +262,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     if ((rc = ensure_pairs(g, (size_t)n_pairs)) != TLC_OK) return rc;
     if ((rc = ensure_vic_scratch(g, hop)) != TLC_OK) return rc;
     if ((rc = ensure_small(g, (size_t)n_pairs)) != TLC_OK) return rc;
-    TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl, 0, 64 * sizeof(int), s));
+    TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl, 0, (64 + 1024) * sizeof(int), s));
     TLC_HIP_CHECK(hipMemsetAsync(g->d_stats, 0, 4 * sizeof(unsigned long long), s));
 
     TlcVicParams vp;
@@ -287,20 +297,37 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     // exclusive scan of the induced entry counts + tier binning
     const int nb = (n_pairs + 1023) / 1024;
     T0(1, s);
-    hipLaunchKernelGGL(tlc_scan_block_sums, dim3(nb), dim3(1024), 0, s, (const int*)g->hdr_n, (const int*)g->hdr_m2, n_pairs, 1, g->d_block_sums);
-    hipLaunchKernelGGL(tlc_scan_top, dim3(1), dim3(1024), 0, s, g->d_block_sums, nb, g->d_totals);
+    const unsigned seq = ++g->pub_seq;
     TlcScanParams sp;
-    sp.n_pairs = n_pairs; sp.hdr_n = g->hdr_n; sp.hdr_m2 = g->hdr_m2; sp.block_sums = g->d_block_sums;
+    sp.n_pairs = n_pairs; sp.hdr_n = g->hdr_n; sp.hdr_m2 = g->hdr_m2;
+    sp.block_agg = g->d_block_sums; sp.block_flag = g->d_ctl + 64; sp.sync = g->d_ctl + 10; sp.totals = g->d_totals;
     sp.edge_off = g->edge_off; sp.tier_count = g->d_ctl; sp.tier_list = g->tier_list; sp.small_arena = 1;
-    hipLaunchKernelGGL(tlc_scan_down, dim3(nb), dim3(1024), 0, s, sp);
+    // The arena size and the tier counts come back through mapped host memory: the last block of the scan stores them,
+    // fences at system scope and bumps a sequence number the host polls -- no copy kernels, no stream synchronisation on
+    // the critical path.  The poll gives up after 200 us and falls back to synchronising the stream (which also surfaces
+    // a kernel fault).
+    sp.h_total = const_cast<long long*>(&g->h_sync_dev->pub_total);
+    sp.h_tier = const_cast<int*>(g->h_sync_dev->pub_tier);
+    sp.h_seq = const_cast<unsigned*>(&g->h_sync_dev->pub_seq);
+    sp.seq = seq;
+    hipLaunchKernelGGL(tlc_scan_bin, dim3(nb), dim3(1024), 0, s, sp);
     T1(1, s);
     TLC_HIP_CHECK(hipGetLastError());
-    TLC_HIP_CHECK(hipMemcpyAsync(&g->h_sync->total_entries, g->d_totals, sizeof(long long), hipMemcpyDeviceToHost, s));
-    TLC_HIP_CHECK(hipMemcpyAsync(g->h_sync->tier_count, g->d_ctl, TLC_N_TIERS * sizeof(int), hipMemcpyDeviceToHost, s));
-    TLC_HIP_CHECK(hipStreamSynchronize(s));
-    const long long total = g->h_sync->total_entries;
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        while (!(seen = (g->h_sync->pub_seq == seq))) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+        }
+        if (!seen) {
+            TLC_HIP_CHECK(hipStreamSynchronize(s));
+            TLC_REQUIRE(g->h_sync->pub_seq == seq, "size publication did not arrive");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const long long total = g->h_sync->pub_total;
     int tc[TLC_N_TIERS];
-    for (int t = 0; t < TLC_N_TIERS; ++t) tc[t] = g->h_sync->tier_count[t];
+    for (int t = 0; t < TLC_N_TIERS; ++t) tc[t] = g->h_sync->pub_tier[t];
     if ((rc = ensure_arena(g, (size_t)total)) != TLC_OK) return rc;
     if (tc[TLC_TIER_HUGE] > 0 && (rc = ensure_huge(g)) != TLC_OK) return rc;
 

@@ -76,11 +76,19 @@ struct TlcScanParams {
     int n_pairs;
     const int* hdr_n;
     const int* hdr_m2;
-    const long long* block_sums;
+    long long* block_agg;   // [n_blocks] block sums (chained scan)
+    int* block_flag;        // [n_blocks] zeroed per launch: 1 once block_agg[b] is valid
+    int* sync;              // [4] zeroed per launch, 8-byte aligned: block-index ticket, completion count, u64 arena total
+    long long* totals;      // [1] arena entries (device copy)
     long long* edge_off;
     int* tier_count;  // [TLC_N_TIERS]
     int* tier_list;   // [TLC_N_TIERS][n_pairs]
     int small_arena;
+    // mapped host memory the last block publishes into (api.hip, HostSync)
+    long long* h_total;
+    int* h_tier;
+    unsigned* h_seq;
+    unsigned seq;
 };
 
 struct TlcPdParams {
@@ -147,9 +155,7 @@ struct TlcPdfParams {
 #ifdef __HIPCC__
 template <bool FILL, int BW>
 __global__ void tlc_vicinity_kernel(TlcVicParams p);
-__global__ void tlc_scan_block_sums(const int* hn, const int* m2, int n_pairs, int small_arena, long long* block_sums);
-__global__ void tlc_scan_top(long long* block_sums, int n_blocks, long long* totals);
-__global__ void tlc_scan_down(TlcScanParams p);
+__global__ void tlc_scan_bin(TlcScanParams p);
 #endif
 
 // host-side launchers implemented next to their kernels

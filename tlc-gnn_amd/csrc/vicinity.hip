@@ -479,8 +479,11 @@ template __global__ void tlc_vicinity_kernel<false, 64>(TlcVicParams);
 template __global__ void tlc_vicinity_kernel<true, 64>(TlcVicParams);
 template __global__ void tlc_vicinity_kernel<true, 512>(TlcVicParams);
 
-// ---- exclusive scan of the per-pair sizes + tier binning ---------------------------------------------------------
-// Three small kernels (block sums, scan of the block sums, downsweep); n_pairs per chunk is <= 2^20.
+// ---- exclusive scan of the per-pair sizes + tier binning + publication of the sizes, one kernel ----------------------
+// n_pairs per chunk is <= 2^20 (<= 1024 blocks).  Chained scan: a block takes its index from a ticket (so that every
+// block it has to wait for is already running or done), scans its 1024 sizes with wave shuffles, publishes its sum behind
+// a flag and adds up the sums of the blocks before it.  The last block to finish stores the arena size and the tier
+// counts into mapped host memory, fences at system scope and bumps the sequence number the host polls.
 #define SCAN_BLOCK 1024
 
 __device__ __forceinline__ long long arena_entries(int n, int m2, int small_arena) {
@@ -489,57 +492,56 @@ __device__ __forceinline__ long long arena_entries(int n, int m2, int small_aren
     return (long long)m2;
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_block_sums(const int* __restrict__ hn, const int* __restrict__ m2, int n_pairs,
-                                                                  int small_arena, long long* __restrict__ block_sums) {
-    __shared__ long long s[SCAN_BLOCK / TLC_WAVE];
-    const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    long long v = i < n_pairs ? arena_entries(hn[i], m2[i], small_arena) : 0;
-    v = tlc_wave_sum_i64(v);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+__global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
+    __shared__ long long s_wave[SCAN_BLOCK / TLC_WAVE];
+    __shared__ long long s_prefix;
+    __shared__ int s_bid;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_bid = atomicAdd(&p.sync[0], 1);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        long long t = 0;
-        for (int k = 0; k < SCAN_BLOCK / TLC_WAVE; ++k) t += s[k];
-        block_sums[blockIdx.x] = t;
-    }
-}
-
-__global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_top(long long* __restrict__ block_sums, int n_blocks,
-                                                           long long* __restrict__ totals) {
-    // n_blocks <= 1024: one thread per block sum, Hillis-Steele in LDS
-    __shared__ long long s[SCAN_BLOCK];
-    const int t = threadIdx.x;
-    const long long own = t < n_blocks ? block_sums[t] : 0;
-    s[t] = own;
-    __syncthreads();
-    for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
-        const long long a = t >= o ? s[t - o] : 0;
-        __syncthreads();
-        s[t] += a;
-        __syncthreads();
-    }
-    if (t < n_blocks) block_sums[t] = s[t] - own;
-    if (t == SCAN_BLOCK - 1) totals[0] = s[t];
-}
-
-__global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_down(TlcScanParams p) {
-    __shared__ long long s[SCAN_BLOCK];
-    const int t = threadIdx.x;
-    const int i = blockIdx.x * SCAN_BLOCK + t;
+    const int bid = s_bid;
+    const int i = bid * SCAN_BLOCK + t;
     const int n = i < p.n_pairs ? p.hdr_n[i] : 0;
     const int m2v = i < p.n_pairs ? p.hdr_m2[i] : 0;
     const long long own = i < p.n_pairs ? arena_entries(n, m2v, p.small_arena) : 0;
-    s[t] = own;
-    __syncthreads();
-    for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
-        const long long a = t >= o ? s[t - o] : 0;
-        __syncthreads();
-        s[t] += a;
-        __syncthreads();
+    // inclusive scan inside the wavefront, then over the 16 wavefront totals
+    long long incl = own;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
     }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    long long wbase = 0, btotal = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_BLOCK / TLC_WAVE; ++k) {
+        const long long v = s_wave[k];
+        if (k < wave) wbase += v;
+        btotal += v;
+    }
+    // publish this block's sum, then add up the blocks before it (wavefront 0, one predecessor per lane)
+    if (t == 0) {
+        p.block_agg[bid] = btotal;
+        __hip_atomic_store(&p.block_flag[bid], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave == 0) {
+        long long pre = 0;
+        for (int base = 0; base < bid; base += TLC_WAVE) {
+            const int j = base + lane;
+            long long v = 0;
+            if (j < bid) {
+                while (__hip_atomic_load(&p.block_flag[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(&p.block_agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            pre += tlc_wave_sum_i64(v);
+        }
+        if (lane == 0) s_prefix = pre;
+    }
+    __syncthreads();
     int tier = -1;
     if (i < p.n_pairs) {
-        p.edge_off[i] = p.block_sums[blockIdx.x] + s[t] - own;
+        p.edge_off[i] = s_prefix + wbase + incl - own;
         if (n > 0) {
             const int m = m2v >> 1;
             tier = TLC_TIER_HUGE;
@@ -555,8 +557,24 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_down(TlcScanParams p) {
         if (mk == 0) continue;
         int base = 0;
         const int leader = __builtin_ctzll(mk);
-        if (tlc_lane() == leader) base = atomicAdd(&p.tier_count[tt], __popcll(mk));
+        if (lane == leader) base = atomicAdd(&p.tier_count[tt], __popcll(mk));
         base = __shfl(base, leader, 64);
         if (tier == tt) p.tier_list[(size_t)tt * p.n_pairs + base + __popcll(mk & tlc_lanemask_lt())] = i;
+    }
+    // the last block to get here publishes the sizes
+    __syncthreads();
+    if (t == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(p.sync + 2), (unsigned long long)btotal);   // running arena total
+        __threadfence();
+        if (atomicAdd(&p.sync[1], 1) == (int)gridDim.x - 1) {
+            const long long total = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(p.sync + 2), __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+            p.totals[0] = total;
+            *p.h_total = total;
+            for (int tt = 0; tt < TLC_N_TIERS; ++tt)
+                p.h_tier[tt] = __hip_atomic_load(&p.tier_count[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(p.h_seq, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
