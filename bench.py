@@ -107,7 +107,7 @@ def main():
     rowptr_n, col_n, val_n = ops.gcn_norm_csr(edge_index, n)          # cached=True: one-off
     enc = tdist.ShardedGCNEncoder(rowptr_n, col_n, val_n, n, world, rank,
                                   gemm=lambda a, b: ops.gemm(a, b),
-                                  spmm=lambda rp, c, v, xx, bias, relu: ops.spmm(rp, c, v, xx, bias=bias, relu=relu))
+                                  spmm=lambda rp, c, v, xx, bias, relu, renorm=False: ops.spmm(rp, c, v, xx, bias=bias, relu=relu, renorm=renorm))
     x_local = torch.from_numpy(wl["x"][enc.lo:enc.hi]).to(dev).contiguous()
     dec_pairs_np = np.concatenate([wl["pi_pairs"].astype(np.int64), wl["neg"]]).astype(np.int32)
     dec_pairs = torch.from_numpy(dec_pairs_np).to(dev)
@@ -122,8 +122,7 @@ def main():
         g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)
 
     def leg_lp():
-        emb = enc.encode(x_local, w1, b1, w2, b2)
-        ops.renorm_rows_(emb)
+        emb = enc.encode(x_local, w1, b1, w2, b2, renorm=True)         # renorm_ of TLCGNN.py:48 fused into the last SpMM
         ops.lp_decode(dec_pairs, emb, dec_pi, l1w, l1b, l2w, l2b, out=prob)
 
     def barrier():

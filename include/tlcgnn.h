@@ -157,7 +157,8 @@ int tlc_gemm_f32(int32_t M, int32_t N, int32_t K, const float* d_A, const float*
                  int relu, float* d_C, void* stream);
 
 /* Y[n,k] = act( CSR(rowptr,col,val) @ X[n,k] + bias[k] ): the propagate/scatter-add of GCNConv
- * (PD_conv.py:183-188; message_passing.py:275-293 aggr='add'), act = ReLU if relu!=0. */
+ * (PD_conv.py:183-188; message_passing.py:275-293 aggr='add').  relu: bit 0 = ReLU; bit 1 = afterwards renormalise
+ * every row like tlc_renorm_rows_f32 (the emb.renorm_ of TLCGNN.py:48 fused into the last layer's aggregation). */
 int tlc_spmm_csr_f32(int32_t n_rows, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
                      const float* d_X, int32_t k, const float* d_bias, int relu, float* d_Y, void* stream);
 

@@ -166,3 +166,28 @@ def test_spmm_hub_rows_and_clustered_hubs(setup):
         mag = torch.sparse_csr_tensor(torch.from_numpy(rowptr).long(), torch.from_numpy(col).long(), torch.from_numpy(np.abs(val)).double(), (n, n)) @ x.abs().double()
         err = (y.cpu().double() - ref).abs()
         assert bool((err <= ATOL + RTOL * (mag + bias.abs().double())).all()), (k, float(err.max()))
+
+
+def test_spmm_fused_renorm_equals_separate_pass(setup):
+    """relu | renorm in one SpMM pass == SpMM then tlc_renorm_rows_f32 (emb.renorm_(2, 0, 1), TLCGNN.py:48), for the lane-group
+    widths of the vector kernels, the scalar fallback (k % 4 != 0) and rows that go through the hub path."""
+    torch = setup[0]
+    from tlc_gnn_amd import ops
+    rs = np.random.RandomState(9)
+    n = 3000
+    deg = rs.randint(1, 9, size=n)
+    deg[:5] = [40, 200, 33, 3000, 64]
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = np.concatenate([np.sort(rs.choice(n, size=d, replace=False)) for d in deg]).astype(np.int32)
+    val = (rs.rand(len(col)).astype(np.float32) - 0.3)
+    rp, c, v = [torch.from_numpy(a).cuda() for a in (rowptr, col, val)]
+    for k in (16, 100, 8, 128, 7):
+        x = torch.from_numpy((0.6 / np.sqrt(k) * rs.randn(n, k)).astype(np.float32)).cuda()
+        bias = torch.from_numpy((0.1 / np.sqrt(k) * rs.randn(k)).astype(np.float32)).cuda()
+        fused = ops.spmm(rp, c, v, x, bias=bias, relu=True, renorm=True)
+        two = ops.spmm(rp, c, v, x, bias=bias, relu=True)
+        assert float(two.norm(dim=1).max()) > 1.0 and float(two.norm(dim=1).min()) < 1.0    # both branches of renorm_ occur
+        ops.renorm_rows_(two)
+        ok, worst = _close(fused, two)
+        assert ok, (k, worst)
+        assert float(fused.norm(dim=1).max()) <= 1.0 + 1e-5

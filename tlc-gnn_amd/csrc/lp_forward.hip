@@ -341,10 +341,25 @@ __global__ __launch_bounds__(256) void spmm_csr_v4_kernel(int n_rows, const int*
     if (!hub)
         for (int i = gl; i < d; i += G) { s_col[grp * SPMM_HUB + i] = col[b + i]; s_val[grp * SPMM_HUB + i] = val[b + i]; }
     __syncthreads();
-    auto finish = [&](float4 acc, int r) {
-        if (bias) { acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3]; }
-        if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-        *reinterpret_cast<float4*>(Y + (size_t)r * k + c) = acc;
+    // epilogue of one row, called by all G lanes of the row's group (lanes past k carry zeros and do not store):
+    // bias, ReLU (relu & 1) and, with relu & 2, emb.renorm_(2, 0, 1) of TLCGNN.py:48 -- rows with an L2 norm above 1 are
+    // scaled by 1 / (norm + 1e-7); the norm is a shuffle reduction over the group
+    auto finish = [&](float4 acc, int r, bool store) {
+        if (store) {
+            if (bias) { acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3]; }
+            if (relu & 1) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        }
+        if (relu & 2) {
+            float ss = store ? acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w : 0.0f;
+#pragma unroll
+            for (int o = G >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, G);
+            const float nrm = sqrtf(ss);
+            if (nrm > 1.0f) {
+                const float sc = 1.0f / (nrm + 1e-7f);
+                acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
+            }
+        }
+        if (store) *reinterpret_cast<float4*>(Y + (size_t)r * k + c) = acc;
     };
     // staged entries j0, j0+step, ... < j1, eight gathers in flight per round: a gather depends on one global round
     // trip (the X row); the tail round is predicated (entries past j1 re-read the round's first row and are zeroed)
@@ -367,7 +382,12 @@ __global__ __launch_bounds__(256) void spmm_csr_v4_kernel(int n_rows, const int*
         return acc;
     };
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < n_rows && !hub && lane_ok) finish(gather(zero4, s_col + grp * SPMM_HUB, s_val + grp * SPMM_HUB, 0, d, 1), row);
+    {
+        const bool mine = row < n_rows && !hub;             // (uniform over the group)
+        float4 acc = zero4;
+        if (mine && lane_ok) acc = gather(zero4, s_col + grp * SPMM_HUB, s_val + grp * SPMM_HUB, 0, d, 1);
+        if (mine) finish(acc, row, lane_ok);
+    }
     const int nh = n_hub;
     for (int h = 0; h < nh; ++h) {                      // hub row: group g takes entries g, g+NG, ...; fixed-order sum
         const int r = hub_rows[h];
@@ -382,11 +402,11 @@ __global__ __launch_bounds__(256) void spmm_csr_v4_kernel(int n_rows, const int*
         }
         part[grp][gl] = acc;
         __syncthreads();
-        if (grp == 0 && lane_ok) {
+        if (grp == 0) {
             float4 t = part[0][gl];
 #pragma unroll
             for (int q = 1; q < NG; ++q) { const float4 p = part[q][gl]; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }
-            finish(t, r);
+            finish(t, r, lane_ok);
         }
     }
 }
@@ -411,7 +431,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, const int* __
             }
             if (j < e) acc += val[j] * X[(size_t)col[j] * k + c];
             if (bias) acc += bias[c];
-            if (relu) acc = acc > 0.0f ? acc : 0.0f;
+            if (relu & 1) acc = acc > 0.0f ? acc : 0.0f;
             Y[(size_t)gid * k + c] = acc;
         }
     }
@@ -572,6 +592,8 @@ extern "C" int tlc_spmm_csr_f32(int32_t n_rows, const int32_t* d_rowptr, const i
     } else {
         hipLaunchKernelGGL(spmm_csr_kernel<64>, dim3((n_rows * 64 + 255) / 256), dim3(256), 0, s, n_rows, d_rowptr, d_col, d_val, d_X, k, d_bias, relu, d_Y);
     }
+    // the vectorised kernels renormalise the rows in their epilogue (relu & 2); the scalar fallback takes a second pass
+    if ((relu & 2) && !vec) hipLaunchKernelGGL(renorm_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, n_rows, k, d_Y);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }

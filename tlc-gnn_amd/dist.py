@@ -80,12 +80,16 @@ class ShardedGCNEncoder:
         self.col = col[base:end].contiguous()
         self.val = val[base:end].contiguous()
 
-    def layer(self, x_local, weight, bias, relu):
+    def layer(self, x_local, weight, bias, relu, renorm=False):
         xw_local = self.gemm(x_local, weight)                                           # rows of X @ W
         xw = all_gather_rows(xw_local, self.n, self.world, self.rank, self.group)       # exchange step
-        return self.spmm(self.rowptr, self.col, self.val, xw, bias, relu)               # aggregate own rows
+        if renorm:                                                                      # aggregate own rows (+ renorm_)
+            return self.spmm(self.rowptr, self.col, self.val, xw, bias, relu, True)
+        return self.spmm(self.rowptr, self.col, self.val, xw, bias, relu)
 
-    def encode(self, x_local, w1, b1, w2, b2):
+    def encode(self, x_local, w1, b1, w2, b2, renorm=False):
+        """renorm=True: the emb.renorm_(2, 0, 1) that Net.decode applies (TLCGNN.py:48) is fused into the last aggregation
+        (a row's norm does not depend on the other ranks' rows, so it commutes with the final all-gather)."""
         h = self.layer(x_local, w1, b1, True)
-        h = self.layer(h, w2, b2, True)
+        h = self.layer(h, w2, b2, True, renorm)
         return all_gather_rows(h, self.n, self.world, self.rank, self.group)            # every rank decodes its pair shard

@@ -51,8 +51,9 @@ def gemm(a, b, bias=None, relu=False, out=None):
     return out
 
 
-def spmm(rowptr, col, val, x, bias=None, relu=False, out=None):
-    """Y = act(CSR @ X + bias): the normalised scatter-add of GCNConv as a row-owned gather."""
+def spmm(rowptr, col, val, x, bias=None, relu=False, out=None, renorm=False):
+    """Y = act(CSR @ X + bias): the normalised scatter-add of GCNConv as a row-owned gather; renorm=True also applies
+    emb.renorm_(2, 0, 1) (TLCGNN.py:48) to every output row in the same pass."""
     torch = _lib.require_gpu()
     x = _f32(x)
     n = rowptr.numel() - 1
@@ -60,7 +61,7 @@ def spmm(rowptr, col, val, x, bias=None, relu=False, out=None):
     if out is None:
         out = torch.empty((n, k), dtype=torch.float32, device=x.device)
     rc = _lib.lib().tlc_spmm_csr_f32(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.ptr(x), C.c_int32(k),
-                                     _lib.ptr(_f32(bias)) if bias is not None else None, C.c_int(1 if relu else 0),
+                                     _lib.ptr(_f32(bias)) if bias is not None else None, C.c_int((1 if relu else 0) | (2 if renorm else 0)),
                                      _lib.ptr(out), _lib.stream_ptr())
     _lib.check(rc, "tlc_spmm_csr_f32")
     return out
