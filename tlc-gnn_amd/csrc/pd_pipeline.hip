@@ -655,18 +655,50 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
     }
     if (tid == 0) par[root] = (unsigned)root;
     __syncthreads();
-    for (int round = 0; round <= n; ++round) {
-        bool prog = false;
-        for (int k = tid; k < nneg; k += W) {
-            const unsigned eid = M.pn[MMcap - 1 - k];
-            const unsigned ab = ends[eid];
-            const int a = ab >> 16, b = ab & 0xffffu;
-            const unsigned pa = par[a], pb = par[b];
-            if (pa != NONE && pb == NONE) { par[b] = (unsigned)a; key[b] = (M.arank[eid] + 1u) << 8; prog = true; }
-            else if (pb != NONE && pa == NONE) { par[a] = (unsigned)b; key[a] = (M.arank[eid] + 1u) << 8; prog = true; }
+    if (nneg <= 4 * W) {
+        // (every LDS tier: at most four Neg edges per thread) the edges stay in registers over the rounds and retire once
+        // oriented, so a round costs the two parent reads of the edges still open, not the whole list again
+        unsigned eab[4], ekey[4];
+        bool open[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = tid + q * W;
+            open[q] = k < nneg;
+            eab[q] = 0u; ekey[q] = 0u;
+            if (open[q]) {
+                const unsigned eid = M.pn[MMcap - 1 - k];
+                eab[q] = ends[eid];
+                ekey[q] = (M.arank[eid] + 1u) << 8;
+            }
         }
-        __syncthreads();
-        if (!block_any<W>(prog, M.ctl, 5)) break;
+        for (int round = 0; round <= n; ++round) {
+            bool prog = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (open[q]) {
+                    const int a = eab[q] >> 16, b = eab[q] & 0xffffu;
+                    const unsigned pa = par[a], pb = par[b];
+                    if (pa != NONE && pb == NONE) { par[b] = (unsigned)a; key[b] = ekey[q]; prog = true; open[q] = false; }
+                    else if (pb != NONE && pa == NONE) { par[a] = (unsigned)b; key[a] = ekey[q]; prog = true; open[q] = false; }
+                }
+            }
+            __syncthreads();
+            if (!block_any<W>(prog, M.ctl, 5)) break;
+        }
+    } else {
+        for (int round = 0; round <= n; ++round) {
+            bool prog = false;
+            for (int k = tid; k < nneg; k += W) {
+                const unsigned eid = M.pn[MMcap - 1 - k];
+                const unsigned ab = ends[eid];
+                const int a = ab >> 16, b = ab & 0xffffu;
+                const unsigned pa = par[a], pb = par[b];
+                if (pa != NONE && pb == NONE) { par[b] = (unsigned)a; key[b] = (M.arank[eid] + 1u) << 8; prog = true; }
+                else if (pb != NONE && pa == NONE) { par[a] = (unsigned)b; key[a] = (M.arank[eid] + 1u) << 8; prog = true; }
+            }
+            __syncthreads();
+            if (!block_any<W>(prog, M.ctl, 5)) break;
+        }
     }
     // above the root sits the spare slot, its own parent, behind edges of key 0: a walk that passes the root keeps
     // stepping in place there, so a step needs no "at the root" case
