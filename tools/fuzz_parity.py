@@ -1,0 +1,65 @@
+"""Randomised parity sweep of tlc_pd_pi_batch against the CPU restatement (test infrastructure, like tests/): graph
+families x weight styles x hops x flags.  Statuses must agree exactly, images within 1e-8 relative."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from tlc_gnn_amd import engine, synth
+from oracle import oracle
+
+def graph(kind, n, rs):
+    if kind == "er":
+        m = int(n * rs.uniform(1.0, 6.0))
+        e = rs.randint(0, n, size=(m, 2))
+    elif kind == "ba":
+        return synth.holme_kim_edges(n, int(n * rs.uniform(1.5, 5.0)), triad_p=rs.uniform(0, 0.8), seed=int(rs.randint(1 << 30)))
+    elif kind == "grid":
+        w = int(np.sqrt(n)); idx = np.arange(w * w).reshape(w, w)
+        e = np.concatenate([np.stack([idx[:, :-1].ravel(), idx[:, 1:].ravel()], 1), np.stack([idx[:-1].ravel(), idx[1:].ravel()], 1)])
+        extra = rs.randint(0, w * w, size=(w, 2)); e = np.concatenate([e, extra])
+    elif kind == "caveman":
+        k = 12; c = n // k
+        e = [(g * k + i, g * k + j) for g in range(c) for i in range(k) for j in range(i + 1, k) if rs.rand() < 0.7]
+        e += [(g * k, ((g + 1) % c) * k + 1) for g in range(c)]
+        e = np.array(e)
+    elif kind == "star":
+        hubs = rs.randint(0, n, size=5)
+        e = np.stack([rs.choice(hubs, size=3 * n), rs.randint(0, n, size=3 * n)], 1)
+        e = np.concatenate([e, rs.randint(0, n, size=(n, 2))])
+    e = e[e[:, 0] != e[:, 1]]
+    e = np.unique(np.sort(e, 1), axis=0)
+    return e.astype(np.int64)
+
+bad = 0
+t0 = time.time()
+seeds = range(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 24)
+for seed in seeds:
+    rs = np.random.RandomState(1000 + seed)
+    kind = ["er", "ba", "grid", "caveman", "star"][seed % 5]
+    n = int(rs.choice([150, 600, 2500, 6000]))
+    e = graph(kind, n, rs)
+    n = int(e.max()) + 1
+    style = seed % 3
+    kappa = rs.uniform(-0.5, 0.9, size=len(e))
+    if style == 1: kappa = np.round(kappa, 1)                    # heavy ties
+    if style == 2: kappa = np.full(len(e), 0.0)                  # unweighted
+    rowptr, col, w = synth.edges_to_csr(n, e, kappa)
+    g = engine.DeviceGraph(rowptr, col, w)
+    for hop in (1, 2, 3):
+        if hop == 3 and n > 700: continue
+        if hop == 2 and kind == "star" and n > 3000: continue
+        pos = e[rs.permutation(len(e))[:1500]]
+        neg = rs.randint(0, n, size=(300, 2))
+        pairs = np.concatenate([pos, neg, [[0, 0], [n + 5, 1], [-1, 2]]]).astype(np.int32)
+        for flags in (0, engine.NO_EXT1 if hasattr(engine, "NO_EXT1") else 0x10):
+            got, st = g.pd_pi_batch(torch.as_tensor(pairs).cuda(), hop, flags=flags)
+            got, st = got.cpu().numpy(), st.cpu().numpy()
+            ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, hop, flags=flags, n_threads=0)
+            ok_st = np.array_equal(st, rst)
+            scale = np.abs(ref).max(axis=1, keepdims=True) + 1e-300
+            err = (np.abs(got - ref) / scale).max()
+            tiers = {k: v for k, v in g.stats().items() if k.startswith("tier")}
+            flag = "" if (ok_st and err < 1e-8) else "   <<<<<<<< MISMATCH"
+            if flag: bad += 1
+            print("seed %2d %-8s n=%5d m=%6d w=%d hop=%d flags=%#x: status %s, max rel err %.1e, %s%s" % (seed, kind, n, len(e), style, hop, flags, "ok" if ok_st else "DIFF", err, tiers, flag), flush=True)
+print("done in %.0f s, mismatches: %d" % (time.time() - t0, bad))
+sys.exit(1 if bad else 0)
