@@ -1,4 +1,4 @@
-"""Randomised parity sweep of tlc_pd_pi_batch against the CPU restatement (test infrastructure, like tests/): graph
+"""Randomised parity sweep of tlc_pd_pi_batch against the CPU restatement (test infrastructure; run from the repo root): graph
 families x weight styles x hops x flags.  Statuses must agree exactly, images within 1e-8 relative."""
 import sys, time
 import numpy as np, torch
