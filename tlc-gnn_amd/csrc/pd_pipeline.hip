@@ -1394,10 +1394,12 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
         }
         case TLC_TIER_LARGE: {
             constexpr Layout L = make_layout(TLC_L_NMAX, TLC_L_MMAX, false, 2);
-            int rc = set_lds_limit(tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, 512, false, false>, L.total);
+            // the whole CU: no SMALL workgroup beside the wavefront that carries the batch's longest serial chain
+            constexpr size_t lds_bytes = L.total > 156 * 1024 ? L.total : 156 * 1024;
+            int rc = set_lds_limit(tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, 512, false, false>, lds_bytes);
             if (rc) return rc;
             hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, 512, false, false>), dim3(p.tier_count),
-                               dim3(512), L.total, s, p);
+                               dim3(512), lds_bytes, s, p);
             break;
         }
         case TLC_TIER_HUGE: {
