@@ -237,30 +237,10 @@ __device__ __forceinline__ void bellman_ford(ull* d0, ull* d1, const unsigned* d
 // ---- bitonic sort of (key u64, payload u32), ascending by key, P a power of two ------------------------------------
 // One compare-exchange of the bitonic network between lanes l and l^J of a wavefront (element i = base + lane against
 // i^J).  Same rule as the LDS pass below: the pair is swapped iff (key_lo > key_hi) == up, equal keys stay put.
-// value of lane (l ^ J) for J = 1 .. 32, on the vector ALU: DPP quad permutes / row shifts / row rotate for 1, 2, 4, 8 and
-// the gfx950 permlane swaps for 16 and 32.  __shfl_xor compiles to ds_bpermute, which goes through the LDS crossbar: with
-// eight wavefronts sorting at once that pipe, not latency, was what the register stages of the sort ran at.
-template <int J>
-__device__ __forceinline__ unsigned lane_xor_u32(unsigned v) {
-    if (J == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);          // quad_perm [1,0,3,2]
-    if (J == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);          // quad_perm [2,3,0,1]
-    if (J == 4) {
-        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);                     // row_shl:4 -> banks 0, 2
-        return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);                 // row_shr:4 -> banks 1, 3
-    }
-    if (J == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);          // row_ror:8
-    if (J == 16) {
-        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-        return (tlc_lane() & 16) ? r[0] : r[1];
-    }
-    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return (tlc_lane() & 32) ? r[0] : r[1];
-}
-
 template <int J>
 __device__ __forceinline__ void bitonic_lane_step(ull& kk, unsigned& vv, bool up) {
-    const ull ok = ((ull)lane_xor_u32<J>((unsigned)(kk >> 32)) << 32) | (ull)lane_xor_u32<J>((unsigned)kk);
-    const unsigned ov = lane_xor_u32<J>(vv);
+    const ull ok = ((ull)tlc_lane_xor_u32<J>((unsigned)(kk >> 32)) << 32) | (ull)tlc_lane_xor_u32<J>((unsigned)kk);
+    const unsigned ov = tlc_lane_xor_u32<J>(vv);
     const bool lo = (tlc_lane() & J) == 0;
     const ull klo = lo ? kk : ok, khi = lo ? ok : kk;
     if (((klo > khi) == up) && (klo != khi)) { kk = ok; vv = ov; }

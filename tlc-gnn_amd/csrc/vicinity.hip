@@ -59,12 +59,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
     const int m2v = i < p.n_pairs ? p.hdr_m2[i] : 0;
     const long long own = i < p.n_pairs ? arena_entries(n, m2v, p.small_arena) : 0;
     // inclusive scan inside the wavefront, then over the 16 wavefront totals
-    long long incl = own;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const long long v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
+    // (sizes are < 2^25 per pair, so a wavefront's running sum fits 32 bits)
+    long long incl = (long long)(unsigned)tlc_wave_iscan_i32((int)own);
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
     long long wbase = 0, btotal = 0;
@@ -112,7 +108,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
         int base = 0;
         const int leader = __builtin_ctzll(mk);
         if (lane == leader) base = atomicAdd(&p.tier_count[tt], __popcll(mk));
-        base = __shfl(base, leader, 64);
+        base = __builtin_amdgcn_readlane(base, leader);
         if (tier == tt) p.tier_list[(size_t)tt * p.n_pairs + base + __popcll(mk & tlc_lanemask_lt())] = i;
     }
     // the last block to get here publishes the sizes

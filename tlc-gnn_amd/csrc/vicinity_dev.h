@@ -12,7 +12,7 @@ template <int BW>
 __device__ __forceinline__ int block_escan_i32(int v, int* xw, int* total) {
     const int inc = tlc_wave_iscan_i32(v);
     if (BW == 64) {
-        *total = __shfl(inc, 63, 64);
+        *total = __builtin_amdgcn_readlane(inc, 63);
         return inc - v;
     }
     const int wv = threadIdx.x >> 6;
@@ -89,7 +89,7 @@ __device__ __forceinline__ void expand_rows(const int* __restrict__ list, int co
         while (mask) {
             const int L = __builtin_ctzll(mask);
             mask &= mask - 1;
-            const int bb = __shfl(beg, L, 64), ee = __shfl(end, L, 64);
+            const int bb = __builtin_amdgcn_readlane(beg, L), ee = __builtin_amdgcn_readlane(end, L);
             for (int j = bb + lane; j < ee; j += TLC_WAVE) {
                 const int b = col[j];
                 const unsigned bit = 1u << (b & 31);
@@ -166,7 +166,7 @@ __device__ __forceinline__ int induced_batch(int k, int kbase, int beg, int end,
     while (mask) {
         const int L = __builtin_ctzll(mask);
         mask &= mask - 1;
-        const int bb = __shfl(beg, L, 64), ee = __shfl(end, L, 64), tt = __shfl(t, L, 64);
+        const int bb = __builtin_amdgcn_readlane(beg, L), ee = __builtin_amdgcn_readlane(end, L), tt = __builtin_amdgcn_readlane(t, L);
         const int kk = kbase + L;
         int run = 0;
         for (int j0 = bb; j0 < ee; j0 += TLC_WAVE) {
@@ -257,7 +257,7 @@ __device__ __forceinline__ void mark_two_balls_hop2(unsigned* bitsU, unsigned* b
         while (mask) {
             const int L = __builtin_ctzll(mask);
             mask &= mask - 1;
-            const int bb = __shfl(beg, L, 64), ee = __shfl(end, L, 64);
+            const int bb = __builtin_amdgcn_readlane(beg, L), ee = __builtin_amdgcn_readlane(end, L);
             unsigned* wb = ((base + L) < du) ? bitsU : bitsV;
             for (int j = bb + lane; j < ee; j += TLC_WAVE) {
                 const int b = p.col[j];
