@@ -100,13 +100,13 @@ int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int64_t n_pair
 
 /* Counters of the last tlc_pd_pi_batch on this handle (synchronises the stream):
  * h_out[0..3] = pairs in tier small / medium / large / huge, [4] = induced directed entries (arena size),
- * [5] = sources that needed the exact tie fallback, [6] = chunks, [7] reserved. */
+ * [5] = sources that needed the exact tie fallback, [6] = chunks, [7] = pairs in tier mid (between small and medium). */
 int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream);
 
 /* Measurement helpers used by bench.py (no reference counterpart: the reference only prints time.time() deltas,
  * riccidist2dgm.py:349-350).  set_timing(1) makes every later tlc_pd_pi_batch bracket each of its kernels with HIP
  * events on the stream that kernel runs on; timings() returns the last chunk's durations in ms:
- * h_ms[0..6] = COUNT, scan+binning, FILL, PD tier SMALL, MEDIUM, LARGE, HUGE (-1 = not launched).  Synchronises.
+ * h_ms[0..7] = COUNT, scan+binning, FILL, PD tier SMALL, MEDIUM, LARGE, HUGE, MID (-1 = not launched).  Synchronises.
  * sizes(): per pair of the last chunk, |S| and the induced directed entry count.
  * algorithmic_bytes(): SURVEY.md 8(d) per-pair byte model, evaluated on the HOST CSR (pure accounting). */
 int tlc_pd_pi_batch_set_timing(tlc_graph* g, int enable);

@@ -102,12 +102,14 @@ def test_algorithmic_bytes_model_matches_oracle_accounting():
 def test_tier_classification_mirrors_kernel_constants():
     from tlc_gnn_amd import engine
     hdr = open(os.path.join(ROOT, "tlc-gnn_amd", "csrc", "tlc_kernels.h")).read()
-    vals = {k: int(v) for k, v in re.findall(r"#define (TLC_[SML]_[NM]MAX) (\d+)", hdr)}
+    vals = {k: int(v) for k, v in re.findall(r"#define (TLC_[SDML]_[NM]MAX) (\d+)", hdr)}
     assert engine.TIER_LIMITS == [("pd_tier_small", vals["TLC_S_NMAX"], vals["TLC_S_MMAX"]),
+                                  ("pd_tier_mid", vals["TLC_D_NMAX"], vals["TLC_D_MMAX"]),
                                   ("pd_tier_medium", vals["TLC_M_NMAX"], vals["TLC_M_MMAX"]),
                                   ("pd_tier_large", vals["TLC_L_NMAX"], vals["TLC_L_MMAX"])]
-    t = engine.tier_of(np.array([0, 10, 64, 65, 512, 513, 3000]), np.array([0, 20, 256, 10, 2048, 10, 10]))
-    assert t.tolist() == ["", "pd_tier_small", "pd_tier_small", "pd_tier_medium", "pd_tier_medium", "pd_tier_large", "pd_tier_huge"]
+    t = engine.tier_of(np.array([0, 10, 64, 65, 128, 129, 512, 513, 3000]), np.array([0, 20, 256, 10, 512, 10, 2048, 10, 10]))
+    assert t.tolist() == ["", "pd_tier_small", "pd_tier_small", "pd_tier_mid", "pd_tier_mid", "pd_tier_medium", "pd_tier_medium",
+                          "pd_tier_large", "pd_tier_huge"]
 
 
 def test_shard_helpers():

@@ -144,7 +144,7 @@ def test_full_pubmed_batch_vs_oracle(torch_cuda):
     nz = ref != 0
     assert rel_err(out[nz], ref[nz]).max() < 1e-8
     stats = g.stats()
-    assert stats["tier_small"] + stats["tier_medium"] + stats["tier_large"] + stats["tier_huge"] == len(pairs)
+    assert stats["tier_small"] + stats["tier_mid"] + stats["tier_medium"] + stats["tier_large"] + stats["tier_huge"] == len(pairs)
     g.close()
 
 

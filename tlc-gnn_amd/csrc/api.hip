@@ -32,7 +32,7 @@ extern "C" int tlc_device_count(void) {
 }
 
 #define TLC_CHUNK_PAIRS (1 << 20)
-#define TLC_N_SIDE 3
+#define TLC_N_SIDE 4
 
 struct HostSync {
     long long total_entries;
@@ -207,7 +207,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     for (int k = 0; k < TLC_N_SIDE; ++k) {
         // side[1] carries the heavy tiers (the critical path): highest priority; side[2] (MEDIUM, the second longest
         // chain) sits between it and side[0] (SMALL, which only has to finish before the other two do)
-        const int prio = k == 1 ? prio_hi : (k == 2 ? (prio_lo + prio_hi) / 2 : prio_lo);
+        const int prio = k == 1 ? prio_hi : (k >= 2 ? (prio_lo + prio_hi) / 2 : prio_lo);
         CK(hipStreamCreateWithPriority(&g->side[k], hipStreamNonBlocking, prio));
         CK(hipEventCreateWithFlags(&g->ev_join[k], hipEventDisableTiming));
     }
@@ -331,7 +331,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     if ((rc = ensure_arena(g, (size_t)total)) != TLC_OK) return rc;
     if (tc[TLC_TIER_HUGE] > 0 && (rc = ensure_huge(g)) != TLC_OK) return rc;
 
-    const int todo = tc[0] + tc[1] + tc[2] + tc[3];
+    const int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4];
     if (todo > 0) {
         vp.A_dir = g->A_dir; vp.A_lw = g->A_lw;
         TlcPdParams pp;
@@ -346,16 +346,17 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         pp.huge_nmax = std::min(g->n_nodes, TLC_MAX_SUBGRAPH_NODES); pp.huge_mmax = (int)std::min<long long>(g->nnz / 2 + 1, TLC_MAX_SUBGRAPH_EDGES); pp.huge_slots = g->huge_slots;
         pp.stats = g->d_stats;
         pp.started = (int*)(g->d_stats + 2);
-        bool used[TLC_N_SIDE] = {false, false, false};
+        bool used[TLC_N_SIDE] = {false, false, false, false};
+        static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7};   // timing slot of each tier kernel
         auto launch_side = [&](int k, int t) -> int {
             TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s));
             TLC_HIP_CHECK(hipStreamWaitEvent(g->side[k], g->ev_fork, 0));
             pp.tier_list = g->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
-            T0(3 + t, g->side[k]);
+            T0(tslot[t], g->side[k]);
             int r = tlc_launch_pd_tier(t, pp, g->side[k]);
             if (r != TLC_OK) return r;
-            T1(3 + t, g->side[k]);
+            T1(tslot[t], g->side[k]);
             TLC_HIP_CHECK(hipEventRecord(g->ev_join[k], g->side[k]));
             used[k] = true;
             return TLC_OK;
@@ -388,12 +389,13 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         //    heavy chain so that its many workgroups do not delay that chain's start
         if (tc[TLC_TIER_SMALL] > 0 && (rc = launch_side(0, TLC_TIER_SMALL)) != TLC_OK) return rc;
         // 2. the MEDIUM tier
-        if (tc[TLC_TIER_MEDIUM] > 0) {
+        if (tc[TLC_TIER_MEDIUM] + tc[TLC_TIER_MID] > 0) {
             vp.fill_mode = heavy > 0 ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
             hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
             TLC_HIP_CHECK(hipGetLastError());
             T1(2, s);
-            if ((rc = launch_side(2, TLC_TIER_MEDIUM)) != TLC_OK) return rc;
+            if (tc[TLC_TIER_MEDIUM] > 0 && (rc = launch_side(2, TLC_TIER_MEDIUM)) != TLC_OK) return rc;
+            if (tc[TLC_TIER_MID] > 0 && (rc = launch_side(3, TLC_TIER_MID)) != TLC_OK) return rc;
         } else {
             T1(2, s);
         }
@@ -402,7 +404,8 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     }
 #undef T0
 #undef T1
-    for (int t = 0; t < TLC_N_TIERS; ++t) g->last_stats[t] += tc[t];
+    for (int t = 0; t <= TLC_TIER_HUGE; ++t) g->last_stats[t] += tc[t];
+    g->last_stats[7] += tc[TLC_TIER_MID];
     g->last_stats[4] += total;
     g->last_stats[6] += 1;
     return TLC_OK;
@@ -480,7 +483,7 @@ extern "C" int tlc_pd_from_filtration(int32_t n_graphs, const int64_t* d_node_of
     int* d_tier = nullptr;   // [4 counts | 4*n lists]
     TLC_HIP_CHECK(hipMalloc(&d_tier, ((size_t)TLC_N_TIERS * n_graphs + 8) * sizeof(int)));
     int rc = TLC_OK;
-    int tc[TLC_N_TIERS] = {0, 0, 0, 0};
+    int tc[TLC_N_TIERS] = {0, 0, 0, 0, 0};
     long long tail[2] = {0, 0};
     unsigned char* huge = nullptr;
     do {
@@ -528,13 +531,13 @@ extern "C" int tlc_pi_raster(int32_t n_dgms, const int64_t* d_offs, const double
 }
 
 // ---- diagnostics (not part of include/tlcgnn.h): per-phase cycle counters of the PD tier kernels -------------------
-extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out /* [4][32] or null */) {
+extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out /* [TLC_N_TIERS][32] or null */) {
     TLC_REQUIRE(g != nullptr, "null graph");
     TLC_HIP_CHECK(hipSetDevice(g->device));
     TLC_HIP_CHECK(hipDeviceSynchronize());
-    if (h_out && g->d_phase) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_phase, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (enable && !g->d_phase) TLC_HIP_CHECK(hipMalloc(&g->d_phase, 128 * sizeof(unsigned long long)));
-    if (g->d_phase) TLC_HIP_CHECK(hipMemset(g->d_phase, 0, 128 * sizeof(unsigned long long)));
+    if (h_out && g->d_phase) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_phase, (size_t)TLC_N_TIERS * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (enable && !g->d_phase) TLC_HIP_CHECK(hipMalloc(&g->d_phase, (size_t)TLC_N_TIERS * 32 * sizeof(unsigned long long)));
+    if (g->d_phase) TLC_HIP_CHECK(hipMemset(g->d_phase, 0, (size_t)TLC_N_TIERS * 32 * sizeof(unsigned long long)));
     if (!enable && g->d_phase) { hipFree(g->d_phase); g->d_phase = nullptr; }
     return TLC_OK;
 }
@@ -546,13 +549,13 @@ extern "C" int tlc_pd_pi_batch_set_timing(tlc_graph* g, int enable) {
     return TLC_OK;
 }
 
-// h_ms[0..6] = COUNT, scan+binning, FILL, tier SMALL, MEDIUM, LARGE, HUGE kernel durations (ms, -1 = not launched) of the
+// h_ms[0..7] = COUNT, scan+binning, FILL, tier SMALL, MEDIUM, LARGE, HUGE, MEDIUM's 128-thread sub-tier: kernel durations (ms, -1 = not launched) of the
 // LAST chunk of the last tlc_pd_pi_batch, from HIP events recorded on the stream each kernel ran on.  Synchronises.
 extern "C" int tlc_pd_pi_batch_timings(tlc_graph* g, double* h_ms, void* stream) {
     TLC_REQUIRE(g && h_ms, "null argument");
     TLC_HIP_CHECK(hipSetDevice(g->device));
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < 8; ++k) {
         h_ms[k] = -1.0;
         if (g->timing && g->ev_used[k]) {
             TLC_HIP_CHECK(hipEventSynchronize(g->ev_t[2 * k + 1]));

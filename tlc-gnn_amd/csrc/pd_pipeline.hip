@@ -991,7 +991,7 @@ template <int NM, int MM, int W, bool LWL, bool HUGE>
 __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {       // (the counters need the registers)
 #else
 // 128 VGPRs for the SMALL and MEDIUM tiers: four wavefronts per SIMD (16 resp. 4 workgroups per CU)
-__global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W == 64 ? 4 : 1))) void tlc_pd_tier_kernel(TlcPdParams p) {
+__global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) void tlc_pd_tier_kernel(TlcPdParams p) {
 #endif
     typedef unsigned short idx_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1390,6 +1390,12 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             constexpr Layout L = make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2);
             hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, false, false>), dim3(p.tier_count),
                                dim3(256), L.total, s, p);
+            break;
+        }
+        case TLC_TIER_MID: {
+            constexpr Layout L = make_layout(TLC_D_NMAX, TLC_D_MMAX, false, 2);
+            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_D_NMAX, TLC_D_MMAX, TLC_D_THREADS, false, false>), dim3(p.tier_count),
+                               dim3(TLC_D_THREADS), L.total, s, p);
             break;
         }
         case TLC_TIER_LARGE: {

@@ -16,13 +16,17 @@
 #define TLC_TIER_MEDIUM 1
 #define TLC_TIER_LARGE 2
 #define TLC_TIER_HUGE 3
+#define TLC_TIER_MID 4      /* the lower end of MEDIUM (reported with it): 128 threads, ~10 KB of LDS, 8 workgroups per CU */
 // hard limits of one subgraph: local node ids are packed in 16 bits, edge ranks + 1 in 24
 #define TLC_MAX_SUBGRAPH_NODES 65535
 #define TLC_MAX_SUBGRAPH_EDGES ((1 << 24) - 2)
-#define TLC_N_TIERS 4
+#define TLC_N_TIERS 5
 
 #define TLC_S_NMAX 64
 #define TLC_S_MMAX 128
+#define TLC_D_NMAX 128
+#define TLC_D_MMAX 256
+#define TLC_D_THREADS 128
 #define TLC_M_NMAX 512
 #define TLC_M_MMAX 1024
 #define TLC_L_NMAX 2048

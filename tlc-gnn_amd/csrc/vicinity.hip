@@ -96,6 +96,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
             const int m = m2v >> 1;
             tier = TLC_TIER_HUGE;
             if (n <= TLC_S_NMAX && m <= TLC_S_MMAX) tier = TLC_TIER_SMALL;
+            else if (n <= TLC_D_NMAX && m <= TLC_D_MMAX) tier = TLC_TIER_MID;
             else if (n <= TLC_M_NMAX && m <= TLC_M_MMAX) tier = TLC_TIER_MEDIUM;
             else if (n <= TLC_L_NMAX && m <= TLC_L_MMAX) tier = TLC_TIER_LARGE;
         }

@@ -66,10 +66,12 @@ class DeviceGraph:
         _lib.check(rc, "tlc_pd_pi_batch_stats")
         v = list(out)
         return {"tier_small": v[0], "tier_medium": v[1], "tier_large": v[2], "tier_huge": v[3],
+                "tier_mid": v[7],
                 "induced_entries": v[4], "tie_fallback_sources": v[5], "chunks": v[6]}
 
     # ---- measurement helpers (bench.py) -----------------------------------------------------------------------
-    KERNELS = ["vicinity_count", "scan_bin", "vicinity_fill", "pd_tier_small", "pd_tier_medium", "pd_tier_large", "pd_tier_huge"]
+    KERNELS = ["vicinity_count", "scan_bin", "vicinity_fill", "pd_tier_small", "pd_tier_medium", "pd_tier_large", "pd_tier_huge",
+               "pd_tier_mid"]
 
     def set_timing(self, on=True):
         _lib.check(_lib.lib().tlc_pd_pi_batch_set_timing(self._h, C.c_int(1 if on else 0)), "set_timing")
@@ -78,7 +80,7 @@ class DeviceGraph:
         """ms per kernel of the last batch (HIP events on the stream each kernel ran on); -1 = not launched."""
         out = (C.c_double * 8)()
         _lib.check(_lib.lib().tlc_pd_pi_batch_timings(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr()), "timings")
-        return dict(zip(self.KERNELS, list(out)[:7]))
+        return dict(zip(self.KERNELS, list(out)[:8]))
 
     def sizes(self, n_pairs):
         n = np.zeros(n_pairs, dtype=np.int32)
@@ -155,7 +157,7 @@ def pi_raster(offs, pts, res=5):
 
 
 # size tiers of the PD kernel (csrc/tlc_kernels.h)
-TIER_LIMITS = [("pd_tier_small", 64, 128), ("pd_tier_medium", 512, 1024), ("pd_tier_large", 2048, 4096)]
+TIER_LIMITS = [("pd_tier_small", 64, 128), ("pd_tier_mid", 128, 256), ("pd_tier_medium", 512, 1024), ("pd_tier_large", 2048, 4096)]
 
 
 def tier_of(n, m2):

@@ -16,10 +16,10 @@ L.tlc_debug_phase_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 g.pd_pi_batch(pairs, 2)
 L.tlc_debug_phase_profile(g._h, 1, None)
 g.pd_pi_batch(pairs, 2)
-buf = (C.c_uint64 * 128)()
+buf = (C.c_uint64 * 160)()
 L.tlc_debug_phase_profile(g._h, 0, C.cast(buf, C.c_void_p))
-a = np.array(list(buf), dtype=np.float64).reshape(4, 32)
-for t, tn in enumerate(["small", "medium", "large", "huge"]):
+a = np.array(list(buf), dtype=np.float64).reshape(5, 32)
+for t, tn in enumerate(["small", "medium", "large", "huge", "mid"]):
     if a[t, 14] == 0:
         continue
     print("tier %s: %d workgroups, mean %.0f cycles, max %.0f cycles" % (tn, a[t, 14], a[t, 12] / a[t, 14], a[t, 13]))

@@ -12,7 +12,7 @@ g.pd_pi_batch(pd, wl["hop"])
 nn, m2 = g.sizes(len(pairs))
 tiers = engine.tier_of(nn, m2)
 g.set_timing(True)
-for name in ("pd_tier_large", "pd_tier_medium"):
+for name in ("pd_tier_large", "pd_tier_medium", "pd_tier_small"):
     sel = torch.as_tensor(pairs[tiers == name]).cuda()
     for _ in range(3):
         g.pd_pi_batch(sel, wl["hop"])
