@@ -613,7 +613,7 @@ __device__ __forceinline__ void split_pos_neg(Mem<idx_t>& M, int m, int MMcap) {
     __syncthreads();
 }
 
-// Accelerate_PD (accelerated_PD.py:115-178).  Requires ctl[4] (#Neg) >= 1.
+// Accelerate_PD (accelerated_PD.py:115-178).
 //
 // Tree state per node (u32 arrays carved from the dead sort / union-find regions): par[x], key[x] = (ascending rank + 1)
 // << 8 of the edge (x, par x), mark[x] = stamp of the last walk through x, pmP[x] / pmQ[x] = (running maximum rank+1, child endpoint
@@ -624,22 +624,34 @@ __device__ __forceinline__ void split_pos_neg(Mem<idx_t>& M, int m, int MMcap) {
 // the other walk's stamp exactly once, at the lowest common ancestor (two lanes hitting the same word in one instruction
 // are serialised by the LDS, so simultaneous arrival is detected too).  One LDS round trip per step, no second pass over
 // the loop, cost per Pos edge ~ cycle length instead of the two root paths of :131-148.  The path eversion that swaps the
-// edges (:168-176) runs on lane 0.
-template <int W, typename idx_t, class Sink>
-__device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, unsigned flags, int MMcap, int NMcap, ull* pc,
-                                           ull& t_prev, ull* ph) {
+// edges (:168-176) re-parents the whole path in one parallel step.
+
+// the cycle swap's per-node tables: NMcap + 1 slots each (slot NMcap is a spare node: the target of an idle walker's traffic)
+struct SwapTables {
+    unsigned *par, *key, *mark;
+    ull *pmP, *pmQ;
+};
+__host__ __device__ constexpr size_t swap_table_bytes(int NMcap) { return (size_t)(NMcap + 1) * 28 + 16; }
+__device__ __forceinline__ SwapTables carve_swap(void* base, int NMcap) {
+    const int NS = NMcap + 1;
+    SwapTables T;
+    T.par = (unsigned*)base;
+    T.key = T.par + NS;
+    T.mark = T.key + NS;
+    T.pmP = (ull*)(T.mark + NS + (NS & 1));
+    T.pmQ = T.pmP + NS;
+    return T;
+}
+
+// Orient the spanning tree of the Neg edges (:119-125) into T.par / T.key and clear the stamps; all W threads.  Returns whether
+// some node was not reached (disconnected input: only then does a query have to test its endpoints).
+template <int W, typename idx_t>
+__device__ __forceinline__ bool ext1_build_tree(Mem<idx_t>& M, const SwapTables& T, int n, int MMcap, int NMcap) {
     const int tid = threadIdx.x;
-    const bool keep0 = (flags & TLC_KEEP_ZERO_PERS) != 0;
     const unsigned NONE = 0xffffffffu;
-    const int npos = M.ctl[3], nneg = M.ctl[4];
+    const int nneg = M.ctl[4];
     const unsigned* ends = M.dir;
-    double* f = M.f;
-    const int NS = NMcap + 1;                  // slot NMcap is a spare node: the target of an idle walker's LDS traffic
-    unsigned* par = (unsigned*)M.keyS;
-    unsigned* key = par + NS;
-    unsigned* mark = key + NS;
-    ull* pmP = (ull*)(mark + NS + (NS & 1));
-    ull* pmQ = pmP + NS;
+    unsigned *par = T.par, *key = T.key, *mark = T.mark;
     // spanning tree of the Neg edges (:119-125).  Any root gives the same diagram; rank 0 (a root of the vicinity) keeps
     // the tree shallow.  If rank 0 is not incident to a Neg edge (disconnected input) fall back to the reference's choice.
     // (the Neg list in M.pn and the edge tables in M.dir are outside the regions re-used here)
@@ -708,30 +720,83 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
     const bool any_unreached = block_any<W>(unreached, M.ctl, 5);
     if (tid == 0) { par[root] = (unsigned)NMcap; key[root] = 0u; par[NMcap] = (unsigned)NMcap; key[NMcap] = 0u; mark[NMcap] = 0u; }
     __syncthreads();
-    TLC_STAMP(9);
-    if (tid < 64) {                                                 // first wavefront; lanes 0 and 1 walk
+    return any_unreached;
+}
+
+// The queries of the cycle swap -- (endpoints p<<16|q in rank space, (ascending rank + 1) << 8) of the Pos edges in
+// descending-pass order -- do not depend on the tree, so they are fetched ahead of their use: no load of this chain is ever
+// waited for inside a query.  QueryLds: from the Pos list / edge tables in LDS (edge id two queries ahead, endpoints and rank
+// one ahead).
+struct QueryLds {
+    const unsigned *pn, *ends, *arank;
+    int npos;
+    unsigned eid1, n_pq, n_ar;
+    __device__ __forceinline__ void init(int) {
+        eid1 = npos > 0 ? pn[npos > 1 ? 1 : 0] : 0u;
+        n_pq = 0u; n_ar = 0u;
+        if (npos > 0) { const unsigned e0 = pn[0]; n_pq = ends[e0]; n_ar = (arank[e0] + 1u) << 8; }
+    }
+    // (unconditional: past the end it re-reads the last query's operands, which nobody uses)
+    __device__ __forceinline__ void advance(int pi, int) {
+        n_pq = ends[eid1];
+        n_ar = (arank[eid1] + 1u) << 8;
+        eid1 = pn[pi + 2 < npos ? pi + 2 : npos - 1];
+    }
+};
+// QueryGlobal: from the packed list (rank word << 32 | endpoints) a tier kernel left in HBM: lane l of the wavefront holds
+// query 64 b + l of the current block b and of the next one, a query is a v_readlane away, and a block is loaded (one
+// coalesced 512-byte read) 64 queries before its first use.
+struct QueryGlobal {
+    const ull* q;
+    int npos;
+    unsigned cur_lo, cur_hi, nxt_lo, nxt_hi, n_pq, n_ar;
+    __device__ __forceinline__ ull load(int idx) const { return q[idx < npos ? idx : (npos > 0 ? npos - 1 : 0)]; }
+    __device__ __forceinline__ void init(int lane) {
+        const ull c = load(lane), x = load(64 + lane);
+        cur_lo = (unsigned)c; cur_hi = (unsigned)(c >> 32);
+        nxt_lo = (unsigned)x; nxt_hi = (unsigned)(x >> 32);
+        n_pq = (unsigned)__builtin_amdgcn_readlane((int)cur_lo, 0);
+        n_ar = (unsigned)__builtin_amdgcn_readlane((int)cur_hi, 0);
+    }
+    __device__ __forceinline__ void advance(int pi, int lane) {
+        const int idx = pi + 1;
+        if ((idx & 63) == 0) {
+            cur_lo = nxt_lo; cur_hi = nxt_hi;
+            const ull x = load(idx + 64 + lane);
+            nxt_lo = (unsigned)x; nxt_hi = (unsigned)(x >> 32);
+        }
+        n_pq = (unsigned)__builtin_amdgcn_readlane((int)cur_lo, idx & 63);
+        n_ar = (unsigned)__builtin_amdgcn_readlane((int)cur_hi, idx & 63);
+    }
+};
+
+// The serial part of Accelerate_PD: one wavefront (all 64 lanes call; lanes 0 and 1 walk).  `recs` = 2 x 65 path records.
+// Points go to sink.one_at(f, out0 + k, k, ...); returns the number of points emitted.
+template <class Sink, class Query>
+__device__ __forceinline__ int ext1_walk(const SwapTables& T, ull* recs, Query& qs, int npos, int NMcap, bool any_unreached,
+                                         Sink& sink, const double* f, bool keep0, int out0, ull* pc) {
+    const unsigned NONE = 0xffffffffu;
+    unsigned *par = T.par, *key = T.key, *mark = T.mark;
+    ull *pmP = T.pmP, *pmQ = T.pmQ;
+    int n_out = 0;                         // points emitted by this stage (wave-uniform)
+    {
         // this wave carries the critical serial chain of the batch: let it win issue arbitration against the other
         // kernels' waves that share the SIMD
         __builtin_amdgcn_s_setprio(3);
-        const int lane = tid;
+        const int lane = tlc_lane();
         const bool qside = (lane & 1) != 0;
         ull* pmMine = qside ? pmQ : pmP;
         const ull* pmTheirs = qside ? pmP : pmQ;
         // path records: (key << 32 | node) of the edge crossed at step s of either walk (slot 64 = spare); a swap then
         // re-parents its whole path in one parallel step instead of one dependent LDS round trip per node
-        ull* rec = (ull*)M.rec + (qside ? 65 : 0);
+        ull* rec = recs + (qside ? 65 : 0);
         unsigned stamp = 0;
-        // the per-query operands do not depend on the tree: the edge id is fetched two queries ahead and its endpoints
-        // and rank one query ahead, so that no load of this chain is ever waited for inside a query
-        unsigned eid1 = npos > 0 ? M.pn[npos > 1 ? 1 : 0] : 0u;     // edge id of query pi+1
-        unsigned n_pq = 0u, n_ar = 0u;                             // endpoints / ascending rank of query pi
-        if (npos > 0) { const unsigned e0 = M.pn[0]; n_pq = ends[e0]; n_ar = (M.arank[e0] + 1u) << 8; }
-        // ... and so are the walkers' first nodes, read under the previous query's swap (patched if it touched them)
+        qs.init(lane);
+        unsigned n_pq = qs.n_pq, n_ar = qs.n_ar;                   // endpoints / ascending rank of query pi
+        // ... and so are the walkers' first nodes, read under the previous query's swap
         const unsigned side_shift = qside ? 0u : 16u;           // a walker's first node: p in the high, q in the low half
         int n_cur = (int)((n_pq >> side_shift) & 0xffffu);
         unsigned n_pcur = par[n_cur], n_kcur = key[n_cur];
-        int n_out = 0;                         // points emitted by this stage (wave-uniform)
-        const int out0 = M.ctl[2];
 #ifdef TLC_PHASE_DEBUG
         ull dbg_a = 0, dbg_b = 0, dbg_c = 0, dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0;
 #define DBG_T(v) v = clock64()
@@ -743,10 +808,9 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
             const unsigned pq = n_pq, ar = n_ar;
             int cur = n_cur;
             unsigned pcur = n_pcur, kcur = n_kcur;
-            // (unconditional: past the end they re-read the last query's operands, which nobody uses)
-            n_pq = ends[eid1];
-            n_ar = (M.arank[eid1] + 1u) << 8;
-            eid1 = M.pn[pi + 2 < npos ? pi + 2 : npos - 1];
+            qs.advance(pi, lane);
+            n_pq = qs.n_pq;
+            n_ar = qs.n_ar;
             const int p = pq >> 16, q = pq & 0xffffu;              // f[p] <= f[q]: low_value = f[p] (:162)
             // winner's record: hi = (max rank + 1) << 8 | step of that edge, lo = child << 16 | parent (ranks are unique,
             // so comparing hi words compares ranks)
@@ -815,7 +879,7 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
             // evert the path so that (p,q) replaces the removed tree edge (:168-176): node x_i of the winner's walk gets
             // x_{i-1} as parent (x_{-1} = the other endpoint) and inherits the key of the edge below it
             if (bstep < 64u) {
-                const ull* rr = (const ull*)M.rec + (res_s ? 65 : 0);
+                const ull* rr = recs + (res_s ? 65 : 0);
                 const bool mine_i = (unsigned)lane <= bstep;
                 const int li = mine_i ? lane : 0;
                 const ull r1 = rr[li], r0 = rr[li > 0 ? li - 1 : 0];
@@ -847,8 +911,24 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
 #ifdef TLC_PHASE_DEBUG
         if (pc && lane == 0) { atomicAdd(&pc[15], dbg_a); atomicAdd(&pc[30], dbg_b); atomicAdd(&pc[31], dbg_c); }
 #endif
-        if (lane == 0) { M.ctl[2] = out0 + n_out; M.ctl[8] = n_out; }
         __builtin_amdgcn_s_setprio(0);
+    }
+    return n_out;
+}
+
+// Accelerate_PD (accelerated_PD.py:115-178) on a subgraph whose Pos / Neg lists sit in M.pn.  Requires ctl[4] (#Neg) >= 1.
+template <int W, typename idx_t, class Sink>
+__device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, unsigned flags, int MMcap, int NMcap, ull* pc,
+                                           ull& t_prev, ull* ph) {
+    const SwapTables T = carve_swap(M.keyS, NMcap);
+    const bool any_unreached = ext1_build_tree<W>(M, T, n, MMcap, NMcap);
+    TLC_STAMP(9);
+    if (threadIdx.x < 64) {                                          // first wavefront
+        QueryLds qs{M.pn, M.dir, M.arank, M.ctl[3], 0u, 0u, 0u};
+        const int out0 = M.ctl[2];
+        const int n_out = ext1_walk(T, (ull*)M.rec, qs, M.ctl[3], NMcap, any_unreached, sink, M.f,
+                                    (flags & TLC_KEEP_ZERO_PERS) != 0, out0, pc);
+        if (threadIdx.x == 0) { M.ctl[2] = out0 + n_out; M.ctl[8] = n_out; }
     }
     __syncthreads();
     TLC_STAMP(10);
