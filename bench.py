@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the auxiliary random-pair sweep (profiling runs)")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="development: no per-kernel HIP events in the timed region (the roofline block is then meaningless)")
     args = ap.parse_args()
 
     import torch
@@ -134,7 +136,7 @@ def main():
     for _ in range(args.warmup):
         leg_pi()
         leg_lp()
-    g.set_timing(True)
+    g.set_timing(not args.no_kernel_events)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     ktimes = {k: [] for k in engine.DeviceGraph.KERNELS}
     barrier()

@@ -373,3 +373,38 @@ def test_pd_from_filtration_rejects_oversized_graph(torch_cuda):
     assert np.array_equal(c[0], ref["counts"][0])
     assert same_multiset(got["one"].cpu().numpy()[:c[0][2]], ref["one"][:c[0][2]])
     assert c[2][2] == 1 and c[2][3] == 1
+
+
+def test_early_pass_overflow_takes_the_ordinary_path(torch_cuda):
+    """A batch whose every pair is predicted heavy and LARGE-tier: the early pass (the predicted-heavy pairs counted and written
+    ahead of the batch, api.hip run_chunk) has 512 candidate and 256 arena slots, everything beyond them must come out of
+    the ordinary COUNT -> scan -> FILL -> tier path with the same rows."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    rs = np.random.RandomState(11)
+    L = 640                                                   # hub 0 + a ring of leaves with a few chords
+    e = [(0, k) for k in range(1, L + 1)] + [(k, k % L + 1) for k in range(1, L + 1)]
+    e += [(int(a), int(b)) for a, b in rs.randint(1, L + 1, size=(200, 2)) if a != b]
+    e = np.unique(np.sort(np.array(e, dtype=np.int64), axis=1), axis=0)
+    kappa = rs.uniform(-0.5, 0.9, size=len(e))
+    rowptr, col, w = synth.edges_to_csr(L + 1, e, kappa)
+    g = engine.DeviceGraph(rowptr, col, w)
+    distinct = e[rs.permutation(len(e))[:192]].astype(np.int32)
+    reps = 24
+    pairs = np.tile(distinct, (reps, 1))                      # 4 608 pairs, every vicinity = the whole graph (641 nodes)
+    perm = rs.permutation(len(pairs))
+    out, st = g.pd_pi_batch(_dev(torch, pairs[perm], torch.int32), 2)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    stats = g.stats()
+    assert stats["tier_large"] == len(pairs)
+    ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, distinct, 2, n_threads=0)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(perm))
+    out, st = out[inv].reshape(reps, len(distinct), 25), st[inv].reshape(reps, len(distinct))
+    assert (st == rst[None, :]).all()
+    assert (out == out[0:1]).all()                            # early slot or ordinary path: bit-identical rows
+    nz = ref != 0
+    assert nz.any() and np.array_equal(out[0] == 0, ~nz)
+    assert rel_err(out[0][nz], ref[nz]).max() < 1e-8
+    g.close()

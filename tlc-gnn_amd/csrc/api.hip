@@ -32,7 +32,13 @@ extern "C" int tlc_device_count(void) {
 }
 
 #define TLC_CHUNK_PAIRS (1 << 20)
-#define TLC_N_SIDE 4
+#define TLC_N_SIDE 5
+// early pass (run_chunk): at most this many predicted-heavy pairs are counted ahead of the batch, at most this many LARGE-tier
+// vicinities among them get a slot of the early arena (12 B x 2*TLC_L_MMAX entries each)
+#define TLC_EARLY_CAND 512
+#define TLC_EARLY_SLOTS 256
+#define TLC_EARLY_WG 256          /* workgroups (and scratch slots) of the early COUNT */
+#define TLC_EARLY_MIN_PAIRS 4096  /* smaller batches gain nothing from a second COUNT launch */
 
 struct HostSync {
     long long total_entries;
@@ -42,6 +48,7 @@ struct HostSync {
     // written by tlc_publish_sizes straight into this (pinned, device-mapped) block; seq last, after a system-scope fence
     volatile long long pub_total;
     volatile int pub_tier[TLC_N_TIERS];
+    volatile int pub_early;
     volatile unsigned pub_seq;
 };
 
@@ -81,6 +88,16 @@ struct tlc_graph {
     // HUGE tier scratch
     int huge_slots;
     unsigned char* huge_scratch;
+    // early pass: ball-size bounds per node for one hop value, candidate / early lists, the early arena
+    int ball_hop;
+    int* d_ball_ub[2];
+    int* d_cand_list;
+    int* d_early_list;
+    unsigned* E_dir;
+    double* E_lw;
+    hipEvent_t ev_early, ev_sel;
+    unsigned char* handoff;        // hand-off slots between the tier kernels and tlc_pd_swap_kernel
+    size_t cap_handoff;
     size_t huge_stride;
     hipStream_t side[TLC_N_SIDE];
     hipEvent_t ev_fork, ev_join[TLC_N_SIDE];
@@ -120,6 +137,16 @@ static int ensure_arena(tlc_graph* g, size_t entries) {
     return TLC_OK;
 }
 
+static int ensure_handoff(tlc_graph* g, size_t bytes) {
+    if (bytes <= g->cap_handoff) return TLC_OK;
+    const size_t want = std::max(bytes + bytes / 4, (size_t)1 << 20);
+    hipFree(g->handoff);
+    g->handoff = nullptr; g->cap_handoff = 0;
+    TLC_HIP_CHECK(hipMalloc(&g->handoff, want));
+    g->cap_handoff = want;
+    return TLC_OK;
+}
+
 static int ensure_small(tlc_graph* g, size_t n_pairs) {
     if (n_pairs <= g->cap_small) return TLC_OK;
     hipFree(g->S_dir); hipFree(g->S_lw);
@@ -139,8 +166,31 @@ static int ensure_vic_scratch(tlc_graph* g, int hop) {
     // the graph's size), and for hop >= 3 the two BFS frontiers (up to n_nodes each)
     const long long cap = std::min<long long>(g->n_nodes, TLC_MAX_SUBGRAPH_NODES + 1);
     g->vic_stride = 2 * cap + (need_front ? 2ll * g->n_nodes : 0) + 16;
-    TLC_HIP_CHECK(hipMalloc(&g->vic_scratch, (size_t)g->vic_slots * g->vic_stride * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&g->vic_scratch, (size_t)(g->vic_slots + TLC_EARLY_WG) * g->vic_stride * sizeof(int)));
     g->vic_hop_cap = need_front;
+    return TLC_OK;
+}
+
+// per-node upper bound of |ball_hop(x)| (vicinity.hip, tlc_ball_bound_kernel) and the early pass's buffers; one-off per
+// (graph, hop)
+static int ensure_early(tlc_graph* g, int hop, hipStream_t s) {
+    if (!g->d_cand_list) {
+        TLC_HIP_CHECK(hipMalloc(&g->d_ball_ub[0], (size_t)g->n_nodes * sizeof(int)));
+        TLC_HIP_CHECK(hipMalloc(&g->d_ball_ub[1], (size_t)g->n_nodes * sizeof(int)));
+        TLC_HIP_CHECK(hipMalloc(&g->d_early_list, TLC_EARLY_SLOTS * sizeof(int)));
+        TLC_HIP_CHECK(hipMalloc(&g->E_dir, (size_t)TLC_EARLY_SLOTS * 2 * TLC_L_MMAX * sizeof(unsigned)));
+        TLC_HIP_CHECK(hipMalloc(&g->E_lw, (size_t)TLC_EARLY_SLOTS * 2 * TLC_L_MMAX * sizeof(double)));
+        TLC_HIP_CHECK(hipMalloc(&g->d_cand_list, TLC_EARLY_CAND * sizeof(int)));
+    }
+    if (g->ball_hop != hop) {
+        int rc;
+        for (int h = 1; h <= hop; ++h) {
+            // the result of round h lands in buffer (h - 1) & 1 ... the caller reads buffer (hop - 1) & 1
+            if ((rc = tlc_launch_ball_bound(g->n_nodes, g->d_rowptr, g->d_col, h == 1 ? nullptr : g->d_ball_ub[h & 1],
+                                            g->d_ball_ub[(h - 1) & 1], s)) != TLC_OK) return rc;
+        }
+        g->ball_hop = hop;
+    }
     return TLC_OK;
 }
 
@@ -207,11 +257,13 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     for (int k = 0; k < TLC_N_SIDE; ++k) {
         // side[1] carries the heavy tiers (the critical path): highest priority; side[2] (MEDIUM, the second longest
         // chain) sits between it and side[0] (SMALL, which only has to finish before the other two do)
-        const int prio = k == 1 ? prio_hi : (k >= 2 ? (prio_lo + prio_hi) / 2 : prio_lo);
+        const int prio = (k == 1 || k == 4) ? prio_hi : (k >= 2 ? (prio_lo + prio_hi) / 2 : prio_lo);
         CK(hipStreamCreateWithPriority(&g->side[k], hipStreamNonBlocking, prio));
         CK(hipEventCreateWithFlags(&g->ev_join[k], hipEventDisableTiming));
     }
     CK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&g->ev_early, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&g->ev_sel, hipEventDisableTiming));
     for (int k = 0; k < 16; ++k) CK(hipEventCreate(&g->ev_t[k]));
 #undef CK
     // concurrent vicinity workgroups worth launching: LDS-bound per CU, 256 CUs
@@ -234,7 +286,10 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
     hipFree(g->d_ctl); hipFree(g->d_block_sums); hipFree(g->d_totals); hipFree(g->d_stats);
     if (g->h_sync) hipHostFree(g->h_sync);
-    hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->S_dir); hipFree(g->S_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch); hipFree(g->d_phase);
+    hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->S_dir); hipFree(g->S_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch); hipFree(g->handoff); hipFree(g->d_phase);
+    hipFree(g->d_ball_ub[0]); hipFree(g->d_ball_ub[1]); hipFree(g->d_cand_list); hipFree(g->d_early_list); hipFree(g->E_dir); hipFree(g->E_lw);
+    if (g->ev_early) hipEventDestroy(g->ev_early);
+    if (g->ev_sel) hipEventDestroy(g->ev_sel);
     for (int k = 0; k < TLC_N_SIDE; ++k) {
         if (g->side[k]) hipStreamDestroy(g->side[k]);
         if (g->ev_join[k]) hipEventDestroy(g->ev_join[k]);
@@ -251,6 +306,16 @@ __global__ void tlc_wait_started(const int* counter, int target, long long max_t
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && wall_clock64() - t0 < max_ticks)
+        __builtin_amdgcn_s_sleep(8);
+}
+
+// the same with the target on the device (the early pass's LARGE count), clamped to `cap`
+__global__ void tlc_wait_started_dev(const int* counter, const int* target, int cap, long long max_ticks) {
+    if (threadIdx.x != 0) return;
+    int tg = *target;
+    tg = tg < cap ? tg : cap;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tg && wall_clock64() - t0 < max_ticks)
         __builtin_amdgcn_s_sleep(8);
 }
 
@@ -282,6 +347,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
         TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
         TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
+        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
         lds_attr = true;
     }
     const int vgrid = std::min(n_pairs, g->vic_slots);
@@ -289,10 +355,71 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     g->last_n_pairs = n_pairs;
 #define T0(k, st) do { if (g->timing) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k)], st)); } } while (0)
 #define T1(k, st) do { if (g->timing) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k) + 1], st)); g->ev_used[k] = 1; } } while (0)
+    // ---- early pass --------------------------------------------------------------------------------------------------------
+    // The batch waits for its largest vicinity: 0.9 ms of mostly serial work that used to start only after COUNT, the scan,
+    // the size publication and the heavy FILL (0.31 ms into the batch).  The pairs that can be that large are known up
+    // front -- a vicinity is no larger than the smaller of its endpoints' balls, and a per-node bound on the ball size
+    // is a one-off pass over the CSR -- so they are counted ahead of and beside the main COUNT by 512-thread workgroups
+    // on the high-priority stream; those that do come out LARGE-tier are written to fixed slots of a separate arena at once
+    // and their tier kernel follows on the same stream, no host round trip in between.  The main COUNT still counts them
+    // (same header values); the scan leaves them out of the arena and of the tier lists.  Whatever the prediction misses,
+    // or the slots cannot hold, takes the ordinary path below.
+    const bool early = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges && hop <= 2 && n_pairs >= TLC_EARLY_MIN_PAIRS;
+    int* d_cand_count = g->d_ctl + 16;
+    int* d_early_count = g->d_ctl + 17;
+    int* d_early_started = g->d_ctl + 18;
+    int* d_cand_started = g->d_ctl + 19;
+    TlcPdParams pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.hdr_n = g->hdr_n; pp.hdr_m2 = g->hdr_m2; pp.hdr_lu = g->hdr_lu; pp.hdr_lv = g->hdr_lv;
+    pp.edge_off = g->edge_off;
+    pp.small_dir = g->S_dir; pp.small_lw = g->S_lw;
+    pp.flags = flags; pp.res = res; pp.out_pi = d_out_pi; pp.out_status = d_out_status;
+    pp.ids_off = (const long long*)d_ids_off; pp.out_f = d_out_f; pp.out_n = d_out_n; pp.pi_enabled = pi_enabled;
+    pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
+    pp.stats = g->d_stats;
+    if (early) {
+        if ((rc = ensure_early(g, hop, s)) != TLC_OK) return rc;
+        hipStream_t es = g->side[4];
+        TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s));                  // after the memsets (and the one-off bounds)
+        TLC_HIP_CHECK(hipStreamWaitEvent(es, g->ev_fork, 0));
+        // (TLC_INCLUDE_ROOTS adds at most the two roots to a vicinity)
+        if ((rc = tlc_launch_select_heavy(n_pairs, d_pairs, g->n_nodes, g->d_ball_ub[(hop - 1) & 1], TLC_M_NMAX - 1, TLC_EARLY_CAND,
+                                          d_cand_count, g->d_cand_list, es)) != TLC_OK) return rc;
+        TlcVicParams ep = vp;
+        ep.fill_mode = 1; ep.fill_list = g->d_cand_list; ep.fill_count = TLC_EARLY_CAND; ep.work_count_dev = d_cand_count;
+        ep.scratch_base_slot = g->vic_slots;
+        ep.out_pi = nullptr; ep.out_status = nullptr; ep.out_n = nullptr; ep.out_m = nullptr;   // the main COUNT reports
+        ep.small_dir = nullptr; ep.small_lw = nullptr; ep.dbg = nullptr;
+        ep.early_list = g->d_early_list; ep.early_count = d_early_count; ep.early_cap = TLC_EARLY_SLOTS;
+        ep.early_dir = g->E_dir; ep.early_lw = g->E_lw;
+        ep.started = d_cand_started;
+        TLC_HIP_CHECK(hipEventRecord(g->ev_sel, es));
+        hipLaunchKernelGGL((tlc_vicinity_kernel<false, 512>), dim3(TLC_EARLY_WG), dim3(512), g->vic_lds, es, ep);
+        TLC_HIP_CHECK(hipGetLastError());
+        TLC_HIP_CHECK(hipEventRecord(g->ev_early, es));
+        TlcPdParams lp = pp;
+        lp.tier_list = g->d_early_list; lp.tier_count = TLC_EARLY_SLOTS; lp.tier_count_dev = d_early_count;
+        lp.slot_entries = 2 * TLC_L_MMAX; lp.A_dir = g->E_dir; lp.A_lw = g->E_lw;
+        lp.started = d_early_started;
+        lp.phase_cycles = g->d_phase ? g->d_phase + 32 * TLC_TIER_LARGE : nullptr;
+        T0(5, es);
+        if ((rc = tlc_launch_pd_tier(TLC_TIER_LARGE, lp, es)) != TLC_OK) return rc;
+        T1(5, es);
+        TLC_HIP_CHECK(hipEventRecord(g->ev_join[4], es));
+        // The workgroups of the main COUNT are persistent (each strides over its share of the pairs) and fill every wavefront
+        // slot of the machine: submitted first, they would keep the early pass's 512-thread workgroups out for most of their
+        // run, stream priority or not.  So the main COUNT is held until the early workgroups are resident (bounded: 20 us).
+        TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_sel, 0));
+        hipLaunchKernelGGL(tlc_wait_started_dev, dim3(1), dim3(TLC_WAVE), 0, s, (const int*)d_cand_started, (const int*)d_cand_count,
+                           TLC_EARLY_WG, 2000ll);
+        TLC_HIP_CHECK(hipGetLastError());
+    }
     T0(0, s);
     hipLaunchKernelGGL((tlc_vicinity_kernel<false, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
     T1(0, s);
     TLC_HIP_CHECK(hipGetLastError());
+    if (early) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_early, 0));   // the scan reads the early list
 
     // exclusive scan of the induced entry counts + tier binning
     const int nb = (n_pairs + 1023) / 1024;
@@ -302,6 +429,8 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     sp.n_pairs = n_pairs; sp.hdr_n = g->hdr_n; sp.hdr_m2 = g->hdr_m2;
     sp.block_agg = g->d_block_sums; sp.block_flag = g->d_ctl + 64; sp.sync = g->d_ctl + 10; sp.totals = g->d_totals;
     sp.edge_off = g->edge_off; sp.tier_count = g->d_ctl; sp.tier_list = g->tier_list; sp.small_arena = 1;
+    sp.early_list = early ? g->d_early_list : nullptr; sp.early_count = d_early_count; sp.early_cap = TLC_EARLY_SLOTS;
+    sp.h_early = const_cast<int*>(&g->h_sync_dev->pub_early);
     // The arena size and the tier counts come back through mapped host memory: the last block of the scan stores them,
     // fences at system scope and bumps a sequence number the host polls -- no copy kernels, no stream synchronisation on
     // the critical path.  The poll gives up after 200 us and falls back to synchronising the stream (which also surfaces
@@ -331,32 +460,39 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     if ((rc = ensure_arena(g, (size_t)total)) != TLC_OK) return rc;
     if (tc[TLC_TIER_HUGE] > 0 && (rc = ensure_huge(g)) != TLC_OK) return rc;
 
+    const int n_early = early ? g->h_sync->pub_early : 0;
     const int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4];
+    bool used[TLC_N_SIDE] = {false, false, false, false, early};
     if (todo > 0) {
         vp.A_dir = g->A_dir; vp.A_lw = g->A_lw;
-        TlcPdParams pp;
-        memset(&pp, 0, sizeof(pp));
-        pp.hdr_n = g->hdr_n; pp.hdr_m2 = g->hdr_m2; pp.hdr_lu = g->hdr_lu; pp.hdr_lv = g->hdr_lv;
-        pp.edge_off = g->edge_off; pp.A_dir = g->A_dir; pp.A_lw = g->A_lw;
-        pp.small_dir = g->S_dir; pp.small_lw = g->S_lw;
-        pp.flags = flags; pp.res = res; pp.out_pi = d_out_pi; pp.out_status = d_out_status;
-        pp.ids_off = (const long long*)d_ids_off; pp.out_f = d_out_f; pp.out_n = d_out_n; pp.pi_enabled = pi_enabled;
-        pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
+        pp.A_dir = g->A_dir; pp.A_lw = g->A_lw;
         pp.huge_scratch = g->huge_scratch; pp.huge_stride = (long long)g->huge_stride;
         pp.huge_nmax = std::min(g->n_nodes, TLC_MAX_SUBGRAPH_NODES); pp.huge_mmax = (int)std::min<long long>(g->nnz / 2 + 1, TLC_MAX_SUBGRAPH_EDGES); pp.huge_slots = g->huge_slots;
-        pp.stats = g->d_stats;
         pp.started = (int*)(g->d_stats + 2);
-        bool used[TLC_N_SIDE] = {false, false, false, false};
         static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7};   // timing slot of each tier kernel
+        // hand-off slots (images only): the tiers with long serial tails run their cycle swap in a second, one-wavefront kernel
+        size_t hand_base[TLC_N_TIERS] = {0, 0, 0, 0, 0};
+        if (pi_enabled) {
+            size_t hand_total = 0;
+            for (int t = 0; t < TLC_N_TIERS; ++t) {
+                hand_base[t] = hand_total;
+                hand_total += (size_t)tc[t] * tlc_handoff_slot_bytes(t);
+            }
+            if ((rc = ensure_handoff(g, hand_total)) != TLC_OK) return rc;
+        }
         auto launch_side = [&](int k, int t) -> int {
             TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s));
             TLC_HIP_CHECK(hipStreamWaitEvent(g->side[k], g->ev_fork, 0));
             pp.tier_list = g->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
+            const size_t hs = pi_enabled ? tlc_handoff_slot_bytes(t) : 0;
+            pp.handoff = hs ? g->handoff + hand_base[t] : nullptr;
+            pp.handoff_stride = (long long)hs;
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
-            T0(tslot[t], g->side[k]);
+            const bool timed = !(early && t == TLC_TIER_LARGE);     // (that slot times the early launch)
+            if (timed) T0(tslot[t], g->side[k]);
             int r = tlc_launch_pd_tier(t, pp, g->side[k]);
             if (r != TLC_OK) return r;
-            T1(tslot[t], g->side[k]);
+            if (timed) T1(tslot[t], g->side[k]);
             TLC_HIP_CHECK(hipEventRecord(g->ev_join[k], g->side[k]));
             used[k] = true;
             return TLC_OK;
@@ -385,12 +521,17 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
                                std::min(tc[TLC_TIER_LARGE], 192), 5000ll);
             TLC_HIP_CHECK(hipGetLastError());
         }
+        if (n_early > 0) {       // normally long since true: the early tier kernel was submitted before the main COUNT
+            hipLaunchKernelGGL(tlc_wait_started_dev, dim3(1), dim3(TLC_WAVE), 0, s, (const int*)d_early_started,
+                               (const int*)d_early_count, 192, 5000ll);
+            TLC_HIP_CHECK(hipGetLastError());
+        }
         // 0. the SMALL tier needs nothing more (its subgraphs were written by the COUNT pass); it is submitted after the
         //    heavy chain so that its many workgroups do not delay that chain's start
         if (tc[TLC_TIER_SMALL] > 0 && (rc = launch_side(0, TLC_TIER_SMALL)) != TLC_OK) return rc;
         // 2. the MEDIUM tier
         if (tc[TLC_TIER_MEDIUM] + tc[TLC_TIER_MID] > 0) {
-            vp.fill_mode = heavy > 0 ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
+            vp.fill_mode = (heavy > 0 || n_early > 0) ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
             hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
             TLC_HIP_CHECK(hipGetLastError());
             T1(2, s);
@@ -399,12 +540,13 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         } else {
             T1(2, s);
         }
-        for (int k = 0; k < TLC_N_SIDE; ++k)
-            if (used[k]) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_join[k], 0));
     }
+    for (int k = 0; k < TLC_N_SIDE; ++k)
+        if (used[k]) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_join[k], 0));
 #undef T0
 #undef T1
     for (int t = 0; t <= TLC_TIER_HUGE; ++t) g->last_stats[t] += tc[t];
+    g->last_stats[TLC_TIER_LARGE] += n_early;
     g->last_stats[7] += tc[TLC_TIER_MID];
     g->last_stats[4] += total;
     g->last_stats[6] += 1;

@@ -916,6 +916,50 @@ __device__ __forceinline__ int ext1_walk(const SwapTables& T, ull* recs, Query& 
     return n_out;
 }
 
+// Hand-off record of one subgraph between a tier kernel (parallel stages, W threads, the tier's full LDS footprint) and
+// tlc_pd_swap_kernel (the serial cycle swap + the image: one wavefront and a quarter of the LDS, so that the long serial
+// tails of a tier run at several times the tier kernel's residency).  Slot layout, NM / MM = the tier's capacities:
+//   int hdr[8]  : [0] pending  [1] n  [2] #Pos  [3] #0-dim points  [4] #PD_up points  [5] tree has unreached nodes
+//   f64 f[NM] | u32 par[NM] | u32 key[NM] | u32 pts[NM] | u64 query[MM]   (query = (asc rank + 1) << 40 | p << 16 | q)
+__host__ __device__ constexpr size_t handoff_bytes(int NM, int MM) { return al16(32 + (size_t)20 * NM + (size_t)8 * MM); }
+struct Handoff {
+    int* hdr;
+    double* f;
+    unsigned *par, *key, *pts;
+    ull* query;
+};
+__device__ __forceinline__ Handoff carve_handoff(unsigned char* slot, int NM) {
+    Handoff H;
+    H.hdr = (int*)slot;
+    H.f = (double*)(slot + 32);
+    H.par = (unsigned*)(slot + 32 + (size_t)8 * NM);
+    H.key = H.par + NM;
+    H.pts = H.key + NM;
+    H.query = (ull*)(slot + 32 + (size_t)20 * NM);
+    return H;
+}
+
+// The parallel half of Accelerate_PD, then everything the serial half and the image need goes to the hand-off slot.
+template <int W, typename idx_t>
+__device__ __forceinline__ void ext1_handoff(Mem<idx_t>& M, int n, int MMcap, int NMcap, unsigned char* slot) {
+    const int tid = threadIdx.x;
+    const SwapTables T = carve_swap(M.keyS, NMcap);
+    const bool any_unreached = ext1_build_tree<W>(M, T, n, MMcap, NMcap);
+    const Handoff H = carve_handoff(slot, NMcap);
+    const int npos = M.ctl[3], np0 = M.ctl[2];
+    for (int i = tid; i < n; i += W) { H.f[i] = M.f[i]; H.par[i] = T.par[i]; H.key[i] = T.key[i]; }
+    for (int i = tid; i < np0; i += W) H.pts[i] = M.pts[i];
+    for (int k = tid; k < npos; k += W) {
+        const unsigned e = M.pn[k];
+        H.query[k] = ((ull)((M.arank[e] + 1u) << 8) << 32) | (ull)M.dir[e];
+    }
+    if (tid == 0) {
+        H.hdr[1] = n; H.hdr[2] = npos; H.hdr[3] = np0; H.hdr[4] = M.ctl[6]; H.hdr[5] = any_unreached ? 1 : 0;
+        H.hdr[0] = 1;
+    }
+    __syncthreads();
+}
+
 // Accelerate_PD (accelerated_PD.py:115-178) on a subgraph whose Pos / Neg lists sit in M.pn.  Requires ctl[4] (#Neg) >= 1.
 template <int W, typename idx_t, class Sink>
 __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, unsigned flags, int MMcap, int NMcap, ull* pc,
@@ -935,9 +979,10 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
 }
 
 // All PD stages on a subgraph whose f[0..n) is final and whose m undirected edges sit in M.dir[0..m) as node-id pairs.
+// `slot` != null: a subgraph with Pos edges leaves its cycle swap to tlc_pd_swap_kernel (deferred = true).
 template <int W, typename idx_t, class Sink>
 __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, int m, unsigned flags, int MMcap, int NMcap,
-                                            ull* pc, ull& t_prev, ull* ph) {
+                                            ull* pc, ull& t_prev, ull* ph, unsigned char* slot, bool& deferred) {
     relabel_by_rank<W>(M, n, m);
     sort_edges<W, idx_t, false>(M, m);
     for (int pos = threadIdx.x; pos < m; pos += W) M.arank[M.valS[pos]] = (unsigned)pos;
@@ -960,7 +1005,11 @@ __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, i
     int status = TLC_ST_OK;
     if (!(flags & TLC_NO_EXT1)) {
         if (M.ctl[4] == 0) status = TLC_ST_NO_TREE_EDGE;              // list(Nodes)[0] -> IndexError (:122)
-        else ext1_stage<W>(M, sink, n, flags, MMcap, NMcap, pc, t_prev, ph);
+        else if (slot != nullptr && M.ctl[3] > 0) {
+            ext1_handoff<W>(M, n, MMcap, NMcap, slot);
+            deferred = true;
+            TLC_STAMP(9);
+        } else ext1_stage<W>(M, sink, n, flags, MMcap, NMcap, pc, t_prev, ph);
     }
     return status;
 }
@@ -1093,14 +1142,20 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
     const int res = p.res, res2 = res * res;
 
     // this workgroup is resident: tell the launcher's gate (api.hip, tlc_wait_started)
-    if (NM == TLC_L_NMAX && !HUGE && p.started && tid == 0) atomicAdd(p.started, 1);
-    for (int wi = blockIdx.x; wi < p.tier_count; wi += gridDim.x) {
+    int tier_count = p.tier_count;
+    if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
+    if (NM == TLC_L_NMAX && !HUGE && p.started && tid == 0 && (int)blockIdx.x < tier_count) atomicAdd(p.started, 1);
+    for (int wi = blockIdx.x; wi < tier_count; wi += gridDim.x) {
         const int i = p.tier_list[wi];
         const int n = p.hdr_n[i], m2 = p.hdr_m2[i], lu = p.hdr_lu[i], lv = p.hdr_lv[i];
-        const long long eo = p.edge_off[i];
+        const long long eo = p.slot_entries ? (long long)wi * p.slot_entries : p.edge_off[i];
         const int m = m2 >> 1;
         const bool far = (lu < 0);        // u in S <=> v in S <=> d(u,v) <= hop  
         int status = TLC_ST_OK;
+        // hand-off slot of this subgraph (tiers whose cycle swap runs in tlc_pd_swap_kernel); "nothing pending" until decided
+        unsigned char* slot = (!HUGE && p.handoff) ? p.handoff + (size_t)wi * (size_t)p.handoff_stride : nullptr;
+        bool deferred = false;
+        if (slot && tid == 0) *(int*)slot = 0;
 #ifdef TLC_PHASE_DEBUG
         ull* pc = p.phase_cycles;
         ull t_prev = pc ? clock64() : 0ull;
@@ -1309,8 +1364,8 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
             __syncthreads();
             PtsSink sink{M.pts, M.ctl};
             TLC_STAMP(4);
-            status = pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph);
-            if (status == TLC_ST_OK) {
+            status = pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, slot, deferred);
+            if (status == TLC_ST_OK && !deferred) {
                 const int np = M.ctl[2], n_up = M.ctl[6];
                 auto get = [&](int k, double& b, double& d) {
                     const unsigned bd = M.pts[k];
@@ -1340,10 +1395,82 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
         }
 #endif
         if (status != TLC_ST_OK) acc = 0.0;
-        if (p.out_pi && tid < res2) p.out_pi[(size_t)i * res2 + tid] = acc;
-        if (p.out_status && tid == 0) p.out_status[i] = (unsigned char)status;
+        if (!deferred) {                  // (else tlc_pd_swap_kernel writes the image row and the status)
+            if (p.out_pi && tid < res2) p.out_pi[(size_t)i * res2 + tid] = acc;
+            if (p.out_status && tid == 0) p.out_status[i] = (unsigned char)status;
+        }
         __syncthreads();
     }
+}
+
+// ======================================================================================================================
+// The serial half of a tier: cycle swap + image of the subgraphs a tier kernel handed off.  One wavefront per subgraph.
+// ======================================================================================================================
+struct SwapLayout {
+    size_t o_rec, o_pts, o_ctl, total, table_bytes;
+};
+__host__ __device__ constexpr SwapLayout make_swap_layout(int NM, int MM) {
+    SwapLayout L{};
+    // [0, o_rec): the swap tables; afterwards f[NM] and the image table (64 points per round at res 5)
+    size_t o = al16(smax(swap_table_bytes(NM), (size_t)8 * NM + (size_t)64 * 13 * 8));
+    L.table_bytes = o - (size_t)8 * NM;
+    L.o_rec = o;  o += 1280;
+    L.o_pts = o;  o += al16((size_t)(MM + 2) * 4);
+    L.o_ctl = o;  o += 64;
+    L.total = o;
+    return L;
+}
+
+template <int NM, int MM>
+__global__ __launch_bounds__(64, 4) void tlc_pd_swap_kernel(TlcPdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr SwapLayout L = make_swap_layout(NM, MM);
+    const int tid = threadIdx.x;
+    const int wi = blockIdx.x;                                        // grid = the tier's subgraph count
+    if (wi >= p.tier_count) return;
+    const Handoff H = carve_handoff(p.handoff + (size_t)wi * (size_t)p.handoff_stride, NM);
+    if (H.hdr[0] == 0) return;                                        // finished by the tier kernel itself
+    const int i = p.tier_list[wi];
+    const int n = H.hdr[1], npos = H.hdr[2], np0 = H.hdr[3], n_up = H.hdr[4];
+    const bool any_unreached = H.hdr[5] != 0;
+    const SwapTables T = carve_swap(lds_raw, NM);
+    ull* recs = (ull*)(lds_raw + L.o_rec);
+    unsigned* pts = (unsigned*)(lds_raw + L.o_pts);
+    int* ctl = (int*)(lds_raw + L.o_ctl);
+#ifdef TLC_PHASE_DEBUG
+    const ull t_begin = clock64();
+#endif
+    for (int k = tid; k < n; k += 64) { T.par[k] = H.par[k]; T.key[k] = H.key[k]; T.mark[k] = 0u; }
+    for (int k = tid; k < np0; k += 64) pts[k] = H.pts[k];
+    if (tid == 0) { T.par[NM] = (unsigned)NM; T.key[NM] = 0u; T.mark[NM] = 0u; }
+    __syncthreads();
+    PtsSink sink{pts, ctl};
+    QueryGlobal qs{H.query, npos, 0u, 0u, 0u, 0u, 0u, 0u};
+    const int np = np0 + ext1_walk(T, recs, qs, npos, NM, any_unreached, sink, (const double*)nullptr, false, np0, nullptr);
+    __syncthreads();
+    // the tables are dead: f and the image table take their place
+    double* f = (double*)lds_raw;
+    for (int k = tid; k < n; k += 64) f[k] = H.f[k];
+    __syncthreads();
+    auto get = [&](int k, double& b, double& d) {
+        const unsigned bd = pts[k];
+        b = f[bd >> 16];
+        d = f[bd & 0xffffu];
+    };
+    const int res = p.res, res2 = res * res;
+    double* table = (double*)(lds_raw + (size_t)8 * NM);
+    double acc = 0.0;
+    if (p.flags & TLC_PI_ORD0_EXT1) {
+        acc = pi_stage<64, true>(table, L.table_bytes, get, 0, n_up, res, acc);
+        acc = pi_stage<64, true>(table, L.table_bytes, get, n_up + 1, np, res, acc);
+    } else {
+        acc = pi_stage<64, true>(table, L.table_bytes, get, 0, np, res, acc);
+    }
+    if (p.out_pi && tid < res2) p.out_pi[(size_t)i * res2 + tid] = acc;
+    if (p.out_status && tid == 0) p.out_status[i] = (unsigned char)TLC_ST_OK;
+#ifdef TLC_PHASE_DEBUG
+    if (p.phase_cycles && tid == 0) { atomicAdd(&p.phase_cycles[10], clock64() - t_begin); atomicAdd(&p.phase_cycles[12], clock64() - t_begin); }
+#endif
 }
 
 // ======================================================================================================================
@@ -1382,7 +1509,8 @@ __global__ __launch_bounds__(W) void tlc_pdf_tier_kernel(TlcPdfParams p) {
         ull t_prev = 0;
         ull* ph = nullptr;
         if (m > 0) {
-            pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph);
+            bool deferred = false;
+            pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, nullptr, deferred);
         } else if (tid == 0) {
             double mn = 99999999.0, mx = -99999999.0;
             for (int k = 0; k < n; ++k) { mn = M.f[k] < mn ? M.f[k] : mn; mx = M.f[k] > mx ? M.f[k] : mx; }
@@ -1448,6 +1576,15 @@ __global__ __launch_bounds__(64) void tlc_pi_raster_kernel(int n_dgms, const lon
 }
 
 // ---- host launchers ------------------------------------------------------------------------------------------------------
+size_t tlc_handoff_slot_bytes(int tier) {
+    switch (tier) {
+        case TLC_TIER_MID: return handoff_bytes(TLC_D_NMAX, TLC_D_MMAX);
+        case TLC_TIER_MEDIUM: return handoff_bytes(TLC_M_NMAX, TLC_M_MMAX);
+        // (LARGE keeps its cycle swap: its subgraphs are few and the batch waits for the slowest of them, which runs
+        // fastest with a CU to itself -- measured 0.91 vs 1.07 ms with the swap in the shared one-wavefront kernel)
+        default: return 0;
+    }
+}
 size_t tlc_huge_slot_bytes(int nmax, int mmax) { return al16(make_layout(nmax, mmax, false, 2, TLC_HUGE_MIN_TABLE).total); }
 
 template <class K>
@@ -1459,6 +1596,8 @@ static int set_lds_limit(K kernel, size_t bytes) {
 int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (p.tier_count <= 0) return TLC_OK;
+    // tiers with a hand-off buffer leave the cycle swap + image of their subgraphs to tlc_pd_swap_kernel, same stream
+    const bool deferring = p.handoff != nullptr && p.pi_enabled && !(p.flags & TLC_NO_EXT1);
     switch (tier) {
         case TLC_TIER_SMALL: {
             constexpr Layout L = make_layout(TLC_S_NMAX, TLC_S_MMAX, true, 2);
@@ -1470,12 +1609,20 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             constexpr Layout L = make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2);
             hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, false, false>), dim3(p.tier_count),
                                dim3(256), L.total, s, p);
+            if (deferring) {
+                constexpr SwapLayout SL = make_swap_layout(TLC_M_NMAX, TLC_M_MMAX);
+                hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_M_NMAX, TLC_M_MMAX>), dim3(p.tier_count), dim3(64), SL.total, s, p);
+            }
             break;
         }
         case TLC_TIER_MID: {
             constexpr Layout L = make_layout(TLC_D_NMAX, TLC_D_MMAX, false, 2);
             hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_D_NMAX, TLC_D_MMAX, TLC_D_THREADS, false, false>), dim3(p.tier_count),
                                dim3(TLC_D_THREADS), L.total, s, p);
+            if (deferring) {
+                constexpr SwapLayout SL = make_swap_layout(TLC_D_NMAX, TLC_D_MMAX);
+                hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_D_NMAX, TLC_D_MMAX>), dim3(p.tier_count), dim3(64), SL.total, s, p);
+            }
             break;
         }
         case TLC_TIER_LARGE: {
@@ -1486,6 +1633,12 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             if (rc) return rc;
             hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, 512, false, false>), dim3(p.tier_count),
                                dim3(512), lds_bytes, s, p);
+            if (deferring) {
+                constexpr SwapLayout SL = make_swap_layout(TLC_L_NMAX, TLC_L_MMAX);
+                rc = set_lds_limit(tlc_pd_swap_kernel<TLC_L_NMAX, TLC_L_MMAX>, SL.total);
+                if (rc) return rc;
+                hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_L_NMAX, TLC_L_MMAX>), dim3(p.tier_count), dim3(64), SL.total, s, p);
+            }
             break;
         }
         case TLC_TIER_HUGE: {

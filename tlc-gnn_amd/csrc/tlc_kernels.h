@@ -70,6 +70,17 @@ struct TlcVicParams {
     int fill_mode;
     const int* fill_list;
     int fill_count;
+    const int* work_count_dev;   // fill_mode 1: the list length lives on the device (clamped to fill_count); null: fill_count
+    int scratch_base_slot;       // first scratch slot of this launch (concurrent launches use disjoint slot ranges)
+    // early pass (COUNT over the predicted-heavy pairs, ahead of and concurrent with the main COUNT): a vicinity that
+    // turns out to be LARGE-tier takes the next fixed-size slot of the early arena (2*TLC_L_MMAX entries), is written
+    // there at once and appended to early_list, so that its tier kernel starts without waiting for the scan of the batch
+    int* early_list;             // [early_cap] pair indices (null: not an early pass)
+    int* early_count;
+    int early_cap;
+    unsigned* early_dir;
+    double* early_lw;
+    int* started;                // early pass: workgroups with work count themselves here once resident (null: no count)
     // fixed-size slots (2*TLC_S_MMAX entries per pair) for the vicinities of the SMALL tier, written by the COUNT pass
     unsigned* small_dir;
     double* small_lw;
@@ -88,6 +99,11 @@ struct TlcScanParams {
     int* tier_count;  // [TLC_N_TIERS]
     int* tier_list;   // [TLC_N_TIERS][n_pairs]
     int small_arena;
+    // pairs the early pass has already written (they are left out of the arena and of the tier lists); null: none
+    const int* early_list;
+    const int* early_count;
+    int early_cap;
+    int* h_early;           // mapped host memory: number of early pairs (statistics)
     // mapped host memory the last block publishes into (api.hip, HostSync)
     long long* h_total;
     int* h_tier;
@@ -132,6 +148,14 @@ struct TlcPdParams {
     // diagnostics (null in production): per tier 16 accumulated cycle counts of thread 0, see pd_pipeline.hip
     unsigned long long* phase_cycles;
     int* started;      // LARGE tier: workgroups that have begun (the launcher holds the small tiers back until then)
+    // hand-off slots of this tier ([tier_count] x handoff_stride bytes) between the tier kernel and tlc_pd_swap_kernel;
+    // null: the tier kernel runs the cycle swap and the image itself
+    unsigned char* handoff;
+    long long handoff_stride;
+    // early LARGE launch: the list length lives on the device (grid = capacity), subgraph wi sits in slot wi of the early
+    // arena (A_dir / A_lw point at it), and the workgroups that have work count themselves in `started`
+    const int* tier_count_dev;
+    long long slot_entries;      // != 0: entry offset of list position wi is wi * slot_entries instead of edge_off[i]
 };
 
 // PD from a caller-supplied filtration (tlc_pd_from_filtration)
@@ -167,5 +191,9 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream);
 int tlc_launch_pdf_tier(int tier, const TlcPdfParams& p, void* stream);
 int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long* edge_offs, int* counts, int* tier_count,
                        int* tier_list, void* stream);
+int tlc_launch_ball_bound(int n_nodes, const int* rowptr, const int* col, const int* prev, int* out, void* stream);
+int tlc_launch_select_heavy(int n_pairs, const int* pairs, int n_nodes, const int* ub, int threshold, int cap, int* count,
+                            int* list, void* stream);
 size_t tlc_huge_slot_bytes(int nmax, int mmax);
+size_t tlc_handoff_slot_bytes(int tier);   // 0: the tier has no hand-off (its kernel runs the cycle swap itself)
 int tlc_launch_pi_raster(int n_dgms, const long long* offs, const double* pts, int res, double* out, void* stream);

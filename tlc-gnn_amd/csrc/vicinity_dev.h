@@ -428,6 +428,21 @@ __device__ __forceinline__ void vicinity_pair(const TlcVicParams& p, int i, unsi
             write = true;
             wdir = p.small_dir + (size_t)i * (2 * TLC_S_MMAX);
             wlw = p.small_lw + (size_t)i * (2 * TLC_S_MMAX);
+        } else if (p.early_list) {
+            // early pass: a LARGE-tier vicinity takes a slot of the early arena and is written right away
+            const int m = m2 >> 1;
+            if ((n > TLC_M_NMAX || m > TLC_M_MMAX) && n <= TLC_L_NMAX && m <= TLC_L_MMAX) {
+                __syncthreads();
+                if (tid == 0) s_cnt[3] = atomicAdd(p.early_count, 1);
+                __syncthreads();
+                const int es = s_cnt[3];
+                if (es < p.early_cap) {
+                    if (tid == 0) p.early_list[es] = i;
+                    write = true;
+                    wdir = p.early_dir + (size_t)es * (2 * TLC_L_MMAX);
+                    wlw = p.early_lw + (size_t)es * (2 * TLC_L_MMAX);
+                }
+            }
         }
     } else {
         const long long eo = p.edge_off[i];
