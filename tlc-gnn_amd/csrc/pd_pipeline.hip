@@ -89,7 +89,7 @@ __host__ __device__ constexpr Layout make_layout(int NM, int MM, bool lwl, int i
     L.o_mark = o; o += al16((size_t)NM * idxb);                         // node ranks, then path stamps
     L.o_pn = o;   o += al16((size_t)MM * 4);                            // Pos from the front, Neg from the back (edge ids)
     L.o_pts = o;  o += al16((size_t)(MM + 2) * 4);                      // diagram points (birth node<<16 | death node)
-    L.o_ctl = o;  o += 256;
+    L.o_ctl = o;  o += 320;                                             // 16 ints | 16 doubles | 32 ints
     // cycle swap: the two walks' path records, [2][65] nodes + [2][65] keys (the entry weights are dead by then)
     if (lwl && (size_t)2 * MM * 8 >= 1280) L.o_rec = L.o_lw;
     else { L.o_rec = o; o += 1280; }
@@ -116,7 +116,7 @@ struct Mem {
     unsigned *pn, *pts;
     int* ctl;      // [0] flag [1] namb [2] npts [3] npos [4] nneg [5] flag2 [6] n_up [7] n_down [8] n_one
     double* red;   // 16 doubles for block reductions
-    int* wcnt;     // 16 ints for block compaction
+    int* wcnt;     // 32 ints for block compaction
     unsigned* rec; // cycle swap: path records of the two walks
     unsigned char* table;  // PI table: spans dir (+lw)
     size_t table_bytes;
@@ -590,12 +590,12 @@ __device__ __forceinline__ void split_pos_neg(Mem<idx_t>& M, int m, int MMcap) {
             npos += __popcll(mp);
             nneg += __popcll(mn);
         } else {
-            if (tlc_lane() == 0) { M.wcnt[tid >> 6] = __popcll(mp); M.wcnt[8 + (tid >> 6)] = __popcll(mn); }
+            if (tlc_lane() == 0) { M.wcnt[tid >> 6] = __popcll(mp); M.wcnt[16 + (tid >> 6)] = __popcll(mn); }
             __syncthreads();
             int bp = 0, bn = 0, tp = 0, tn = 0;
 #pragma unroll
             for (int k = 0; k < W / 64; ++k) {
-                const int cp = M.wcnt[k], cn = M.wcnt[8 + k];
+                const int cp = M.wcnt[k], cn = M.wcnt[16 + k];
                 if (k < (tid >> 6)) { bp += cp; bn += cn; }
                 tp += cp; tn += cn;
             }
@@ -1629,10 +1629,10 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             constexpr Layout L = make_layout(TLC_L_NMAX, TLC_L_MMAX, false, 2);
             // the whole CU: no SMALL workgroup beside the wavefront that carries the batch's longest serial chain
             constexpr size_t lds_bytes = L.total > 156 * 1024 ? L.total : 156 * 1024;
-            int rc = set_lds_limit(tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, 512, false, false>, lds_bytes);
+            int rc = set_lds_limit(tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>, lds_bytes);
             if (rc) return rc;
-            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, 512, false, false>), dim3(p.tier_count),
-                               dim3(512), lds_bytes, s, p);
+            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>), dim3(p.tier_count),
+                               dim3(TLC_L_THREADS), lds_bytes, s, p);
             if (deferring) {
                 constexpr SwapLayout SL = make_swap_layout(TLC_L_NMAX, TLC_L_MMAX);
                 rc = set_lds_limit(tlc_pd_swap_kernel<TLC_L_NMAX, TLC_L_MMAX>, SL.total);

@@ -57,6 +57,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
     __shared__ long long s_prefix;
     __shared__ int s_bid;
     __shared__ unsigned s_pre[SCAN_BLOCK / 32];       // pairs of this block that the early pass has already written
+    __shared__ int s_tc[TLC_N_TIERS][SCAN_BLOCK / TLC_WAVE];
+    __shared__ int s_tbase[TLC_N_TIERS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) s_bid = atomicAdd(&p.sync[0], 1);
     if (t < SCAN_BLOCK / 32) s_pre[t] = 0u;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
         __hip_atomic_store(&p.block_flag[bid], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (wave == 0) {
-        long long pre = 0;
+        long long acc = 0;
         for (int base = 0; base < bid; base += TLC_WAVE) {
             const int j = base + lane;
             long long v = 0;
@@ -103,9 +105,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
                 while (__hip_atomic_load(&p.block_flag[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
                 v = __hip_atomic_load(&p.block_agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            pre += tlc_wave_sum_i64(v);
+            acc += tlc_wave_sum_i64(v);
         }
-        if (lane == 0) s_prefix = pre;
+        if (lane == 0) s_prefix = acc;
     }
     __syncthreads();
     int tier = -1;
@@ -120,17 +122,23 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
             else if (n <= TLC_L_NMAX && m <= TLC_L_MMAX) tier = TLC_TIER_LARGE;
         }
     }
-    // wave-aggregated append: one atomic per wave and tier
+    // block-aggregated append: one atomic per block and tier (every wavefront of every block adding to the same five counters
+    // cost the scan ~15 us of serialised L2 atomics)
+    int my_rank = 0;                                  // position of this pair among the block's pairs of its tier
 #pragma unroll
     for (int tt = 0; tt < TLC_N_TIERS; ++tt) {
         const unsigned long long mk = __ballot(tier == tt);
-        if (mk == 0) continue;
-        int base = 0;
-        const int leader = __builtin_ctzll(mk);
-        if (lane == leader) base = atomicAdd(&p.tier_count[tt], __popcll(mk));
-        base = __builtin_amdgcn_readlane(base, leader);
-        if (tier == tt) p.tier_list[(size_t)tt * p.n_pairs + base + __popcll(mk & tlc_lanemask_lt())] = i;
+        if (lane == 0) s_tc[tt][wave] = __popcll(mk);
+        if (tier == tt) my_rank = __popcll(mk & tlc_lanemask_lt());
     }
+    __syncthreads();
+    if (t < TLC_N_TIERS) {
+        int tot = 0;
+        for (int k = 0; k < SCAN_BLOCK / TLC_WAVE; ++k) { const int c = s_tc[t][k]; s_tc[t][k] = tot; tot += c; }
+        s_tbase[t] = tot > 0 ? atomicAdd(&p.tier_count[t], tot) : 0;
+    }
+    __syncthreads();
+    if (tier >= 0) p.tier_list[(size_t)tier * p.n_pairs + s_tbase[tier] + s_tc[tier][wave] + my_rank] = i;
     // the last block to get here publishes the sizes
     __syncthreads();
     if (t == 0) {
