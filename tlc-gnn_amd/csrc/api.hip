@@ -390,7 +390,8 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         ep.fill_mode = 1; ep.fill_list = g->d_cand_list; ep.fill_count = TLC_EARLY_CAND; ep.work_count_dev = d_cand_count;
         ep.scratch_base_slot = g->vic_slots;
         ep.out_pi = nullptr; ep.out_status = nullptr; ep.out_n = nullptr; ep.out_m = nullptr;   // the main COUNT reports
-        ep.small_dir = nullptr; ep.small_lw = nullptr; ep.dbg = nullptr;
+        ep.small_dir = nullptr; ep.small_lw = nullptr;
+        ep.dbg = g->d_phase ? g->d_phase + 32 * TLC_N_TIERS : nullptr;        // (diagnostics: the early pass has its own row)
         ep.early_list = g->d_early_list; ep.early_count = d_early_count; ep.early_cap = TLC_EARLY_SLOTS;
         ep.early_dir = g->E_dir; ep.early_lw = g->E_lw;
         ep.started = d_cand_started;
@@ -408,11 +409,13 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         T1(5, es);
         TLC_HIP_CHECK(hipEventRecord(g->ev_join[4], es));
         // The workgroups of the main COUNT are persistent (each strides over its share of the pairs) and fill every wavefront
-        // slot of the machine: submitted first, they would keep the early pass's 512-thread workgroups out for most of their
-        // run, stream priority or not.  So the main COUNT is held until the early workgroups are resident (bounded: 20 us).
-        TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_sel, 0));
-        hipLaunchKernelGGL(tlc_wait_started_dev, dim3(1), dim3(TLC_WAVE), 0, s, (const int*)d_cand_started, (const int*)d_cand_count,
-                           TLC_EARLY_WG, 2000ll);
+        // slot and most of the LDS of the machine: once they are running, a 512-thread workgroup of the early pass -- let alone
+        // one of its tier kernel, which needs a whole CU's LDS -- is placed only as they drain (measured: the early tier kernel
+        // then runs 1.05 instead of 0.88 ms because its last workgroups start ~0.15 ms late).  So the main COUNT is held until
+        // the early COUNT is done and the early tier kernel's workgroups are resident (bounded: 50 us after the former).
+        TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_early, 0));
+        hipLaunchKernelGGL(tlc_wait_started_dev, dim3(1), dim3(TLC_WAVE), 0, s, (const int*)d_early_started, (const int*)d_early_count,
+                           192, 5000ll);
         TLC_HIP_CHECK(hipGetLastError());
     }
     T0(0, s);
@@ -673,13 +676,13 @@ extern "C" int tlc_pi_raster(int32_t n_dgms, const int64_t* d_offs, const double
 }
 
 // ---- diagnostics (not part of include/tlcgnn.h): per-phase cycle counters of the PD tier kernels -------------------
-extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out /* [TLC_N_TIERS][32] or null */) {
+extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out /* [TLC_N_TIERS + 1][32] or null */) {
     TLC_REQUIRE(g != nullptr, "null graph");
     TLC_HIP_CHECK(hipSetDevice(g->device));
     TLC_HIP_CHECK(hipDeviceSynchronize());
-    if (h_out && g->d_phase) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_phase, (size_t)TLC_N_TIERS * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (enable && !g->d_phase) TLC_HIP_CHECK(hipMalloc(&g->d_phase, (size_t)TLC_N_TIERS * 32 * sizeof(unsigned long long)));
-    if (g->d_phase) TLC_HIP_CHECK(hipMemset(g->d_phase, 0, (size_t)TLC_N_TIERS * 32 * sizeof(unsigned long long)));
+    if (h_out && g->d_phase) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_phase, (size_t)(TLC_N_TIERS + 1) * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (enable && !g->d_phase) TLC_HIP_CHECK(hipMalloc(&g->d_phase, (size_t)(TLC_N_TIERS + 1) * 32 * sizeof(unsigned long long)));
+    if (g->d_phase) TLC_HIP_CHECK(hipMemset(g->d_phase, 0, (size_t)(TLC_N_TIERS + 1) * 32 * sizeof(unsigned long long)));
     if (!enable && g->d_phase) { hipFree(g->d_phase); g->d_phase = nullptr; }
     return TLC_OK;
 }

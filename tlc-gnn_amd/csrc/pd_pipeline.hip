@@ -202,9 +202,51 @@ __device__ __forceinline__ double key_desc(double fa, double fb) {
 }
 
 // ---- Bellman-Ford over the directed entries: dist = min over paths of the fp64 sum accumulated from the source --
-template <int W, bool TWO, class LWF>
+// CE > 0: a thread's (at most CE) entries and their weights stay in registers over the rounds.  The tiers that leave the
+// weights in HBM/L2 would otherwise pay a global round trip per round -- several microseconds each while the vicinity
+// kernels of the batch saturate the memory pipeline beside an early-started tier kernel.
+template <int W, bool TWO, int CE, class LWF>
 __device__ __forceinline__ void bellman_ford(ull* d0, ull* d1, const unsigned* dir, int m2, int n, LWF LW, int* ctl) {
     const int tid = threadIdx.x;
+    if constexpr (CE > 0) {
+        unsigned ec[CE];
+        double wc[CE];
+#pragma unroll
+        for (int c = 0; c < CE; ++c) {
+            const int j = tid + c * W;
+            ec[c] = j < m2 ? dir[j] : 0u;
+            wc[c] = j < m2 ? LW(j) : 0.0;
+        }
+        for (int iter = 0; iter <= n; ++iter) {
+            if (tid == 0) ctl[0] = 0;
+            __syncthreads();
+            int ch = 0;
+#pragma unroll
+            for (int c = 0; c < CE; ++c) {
+                if (tid + c * W < m2) {
+                    const int a = ec[c] >> 16, b = ec[c] & 0xffffu;
+                    {
+                        const double cd = __longlong_as_double((long long)d0[a]) + wc[c];
+                        const ull cb = (ull)__double_as_longlong(cd);
+                        const ull old = atomicMin(&d0[b], cb);
+                        ch |= (cb < old);
+                    }
+                    if (TWO) {
+                        const double cd = __longlong_as_double((long long)d1[a]) + wc[c];
+                        const ull cb = (ull)__double_as_longlong(cd);
+                        const ull old = atomicMin(&d1[b], cb);
+                        ch |= (cb < old);
+                    }
+                }
+            }
+            if (ch) ctl[0] = 1;
+            __syncthreads();
+            const int any = ctl[0];
+            __syncthreads();
+            if (!any) break;
+        }
+        return;
+    }
     for (int iter = 0; iter <= n; ++iter) {
         if (tid == 0) ctl[0] = 0;
         __syncthreads();
@@ -1180,13 +1222,21 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
         __syncthreads();
         const double* glw = alw;
         auto LW = [&](int j) -> double { return LWL ? M.lw[j] : glw[j]; };
+        // tiers whose weights stay in HBM/L2: Bellman-Ford keeps a thread's entries in registers, and the weight of every
+        // node's tight successor entry goes to LDS beside its index (the Pos/Neg and point lists are not live yet), so that
+        // neither the rounds nor the chain walks wait for global memory
+        constexpr int BF_CE = (!LWL && !HUGE) ? (2 * MM + W - 1) / W : 0;
+        constexpr bool WTAB = !LWL && !HUGE;
+        static_assert(HUGE || LWL || ((size_t)MM * 4 >= (size_t)NM * 8), "tight-successor weight tables alias pn / pts");
+        double* wU = (double*)M.pn;
+        double* wV = (double*)M.pts;
 
         if (!far) {
             // ---- P5: filtration.build_fv, weighted branch, descriptor 'sum' (riccidist2dgm.py:20-61) ------------------
             if (tid == 0) { du[lu] = 0ull; M.dv[lv] = 0ull; }
             __syncthreads();
             TLC_STAMP(0);
-            bellman_ford<W, true>(du, M.dv, M.dir, m2, n, LW, M.ctl);
+            bellman_ford<W, true, BF_CE>(du, M.dv, M.dir, m2, n, LW, M.ctl);
             TLC_STAMP(1);
             // assert one connected component (:318): everything must be reachable from u
             double dmx = 0.0;
@@ -1213,11 +1263,11 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
                     const double w = LW(j);
                     if (a != lu) {
                         const double s = (w + __longlong_as_double((long long)du[b])) - __longlong_as_double((long long)du[a]);
-                        if (s <= tol) { atomicAdd(&M.cntU[a], 1u); M.nxtU[a] = (unsigned)j; }
+                        if (s <= tol) { atomicAdd(&M.cntU[a], 1u); M.nxtU[a] = (unsigned)j; if (WTAB) wU[a] = w; }
                     }
                     if (a != lv) {
                         const double s = (w + __longlong_as_double((long long)M.dv[b])) - __longlong_as_double((long long)M.dv[a]);
-                        if (s <= tol) { atomicAdd(&M.cntV[a], 1u); M.nxtV[a] = (unsigned)j; }
+                        if (s <= tol) { atomicAdd(&M.cntV[a], 1u); M.nxtV[a] = (unsigned)j; if (WTAB) wV[a] = w; }
                     }
                 }
                 __syncthreads();
@@ -1235,7 +1285,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
                         while (a != lu) {
                             if (M.cntU[a] != 1u || ++steps > n) { amb = true; break; }
                             const int j = (int)M.nxtU[a];
-                            d1 = d1 + LW(j);
+                            d1 = d1 + (WTAB ? wU[a] : LW(j));
                             a = (int)(M.dir[j] & 0xffffu);
                         }
                         a = x; steps = 0;
@@ -1243,7 +1293,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
                         while (!amb && a != lv) {
                             if (M.cntV[a] != 1u || ++steps > n) { amb = true; break; }
                             const int j = (int)M.nxtV[a];
-                            d2 = d2 + LW(j);
+                            d2 = d2 + (WTAB ? wV[a] : LW(j));
                             a = (int)(M.dir[j] & 0xffffu);
                         }
                         fr = d1 + d2;                                     // 'sum' = dist_1 + dist_2 (:49)
@@ -1263,7 +1313,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
                     __syncthreads();
                     if (tid == 0) M.dv[x] = 0ull;
                     __syncthreads();
-                    bellman_ford<W, false>(M.dv, M.dv, M.dir, m2, n, LW, M.ctl);
+                    bellman_ford<W, false, 0>(M.dv, M.dv, M.dir, m2, n, LW, M.ctl);
                     if (tid == 0) {
                         const double e1 = M.dv[lu] == TLC_INF_BITS ? 100.0 : __longlong_as_double((long long)M.dv[lu]);
                         const double e2 = M.dv[lv] == TLC_INF_BITS ? 100.0 : __longlong_as_double((long long)M.dv[lv]);
@@ -1288,7 +1338,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
             // d(u,v) > hop: every distance is the sentinel 100 (:31-37) => f == 200/200; only connectivity matters
             if (tid == 0) du[0] = 0ull;
             __syncthreads();
-            bellman_ford<W, false>(du, du, M.dir, m2, n, LW, M.ctl);
+            bellman_ford<W, false, 0>(du, du, M.dir, m2, n, LW, M.ctl);
             int unreach = 0;
             for (int k = tid; k < n; k += W) unreach |= (du[k] == TLC_INF_BITS);
             const double un = block_max<W>(unreach ? 1.0 : 0.0, M.red);

@@ -4,6 +4,8 @@
 #include "tlc_common.h"
 #include "tlc_kernels.h"
 
+#define TLC_BIG_ROWS 4   /* long CSR rows a wavefront keeps in flight at once */
+
 namespace {
 
 // exclusive scan of one int per thread over a BW-thread workgroup (BW multiple of 64); *total = sum.  `xw` is an LDS array
@@ -134,11 +136,11 @@ __device__ __forceinline__ int local_id(const unsigned* S, const unsigned short*
     return (int)pref[w] + __popc(S[w] & ((1u << (b & 31)) - 1u));
 }
 
-// One wavefront's batch of rows (lane = row k with CSR range [beg, end), empty for idle lanes): counts the entries whose
-// column is in S and, with WRITE, stores them as (k << 16 | local id, weight) from offset t on.  Short rows are scanned
-// by their own lane, rows of >= 32 entries by the whole wavefront.  Returns the lane's induced degree.
+// One wavefront's batch of rows (lane L = row kbase + L * kstride with CSR range [beg, end), empty for idle lanes): counts
+// the entries whose column is in S and, with WRITE, stores them as (k << 16 | local id, weight) from offset t on.  Short
+// rows are scanned by their own lane, rows of >= 32 entries by the whole wavefront.  Returns the lane's induced degree.
 template <bool WRITE>
-__device__ __forceinline__ int induced_batch(int k, int kbase, int beg, int end, int t, const unsigned* S,
+__device__ __forceinline__ int induced_batch(int k, int kbase, int kstride, int beg, int end, int t, const unsigned* S,
                                              const unsigned short* pref, const TlcVicParams& p, unsigned* dir, double* lw) {
     const int lane = tlc_lane();
     const bool big = (end - beg) >= 32;
@@ -162,53 +164,97 @@ __device__ __forceinline__ int induced_batch(int k, int kbase, int beg, int end,
             }
         }
     }
+    // Long rows as a sequence of 64-entry chunks, four chunks in flight: all four are requested before any is looked at, so
+    // the long rows of a batch (the vicinities of hub pairs are full of them, and a hub's own row is several chunks) cost
+    // one global round trip per four chunks instead of one per chunk.
     unsigned long long mask = __ballot(big);
-    while (mask) {
-        const int L = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        const int bb = __builtin_amdgcn_readlane(beg, L), ee = __builtin_amdgcn_readlane(end, L), tt = __builtin_amdgcn_readlane(t, L);
-        const int kk = kbase + L;
-        int run = 0;
-        for (int j0 = bb; j0 < ee; j0 += TLC_WAVE) {
-            const int j = j0 + lane;
-            int b = -1;
-            bool in = false;
-            if (j < ee) {
-                b = p.col[j];
-                in = bit_test(S, b);
+    int curL = -1, cur_j = 0, cur_e = 0, cur_t = 0;       // the row being chunked (wave-uniform)
+    int run = 0;
+    for (;;) {
+        int cL[TLC_BIG_ROWS], cj[TLC_BIG_ROWS], ce[TLC_BIG_ROWS], ct[TLC_BIG_ROWS], bv[TLC_BIG_ROWS];
+        bool first[TLC_BIG_ROWS];
+        double wv[TLC_BIG_ROWS];
+#pragma unroll
+        for (int q = 0; q < TLC_BIG_ROWS; ++q) {
+            first[q] = false;
+            if (curL < 0 || cur_j >= cur_e) {
+                curL = -1;
+                if (mask) {
+                    curL = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    cur_j = __builtin_amdgcn_readlane(beg, curL);
+                    cur_e = __builtin_amdgcn_readlane(end, curL);
+                    cur_t = __builtin_amdgcn_readlane(t, curL);
+                    first[q] = true;
+                }
             }
+            cL[q] = curL; cj[q] = cur_j; ce[q] = cur_e; ct[q] = cur_t;
+            cur_j += TLC_WAVE;
+        }
+        if (cL[0] < 0) break;
+#pragma unroll
+        for (int q = 0; q < TLC_BIG_ROWS; ++q) {
+            const int j = cj[q] + lane;
+            const bool ok = cL[q] >= 0 && j < ce[q];
+            bv[q] = ok ? p.col[j] : -1;
+            if (WRITE) wv[q] = ok ? p.w[j] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < TLC_BIG_ROWS; ++q) {
+            if (cL[q] < 0) continue;                                  // (uniform)
+            if (first[q]) run = 0;
+            const int b = bv[q];
+            const bool in = b >= 0 && bit_test(S, b);
             const unsigned long long m = __ballot(in);
             if (WRITE && in) {
-                const int pos = tt + run + __popcll(m & tlc_lanemask_lt());
-                dir[pos] = ((unsigned)kk << 16) | (unsigned)local_id(S, pref, b);
-                lw[pos] = p.w[j];
+                const int pos = ct[q] + run + __popcll(m & tlc_lanemask_lt());
+                dir[pos] = ((unsigned)(kbase + cL[q] * kstride) << 16) | (unsigned)local_id(S, pref, b);
+                lw[pos] = wv[q];
             }
             run += __popcll(m);
+            if (lane == cL[q]) cnt = run;                             // (the row's last chunk leaves the total)
         }
-        if (lane == L) cnt = run;
     }
     return cnt;
 }
 
 // Walk the CSR rows of ids[0..n).  WRITE=false: ldeg[k] = induced degree of row k (if ldeg), returns the
 // wave-uniform total.  WRITE=true: row k's entries go to dir/lw starting at lrow[k].
+// Rows are dealt to the wavefronts round-robin (row k -> wavefront k mod NW): the ids are ascending and, in a graph grown by
+// preferential attachment, the low ids are the hubs -- contiguous batches would hand every long row to the first wavefront.
 template <bool WRITE, int BW>
 __device__ __forceinline__ int induced_rows(const int* __restrict__ ids, int n, const unsigned* S, const unsigned short* pref,
                                             const TlcVicParams& p, int* ldeg_or_lrow, unsigned* dir, double* lw, int* xw) {
     const int lane = tlc_lane();
+    constexpr int NW = BW / TLC_WAVE;
+    const int wv = (int)(threadIdx.x >> 6);
     int total = 0;
-    for (int base = (int)(threadIdx.x >> 6) * TLC_WAVE; base < n; base += BW) {
-        const int k = base + lane;
-        int beg = 0, end = 0, t = 0;
-        if (k < n) {
-            const int a = ids[k];
-            row_bounds(p.rowptr, a, beg, end);
-            if (WRITE) t = ldeg_or_lrow[k];
+    // four batches of 64 rows per wavefront at a time: their node ids (and write offsets), then their row bounds, are
+    // requested together, so the chain id -> row bounds -> columns is paid once per four batches
+    constexpr int R = 4;
+    for (int b0 = 0; b0 * TLC_WAVE * NW + wv < n; b0 += R) {
+        int a[R], beg[R], end[R], t[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int k = ((b0 + r) * TLC_WAVE + lane) * NW + wv;
+            a[r] = k < n ? ids[k] : -1;
+            t[r] = (WRITE && k < n) ? ldeg_or_lrow[k] : 0;
         }
-        const int cnt = induced_batch<WRITE>(k, base, beg, end, t, S, pref, p, dir, lw);
-        if (!WRITE) {
-            if (ldeg_or_lrow && k < n) ldeg_or_lrow[k] = cnt;
-            total += cnt;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            beg[r] = 0; end[r] = 0;
+            if (a[r] >= 0) row_bounds(p.rowptr, a[r], beg[r], end[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int kbase = (b0 + r) * TLC_WAVE * NW + wv;          // row of lane 0
+            if (kbase >= n) continue;                                 // (uniform)
+            const int k = kbase + lane * NW;
+            const int cnt = induced_batch<WRITE>(k, kbase, NW, beg[r], end[r], t[r], S, pref, p, dir, lw);
+            if (!WRITE) {
+                if (ldeg_or_lrow && k < n) ldeg_or_lrow[k] = cnt;
+                total += cnt;
+            }
         }
     }
     if (WRITE) return 0;
@@ -231,8 +277,11 @@ __device__ __forceinline__ void mark_two_balls_hop2(unsigned* bitsU, unsigned* b
         atomicOr(&bitsU[u >> 5], 1u << (u & 31));
         atomicOr(&bitsV[v >> 5], 1u << (v & 31));
     }
-    for (int base = (int)(threadIdx.x >> 6) * TLC_WAVE; base < tot; base += BW) {
-        const int k = base + lane;
+    // frontier entries dealt to the wavefronts round-robin (see induced_rows: the low ids, first in every row, are the hubs)
+    constexpr int NW = BW / TLC_WAVE;
+    const int wv = (int)(threadIdx.x >> 6);
+    for (int kbase = wv; kbase < tot; kbase += BW) {
+        const int k = kbase + lane * NW;
         int beg = 0, end = 0;
         unsigned* bits = bitsU;
         if (k < tot) {
@@ -253,15 +302,36 @@ __device__ __forceinline__ void mark_two_balls_hop2(unsigned* bitsU, unsigned* b
                     if (j0 + q < end) atomicOr(&bits[bb[q] >> 5], 1u << (bb[q] & 31));
             }
         }
+        // long rows as 64-entry chunks, four in flight (see induced_batch)
         unsigned long long mask = __ballot(big);
-        while (mask) {
-            const int L = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const int bb = __builtin_amdgcn_readlane(beg, L), ee = __builtin_amdgcn_readlane(end, L);
-            unsigned* wb = ((base + L) < du) ? bitsU : bitsV;
-            for (int j = bb + lane; j < ee; j += TLC_WAVE) {
-                const int b = p.col[j];
-                atomicOr(&wb[b >> 5], 1u << (b & 31));
+        int curL = -1, cur_j = 0, cur_e = 0;
+        for (;;) {
+            int cL[TLC_BIG_ROWS], bv[TLC_BIG_ROWS], cj[TLC_BIG_ROWS], ce[TLC_BIG_ROWS];
+#pragma unroll
+            for (int q = 0; q < TLC_BIG_ROWS; ++q) {
+                if (curL < 0 || cur_j >= cur_e) {
+                    curL = -1;
+                    if (mask) {
+                        curL = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        cur_j = __builtin_amdgcn_readlane(beg, curL);
+                        cur_e = __builtin_amdgcn_readlane(end, curL);
+                    }
+                }
+                cL[q] = curL; cj[q] = cur_j; ce[q] = cur_e;
+                cur_j += TLC_WAVE;
+            }
+            if (cL[0] < 0) break;
+#pragma unroll
+            for (int q = 0; q < TLC_BIG_ROWS; ++q) {
+                const int j = cj[q] + lane;
+                bv[q] = (cL[q] >= 0 && j < ce[q]) ? p.col[j] : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < TLC_BIG_ROWS; ++q) {
+                if (cL[q] < 0) continue;
+                unsigned* wb = ((kbase + cL[q] * NW) < du) ? bitsU : bitsV;
+                if (bv[q] >= 0) atomicOr(&wb[bv[q] >> 5], 1u << (bv[q] & 31));
             }
         }
     }
@@ -401,7 +471,7 @@ __device__ __forceinline__ void vicinity_pair(const TlcVicParams& p, int i, unsi
     int m2;
     if (reg_rows) {
         if (tid < n) row_bounds(p.rowptr, ids[tid], rb, re);
-        rcnt = induced_batch<false>(tid, 0, rb, re, 0, S, pref, p, nullptr, nullptr);
+        rcnt = induced_batch<false>(tid, 0, 1, rb, re, 0, S, pref, p, nullptr, nullptr);
         m2 = tlc_wave_sum_i32(rcnt);
     } else {
         m2 = induced_rows<false, BW>(ids, n, S, pref, p, lrow, nullptr, nullptr, xw);
@@ -451,7 +521,7 @@ __device__ __forceinline__ void vicinity_pair(const TlcVicParams& p, int i, unsi
     }
     if (write && reg_rows) {
         const int t0 = tlc_wave_iscan_i32(rcnt) - rcnt;
-        induced_batch<true>(tid, 0, rb, re, t0, S, pref, p, wdir, wlw);
+        induced_batch<true>(tid, 0, 1, rb, re, t0, S, pref, p, wdir, wlw);
     } else if (write) {
         __syncthreads();
         int run = 0;

@@ -16,9 +16,9 @@ L.tlc_debug_phase_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 g.pd_pi_batch(pairs, 2)
 L.tlc_debug_phase_profile(g._h, 1, None)
 g.pd_pi_batch(pairs, 2)
-buf = (C.c_uint64 * 160)()
+buf = (C.c_uint64 * 192)()
 L.tlc_debug_phase_profile(g._h, 0, C.cast(buf, C.c_void_p))
-a = np.array(list(buf), dtype=np.float64).reshape(5, 32)
+a = np.array(list(buf), dtype=np.float64).reshape(6, 32)
 for t, tn in enumerate(["small", "medium", "large", "huge", "mid"]):
     if a[t, 14] == 0:
         continue
@@ -31,3 +31,7 @@ for t, tn in enumerate(["small", "medium", "large", "huge", "mid"]):
 c = a[3]
 if c[4] > 0:
     print("COUNT pass: %d pairs; mean cycles per pair: balls %.0f | S sweep + id list %.0f | induced count %.0f | small-tier write %.0f" % (c[4], c[0] / c[4], c[1] / c[4], c[2] / c[4], c[3] / c[4]))
+c = a[5]
+if c[4] > 0:
+    print("early pass: %d pairs; mean cycles per pair: balls %.0f | S sweep + id list %.0f | induced count %.0f | write %.0f" % (c[4], c[0] / c[4], c[1] / c[4], c[2] / c[4], c[3] / c[4]))
+    print("   early count pass, wave 0: short-row cycles %.0f | long-row cycles %.0f | batches %d | long rows %d" % (c[8], c[9], c[10], c[11]))
