@@ -49,6 +49,7 @@ struct HostSync {
     volatile long long pub_total;
     volatile int pub_tier[TLC_N_TIERS];
     volatile int pub_early;
+    volatile int pub_overflow;
     volatile unsigned pub_seq;
 };
 
@@ -126,13 +127,22 @@ static int ensure_pairs(tlc_graph* g, size_t n) {
     return TLC_OK;
 }
 
-static int ensure_arena(tlc_graph* g, size_t entries) {
+// `keep` > 0: the first `keep` entries hold vicinities already written on stream s and survive the growth
+static int ensure_arena(tlc_graph* g, size_t entries, size_t keep = 0, hipStream_t s = nullptr) {
     if (entries <= g->cap_entries) return TLC_OK;
     size_t want = std::max(entries + entries / 4, (size_t)1 << 16);
-    hipFree(g->A_dir); hipFree(g->A_lw);
+    unsigned* old_dir = g->A_dir;
+    double* old_lw = g->A_lw;
     g->A_dir = nullptr; g->A_lw = nullptr; g->cap_entries = 0;
+    if (keep == 0) { hipFree(old_dir); hipFree(old_lw); old_dir = nullptr; old_lw = nullptr; }
     TLC_HIP_CHECK(hipMalloc(&g->A_dir, want * sizeof(unsigned)));
     TLC_HIP_CHECK(hipMalloc(&g->A_lw, want * sizeof(double)));
+    if (keep > 0) {
+        TLC_HIP_CHECK(hipMemcpyAsync(g->A_dir, old_dir, keep * sizeof(unsigned), hipMemcpyDeviceToDevice, s));
+        TLC_HIP_CHECK(hipMemcpyAsync(g->A_lw, old_lw, keep * sizeof(double), hipMemcpyDeviceToDevice, s));
+        TLC_HIP_CHECK(hipStreamSynchronize(s));
+        hipFree(old_dir); hipFree(old_lw);
+    }
     g->cap_entries = want;
     return TLC_OK;
 }
@@ -364,6 +374,18 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     // and their tier kernel follows on the same stream, no host round trip in between.  The main COUNT still counts them
     // (same header values); the scan leaves them out of the arena and of the tier lists.  Whatever the prediction misses,
     // or the slots cannot hold, takes the ordinary path below.
+    // COUNT writes the MID / MEDIUM vicinities itself at bump-allocated arena offsets (images only): the arena has to exist
+    // before the sizes are known, so it starts from a guess and grows when a chunk overflows it (that chunk falls back to the
+    // scan + FILL path below)
+    const bool bump = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges;
+    unsigned long long* d_bump_top = reinterpret_cast<unsigned long long*>(g->d_ctl + 20);
+    int* d_bump_overflow = g->d_ctl + 22;
+    if (bump) {
+        if (g->cap_entries == 0 &&
+            (rc = ensure_arena(g, std::min<size_t>((size_t)n_pairs * 128, (size_t)1 << 23))) != TLC_OK) return rc;
+        vp.A_dir = g->A_dir; vp.A_lw = g->A_lw;
+        vp.bump_top = d_bump_top; vp.bump_cap = (long long)g->cap_entries; vp.bump_overflow = d_bump_overflow;
+    }
     const bool early = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges && hop <= 2 && n_pairs >= TLC_EARLY_MIN_PAIRS;
     int* d_cand_count = g->d_ctl + 16;
     int* d_early_count = g->d_ctl + 17;
@@ -387,6 +409,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         if ((rc = tlc_launch_select_heavy(n_pairs, d_pairs, g->n_nodes, g->d_ball_ub[(hop - 1) & 1], TLC_M_NMAX - 1, TLC_EARLY_CAND,
                                           d_cand_count, g->d_cand_list, es)) != TLC_OK) return rc;
         TlcVicParams ep = vp;
+        ep.bump_top = nullptr;
         ep.fill_mode = 1; ep.fill_list = g->d_cand_list; ep.fill_count = TLC_EARLY_CAND; ep.work_count_dev = d_cand_count;
         ep.scratch_base_slot = g->vic_slots;
         ep.out_pi = nullptr; ep.out_status = nullptr; ep.out_n = nullptr; ep.out_m = nullptr;   // the main COUNT reports
@@ -434,6 +457,8 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     sp.edge_off = g->edge_off; sp.tier_count = g->d_ctl; sp.tier_list = g->tier_list; sp.small_arena = 1;
     sp.early_list = early ? g->d_early_list : nullptr; sp.early_count = d_early_count; sp.early_cap = TLC_EARLY_SLOTS;
     sp.h_early = const_cast<int*>(&g->h_sync_dev->pub_early);
+    sp.bump_top = bump ? d_bump_top : nullptr; sp.bump_overflow = d_bump_overflow;
+    sp.h_overflow = const_cast<int*>(&g->h_sync_dev->pub_overflow);
     // The arena size and the tier counts come back through mapped host memory: the last block of the scan stores them,
     // fences at system scope and bumps a sequence number the host polls -- no copy kernels, no stream synchronisation on
     // the critical path.  The poll gives up after 200 us and falls back to synchronising the stream (which also surfaces
@@ -460,7 +485,9 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     const long long total = g->h_sync->pub_total;
     int tc[TLC_N_TIERS];
     for (int t = 0; t < TLC_N_TIERS; ++t) tc[t] = g->h_sync->pub_tier[t];
-    if ((rc = ensure_arena(g, (size_t)total)) != TLC_OK) return rc;
+    // (COUNT's writes stand unless the chunk overflowed the arena: then everything is laid out by the scan and written by FILL)
+    const bool bumped = bump && g->h_sync->pub_overflow == 0;
+    if ((rc = ensure_arena(g, (size_t)total, bumped ? (size_t)std::min<long long>(total, (long long)g->cap_entries) : 0, s)) != TLC_OK) return rc;
     if (tc[TLC_TIER_HUGE] > 0 && (rc = ensure_huge(g)) != TLC_OK) return rc;
 
     const int n_early = early ? g->h_sync->pub_early : 0;
@@ -534,9 +561,11 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         if (tc[TLC_TIER_SMALL] > 0 && (rc = launch_side(0, TLC_TIER_SMALL)) != TLC_OK) return rc;
         // 2. the MEDIUM tier
         if (tc[TLC_TIER_MEDIUM] + tc[TLC_TIER_MID] > 0) {
-            vp.fill_mode = (heavy > 0 || n_early > 0) ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
-            hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
-            TLC_HIP_CHECK(hipGetLastError());
+            if (!bumped) {
+                vp.fill_mode = (heavy > 0 || n_early > 0) ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
+                hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
+                TLC_HIP_CHECK(hipGetLastError());
+            }
             T1(2, s);
             if (tc[TLC_TIER_MEDIUM] > 0 && (rc = launch_side(2, TLC_TIER_MEDIUM)) != TLC_OK) return rc;
             if (tc[TLC_TIER_MID] > 0 && (rc = launch_side(3, TLC_TIER_MID)) != TLC_OK) return rc;

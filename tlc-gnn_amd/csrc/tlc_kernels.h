@@ -61,9 +61,15 @@ struct TlcVicParams {
     int* out_n;  // optional (tlc_vicinity_filtration)
     int* out_m;  // optional (tlc_vicinity_filtration)
     // FILL
-    const long long* edge_off;
+    long long* edge_off;
     unsigned* A_dir;
     double* A_lw;
+    // COUNT writing the MID / MEDIUM vicinities itself (rows still warm, no second pass over the pair): the arena offset comes
+    // from a bump counter; a vicinity that does not fit below bump_cap is counted in *bump_overflow and the whole chunk then
+    // takes the scan + FILL path.  Null: COUNT writes only the SMALL tier's fixed slots.
+    unsigned long long* bump_top;
+    long long bump_cap;
+    int* bump_overflow;
     const long long* ids_off;  // optional id output (tlc_vicinity_filtration)
     int* out_ids;
     // FILL scheduling: 0 = every pair, 1 = only the pairs in fill_list[0..fill_count) (the heavy tiers go first so that
@@ -100,6 +106,11 @@ struct TlcScanParams {
     int* tier_count;  // [TLC_N_TIERS]
     int* tier_list;   // [TLC_N_TIERS][n_pairs]
     int small_arena;
+    // COUNT wrote the MID / MEDIUM vicinities at bump-allocated offsets (TlcVicParams::bump_top): unless *bump_overflow, only
+    // the heavy tiers still need arena space, handed out above *bump_top; null: every vicinity outside the SMALL tier does
+    const unsigned long long* bump_top;
+    const int* bump_overflow;
+    int* h_overflow;        // mapped host memory: *bump_overflow
     // pairs the early pass has already written (they are left out of the arena and of the tier lists); null: none
     const int* early_list;
     const int* early_count;

@@ -46,9 +46,11 @@ template __global__ void tlc_vicinity_kernel<true, 512>(TlcVicParams);
 // counts into mapped host memory, fences at system scope and bumps the sequence number the host polls.
 #define SCAN_BLOCK 1024
 
-__device__ __forceinline__ long long arena_entries(int n, int m2, int small_arena) {
+// `bumped`: COUNT has written the MID / MEDIUM vicinities already; only the heavy tiers need space
+__device__ __forceinline__ long long arena_entries(int n, int m2, int small_arena, bool bumped) {
     if (n <= 0) return 0;
     if (small_arena && n <= TLC_S_NMAX && (m2 >> 1) <= TLC_S_MMAX) return 0;
+    if (bumped && n <= TLC_M_NMAX && (m2 >> 1) <= TLC_M_MMAX) return 0;
     return (long long)m2;
 }
 
@@ -78,7 +80,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
     const bool pre = (s_pre[t >> 5] >> (t & 31)) & 1u;
     const int n = i < p.n_pairs ? p.hdr_n[i] : 0;
     const int m2v = i < p.n_pairs ? p.hdr_m2[i] : 0;
-    const long long own = (i < p.n_pairs && !pre) ? arena_entries(n, m2v, p.small_arena) : 0;
+    const bool bumped = p.bump_top != nullptr && *p.bump_overflow == 0;
+    const long long arena_base = bumped ? (long long)*p.bump_top : 0;
+    const long long own = (i < p.n_pairs && !pre) ? arena_entries(n, m2v, p.small_arena, bumped) : 0;
     // inclusive scan inside the wavefront, then over the 16 wavefront totals
     // (sizes are < 2^25 per pair, so a wavefront's running sum fits 32 bits)
     long long incl = (long long)(unsigned)tlc_wave_iscan_i32((int)own);
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
     __syncthreads();
     int tier = -1;
     if (i < p.n_pairs) {
-        p.edge_off[i] = s_prefix + wbase + incl - own;
+        if (own > 0 || !bumped) p.edge_off[i] = arena_base + s_prefix + wbase + incl - own;   // (else: COUNT's offset stands)
         if (n > 0 && !pre) {
             const int m = m2v >> 1;
             tier = TLC_TIER_HUGE;
@@ -145,8 +149,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
         atomicAdd(reinterpret_cast<unsigned long long*>(p.sync + 2), (unsigned long long)btotal);   // running arena total
         __threadfence();
         if (atomicAdd(&p.sync[1], 1) == (int)gridDim.x - 1) {
-            const long long total = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(p.sync + 2), __ATOMIC_RELAXED,
-                                                                 __HIP_MEMORY_SCOPE_AGENT);
+            const long long total = arena_base + (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(p.sync + 2),
+                                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.h_overflow) *p.h_overflow = p.bump_overflow ? *p.bump_overflow : 0;
             p.totals[0] = total;
             *p.h_total = total;
             if (p.h_early) *p.h_early = n_early;

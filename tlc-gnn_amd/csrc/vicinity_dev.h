@@ -498,6 +498,23 @@ __device__ __forceinline__ void vicinity_pair(const TlcVicParams& p, int i, unsi
             write = true;
             wdir = p.small_dir + (size_t)i * (2 * TLC_S_MMAX);
             wlw = p.small_lw + (size_t)i * (2 * TLC_S_MMAX);
+        } else if (p.bump_top && n <= TLC_M_NMAX && (m2 >> 1) <= TLC_M_MMAX) {
+            // MID / MEDIUM tier: written right here at a bump-allocated arena offset
+            long long* s_off = (long long*)(s_cnt + 2);
+            __syncthreads();
+            if (tid == 0) {
+                long long off = (long long)atomicAdd(p.bump_top, (unsigned long long)m2);
+                if (off + m2 > p.bump_cap) { off = -1; atomicAdd(p.bump_overflow, 1); }
+                p.edge_off[i] = off;
+                *s_off = off;
+            }
+            __syncthreads();
+            const long long off = *s_off;
+            if (off >= 0) {
+                write = true;
+                wdir = p.A_dir + off;
+                wlw = p.A_lw + off;
+            }
         } else if (p.early_list) {
             // early pass: a LARGE-tier vicinity takes a slot of the early arena and is written right away
             const int m = m2 >> 1;
