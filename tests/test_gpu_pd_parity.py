@@ -408,3 +408,35 @@ def test_early_pass_overflow_takes_the_ordinary_path(torch_cuda):
     assert nz.any() and np.array_equal(out[0] == 0, ~nz)
     assert rel_err(out[0][nz], ref[nz]).max() < 1e-8
     g.close()
+
+
+def test_count_pass_arena_overflow_falls_back_to_scan_and_fill(torch_cuda):
+    """COUNT writes MID / MEDIUM vicinities at bump-allocated arena offsets; the arena is sized from a guess before the sizes are
+    known.  First call on a fresh handle: the guess (64 Ki entries here) is far too small, the chunk must take the scan +
+    FILL path; second call: the arena has grown, COUNT's own writes are used.  Same rows both times, equal to the oracle's."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    rs = np.random.RandomState(5)
+    L = 300                                                   # hub 0 + a ring of leaves + chords: every vicinity is the graph
+    e = [(0, k) for k in range(1, L + 1)] + [(k, k % L + 1) for k in range(1, L + 1)]
+    e += [(int(a), int(b)) for a, b in rs.randint(1, L + 1, size=(120, 2)) if a != b]
+    e = np.unique(np.sort(np.array(e, dtype=np.int64), axis=1), axis=0)
+    rowptr, col, w = synth.edges_to_csr(L + 1, e, rs.uniform(-0.5, 0.9, size=len(e)))
+    g = engine.DeviceGraph(rowptr, col, w)
+    distinct = e[rs.permutation(len(e))[:100]].astype(np.int32)
+    pairs = np.tile(distinct, (4, 1))                         # 400 pairs x ~1 400 directed entries >> 65 536
+    dp = _dev(torch, pairs, torch.int32)
+    out1, st1 = g.pd_pi_batch(dp, 2)
+    s1 = g.stats()
+    out2, st2 = g.pd_pi_batch(dp, 2)
+    s2 = g.stats()
+    assert s1["tier_medium"] == len(pairs) and s2["tier_medium"] == len(pairs)
+    assert s1["induced_entries"] == s2["induced_entries"] > 65536
+    assert bool((out1 == out2).all()) and bool((st1 == st2).all())
+    ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, distinct, 2, n_threads=0)
+    o = out2.cpu().numpy().reshape(4, len(distinct), 25)
+    assert (o == o[0:1]).all() and (st2.cpu().numpy().reshape(4, -1) == rst[None, :]).all()
+    nz = ref != 0
+    assert nz.any() and rel_err(o[0][nz], ref[nz]).max() < 1e-8
+    g.close()

@@ -441,9 +441,12 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
                            192, 5000ll);
         TLC_HIP_CHECK(hipGetLastError());
     }
+    vp.work_counter = g->d_ctl + 24;
+    vp.work_chunk = std::max(4, n_pairs / 8192);
     T0(0, s);
     hipLaunchKernelGGL((tlc_vicinity_kernel<false, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
     T1(0, s);
+    vp.work_counter = nullptr;
     TLC_HIP_CHECK(hipGetLastError());
     if (early) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_early, 0));   // the scan reads the early list
 

@@ -79,6 +79,10 @@ struct TlcVicParams {
     int fill_count;
     const int* work_count_dev;   // fill_mode 1: the list length lives on the device (clamped to fill_count); null: fill_count
     int scratch_base_slot;       // first scratch slot of this launch (concurrent launches use disjoint slot ranges)
+    // work distribution: null = pairs statically strided over the workgroups; else chunks of work_chunk consecutive pairs are
+    // taken from this counter (zeroed per launch), which evens out the heavy-tailed per-pair cost
+    int* work_counter;
+    int work_chunk;
     // early pass (COUNT over the predicted-heavy pairs, ahead of and concurrent with the main COUNT): a vicinity that
     // turns out to be LARGE-tier takes the next fixed-size slot of the early arena (2*TLC_L_MMAX entries), is written
     // there at once and appended to early_list, so that its tier kernel starts without waiting for the scan of the batch

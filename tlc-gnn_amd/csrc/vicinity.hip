@@ -28,6 +28,24 @@ __global__ __launch_bounds__(BW) void tlc_vicinity_kernel(TlcVicParams p) {
         if (p.work_count_dev) { const int c = *p.work_count_dev; n_work = c < n_work ? c : n_work; }
     }
     if (p.started && threadIdx.x == 0 && (int)blockIdx.x < n_work) atomicAdd(p.started, 1);
+    if (p.work_counter) {
+        // (one dequeue per chunk: a single counter serves ~90 dequeues/us, MI355X_MICROARCH.md, so the host sizes the chunks
+        // to keep the total in the low thousands)
+        __shared__ int s_chunk;
+        const int n_chunks = (n_work + p.work_chunk - 1) / p.work_chunk;
+        // the first chunk of a workgroup is its own index (thousands of workgroups hitting the counter at once would wait
+        // ~70 us for it); the counter hands out the chunks from gridDim.x on
+        for (int c = blockIdx.x;;) {
+            if (c >= n_chunks) break;
+            // (a chunk is strided, not contiguous: runs of the pair list that share a hub endpoint stay spread out)
+            for (int wi = c; wi < n_work; wi += n_chunks) vicinity_pair<FILL, BW>(p, p.fill_mode == 1 ? p.fill_list[wi] : wi, lds, slot);
+            if (threadIdx.x == 0) s_chunk = (int)gridDim.x + atomicAdd(p.work_counter, 1);
+            __syncthreads();
+            c = s_chunk;
+            __syncthreads();
+        }
+        return;
+    }
     for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
         const int i = p.fill_mode == 1 ? p.fill_list[wi] : wi;
         vicinity_pair<FILL, BW>(p, i, lds, slot);
