@@ -4,8 +4,11 @@ import collections, csv, glob, json, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 NAMES = [("tlc_pd_tier_kernel<2048", "pd_tier_large"), ("tlc_pd_tier_kernel<512", "pd_tier_medium"),
+         ("tlc_pd_tier_kernel<128", "pd_tier_mid"), ("tlc_pd_swap_kernel<512", "pd_swap_medium"),
+         ("tlc_pd_swap_kernel<128", "pd_swap_mid"),
          ("tlc_pd_tier_kernel<64", "pd_tier_small"), ("tlc_pd_tier_kernel<0", "pd_tier_huge"),
-         ("tlc_vicinity_kernel<true", "vicinity_fill"), ("tlc_vicinity_kernel<false", "vicinity_count"),
+         ("tlc_vicinity_kernel<true", "vicinity_fill"), ("tlc_vicinity_kernel<false, 512", "vicinity_count_early"),
+         ("tlc_vicinity_kernel<false", "vicinity_count"),
          ("tlc_scan_", "scan_bin"), ("gemm16_f32_kernel", "gemm_f32"), ("spmm_csr", "spmm_csr"), ("lp_decode", "lp_decode")]
 raw = {}
 vals = {}
@@ -28,8 +31,10 @@ for cname in raw:
     for k, v in raw[cname].items():
         for pat, nm in NAMES:
             if pat in k:
+                if v["launches"] < steps:      # set-up only (e.g. the FILL fallback of the first batch on a fresh handle)
+                    break
                 # median dispatch x dispatches per step: robust against the one odd-sized set-up batch
-                per_step = max(1, int(round(v["launches"] / float(steps)))) if v["launches"] >= steps else 1
+                per_step = max(1, int(round(v["launches"] / float(steps))))
                 out[nm][cname + "_KB"] += v["median_KB"] * per_step
                 if cname == "FETCH_SIZE":
                     out[nm]["launches_per_step"] += per_step
