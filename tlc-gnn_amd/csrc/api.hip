@@ -96,7 +96,7 @@ struct tlc_graph {
     int* d_early_list;
     unsigned* E_dir;
     double* E_lw;
-    hipEvent_t ev_early, ev_sel;
+    hipEvent_t ev_early, ev_sel, ev_scan;
     unsigned char* handoff;        // hand-off slots between the tier kernels and tlc_pd_swap_kernel
     size_t cap_handoff;
     size_t huge_stride;
@@ -109,6 +109,7 @@ struct tlc_graph {
     hipEvent_t ev_t[16];           // 0/1 count, 2/3 scan, 4/5 fill, 6+2t / 7+2t tier t
     int ev_used[8];
     int last_n_pairs;
+    int prev_tc[TLC_N_TIERS];      // tier counts of the previous chunk (sizes of the speculative launches)
 };
 
 static int ensure_pairs(tlc_graph* g, size_t n) {
@@ -140,7 +141,7 @@ static int ensure_arena(tlc_graph* g, size_t entries, size_t keep = 0, hipStream
     if (keep > 0) {
         TLC_HIP_CHECK(hipMemcpyAsync(g->A_dir, old_dir, keep * sizeof(unsigned), hipMemcpyDeviceToDevice, s));
         TLC_HIP_CHECK(hipMemcpyAsync(g->A_lw, old_lw, keep * sizeof(double), hipMemcpyDeviceToDevice, s));
-        TLC_HIP_CHECK(hipStreamSynchronize(s));
+        TLC_HIP_CHECK(hipDeviceSynchronize());          // (speculatively launched tier kernels may still read the old arena)
         hipFree(old_dir); hipFree(old_lw);
     }
     g->cap_entries = want;
@@ -274,6 +275,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     CK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&g->ev_early, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&g->ev_sel, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&g->ev_scan, hipEventDisableTiming));
     for (int k = 0; k < 16; ++k) CK(hipEventCreate(&g->ev_t[k]));
 #undef CK
     // concurrent vicinity workgroups worth launching: LDS-bound per CU, 256 CUs
@@ -300,6 +302,7 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     hipFree(g->d_ball_ub[0]); hipFree(g->d_ball_ub[1]); hipFree(g->d_cand_list); hipFree(g->d_early_list); hipFree(g->E_dir); hipFree(g->E_lw);
     if (g->ev_early) hipEventDestroy(g->ev_early);
     if (g->ev_sel) hipEventDestroy(g->ev_sel);
+    if (g->ev_scan) hipEventDestroy(g->ev_scan);
     for (int k = 0; k < TLC_N_SIDE; ++k) {
         if (g->side[k]) hipStreamDestroy(g->side[k]);
         if (g->ev_join[k]) hipEventDestroy(g->ev_join[k]);
@@ -473,16 +476,60 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     hipLaunchKernelGGL(tlc_scan_bin, dim3(nb), dim3(1024), 0, s, sp);
     T1(1, s);
     TLC_HIP_CHECK(hipGetLastError());
+    // ---- speculative submission of the MID / MEDIUM tiers ---------------------------------------------------------------
+    // Their inputs are complete once the scan has run (COUNT wrote the vicinities, the scan the tier lists), so they are
+    // submitted behind it right away, with the list lengths on the device and grids / hand-off buffers sized from the
+    // previous chunk: the ~50 us the host needs to see the published sizes and issue a dozen launch calls are no longer
+    // between the scan and the batch's second-longest chain.  If COUNT overflowed the arena the kernels return at once
+    // (abort flag) and the chunk is redone below.
+    static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7};   // timing slot of each tier kernel
+    bool used[TLC_N_SIDE] = {false, false, false, false, early};
+    const bool spec = bump;
+    size_t spec_base[TLC_N_TIERS] = {0, 0, 0, 0, 0};
+    int spec_cap[TLC_N_TIERS] = {0, 0, 0, 0, 0};
+    if (spec) {
+        spec_cap[TLC_TIER_MID] = std::min(n_pairs, std::max(4096, g->prev_tc[TLC_TIER_MID] + g->prev_tc[TLC_TIER_MID] / 4));
+        spec_cap[TLC_TIER_MEDIUM] = std::min(n_pairs, std::max(2048, g->prev_tc[TLC_TIER_MEDIUM] + g->prev_tc[TLC_TIER_MEDIUM] / 4));
+        spec_base[TLC_TIER_MEDIUM] = (size_t)spec_cap[TLC_TIER_MID] * tlc_handoff_slot_bytes(TLC_TIER_MID);
+        if ((rc = ensure_handoff(g, spec_base[TLC_TIER_MEDIUM] +
+                                        (size_t)spec_cap[TLC_TIER_MEDIUM] * tlc_handoff_slot_bytes(TLC_TIER_MEDIUM))) != TLC_OK) return rc;
+        pp.A_dir = g->A_dir; pp.A_lw = g->A_lw;
+        // On the caller's stream itself, tier kernels first, then their swap kernels.  (On side streams they would sit behind
+        // event waits until the scan is done, and a blocked stream stalls whatever shares its hardware queue -- ROCm maps all
+        // streams onto 4 by default: measured, the scan then started 0.1 ms late and took 55 instead of 11 us.)  The fork
+        // point of the side-stream launches below is the event recorded here, ahead of these kernels.
+        TLC_HIP_CHECK(hipEventRecord(g->ev_scan, s));
+        // (only the MEDIUM tier, the longer chain: kernels on one stream do not overlap, and the MID tier's pair of kernels
+        // between the MEDIUM tier kernel and its swap kernel cost more than the host round trip saves -- measured)
+        {
+            const int t = TLC_TIER_MEDIUM;
+            pp.tier_list = g->tier_list + (size_t)t * n_pairs; pp.tier_count = n_pairs; pp.tier_count_dev = g->d_ctl + t;
+            pp.grid = spec_cap[t]; pp.handoff_cap = spec_cap[t]; pp.phase = 0;
+            pp.handoff = g->handoff + spec_base[t]; pp.handoff_stride = (long long)tlc_handoff_slot_bytes(t);
+            pp.abort_flag = d_bump_overflow;
+            pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
+            T0(tslot[t], s);
+            if ((rc = tlc_launch_pd_tier(t, pp, s)) != TLC_OK) return rc;
+            T1(tslot[t], s);
+        }
+        pp.phase = 0;
+        pp.grid = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr; pp.handoff = nullptr; pp.handoff_cap = 0;
+    }
     {
+        // (hipStreamSynchronize would also wait for the kernels submitted behind the scan; the stream is only queried, now and
+        // then, so that a fault surfaces instead of a spin)
         const auto t0 = std::chrono::steady_clock::now();
         bool seen = false;
-        while (!(seen = (g->h_sync->pub_seq == seq))) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+        for (unsigned it = 1; !(seen = (g->h_sync->pub_seq == seq)); ++it) {
+            if ((it & 0x3ff) != 0) continue;
+            const auto el = std::chrono::steady_clock::now() - t0;
+            if (el < std::chrono::microseconds(300)) continue;
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) { seen = (g->h_sync->pub_seq == seq); break; }
+            if (q != hipErrorNotReady) { tlc_set_error(hipGetErrorString(q)); return TLC_ERR_HIP; }
+            if (el > std::chrono::seconds(20)) break;
         }
-        if (!seen) {
-            TLC_HIP_CHECK(hipStreamSynchronize(s));
-            TLC_REQUIRE(g->h_sync->pub_seq == seq, "size publication did not arrive");
-        }
+        TLC_REQUIRE(seen, "size publication did not arrive");
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     const long long total = g->h_sync->pub_total;
@@ -495,31 +542,42 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
 
     const int n_early = early ? g->h_sync->pub_early : 0;
     const int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4];
-    bool used[TLC_N_SIDE] = {false, false, false, false, early};
+    const bool spec_done = spec && bumped;          // the MID / MEDIUM tiers are already running
+    g->prev_tc[TLC_TIER_MID] = tc[TLC_TIER_MID]; g->prev_tc[TLC_TIER_MEDIUM] = tc[TLC_TIER_MEDIUM];
     if (todo > 0) {
         vp.A_dir = g->A_dir; vp.A_lw = g->A_lw;
         pp.A_dir = g->A_dir; pp.A_lw = g->A_lw;
         pp.huge_scratch = g->huge_scratch; pp.huge_stride = (long long)g->huge_stride;
         pp.huge_nmax = std::min(g->n_nodes, TLC_MAX_SUBGRAPH_NODES); pp.huge_mmax = (int)std::min<long long>(g->nnz / 2 + 1, TLC_MAX_SUBGRAPH_EDGES); pp.huge_slots = g->huge_slots;
         pp.started = (int*)(g->d_stats + 2);
-        static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7};   // timing slot of each tier kernel
         // hand-off slots (images only): the tiers with long serial tails run their cycle swap in a second, one-wavefront kernel
         size_t hand_base[TLC_N_TIERS] = {0, 0, 0, 0, 0};
-        if (pi_enabled) {
+        if (pi_enabled && !spec_done) {
             size_t hand_total = 0;
             for (int t = 0; t < TLC_N_TIERS; ++t) {
                 hand_base[t] = hand_total;
                 hand_total += (size_t)tc[t] * tlc_handoff_slot_bytes(t);
             }
             if ((rc = ensure_handoff(g, hand_total)) != TLC_OK) return rc;
+        } else if (pi_enabled) {
+            // the speculative MEDIUM launch in flight owns [spec_base, ...) of the buffer, which must not move: the MID tier's
+            // slots were reserved in front of it for spec_cap[MID] subgraphs; beyond that the tier runs its cycle swap itself
+            hand_base[TLC_TIER_MID] = 0;
         }
-        auto launch_side = [&](int k, int t) -> int {
-            TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s));
-            TLC_HIP_CHECK(hipStreamWaitEvent(g->side[k], g->ev_fork, 0));
+        // (`behind_s`: the launch depends on what was just submitted to s, e.g. a FILL; else only on the scan)
+        auto launch_side = [&](int k, int t, bool behind_s = true) -> int {
+            if (spec_done && !behind_s) {
+                TLC_HIP_CHECK(hipStreamWaitEvent(g->side[k], g->ev_scan, 0));    // (not behind the speculative kernels on s)
+            } else {
+                TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s));
+                TLC_HIP_CHECK(hipStreamWaitEvent(g->side[k], g->ev_fork, 0));
+            }
             pp.tier_list = g->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
             const size_t hs = pi_enabled ? tlc_handoff_slot_bytes(t) : 0;
             pp.handoff = hs ? g->handoff + hand_base[t] : nullptr;
             pp.handoff_stride = (long long)hs;
+            pp.handoff_cap = (spec_done && t == TLC_TIER_MID) ? std::min(tc[t], spec_cap[t]) : tc[t];
+            pp.grid = 0; pp.phase = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
             const bool timed = !(early && t == TLC_TIER_LARGE);     // (that slot times the early launch)
             if (timed) T0(tslot[t], g->side[k]);
@@ -554,14 +612,9 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
                                std::min(tc[TLC_TIER_LARGE], 192), 5000ll);
             TLC_HIP_CHECK(hipGetLastError());
         }
-        if (n_early > 0) {       // normally long since true: the early tier kernel was submitted before the main COUNT
-            hipLaunchKernelGGL(tlc_wait_started_dev, dim3(1), dim3(TLC_WAVE), 0, s, (const int*)d_early_started,
-                               (const int*)d_early_count, 192, 5000ll);
-            TLC_HIP_CHECK(hipGetLastError());
-        }
         // 0. the SMALL tier needs nothing more (its subgraphs were written by the COUNT pass); it is submitted after the
         //    heavy chain so that its many workgroups do not delay that chain's start
-        if (tc[TLC_TIER_SMALL] > 0 && (rc = launch_side(0, TLC_TIER_SMALL)) != TLC_OK) return rc;
+        if (tc[TLC_TIER_SMALL] > 0 && (rc = launch_side(0, TLC_TIER_SMALL, false)) != TLC_OK) return rc;
         // 2. the MEDIUM tier
         if (tc[TLC_TIER_MEDIUM] + tc[TLC_TIER_MID] > 0) {
             if (!bumped) {
@@ -570,8 +623,8 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
                 TLC_HIP_CHECK(hipGetLastError());
             }
             T1(2, s);
-            if (tc[TLC_TIER_MEDIUM] > 0 && (rc = launch_side(2, TLC_TIER_MEDIUM)) != TLC_OK) return rc;
-            if (tc[TLC_TIER_MID] > 0 && (rc = launch_side(3, TLC_TIER_MID)) != TLC_OK) return rc;
+            if (!spec_done && tc[TLC_TIER_MEDIUM] > 0 && (rc = launch_side(2, TLC_TIER_MEDIUM)) != TLC_OK) return rc;
+            if (tc[TLC_TIER_MID] > 0 && (rc = launch_side(3, TLC_TIER_MID, !bumped)) != TLC_OK) return rc;
         } else {
             T1(2, s);
         }

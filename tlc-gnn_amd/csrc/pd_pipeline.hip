@@ -1096,7 +1096,10 @@ __device__ __forceinline__ double tlc_norm_cdf(double x) {
 // one lane per pixel sums w * dPhi_b * dPhi_p over the points in diagram order (the factored form of the reference's
 // 4-term inclusion-exclusion).  `get(k, b, d)` yields the k-th (birth, death).  Returns this thread's
 // pixel value (threads >= res*res carry `acc` through unchanged).
-template <int W, bool BOUNDED, class Get>
+// SW = the width the pixel sums are sliced for (S = SW / res^2 point slices per pixel, a point's slice = its index mod S, so the
+// summation order -- and with it the last bit of the image -- depends on SW only, not on W or on the table size: the MID /
+// MEDIUM tier kernels pass 64 so that a subgraph gives the same bits whether its image is made here or in tlc_pd_swap_kernel).
+template <int W, bool BOUNDED, int SW, class Get>
 __device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get get, int first, int last, int res,
                                            double acc) {
     const int tid = threadIdx.x;
@@ -1104,7 +1107,7 @@ __device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get 
     int batch = (int)(table_bytes / ((size_t)stride * 8));
     if (batch > W) batch = W;
     // phase B layout: S slices of the point list per pixel; thread = slice * res^2 + pixel
-    const int S = W / res2 > 0 ? W / res2 : 1;
+    const int S = SW / res2 > 0 ? SW / res2 : 1;
     const int sl = tid / res2, pix = tid - sl * res2;
     const int pi = pix / res, pj = pix - pi * res;
     const double acc_in = acc;
@@ -1130,7 +1133,8 @@ __device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get 
         }
         __syncthreads();
         if (tid < res2 * S) {
-            for (int pt = sl; pt < nb; pt += S) {
+            const int o = (b0 - first) % S;                            // slice of this batch's first point
+            for (int pt = (sl - o + S) % S; pt < nb; pt += S) {
                 const double* r = tbl + pt * stride;
                 const double wgt = r[2 * G];
                 if (wgt != 0.0) acc += wgt * ((r[pi + 1] - r[pi]) * (r[G + pj + 1] - r[G + pj]));
@@ -1184,6 +1188,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
     const int res = p.res, res2 = res * res;
 
     // this workgroup is resident: tell the launcher's gate (api.hip, tlc_wait_started)
+    if (p.abort_flag && *p.abort_flag) return;
     int tier_count = p.tier_count;
     if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
     if (NM == TLC_L_NMAX && !HUGE && p.started && tid == 0 && (int)blockIdx.x < tier_count) atomicAdd(p.started, 1);
@@ -1195,7 +1200,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
         const bool far = (lu < 0);        // u in S <=> v in S <=> d(u,v) <= hop  
         int status = TLC_ST_OK;
         // hand-off slot of this subgraph (tiers whose cycle swap runs in tlc_pd_swap_kernel); "nothing pending" until decided
-        unsigned char* slot = (!HUGE && p.handoff) ? p.handoff + (size_t)wi * (size_t)p.handoff_stride : nullptr;
+        unsigned char* slot = (!HUGE && p.handoff && wi < p.handoff_cap) ? p.handoff + (size_t)wi * (size_t)p.handoff_stride : nullptr;
         bool deferred = false;
         if (slot && tid == 0) *(int*)slot = 0;
 #ifdef TLC_PHASE_DEBUG
@@ -1227,6 +1232,8 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
         // neither the rounds nor the chain walks wait for global memory
         constexpr int BF_CE = (!LWL && !HUGE) ? (2 * MM + W - 1) / W : 0;
         constexpr bool WTAB = !LWL && !HUGE;
+        // image slicing: the tiers that may hand a subgraph to tlc_pd_swap_kernel slice like that kernel does
+        constexpr int PSW = (!HUGE && (NM == TLC_D_NMAX || NM == TLC_M_NMAX)) ? 64 : W;
         static_assert(HUGE || LWL || ((size_t)MM * 4 >= (size_t)NM * 8), "tight-successor weight tables alias pn / pts");
         double* wU = (double*)M.pn;
         double* wV = (double*)M.pts;
@@ -1425,10 +1432,10 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
                 // transform(np.array(PD_zero + PD_one)) (riccidist2dgm.py:327-328); Rel1 and [max,min] have negative
                 // persistence => weight 0 (PersistenceImager.pyx:23-24), so they are never materialised here
                 if (p.flags & TLC_PI_ORD0_EXT1) {
-                    acc = pi_stage<W, true>((double*)M.table, M.table_bytes, get, 0, n_up, res, acc);
-                    acc = pi_stage<W, true>((double*)M.table, M.table_bytes, get, n_up + 1, np, res, acc);
+                    acc = pi_stage<W, true, PSW>((double*)M.table, M.table_bytes, get, 0, n_up, res, acc);
+                    acc = pi_stage<W, true, PSW>((double*)M.table, M.table_bytes, get, n_up + 1, np, res, acc);
                 } else {
-                    acc = pi_stage<W, true>((double*)M.table, M.table_bytes, get, 0, np, res, acc);
+                    acc = pi_stage<W, true, PSW>((double*)M.table, M.table_bytes, get, 0, np, res, acc);
                 }
             }
         }
@@ -1476,10 +1483,13 @@ __global__ __launch_bounds__(64, 4) void tlc_pd_swap_kernel(TlcPdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr SwapLayout L = make_swap_layout(NM, MM);
     const int tid = threadIdx.x;
-    const int wi = blockIdx.x;                                        // grid = the tier's subgraph count
-    if (wi >= p.tier_count) return;
+    if (p.abort_flag && *p.abort_flag) return;
+    int tier_count = p.tier_count;
+    if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
+    if (tier_count > p.handoff_cap) tier_count = p.handoff_cap;       // (list positions beyond it were not handed off)
+    for (int wi = blockIdx.x; wi < tier_count; wi += gridDim.x) {     // (one subgraph per workgroup unless the grid was capped)
     const Handoff H = carve_handoff(p.handoff + (size_t)wi * (size_t)p.handoff_stride, NM);
-    if (H.hdr[0] == 0) return;                                        // finished by the tier kernel itself
+    if (H.hdr[0] == 0) continue;                                      // finished by the tier kernel itself
     const int i = p.tier_list[wi];
     const int n = H.hdr[1], npos = H.hdr[2], np0 = H.hdr[3], n_up = H.hdr[4];
     const bool any_unreached = H.hdr[5] != 0;
@@ -1511,16 +1521,18 @@ __global__ __launch_bounds__(64, 4) void tlc_pd_swap_kernel(TlcPdParams p) {
     double* table = (double*)(lds_raw + (size_t)8 * NM);
     double acc = 0.0;
     if (p.flags & TLC_PI_ORD0_EXT1) {
-        acc = pi_stage<64, true>(table, L.table_bytes, get, 0, n_up, res, acc);
-        acc = pi_stage<64, true>(table, L.table_bytes, get, n_up + 1, np, res, acc);
+        acc = pi_stage<64, true, 64>(table, L.table_bytes, get, 0, n_up, res, acc);
+        acc = pi_stage<64, true, 64>(table, L.table_bytes, get, n_up + 1, np, res, acc);
     } else {
-        acc = pi_stage<64, true>(table, L.table_bytes, get, 0, np, res, acc);
+        acc = pi_stage<64, true, 64>(table, L.table_bytes, get, 0, np, res, acc);
     }
     if (p.out_pi && tid < res2) p.out_pi[(size_t)i * res2 + tid] = acc;
     if (p.out_status && tid == 0) p.out_status[i] = (unsigned char)TLC_ST_OK;
 #ifdef TLC_PHASE_DEBUG
     if (p.phase_cycles && tid == 0) { atomicAdd(&p.phase_cycles[10], clock64() - t_begin); atomicAdd(&p.phase_cycles[12], clock64() - t_begin); }
 #endif
+    __syncthreads();
+    }
 }
 
 // ======================================================================================================================
@@ -1619,7 +1631,7 @@ __global__ __launch_bounds__(64) void tlc_pi_raster_kernel(int n_dgms, const lon
             b = pts[2 * (o + i)];
             dd = pts[2 * (o + i) + 1];
         };
-        const double acc = pi_stage<64, false>(tbl, sizeof(tbl), get, 0, k, res, 0.0);
+        const double acc = pi_stage<64, false, 64>(tbl, sizeof(tbl), get, 0, k, res, 0.0);
         if (tid < res * res) out[(size_t)d * res * res + tid] = acc;
         __syncthreads();
     }
@@ -1648,6 +1660,7 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
     if (p.tier_count <= 0) return TLC_OK;
     // tiers with a hand-off buffer leave the cycle swap + image of their subgraphs to tlc_pd_swap_kernel, same stream
     const bool deferring = p.handoff != nullptr && p.pi_enabled && !(p.flags & TLC_NO_EXT1);
+    const int grid = p.grid > 0 ? p.grid : p.tier_count;
     switch (tier) {
         case TLC_TIER_SMALL: {
             constexpr Layout L = make_layout(TLC_S_NMAX, TLC_S_MMAX, true, 2);
@@ -1657,21 +1670,23 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
         }
         case TLC_TIER_MEDIUM: {
             constexpr Layout L = make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2);
-            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, false, false>), dim3(p.tier_count),
-                               dim3(256), L.total, s, p);
-            if (deferring) {
+            if (p.phase != 2)
+                hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, false, false>), dim3(grid),
+                                   dim3(256), L.total, s, p);
+            if (deferring && p.phase != 1) {
                 constexpr SwapLayout SL = make_swap_layout(TLC_M_NMAX, TLC_M_MMAX);
-                hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_M_NMAX, TLC_M_MMAX>), dim3(p.tier_count), dim3(64), SL.total, s, p);
+                hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_M_NMAX, TLC_M_MMAX>), dim3(grid), dim3(64), SL.total, s, p);
             }
             break;
         }
         case TLC_TIER_MID: {
             constexpr Layout L = make_layout(TLC_D_NMAX, TLC_D_MMAX, false, 2);
-            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_D_NMAX, TLC_D_MMAX, TLC_D_THREADS, false, false>), dim3(p.tier_count),
-                               dim3(TLC_D_THREADS), L.total, s, p);
-            if (deferring) {
+            if (p.phase != 2)
+                hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_D_NMAX, TLC_D_MMAX, TLC_D_THREADS, false, false>), dim3(grid),
+                                   dim3(TLC_D_THREADS), L.total, s, p);
+            if (deferring && p.phase != 1) {
                 constexpr SwapLayout SL = make_swap_layout(TLC_D_NMAX, TLC_D_MMAX);
-                hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_D_NMAX, TLC_D_MMAX>), dim3(p.tier_count), dim3(64), SL.total, s, p);
+                hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_D_NMAX, TLC_D_MMAX>), dim3(grid), dim3(64), SL.total, s, p);
             }
             break;
         }

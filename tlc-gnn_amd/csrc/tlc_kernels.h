@@ -172,6 +172,14 @@ struct TlcPdParams {
     // arena (A_dir / A_lw point at it), and the workgroups that have work count themselves in `started`
     const int* tier_count_dev;
     long long slot_entries;      // != 0: entry offset of list position wi is wi * slot_entries instead of edge_off[i]
+    // speculative launch (submitted behind the scan without waiting for the host to see the sizes): grid > 0 overrides the
+    // grid (the workgroups stride over the list, whose length is tier_count_dev), only the first handoff_cap list positions
+    // have a hand-off slot (the rest run the cycle swap in the tier kernel), and a set *abort_flag (COUNT overflowed the
+    // arena: the chunk is redone by the scan + FILL path) makes every workgroup return at once
+    int grid;
+    int phase;                   // 0 = tier kernel + its swap kernel, 1 = tier kernel only, 2 = swap kernel only
+    int handoff_cap;
+    const int* abort_flag;
 };
 
 // PD from a caller-supplied filtration (tlc_pd_from_filtration)
