@@ -839,7 +839,8 @@ __device__ __forceinline__ int ext1_walk(const SwapTables& T, ull* recs, Query& 
         const unsigned side_shift = qside ? 0u : 16u;           // a walker's first node: p in the high, q in the low half
         int n_cur = (int)((n_pq >> side_shift) & 0xffffu);
         unsigned n_pcur = par[n_cur], n_kcur = key[n_cur];
-#ifdef TLC_PHASE_DEBUG
+        // (PHASE_DEBUG=2: per-query clocks inside the walk as well; they slow it down by half, so level 1 leaves them out)
+#if defined(TLC_PHASE_DEBUG) && TLC_PHASE_DEBUG > 1
         ull dbg_a = 0, dbg_b = 0, dbg_c = 0, dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0;
 #define DBG_T(v) v = clock64()
 #else
@@ -896,7 +897,7 @@ __device__ __forceinline__ int ext1_walk(const SwapTables& T, ull* recs, Query& 
                     res_s = (unsigned)(lane & 1) ^ (mwin ? 0u : 1u);
                 }
                 DBG_T(dbg_t2);
-#ifdef TLC_PHASE_DEBUG
+#if defined(TLC_PHASE_DEBUG) && TLC_PHASE_DEBUG > 1
                 dbg_a += dbg_t1 - dbg_t0; dbg_b += dbg_t2 - dbg_t1;
 #endif
                 fl = __builtin_amdgcn_readfirstlane(fl);           // lanes 0 and 1 agree; the rest follow lane 0
@@ -946,11 +947,11 @@ __device__ __forceinline__ int ext1_walk(const SwapTables& T, ull* recs, Query& 
             // LDS executes in order: these reads see the swap; their latency hides under the next query's set-up
             n_pcur = par[n_cur];
             n_kcur = key[n_cur];
-#ifdef TLC_PHASE_DEBUG
+#if defined(TLC_PHASE_DEBUG) && TLC_PHASE_DEBUG > 1
             dbg_c += clock64() - dbg_t2;
 #endif
         }
-#ifdef TLC_PHASE_DEBUG
+#if defined(TLC_PHASE_DEBUG) && TLC_PHASE_DEBUG > 1
         if (pc && lane == 0) { atomicAdd(&pc[15], dbg_a); atomicAdd(&pc[30], dbg_b); atomicAdd(&pc[31], dbg_c); }
 #endif
         __builtin_amdgcn_s_setprio(0);
