@@ -47,7 +47,7 @@ for seed in seeds:
     for hop in (1, 2, 3):
         if hop == 3 and n > 700: continue
         if hop == 2 and kind == "star" and n > 3000: continue
-        pos = e[rs.permutation(len(e))[:1500]]
+        pos = e[rs.permutation(len(e))[:4500]]          # (>= 4096 pairs where the graph has them: the early pass runs)
         neg = rs.randint(0, n, size=(300, 2))
         pairs = np.concatenate([pos, neg, [[0, 0], [n + 5, 1], [-1, 2]]]).astype(np.int32)
         for flags in (0, engine.NO_EXT1 if hasattr(engine, "NO_EXT1") else 0x10):
