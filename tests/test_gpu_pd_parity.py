@@ -440,3 +440,31 @@ def test_count_pass_arena_overflow_falls_back_to_scan_and_fill(torch_cuda):
     nz = ref != 0
     assert nz.any() and rel_err(o[0][nz], ref[nz]).max() < 1e-8
     g.close()
+
+
+@pytest.mark.parametrize("res", [5, 8])
+def test_variant_flags_through_the_early_and_handoff_paths(torch_cuda, res):
+    """The flag variants and a non-default resolution on a batch large enough for the early pass (>= 4 096 pairs, hub pairs
+    whose vicinities reach the LARGE tier) and with MID / MEDIUM vicinities that take the hand-off to the swap kernel."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    e = synth.holme_kim_edges(3000, 9000, triad_p=0.4, seed=77)
+    rs = np.random.RandomState(3)
+    rowptr, col, w = synth.edges_to_csr(3000, e, rs.uniform(-0.5, 0.9, size=len(e)))
+    g = engine.DeviceGraph(rowptr, col, w)
+    pairs = np.concatenate([e[rs.permutation(len(e))[:4300]], rs.randint(0, 3000, size=(200, 2))]).astype(np.int32)
+    seen_large = False
+    for flags in (engine.INCLUDE_ROOTS | engine.NORM_EPS | engine.UNREACHABLE_100, engine.KEEP_ZERO_PERS | engine.PI_ORD0_EXT1):
+        out, st = g.pd_pi_batch(_dev(torch, pairs, torch.int32), 2, flags=flags, res=res)
+        stats = g.stats()
+        seen_large |= stats["tier_large"] > 0
+        assert stats["tier_mid"] > 0 and stats["tier_medium"] > 0
+        ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, 2, flags=flags, res=res, n_threads=0)
+        out = out.cpu().numpy()
+        assert np.array_equal(st.cpu().numpy(), rst), flags
+        nz = ref != 0
+        assert np.array_equal(out == 0, ref == 0), flags
+        assert rel_err(out[nz], ref[nz]).max() < 1e-8
+    assert seen_large
+    g.close()
