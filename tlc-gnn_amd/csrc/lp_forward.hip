@@ -451,42 +451,74 @@ __global__ void renorm_rows_kernel(int n_rows, int k, float* __restrict__ emb) {
     }
 }
 
-// Net.decode after the renorm: one thread per pair; W1/W2 are wave-uniform (scalar loads).
-template <int ED, int PD>
-__global__ __launch_bounds__(256) void lp_decode_kernel(long long n_pairs, const int* __restrict__ pairs, const float* __restrict__ emb,
-                                                        const double* __restrict__ pi, const float* __restrict__ W1,
-                                                        const float* __restrict__ b1, const float* __restrict__ W2,
-                                                        const float* __restrict__ b2, float* __restrict__ prob) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_pairs) return;
-    const int u = pairs[2 * i], v = pairs[2 * i + 1];
-    float in[ED + PD];
-    const float* eu = emb + (size_t)u * ED;
-    const float* ev = emb + (size_t)v * ED;
-#pragma unroll
-    for (int c = 0; c < ED; ++c) {
-        const float d = eu[c] - ev[c];
-        in[c] = d * d;                                    // (emb_in - emb_out).pow(2)  (:57)
+// Net.decode after the renorm (baselines/TLCGNN.py:52-61), emb 16 / image 25, eight lanes per pair: one lane per pair leaves one wavefront per SIMD and every one of its
+// 25 x 41 multiply-adds waits on a scalar weight load.  Here a workgroup stages W1 (rows padded to 44), b1 and W2 in LDS once,
+// the eight lanes of a pair load its 41 inputs together (each input once) and share them through LDS, lane g computes the
+// hidden units g, g+8, g+16 (and 24 for g = 0) in the reference's accumulation order, and the eight partial sums of W2 . h are
+// folded with DPP row shifts.  Nine wavefronts per SIMD instead of one.
+__global__ __launch_bounds__(256) void lp_decode8_kernel(long long n_pairs, const int* __restrict__ pairs, const float* __restrict__ emb,
+                                                         const double* __restrict__ pi, const float* __restrict__ W1,
+                                                         const float* __restrict__ b1, const float* __restrict__ W2,
+                                                         const float* __restrict__ b2, float* __restrict__ prob) {
+    constexpr int ED = 16, PD = 25, IN = ED + PD, INP = 44;
+    __shared__ __attribute__((aligned(16))) float s_w1[PD * INP];
+    __shared__ float s_b1[PD + 7], s_w2[PD + 7];
+    __shared__ __attribute__((aligned(16))) float s_in[32 * INP];
+    const int tid = threadIdx.x, g = tid & 7, pl = tid >> 3;           // lane in the pair's group, pair in the workgroup
+    for (int k = tid; k < PD * INP; k += 256) { const int o = k / INP, c = k - o * INP; s_w1[k] = c < IN ? W1[o * IN + c] : 0.0f; }
+    if (tid < PD + 7) { s_b1[tid] = tid < PD ? b1[tid] : 0.0f; s_w2[tid] = tid < PD ? W2[tid] : 0.0f; }
+    const long long i = (long long)blockIdx.x * 32 + pl;
+    const bool live = i < n_pairs;
+    float* in = s_in + pl * INP;
+    if (live) {
+        const int u = pairs[2 * i], v = pairs[2 * i + 1];
+        if (g < 4) {                                                  // (emb_in - emb_out).pow(2)  (:57): four columns per lane
+            const float4 a = *reinterpret_cast<const float4*>(emb + (size_t)u * ED + 4 * g);
+            const float4 b = *reinterpret_cast<const float4*>(emb + (size_t)v * ED + 4 * g);
+            float4 d;
+            d.x = (a.x - b.x) * (a.x - b.x); d.y = (a.y - b.y) * (a.y - b.y);
+            d.z = (a.z - b.z) * (a.z - b.z); d.w = (a.w - b.w) * (a.w - b.w);
+            *reinterpret_cast<float4*>(in + 4 * g) = d;
+        }
+        const double* pr = pi + (size_t)i * PD;
+        for (int c = g; c < PD; c += 8) in[ED + c] = (float)pr[c];    // torch.Tensor(PI): float64 -> float32 (:52-53)
+        if (g < INP - IN) in[IN + g] = 0.0f;
     }
-    const double* pr = pi + (size_t)i * PD;
+    __syncthreads();
+    float part = 0.0f;
+    if (live) {
+        float x[INP];
 #pragma unroll
-    for (int c = 0; c < PD; ++c) in[ED + c] = (float)pr[c];   // torch.Tensor(PI): float64 -> float32 (:52-53)
-    float d = b2[0];
-#pragma unroll 1
-    for (int o = 0; o < PD; ++o) {
-        const float* wr = W1 + o * (ED + PD);
-        float h = b1[o];
+        for (int c = 0; c < INP; c += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(in + c);
+            x[c] = t.x; x[c + 1] = t.y; x[c + 2] = t.z; x[c + 3] = t.w;
+        }
 #pragma unroll
-        for (int c = 0; c < ED + PD; ++c) h += wr[c] * in[c];
-        h = h > 0.0f ? h : 0.2f * h;                      // LeakyReLU(0.2) (:58)
-        d += W2[o] * h;
+        for (int q = 0; q < 4; ++q) {
+            const int o = g + 8 * q;                                   // (o >= 25: zero weights, contributes 0)
+            if (o < PD) {
+                const float* wr = s_w1 + o * INP;
+                float h = s_b1[o];
+#pragma unroll
+                for (int c = 0; c < IN; ++c) h += wr[c] * x[c];
+                h = h > 0.0f ? h : 0.2f * h;                          // LeakyReLU(0.2) (:58)
+                part += s_w2[o] * h;
+            }
+        }
     }
-    d = fabsf(d);                                         // :59
-    d = d < 0.0f ? 0.0f : (d > 40.0f ? 40.0f : d);        // clamp (:60)
-    prob[i] = 1.0f / (expf((d - 2.0f) / 1.0f) + 1.0f);    // Fermi-Dirac (:61)
+    // fold the eight lanes of a group (row_shr 4, 2, 1 inside a DPP row of 16: groups are aligned to 8)
+    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x104, 0xF, 0xF, true));   // row_shl:4
+    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x102, 0xF, 0xF, true));   // row_shl:2
+    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x101, 0xF, 0xF, true));   // row_shl:1
+    if (live && g == 0) {
+        float d = b2[0] + part;
+        d = fabsf(d);                                                 // :59
+        d = d < 0.0f ? 0.0f : (d > 40.0f ? 40.0f : d);                // clamp (:60)
+        prob[i] = 1.0f / (expf((d - 2.0f) / 1.0f) + 1.0f);            // Fermi-Dirac (:61)
+    }
 }
 
-// generic fallback for other dimensions (inputs staged in LDS per thread would not fit: loop from global)
+// generic fallback for other dimensions: one thread per pair, everything from global
 __global__ __launch_bounds__(256) void lp_decode_generic_kernel(long long n_pairs, const int* __restrict__ pairs,
                                                                 const float* __restrict__ emb, int ED, const double* __restrict__ pi,
                                                                 int PD, const float* __restrict__ W1, const float* __restrict__ b1,
@@ -616,7 +648,8 @@ extern "C" int tlc_lp_decode_fused(int64_t n_pairs, const int32_t* d_pairs, cons
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((n_pairs + 255) / 256)), block(256);
     if (emb_dim == 16 && pi_dim == 25)
-        hipLaunchKernelGGL((lp_decode_kernel<16, 25>), grid, block, 0, s, (long long)n_pairs, d_pairs, d_emb, d_pi, d_W1, d_b1, d_W2, d_b2, d_prob);
+        hipLaunchKernelGGL(lp_decode8_kernel, dim3((unsigned)((n_pairs + 31) / 32)), block, 0, s, (long long)n_pairs, d_pairs, d_emb, d_pi,
+                           d_W1, d_b1, d_W2, d_b2, d_prob);
     else
         hipLaunchKernelGGL(lp_decode_generic_kernel, grid, block, 0, s, (long long)n_pairs, d_pairs, d_emb, emb_dim, d_pi, pi_dim, d_W1, d_b1, d_W2, d_b2, d_prob);
     TLC_HIP_CHECK(hipGetLastError());
