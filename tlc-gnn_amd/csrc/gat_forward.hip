@@ -25,8 +25,9 @@ __global__ __launch_bounds__(256) void gat_node_kernel(int n, const float* __res
     float* sWl = sm;                       // [C][c_in]
     float* sWij = sm + C * c_in;           // [C][2C]
     float* sXl = sWij + C * 2 * C;         // [256/C nodes][C]
-    for (int t = threadIdx.x; t < C * c_in; t += 256) sWl[t] = Wl[t];
-    for (int t = threadIdx.x; t < C * 2 * C; t += 256) sWij[t] = Wij[t];
+    // transposed in LDS: the C lanes of a node read C consecutive words per k (row-major [c][k] put all of them on one bank)
+    for (int t = threadIdx.x; t < C * c_in; t += 256) { const int c = t / c_in, k = t - c * c_in; sWl[k * C + c] = Wl[t]; }
+    for (int t = threadIdx.x; t < C * 2 * C; t += 256) { const int c = t / (2 * C), k = t - c * 2 * C; sWij[k * C + c] = Wij[t]; }
     __syncthreads();
     constexpr int NPB = 256 / C;           // nodes per block
     const int ln = threadIdx.x / C, c = threadIdx.x % C;
@@ -35,8 +36,7 @@ __global__ __launch_bounds__(256) void gat_node_kernel(int n, const float* __res
         float xl = 0.0f;
         if (i < n) {
             const float* xr = X + (size_t)i * c_in;
-            const float* wr = sWl + c * c_in;
-            for (int k = 0; k < c_in; ++k) xl += wr[k] * xr[k];
+            for (int k = 0; k < c_in; ++k) xl += sWl[k * C + c] * xr[k];
         }
         sXl[ln * C + c] = xl;
         // alpha = (x_l * att_l).sum(-1)  (gat_conv.py:135): reduce over the C lanes of this node
@@ -46,12 +46,11 @@ __global__ __launch_bounds__(256) void gat_node_kernel(int n, const float* __res
         __syncthreads();
         if (i < n) {
             const float* xs = sXl + ln * C;
-            const float* wr = sWij + c * 2 * C;
             float p = 0.0f, q = 0.0f;
 #pragma unroll 8
             for (int k = 0; k < C; ++k) {
-                p += wr[k] * xs[k];          // target half:  x_i
-                q += wr[C + k] * xs[k];      // source half:  x_j
+                p += sWij[k * C + c] * xs[k];          // target half:  x_i
+                q += sWij[(C + k) * C + c] * xs[k];    // source half:  x_j
             }
             float* w = work + (size_t)i * (3 * C + 1);
             w[c] = xl;
