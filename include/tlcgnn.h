@@ -197,10 +197,12 @@ int tlc_scatter_f32(int64_t n_src, const int64_t* d_index, const float* d_src, i
                     float* d_out, int32_t* d_count_work, void* stream);
 
 /* Edge head of Teacher_Model.forward (Teacher_model.py:54-59): for every non-self-loop edge e=(s,t):
- *   pd[e] = W6 @ prelu(W5 @ [x[s] || x[t]] + b5) + b6   -> float32[n_edges,2] */
+ *   pd[e] = W6 @ prelu(W5 @ [x[s] || x[t]] + b5) + b6   -> float32[n_edges,2]
+ * d_work (optional, float32[(n_nodes + c) * 2 * hidden]): with it the first layer is computed per node on the MFMA GEMM
+ * (W5[:, :c] x_s + W5[:, c:] x_t) and only gathered per edge; NULL: one 2c x hidden product per edge. */
 int tlc_edge_head_fwd(int64_t n_edges, const int32_t* d_src, const int32_t* d_dst, const float* d_X,
                       int32_t c, const float* d_W5, const float* d_b5, int32_t hidden, float prelu_slope,
-                      const float* d_W6, const float* d_b6, float* d_pd, void* stream);
+                      const float* d_W6, const float* d_b6, float* d_pd, int32_t n_nodes, float* d_work, void* stream);
 
 #ifdef __cplusplus
 }

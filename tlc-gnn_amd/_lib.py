@@ -88,7 +88,7 @@ def lib():
                                           C.c_void_p, C.c_void_p]
             L.tlc_edge_head_fwd.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
-                                            C.c_void_p]
+                                            C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 

@@ -140,6 +140,45 @@ __global__ __launch_bounds__(256) void edge_head_kernel(long long n_edges, const
     pd[2 * e + 1] = o1;
 }
 
+// The edge head per NODE first: lin5([x_s || x_t]) = W5[:, :c] x_s + W5[:, c:] x_t, so U = X @ W5[:, :c]^T and V = X @ W5[:, c:]^T
+// are computed once per node on the MFMA GEMM (a molecule batch has as many nodes as edges, but every node is the endpoint of
+// several edges, and a 32 x 64 product per EDGE on the vector ALU was 0.34 ms of a 1 ms PDGNN forward); the per-edge kernel
+// then gathers two rows of 2*hidden floats, adds, applies b5 / PReLU and the 2 x hidden output layer.
+__global__ void edge_head_pack_kernel(int c, int hidden, const float* __restrict__ W5, float* __restrict__ Bt) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;               // Bt[k][j], k < c, j < 2*hidden
+    if (t >= c * 2 * hidden) return;
+    const int k = t / (2 * hidden), j = t - k * 2 * hidden;
+    Bt[t] = j < hidden ? W5[(size_t)j * 2 * c + k] : W5[(size_t)(j - hidden) * 2 * c + c + k];
+}
+__global__ __launch_bounds__(256) void edge_head_gather_kernel(long long n_edges, const int* __restrict__ src, const int* __restrict__ dst,
+                                                               const float* __restrict__ UV, int hidden, const float* __restrict__ b5,
+                                                               float slope, const float* __restrict__ W6, const float* __restrict__ b6,
+                                                               float* __restrict__ pd) {
+    extern __shared__ float sm[];                                      // [b5 (hidden) | W6 (2*hidden)]
+    for (int t = threadIdx.x; t < hidden; t += 256) sm[t] = b5[t];
+    for (int t = threadIdx.x; t < 2 * hidden; t += 256) sm[hidden + t] = W6[t];
+    __syncthreads();
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_edges) return;
+    const float4* us = reinterpret_cast<const float4*>(UV + (size_t)src[e] * 2 * hidden);
+    const float4* vd = reinterpret_cast<const float4*>(UV + (size_t)dst[e] * 2 * hidden + hidden);
+    float o0 = b6[0], o1 = b6[1];
+    for (int h4 = 0; h4 < hidden / 4; ++h4) {
+        const float4 a = us[h4], b = vd[h4];
+        float v[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int h = 4 * h4 + q;
+            float t = v[q] + sm[h];
+            t = t > 0.0f ? t : slope * t;                              // F.prelu(x, 0.1) (Teacher_model.py:57)
+            o0 += sm[hidden + h] * t;
+            o1 += sm[2 * hidden + h] * t;
+        }
+    }
+    pd[2 * e] = o0;
+    pd[2 * e + 1] = o1;
+}
+
 template <int C>
 int launch_gat(int n, const int* rowptr, const int* src, const float* X, int c_in, const float* Wl, const float* att,
                const float* Wij, const float* bias, float slope, float* work, float* out, hipStream_t s) {
@@ -236,10 +275,25 @@ extern "C" int tlc_gat_layer_fwd(int32_t n_nodes, const int32_t* d_rowptr, const
 
 extern "C" int tlc_edge_head_fwd(int64_t n_edges, const int32_t* d_src, const int32_t* d_dst, const float* d_X, int32_t c,
                                  const float* d_W5, const float* d_b5, int32_t hidden, float prelu_slope, const float* d_W6,
-                                 const float* d_b6, float* d_pd, void* stream) {
+                                 const float* d_b6, float* d_pd, int32_t n_nodes, float* d_work, void* stream) {
     TLC_REQUIRE(n_edges >= 0 && c > 0 && hidden > 0, "bad sizes");
     if (n_edges == 0) return TLC_OK;
     TLC_REQUIRE(d_src && d_dst && d_X && d_W5 && d_b5 && d_W6 && d_b6 && d_pd, "null pointer");
+    if (d_work && n_nodes > 0 && hidden % 4 == 0 && 2 * hidden <= 128) {
+        // per-node projections U | V (work[0 .. n_nodes * 2 * hidden)) on the MFMA GEMM, then the per-edge gather
+        float* d_UV = d_work;
+        float* d_Bt = d_work + (size_t)n_nodes * 2 * hidden;
+        hipLaunchKernelGGL(edge_head_pack_kernel, dim3((unsigned)((c * 2 * hidden + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c,
+                           hidden, d_W5, d_Bt);
+        TLC_HIP_CHECK(hipGetLastError());
+        int rc = tlc_gemm_f32(n_nodes, 2 * hidden, c, d_X, d_Bt, nullptr, 0, d_UV, stream);
+        if (rc != TLC_OK) return rc;
+        hipLaunchKernelGGL(edge_head_gather_kernel, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 3 * (size_t)hidden * sizeof(float),
+                           (hipStream_t)stream, (long long)n_edges, d_src, d_dst, (const float*)d_UV, hidden, d_b5, prelu_slope, d_W6,
+                           d_b6, d_pd);
+        TLC_HIP_CHECK(hipGetLastError());
+        return TLC_OK;
+    }
     const size_t lds = ((size_t)hidden * 2 * c + 2 * (size_t)hidden) * sizeof(float);
     TLC_REQUIRE(lds <= 64 * 1024, "edge head weights do not fit LDS");
     hipLaunchKernelGGL(edge_head_kernel, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), lds, (hipStream_t)stream,

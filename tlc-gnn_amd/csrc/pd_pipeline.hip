@@ -1599,8 +1599,8 @@ __global__ __launch_bounds__(W) void tlc_pdf_tier_kernel(TlcPdfParams p) {
 __global__ void tlc_pdf_bin_kernel(int n_graphs, const long long* node_offs, const long long* edge_offs, int* tier_count,
                                    int* tier_list, int* counts) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_graphs) return;
-    const long long n = node_offs[g + 1] - node_offs[g], m = edge_offs[g + 1] - edge_offs[g];
+    const bool live = g < n_graphs;
+    const long long n = live ? node_offs[g + 1] - node_offs[g] : 0, m = live ? edge_offs[g + 1] - edge_offs[g] : 0;
     int tier = TLC_TIER_HUGE;
     if (n <= 0) tier = -1;
     else if (n > TLC_MAX_SUBGRAPH_NODES || m > TLC_MAX_SUBGRAPH_EDGES) {
@@ -1611,9 +1611,17 @@ __global__ void tlc_pdf_bin_kernel(int n_graphs, const long long* node_offs, con
     else if (n <= TLC_S_NMAX && m <= TLC_S_MMAX) tier = TLC_TIER_SMALL;
     else if (n <= TLC_M_NMAX && m <= TLC_M_MMAX) tier = TLC_TIER_MEDIUM;
     else if (n <= TLC_L_NMAX && m <= TLC_L_MMAX) tier = TLC_TIER_LARGE;
-    if (tier >= 0) {
-        const int pos = atomicAdd(&tier_count[tier], 1);
-        tier_list[(size_t)tier * n_graphs + pos] = g;
+    // wave-aggregated append: one returning atomic per wavefront and tier (one per graph on the same counter is served at
+    // ~90/us: 8 192 molecule graphs took 96 us to bin)
+#pragma unroll
+    for (int tt = 0; tt <= TLC_TIER_HUGE; ++tt) {
+        const unsigned long long mk = __ballot(tier == tt);
+        if (mk == 0ull) continue;
+        int base = 0;
+        const int leader = __builtin_ctzll(mk);
+        if (tlc_lane() == leader) base = atomicAdd(&tier_count[tt], __popcll(mk));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if (tier == tt) tier_list[(size_t)tt * n_graphs + base + __popcll(mk & tlc_lanemask_lt())] = g;
     }
 }
 

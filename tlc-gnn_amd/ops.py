@@ -114,9 +114,12 @@ def edge_head(src, dst, x, w5, b5, prelu_slope, w6, b6, out=None):
     E = src.numel()
     if out is None:
         out = torch.empty((E, 2), dtype=torch.float32, device=x.device)
-    rc = _lib.lib().tlc_edge_head_fwd(C.c_int64(E), _lib.ptr(src), _lib.ptr(dst), _lib.ptr(x), C.c_int32(x.shape[1]),
-                                      _lib.ptr(_f32(w5)), _lib.ptr(_f32(b5)), C.c_int32(w5.shape[0]), C.c_float(prelu_slope),
-                                      _lib.ptr(_f32(w6)), _lib.ptr(_f32(b6)), _lib.ptr(out), _lib.stream_ptr())
+    n, c, hidden = x.shape[0], x.shape[1], w5.shape[0]
+    work = torch.empty((n + c) * 2 * hidden, dtype=torch.float32, device=x.device)      # per-node projections + packed W5
+    rc = _lib.lib().tlc_edge_head_fwd(C.c_int64(E), _lib.ptr(src), _lib.ptr(dst), _lib.ptr(x), C.c_int32(c),
+                                      _lib.ptr(_f32(w5)), _lib.ptr(_f32(b5)), C.c_int32(hidden), C.c_float(prelu_slope),
+                                      _lib.ptr(_f32(w6)), _lib.ptr(_f32(b6)), _lib.ptr(out), C.c_int32(n), _lib.ptr(work),
+                                      _lib.stream_ptr())
     _lib.check(rc, "tlc_edge_head_fwd")
     return out
 
