@@ -182,7 +182,8 @@ int tlc_lp_decode_fused(int64_t n_pairs, const int32_t* d_pairs, const float* d_
  *   m = leaky_relu(Wij @ [x_i || x_j]) * a;  out_i = [ sum m || (min m + max m) ] + bias  (:166-172,202-216)
  *   d_X float32[n, c_in]; d_Wl float32[c_out, c_in]; d_att float32[c_out]; d_Wij float32[c_out, 2*c_out];
  *   d_bias float32[2*c_out]; d_out float32[n, 2*c_out]; prelu_slope < 0 disables the fused PReLU.
- *   d_work float32[n * (3*c_out + 1)]: caller-provided scratch (per node: x_l, the two lin_ij half-projections, alpha).
+ *   d_work float32[n * (3*c_out + 4) + c_in*c_out + c_out*(2*c_out + 4)]: caller-provided scratch (per node: x_l, the two
+ *   lin_ij half-projections, alpha; then the layer's weights packed for the MFMA GEMM).
  *   c_out in {8,16,32,64}. */
 int tlc_gat_layer_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_src,
                       const float* d_X, int32_t c_in, int32_t c_out,

@@ -65,34 +65,74 @@ __global__ __launch_bounds__(256) void gat_node_kernel(int n, const float* __res
 // kernel 2: one group of C lanes per target node
 template <int C>
 __global__ __launch_bounds__(256) void gat_aggregate_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ src,
-                                                            const float* __restrict__ work, const float* __restrict__ bias,
+                                                            const float* __restrict__ pqa, int S, const float* __restrict__ bias,
                                                             float prelu_slope, float* __restrict__ out) {
-    constexpr int S = 3 * C + 1;
+    // pqa: per node [P (C) | Q (C) | alpha (1)] with row stride S
     const int i = (blockIdx.x * 256 + threadIdx.x) / C, c = threadIdx.x % C;
     if (i >= n) return;
     const int b = rowptr[i], e = rowptr[i + 1];
-    const float ai = work[(size_t)i * S + 3 * C];
-    const float pi = work[(size_t)i * S + C + c];
+    const float ai = pqa[(size_t)i * S + 2 * C];
+    const float pi = pqa[(size_t)i * S + c];
     // softmax over the incoming edges (torch_geometric.utils.softmax: subtract the segment max)
     float mx = -INFINITY;
-    for (int j = b; j < e; ++j) {
-        float t = work[(size_t)src[j] * S + 3 * C] + ai;      // alpha_j + alpha_i  (gat_conv.py:184)
-        t = t > 0.0f ? t : 0.2f * t;                          // leaky_relu(negative_slope=0.2) (:185)
-        mx = t > mx ? t : mx;
-    }
     float den = 0.0f, sum = 0.0f, mn = INFINITY, mxv = -INFINITY;
-    for (int j = b; j < e; ++j) {
-        const float* wj = work + (size_t)src[j] * S;
-        float t = wj[3 * C] + ai;
-        t = t > 0.0f ? t : 0.2f * t;
-        const float ex = expf(t - mx);
-        den += ex;
-        float m = pi + wj[2 * C + c];                         // lin_ij([x_i || x_j]) (:193-194)
-        m = m > 0.0f ? m : 0.2f * m;                          // leaky_relu (:195)
-        m *= ex;                                              // * alpha (:198-200), normalised below
-        sum += m;
-        mn = m < mn ? m : mn;
-        mxv = m > mxv ? m : mxv;
+    if (e - b <= 8) {
+        // the usual case (molecules, vicinity graphs: a handful of neighbours + the self loop): all source ids, then all
+        // alphas and Q values, are requested together -- one dependent round trip each instead of one per edge and pass
+        int sj[8];
+        float tj[8], qj[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sj[q] = b + q < e ? src[b + q] : -1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            tj[q] = 0.0f; qj[q] = 0.0f;
+            if (sj[q] >= 0) {
+                const float* wj = pqa + (size_t)sj[q] * S;
+                tj[q] = wj[2 * C];
+                qj[q] = wj[C + c];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (sj[q] >= 0) {
+                float t = tj[q] + ai;                         // alpha_j + alpha_i  (gat_conv.py:184)
+                t = t > 0.0f ? t : 0.2f * t;                  // leaky_relu(negative_slope=0.2) (:185)
+                tj[q] = t;
+                mx = t > mx ? t : mx;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (sj[q] >= 0) {
+                const float ex = expf(tj[q] - mx);
+                den += ex;
+                float m = pi + qj[q];                         // lin_ij([x_i || x_j]) (:193-194)
+                m = m > 0.0f ? m : 0.2f * m;                  // leaky_relu (:195)
+                m *= ex;                                      // * alpha (:198-200), normalised below
+                sum += m;
+                mn = m < mn ? m : mn;
+                mxv = m > mxv ? m : mxv;
+            }
+        }
+    } else {
+        for (int j = b; j < e; ++j) {
+            float t = pqa[(size_t)src[j] * S + 2 * C] + ai;
+            t = t > 0.0f ? t : 0.2f * t;
+            mx = t > mx ? t : mx;
+        }
+        for (int j = b; j < e; ++j) {
+            const float* wj = pqa + (size_t)src[j] * S;
+            float t = wj[2 * C] + ai;
+            t = t > 0.0f ? t : 0.2f * t;
+            const float ex = expf(t - mx);
+            den += ex;
+            float m = pi + wj[C + c];
+            m = m > 0.0f ? m : 0.2f * m;
+            m *= ex;
+            sum += m;
+            mn = m < mn ? m : mn;
+            mxv = m > mxv ? m : mxv;
+        }
     }
     float o_sum = 0.0f, o_mm = 0.0f;                          // empty segment: scatter leaves zeros
     if (e > b) {
@@ -179,17 +219,64 @@ __global__ __launch_bounds__(256) void edge_head_gather_kernel(long long n_edges
     pd[2 * e + 1] = o1;
 }
 
+// weights of one layer packed for the MFMA GEMM path: Bt1[k][c] = Wl[c][k]  (c_in x C);  Bt2[k][j] (C x (2C+4), rows a multiple
+// of 16 bytes so that the GEMM takes its vector path): j < C: Wij[j][k] (target half), C <= j < 2C: Wij[j-C][C+k] (source
+// half), j = 2C: att[k], then zeros
+__global__ void gat_pack_kernel(int C, int c_in, const float* __restrict__ Wl, const float* __restrict__ att,
+                                const float* __restrict__ Wij, float* __restrict__ Bt1, float* __restrict__ Bt2) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < c_in * C) { const int k = t / C, c = t - k * C; Bt1[t] = Wl[(size_t)c * c_in + k]; }
+    const int N2 = 2 * C + 4;
+    if (t < C * N2) {
+        const int k = t / N2, j = t - k * N2;
+        Bt2[t] = j < C ? Wij[(size_t)j * 2 * C + k] : (j < 2 * C ? Wij[(size_t)(j - C) * 2 * C + C + k] : (j == 2 * C ? att[k] : 0.0f));
+    }
+}
+// x_l = X Wl^T for a narrow input (c_in < 16, e.g. the filtration value alone): one thread per (node, channel)
+__global__ void gat_xl_narrow_kernel(int n, int C, int c_in, const float* __restrict__ X, const float* __restrict__ Wl,
+                                     float* __restrict__ XL) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n * C) return;
+    const int i = (int)(t / C), c = (int)(t - (long long)i * C);
+    float a = 0.0f;
+    for (int k = 0; k < c_in; ++k) a += Wl[(size_t)c * c_in + k] * X[(size_t)i * c_in + k];
+    XL[t] = a;
+}
+
 template <int C>
 int launch_gat(int n, const int* rowptr, const int* src, const float* X, int c_in, const float* Wl, const float* att,
                const float* Wij, const float* bias, float slope, float* work, float* out, hipStream_t s) {
+    const unsigned agrid = (unsigned)(((size_t)n * C + 255) / 256);
+    if (2 * C + 4 <= 128 && C % 4 == 0) {
+        // x_l = X Wl^T and [P | Q | alpha] = x_l [Wij_t^T | Wij_s^T | att] as two products on the f32 MFMA (per node on the
+        // vector ALU this was 95 us of a layer; the products are 2 x ~15 us)
+        float* XL = work;
+        float* PQA = work + (size_t)n * C;
+        float* Bt1 = work + (size_t)n * (3 * C + 4);
+        float* Bt2 = Bt1 + (size_t)c_in * C;
+        const int N2 = 2 * C + 4;
+        const int np = std::max(c_in * C, C * N2);
+        hipLaunchKernelGGL(gat_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, C, c_in, Wl, att, Wij, Bt1, Bt2);
+        TLC_HIP_CHECK(hipGetLastError());
+        int rc = TLC_OK;
+        if (c_in >= 16 && c_in % 4 == 0) rc = tlc_gemm_f32(n, C, c_in, X, Bt1, nullptr, 0, XL, s);
+        else hipLaunchKernelGGL(gat_xl_narrow_kernel, dim3(agrid), dim3(256), 0, s, n, C, c_in, X, Wl, XL);
+        if (rc != TLC_OK) return rc;
+        rc = tlc_gemm_f32(n, N2, C, XL, Bt2, nullptr, 0, PQA, s);
+        if (rc != TLC_OK) return rc;
+        hipLaunchKernelGGL(gat_aggregate_kernel<C>, dim3(agrid), dim3(256), 0, s, n, rowptr, src, (const float*)PQA, N2, bias,
+                           slope, out);
+        TLC_HIP_CHECK(hipGetLastError());
+        return TLC_OK;
+    }
     const size_t lds = ((size_t)C * c_in + (size_t)C * 2 * C + 256) * sizeof(float);
     if (lds > 64 * 1024) { tlc_set_error("tlc_gat_layer_fwd: c_in too large for the LDS-staged weights"); return TLC_ERR_UNSUPPORTED; }
     constexpr int NPB = 256 / C;
     int grid = (n + NPB - 1) / NPB;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(gat_node_kernel<C>, dim3(grid), dim3(256), lds, s, n, X, c_in, Wl, att, Wij, work);
-    hipLaunchKernelGGL(gat_aggregate_kernel<C>, dim3((unsigned)(((size_t)n * C + 255) / 256)), dim3(256), 0, s, n, rowptr, src,
-                       (const float*)work, bias, slope, out);
+    hipLaunchKernelGGL(gat_aggregate_kernel<C>, dim3(agrid), dim3(256), 0, s, n, rowptr, src, (const float*)(work + C), 3 * C + 1, bias,
+                       slope, out);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }

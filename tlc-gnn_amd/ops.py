@@ -98,7 +98,7 @@ def gat_layer(rowptr, src, x, wl, att, wij, bias, prelu_slope=-1.0, out=None):
     c_out = wl.shape[0]
     if out is None:
         out = torch.empty((n, 2 * c_out), dtype=torch.float32, device=x.device)
-    work = torch.empty(max(n, 1) * (3 * c_out + 1), dtype=torch.float32, device=x.device)
+    work = torch.empty(max(n, 1) * (3 * c_out + 4) + c_in * c_out + c_out * (2 * c_out + 4), dtype=torch.float32, device=x.device)
     rc = _lib.lib().tlc_gat_layer_fwd(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(src), _lib.ptr(x), C.c_int32(c_in),
                                       C.c_int32(c_out), _lib.ptr(_f32(wl)), _lib.ptr(_f32(att).reshape(-1)), _lib.ptr(_f32(wij)),
                                       _lib.ptr(_f32(bias)), C.c_float(prelu_slope), _lib.ptr(work), _lib.ptr(out),

@@ -1,0 +1,6 @@
+"""PDGNN forward vs exact PD on HIV-shaped molecules (bench.py's auxiliary block on its own) -- development aid."""
+import sys
+import torch
+sys.path.insert(0, ".")
+import bench
+print(bench.pdgnn_aux(torch, torch.device("cuda:0")))
