@@ -256,10 +256,10 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     CK(hipMemcpy(g->d_rowptr, h_rowptr, (size_t)(n_nodes + 1) * sizeof(int), hipMemcpyHostToDevice));
     CK(hipMemcpy(g->d_col, h_col, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
     CK(hipMemcpy(g->d_w, h_w, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
-    CK(hipMalloc(&g->d_ctl, (64 + 1024) * sizeof(int)));   // counters, then the scan's per-block flags
+    CK(hipMalloc(&g->d_ctl, (64 + 1024 + 8) * sizeof(int)));   // counters, the scan's per-block flags, 4 x u64 statistics
+    g->d_stats = reinterpret_cast<unsigned long long*>(g->d_ctl + 64 + 1024);      // (8-byte aligned: hipMalloc is 256-byte aligned)
     CK(hipMalloc(&g->d_block_sums, 1024 * sizeof(long long)));
     CK(hipMalloc(&g->d_totals, 2 * sizeof(long long)));
-    CK(hipMalloc(&g->d_stats, 4 * sizeof(unsigned long long)));
     CK(hipHostMalloc((void**)&g->h_sync, sizeof(HostSync), hipHostMallocMapped | hipHostMallocCoherent));
     memset(g->h_sync, 0, sizeof(HostSync));
     CK(hipHostGetDevicePointer((void**)&g->h_sync_dev, g->h_sync, 0));
@@ -296,7 +296,7 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     hipDeviceSynchronize();
     hipFree(g->d_rowptr); hipFree(g->d_col); hipFree(g->d_w);
     hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
-    hipFree(g->d_ctl); hipFree(g->d_block_sums); hipFree(g->d_totals); hipFree(g->d_stats);
+    hipFree(g->d_ctl); hipFree(g->d_block_sums); hipFree(g->d_totals);
     if (g->h_sync) hipHostFree(g->h_sync);
     hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->S_dir); hipFree(g->S_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch); hipFree(g->handoff); hipFree(g->d_phase);
     hipFree(g->d_ball_ub[0]); hipFree(g->d_ball_ub[1]); hipFree(g->d_cand_list); hipFree(g->d_early_list); hipFree(g->E_dir); hipFree(g->E_lw);
@@ -340,8 +340,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     if ((rc = ensure_pairs(g, (size_t)n_pairs)) != TLC_OK) return rc;
     if ((rc = ensure_vic_scratch(g, hop)) != TLC_OK) return rc;
     if ((rc = ensure_small(g, (size_t)n_pairs)) != TLC_OK) return rc;
-    TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl, 0, (64 + 1024) * sizeof(int), s));
-    TLC_HIP_CHECK(hipMemsetAsync(g->d_stats, 0, 4 * sizeof(unsigned long long), s));
+    TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl, 0, (64 + 1024 + 8) * sizeof(int), s));       // control words, scan flags, statistics
 
     TlcVicParams vp;
     memset(&vp, 0, sizeof(vp));
@@ -421,7 +420,6 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         ep.early_list = g->d_early_list; ep.early_count = d_early_count; ep.early_cap = TLC_EARLY_SLOTS;
         ep.early_dir = g->E_dir; ep.early_lw = g->E_lw;
         ep.started = d_cand_started;
-        TLC_HIP_CHECK(hipEventRecord(g->ev_sel, es));
         hipLaunchKernelGGL((tlc_vicinity_kernel<false, 512>), dim3(TLC_EARLY_WG), dim3(512), g->vic_lds, es, ep);
         TLC_HIP_CHECK(hipGetLastError());
         TLC_HIP_CHECK(hipEventRecord(g->ev_early, es));
