@@ -96,7 +96,7 @@ struct tlc_graph {
     int* d_early_list;
     unsigned* E_dir;
     double* E_lw;
-    hipEvent_t ev_early, ev_sel, ev_scan;
+    hipEvent_t ev_early, ev_scan;
     unsigned char* handoff;        // hand-off slots between the tier kernels and tlc_pd_swap_kernel
     size_t cap_handoff;
     size_t huge_stride;
@@ -274,7 +274,6 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     }
     CK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&g->ev_early, hipEventDisableTiming));
-    CK(hipEventCreateWithFlags(&g->ev_sel, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&g->ev_scan, hipEventDisableTiming));
     for (int k = 0; k < 16; ++k) CK(hipEventCreate(&g->ev_t[k]));
 #undef CK
@@ -301,7 +300,6 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->S_dir); hipFree(g->S_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch); hipFree(g->handoff); hipFree(g->d_phase);
     hipFree(g->d_ball_ub[0]); hipFree(g->d_ball_ub[1]); hipFree(g->d_cand_list); hipFree(g->d_early_list); hipFree(g->E_dir); hipFree(g->E_lw);
     if (g->ev_early) hipEventDestroy(g->ev_early);
-    if (g->ev_sel) hipEventDestroy(g->ev_sel);
     if (g->ev_scan) hipEventDestroy(g->ev_scan);
     for (int k = 0; k < TLC_N_SIDE; ++k) {
         if (g->side[k]) hipStreamDestroy(g->side[k]);
