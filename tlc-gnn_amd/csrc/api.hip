@@ -45,7 +45,7 @@ struct HostSync {
     int tier_count[TLC_N_TIERS];
     int pad[2];
     unsigned long long stats[2];
-    // written by tlc_publish_sizes straight into this (pinned, device-mapped) block; seq last, after a system-scope fence
+    // written by tlc_scan_bin straight into this (pinned, device-mapped) block; seq last, after a system-scope fence
     volatile long long pub_total;
     volatile int pub_tier[TLC_N_TIERS];
     volatile int pub_early;

@@ -79,7 +79,7 @@ struct TlcVicParams {
     int fill_count;
     const int* work_count_dev;   // fill_mode 1: the list length lives on the device (clamped to fill_count); null: fill_count
     int scratch_base_slot;       // first scratch slot of this launch (concurrent launches use disjoint slot ranges)
-    // work distribution: null = pairs statically strided over the workgroups; else chunks of work_chunk consecutive pairs are
+    // work distribution: null = pairs statically strided over the workgroups; else chunks of work_chunk (strided) pairs are
     // taken from this counter (zeroed per launch), which evens out the heavy-tailed per-pair cost
     int* work_counter;
     int work_chunk;

@@ -1,5 +1,5 @@
 // vicinity_dev.h -- device code of the vicinity pass (S = ball(u) & ball(v), induced subgraph), shared by
-// vicinity.hip (COUNT / FILL kernels) and pd_pipeline.hip (the LARGE tier extracts its own vicinities).
+// vicinity.hip (COUNT / FILL kernels; kept in a header so that a tier kernel could extract a vicinity itself).
 #pragma once
 #include "tlc_common.h"
 #include "tlc_kernels.h"
@@ -338,10 +338,9 @@ __device__ __forceinline__ void mark_two_balls_hop2(unsigned* bitsU, unsigned* b
     __syncthreads();
 }
 
-// One pair: S = ball(u) & ball(v), the induced rows, and (FILL, or COUNT for a SMALL-tier vicinity) the packed subgraph.
-// `lds` = the workgroup's bitmap area (TlcVicParams::nw words x 2.5 + 24), `slot` = its global scratch slot.  Called by
-// tlc_vicinity_kernel and, for the LARGE tier, by the PD kernel itself (pd_pipeline.hip: a LARGE workgroup extracts its own
-// vicinity, so the tier that is the critical path of a batch does not wait for a separate FILL launch).
+// One pair: S = ball(u) & ball(v), the induced rows, and (FILL; or COUNT for a SMALL-tier vicinity -> its fixed slot, a MID / MEDIUM one -> a bump-allocated arena offset, a LARGE one in the
+// early pass -> a slot of the early arena) the packed subgraph.
+// `lds` = the workgroup's bitmap area (TlcVicParams::nw words x 2.5 + 24), `slot` = its global scratch slot.
 template <bool FILL, int BW>
 __device__ __forceinline__ void vicinity_pair(const TlcVicParams& p, int i, unsigned* lds, int* slot) {
     const int nw4 = (p.nw + 3) & ~3;          // bitmaps padded to 16 bytes

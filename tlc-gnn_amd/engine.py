@@ -161,7 +161,7 @@ TIER_LIMITS = [("pd_tier_small", 64, 128), ("pd_tier_mid", 128, 256), ("pd_tier_
 
 
 def tier_of(n, m2):
-    """tier name per pair from (|S|, induced directed entries), mirroring tlc_scan_down; '' for pairs finished early."""
+    """tier name per pair from (|S|, induced directed entries), mirroring tlc_scan_bin; '' for pairs finished early."""
     n = np.asarray(n)
     m = np.asarray(m2) // 2
     out = np.full(n.shape, "pd_tier_huge", dtype=object)
