@@ -40,6 +40,36 @@ def test_pi_raster_goldens(torch_cuda):
         assert np.abs(o - r).max() <= 1e-11 * max(1.0, np.abs(r).max())
 
 
+def test_pi_raster_ragged_batch_vs_oracle(torch_cuda):
+    """Lane-per-point raster: empty diagrams, lengths around the 16-lane round and the whole-wavefront threshold (512),
+    points outside [0,1]^2 (erfc branch), below the diagonal (weight 0) and with persistence > 1 (weight 1), every res."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine
+    from oracle import oracle
+    rs = np.random.RandomState(11)
+    lens = [0, 1, 15, 16, 17, 0, 63, 64, 65, 511, 512, 513, 2000, 3, 0, 700, 31, 5000] + rs.randint(0, 120, size=203).tolist()
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    k = int(offs[-1])
+    b = rs.uniform(-0.5, 1.5, size=k)
+    pts = np.stack([b, b + rs.uniform(-0.3, 2.5, size=k)], 1)
+    inside = rs.rand(k) < 0.6                                  # most points as the pipeline produces them
+    pts[inside, 0] = rs.rand(inside.sum())
+    pts[inside, 1] = pts[inside, 0] + rs.rand(inside.sum()) * (1 - pts[inside, 0])
+    for res in (1, 2, 3, 4, 5, 6, 7, 8):
+        ref = oracle.pi_raster(offs, pts, res)
+        out = engine.pi_raster(_dev(torch, offs, torch.int64), _dev(torch, pts, torch.float64), res).cpu().numpy()
+        assert out.shape == ref.shape
+        empty = np.diff(offs) == 0
+        assert np.all(out[empty] == 0.0)
+        assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), res
+        nz = np.abs(ref) > 1e-9
+        assert rel_err(out[nz], ref[nz]).max() < 1e-8, res
+    # a batch that is not a multiple of four diagrams, one diagram only, and a strided grid is not needed below 2^24 diagrams
+    for B in (1, 2, 3, 5):
+        o = engine.pi_raster(_dev(torch, offs[: B + 1], torch.int64), _dev(torch, pts[: offs[B]] if offs[B] else pts[:1], torch.float64), 5).cpu().numpy()
+        assert np.abs(o - oracle.pi_raster(offs[: B + 1], pts[: max(int(offs[B]), 1)], 5)).max() <= 1e-11
+
+
 @pytest.mark.parametrize("fork", ["tlc", "kd"])
 def test_pd_from_filtration_golden(torch_cuda, fork):
     torch = torch_cuda

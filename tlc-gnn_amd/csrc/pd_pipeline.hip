@@ -1626,23 +1626,183 @@ __global__ void tlc_pdf_bin_kernel(int n_graphs, const long long* node_offs, con
 }
 
 // ======================================================================================================================
-// tlc_pi_raster: one wavefront per diagram, points streamed from HBM in table-sized batches.
+// tlc_pi_raster (PersistenceImager.transform, PersistenceImager.pyx:352-388): one LANE per diagram point.
+// Sixteen lanes share a diagram (four diagrams per wavefront; mean 41 points on the PubMed batch).  A lane evaluates the
+// 2*(res+1) normal CDFs of its point in registers, forms w * dPhi_b[i] and dPhi_p[j] (the factored form of the reference's
+// 4-term inclusion-exclusion) and accumulates its res^2 pixel terms in registers; the sixteen partial
+// images are folded with DPP butterflies on the vector ALU and stored as whole rows.  No LDS, no barrier: the former
+// table version (one lane per (point, grid line) into LDS, then one lane per pixel) spent 0.37 ms on 1.5 M points,
+// most of it in LDS round trips and in a wavefront that executed the erfc and the series branch of every table entry.
+// Diagrams of TLC_RASTER_BIG points or more are taken by the whole workgroup (256 lanes), one after the other.
+// Summation order: a lane adds its points in index order (stride 16, or 256 for the whole-workgroup case), the lanes are
+// folded in butterfly order and the four wavefronts in index order -- fixed for a given diagram length, so results are
+// reproducible.
 // ======================================================================================================================
-__global__ __launch_bounds__(64) void tlc_pi_raster_kernel(int n_dgms, const long long* __restrict__ offs,
-                                                           const double* __restrict__ pts, int res,
-                                                           double* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) double tbl[64 * 17];
-    const int tid = threadIdx.x;
-    for (int d = blockIdx.x; d < n_dgms; d += gridDim.x) {
-        const long long o = offs[d];
-        const int k = (int)(offs[d + 1] - o);
-        auto get = [&](int i, double& b, double& dd) {
-            b = pts[2 * (o + i)];
-            dd = pts[2 * (o + i) + 1];
-        };
-        const double acc = pi_stage<64, false, 64>(tbl, sizeof(tbl), get, 0, k, res, 0.0);
-        if (tid < res * res) out[(size_t)d * res * res + tid] = acc;
+#define TLC_RASTER_BIG 512
+
+// Normal CDF at the G grid lines g * step - base, all G Maclaurin series advanced together (independent chains: evaluated one
+// after the other inside per-value branches they were 12 x 19 dependent fp64 FMAs per point and the kernel ran at the FMA
+// latency).  Arguments beyond the series' range get 0 here and set `slow`; raster_point patches them with erfc.
+template <int G>
+__device__ __forceinline__ void raster_cdf_row(double base, double step, double (&c)[G], bool& slow) {
+    double z[G], t[G], a[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const double zz = ((double)g * step - base) * 0.70710678118654752440;
+        const bool in = fabs(zz) <= 0.95;
+        slow |= !in;
+        z[g] = in ? zz : 0.0;
+        t[g] = z[g] * z[g];
+        a[g] = 4.22140728880708822e-18;
+    }
+#define TLC_SERIES_TERM(C)                         \
+    _Pragma("unroll") for (int g = 0; g < G; ++g) a[g] = fma(a[g], t[g], (C));
+    TLC_SERIES_TERM(-8.03273501241577328e-17) TLC_SERIES_TERM(1.44832646435981379e-15) TLC_SERIES_TERM(-2.46682701026445706e-14)
+    TLC_SERIES_TERM(3.95542951645852569e-13) TLC_SERIES_TERM(-5.94779401363763541e-12) TLC_SERIES_TERM(8.35070279514723971e-11)
+    TLC_SERIES_TERM(-1.08922210371485731e-09) TLC_SERIES_TERM(1.31225329638028058e-08) TLC_SERIES_TERM(-1.45038522231504685e-07)
+    TLC_SERIES_TERM(1.45891690009337058e-06) TLC_SERIES_TERM(-1.32275132275132281e-05) TLC_SERIES_TERM(1.06837606837606838e-04)
+    TLC_SERIES_TERM(-7.57575757575757575e-04) TLC_SERIES_TERM(4.62962962962962937e-03) TLC_SERIES_TERM(-2.38095238095238082e-02)
+    TLC_SERIES_TERM(1.00000000000000006e-01) TLC_SERIES_TERM(-3.33333333333333315e-01) TLC_SERIES_TERM(1.0)
+#undef TLC_SERIES_TERM
+#pragma unroll
+    for (int g = 0; g < G; ++g) c[g] = fma(0.5 * 1.1283791670955126, z[g] * a[g], 0.5);     // same closing step as tlc_norm_cdf
+}
+
+// erfc for the grid lines whose argument lies beyond the series' range (c[0..G) birth lines, c[G..2G) persistence lines)
+__device__ __attribute__((noinline)) void raster_cdf_slow(double b, double pers, double step, int G, double* c) {
+#pragma unroll 1
+    for (int g = 0; g < 2 * G; ++g) {
+        const double x = (g < G) ? ((double)g * step - b) : ((double)(g - G) * step - pers);
+        const double z = x * 0.70710678118654752440;
+        if (!(fabs(z) <= 0.95)) c[g] = 0.5 * erfc(-z);
+    }
+}
+
+template <int RES>
+__device__ __forceinline__ void raster_point(double b, double d, double (&acc)[RES * RES]) {
+    const double pers = d - b;                                         // skew (:367-368)
+    const double wgt = pers < 0.0 ? 0.0 : (pers > 1.0 ? 1.0 : pers);   // linear_ramp (:9-30)
+    if (!(wgt != 0.0)) return;                                         // weight 0 (NaN stays in: it propagates as in the reference)
+    const double pixel = 1.0 / (double)RES;
+    const double step = ((1.0 + pixel) - 0.0) / (double)(RES + 1);     // _create_mesh (:302-314)
+    constexpr int G = RES + 1;
+    double cb[G], cp[G];                                               // _norm_cdf (:54-60) at the grid lines
+    bool slow = false;
+    raster_cdf_row<G>(b, step, cb, slow);
+    raster_cdf_row<G>(pers, step, cp, slow);
+    if (slow) {
+        // out of line, through scratch: the library's erfc inlined here costs the whole kernel 70 VGPRs (2 instead of 4
+        // wavefronts per SIMD) for a branch that diagrams inside [0,1]^2 never take
+        double cc[2 * G];
+#pragma unroll
+        for (int q = 0; q < G; ++q) { cc[q] = cb[q]; cc[G + q] = cp[q]; }
+        raster_cdf_slow(b, pers, step, G, cc);
+#pragma unroll
+        for (int q = 0; q < G; ++q) { cb[q] = cc[q]; cp[q] = cc[G + q]; }
+    }
+    double wb[RES], dp[RES];
+#pragma unroll
+    for (int g = 0; g < RES; ++g) {
+        wb[g] = wgt * (cb[g + 1] - cb[g]);
+        dp[g] = cp[g + 1] - cp[g];
+    }
+#pragma unroll
+    for (int i = 0; i < RES; ++i)
+#pragma unroll
+        for (int j = 0; j < RES; ++j) acc[i * RES + j] = fma(wb[i], dp[j], acc[i * RES + j]);
+}
+
+template <int RES>
+__global__ __launch_bounds__(256, (RES <= 5 ? 4 : (RES == 6 ? 3 : 2))) void tlc_pi_raster_kernel(int n_dgms, const long long* __restrict__ offs,
+                                                            const double* __restrict__ pts, double* __restrict__ out) {
+    constexpr int R2 = RES * RES;
+    __shared__ long long s_k[16], s_o[16];
+    __shared__ double s_red[4][R2];
+    __shared__ double s_t[4][64][17];
+    const int tid = threadIdx.x, lane = tlc_lane(), sub = lane & 15, slot = tid >> 4, wv = tid >> 6;
+    const double2* __restrict__ pts2 = reinterpret_cast<const double2*>(pts);
+    // a workgroup takes sixteen consecutive diagrams per iteration (block-uniform trip count: the long-diagram path has barriers)
+    for (long long base = (long long)blockIdx.x * 16; base < n_dgms; base += (long long)gridDim.x * 16) {
+        const long long d = base + slot;
+        long long o = 0, kl = 0;
+        if (d < n_dgms) { o = offs[d]; kl = offs[d + 1] - o; }
+        if (kl < 0) kl = 0;
+        const bool big = kl >= TLC_RASTER_BIG;
+        if (sub == 0) { s_k[slot] = kl; s_o[slot] = o; }
+        // ---- diagrams below TLC_RASTER_BIG points: sixteen lanes each ------------------------------------------------
+        {
+            const int k = big ? 0 : (int)kl;
+            int rounds = (k + 15) >> 4;
+            rounds = max(max(__builtin_amdgcn_readlane(rounds, 0), __builtin_amdgcn_readlane(rounds, 16)),
+                         max(__builtin_amdgcn_readlane(rounds, 32), __builtin_amdgcn_readlane(rounds, 48)));
+            double acc[R2];
+#pragma unroll
+            for (int q = 0; q < R2; ++q) acc[q] = 0.0;
+            double2 nxt = make_double2(0.0, 0.0);
+            if (sub < k) nxt = pts2[o + sub];
+            for (int r = 0; r < rounds; ++r) {
+                const int idx = r * 16 + sub;
+                const double2 bd = nxt;
+                if (idx + 16 < k) nxt = pts2[o + idx + 16];             // next round's point while this one is rasterised
+                if (idx < k) raster_point<RES>(bd.x, bd.y, acc);
+            }
+            // fold the sixteen partial images through LDS, sixteen pixels at a time: lane `sub` of a group sums pixel
+            // c*16 + sub over the group's lanes and stores it (one 128-byte store per group instead of 25 single-lane
+            // stores behind 100 DPP exchanges).  Rows of 17 doubles: writes and reads are bank-conflict free.
+#pragma unroll
+            for (int c = 0; c < (R2 + 15) / 16; ++c) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (c * 16 + q < R2) s_t[wv][lane][q] = acc[c * 16 + q];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (c * 16 + sub < R2) {
+                    const int l0 = lane & 48;
+                    double v0 = s_t[wv][l0][sub], v1 = s_t[wv][l0 + 1][sub], v2 = s_t[wv][l0 + 2][sub], v3 = s_t[wv][l0 + 3][sub];
+#pragma unroll
+                    for (int l = 4; l < 16; l += 4) {
+                        v0 += s_t[wv][l0 + l][sub];
+                        v1 += s_t[wv][l0 + l + 1][sub];
+                        v2 += s_t[wv][l0 + l + 2][sub];
+                        v3 += s_t[wv][l0 + l + 3][sub];
+                    }
+                    if (!big && d < n_dgms) out[(size_t)d * R2 + c * 16 + sub] = (v0 + v1) + (v2 + v3);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+        }
+        // ---- longer diagrams: the whole workgroup, one diagram after the other ---------------------------------------
         __syncthreads();
+        for (int g = 0; g < 16; ++g) {
+            const long long kg = s_k[g];
+            if (kg < TLC_RASTER_BIG) continue;                          // block-uniform
+            const long long og = s_o[g];
+            double acc[R2];
+#pragma unroll
+            for (int q = 0; q < R2; ++q) acc[q] = 0.0;
+            for (long long idx = tid; idx < kg; idx += 256) {
+                const double2 bd = pts2[og + idx];
+                raster_point<RES>(bd.x, bd.y, acc);
+            }
+#pragma unroll
+            for (int q = 0; q < R2; ++q) {
+                double v = acc[q];
+                v += tlc_lane_xor_f64<1>(v);
+                v += tlc_lane_xor_f64<2>(v);
+                v += tlc_lane_xor_f64<4>(v);
+                v += tlc_lane_xor_f64<8>(v);
+                v += tlc_lane_xor_f64<16>(v);
+                v += tlc_lane_xor_f64<32>(v);
+                if (lane == (q & 63)) s_red[wv][q] = v;
+            }
+            __syncthreads();
+            if (tid < R2) out[(size_t)(base + g) * R2 + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+            __syncthreads();
+        }
+        __syncthreads();                                                // s_k / s_o are rewritten by the next iteration
     }
 }
 
@@ -1773,10 +1933,28 @@ int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long
     return TLC_OK;
 }
 
+template <int RES>
+static void launch_pi_raster(int n_dgms, const long long* offs, const double* pts, double* out, hipStream_t s) {
+    // four diagrams per wavefront, four wavefronts per workgroup; the grid is capped and strided beyond 2^20 workgroups
+    long long blocks = ((long long)n_dgms + 15) / 16;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(tlc_pi_raster_kernel<RES>, dim3((unsigned)blocks), dim3(256), 0, s, n_dgms, offs, pts, out);
+}
+
 int tlc_launch_pi_raster(int n_dgms, const long long* offs, const double* pts, int res, double* out, void* stream) {
     if (n_dgms <= 0) return TLC_OK;
-    const int grid = n_dgms < 65536 ? n_dgms : 65536;
-    hipLaunchKernelGGL(tlc_pi_raster_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, n_dgms, offs, pts, res, out);
+    hipStream_t s = (hipStream_t)stream;
+    switch (res) {
+        case 1: launch_pi_raster<1>(n_dgms, offs, pts, out, s); break;
+        case 2: launch_pi_raster<2>(n_dgms, offs, pts, out, s); break;
+        case 3: launch_pi_raster<3>(n_dgms, offs, pts, out, s); break;
+        case 4: launch_pi_raster<4>(n_dgms, offs, pts, out, s); break;
+        case 5: launch_pi_raster<5>(n_dgms, offs, pts, out, s); break;
+        case 6: launch_pi_raster<6>(n_dgms, offs, pts, out, s); break;
+        case 7: launch_pi_raster<7>(n_dgms, offs, pts, out, s); break;
+        case 8: launch_pi_raster<8>(n_dgms, offs, pts, out, s); break;
+        default: tlc_set_error("res must be in 1..8"); return TLC_ERR_INVALID_ARG;
+    }
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }
