@@ -41,13 +41,13 @@ def test_pi_raster_goldens(torch_cuda):
 
 
 def test_pi_raster_ragged_batch_vs_oracle(torch_cuda):
-    """Lane-per-point raster: empty diagrams, lengths around the 16-lane round and the whole-wavefront threshold (512),
+    """Lane-per-point raster: empty diagrams, lengths around the 16-lane round, the whole-wavefront (96) and the whole-workgroup threshold (1024),
     points outside [0,1]^2 (erfc branch), below the diagonal (weight 0) and with persistence > 1 (weight 1), every res."""
     torch = torch_cuda
     from tlc_gnn_amd import engine
     from oracle import oracle
     rs = np.random.RandomState(11)
-    lens = [0, 1, 15, 16, 17, 0, 63, 64, 65, 511, 512, 513, 2000, 3, 0, 700, 31, 5000] + rs.randint(0, 120, size=203).tolist()
+    lens = [0, 1, 15, 16, 17, 0, 63, 64, 65, 95, 96, 97, 511, 512, 513, 1023, 1024, 1025, 2000, 3, 0, 700, 31, 5000] + rs.randint(0, 120, size=203).tolist()
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     k = int(offs[-1])
     b = rs.uniform(-0.5, 1.5, size=k)
@@ -61,6 +61,17 @@ def test_pi_raster_ragged_batch_vs_oracle(torch_cuda):
         assert out.shape == ref.shape
         empty = np.diff(offs) == 0
         assert np.all(out[empty] == 0.0)
+        assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), res
+        nz = np.abs(ref) > 1e-9
+        assert rel_err(out[nz], ref[nz]).max() < 1e-8, res
+    # sixteen diagrams per workgroup (batches of 16 384 diagrams and more; smaller ones above ran one diagram per workgroup)
+    reps = 75
+    offs_l = np.concatenate([[0], np.cumsum(np.tile(np.diff(offs), reps))]).astype(np.int64)
+    pts_l = np.tile(pts, (reps, 1)) * np.repeat(np.linspace(0.9, 1.1, reps), len(pts))[:, None]
+    assert len(offs_l) - 1 >= 16384
+    for res in (5, 2):
+        ref = oracle.pi_raster(offs_l, pts_l, res)
+        out = engine.pi_raster(_dev(torch, offs_l, torch.int64), _dev(torch, pts_l, torch.float64), res).cpu().numpy()
         assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), res
         nz = np.abs(ref) > 1e-9
         assert rel_err(out[nz], ref[nz]).max() < 1e-8, res

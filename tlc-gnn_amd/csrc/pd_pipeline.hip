@@ -1633,12 +1633,13 @@ __global__ void tlc_pdf_bin_kernel(int n_graphs, const long long* node_offs, con
 // images are folded with DPP butterflies on the vector ALU and stored as whole rows.  No LDS, no barrier: the former
 // table version (one lane per (point, grid line) into LDS, then one lane per pixel) spent 0.37 ms on 1.5 M points,
 // most of it in LDS round trips and in a wavefront that executed the erfc and the series branch of every table entry.
-// Diagrams of TLC_RASTER_BIG points or more are taken by the whole workgroup (256 lanes), one after the other.
-// Summation order: a lane adds its points in index order (stride 16, or 256 for the whole-workgroup case), the lanes are
-// folded in butterfly order and the four wavefronts in index order -- fixed for a given diagram length, so results are
-// reproducible.
+// Diagrams of TLC_RASTER_MID points or more are taken by the whole wavefront, of TLC_RASTER_BIG or more by the whole
+// workgroup (256 lanes), one after the other (a 500-point diagram on sixteen lanes kept its wavefront for 32 rounds).
+// Summation order: a lane adds its points in index order (stride 16 / 64 / 256), the lanes are folded in a fixed order
+// -- a function of the diagram length only, so results are reproducible.
 // ======================================================================================================================
-#define TLC_RASTER_BIG 512
+#define TLC_RASTER_MID 96
+#define TLC_RASTER_BIG 1024
 
 // Normal CDF at the G grid lines g * step - base, all G Maclaurin series advanced together (independent chains: evaluated one
 // after the other inside per-value branches they were 12 x 19 dependent fp64 FMAs per point and the kernel ran at the FMA
@@ -1712,8 +1713,47 @@ __device__ __forceinline__ void raster_point(double b, double d, double (&acc)[R
         for (int j = 0; j < RES; ++j) acc[i * RES + j] = fma(wb[i], dp[j], acc[i * RES + j]);
 }
 
+// Fold the partial images of a wavefront's lanes through LDS, sixteen pixels at a time: lane `sub` of each 16-lane group sums
+// pixel c*16 + sub over its group's lanes (one 128-byte store per diagram instead of 25 single-lane stores behind 100 DPP
+// exchanges).  Rows of 17 doubles: writes and reads are bank-conflict free.  WIDE: the four groups hold parts of ONE
+// diagram and are added on top (group order fixed).  LDS operations of one wavefront execute in order; the fences only
+// keep the compiler from moving them.
+template <int R2, bool WIDE>
+__device__ __forceinline__ void raster_fold(const double (&acc)[R2], double (*st)[17], bool store, double* __restrict__ row) {
+    const int lane = tlc_lane(), sub = lane & 15;
+#pragma unroll
+    for (int c = 0; c < (R2 + 15) / 16; ++c) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (c * 16 + q < R2) st[lane][q] = acc[c * 16 + q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (c * 16 + sub < R2) {
+            const int l0 = lane & 48;
+            double v0 = st[l0][sub], v1 = st[l0 + 1][sub], v2 = st[l0 + 2][sub], v3 = st[l0 + 3][sub];
+#pragma unroll
+            for (int l = 4; l < 16; l += 4) {
+                v0 += st[l0 + l][sub];
+                v1 += st[l0 + l + 1][sub];
+                v2 += st[l0 + l + 2][sub];
+                v3 += st[l0 + l + 3][sub];
+            }
+            double v = (v0 + v1) + (v2 + v3);
+            if (WIDE) {
+                v += tlc_lane_xor_f64<16>(v);
+                v += tlc_lane_xor_f64<32>(v);
+                if (store && lane < 16) row[c * 16 + sub] = v;
+            } else if (store) row[c * 16 + sub] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
 template <int RES>
-__global__ __launch_bounds__(256, (RES <= 5 ? 4 : (RES == 6 ? 3 : 2))) void tlc_pi_raster_kernel(int n_dgms, const long long* __restrict__ offs,
+__global__ __launch_bounds__(256, (RES <= 5 ? 3 : 2)) void tlc_pi_raster_kernel(int n_dgms, int dpb, const long long* __restrict__ offs,
                                                             const double* __restrict__ pts, double* __restrict__ out) {
     constexpr int R2 = RES * RES;
     __shared__ long long s_k[16], s_o[16];
@@ -1721,17 +1761,17 @@ __global__ __launch_bounds__(256, (RES <= 5 ? 4 : (RES == 6 ? 3 : 2))) void tlc_
     __shared__ double s_t[4][64][17];
     const int tid = threadIdx.x, lane = tlc_lane(), sub = lane & 15, slot = tid >> 4, wv = tid >> 6;
     const double2* __restrict__ pts2 = reinterpret_cast<const double2*>(pts);
-    // a workgroup takes sixteen consecutive diagrams per iteration (block-uniform trip count: the long-diagram path has barriers)
-    for (long long base = (long long)blockIdx.x * 16; base < n_dgms; base += (long long)gridDim.x * 16) {
-        const long long d = base + slot;
+    // a workgroup takes dpb = sixteen consecutive diagrams per iteration -- or one, when the batch has too few diagrams to fill
+    // the machine that way (block-uniform trip count: the long-diagram path has barriers)
+    for (long long base = (long long)blockIdx.x * dpb; base < n_dgms; base += (long long)gridDim.x * dpb) {
+        const long long d = slot < dpb ? base + slot : (long long)n_dgms;
         long long o = 0, kl = 0;
         if (d < n_dgms) { o = offs[d]; kl = offs[d + 1] - o; }
         if (kl < 0) kl = 0;
-        const bool big = kl >= TLC_RASTER_BIG;
         if (sub == 0) { s_k[slot] = kl; s_o[slot] = o; }
-        // ---- diagrams below TLC_RASTER_BIG points: sixteen lanes each ------------------------------------------------
+        // ---- diagrams below TLC_RASTER_MID points: sixteen lanes each, four diagrams per wavefront ---------------------
         {
-            const int k = big ? 0 : (int)kl;
+            const int k = kl < TLC_RASTER_MID ? (int)kl : 0;
             int rounds = (k + 15) >> 4;
             rounds = max(max(__builtin_amdgcn_readlane(rounds, 0), __builtin_amdgcn_readlane(rounds, 16)),
                          max(__builtin_amdgcn_readlane(rounds, 32), __builtin_amdgcn_readlane(rounds, 48)));
@@ -1746,35 +1786,33 @@ __global__ __launch_bounds__(256, (RES <= 5 ? 4 : (RES == 6 ? 3 : 2))) void tlc_
                 if (idx + 16 < k) nxt = pts2[o + idx + 16];             // next round's point while this one is rasterised
                 if (idx < k) raster_point<RES>(bd.x, bd.y, acc);
             }
-            // fold the sixteen partial images through LDS, sixteen pixels at a time: lane `sub` of a group sums pixel
-            // c*16 + sub over the group's lanes and stores it (one 128-byte store per group instead of 25 single-lane
-            // stores behind 100 DPP exchanges).  Rows of 17 doubles: writes and reads are bank-conflict free.
+            raster_fold<R2, false>(acc, s_t[wv], kl < TLC_RASTER_MID && d < n_dgms, out + (size_t)(d < n_dgms ? d : 0) * R2);
+        }
+        // ---- TLC_RASTER_MID .. TLC_RASTER_BIG - 1 points: the whole wavefront, one diagram after the other --------------
+        {
+            const int kmid = (kl >= TLC_RASTER_MID && kl < TLC_RASTER_BIG) ? (int)kl : 0;
+            if (__builtin_amdgcn_ballot_w64(kmid != 0)) {
+                for (int g = 0; g < 4; ++g) {
+                    const int kg = __builtin_amdgcn_readlane(kmid, g * 16);
+                    if (kg == 0) continue;                              // wavefront-uniform
+                    const unsigned olo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)o, g * 16);
+                    const unsigned ohi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(o >> 32), g * 16);
+                    const long long og = (long long)(((unsigned long long)ohi << 32) | olo);
+                    double acc[R2];
 #pragma unroll
-            for (int c = 0; c < (R2 + 15) / 16; ++c) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    if (c * 16 + q < R2) s_t[wv][lane][q] = acc[c * 16 + q];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                if (c * 16 + sub < R2) {
-                    const int l0 = lane & 48;
-                    double v0 = s_t[wv][l0][sub], v1 = s_t[wv][l0 + 1][sub], v2 = s_t[wv][l0 + 2][sub], v3 = s_t[wv][l0 + 3][sub];
-#pragma unroll
-                    for (int l = 4; l < 16; l += 4) {
-                        v0 += s_t[wv][l0 + l][sub];
-                        v1 += s_t[wv][l0 + l + 1][sub];
-                        v2 += s_t[wv][l0 + l + 2][sub];
-                        v3 += s_t[wv][l0 + l + 3][sub];
+                    for (int q = 0; q < R2; ++q) acc[q] = 0.0;
+                    double2 nxt = make_double2(0.0, 0.0);
+                    if (lane < kg) nxt = pts2[og + lane];
+                    for (int idx = lane; idx < kg; idx += 64) {
+                        const double2 bd = nxt;
+                        if (idx + 64 < kg) nxt = pts2[og + idx + 64];
+                        raster_point<RES>(bd.x, bd.y, acc);
                     }
-                    if (!big && d < n_dgms) out[(size_t)d * R2 + c * 16 + sub] = (v0 + v1) + (v2 + v3);
+                    raster_fold<R2, true>(acc, s_t[wv], true, out + (size_t)(base + wv * 4 + g) * R2);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
         }
-        // ---- longer diagrams: the whole workgroup, one diagram after the other ---------------------------------------
+        // ---- TLC_RASTER_BIG points and more: the whole workgroup, one diagram after the other ---------------------------
         __syncthreads();
         for (int g = 0; g < 16; ++g) {
             const long long kg = s_k[g];
@@ -1936,9 +1974,10 @@ int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long
 template <int RES>
 static void launch_pi_raster(int n_dgms, const long long* offs, const double* pts, double* out, hipStream_t s) {
     // four diagrams per wavefront, four wavefronts per workgroup; the grid is capped and strided beyond 2^20 workgroups
-    long long blocks = ((long long)n_dgms + 15) / 16;
+    const int dpb = n_dgms >= 16 * 1024 ? 16 : 1;
+    long long blocks = ((long long)n_dgms + dpb - 1) / dpb;
     if (blocks > (1 << 20)) blocks = 1 << 20;
-    hipLaunchKernelGGL(tlc_pi_raster_kernel<RES>, dim3((unsigned)blocks), dim3(256), 0, s, n_dgms, offs, pts, out);
+    hipLaunchKernelGGL(tlc_pi_raster_kernel<RES>, dim3((unsigned)blocks), dim3(256), 0, s, n_dgms, dpb, offs, pts, out);
 }
 
 int tlc_launch_pi_raster(int n_dgms, const long long* offs, const double* pts, int res, double* out, void* stream) {
