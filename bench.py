@@ -287,12 +287,13 @@ def main():
         gen = torch.Generator(device=dev).manual_seed(7)
         bd = torch.rand((int(kpts.sum()), 2), generator=gen, device=dev, dtype=torch.float64)
         bd[:, 1] = bd[:, 0] + bd[:, 1] * (1.0 - bd[:, 0])                     # death >= birth
-        us_r = _avg_us(lambda: engine.pi_raster(offs_r, bd, 5), reps=5)
+        us_r = _avg_us(lambda: engine.pi_raster(offs_r, bd, 5), reps=20)
         raster_bytes = 16.0 * float(kpts.sum()) + 8.0 * 25 * E + 8.0 * (E + 1)
         lp_roof["pi_raster"] = {"bound": "hbm", "diagrams": int(E), "points": int(kpts.sum()), "kernel_us": us_r,
                                 "achieved": raster_bytes / us_r / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": raster_bytes / us_r / 1e3 / HBM_PEAK_GBS,
-                                "note": "fp64 erfc issue-bound: 2*(res+1) CDF evaluations per point"}
+                                "note": "fp64 FMA issue-bound: 2*(res+1) CDF series of 19 terms + res^2 pixel terms per point "
+                                        "(~370 fp64 instructions per point), not HBM"}
         del bd, offs_r
     if rank == 0:
         stats = g.stats()
@@ -354,6 +355,10 @@ def main():
             out["cpu_baseline"] = {"value": len(sample) / cdt, "unit": "persistence-images/sec", "cores": int(used),
                                    "kind": "port", "sample": "first %d pairs of the same PI-A batch, OpenMP over pairs, "
                                    "%.2f s wall" % (len(sample), cdt)}
+            # the same restatement on ONE host thread (SURVEY.md 8d asks for both), first 2 000 pairs
+            c0 = time.perf_counter()
+            oracle.pd_pi_batch(wl["rowptr"], wl["col"], wl["w"], sample[:2000], hop, n_threads=1)
+            out["cpu_baseline"]["value_1thread"] = min(len(sample), 2000) / (time.perf_counter() - c0)
             got = pi_out[: len(sample)].cpu().numpy()
             nz = ref != 0
             out["cpu_baseline"]["max_rel_diff_vs_gpu"] = float((np.abs(got[nz] - ref[nz]) / np.abs(ref[nz])).max()) if nz.any() else 0.0

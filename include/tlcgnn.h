@@ -205,6 +205,29 @@ int tlc_edge_head_fwd(int64_t n_edges, const int32_t* d_src, const int32_t* d_ds
                       int32_t c, const float* d_W5, const float* d_b5, int32_t hidden, float prelu_slope,
                       const float* d_W6, const float* d_b6, float* d_pd, int32_t n_nodes, float* d_work, void* stream);
 
+/* ---- the callers' side of the path: negative enumeration and the image cache ----------
+ *
+ * loaddatas.py:44-45 lists the non-edges as `sp.triu(sp.csr_matrix(1. - adj.toarray())).nonzero()` (a dense N x N float64
+ * matrix), shuffles the [n_neg, 2] array and slices it (:46,:51-53).  Pair number r of that list -- row-major over x <= y with
+ * adj[x,y] == 0, the diagonal included -- is a function of the CSR alone:
+ *
+ * tlc_complement_rows: d_row_start int64[n_nodes+1] = exclusive prefix of the per-row non-edge counts (d_row_start[n_nodes] =
+ *   n_neg).  The CSR must be the symmetric adjacency with columns ascending and unique inside a row (a stored entry is an
+ *   edge, whatever its weight -- the reference's matrices are 0/1).
+ * tlc_complement_pairs: d_pairs int32[count,2] = the pairs with list numbers d_ranks[0..count) (int64; e.g. a slice of the
+ *   shuffled index list), or first, first+1, ... when d_ranks is NULL.  A number outside [0, n_neg) yields (-1, -1). */
+int tlc_complement_rows(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, int64_t* d_row_start, void* stream);
+int tlc_complement_pairs(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const int64_t* d_row_start,
+                         const int64_t* d_ranks, int64_t first, int64_t count, int32_t* d_pairs, void* stream);
+
+/* The reference caches the dense float64[n_pairs, res^2] image array (loaddatas.py:62-64,102: 39 GB for PubMed's sweep) although
+ * every pair with d(u,v) > hop has a zero row.  tlc_select_rows appends the rows of one image block that carry information
+ * (status != TLC_ST_OK or any entry != 0) to a sparse store: d_out_idx[k] = index_base + row number, d_out_status[k] (may be
+ * NULL), d_out_rows[k, width].  *d_count (uint64, device; the caller zeroes it once) is advanced by the number of such rows even
+ * beyond `cap` (rows past the capacity are not written: re-run the block with a larger store).  Append order is not fixed. */
+int tlc_select_rows(int64_t n_rows, int32_t width, const double* d_pi, const uint8_t* d_status, int64_t index_base, int64_t cap,
+                    uint64_t* d_count, int64_t* d_out_idx, uint8_t* d_out_status, double* d_out_rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

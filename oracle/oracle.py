@@ -126,3 +126,11 @@ def algorithmic_bytes(rowptr, col, pairs, hop, res=5):
 
 def max_threads():
     return int(lib().tlco_max_threads())
+
+
+def complement_pairs_dense(adj_dense):
+    """The reference's negative list before the shuffle, loaddatas.py:44: `sp.triu(sp.csr_matrix(1. - adj.toarray())).nonzero()`
+    -- row-major over x <= y with 1 - adj[x, y] != 0.  Dense: test sizes only.  (Checker for tlc_complement_pairs.)"""
+    c = np.triu(1.0 - np.asarray(adj_dense, dtype=np.float64))
+    x, y = np.nonzero(c)
+    return np.stack([x, y], 1).astype(np.int64)

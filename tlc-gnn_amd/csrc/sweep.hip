@@ -1,0 +1,177 @@
+// sweep.hip -- the two steps either side of the PD/PI batch when the pair list is the reference's NEGATIVE SWEEP
+// (SURVEY.md 8(f) items 2 and 3):
+//
+//   tlc_complement_rows / tlc_complement_pairs
+//       loaddatas.py:44-45 enumerates the non-edges as `sp.triu(sp.csr_matrix(1. - adj.toarray())).nonzero()`: a dense
+//       N x N float64 matrix (3.1 GB for PubMed) and a [1.9e8, 2] int64 pair array, only to be shuffled and sliced.  The
+//       same list is a function of the CSR: pair number r (row-major over x <= y, adj[x,y] == 0, diagonal included) is
+//       found by two binary searches -- over the per-row complement prefix, then over the row's sorted neighbours for
+//       "the t-th column >= x that is not a neighbour".  One thread per requested rank; ranks are either a contiguous
+//       range or the caller's (shuffled) index list, so the pairs of any slice of the reference's shuffled negative list
+//       are produced on the device without ever materialising the list.
+//   tlc_select_rows
+//       the sweep's images are zero for every pair with d(u,v) > hop (99.7 % of PubMed's 1.9e8): keeps (index, status, row)
+//       of the rows that carry information, which is what the sparse image cache stores (the reference caches the dense
+//       float64[n_pairs, 25]: 39 GB).
+//
+// HBM-bound integer work: no MFMA, no LDS tiling; the searches run out of L2 (the CSR is ~1 MB).
+#include "tlc_common.h"
+
+namespace {
+
+// first position in [lo, hi) whose column is >= x (columns ascending)
+__device__ __forceinline__ int lower_bound_col(const int* __restrict__ col, int lo, int hi, int x) {
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (col[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// row x: columns x..n-1 minus the stored neighbours among them
+__global__ void complement_count_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                        long long* __restrict__ row_start) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    const int rs = rowptr[x], re = rowptr[x + 1];
+    const int lb = lower_bound_col(col, rs, re, x);
+    row_start[x + 1] = (long long)(n - x) - (long long)(re - lb);
+    if (x == 0) row_start[0] = 0;
+}
+
+// in-place inclusive scan of row_start[1..n] by ONE workgroup (a one-off per graph; n <= ~5e5)
+__global__ __launch_bounds__(1024) void complement_scan_kernel(int n, long long* __restrict__ row_start) {
+    __shared__ long long part[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int lo = tid * chunk, hi = min(n, lo + chunk);
+    long long s = 0;
+    for (int i = lo; i < hi; ++i) s += row_start[i + 1];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const long long v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    long long run = tid ? part[tid - 1] : 0;
+    for (int i = lo; i < hi; ++i) {
+        run += row_start[i + 1];
+        row_start[i + 1] = run;
+    }
+}
+
+__global__ void complement_pairs_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                        const long long* __restrict__ row_start, const long long* __restrict__ ranks,
+                                        long long first, long long count, int* __restrict__ pairs) {
+    const long long total = row_start[n];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = ranks ? ranks[i] : first + i;
+        int x = -1, y = -1;
+        if (r >= 0 && r < total) {
+            // row: the last x with row_start[x] <= r (rows without a non-edge share their start with the next row)
+            int lo = 0, hi = n;                    // invariant: row_start[lo] <= r < row_start[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (row_start[mid] <= r) lo = mid; else hi = mid;
+            }
+            x = lo;
+            const long long t = r - row_start[x];  // t-th missing column among x, x+1, ...
+            const int re = rowptr[x + 1];
+            const int lb = lower_bound_col(col, rowptr[x], re, x);
+            // j = number of neighbours below the answer: the first j with (col[lb+j] - x) - j > t; that count is monotone
+            int jl = 0, jh = re - lb;
+            while (jl < jh) {
+                const int mid = (jl + jh) >> 1;
+                if ((long long)(col[lb + mid] - x) - mid > t) jh = mid; else jl = mid + 1;
+            }
+            y = (int)((long long)x + t + jl);
+        }
+        reinterpret_cast<int2*>(pairs)[i] = make_int2(x, y);
+    }
+}
+
+// rows of a float64 [n, width] image block that carry information: status != 0 or any entry != 0
+__global__ void select_rows_kernel(long long n, int width, const double* __restrict__ pi, const unsigned char* __restrict__ status,
+                                   long long index_base, long long cap, unsigned long long* __restrict__ count,
+                                   long long* __restrict__ out_idx, unsigned char* __restrict__ out_status,
+                                   double* __restrict__ out_rows) {
+    for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < n; i0 += (long long)gridDim.x * blockDim.x) {
+        const long long i = i0 + threadIdx.x;
+        bool keep = false;
+        unsigned char st = 0;
+        if (i < n) {
+            st = status ? status[i] : 0;
+            keep = st != 0;
+            const double* __restrict__ row = pi + (size_t)i * width;
+            for (int q = 0; q < width && !keep; ++q) keep = row[q] != 0.0;
+        }
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(keep);
+        if (mk == 0) continue;
+        unsigned long long base = 0;
+        const int leader = __builtin_ctzll(mk);
+        if (tlc_lane() == leader) base = atomicAdd(count, (unsigned long long)__popcll(mk));
+        base = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
+               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)base, leader);
+        if (keep) {
+            const long long o = (long long)base + __popcll(mk & tlc_lanemask_lt());
+            if (o < cap) {
+                out_idx[o] = index_base + i;
+                if (out_status) out_status[o] = st;
+                const double* __restrict__ row = pi + (size_t)i * width;
+                for (int q = 0; q < width; ++q) out_rows[(size_t)o * width + q] = row[q];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tlc_complement_rows(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, int64_t* d_row_start,
+                                   void* stream) {
+    TLC_REQUIRE(n_nodes >= 0, "n_nodes < 0");
+    TLC_REQUIRE(d_row_start != nullptr, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_nodes == 0) {
+        TLC_HIP_CHECK(hipMemsetAsync(d_row_start, 0, sizeof(int64_t), s));
+        return TLC_OK;
+    }
+    TLC_REQUIRE(d_rowptr != nullptr, "null pointer");
+    hipLaunchKernelGGL(complement_count_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, n_nodes, d_rowptr, d_col,
+                       (long long*)d_row_start);
+    hipLaunchKernelGGL(complement_scan_kernel, dim3(1), dim3(1024), 0, s, n_nodes, (long long*)d_row_start);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
+extern "C" int tlc_complement_pairs(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const int64_t* d_row_start,
+                                    const int64_t* d_ranks, int64_t first, int64_t count, int32_t* d_pairs, void* stream) {
+    TLC_REQUIRE(n_nodes >= 0 && count >= 0, "negative size");
+    if (count == 0) return TLC_OK;
+    TLC_REQUIRE(n_nodes > 0, "no nodes");
+    TLC_REQUIRE(d_rowptr && d_row_start && d_pairs, "null pointer");
+    long long blocks = (count + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(complement_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_nodes, d_rowptr,
+                       d_col, (const long long*)d_row_start, (const long long*)d_ranks, (long long)first, (long long)count,
+                       d_pairs);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
+extern "C" int tlc_select_rows(int64_t n_rows, int32_t width, const double* d_pi, const uint8_t* d_status, int64_t index_base,
+                               int64_t cap, uint64_t* d_count, int64_t* d_out_idx, uint8_t* d_out_status, double* d_out_rows,
+                               void* stream) {
+    TLC_REQUIRE(n_rows >= 0 && width >= 1 && cap >= 0, "bad size");
+    TLC_REQUIRE(d_count != nullptr, "null counter");
+    if (n_rows == 0) return TLC_OK;
+    TLC_REQUIRE(d_pi && (cap == 0 || (d_out_idx && d_out_rows)), "null pointer");
+    long long blocks = (n_rows + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(select_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long long)n_rows, width,
+                       d_pi, d_status, (long long)index_base, (long long)cap, (unsigned long long*)d_count,
+                       (long long*)d_out_idx, d_out_status, d_out_rows);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}

@@ -183,3 +183,62 @@ def algorithmic_bytes(rowptr, col, pairs, hop, res=5):
                                                 out.ctypes.data_as(C.c_void_p))
     _lib.check(rc, "tlc_pd_pi_algorithmic_bytes")
     return out
+
+
+# ---- the negative list of loaddatas.py:44-45 and the sparse image store ----------------------------
+class ComplementIndex:
+    """Non-edges of a symmetric 0/1 adjacency in the order of `sp.triu(sp.csr_matrix(1. - adj.toarray())).nonzero()`
+    (loaddatas.py:44), addressed by list number on the device -- no N x N matrix, no [n_neg, 2] array.
+
+    rowptr/col: numpy CSR of the symmetric adjacency, columns ascending and unique inside a row (checked here)."""
+
+    def __init__(self, rowptr, col, device=None):
+        torch = _lib.require_gpu()
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        n = len(rowptr) - 1
+        if len(col):
+            inner = np.ones(len(col), dtype=bool)
+            inner[rowptr[:-1][rowptr[:-1] < len(col)]] = False          # first entry of every non-empty row
+            if not np.all(np.diff(col.astype(np.int64))[inner[1:]] > 0):
+                raise ValueError("ComplementIndex: CSR columns must be ascending and unique inside every row")
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        self.n_nodes = n
+        self.rowptr = torch.from_numpy(rowptr).to(dev)
+        self.col = torch.from_numpy(col).to(dev) if len(col) else torch.zeros(1, dtype=torch.int32, device=dev)
+        self.row_start = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().tlc_complement_rows(C.c_int32(n), _lib.ptr(self.rowptr), _lib.ptr(self.col),
+                                                _lib.ptr(self.row_start), _lib.stream_ptr())
+        _lib.check(rc, "tlc_complement_rows")
+        self.n_neg = int(self.row_start[-1].item())
+
+    def __len__(self):
+        return self.n_neg
+
+    def pairs(self, ranks=None, first=0, count=None, out=None):
+        """int32 CUDA [count, 2]: the pairs numbered ranks[...] (int64 CUDA tensor) or first .. first+count-1."""
+        import torch
+        if ranks is not None:
+            assert ranks.is_cuda and ranks.dtype == torch.int64
+            ranks = ranks.contiguous()
+            count = ranks.numel()
+        elif count is None:
+            count = self.n_neg - first
+        if out is None:
+            out = torch.empty((count, 2), dtype=torch.int32, device=self.rowptr.device)
+        with torch.cuda.device(self.rowptr.device):
+            rc = _lib.lib().tlc_complement_pairs(C.c_int32(self.n_nodes), _lib.ptr(self.rowptr), _lib.ptr(self.col),
+                                                 _lib.ptr(self.row_start), _lib.ptr(ranks), C.c_int64(first), C.c_int64(count),
+                                                 _lib.ptr(out), _lib.stream_ptr())
+        _lib.check(rc, "tlc_complement_pairs")
+        return out
+
+
+def select_rows(pi, status, index_base, count, out_idx, out_status, out_rows):
+    """Append the informative rows of an image block (status != 0 or any entry != 0) to a sparse store (tlc_select_rows).
+    count: uint64-as-int64 CUDA scalar tensor the caller zeroed; returns nothing (read `count` after synchronising)."""
+    rc = _lib.lib().tlc_select_rows(C.c_int64(pi.shape[0]), C.c_int32(pi.shape[1]), _lib.ptr(pi), _lib.ptr(status),
+                                    C.c_int64(index_base), C.c_int64(out_idx.shape[0]), _lib.ptr(count), _lib.ptr(out_idx),
+                                    _lib.ptr(out_status), _lib.ptr(out_rows), _lib.stream_ptr())
+    _lib.check(rc, "tlc_select_rows")

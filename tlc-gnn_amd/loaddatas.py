@@ -60,6 +60,61 @@ def get_adj_split(adj, val_prop=0.05, test_prop=0.1, seed=1234):
     return train_edges, train_edges_false, val_edges, val_edges_false, test_edges, test_edges_false
 
 
+def get_adj_split_streamed(adj, val_prop=0.05, test_prop=0.1, seed=1234, device=None):
+    """get_adj_split (loaddatas.py:38-54) without the dense complement: same RNG stream, same six lists, but the negative
+    list stays on the device side as (seeded permutation, CSR enumeration) -- SURVEY.md 8(f) item 2.
+
+    Returns (train_edges, negatives, val_edges, val_edges_false, test_edges, test_edges_false) where `negatives` is a
+    pi_cache.ShuffledNegatives standing for the reference's shuffled `neg_edges`; the reference's
+    `train_edges_false` is negatives ++ val_edges ++ test_edges (:53)."""
+    from .pi_cache import ShuffledNegatives
+    adj = sp.csr_matrix(adj)
+    adj.sum_duplicates()
+    adj.eliminate_zeros()
+    adj.sort_indices()
+    if adj.nnz and not np.all(adj.data == 1):
+        raise ValueError("get_adj_split_streamed: the adjacency must be 0/1 (`1. - adj` of the reference is a non-edge "
+                         "only where adj == 1)")
+    np.random.seed(seed)
+    up = sp.triu(adj).tocoo()
+    keep = up.data != 0
+    pos_edges = np.stack([up.row[keep], up.col[keep]], 1).astype(np.int64)
+    np.random.shuffle(pos_edges)
+    stored = sp.csr_matrix(adj)
+    negatives = ShuffledNegatives(stored.indptr, stored.indices, device=device)     # draws the second shuffle
+    m_pos = len(pos_edges)
+    n_val, n_test = int(m_pos * val_prop), int(m_pos * test_prop)
+    val_edges, test_edges, train_edges = pos_edges[:n_val], pos_edges[n_val:n_test + n_val], pos_edges[n_test + n_val:]
+    return train_edges, negatives, val_edges, negatives[:n_val], test_edges, negatives[n_val:n_test + n_val]
+
+
+def compute_persistence_image_streamed(data, train_edges, negatives, val_edges, val_edges_false, test_edges, test_edges_false,
+                                       hop=1, chunk=1 << 22, progress=None):
+    """compute_persistence_image (loaddatas.py:56-103) for the streamed split: the images of all six lists in the reference's
+    order (:65-66) as a pi_cache.SparseImages, plus the LazyPairList standing for `total_edges`.
+    data.edge_index must already have lost the val/test positives (TLCGNN.py:88-100)."""
+    import torch
+    from . import engine, synth
+    from .pi_cache import LazyPairList, sweep_images, assemble
+    tail = np.concatenate([val_edges, test_edges]).astype(np.int64)
+    total = LazyPairList([(train_edges, 1), (negatives, 0), (tail, 0), (val_edges, 1), (val_edges_false, 0),
+                          (test_edges, 1), (test_edges_false, 0)])
+    ei = _edge_index_numpy(data.edge_index)
+    ei = ei[:, ei[0] != ei[1]]
+    und = np.unique(np.sort(ei.T, axis=1), axis=0)
+    ricci = compute_ricci_curvature(data)
+    kap = {(int(a), int(b)): float(k) for a, b, k in ricci}
+    kappa = np.array([kap[(int(a), int(b))] for a, b in und.tolist()])
+    n = int(max(len(data.y), und.max() + 1)) if len(und) else len(data.y)
+    rowptr, col, w = synth.edges_to_csr(n, und, kappa)
+    g = engine.DeviceGraph(rowptr, col, w)
+    pieces = []
+    dev = torch.device("cuda", g.device)
+    sweep_images(g, lambda lo, hi: total.device_pairs(lo, hi, device=dev), len(total), hop, chunk=chunk, store=pieces)
+    g.close()
+    return assemble(pieces, len(total), 25), total
+
+
 def compute_ricci_curvature(data):
     """loaddatas.py:105-123 calls the third-party GraphRicciCurvature (Sinkhorn, alpha=0.5); that solver is the
     step BEFORE the path.  Here the curvature must be supplied as `data.ricci_list`:
