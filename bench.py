@@ -240,6 +240,30 @@ def main():
         del sw_out, sw_pairs, sw_st
         g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)      # restore the headline batch's header for sizes()/stats()
         torch.cuda.synchronize()
+    # auxiliary (untimed region): the reference's whole negative sweep (loaddatas.py:44-53 + TLCGNN.py:80-107: every non-edge of
+    # the graph gets an image) -- pairs enumerated on the device by list number (tlc_complement_pairs), streamed through
+    # tlc_pd_pi_batch in 2^22-pair chunks, informative rows kept by tlc_select_rows.  List order (the reference's seeded
+    # shuffle permutes the same list; it costs ~20 s of host MT19937 and does not change the device work).
+    full_sweep = None
+    if rank == 0 and not args.no_sweep:
+        try:
+            from tlc_gnn_amd import pi_cache
+            ci = engine.ComplementIndex(wl["rowptr"], wl["col"], device=local_rank)
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            store = pi_cache.sweep_images(g, lambda lo, hi: ci.pairs(first=lo, count=hi - lo), len(ci), hop, chunk=1 << 22)
+            torch.cuda.synchronize()
+            fdt = time.perf_counter() - c0
+            full_sweep = {"pairs": len(ci), "seconds": fdt, "pairs_per_sec": len(ci) / fdt, "stored_rows": int(len(store.idx)),
+                          "stored_fraction": len(store.idx) / len(ci), "dense_bytes": len(ci) * 200,
+                          "sparse_bytes": int(store.idx.nbytes + store.rows.nbytes + store.status.nbytes),
+                          "note": "all N(N+1)/2 - M non-edges of the training graph incl. the diagonal, host wall clock incl. the "
+                                  "D2H of the kept rows; not part of `value`"}
+            del store, ci
+            g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)      # restore the headline batch's header
+            torch.cuda.synchronize()
+        except Exception as ex:
+            full_sweep = {"error": repr(ex)}
     # auxiliary (untimed region): configs 3/5 of BASELINE.json -- the per-graph PDGNN forward next to the exact PD of the same
     # graphs (Knowledge_Distillation evaluate_time, train_Teacher_Model_GC.py:118-143) on HIV-shaped synthetic molecules
     # (n ~ Poisson(25), a random tree plus a few ring-closing edges, degree filtration / (max + 1e-10), data_utils_GC.py:117-119),
@@ -341,6 +365,7 @@ def main():
             "kernel_ms": kavg,
             "roofline_lp": lp_roof,
             "sweep": sweep,
+            "full_sweep": full_sweep,
             "pdgnn": pdgnn,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -180,3 +180,50 @@ def test_select_rows_overflow_reports_the_needed_capacity(torch_cuda):
     assert np.array_equal(idx[:k].cpu().numpy()[o], np.sort(np.concatenate([np.arange(0, 1000, 10), [5]])) + 100)
     assert np.array_equal(rows[:k].cpu().numpy()[o], pi.cpu().numpy()[idx[:k].cpu().numpy()[o] - 100])
     assert ost[:k].cpu().numpy()[o][1] == 2
+
+
+def test_call_streamed_equals_call_dense(torch_cuda):
+    """TLCGNN.call with the streamed tables (lazy pair list + sparse images) against the dense harness: same counts, same
+    pairs, same images, same probabilities for val / test / a train draw."""
+    torch = torch_cuda
+    import tempfile
+    from tlc_gnn_amd import synth
+    from tlc_gnn_amd.baselines import TLCGNN
+    from tlc_gnn_amd.data import Data
+    n, m, F_ = 260, 700, 40
+    edges = synth.holme_kim_edges(n, m, triad_p=0.5, seed=21)
+
+    def make():
+        ei = torch.from_numpy(np.concatenate([edges, edges[:, ::-1]]).T.copy()).long()
+        d = Data(x=torch.from_numpy(synth.synthetic_features(n, F_, seed=2)), edge_index=ei, y=torch.zeros(n, dtype=torch.long))
+        d.ricci_list = synth.synthetic_curvature(edges, seed=21)
+        return d
+    out = {}
+    cwd = os.getcwd()
+    for streamed in (False, True):
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                torch.manual_seed(3)
+                model, data = TLCGNN.call(make(), "Cora", F_, 2, 0, streamed=streamed)
+            finally:
+                os.chdir(cwd)
+        model.eval()
+        res = {"counts": (data.train_pos, data.train_neg, data.val_pos, data.val_neg, data.test_pos, data.test_neg),
+               "ei": data.edge_index.cpu().numpy()}
+        with torch.no_grad():
+            emb = model.encode(data)
+            for t in ("val", "test", "train"):
+                np.random.seed(11)
+                p, y = model.decode(data, emb.clone(), t)
+                res[t] = (p.cpu().numpy(), y.cpu().numpy())
+        out[streamed] = (res, model, data)
+    a, b = out[False][0], out[True][0]
+    assert a["counts"] == b["counts"] and np.array_equal(a["ei"], b["ei"])
+    dense_pairs = np.asarray(out[False][2].total_edges)
+    lazy = out[True][2].total_edges
+    assert np.array_equal(lazy.gather(np.arange(len(lazy))), dense_pairs)
+    assert np.array_equal(out[True][1].PI.to_dense(), np.asarray(out[False][1].PI))
+    for t in ("val", "test", "train"):
+        assert np.array_equal(a[t][1], b[t][1]), t
+        assert np.array_equal(a[t][0], b[t][0]), t

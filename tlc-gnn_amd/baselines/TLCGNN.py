@@ -63,17 +63,25 @@ class Net(torch.nn.Module):
         self._pi_dev = None
         self._pairs_dev = None
 
-    # device-resident copies of the per-pair tables (the reference re-uploads a slice on every decode, TLCGNN.py:52-53)
+    # device-resident copies of the per-pair tables (the reference re-uploads a slice on every decode, TLCGNN.py:52-53).
+    # At PubMed scale the tables are the streamed forms of pi_cache (SparseImages / LazyPairList): rows are gathered by index.
     def _tables(self, data, device):
-        if self._pi_dev is None or self._pi_dev.device != device:
+        from ..pi_cache import SparseImages, LazyPairList
+        if self._pi_dev is None or (isinstance(self._pi_dev, torch.Tensor) and self._pi_dev.device != device):
             pi = self.PI
-            if not isinstance(pi, torch.Tensor):
-                pi = torch.from_numpy(np.ascontiguousarray(pi, dtype=np.float64))
-            self._pi_dev = pi.to(device=device, dtype=torch.float64).reshape(pi.shape[0], -1).contiguous()
+            if isinstance(pi, SparseImages):
+                self._pi_dev = pi
+            else:
+                if not isinstance(pi, torch.Tensor):
+                    pi = torch.from_numpy(np.ascontiguousarray(pi, dtype=np.float64))
+                self._pi_dev = pi.to(device=device, dtype=torch.float64).reshape(pi.shape[0], -1).contiguous()
             te = data.total_edges
-            if not isinstance(te, torch.Tensor):
-                te = torch.from_numpy(np.ascontiguousarray(te, dtype=np.int64))
-            self._pairs_dev = te.to(device=device, dtype=torch.int32).contiguous()
+            if isinstance(te, LazyPairList):
+                self._pairs_dev = te
+            else:
+                if not isinstance(te, torch.Tensor):
+                    te = torch.from_numpy(np.ascontiguousarray(te, dtype=np.int64))
+                self._pairs_dev = te.to(device=device, dtype=torch.int32).contiguous()
         return self._pi_dev, self._pairs_dev
 
     def encode(self, data):
@@ -90,23 +98,24 @@ class Net(torch.nn.Module):
         device = emb.device
         pi_all, pairs_all = self._tables(data, device)
         tp, tn, vp, vn = data.train_pos, data.train_neg, data.val_pos, data.val_neg
+        n_all = len(pairs_all) if not isinstance(pairs_all, torch.Tensor) else pairs_all.shape[0]
         if type == 'train':
             index = np.random.randint(0, tn, tp)                       # same RNG call as TLCGNN.py:31
-            idx = torch.cat((torch.arange(tp, device=device),
-                             tp + torch.from_numpy(index).to(device)))
-            edges_y = torch.cat((data.total_edges_y[:tp], data.total_edges_y[tp:tp + tn][torch.from_numpy(index).to(data.total_edges_y.device)]))
-            total_edges = pairs_all[idx].contiguous()
-            PI = pi_all[idx].contiguous()
+            idx = torch.cat((torch.arange(tp, device=device), tp + torch.from_numpy(index).to(device)))
         elif type == 'val':
-            total_edges = pairs_all[tp + tn:tp + tn + vp + vn]
-            edges_y = data.total_edges_y[tp + tn:tp + tn + vp + vn]
-            PI = pi_all[tp + tn:tp + tn + vp + vn]
+            idx = torch.arange(tp + tn, tp + tn + vp + vn, device=device)
         elif type == 'test':
-            total_edges = pairs_all[tp + tn + vp + vn:]
-            edges_y = data.total_edges_y[tp + tn + vp + vn:]
-            PI = pi_all[tp + tn + vp + vn:]
+            idx = torch.arange(tp + tn + vp + vn, n_all, device=device)
         else:
             raise ValueError("type must be 'train', 'val' or 'test'")
+        if isinstance(pairs_all, torch.Tensor):
+            total_edges = pairs_all[idx].contiguous()
+            edges_y = data.total_edges_y[idx.to(data.total_edges_y.device)]
+        else:                                                           # LazyPairList: pairs and labels by list position
+            idx_h = idx.cpu().numpy()
+            total_edges = torch.from_numpy(pairs_all.gather(idx_h).astype(np.int32)).to(device)
+            edges_y = torch.from_numpy(pairs_all.labels(idx_h)).to(device)
+        PI = pi_all[idx].contiguous() if isinstance(pi_all, torch.Tensor) else pi_all.gather_device(idx)
         # linear to gather edge features
         emb = ops.renorm_rows_(emb)                                    # emb.renorm_(2,0,1), in place (:48)
         prob = ops.lp_decode(total_edges, emb, PI, self.linear_1.weight.detach(), self.linear_1.bias.detach(),
@@ -121,14 +130,21 @@ def num(strings):
         return float(strings)
 
 
-def call(data, name, num_features, num_classes, data_cnt):
+def call(data, name, num_features, num_classes, data_cnt, streamed=None):
     # to generate data and models  (TLCGNN.py:71-111)
+    # streamed (not in the reference; None = by size): keep the negative list and the image array in their streamed forms
+    # (pi_cache.LazyPairList / SparseImages) instead of the dense N x N complement and the dense [n_pairs, 25] array --
+    # same split, same pair order, same images; the only way PubMed's 1.9e8-pair sweep fits.
     if name in ['PPI']:
         val_prop = 0.2
         test_prop = 0.2
     else:
         val_prop = 0.05
         test_prop = 0.1
+    if streamed is None:
+        streamed = len(data.y) > 6000
+    if streamed:
+        return _call_streamed(data, name, num_features, num_classes, val_prop, test_prop)
     train_edges, train_edges_false, val_edges, val_edges_false, test_edges, test_edges_false = get_edges_split(
         data, val_prop=val_prop, test_prop=test_prop)
     total_edges = np.concatenate((train_edges, train_edges_false, val_edges, val_edges_false, test_edges, test_edges_false))
@@ -152,6 +168,27 @@ def call(data, name, num_features, num_classes, data_cnt):
                                        test_edges_false, name, hop=hop)
     if not torch.cuda.is_available():
         raise RuntimeError("TLCGNN.call: no MI355X visible; the HIP forward has no CPU fallback")
+    device = torch.device('cuda')
+    model, data = Net(data, num_features, num_classes, PI=f1).to(device), data.to(device)
+    return model, data
+
+
+def _call_streamed(data, name, num_features, num_classes, val_prop, test_prop):
+    from ..loaddatas import get_edges_split_streamed, compute_persistence_image_streamed
+    if not torch.cuda.is_available():
+        raise RuntimeError("TLCGNN.call: no MI355X visible; the HIP forward has no CPU fallback")
+    train_edges, negatives, val_edges, val_edges_false, test_edges, test_edges_false = get_edges_split_streamed(
+        data, val_prop=val_prop, test_prop=test_prop)
+    data.train_pos, data.train_neg = len(train_edges), len(negatives) + len(val_edges) + len(test_edges)   # :53
+    data.val_pos, data.val_neg = len(val_edges), len(val_edges_false)
+    data.test_pos, data.test_neg = len(test_edges), len(test_edges_false)
+    data.edge_index = remove_pairs_both_directions(data.edge_index, np.concatenate((val_edges, test_edges)))
+    hop = 2 if name in ["PubMed"] else 1
+    f1, total = compute_persistence_image_streamed(data, train_edges, negatives, val_edges, val_edges_false, test_edges,
+                                                   test_edges_false, hop=hop)
+    ei = data.edge_index.cpu().numpy()
+    data.edge_index = torch.from_numpy(ei[:, ei[0] != ei[1]]).long()    # remove_self_loops (loaddatas.py:86)
+    data.total_edges, data.total_edges_y = total, None
     device = torch.device('cuda')
     model, data = Net(data, num_features, num_classes, PI=f1).to(device), data.to(device)
     return model, data

@@ -60,6 +60,15 @@ def get_adj_split(adj, val_prop=0.05, test_prop=0.1, seed=1234):
     return train_edges, train_edges_false, val_edges, val_edges_false, test_edges, test_edges_false
 
 
+def get_edges_split_streamed(data, val_prop=0.2, test_prop=0.2, seed=1234, device=None):
+    """get_edges_split (loaddatas.py:26-35) on top of get_adj_split_streamed."""
+    n = len(data.y)
+    ei = _edge_index_numpy(data.edge_index).astype(np.int64)
+    a = sp.coo_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(n, n)).tocsr()
+    a = ((a + a.T) > 0).astype(np.int64)
+    return get_adj_split_streamed(sp.csr_matrix(a), val_prop=val_prop, test_prop=test_prop, seed=seed, device=device)
+
+
 def get_adj_split_streamed(adj, val_prop=0.05, test_prop=0.1, seed=1234, device=None):
     """get_adj_split (loaddatas.py:38-54) without the dense complement: same RNG stream, same six lists, but the negative
     list stays on the device side as (seeded permutation, CSR enumeration) -- SURVEY.md 8(f) item 2.
