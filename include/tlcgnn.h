@@ -221,12 +221,17 @@ int tlc_complement_pairs(int32_t n_nodes, const int32_t* d_rowptr, const int32_t
                          const int64_t* d_ranks, int64_t first, int64_t count, int32_t* d_pairs, void* stream);
 
 /* The reference caches the dense float64[n_pairs, res^2] image array (loaddatas.py:62-64,102: 39 GB for PubMed's sweep) although
- * every pair with d(u,v) > hop has a zero row.  tlc_select_rows appends the rows of one image block that carry information
- * (status != TLC_ST_OK or any entry != 0) to a sparse store: d_out_idx[k] = index_base + row number, d_out_status[k] (may be
- * NULL), d_out_rows[k, width].  *d_count (uint64, device; the caller zeroes it once) is advanced by the number of such rows even
- * beyond `cap` (rows past the capacity are not written: re-run the block with a larger store).  Append order is not fixed. */
+ * every pair with d(u,v) > hop has a zero row, and keeps of the exceptions it swallows only their number (`cnt_compute`,
+ * riccidist2dgm.py:355).  tlc_select_rows appends the rows of one image block that have a non-zero entry -- with
+ * TLC_SELECT_KEEP_FAILED also the zero rows whose status is not TLC_ST_OK -- to a sparse store: d_out_idx[k] = index_base + row
+ * number, d_out_status[k] (may be NULL), d_out_rows[k, width]; and adds the block's status bytes to the histogram
+ * d_status_hist uint64[8] (may be NULL; the caller zeroes it once per store).  *d_count (uint64, device; the caller zeroes it
+ * per call) is advanced by the number of kept rows even beyond `cap` (rows past the capacity are not written: re-run the block
+ * with a larger store, and a fresh histogram).  Append order is not fixed. */
+#define TLC_SELECT_KEEP_FAILED 0x1u
 int tlc_select_rows(int64_t n_rows, int32_t width, const double* d_pi, const uint8_t* d_status, int64_t index_base, int64_t cap,
-                    uint64_t* d_count, int64_t* d_out_idx, uint8_t* d_out_status, double* d_out_rows, void* stream);
+                    uint32_t flags, uint64_t* d_count, uint64_t* d_status_hist, int64_t* d_out_idx, uint8_t* d_out_status,
+                    double* d_out_rows, void* stream);
 
 #ifdef __cplusplus
 }

@@ -58,11 +58,12 @@ def test_sparse_images_behave_like_the_dense_array(tmp_path):
     idx = rs.randint(0, 1000, 500)
     assert np.array_equal(sp_[idx], dense[idx])
     assert np.array_equal(sp_[10:200], dense[10:200])
-    assert sp_.cnt_compute == 998
+    assert sp_.cnt_compute == 998 and sp_.status_counts.tolist() == [998, 0, 1, 0, 1, 0, 0, 0]
     f = str(tmp_path / "pi.npz")
     sp_.save(f)
     back = SparseImages.load(f)
     assert np.array_equal(back.to_dense(), dense) and np.array_equal(back.status, sp_.status)
+    assert np.array_equal(back.status_counts, sp_.status_counts)
     empty = SparseImages.from_dense(np.zeros((7, 25)))
     assert np.array_equal(empty[np.array([0, 6])], np.zeros((2, 25)))
 

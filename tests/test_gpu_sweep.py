@@ -123,7 +123,7 @@ def test_streamed_images_equal_the_dense_path(torch_cuda, tmp_path):
     ricci = sorted([[a_, b_, kap[(min(a_, b_), max(a_, b_))]] for a_, b_ in und.tolist()] +
                    [[b_, a_, kap[(min(a_, b_), max(a_, b_))]] for a_, b_ in und.tolist()])
     data = Data(x=None, edge_index=ei, y=torch.zeros(n), ricci_list=ricci)
-    images, total = loaddatas.compute_persistence_image_streamed(data, tr, neg, va, vaf, te, tef, hop=hop, chunk=100003)
+    images, total = loaddatas.compute_persistence_image_streamed(data, tr, neg, va, vaf, te, tef, hop=hop, chunk=100003, keep_failed=True)
     assert len(total) == len(tr) + len(neg) + len(va) + len(te) + len(va) + len(vaf) + len(te) + len(tef)
     assert images.shape == (len(total), 25)
     # dense path on the materialised list
@@ -139,6 +139,11 @@ def test_streamed_images_equal_the_dense_path(torch_cuda, tmp_path):
     full_status[images.idx] = images.status
     assert np.array_equal(full_status, st) and (st == 1).any()
     assert images.cnt_compute == int((st == 0).sum())
+    assert np.array_equal(images.status_counts, np.bincount(st, minlength=8))
+    # default store: non-zero rows only, the failures as a histogram
+    lean, _ = loaddatas.compute_persistence_image_streamed(data, tr, neg, va, vaf, te, tef, hop=hop, chunk=50000)
+    assert np.array_equal(lean.idx, np.nonzero((dense != 0).any(1))[0]) and np.array_equal(lean.to_dense(), dense)
+    assert np.array_equal(lean.status_counts, images.status_counts) and not lean.status.any()
     assert len(images.idx) < len(total)                                         # (a 600-node graph at hop 2 is not sparse; PubMed's sweep keeps 0.3 %)
     # and against the oracle on a sample
     pick = np.concatenate([np.arange(0, len(total), 97), images.idx[:: max(1, len(images.idx) // 400)]])
@@ -167,19 +172,24 @@ def test_select_rows_overflow_reports_the_needed_capacity(torch_cuda):
     idx = torch.full((16,), -7, dtype=torch.int64, device="cuda")
     ost = torch.zeros(16, dtype=torch.uint8, device="cuda")
     rows = torch.zeros((16, 25), dtype=torch.float64, device="cuda")
-    engine.select_rows(pi, st, 100, count, idx, ost, rows)
+    hist = torch.zeros(8, dtype=torch.int64, device="cuda")
+    engine.select_rows(pi, st, 100, count, idx, ost, rows, hist=hist, keep_failed=True)
     assert int(count.item()) == 101                                             # needed, not written
+    assert hist.cpu().numpy().tolist() == [999, 0, 1, 0, 0, 0, 0, 0]
     got = idx.cpu().numpy()
     assert np.all(got >= 100) and len(set(got.tolist())) == 16
     idx = torch.empty(128, dtype=torch.int64, device="cuda"); ost = torch.empty(128, dtype=torch.uint8, device="cuda")
     rows = torch.empty((128, 25), dtype=torch.float64, device="cuda")
     count.zero_()
-    engine.select_rows(pi, st, 100, count, idx, ost, rows)
+    engine.select_rows(pi, st, 100, count, idx, ost, rows, keep_failed=True)
     k = int(count.item())
     o = np.argsort(idx[:k].cpu().numpy())
     assert np.array_equal(idx[:k].cpu().numpy()[o], np.sort(np.concatenate([np.arange(0, 1000, 10), [5]])) + 100)
     assert np.array_equal(rows[:k].cpu().numpy()[o], pi.cpu().numpy()[idx[:k].cpu().numpy()[o] - 100])
     assert ost[:k].cpu().numpy()[o][1] == 2
+    count.zero_()
+    engine.select_rows(pi, st, 100, count, idx, ost, rows)                       # default: non-zero rows only
+    assert int(count.item()) == 100
 
 
 def test_call_streamed_equals_call_dense(torch_cuda):

@@ -93,8 +93,8 @@ def lib():
         L.tlc_complement_rows.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.tlc_complement_pairs.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                            C.c_void_p, C.c_void_p]
-        L.tlc_select_rows.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tlc_select_rows.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 

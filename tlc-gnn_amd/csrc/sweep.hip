@@ -11,7 +11,8 @@
 //       are produced on the device without ever materialising the list.
 //   tlc_select_rows
 //       the sweep's images are zero for every pair with d(u,v) > hop (99.7 % of PubMed's 1.9e8): keeps (index, status, row)
-//       of the rows that carry information, which is what the sparse image cache stores (the reference caches the dense
+//       of the non-zero rows plus a histogram of the status bytes (all the reference keeps of its swallowed exceptions is
+//       their number, `cnt_compute`), which is what the sparse image cache stores (the reference caches the dense
 //       float64[n_pairs, 25]: 39 GB).
 //
 // HBM-bound integer work: no MFMA, no LDS tiling; the searches run out of L2 (the CSR is ~1 MB).
@@ -92,20 +93,27 @@ __global__ void complement_pairs_kernel(int n, const int* __restrict__ rowptr, c
     }
 }
 
-// rows of a float64 [n, width] image block that carry information: status != 0 or any entry != 0
+// rows of a float64 [n, width] image block that carry information: any entry != 0 (keep_failed: or status != 0); the status
+// histogram counts every row (wave-aggregated: one atomic per status value and wavefront)
 __global__ void select_rows_kernel(long long n, int width, const double* __restrict__ pi, const unsigned char* __restrict__ status,
-                                   long long index_base, long long cap, unsigned long long* __restrict__ count,
-                                   long long* __restrict__ out_idx, unsigned char* __restrict__ out_status,
-                                   double* __restrict__ out_rows) {
+                                   long long index_base, long long cap, int keep_failed, unsigned long long* __restrict__ count,
+                                   unsigned long long* __restrict__ hist, long long* __restrict__ out_idx,
+                                   unsigned char* __restrict__ out_status, double* __restrict__ out_rows) {
     for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < n; i0 += (long long)gridDim.x * blockDim.x) {
         const long long i = i0 + threadIdx.x;
         bool keep = false;
         unsigned char st = 0;
         if (i < n) {
             st = status ? status[i] : 0;
-            keep = st != 0;
+            keep = keep_failed && st != 0;
             const double* __restrict__ row = pi + (size_t)i * width;
             for (int q = 0; q < width && !keep; ++q) keep = row[q] != 0.0;
+        }
+        if (hist) {
+            for (int v = 0; v < 8; ++v) {
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(i < n && (st & 7) == v);
+                if (hm && tlc_lane() == __builtin_ctzll(hm)) atomicAdd(&hist[v], (unsigned long long)__popcll(hm));
+            }
         }
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(keep);
         if (mk == 0) continue;
@@ -161,8 +169,8 @@ extern "C" int tlc_complement_pairs(int32_t n_nodes, const int32_t* d_rowptr, co
 }
 
 extern "C" int tlc_select_rows(int64_t n_rows, int32_t width, const double* d_pi, const uint8_t* d_status, int64_t index_base,
-                               int64_t cap, uint64_t* d_count, int64_t* d_out_idx, uint8_t* d_out_status, double* d_out_rows,
-                               void* stream) {
+                               int64_t cap, uint32_t flags, uint64_t* d_count, uint64_t* d_status_hist, int64_t* d_out_idx,
+                               uint8_t* d_out_status, double* d_out_rows, void* stream) {
     TLC_REQUIRE(n_rows >= 0 && width >= 1 && cap >= 0, "bad size");
     TLC_REQUIRE(d_count != nullptr, "null counter");
     if (n_rows == 0) return TLC_OK;
@@ -170,8 +178,9 @@ extern "C" int tlc_select_rows(int64_t n_rows, int32_t width, const double* d_pi
     long long blocks = (n_rows + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(select_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long long)n_rows, width,
-                       d_pi, d_status, (long long)index_base, (long long)cap, (unsigned long long*)d_count,
-                       (long long*)d_out_idx, d_out_status, d_out_rows);
+                       d_pi, d_status, (long long)index_base, (long long)cap, (int)(flags & TLC_SELECT_KEEP_FAILED),
+                       (unsigned long long*)d_count, (unsigned long long*)d_status_hist, (long long*)d_out_idx, d_out_status,
+                       d_out_rows);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }

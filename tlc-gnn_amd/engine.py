@@ -235,10 +235,12 @@ class ComplementIndex:
         return out
 
 
-def select_rows(pi, status, index_base, count, out_idx, out_status, out_rows):
-    """Append the informative rows of an image block (status != 0 or any entry != 0) to a sparse store (tlc_select_rows).
-    count: uint64-as-int64 CUDA scalar tensor the caller zeroed; returns nothing (read `count` after synchronising)."""
+def select_rows(pi, status, index_base, count, out_idx, out_status, out_rows, hist=None, keep_failed=False):
+    """Append the non-zero rows of an image block (keep_failed: and the zero rows with status != 0) to a sparse store and add
+    the block's status bytes to `hist` (int64 CUDA [8]) -- tlc_select_rows.  count: int64 CUDA scalar tensor the caller zeroed
+    (read it after synchronising; it may exceed the capacity)."""
     rc = _lib.lib().tlc_select_rows(C.c_int64(pi.shape[0]), C.c_int32(pi.shape[1]), _lib.ptr(pi), _lib.ptr(status),
-                                    C.c_int64(index_base), C.c_int64(out_idx.shape[0]), _lib.ptr(count), _lib.ptr(out_idx),
-                                    _lib.ptr(out_status), _lib.ptr(out_rows), _lib.stream_ptr())
+                                    C.c_int64(index_base), C.c_int64(out_idx.shape[0]), C.c_uint32(1 if keep_failed else 0),
+                                    _lib.ptr(count), _lib.ptr(hist), _lib.ptr(out_idx), _lib.ptr(out_status), _lib.ptr(out_rows),
+                                    _lib.stream_ptr())
     _lib.check(rc, "tlc_select_rows")

@@ -98,7 +98,7 @@ def get_adj_split_streamed(adj, val_prop=0.05, test_prop=0.1, seed=1234, device=
 
 
 def compute_persistence_image_streamed(data, train_edges, negatives, val_edges, val_edges_false, test_edges, test_edges_false,
-                                       hop=1, chunk=1 << 22, progress=None):
+                                       hop=1, chunk=1 << 22, keep_failed=False):
     """compute_persistence_image (loaddatas.py:56-103) for the streamed split: the images of all six lists in the reference's
     order (:65-66) as a pi_cache.SparseImages, plus the LazyPairList standing for `total_edges`.
     data.edge_index must already have lost the val/test positives (TLCGNN.py:88-100)."""
@@ -119,7 +119,8 @@ def compute_persistence_image_streamed(data, train_edges, negatives, val_edges, 
     g = engine.DeviceGraph(rowptr, col, w)
     pieces = []
     dev = torch.device("cuda", g.device)
-    sweep_images(g, lambda lo, hi: total.device_pairs(lo, hi, device=dev), len(total), hop, chunk=chunk, store=pieces)
+    sweep_images(g, lambda lo, hi: total.device_pairs(lo, hi, device=dev), len(total), hop, chunk=chunk, store=pieces,
+                 keep_failed=keep_failed)
     g.close()
     return assemble(pieces, len(total), 25), total
 

@@ -99,21 +99,27 @@ class LazyPairList:
 class SparseImages:
     """float64 [n_rows, width] image array of which only the rows that carry information are stored.
 
-    idx int64[nnz] ascending, rows float64[nnz, width], status uint8[nnz] (TLC_ST_*: a stored row with status != 0 is a zero
-    row whose pair the reference would have swallowed an exception for).  Rows not stored are zero with status TLC_ST_OK."""
+    idx int64[nnz] ascending, rows float64[nnz, width], status uint8[nnz] (TLC_ST_* of the stored rows: 0 for every non-zero
+    row; a stored zero row with status != 0 is a pair the reference swallowed an exception for -- kept only on request),
+    status_counts int64[8]: how many of ALL n_rows rows ended with each status byte (the reference keeps just that:
+    `cnt_compute`).  Rows not stored are zero."""
 
-    def __init__(self, n_rows, width, idx, rows, status):
+    def __init__(self, n_rows, width, idx, rows, status, status_counts=None):
         self.shape = (int(n_rows), int(width))
         order = np.argsort(idx, kind="stable")
         self.idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int64)[order])
         self.rows = np.ascontiguousarray(np.asarray(rows, dtype=np.float64).reshape(-1, width)[order])
         self.status = np.ascontiguousarray(np.asarray(status, dtype=np.uint8)[order])
+        if status_counts is None:                       # every failed row is stored: the rest is TLC_ST_OK
+            status_counts = np.bincount(self.status, minlength=8).astype(np.int64)
+            status_counts[0] += self.shape[0] - len(self.idx)
+        self.status_counts = np.asarray(status_counts, dtype=np.int64)
         self._dev = None
 
     @property
     def cnt_compute(self):
         """graph2pi.cnt_compute (riccidist2dgm.py:355): pairs whose image was computed without an exception."""
-        return self.shape[0] - int((self.status != _lib.ST_OK).sum())
+        return int(self.status_counts[_lib.ST_OK])
 
     def __len__(self):
         return self.shape[0]
@@ -155,12 +161,13 @@ class SparseImages:
         return out
 
     def save(self, path):
-        np.savez(path, shape=np.asarray(self.shape, dtype=np.int64), idx=self.idx, rows=self.rows, status=self.status)
+        np.savez(path, shape=np.asarray(self.shape, dtype=np.int64), idx=self.idx, rows=self.rows, status=self.status,
+                 status_counts=self.status_counts)
 
     @classmethod
     def load(cls, path):
         d = np.load(path)
-        return cls(int(d["shape"][0]), int(d["shape"][1]), d["idx"], d["rows"], d["status"])
+        return cls(int(d["shape"][0]), int(d["shape"][1]), d["idx"], d["rows"], d["status"], d["status_counts"])
 
     @classmethod
     def from_dense(cls, pi, status=None):
@@ -171,12 +178,13 @@ class SparseImages:
         return cls(pi.shape[0], pi.shape[1], idx, pi[idx], status[idx])
 
 
-def sweep_images(graph, pair_source, n_pairs, hop, flags=0, res=5, chunk=1 << 22, index_base=0, store=None):
+def sweep_images(graph, pair_source, n_pairs, hop, flags=0, res=5, chunk=1 << 22, index_base=0, store=None, keep_failed=False):
     """Images of a long pair list, streamed: pair_source(lo, hi) -> int32 CUDA [hi-lo, 2] for list positions lo..hi-1.
 
-    Every chunk goes through tlc_pd_pi_batch (graph: engine.DeviceGraph) and tlc_select_rows; only informative rows leave the
-    device.  Returns SparseImages over positions index_base .. index_base + n_pairs - 1 of a store with n_pairs rows (or
-    extends `store`, a list of (idx, rows, status) pieces, and returns None)."""
+    Every chunk goes through tlc_pd_pi_batch (graph: engine.DeviceGraph) and tlc_select_rows; only the non-zero rows (and, with
+    keep_failed, the zero rows whose pair failed) leave the device, plus the histogram of the status bytes.  Returns
+    SparseImages over positions index_base .. index_base + n_pairs - 1 of a store with n_pairs rows (or extends `store`, a list
+    of (idx, rows, status, status_counts) pieces, and returns None)."""
     import torch
     width = res * res
     dev = torch.device("cuda", graph.device)
@@ -186,6 +194,7 @@ def sweep_images(graph, pair_source, n_pairs, hop, flags=0, res=5, chunk=1 << 22
         out = torch.empty((min(chunk, max(n_pairs, 1)), width), dtype=torch.float64, device=dev)
         st = torch.empty(out.shape[0], dtype=torch.uint8, device=dev)
         count = torch.zeros(1, dtype=torch.int64, device=dev)
+        hist = torch.zeros(8, dtype=torch.int64, device=dev)
         for lo in range(0, n_pairs, chunk):
             hi = min(n_pairs, lo + chunk)
             pairs = pair_source(lo, hi)
@@ -195,12 +204,14 @@ def sweep_images(graph, pair_source, n_pairs, hop, flags=0, res=5, chunk=1 << 22
                 sel_st = torch.empty(cap, dtype=torch.uint8, device=dev)
                 sel_rows = torch.empty((cap, width), dtype=torch.float64, device=dev)
                 count.zero_()
-                engine.select_rows(out[: hi - lo], st[: hi - lo], index_base + lo, count, sel_idx, sel_st, sel_rows)
+                hist.zero_()
+                engine.select_rows(out[: hi - lo], st[: hi - lo], index_base + lo, count, sel_idx, sel_st, sel_rows, hist=hist,
+                                   keep_failed=keep_failed)
                 k = int(count.item())
                 if k <= cap:
                     break
                 cap = 2 * k                                                  # store too small for this chunk: once more
-            pieces.append((sel_idx[:k].cpu().numpy(), sel_rows[:k].cpu().numpy(), sel_st[:k].cpu().numpy()))
+            pieces.append((sel_idx[:k].cpu().numpy(), sel_rows[:k].cpu().numpy(), sel_st[:k].cpu().numpy(), hist.cpu().numpy()))
     if store is not None:
         return None
     return assemble(pieces, n_pairs, width)
@@ -210,4 +221,5 @@ def assemble(pieces, n_rows, width):
     idx = np.concatenate([p[0] for p in pieces]) if pieces else np.zeros(0, dtype=np.int64)
     rows = np.concatenate([p[1] for p in pieces]) if pieces else np.zeros((0, width))
     status = np.concatenate([p[2] for p in pieces]) if pieces else np.zeros(0, dtype=np.uint8)
-    return SparseImages(n_rows, width, idx, rows, status)
+    counts = np.sum([p[3] for p in pieces], axis=0) if pieces else np.zeros(8, dtype=np.int64)
+    return SparseImages(n_rows, width, idx, rows, status, counts)
