@@ -191,3 +191,44 @@ def test_spmm_fused_renorm_equals_separate_pass(setup):
         ok, worst = _close(fused, two)
         assert ok, (k, worst)
         assert float(fused.norm(dim=1).max()) <= 1.0 + 1e-5
+
+
+def test_hip_graph_replay_equals_eager_forward(setup):
+    """ops.capture: the encode + decode chain as one HIP graph; replays give the eager launch's bits, also after the inputs
+    held in the captured buffers change."""
+    torch, n, F_, x, ei = setup
+    from tlc_gnn_amd import ops
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    xd = x.to(dev)
+    w1, b1 = torch.randn(F_, 100, device=dev) * 0.1, torch.randn(100, device=dev) * 0.1
+    w2, b2 = torch.randn(100, 16, device=dev) * 0.1, torch.randn(16, device=dev) * 0.1
+    l1w, l1b = torch.randn(25, 41, device=dev) * 0.3, torch.randn(25, device=dev) * 0.1
+    l2w, l2b = torch.randn(1, 25, device=dev) * 0.3, torch.randn(1, device=dev) * 0.1
+    rowptr, col, val = ops.gcn_norm_csr(ei.to(dev), n)
+    E = 4000
+    pairs = torch.randint(0, n, (E, 2), device=dev, dtype=torch.int32)
+    pi = torch.rand((E, 25), device=dev, dtype=torch.float64)
+    prob = torch.empty(E, dtype=torch.float32, device=dev)
+
+    def fwd():
+        h = ops.spmm(rowptr, col, val, ops.gemm(xd, w1), bias=b1, relu=True)
+        emb = ops.spmm(rowptr, col, val, ops.gemm(h, w2), bias=b2, relu=True, renorm=True)
+        ops.lp_decode(pairs, emb, pi, l1w, l1b, l2w, l2b, out=prob)
+
+    fwd()
+    torch.cuda.synchronize()
+    eager = prob.clone()
+    g = ops.capture(fwd)
+    prob.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(prob, eager)
+    xd.mul_(0.5)                                                 # same buffers, new contents
+    pi.mul_(2.0)
+    g.replay()
+    torch.cuda.synchronize()
+    replayed = prob.clone()
+    fwd()
+    torch.cuda.synchronize()
+    assert torch.equal(prob, replayed) and not torch.equal(replayed, eager)

@@ -146,3 +146,24 @@ def scatter(src, index, dim_size, reduce="sum"):
                                     C.c_int32(dim_size), _lib.ptr(out), _lib.ptr(cnt), _lib.stream_ptr())
     _lib.check(rc, "tlc_scatter_f32")
     return out
+
+
+def capture(fn, warmup=2):
+    """HIP graph of a forward closure: `fn` (C-ABI launches on the current stream, outputs in caller-held or graph-pool buffers,
+    no host synchronisation inside) is warmed up on a side stream, captured once, and replayed with `.replay()`.
+    torch.cuda.CUDAGraph is hipStreamBeginCapture / hipGraphLaunch plumbing.  Every LP-forward entry point of the C ABI is
+    capturable (tests/test_gpu_lp_forward.py).  Measured on the PubMed forward (five kernels, 70 us of kernel time): replay
+    86 us vs 78 us launched kernel by kernel from Python -- ROCm's graph launch costs more than the launch gaps it removes, so
+    bench.py does not use it."""
+    torch = _lib.require_gpu()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fn()
+    return graph
