@@ -233,6 +233,22 @@ int tlc_select_rows(int64_t n_rows, int32_t width, const double* d_pi, const uin
                     uint32_t flags, uint64_t* d_count, uint64_t* d_status_hist, int64_t* d_out_idx, uint8_t* d_out_status,
                     double* d_out_rows, void* stream);
 
+/* ---- the producer of the path's edge weights -------------------------------------------------------
+ * compute_ricci_curvature (loaddatas.py:105-123) = third-party GraphRicciCurvature `OllivierRicci(G, alpha=0.5,
+ * method="Sinkhorn")` (not in the reference tree, version not pinned; restated in oracle/ricci_ref.py -- parity unpinned):
+ * per edge (s,t), m_s = alpha at s + (1-alpha)/deg on the neighbours, cost = hop distance, W = <P, d> of POT's
+ * `sinkhorn2(x, y, d, reg)` (sinkhorn_knopp: stop when the marginal violation <= stop_thr, tested every 10th iteration, or after
+ * max_iter iterations), kappa = 1 - W.  The library's call is (alpha 0.5, reg 0.1, max_iter 1000, stop_thr 1e-9).
+ *   CSR: symmetric, no self loops, columns ascending and unique inside a row, unit weights.  d_edges int32[n_edges,2]: adjacent
+ *   pairs (a self pair gets curvature 0).  d_kappa double[n_edges]; d_iters int32[n_edges] (may be NULL): iterations used.
+ *   d_work/work_bytes: >= 16 + 4*n_edges (rounded up to 16) + k * max_product bytes (rounded up to 16), k >= 1 slots for the
+ *   hub edges; max_support >= max over edges of deg(s)+deg(t)+2 and max_product >= max of (deg(s)+1)*(deg(t)+1) over the edges
+ *   above 3 072 entries.  An edge that exceeds them gets NaN (and iters -1), never a silent value. */
+int tlc_ollivier_ricci_sinkhorn(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, int64_t n_edges,
+                                const int32_t* d_edges, double alpha, double reg, int32_t max_iter, double stop_thr,
+                                double* d_kappa, int32_t* d_iters, void* d_work, int64_t work_bytes, int32_t max_support,
+                                int64_t max_product, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,115 @@
+"""Ollivier-Ricci curvature with the Sinkhorn distance on the GPU against the CPU restatement of
+GraphRicciCurvature + POT in oracle/ricci_ref.py (parity unpinned: neither package nor golden values exist here).
+Tolerance 1e-7 absolute on kappa in [-2, 1]: the two sides sum in different orders and may stop one check (10 iterations) apart."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def _graph(kind, rs):
+    from tlc_gnn_amd import synth
+    if kind == "clustered":
+        return 300, synth.holme_kim_edges(300, 900, triad_p=0.6, seed=4)
+    if kind == "sparse":
+        n = 200
+        par = np.array([rs.randint(0, k) for k in range(1, n)])
+        e = np.stack([par, np.arange(1, n)], 1)                      # a tree: leaves, paths, no triangles
+        return n, e
+    if kind == "hub":                                                # a hub of degree 220 whose neighbours have ~20 neighbours:
+        n = 700                                                      # (221 x 21 codes) > 3072 -> the workgroup kernel
+        e = [[0, k] for k in range(1, 221)]
+        for k in range(1, 221):
+            for x in rs.choice(np.arange(221, n), 19, replace=False):
+                e.append([k, int(x)])
+        return n, np.unique(np.sort(np.array(e), 1), axis=0)
+    if kind == "tiny":
+        return 4, np.array([[0, 1], [1, 2], [2, 0], [2, 3]])
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["tiny", "clustered", "sparse", "hub"])
+def test_ollivier_ricci_sinkhorn_vs_restatement(kind):
+    import torch
+    assert torch.cuda.is_available()
+    from tlc_gnn_amd import engine, synth
+    from oracle import ricci_ref
+    rs = np.random.RandomState(3)
+    n, edges = _graph(kind, rs)
+    rowptr, col, _ = synth.edges_to_csr(n, edges)
+    pick = edges if kind != "hub" else edges[np.concatenate([np.arange(0, 40), rs.choice(len(edges), 60, replace=False)])]
+    ref, rit = ricci_ref.ollivier_ricci_sinkhorn(n, pick) if kind != "hub" else _ref_subset(n, edges, pick)
+    got, git = engine.ollivier_ricci_sinkhorn(rowptr, col, pick, want_iters=True)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 1e-7, np.abs(got - ref).max()
+    assert np.all(np.abs(git - rit) <= 10)
+    assert (got <= 1.0 + 1e-9).all() and (got >= -2.0).all()
+    # the other orientation: the Sinkhorn iteration stops on the TARGET marginal, so (t, s) differs from (s, t) at the level
+    # of the stopping threshold -- in the restatement as well; the drop-in therefore keeps networkx's orientation
+    got_r = engine.ollivier_ricci_sinkhorn(rowptr, col, pick[:, ::-1])
+    assert np.abs(got_r - got).max() < 1e-5
+    if kind == "clustered":
+        ref_r, _ = ricci_ref.ollivier_ricci_sinkhorn(n, pick[:, ::-1])
+        assert np.abs(got_r - ref_r).max() < 1e-7
+
+
+def _ref_subset(n, edges, pick):
+    """restatement on the full graph, evaluated for the picked edges only"""
+    from oracle import ricci_ref
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import shortest_path
+    a = sp.coo_matrix((np.ones(len(edges)), (edges[:, 0], edges[:, 1])), shape=(n, n))
+    adj = ((a + a.T) > 0).astype(np.float64).tocsr()
+    dist = shortest_path(adj, method="D", unweighted=True)
+    out, its = [], []
+    for s, t in pick.tolist():
+        xs = np.concatenate([adj.indices[adj.indptr[s]:adj.indptr[s + 1]], [s]])
+        ys = np.concatenate([adj.indices[adj.indptr[t]:adj.indptr[t + 1]], [t]])
+        x = np.concatenate([np.full(len(xs) - 1, 0.5 / (len(xs) - 1)), [0.5]])
+        y = np.concatenate([np.full(len(ys) - 1, 0.5 / (len(ys) - 1)), [0.5]])
+        m, it = ricci_ref.sinkhorn2(x, y, dist[np.ix_(xs, ys)])
+        out.append(1.0 - m)
+        its.append(it)
+    return np.array(out), np.array(its)
+
+
+def test_compute_ricci_curvature_dropin_and_pipeline():
+    """loaddatas.compute_ricci_curvature without a supplied list: the reference's sorted [u, v, kappa] format, both
+    directions, and TLCGNN.call runs end to end from edge_index alone."""
+    import torch
+    from tlc_gnn_amd import loaddatas, synth
+    from tlc_gnn_amd.baselines import TLCGNN
+    from tlc_gnn_amd.data import Data
+    from oracle import ricci_ref
+    n, m, F_ = 200, 520, 24
+    edges = synth.holme_kim_edges(n, m, triad_p=0.5, seed=9)
+    ei = torch.from_numpy(np.concatenate([edges, edges[:, ::-1]]).T.copy()).long()
+    data = Data(x=torch.from_numpy(synth.synthetic_features(n, F_, seed=2)), edge_index=ei, y=torch.zeros(n, dtype=torch.long))
+    lst = loaddatas.compute_ricci_curvature(data)
+    assert len(lst) == 2 * m and lst == sorted(lst)
+    # orientation of every edge as networkx's G.edges() gives it: the endpoint that entered the graph first comes first
+    import networkx as nx
+    g = nx.Graph()
+    g.add_edges_from([(int(a), int(b)) for a, b in ei.numpy().T.tolist()])
+    oriented = np.array(list(g.edges()))
+    ref, _ = ricci_ref.ollivier_ricci_sinkhorn(n, oriented)
+    d = {(a, b): k for a, b, k in lst}
+    for (a, b), k in zip(oriented.tolist(), ref.tolist()):
+        assert abs(d[(a, b)] - k) < 1e-7 and d[(a, b)] == d[(b, a)]
+    import tempfile
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            model, data = TLCGNN.call(data, "Cora", F_, 2, 0)          # no ricci_list: curvature computed on the way
+        finally:
+            os.chdir(cwd)
+    model.eval()
+    with torch.no_grad():
+        prob, y = model.decode(data, model.encode(data), "test")
+    assert torch.isfinite(prob).all() and (np.abs(np.asarray(model.PI)).sum(1) > 0).any()

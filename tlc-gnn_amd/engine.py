@@ -244,3 +244,45 @@ def select_rows(pi, status, index_base, count, out_idx, out_status, out_rows, hi
                                     _lib.ptr(count), _lib.ptr(hist), _lib.ptr(out_idx), _lib.ptr(out_status), _lib.ptr(out_rows),
                                     _lib.stream_ptr())
     _lib.check(rc, "tlc_select_rows")
+
+
+def ollivier_ricci_sinkhorn(rowptr, col, edges, alpha=0.5, reg=0.1, max_iter=1000, stop_thr=1e-9, device=None, want_iters=False):
+    """Ollivier-Ricci curvature of the given edges with the Sinkhorn transport distance -- GraphRicciCurvature's
+    OllivierRicci(G, alpha, method="Sinkhorn") as loaddatas.py:105-123 calls it (tlc_ollivier_ricci_sinkhorn).
+
+    rowptr/col: numpy CSR of the symmetric, loop-free, unit-weight graph (columns ascending); edges: int [E,2] adjacent pairs.
+    Returns float64 numpy [E] (and the iteration counts)."""
+    torch = _lib.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+    E, n = len(edges), len(rowptr) - 1
+    if E == 0:
+        return (np.zeros(0), np.zeros(0, dtype=np.int32)) if want_iters else np.zeros(0)
+    deg = np.diff(rowptr).astype(np.int64)
+    ok = (edges >= 0).all(1) & (edges < n).all(1)
+    na = np.where(ok, deg[np.clip(edges[:, 0], 0, n - 1)] + 1, 1)
+    nb = np.where(ok, deg[np.clip(edges[:, 1], 0, n - 1)] + 1, 1)
+    prod = na * nb
+    big = prod > 3072
+    max_support = int(max(2, (na + nb).max()))
+    max_product = int(prod[big].max()) if big.any() else 16
+    slots = int(min(max(int(big.sum()), 1), 512))
+    work_bytes = 16 + ((4 * E + 15) // 16) * 16 + slots * (((max_product + 15) // 16) * 16)
+    with torch.cuda.device(dev):
+        d_rowptr, d_col = torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev)
+        d_edges = torch.from_numpy(edges).to(dev)
+        kappa = torch.empty(E, dtype=torch.float64, device=dev)
+        iters = torch.empty(E, dtype=torch.int32, device=dev)
+        work = torch.empty(work_bytes, dtype=torch.uint8, device=dev)
+        rc = _lib.lib().tlc_ollivier_ricci_sinkhorn(C.c_int32(n), _lib.ptr(d_rowptr), _lib.ptr(d_col), C.c_int64(E), _lib.ptr(d_edges),
+                                                    C.c_double(alpha), C.c_double(reg), C.c_int32(max_iter), C.c_double(stop_thr),
+                                                    _lib.ptr(kappa), _lib.ptr(iters), _lib.ptr(work), C.c_int64(work_bytes),
+                                                    C.c_int32(max_support), C.c_int64(max_product), _lib.stream_ptr())
+        _lib.check(rc, "tlc_ollivier_ricci_sinkhorn")
+        out = kappa.cpu().numpy()
+        it = iters.cpu().numpy()
+    if np.isnan(out).any():
+        raise _lib.TlcError("tlc_ollivier_ricci_sinkhorn: an edge exceeded the workspace (max_support / max_product)")
+    return (out, it) if want_iters else out

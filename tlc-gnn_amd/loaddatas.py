@@ -126,16 +126,33 @@ def compute_persistence_image_streamed(data, train_edges, negatives, val_edges, 
 
 
 def compute_ricci_curvature(data):
-    """loaddatas.py:105-123 calls the third-party GraphRicciCurvature (Sinkhorn, alpha=0.5); that solver is the
-    step BEFORE the path.  Here the curvature must be supplied as `data.ricci_list`:
-    the reference's format, a sorted list of [u, v, kappa] holding both directions of every edge."""
+    """loaddatas.py:105-123: Ollivier-Ricci curvature (alpha 0.5, Sinkhorn) of every edge of data.edge_index as the sorted list
+    [[u, v, kappa], [v, u, kappa], ...].  The reference delegates to the third-party GraphRicciCurvature (absent here); this
+    runs the same computation on the GPU (tlc_ollivier_ricci_sinkhorn; parity unpinned, see the checker's header in
+    tests/).  A caller-supplied `data.ricci_list` (the reference's format) takes precedence -- e.g. curvature computed
+    elsewhere, or the seeded stand-in of tlc_gnn_amd.synth.synthetic_curvature."""
     ricci = getattr(data, "ricci_list", None)
-    if ricci is None:
-        raise NotImplementedError(
-            "compute_ricci_curvature: supply data.ricci_list ([[u, v, kappa], ...], both directions, sorted); the "
-            "Ollivier-Ricci solver is not part of the accelerated path (tlc_gnn_amd.synth.synthetic_curvature makes a "
-            "seeded stand-in)")
-    return ricci
+    if ricci is not None:
+        return ricci
+    from . import engine, synth
+    ei = _edge_index_numpy(data.edge_index).astype(np.int64)
+    ei = ei[:, ei[0] != ei[1]]                                   # the library drops self loops
+    und = np.unique(np.sort(ei.T, axis=1), axis=0)
+    n = int(max(len(data.y), und.max() + 1)) if len(und) else len(data.y)
+    rowptr, col, _ = synth.edges_to_csr(n, und)
+    # (source, target) as networkx's G.edges() yields it after add_edges_from(edge list): the endpoint that entered the graph
+    # first is the source.  The Sinkhorn loop stops on the target marginal, so the orientation shows at the 1e-6 level.
+    flat = ei.T.reshape(-1)
+    first = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(first, flat, np.arange(len(flat)))
+    swap = first[und[:, 0]] > first[und[:, 1]]
+    oriented = np.where(swap[:, None], und[:, ::-1], und)
+    kappa = engine.ollivier_ricci_sinkhorn(rowptr, col, oriented, alpha=0.5)
+    ricci_list = []
+    for (n1, n2), k in zip(oriented.tolist(), kappa.tolist()):
+        ricci_list.append([n1, n2, k])
+        ricci_list.append([n2, n1, k])
+    return sorted(ricci_list)
 
 
 def compute_persistence_image(data, train_edges, train_edges_false, val_edges, val_edges_false, test_edges,
