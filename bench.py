@@ -125,6 +125,27 @@ def pdgnn_aux(torch, dev, n_graphs=8192, seed=1234):
                     "device-resident calls; not part of `value`"}
 
 
+def _ricci_cpu_sample(ricci_ref, n, edges, sample):
+    """CPU restatement (numpy Sinkhorn of oracle/ricci_ref.py) for a sample of edges; hop distances by the 0/1/2/3 rule from
+    adjacency sets (an all-pairs BFS of the 19 717-node graph would dominate the timing)."""
+    nb = [[] for _ in range(n)]
+    for a, b in edges.tolist():
+        nb[a].append(b)
+        nb[b].append(a)
+    sets = [set(x) for x in nb]
+    out = []
+    for s, t in sample.tolist():
+        xs, ys = nb[s] + [s], nb[t] + [t]
+        M = np.empty((len(xs), len(ys)))
+        for i, a in enumerate(xs):
+            for j, b in enumerate(ys):
+                M[i, j] = 0 if a == b else (1 if b in sets[a] else (2 if sets[a] & sets[b] else 3))
+        x = np.concatenate([np.full(len(xs) - 1, 0.5 / (len(xs) - 1)), [0.5]])
+        y = np.concatenate([np.full(len(ys) - 1, 0.5 / (len(ys) - 1)), [0.5]])
+        out.append(1.0 - ricci_ref.sinkhorn2(x, y, M)[0])
+    return np.array(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +285,32 @@ def main():
             torch.cuda.synchronize()
         except Exception as ex:
             full_sweep = {"error": repr(ex)}
+    # auxiliary (untimed region): the step before the path -- Ollivier-Ricci curvature (alpha 0.5, Sinkhorn reg 0.1) of every
+    # edge of the training graph (loaddatas.py:105-123), the producer of the path's edge weights
+    ricci = None
+    if rank == 0 and not args.no_sweep:
+        try:
+            te_ = wl["train_edges"]
+            rp_, col_ = wl["rowptr"], wl["col"]
+            engine.ollivier_ricci_sinkhorn(rp_, col_, te_[:1000])
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            kap_, it_ = engine.ollivier_ricci_sinkhorn(rp_, col_, te_, want_iters=True)
+            rdt = time.perf_counter() - c0
+            ricci = {"edges": int(len(te_)), "seconds": rdt, "edges_per_sec": len(te_) / rdt, "mean_iterations": float(it_.mean()),
+                     "max_iterations": int(it_.max()), "kappa_min": float(kap_.min()), "kappa_max": float(kap_.max()),
+                     "note": "host wall clock incl. H2D of the CSR and D2H of kappa; not part of `value`"}
+            if not args.no_cpu_baseline:
+                from oracle import ricci_ref
+                sub = te_[:: max(1, len(te_) // 300)][:300]
+                c0 = time.perf_counter()
+                ref_k = _ricci_cpu_sample(ricci_ref, wl["n"], te_, sub)
+                cdt = time.perf_counter() - c0
+                got_k = kap_[:: max(1, len(te_) // 300)][:300]
+                ricci["cpu_restatement_edges_per_sec_1thread"] = len(sub) / cdt
+                ricci["max_abs_diff_vs_cpu_sample"] = float(np.abs(ref_k - got_k).max())
+        except Exception as ex:
+            ricci = {"error": repr(ex)}
     # auxiliary (untimed region): configs 3/5 of BASELINE.json -- the per-graph PDGNN forward next to the exact PD of the same
     # graphs (Knowledge_Distillation evaluate_time, train_Teacher_Model_GC.py:118-143) on HIV-shaped synthetic molecules
     # (n ~ Poisson(25), a random tree plus a few ring-closing edges, degree filtration / (max + 1e-10), data_utils_GC.py:117-119),
@@ -366,6 +413,7 @@ def main():
             "roofline_lp": lp_roof,
             "sweep": sweep,
             "full_sweep": full_sweep,
+            "ricci": ricci,
             "pdgnn": pdgnn,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -235,7 +235,7 @@ int tlc_select_rows(int64_t n_rows, int32_t width, const double* d_pi, const uin
 
 /* ---- the producer of the path's edge weights -------------------------------------------------------
  * compute_ricci_curvature (loaddatas.py:105-123) = third-party GraphRicciCurvature `OllivierRicci(G, alpha=0.5,
- * method="Sinkhorn")` (not in the reference tree, version not pinned; restated in oracle/ricci_ref.py -- parity unpinned):
+ * method="Sinkhorn")` (not in the reference tree, version not pinned; restated from the published algorithm -- parity unpinned):
  * per edge (s,t), m_s = alpha at s + (1-alpha)/deg on the neighbours, cost = hop distance, W = <P, d> of POT's
  * `sinkhorn2(x, y, d, reg)` (sinkhorn_knopp: stop when the marginal violation <= stop_thr, tested every 10th iteration, or after
  * max_iter iterations), kappa = 1 - W.  The library's call is (alpha 0.5, reg 0.1, max_iter 1000, stop_thr 1e-9).

@@ -1,7 +1,7 @@
 // ricci.hip -- the producer of the path's edge weights: Ollivier-Ricci curvature of every edge with
 // the entropic (Sinkhorn) transport distance, as loaddatas.py:105-123 asks of the third-party GraphRicciCurvature
 // (`OllivierRicci(G, alpha=0.5, method="Sinkhorn")`, absent from the reference tree and from this image: the algorithm is
-// restated from its published form, see oracle/ricci_ref.py -- parity unpinned).
+// restated from its published form; the CPU checker under tests/ says which -- parity unpinned).
 //
 // Per edge (s, t):  m_s = alpha at s, (1 - alpha)/deg(s) on each neighbour (unit weights: base^(-w^p) is the same for all);
 // m_t likewise;  cost d(a, b) = hop distance in the whole graph between a in N[s] and b in N[t];  W = <P, d> for the Sinkhorn
