@@ -241,9 +241,9 @@ int tlc_select_rows(int64_t n_rows, int32_t width, const double* d_pi, const uin
  * max_iter iterations), kappa = 1 - W.  The library's call is (alpha 0.5, reg 0.1, max_iter 1000, stop_thr 1e-9).
  *   CSR: symmetric, no self loops, columns ascending and unique inside a row, unit weights.  d_edges int32[n_edges,2]: adjacent
  *   pairs (a self pair gets curvature 0).  d_kappa double[n_edges]; d_iters int32[n_edges] (may be NULL): iterations used.
- *   d_work/work_bytes: >= 16 + 4*n_edges (rounded up to 16) + k * max_product bytes (rounded up to 16), k >= 1 slots for the
- *   hub edges; max_support >= max over edges of deg(s)+deg(t)+2 and max_product >= max of (deg(s)+1)*(deg(t)+1) over the edges
- *   above 3 072 entries.  An edge that exceeds them gets NaN (and iters -1), never a silent value. */
+ *   d_work/work_bytes: >= 16 + 4*n_edges (rounded up to 16) + k * max_product/4 bytes (rounded up to 16), k >= 1 slots for the
+ *   hub edges (2-bit hop codes of supports beyond the LDS); max_support >= max over edges of deg(s)+deg(t)+2 and max_product >= max of (deg(s)+1)*(deg(t)+1) over the edges
+ *   with more than 8 192 entries or deg(s)+deg(t)+2 > 256 (those the one-wavefront kernel leaves to the workgroup kernel).  An edge that exceeds them gets NaN (and iters -1), never a silent value. */
 int tlc_ollivier_ricci_sinkhorn(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, int64_t n_edges,
                                 const int32_t* d_edges, double alpha, double reg, int32_t max_iter, double stop_thr,
                                 double* d_kappa, int32_t* d_iters, void* d_work, int64_t work_bytes, int32_t max_support,

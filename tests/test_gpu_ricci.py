@@ -21,8 +21,8 @@ def _graph(kind, rs):
         par = np.array([rs.randint(0, k) for k in range(1, n)])
         e = np.stack([par, np.arange(1, n)], 1)                      # a tree: leaves, paths, no triangles
         return n, e
-    if kind == "hub":                                                # a hub of degree 220 whose neighbours have ~20 neighbours:
-        n = 700                                                      # (221 x 21 codes) > 3072 -> the workgroup kernel
+    if kind == "hub":                                                # a hub of degree 220 (+ 1 + 20 + 1 > 256 support entries):
+        n = 700                                                      # left to the workgroup kernel
         e = [[0, k] for k in range(1, 221)]
         for k in range(1, 221):
             for x in rs.choice(np.arange(221, n), 19, replace=False):

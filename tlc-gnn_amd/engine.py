@@ -265,11 +265,11 @@ def ollivier_ricci_sinkhorn(rowptr, col, edges, alpha=0.5, reg=0.1, max_iter=100
     na = np.where(ok, deg[np.clip(edges[:, 0], 0, n - 1)] + 1, 1)
     nb = np.where(ok, deg[np.clip(edges[:, 1], 0, n - 1)] + 1, 1)
     prod = na * nb
-    big = prod > 3072
+    big = (prod > 8192) | (na + nb > 256)                         # what the wavefront kernel leaves to the workgroup kernel
     max_support = int(max(2, (na + nb).max()))
     max_product = int(prod[big].max()) if big.any() else 16
     slots = int(min(max(int(big.sum()), 1), 512))
-    work_bytes = 16 + ((4 * E + 15) // 16) * 16 + slots * (((max_product + 15) // 16) * 16)
+    work_bytes = 16 + ((4 * E + 15) // 16) * 16 + slots * ((((max_product + 3) // 4 + 15) // 16) * 16)
     with torch.cuda.device(dev):
         d_rowptr, d_col = torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev)
         d_edges = torch.from_numpy(edges).to(dev)
