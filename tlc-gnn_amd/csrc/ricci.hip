@@ -237,10 +237,11 @@ __global__ __launch_bounds__(256) void ricci_small_kernel(RicciParams p) {
     }
 }
 
-// hub edges: 256 threads per edge, u / v and (when they fit: lds_codes bytes) the codes in LDS, else the codes in an HBM slot
-__global__ __launch_bounds__(256) void ricci_big_kernel(RicciParams p, int lds_codes) {
+// hub edges: RICCI_BIG_THREADS threads per edge (a 437 x 404 hub-hub edge with 181 iterations kept a 256-thread workgroup for 44 ms), u / v and (when they fit: lds_codes bytes) the codes in LDS, else the codes in an HBM slot
+#define RICCI_BIG_THREADS 1024
+__global__ __launch_bounds__(RICCI_BIG_THREADS) void ricci_big_kernel(RicciParams p, int lds_codes) {
     extern __shared__ __attribute__((aligned(16))) double s_big[];
-    __shared__ double s_red[4];
+    __shared__ double s_red[RICCI_BIG_THREADS / 64];
     int* const s_idx = reinterpret_cast<int*>(s_big + p.max_support);                    // [max_support + 2]
     unsigned int* lds_code_base = reinterpret_cast<unsigned int*>(s_idx + ((p.max_support + 2 + 3) & ~3));
     const int n_big = *p.big_count;
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void ricci_big_kernel(RicciParams p, int lds_c
             if (threadIdx.x == 0) { p.kappa[e] = __longlong_as_double(0x7ff8000000000000LL); if (p.iters) p.iters[e] = -1; }
             continue;
         }
-        ricci_edge<256>(p, e, in_lds ? lds_code_base : p.big_codes + (size_t)blockIdx.x * (size_t)(p.slot_bytes / 4), s_big, s_big + na, s_idx,
+        ricci_edge<RICCI_BIG_THREADS>(p, e, in_lds ? lds_code_base : p.big_codes + (size_t)blockIdx.x * (size_t)(p.slot_bytes / 4), s_big, s_big + na, s_idx,
                         s_red, threadIdx.x);
     }
 }
@@ -297,7 +298,7 @@ extern "C" int tlc_ollivier_ricci_sinkhorn(int32_t n_nodes, const int32_t* d_row
     if (lds_codes < 0) lds_codes = 0;
     const size_t lds = (size_t)max_support * 8 + (size_t)idx_bytes + (size_t)lds_codes;
     if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)ricci_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ricci_big_kernel, dim3((unsigned)slots), dim3(256), lds, s, p, (int)lds_codes);
+    hipLaunchKernelGGL(ricci_big_kernel, dim3((unsigned)slots), dim3(RICCI_BIG_THREADS), lds, s, p, (int)lds_codes);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }

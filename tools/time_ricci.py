@@ -6,7 +6,7 @@ from tlc_gnn_amd import engine, synth
 
 n, e, k, hop, _ = synth.shaped_graph("PubMed")
 rowptr, col, w = synth.edges_to_csr(n, e)
-engine.ollivier_ricci_sinkhorn(rowptr, col, e[:1000])
+engine.ollivier_ricci_sinkhorn(rowptr, col, e)
 for name, sub in (("all edges", e), ("edges with a small support", None), ("hub edges", None)):
     deg = np.diff(rowptr)
     prod = (deg[e[:, 0]] + 1) * (deg[e[:, 1]] + 1)
