@@ -113,3 +113,17 @@ def test_compute_ricci_curvature_dropin_and_pipeline():
     with torch.no_grad():
         prob, y = model.decode(data, model.encode(data), "test")
     assert torch.isfinite(prob).all() and (np.abs(np.asarray(model.PI)).sum(1) > 0).any()
+
+
+def test_kd_compute_ricci_curvature_cache_roundtrip(tmp_path):
+    import torch
+    from tlc_gnn_amd import synth
+    from tlc_gnn_amd.data import Data
+    from tlc_gnn_amd.Knowledge_Distillation import data_utils_LP
+    edges = synth.holme_kim_edges(80, 200, triad_p=0.5, seed=1)
+    ei = torch.from_numpy(np.concatenate([edges, edges[:, ::-1]]).T.copy()).long()
+    data = Data(x=None, edge_index=ei, y=torch.zeros(80))
+    a = data_utils_LP.compute_ricci_curvature(data, "toy", cache_dir=str(tmp_path))
+    assert os.path.exists(str(tmp_path / "graph_toy_removevaltest.edge_list"))
+    b = data_utils_LP.compute_ricci_curvature(data, "toy", cache_dir=str(tmp_path))          # second call: from the file
+    assert a == b and len(a) == 400

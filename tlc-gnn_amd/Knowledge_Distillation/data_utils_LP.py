@@ -100,3 +100,33 @@ def compute_persistence_image(g, u, v, filt='hks', hks_time=0.1, hop=2, ricci_cu
     both = torch.cat((ord0, ext1))
     pers_img = PI1 if c[0] == 0 else (PI0 if c[2] == 0 else img(both))
     return ord0.cpu().numpy(), ext1.cpu().numpy(), pers_img, fv.tolist(), edge_index, PI0, PI1, 0.0, 0.0
+
+
+def load_ricci_file(filename):
+    """The reference's curvature cache: one `u v kappa` line per directed edge (data_utils_LP.py:233-240 writes it)."""
+    ricci_list = []
+    with open(filename) as f:
+        for line in f:
+            a, b, k = line.split()
+            ricci_list.append([int(a), int(b), float(k)])
+    return ricci_list
+
+
+def compute_ricci_curvature(data, data_name, cache_dir='./data/curvature'):
+    """data_utils_LP.py:202-242: Ollivier-Ricci curvature (alpha 0.5, Sinkhorn) of data.edge_index, cached as a text file of
+    `u v kappa` lines.  The reference delegates to GraphRicciCurvature and writes under a hard-wired absolute path; here the
+    curvature comes from the GPU (loaddatas.compute_ricci_curvature -> tlc_ollivier_ricci_sinkhorn) and the path is a
+    parameter (None disables the cache)."""
+    import os
+    from ..loaddatas import compute_ricci_curvature as _compute
+    filename = os.path.join(cache_dir, 'graph_' + data_name + '_removevaltest.edge_list') if cache_dir else None
+    if filename and os.path.exists(filename):
+        print("curvature file exists, directly loading")
+        return load_ricci_file(filename)
+    ricci_list = _compute(data)
+    if filename:
+        os.makedirs(os.path.dirname(filename), exist_ok=True)
+        with open(filename, 'w') as f:
+            for a, b, k in ricci_list:
+                f.write(str(a) + " " + str(b) + " " + repr(float(k)) + "\n")
+    return ricci_list
