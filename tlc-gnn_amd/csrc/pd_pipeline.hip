@@ -346,6 +346,55 @@ __device__ __forceinline__ void bitonic_sort(ull* key, unsigned* val, int P) {
     }
 }
 
+// Sort of `cnt` pairs whose array is padded with ~0 keys up to P = pow2ceil(cnt) (callers read the first cnt positions).
+// The bitonic network costs P log^2 P whatever cnt is, and a count just above a power of two pays for twice its size (the
+// batch's heaviest vicinity has 2 270 edges: P = 4 096).  When the part above P/2 fits a quarter of P, the two parts are
+// sorted as runs of P/2 and R = pow2ceil(cnt - P/2) elements and merged by rank: an element's final position is its index in
+// its own run plus the number of elements of the other run ordered before it (binary search in LDS; equal keys: the lower
+// run first), elements held in registers across the barrier.  Falls back to the plain network when the runs do not pay
+// or a thread would have to hold more than eight elements (HUGE tier).
+template <int W>
+__device__ __forceinline__ void sort_padded(ull* key, unsigned* val, int cnt) {
+    const int P = pow2ceil(cnt < 2 ? 2 : cnt);
+    const int H = P >> 1, r = cnt - H;
+    const int R = r > 0 ? pow2ceil(r < 2 ? 2 : r) : P;
+    const int total = H + R;
+    if (P < 256 || 4 * R > P || total > 8 * W) {
+        bitonic_sort<W>(key, val, P);
+        return;
+    }
+    bitonic_sort<W>(key, val, H);
+    bitonic_sort<W>(key + H, val + H, R);
+    ull kk[8];
+    unsigned vv[8];
+    int pp[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = (int)threadIdx.x + q * W;
+        pp[q] = -1;
+        if (i < total) {
+            const ull k = key[i];
+            kk[q] = k;
+            vv[q] = val[i];
+            int lo, hi;
+            if (i < H) {                               // strictly smaller elements of the upper run
+                lo = 0; hi = R;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[H + mid] < k) lo = mid + 1; else hi = mid; }
+                pp[q] = i + lo;
+            } else {                                   // smaller or equal elements of the lower run
+                lo = 0; hi = H;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[mid] <= k) lo = mid + 1; else hi = mid; }
+                pp[q] = (i - H) + lo;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (pp[q] >= 0) { key[pp[q]] = kk[q]; val[pp[q]] = vv[q]; }
+    __syncthreads();
+}
+
 template <typename idx_t>
 __device__ __forceinline__ int uf_find(idx_t* comp, int p) {
     // path halving exactly as accelerated_PD.py:53-58
@@ -456,7 +505,7 @@ __device__ __forceinline__ void sort_edges(Mem<idx_t>& M, int m) {
         M.valS[e] = (unsigned)e;
     }
     __syncthreads();
-    bitonic_sort<W>(M.keyS, M.valS, P);
+    sort_padded<W>(M.keyS, M.valS, m);
 }
 
 // ---- one filtration pass as a minimum-spanning-forest computation in sorted-position order -----------------------------
