@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the auxiliary random-pair sweep (profiling runs)")
+    ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: 'gloo' lets N ranks share ONE GPU with --single-device "
+                    "(RCCL refuses two ranks on a device); the measured configuration is always nccl = RCCL, one rank per GPU")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="development: no per-kernel HIP events in the timed region (the roofline block is then meaningless)")
     args = ap.parse_args()
@@ -165,11 +168,16 @@ def main():
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     _lib.require_gpu()
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     wl = build_workload(rank)
     n, hop = wl["n"], wl["hop"]
