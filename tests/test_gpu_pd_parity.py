@@ -393,6 +393,48 @@ def test_cycle_swap_long_loops_vs_oracle(torch_cuda, flags):
             assert same_multiset(got[key][base:base + k], ref[key][base:base + k]), (g, key, gs[g][0])   # bit-exact
 
 
+@pytest.mark.parametrize("flags", [0, 1])
+def test_edge_counts_just_above_a_power_of_two(torch_cuda, flags):
+    """The edge sorts split a count just above a power of two into two bitonic runs merged by rank (pd_pipeline.hip,
+    sort_padded): counts around 2^k and 2^k + 2^(k-2) in every tier, with continuous and with heavily tied filtration values
+    (equal keys across the two runs), both forks, bit-exact against the oracle."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine
+    from oracle import oracle
+    rs = np.random.RandomState(17)
+    gs = []
+    for m in (255, 256, 257, 300, 319, 320, 321, 512, 513, 600, 640, 641, 1023, 1025, 1100, 2049, 2270, 2560, 2561, 4000):
+        n = max(8, int(m * 0.68))                              # the batch's heaviest vicinity: 1 539 nodes, 2 270 edges
+        par = np.array([rs.randint(0, k) for k in range(1, n)])
+        tree = np.stack([par, np.arange(1, n)], 1)
+        extra = set()
+        while len(extra) < m - (n - 1):
+            a, b = rs.randint(0, n, 2)
+            if a != b and (min(a, b), max(a, b)) not in extra and par[max(a, b) - 1] != min(a, b):
+                extra.add((min(a, b), max(a, b)))
+        e = np.concatenate([tree, np.array(sorted(extra)).reshape(-1, 2)]).astype(np.int32)
+        assert len(e) == m
+        e = e[rs.permutation(m)]
+        for mode in ("random", "ties"):
+            f = rs.rand(n) if mode == "random" else rs.randint(0, 5, size=n) / 4.0
+            gs.append((n, e, f.astype(np.float64)))
+    node_offs = np.concatenate([[0], np.cumsum([g[0] for g in gs])]).astype(np.int64)
+    edge_offs = np.concatenate([[0], np.cumsum([len(g[1]) for g in gs])]).astype(np.int64)
+    edges = np.concatenate([g[1] for g in gs]).astype(np.int32)
+    f = np.concatenate([g[2] for g in gs])
+    ref = oracle.pd_from_filtration(node_offs, edge_offs, edges, f, flags)
+    got = engine.pd_from_filtration(_dev(torch, node_offs, torch.int64), _dev(torch, edge_offs, torch.int64),
+                                    _dev(torch, edges, torch.int32), _dev(torch, f, torch.float64), flags)
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    assert np.array_equal(got["counts"], ref["counts"])
+    assert np.array_equal(got["ext0"], ref["ext0"])
+    for g in range(len(gs)):
+        no, eo = node_offs[g], edge_offs[g]
+        c = ref["counts"][g]
+        for key, base, k in (("up", no, c[0]), ("down", no, c[1]), ("one", eo, c[2])):
+            assert same_multiset(got[key][base:base + k], ref[key][base:base + k]), (g, key, gs[g][0], len(gs[g][1]))
+
+
 def test_pd_from_filtration_rejects_oversized_graph(torch_cuda):
     """More than 65 535 nodes do not fit the packed local ids: the graph is skipped and says so (counts row = -1); its
     neighbours in the batch are still computed."""
