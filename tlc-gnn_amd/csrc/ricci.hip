@@ -106,9 +106,8 @@ __device__ void ricci_edge(const RicciParams& p, long long e, unsigned int* code
     const int sl = p.rowptr[s], tl = p.rowptr[t];
     const int ds = p.rowptr[s + 1] - sl, dt = p.rowptr[t + 1] - tl;
     const int na = ds + 1, nb = dt + 1;
-    // support a_i: the neighbours of s, then s itself (mass alpha); same for t
+    // support a_i: the neighbours of s, then s itself (mass alpha); the target support likewise (its ids are staged in LDS below)
     auto sup_a = [&](int i) { return i < ds ? p.col[sl + i] : s; };
-    auto sup_b = [&](int j) { return j < dt ? p.col[tl + j] : t; };
     const double ma = ds > 0 ? (1.0 - p.alpha) / (double)ds : 0.0, mb = dt > 0 ? (1.0 - p.alpha) / (double)dt : 0.0;
     auto mass_a = [&](int i) { return i < ds ? ma : (ds > 0 ? p.alpha : 1.0); };
     auto mass_b = [&](int j) { return j < dt ? mb : (dt > 0 ? p.alpha : 1.0); };
