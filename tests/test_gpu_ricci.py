@@ -58,6 +58,16 @@ def test_ollivier_ricci_sinkhorn_vs_restatement(kind):
         assert np.abs(got_r - ref_r).max() < 1e-7
 
 
+def test_non_adjacent_pairs_are_refused():
+    from tlc_gnn_amd import engine, synth
+    rowptr, col, _ = synth.edges_to_csr(5, np.array([[0, 1], [1, 2], [3, 4]]))
+    with pytest.raises(ValueError):
+        engine.ollivier_ricci_sinkhorn(rowptr, col, np.array([[0, 2]]))           # two hops apart: not an edge
+    with pytest.raises(ValueError):
+        engine.ollivier_ricci_sinkhorn(rowptr, col, np.array([[0, 7]]))
+    assert engine.ollivier_ricci_sinkhorn(rowptr, col, np.array([[2, 2], [3, 4]]))[0] == 0.0   # self pair: 0
+
+
 def _ref_subset(n, edges, pick):
     """restatement on the full graph, evaluated for the picked edges only"""
     from oracle import ricci_ref

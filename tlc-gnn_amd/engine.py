@@ -262,6 +262,16 @@ def ollivier_ricci_sinkhorn(rowptr, col, edges, alpha=0.5, reg=0.1, max_iter=100
         return (np.zeros(0), np.zeros(0, dtype=np.int32)) if want_iters else np.zeros(0)
     deg = np.diff(rowptr).astype(np.int64)
     ok = (edges >= 0).all(1) & (edges < n).all(1)
+    if not ok.all():
+        raise ValueError("ollivier_ricci_sinkhorn: edge endpoint out of range")
+    # the 0/1/2/3 hop-distance rule of the kernel holds for ADJACENT pairs only: every edge must be in the CSR (self pairs get 0)
+    keys = np.repeat(np.arange(n, dtype=np.int64), deg) * n + col.astype(np.int64)
+    want = edges[:, 0].astype(np.int64) * n + edges[:, 1].astype(np.int64)
+    loops = edges[:, 0] == edges[:, 1]
+    pos = np.searchsorted(keys, want)
+    found = (pos < len(keys)) & (keys[np.minimum(pos, max(len(keys) - 1, 0))] == want) if len(keys) else np.zeros(E, dtype=bool)
+    if not (found | loops).all():
+        raise ValueError("ollivier_ricci_sinkhorn: every pair must be an edge of the CSR (columns ascending)")
     na = np.where(ok, deg[np.clip(edges[:, 0], 0, n - 1)] + 1, 1)
     nb = np.where(ok, deg[np.clip(edges[:, 1], 0, n - 1)] + 1, 1)
     prod = na * nb
