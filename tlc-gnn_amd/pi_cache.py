@@ -178,40 +178,45 @@ class SparseImages:
         return cls(pi.shape[0], pi.shape[1], idx, pi[idx], status[idx])
 
 
-def sweep_images(graph, pair_source, n_pairs, hop, flags=0, res=5, chunk=1 << 22, index_base=0, store=None, keep_failed=False):
+def sweep_images(graph, pair_source, n_pairs, hop, flags=0, res=5, chunk=1 << 22, index_base=0, store=None, keep_failed=False,
+                 expect_fraction=0.004):
     """Images of a long pair list, streamed: pair_source(lo, hi) -> int32 CUDA [hi-lo, 2] for list positions lo..hi-1.
 
-    Every chunk goes through tlc_pd_pi_batch (graph: engine.DeviceGraph) and tlc_select_rows; only the non-zero rows (and, with
-    keep_failed, the zero rows whose pair failed) leave the device, plus the histogram of the status bytes.  Returns
-    SparseImages over positions index_base .. index_base + n_pairs - 1 of a store with n_pairs rows (or extends `store`, a list
-    of (idx, rows, status, status_counts) pieces, and returns None)."""
+    Every chunk goes through tlc_pd_pi_batch (graph: engine.DeviceGraph) and tlc_select_rows, which appends the non-zero rows (and,
+    with keep_failed, the zero rows whose pair failed) to ONE device-side store and adds the status bytes to a histogram; nothing is
+    synchronised or copied until the list is through (the store is sized from `expect_fraction`; if it turns out too small the
+    sweep is repeated with the size it reported).  Returns SparseImages over positions index_base .. index_base + n_pairs - 1 of
+    a store with n_pairs rows (or extends `store`, a list of (idx, rows, status, status_counts) pieces, and returns None)."""
     import torch
     width = res * res
     dev = torch.device("cuda", graph.device)
     pieces = [] if store is None else store
-    cap = max(1 << 16, chunk // 16)
+    cap = max(1 << 16, int(n_pairs * expect_fraction) + (1 << 14))
+    if keep_failed:
+        cap = max(cap, n_pairs)
     with torch.cuda.device(dev):
         out = torch.empty((min(chunk, max(n_pairs, 1)), width), dtype=torch.float64, device=dev)
         st = torch.empty(out.shape[0], dtype=torch.uint8, device=dev)
         count = torch.zeros(1, dtype=torch.int64, device=dev)
         hist = torch.zeros(8, dtype=torch.int64, device=dev)
-        for lo in range(0, n_pairs, chunk):
-            hi = min(n_pairs, lo + chunk)
-            pairs = pair_source(lo, hi)
-            graph.pd_pi_batch(pairs, hop, flags=flags, res=res, out=out[: hi - lo], status=st[: hi - lo])
-            while True:
-                sel_idx = torch.empty(cap, dtype=torch.int64, device=dev)
-                sel_st = torch.empty(cap, dtype=torch.uint8, device=dev)
-                sel_rows = torch.empty((cap, width), dtype=torch.float64, device=dev)
-                count.zero_()
-                hist.zero_()
+        while True:
+            sel_idx = torch.empty(cap, dtype=torch.int64, device=dev)
+            sel_st = torch.empty(cap, dtype=torch.uint8, device=dev)
+            sel_rows = torch.empty((cap, width), dtype=torch.float64, device=dev)
+            count.zero_()
+            hist.zero_()
+            for lo in range(0, n_pairs, chunk):
+                hi = min(n_pairs, lo + chunk)
+                pairs = pair_source(lo, hi)
+                graph.pd_pi_batch(pairs, hop, flags=flags, res=res, out=out[: hi - lo], status=st[: hi - lo])
                 engine.select_rows(out[: hi - lo], st[: hi - lo], index_base + lo, count, sel_idx, sel_st, sel_rows, hist=hist,
                                    keep_failed=keep_failed)
-                k = int(count.item())
-                if k <= cap:
-                    break
-                cap = 2 * k                                                  # store too small for this chunk: once more
-            pieces.append((sel_idx[:k].cpu().numpy(), sel_rows[:k].cpu().numpy(), sel_st[:k].cpu().numpy(), hist.cpu().numpy()))
+            k = int(count.item())                                        # the only synchronisation of the sweep
+            if k <= cap:
+                break
+            del sel_idx, sel_st, sel_rows
+            cap = k + (k >> 3) + 1024                                    # the store was too small: once more, with what it needs
+        pieces.append((sel_idx[:k].cpu().numpy(), sel_rows[:k].cpu().numpy(), sel_st[:k].cpu().numpy(), hist.cpu().numpy()))
     if store is not None:
         return None
     return assemble(pieces, n_pairs, width)
