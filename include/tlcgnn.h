@@ -220,6 +220,14 @@ int tlc_complement_rows(int32_t n_nodes, const int32_t* d_rowptr, const int32_t*
 int tlc_complement_pairs(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const int64_t* d_row_start,
                          const int64_t* d_ranks, int64_t first, int64_t count, int32_t* d_pairs, void* stream);
 
+/* The distance <= hop pre-filter of the sweep (PI-C): an image row can be non-zero only when d(u,v) <= hop
+ * (SURVEY.md A.6, Z0), so only those non-edges need tlc_pd_pi_batch.  Appends every non-adjacent pair u <= v with d(u,v) <= hop
+ * (the diagonal included unless u has a self loop): d_out_pairs int32[k,2] and d_out_rank int64[k] = the pair's number in the
+ * list of tlc_complement_pairs.  *d_count (uint64, device, zeroed by the caller) is advanced even beyond `cap` (pairs past the
+ * capacity are not written).  Append order is not fixed.  Graphs up to ~100 000 nodes (three LDS bitmaps per wavefront). */
+int tlc_near_pairs(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const int64_t* d_row_start, int hop, int64_t cap,
+                   uint64_t* d_count, int64_t* d_out_rank, int32_t* d_out_pairs, void* stream);
+
 /* The reference caches the dense float64[n_pairs, res^2] image array (loaddatas.py:62-64,102: 39 GB for PubMed's sweep) although
  * every pair with d(u,v) > hop has a zero row, and keeps of the exceptions it swallows only their number (`cnt_compute`,
  * riccidist2dgm.py:355).  tlc_select_rows appends the rows of one image block that have a non-zero entry -- with

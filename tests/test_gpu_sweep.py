@@ -237,3 +237,39 @@ def test_call_streamed_equals_call_dense(torch_cuda):
     for t in ("val", "test", "train"):
         assert np.array_equal(a[t][1], b[t][1]), t
         assert np.array_equal(a[t][0], b[t][0]), t
+
+
+@pytest.mark.parametrize("hop", [1, 2, 3])
+def test_near_pairs_prefilter_equals_the_full_sweep(torch_cuda, hop):
+    """tlc_near_pairs against a BFS on the host (exactly the non-adjacent pairs u <= v within `hop`, with their list numbers),
+    and the pre-filtered sweep against the full one: the same non-zero rows at the same indices."""
+    torch = torch_cuda
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import shortest_path
+    from tlc_gnn_amd import engine, synth, pi_cache
+    n, edges, kappa, _, _ = synth.shaped_graph("PubMed", scale=0.04)
+    n += 2                                                                        # two isolated nodes
+    rowptr, col, w = synth.edges_to_csr(n, edges, kappa)
+    ci = engine.ComplementIndex(rowptr, col)
+    pairs, ranks = engine.near_pairs(ci, hop)
+    pairs, ranks = pairs.cpu().numpy(), ranks.cpu().numpy()
+    a = sp.coo_matrix((np.ones(len(edges)), (edges[:, 0], edges[:, 1])), shape=(n, n))
+    adj = ((a + a.T) > 0).astype(np.float64).tocsr()
+    dist = shortest_path(adj, method="D", unweighted=True)
+    uu, vv = np.nonzero(np.triu((dist <= hop) & (adj.toarray() == 0)))
+    want = set(zip(uu.tolist(), vv.tolist()))
+    assert len(pairs) == len(want) and set(map(tuple, pairs.tolist())) == want
+    back = ci.pairs(ranks=torch.from_numpy(ranks).cuda()).cpu().numpy()
+    assert np.array_equal(back, pairs)                                            # the list numbers are the pairs' own
+    g = engine.DeviceGraph(rowptr, col, w)
+    full = pi_cache.sweep_images(g, lambda lo, hi: ci.pairs(first=lo, count=hi - lo), len(ci), hop, chunk=70001)
+    near = pi_cache.sweep_near(g, ci, hop)
+    assert np.array_equal(near.idx, full.idx) and np.array_equal(near.rows, full.rows)
+    assert near.near_pairs == len(want) and near.unclassified == len(ci) - len(want)
+    # with the reference's shuffle: positions through the inverse permutation
+    perm = np.random.RandomState(3).permutation(len(ci))
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(ci))
+    shuffled = pi_cache.sweep_near(g, ci, hop, positions=lambda r: inv[r])
+    dense_shuffled = full.to_dense()[perm]                                        # row p of the shuffled list = list number perm[p]
+    assert np.array_equal(shuffled.to_dense(), dense_shuffled)
+    g.close()

@@ -27,6 +27,7 @@ SYMBOLS = [
     "tlc_pi_raster", "tlc_gcn_norm_csr", "tlc_gemm_f32", "tlc_spmm_csr_f32", "tlc_renorm_rows_f32",
     "tlc_lp_decode_fused", "tlc_gat_layer_fwd", "tlc_scatter_f32", "tlc_edge_head_fwd",
     "tlc_complement_rows", "tlc_complement_pairs", "tlc_select_rows", "tlc_ollivier_ricci_sinkhorn",
+    "tlc_near_pairs",
 ]
 
 
@@ -98,6 +99,8 @@ def lib():
         L.tlc_ollivier_ricci_sinkhorn.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_double,
                                                   C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                                   C.c_int64, C.c_void_p]
+        L.tlc_near_pairs.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 

@@ -184,3 +184,114 @@ extern "C" int tlc_select_rows(int64_t n_rows, int32_t width, const double* d_pi
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }
+
+// ======================================================================================================================
+// tlc_near_pairs: the distance <= hop pre-filter of the sweep (PI-C).  An image row can be non-zero only when
+// d(u,v) <= hop (otherwise u, v are outside their own vicinity, every filtration value is the sentinel and every point has
+// persistence 0: SURVEY.md A.6, Z0), so of PubMed's 1.9e8 non-edges only the few million inside each other's hop-ball need the
+// PD/PI pipeline at all.  One wavefront per source node u: breadth-first levels over three LDS bitmaps (visited / current /
+// next, atomicOr), then every visited v >= u that is not adjacent to u is appended -- with its number in the reference's
+// negative list (row_start[u] + (v - u) - #neighbours of u in [u, v)) -- through one wave-aggregated atomic per 64 pairs.
+// ======================================================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void near_pairs_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                         const long long* __restrict__ row_start, int hop, long long cap,
+                                                         unsigned long long* __restrict__ count, long long* __restrict__ out_rank,
+                                                         int* __restrict__ out_pairs) {
+    extern __shared__ unsigned int bm_all[];
+    const int W = (n + 31) >> 5;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned int* visited = bm_all + (size_t)wv * 3 * W;
+    unsigned int* cur = visited + W;
+    unsigned int* nxt = cur + W;
+    const long long n_waves = (long long)gridDim.x * 4;
+    auto fence = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    for (long long u = (long long)blockIdx.x * 4 + wv; u < n; u += n_waves) {
+        for (int w = lane; w < W; w += 64) { visited[w] = 0u; cur[w] = 0u; }
+        fence();
+        if (lane == 0) { visited[u >> 5] = 1u << (u & 31); cur[u >> 5] = 1u << (u & 31); }
+        fence();
+        for (int level = 0; level < hop; ++level) {
+            for (int w = lane; w < W; w += 64) nxt[w] = 0u;
+            fence();
+            for (int w = lane; w < W; w += 64) {
+                unsigned bits = cur[w];
+                while (bits) {
+                    const int x = (w << 5) + __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const int xe = rowptr[x + 1];
+                    for (int j = rowptr[x]; j < xe; ++j) {
+                        const int y = col[j];
+                        const unsigned bit = 1u << (y & 31);
+                        if (!(atomicOr(&visited[y >> 5], bit) & bit)) atomicOr(&nxt[y >> 5], bit);
+                    }
+                }
+            }
+            fence();
+            unsigned int* t = cur; cur = nxt; nxt = t;
+        }
+        // emit the visited v >= u that are not neighbours of u, in lockstep rounds (one wave-aggregated append per round)
+        const int ub = rowptr[u], ue = rowptr[u + 1];
+        const int lb_u = lower_bound_col(col, ub, ue, (int)u);
+        int w = (int)(u >> 5) + lane;
+        unsigned bits = 0u;
+        if (w < W) { bits = visited[w]; if (w == (int)(u >> 5)) bits &= ~((1u << (u & 31)) - 1u); }
+        while (true) {
+            while (bits == 0u && w < W) { w += 64; if (w < W) bits = visited[w]; }
+            const bool have = w < W && bits != 0u;
+            if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+            int v = -1;
+            long long rank = -1;
+            bool emit = false;
+            if (have) {
+                v = (w << 5) + __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int lb_v = lower_bound_col(col, ub, ue, v);
+                const bool adjacent = lb_v < ue && col[lb_v] == v;
+                if (!adjacent) { emit = true; rank = row_start[u] + (long long)(v - (int)u) - (long long)(lb_v - lb_u); }
+            }
+            const unsigned long long mk = __builtin_amdgcn_ballot_w64(emit);
+            if (mk) {
+                unsigned long long base = 0;
+                const int leader = __builtin_ctzll(mk);
+                if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(mk));
+                base = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
+                       (unsigned)__builtin_amdgcn_readlane((int)(unsigned)base, leader);
+                if (emit) {
+                    const long long o = (long long)base + __popcll(mk & tlc_lanemask_lt());
+                    if (o < cap) {
+                        out_rank[o] = rank;
+                        reinterpret_cast<int2*>(out_pairs)[o] = make_int2((int)u, v);
+                    }
+                }
+            }
+        }
+        fence();
+    }
+}
+
+}  // namespace
+
+extern "C" int tlc_near_pairs(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const int64_t* d_row_start, int hop,
+                              int64_t cap, uint64_t* d_count, int64_t* d_out_rank, int32_t* d_out_pairs, void* stream) {
+    TLC_REQUIRE(n_nodes >= 0 && hop >= 1 && cap >= 0, "bad argument");
+    TLC_REQUIRE(d_count != nullptr, "null counter");
+    if (n_nodes == 0) return TLC_OK;
+    TLC_REQUIRE(d_rowptr && d_row_start && (cap == 0 || (d_out_rank && d_out_pairs)), "null pointer");
+    const size_t words = ((size_t)n_nodes + 31) / 32;
+    const size_t lds = 4 * 3 * words * 4;                       // four wavefronts x three bitmaps
+    if (lds > 150 * 1024) { tlc_set_error("tlc_near_pairs: graph too large for the LDS bitmaps (%d nodes; limit ~100 000)", n_nodes); return TLC_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)near_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long long blocks = ((long long)n_nodes + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(near_pairs_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, n_nodes, d_rowptr, d_col,
+                       (const long long*)d_row_start, hop, (long long)cap, (unsigned long long*)d_count, (long long*)d_out_rank,
+                       d_out_pairs);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}

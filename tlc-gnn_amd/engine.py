@@ -235,6 +235,29 @@ class ComplementIndex:
         return out
 
 
+def near_pairs(index, hop, cap=None):
+    """Non-adjacent pairs u <= v with d(u,v) <= hop (tlc_near_pairs) of a ComplementIndex: (pairs int32 CUDA [k,2], ranks int64
+    CUDA [k]) with ranks = their numbers in the complement list.  Unordered."""
+    import torch
+    dev = index.rowptr.device
+    cap = max(1 << 16, 64 * index.n_nodes) if cap is None else int(cap)
+    with torch.cuda.device(dev):
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        while True:
+            ranks = torch.empty(cap, dtype=torch.int64, device=dev)
+            pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+            count.zero_()
+            rc = _lib.lib().tlc_near_pairs(C.c_int32(index.n_nodes), _lib.ptr(index.rowptr), _lib.ptr(index.col),
+                                           _lib.ptr(index.row_start), C.c_int(hop), C.c_int64(cap), _lib.ptr(count), _lib.ptr(ranks),
+                                           _lib.ptr(pairs), _lib.stream_ptr())
+            _lib.check(rc, "tlc_near_pairs")
+            k = int(count.item())
+            if k <= cap:
+                return pairs[:k], ranks[:k]
+            del ranks, pairs
+            cap = k + 1024
+
+
 def select_rows(pi, status, index_base, count, out_idx, out_status, out_rows, hist=None, keep_failed=False):
     """Append the non-zero rows of an image block (keep_failed: and the zero rows with status != 0) to a sparse store and add
     the block's status bytes to `hist` (int64 CUDA [8]) -- tlc_select_rows.  count: int64 CUDA scalar tensor the caller zeroed

@@ -114,11 +114,13 @@ class SparseImages:
             status_counts = np.bincount(self.status, minlength=8).astype(np.int64)
             status_counts[0] += self.shape[0] - len(self.idx)
         self.status_counts = np.asarray(status_counts, dtype=np.int64)
+        self.unclassified = 0               # rows whose status byte was never computed (sweep_near: zero by the distance rule)
         self._dev = None
 
     @property
     def cnt_compute(self):
-        """graph2pi.cnt_compute (riccidist2dgm.py:355): pairs whose image was computed without an exception."""
+        """graph2pi.cnt_compute (riccidist2dgm.py:355): pairs whose image was computed without an exception (a lower bound when
+        `unclassified` rows exist: the pre-filtered sweep does not run the pairs it knows to be zero)."""
         return int(self.status_counts[_lib.ST_OK])
 
     def __len__(self):
@@ -220,6 +222,35 @@ def sweep_images(graph, pair_source, n_pairs, hop, flags=0, res=5, chunk=1 << 22
     if store is not None:
         return None
     return assemble(pieces, n_pairs, width)
+
+
+def sweep_near(graph, index, hop, positions=None, flags=0, res=5, chunk=1 << 20):
+    """The images of a whole negative list through the distance pre-filter (PI-C): only the non-edges with
+    d(u,v) <= hop can have a non-zero row (A.6), so tlc_near_pairs lists those (with their numbers in the complement list of
+    `index`, an engine.ComplementIndex) and only they go through tlc_pd_pi_batch.
+
+    positions: None -> a row's index is its list number; or a callable mapping list numbers (int64 numpy) to row indices, e.g.
+    the inverse of the reference's shuffle.  Returns SparseImages over len(index) rows whose status_counts cover the near
+    pairs only; the rows left out are zero by the distance rule and their status bytes are not computed (`unclassified`)."""
+    import torch
+    width = res * res
+    dev = torch.device("cuda", graph.device)
+    with torch.cuda.device(dev):
+        pairs, ranks = engine.near_pairs(index, hop)
+        k = pairs.shape[0]
+        out = torch.empty((max(k, 1), width), dtype=torch.float64, device=dev)
+        st = torch.empty(max(k, 1), dtype=torch.uint8, device=dev)
+        if k:
+            graph.pd_pi_batch(pairs, hop, flags=flags, res=res, out=out[:k], status=st[:k])
+        keep = (out[:k] != 0).any(1)
+        rows = out[:k][keep].cpu().numpy()
+        rk = ranks[keep].cpu().numpy()
+        counts = np.bincount(st[:k].cpu().numpy(), minlength=8).astype(np.int64) if k else np.zeros(8, dtype=np.int64)
+    idx = rk if positions is None else np.asarray(positions(rk), dtype=np.int64)
+    images = SparseImages(len(index), width, idx, rows, np.zeros(len(rk), dtype=np.uint8), counts)
+    images.unclassified = len(index) - k
+    images.near_pairs = k
+    return images
 
 
 def assemble(pieces, n_rows, width):
