@@ -289,7 +289,18 @@ def main():
                           "sparse_bytes": int(store.idx.nbytes + store.rows.nbytes + store.status.nbytes),
                           "note": "all N(N+1)/2 - M non-edges of the training graph incl. the diagonal, host wall clock incl. the "
                                   "D2H of the kept rows; not part of `value`"}
-            del store, ci
+            # the same sweep through the distance <= hop pre-filter (PI-C): only the non-edges inside each other's
+            # hop-ball can have a non-zero row, so only they go through the pipeline; same stored rows
+            pi_cache.sweep_near(g, ci, hop)
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            near = pi_cache.sweep_near(g, ci, hop)
+            torch.cuda.synchronize()
+            ndt = time.perf_counter() - c0
+            full_sweep["prefiltered"] = {"seconds": ndt, "near_pairs": int(near.near_pairs), "list_pairs_per_sec": len(ci) / ndt,
+                                         "nontrivial_pi_per_sec": near.near_pairs / ndt, "stored_rows": int(len(near.idx)),
+                                         "same_rows_as_full_sweep": bool(np.array_equal(near.idx, store.idx) and np.array_equal(near.rows, store.rows))}
+            del store, ci, near
             g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)      # restore the headline batch's header
             torch.cuda.synchronize()
         except Exception as ex:

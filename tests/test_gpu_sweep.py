@@ -144,6 +144,10 @@ def test_streamed_images_equal_the_dense_path(torch_cuda, tmp_path):
     lean, _ = loaddatas.compute_persistence_image_streamed(data, tr, neg, va, vaf, te, tef, hop=hop, chunk=50000)
     assert np.array_equal(lean.idx, np.nonzero((dense != 0).any(1))[0]) and np.array_equal(lean.to_dense(), dense)
     assert np.array_equal(lean.status_counts, images.status_counts) and not lean.status.any()
+    # through the distance pre-filter: the same rows; the far negatives' status bytes are left uncomputed
+    pre, _ = loaddatas.compute_persistence_image_streamed(data, tr, neg, va, vaf, te, tef, hop=hop, prefilter=True)
+    assert np.array_equal(pre.idx, lean.idx) and np.array_equal(pre.rows, lean.rows)
+    assert pre.unclassified > 0 and pre.status_counts.sum() + pre.unclassified == len(total)
     assert len(images.idx) < len(total)                                         # (a 600-node graph at hop 2 is not sparse; PubMed's sweep keeps 0.3 %)
     # and against the oracle on a sample
     pick = np.concatenate([np.arange(0, len(total), 97), images.idx[:: max(1, len(images.idx) // 400)]])

@@ -98,7 +98,7 @@ def get_adj_split_streamed(adj, val_prop=0.05, test_prop=0.1, seed=1234, device=
 
 
 def compute_persistence_image_streamed(data, train_edges, negatives, val_edges, val_edges_false, test_edges, test_edges_false,
-                                       hop=1, chunk=1 << 22, keep_failed=False):
+                                       hop=1, chunk=1 << 22, keep_failed=False, prefilter=False):
     """compute_persistence_image (loaddatas.py:56-103) for the streamed split: the images of all six lists in the reference's
     order (:65-66) as a pi_cache.SparseImages, plus the LazyPairList standing for `total_edges`.
     data.edge_index must already have lost the val/test positives (TLCGNN.py:88-100)."""
@@ -119,6 +119,23 @@ def compute_persistence_image_streamed(data, train_edges, negatives, val_edges, 
     g = engine.DeviceGraph(rowptr, col, w)
     pieces = []
     dev = torch.device("cuda", g.device)
+    if prefilter and not keep_failed:
+        # the negative list through the distance <= hop pre-filter (pi_cache.sweep_near): its zero rows are known without running
+        # them (their status bytes stay uncomputed: `unclassified`); the five short lists go through the pipeline as they are
+        from .pi_cache import sweep_near, SparseImages
+        lo_neg, hi_neg = int(total.bounds[1]), int(total.bounds[2])
+        inv = np.empty(len(negatives), dtype=np.int64)
+        inv[negatives.perm] = np.arange(len(negatives), dtype=np.int64)
+        near = sweep_near(g, negatives.index, hop, positions=lambda r: inv[r] + lo_neg)
+        sweep_images(g, lambda lo, hi: total.device_pairs(lo, hi, device=dev), lo_neg, hop, chunk=chunk, store=pieces)
+        sweep_images(g, lambda lo, hi: total.device_pairs(hi_neg + lo, hi_neg + hi, device=dev), len(total) - hi_neg, hop,
+                     chunk=chunk, index_base=hi_neg, store=pieces)
+        g.close()
+        rest = assemble(pieces, len(total), 25)
+        out = SparseImages(len(total), 25, np.concatenate([rest.idx, near.idx]), np.concatenate([rest.rows, near.rows]),
+                           np.concatenate([rest.status, near.status]), rest.status_counts + near.status_counts)
+        out.unclassified = near.unclassified
+        return out, total
     sweep_images(g, lambda lo, hi: total.device_pairs(lo, hi, device=dev), len(total), hop, chunk=chunk, store=pieces,
                  keep_failed=keep_failed)
     g.close()
