@@ -14,3 +14,7 @@ for _ in range(2):
     out, st = g.pd_pi_batch(pairs, 2)
     torch.cuda.synchronize(); t2 = time.time()
     print("near_pairs %.2f ms (%d pairs); pd_pi_batch %.2f ms (%.1f M PI/s)" % ((t1 - t0) * 1e3, len(pairs), (t2 - t1) * 1e3, len(pairs) / (t2 - t1) / 1e6), g.stats())
+g.set_timing(True)
+out, st = g.pd_pi_batch(pairs, 2)
+torch.cuda.synchronize()
+print({k: round(v, 3) for k, v in g.timings().items()})
