@@ -1,5 +1,5 @@
-// sweep.hip -- the two steps either side of the PD/PI batch when the pair list is the reference's NEGATIVE SWEEP
-// (SURVEY.md 8(f) items 2 and 3):
+// sweep.hip -- the steps either side of the PD/PI batch when the pair list is the reference's NEGATIVE SWEEP
+// (tlc_near_pairs, the distance pre-filter of SURVEY.md 8d, is at the end of the file):
 //
 //   tlc_complement_rows / tlc_complement_pairs
 //       loaddatas.py:44-45 enumerates the non-edges as `sp.triu(sp.csr_matrix(1. - adj.toarray())).nonzero()`: a dense
@@ -15,7 +15,8 @@
 //       their number, `cnt_compute`), which is what the sparse image cache stores (the reference caches the dense
 //       float64[n_pairs, 25]: 39 GB).
 //
-// HBM-bound integer work: no MFMA, no LDS tiling; the searches run out of L2 (the CSR is ~1 MB).
+// Integer work on cache-resident tables: no MFMA; the searches run out of L2 (the CSR is ~1 MB), the pre-filter's
+// breadth-first levels on LDS bitmaps.
 #include "tlc_common.h"
 
 namespace {
