@@ -69,6 +69,30 @@ def test_gemm_f32_mfma(setup, shape):
     assert torch.equal(out.cpu(), b)
 
 
+@pytest.mark.parametrize("shape", [(4096, 32, 68), (5000, 16, 36), (100003, 64, 32), (7777, 64, 16), (4097, 32, 64), (9001, 16, 5),
+                                   (8192, 64, 80), (4100, 32, 1)])
+def test_gemm_skinny_k(setup, shape):
+    """the streaming kernel for K = 16 / 32 / 64 and M >= 4096 (the PDGNN shapes): ragged M and N, bias and ReLU, no bias, and
+    an asymmetric layout check (A with one 1 per row picks rows of B)."""
+    torch = setup[0]
+    from tlc_gnn_amd import ops
+    M, K, N = shape
+    g = torch.Generator().manual_seed(M + 13 * N)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    out = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), relu=True)
+    ref = torch.relu(a.double() @ b.double() + bias.double())
+    scale = (a.abs().double() @ b.abs().double()).max().item()
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-6 * scale + 1e-6
+    out = ops.gemm(a.cuda(), b.cuda())
+    assert (out.cpu().double() - a.double() @ b.double()).abs().max().item() <= 1e-6 * scale + 1e-6
+    pick = torch.randint(0, K, (M,), generator=g)
+    sel = torch.zeros(M, K)
+    sel[torch.arange(M), pick] = 1.0
+    assert torch.equal(ops.gemm(sel.cuda(), b.cuda()).cpu(), b[pick])
+
+
 def test_encode_decode_vs_torch_reference(setup):
     torch, n, F_, x, ei = setup
     from tlc_gnn_amd.baselines import TLCGNN

@@ -305,6 +305,85 @@ static hipError_t gemm16_launch(int M, int N, int K, const float* A, const float
 }
 
 // ======================================================================================================================
+// Skinny-K variant of the same product: K = 16 / 32 / 64 (the PDGNN layers: x_l, [P|Q|alpha], the edge head), M in the millions.
+// With one or two K chunks the tiled kernel above is all prologue and epilogue (274 us for [1M,32] @ [32,68], 1.5 TB/s of its
+// 411 MB); here nothing goes through LDS: the whole B sits in registers in MFMA operand layout (K/4 x NT floats per lane),
+// persistent wavefronts stream 16-row tiles of A straight from global memory -- lane (row, g) reads the K/4 CONTIGUOUS floats
+// k = g*K/4 .. of its row (MFMA step s of lane group g consumes k = g*K/4 + s for A and B alike: a sum over k does not care
+// about the order), so a tile is one fully coalesced 16 x K block -- the next tile's loads are issued before this tile's
+// MFMAs, and the accumulators go out as 64-byte row segments.
+// ======================================================================================================================
+template <int KQ, int NT>
+__global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(int M, int N, const float* __restrict__ A, const float* __restrict__ B,
+                                                              const float* __restrict__ bias, int relu, float* __restrict__ C) {
+    constexpr int K = KQ * 4;
+    const int lane = threadIdx.x & 63, l16 = lane & 15, g = lane >> 4;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    float b[KQ][NT];
+#pragma unroll
+    for (int sidx = 0; sidx < KQ; ++sidx)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c = t * 16 + l16;
+            b[sidx][t] = c < N ? B[(size_t)(g * KQ + sidx) * N + c] : 0.0f;
+        }
+    float bs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bs[t] = (bias && t * 16 + l16 < N) ? bias[t * 16 + l16] : 0.0f;
+    const long long n_tiles = ((long long)M + 15) >> 4;
+    auto load_tile = [&](long long tile, f32x4 (&a)[KQ / 4]) {
+        long long r = tile * 16 + l16;
+        if (r >= M) r = M - 1;                                          // (rows past M are computed and not stored)
+        const f32x4* src = reinterpret_cast<const f32x4*>(A + (size_t)r * K + g * KQ);
+#pragma unroll
+        for (int q = 0; q < KQ / 4; ++q) a[q] = src[q];
+    };
+    f32x4 a_cur[KQ / 4], a_nxt[KQ / 4];
+    long long tile = wave;
+    if (tile < n_tiles) load_tile(tile, a_cur);
+    for (; tile < n_tiles; tile += n_waves) {
+        const long long nt = tile + n_waves;
+        if (nt < n_tiles) load_tile(nt, a_nxt);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sidx = 0; sidx < KQ; ++sidx)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[sidx >> 2][sidx & 3], b[sidx][t], acc[t], 0, 0, 0);
+        // C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c = t * 16 + l16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long row = tile * 16 + 4 * g + r;
+                float v = acc[t][r] + bs[t];
+                if (relu) v = fmaxf(v, 0.f);
+                if (row < M && c < N) C[(size_t)row * N + c] = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < KQ / 4; ++q) a_cur[q] = a_nxt[q];
+    }
+}
+
+template <int KQ>
+static bool gemm_skinny_launch(int M, int N, const float* A, const float* B, const float* bias, int relu, float* C, hipStream_t s) {
+    const long long tiles = ((long long)M + 15) / 16;
+    long long blocks = (tiles + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;                             // persistent: at most 8 workgroups per CU
+#define TLC_SK(NT_) case NT_: hipLaunchKernelGGL((gemm_skinny_f32_kernel<KQ, NT_>), dim3((unsigned)blocks), dim3(256), 0, s, M, N, A, B, bias, relu, C); return true;
+    switch ((N + 15) / 16) {
+        TLC_SK(1) TLC_SK(2) TLC_SK(3) TLC_SK(4) TLC_SK(5)
+        default: return false;
+    }
+#undef TLC_SK
+}
+
+// ======================================================================================================================
 // CSR SpMM: Y[i,:] = act(sum_j val[j] * X[col[j],:] + bias).  Each row is owned by G lanes, every lane covering 4 adjacent
 // feature columns with 16-byte gathers; 8 neighbour rows are in flight per lane (hub rows of the graph have hundreds of
 // entries and would otherwise serialise on the gather latency).  k % 4 == 0; k <= 4*G.
@@ -584,6 +663,18 @@ extern "C" int tlc_gemm_f32(int32_t M, int32_t N, int32_t K, const float* d_A, c
     const bool vec = (K % 4) == 0 && (N % 4) == 0 &&
                      ((reinterpret_cast<uintptr_t>(d_A) | reinterpret_cast<uintptr_t>(d_B) | reinterpret_cast<uintptr_t>(d_C) |
                        reinterpret_cast<uintptr_t>(d_bias)) & 15) == 0;
+    // skinny K (the PDGNN shapes) with enough rows to stream: B in registers, A straight from global memory
+    if (M >= 4096 && (K == 16 || K == 32 || K == 64) && (K / 4) * ((N + 15) / 16) <= 80 &&
+        (reinterpret_cast<uintptr_t>(d_A) & 15) == 0) {
+        bool done = false;
+        if (K == 16) done = gemm_skinny_launch<4>(M, N, d_A, d_B, d_bias, relu, d_C, s);
+        else if (K == 32) done = gemm_skinny_launch<8>(M, N, d_A, d_B, d_bias, relu, d_C, s);
+        else done = gemm_skinny_launch<16>(M, N, d_A, d_B, d_bias, relu, d_C, s);
+        if (done) {
+            TLC_HIP_CHECK(hipGetLastError());
+            return TLC_OK;
+        }
+    }
     hipError_t le = hipSuccess;
 #define TLC_G16(NT_)                                                                              \
     case NT_:                                                                                     \
