@@ -47,6 +47,31 @@ def test_gcn_norm_csr(setup):
 
 # vectorised (K, N multiples of 4) and element-wise load paths, K a multiple of the 32-chunk or not, odd chunk counts,
 # row counts around the 80-row tile, every column-tile count of the 16x16x4 kernel
+def test_gcn_norm_csr_large_graph_multi_block_scan(setup):
+    """above 8 192 nodes the row-pointer prefix is a three-kernel scan: a 50 000-node graph (isolated nodes, self loops,
+    duplicates) against numpy."""
+    torch = setup[0]
+    from tlc_gnn_amd import ops
+    rs = np.random.RandomState(8)
+    n, E = 50000, 160000
+    src, dst = rs.randint(0, n - 500, E), rs.randint(0, n - 500, E)          # the last 500 nodes stay isolated
+    src[:100] = dst[:100]                                                     # some self loops
+    ei = torch.from_numpy(np.stack([np.concatenate([src, src[:50]]), np.concatenate([dst, dst[:50]])])).long()
+    rowptr, col, val = ops.gcn_norm_csr(ei.cuda(), n)
+    rp, c, v = rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+    # reference: every non-loop entry (duplicates kept), one self loop per node; CSR by target, sources ascending
+    keep = src != dst
+    s2 = np.concatenate([src[keep], src[:50][keep[:50]], np.arange(n)])
+    d2 = np.concatenate([dst[keep], dst[:50][keep[:50]], np.arange(n)])
+    order = np.lexsort((s2, d2))
+    s2, d2 = s2[order], d2[order]
+    deg = np.bincount(d2, minlength=n).astype(np.float64)
+    assert np.array_equal(rp, np.concatenate([[0], np.cumsum(np.bincount(d2, minlength=n))]))
+    assert np.array_equal(c, s2)
+    ref = (1.0 / np.sqrt(deg[s2])) * (1.0 / np.sqrt(deg[d2]))
+    assert np.abs(v - ref).max() < 1e-6
+
+
 @pytest.mark.parametrize("shape", [(1500, 233, 100), (1500, 100, 16), (77, 5, 3), (130, 64, 128), (1, 1, 1), (19717, 500, 100),
                                    (2708, 1433, 7), (80, 32, 16), (81, 33, 17), (79, 96, 48), (161, 31, 65), (400, 768, 80),
                                    (333, 160, 112), (5, 4, 4)])

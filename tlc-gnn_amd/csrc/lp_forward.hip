@@ -54,6 +54,54 @@ __global__ __launch_bounds__(1024) void gcn_scan_kernel(int n_nodes, const int* 
     if (t == 0 && nnz_out) *nnz_out = carry;
 }
 
+// The same prefix for graphs beyond a few thousand nodes (a PDGNN batch of 41 127 molecule graphs has a million: the single
+// workgroup above took 1.75 ms, longer than the four-layer forward): blocks of 1024 scan locally and leave their totals, one
+// workgroup scans the totals, the blocks add their offsets.
+__global__ __launch_bounds__(1024) void gcn_scan_block_kernel(int n_nodes, const int* __restrict__ cnt, int* __restrict__ rowptr,
+                                                              int* __restrict__ block_sum) {
+    __shared__ int s[1024];
+    const int t = threadIdx.x, i = blockIdx.x * 1024 + t;
+    s[t] = i < n_nodes ? cnt[i] + 1 : 0;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int a = t >= o ? s[t - o] : 0;
+        __syncthreads();
+        s[t] += a;
+        __syncthreads();
+    }
+    if (i < n_nodes) rowptr[i + 1] = s[t];
+    if (t == 1023) block_sum[blockIdx.x] = s[t];
+}
+__global__ __launch_bounds__(1024) void gcn_scan_top_kernel(int n_blocks, int* __restrict__ block_sum, int* __restrict__ rowptr,
+                                                            int* __restrict__ nnz_out) {
+    __shared__ int s[1024];
+    __shared__ int carry;
+    const int t = threadIdx.x;
+    if (t == 0) { carry = 0; rowptr[0] = 0; }
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += 1024) {
+        const int i = base + t;
+        const int v = i < n_blocks ? block_sum[i] : 0;
+        s[t] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int a = t >= o ? s[t - o] : 0;
+            __syncthreads();
+            s[t] += a;
+            __syncthreads();
+        }
+        if (i < n_blocks) block_sum[i] = carry + s[t] - v;             // exclusive prefix of the block totals
+        __syncthreads();
+        if (t == 1023) carry += s[t];
+        __syncthreads();
+    }
+    if (t == 0 && nnz_out) *nnz_out = carry;
+}
+__global__ __launch_bounds__(1024) void gcn_scan_add_kernel(int n_nodes, int* __restrict__ rowptr, const int* __restrict__ block_sum) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n_nodes) rowptr[i + 1] += block_sum[blockIdx.x];
+}
+
 __global__ void gcn_fill_kernel(long long n_edges, const long long* __restrict__ ei, int n_nodes,
                                 const int* __restrict__ rowptr, int* __restrict__ cursor, int* __restrict__ col) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -640,7 +688,15 @@ extern "C" int tlc_gcn_norm_csr(int32_t n_nodes, int64_t n_edges, const int64_t*
         if (hipMemsetAsync(tmp, 0, 2 * (size_t)n_nodes * sizeof(int), s) != hipSuccess) { rc = TLC_ERR_HIP; break; }
         const int eb = (int)((n_edges + 255) / 256), nb = (n_nodes + 255) / 256;
         if (n_edges) hipLaunchKernelGGL(gcn_count_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, tmp);
-        hipLaunchKernelGGL(gcn_scan_kernel, dim3(1), dim3(1024), 0, s, n_nodes, (const int*)tmp, d_rowptr, d_nnz);
+        if (n_nodes <= 8192) {
+            hipLaunchKernelGGL(gcn_scan_kernel, dim3(1), dim3(1024), 0, s, n_nodes, (const int*)tmp, d_rowptr, d_nnz);
+        } else {
+            // block totals in the head of d_col (written for good only by gcn_finish_kernel, after the fill)
+            const int sb = (n_nodes + 1023) / 1024;
+            hipLaunchKernelGGL(gcn_scan_block_kernel, dim3(sb), dim3(1024), 0, s, n_nodes, (const int*)tmp, d_rowptr, d_col);
+            hipLaunchKernelGGL(gcn_scan_top_kernel, dim3(1), dim3(1024), 0, s, sb, d_col, d_rowptr, d_nnz);
+            hipLaunchKernelGGL(gcn_scan_add_kernel, dim3(sb), dim3(1024), 0, s, n_nodes, d_rowptr, (const int*)d_col);
+        }
         if (n_edges) hipLaunchKernelGGL(gcn_fill_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, (const int*)d_rowptr, tmp + n_nodes, tmp + 2 * (size_t)n_nodes);
         hipLaunchKernelGGL(gcn_finish_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)(tmp + 2 * (size_t)n_nodes), d_col);
         hipLaunchKernelGGL(gcn_val_kernel, dim3(nb), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)d_col, d_val);
