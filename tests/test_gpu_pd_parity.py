@@ -393,6 +393,33 @@ def test_cycle_swap_long_loops_vs_oracle(torch_cuda, flags):
             assert same_multiset(got[key][base:base + k], ref[key][base:base + k]), (g, key, gs[g][0])   # bit-exact
 
 
+@pytest.mark.parametrize("name", ["Cora", "PPI", "Photo", "Computers"])
+def test_other_baseline_shapes_hop1_vs_oracle(torch_cuda, name):
+    """BASELINE.json's other configurations (Cora plumbing case, PPI graphs, Amazon Photo / Computers; TLCGNN.py:102 gives them
+    hop 1): positives and sampled negatives of the shaped synthetic graph against the oracle -- status bytes equal, zero
+    patterns equal, images within 1e-8 relative."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    n, edges, kappa, hop, _ = synth.shaped_graph(name)
+    assert hop == 1
+    rowptr, col, w = synth.edges_to_csr(n, edges, kappa)
+    rs = np.random.RandomState(5)
+    k = 1500 if name in ("Photo", "Computers") else 3000
+    pos = edges[rs.permutation(len(edges))[:k]]
+    neg = rs.randint(0, n, size=(k // 2, 2))
+    pairs = np.concatenate([pos, pos[: k // 4, ::-1], neg, [[0, 0], [n - 1, n - 1]]]).astype(np.int32)
+    g = engine.DeviceGraph(rowptr, col, w)
+    out, st = g.pd_pi_batch(torch.from_numpy(pairs).cuda(), hop)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, hop, n_threads=0)
+    assert np.array_equal(st, rst)
+    assert np.array_equal(out == 0, ref == 0)
+    nz = ref != 0
+    assert nz.any() and rel_err(out[nz], ref[nz]).max() < 1e-8
+    g.close()
+
+
 @pytest.mark.parametrize("flags", [0, 1])
 def test_edge_counts_just_above_a_power_of_two(torch_cuda, flags):
     """The edge sorts split a count just above a power of two into two bitonic runs merged by rank (pd_pipeline.hip,
