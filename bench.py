@@ -305,6 +305,33 @@ def main():
             torch.cuda.synchronize()
         except Exception as ex:
             full_sweep = {"error": repr(ex)}
+    # auxiliary (untimed region): BASELINE.json's other graph shapes (hop 1, TLCGNN.py:102) -- all positive pairs of the
+    # shaped synthetic graph through tlc_pd_pi_batch, one call, device-resident; host wall clock
+    other_shapes = None
+    if rank == 0 and not args.no_sweep:
+        other_shapes = {}
+        for shape_name in ("Cora", "PPI", "Photo", "Computers"):
+            try:
+                from tlc_gnn_amd import synth as _synth
+                n_s, e_s, k_s, hop_s, _ = _synth.shaped_graph(shape_name)
+                rp_s, col_s, w_s = _synth.edges_to_csr(n_s, e_s, k_s)
+                g_s = engine.DeviceGraph(rp_s, col_s, w_s, device=local_rank)
+                p_s = torch.from_numpy(np.ascontiguousarray(e_s, dtype=np.int32)).to(dev)
+                o_s = torch.empty((len(e_s), 25), dtype=torch.float64, device=dev)
+                st_s = torch.empty(len(e_s), dtype=torch.uint8, device=dev)
+                g_s.pd_pi_batch(p_s, hop_s, out=o_s, status=st_s)
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                g_s.pd_pi_batch(p_s, hop_s, out=o_s, status=st_s)
+                torch.cuda.synchronize()
+                sdt_ = time.perf_counter() - c0
+                other_shapes[shape_name] = {"nodes": int(n_s), "pairs": int(len(e_s)), "hop": int(hop_s), "ms": sdt_ * 1e3,
+                                            "images_per_sec": len(e_s) / sdt_,
+                                            "tiers": {k: int(v) for k, v in g_s.stats().items() if k.startswith("tier")}}
+                g_s.close()
+                del p_s, o_s, st_s
+            except Exception as ex:
+                other_shapes[shape_name] = {"error": repr(ex)}
     # auxiliary (untimed region): the step before the path -- Ollivier-Ricci curvature (alpha 0.5, Sinkhorn reg 0.1) of every
     # edge of the training graph (loaddatas.py:105-123), the producer of the path's edge weights
     ricci = None
@@ -434,6 +461,7 @@ def main():
             "sweep": sweep,
             "full_sweep": full_sweep,
             "ricci": ricci,
+            "other_shapes": other_shapes,
             "pdgnn": pdgnn,
         }
         if world == 1 and not args.no_cpu_baseline:
