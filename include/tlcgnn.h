@@ -224,7 +224,8 @@ int tlc_complement_pairs(int32_t n_nodes, const int32_t* d_rowptr, const int32_t
  * (SURVEY.md A.6, Z0), so only those non-edges need tlc_pd_pi_batch.  Appends every non-adjacent pair u <= v with d(u,v) <= hop
  * (the diagonal included unless u has a self loop): d_out_pairs int32[k,2] and d_out_rank int64[k] = the pair's number in the
  * list of tlc_complement_pairs.  *d_count (uint64, device, zeroed by the caller) is advanced even beyond `cap` (pairs past the
- * capacity are not written).  Append order is not fixed.  Graphs up to ~100 000 nodes (three LDS bitmaps per wavefront). */
+ * capacity are not written).  Append order is not fixed.  Graphs up to ~400 000 nodes (three LDS bitmaps per wavefront);
+ * beyond that TLC_ERR_UNSUPPORTED (the full sweep does not have the limit). */
 int tlc_near_pairs(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const int64_t* d_row_start, int hop, int64_t cap,
                    uint64_t* d_count, int64_t* d_out_rank, int32_t* d_out_pairs, void* stream);
 

@@ -277,3 +277,34 @@ def test_near_pairs_prefilter_equals_the_full_sweep(torch_cuda, hop):
     dense_shuffled = full.to_dense()[perm]                                        # row p of the shuffled list = list number perm[p]
     assert np.array_equal(shuffled.to_dense(), dense_shuffled)
     g.close()
+
+
+def test_near_pairs_on_a_graph_beyond_four_bitmaps_per_workgroup(torch_cuda):
+    """150 000 nodes: the pre-filter runs one wavefront per workgroup (three 18 KB bitmaps); against a host BFS on a sample of
+    source nodes, and every returned list number maps back to its pair."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine
+    rs = np.random.RandomState(2)
+    n = 150000
+    par = (rs.rand(n - 1) * np.arange(1, n)).astype(np.int64)                  # a random recursive tree + a few extra edges
+    edges = np.concatenate([np.stack([par, np.arange(1, n)], 1), rs.randint(0, n, size=(20000, 2))])
+    edges = edges[edges[:, 0] != edges[:, 1]]
+    edges = np.unique(np.sort(edges, 1), axis=0)
+    import scipy.sparse as sp
+    a = sp.coo_matrix((np.ones(len(edges)), (edges[:, 0], edges[:, 1])), shape=(n, n))
+    adj = ((a + a.T) > 0).astype(np.int8).tocsr()
+    adj.sort_indices()
+    ci = engine.ComplementIndex(adj.indptr.astype(np.int32), adj.indices.astype(np.int32))
+    pairs, ranks = engine.near_pairs(ci, 2)
+    assert np.array_equal(ci.pairs(ranks=ranks).cpu().numpy(), pairs.cpu().numpy())
+    pairs = pairs.cpu().numpy()
+    order = np.lexsort((pairs[:, 1], pairs[:, 0]))
+    pairs = pairs[order]
+    starts = np.searchsorted(pairs[:, 0], np.arange(n + 1))
+    for u in rs.randint(0, n, 300).tolist() + [0, n - 1]:
+        n1 = adj.indices[adj.indptr[u]:adj.indptr[u + 1]]
+        ball = {u} | set(n1.tolist())
+        for x in n1.tolist():
+            ball |= set(adj.indices[adj.indptr[x]:adj.indptr[x + 1]].tolist())
+        want = sorted(v for v in ball if v >= u and v not in set(n1.tolist()))
+        assert pairs[starts[u]:starts[u + 1], 1].tolist() == want, u

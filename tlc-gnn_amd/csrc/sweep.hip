@@ -202,17 +202,17 @@ __global__ __launch_bounds__(256) void near_pairs_kernel(int n, const int* __res
                                                          int* __restrict__ out_pairs) {
     extern __shared__ unsigned int bm_all[];
     const int W = (n + 31) >> 5;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;     // 4 wavefronts per workgroup, or 1
     unsigned int* visited = bm_all + (size_t)wv * 3 * W;
     unsigned int* cur = visited + W;
     unsigned int* nxt = cur + W;
-    const long long n_waves = (long long)gridDim.x * 4;
+    const long long n_waves = (long long)gridDim.x * wpb;
     auto fence = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
-    for (long long u = (long long)blockIdx.x * 4 + wv; u < n; u += n_waves) {
+    for (long long u = (long long)blockIdx.x * wpb + wv; u < n; u += n_waves) {
         for (int w = lane; w < W; w += 64) { visited[w] = 0u; cur[w] = 0u; }
         fence();
         if (lane == 0) { visited[u >> 5] = 1u << (u & 31); cur[u >> 5] = 1u << (u & 31); }
@@ -285,12 +285,15 @@ extern "C" int tlc_near_pairs(int32_t n_nodes, const int32_t* d_rowptr, const in
     if (n_nodes == 0) return TLC_OK;
     TLC_REQUIRE(d_rowptr && d_row_start && (cap == 0 || (d_out_rank && d_out_pairs)), "null pointer");
     const size_t words = ((size_t)n_nodes + 31) / 32;
-    const size_t lds = 4 * 3 * words * 4;                       // four wavefronts x three bitmaps
-    if (lds > 150 * 1024) { tlc_set_error("tlc_near_pairs: graph too large for the LDS bitmaps (%d nodes; limit ~100 000)", n_nodes); return TLC_ERR_UNSUPPORTED; }
+    // three bitmaps per wavefront: four wavefronts per workgroup while they fit the LDS (~100 000 nodes), else one (~400 000)
+    int wpb = 4;
+    size_t lds = (size_t)wpb * 3 * words * 4;
+    if (lds > 150 * 1024) { wpb = 1; lds = 3 * words * 4; }
+    if (lds > 150 * 1024) { tlc_set_error("tlc_near_pairs: graph too large for the LDS bitmaps (%d nodes; limit ~400 000)", n_nodes); return TLC_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)near_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    long long blocks = ((long long)n_nodes + 3) / 4;
+    long long blocks = ((long long)n_nodes + wpb - 1) / wpb;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(near_pairs_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, n_nodes, d_rowptr, d_col,
+    hipLaunchKernelGGL(near_pairs_kernel, dim3((unsigned)blocks), dim3(64 * wpb), lds, (hipStream_t)stream, n_nodes, d_rowptr, d_col,
                        (const long long*)d_row_start, hop, (long long)cap, (unsigned long long*)d_count, (long long*)d_out_rank,
                        d_out_pairs);
     TLC_HIP_CHECK(hipGetLastError());
