@@ -265,6 +265,8 @@ def test_near_pairs_prefilter_equals_the_full_sweep(torch_cuda, hop):
     assert len(pairs) == len(want) and set(map(tuple, pairs.tolist())) == want
     back = ci.pairs(ranks=torch.from_numpy(ranks).cuda()).cpu().numpy()
     assert np.array_equal(back, pairs)                                            # the list numbers are the pairs' own
+    small_cap, _ = engine.near_pairs(ci, hop, cap=10)                             # a store that is too small: counted, then redone
+    assert set(map(tuple, small_cap.cpu().numpy().tolist())) == want
     g = engine.DeviceGraph(rowptr, col, w)
     full = pi_cache.sweep_images(g, lambda lo, hi: ci.pairs(first=lo, count=hi - lo), len(ci), hop, chunk=70001)
     near = pi_cache.sweep_near(g, ci, hop)
