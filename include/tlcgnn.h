@@ -105,7 +105,9 @@ int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream);
 
 /* Measurement helpers used by bench.py (no reference counterpart: the reference only prints time.time() deltas,
  * riccidist2dgm.py:349-350).  set_timing(1) makes every later tlc_pd_pi_batch bracket each of its kernels with HIP
- * events on the stream that kernel runs on; timings() returns the last chunk's durations in ms:
+ * events on the stream that kernel runs on (set_timing(1 << (k+1)), or a sum of such bits: only the kernels of slots k -- the
+ * event records themselves cost time, 48 us of the 1.06 ms PubMed batch for all eight); timings() returns the last chunk's
+ * durations in ms:
  * h_ms[0..7] = COUNT, scan+binning, FILL, PD tier SMALL, MEDIUM, LARGE, HUGE, MID (-1 = not launched).  Synchronises.
  * sizes(): per pair of the last chunk, |S| and the induced directed entry count.
  * algorithmic_bytes(): SURVEY.md 8(d) per-pair byte model, evaluated on the HOST CSR (pure accounting). */
