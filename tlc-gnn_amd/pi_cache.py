@@ -115,6 +115,7 @@ class SparseImages:
             status_counts[0] += self.shape[0] - len(self.idx)
         self.status_counts = np.asarray(status_counts, dtype=np.int64)
         self.unclassified = 0               # rows whose status byte was never computed (sweep_near: zero by the distance rule)
+        self.near_pairs = None              # sweep_near: how many pairs passed the distance pre-filter
         self._dev = None
 
     @property
