@@ -137,3 +137,11 @@ def test_kd_compute_ricci_curvature_cache_roundtrip(tmp_path):
     assert os.path.exists(str(tmp_path / "graph_toy_removevaltest.edge_list"))
     b = data_utils_LP.compute_ricci_curvature(data, "toy", cache_dir=str(tmp_path))          # second call: from the file
     assert a == b and len(a) == 400
+
+
+def test_curvature_degenerate_inputs():
+    from tlc_gnn_amd import engine, synth
+    rowptr, col, _ = synth.edges_to_csr(4, np.array([[0, 1]]))
+    assert engine.ollivier_ricci_sinkhorn(rowptr, col, np.zeros((0, 2), dtype=np.int32)).shape == (0,)
+    k = engine.ollivier_ricci_sinkhorn(rowptr, col, np.array([[0, 1], [1, 0]]))
+    assert k.shape == (2,) and abs(k[0] - k[1]) < 1e-9 and abs(k[0] - 1.0) < 1e-4     # two leaves: m_s = m_t up to a swap; the entropic plan leaks e^-10

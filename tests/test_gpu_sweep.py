@@ -310,3 +310,23 @@ def test_near_pairs_on_a_graph_beyond_four_bitmaps_per_workgroup(torch_cuda):
             ball |= set(adj.indices[adj.indptr[x]:adj.indptr[x + 1]].tolist())
         want = sorted(v for v in ball if v >= u and v not in set(n1.tolist()))
         assert pairs[starts[u]:starts[u + 1], 1].tolist() == want, u
+
+
+def test_degenerate_inputs_of_the_sweep_entry_points(torch_cuda):
+    """no nodes, one node, no edges, empty requests: sizes come out right and nothing faults"""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine, pi_cache
+    ci0 = engine.ComplementIndex(np.array([0], dtype=np.int32), np.zeros(0, dtype=np.int32))
+    assert len(ci0) == 0 and ci0.pairs().shape == (0, 2)
+    ci1 = engine.ComplementIndex(np.array([0, 0], dtype=np.int32), np.zeros(0, dtype=np.int32))
+    assert len(ci1) == 1 and ci1.pairs().cpu().numpy().tolist() == [[0, 0]]          # the diagonal pair
+    p, r = engine.near_pairs(ci1, 2)
+    assert p.cpu().numpy().tolist() == [[0, 0]] and r.cpu().numpy().tolist() == [0]
+    ci5 = engine.ComplementIndex(np.zeros(6, dtype=np.int32), np.zeros(0, dtype=np.int32))   # five isolated nodes
+    assert len(ci5) == 15
+    p, r = engine.near_pairs(ci5, 1)
+    assert sorted(map(tuple, p.cpu().numpy().tolist())) == [(i, i) for i in range(5)]  # only the diagonal is within any hop
+    assert ci5.pairs(first=3, count=0).shape == (0, 2)
+    assert ci5.pairs(ranks=torch.zeros(0, dtype=torch.int64, device="cuda")).shape == (0, 2)
+    empty = pi_cache.SparseImages(0, 25, np.zeros(0, dtype=np.int64), np.zeros((0, 25)), np.zeros(0, dtype=np.uint8))
+    assert empty.to_dense().shape == (0, 25) and empty.gather(np.zeros(0, dtype=np.int64)).shape == (0, 25)
