@@ -63,91 +63,111 @@ __global__ __launch_bounds__(256) void gat_node_kernel(int n, const float* __res
 }
 
 // kernel 2: one group of C lanes per target node
-template <int C>
+// NPG nodes per lane group: the kernel is a chain of three dependent round trips per node (row bounds -> source ids -> alpha / Q
+// of the sources) and its duration was (wavefronts / resident wavefronts) x that chain: 336 us for a million nodes.  With the loads
+// of NPG nodes issued together a wavefront's lifetime serves NPG times the nodes.
+template <int C, int NPG>
 __global__ __launch_bounds__(256) void gat_aggregate_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ src,
                                                             const float* __restrict__ pqa, int S, const float* __restrict__ bias,
                                                             float prelu_slope, float* __restrict__ out) {
     // pqa: per node [P (C) | Q (C) | alpha (1)] with row stride S
-    const int i = (blockIdx.x * 256 + threadIdx.x) / C, c = threadIdx.x % C;
-    if (i >= n) return;
-    const int b = rowptr[i], e = rowptr[i + 1];
-    const float ai = pqa[(size_t)i * S + 2 * C];
-    const float pi = pqa[(size_t)i * S + c];
-    // softmax over the incoming edges (torch_geometric.utils.softmax: subtract the segment max)
-    float mx = -INFINITY;
-    float den = 0.0f, sum = 0.0f, mn = INFINITY, mxv = -INFINITY;
-    if (e - b <= 8) {
-        // the usual case (molecules, vicinity graphs: a handful of neighbours + the self loop): all source ids, then all
-        // alphas and Q values, are requested together -- one dependent round trip each instead of one per edge and pass
-        int sj[8];
-        float tj[8], qj[8];
+    const int grp = (blockIdx.x * 256 + threadIdx.x) / C, c = threadIdx.x % C;
+    int b[NPG], e[NPG];
+    float ai[NPG], pi[NPG];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sj[q] = b + q < e ? src[b + q] : -1;
+    for (int u = 0; u < NPG; ++u) {
+        const int i = grp * NPG + u;
+        b[u] = 0; e[u] = 0; ai[u] = 0.0f; pi[u] = 0.0f;
+        if (i < n) {
+            b[u] = rowptr[i]; e[u] = rowptr[i + 1];
+            ai[u] = pqa[(size_t)i * S + 2 * C];
+            pi[u] = pqa[(size_t)i * S + c];
+        }
+    }
+    // the usual case (molecules, vicinity graphs: a handful of neighbours + the self loop): all source ids, then all alphas and
+    // Q values, of all NPG nodes are requested together -- one dependent round trip each instead of one per edge and pass
+    int sj[NPG][8];
+    float tj[NPG][8], qj[NPG][8];
+#pragma unroll
+    for (int u = 0; u < NPG; ++u)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sj[u][q] = (e[u] - b[u] <= 8 && b[u] + q < e[u]) ? src[b[u] + q] : -1;
+#pragma unroll
+    for (int u = 0; u < NPG; ++u)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            tj[q] = 0.0f; qj[q] = 0.0f;
-            if (sj[q] >= 0) {
-                const float* wj = pqa + (size_t)sj[q] * S;
-                tj[q] = wj[2 * C];
-                qj[q] = wj[C + c];
+            tj[u][q] = 0.0f; qj[u][q] = 0.0f;
+            if (sj[u][q] >= 0) {
+                const float* wj = pqa + (size_t)sj[u][q] * S;
+                tj[u][q] = wj[2 * C];
+                qj[u][q] = wj[C + c];
             }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (sj[q] >= 0) {
-                float t = tj[q] + ai;                         // alpha_j + alpha_i  (gat_conv.py:184)
-                t = t > 0.0f ? t : 0.2f * t;                  // leaky_relu(negative_slope=0.2) (:185)
-                tj[q] = t;
+    for (int u = 0; u < NPG; ++u) {
+        const int i = grp * NPG + u;
+        if (i >= n) continue;
+        // softmax over the incoming edges (torch_geometric.utils.softmax: subtract the segment max)
+        float mx = -INFINITY;
+        float den = 0.0f, sum = 0.0f, mn = INFINITY, mxv = -INFINITY;
+        if (e[u] - b[u] <= 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (sj[u][q] >= 0) {
+                    float t = tj[u][q] + ai[u];                   // alpha_j + alpha_i  (gat_conv.py:184)
+                    t = t > 0.0f ? t : 0.2f * t;                  // leaky_relu(negative_slope=0.2) (:185)
+                    tj[u][q] = t;
+                    mx = t > mx ? t : mx;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (sj[u][q] >= 0) {
+                    const float ex = expf(tj[u][q] - mx);
+                    den += ex;
+                    float m = pi[u] + qj[u][q];                   // lin_ij([x_i || x_j]) (:193-194)
+                    m = m > 0.0f ? m : 0.2f * m;                  // leaky_relu (:195)
+                    m *= ex;                                      // * alpha (:198-200), normalised below
+                    sum += m;
+                    mn = m < mn ? m : mn;
+                    mxv = m > mxv ? m : mxv;
+                }
+            }
+        } else {
+            for (int j = b[u]; j < e[u]; ++j) {
+                float t = pqa[(size_t)src[j] * S + 2 * C] + ai[u];
+                t = t > 0.0f ? t : 0.2f * t;
                 mx = t > mx ? t : mx;
             }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (sj[q] >= 0) {
-                const float ex = expf(tj[q] - mx);
+            for (int j = b[u]; j < e[u]; ++j) {
+                const float* wj = pqa + (size_t)src[j] * S;
+                float t = wj[2 * C] + ai[u];
+                t = t > 0.0f ? t : 0.2f * t;
+                const float ex = expf(t - mx);
                 den += ex;
-                float m = pi + qj[q];                         // lin_ij([x_i || x_j]) (:193-194)
-                m = m > 0.0f ? m : 0.2f * m;                  // leaky_relu (:195)
-                m *= ex;                                      // * alpha (:198-200), normalised below
+                float m = pi[u] + wj[C + c];
+                m = m > 0.0f ? m : 0.2f * m;
+                m *= ex;
                 sum += m;
                 mn = m < mn ? m : mn;
                 mxv = m > mxv ? m : mxv;
             }
         }
-    } else {
-        for (int j = b; j < e; ++j) {
-            float t = pqa[(size_t)src[j] * S + 2 * C] + ai;
-            t = t > 0.0f ? t : 0.2f * t;
-            mx = t > mx ? t : mx;
+        float o_sum = 0.0f, o_mm = 0.0f;                          // empty segment: scatter leaves zeros
+        if (e[u] > b[u]) {
+            const float inv = 1.0f / (den + 1e-16f);
+            o_sum = sum * inv;
+            o_mm = mn * inv + mxv * inv;                          // scatter min + scatter max (:216)
         }
-        for (int j = b; j < e; ++j) {
-            const float* wj = pqa + (size_t)src[j] * S;
-            float t = wj[2 * C] + ai;
-            t = t > 0.0f ? t : 0.2f * t;
-            const float ex = expf(t - mx);
-            den += ex;
-            float m = pi + wj[C + c];
-            m = m > 0.0f ? m : 0.2f * m;
-            m *= ex;
-            sum += m;
-            mn = m < mn ? m : mn;
-            mxv = m > mxv ? m : mxv;
+        o_sum += bias[c];                                         // mean over the single head, + bias (:166-172)
+        o_mm += bias[C + c];
+        if (prelu_slope >= 0.0f) {                                // F.prelu(x, 0.1) between layers (Teacher_model.py:219-227)
+            o_sum = o_sum > 0.0f ? o_sum : prelu_slope * o_sum;
+            o_mm = o_mm > 0.0f ? o_mm : prelu_slope * o_mm;
         }
+        out[(size_t)i * 2 * C + c] = o_sum;
+        out[(size_t)i * 2 * C + C + c] = o_mm;
     }
-    float o_sum = 0.0f, o_mm = 0.0f;                          // empty segment: scatter leaves zeros
-    if (e > b) {
-        const float inv = 1.0f / (den + 1e-16f);
-        o_sum = sum * inv;
-        o_mm = mn * inv + mxv * inv;                          // scatter min + scatter max (:216)
-    }
-    o_sum += bias[c];                                         // mean over the single head, + bias (:166-172)
-    o_mm += bias[C + c];
-    if (prelu_slope >= 0.0f) {                                // F.prelu(x, 0.1) between layers (Teacher_model.py:219-227)
-        o_sum = o_sum > 0.0f ? o_sum : prelu_slope * o_sum;
-        o_mm = o_mm > 0.0f ? o_mm : prelu_slope * o_mm;
-    }
-    out[(size_t)i * 2 * C + c] = o_sum;
-    out[(size_t)i * 2 * C + C + c] = o_mm;
 }
 
 // edge head: one thread per edge; W5 / W6 staged in LDS
@@ -247,6 +267,8 @@ template <int C>
 int launch_gat(int n, const int* rowptr, const int* src, const float* X, int c_in, const float* Wl, const float* att,
                const float* Wij, const float* bias, float slope, float* work, float* out, hipStream_t s) {
     const unsigned agrid = (unsigned)(((size_t)n * C + 255) / 256);
+    constexpr int NPG = 2;                                   // nodes per lane group in the aggregation (4: 321 us, 1: 336 us, 2: 243 us)
+    const unsigned agrid2 = (unsigned)((((size_t)n + NPG - 1) / NPG * C + 255) / 256);
     if (2 * C + 4 <= 128 && C % 4 == 0) {
         // x_l = X Wl^T and [P | Q | alpha] = x_l [Wij_t^T | Wij_s^T | att] as two products on the f32 MFMA (per node on the
         // vector ALU this was 95 us of a layer; the products are 2 x ~15 us)
@@ -264,7 +286,7 @@ int launch_gat(int n, const int* rowptr, const int* src, const float* X, int c_i
         if (rc != TLC_OK) return rc;
         rc = tlc_gemm_f32(n, N2, C, XL, Bt2, nullptr, 0, PQA, s);
         if (rc != TLC_OK) return rc;
-        hipLaunchKernelGGL(gat_aggregate_kernel<C>, dim3(agrid), dim3(256), 0, s, n, rowptr, src, (const float*)PQA, N2, bias,
+        hipLaunchKernelGGL((gat_aggregate_kernel<C, NPG>), dim3(agrid2), dim3(256), 0, s, n, rowptr, src, (const float*)PQA, N2, bias,
                            slope, out);
         TLC_HIP_CHECK(hipGetLastError());
         return TLC_OK;
@@ -275,7 +297,7 @@ int launch_gat(int n, const int* rowptr, const int* src, const float* X, int c_i
     int grid = (n + NPB - 1) / NPB;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(gat_node_kernel<C>, dim3(grid), dim3(256), lds, s, n, X, c_in, Wl, att, Wij, work);
-    hipLaunchKernelGGL(gat_aggregate_kernel<C>, dim3(agrid), dim3(256), 0, s, n, rowptr, src, (const float*)(work + C), 3 * C + 1, bias,
+    hipLaunchKernelGGL((gat_aggregate_kernel<C, NPG>), dim3(agrid2), dim3(256), 0, s, n, rowptr, src, (const float*)(work + C), 3 * C + 1, bias,
                        slope, out);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
