@@ -66,12 +66,18 @@ __global__ __launch_bounds__(256) void gat_node_kernel(int n, const float* __res
 // NPG nodes per lane group: the kernel is a chain of three dependent round trips per node (row bounds -> source ids -> alpha / Q
 // of the sources) and its duration was (wavefronts / resident wavefronts) x that chain: 336 us for a million nodes.  With the loads
 // of NPG nodes issued together a wavefront's lifetime serves NPG times the nodes.
-template <int C, int NPG>
+// RANK1 (c_in == 1, the first PDGNN layer: the node feature is the filtration value alone): x_l = f_i * Wl[:,0], so the whole row
+// [P | Q | alpha] of node i is f_i * v with ONE vector v = Wl[:,0]^T [Wij_t^T | Wij_s^T | att] -- neither x_l nor the rows are
+// materialised (no 70 us narrow product, no 120 us GEMM, 4-byte instead of 132-byte gathers): pqa then points at f (stride S = 1)
+// and `vec` at v.
+template <int C, int NPG, bool RANK1>
 __global__ __launch_bounds__(256) void gat_aggregate_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ src,
                                                             const float* __restrict__ pqa, int S, const float* __restrict__ bias,
-                                                            float prelu_slope, float* __restrict__ out) {
+                                                            float prelu_slope, float* __restrict__ out, const float* __restrict__ vec) {
     // pqa: per node [P (C) | Q (C) | alpha (1)] with row stride S
     const int grp = (blockIdx.x * 256 + threadIdx.x) / C, c = threadIdx.x % C;
+    float vP = 0.0f, vQ = 0.0f, vA = 0.0f;
+    if (RANK1) { vP = vec[c]; vQ = vec[C + c]; vA = vec[2 * C]; }
     int b[NPG], e[NPG];
     float ai[NPG], pi[NPG];
 #pragma unroll
@@ -80,8 +86,8 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(int n, const int* __
         b[u] = 0; e[u] = 0; ai[u] = 0.0f; pi[u] = 0.0f;
         if (i < n) {
             b[u] = rowptr[i]; e[u] = rowptr[i + 1];
-            ai[u] = pqa[(size_t)i * S + 2 * C];
-            pi[u] = pqa[(size_t)i * S + c];
+            if (RANK1) { const float fi = pqa[i]; ai[u] = fi * vA; pi[u] = fi * vP; }
+            else { ai[u] = pqa[(size_t)i * S + 2 * C]; pi[u] = pqa[(size_t)i * S + c]; }
         }
     }
     // the usual case (molecules, vicinity graphs: a handful of neighbours + the self loop): all source ids, then all alphas and
@@ -98,9 +104,12 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(int n, const int* __
         for (int q = 0; q < 8; ++q) {
             tj[u][q] = 0.0f; qj[u][q] = 0.0f;
             if (sj[u][q] >= 0) {
-                const float* wj = pqa + (size_t)sj[u][q] * S;
-                tj[u][q] = wj[2 * C];
-                qj[u][q] = wj[C + c];
+                if (RANK1) { const float fj = pqa[sj[u][q]]; tj[u][q] = fj * vA; qj[u][q] = fj * vQ; }
+                else {
+                    const float* wj = pqa + (size_t)sj[u][q] * S;
+                    tj[u][q] = wj[2 * C];
+                    qj[u][q] = wj[C + c];
+                }
             }
         }
 #pragma unroll
@@ -135,17 +144,18 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(int n, const int* __
             }
         } else {
             for (int j = b[u]; j < e[u]; ++j) {
-                float t = pqa[(size_t)src[j] * S + 2 * C] + ai[u];
+                float t = (RANK1 ? pqa[src[j]] * vA : pqa[(size_t)src[j] * S + 2 * C]) + ai[u];
                 t = t > 0.0f ? t : 0.2f * t;
                 mx = t > mx ? t : mx;
             }
             for (int j = b[u]; j < e[u]; ++j) {
                 const float* wj = pqa + (size_t)src[j] * S;
-                float t = wj[2 * C] + ai[u];
+                const float fj = RANK1 ? pqa[src[j]] : 0.0f;
+                float t = (RANK1 ? fj * vA : wj[2 * C]) + ai[u];
                 t = t > 0.0f ? t : 0.2f * t;
                 const float ex = expf(t - mx);
                 den += ex;
-                float m = pi[u] + wj[C + c];
+                float m = pi[u] + (RANK1 ? fj * vQ : wj[C + c]);
                 m = m > 0.0f ? m : 0.2f * m;
                 m *= ex;
                 sum += m;
@@ -252,7 +262,19 @@ __global__ void gat_pack_kernel(int C, int c_in, const float* __restrict__ Wl, c
         Bt2[t] = j < C ? Wij[(size_t)j * 2 * C + k] : (j < 2 * C ? Wij[(size_t)(j - C) * 2 * C + C + k] : (j == 2 * C ? att[k] : 0.0f));
     }
 }
-// x_l = X Wl^T for a narrow input (c_in < 16, e.g. the filtration value alone): one thread per (node, channel)
+// c_in == 1: v[j] = sum_k Wl[k] * B2[k][j] with B2 = [Wij_t^T | Wij_s^T | att]  (j < 2C + 1)
+__global__ void gat_rank1_vec_kernel(int C, const float* __restrict__ Wl, const float* __restrict__ att, const float* __restrict__ Wij,
+                                     float* __restrict__ vec) {
+    const int j = threadIdx.x;
+    if (j > 2 * C) return;
+    float a = 0.0f;
+    for (int k = 0; k < C; ++k) {
+        const float bkj = j < C ? Wij[(size_t)j * 2 * C + k] : (j < 2 * C ? Wij[(size_t)(j - C) * 2 * C + C + k] : att[k]);
+        a += Wl[k] * bkj;                                    // Wl is [C, 1]
+    }
+    vec[j] = a;
+}
+// x_l = X Wl^T for a narrow input (1 < c_in < 16): one thread per (node, channel)
 __global__ void gat_xl_narrow_kernel(int n, int C, int c_in, const float* __restrict__ X, const float* __restrict__ Wl,
                                      float* __restrict__ XL) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,6 +291,15 @@ int launch_gat(int n, const int* rowptr, const int* src, const float* X, int c_i
     const unsigned agrid = (unsigned)(((size_t)n * C + 255) / 256);
     constexpr int NPG = 2;                                   // nodes per lane group in the aggregation (4: 321 us, 1: 336 us, 2: 243 us)
     const unsigned agrid2 = (unsigned)((((size_t)n + NPG - 1) / NPG * C + 255) / 256);
+    if (c_in == 1) {
+        // the first PDGNN layer: rows are f_i * v (see gat_aggregate_kernel, RANK1)
+        float* vec = work;                                   // [2C + 1]
+        hipLaunchKernelGGL(gat_rank1_vec_kernel, dim3(1), dim3(256), 0, s, C, Wl, att, Wij, vec);
+        hipLaunchKernelGGL((gat_aggregate_kernel<C, NPG, true>), dim3(agrid2), dim3(256), 0, s, n, rowptr, src, X, 1, bias, slope, out,
+                           (const float*)vec);
+        TLC_HIP_CHECK(hipGetLastError());
+        return TLC_OK;
+    }
     if (2 * C + 4 <= 128 && C % 4 == 0) {
         // x_l = X Wl^T and [P | Q | alpha] = x_l [Wij_t^T | Wij_s^T | att] as two products on the f32 MFMA (per node on the
         // vector ALU this was 95 us of a layer; the products are 2 x ~15 us)
@@ -286,8 +317,8 @@ int launch_gat(int n, const int* rowptr, const int* src, const float* X, int c_i
         if (rc != TLC_OK) return rc;
         rc = tlc_gemm_f32(n, N2, C, XL, Bt2, nullptr, 0, PQA, s);
         if (rc != TLC_OK) return rc;
-        hipLaunchKernelGGL((gat_aggregate_kernel<C, NPG>), dim3(agrid2), dim3(256), 0, s, n, rowptr, src, (const float*)PQA, N2, bias,
-                           slope, out);
+        hipLaunchKernelGGL((gat_aggregate_kernel<C, NPG, false>), dim3(agrid2), dim3(256), 0, s, n, rowptr, src, (const float*)PQA, N2, bias,
+                           slope, out, (const float*)nullptr);
         TLC_HIP_CHECK(hipGetLastError());
         return TLC_OK;
     }
@@ -297,8 +328,8 @@ int launch_gat(int n, const int* rowptr, const int* src, const float* X, int c_i
     int grid = (n + NPB - 1) / NPB;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(gat_node_kernel<C>, dim3(grid), dim3(256), lds, s, n, X, c_in, Wl, att, Wij, work);
-    hipLaunchKernelGGL((gat_aggregate_kernel<C, NPG>), dim3(agrid2), dim3(256), 0, s, n, rowptr, src, (const float*)(work + C), 3 * C + 1, bias,
-                       slope, out);
+    hipLaunchKernelGGL((gat_aggregate_kernel<C, NPG, false>), dim3(agrid2), dim3(256), 0, s, n, rowptr, src, (const float*)(work + C), 3 * C + 1, bias,
+                       slope, out, (const float*)nullptr);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }
