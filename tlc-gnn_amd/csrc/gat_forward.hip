@@ -312,11 +312,21 @@ int launch_gat(int n, const int* rowptr, const int* src, const float* X, int c_i
         hipLaunchKernelGGL(gat_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, C, c_in, Wl, att, Wij, Bt1, Bt2);
         TLC_HIP_CHECK(hipGetLastError());
         int rc = TLC_OK;
-        if (c_in >= 16 && c_in % 4 == 0) rc = tlc_gemm_f32(n, C, c_in, X, Bt1, nullptr, 0, XL, s);
-        else hipLaunchKernelGGL(gat_xl_narrow_kernel, dim3(agrid), dim3(256), 0, s, n, C, c_in, X, Wl, XL);
-        if (rc != TLC_OK) return rc;
-        rc = tlc_gemm_f32(n, N2, C, XL, Bt2, nullptr, 0, PQA, s);
-        if (rc != TLC_OK) return rc;
+        if (c_in >= 16 && c_in % 4 == 0 && c_in <= 64 && (size_t)n * C >= (size_t)c_in * N2) {
+            // [P | Q | alpha] = X (Wl^T B2): the two weight matrices are multiplied first (c_in x N2, in the space x_l would
+            // have taken), so the node features make ONE pass through the MFMA and x_l [n, C] is never written or read back
+            float* Wf = XL;
+            rc = tlc_gemm_f32(c_in, N2, C, Bt1, Bt2, nullptr, 0, Wf, s);
+            if (rc != TLC_OK) return rc;
+            rc = tlc_gemm_f32(n, N2, c_in, X, Wf, nullptr, 0, PQA, s);
+            if (rc != TLC_OK) return rc;
+        } else {
+            if (c_in >= 16 && c_in % 4 == 0) rc = tlc_gemm_f32(n, C, c_in, X, Bt1, nullptr, 0, XL, s);
+            else hipLaunchKernelGGL(gat_xl_narrow_kernel, dim3(agrid), dim3(256), 0, s, n, C, c_in, X, Wl, XL);
+            if (rc != TLC_OK) return rc;
+            rc = tlc_gemm_f32(n, N2, C, XL, Bt2, nullptr, 0, PQA, s);
+            if (rc != TLC_OK) return rc;
+        }
         hipLaunchKernelGGL((gat_aggregate_kernel<C, NPG, false>), dim3(agrid2), dim3(256), 0, s, n, rowptr, src, (const float*)PQA, N2, bias,
                            slope, out, (const float*)nullptr);
         TLC_HIP_CHECK(hipGetLastError());
