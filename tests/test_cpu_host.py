@@ -122,3 +122,21 @@ def test_shard_helpers():
     cost = np.array([1, 1, 1, 100, 1, 1, 1, 1])
     bounds = tdist.shard_pairs_by_cost(cost, 2)
     assert bounds[0] == 0 and bounds[-1] == len(cost) and 0 < bounds[1] < len(cost)
+
+
+def test_simplex_filter_keys_are_the_reference_expressions():
+    """perturb_filter_function (accelerated_PD.py:6-23): node entries {'old','new'}, edge entries keyed (a, b) with
+    asc = hi + (lo + 1)*1e-6, desc = lo - (101 - hi)*1e-6 evaluated in that association in float64 (KAT: scalar CPython)."""
+    from tlc_gnn_amd.sg2dgm.accelerated_PD import build_simplex_filter
+    rs = np.random.RandomState(3)
+    f = np.concatenate([rs.rand(40), [0.0, 1.0, 1 / 3, 2 / 3, 1 / 3]]).tolist()
+    nodes = ["n%d" % i for i in range(len(f))]
+    edges = [(nodes[a], nodes[b]) for a, b in rs.randint(0, len(f), size=(120, 2)).tolist()]
+    sf = build_simplex_filter(nodes, f, edges)
+    assert list(sf)[:len(nodes)] == nodes                       # nodes first, in order; then the edges
+    for nd, v in zip(nodes, f):
+        assert sf[nd] == {'old': v, 'new': v}
+    for a, b in edges:
+        hi, lo = max(sf[a]['old'], sf[b]['old']), min(sf[a]['old'], sf[b]['old'])
+        assert sf[(a, b)]['asc'] == hi + (lo + 1) * 1e-6 and sf[(a, b)]['desc'] == lo - (101 - hi) * 1e-6
+        assert type(sf[(a, b)]['asc']) is float

@@ -75,6 +75,16 @@ def test_accelerated_pd_dropins():
         assert same_multiset(r1, ragged_slice(d["kd_rel1"], d["kd_rel1_offs"], g))
         e1 = kd.Accelerate_PD(pos, neg, sf)
         assert same_multiset(e1, ragged_slice(d["kd_ext1"], d["kd_ext1_offs"], g))
+        # the split is re-derived on the device: lists that are not Union_find's own are refused, never silently ignored
+        if len(pos) >= 2:
+            with pytest.raises(ValueError):
+                kd.Accelerate_PD(pos[::-1], neg, sf)
+            with pytest.raises(ValueError):
+                apd.Accelerate_PD(pos[:-1], neg, sf)
+            with pytest.raises(ValueError):
+                apd.Accelerate_PD(pos, neg[:-1] + [pos[0]], sf)
+        # an edge handed back with its endpoints swapped is the same edge
+        assert same_multiset(kd.Accelerate_PD([[b, a] for a, b in pos], neg, sf), e1)
 
 
 def test_persistence_imager_dropin():

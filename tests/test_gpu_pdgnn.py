@@ -87,6 +87,40 @@ def test_gat_layer_and_teacher_forward():
     assert img0.shape == (25,)
 
 
+def test_same_shape_graphs_from_temporaries_do_not_share_a_csr():
+    """The reference's per-graph loop (evaluate_time; gcn_LP_GIN.compute_PI) feeds one graph after another from temporaries:
+    the allocator hands the freed block back at the same address, so two graphs with equal (n, m) but different edges
+    must not see each other's grouping-by-target.  Also: an in-place edit of edge_index is honoured."""
+    import torch
+    from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
+    torch.manual_seed(11)
+    model = Teacher_Model(type='GAT').cuda().eval()
+    n = 12
+    loops = torch.stack([torch.arange(n), torch.arange(n)])
+    ring = torch.tensor([[i, (i + 1) % n] for i in range(n)]).t()
+    star = torch.tensor([[0, i] for i in range(1, n)] + [[1, 2]]).t()
+    assert ring.shape == star.shape
+    x = torch.linspace(0, 1, n).view(-1, 1)
+
+    def run(e):
+        ei = torch.cat([e, e.flip(0), loops], dim=1)
+        with torch.no_grad():
+            return model(x.cuda(), ei.cuda(), None, compute_loss=False, grad_PI=False)[0].cpu()
+
+    a1 = run(ring)
+    b1 = run(star)
+    a2 = run(ring)
+    assert torch.equal(a1, a2)
+    assert not torch.allclose(a1, b1)
+    # same tensor object, edited in place between two calls
+    ei = torch.cat([ring, ring.flip(0), loops], dim=1).cuda()
+    with torch.no_grad():
+        first = model(x.cuda(), ei, None, compute_loss=False, grad_PI=False)[0].cpu()
+        ei[:, :2 * n] = torch.cat([star, star.flip(0)], dim=1).cuda()
+        second = model(x.cuda(), ei, None, compute_loss=False, grad_PI=False)[0].cpu()
+    assert torch.equal(first, a1) and torch.equal(second, b1)
+
+
 def test_message_passing_dropin_and_scatter():
     """MessagePassing.propagate on a dense edge_index (gather -> message -> HIP scatter -> update) and the four reductions."""
     import torch

@@ -36,7 +36,7 @@ class Base_Model(torch.nn.Module):
             return torch.zeros([0, 2], device=x.device)
         if self.training:
             raise NotImplementedError("Base_Model (HIP): forward/eval only (dropout is the identity)")
-        csr = self.conv1._csr_by_target(edge_index, x.shape[0])       # one CSR for the four layers
+        csr = GATConv.csr_by_target(edge_index, x.shape[0])            # one CSR for the four layers of THIS call
         x = self.conv1(x, edge_index, prelu_slope=0.1, csr=csr)       # conv -> F.prelu(0.1) fused (:218-219)
         x = self.conv2(x, edge_index, prelu_slope=0.1, csr=csr)
         x = self.conv4(x, edge_index, prelu_slope=0.1, csr=csr)

@@ -4,27 +4,13 @@ fork with the TLC_KEEP_ZERO_PERS flag."""
 import numpy as np
 
 from .. import _lib
-from ..sg2dgm.accelerated_PD import _run, _pos_neg
+from ..sg2dgm.accelerated_PD import _run, _pos_neg, build_simplex_filter, check_split
 
 
 def perturb_filter_function(g, filtration_val):
-    """:6-22.  filtration_val[node] for every node of g."""
-    simplex_filter = {}
-    ee = 1e-6
-    max_filter = 101
-    for node in g.nodes():
-        temp = {}
-        temp['old'] = filtration_val[node]
-        temp['new'] = filtration_val[node]
-        simplex_filter[node] = temp
-    for edge in g.edges():
-        temp = {}
-        max_node, min_node = max(simplex_filter[edge[0]]['old'], simplex_filter[edge[1]]['old']), min(
-            simplex_filter[edge[0]]['old'], simplex_filter[edge[1]]['old'])
-        temp['asc'] = max_node + (min_node + 1) * ee
-        temp['desc'] = min_node - (max_filter - max_node) * ee
-        simplex_filter[(edge[0], edge[1])] = temp
-    return simplex_filter
+    """:6-22.  filtration_val[node] for every node of g (array or dict)."""
+    nodes = list(g.nodes())
+    return build_simplex_filter(nodes, [filtration_val[nd] for nd in nodes], g.edges())
 
 
 def Union_find(simplex_filter):
@@ -40,4 +26,5 @@ def Accelerate_PD(Pos_edges, Neg_edges, simplex_filter):
     if len(Neg_edges) == 0:
         raise IndexError("list index out of range")
     res = _run(simplex_filter, _lib.KEEP_ZERO_PERS)
+    check_split(res, Pos_edges, Neg_edges)
     return np.array(res["one"])

@@ -39,22 +39,23 @@ class GATConv(torch.nn.Module):
         self.att_l = Parameter(torch.Tensor(1, heads, out_channels))
         self.att_r = Parameter(torch.Tensor(1, heads, out_channels))                            # unused on the tensor path (:135-136)
         self.bias = Parameter(torch.Tensor(2 * out_channels))                                   # :99-101
-        self._csr_key, self._csr = None, None
         self.reset_parameters()
 
     def reset_parameters(self):
         glorot(self.lin_l.weight)
-        glorot(self.att_l)
+        glorot(self.lin_r.weight)          # lin_r IS lin_l (:86): the reference draws the shared weight twice (:107-108); the
+        glorot(self.att_l)                 # second draw is kept so that every later parameter sees the same RNG stream
         glorot(self.att_r)
         self.bias.data.zero_()
 
-    def _csr_by_target(self, edge_index, n):
-        key = (edge_index.data_ptr(), tuple(edge_index.shape), n)
-        if self._csr_key != key:
-            # remove_self_loops + add_self_loops (:146-152) and grouping by target == the structure gcn_norm builds
-            rowptr, col, _ = ops.gcn_norm_csr(edge_index, n)
-            self._csr_key, self._csr = key, (rowptr, col)
-        return self._csr
+    @staticmethod
+    def csr_by_target(edge_index, n):
+        """remove_self_loops + add_self_loops (:146-152) and grouping by target == the structure gcn_norm builds.  Built per
+        call, like the reference (no cache: an address-keyed cache is stale as soon as the allocator reuses a block or
+        the caller edits edge_index in place); a caller that runs several layers on one graph builds it once and passes
+        `csr=` down, as Base_Model.forward does."""
+        rowptr, col, _ = ops.gcn_norm_csr(edge_index, n)
+        return rowptr, col
 
     def forward(self, x, edge_index, size=None, return_attention_weights=None, prelu_slope=-1.0, csr=None):
         if not isinstance(x, torch.Tensor) or size is not None or return_attention_weights is not None:
@@ -62,7 +63,7 @@ class GATConv(torch.nn.Module):
         assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
         if self.training and self.dropout > 0:
             raise NotImplementedError("GATConv (HIP): attention dropout in training mode is not implemented (forward/eval only)")
-        rowptr, col = csr if csr is not None else self._csr_by_target(edge_index, x.shape[0])
+        rowptr, col = csr if csr is not None else self.csr_by_target(edge_index, x.shape[0])
         return ops.gat_layer(rowptr, col, x, self.lin_l.weight.detach(), self.att_l.detach().reshape(-1),
                              self.lin_ij.weight.detach(), self.bias.detach(), prelu_slope=prelu_slope)
 

@@ -118,9 +118,29 @@ def require_gpu():
     return torch
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """torch's current stream ON `device` (default: torch's current device) -- a stream belongs to one device."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_device_of(fn):
+    """Decorator for the pointer-only entry points (no handle, so the library cannot know the device): run the call with the
+    device of its first CUDA tensor argument current, so the stream handed over and the temporaries belong to the device
+    that owns the pointers; the caller's current device is restored on exit."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        import torch
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapped
 
 
 def ptr(t):

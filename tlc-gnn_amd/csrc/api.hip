@@ -86,6 +86,7 @@ struct tlc_graph {
     int* vic_scratch;
     long long vic_stride;
     size_t vic_lds;
+    int lds_attr_set;          // hipFuncAttributeMaxDynamicSharedMemorySize raised for this handle's device and vic_lds
     // HUGE tier scratch
     int huge_slots;
     unsigned char* huge_scratch;
@@ -239,7 +240,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
         tlc_set_error("graph has %d nodes: the vicinity bitmaps (%zu B) exceed the 160 KiB LDS of a CU", n_nodes, lds);
         return TLC_ERR_UNSUPPORTED;
     }
-    TLC_HIP_CHECK(hipSetDevice(device));
+    TLC_ON_DEVICE(device);
     tlc_graph* g = new (std::nothrow) tlc_graph();
     if (!g) return TLC_ERR_OUT_OF_MEMORY;
     memset(g, 0, sizeof(*g));
@@ -291,7 +292,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
 
 extern "C" int tlc_graph_destroy(tlc_graph* g) {
     if (!g) return TLC_OK;
-    hipSetDevice(g->device);
+    TlcDeviceScope scope(g->device);
     hipDeviceSynchronize();
     hipFree(g->d_rowptr); hipFree(g->d_col); hipFree(g->d_w);
     hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
@@ -352,13 +353,13 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     vp.ids_off = (const long long*)d_ids_off; vp.out_ids = d_out_ids;
     vp.small_dir = g->S_dir; vp.small_lw = g->S_lw;
 
-    static bool lds_attr = false;
-    if (!lds_attr && g->vic_lds > 64 * 1024) {
+    // (the attribute is per device and per size: tracked in the handle, which is bound to one device and one graph size)
+    if (!g->lds_attr_set && g->vic_lds > 64 * 1024) {
         TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
         TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
         TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
         TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_vicinity_kernel<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->vic_lds));
-        lds_attr = true;
+        g->lds_attr_set = 1;
     }
     const int vgrid = std::min(n_pairs, g->vic_slots);
     memset(g->ev_used, 0, sizeof(g->ev_used));
@@ -646,7 +647,7 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
     TLC_REQUIRE(hop >= 1 && hop <= 64, "hop must be in 1..64");
     TLC_REQUIRE(res >= 1 && res <= 8, "res must be in 1..8");
     TLC_REQUIRE(n_pairs == 0 || d_pairs != nullptr, "pairs is null");
-    TLC_HIP_CHECK(hipSetDevice(g->device));
+    TLC_ON_DEVICE(g->device);
     memset(g->last_stats, 0, sizeof(g->last_stats));
     hipStream_t s = (hipStream_t)stream;
     for (int64_t off = 0; off < n_pairs; off += TLC_CHUNK_PAIRS) {
@@ -689,7 +690,7 @@ extern "C" int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int
 
 extern "C" int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream) {
     TLC_REQUIRE(g && h_out, "null argument");
-    TLC_HIP_CHECK(hipSetDevice(g->device));
+    TLC_ON_DEVICE(g->device);
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     TLC_HIP_CHECK(hipMemcpy(g->h_sync->stats, g->d_stats, sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int k = 0; k < 8; ++k) h_out[k] = g->last_stats[k];
@@ -759,7 +760,7 @@ extern "C" int tlc_pi_raster(int32_t n_dgms, const int64_t* d_offs, const double
 // ---- diagnostics (not part of include/tlcgnn.h): per-phase cycle counters of the PD tier kernels -------------------
 extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out /* [TLC_N_TIERS + 1][32] or null */) {
     TLC_REQUIRE(g != nullptr, "null graph");
-    TLC_HIP_CHECK(hipSetDevice(g->device));
+    TLC_ON_DEVICE(g->device);
     TLC_HIP_CHECK(hipDeviceSynchronize());
     if (h_out && g->d_phase) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_phase, (size_t)(TLC_N_TIERS + 1) * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (enable && !g->d_phase) TLC_HIP_CHECK(hipMalloc(&g->d_phase, (size_t)(TLC_N_TIERS + 1) * 32 * sizeof(unsigned long long)));
@@ -781,7 +782,7 @@ extern "C" int tlc_pd_pi_batch_set_timing(tlc_graph* g, int enable) {
 // LAST chunk of the last tlc_pd_pi_batch, from HIP events recorded on the stream each kernel ran on.  Synchronises.
 extern "C" int tlc_pd_pi_batch_timings(tlc_graph* g, double* h_ms, void* stream) {
     TLC_REQUIRE(g && h_ms, "null argument");
-    TLC_HIP_CHECK(hipSetDevice(g->device));
+    TLC_ON_DEVICE(g->device);
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     for (int k = 0; k < 8; ++k) {
         h_ms[k] = -1.0;
@@ -798,7 +799,7 @@ extern "C" int tlc_pd_pi_batch_timings(tlc_graph* g, double* h_ms, void* stream)
 // vicinity sizes of the last chunk: h_n[i] = |S| (0 for pairs finished early), h_m2[i] = induced directed entries
 extern "C" int tlc_pd_pi_batch_sizes(tlc_graph* g, int32_t* h_n, int32_t* h_m2, int64_t cap, void* stream) {
     TLC_REQUIRE(g && h_n && h_m2, "null argument");
-    TLC_HIP_CHECK(hipSetDevice(g->device));
+    TLC_ON_DEVICE(g->device);
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     const size_t k = (size_t)std::min<int64_t>(cap, g->last_n_pairs);
     if (k) {

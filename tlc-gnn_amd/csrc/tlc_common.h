@@ -29,6 +29,32 @@ void tlc_set_error(const char* fmt, ...);
         }                                                        \
     } while (0)
 
+// Entry points that take a graph handle run on the handle's device whatever the caller's current device is, and leave the
+// caller's current device as they found it (a library call must not move later torch allocations to another GPU).
+struct TlcDeviceScope {
+    int prev = -1;
+    bool moved = false;
+    hipError_t err = hipSuccess;
+    explicit TlcDeviceScope(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            moved = err == hipSuccess;
+        }
+    }
+    ~TlcDeviceScope() {
+        if (moved) (void)hipSetDevice(prev);
+    }
+    TlcDeviceScope(const TlcDeviceScope&) = delete;
+    TlcDeviceScope& operator=(const TlcDeviceScope&) = delete;
+};
+#define TLC_ON_DEVICE(dev)                                                                                   \
+    TlcDeviceScope _tlc_scope(dev);                                                                          \
+    if (_tlc_scope.err != hipSuccess) {                                                                      \
+        tlc_set_error("%s: cannot select device %d: %s", __func__, (int)(dev), hipGetErrorString(_tlc_scope.err)); \
+        return TLC_ERR_HIP;                                                                                  \
+    }
+
 // ---- device helpers ---------------------------------------------------------------------------------
 #ifdef __HIPCC__
 __device__ __forceinline__ int tlc_lane() { return (int)(threadIdx.x & 63); }

@@ -49,6 +49,7 @@ class DeviceGraph:
         """pairs: int32 CUDA tensor [E,2] -> (pi float64[E,res*res], status uint8[E]) on the current stream."""
         import torch
         assert pairs.is_cuda and pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2
+        assert pairs.device.index == self.device, "pairs live on cuda:%s, the graph on cuda:%d" % (pairs.device.index, self.device)
         pairs = pairs.contiguous()
         E = pairs.shape[0]
         if out is None:
@@ -56,13 +57,13 @@ class DeviceGraph:
         if status is None:
             status = torch.empty((E,), dtype=torch.uint8, device=pairs.device)
         rc = _lib.lib().tlc_pd_pi_batch(self._h, _lib.ptr(pairs), C.c_int64(E), C.c_int(hop), C.c_uint32(flags),
-                                        C.c_int(res), _lib.ptr(out), _lib.ptr(status), _lib.stream_ptr())
+                                        C.c_int(res), _lib.ptr(out), _lib.ptr(status), _lib.stream_ptr(self.device))
         _lib.check(rc, "tlc_pd_pi_batch")
         return out, status
 
     def stats(self):
         out = (C.c_int64 * 8)()
-        rc = _lib.lib().tlc_pd_pi_batch_stats(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr())
+        rc = _lib.lib().tlc_pd_pi_batch_stats(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr(self.device))
         _lib.check(rc, "tlc_pd_pi_batch_stats")
         v = list(out)
         return {"tier_small": v[0], "tier_medium": v[1], "tier_large": v[2], "tier_huge": v[3],
@@ -82,20 +83,21 @@ class DeviceGraph:
     def timings(self):
         """ms per kernel of the last batch (HIP events on the stream each kernel ran on); -1 = not launched."""
         out = (C.c_double * 8)()
-        _lib.check(_lib.lib().tlc_pd_pi_batch_timings(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr()), "timings")
+        _lib.check(_lib.lib().tlc_pd_pi_batch_timings(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr(self.device)), "timings")
         return dict(zip(self.KERNELS, list(out)[:8]))
 
     def sizes(self, n_pairs):
         n = np.zeros(n_pairs, dtype=np.int32)
         m2 = np.zeros(n_pairs, dtype=np.int32)
         _lib.check(_lib.lib().tlc_pd_pi_batch_sizes(self._h, n.ctypes.data_as(C.c_void_p), m2.ctypes.data_as(C.c_void_p),
-                                                    C.c_int64(n_pairs), _lib.stream_ptr()), "sizes")
+                                                    C.c_int64(n_pairs), _lib.stream_ptr(self.device)), "sizes")
         return n, m2
 
     def vicinity_filtration(self, pairs, hop, flags=0, cap=None, edge_cap=None):
         """-> (node_offs int64[E+1], ids int32[E*cap], f float64[E*cap], n int32[E], status uint8[E])
         with edge_cap: additionally (edge_offs int64[E+1], edges int32[E*edge_cap,2] local ids, m int32[E])"""
         import torch
+        assert pairs.device.index == self.device, "pairs live on cuda:%s, the graph on cuda:%d" % (pairs.device.index, self.device)
         pairs = pairs.contiguous()
         E = pairs.shape[0]
         cap = self.n_nodes if cap is None else int(cap)
@@ -112,13 +114,14 @@ class DeviceGraph:
             m = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
         rc = _lib.lib().tlc_vicinity_filtration(self._h, _lib.ptr(pairs), C.c_int64(E), C.c_int(hop), C.c_uint32(flags),
                                                 _lib.ptr(offs), _lib.ptr(ids), _lib.ptr(f), _lib.ptr(n), _lib.ptr(st),
-                                                _lib.ptr(eoffs), _lib.ptr(edges), _lib.ptr(m), _lib.stream_ptr())
+                                                _lib.ptr(eoffs), _lib.ptr(edges), _lib.ptr(m), _lib.stream_ptr(self.device))
         _lib.check(rc, "tlc_vicinity_filtration")
         if edge_cap is not None:
             return offs, ids, f, n[:E], st[:E], eoffs, edges, m[:E]
         return offs, ids, f, n[:E], st[:E]
 
 
+@_lib.on_device_of
 def pd_from_filtration(node_offs, edge_offs, edges, f, flags=0, want_rank=True):
     """Batched perturb_filter_function + Union_find + Accelerate_PD (sg2dgm/accelerated_PD.py:6-178).
 
@@ -144,6 +147,7 @@ def pd_from_filtration(node_offs, edge_offs, edges, f, flags=0, want_rank=True):
     return dict(up=up, down=down, one=one, ext0=ext0[:B], counts=counts[:B], edge_rank=None if rank is None else rank[:sm])
 
 
+@_lib.on_device_of
 def pi_raster(offs, pts, res=5):
     """Batched PersistenceImager(resolution=res).transform (sg2dgm/PersistenceImager.pyx:352-388).
 
@@ -261,6 +265,7 @@ def near_pairs(index, hop, cap=None):
             cap = k + 1024
 
 
+@_lib.on_device_of
 def select_rows(pi, status, index_base, count, out_idx, out_status, out_rows, hist=None, keep_failed=False):
     """Append the non-zero rows of an image block (keep_failed: and the zero rows with status != 0) to a sparse store and add
     the block's status bytes to `hist` (int64 CUDA [8]) -- tlc_select_rows.  count: int64 CUDA scalar tensor the caller zeroed

@@ -36,28 +36,51 @@ def get_edges_split(data, val_prop=0.2, test_prop=0.2, seed=1234):
     return get_adj_split(sp.csr_matrix(a), val_prop=val_prop, test_prop=test_prop, seed=seed)
 
 
+def _upper_positives(adj):
+    """Stored entries of the upper triangle in CSR (row-major) order -- the order `sp.triu(adj).nonzero()` walks."""
+    up = sp.triu(adj).tocoo()
+    stored = up.data != 0
+    return np.stack([up.row[stored], up.col[stored]], 1).astype(np.int64)
+
+
+def _upper_non_edges(adj, block_cells=1 << 24):
+    """[n_neg, 2] int64: every (x, y), y >= x, with adj[x, y] != 1, row-major -- what `sp.triu(1. - adj.toarray()).nonzero()`
+    enumerates (loaddatas.py:44), built from boolean row blocks instead of the N x N float64 array."""
+    n = adj.shape[0]
+    cols = np.arange(n)
+    rows_per_block = max(1, block_cells // max(n, 1))
+    parts = []
+    for r0 in range(0, n, rows_per_block):
+        r1 = min(n, r0 + rows_per_block)
+        free = cols[None, :] >= np.arange(r0, r1)[:, None]
+        ones = adj[r0:r1].tocoo()
+        is_one = ones.data == 1
+        free[ones.row[is_one], ones.col[is_one]] = False
+        x, y = np.nonzero(free)
+        parts.append(np.stack([x + r0, y], 1))
+    return np.concatenate(parts).astype(np.int64) if parts else np.zeros((0, 2), np.int64)
+
+
+def _cut(pos_edges, negatives, val_prop, test_prop):
+    """The three slices of both lists (loaddatas.py:48-52); `negatives` only needs slicing."""
+    n_val, n_test = int(len(pos_edges) * val_prop), int(len(pos_edges) * test_prop)
+    a, b = n_val, n_val + n_test
+    return (pos_edges[b:], pos_edges[:a], pos_edges[a:b]), (negatives[:a], negatives[a:b])
+
+
 def get_adj_split(adj, val_prop=0.05, test_prop=0.1, seed=1234):
-    """loaddatas.py:38-54, statement for statement (same RNG stream, same orders).
-
-    Like the reference this materialises the dense complement `1. - adj.toarray()` (N x N float64): fine for the
-    plumbing-sized graphs it is tested on, 3.1 GB for PubMed -- replacing it is SURVEY.md §8(f) item 2.
-    """
-    np.random.seed(seed)  # get tp edges
-    x, y = sp.triu(adj).nonzero()
-    pos_edges = np.array(list(zip(x, y)))
+    """loaddatas.py:38-54 with the reference's array outputs: the same two legacy-MT19937 shuffles in the same order
+    (positives, then negatives), `train_edges_false` = the whole shuffled negative list ++ val ++ test positives (:53).
+    The host-side twin of get_adj_split_streamed for plumbing-sized graphs: the negatives are enumerated by
+    `_upper_non_edges` (n_neg x 2 int64 -- 3.1 GB for PubMed, which is what the streamed form is for)."""
+    adj = sp.csr_matrix(adj)
+    np.random.seed(seed)
+    pos_edges = _upper_positives(adj)
     np.random.shuffle(pos_edges)
-    # get tn edges
-    x, y = sp.triu(sp.csr_matrix(1. - adj.toarray())).nonzero()
-    neg_edges = np.array(list(zip(x, y)))
+    neg_edges = _upper_non_edges(adj)
     np.random.shuffle(neg_edges)
-
-    m_pos = len(pos_edges)
-    n_val = int(m_pos * val_prop)
-    n_test = int(m_pos * test_prop)
-    val_edges, test_edges, train_edges = pos_edges[:n_val], pos_edges[n_val:n_test + n_val], pos_edges[n_test + n_val:]
-    val_edges_false, test_edges_false = neg_edges[:n_val], neg_edges[n_val:n_test + n_val]
-    train_edges_false = np.concatenate([neg_edges, val_edges, test_edges], axis=0)
-    return train_edges, train_edges_false, val_edges, val_edges_false, test_edges, test_edges_false
+    (train, val, test), (val_false, test_false) = _cut(pos_edges, neg_edges, val_prop, test_prop)
+    return train, np.concatenate([neg_edges, val, test]), val, val_false, test, test_false
 
 
 def get_edges_split_streamed(data, val_prop=0.2, test_prop=0.2, seed=1234, device=None):
@@ -85,16 +108,11 @@ def get_adj_split_streamed(adj, val_prop=0.05, test_prop=0.1, seed=1234, device=
         raise ValueError("get_adj_split_streamed: the adjacency must be 0/1 (`1. - adj` of the reference is a non-edge "
                          "only where adj == 1)")
     np.random.seed(seed)
-    up = sp.triu(adj).tocoo()
-    keep = up.data != 0
-    pos_edges = np.stack([up.row[keep], up.col[keep]], 1).astype(np.int64)
+    pos_edges = _upper_positives(adj)
     np.random.shuffle(pos_edges)
-    stored = sp.csr_matrix(adj)
-    negatives = ShuffledNegatives(stored.indptr, stored.indices, device=device)     # draws the second shuffle
-    m_pos = len(pos_edges)
-    n_val, n_test = int(m_pos * val_prop), int(m_pos * test_prop)
-    val_edges, test_edges, train_edges = pos_edges[:n_val], pos_edges[n_val:n_test + n_val], pos_edges[n_test + n_val:]
-    return train_edges, negatives, val_edges, negatives[:n_val], test_edges, negatives[n_val:n_test + n_val]
+    negatives = ShuffledNegatives(adj.indptr, adj.indices, device=device)     # draws the second shuffle
+    (train, val, test), (val_false, test_false) = _cut(pos_edges, negatives, val_prop, test_prop)
+    return train, negatives, val, val_false, test, test_false
 
 
 def compute_persistence_image_streamed(data, train_edges, negatives, val_edges, val_edges_false, test_edges, test_edges_false,

@@ -14,6 +14,7 @@ def _f32(t):
     return t.contiguous()
 
 
+@_lib.on_device_of
 def gcn_norm_csr(edge_index, num_nodes):
     """gcn_norm of GCNConv(cached=True) (Knowledge_Distillation/PD_conv.py:35-70) as CSR by target.
 
@@ -35,6 +36,7 @@ def gcn_norm_csr(edge_index, num_nodes):
     return rowptr, col[:k].contiguous(), val[:k].contiguous()
 
 
+@_lib.on_device_of
 def gemm(a, b, bias=None, relu=False, out=None):
     """C = A @ B (+bias)(ReLU) on the f32 MFMA; A [M,K], B [K,N<=128] float32 CUDA."""
     torch = _lib.require_gpu()
@@ -51,6 +53,7 @@ def gemm(a, b, bias=None, relu=False, out=None):
     return out
 
 
+@_lib.on_device_of
 def spmm(rowptr, col, val, x, bias=None, relu=False, out=None, renorm=False):
     """Y = act(CSR @ X + bias): the normalised scatter-add of GCNConv as a row-owned gather; renorm=True also applies
     emb.renorm_(2, 0, 1) (TLCGNN.py:48) to every output row in the same pass."""
@@ -67,6 +70,7 @@ def spmm(rowptr, col, val, x, bias=None, relu=False, out=None, renorm=False):
     return out
 
 
+@_lib.on_device_of
 def renorm_rows_(emb):
     """emb.renorm_(2, 0, 1) in place (baselines/TLCGNN.py:48)."""
     emb_c = _f32(emb)
@@ -76,6 +80,7 @@ def renorm_rows_(emb):
     return emb
 
 
+@_lib.on_device_of
 def lp_decode(pairs, emb, pi, w1, b1, w2, b2, out=None):
     """Fused Net.decode tail (baselines/TLCGNN.py:52-61).  pairs int32 [E,2], emb f32 [N,D], pi f64 [E,P]."""
     torch = _lib.require_gpu()
@@ -90,6 +95,7 @@ def lp_decode(pairs, emb, pi, w1, b1, w2, b2, out=None):
     return out
 
 
+@_lib.on_device_of
 def gat_layer(rowptr, src, x, wl, att, wij, bias, prelu_slope=-1.0, out=None):
     """One PDGNN layer (Knowledge_Distillation/gat_conv.py:113-216) on a CSR-by-target batch."""
     torch = _lib.require_gpu()
@@ -107,6 +113,7 @@ def gat_layer(rowptr, src, x, wl, att, wij, bias, prelu_slope=-1.0, out=None):
     return out
 
 
+@_lib.on_device_of
 def edge_head(src, dst, x, w5, b5, prelu_slope, w6, b6, out=None):
     """Edge head of Teacher_Model.forward (Knowledge_Distillation/Teacher_model.py:54-59) -> f32 [E,2]."""
     torch = _lib.require_gpu()
@@ -127,6 +134,7 @@ def edge_head(src, dst, x, w5, b5, prelu_slope, w6, b6, out=None):
 REDUCE = {"add": 0, "sum": 0, "mean": 1, "min": 2, "max": 3}
 
 
+@_lib.on_device_of
 def scatter(src, index, dim_size, reduce="sum"):
     """torch_scatter.scatter(src, index, dim=0, dim_size=dim_size, reduce=...) (message_passing.py:292).
 

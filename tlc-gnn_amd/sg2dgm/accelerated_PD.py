@@ -10,24 +10,36 @@ import numpy as np
 from .. import engine, _lib
 
 
+EE = 1e-6            # accelerated_PD.py:9
+MAX_FILTER = 101     # accelerated_PD.py:10
+
+
+def build_simplex_filter(nodes, values, edges):
+    """The dict the reference's three functions pass around: node -> {'old', 'new'} (both the filtration value) and
+    (a, b) -> {'asc': hi + (lo + 1)*EE, 'desc': lo - (MAX_FILTER - hi)*EE} with hi/lo the larger/smaller endpoint value
+    (accelerated_PD.py:12-22).  Keys for all edges are evaluated in one numpy pass: elementwise float64 add/mul round
+    exactly like CPython's (two roundings, no FMA), the association is the reference's."""
+    nodes = list(nodes)
+    values = list(values)
+    sf = {nd: {'old': v, 'new': v} for nd, v in zip(nodes, values)}
+    edges = [(e[0], e[1]) for e in edges]
+    if edges:
+        slot = {nd: i for i, nd in enumerate(nodes)}
+        f = np.asarray(values, dtype=np.float64)
+        fa = f[[slot[a] for a, _ in edges]]
+        fb = f[[slot[b] for _, b in edges]]
+        hi, lo = np.maximum(fa, fb), np.minimum(fa, fb)
+        asc = hi + (lo + 1) * EE
+        desc = lo - (MAX_FILTER - hi) * EE
+        for e, up, down in zip(edges, asc.tolist(), desc.tolist()):
+            sf[e] = {'asc': up, 'desc': down}
+    return sf
+
+
 def perturb_filter_function(g, descriptor='seal'):
     """:6-23.  g: networkx-like graph whose nodes carry g.nodes[n][descriptor]."""
-    simplex_filter = {}
-    ee = 1e-6
-    max_filter = 101
-    for node in g.nodes():
-        temp = {}
-        temp['old'] = g.nodes[node][descriptor]
-        temp['new'] = g.nodes[node][descriptor]
-        simplex_filter[node] = temp
-    for edge in g.edges():
-        temp = {}
-        max_node, min_node = max(simplex_filter[edge[0]]['old'], simplex_filter[edge[1]]['old']), min(
-            simplex_filter[edge[0]]['old'], simplex_filter[edge[1]]['old'])
-        temp['asc'] = max_node + (min_node + 1) * ee
-        temp['desc'] = min_node - (max_filter - max_node) * ee
-        simplex_filter[(edge[0], edge[1])] = temp
-    return simplex_filter
+    nodes = list(g.nodes())
+    return build_simplex_filter(nodes, [g.nodes[nd][descriptor] for nd in nodes], g.edges())
 
 
 def _unpack(simplex_filter):
@@ -70,9 +82,24 @@ def Union_find(simplex_filter):
     return PD, Pos_edges, Neg_edges
 
 
+def check_split(res, Pos_edges, Neg_edges):
+    """The cycle swap runs on the device from the filtration alone: it re-derives the tree (Neg) and the query order (Pos)
+    that Union_find reported.  A caller that hands in anything else (edited lists, lists of another filtration) would get
+    the diagram of the unedited split -- refuse instead of answering a different question."""
+    pos, neg = _pos_neg(res)
+    as_sets = lambda edges: [frozenset((a, b)) for a, b in edges]
+    if as_sets(Pos_edges) != as_sets(pos):
+        raise ValueError("Accelerate_PD: Pos_edges is not the cycle-edge sequence Union_find yields for this simplex_filter "
+                         "(the HIP kernel derives the split itself; edited lists are not supported)")
+    if set(as_sets(Neg_edges)) != set(as_sets(neg)):
+        raise ValueError("Accelerate_PD: Neg_edges is not the spanning tree Union_find yields for this simplex_filter")
+
+
 def Accelerate_PD(Pos_edges, Neg_edges, simplex_filter):
-    """:115-178 -> PD_one (list of [low, large]).  Pos/Neg must come from Union_find on the same simplex_filter."""
+    """:115-178 -> PD_one (list of [low, large]).  Pos/Neg must be what Union_find returned for the same
+    simplex_filter (checked: ValueError otherwise)."""
     if len(Neg_edges) == 0:
         raise IndexError("list index out of range")          # list(Nodes)[0] on an empty graph (:122)
     res = _run(simplex_filter, 0)
+    check_split(res, Pos_edges, Neg_edges)
     return res["one"].tolist()
