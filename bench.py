@@ -7,9 +7,13 @@
 One "step" = one pass of the hot path over one batch per GPU:
   leg 1  PD/PI : all 37 676 train-positive pairs (hop 2) -> 5x5 persistence images        (tlc_pd_pi_batch)
   leg 2  LP fwd: TLCGNN encode (2-layer GCN) + fused decode over 2*37 676 = 75 352 pairs, image rows resident in HBM
-Inputs are resident in HBM before the timed region.  Weak scaling: every rank owns a full batch (its own permutation of
-the training pairs, the small CSR replicated, no data-path collective for leg 1; the encoder of leg 2 is node-row
-sharded with one RCCL all-gather per layer).  Rank 0 prints ONE JSON line.
+Inputs are resident in HBM before the timed region.  The timed region is K steps with no host synchronisation inside: the K
+image batches enqueued back to back, then the K forwards (the two legs of a step do not depend on each other); `value` is
+the image throughput of that region, `pi_latency_ms` the time of one synchronised batch.  --rotate-batches feeds a different
+batch every step.  Weak scaling: every rank owns a full batch (the small CSR replicated, no data-path collective in leg 1;
+the encoder of leg 2 either node-row sharded with one RCCL all-gather per layer or replicated, whichever is faster);
+`strong_scaling` beside it cuts ONE list (the 504 514 non-edges within hop distance) into cost-balanced shards.
+`--gpus N` without a launcher starts its own N ranks (torch.distributed.run, before any GPU call).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -60,7 +64,7 @@ def build_workload(rank, seed=1234):
                     break
     neg = np.array(neg, dtype=np.int64)
     x = synth.synthetic_features(n, n_feat, seed=seed)
-    return dict(n=n, hop=hop, n_feat=n_feat, rowptr=rowptr, col=col, w=w, train_edges=tr_sorted,
+    return dict(n=n, hop=hop, n_feat=n_feat, rowptr=rowptr, col=col, w=w, train_edges=tr_sorted, all_pos=pos,
                 pi_pairs=np.ascontiguousarray(pi_pairs, dtype=np.int32), neg=neg, x=x)
 
 
@@ -147,13 +151,51 @@ def _ricci_cpu_sample(ricci_ref, n, edges, sample):
     return np.array(out)
 
 
+def _self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves -- a child
+    `python -m torch.distributed.run` (one process per GPU, rendezvous on 127.0.0.1), BEFORE this process has touched the
+    GPU (nothing here has even imported torch), and hand its exit code back.  Never an exec of a GPU-initialised process."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def rotated_batches(wl, count, seed=4321):
+    """`count` different batches of the headline size: samples without replacement of ALL positive pairs of the graph
+    (train + val + test positives: 44 324), random orientation -- tier counts, arena size and the heavy-pair list differ
+    from batch to batch, so the library's guesses from the previous chunk (arena size, speculative grid sizes) are
+    never exactly right, as in a sweep over changing chunks."""
+    E = len(wl["pi_pairs"])
+    out = []
+    for j in range(count):
+        rs = np.random.RandomState(seed + j)
+        b = wl["all_pos"][rs.choice(len(wl["all_pos"]), size=E, replace=False)]
+        flip = rs.rand(E) < 0.5
+        b = np.where(flip[:, None], b[:, ::-1], b)
+        out.append(np.ascontiguousarray(b, dtype=np.int32))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sweep", action="store_true", help="skip the auxiliary random-pair sweep (profiling runs)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the auxiliary blocks (profiling runs)")
+    ap.add_argument("--rotate-batches", action="store_true",
+                    help="timed region over different 37 676-pair batches (see rotated_batches) instead of the same one")
+    ap.add_argument("--encoder", default="auto", choices=["auto", "allgather", "replicated"],
+                    help="N > 1: node-row sharded encoder with one RCCL all-gather per layer, or the whole encoder on every "
+                         "rank; auto = time both before the timed region and keep the faster")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: 'gloo' lets N ranks share ONE GPU with --single-device "
                     "(RCCL refuses two ranks on a device); the measured configuration is always nccl = RCCL, one rank per GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -161,13 +203,17 @@ def main():
                     help="development: no per-kernel HIP events in the timed region (the roofline block is then meaningless)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args.gpus, sys.argv[1:]))
+
     import torch
     from tlc_gnn_amd import engine, ops, dist as tdist, _lib
     from tlc_gnn_amd.baselines import TLCGNN
 
     rank, local_rank, world = tdist.env_world()
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but the launcher started %d rank(s): `value` is the aggregate over WORLD_SIZE ranks, "
+                         "the two must agree" % (args.gpus, world))
     _lib.require_gpu()
     if args.single_device:
         local_rank = 0
@@ -187,6 +233,7 @@ def main():
     E = pi_pairs.shape[0]
     pi_out = torch.empty((E, 25), dtype=torch.float64, device=dev)
     pi_status = torch.empty(E, dtype=torch.uint8, device=dev)
+    rot = [torch.from_numpy(b).to(dev) for b in rotated_batches(wl, 8, seed=4321 + 100 * rank)]
 
     # ---- LP leg setup: model, graph operator, decode tables (all resident before the timed region) ---------------------
     torch.manual_seed(1234)
@@ -198,10 +245,7 @@ def main():
     te = wl["train_edges"]
     edge_index = torch.from_numpy(np.concatenate([te, te[:, ::-1]]).T.copy()).long().to(dev)
     rowptr_n, col_n, val_n = ops.gcn_norm_csr(edge_index, n)          # cached=True: one-off
-    enc = tdist.ShardedGCNEncoder(rowptr_n, col_n, val_n, n, world, rank,
-                                  gemm=lambda a, b: ops.gemm(a, b),
-                                  spmm=lambda rp, c, v, xx, bias, relu, renorm=False: ops.spmm(rp, c, v, xx, bias=bias, relu=relu, renorm=renorm))
-    x_local = torch.from_numpy(wl["x"][enc.lo:enc.hi]).to(dev).contiguous()
+    x_full = torch.from_numpy(wl["x"]).to(dev).contiguous()
     dec_pairs_np = np.concatenate([wl["pi_pairs"].astype(np.int64), wl["neg"]]).astype(np.int32)
     dec_pairs = torch.from_numpy(dec_pairs_np).to(dev)
     dec_pi, _ = g.pd_pi_batch(dec_pairs, hop)                         # image rows of the decode batch: resident
@@ -211,53 +255,168 @@ def main():
     l2w, l2b = model.linear.weight.detach(), model.linear.bias.detach()
     prob = torch.empty(dec_pairs.shape[0], dtype=torch.float32, device=dev)
 
-    def leg_pi():
-        g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)
-
-    def leg_lp():
-        emb = enc.encode(x_local, w1, b1, w2, b2, renorm=True)         # renorm_ of TLCGNN.py:48 fused into the last SpMM
-        ops.lp_decode(dec_pairs, emb, dec_pi, l1w, l1b, l2w, l2b, out=prob)
-
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
+    def make_encoder(mode):
+        enc = tdist.ShardedGCNEncoder(rowptr_n, col_n, val_n, n, world, rank, mode=mode,
+                                      gemm=lambda a, b, out=None: ops.gemm(a, b, out=out),
+                                      spmm=lambda rp, c, v, xx, bias, relu, renorm=False, out=None:
+                                      ops.spmm(rp, c, v, xx, bias=bias, relu=relu, renorm=renorm, out=out))
+        x_local = x_full[enc.lo:enc.hi].contiguous()
+        pairs_mapped = enc.row_map(dec_pairs.long()).to(torch.int32).contiguous()      # decode pairs index encode()'s layout
+
+        def leg():
+            emb = enc.encode(x_local, w1, b1, w2, b2, renorm=True)     # renorm_ of TLCGNN.py:48 fused into the last SpMM
+            ops.lp_decode(pairs_mapped, emb, dec_pi, l1w, l1b, l2w, l2b, out=prob)
+        return leg
+
+    def time_leg(fn, reps):
+        fn()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        barrier()
+        t = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # N > 1: the encoder either shards node rows (3 all-gathers per forward) or runs whole on every rank (no collective);
+    # both are timed here, outside the timed region, and the faster one is the LP leg (same result either way)
+    encoder_ms = {}
+    modes = ["replicated"] if world == 1 else (["allgather", "replicated"] if args.encoder == "auto" else [args.encoder])
+    legs = {}
+    for mode in modes:
+        legs[mode] = make_encoder(mode)
+        encoder_ms[mode] = time_leg(legs[mode], 10)
+    enc_mode = min(encoder_ms, key=lambda k: encoder_ms[k])
+    leg_lp = legs[enc_mode]
+
+    def leg_pi(step=0):
+        g.pd_pi_batch(rot[step % len(rot)] if args.rotate_batches else pi_pairs, hop, out=pi_out, status=pi_status)
+
+    # ---- warm-up + latency line -------------------------------------------------------------------------------------------
     # Per-kernel HIP events (recorded inside the library on the stream each kernel runs on) cost time themselves: all eight
-    # pairs add 48 us to the 1.06 ms batch.  So every kernel is timed during the warm-up steps (-> `kernel_ms` of the others,
-    # and which kernel dominates), and inside the timed region only the dominant kernel carries events (-> `roofline`).
+    # pairs add 48 us to the 1.06 ms batch.  Every kernel is timed during the warm-up steps (-> `kernel_ms` and which kernel
+    # dominates); in the timed region only the dominant kernel carries events, kept by the library in a ring and read AFTER
+    # the region.  The warm-up steps synchronise after every batch: their median is the LATENCY of one batch
+    # (`pi_latency_ms`); the timed region below measures THROUGHPUT (batches enqueued back to back, no host sync).
     ktimes = {k: [] for k in engine.DeviceGraph.KERNELS}
     g.set_timing(not args.no_kernel_events)
-    for _ in range(max(args.warmup, 1)):
-        leg_pi()
+    lat = []
+    for s in range(max(args.warmup, 1)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        leg_pi(s)
+        e1.record()
         leg_lp()
         for k, v in g.timings().items():
             ktimes[k].append(v)
-    warm_avg = {k: float(np.mean([x for x in v if x >= 0])) if any(x >= 0 for x in v) else -1.0 for k, v in ktimes.items()}
+        lat.append(e0.elapsed_time(e1))
+    warm_avg = {k: float(np.median([x for x in v if x >= 0])) if any(x >= 0 for x in v) else -1.0 for k, v in ktimes.items()}
     dom_warm = max(warm_avg, key=lambda k: warm_avg[k])
+    g.set_timing(False)
+    lat_plain = []
+    for s in range(5):                                                # latency without any kernel events
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        leg_pi(s)
+        e1.record()
+        torch.cuda.synchronize()
+        lat_plain.append(e0.elapsed_time(e1))
     if not args.no_kernel_events:
         g.set_timing(True, only=[dom_warm])
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    ktimes_timed = []
+
+    # ---- timed region: EXACTLY K steps; the two legs of a step are independent (the decode reads resident image rows), so the
+    # K image batches go first, back to back, then the K forwards -- no host synchronisation anywhere inside -------------------
+    K = args.steps
+    ev_pi = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    ev_lp = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
     barrier()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        ev[s][0].record()
-        leg_pi()
-        ev[s][1].record()
+    ev_pi[0].record()
+    for s in range(K):
+        leg_pi(s)
+        ev_pi[s + 1].record()
+    for s in range(K):
         leg_lp()
-        ev[s][2].record()
-        ktimes_timed.append(g.timings()[dom_warm])   # HIP events on the stream the kernel ran on (synchronises: part of the step)
+        ev_lp[s].record()
     barrier()
     wall = time.perf_counter() - t0
-    t_pi = sum(ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)) * 1e-3
-    t_lp = sum(ev[s][1].elapsed_time(ev[s][2]) for s in range(args.steps)) * 1e-3
+    t_pi = ev_pi[0].elapsed_time(ev_pi[K]) * 1e-3
+    t_lp = ev_pi[K].elapsed_time(ev_lp[K - 1]) * 1e-3
+    pi_steps = [ev_pi[s].elapsed_time(ev_pi[s + 1]) for s in range(K)]
+    lp_steps = [(ev_pi[K] if s == 0 else ev_lp[s - 1]).elapsed_time(ev_lp[s]) for s in range(K)]
+    ktimes_timed = [] if args.no_kernel_events else g.timing_history(dom_warm, cap=min(K, 64))
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([wall, t_pi, t_lp], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, t_pi, t_lp = [float(v) for v in t.tolist()]
+    g.set_timing(False)
+
+    # ---- the other mode of the same region (same batch every step <-> rotating batches), K steps, reported beside `value` ----
+    def pi_region(rotate):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        ev0.record()
+        for s in range(K):
+            g.pd_pi_batch(rot[s % len(rot)] if rotate else pi_pairs, hop, out=pi_out, status=pi_status)
+        ev1.record()
+        barrier()
+        t = torch.tensor([ev0.elapsed_time(ev1) * 1e-3], dtype=torch.float64, device=dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    t_other = pi_region(not args.rotate_batches)
+    g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)          # the headline batch's header for sizes()/stats() below
+    torch.cuda.synchronize()
+
+    # ---- strong scaling (every N): ONE list -- the non-edges of the graph inside each other's hop-ball, the part of the
+    # reference's negative sweep that has non-zero images (loaddatas.py:44-53, riccidist2dgm.py:362-370) -- cut into N
+    # contiguous shards of equal estimated cost, each rank runs its shard, the image rows are exchanged (one all-gather) ------
+    strong = None
+    if not args.no_sweep:
+        try:
+            ci = engine.ComplementIndex(wl["rowptr"], wl["col"], device=local_rank)
+            near, ranks = engine.near_pairs(ci, hop)
+            near = near[torch.argsort(ranks)].contiguous()                                # list order: the same on every rank
+            near_np = near.cpu().numpy()
+            cost = tdist.pair_cost(tdist.ball_bound(wl["rowptr"], wl["col"], hop), near_np)
+            run = lambda shard: g.pd_pi_batch(shard.contiguous(), hop)
+            gather = tdist.gather_shards if world > 1 else None
+            reps = []
+            for it in range(4):
+                barrier()
+                c0 = time.perf_counter()
+                rows_s, st_s, (slo, shi) = tdist.pd_pi_batch_sharded(run, near, world, rank, cost=cost, gather=gather)
+                barrier()
+                reps.append(time.perf_counter() - c0)
+            tt = torch.tensor([float(np.median(reps[1:]))], dtype=torch.float64, device=dev)
+            if world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sdt = float(tt.item())
+            bounds = tdist.shard_pairs_by_cost(cost, world)
+            strong = {"pairs": int(len(near_np)), "seconds": sdt, "images_per_sec": len(near_np) / sdt,
+                      "shard_pairs": [int(bounds[r + 1] - bounds[r]) for r in range(world)],
+                      "rows_gathered_on_every_rank": bool(world > 1), "nonzero_rows": int((rows_s.abs().sum(1) > 0).sum()),
+                      "note": "strong scaling: fixed list (all non-adjacent pairs with d(u,v) <= hop), cost-balanced contiguous "
+                              "shards (cost = smaller ball-size bound of the endpoints), host wall clock, median of 3, max over ranks"}
+            del rows_s, st_s, near, ranks, ci
+            g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)
+            torch.cuda.synchronize()
+        except Exception as ex:
+            strong = {"error": repr(ex)}
 
     # auxiliary (untimed region, single pass): the negative sweep of loaddatas.py:44-53 is dominated by pairs with
     # d(u,v) > hop; report the throughput on 2^20 uniformly random pairs (PI-C of SURVEY.md 8d) next to the headline
@@ -391,9 +550,9 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps * 1e3
-        Mr, Kf, Nh = x_local.shape[0], x_local.shape[1], w1.shape[1]
+        Mr, Kf, Nh = x_full.shape[0], x_full.shape[1], w1.shape[1]
         xw = torch.empty((Mr, Nh), dtype=torch.float32, device=dev)
-        us_g = _avg_us(lambda: ops.gemm(x_local, w1, out=xw))
+        us_g = _avg_us(lambda: ops.gemm(x_full, w1, out=xw))
         hfull = torch.empty((n, Nh), dtype=torch.float32, device=dev).normal_()
         yfull = torch.empty((n, Nh), dtype=torch.float32, device=dev)
         us_s = _avg_us(lambda: ops.spmm(rowptr_n, col_n, val_n, hfull, bias=b1, relu=True, out=yfull))
@@ -408,6 +567,7 @@ def main():
         del xw, hfull, yfull
         # the stand-alone PI raster (tlc_pi_raster = PersistenceImager.transform) on diagrams shaped like this batch's:
         # one diagram per pair with as many points as the vicinity has edges (Ord0 + ext0 + Ext1 points), values in [0,1]
+        g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)
         n_sz_r, m2_sz_r = g.sizes(E)
         kpts = np.maximum(m2_sz_r // 2, 1).astype(np.int64)
         offs_r = torch.from_numpy(np.concatenate([[0], np.cumsum(kpts)])).to(dev)
@@ -423,55 +583,78 @@ def main():
                                         "(~370 fp64 instructions per point), not HBM"}
         del bd, offs_r
     if rank == 0:
-        stats = g.stats()
-        n_sz, m2_sz = g.sizes(E)
-        tiers = engine.tier_of(n_sz, m2_sz)
-        bytes_pp = engine.algorithmic_bytes(wl["rowptr"], wl["col"], wl["pi_pairs"], hop)
-        kavg = dict(warm_avg)                                   # all kernels: warm-up steps (every kernel carried events there)
+        # per-pair byte model and tier of every pair of the batches the timed region ran
+        used = [rot[j] for j in range(min(K, len(rot)))] if args.rotate_batches else [pi_pairs]
+        weight = [len(range(j, K, len(rot))) for j in range(len(used))] if args.rotate_batches else [K]
         dom = dom_warm
+        dom_bytes = dom_units = all_bytes = 0.0
+        for b_dev, wgt in zip(used, weight):
+            g.pd_pi_batch(b_dev, hop, out=pi_out, status=pi_status)
+            n_sz, m2_sz = g.sizes(E)
+            tiers = engine.tier_of(n_sz, m2_sz)
+            bpp = engine.algorithmic_bytes(wl["rowptr"], wl["col"], b_dev.cpu().numpy(), hop)
+            sel = (tiers == dom) if dom.startswith("pd_tier") else np.ones(E, dtype=bool)
+            dom_bytes += wgt * float(bpp[sel].sum()) / K
+            dom_units += wgt * float(sel.sum()) / K
+            all_bytes += wgt * float(bpp.sum()) / K
+        g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)
+        stats = g.stats()
+        kavg = dict(warm_avg)                                   # all kernels: warm-up steps (every kernel carried events there)
         live = [x for x in ktimes_timed if x >= 0]
         if live:
             kavg[dom] = float(np.mean(live))                    # the dominant kernel: live, inside the timed region
-        if dom.startswith("pd_tier"):
-            dom_bytes = float(bytes_pp[tiers == dom].sum())
-            dom_units = int((tiers == dom).sum())
-        else:
-            dom_bytes, dom_units = float(bytes_pp.sum()), E
         achieved = dom_bytes / (kavg[dom] * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(dom)
+                tj = json.load(open(tf))
+                traffic = tj.get(dom)
+                traffic_source = "NOT measured in this run: profiles/pmc_traffic.json (%s), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE " \
+                                 "passes over this command; bytes per launch" % tj.get("_collected", "round-1 profile")
             except Exception:
                 traffic = None
         out = {
             "metric": "persistence-images/sec + LP-forward edges/sec, PubMed-scale, 1/2/4/8 GPU",
-            "value": world * E * args.steps / t_pi,
+            "value": world * E * K / t_pi,
             "unit": "persistence-images/sec",
-            "lp_forward_edges_per_sec": world * dec_pairs.shape[0] * args.steps / t_lp,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
-            "pi_ms_per_step": t_pi / args.steps * 1e3, "lp_ms_per_step": t_lp / args.steps * 1e3,
+            "lp_forward_edges_per_sec": world * dec_pairs.shape[0] * K / t_lp,
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": wall / K * 1e3,
+            "pi_ms_per_step": t_pi / K * 1e3, "lp_ms_per_step": t_lp / K * 1e3,
+            "pi_ms_per_step_median": float(np.median(pi_steps)), "lp_ms_per_step_median": float(np.median(lp_steps)),
+            "pi_latency_ms": float(np.median(lat_plain)),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "PubMed-shaped synthetic graph (N=19717, M=44324, F=500, seed 1234), hop=2; per GPU: "
-                                   "PI-A = all %d train-positive pairs -> 5x5 persistence images, then TLCGNN forward "
-                                   "(GCN 500->100->16 encode + fused decode of %d pairs, image rows resident)" % (E, dec_pairs.shape[0]),
-                       "pairs_per_gpu": E, "decode_pairs_per_gpu": int(dec_pairs.shape[0]),
-                       "parallelism": "pair shards per GPU (no collective); encoder node-row sharded, 1 all-gather per layer",
+            "config": {"workload": "PubMed-shaped synthetic graph (N=19717, M=44324, F=500, seed 1234), hop=2; per GPU and step: "
+                                   "PI-A = %s -> 5x5 persistence images, and one TLCGNN forward "
+                                   "(GCN 500->100->16 encode + fused decode of %d pairs, image rows resident)"
+                                   % ("a different %d-pair sample of the graph's positive pairs every step (--rotate-batches)" % E
+                                      if args.rotate_batches else "all %d train-positive pairs" % E, dec_pairs.shape[0]),
+                       "timed_region": "K image batches enqueued back to back, then K forwards, no host synchronisation inside "
+                                       "(throughput); pi_latency_ms = one batch with a synchronisation after it",
+                       "pairs_per_gpu": E, "decode_pairs_per_gpu": int(dec_pairs.shape[0]), "rotate_batches": bool(args.rotate_batches),
+                       "parallelism": "every rank its own batch (weak; no collective in the image leg); encoder: " + enc_mode,
                        "vicinity_tiers": {k: int(v) for k, v in stats.items() if k.startswith("tier")},
                        "tie_fallback_sources": int(stats["tie_fallback_sources"])},
             "roofline": {"bound": "hbm", "kernel": dom, "kernel_ms": kavg[dom], "units_per_launch": dom_units,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic},
-            "roofline_chain": {"bound": "hbm", "algorithmic_bytes_per_pi": float(bytes_pp.mean()),
-                               "achieved": float(bytes_pp.sum()) * world * args.steps / t_pi / 1e9, "peak": HBM_PEAK_GBS * world,
-                               "unit": "GB/s", "frac": float(bytes_pp.sum()) * args.steps / t_pi / 1e9 / HBM_PEAK_GBS},
+                         "traffic": traffic, "traffic_source": traffic_source},
+            "roofline_chain": {"bound": "hbm", "algorithmic_bytes_per_pi": all_bytes / E,
+                               "achieved": all_bytes * world * K / t_pi / 1e9, "peak": HBM_PEAK_GBS * world,
+                               "unit": "GB/s", "frac": all_bytes * K / t_pi / 1e9 / HBM_PEAK_GBS},
+            ("same_batch_every_step" if args.rotate_batches else "rotated_batches"): {
+                "value": world * E * K / t_other, "pi_ms_per_step": t_other / K * 1e3,
+                "note": "the same K-step region with %s" % ("the one train-positive batch every step" if args.rotate_batches else
+                                                            "8 different 37 676-pair samples of the positive pairs in turn: the "
+                                                            "previous chunk's sizes never match exactly")},
+            "encoder": {"mode": enc_mode, "lp_leg_ms": encoder_ms,
+                        "note": "LP leg (encode + decode) timed per mode before the timed region, max over ranks; N=1 has no exchange"},
+            "strong_scaling": strong,
             "kernel_ms": kavg,
-            "kernel_ms_note": "'%s' (the roofline kernel): HIP events inside the timed region, mean of %d steps; the others: events "
-                              "during the %d warm-up steps (all eight event pairs inside the timed region cost 48 us per batch)"
-                              % (dom, len(live), max(args.warmup, 1)),
+            "kernel_ms_note": "'%s' (the roofline kernel): HIP events kept by the library in a ring and read after the timed region, "
+                              "mean of %d steps; the others: median of the %d warm-up steps (all eight event pairs inside the timed "
+                              "region cost 48 us per batch)" % (dom, len(live), max(args.warmup, 1)),
             "roofline_lp": lp_roof,
             "sweep": sweep,
             "full_sweep": full_sweep,

@@ -113,6 +113,11 @@ int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream);
  * algorithmic_bytes(): SURVEY.md 8(d) per-pair byte model, evaluated on the HOST CSR (pure accounting). */
 int tlc_pd_pi_batch_set_timing(tlc_graph* g, int enable);
 int tlc_pd_pi_batch_timings(tlc_graph* g, double* h_ms, void* stream);
+/* The same for a caller that enqueues chunk after chunk WITHOUT synchronising (the shape of the reference's sweep over
+ * total_edges, riccidist2dgm.py:362-370): the events of the last 64 chunks are kept; history() synchronises once, afterwards,
+ * and returns timing slot `slot` (index into h_ms above) of the most recent min(cap, 64, chunks so far) chunks, oldest
+ * first, -1 where the kernel did not run; *n_out = entries written. */
+int tlc_pd_pi_batch_timing_history(tlc_graph* g, int slot, double* h_ms, int32_t cap, int32_t* n_out, void* stream);
 int tlc_pd_pi_batch_sizes(tlc_graph* g, int32_t* h_n, int32_t* h_m2, int64_t cap, void* stream);
 int tlc_pd_pi_algorithmic_bytes(int32_t n_nodes, const int32_t* h_rowptr, const int32_t* h_col, const int32_t* h_pairs,
                                 int64_t n_pairs, int hop, int res, double* h_out_bytes);

@@ -10,7 +10,10 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtlc_oracle.so")
+# TLC_ORACLE_ASAN=1: load the AddressSanitizer/UBSan build (make -C oracle asan); the process must have been started with
+# LD_PRELOAD=$(gcc -print-file-name=libasan.so) -- tests/test_oracle_asan.py does that for a child pytest
+ASAN = os.environ.get("TLC_ORACLE_ASAN") == "1"
+LIB_PATH = os.path.join(HERE, "libtlc_oracle_asan.so" if ASAN else "libtlc_oracle.so")
 
 ST_OK, ST_MISSING_NODE, ST_DISCONNECTED, ST_ZERO_RANGE, ST_NO_TREE_EDGE = range(5)
 KEEP_ZERO_PERS, INCLUDE_ROOTS, NORM_EPS, PI_ORD0_EXT1, NO_EXT1, UNREACHABLE_100 = 1, 2, 4, 8, 16, 32
@@ -21,7 +24,7 @@ _lib = None
 def build(force=False):
     src = os.path.join(HERE, "tlc_oracle.c")
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", HERE, "-s", "-B"])
+        subprocess.check_call(["make", "-C", HERE, "-s", "-B"] + (["asan"] if ASAN else []))
     return LIB_PATH
 
 

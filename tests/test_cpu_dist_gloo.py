@@ -31,12 +31,22 @@ def _csr_from_norm(ei, norm, n):
     return rowptr, col, val
 
 
-def _spmm_cpu(rowptr, col, val, x, bias, relu):
+def _spmm_cpu(rowptr, col, val, x, bias, relu, renorm=False, out=None):
     n = rowptr.numel() - 1
     rows = torch.repeat_interleave(torch.arange(n), (rowptr[1:] - rowptr[:-1]).long())
-    out = torch.zeros(n, x.shape[1]).index_add_(0, rows, val[:, None] * x[col.long()])
-    out = out + bias
-    return torch.relu(out) if relu else out
+    res = torch.zeros(n, x.shape[1]).index_add_(0, rows, val[:, None] * x[col.long()])
+    res = res + bias
+    res = torch.relu(res) if relu else res
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def _gemm_cpu(a, b, out=None):
+    if out is not None:
+        return torch.matmul(a, b, out=out)
+    return a @ b
 
 
 def _worker(rank, world, port, q):
@@ -54,9 +64,17 @@ def _worker(rank, world, port, q):
     w2, b2 = torch.randn(20, 16) * 0.2, torch.randn(16) * 0.1
     rei, norm = ref.gcn_norm(ei, n)
     rowptr, col, val = _csr_from_norm(rei, norm, n)
-    enc = tdist.ShardedGCNEncoder(rowptr, col, val, n, world, rank, gemm=lambda a, b: a @ b, spmm=_spmm_cpu)
-    emb = enc.encode(x[enc.lo:enc.hi].contiguous(), w1, b1, w2, b2)
     full = ref.tlcgnn_encode(x, ei, w1, b1, w2, b2)
+    # replicated encoder: the whole forward on every rank, no collective
+    rep = tdist.ShardedGCNEncoder(rowptr, col, val, n, world, rank, gemm=_gemm_cpu, spmm=_spmm_cpu, mode="replicated")
+    emb_rep = rep.encode(x, w1, b1, w2, b2)
+    assert (emb_rep - full).abs().max() < 1e-5 and rep.row_map(torch.arange(n)).equal(torch.arange(n))
+    # node-row sharded encoder: one all-gather per layer into the padded block layout, read in place through row_map
+    enc = tdist.ShardedGCNEncoder(rowptr, col, val, n, world, rank, gemm=_gemm_cpu, spmm=_spmm_cpu)
+    for _ in range(2):                                  # twice: the persistent exchange buffers are reused
+        emb_padded = enc.encode(x[enc.lo:enc.hi].contiguous(), w1, b1, w2, b2)
+    assert emb_padded.shape[0] == world * enc.rows.blk
+    emb = emb_padded[enc.row_map(torch.arange(n))]
     # pair-sharded decode: every rank owns a contiguous shard, no collective
     pairs = torch.randint(0, n, (501, 2))
     pi = torch.rand(501, 25, dtype=torch.float64)
@@ -64,6 +82,25 @@ def _worker(rank, world, port, q):
     lo, hi = tdist.shard_bounds(501, world, rank)
     prob = ref.tlcgnn_decode(emb.clone(), pairs[lo:hi], pi[lo:hi], l1w, l1b, l2w, l2b)
     prob_full = ref.tlcgnn_decode(full.clone(), pairs, pi, l1w, l1b, l2w, l2b)
+    # the same decode reading the padded buffer through remapped pair ids
+    prob_p = ref.tlcgnn_decode(emb_padded.clone(), enc.row_map(pairs[lo:hi]), pi[lo:hi], l1w, l1b, l2w, l2b)
+    assert torch.equal(prob_p, prob)
+    # PD/PI pair shards: cost-balanced contiguous cuts, rows exchanged with ONE all-gather, identical to the single-rank rows
+    from oracle import oracle
+    from tlc_gnn_amd import synth as _s
+    kap = np.random.RandomState(4).uniform(-0.5, 0.9, size=len(edges))
+    rp, cl, ww = _s.edges_to_csr(n, edges, kap)
+    pr = np.concatenate([edges[:150], np.random.RandomState(5).randint(0, n, size=(60, 2))]).astype(np.int32)
+    single_rows, single_st, _ = oracle.pd_pi_batch(rp, cl, ww, pr, 2, n_threads=1)
+
+    def run(shard):                                     # the checker stands in for the HIP path (no GPU in this test)
+        r_, s_, _ = oracle.pd_pi_batch(rp, cl, ww, np.ascontiguousarray(shard), 2, n_threads=1)
+        return torch.from_numpy(r_), torch.from_numpy(s_)
+
+    cost = tdist.pair_cost(tdist.ball_bound(rp, cl, 2), pr)
+    rows, st, (slo, shi) = tdist.pd_pi_batch_sharded(run, pr, world, rank, cost=cost, gather=tdist.gather_shards)
+    assert 0 < shi - slo < len(pr)
+    assert np.array_equal(rows.numpy(), single_rows) and np.array_equal(st.numpy(), single_st)      # bit for bit
     q.put((rank, float((emb - full).abs().max()), float((prob - prob_full[lo:hi]).abs().max()), tuple(emb.shape)))
     dist.barrier()
     dist.destroy_process_group()
@@ -87,7 +124,11 @@ def test_sharded_forward_world2_gloo():
         assert e_emb < 1e-5 and e_prob < 1e-6, (rank, e_emb, e_prob)
 
 
-def test_all_gather_rows_single_rank_is_identity():
+def test_single_rank_layout_is_the_identity():
     from tlc_gnn_amd import dist as tdist
     x = torch.arange(12.0).view(4, 3)
-    assert tdist.all_gather_rows(x, 4, 1, 0) is x
+    assert tdist.gather_shards(x, [0, 4]) is x
+    rows = tdist.PaddedRows(4, 1, 0)
+    assert rows.remap(torch.arange(4)).equal(torch.arange(4)) and rows.blk == 4
+    got = tdist.pd_pi_batch_sharded(lambda p: (p * 2, p[:, 0]), x, 1, 0, cost=np.ones(4))
+    assert got[2] == (0, 4) and torch.equal(got[0], x * 2)

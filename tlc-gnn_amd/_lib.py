@@ -23,7 +23,7 @@ KEEP_ZERO_PERS, INCLUDE_ROOTS, NORM_EPS, PI_ORD0_EXT1, NO_EXT1, UNREACHABLE_100 
 SYMBOLS = [
     "tlc_version", "tlc_last_error", "tlc_device_count", "tlc_graph_create", "tlc_graph_destroy",
     "tlc_pd_pi_batch", "tlc_vicinity_filtration", "tlc_pd_pi_batch_stats", "tlc_pd_pi_batch_set_timing",
-    "tlc_pd_pi_batch_timings", "tlc_pd_pi_batch_sizes", "tlc_pd_pi_algorithmic_bytes", "tlc_pd_from_filtration",
+    "tlc_pd_pi_batch_timings", "tlc_pd_pi_batch_timing_history", "tlc_pd_pi_batch_sizes", "tlc_pd_pi_algorithmic_bytes", "tlc_pd_from_filtration",
     "tlc_pi_raster", "tlc_gcn_norm_csr", "tlc_gemm_f32", "tlc_spmm_csr_f32", "tlc_renorm_rows_f32",
     "tlc_lp_decode_fused", "tlc_gat_layer_fwd", "tlc_scatter_f32", "tlc_edge_head_fwd",
     "tlc_complement_rows", "tlc_complement_pairs", "tlc_select_rows", "tlc_ollivier_ricci_sinkhorn",
@@ -35,8 +35,12 @@ class TlcError(RuntimeError):
     pass
 
 
-def build(verbose=False):
-    """Compile the HIP sources for gfx950 into tlc-gnn_amd/libtlcgnn_hip.so (hipcc cross-compiles without a GPU)."""
+def build(verbose=False, force=False):
+    """Compile the HIP sources for gfx950 into tlc-gnn_amd/libtlcgnn_hip.so (hipcc cross-compiles without a GPU).
+    force=True: `make clean` first, so every object is rebuilt from source (the "does it build" check must not be
+    satisfied by a shipped .so)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
@@ -69,6 +73,7 @@ def lib():
         L.tlc_pd_pi_batch_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.tlc_pd_pi_batch_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.tlc_pd_pi_batch_timings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tlc_pd_pi_batch_timing_history.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.tlc_pd_pi_batch_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.tlc_pd_pi_algorithmic_bytes.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         L.tlc_pd_from_filtration.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 7

@@ -39,6 +39,7 @@ extern "C" int tlc_device_count(void) {
 #define TLC_EARLY_SLOTS 256
 #define TLC_EARLY_WG 256          /* workgroups (and scratch slots) of the early COUNT */
 #define TLC_EARLY_MIN_PAIRS 4096  /* smaller batches gain nothing from a second COUNT launch */
+#define TLC_TIMING_RING 64        /* chunks whose kernel events are kept */
 
 struct HostSync {
     long long total_entries;
@@ -107,8 +108,14 @@ struct tlc_graph {
     unsigned long long* d_phase;   // diagnostics: [TLC_N_TIERS][32] cycle counters, null unless enabled
     // optional per-kernel timing (tlc_pd_pi_batch_set_timing): events bracket each launch on its own stream
     int timing;
-    hipEvent_t ev_t[16];           // 0/1 count, 2/3 scan, 4/5 fill, 6+2t / 7+2t tier t
-    int ev_used[8];
+    // A ring of event sets, one per chunk: a caller that enqueues batch after batch without synchronising reads the
+    // durations of the last TLC_TIMING_RING chunks afterwards (tlc_pd_pi_batch_timing_history).  Created on first use.
+    hipEvent_t ev_ring[TLC_TIMING_RING][16];   // per set: 0/1 count, 2/3 scan, 4/5 fill, 6+2t / 7+2t tier t
+    unsigned char ev_ring_used[TLC_TIMING_RING][8];
+    int ev_ring_ready;
+    unsigned long long ring_pos;   // chunks timed so far; the current set is (ring_pos - 1) % TLC_TIMING_RING
+    hipEvent_t* ev_t;              // the current set
+    unsigned char* ev_used;
     int last_n_pairs;
     int prev_tc[TLC_N_TIERS];      // tier counts of the previous chunk (sizes of the speculative launches)
 };
@@ -276,7 +283,6 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     CK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&g->ev_early, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&g->ev_scan, hipEventDisableTiming));
-    for (int k = 0; k < 16; ++k) CK(hipEventCreate(&g->ev_t[k]));
 #undef CK
     // concurrent vicinity workgroups worth launching: LDS-bound per CU, 256 CUs
     hipDeviceProp_t prop;
@@ -307,7 +313,9 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
         if (g->ev_join[k]) hipEventDestroy(g->ev_join[k]);
     }
     if (g->ev_fork) hipEventDestroy(g->ev_fork);
-    for (int k = 0; k < 16; ++k) if (g->ev_t[k]) hipEventDestroy(g->ev_t[k]);
+    if (g->ev_ring_ready)
+        for (int r = 0; r < TLC_TIMING_RING; ++r)
+            for (int k = 0; k < 16; ++k) if (g->ev_ring[r][k]) hipEventDestroy(g->ev_ring[r][k]);
     delete g;
     return TLC_OK;
 }
@@ -362,7 +370,17 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         g->lds_attr_set = 1;
     }
     const int vgrid = std::min(n_pairs, g->vic_slots);
-    memset(g->ev_used, 0, sizeof(g->ev_used));
+    if (g->timing) {
+        if (!g->ev_ring_ready) {
+            for (int r = 0; r < TLC_TIMING_RING; ++r)
+                for (int k = 0; k < 16; ++k) TLC_HIP_CHECK(hipEventCreate(&g->ev_ring[r][k]));
+            g->ev_ring_ready = 1;
+        }
+        const int set = (int)(g->ring_pos++ % TLC_TIMING_RING);
+        g->ev_t = g->ev_ring[set];
+        g->ev_used = g->ev_ring_used[set];
+        memset(g->ev_used, 0, 8);
+    }
     g->last_n_pairs = n_pairs;
 #define T0(k, st) do { if ((g->timing >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k)], st)); } } while (0)
 #define T1(k, st) do { if ((g->timing >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k) + 1], st)); g->ev_used[k] = 1; } } while (0)
@@ -786,13 +804,37 @@ extern "C" int tlc_pd_pi_batch_timings(tlc_graph* g, double* h_ms, void* stream)
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     for (int k = 0; k < 8; ++k) {
         h_ms[k] = -1.0;
-        if (g->timing && g->ev_used[k]) {
+        if (g->timing && g->ev_used && g->ev_used[k]) {
             TLC_HIP_CHECK(hipEventSynchronize(g->ev_t[2 * k + 1]));
             float ms = 0.f;
             TLC_HIP_CHECK(hipEventElapsedTime(&ms, g->ev_t[2 * k], g->ev_t[2 * k + 1]));
             h_ms[k] = (double)ms;
         }
     }
+    return TLC_OK;
+}
+
+// Durations (ms) of timing slot `slot` (the order of tlc_pd_pi_batch_timings) over the most recent chunks, oldest first:
+// at most `cap` and at most TLC_TIMING_RING (64) of them; -1 where the kernel was not launched or not selected.
+// *n_out = how many were written.  Synchronises the stream; nothing was synchronised while the chunks ran.
+extern "C" int tlc_pd_pi_batch_timing_history(tlc_graph* g, int slot, double* h_ms, int32_t cap, int32_t* n_out, void* stream) {
+    TLC_REQUIRE(g && h_ms && n_out, "null argument");
+    TLC_REQUIRE(slot >= 0 && slot < 8 && cap >= 0, "slot must be in 0..7");
+    TLC_ON_DEVICE(g->device);
+    TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    const unsigned long long have = std::min<unsigned long long>(g->ring_pos, TLC_TIMING_RING);
+    const int n = (int)std::min<unsigned long long>(have, (unsigned long long)cap);
+    for (int i = 0; i < n; ++i) {
+        const int set = (int)((g->ring_pos - n + i) % TLC_TIMING_RING);
+        h_ms[i] = -1.0;
+        if (g->ev_ring_ready && g->ev_ring_used[set][slot]) {
+            TLC_HIP_CHECK(hipEventSynchronize(g->ev_ring[set][2 * slot + 1]));
+            float ms = 0.f;
+            TLC_HIP_CHECK(hipEventElapsedTime(&ms, g->ev_ring[set][2 * slot], g->ev_ring[set][2 * slot + 1]));
+            h_ms[i] = (double)ms;
+        }
+    }
+    *n_out = n;
     return TLC_OK;
 }
 

@@ -40,56 +40,164 @@ def shard_pairs_by_cost(cost, world):
     return bounds
 
 
-def all_gather_rows(local_rows, n_total, world, rank, group=None):
-    """All-gather of row blocks laid out by shard_bounds: local [hi-lo, k] -> full [n_total, k] on every rank.
+def ball_bound(rowptr, col, hop):
+    """Host twin of tlc_ball_bound_kernel: per-node upper bound of |ball_hop(x)| (ub_1 = 1 + deg, ub_h(x) = 1 + sum_y ub_{h-1}(y)
+    over the neighbours y).  A vicinity is a subset of both endpoints' balls, so min(ub[u], ub[v]) bounds its size: the cost
+    estimate the pair list is cut by."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    deg = np.diff(rowptr)
+    ub = 1.0 + deg
+    rows = np.repeat(np.arange(len(deg)), deg)
+    for _ in range(1, hop):
+        ub = 1.0 + np.bincount(rows, weights=ub[col], minlength=len(deg))
+    return ub
 
-    Blocks are padded to the largest block so that a single all_gather_into_tensor (one RCCL collective) moves them."""
+
+def pair_cost(ub, pairs):
+    """Work estimate of one pair: the smaller of the two ball bounds (the vicinity's size bound) plus a constant for the
+    extraction itself; far pairs (most of a negative sweep) cost the constant."""
+    pairs = np.asarray(pairs).reshape(-1, 2)
+    return 8.0 + np.minimum(ub[pairs[:, 0]], ub[pairs[:, 1]])
+
+
+def pd_pi_batch_sharded(run, pairs, world, rank, cost=None, gather=None):
+    """The pair list of get_pimg_for_all_edges (sg2dgm/riccidist2dgm.py:362-370; the reference maps its ThreadPool over exactly
+    this list) cut into `world` contiguous shards of equal summed cost; rank `rank` runs its own shard, no data-path collective.
+
+    run(pairs_shard) -> (rows [k, 25], status [k]) is the per-GPU path (DeviceGraph.pd_pi_batch in the product).
+    Returns (rows, status, (lo, hi)); with gather=callable the shards of all ranks are exchanged by it (see gather_shards)
+    and the full arrays come back in list order."""
+    n = len(pairs)
+    bounds = shard_pairs_by_cost(cost, world) if cost is not None else [shard_bounds(n, world, r)[0] for r in range(world)] + [n]
+    lo, hi = bounds[rank], bounds[rank + 1]
+    rows, status = run(pairs[lo:hi])
+    if gather is None:
+        return rows, status, (lo, hi)
+    return gather(rows, bounds), gather(status, bounds), (lo, hi)
+
+
+def gather_shards(local, bounds, group=None):
+    """Ragged contiguous shards -> the whole array on every rank: one all_gather_into_tensor over blocks padded to the largest
+    shard (RCCL over xGMI with backend nccl), then the blocks are laid end to end."""
     import torch
     import torch.distributed as dist
+    world = len(bounds) - 1
     if world == 1:
-        return local_rows
-    k = local_rows.shape[1]
-    blk = (n_total + world - 1) // world
-    send = torch.zeros((blk, k), dtype=local_rows.dtype, device=local_rows.device)
-    send[:local_rows.shape[0]] = local_rows
-    recv = torch.empty((world * blk, k), dtype=local_rows.dtype, device=local_rows.device)
+        return local
+    sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
+    blk = max(max(sizes), 1)
+    tail = tuple(local.shape[1:])
+    send = torch.zeros((blk,) + tail, dtype=local.dtype, device=local.device)
+    send[:local.shape[0]] = local
+    recv = torch.empty((world * blk,) + tail, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(recv, send, group=group)
-    out = torch.empty((n_total, k), dtype=local_rows.dtype, device=local_rows.device)
-    for r in range(world):
-        lo, hi = shard_bounds(n_total, world, r)
-        out[lo:hi] = recv[r * blk:r * blk + (hi - lo)]
-    return out
+    return torch.cat([recv[r * blk:r * blk + sizes[r]] for r in range(world)])
+
+
+class PaddedRows:
+    """Row blocks of shard_bounds laid out for ONE all_gather_into_tensor and read in place afterwards.
+
+    Rank r's rows sit at [r*blk, r*blk + count_r) of a [world*blk, k] buffer (blk = the largest block).  Nothing is copied
+    around the collective: the producer writes its rows straight into `send(k)` (a view of persistent storage whose pad rows
+    stay zero), the consumers index the gathered buffer through `remap(ids)` (global row id -> padded row id, computed once
+    for the CSR columns and the decode pairs)."""
+
+    def __init__(self, n_total, world, rank):
+        self.n, self.world, self.rank = n_total, world, rank
+        self.blk = (n_total + world - 1) // world if world > 1 else n_total
+        self.lo, self.hi = shard_bounds(n_total, world, rank)
+        self._send, self._recv = {}, {}
+
+    def remap(self, ids):
+        """global row ids (tensor or ndarray of ints) -> row ids of the padded buffer."""
+        if self.world == 1:
+            return ids
+        base, rem = divmod(self.n, self.world)
+        # rows [0, rem*(base+1)) belong to the first `rem` ranks (base+1 rows each), the rest to ranks of `base` rows
+        big = rem * (base + 1)
+        if type(ids).__module__.startswith("torch"):
+            import torch
+            owner = torch.where(ids < big, ids // (base + 1), rem + (ids - big) // max(base, 1))
+            start = torch.where(owner < rem, owner * (base + 1), big + (owner - rem) * base)
+        else:
+            ids = np.asarray(ids)
+            owner = np.where(ids < big, ids // (base + 1), rem + (ids - big) // max(base, 1))
+            start = np.where(owner < rem, owner * (base + 1), big + (owner - rem) * base)
+        return owner * self.blk + (ids - start)
+
+    def send(self, key, k, like):
+        """[hi-lo, k] view to write the local rows into (the pad rows of the block were zeroed once).  `key` names the buffer
+        pair: one per exchange step of a forward, so that a block is never rewritten while a later kernel still reads it."""
+        import torch
+        if key not in self._send:
+            self._send[key] = torch.zeros((self.blk, k), dtype=like.dtype, device=like.device)
+            self._recv[key] = torch.empty((self.world * self.blk, k), dtype=like.dtype, device=like.device)
+        return self._send[key][:self.hi - self.lo]
+
+    def gather(self, key, group=None):
+        """all-gather of the block last written through send(key, ...) -> [world*blk, k] padded buffer (persistent)."""
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(self._recv[key], self._send[key], group=group)
+        return self._recv[key]
 
 
 class ShardedGCNEncoder:
-    """Net.encode (baselines/TLCGNN.py:19-26, eval mode) with node rows sharded over ranks.
+    """Net.encode (baselines/TLCGNN.py:19-26, eval mode) over `world` ranks.
 
-    gemm(x_rows, W) -> rows @ W;  spmm(rowptr_local, col, val, X_full, bias, relu) -> aggregated local rows.
+    mode "allgather": node rows sharded; per layer every rank projects its rows, ONE all-gather of the projected rows, then
+      aggregates its rows; a last all-gather hands every rank the whole embedding for its pair shard.  The gathered buffers
+      keep the padded block layout (PaddedRows): the CSR columns are remapped once, `row_map` remaps the decode pairs.
+    mode "replicated": every rank runs the whole (tiny) encoder, no collective at all (the PubMed layers move
+      ~1 MB per link, i.e. the all-gathers are latency, not bandwidth).
+    gemm(x_rows, W, out=None) -> rows @ W;  spmm(rowptr, col, val, X, bias, relu[, renorm][, out=]) -> aggregated rows.
     rowptr/col/val: the gcn-normalised CSR by target of the WHOLE graph (replicated); each rank slices its rows.
     """
 
-    def __init__(self, rowptr, col, val, n_nodes, world, rank, gemm, spmm, group=None):
+    def __init__(self, rowptr, col, val, n_nodes, world, rank, gemm, spmm, group=None, mode="allgather"):
+        assert mode in ("allgather", "replicated")
         self.n, self.world, self.rank, self.group = n_nodes, world, rank, group
         self.gemm, self.spmm = gemm, spmm
-        self.lo, self.hi = shard_bounds(n_nodes, world, rank)
-        lo, hi = self.lo, self.hi
+        self.mode = mode if world > 1 else "replicated"
+        if self.mode == "replicated":
+            self.lo, self.hi = 0, n_nodes
+            self.rowptr, self.col, self.val = rowptr, col, val
+            self.rows = None
+            return
+        self.rows = PaddedRows(n_nodes, world, rank)
+        self.lo, self.hi = lo, hi = self.rows.lo, self.rows.hi
         rp = rowptr[lo:hi + 1]
         base = int(rp[0])
         self.rowptr = (rp - base).contiguous()
         end = int(rp[-1])
-        self.col = col[base:end].contiguous()
+        self.col = self.rows.remap(col[base:end].long()).to(col.dtype).contiguous()      # columns index the padded buffers
         self.val = val[base:end].contiguous()
 
-    def layer(self, x_local, weight, bias, relu, renorm=False):
-        xw_local = self.gemm(x_local, weight)                                           # rows of X @ W
-        xw = all_gather_rows(xw_local, self.n, self.world, self.rank, self.group)       # exchange step
-        if renorm:                                                                      # aggregate own rows (+ renorm_)
-            return self.spmm(self.rowptr, self.col, self.val, xw, bias, relu, True)
-        return self.spmm(self.rowptr, self.col, self.val, xw, bias, relu)
+    def row_map(self, ids):
+        """node ids -> rows of the tensor encode() returns (identity unless the padded all-gather layout is in use)."""
+        return ids if self.rows is None else self.rows.remap(ids)
+
+    def _aggregate(self, xw, bias, relu, renorm, out=None):
+        kw = {} if out is None else {"out": out}
+        if renorm:
+            return self.spmm(self.rowptr, self.col, self.val, xw, bias, relu, True, **kw)
+        return self.spmm(self.rowptr, self.col, self.val, xw, bias, relu, **kw)
+
+    def layer(self, x_local, weight, bias, relu, renorm=False, key=0, out=None):
+        if self.rows is None:
+            return self._aggregate(self.gemm(x_local, weight), bias, relu, renorm)
+        k = weight.shape[1]
+        self.gemm(x_local, weight, out=self.rows.send(("xw", key), k, x_local))         # rows of X @ W, written in place
+        xw = self.rows.gather(("xw", key), self.group)                                  # exchange step
+        return self._aggregate(xw, bias, relu, renorm, out=out)
 
     def encode(self, x_local, w1, b1, w2, b2, renorm=False):
         """renorm=True: the emb.renorm_(2, 0, 1) that Net.decode applies (TLCGNN.py:48) is fused into the last aggregation
-        (a row's norm does not depend on the other ranks' rows, so it commutes with the final all-gather)."""
-        h = self.layer(x_local, w1, b1, True)
-        h = self.layer(h, w2, b2, True, renorm)
-        return all_gather_rows(h, self.n, self.world, self.rank, self.group)            # every rank decodes its pair shard
+        (a row's norm does not depend on the other ranks' rows, so it commutes with the final all-gather).
+        Returns the embedding of ALL nodes; index it through row_map()."""
+        h = self.layer(x_local, w1, b1, True, key=1)
+        if self.rows is None:
+            return self.layer(h, w2, b2, True, renorm)
+        # the last aggregation writes straight into the send block of the final exchange
+        self.layer(h, w2, b2, True, renorm, key=2, out=self.rows.send("emb", w2.shape[1], x_local))
+        return self.rows.gather("emb", self.group)                                      # every rank decodes its pair shard

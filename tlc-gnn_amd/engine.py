@@ -86,6 +86,15 @@ class DeviceGraph:
         _lib.check(_lib.lib().tlc_pd_pi_batch_timings(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr(self.device)), "timings")
         return dict(zip(self.KERNELS, list(out)[:8]))
 
+    def timing_history(self, kernel, cap=64):
+        """ms of `kernel` (a name of KERNELS) over the most recent chunks, oldest first -- read once after a run of batches
+        that were enqueued without synchronising (the library keeps the events of the last 64 chunks)."""
+        out = (C.c_double * cap)()
+        n = C.c_int32(0)
+        _lib.check(_lib.lib().tlc_pd_pi_batch_timing_history(self._h, C.c_int(self.KERNELS.index(kernel)), C.cast(out, C.c_void_p),
+                                                             C.c_int32(cap), C.byref(n), _lib.stream_ptr(self.device)), "timing_history")
+        return list(out)[:n.value]
+
     def sizes(self, n_pairs):
         n = np.zeros(n_pairs, dtype=np.int32)
         m2 = np.zeros(n_pairs, dtype=np.int32)
