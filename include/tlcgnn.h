@@ -56,6 +56,19 @@ extern "C" {
 #define TLC_NO_EXT1          0x10u /* extended_flag=False: riccidist2dgm.py:323-326                  */
 #define TLC_UNREACHABLE_100  0x20u /* no connectivity assert; an unreachable root costs the sentinel 100:
                                       Knowledge_Distillation/data_utils_LP.py:41-49 (filtration only)  */
+/* which of the three node values of filtration.build_fv (riccidist2dgm.py:47-49) is the filtration: 'sum' = d1 + d2 (the
+ * pipeline's choice, loaddatas.py:101; flag value 0), 'min', 'max' (get_pimg_for_all_edges' own default is 'min', :362) --
+ * 'min' and 'max' are both divided by max_S max(d1, d2), 'sum' by max_S (d1 + d2) (:51-56) -- or the distance to the FIRST
+ * root alone, the single-root filtration of the node-centred PDGNN vicinities (Knowledge_Distillation/data_utils_NC.py:27-50;
+ * hand the node in as the pair (u, u): ball(u) & ball(u) is its ball) */
+#define TLC_DESC_MIN         0x40u
+#define TLC_DESC_MAX         0x80u
+#define TLC_DESC_ROOT1       0xC0u
+#define TLC_DESC_MASK        0xC0u
+/* norm=False of build_fv (:50): raw distances, no division, no ZeroDivisionError.  tlc_vicinity_filtration only: the image
+ * stage of tlc_pd_pi_batch assumes values in [0, 1] (TLC_ERR_UNSUPPORTED there); unnormalised images are
+ * tlc_vicinity_filtration -> tlc_pd_from_filtration -> tlc_pi_raster (what the sg2dgm_accelerate drop-in does) */
+#define TLC_NO_NORM          0x100u
 
 typedef struct tlc_graph tlc_graph;   /* opaque: device CSR + scratch, bound to one device */
 

@@ -19,6 +19,10 @@ Fixtures:
   G4b kd_lp_filtration.npz  PDGNN LP vicinity: ids, f, induced edges  (Knowledge_Distillation/data_utils_LP.py:105-200)
   G6 kd_gc.npz           PDGNN ground-truth tuples, degree filtration (Knowledge_Distillation/data_utils_GC.py:98-166)
   G7 adj_split.npz       get_adj_split outputs, seed 1234         (loaddatas.py:38-54)
+  G8 variants.npz        descriptor 'min' / 'max' and norm=False of sg2dgm_accelerate: f[n] + image rows + exception class
+                         (sg2dgm/riccidist2dgm.py:20-61,310-329)
+  G4c kd_nc.npz          PDGNN node-centred vicinity: ball(u), single root, f = d(x,u)/(max + 1e-10); Ord0 / Ext1 / images
+                         (Knowledge_Distillation/data_utils_NC.py:27-50,95-187)
 """
 import argparse
 import importlib
@@ -94,6 +98,11 @@ def import_reference():
     except Exception as e:  # pragma: no cover
         print("WARN: data_utils_LP not importable:", repr(e))
         mods["kd_lp"] = None
+    try:
+        mods["kd_nc"] = importlib.import_module("Knowledge_Distillation.data_utils_NC")
+    except Exception as e:  # pragma: no cover
+        print("WARN: data_utils_NC not importable:", repr(e))
+        mods["kd_nc"] = None
     try:
         mods["lds"] = importlib.import_module("loaddatas")
     except Exception as e:  # pragma: no cover
@@ -489,15 +498,113 @@ def make_g7(mods):
     print("G7 sizes:", [len(p) for p in parts])
 
 
+# ----------------------------------------------------------------------------------------------- G8 / G4c
+def make_g8(mods):
+    """descriptor 'min' / 'max' (and 'sum') with norm=True, and norm=False, of sg2dgm_accelerate on the G5 graph: the node
+    values build_fv leaves on the subgraph (riccidist2dgm.py:47-56), the image row and the exception class per pair."""
+    import networkx as nx
+    r2d = mods["r2d"]
+    d = np.load(os.path.join(HERE, "e2e.npz"))
+    n_nodes, edges, kappa, pairs = int(d["n_nodes"]), d["edges"], d["kappa"], d["pairs"]
+    pi = build_ref_graph2pi(mods, n_nodes, edges, kappa)
+    inv = {new: old for old, new in pi.dict_node.items()}
+    out = {"pairs": pairs}
+    for hop in (1, 2):
+        for desc in ("min", "max", "sum"):
+            for norm in (True, False):
+                if desc == "sum" and norm:
+                    continue                                     # that is G5
+                rows, cls, ids_l, f_l, sel = [], [], [], [], []
+                for i, (u, v) in enumerate(pairs.tolist()):
+                    try:
+                        uu, vv = pi.dict_node[u], pi.dict_node[v]
+                        img = pi.sg2dgm_accelerate(uu, vv, hop, norm=norm, extended_flag=True, resolution=5, descriptor=desc)
+                        rows.append(img.reshape(-1))
+                        cls.append(0)
+                    except BaseException as e:  # noqa
+                        rows.append(np.zeros(25))
+                        cls.append(EXC_CLASS.get(type(e).__name__, 9))
+                    if cls[-1] in (0, 4) and i % 4 == 0:
+                        nodes_u = [uu] + [x for _, x in nx.bfs_edges(pi.graph, uu, depth_limit=hop)]
+                        nodes_v = [vv] + [x for _, x in nx.bfs_edges(pi.graph, vv, depth_limit=hop)]
+                        sub = pi.graph.subgraph(list(set(nodes_u) & set(nodes_v))).copy()
+                        g = r2d.filtration(sub, uu, vv, hop, ricci_curv=pi.ricci_curv).build_fv(weight_graph=True, norm=norm)
+                        ids = np.array(sorted(inv[x] for x in g.nodes()), dtype=np.int64)
+                        back = {inv[x]: x for x in g.nodes()}
+                        ids_l.append(ids)
+                        f_l.append(np.array([g.nodes[back[k]][desc] for k in ids.tolist()], dtype=np.float64))
+                        sel.append(i)
+                tag = "%s_%s_hop%d" % (desc, "norm" if norm else "raw", hop)
+                out["pi_" + tag] = np.stack(rows)
+                out["cls_" + tag] = np.array(cls, dtype=np.int64)
+                out["fsel_" + tag] = np.array(sel, dtype=np.int64)
+                out["ids_" + tag], out["offs_" + tag] = ragged(ids_l, 0, np.int64)
+                out["f_" + tag], _ = ragged(f_l, 0, np.float64)
+                print("G8", tag, "classes:", np.bincount(cls, minlength=5), "f cases:", len(sel))
+        # the shipped entry point with its own default descriptor ('min', :362) agrees with the mirror
+        pi.get_pimg_for_all_edges(pairs.tolist(), cores=1, hop=hop, norm=True, extended_flag=True, resolution=5)
+        assert np.array_equal(pi.pi_sg, out["pi_min_norm_hop%d" % hop])
+    np.savez_compressed(os.path.join(HERE, "variants.npz"), **out)
+
+
+def make_g4c(mods):
+    """PDGNN node-centred vicinity (data_utils_NC.py:95-187, filt='ricci'): ball_hop(u), ONE root, unreachable -> 100,
+    f / (max + 1e-10) (:27-50); mode='filtration' values and induced edges, mode='PI' diagrams and images."""
+    import networkx as nx
+    kd = mods["kd_nc"]
+    if kd is None:
+        print("G4c skipped")
+        return
+    d = np.load(os.path.join(HERE, "e2e.npz"))
+    edges, kappa = d["edges"], d["kappa"]
+    g = nx.Graph()
+    g.add_edges_from([(int(a), int(b)) for a, b in edges])
+    ricci = sorted([[int(a), int(b), float(k)] for (a, b), k in zip(edges.tolist(), kappa.tolist())] +
+                   [[int(b), int(a), float(k)] for (a, b), k in zip(edges.tolist(), kappa.tolist())])
+    rs = np.random.RandomState(77)
+    roots = sorted(set(rs.choice(sorted(g.nodes()), size=70, replace=False).tolist()) | {int(d["n_nodes"]) - 6, int(d["n_nodes"]) - 5})
+    ids_l, f_l, e_l, o0_l, e1_l, pis, pi0s, pi1s, rt, hops = [], [], [], [], [], [], [], [], [], []
+    for hop in (1, 2):
+        for u in roots:
+            fv, ei = kd.compute_persistence_image(g, u, filt="ricci", hop=hop, ricci_curv=ricci, mode="filtration")
+            if fv is None:
+                continue
+            res = kd.compute_persistence_image(g, u, filt="ricci", hop=hop, ricci_curv=ricci, mode="PI")
+            nodes = [u] + [x for _, x in nx.bfs_edges(g, u, depth_limit=hop)]                     # :97-99
+            sub = nx.convert_node_labels_to_integers(g.subgraph(nodes), label_attribute="old_label")
+            old = np.array([sub._node[k]["old_label"] for k in range(len(sub))], dtype=np.int64)
+            order = np.argsort(old)
+            ids_l.append(old[order])
+            f_l.append(np.asarray(fv, dtype=np.float64)[order])
+            ee = np.sort(old[np.asarray(ei).T.reshape(-1, 2)], axis=1)
+            e_l.append(ee[np.lexsort((ee[:, 1], ee[:, 0]))])
+            o0_l.append(np.asarray(res[0], dtype=np.float64).reshape(-1, 2))
+            e1_l.append(np.asarray(res[1], dtype=np.float64).reshape(-1, 2))
+            pis.append(np.asarray(res[2], dtype=np.float64).reshape(-1))
+            pi0s.append(np.asarray(res[5], dtype=np.float64).reshape(-1))
+            pi1s.append(np.asarray(res[6], dtype=np.float64).reshape(-1))
+            rt.append(u)
+            hops.append(hop)
+    ids_flat, offs = ragged(ids_l, 0, np.int64)
+    f_flat, _ = ragged(f_l, 0, np.float64)
+    e_flat, e_offs = ragged(e_l, 2, np.int64)
+    o0, o0_offs = ragged(o0_l, 2)
+    e1, e1_offs = ragged(e1_l, 2)
+    np.savez_compressed(os.path.join(HERE, "kd_nc.npz"), roots=np.array(rt, dtype=np.int64), hop=np.array(hops), ids=ids_flat,
+                        f=f_flat, offs=offs, edges=e_flat, e_offs=e_offs, ord0=o0, ord0_offs=o0_offs, ext1=e1, ext1_offs=e1_offs,
+                        pi=np.stack(pis), pi0=np.stack(pi0s), pi1=np.stack(pi1s))
+    print("G4c cases:", len(rt), "largest ball:", max(len(x) for x in ids_l))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true", help="also time the reference on the PubMed-shaped graph")
-    ap.add_argument("--only", default="", help="regenerate a single fixture (g4b)")
+    ap.add_argument("--only", default="", help="regenerate a single fixture (g4b | g8 | g4c)")
     args = ap.parse_args()
     assert sys.version_info[:2] < (3, 12), "python>=3.12 sums with compensation: goldens would differ (SURVEY A.2)"
     mods = import_reference()
-    if args.only == "g4b":
-        make_g4b(mods)
+    if args.only:
+        {"g4b": make_g4b, "g8": make_g8, "g4c": make_g4c}[args.only](mods)
         return
     make_g1_g2(mods)
     make_g3(mods)
@@ -505,6 +612,8 @@ def main():
     make_g4b(mods)
     make_g6(mods)
     make_g7(mods)
+    make_g8(mods)
+    make_g4c(mods)
 
 
 if __name__ == "__main__":

@@ -208,7 +208,7 @@ def test_gcn_lp_gin_compute_pi_batched_equals_per_pair():
     edges, kappa = g5["edges"], g5["kappa"]
     ricci = sorted([[int(a), int(b), float(k)] for (a, b), k in zip(edges.tolist(), kappa.tolist())] +
                    [[int(b), int(a), float(k)] for (a, b), k in zip(edges.tolist(), kappa.tolist())])
-    torch.manual_seed(11)
+    torch.manual_seed(3)          # (a seed whose random-init head predicts death > birth: other draws give all-zero images)
     teacher = Teacher_Model(type='GAT').cuda().eval()
     pairs = g5["pairs"][:120]
     data = Data(total_edges=pairs)

@@ -27,7 +27,7 @@ class Vicinities:
         for old, new in self.dict_node.items():
             self.inv[new] = old
 
-    def batch(self, pairs, hop, node_cap=None, edge_cap=None):
+    def batch(self, pairs, hop, node_cap=None, edge_cap=None, flags=None):
         """pairs: [E,2] original labels -> dict of CUDA tensors: node_ptr int64[E+1], edge_ptr int64[E+1], ids int64 (original
         labels, ascending inside a vicinity), f float64, edges int32 [sum m, 2] (local ids, lower first), status uint8[E].
         Vicinities without an edge have empty slices (the reference returns (None, None) for them, :117-118)."""
@@ -36,7 +36,8 @@ class Vicinities:
         mapped = torch.from_numpy(self._g2p._map_pairs(pairs)).cuda()
         n_cap = dev_graph.n_nodes if node_cap is None else int(node_cap)
         e_cap = max(dev_graph.nnz // 2, 1) if edge_cap is None else int(edge_cap)
-        offs, ids, f, n, st, eoffs, edges, m = dev_graph.vicinity_filtration(mapped, hop, flags=KD_LP_FLAGS, cap=n_cap, edge_cap=e_cap)
+        offs, ids, f, n, st, eoffs, edges, m = dev_graph.vicinity_filtration(mapped, hop, flags=KD_LP_FLAGS if flags is None else flags,
+                                                                             cap=n_cap, edge_cap=e_cap)
         if bool((n < 0).any()) or bool((m < 0).any()):
             raise RuntimeError("vicinity larger than the requested node_cap / edge_cap")
         n = torch.where(m > 0, n, torch.zeros_like(n))              # no edge -> (None, None)
@@ -84,6 +85,14 @@ def compute_persistence_image(g, u, v, filt='hks', hks_time=0.1, hop=2, ricci_cu
         return fv.tolist(), edge_index
     if mode != 'PI':
         raise ValueError("mode must be 'PI' or 'filtration'")
+    return diagrams_and_images(b, fv, edge_index)
+
+
+def diagrams_and_images(b, fv, edge_index):
+    """mode 'PI' tail shared by the edge- and node-centred vicinities (data_utils_LP.py:178-197, data_utils_NC.py:155-183):
+    original_extended_persistence (Knowledge_Distillation fork: zero-persistence pairs kept) -> Ord0, Ext1, then the three
+    images PI(Ord0 ++ Ext1), PI0, PI1; the reference's 9-tuple (times are 0)."""
+    import torch
     n, m = len(fv), edge_index.shape[1]
     r = engine.pd_from_filtration(torch.tensor([0, n], dtype=torch.int64, device="cuda"),
                                   torch.tensor([0, m], dtype=torch.int64, device="cuda"),
@@ -92,6 +101,7 @@ def compute_persistence_image(g, u, v, filt='hks', hks_time=0.1, hop=2, ricci_cu
     if c[3] != 1:
         raise KeyError("vicinity is not connected: the reference's Accelerate_PD raises here (accelerated_PD.py:132-148)")
     ord0, ext1 = r["up"][:c[0]], r["one"][:c[2]]
+
     def img(pts):
         if pts.shape[0] == 0:
             return np.zeros(25)

@@ -1,0 +1,58 @@
+"""Drop-in for the vicinity / filtration part of the reference's Knowledge_Distillation/data_utils_NC.py (PDGNN, node
+classification: one diagram per NODE), filt='ricci'.
+
+  ricci_filtration.build_fv :27-50, compute_persistence_image :95-187 (modes 'filtration' and 'PI').
+
+The node-centred variant of the vicinity kernels (SURVEY.md A.7 ii): the subgraph is the whole ball_hop(u) (:97-99), there is
+ONE root, f(x) = weighted distance x -> u (sentinel 100 if unreachable, :41-42) divided by max + 1e-10 (:47-49).  On the
+device that is the pair (u, u) -- ball(u) & ball(u) -- with TLC_DESC_ROOT1 | TLC_INCLUDE_ROOTS | TLC_NORM_EPS |
+TLC_UNREACHABLE_100.  Node labels of a vicinity are positions in ASCENDING original id (the reference's
+`convert_node_labels_to_integers` order is arbitrary); edges are listed once, lower label first.
+HKS / centrality / clustering / degree filtrations are host-side inputs (pass f to tlc_pd_from_filtration) and `call` is not
+reproduced.
+"""
+import numpy as np
+
+from .. import _lib
+from .data_utils_LP import Vicinities, diagrams_and_images
+
+KD_NC_FLAGS = _lib.INCLUDE_ROOTS | _lib.NORM_EPS | _lib.UNREACHABLE_100 | _lib.DESC_ROOT1
+
+
+class NodeVicinities(Vicinities):
+    """Device-resident weighted graph for PDGNN's node-centred vicinities; build once, query many nodes."""
+
+    def batch(self, nodes, hop, node_cap=None, edge_cap=None):
+        """nodes: [B] original labels -> the dict of Vicinities.batch (one vicinity per node)."""
+        nodes = np.asarray(nodes, dtype=np.int64).reshape(-1)
+        return super().batch(np.stack([nodes, nodes], 1), hop, node_cap=node_cap, edge_cap=edge_cap, flags=KD_NC_FLAGS)
+
+
+_CACHE = {}
+
+
+def _vicinities(g, ricci_curv):
+    key = (id(g), id(ricci_curv))
+    if key not in _CACHE:
+        _CACHE.clear()
+        _CACHE[key] = NodeVicinities(g, ricci_curv)
+    return _CACHE[key]
+
+
+def compute_persistence_image(g, u, filt='hks', hks_time=0.1, hop=2, ricci_curv=None, mode='PI', num_models=5, max_loop_len=10,
+                              cycle_the=2):
+    """Reference signature (:95).  filt='ricci' only; mode 'filtration' -> (filtration_val list, edge_index LongTensor[2,m])
+    or (None, None) for a ball without an edge (:103-104); mode 'PI' -> the reference's 9-tuple (:183; times are 0)."""
+    if filt != 'ricci':
+        raise NotImplementedError("data_utils_NC (HIP): only filt='ricci' is implemented (hks / centrality / clustering / degree "
+                                  "filtrations are host-side inputs)")
+    b = _vicinities(g, ricci_curv).batch([u], hop)
+    if int(b["edge_ptr"][-1]) == 0:
+        return None, None
+    fv = b["f"].cpu().numpy()
+    edge_index = b["edges"].t().contiguous().long().cpu()
+    if mode == 'filtration':
+        return fv.tolist(), edge_index
+    if mode != 'PI':
+        raise ValueError("mode must be 'PI' or 'filtration'")
+    return diagrams_and_images(b, fv, edge_index)

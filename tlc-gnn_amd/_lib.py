@@ -18,6 +18,8 @@ ERRORS = {1: "TLC_ERR_INVALID_ARG", 2: "TLC_ERR_HIP", 3: "TLC_ERR_NO_DEVICE", 4:
 
 ST_OK, ST_MISSING_NODE, ST_DISCONNECTED, ST_ZERO_RANGE, ST_NO_TREE_EDGE, ST_TOO_LARGE = range(6)
 KEEP_ZERO_PERS, INCLUDE_ROOTS, NORM_EPS, PI_ORD0_EXT1, NO_EXT1, UNREACHABLE_100 = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+DESC_MIN, DESC_MAX, DESC_ROOT1, NO_NORM = 0x40, 0x80, 0xC0, 0x100
+DESCRIPTOR_FLAG = {"sum": 0, "min": DESC_MIN, "max": DESC_MAX}      # the three node values of filtration.build_fv
 
 # every symbol include/tlcgnn.h declares (tests check that the library exports all of them)
 SYMBOLS = [

@@ -691,6 +691,11 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
 extern "C" int tlc_pd_pi_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags, int res,
                                double* d_out_pi, uint8_t* d_out_status, void* stream) {
     TLC_REQUIRE(n_pairs == 0 || d_out_pi != nullptr, "out_pi is null");
+    if (flags & TLC_NO_NORM) {
+        tlc_set_error("tlc_pd_pi_batch: TLC_NO_NORM is not supported by the fused image stage (it assumes filtration values in "
+                      "[0, 1]); use tlc_vicinity_filtration + tlc_pd_from_filtration + tlc_pi_raster");
+        return TLC_ERR_UNSUPPORTED;
+    }
     return run_batch(g, d_pairs, n_pairs, hop, flags, res, d_out_pi, d_out_status, nullptr, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, 1, stream);
 }

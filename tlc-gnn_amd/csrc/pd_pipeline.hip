@@ -1288,8 +1288,9 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
         double* wU = (double*)M.pn;
         double* wV = (double*)M.pts;
 
+        const unsigned desc = p.flags & TLC_DESC_MASK;
         if (!far) {
-            // ---- P5: filtration.build_fv, weighted branch, descriptor 'sum' (riccidist2dgm.py:20-61) ------------------
+            // ---- P5: filtration.build_fv, weighted branch (riccidist2dgm.py:20-61); descriptor by flag ---------------------
             if (tid == 0) { du[lu] = 0ull; M.dv[lv] = 0ull; }
             __syncthreads();
             TLC_STAMP(0);
@@ -1330,6 +1331,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
                 __syncthreads();
                 // chain walks: sum the weights from x towards the root, left to right (:29-30, :34-35).
                 // f aliases du, which is dead from here on: the walks only read cnt/nxt/dir/lw.
+                double nrm_min = 0.0;                  // descriptor 'min': this thread's share of max_S max(d1, d2)
                 for (int x0 = 0; x0 < n; x0 += W) {
                     const int x = x0 + tid;
                     double fr = 0.0;
@@ -1347,13 +1349,17 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
                         }
                         a = x; steps = 0;
                         if (no_v) { d2 = 100.0; a = lv; }
+                        if (desc == TLC_DESC_ROOT1) a = lv;               // single root: no second distance
                         while (!amb && a != lv) {
                             if (M.cntV[a] != 1u || ++steps > n) { amb = true; break; }
                             const int j = (int)M.nxtV[a];
                             d2 = d2 + (WTAB ? wV[a] : LW(j));
                             a = (int)(M.dir[j] & 0xffffu);
                         }
-                        fr = d1 + d2;                                     // 'sum' = dist_1 + dist_2 (:49)
+                        // 'sum' = dist_1 + dist_2, 'min', 'max' (:47-49); single root: dist_1 (data_utils_NC.py:46)
+                        fr = desc == 0u ? d1 + d2 : (desc == TLC_DESC_MIN ? (d2 < d1 ? d2 : d1) : (desc == TLC_DESC_MAX ? (d2 > d1 ? d2 : d1) : d1));
+                        // 'min' is normalised by the maximum of 'max' (:51), not by its own
+                        if (desc == TLC_DESC_MIN && !amb) { const double dm = d2 > d1 ? d2 : d1; nrm_min = dm > nrm_min ? dm : nrm_min; }
                     }
                     if (x < n) {
                         if (amb) M.amb[atomicAdd(&M.ctl[1], 1)] = (idx_t)x;
@@ -1374,21 +1380,25 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
                     if (tid == 0) {
                         const double e1 = M.dv[lu] == TLC_INF_BITS ? 100.0 : __longlong_as_double((long long)M.dv[lu]);
                         const double e2 = M.dv[lv] == TLC_INF_BITS ? 100.0 : __longlong_as_double((long long)M.dv[lv]);
-                        M.f[x] = e1 + e2;
+                        M.f[x] = desc == 0u ? e1 + e2 : (desc == TLC_DESC_MIN ? (e2 < e1 ? e2 : e1) : (desc == TLC_DESC_MAX ? (e2 > e1 ? e2 : e1) : e1));
+                        if (desc == TLC_DESC_MIN) { const double dm = e2 > e1 ? e2 : e1; nrm_min = dm > nrm_min ? dm : nrm_min; }
                     }
                     __syncthreads();
                 }
                 if (namb && tid == 0 && p.stats) atomicAdd(&p.stats[0], (ull)namb);
                 TLC_STAMP(3);
                 // normalise (:50-56): plain division by the maximum
-                double mx = 0.0;
-                for (int k = tid; k < n; k += W) mx = M.f[k] > mx ? M.f[k] : mx;
-                mx = block_max<W>(mx, M.red);
-                double scaler = mx;
-                if (p.flags & TLC_NORM_EPS) scaler = mx + 1e-10;          // data_utils_LP.py:64
-                else if (mx == 0.0) status = TLC_ST_ZERO_RANGE;           // ZeroDivisionError (:54)
-                if (status == TLC_ST_OK)
-                    for (int k = tid; k < n; k += W) M.f[k] = M.f[k] / scaler;
+                if (!(p.flags & TLC_NO_NORM)) {                           // (norm=False: the raw distances stand)
+                    double mx = 0.0;
+                    if (desc == TLC_DESC_MIN) mx = nrm_min;                   // norm_scaler = max of 'max' (:51)
+                    else for (int k = tid; k < n; k += W) mx = M.f[k] > mx ? M.f[k] : mx;
+                    mx = block_max<W>(mx, M.red);
+                    double scaler = mx;
+                    if (p.flags & TLC_NORM_EPS) scaler = mx + 1e-10;          // data_utils_LP.py:64
+                    else if (mx == 0.0) status = TLC_ST_ZERO_RANGE;           // ZeroDivisionError (:54)
+                    if (status == TLC_ST_OK)
+                        for (int k = tid; k < n; k += W) M.f[k] = M.f[k] / scaler;
+                }
                 __syncthreads();
             }
         } else {
@@ -1401,7 +1411,9 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
             const double un = block_max<W>(unreach ? 1.0 : 0.0, M.red);
             if (un != 0.0) status = TLC_ST_DISCONNECTED;
             __syncthreads();
-            const double one = (p.flags & TLC_NORM_EPS) ? (200.0 / (200.0 + 1e-10)) : (200.0 / 200.0);
+            // both sentinels: 'sum' = 200, 'min' = 'max' = 100 (:31-37,47-49), then the same division as above
+            const double raw = desc == 0u ? 200.0 : 100.0;
+            const double one = (p.flags & TLC_NO_NORM) ? raw : ((p.flags & TLC_NORM_EPS) ? (raw / (raw + 1e-10)) : (raw / raw));
             for (int k = tid; k < n; k += W) M.f[k] = one;
             __syncthreads();
         }

@@ -85,14 +85,15 @@ class graph2pi():
 
         `cores` is accepted for signature compatibility (the reference's ThreadPool is GIL-bound and racy; here every
         pair is one independent wavefront/workgroup).  `norm` is ignored exactly as the reference ignores it (:353
-        hard-wires norm=True).  Only descriptor='sum' -- the one the pipeline uses (loaddatas.py:101) -- is implemented.
+        hard-wires norm=True).  descriptor: 'sum' (what the pipeline passes, loaddatas.py:101), 'min' (this function's own
+        default, like the reference's) or 'max' -- the three node values of filtration.build_fv (:47-56).
         """
-        if descriptor != 'sum':
-            raise NotImplementedError("graph2pi: only descriptor='sum' is implemented on the HIP path")
+        if descriptor not in _lib.DESCRIPTOR_FLAG:
+            raise KeyError(descriptor)            # g.nodes[node][descriptor] (accelerated_PD.py:13): no such node attribute
         import torch
         dev_graph = self._device_graph()
         pairs = torch.from_numpy(self._map_pairs(total_edges)).cuda()
-        flags = 0 if extended_flag else _lib.NO_EXT1
+        flags = (0 if extended_flag else _lib.NO_EXT1) | _lib.DESCRIPTOR_FLAG[descriptor]
         out, status = dev_graph.pd_pi_batch(pairs, hop, flags=flags, res=resolution)
         self.pi_sg = out.cpu().numpy()
         self.status = status.cpu().numpy()
@@ -105,19 +106,8 @@ class graph2pi():
                                           resolution=resolution, descriptor=descriptor)[0]
         return row
 
-    def sg2dgm_accelerate(self, u, v, hop, extended_flag=False, descriptor="seal", resolution=5, norm=False, cnt=0):
-        """:310-329 with already-relabelled ids (u, v are NEW labels, as in the reference); returns [res,res].
-
-        Raises the reference's exception classes for the four zero-row conditions.  norm=True only.
-        """
-        if not norm:
-            raise NotImplementedError("sg2dgm_accelerate: only norm=True (what get_pimg_for_one_edge passes) is implemented")
-        if descriptor != 'sum':
-            raise NotImplementedError("only descriptor='sum' is implemented on the HIP path")
-        import torch
-        pairs = torch.tensor([[int(u), int(v)]], dtype=torch.int32, device="cuda")
-        out, st = self._device_graph().pd_pi_batch(pairs, hop, flags=0 if extended_flag else _lib.NO_EXT1, res=resolution)
-        st = int(st.item())
+    @staticmethod
+    def _raise_for(st, u, v):
         if st == _lib.ST_MISSING_NODE:
             raise KeyError((u, v))
         if st == _lib.ST_DISCONNECTED:
@@ -128,4 +118,43 @@ class graph2pi():
             raise IndexError("list index out of range")
         if st != _lib.ST_OK:
             raise RuntimeError("vicinity too large for the packed local ids (status %d)" % st)
-        return out.cpu().numpy().reshape(resolution, resolution)
+
+    def sg2dgm_accelerate(self, u, v, hop, extended_flag=False, descriptor="seal", resolution=5, norm=False, cnt=0):
+        """:310-329 with already-relabelled ids (u, v are NEW labels, as in the reference); returns [res,res].
+
+        Raises the reference's exception classes for the zero-row conditions.  norm=True: one call of the fused batch path.
+        norm=False (raw distances, this function's own default; the pipeline never passes it): the image stage of the fused
+        path assumes values in [0, 1], so the three stages run as separate entry points -- tlc_vicinity_filtration
+        (TLC_NO_NORM) -> tlc_pd_from_filtration -> tlc_pi_raster.
+        """
+        if descriptor not in _lib.DESCRIPTOR_FLAG:
+            raise KeyError(descriptor)            # g.nodes[node][descriptor] (accelerated_PD.py:13)
+        import torch
+        dflag = _lib.DESCRIPTOR_FLAG[descriptor]
+        pairs = torch.tensor([[int(u), int(v)]], dtype=torch.int32, device="cuda")
+        g = self._device_graph()
+        if norm:
+            out, st = g.pd_pi_batch(pairs, hop, flags=(0 if extended_flag else _lib.NO_EXT1) | dflag, res=resolution)
+            self._raise_for(int(st.item()), u, v)
+            return out.cpu().numpy().reshape(resolution, resolution)
+        offs, ids, f, n, st, eoffs, edges, m = g.vicinity_filtration(pairs, hop, flags=dflag | _lib.NO_NORM, cap=g.n_nodes,
+                                                                     edge_cap=max(g.nnz // 2, 1))
+        self._raise_for(int(st.item()), u, v)
+        n, m = int(n.item()), int(m.item())
+        f, edges = f[:n].contiguous(), edges[:m].contiguous()
+        if m > 0 and float(f.max()) > 101:
+            # both roots outside the vicinity and descriptor 'sum': every value is the double sentinel 200 > max_filter, so
+            # 'desc' = lo - (101 - hi)*1e-6 exceeds the node values, the descending pass meets an edge before its endpoints
+            # and the reference's dict lookup fails (accelerated_PD.py:10,21,90)
+            raise KeyError(0)
+        if extended_flag and m == 0:
+            raise IndexError("list index out of range")              # list(Nodes)[0] (accelerated_PD.py:122)
+        r = engine.pd_from_filtration(torch.tensor([0, n], dtype=torch.int64, device="cuda"),
+                                      torch.tensor([0, m], dtype=torch.int64, device="cuda"), edges, f,
+                                      0 if extended_flag else _lib.NO_EXT1, want_rank=False)
+        c = r["counts"][0]
+        ext0 = r["ext0"][0]
+        pts = torch.cat([r["up"][:int(c[0])], ext0.view(1, 2), r["down"][:int(c[1])], ext0.flip(0).view(1, 2),
+                         r["one"][:int(c[2])] if extended_flag else r["one"][:0]])                  # PD_zero + PD_one (:327)
+        img = engine.pi_raster(torch.tensor([0, pts.shape[0]], dtype=torch.int64, device="cuda"), pts.contiguous(), resolution)
+        return img[0].cpu().numpy().reshape(resolution, resolution)
