@@ -130,6 +130,72 @@ def pdgnn_aux(torch, dev, n_graphs=41127, seed=1234):
                     "device-resident calls; not part of `value`"}
 
 
+def pdgnn_amazon_aux(torch, dev, n_pairs=4096, seed=1234):
+    """BASELINE configs[2]: PDGNN (gat_conv.py) forward on the hop-1 vicinities of the Amazon-shaped graphs, the caller shape of
+    gcn_LP_GIN.Net.compute_PI (:43-64) -- vicinity + filtration of every candidate pair on the device (tlc_vicinity_filtration),
+    all vicinities of the sample stacked block-diagonally, ONE Teacher_Model forward, one image per vicinity -- beside the exact
+    diagrams + images of the same pairs (tlc_pd_pi_batch with the PDGNN fork's flags).  Device-resident, median of 5."""
+    from tlc_gnn_amd import synth, _lib
+    from tlc_gnn_amd.Knowledge_Distillation.data_utils_LP import Vicinities, KD_LP_FLAGS
+    from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
+    out = {}
+    torch.manual_seed(seed)
+    model = Teacher_Model(type='GAT').eval().to(dev)
+
+    def med_ms(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3
+
+    for shape in ("Photo", "Computers"):
+        n, edges, kappa, hop, _ = synth.shaped_graph(shape)
+        ricci = np.concatenate([np.concatenate([edges, kappa[:, None]], 1), np.concatenate([edges[:, ::-1], kappa[:, None]], 1)]).tolist()
+        vic = Vicinities(edges, ricci)
+        rs = np.random.RandomState(seed)
+        pairs = edges[rs.permutation(len(edges))[:n_pairs]]
+        state = {}
+
+        def extract():
+            state["b"] = vic.batch(pairs, hop, node_cap=512, edge_cap=8192)
+
+        def forward():
+            b = state["b"]
+            node_ptr, edge_ptr = b["node_ptr"], b["edge_ptr"]
+            n_tot = int(node_ptr[-1])
+            e = b["edges"].long() + node_ptr[b["pair_of_edge"]].view(-1, 1)
+            loops = torch.arange(n_tot, device=e.device)
+            ei = torch.cat([e.t(), torch.stack([loops, loops])], dim=1)
+            x = b["f"].to(torch.float32).view(-1, 1)
+            with torch.no_grad():
+                state["img"] = model(x, ei, None, compute_loss=False, grad_PI=False, graph_ptr=node_ptr, edge_ptr=edge_ptr)[1]
+
+        ex_ms = med_ms(extract)
+        fw_ms = med_ms(forward)
+        g = vic._g2p._device_graph()
+        mapped = torch.from_numpy(vic._g2p._map_pairs(pairs)).to(dev)
+        flags = KD_LP_FLAGS | _lib.KEEP_ZERO_PERS | _lib.PI_ORD0_EXT1
+        exact_ms = med_ms(lambda: g.pd_pi_batch(mapped, hop, flags=flags))
+        b = state["b"]
+        sizes = (b["node_ptr"][1:] - b["node_ptr"][:-1]).cpu().numpy()
+        out[shape] = {"pairs": int(len(pairs)), "hop": int(hop), "nodes": int(b["node_ptr"][-1]), "edges": int(b["edge_ptr"][-1]),
+                      "largest_vicinity_nodes": int(sizes.max()), "vicinity_extraction_ms": ex_ms, "pdgnn_forward_ms": fw_ms,
+                      "pdgnn_vicinities_per_sec": len(pairs) / ((ex_ms + fw_ms) * 1e-3),
+                      "pdgnn_forward_only_vicinities_per_sec": len(pairs) / (fw_ms * 1e-3),
+                      "exact_pd_pi_ms": exact_ms, "exact_vicinities_per_sec": len(pairs) / (exact_ms * 1e-3)}
+        g.close()
+    out["note"] = ("Amazon-shaped synthetic graphs, hop 1, a sample of the positive pairs; PDGNN = vicinity extraction + 4 GAT layers + "
+                   "edge head + 5x5 image per vicinity (random-init weights, seed 1234, one edge per undirected pair as in "
+                   "gcn_LP_GIN.compute_PI); exact = tlc_pd_pi_batch on the same pairs with the PDGNN fork's flags; host wall clock "
+                   "around device-resident calls; not part of `value`")
+    return out
+
+
 def _ricci_cpu_sample(ricci_ref, n, edges, sample):
     """CPU restatement (numpy Sinkhorn of oracle/ricci_ref.py) for a sample of edges; hop distances by the 0/1/2/3 rule from
     adjacency sets (an all-pairs BFS of the 19 717-node graph would dominate the timing)."""
@@ -536,6 +602,12 @@ def main():
             pdgnn = pdgnn_aux(torch, dev)
         except Exception as ex:                                   # the headline line must not depend on the auxiliary
             pdgnn = {"error": repr(ex)}
+    pdgnn_amazon = None
+    if rank == 0 and not args.no_sweep:
+        try:
+            pdgnn_amazon = pdgnn_amazon_aux(torch, dev)
+        except Exception as ex:
+            pdgnn_amazon = {"error": repr(ex)}
     # auxiliary (untimed): the LP leg's two bounded kernels on their own -- the feature GEMM against the f32 MFMA peak and
     # the scatter-add SpMM against HBM (north_star); torch events on the current stream, which is where ops.* enqueue
     lp_roof = None
@@ -661,6 +733,7 @@ def main():
             "ricci": ricci,
             "other_shapes": other_shapes,
             "pdgnn": pdgnn,
+            "pdgnn_amazon": pdgnn_amazon,
         }
         if world == 1 and not args.no_cpu_baseline:
             # the CPU restatement (oracle/tlc_oracle.c, a port of the reference's algorithm) on this box's host cores,
