@@ -792,6 +792,19 @@ extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long l
     return TLC_OK;
 }
 
+// diagnostics: subgraphs of the last chunk whose cycle swap ran as a divide and conquer (h_out[0]) / fell back to the serial walk
+// after trying (h_out[1])
+extern "C" int tlc_debug_dc_stats(tlc_graph* g, long long* h_out, void* stream) {
+    TLC_REQUIRE(g && h_out, "null argument");
+    TLC_ON_DEVICE(g->device);
+    TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    unsigned long long v[4];
+    TLC_HIP_CHECK(hipMemcpy(v, g->d_stats, sizeof(v), hipMemcpyDeviceToHost));
+    h_out[0] = (long long)v[1];
+    h_out[1] = (long long)v[3];
+    return TLC_OK;
+}
+
 // ---- measurement helpers (declared in include/tlcgnn.h) ----------------------------------------------------------------
 extern "C" int tlc_pd_pi_batch_set_timing(tlc_graph* g, int enable) {
     TLC_REQUIRE(g != nullptr, "null graph");

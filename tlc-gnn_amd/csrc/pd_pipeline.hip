@@ -120,6 +120,9 @@ struct Mem {
     unsigned* rec; // cycle swap: path records of the two walks
     unsigned char* table;  // PI table: spans dir (+lw)
     size_t table_bytes;
+    unsigned char* xbase;  // everything between the edge tables and the Pos/Neg lists: free once the passes are done
+    size_t xbytes;
+    unsigned long long* stats;   // batch statistics (device, may be null): [1] subgraphs whose cycle swap ran as a divide and conquer, [3] fell back
     int P;
 };
 
@@ -155,6 +158,9 @@ __device__ __forceinline__ Mem<idx_t> carve(unsigned char* base, const Layout& L
     m.rec = (unsigned*)(base + L.o_rec);
     m.table = base + L.o_dir;
     m.table_bytes = L.o_x - L.o_dir;
+    m.xbase = base + L.o_x;
+    m.xbytes = L.o_pn - L.o_x;
+    m.stats = nullptr;
     m.P = L.P;
     return m;
 }
@@ -451,6 +457,12 @@ struct PtsSink {
     __device__ __forceinline__ void ext0(const double*, int mn, int mx) { pts[ctl[2]++] = ((unsigned)mn << 16) | (unsigned)mx; }
     __device__ __forceinline__ void down(const double*, int, int) {}
     __device__ __forceinline__ void one_at(const double*, int slot, int, int b, int d) { pts[slot] = ((unsigned)b << 16) | (unsigned)d; }
+};
+// development check (TLC_DC_VERIFY): the higher endpoint per query
+struct VerifySink {
+    unsigned short* o;
+    static constexpr bool want_down = false, is_global = false;
+    __device__ __forceinline__ void one_at(const double*, int, int k, int, int d) { o[k] = (unsigned short)d; }
 };
 // tlc_pd_from_filtration: values straight to the caller's arrays.
 struct GlobalSink {
@@ -1008,6 +1020,10 @@ __device__ __forceinline__ int ext1_walk(const SwapTables& T, ull* recs, Query& 
     return n_out;
 }
 
+}  // namespace
+#include "ext1_dc.h"
+namespace {
+
 // Hand-off record of one subgraph between a tier kernel (parallel stages, W threads, the tier's full LDS footprint) and
 // tlc_pd_swap_kernel (the serial cycle swap + the image: one wavefront and a quarter of the LDS, so that the long serial
 // tails of a tier run at several times the tier kernel's residency).  Slot layout, NM / MM = the tier's capacities:
@@ -1053,9 +1069,66 @@ __device__ __forceinline__ void ext1_handoff(Mem<idx_t>& M, int n, int MMcap, in
 }
 
 // Accelerate_PD (accelerated_PD.py:115-178) on a subgraph whose Pos / Neg lists sit in M.pn.  Requires ctl[4] (#Neg) >= 1.
+// dc: the descending order has its ties fixed and M.rec holds the spanning-tree bits of the ascending pass (pd_all_stages):
+// try the divide-and-conquer form (ext1_dc.h); the serial walk below is the fallback and the form for few Pos edges.
 template <int W, typename idx_t, class Sink>
 __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, unsigned flags, int MMcap, int NMcap, ull* pc,
-                                           ull& t_prev, ull* ph) {
+                                           ull& t_prev, ull* ph, bool dc) {
+    if (dc) {
+        const int K = M.ctl[3];
+        const size_t hin_bytes = al16((size_t)K * 2);
+        unsigned short* hin = (unsigned short*)(M.xbase + (M.xbytes - hin_bytes));
+        const bool ok = M.xbytes > hin_bytes &&
+                        ext1_dc_solve<W>(M, n, MMcap, (const unsigned*)M.rec, M.xbase, M.xbytes - hin_bytes, hin);
+        if (threadIdx.x == 0 && M.stats) atomicAdd(&M.stats[ok ? 1 : 3], 1ull);
+#ifdef TLC_DC_VERIFY
+        if (ok && (size_t)(M.ctl[2] + K) * 4 + (size_t)K * 2 + 16 <= (size_t)(MMcap + 2) * 4) {
+            // development check: the serial walk on the same input, answer for answer (mismatches are counted in stats[3])
+            unsigned short* v_hin = (unsigned short*)(M.pts + M.ctl[2] + K + 2);
+            VerifySink vs{v_hin};
+            unsigned short keep[8];
+            for (int q = 0; q < 8; ++q) { const int k = (int)threadIdx.x + q * W; keep[q] = k < K ? hin[k] : 0; }
+            __syncthreads();
+            const SwapTables Tv = carve_swap(M.keyS, NMcap);
+            const bool anyu = ext1_build_tree<W>(M, Tv, n, MMcap, NMcap);
+            if (threadIdx.x < 64) {
+                QueryLds qv{M.pn, M.dir, M.arank, K, 0u, 0u, 0u};
+                ext1_walk(Tv, (ull*)M.rec, qv, K, NMcap, anyu, vs, M.f, true, 0, nullptr);
+            }
+            __syncthreads();
+            int mism = 0;
+            for (int q = 0; q < 8; ++q) { const int k = (int)threadIdx.x + q * W; if (k < K) { mism += (keep[q] != v_hin[k]); hin[k] = keep[q]; } }
+            if (mism && M.stats) atomicAdd(&M.stats[3], (unsigned long long)mism);
+            __syncthreads();
+        }
+#endif
+        if (ok) {
+            const bool keep0 = (flags & TLC_KEEP_ZERO_PERS) != 0;
+            const int out0 = M.ctl[2];
+            __syncthreads();                       // (every wavefront has read out0 before thread 0 moves the counter)
+            if (!(Sink::is_global && !keep0)) {
+                for (int k = (int)threadIdx.x; k < K; k += W)
+                    sink.one_at(M.f, out0 + k, k, (int)(M.dir[M.pn[k]] >> 16), (int)hin[k]);
+                if (threadIdx.x == 0) { M.ctl[2] = out0 + K; M.ctl[8] = K; }
+            } else {
+                // the TLC fork drops low_value >= large_value (:164): deterministic compaction in query order
+                unsigned short* pos = (unsigned short*)M.xbase;
+                for (int k = (int)threadIdx.x; k < K; k += W)
+                    pos[k] = (unsigned short)(M.f[hin[k]] > M.f[M.dir[M.pn[k]] >> 16] ? 1 : 0);
+                __syncthreads();
+                const int total = block_exscan_u16<W>(pos, K, M.wcnt);
+                for (int k = (int)threadIdx.x; k < K; k += W) {
+                    const int p = (int)(M.dir[M.pn[k]] >> 16);
+                    if (M.f[hin[k]] > M.f[p]) sink.one_at(M.f, out0 + pos[k], pos[k], p, (int)hin[k]);
+                }
+                if (threadIdx.x == 0) { M.ctl[2] = out0 + total; M.ctl[8] = total; }
+            }
+            __syncthreads();
+            TLC_STAMP(10);
+            return;
+        }
+        __syncthreads();
+    }
     const SwapTables T = carve_swap(M.keyS, NMcap);
     const bool any_unreached = ext1_build_tree<W>(M, T, n, MMcap, NMcap);
     TLC_STAMP(9);
@@ -1074,7 +1147,8 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
 // `slot` != null: a subgraph with Pos edges leaves its cycle swap to tlc_pd_swap_kernel (deferred = true).
 template <int W, typename idx_t, class Sink>
 __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, int m, unsigned flags, int MMcap, int NMcap,
-                                            ull* pc, ull& t_prev, ull* ph, unsigned char* slot, bool& deferred) {
+                                            ull* pc, ull& t_prev, ull* ph, unsigned char* slot, bool& deferred,
+                                            bool allow_dc = false) {
     relabel_by_rank<W>(M, n, m);
     sort_edges<W, idx_t, false>(M, m);
     for (int pos = threadIdx.x; pos < m; pos += W) M.arank[M.valS[pos]] = (unsigned)pos;
@@ -1088,7 +1162,20 @@ __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, i
     // edge and no 1-dimensional point, and the descending pass would only add Rel1 points, which weigh 0 in the image.
     // (The batch path is entered for connected vicinities only; tlc_pd_from_filtration reports Rel1 and takes the long way.)
     if (!Sink::is_global && m == n - 1) return TLC_ST_OK;
+    // Many Pos edges (m - n + 1 of them in a connected graph): the cycle swap runs as a divide and conquer (ext1_dc.h), which
+    // needs the ascending pass's spanning tree per edge id -- kept in M.rec, the serial walk's record area -- and the descending
+    // order with its ties fixed
+    bool dc = allow_dc && !(flags & TLC_NO_EXT1) && (m - n + 1) >= TLC_DC_MIN_POS && m <= 8 * W && m < 65536 && (size_t)((m + 31) / 32) * 4 <= 1280;
+    if (dc) {
+        unsigned* finb = (unsigned*)M.rec;
+        for (int w = threadIdx.x; w < (m + 31) / 32; w += W) finb[w] = 0u;
+        __syncthreads();
+        for (int pos = threadIdx.x; pos < m; pos += W)
+            if ((M.tbits[pos >> 5] >> (pos & 31)) & 1u) { const unsigned e = M.valS[pos]; atomicOr(&finb[e >> 5], 1u << (e & 31)); }
+        __syncthreads();
+    }
     sort_edges<W, idx_t, true>(M, m);
+    if (dc) dc = fix_desc_ties<W>(M, m);
     TLC_STAMP(7);
     if (Sink::want_down) mst_pass<W, idx_t, true, true>(M, sink, n, m, flags);
     else mst_pass<W, idx_t, true, false>(M, sink, n, m, flags);
@@ -1101,7 +1188,7 @@ __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, i
             ext1_handoff<W>(M, n, MMcap, NMcap, slot);
             deferred = true;
             TLC_STAMP(9);
-        } else ext1_stage<W>(M, sink, n, flags, MMcap, NMcap, pc, t_prev, ph);
+        } else ext1_stage<W>(M, sink, n, flags, MMcap, NMcap, pc, t_prev, ph, dc && M.ctl[3] == m - n + 1);
     }
     return status;
 }
@@ -1235,6 +1322,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
         base = lds_raw;
     }
     Mem<idx_t> M = carve<idx_t>(base, L, NMr, MMr, LWL);
+    M.stats = p.stats;
     const int res = p.res, res2 = res * res;
 
     // this workgroup is resident: tell the launcher's gate (api.hip, tlc_wait_started)
@@ -1483,7 +1571,8 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
             __syncthreads();
             PtsSink sink{M.pts, M.ctl};
             TLC_STAMP(4);
-            status = pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, slot, deferred);
+            status = pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, slot, deferred,
+                                      /*allow_dc=*/NM == TLC_L_NMAX && !HUGE);
             if (status == TLC_ST_OK && !deferred) {
                 const int np = M.ctl[2], n_up = M.ctl[6];
                 auto get = [&](int k, double& b, double& d) {
@@ -1634,7 +1723,8 @@ __global__ __launch_bounds__(W) void tlc_pdf_tier_kernel(TlcPdfParams p) {
         ull* ph = nullptr;
         if (m > 0) {
             bool deferred = false;
-            pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, nullptr, deferred);
+            pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, nullptr, deferred,
+                             /*allow_dc=*/NM == TLC_L_NMAX && !HUGE);
         } else if (tid == 0) {
             double mn = 99999999.0, mx = -99999999.0;
             for (int k = 0; k < n; ++k) { mn = M.f[k] < mn ? M.f[k] : mn; mx = M.f[k] > mx ? M.f[k] : mx; }
