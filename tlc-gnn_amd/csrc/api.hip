@@ -64,6 +64,7 @@ struct tlc_graph {
     // per-chunk workspace
     size_t cap_pairs;
     int *hdr_n, *hdr_m2, *hdr_lu, *hdr_lv, *tier_list;
+    int* dc_lists;             // [4][cap_pairs]: MEDIUM / LARGE lists for tlc_pd_dc_kernel, and what it left for the serial kernel
     long long* edge_off;
     // small device block: [0..3] tier counts
     int* d_ctl;
@@ -101,6 +102,8 @@ struct tlc_graph {
     hipEvent_t ev_early, ev_scan;
     unsigned char* handoff;        // hand-off slots between the tier kernels and tlc_pd_swap_kernel
     size_t cap_handoff;
+    unsigned char* handoff_large;  // the LARGE tier's own slots (only subgraphs meant for tlc_pd_dc_kernel use theirs)
+    size_t cap_handoff_large;
     size_t huge_stride;
     hipStream_t side[TLC_N_SIDE];
     hipEvent_t ev_fork, ev_join[TLC_N_SIDE];
@@ -123,7 +126,8 @@ struct tlc_graph {
 static int ensure_pairs(tlc_graph* g, size_t n) {
     if (n <= g->cap_pairs) return TLC_OK;
     hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
-    g->hdr_n = g->hdr_m2 = g->hdr_lu = g->hdr_lv = g->tier_list = nullptr;
+    hipFree(g->dc_lists);
+    g->hdr_n = g->hdr_m2 = g->hdr_lu = g->hdr_lv = g->tier_list = g->dc_lists = nullptr;
     g->edge_off = nullptr;
     g->cap_pairs = 0;
     TLC_HIP_CHECK(hipMalloc(&g->hdr_n, n * sizeof(int)));
@@ -132,6 +136,7 @@ static int ensure_pairs(tlc_graph* g, size_t n) {
     TLC_HIP_CHECK(hipMalloc(&g->hdr_lv, n * sizeof(int)));
     TLC_HIP_CHECK(hipMalloc(&g->tier_list, n * TLC_N_TIERS * sizeof(int)));
     TLC_HIP_CHECK(hipMalloc(&g->edge_off, (n + 1) * sizeof(long long)));
+    TLC_HIP_CHECK(hipMalloc(&g->dc_lists, 6 * (n + TLC_EARLY_SLOTS) * sizeof(int)));
     g->cap_pairs = n;
     return TLC_OK;
 }
@@ -163,6 +168,16 @@ static int ensure_handoff(tlc_graph* g, size_t bytes) {
     g->handoff = nullptr; g->cap_handoff = 0;
     TLC_HIP_CHECK(hipMalloc(&g->handoff, want));
     g->cap_handoff = want;
+    return TLC_OK;
+}
+
+static int ensure_handoff_large(tlc_graph* g, size_t slots) {
+    const size_t bytes = slots * tlc_handoff_slot_bytes(TLC_TIER_LARGE);
+    if (bytes <= g->cap_handoff_large) return TLC_OK;
+    hipFree(g->handoff_large);
+    g->handoff_large = nullptr; g->cap_handoff_large = 0;
+    TLC_HIP_CHECK(hipMalloc(&g->handoff_large, bytes));
+    g->cap_handoff_large = bytes;
     return TLC_OK;
 }
 
@@ -302,9 +317,10 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     hipDeviceSynchronize();
     hipFree(g->d_rowptr); hipFree(g->d_col); hipFree(g->d_w);
     hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
+    hipFree(g->dc_lists);
     hipFree(g->d_ctl); hipFree(g->d_block_sums); hipFree(g->d_totals);
     if (g->h_sync) hipHostFree(g->h_sync);
-    hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->S_dir); hipFree(g->S_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch); hipFree(g->handoff); hipFree(g->d_phase);
+    hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->S_dir); hipFree(g->S_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch); hipFree(g->handoff); hipFree(g->handoff_large); hipFree(g->d_phase);
     hipFree(g->d_ball_ub[0]); hipFree(g->d_ball_ub[1]); hipFree(g->d_cand_list); hipFree(g->d_early_list); hipFree(g->E_dir); hipFree(g->E_lw);
     if (g->ev_early) hipEventDestroy(g->ev_early);
     if (g->ev_scan) hipEventDestroy(g->ev_scan);
@@ -419,6 +435,14 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     pp.ids_off = (const long long*)d_ids_off; pp.out_f = d_out_f; pp.out_n = d_out_n; pp.pi_enabled = pi_enabled;
     pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
     pp.stats = g->d_stats;
+    // lists for tlc_pd_dc_kernel: counters in the control block (zeroed with it), [d_ctl + 26 + 2k] count / [.. + 1] left over;
+    // k = 0 MEDIUM, 1 LARGE (regular launch), 2 LARGE (early launch)
+    auto dc_lists_for = [&](TlcPdParams& q, int k) {
+        const size_t cap = g->cap_pairs + TLC_EARLY_SLOTS;
+        q.dc_count = g->d_ctl + 26 + 2 * k; q.dcf_count = g->d_ctl + 27 + 2 * k;
+        q.dc_list = g->dc_lists + (size_t)k * cap;
+        q.dcf_list = g->dc_lists + (size_t)(3 + k) * cap;
+    };
     if (early) {
         if ((rc = ensure_early(g, hop, s)) != TLC_OK) return rc;
         hipStream_t es = g->side[4];
@@ -444,6 +468,12 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         lp.tier_list = g->d_early_list; lp.tier_count = TLC_EARLY_SLOTS; lp.tier_count_dev = d_early_count;
         lp.slot_entries = 2 * TLC_L_MMAX; lp.A_dir = g->E_dir; lp.A_lw = g->E_lw;
         lp.started = d_early_started;
+        if (tlc_handoff_slot_bytes(TLC_TIER_LARGE) != 0) {
+            if ((rc = ensure_handoff_large(g, TLC_EARLY_SLOTS)) != TLC_OK) return rc;
+            lp.handoff = g->handoff_large; lp.handoff_stride = (long long)tlc_handoff_slot_bytes(TLC_TIER_LARGE);
+            lp.handoff_cap = TLC_EARLY_SLOTS;
+            dc_lists_for(lp, 2);
+        }
         lp.phase_cycles = g->d_phase ? g->d_phase + 32 * TLC_TIER_LARGE : nullptr;
         T0(5, es);
         if ((rc = tlc_launch_pd_tier(TLC_TIER_LARGE, lp, es)) != TLC_OK) return rc;
@@ -522,6 +552,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
             pp.grid = spec_cap[t]; pp.handoff_cap = spec_cap[t]; pp.phase = 0;
             pp.handoff = g->handoff + spec_base[t]; pp.handoff_stride = (long long)tlc_handoff_slot_bytes(t);
             pp.abort_flag = d_bump_overflow;
+            dc_lists_for(pp, 0);
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
             T0(tslot[t], s);
             if ((rc = tlc_launch_pd_tier(t, pp, s)) != TLC_OK) return rc;
@@ -570,6 +601,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         if (pi_enabled && !spec_done) {
             size_t hand_total = 0;
             for (int t = 0; t < TLC_N_TIERS; ++t) {
+                if (t == TLC_TIER_LARGE) continue;                   // (its own buffer)
                 hand_base[t] = hand_total;
                 hand_total += (size_t)tc[t] * tlc_handoff_slot_bytes(t);
             }
@@ -592,6 +624,15 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
             pp.handoff = hs ? g->handoff + hand_base[t] : nullptr;
             pp.handoff_stride = (long long)hs;
             pp.handoff_cap = (spec_done && t == TLC_TIER_MID) ? std::min(tc[t], spec_cap[t]) : tc[t];
+            pp.dc_count = pp.dcf_count = nullptr; pp.dc_list = pp.dcf_list = nullptr;
+            if (t == TLC_TIER_MEDIUM) dc_lists_for(pp, 0);
+            if (t == TLC_TIER_LARGE) dc_lists_for(pp, 1);
+            if (hs && t == TLC_TIER_LARGE) {
+                // (the early launch may still be using the first TLC_EARLY_SLOTS slots: this launch takes the ones behind them)
+                int r2 = ensure_handoff_large(g, (size_t)TLC_EARLY_SLOTS + (size_t)tc[t]);
+                if (r2 != TLC_OK) return r2;
+                pp.handoff = g->handoff_large + (size_t)TLC_EARLY_SLOTS * hs;
+            }
             pp.grid = 0; pp.phase = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
             const bool timed = !(early && t == TLC_TIER_LARGE);     // (that slot times the early launch)

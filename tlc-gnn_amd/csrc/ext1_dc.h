@@ -19,7 +19,13 @@
 // the last bits) some query ends without its edge: the stage reports failure and the caller runs the serial walk.
 #pragma once
 
-#define TLC_DC_MIN_POS 160          /* below this many Pos edges the serial walk wins */
+#define TLC_DC_MIN_POS 160          /* below this many Pos edges the serial walk wins (a workgroup with a CU to itself) */
+/* 256-thread tiers (MEDIUM): measured on the PubMed batch, a level costs ~30k cycles there as well (phases of two or three
+ * dependent LDS round trips, no latency hiding) -- 8 levels = 100 us for 190 queries against 185 us for the serial walk in
+ * tlc_pd_swap_kernel, and the kernel sits between the tier kernel and the serial kernel on the same stream: the chain gets
+ * longer, not shorter.  Only the sizes the tier cannot reach in this batch take it. */
+#define TLC_DC_MIN_POS_SHARED 320
+#define TLC_DC_LARGE_MODE 2          /* LARGE tier: 1 = in the tier kernel, 2 = hand the subgraph to tlc_pd_dc_kernel */
 #define TLC_DC_MAX_TIE_RUN 64       /* longer runs of equal descending keys: no fix-up, serial walk */
 
 namespace {
@@ -93,77 +99,174 @@ __device__ __forceinline__ int block_exscan_u16(unsigned short* a, int N, int* w
     return total;
 }
 
-// Components of the forest given by the marked items, as labels = the smallest id of the component.  `want(code, ab)`
-// says whether an item is an edge of the forest.  Roots hook under ANY smaller neighbouring root (plain 16-bit stores: the
-// race only decides which smaller root wins), then everything is flattened; a root that survives a round is a local
-// minimum among the roots, so the number of roots at least halves per round.
-template <int W, class Items>
-__device__ __forceinline__ void dc_components(unsigned short* lab, int S, const Items& items, int* ctl) {
-    const int tid = threadIdx.x;
-    for (int x = tid; x < S; x += W) lab[x] = (unsigned short)x;
-    __syncthreads();
-    for (int round = 0; round < 64; ++round) {
-        bool ch = false;
-        items([&](unsigned ab) {
-            const unsigned ra = lab[ab >> 16], rb = lab[ab & 0xffffu];
-            if (ra < rb) { lab[rb] = (unsigned short)ra; ch = true; }
-            else if (rb < ra) { lab[ra] = (unsigned short)rb; ch = true; }
-        });
+// "Did any thread raise the flag" with ONE barrier per call (block_any of pd_pipeline.hip takes three): three rotating LDS
+// slots; call i uses slot i % 3 and clears the slot of call i - 1, which every thread has read before it reached this
+// call's barrier and which is not written again before the barrier of call i + 1.  `turn` is uniform across the workgroup.
+// The barrier also orders the LDS traffic of the phase that computed `v`.
+template <int W>
+struct AnyFlag {
+    int* slots;
+    int turn;
+    __device__ __forceinline__ void init(int* three_ints) {
+        slots = three_ints; turn = 0;
+        if (threadIdx.x < 3) slots[threadIdx.x] = 0;
         __syncthreads();
-        if (!block_any<W>(ch, ctl, 0)) break;
-        flatten<W>(lab, S, ctl);
+    }
+    __device__ __forceinline__ bool any(bool v) {
+        if (W == 64) { __syncthreads(); return __ballot(v) != 0ull; }
+        const int sl = turn % 3;
+        if (v) slots[sl] = 1;
+        __syncthreads();
+        const bool r = slots[sl] != 0;
+        if (threadIdx.x == 0) slots[(sl + 2) % 3] = 0;
+        ++turn;
+        return r;
+    }
+};
+
+// Every entry to its root.  The arrays are flat before a hooking round, so an entry's depth afterwards is the depth of its old
+// root in the hook forest -- a handful.  A sweep follows up to four pointers per entry (dependent LDS reads, but one barrier)
+// and reports whether anybody is still short of a root; long hook chains shrink at least fourfold per sweep.
+__device__ __forceinline__ bool dc_jump4(unsigned short* a, int y) {
+    const unsigned c = a[y];
+    const unsigned p1 = a[c];
+    if (p1 == c) return false;
+    const unsigned p2 = a[p1];
+    const unsigned p3 = a[p2];
+    a[y] = (unsigned short)p3;
+    return a[p3] != p3;
+}
+template <int W>
+__device__ __forceinline__ void dc_flatten(unsigned short* a, int S, AnyFlag<W>& af) {
+    for (int it = 0; it < 32; ++it) {
+        bool more = false;
+        for (int y = threadIdx.x; y < S; y += W) more |= dc_jump4(a, y);
+        if (!af.any(more)) break;
+    }
+}
+template <int W>
+__device__ __forceinline__ void dc_flatten2(unsigned short* a, unsigned short* b, int S, AnyFlag<W>& af) {
+    for (int it = 0; it < 32; ++it) {
+        bool more = false;
+        for (int y = threadIdx.x; y < S; y += W) { more |= dc_jump4(a, y); more |= dc_jump4(b, y); }
+        if (!af.any(more)) break;
     }
 }
 
-// The divide-and-conquer cycle swap on the subgraph in M (rank space): Pos list M.pn[0..K), Neg list from the back, ends in
-// M.dir, ascending ranks in M.arank, `finb` = bit per edge id: the edge is in the ascending pass's spanning tree (= alive at
-// the end).  `out_hin[k]` (K u16, caller's) receives the higher endpoint of the edge query k removes.  Returns false if it
-// does not apply (scratch too small) or the ranks turned out not to be an MST order; nothing the serial walk needs has been
-// touched then.
-template <int W, typename idx_t>
-__device__ __noinline__ bool ext1_dc_solve(Mem<idx_t>& M, int n, int MMcap, const unsigned* finb, unsigned char* scratch, size_t scratch_bytes,
-                              unsigned short* out_hin) {
+// Components of the forests given by two sets of marked items, as labels = the smallest id of the component, both label
+// arrays in the same sweeps.  itemsA / itemsB call edge(ab) for every edge of their forest (itemsB may be empty).  Roots hook
+// under ANY smaller neighbouring root (plain 16-bit stores: the race only decides which smaller root wins), then everything is
+// flattened; a root that survives a round is a local minimum among the roots, so the number of roots at least halves per round.
+template <int W, class ItemsA, class ItemsB>
+__device__ __forceinline__ void dc_components2(unsigned short* labA, unsigned short* labB, int S, const ItemsA& itemsA,
+                                               const ItemsB& itemsB, AnyFlag<W>& af) {
     const int tid = threadIdx.x;
-    const int K = M.ctl[3], nneg = M.ctl[4];
+    for (int x = tid; x < S; x += W) { labA[x] = (unsigned short)x; labB[x] = (unsigned short)x; }
+    __syncthreads();
+    for (int round = 0; round < 64; ++round) {
+        bool ch = false;
+        itemsA([&](unsigned ab) {
+            const unsigned ra = labA[ab >> 16], rb = labA[ab & 0xffffu];
+            if (ra < rb) { labA[rb] = (unsigned short)ra; ch = true; }
+            else if (rb < ra) { labA[ra] = (unsigned short)rb; ch = true; }
+        });
+        itemsB([&](unsigned ab) {
+            const unsigned ra = labB[ab >> 16], rb = labB[ab & 0xffffu];
+            if (ra < rb) { labB[rb] = (unsigned short)ra; ch = true; }
+            else if (rb < ra) { labB[ra] = (unsigned short)rb; ch = true; }
+        });
+        if (!af.any(ch)) break;
+        dc_flatten2<W>(labA, labB, S, af);
+    }
+}
+
+// Where the edges come from.  neg(i, ab, w, fin) -> false if item i is not a Neg edge; pos(k, ...): query k.  ab = endpoints
+// (rank space, any orientation), w = ascending rank, fin = the edge is in the ascending pass's spanning tree (alive at the end).
+// LdsSrc: the lists a tier kernel holds in LDS.  `finb` is the ascending pass's tree bitmap, indexed by ascending rank.
+struct LdsSrc {
+    const unsigned *pn, *ends, *arank, *finb;
+    int MMcap;
+    __device__ __forceinline__ bool neg(int i, unsigned& ab, unsigned& w, bool& fin) const {
+        const unsigned e = pn[MMcap - 1 - i];
+        ab = ends[e]; w = arank[e]; fin = ((finb[w >> 5] >> (w & 31)) & 1u) != 0u;
+        return true;
+    }
+    __device__ __forceinline__ void pos(int k, unsigned& ab, unsigned& w, bool& fin) const {
+        const unsigned e = pn[k];
+        ab = ends[e]; w = arank[e]; fin = ((finb[w >> 5] >> (w & 31)) & 1u) != 0u;
+    }
+};
+// HandoffSrc: the record a tier kernel left in HBM (pd_pipeline.hip, Handoff): the oriented tree -- node i hangs under
+// par[i] & 0x7fffffff behind the edge of key[i] = (rank + 1) << 8, bit 31 of par = fin; the root has key 0 -- and the queries
+// ((rank + 1) << 8 | fin) << 32 | p << 16 | q.
+struct HandoffSrc {
+    const unsigned *par, *key;
+    const ull* query;
+    __device__ __forceinline__ bool neg(int i, unsigned& ab, unsigned& w, bool& fin) const {
+        const unsigned k = key[i];
+        if (k == 0u) return false;
+        const unsigned pr = par[i];
+        ab = ((unsigned)i << 16) | (pr & 0xffffu); w = (k >> 8) - 1u; fin = (pr >> 31) != 0u;
+        return true;
+    }
+    __device__ __forceinline__ void pos(int k, unsigned& ab, unsigned& w, bool& fin) const {
+        const ull q = query[k];
+        ab = (unsigned)q; w = ((unsigned)(q >> 40)) - 1u; fin = ((q >> 32) & 1ull) != 0ull;
+    }
+};
+
+// The divide-and-conquer cycle swap: K queries, n_neg_items candidates for Neg edges (Src::neg), n nodes (rank space).
+// `out_hin[k]` (K u16, caller's) receives the higher endpoint of the edge query k removes.  ctl: 16 ints, wcnt: 32 ints of
+// LDS.  Returns false if it does not apply (scratch too small) or the ranks turned out not to be an MST order; nothing of the
+// caller's has been touched then.
+template <int W, class Src>
+__device__ __forceinline__ bool ext1_dc_solve(const Src& src, int n, int K, int n_neg_items, int* ctl, int* wcnt,
+                                              unsigned char* scratch, size_t scratch_bytes, unsigned short* out_hin,
+                                              unsigned long long* prof = nullptr) {
+    const int tid = threadIdx.x;
+    // prof (diagnostics, thread 0): [0] setup [1] MSF [2] contraction labels [3] renumber + move, cycles; [4] Boruvka rounds [5] levels
+    unsigned long long t_prev = prof ? clock64() : 0ull;
+#define DC_STAMP(k) do { if (prof && tid == 0) { const unsigned long long _t = clock64(); prof[(k)] += _t - t_prev; t_prev = _t; } } while (0)
     const int S_cap = (n > 2 * K + 2 ? n : 2 * K + 2);
     if (K < 2 || K > 16000 || S_cap > 65000 || dc_bytes(K, S_cap) > scratch_bytes) return false;
     const DcMem D = dc_carve(scratch, K, S_cap);
-    const unsigned* ends = M.dir;
-    int* ctl = M.ctl;
     int* n_pslot = &ctl[10];                      // P slots handed out so far
     int* bad = &ctl[11];
     // ---- root segment [0, K): supernodes = components of the Neg edges that are never removed -----------------------------
     if (tid == 0) { *n_pslot = 0; *bad = 0; }
-    dc_components<W>(D.labL, n, [&](auto edge) {
-        for (int k = tid; k < nneg; k += W) {
-            const unsigned e = M.pn[MMcap - 1 - k];
-            if ((finb[e >> 5] >> (e & 31)) & 1u) edge(ends[e]);
+    AnyFlag<W> af;
+    af.init(&ctl[12]);
+    dc_components2<W>(D.labL, D.labR, n, [&](auto edge) {
+        for (int i = tid; i < n_neg_items; i += W) {
+            unsigned ab, w; bool fin;
+            if (src.neg(i, ab, w, fin) && fin) edge(ab);
         }
-    }, ctl);
+    }, [&](auto) {}, af);
     for (int d = tid; d < K; d += W) D.Pseg[d] = 0xFFFFu;
     __syncthreads();
-    for (int k = tid; k < nneg; k += W) {         // Neg edges that die: P copies of the root segment
-        const unsigned e = M.pn[MMcap - 1 - k];
-        if (!((finb[e >> 5] >> (e & 31)) & 1u)) {
+    for (int i = tid; i < n_neg_items; i += W) {  // Neg edges that die: P copies of the root segment
+        unsigned ab, w; bool fin;
+        if (src.neg(i, ab, w, fin) && !fin) {
             const int d = atomicAdd(n_pslot, 1);
             if (d < K) {
-                const unsigned ab = ends[e];
-                D.Pab[d] = ((unsigned)D.labL[ab >> 16] << 16) | D.labL[ab & 0xffffu];
-                D.Pw[d] = (unsigned short)M.arank[e];
-                D.Phin[d] = (unsigned short)(ab & 0xffffu);
+                const unsigned a = ab >> 16, b = ab & 0xffffu;
+                D.Pab[d] = ((unsigned)D.labL[a] << 16) | D.labL[b];
+                D.Pw[d] = (unsigned short)w;
+                D.Phin[d] = (unsigned short)(a > b ? a : b);
                 D.Pseg[d] = 0;
             }
         }
     }
     for (int k = tid; k < K; k += W) {
-        const unsigned e = M.pn[k];
-        const unsigned ab = ends[e];
+        unsigned ab, w; bool fin;
+        src.pos(k, ab, w, fin);
         D.Qab[k] = ((unsigned)D.labL[ab >> 16] << 16) | D.labL[ab & 0xffffu];
-        D.Qw[k] = (unsigned short)M.arank[e];
-        D.Qseg[k] = (unsigned short)(((finb[e >> 5] >> (e & 31)) & 1u) ? 0x8000u : 0u);
+        D.Qw[k] = (unsigned short)w;
+        D.Qseg[k] = (unsigned short)(fin ? 0x8000u : 0u);
     }
     __syncthreads();
     // (#dying Neg + #dying Pos == K exactly when the ranks are an MST order; checked at the end through the bijection)
+    DC_STAMP(0);
     int S = n;
     int levels = 0;
     while ((1 << levels) < K) ++levels;
@@ -198,8 +301,7 @@ __device__ __noinline__ bool ext1_dc_solve(Mem<idx_t>& M, int n, int MMcap, cons
                     found = true;
                 }
             }
-            __syncthreads();
-            if (!block_any<W>(found, ctl, 0)) break;
+            if (!af.any(found)) break;
             for (int x = tid; x < S; x += W) {
                 const unsigned key = D.best[x];
                 if (key == 0xFFFFFFFFu || D.comp[x] != x) continue;
@@ -215,20 +317,22 @@ __device__ __noinline__ bool ext1_dc_solve(Mem<idx_t>& M, int n, int MMcap, cons
             for (int x = tid; x < S; x += W)
                 if (D.hook[x] != 0xFFFFu) D.comp[x] = D.hook[x];
             __syncthreads();
-            flatten<W>(D.comp, S, ctl);
+            dc_flatten<W>(D.comp, S, af);
+            if (prof && tid == 0) prof[4] += 1;
         }
+        DC_STAMP(1);
         auto in_t = [&](int code) { return ((D.inT[code >> 5] >> (code & 31)) & 1u) != 0u; };
         // ---- B. what each half contracts: left = P edges alive at mid, right = Q[l, mid) edges alive at mid and at r -----
-        dc_components<W>(D.labL, S, [&](auto edge) {
+        dc_components2<W>(D.labL, D.labR, S, [&](auto edge) {
             for (int d = tid; d < n_p; d += W)
                 if (D.Pseg[d] != 0xFFFFu && in_t(d)) edge(D.Pab[d]);
-        }, ctl);
-        dc_components<W>(D.labR, S, [&](auto edge) {
+        }, [&](auto edge) {
             for (int k = tid; k < K; k += W) {
                 const unsigned sg = D.Qseg[k];
                 if (k < mid_of(sg & 0x7FFF) && (sg & 0x8000u) && in_t(K + k)) edge(D.Qab[k]);
             }
-        }, ctl);
+        }, af);
+        DC_STAMP(2);
         // ---- C. the supernodes the children use: left copies keep [0, S), right copies move to [S, 2S) ---------------------
         unsigned short* flag = D.comp;                                    // comp | hook = 2S flags, then the new ids
         for (int x = tid; x < 2 * S; x += W) flag[x] = 0;
@@ -253,7 +357,7 @@ __device__ __noinline__ bool ext1_dc_solve(Mem<idx_t>& M, int n, int MMcap, cons
             }
         }
         __syncthreads();
-        const int S_next = block_exscan_u16<W>(flag, 2 * S, M.wcnt);
+        const int S_next = block_exscan_u16<W>(flag, 2 * S, wcnt);
         if (S_next > S_cap) { if (tid == 0) *bad = 1; __syncthreads(); break; }
         // ---- D. move every copy to its child -----------------------------------------------------------------------------------
         auto renum = [&](unsigned c) -> unsigned { return ((unsigned)flag[c >> 16] << 16) | (unsigned)flag[c & 0xffffu]; };
@@ -275,7 +379,8 @@ __device__ __noinline__ bool ext1_dc_solve(Mem<idx_t>& M, int n, int MMcap, cons
                     if (d < K) {
                         D.Pab[d] = renum(child_ab(ab, true));
                         D.Pw[d] = D.Qw[k];
-                        D.Phin[d] = (unsigned short)(ends[M.pn[k]] & 0xffffu);
+                        { unsigned qab, qw; bool qf; src.pos(k, qab, qw, qf);
+                          D.Phin[d] = (unsigned short)((qab >> 16) > (qab & 0xffffu) ? (qab >> 16) : (qab & 0xffffu)); }
                         D.Pseg[d] = (unsigned short)(2 * j + 1);
                     } else *bad = 1;
                 }
@@ -288,6 +393,8 @@ __device__ __noinline__ bool ext1_dc_solve(Mem<idx_t>& M, int n, int MMcap, cons
         }
         __syncthreads();
         S = S_next;
+        DC_STAMP(3);
+        if (prof && tid == 0) prof[5] += 1;
         if (*bad) break;
     }
     // ---- every segment is one query now: the P copy in it is the edge that query removes ----------------------------------------
@@ -309,7 +416,8 @@ __device__ __noinline__ bool ext1_dc_solve(Mem<idx_t>& M, int n, int MMcap, cons
         }
         __syncthreads();
     }
-    return !block_any<W>(fail, ctl, 0);
+#undef DC_STAMP
+    return !af.any(fail);
 }
 
 // Descending sort, equal keys: the edge with the HIGHER ascending rank first (module comment).  valS/keyS hold the sorted

@@ -859,7 +859,7 @@ struct QueryGlobal {
         cur_lo = (unsigned)c; cur_hi = (unsigned)(c >> 32);
         nxt_lo = (unsigned)x; nxt_hi = (unsigned)(x >> 32);
         n_pq = (unsigned)__builtin_amdgcn_readlane((int)cur_lo, 0);
-        n_ar = (unsigned)__builtin_amdgcn_readlane((int)cur_hi, 0);
+        n_ar = (unsigned)__builtin_amdgcn_readlane((int)cur_hi, 0) & ~0xffu;     // (bit 0: the divide and conquer's flag)
     }
     __device__ __forceinline__ void advance(int pi, int lane) {
         const int idx = pi + 1;
@@ -869,7 +869,7 @@ struct QueryGlobal {
             nxt_lo = (unsigned)x; nxt_hi = (unsigned)(x >> 32);
         }
         n_pq = (unsigned)__builtin_amdgcn_readlane((int)cur_lo, idx & 63);
-        n_ar = (unsigned)__builtin_amdgcn_readlane((int)cur_hi, idx & 63);
+        n_ar = (unsigned)__builtin_amdgcn_readlane((int)cur_hi, idx & 63) & ~0xffu;
     }
 };
 
@@ -1048,21 +1048,31 @@ __device__ __forceinline__ Handoff carve_handoff(unsigned char* slot, int NM) {
 }
 
 // The parallel half of Accelerate_PD, then everything the serial half and the image need goes to the hand-off slot.
+// finb != null: the subgraph is meant for tlc_pd_dc_kernel (hdr[6] = 1): its descending ties are fixed and the record carries,
+// per tree edge (bit 31 of par) and per query (bit 32), whether the edge is in the ascending pass's spanning tree.
 template <int W, typename idx_t>
-__device__ __forceinline__ void ext1_handoff(Mem<idx_t>& M, int n, int MMcap, int NMcap, unsigned char* slot) {
+__device__ __forceinline__ void ext1_handoff(Mem<idx_t>& M, int n, int MMcap, int NMcap, unsigned char* slot, const unsigned* finb) {
     const int tid = threadIdx.x;
     const SwapTables T = carve_swap(M.keyS, NMcap);
     const bool any_unreached = ext1_build_tree<W>(M, T, n, MMcap, NMcap);
     const Handoff H = carve_handoff(slot, NMcap);
     const int npos = M.ctl[3], np0 = M.ctl[2];
-    for (int i = tid; i < n; i += W) { H.f[i] = M.f[i]; H.par[i] = T.par[i]; H.key[i] = T.key[i]; }
+    auto fin_of = [&](unsigned rank) -> unsigned { return finb ? ((finb[rank >> 5] >> (rank & 31)) & 1u) : 0u; };
+    for (int i = tid; i < n; i += W) {
+        const unsigned k = T.key[i];
+        H.f[i] = M.f[i];
+        H.par[i] = T.par[i] | ((k != 0u && fin_of((k >> 8) - 1u)) ? 0x80000000u : 0u);
+        H.key[i] = k;
+    }
     for (int i = tid; i < np0; i += W) H.pts[i] = M.pts[i];
     for (int k = tid; k < npos; k += W) {
         const unsigned e = M.pn[k];
-        H.query[k] = ((ull)((M.arank[e] + 1u) << 8) << 32) | (ull)M.dir[e];
+        const unsigned ar = M.arank[e];
+        H.query[k] = ((ull)(((ar + 1u) << 8) | fin_of(ar)) << 32) | (ull)M.dir[e];
     }
     if (tid == 0) {
         H.hdr[1] = n; H.hdr[2] = npos; H.hdr[3] = np0; H.hdr[4] = M.ctl[6]; H.hdr[5] = any_unreached ? 1 : 0;
+        H.hdr[6] = (finb != nullptr && !any_unreached) ? 1 : 0;
         H.hdr[0] = 1;
     }
     __syncthreads();
@@ -1078,8 +1088,9 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
         const int K = M.ctl[3];
         const size_t hin_bytes = al16((size_t)K * 2);
         unsigned short* hin = (unsigned short*)(M.xbase + (M.xbytes - hin_bytes));
+        const LdsSrc src{M.pn, M.dir, M.arank, (const unsigned*)M.rec, MMcap};
         const bool ok = M.xbytes > hin_bytes &&
-                        ext1_dc_solve<W>(M, n, MMcap, (const unsigned*)M.rec, M.xbase, M.xbytes - hin_bytes, hin);
+                        ext1_dc_solve<W>(src, n, K, M.ctl[4], M.ctl, M.wcnt, M.xbase, M.xbytes - hin_bytes, hin);
         if (threadIdx.x == 0 && M.stats) atomicAdd(&M.stats[ok ? 1 : 3], 1ull);
 #ifdef TLC_DC_VERIFY
         if (ok && (size_t)(M.ctl[2] + K) * 4 + (size_t)K * 2 + 16 <= (size_t)(MMcap + 2) * 4) {
@@ -1148,7 +1159,7 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
 template <int W, typename idx_t, class Sink>
 __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, int m, unsigned flags, int MMcap, int NMcap,
                                             ull* pc, ull& t_prev, ull* ph, unsigned char* slot, bool& deferred,
-                                            bool allow_dc = false) {
+                                            int dc_mode = 0, bool handoff_all = true) {
     relabel_by_rank<W>(M, n, m);
     sort_edges<W, idx_t, false>(M, m);
     for (int pos = threadIdx.x; pos < m; pos += W) M.arank[M.valS[pos]] = (unsigned)pos;
@@ -1165,13 +1176,14 @@ __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, i
     // Many Pos edges (m - n + 1 of them in a connected graph): the cycle swap runs as a divide and conquer (ext1_dc.h), which
     // needs the ascending pass's spanning tree per edge id -- kept in M.rec, the serial walk's record area -- and the descending
     // order with its ties fixed
-    bool dc = allow_dc && !(flags & TLC_NO_EXT1) && (m - n + 1) >= TLC_DC_MIN_POS && m <= 8 * W && m < 65536 && (size_t)((m + 31) / 32) * 4 <= 1280;
+    // dc_mode 1: here, in this workgroup (LARGE: a CU to itself);  2: through the hand-off record, by tlc_pd_dc_kernel
+    const int k_pos = m - n + 1;
+    bool dc = dc_mode != 0 && !(flags & TLC_NO_EXT1) && k_pos >= (W >= 512 ? TLC_DC_MIN_POS : TLC_DC_MIN_POS_SHARED) && m <= 8 * W &&
+              m < 65536 && (size_t)((m + 31) / 32) * 4 <= 1280 && (dc_mode == 1 || slot != nullptr) &&
+              (dc_mode == 2 || dc_bytes(k_pos, n > 2 * k_pos + 2 ? n : 2 * k_pos + 2) + al16((size_t)k_pos * 2) < M.xbytes);
     if (dc) {
-        unsigned* finb = (unsigned*)M.rec;
-        for (int w = threadIdx.x; w < (m + 31) / 32; w += W) finb[w] = 0u;
-        __syncthreads();
-        for (int pos = threadIdx.x; pos < m; pos += W)
-            if ((M.tbits[pos >> 5] >> (pos & 31)) & 1u) { const unsigned e = M.valS[pos]; atomicOr(&finb[e >> 5], 1u << (e & 31)); }
+        unsigned* finb = (unsigned*)M.rec;                            // the tree bitmap is indexed by ascending position = rank
+        for (int w = threadIdx.x; w < (m + 31) / 32; w += W) finb[w] = M.tbits[w];
         __syncthreads();
     }
     sort_edges<W, idx_t, true>(M, m);
@@ -1184,11 +1196,11 @@ __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, i
     int status = TLC_ST_OK;
     if (!(flags & TLC_NO_EXT1)) {
         if (M.ctl[4] == 0) status = TLC_ST_NO_TREE_EDGE;              // list(Nodes)[0] -> IndexError (:122)
-        else if (slot != nullptr && M.ctl[3] > 0) {
-            ext1_handoff<W>(M, n, MMcap, NMcap, slot);
+        else if (slot != nullptr && M.ctl[3] > 0 && (handoff_all || (dc && dc_mode == 2 && M.ctl[3] == k_pos))) {
+            ext1_handoff<W>(M, n, MMcap, NMcap, slot, (dc && dc_mode == 2 && M.ctl[3] == k_pos) ? (const unsigned*)M.rec : nullptr);
             deferred = true;
             TLC_STAMP(9);
-        } else ext1_stage<W>(M, sink, n, flags, MMcap, NMcap, pc, t_prev, ph, dc && M.ctl[3] == m - n + 1);
+        } else ext1_stage<W>(M, sink, n, flags, MMcap, NMcap, pc, t_prev, ph, dc && dc_mode == 1 && M.ctl[3] == k_pos);
     }
     return status;
 }
@@ -1572,7 +1584,12 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
             PtsSink sink{M.pts, M.ctl};
             TLC_STAMP(4);
             status = pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, slot, deferred,
-                                      /*allow_dc=*/NM == TLC_L_NMAX && !HUGE);
+                                      /*dc_mode=*/(!HUGE && NM == TLC_L_NMAX) ? TLC_DC_LARGE_MODE : 0,
+                                      /*handoff_all=*/NM != TLC_L_NMAX);
+            if (deferred && slot && tid == 0 && p.dc_count && ((const int*)slot)[6] != 0) {
+                const int li = atomicAdd(p.dc_count, 1);              // meant for tlc_pd_dc_kernel
+                p.dc_list[li] = wi;
+            }
             if (status == TLC_ST_OK && !deferred) {
                 const int np = M.ctl[2], n_up = M.ctl[6];
                 auto get = [&](int k, double& b, double& d) {
@@ -1629,18 +1646,14 @@ __host__ __device__ constexpr SwapLayout make_swap_layout(int NM, int MM) {
     return L;
 }
 
-template <int NM, int MM>
-__global__ __launch_bounds__(64, 4) void tlc_pd_swap_kernel(TlcPdParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+// The serial cycle swap + the image of the handed-off subgraph at list position wi; W threads (the walk itself is the first
+// wavefront's), LDS as make_swap_layout(NM, MM).
+template <int NM, int MM, int W>
+__device__ __forceinline__ void swap_subgraph(const TlcPdParams& p, int wi, unsigned char* lds_raw) {
     constexpr SwapLayout L = make_swap_layout(NM, MM);
     const int tid = threadIdx.x;
-    if (p.abort_flag && *p.abort_flag) return;
-    int tier_count = p.tier_count;
-    if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
-    if (tier_count > p.handoff_cap) tier_count = p.handoff_cap;       // (list positions beyond it were not handed off)
-    for (int wi = blockIdx.x; wi < tier_count; wi += gridDim.x) {     // (one subgraph per workgroup unless the grid was capped)
     const Handoff H = carve_handoff(p.handoff + (size_t)wi * (size_t)p.handoff_stride, NM);
-    if (H.hdr[0] == 0) continue;                                      // finished by the tier kernel itself
+    if (H.hdr[0] == 0) return;                                        // finished by the tier kernel itself
     const int i = p.tier_list[wi];
     const int n = H.hdr[1], npos = H.hdr[2], np0 = H.hdr[3], n_up = H.hdr[4];
     const bool any_unreached = H.hdr[5] != 0;
@@ -1651,17 +1664,21 @@ __global__ __launch_bounds__(64, 4) void tlc_pd_swap_kernel(TlcPdParams p) {
 #ifdef TLC_PHASE_DEBUG
     const ull t_begin = clock64();
 #endif
-    for (int k = tid; k < n; k += 64) { T.par[k] = H.par[k]; T.key[k] = H.key[k]; T.mark[k] = 0u; }
-    for (int k = tid; k < np0; k += 64) pts[k] = H.pts[k];
+    for (int k = tid; k < n; k += W) { T.par[k] = H.par[k] & 0x7fffffffu; T.key[k] = H.key[k]; T.mark[k] = 0u; }
+    for (int k = tid; k < np0; k += W) pts[k] = H.pts[k];
     if (tid == 0) { T.par[NM] = (unsigned)NM; T.key[NM] = 0u; T.mark[NM] = 0u; }
     __syncthreads();
     PtsSink sink{pts, ctl};
-    QueryGlobal qs{H.query, npos, 0u, 0u, 0u, 0u, 0u, 0u};
-    const int np = np0 + ext1_walk(T, recs, qs, npos, NM, any_unreached, sink, (const double*)nullptr, false, np0, nullptr);
+    if (tid < 64) {
+        QueryGlobal qs{H.query, npos, 0u, 0u, 0u, 0u, 0u, 0u};
+        const int n_out = ext1_walk(T, recs, qs, npos, NM, any_unreached, sink, (const double*)nullptr, false, np0, nullptr);
+        if (tid == 0) ctl[2] = np0 + n_out;
+    }
     __syncthreads();
+    const int np = ctl[2];
     // the tables are dead: f and the image table take their place
     double* f = (double*)lds_raw;
-    for (int k = tid; k < n; k += 64) f[k] = H.f[k];
+    for (int k = tid; k < n; k += W) f[k] = H.f[k];
     __syncthreads();
     auto get = [&](int k, double& b, double& d) {
         const unsigned bd = pts[k];
@@ -1672,10 +1689,10 @@ __global__ __launch_bounds__(64, 4) void tlc_pd_swap_kernel(TlcPdParams p) {
     double* table = (double*)(lds_raw + (size_t)8 * NM);
     double acc = 0.0;
     if (p.flags & TLC_PI_ORD0_EXT1) {
-        acc = pi_stage<64, true, 64>(table, L.table_bytes, get, 0, n_up, res, acc);
-        acc = pi_stage<64, true, 64>(table, L.table_bytes, get, n_up + 1, np, res, acc);
+        acc = pi_stage<W, true, 64>(table, L.table_bytes, get, 0, n_up, res, acc);
+        acc = pi_stage<W, true, 64>(table, L.table_bytes, get, n_up + 1, np, res, acc);
     } else {
-        acc = pi_stage<64, true, 64>(table, L.table_bytes, get, 0, np, res, acc);
+        acc = pi_stage<W, true, 64>(table, L.table_bytes, get, 0, np, res, acc);
     }
     if (p.out_pi && tid < res2) p.out_pi[(size_t)i * res2 + tid] = acc;
     if (p.out_status && tid == 0) p.out_status[i] = (unsigned char)TLC_ST_OK;
@@ -1683,6 +1700,106 @@ __global__ __launch_bounds__(64, 4) void tlc_pd_swap_kernel(TlcPdParams p) {
     if (p.phase_cycles && tid == 0) { atomicAdd(&p.phase_cycles[10], clock64() - t_begin); atomicAdd(&p.phase_cycles[12], clock64() - t_begin); }
 #endif
     __syncthreads();
+}
+
+template <int NM, int MM>
+__global__ __launch_bounds__(64, 4) void tlc_pd_swap_kernel(TlcPdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (p.abort_flag && *p.abort_flag) return;
+    int tier_count = p.tier_count;
+    if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
+    if (tier_count > p.handoff_cap) tier_count = p.handoff_cap;       // (list positions beyond it were not handed off)
+    for (int wi = blockIdx.x; wi < tier_count; wi += gridDim.x)       // (one subgraph per workgroup unless the grid was capped)
+        swap_subgraph<NM, MM, 64>(p, wi, lds_raw);
+}
+
+// ======================================================================================================================
+// The cycle swap of the subgraphs with MANY Pos edges as a divide and conquer (ext1_dc.h), from the hand-off record, then the
+// image.  One workgroup of W threads per subgraph; runs between a tier kernel and its tlc_pd_swap_kernel on the same stream.
+// A record it finishes is marked "nothing pending"; whatever it does not take (few Pos edges, not marked for it, does not fit
+// its LDS budget, or -- rounding of nearly equal keys -- the ranks turn out not to be an MST order) stays for the serial kernel.
+// ======================================================================================================================
+__host__ __device__ constexpr size_t dc_kernel_lds(int NM, int MM) {
+    // LDS budget: the solver's arrays for a subgraph of the tier's typical heavy shape (K = MM/2 queries on NM nodes), the
+    // answers, the points; f and the image table re-use the solver's arrays afterwards
+    const size_t dc = al16(dc_bytes(MM / 2, NM > MM + 2 ? NM : MM + 2) + (size_t)MM + 16) + al16((size_t)(MM + 2) * 4) + 256;
+    return dc > make_swap_layout(NM, MM).total ? dc : make_swap_layout(NM, MM).total;     // (the serial fallback's layout fits too)
+}
+template <int NM, int MM, int W>
+__global__ __launch_bounds__(W, (W <= 256 ? 4 : 1)) void tlc_pd_dc_kernel(TlcPdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr size_t total = dc_kernel_lds(NM, MM);
+    constexpr size_t o_pts = total - 256 - al16((size_t)(MM + 2) * 4), o_ctl = total - 256;
+    const int tid = threadIdx.x;
+    if (p.abort_flag && *p.abort_flag) return;
+    int tier_count = p.tier_count;
+    if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
+    if (tier_count > p.handoff_cap) tier_count = p.handoff_cap;
+    unsigned* pts = (unsigned*)(lds_raw + o_pts);
+    int* ctl = (int*)(lds_raw + o_ctl);               // 16 ints, then 32 ints for block scans
+    int* wcnt = ctl + 16;
+    // a chain of short barrier-separated phases: its wavefronts should win issue arbitration against the throughput kernels
+    // of the other tiers that share the CU
+    __builtin_amdgcn_s_setprio(3);
+    const int n_list = p.dc_count ? *p.dc_count : 0;
+    for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const int wi = p.dc_list[li];
+        if (wi < 0 || wi >= tier_count) continue;
+        const Handoff H = carve_handoff(p.handoff + (size_t)wi * (size_t)p.handoff_stride, NM);
+        if (H.hdr[0] == 0 || H.hdr[6] == 0) continue;                 // finished by the tier kernel / not meant for this kernel
+        const int i = p.tier_list[wi];
+        const int n = H.hdr[1], K = H.hdr[2], np0 = H.hdr[3], n_up = H.hdr[4];
+        const size_t hin_bytes = al16((size_t)K * 2);
+        // what the divide and conquer cannot take (does not fit, or the ranks are no MST order): the serial walk, here
+        if (hin_bytes + 16 >= o_pts || np0 + K > MM + 2) { __syncthreads(); swap_subgraph<NM, MM, W>(p, wi, lds_raw); continue; }
+        unsigned short* hin = (unsigned short*)(lds_raw + (o_pts - hin_bytes));
+        const HandoffSrc src{H.par, H.key, H.query};
+        __syncthreads();
+        unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned long long t_begin = p.phase_cycles ? clock64() : 0ull;
+        const bool ok = ext1_dc_solve<W>(src, n, K, n, ctl, wcnt, lds_raw, o_pts - hin_bytes, hin, p.phase_cycles ? prof : nullptr);
+        if (p.phase_cycles && tid == 0) {                             // diagnostics: the slowest subgraph's split
+            const unsigned long long tot = clock64() - t_begin;
+            if (atomicMax(&p.phase_cycles[13], tot) < tot) {
+                for (int k = 0; k < 6; ++k) p.phase_cycles[16 + k] = prof[k];
+                p.phase_cycles[22] = tot; p.phase_cycles[28] = (unsigned long long)n; p.phase_cycles[29] = (unsigned long long)K;
+            }
+        }
+        if (!ok) {
+            if (p.stats && tid == 0) atomicAdd(&p.stats[3], 1ull);
+            __syncthreads();
+            swap_subgraph<NM, MM, W>(p, wi, lds_raw);
+            continue;
+        }
+        if (p.stats && tid == 0) atomicAdd(&p.stats[1], 1ull);
+        for (int k = tid; k < np0; k += W) pts[k] = H.pts[k];
+        for (int k = tid; k < K; k += W) pts[np0 + k] = (((unsigned)(H.query[k] >> 16) & 0xffffu) << 16) | (unsigned)hin[k];
+        __syncthreads();
+        // the solver's arrays are dead: f and the image table take their place (same slicing as tlc_pd_swap_kernel: same bits)
+        double* f = (double*)lds_raw;
+        for (int k = tid; k < n; k += W) f[k] = H.f[k];
+        __syncthreads();
+        auto get = [&](int k, double& b, double& d) {
+            const unsigned bd = pts[k];
+            b = f[bd >> 16];
+            d = f[bd & 0xffffu];
+        };
+        const int res = p.res, res2 = res * res, np = np0 + K;
+        double* table = (double*)(lds_raw + al16((size_t)8 * n));
+        const size_t table_bytes = (o_pts - hin_bytes) - al16((size_t)8 * n);
+        double acc = 0.0;
+        if (p.flags & TLC_PI_ORD0_EXT1) {
+            acc = pi_stage<W, true, 64>(table, table_bytes, get, 0, n_up, res, acc);
+            acc = pi_stage<W, true, 64>(table, table_bytes, get, n_up + 1, np, res, acc);
+        } else {
+            acc = pi_stage<W, true, 64>(table, table_bytes, get, 0, np, res, acc);
+        }
+        if (p.out_pi && tid < res2) p.out_pi[(size_t)i * res2 + tid] = acc;
+        if (tid == 0) {
+            if (p.out_status) p.out_status[i] = (unsigned char)TLC_ST_OK;
+            H.hdr[0] = 0;                                             // nothing pending for tlc_pd_swap_kernel
+        }
+        __syncthreads();
     }
 }
 
@@ -1724,7 +1841,7 @@ __global__ __launch_bounds__(W) void tlc_pdf_tier_kernel(TlcPdfParams p) {
         if (m > 0) {
             bool deferred = false;
             pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, nullptr, deferred,
-                             /*allow_dc=*/NM == TLC_L_NMAX && !HUGE);
+                             /*dc_mode=*/(NM == TLC_L_NMAX && !HUGE) ? 1 : 0);
         } else if (tid == 0) {
             double mn = 99999999.0, mx = -99999999.0;
             for (int k = 0; k < n; ++k) { mn = M.f[k] < mn ? M.f[k] : mn; mx = M.f[k] > mx ? M.f[k] : mx; }
@@ -2000,8 +2117,10 @@ size_t tlc_handoff_slot_bytes(int tier) {
     switch (tier) {
         case TLC_TIER_MID: return handoff_bytes(TLC_D_NMAX, TLC_D_MMAX);
         case TLC_TIER_MEDIUM: return handoff_bytes(TLC_M_NMAX, TLC_M_MMAX);
-        // (LARGE keeps its cycle swap: its subgraphs are few and the batch waits for the slowest of them, which runs
-        // fastest with a CU to itself -- measured 0.91 vs 1.07 ms with the swap in the shared one-wavefront kernel)
+        // (LARGE keeps the serial cycle swap of its subgraphs with few Pos edges: they are few and the batch waits for the
+        // slowest of them, which runs fastest with a CU to itself -- measured 0.91 vs 1.07 ms with the swap in the shared
+        // one-wavefront kernel; only the subgraphs meant for tlc_pd_dc_kernel are handed off, into a buffer of their own)
+        case TLC_TIER_LARGE: return TLC_DC_LARGE_MODE == 2 ? handoff_bytes(TLC_L_NMAX, TLC_L_MMAX) : 0;
         default: return 0;
     }
 }
@@ -2057,10 +2176,15 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>), dim3(p.tier_count),
                                dim3(TLC_L_THREADS), lds_bytes, s, p);
             if (deferring) {
+                // (only the subgraphs marked for the divide and conquer were handed off; the serial kernel is their fallback)
                 constexpr SwapLayout SL = make_swap_layout(TLC_L_NMAX, TLC_L_MMAX);
-                rc = set_lds_limit(tlc_pd_swap_kernel<TLC_L_NMAX, TLC_L_MMAX>, SL.total);
+                // (like the tier kernel: the whole CU's LDS, so that no throughput workgroup shares the CU with the longest chain)
+                constexpr size_t dcl = dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX) > 156 * 1024 ? dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX) : 156 * 1024;
+                rc = set_lds_limit(tlc_pd_dc_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS>, dcl);
                 if (rc) return rc;
-                hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_L_NMAX, TLC_L_MMAX>), dim3(p.tier_count), dim3(64), SL.total, s, p);
+                if (p.dc_count)
+                    hipLaunchKernelGGL((tlc_pd_dc_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS>), dim3(p.tier_count < 128 ? p.tier_count : 128),
+                                       dim3(TLC_L_THREADS), dcl, s, p);
             }
             break;
         }
