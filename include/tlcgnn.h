@@ -113,7 +113,8 @@ int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int64_t n_pair
 
 /* Counters of the last tlc_pd_pi_batch on this handle (synchronises the stream):
  * h_out[0..3] = pairs in tier small / medium / large / huge, [4] = induced directed entries (arena size),
- * [5] = sources that needed the exact tie fallback, [6] = chunks, [7] = pairs in tier mid (between small and medium). */
+ * [5] = sources that needed the exact tie fallback, [6] = chunks, [7] = pairs in tier mid (between small and medium),
+ * [8] = pairs of tier small that took the lane-per-subgraph kernel (at most 16 nodes / 24 edges), [9] = pairs of tier medium with many Pos edges (launched first).  h_out: 10 entries. */
 int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream);
 
 /* Measurement helpers used by bench.py (no reference counterpart: the reference only prints time.time() deltas,

@@ -5,6 +5,7 @@
 //   counts] -> FILL (induced subgraphs into the arena) -> one PD kernel per size tier, the tiers running
 //   concurrently on side streams so that the few large subgraphs overlap the many small ones.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <new>
@@ -32,7 +33,7 @@ extern "C" int tlc_device_count(void) {
 }
 
 #define TLC_CHUNK_PAIRS (1 << 20)
-#define TLC_N_SIDE 5
+#define TLC_N_SIDE 7
 // early pass (run_chunk): at most this many predicted-heavy pairs are counted ahead of the batch, at most this many LARGE-tier
 // vicinities among them get a slot of the early arena (12 B x 2*TLC_L_MMAX entries each)
 #define TLC_EARLY_CAND 512
@@ -107,7 +108,7 @@ struct tlc_graph {
     size_t huge_stride;
     hipStream_t side[TLC_N_SIDE];
     hipEvent_t ev_fork, ev_join[TLC_N_SIDE];
-    long long last_stats[8];
+    long long last_stats[10];
     unsigned long long* d_phase;   // diagnostics: [TLC_N_TIERS][32] cycle counters, null unless enabled
     // optional per-kernel timing (tlc_pd_pi_batch_set_timing): events bracket each launch on its own stream
     int timing;
@@ -291,7 +292,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     for (int k = 0; k < TLC_N_SIDE; ++k) {
         // side[1] carries the heavy tiers (the critical path): highest priority; side[2] (MEDIUM, the second longest
         // chain) sits between it and side[0] (SMALL, which only has to finish before the other two do)
-        const int prio = (k == 1 || k == 4) ? prio_hi : (k >= 2 ? (prio_lo + prio_hi) / 2 : prio_lo);
+        const int prio = (k == 1 || k == 4) ? prio_hi : (((k >= 2 && k <= 3) || k == 6) ? (prio_lo + prio_hi) / 2 : prio_lo);
         CK(hipStreamCreateWithPriority(&g->side[k], hipStreamNonBlocking, prio));
         CK(hipEventCreateWithFlags(&g->ev_join[k], hipEventDisableTiming));
     }
@@ -506,6 +507,9 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     sp.n_pairs = n_pairs; sp.hdr_n = g->hdr_n; sp.hdr_m2 = g->hdr_m2;
     sp.block_agg = g->d_block_sums; sp.block_flag = g->d_ctl + 64; sp.sync = g->d_ctl + 10; sp.totals = g->d_totals;
     sp.edge_off = g->edge_off; sp.tier_count = g->d_ctl; sp.tier_list = g->tier_list; sp.small_arena = 1;
+    // the plain TLC-GNN image batch at resolution 5: the smallest vicinities go to the lane-per-subgraph kernel (pd_tiny.hip)
+    static const bool tiny_env_off = getenv("TLC_TINY") && getenv("TLC_TINY")[0] == '0';        // (development switch)
+    sp.tiny_ok = (!tiny_env_off && pi_enabled && flags == 0u && res == 5 && !d_out_ids && !d_out_f && !d_out_edges) ? 1 : 0;
     sp.early_list = early ? g->d_early_list : nullptr; sp.early_count = d_early_count; sp.early_cap = TLC_EARLY_SLOTS;
     sp.h_early = const_cast<int*>(&g->h_sync_dev->pub_early);
     sp.bump_top = bump ? d_bump_top : nullptr; sp.bump_overflow = d_bump_overflow;
@@ -527,15 +531,18 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     // previous chunk: the ~50 us the host needs to see the published sizes and issue a dozen launch calls are no longer
     // between the scan and the batch's second-longest chain.  If COUNT overflowed the arena the kernels return at once
     // (abort flag) and the chunk is redone below.
-    static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7};   // timing slot of each tier kernel
-    bool used[TLC_N_SIDE] = {false, false, false, false, early};
+    static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4};   // timing slot of each tier kernel (TINY is reported with SMALL, MEDHI as MEDIUM)
+    bool used[TLC_N_SIDE] = {false, false, false, false, early, false, false};
     const bool spec = bump;
-    size_t spec_base[TLC_N_TIERS] = {0, 0, 0, 0, 0};
-    int spec_cap[TLC_N_TIERS] = {0, 0, 0, 0, 0};
+    size_t spec_base[TLC_N_TIERS] = {0, 0, 0, 0, 0, 0, 0};
+    int spec_cap[TLC_N_TIERS] = {0, 0, 0, 0, 0, 0, 0};
     if (spec) {
         spec_cap[TLC_TIER_MID] = std::min(n_pairs, std::max(4096, g->prev_tc[TLC_TIER_MID] + g->prev_tc[TLC_TIER_MID] / 4));
         spec_cap[TLC_TIER_MEDIUM] = std::min(n_pairs, std::max(2048, g->prev_tc[TLC_TIER_MEDIUM] + g->prev_tc[TLC_TIER_MEDIUM] / 4));
-        spec_base[TLC_TIER_MEDIUM] = (size_t)spec_cap[TLC_TIER_MID] * tlc_handoff_slot_bytes(TLC_TIER_MID);
+        spec_cap[TLC_TIER_MEDHI] = std::min(n_pairs, std::max(1024, g->prev_tc[TLC_TIER_MEDHI] + g->prev_tc[TLC_TIER_MEDHI] / 4));
+        // hand-off buffer: [MID | MEDHI (speculative launch) | MEDIUM]
+        spec_base[TLC_TIER_MEDHI] = (size_t)spec_cap[TLC_TIER_MID] * tlc_handoff_slot_bytes(TLC_TIER_MID);
+        spec_base[TLC_TIER_MEDIUM] = spec_base[TLC_TIER_MEDHI] + (size_t)spec_cap[TLC_TIER_MEDHI] * tlc_handoff_slot_bytes(TLC_TIER_MEDHI);
         if ((rc = ensure_handoff(g, spec_base[TLC_TIER_MEDIUM] +
                                         (size_t)spec_cap[TLC_TIER_MEDIUM] * tlc_handoff_slot_bytes(TLC_TIER_MEDIUM))) != TLC_OK) return rc;
         pp.A_dir = g->A_dir; pp.A_lw = g->A_lw;
@@ -544,15 +551,15 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         // streams onto 4 by default: measured, the scan then started 0.1 ms late and took 55 instead of 11 us.)  The fork
         // point of the side-stream launches below is the event recorded here, ahead of these kernels.
         TLC_HIP_CHECK(hipEventRecord(g->ev_scan, s));
-        // (only the MEDIUM tier, the longer chain: kernels on one stream do not overlap, and the MID tier's pair of kernels
-        // between the MEDIUM tier kernel and its swap kernel cost more than the host round trip saves -- measured)
+        // (only the MEDIUM-sized vicinities with many Pos edges, whose tier kernel + long serial swaps are the longest chain of
+        // the small tiers: kernels on one stream do not overlap, and another tier's pair of kernels between that tier kernel and
+        // its swap kernel costs more than the host round trip saves -- measured)
         {
-            const int t = TLC_TIER_MEDIUM;
+            const int t = TLC_TIER_MEDHI;
             pp.tier_list = g->tier_list + (size_t)t * n_pairs; pp.tier_count = n_pairs; pp.tier_count_dev = g->d_ctl + t;
             pp.grid = spec_cap[t]; pp.handoff_cap = spec_cap[t]; pp.phase = 0;
             pp.handoff = g->handoff + spec_base[t]; pp.handoff_stride = (long long)tlc_handoff_slot_bytes(t);
             pp.abort_flag = d_bump_overflow;
-            dc_lists_for(pp, 0);
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
             T0(tslot[t], s);
             if ((rc = tlc_launch_pd_tier(t, pp, s)) != TLC_OK) return rc;
@@ -587,9 +594,9 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     if (tc[TLC_TIER_HUGE] > 0 && (rc = ensure_huge(g)) != TLC_OK) return rc;
 
     const int n_early = early ? g->h_sync->pub_early : 0;
-    const int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4];
+    const int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4] + tc[5] + tc[6];
     const bool spec_done = spec && bumped;          // the MID / MEDIUM tiers are already running
-    g->prev_tc[TLC_TIER_MID] = tc[TLC_TIER_MID]; g->prev_tc[TLC_TIER_MEDIUM] = tc[TLC_TIER_MEDIUM];
+    g->prev_tc[TLC_TIER_MID] = tc[TLC_TIER_MID]; g->prev_tc[TLC_TIER_MEDIUM] = tc[TLC_TIER_MEDIUM]; g->prev_tc[TLC_TIER_MEDHI] = tc[TLC_TIER_MEDHI];
     if (todo > 0) {
         vp.A_dir = g->A_dir; vp.A_lw = g->A_lw;
         pp.A_dir = g->A_dir; pp.A_lw = g->A_lw;
@@ -597,7 +604,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         pp.huge_nmax = std::min(g->n_nodes, TLC_MAX_SUBGRAPH_NODES); pp.huge_mmax = (int)std::min<long long>(g->nnz / 2 + 1, TLC_MAX_SUBGRAPH_EDGES); pp.huge_slots = g->huge_slots;
         pp.started = (int*)(g->d_stats + 2);
         // hand-off slots (images only): the tiers with long serial tails run their cycle swap in a second, one-wavefront kernel
-        size_t hand_base[TLC_N_TIERS] = {0, 0, 0, 0, 0};
+        size_t hand_base[TLC_N_TIERS] = {0, 0, 0, 0, 0, 0, 0};
         if (pi_enabled && !spec_done) {
             size_t hand_total = 0;
             for (int t = 0; t < TLC_N_TIERS; ++t) {
@@ -607,9 +614,11 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
             }
             if ((rc = ensure_handoff(g, hand_total)) != TLC_OK) return rc;
         } else if (pi_enabled) {
-            // the speculative MEDIUM launch in flight owns [spec_base, ...) of the buffer, which must not move: the MID tier's
-            // slots were reserved in front of it for spec_cap[MID] subgraphs; beyond that the tier runs its cycle swap itself
+            // the speculative launch in flight owns its part of the buffer, which must not move: the MID tier's slots were
+            // reserved in front of it and the MEDIUM tier's behind it, for spec_cap[] subgraphs each; beyond that a tier runs
+            // its cycle swap itself
             hand_base[TLC_TIER_MID] = 0;
+            hand_base[TLC_TIER_MEDIUM] = spec_base[TLC_TIER_MEDIUM];
         }
         // (`behind_s`: the launch depends on what was just submitted to s, e.g. a FILL; else only on the scan)
         auto launch_side = [&](int k, int t, bool behind_s = true) -> int {
@@ -623,9 +632,8 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
             const size_t hs = pi_enabled ? tlc_handoff_slot_bytes(t) : 0;
             pp.handoff = hs ? g->handoff + hand_base[t] : nullptr;
             pp.handoff_stride = (long long)hs;
-            pp.handoff_cap = (spec_done && t == TLC_TIER_MID) ? std::min(tc[t], spec_cap[t]) : tc[t];
+            pp.handoff_cap = (spec_done && (t == TLC_TIER_MID || t == TLC_TIER_MEDIUM)) ? std::min(tc[t], spec_cap[t]) : tc[t];
             pp.dc_count = pp.dcf_count = nullptr; pp.dc_list = pp.dcf_list = nullptr;
-            if (t == TLC_TIER_MEDIUM) dc_lists_for(pp, 0);
             if (t == TLC_TIER_LARGE) dc_lists_for(pp, 1);
             if (hs && t == TLC_TIER_LARGE) {
                 // (the early launch may still be using the first TLC_EARLY_SLOTS slots: this launch takes the ones behind them)
@@ -635,7 +643,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
             }
             pp.grid = 0; pp.phase = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
-            const bool timed = !(early && t == TLC_TIER_LARGE);     // (that slot times the early launch)
+            const bool timed = !(early && t == TLC_TIER_LARGE) && t != TLC_TIER_MEDIUM;   // (those slots time the early launch / MEDHI)
             if (timed) T0(tslot[t], g->side[k]);
             int r = tlc_launch_pd_tier(t, pp, g->side[k]);
             if (r != TLC_OK) return r;
@@ -670,16 +678,32 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         }
         // 0. the SMALL tier needs nothing more (its subgraphs were written by the COUNT pass); it is submitted after the
         //    heavy chain so that its many workgroups do not delay that chain's start
+        // the lower end of the SMALL tier first: one lane per subgraph, a few hundred latency-bound wavefronts that need 66 KB of
+        // LDS each -- they must find room before the other tiers' workgroups take it
+        if (tc[TLC_TIER_TINY] > 0) {
+            if (spec_done) { TLC_HIP_CHECK(hipStreamWaitEvent(g->side[5], g->ev_scan, 0)); }
+            else { TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s)); TLC_HIP_CHECK(hipStreamWaitEvent(g->side[5], g->ev_fork, 0)); }
+            pp.tier_list = g->tier_list + (size_t)TLC_TIER_TINY * n_pairs; pp.tier_count = tc[TLC_TIER_TINY];
+            pp.handoff = nullptr; pp.handoff_stride = 0; pp.handoff_cap = 0; pp.grid = 0; pp.phase = 0;
+            pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
+            pp.dc_count = pp.dcf_count = nullptr; pp.dc_list = pp.dcf_list = nullptr;
+            pp.phase_cycles = g->d_phase ? g->d_phase + 32 * TLC_TIER_TINY : nullptr;
+            if ((rc = tlc_launch_pd_tiny(pp, g->side[5])) != TLC_OK) return rc;
+            TLC_HIP_CHECK(hipEventRecord(g->ev_join[5], g->side[5]));
+            used[5] = true;
+        }
         if (tc[TLC_TIER_SMALL] > 0 && (rc = launch_side(0, TLC_TIER_SMALL, false)) != TLC_OK) return rc;
+
         // 2. the MEDIUM tier
-        if (tc[TLC_TIER_MEDIUM] + tc[TLC_TIER_MID] > 0) {
+        if (tc[TLC_TIER_MEDIUM] + tc[TLC_TIER_MEDHI] + tc[TLC_TIER_MID] > 0) {
             if (!bumped) {
                 vp.fill_mode = (heavy > 0 || n_early > 0) ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
                 hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
                 TLC_HIP_CHECK(hipGetLastError());
             }
             T1(2, s);
-            if (!spec_done && tc[TLC_TIER_MEDIUM] > 0 && (rc = launch_side(2, TLC_TIER_MEDIUM)) != TLC_OK) return rc;
+            if (!spec_done && tc[TLC_TIER_MEDHI] > 0 && (rc = launch_side(2, TLC_TIER_MEDHI)) != TLC_OK) return rc;
+            if (tc[TLC_TIER_MEDIUM] > 0 && (rc = launch_side(6, TLC_TIER_MEDIUM, !bumped)) != TLC_OK) return rc;
             if (tc[TLC_TIER_MID] > 0 && (rc = launch_side(3, TLC_TIER_MID, !bumped)) != TLC_OK) return rc;
         } else {
             T1(2, s);
@@ -690,6 +714,10 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
 #undef T0
 #undef T1
     for (int t = 0; t <= TLC_TIER_HUGE; ++t) g->last_stats[t] += tc[t];
+    g->last_stats[TLC_TIER_MEDIUM] += tc[TLC_TIER_MEDHI];              // (reported with MEDIUM; on its own in [9])
+    g->last_stats[9] += tc[TLC_TIER_MEDHI];
+    g->last_stats[TLC_TIER_SMALL] += tc[TLC_TIER_TINY];                 // (reported with SMALL; on its own in [8])
+    g->last_stats[8] += tc[TLC_TIER_TINY];
     g->last_stats[TLC_TIER_LARGE] += n_early;
     g->last_stats[7] += tc[TLC_TIER_MID];
     g->last_stats[4] += total;
@@ -757,7 +785,7 @@ extern "C" int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream)
     TLC_ON_DEVICE(g->device);
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     TLC_HIP_CHECK(hipMemcpy(g->h_sync->stats, g->d_stats, sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 8; ++k) h_out[k] = g->last_stats[k];
+    for (int k = 0; k < 10; ++k) h_out[k] = g->last_stats[k];
     h_out[5] += (long long)g->h_sync->stats[0];
     return TLC_OK;
 }

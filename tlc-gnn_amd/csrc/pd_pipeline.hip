@@ -2116,6 +2116,7 @@ __global__ __launch_bounds__(256, (RES <= 5 ? 3 : 2)) void tlc_pi_raster_kernel(
 size_t tlc_handoff_slot_bytes(int tier) {
     switch (tier) {
         case TLC_TIER_MID: return handoff_bytes(TLC_D_NMAX, TLC_D_MMAX);
+        case TLC_TIER_MEDHI:
         case TLC_TIER_MEDIUM: return handoff_bytes(TLC_M_NMAX, TLC_M_MMAX);
         // (LARGE keeps the serial cycle swap of its subgraphs with few Pos edges: they are few and the batch waits for the
         // slowest of them, which runs fastest with a CU to itself -- measured 0.91 vs 1.07 ms with the swap in the shared
@@ -2145,6 +2146,7 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
                                L.total, s, p);
             break;
         }
+        case TLC_TIER_MEDHI:
         case TLC_TIER_MEDIUM: {
             constexpr Layout L = make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2);
             if (p.phase != 2)

@@ -17,11 +17,17 @@
 #define TLC_TIER_LARGE 2
 #define TLC_TIER_HUGE 3
 #define TLC_TIER_MID 4      /* the lower end of MEDIUM (reported with it): 128 threads, ~10 KB of LDS, 8 workgroups per CU */
+#define TLC_TIER_MEDHI 6    /* MEDIUM-sized vicinities with many Pos edges (reported with MEDIUM): same kernels, launched FIRST and on the
+                               critical stream, so that their long serial cycle swaps overlap the rest of the MEDIUM tier */
+#define TLC_MH_MIN_POS 120
+#define TLC_TIER_TINY 5     /* the lower end of SMALL (reported with it): ONE LANE per subgraph, 64 subgraphs per wavefront (pd_tiny.hip) */
 // hard limits of one subgraph: local node ids are packed in 16 bits, edge ranks + 1 in 24
 #define TLC_MAX_SUBGRAPH_NODES 65535
 #define TLC_MAX_SUBGRAPH_EDGES ((1 << 24) - 2)
-#define TLC_N_TIERS 5
+#define TLC_N_TIERS 7
 
+#define TLC_T_NMAX 16
+#define TLC_T_MMAX 24
 #define TLC_S_NMAX 64
 #define TLC_S_MMAX 128
 #define TLC_D_NMAX 128
@@ -110,6 +116,7 @@ struct TlcScanParams {
     int* tier_count;  // [TLC_N_TIERS]
     int* tier_list;   // [TLC_N_TIERS][n_pairs]
     int small_arena;
+    int tiny_ok;            // the SMALL-tier vicinities of at most TLC_T_NMAX nodes / TLC_T_MMAX edges get a list of their own
     // COUNT wrote the MID / MEDIUM vicinities at bump-allocated offsets (TlcVicParams::bump_top): unless *bump_overflow, only
     // the heavy tiers still need arena space, handed out above *bump_top; null: every vicinity outside the SMALL tier does
     const unsigned long long* bump_top;
@@ -221,6 +228,7 @@ __global__ void tlc_scan_bin(TlcScanParams p);
 
 // host-side launchers implemented next to their kernels
 int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream);
+int tlc_launch_pd_tiny(const TlcPdParams& p, void* stream);
 int tlc_launch_pdf_tier(int tier, const TlcPdfParams& p, void* stream);
 int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long* edge_offs, int* counts, int* tier_count,
                        int* tier_list, void* stream);

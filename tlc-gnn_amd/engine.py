@@ -62,12 +62,12 @@ class DeviceGraph:
         return out, status
 
     def stats(self):
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * 10)()
         rc = _lib.lib().tlc_pd_pi_batch_stats(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr(self.device))
         _lib.check(rc, "tlc_pd_pi_batch_stats")
         v = list(out)
         return {"tier_small": v[0], "tier_medium": v[1], "tier_large": v[2], "tier_huge": v[3],
-                "tier_mid": v[7],
+                "tier_mid": v[7], "tier_tiny": v[8], "tier_medium_many_pos": v[9],
                 "induced_entries": v[4], "tie_fallback_sources": v[5], "chunks": v[6]}
 
     # ---- measurement helpers (bench.py) -----------------------------------------------------------------------
