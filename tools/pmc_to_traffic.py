@@ -3,7 +3,7 @@ HBM bytes per launch for the kernels bench.py names."""
 import collections, csv, glob, json, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-NAMES = [("tlc_pd_tier_kernel<2048", "pd_tier_large"), ("tlc_pd_tier_kernel<512", "pd_tier_medium"),
+NAMES = [("tlc_pd_tier_kernel<2048", "pd_tier_large"), ("tlc_pd_dc_kernel<2048", "pd_tier_large"), ("tlc_pd_tiny", "pd_tiny"), ("tlc_pd_tier_kernel<512", "pd_tier_medium"),
          ("tlc_pd_tier_kernel<128", "pd_tier_mid"), ("tlc_pd_swap_kernel<512", "pd_swap_medium"),
          ("tlc_pd_swap_kernel<128", "pd_swap_mid"),
          ("tlc_pd_tier_kernel<64", "pd_tier_small"), ("tlc_pd_tier_kernel<0", "pd_tier_huge"),
@@ -23,25 +23,27 @@ for cname, pat in (("FETCH_SIZE", "gpurun_out/prof/pmc_fetch/**/*counter_collect
     vals[cname] = agg
     raw[cname] = {k: {"sum_KB": sum(v), "launches": len(v), "median_KB": sorted(v)[len(v) // 2]} for k, v in agg.items()}
 json.dump(raw, open("profiles/%s_pmc_raw.json" % tag, "w"), indent=1)
-# bench steps in the PMC pass = launches of the COUNT kernel minus the one set-up batch (decode table) = warm-up + steps
-count_launches = max([len(v) for k, v in vals["FETCH_SIZE"].items() if "tlc_vicinity_kernel<false" in k] + [2])
-steps = count_launches - 1
+# batches in the PMC pass = launches of the scan kernel (exactly one per batch)
+steps = max([len(v) for k, v in vals["FETCH_SIZE"].items() if "tlc_scan_bin" in k] + [1])
 out = collections.defaultdict(lambda: {"FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0, "launches_per_step": 0})
 for cname in raw:
     for k, v in raw[cname].items():
         for pat, nm in NAMES:
             if pat in k:
-                if v["launches"] < steps:      # set-up only (e.g. the FILL fallback of the first batch on a fresh handle)
+                if v["launches"] * 2 < steps:  # set-up only (e.g. the FILL fallback of the first batch on a fresh handle)
                     break
-                # median dispatch x dispatches per step: robust against the one odd-sized set-up batch
+                # mean over the batches of the pass (a kernel launched twice per batch with different list sizes -- the two halves
+                # of the MEDIUM tier -- has no meaningful median dispatch)
                 per_step = max(1, int(round(v["launches"] / float(steps))))
-                out[nm][cname + "_KB"] += v["median_KB"] * per_step
+                out[nm][cname + "_KB"] += v["sum_KB"] / float(steps)
                 if cname == "FETCH_SIZE":
                     out[nm]["launches_per_step"] += per_step
                 break
-res = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1 --no-sweep` "
-                "(raw per-kernel sums and medians in profiles/%s_pmc_raw.json); bytes per bench step = (FETCH_SIZE + WRITE_SIZE) * 1024 "
-                "of the median dispatch x dispatches per step. "
+import datetime
+res = {"_collected": "%s, round-2 code (%s)" % (tag, datetime.date.today().isoformat()),
+       "_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1 --no-sweep` "
+                "(raw per-kernel sums and medians in profiles/%s_pmc_raw.json); bytes per batch = (FETCH_SIZE + WRITE_SIZE) * 1024 "
+                "summed over the pass / batches in the pass (one of them is the 75 352-pair set-up batch of the decode table). "
                 "gfx950 caveat (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams and is "
                 "uncalibrated for the 4/8-byte gathers these kernels issue, so the read side is a lower bound; the working set (CSR 1.1 MB, "
                 "arena ~35 MB) sits in L2 / Infinity Cache." % tag}
