@@ -328,11 +328,20 @@ def main():
         torch.cuda.synchronize()
 
     def make_encoder(mode):
-        enc = tdist.ShardedGCNEncoder(rowptr_n, col_n, val_n, n, world, rank, mode=mode,
-                                      gemm=lambda a, b, out=None: ops.gemm(a, b, out=out),
+        box = {}
+
+        def gemm(a, b, out=None):
+            # the feature projection runs over the stored entries of the (10 % dense, never changing) feature rows, like
+            # Net.encode does; every other product is the dense MFMA kernel
+            if a is box.get("x") and box["xs"] is not None:
+                return ops.sparse_gemm(box["xs"], b, out=out)
+            return ops.gemm(a, b, out=out)
+        enc = tdist.ShardedGCNEncoder(rowptr_n, col_n, val_n, n, world, rank, mode=mode, gemm=gemm,
                                       spmm=lambda rp, c, v, xx, bias, relu, renorm=False, out=None:
                                       ops.spmm(rp, c, v, xx, bias=bias, relu=relu, renorm=renorm, out=out))
         x_local = x_full[enc.lo:enc.hi].contiguous()
+        xs_local = ops.SparseRows(x_local)
+        box["x"], box["xs"] = x_local, (xs_local if xs_local.density < TLCGNN.Net.SPARSE_FEATURES_BELOW and x_local.shape[1] <= ops.SPARSE_GEMM_MAX_K else None)
         pairs_mapped = enc.row_map(dec_pairs.long()).to(torch.int32).contiguous()      # decode pairs index encode()'s layout
 
         def leg():
@@ -630,7 +639,18 @@ def main():
         us_s = _avg_us(lambda: ops.spmm(rowptr_n, col_n, val_n, hfull, bias=b1, relu=True, out=yfull))
         nnz = int(col_n.shape[0])
         spmm_bytes = nnz * (Nh * 4 + 8) + n * (Nh * 4 + 4)            # gathered rows + col/val + output rows + rowptr
-        lp_roof = {"feature_gemm": {"bound": "mfma", "shape_mkn": [int(Mr), int(Kf), int(Nh)], "kernel_us": us_g,
+        xs_full = ops.SparseRows(x_full)
+        us_sg = _avg_us(lambda: ops.sparse_gemm(xs_full, w1, out=xw))
+        sp_bytes = xs_full.nnz * 8.0 + 4.0 * (Mr + 1) + 4.0 * Kf * Nh + 4.0 * Mr * Nh          # CSR once per column slice is L2 traffic
+        lp_roof = {"feature_gemm_sparse": {"bound": "hbm", "shape_mkn": [int(Mr), int(Kf), int(Nh)], "nnz": int(xs_full.nnz),
+                                           "density": xs_full.density, "kernel_us": us_sg,
+                                           "achieved": sp_bytes / us_sg / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": sp_bytes / us_sg / 1e3 / HBM_PEAK_GBS,
+                                           "useful_tflops": 2.0 * xs_full.nnz * Nh / us_sg / 1e6,
+                                           "note": "x @ W over the stored entries of x (tlc_spgemm_csr_dense_f32); exact; bytes = CSR + W + "
+                                                   "output, each once.  Used by Net.encode / the LP leg only below %.0f %% density (the dense "
+                                                   "MFMA kernel is faster above): not on this workload" % (100 * TLCGNN.Net.SPARSE_FEATURES_BELOW)},
+                   "feature_gemm": {"bound": "mfma", "shape_mkn": [int(Mr), int(Kf), int(Nh)], "kernel_us": us_g,
                                     "achieved": 2.0 * Mr * Kf * Nh / us_g / 1e6, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": 2.0 * Mr * Kf * Nh / us_g / 1e6 / MFMA_F32_PEAK_TFLOPS, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"},
                    "scatter_add_spmm": {"bound": "hbm", "rows": int(n), "nnz": nnz, "k": int(Nh), "kernel_us": us_s,

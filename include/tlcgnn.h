@@ -177,6 +177,12 @@ int tlc_gcn_norm_csr(int32_t n_nodes, int64_t n_edges, const int64_t* d_edge_ind
 int tlc_gemm_f32(int32_t M, int32_t N, int32_t K, const float* d_A, const float* d_B, const float* d_bias,
                  int relu, float* d_C, void* stream);
 
+/* The same product for a SPARSE A given as CSR (rowptr int32[M+1], col int32[nnz] < K, val f32[nnz]): the feature projection
+ * x @ W of GCNConv (PD_conv.py:179-181) on bag-of-words / TF-IDF features (PubMed: 10 % non-zeros), exact (the zeros contribute
+ * nothing) at a tenth of the flops.  B is staged in LDS in 64-column slices: K <= 640 (TLC_ERR_UNSUPPORTED beyond). */
+int tlc_spgemm_csr_dense_f32(int32_t M, int32_t K, int32_t N, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
+                             const float* d_B, const float* d_bias, int relu, float* d_C, void* stream);
+
 /* Y[n,k] = act( CSR(rowptr,col,val) @ X[n,k] + bias[k] ): the propagate/scatter-add of GCNConv
  * (PD_conv.py:183-188; message_passing.py:275-293 aggr='add').  relu: bit 0 = ReLU; bit 1 = afterwards renormalise
  * every row like tlc_renorm_rows_f32 (the emb.renorm_ of TLCGNN.py:48 fused into the last layer's aggregation). */

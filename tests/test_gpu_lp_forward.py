@@ -236,6 +236,63 @@ def test_full_size_pubmed_encode_decode_vs_restatement():
     assert ok, worst
 
 
+@pytest.mark.parametrize("shape,density", [((19717, 500, 100), 0.1), ((2708, 640, 100), 0.013), ((777, 33, 7), 0.3), ((64, 500, 130), 0.1),
+                                           ((5, 4, 1), 0.5), ((300, 256, 64), 0.0)])
+def test_sparse_feature_projection(setup, shape, density):
+    """x @ W over the stored entries of x (tlc_spgemm_csr_dense_f32): against the float64 product, element by element, and
+    against the dense MFMA kernel; empty rows, N not a multiple of 64, more than one column slice, an all-zero matrix."""
+    torch = setup[0]
+    from tlc_gnn_amd import ops
+    M, K, N = shape
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.rand(M, K, generator=g) * (torch.rand(M, K, generator=g) < density).float()
+    if M > 10:
+        x[3] = 0.0                                                     # an empty row
+    w = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    xs = ops.SparseRows(x.cuda())
+    assert xs.nnz == int((x != 0).sum()) and abs(xs.density - xs.nnz / float(M * K)) < 1e-12
+    out = ops.sparse_gemm(xs, w.cuda(), bias=bias.cuda(), relu=True).cpu()
+    ref = torch.relu(x.double() @ w.double() + bias.double())
+    mag = x.abs().double() @ w.abs().double() + bias.abs().double()
+    err = (out.double() - ref).abs()
+    assert bool((err <= 5e-7 * mag + 1e-30).all()), float((err / mag).max())
+    if N <= 128:                                                       # (the dense kernel's limit: GCN hidden sizes)
+        dense = ops.gemm(x.cuda(), w.cuda(), bias=bias.cuda(), relu=True).cpu()
+        assert torch.allclose(out, dense, rtol=1e-5, atol=1e-5)
+    plain = ops.sparse_gemm(xs, w.cuda()).cpu()
+    assert bool(((plain.double() - x.double() @ w.double()).abs() <= 5e-7 * (mag + 1e-12) + 1e-30).all())
+
+
+def test_encode_uses_the_sparse_projection_and_tracks_feature_edits(setup):
+    """Net.encode keeps the CSR of data.x while x is the same unmodified tensor; an in-place edit or a new tensor rebuilds it."""
+    torch, n, F_, x, ei = setup
+    from tlc_gnn_amd.baselines import TLCGNN
+    from tlc_gnn_amd.data import Data
+    from oracle import lp_forward_ref as ref
+    torch.manual_seed(5)
+    model = TLCGNN.Net(None, F_, 2, PI=None).cuda().eval()
+    x = x * (torch.rand(x.shape, generator=torch.Generator().manual_seed(9)) < 0.2).float()      # ~2 % dense, like Cora's bag of words
+    data = Data(x=x.clone().cuda(), edge_index=ei.cuda(), y=torch.zeros(n))
+    w1, b1 = model.conv1.weight.detach().cpu(), model.conv1.bias.detach().cpu()
+    w2, b2 = model.conv2.weight.detach().cpu(), model.conv2.bias.detach().cpu()
+    with torch.no_grad():
+        e1 = model.encode(data)
+        assert model._xs[2] is not None and model._xs[2].density < model.SPARSE_FEATURES_BELOW
+        ok, worst = _close(e1, ref.tlcgnn_encode(x, ei, w1, b1, w2, b2))
+        assert ok, worst
+        data.x[:50] += 0.5                                                        # in place: same tensor, new version
+        e2 = model.encode(data)
+        x2 = x.clone(); x2[:50] += 0.5
+        ok, worst = _close(e2, ref.tlcgnn_encode(x2, ei, w1, b1, w2, b2))
+        assert ok, worst
+        data.x = torch.ones(n, F_).cuda()                                         # dense features: the MFMA path
+        e3 = model.encode(data)
+        assert model._xs[2] is None
+        ok, worst = _close(e3, ref.tlcgnn_encode(torch.ones(n, F_), ei, w1, b1, w2, b2))
+        assert ok, worst
+
+
 def test_decode_generic_dims(setup):
     torch = setup[0]
     from tlc_gnn_amd import ops

@@ -53,6 +53,52 @@ def gemm(a, b, bias=None, relu=False, out=None):
     return out
 
 
+class SparseRows:
+    """CSR of a feature matrix (the zeros of bag-of-words / TF-IDF features dropped), built once: rowptr int32[M+1],
+    col int32[nnz], val f32[nnz] on the matrix's device.  The conversion is a data-format step (torch index plumbing)."""
+
+    def __init__(self, x):
+        import torch
+        x = _f32(x)
+        self.shape = tuple(x.shape)
+        nz = x != 0
+        counts = nz.sum(dim=1, dtype=torch.int64)
+        self.rowptr = torch.zeros(x.shape[0] + 1, dtype=torch.int32, device=x.device)
+        self.rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        idx = nz.nonzero(as_tuple=False)                                  # row-major: rows ascending, columns ascending
+        self.nnz = int(idx.shape[0])
+        if self.nnz:
+            self.col = idx[:, 1].to(torch.int32).contiguous()
+            self.val = x[nz].contiguous()
+        else:                                                              # (an all-zero matrix: the arrays still need an address)
+            self.col = torch.zeros(1, dtype=torch.int32, device=x.device)
+            self.val = torch.zeros(1, dtype=torch.float32, device=x.device)
+
+    @property
+    def density(self):
+        return self.nnz / float(max(self.shape[0] * self.shape[1], 1))
+
+
+SPARSE_GEMM_MAX_K = 640          # 64-column slices of B in LDS: K * 256 B <= 160 KiB
+
+
+@_lib.on_device_of
+def sparse_gemm(xs, b, bias=None, relu=False, out=None):
+    """C = X @ B (+bias)(ReLU) for X given as SparseRows: exact, the zeros of X cost nothing (tlc_spgemm_csr_dense_f32)."""
+    torch = _lib.require_gpu()
+    b = _f32(b)
+    M, K = xs.shape
+    assert b.shape[0] == K
+    N = b.shape[1]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=b.device)
+    rc = _lib.lib().tlc_spgemm_csr_dense_f32(C.c_int32(M), C.c_int32(K), C.c_int32(N), _lib.ptr(xs.rowptr), _lib.ptr(xs.col),
+                                             _lib.ptr(xs.val), _lib.ptr(b), _lib.ptr(_f32(bias)) if bias is not None else None,
+                                             C.c_int(1 if relu else 0), _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "tlc_spgemm_csr_dense_f32")
+    return out
+
+
 @_lib.on_device_of
 def spmm(rowptr, col, val, x, bias=None, relu=False, out=None, renorm=False):
     """Y = act(CSR @ X + bias): the normalised scatter-add of GCNConv as a row-owned gather; renorm=True also applies
