@@ -130,3 +130,56 @@ def test_tlcgnn_call_harness():
     assert float(prob.min()) >= 0 and float(prob.max()) <= 1
     # the image rows of adjacent training pairs are mostly non-zero at hop 1 on a clustered graph
     assert (np.abs(model.PI[:data.train_pos]).sum(1) > 0).mean() > 0.3
+
+
+def test_pipelines_test_and_train_forward():
+    """pipelines.py:10-40 (harness row H3): test() = encode once + decode val/test + BCE / ROC-AUC / AP, against the same numbers
+    computed from the torch restatement's probabilities; train_forward() = the forward of train() with the reference's
+    np.random.randint negative sampling (same RNG call, TLCGNN.py:31)."""
+    import torch
+    import torch.nn.functional as F
+    from sklearn.metrics import roc_auc_score, average_precision_score
+    from tlc_gnn_amd import synth, pipelines
+    from tlc_gnn_amd.baselines import TLCGNN
+    from tlc_gnn_amd.data import Data
+    from oracle import lp_forward_ref as ref
+    n, m, F_ = 300, 900, 48
+    edges = synth.holme_kim_edges(n, m, triad_p=0.5, seed=5)
+    ei = torch.from_numpy(np.concatenate([edges, edges[:, ::-1]]).T.copy()).long()
+    x = torch.from_numpy(synth.synthetic_features(n, F_, seed=5))
+    rs = np.random.RandomState(2)
+    E = 1200
+    pairs = rs.randint(0, n, size=(E, 2))
+    PI = rs.uniform(0, 0.3, size=(E, 25))
+    y = torch.from_numpy((rs.rand(E) < 0.5).astype(np.int64))
+    data = Data(x=x.clone(), edge_index=ei.clone(), y=torch.zeros(n), total_edges=pairs, total_edges_y=y,
+                train_pos=300, train_neg=400, val_pos=100, val_neg=100, test_pos=150, test_neg=150)
+    pipelines.setup_seed(3)
+    model = TLCGNN.Net(data, F_, 2, PI=PI)
+    model.apply(pipelines.weights_init)
+    model = model.cuda()
+    data = data.to("cuda")
+    accs = pipelines.test(model, data)
+    w = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    emb = ref.tlcgnn_encode(x, ei, w["conv1.weight"], w["conv1.bias"], w["conv2.weight"], w["conv2.bias"])
+    want = []
+    for lo, hi, with_bce in ((700, 900, True), (900, 1200, False)):
+        p = ref.tlcgnn_decode(emb.clone(), torch.from_numpy(pairs[lo:hi]), torch.from_numpy(PI[lo:hi]), w["linear_1.weight"],
+                              w["linear_1.bias"], w["linear.weight"], w["linear.bias"])
+        yy = y[lo:hi].float()
+        if with_bce:
+            want.append(float(F.binary_cross_entropy(p, yy)))
+        want += [roc_auc_score(yy, p.numpy()), average_precision_score(yy, p.numpy())]
+    assert len(accs) == 5
+    assert np.allclose([float(a) for a in accs], want, rtol=1e-4, atol=1e-5), (accs, want)
+    model.eval()                                                # (no dropout: the sampled negatives are what is under test)
+    np.random.seed(9)
+    with torch.no_grad():
+        xx, yy = model.decode(data, model.encode(data))
+    np.random.seed(9)
+    idx = np.concatenate([np.arange(300), 300 + np.random.randint(0, 400, 300)])
+    p = ref.tlcgnn_decode(emb.clone(), torch.from_numpy(pairs[idx]), torch.from_numpy(PI[idx]), w["linear_1.weight"],
+                          w["linear_1.bias"], w["linear.weight"], w["linear.bias"])
+    assert torch.allclose(xx.cpu(), p, rtol=1e-5, atol=1e-6) and torch.equal(yy.cpu(), y[idx].float())
+    xt, yt, loss = pipelines.train_forward(model, data)
+    assert xt.shape == (600,) and yt.shape == (600,) and bool(torch.isfinite(loss))

@@ -867,11 +867,9 @@ extern "C" int tlc_spgemm_csr_dense_f32(int32_t M, int32_t K, int32_t N, const i
     }
     hipStream_t s = (hipStream_t)stream;
     constexpr int NW = 16;
-    static size_t lds_set = 0;                       // (the attribute only ever grows; one device per process in this library's use)
-    if (lds > 64 * 1024 && lds > lds_set) {
+    // (per call: the attribute is per device and a process may drive several; a host-side call of a few hundred nanoseconds)
+    if (lds > 64 * 1024)
         TLC_HIP_CHECK(hipFuncSetAttribute((const void*)spgemm_csr_dense_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
     const int slices = (N + 63) / 64;
     int gx = 256 / slices;                           // one workgroup per CU over all slices
     if (gx < 1) gx = 1;
