@@ -67,8 +67,8 @@ class Net(torch.nn.Module):
         self._xs = None                 # (features tensor, its version, SparseRows or None): see _sparse_features
 
     # density under which x @ W runs over the stored entries of x.  Measured on MI355X, 19 717 x 500 @ 500 x 100: the dense f32
-    # MFMA kernel takes 30 us whatever the zeros; the sparse kernel 39 us at 10 % density (PubMed-like) and proportionally less
-    # below, so it pays under ~7 %: the threshold keeps a margin
+    # MFMA kernel takes 30 us whatever the zeros; the sparse kernel 39 us at 10 % density (PubMed-like).  That is the one point
+    # measured: "pays under ~7 %" assumes its time scales with the stored entries, which was not checked at a lower density
     SPARSE_FEATURES_BELOW = 0.05
 
     def _sparse_features(self, x):
