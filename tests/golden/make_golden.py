@@ -23,6 +23,9 @@ Fixtures:
                          (sg2dgm/riccidist2dgm.py:20-61,310-329)
   G4c kd_nc.npz          PDGNN node-centred vicinity: ball(u), single root, f = d(x,u)/(max + 1e-10); Ord0 / Ext1 / images
                          (Knowledge_Distillation/data_utils_NC.py:27-50,95-187)
+  G10 decode.npz         Net.decode('train' | 'val' | 'test') of the imported baselines/TLCGNN.py on seeded embeddings (rows with
+                         norm above and below 1), images and weights: probabilities, labels, sampled negatives, the renormed
+                         embedding (baselines/TLCGNN.py:27-62; GCNConv is stubbed -- decode never calls it)
 """
 import argparse
 import importlib
@@ -596,15 +599,89 @@ def make_g4c(mods):
     print("G4c cases:", len(rt), "largest ball:", max(len(x) for x in ids_l))
 
 
+def make_g10(mods):
+    """Net.decode of the reference itself (baselines/TLCGNN.py:27-62): plain torch + numpy.  The module imports
+    torch_geometric.nn.GCNConv / ChebConv at the top (third-party, absent: SURVEY 8c) but decode never touches the two conv
+    layers, so they are stubbed as empty modules; the `.cuda()` at :52-53 is a device hop with no arithmetic and is made the
+    identity for the duration of the call (this container has no GPU).  Everything else -- the slicing by split, the
+    np.random.randint negatives, renorm_, the 41->25->1 head, the Fermi-Dirac link function -- is the reference's own code."""
+    import torch
+
+    class _Conv(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    tgnn = _stub("torch_geometric.nn", GCNConv=_Conv, ChebConv=_Conv)
+    sys.modules["torch_geometric"].nn = tgnn
+    tmp = os.path.dirname(mods["lds"].__file__)
+    os.makedirs(os.path.join(tmp, "baselines"), exist_ok=True)
+    open(os.path.join(tmp, "baselines", "__init__.py"), "w").close()
+    link = os.path.join(tmp, "baselines", "TLCGNN.py")
+    if not os.path.exists(link):
+        os.symlink(os.path.join(REF, "baselines", "TLCGNN.py"), link)
+    ref = importlib.import_module("baselines.TLCGNN")
+
+    rs = np.random.RandomState(2024)
+    n_nodes, dim = 400, 5
+    tp, tn, vp, vn, sp_, sn = 300, 900, 40, 40, 60, 60
+    n_pairs = tp + tn + vp + vn + sp_ + sn
+    pairs = rs.randint(0, n_nodes, size=(n_pairs, 2)).astype(np.int64)
+    pairs[5] = (7, 7)                                                    # a self pair: (a - b)^2 = 0
+    y = np.concatenate([np.ones(tp), np.zeros(tn), np.ones(vp), np.zeros(vn), np.ones(sp_), np.zeros(sn)]).astype(np.int64)
+    PI = rs.gamma(0.6, 0.4, size=(n_pairs, dim * dim))                  # non-negative, heavy near 0 like real images
+    PI[rs.rand(n_pairs) < 0.3] = 0.0                                     # zero rows (far pairs)
+    PI[rs.rand(n_pairs) < 0.05] *= 400.0                                 # a few huge rows: |d| beyond the clamp at 40
+    emb = rs.randn(n_nodes, 16).astype(np.float32) * 0.35               # norms around 1.4: most rows are rescaled
+    emb[::3] *= 0.2                                                      # a third of the rows with norm < 1 (untouched)
+    emb[11] = 0.0
+
+    class _Data:
+        pass
+
+    data = _Data()
+    data.total_edges = pairs
+    data.total_edges_y = torch.from_numpy(y)
+    data.train_pos, data.train_neg, data.val_pos, data.val_neg, data.test_pos, data.test_neg = tp, tn, vp, vn, sp_, sn
+    torch.manual_seed(1234)
+    net = ref.Net(data, 32, 2, PI, dimension=dim)
+    net.eval()
+    with torch.no_grad():
+        net.linear.weight.mul_(6.0)                                      # spread |d| over (0, 40): both clamp ends are hit
+        net.linear.bias.add_(0.5)
+        net.linear_1.weight.mul_(3.0)
+    out = dict(n_nodes=n_nodes, pairs=pairs, y=y, PI=PI, emb=emb, counts=np.array([tp, tn, vp, vn, sp_, sn]),
+               lin1_w=net.linear_1.weight.detach().numpy().copy(), lin1_b=net.linear_1.bias.detach().numpy().copy(),
+               lin_w=net.linear.weight.detach().numpy().copy(), lin_b=net.linear.bias.detach().numpy().copy(), np_seed=4321)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for kind in ("train", "val", "test"):
+            np.random.seed(4321)
+            e = torch.from_numpy(emb.copy())
+            with torch.no_grad():
+                prob, yy = net.decode(data, e, kind)
+            out["prob_" + kind] = prob.numpy().astype(np.float32)
+            out["y_" + kind] = yy.numpy().astype(np.float32)
+            out["emb_after_" + kind] = e.numpy().copy()                  # renorm_ is in place (:48)
+        np.random.seed(4321)
+        out["train_index"] = np.random.randint(0, tn, tp)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    sat = [(float(out["prob_" + k].min()), float(out["prob_" + k].max())) for k in ("train", "val", "test")]
+    print("G10 decode: rows", [len(out["prob_" + k]) for k in ("train", "val", "test")], "prob ranges", sat,
+          "rows rescaled:", int((np.linalg.norm(emb, axis=1) > 1).sum()), "of", n_nodes)
+    np.savez_compressed(os.path.join(HERE, "decode.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true", help="also time the reference on the PubMed-shaped graph")
-    ap.add_argument("--only", default="", help="regenerate a single fixture (g4b | g8 | g4c)")
+    ap.add_argument("--only", default="", help="regenerate a single fixture (g4b | g8 | g4c | g10)")
     args = ap.parse_args()
     assert sys.version_info[:2] < (3, 12), "python>=3.12 sums with compensation: goldens would differ (SURVEY A.2)"
     mods = import_reference()
     if args.only:
-        {"g4b": make_g4b, "g8": make_g8, "g4c": make_g4c}[args.only](mods)
+        {"g4b": make_g4b, "g8": make_g8, "g4c": make_g4c, "g10": make_g10}[args.only](mods)
         return
     make_g1_g2(mods)
     make_g3(mods)
@@ -614,6 +691,7 @@ def main():
     make_g7(mods)
     make_g8(mods)
     make_g4c(mods)
+    make_g10(mods)
 
 
 if __name__ == "__main__":

@@ -140,3 +140,70 @@ def test_simplex_filter_keys_are_the_reference_expressions():
         hi, lo = max(sf[a]['old'], sf[b]['old']), min(sf[a]['old'], sf[b]['old'])
         assert sf[(a, b)]['asc'] == hi + (lo + 1) * 1e-6 and sf[(a, b)]['desc'] == lo - (101 - hi) * 1e-6
         assert type(sf[(a, b)]['asc']) is float
+
+
+def _bipartite_case(seed=5):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    n_src, n_dst, E, k = 23, 11, 160, 6
+    xs = torch.randn(n_src, k, generator=g)
+    xd = torch.randn(n_dst, k, generator=g) + 100.0          # (far from xs: a swapped element cannot pass)
+    a_l = torch.randn(n_src, generator=g)
+    a_r = torch.randn(n_dst, generator=g)
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst, (E,), generator=g)])
+    return xs, xd, a_l, a_r, ei
+
+
+def test_message_passing_tuple_arguments_follow_the_reference():
+    """`propagate(ei, x=(x_src, x_dst), alpha=(a_l, a_r))` -- the reference's own hot-path call form
+    (Knowledge_Distillation/gat_conv.py:160-161): `_j` reads element 0 through edge_index[0], `_i` element 1 through
+    edge_index[1] (message_passing.py:147-158), sizes come from the two elements.  Distinct tensors with different
+    node counts; the aggregate is replaced by torch so the whole propagate runs on the CPU."""
+    import torch
+    from tlc_gnn_amd.Knowledge_Distillation.message_passing import MessagePassing
+    xs, xd, a_l, a_r, ei = _bipartite_case()
+
+    class Conv(MessagePassing):
+        def __init__(self, flow):
+            super().__init__(aggr="add", flow=flow, node_dim=0)
+            self.seen = {}
+
+        def message(self, x_j, x_i, alpha_j, alpha_i, index, size_i, size_j):
+            self.seen = dict(x_j=x_j, x_i=x_i, alpha_j=alpha_j, alpha_i=alpha_i, index=index, size_i=size_i, size_j=size_j)
+            return (x_j - x_i) * (alpha_j + alpha_i).view(-1, 1)
+
+        def aggregate(self, inputs, index, dim_size=None):
+            return torch.zeros(dim_size, inputs.size(1)).index_add_(0, index, inputs)
+
+    c = Conv("source_to_target")
+    out = c.propagate(ei, x=(xs, xd), alpha=(a_l, a_r))
+    s = c.seen
+    assert torch.equal(s["x_j"], xs[ei[0]]) and torch.equal(s["x_i"], xd[ei[1]])
+    assert torch.equal(s["alpha_j"], a_l[ei[0]]) and torch.equal(s["alpha_i"], a_r[ei[1]])
+    assert torch.equal(s["index"], ei[1]) and s["size_i"] == xd.size(0) and s["size_j"] == xs.size(0)
+    ref = torch.zeros(xd.size(0), xs.size(1)).index_add_(0, ei[1], (xs[ei[0]] - xd[ei[1]]) * (a_l[ei[0]] + a_r[ei[1]]).view(-1, 1))
+    assert out.shape == ref.shape and torch.allclose(out, ref)
+    # an explicit size that contradicts an element is an error (:115-122)
+    with pytest.raises(ValueError):
+        c.propagate(ei, size=(xs.size(0) + 1, xd.size(0)), x=(xs, xd), alpha=(a_l, a_r))
+    # flow 'target_to_source': the suffix still picks the element (0 for _j, 1 for _i); the rows swap (i, j) = (0, 1)
+    c = Conv("target_to_source")
+    ei_t = torch.stack([ei[1], ei[0]])                      # row 0 = i indexes element 1, row 1 = j indexes element 0
+    c.propagate(ei_t, x=(xs, xd), alpha=(a_l, a_r))
+    s = c.seen
+    assert torch.equal(s["x_j"], xs[ei_t[1]]) and torch.equal(s["x_i"], xd[ei_t[0]]) and torch.equal(s["index"], ei_t[0])
+    # a single tensor is used for both sides, a None element is passed through untouched
+    class One(MessagePassing):
+        def __init__(self):
+            super().__init__(aggr="add", node_dim=0)
+
+        def message(self, x_j, e_i):
+            assert e_i is None
+            return x_j
+
+        def aggregate(self, inputs, index, dim_size=None):
+            return torch.zeros(dim_size, inputs.size(1)).index_add_(0, index, inputs)
+
+    sq = torch.stack([ei[0] % 11, ei[1]])
+    out = One().propagate(sq, x=xd, e=(xd, None))
+    assert torch.allclose(out, torch.zeros(11, xd.size(1)).index_add_(0, sq[1], xd[sq[0]]))

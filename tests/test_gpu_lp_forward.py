@@ -182,6 +182,57 @@ def test_encode_decode_vs_torch_reference(setup):
     assert prob.shape[0] == 2000 and y.shape[0] == 2000
 
 
+def test_decode_matches_reference_golden_g10():
+    """The drop-in Net.decode (HIP: renorm + lp_decode8) against Net.decode of the IMPORTED reference
+    (/root/reference/baselines/TLCGNN.py:27-62; tests/golden/decode.npz, make_golden.py --only g10): probabilities within 1e-5
+    relative for 'train' / 'val' / 'test', labels and the np.random.randint negatives equal, the in-place renorm of the
+    embedding equal.  Also: rebinding model.PI / data.total_edges is honoured by the next decode (the reference re-slices
+    every call, :35-36)."""
+    import os
+    import torch
+    from tlc_gnn_amd.baselines import TLCGNN
+    from tlc_gnn_amd.data import Data
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decode.npz"))
+    tp, tn, vp, vn, sp_, sn = d["counts"].tolist()
+    n = int(d["n_nodes"])
+    data = Data(x=torch.zeros(n, 4), edge_index=torch.zeros(2, 0, dtype=torch.long), y=torch.zeros(n),
+                total_edges=d["pairs"].copy(), total_edges_y=torch.from_numpy(d["y"]),
+                train_pos=tp, train_neg=tn, val_pos=vp, val_neg=vn, test_pos=sp_, test_neg=sn)
+    model = TLCGNN.Net(data, 4, 2, PI=d["PI"].copy())
+    with torch.no_grad():
+        model.linear_1.weight.copy_(torch.from_numpy(d["lin1_w"])); model.linear_1.bias.copy_(torch.from_numpy(d["lin1_b"]))
+        model.linear.weight.copy_(torch.from_numpy(d["lin_w"])); model.linear.bias.copy_(torch.from_numpy(d["lin_b"]))
+    model = model.cuda().eval()
+    data = data.to("cuda")
+    for kind in ("train", "val", "test"):
+        np.random.seed(int(d["np_seed"]))
+        emb = torch.from_numpy(d["emb"].copy()).cuda()
+        with torch.no_grad():
+            prob, y = model.decode(data, emb, kind)
+        want = d["prob_" + kind]
+        got = prob.cpu().numpy()
+        assert got.shape == want.shape
+        # 1e-5 relative (north_star); the floor covers the saturated end 1/(exp(38)+1) = 3.1e-17
+        assert np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 1e-20), (kind, np.abs(got - want).max())
+        assert np.array_equal(y.cpu().numpy(), d["y_" + kind])
+        after = d["emb_after_" + kind]
+        assert np.all(np.abs(emb.cpu().numpy() - after) <= 1e-6 * np.abs(after) + 1e-12)
+        assert np.array_equal(emb.cpu().numpy()[np.linalg.norm(d["emb"], axis=1) <= 1.0 - 1e-4],
+                              d["emb"][np.linalg.norm(d["emb"], axis=1) <= 1.0 - 1e-4])          # short rows untouched, bit for bit
+    # a rebound table is used by the next call
+    model.PI = np.zeros_like(d["PI"])
+    emb = torch.from_numpy(d["emb"].copy()).cuda()
+    with torch.no_grad():
+        p0, _ = model.decode(data, emb, "val")
+    assert np.abs(p0.cpu().numpy() - d["prob_val"]).max() > 1e-3
+    model.PI = d["PI"].copy()
+    data.total_edges = d["pairs"][::-1].copy()
+    emb = torch.from_numpy(d["emb"].copy()).cuda()
+    with torch.no_grad():
+        p1, _ = model.decode(data, emb, "val")
+    assert np.abs(p1.cpu().numpy() - d["prob_val"]).max() > 1e-3
+
+
 def test_full_size_pubmed_encode_decode_vs_restatement():
     """BASELINE configs[1] at full size: the PubMed-shaped graph (N = 19 717, F = 500, hub rows in the SpMM) through
     Net.encode and Net.decode over the 75 352-pair training batch (TLCGNN.py:29-32), against the torch restatement:

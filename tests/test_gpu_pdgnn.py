@@ -232,6 +232,36 @@ def test_message_passing_dropin_and_scatter():
     assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
 
 
+def test_message_passing_tuple_arguments_on_the_gpu():
+    """The reference's own call form `propagate(ei, x=(x_l, x_r), alpha=(alpha_l, alpha_r))` (gat_conv.py:160-161) with DISTINCT
+    source / target tensors of different node counts: `_j` from element 0 via edge_index[0], `_i` from element 1 via
+    edge_index[1] (message_passing.py:147-158), aggregated at the target by the HIP scatter."""
+    import torch
+    from tlc_gnn_amd.Knowledge_Distillation.message_passing import MessagePassing
+    g = torch.Generator().manual_seed(11)
+    n_src, n_dst, E, k = 301, 97, 4000, 12
+    xs = torch.randn(n_src, k, generator=g)
+    xd = torch.randn(n_dst, k, generator=g) + 50.0
+    a_l, a_r = torch.randn(n_src, generator=g), torch.randn(n_dst, generator=g)
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst - 5, (E,), generator=g)])
+
+    class Conv(MessagePassing):
+        def __init__(self, aggr):
+            super().__init__(aggr=aggr, node_dim=0)
+
+        def message(self, x_j, x_i, alpha_j, alpha_i):
+            return (x_j - x_i) * torch.nn.functional.leaky_relu(alpha_j + alpha_i, 0.2).view(-1, 1)
+
+    msg = (xs[ei[0]] - xd[ei[1]]) * torch.nn.functional.leaky_relu(a_l[ei[0]] + a_r[ei[1]], 0.2).view(-1, 1)
+    idx = ei[1].view(-1, 1).expand(E, k)
+    for aggr, red in (("add", "sum"), ("mean", "mean"), ("max", "amax")):
+        out = Conv(aggr).cuda().propagate(ei.cuda(), x=(xs.cuda(), xd.cuda()), alpha=(a_l.cuda(), a_r.cuda())).cpu()
+        ref = torch.zeros(n_dst, k).scatter_reduce(0, idx, msg, reduce=red, include_self=False)
+        assert out.shape == (n_dst, k)
+        assert torch.allclose(out, ref, rtol=1e-5, atol=1e-4), aggr
+        assert bool((out[n_dst - 5:] == 0).all())
+
+
 def test_kd_lp_vicinity_filtration_matches_reference_golden():
     """PDGNN link-prediction vicinities (data_utils_LP.py:105-200, filt='ricci', mode='filtration') on the GPU:
     node sets, filtration values (bit-exact, incl. the 100-sentinel of unreachable roots) and induced edges."""

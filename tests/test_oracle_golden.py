@@ -164,3 +164,27 @@ def test_kd_lp_filtration_g4b():
         if len(nonep):
             _, _, _, nn, mm, st2 = oracle.vicinity_filtration(rowptr, col, w, nonep, hop, flags)
             assert (mm == 0).all()
+
+
+def test_decode_restatement_g10():
+    """oracle/lp_forward_ref.tlcgnn_decode against Net.decode of the imported reference (baselines/TLCGNN.py:27-62, G10):
+    this pins the decoder half of the model-side restatement (M3 / the decode of H3) with the reference's own outputs."""
+    import torch
+    from oracle import lp_forward_ref as ref
+    d = np.load(os.path.join(G, "decode.npz"))
+    tp, tn, vp, vn, sp_, sn = d["counts"].tolist()
+    np.random.seed(int(d["np_seed"]))
+    index = np.random.randint(0, tn, tp)                              # TLCGNN.py:31
+    assert np.array_equal(index, d["train_index"])
+    sel = {"train": np.concatenate([np.arange(tp), tp + index]), "val": np.arange(tp + tn, tp + tn + vp + vn),
+           "test": np.arange(tp + tn + vp + vn, len(d["pairs"]))}
+    w = [torch.from_numpy(d[k]) for k in ("lin1_w", "lin1_b", "lin_w", "lin_b")]
+    for kind, idx in sel.items():
+        emb = torch.from_numpy(d["emb"].copy())
+        prob = ref.tlcgnn_decode(emb, torch.from_numpy(d["pairs"][idx]), torch.from_numpy(d["PI"][idx]), *w).numpy()
+        want = d["prob_" + kind]
+        assert prob.shape == want.shape
+        assert np.all(np.abs(prob - want) <= 1e-6 * np.abs(want) + 1e-30), kind
+        assert np.array_equal(d["y_" + kind], d["y"][idx].astype(np.float32))
+        assert np.array_equal(emb.numpy(), d["emb_after_" + kind])     # renorm_ in place, rows with norm <= 1 untouched
+    assert float(d["prob_train"].min()) < 1e-15 and float(d["prob_train"].max()) > 0.88   # both ends of the clamp occur

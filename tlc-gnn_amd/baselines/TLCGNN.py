@@ -62,8 +62,9 @@ class Net(torch.nn.Module):
         self.leakyrelu = torch.nn.LeakyReLU(0.2, True)
         self.linear = torch.nn.Linear(dimension * dimension, 1, bias=True)
         self.linear_1 = torch.nn.Linear(dimension * dimension + 16, dimension * dimension, bias=True)
-        self._pi_dev = None
-        self._pairs_dev = None
+        self._pi_dev = self._pairs_dev = None           # device tables of decode(), see _tables
+        self._pi_src = self._pairs_src = None
+        self._pi_stamp = self._pairs_stamp = None
         self._xs = None                 # (features tensor, its version, SparseRows or None): see _sparse_features
 
     # density under which x @ W runs over the stored entries of x.  Measured on MI355X, 19 717 x 500 @ 500 x 100: the dense f32
@@ -82,25 +83,37 @@ class Net(torch.nn.Module):
             self._xs = (x, x._version, xs if xs.density < self.SPARSE_FEATURES_BELOW else None)
         return self._xs[2]
 
-    # device-resident copies of the per-pair tables (the reference re-uploads a slice on every decode, TLCGNN.py:52-53).
-    # At PubMed scale the tables are the streamed forms of pi_cache (SparseImages / LazyPairList): rows are gathered by index.
+    # device-resident copies of the per-pair tables (the reference re-slices and re-uploads on every decode, TLCGNN.py:35-36,
+    # 52-53, so it always sees the CURRENT self.PI / data.total_edges).  The copies are therefore tied to the objects they were
+    # made from: rebinding `model.PI` or `data.total_edges` -- or an in-place edit of a torch tensor (its _version) -- makes the
+    # next decode upload again.  numpy has no modification counter: after editing such an array IN PLACE call
+    # `invalidate_tables()`.  At PubMed scale the tables are the streamed forms of pi_cache (SparseImages / LazyPairList).
+    @staticmethod
+    def _stamp(obj, device):
+        return (id(obj), getattr(obj, "_version", None), tuple(getattr(obj, "shape", ())), str(device))
+
+    def invalidate_tables(self):
+        self._pi_dev = self._pairs_dev = None
+        self._pi_src = self._pairs_src = None
+
     def _tables(self, data, device):
         from ..pi_cache import SparseImages, LazyPairList
-        if self._pi_dev is None or (isinstance(self._pi_dev, torch.Tensor) and self._pi_dev.device != device):
-            pi = self.PI
+        pi, te = self.PI, data.total_edges
+        # (the source objects are held, so their ids cannot be recycled while the stamps are compared)
+        if getattr(self, "_pi_src", None) is not pi or self._pi_stamp != self._stamp(pi, device):
             if isinstance(pi, SparseImages):
                 self._pi_dev = pi
             else:
-                if not isinstance(pi, torch.Tensor):
-                    pi = torch.from_numpy(np.ascontiguousarray(pi, dtype=np.float64))
-                self._pi_dev = pi.to(device=device, dtype=torch.float64).reshape(pi.shape[0], -1).contiguous()
-            te = data.total_edges
+                t = pi if isinstance(pi, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pi, dtype=np.float64))
+                self._pi_dev = t.to(device=device, dtype=torch.float64).reshape(t.shape[0], -1).contiguous()
+            self._pi_src, self._pi_stamp = pi, self._stamp(pi, device)
+        if getattr(self, "_pairs_src", None) is not te or self._pairs_stamp != self._stamp(te, device):
             if isinstance(te, LazyPairList):
                 self._pairs_dev = te
             else:
-                if not isinstance(te, torch.Tensor):
-                    te = torch.from_numpy(np.ascontiguousarray(te, dtype=np.int64))
-                self._pairs_dev = te.to(device=device, dtype=torch.int32).contiguous()
+                t = te if isinstance(te, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(te, dtype=np.int64))
+                self._pairs_dev = t.to(device=device, dtype=torch.int32).contiguous()
+            self._pairs_src, self._pairs_stamp = te, self._stamp(te, device)
         return self._pi_dev, self._pairs_dev
 
     def encode(self, data):

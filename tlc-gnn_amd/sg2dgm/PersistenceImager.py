@@ -12,49 +12,47 @@ from .. import engine
 
 
 def linear_ramp(birth, pers, low=0.0, high=1.0, start=0.0, end=1.0):
-    """:9-30 (host helper kept for signature compatibility; the HIP raster applies the same ramp)."""
-    n = birth.shape[0]
-    w = np.zeros((n,))
-    for i in range(n):
-        if pers[i] < start:
-            w[i] = low
-        elif pers[i] > end:
-            w[i] = high
-        else:
-            w[i] = (pers[i] - start) * (high - low) / (end - start) + low
-    return w
+    """Weight of a (birth, persistence) pair (:9-30): `low` below `start`, `high` above `end`, the straight line between.
+    Host-side twin of the ramp the HIP raster applies; vectorised (`birth` only fixes the length)."""
+    pers = np.asarray(pers, dtype=np.float64)
+    line = (pers - start) * (high - low) / (end - start) + low
+    return np.where(pers < start, low, np.where(pers > end, high, line))
 
 
 def bvncdf(birth, pers, mu=None, sigma=None):  # marker for the default kernel (:32-51); evaluated on the GPU
     raise NotImplementedError("bvncdf is evaluated inside the HIP raster; the general (anisotropic) branch is not implemented")
 
 
+_UNIT = (0.0, 1.0)
+
+
 class PersistenceImager:
+    """Constructor signature of :207-208.  Only the configuration the pipeline instantiates is accepted -- unit birth and
+    persistence ranges, square pixels of 1/resolution, sigma = I, the default ramp -- so the state below is derived from
+    `resolution` alone; anything else raises."""
+
     def __init__(self, birth_range=None, pers_range=None, pixel_size=None, resolution=5,
                  weight=linear_ramp, weight_params=None, kernel=bvncdf, kernel_params=None):
-        if birth_range is None:
-            birth_range = (0.0, 1.0)
-        if pers_range is None:
-            pers_range = (0.0, 1.0)
-        self._resolution = (resolution, resolution)
-        if pixel_size is None:
-            pixel_size = np.min([pers_range[1] - pers_range[0], birth_range[1] - birth_range[0]]) / resolution
-        if weight_params is None:
-            weight_params = {}
-        if kernel_params is None:
-            kernel_params = {'sigma': np.array([[1.0, 0.0], [0.0, 1.0]])}
-        sigma = np.asarray(kernel_params.get('sigma'), dtype=np.float64)
-        if (tuple(birth_range) != (0.0, 1.0) or tuple(pers_range) != (0.0, 1.0) or weight is not linear_ramp
-                or weight_params or kernel is not bvncdf or abs(pixel_size - 1.0 / resolution) > 1e-15
-                or not np.array_equal(sigma, np.eye(2)) or not (1 <= resolution <= 8)):
+        sigma = np.eye(2) if kernel_params is None else np.asarray(kernel_params.get('sigma'), dtype=np.float64)
+        supported = (
+            tuple(birth_range or _UNIT) == _UNIT and tuple(pers_range or _UNIT) == _UNIT
+            and weight is linear_ramp and not weight_params and kernel is bvncdf
+            and isinstance(resolution, (int, np.integer)) and 1 <= resolution <= 8
+            and (pixel_size is None or abs(pixel_size - 1.0 / resolution) <= 1e-15)
+            and sigma.shape == (2, 2) and np.array_equal(sigma, np.eye(2)))
+        if not supported:
             raise NotImplementedError("PersistenceImager: only the configuration the TLC-GNN pipeline uses is implemented "
                                       "(ranges [0,1], sigma=I, linear_ramp defaults, resolution 1..8)")
-        self.weight, self.weight_params, self.kernel, self.kernel_params = weight, weight_params, kernel, kernel_params
-        self._pixel_size = pixel_size
-        self._birth_range, self._pers_range = tuple(birth_range), tuple(pers_range)
-        self._width = birth_range[1] - birth_range[0]
-        self._height = pers_range[1] - pers_range[0]
-        self._create_mesh()
+        res = int(resolution)
+        self.weight, self.weight_params = weight, {}
+        self.kernel, self.kernel_params = kernel, {'sigma': sigma}
+        self._resolution = (res, res)
+        self._pixel_size = 1.0 / res
+        self._birth_range = self._pers_range = _UNIT
+        self._width = self._height = 1.0
+        # pixel boundaries (:302-314 with zero padding): res + 1 points, spacing (1 + pixel) / (res + 1)
+        edges = (1.0 + self._pixel_size) / (res + 1) * np.arange(res + 1, dtype=np.float64)
+        self._bpnts, self._ppnts = edges, edges.copy()
 
     resolution = property(lambda self: self._resolution)
     pixel_size = property(lambda self: self._pixel_size)
@@ -62,13 +60,6 @@ class PersistenceImager:
     pers_range = property(lambda self: self._pers_range)
     width = property(lambda self: self._width)
     height = property(lambda self: self._height)
-
-    def _create_mesh(self):
-        # :302-314 (db = dp = 0 for the supported configuration)
-        self._bpnts = np.array(np.linspace(self._birth_range[0], self._birth_range[1] + self._pixel_size,
-                                           self._resolution[0] + 1, endpoint=False, dtype=np.float64))
-        self._ppnts = np.array(np.linspace(self._pers_range[0], self._pers_range[1] + self._pixel_size,
-                                           self._resolution[1] + 1, endpoint=False, dtype=np.float64))
 
     def transform(self, pers_dgm, skew=True):
         """:352-403.  pers_dgm: (N,2) birth-death pairs -> ndarray (res,res), [birth_bin, pers_bin]."""
