@@ -136,6 +136,21 @@ int tlc_pd_pi_batch_sizes(tlc_graph* g, int32_t* h_n, int32_t* h_m2, int64_t cap
 int tlc_pd_pi_algorithmic_bytes(int32_t n_nodes, const int32_t* h_rowptr, const int32_t* h_col, const int32_t* h_pairs,
                                 int64_t n_pairs, int hop, int res, double* h_out_bytes);
 
+/* Diagnostics (development tools and the tests of the divide-and-conquer cycle swap; no reference counterpart).
+ * dc_stats(): of the chunks since the last tlc_pd_pi_batch call began, h_out[0] = subgraphs whose cycle swap ran as the divide
+ * and conquer of tlc_pd_dc_kernel, h_out[1] = subgraphs it gave back to the serial walk (ranks that are no minimum-spanning-tree
+ * order).  Synchronises the stream.
+ * phase_profile(): per-phase cycle counters of the tier kernels in a library built with `make PHASE_DEBUG=1` (all zero
+ * otherwise): rows of 32 u64, one per tier and one for the early pass; at most cap_u64 values are written to h_out (may be
+ * null), *n_rows (may be null) = rows kept.  enable != 0 starts counting, 0 stops and frees the counters.
+ * set_option(): switches of one handle for A/B timing and for the tests that check that results do not depend on them:
+ * "extract" (ball-list extraction of the vicinities, hop <= 2), "heavy" (its hub-row skipping), "tiny" (lane-per-subgraph
+ * kernel for vicinities of at most 16 nodes / 24 edges); 1 = on (default; the environment variables TLC_EXTRACT / TLC_HEAVY /
+ * TLC_TINY = 0 switch them off at handle creation). */
+int tlc_debug_set_option(tlc_graph* g, const char* name, int value);
+int tlc_debug_dc_stats(tlc_graph* g, long long* h_out, void* stream);
+int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out, int64_t cap_u64, int32_t* n_rows);
+
 /* ---- P6-P8: perturb_filter_function / Union_find / Accelerate_PD ---------------------------------
  * (sg2dgm/accelerated_PD.py:6-178 and the Knowledge_Distillation fork, selected by TLC_KEEP_ZERO_PERS)
  * Batch of n_graphs independent graphs with caller-supplied filtration values.

@@ -1,0 +1,144 @@
+"""GPU: the ball-list extraction of the vicinities (csrc/extract.hip, hop <= 2) against the breadth-first kernels it replaces
+(csrc/vicinity.hip) and against the CPU oracle.
+
+The packed subgraph of a pair may list its directed entries in any order (the tier kernels do not care), so what has to agree
+is: |S| and the entry count per pair, the status byte (= the reference's exception class), and the image rows -- bit-exact
+status / sizes, images within 1e-8 relative of the oracle (north_star: 1e-5) and within 1e-12 between the modes (the order of
+the diagram points, hence of the fp64 image sum, may differ where keys tie)."""
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(g, torch, pairs, hop, **opts):
+    for k, v in opts.items():
+        g.set_option(k, v)
+    out, st = g.pd_pi_batch(torch.as_tensor(np.ascontiguousarray(pairs, dtype=np.int32)).cuda(), hop)
+    n, m2 = g.sizes(len(pairs))
+    stats = g.stats()
+    for k in opts:
+        g.set_option(k, 1)
+    return out.cpu().numpy(), st.cpu().numpy(), n, m2, stats
+
+
+def _mixed_pairs(n, edges, rs, k_pos, k_neg):
+    pos = edges[rs.permutation(len(edges))[:k_pos]]
+    neg = rs.randint(0, n, size=(k_neg, 2))
+    selfp = np.stack([np.arange(0, n, max(1, n // 50))] * 2, 1)
+    pairs = np.concatenate([pos, pos[:200, ::-1], neg, selfp]).astype(np.int32)
+    return pairs[rs.permutation(len(pairs))]
+
+
+@pytest.mark.parametrize("shape,scale,hop", [("PubMed", 0.35, 2), ("PubMed", 0.35, 1), ("Photo", 0.2, 1), ("Cora", 1.0, 2)])
+def test_extraction_modes_agree_and_match_the_oracle(shape, scale, hop):
+    import torch
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    n, edges, kappa, _, _ = synth.shaped_graph(shape, scale=scale)
+    rowptr, col, w = synth.edges_to_csr(n, edges, kappa)
+    rs = np.random.RandomState(3)
+    pairs = _mixed_pairs(n, edges, rs, 5000, 1500)
+    # a node without edges and ids outside the graph: KeyError rows
+    iso = np.flatnonzero(np.diff(rowptr) == 0)
+    extra = [[-1, 3], [n, 0]] + ([[int(iso[0]), 1]] if len(iso) else [])
+    pairs = np.concatenate([pairs, np.array(extra, dtype=np.int32)])
+    g = engine.DeviceGraph(rowptr, col, w)
+    new = _run(g, torch, pairs, hop)
+    light = _run(g, torch, pairs, hop, heavy=0)
+    old = _run(g, torch, pairs, hop, extract=0)
+    g.close()
+    for other, name in ((light, "heavy=0"), (old, "extract=0")):
+        assert np.array_equal(new[1], other[1]), name                   # status bytes
+        assert np.array_equal(new[2], other[2]), name                   # |S|
+        assert np.array_equal(new[3], other[3]), name                   # induced directed entries
+        assert np.abs(new[0] - other[0]).max() <= 1e-12 * max(1.0, np.abs(other[0]).max()), name
+        assert new[4]["tier_small"] == other[4]["tier_small"] and new[4]["tier_medium"] == other[4]["tier_medium"], name
+    ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, hop, n_threads=0)
+    assert np.array_equal(new[1], rst)
+    assert np.array_equal(new[0] == 0, ref == 0)
+    nz = ref != 0
+    assert rel_err(new[0][nz], ref[nz]).max() < 1e-8
+    assert (rst == 1).sum() >= 2 and (rst == 0).sum() > 1000
+
+
+def test_heavy_rows_hub_vicinities_and_dense_heavy_core():
+    """A graph built around the heavy-row path: a clique-like core of 40 hubs (every heavy-heavy entry comes from the dense
+    table), each hub with a fan of leaves, leaves cross-linked (light rows that find several heavy members), pairs hub-hub,
+    hub-leaf, leaf-leaf across fans, at hop 1 and 2 -- vicinities from 3 nodes to > 1 000."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    rs = np.random.RandomState(9)
+    H, fan = 40, 45
+    edges = set()
+    for a in range(H):
+        for b in range(a + 1, H):
+            if rs.rand() < 0.6:
+                edges.add((a, b))
+    nxt = H
+    leaves = []
+    for h in range(H):
+        for _ in range(fan):
+            edges.add((h, nxt))
+            leaves.append(nxt)
+            nxt += 1
+    leaves = np.array(leaves)
+    for _ in range(1500):                                  # leaves attached to a second hub / to each other
+        a = int(leaves[rs.randint(len(leaves))])
+        b = int(rs.randint(H)) if rs.rand() < 0.5 else int(leaves[rs.randint(len(leaves))])
+        if a != b:
+            edges.add((min(a, b), max(a, b)))
+    n = nxt + 3                                            # three isolated nodes at the end
+    e = np.array(sorted(edges), dtype=np.int64)
+    kappa = rs.uniform(-0.5, 0.9, size=len(e))
+    rowptr, col, w = synth.edges_to_csr(n, e, kappa)
+    assert (np.diff(rowptr) >= 32).sum() >= H
+    pairs = np.concatenate([e[rs.permutation(len(e))[:3000]], rs.randint(0, n, size=(500, 2)),
+                            np.stack([np.arange(H), (np.arange(H) + 1) % H], 1)]).astype(np.int32)
+    g = engine.DeviceGraph(rowptr, col, w)
+    for hop in (1, 2):
+        new = _run(g, torch, pairs, hop)
+        old = _run(g, torch, pairs, hop, extract=0)
+        assert np.array_equal(new[1], old[1]) and np.array_equal(new[2], old[2]) and np.array_equal(new[3], old[3])
+        ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, hop, n_threads=0)
+        assert np.array_equal(new[1], rst)
+        nz = ref != 0
+        assert np.array_equal(new[0] == 0, ref == 0)
+        assert rel_err(new[0][nz], ref[nz]).max() < 1e-8
+        assert new[2].max() > (500 if hop == 2 else 20)
+    g.close()
+
+
+def test_asymmetric_or_repeated_heavy_rows_switch_the_heavy_set_off():
+    """The mirror emission needs heavy rows that are symmetric and free of repeated columns (csrc/api.hip, build_heavy_set):
+    a CSR that violates this at a hub is still processed -- every row is read -- and equals the breadth-first kernels."""
+    import torch
+    from tlc_gnn_amd import engine
+    rs = np.random.RandomState(4)
+    n = 300
+    rows = [[] for _ in range(n)]
+    for x in range(1, 120):                               # hub 0 with 119 neighbours
+        rows[0].append((x, 1.0 + 0.001 * x)); rows[x].append((0, 1.0 + 0.001 * x))
+    for _ in range(600):
+        a, b = rs.randint(1, n, size=2)
+        if a != b and all(c != b for c, _ in rows[a]):
+            wt = float(rs.uniform(0.5, 1.9))
+            rows[a].append((b, wt)); rows[b].append((a, wt))
+    rows[0].append((5, 1.005))                            # column 5 twice in the hub's row (and once more in row 5)
+    rows[5].append((0, 1.005))
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    col, w = [], []
+    for x in range(n):
+        r = sorted(rows[x])
+        col += [c for c, _ in r]; w += [v for _, v in r]
+        rowptr[x + 1] = len(col)
+    pairs = np.array([[0, x] for x in range(1, 60)] + [[x, x + 1] for x in range(1, 200)], dtype=np.int32)
+    g = engine.DeviceGraph(rowptr, np.array(col, dtype=np.int32), np.array(w))
+    new = _run(g, torch, pairs, 2)
+    old = _run(g, torch, pairs, 2, extract=0)
+    g.close()
+    assert np.array_equal(new[1], old[1]) and np.array_equal(new[2], old[2]) and np.array_equal(new[3], old[3])
+    assert np.abs(new[0] - old[0]).max() <= 1e-12

@@ -520,10 +520,13 @@ def test_early_pass_overflow_takes_the_ordinary_path(torch_cuda):
     g.close()
 
 
-def test_count_pass_arena_overflow_falls_back_to_scan_and_fill(torch_cuda):
-    """COUNT writes MID / MEDIUM vicinities at bump-allocated arena offsets; the arena is sized from a guess before the sizes are
-    known.  First call on a fresh handle: the guess (64 Ki entries here) is far too small, the chunk must take the scan +
-    FILL path; second call: the arena has grown, COUNT's own writes are used.  Same rows both times, equal to the oracle's."""
+@pytest.mark.parametrize("extract", [1, 0])
+def test_count_pass_arena_overflow_falls_back_to_scan_and_fill(torch_cuda, extract):
+    """COUNT writes the vicinities below the heavy tiers into the arena itself (extraction: at the cursor of a per-workgroup
+    region, then into blocks from a bump counter; breadth-first kernels: MID / MEDIUM at bump-allocated offsets); the arena is
+    sized from a guess before the sizes are known.  First call on a fresh handle: the guess (made far too small here) runs
+    out, the chunk must take the scan + FILL path; second call: the arena has grown, COUNT's own writes are used.  Same rows
+    both times, equal to the oracle's."""
     torch = torch_cuda
     from tlc_gnn_amd import engine, synth
     from oracle import oracle
@@ -534,6 +537,9 @@ def test_count_pass_arena_overflow_falls_back_to_scan_and_fill(torch_cuda):
     e = np.unique(np.sort(np.array(e, dtype=np.int64), axis=1), axis=0)
     rowptr, col, w = synth.edges_to_csr(L + 1, e, rs.uniform(-0.5, 0.9, size=len(e)))
     g = engine.DeviceGraph(rowptr, col, w)
+    g.set_option("extract", extract)
+    g.set_option("x_region", 256)                              # (extraction: 400 regions of 256 entries + a bump area of 12 800)
+    g.set_option("x_bump_min", 0)
     distinct = e[rs.permutation(len(e))[:100]].astype(np.int32)
     pairs = np.tile(distinct, (4, 1))                         # 400 pairs x ~1 400 directed entries >> 65 536
     dp = _dev(torch, pairs, torch.int32)

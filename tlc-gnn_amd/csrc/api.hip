@@ -41,6 +41,7 @@ extern "C" int tlc_device_count(void) {
 #define TLC_EARLY_WG 256          /* workgroups (and scratch slots) of the early COUNT */
 #define TLC_EARLY_MIN_PAIRS 4096  /* smaller batches gain nothing from a second COUNT launch */
 #define TLC_TIMING_RING 64        /* chunks whose kernel events are kept */
+#define TLC_X_REGION 4096         /* arena entries of the region each workgroup of the extraction starts with (extract.hip) */
 
 struct HostSync {
     long long total_entries;
@@ -49,6 +50,7 @@ struct HostSync {
     unsigned long long stats[2];
     // written by tlc_scan_bin straight into this (pinned, device-mapped) block; seq last, after a system-scope fence
     volatile long long pub_total;
+    volatile long long pub_entries;
     volatile int pub_tier[TLC_N_TIERS];
     volatile int pub_early;
     volatile int pub_overflow;
@@ -66,6 +68,7 @@ struct tlc_graph {
     size_t cap_pairs;
     int *hdr_n, *hdr_m2, *hdr_lu, *hdr_lv, *tier_list;
     int* dc_lists;             // [4][cap_pairs]: MEDIUM / LARGE lists for tlc_pd_dc_kernel, and what it left for the serial kernel
+    int* big_lists;            // [3][cap_pairs]: the bins of tlc_classify_kernel (extract.hip)
     long long* edge_off;
     // small device block: [0..3] tier counts
     int* d_ctl;
@@ -110,6 +113,8 @@ struct tlc_graph {
     hipEvent_t ev_fork, ev_join[TLC_N_SIDE];
     long long last_stats[10];
     unsigned long long* d_phase;   // diagnostics: [TLC_N_TIERS][32] cycle counters, null unless enabled
+    unsigned long long* d_pair_t;  // diagnostics (PHASE_DEBUG builds): [cap][4] wall-clock stamps per pair of the extraction
+    size_t cap_pair_t;
     // optional per-kernel timing (tlc_pd_pi_batch_set_timing): events bracket each launch on its own stream
     int timing;
     // A ring of event sets, one per chunk: a caller that enqueues batch after batch without synchronising reads the
@@ -122,13 +127,26 @@ struct tlc_graph {
     unsigned char* ev_used;
     int last_n_pairs;
     int prev_tc[TLC_N_TIERS];      // tier counts of the previous chunk (sizes of the speculative launches)
+    // tlc_extract_kernel (extract.hip, hop <= 2): ball lists of one hop value (built on first use), the heavy set (fixed)
+    int ball_list_hop;             // 0: none yet; -1: lists do not fit (the breadth-first kernels are used)
+    int* d_bptr;
+    int* d_bcol;
+    long long ball_entries;
+    int* d_hidx;
+    double* d_hh_w;
+    int hh_k;
+    size_t x_lds64, x_lds512;
+    size_t x_entries_hint;         // induced entries of the largest chunk seen (sizes the bump area of the next one)
+    // development / test switches (tlc_debug_set_option; initial values from the environment: TLC_EXTRACT, TLC_HEAVY, TLC_TINY)
+    int opt_extract, opt_heavy, opt_tiny;
+    int opt_x_region, opt_x_bump_min;   // arena entries per workgroup region / minimum bump area of the extraction (tests shrink them)
 };
 
 static int ensure_pairs(tlc_graph* g, size_t n) {
     if (n <= g->cap_pairs) return TLC_OK;
     hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
-    hipFree(g->dc_lists);
-    g->hdr_n = g->hdr_m2 = g->hdr_lu = g->hdr_lv = g->tier_list = g->dc_lists = nullptr;
+    hipFree(g->dc_lists); hipFree(g->big_lists);
+    g->hdr_n = g->hdr_m2 = g->hdr_lu = g->hdr_lv = g->tier_list = g->dc_lists = g->big_lists = nullptr;
     g->edge_off = nullptr;
     g->cap_pairs = 0;
     TLC_HIP_CHECK(hipMalloc(&g->hdr_n, n * sizeof(int)));
@@ -138,6 +156,7 @@ static int ensure_pairs(tlc_graph* g, size_t n) {
     TLC_HIP_CHECK(hipMalloc(&g->tier_list, n * TLC_N_TIERS * sizeof(int)));
     TLC_HIP_CHECK(hipMalloc(&g->edge_off, (n + 1) * sizeof(long long)));
     TLC_HIP_CHECK(hipMalloc(&g->dc_lists, 6 * (n + TLC_EARLY_SLOTS) * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&g->big_lists, 3 * n * sizeof(int)));
     g->cap_pairs = n;
     return TLC_OK;
 }
@@ -239,6 +258,92 @@ static int ensure_huge(tlc_graph* g) {
     return TLC_OK;
 }
 
+
+// ---- the heavy set of tlc_extract_kernel (extract.hip) -------------------------------------------------------------------
+// The hh_k <= 256 nodes of the highest degrees >= 32.  Their rows are never read by the extraction sweep: an entry h -> x
+// is emitted as the mirror of x -> h found in row x, which needs the CSR to be symmetric AT THE HEAVY ROWS (checked here,
+// entry for entry, weights included) and entries between two heavy nodes come from a dense table (so a repeated entry
+// between two heavy nodes cannot be represented).  Whatever fails switches the heavy set off; the sweep then reads every row.
+#define TLC_HEAVY_MIN_DEG 32
+#define TLC_HEAVY_MAX 256
+static int build_heavy_set(tlc_graph* g, const int32_t* rp, const int32_t* col, const double* w) {
+    const int n = g->n_nodes;
+    std::vector<int> cand;
+    for (int x = 0; x < n; ++x) if (rp[x + 1] - rp[x] >= TLC_HEAVY_MIN_DEG) cand.push_back(x);
+    if (cand.empty()) return TLC_OK;
+    if ((int)cand.size() > TLC_HEAVY_MAX) {
+        std::nth_element(cand.begin(), cand.begin() + TLC_HEAVY_MAX, cand.end(), [&](int a, int b) {
+            const int da = rp[a + 1] - rp[a], db = rp[b + 1] - rp[b];
+            return da != db ? da > db : a < b;
+        });
+        cand.resize(TLC_HEAVY_MAX);
+    }
+    std::sort(cand.begin(), cand.end());
+    const int K = (int)cand.size();
+    std::vector<int> hidx((size_t)n, -1);
+    for (int k = 0; k < K; ++k) hidx[cand[k]] = k;
+    std::vector<double> hh((size_t)K * K, 0.0);
+    bool ok = true;
+    std::vector<int> seen((size_t)n, -1);                     // last heavy row that listed this column
+    for (int k = 0; k < K && ok; ++k) {
+        const int h = cand[k];
+        for (int j = rp[h]; j < rp[h + 1] && ok; ++j) {
+            const int y = col[j];
+            if (seen[y] == k) { ok = false; break; }          // a column twice in one heavy row
+            seen[y] = k;
+            if (hidx[y] >= 0) {
+                hh[(size_t)k * K + hidx[y]] = w[j];
+            } else {
+                // the mirror entry y -> h with the same weight, exactly once
+                int found = 0;
+                for (int t = rp[y]; t < rp[y + 1]; ++t) if (col[t] == h) found += (w[t] == w[j]) ? 1 : 2;
+                if (found != 1) ok = false;
+            }
+        }
+    }
+    for (int a = 0; a < K && ok; ++a)
+        for (int b = 0; b < K && ok; ++b) if ((hh[(size_t)a * K + b] != 0.0) != (hh[(size_t)b * K + a] != 0.0) || hh[(size_t)a * K + b] != hh[(size_t)b * K + a]) ok = false;
+    if (!ok) return TLC_OK;                                   // (not an error: the sweep reads every row)
+    TLC_HIP_CHECK(hipMalloc(&g->d_hidx, (size_t)n * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&g->d_hh_w, (size_t)K * K * sizeof(double)));
+    TLC_HIP_CHECK(hipMemcpy(g->d_hidx, hidx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    TLC_HIP_CHECK(hipMemcpy(g->d_hh_w, hh.data(), (size_t)K * K * sizeof(double), hipMemcpyHostToDevice));
+    g->hh_k = K;
+    return TLC_OK;
+}
+
+// ball_hop(x) of every node as sorted id lists, for tlc_extract_kernel; one-off per (graph, hop), synchronous (the sizes come
+// back to the host for the offsets).  Lists beyond 2^31 - 1 entries or a quarter of the free memory are not built:
+// ball_list_hop = -1 and the caller uses the breadth-first kernels.
+static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
+    if (g->ball_list_hop == hop) return TLC_OK;
+    hipFree(g->d_bptr); hipFree(g->d_bcol);
+    g->d_bptr = g->d_bcol = nullptr; g->ball_list_hop = 0; g->ball_entries = 0;
+    const int n = g->n_nodes;
+    int* d_size = nullptr;
+    TLC_HIP_CHECK(hipMalloc(&d_size, (size_t)n * sizeof(int)));
+    const int grid = std::min(n, 4096);
+    int rc = tlc_launch_ball_list(false, n, g->nw, g->d_rowptr, g->d_col, hop, d_size, nullptr, nullptr, grid, s);
+    std::vector<int> sz((size_t)n + 1, 0);
+    if (rc == TLC_OK && hipMemcpyAsync(sz.data(), d_size, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) rc = TLC_ERR_HIP;
+    if (rc == TLC_OK && hipStreamSynchronize(s) != hipSuccess) rc = TLC_ERR_HIP;
+    hipFree(d_size);
+    if (rc != TLC_OK) { tlc_set_error("ball lists: %s", hipGetErrorString(hipGetLastError())); return rc; }
+    long long tot = 0;
+    for (int x = 0; x < n; ++x) { const int c = sz[x]; sz[x] = (int)tot; tot += c; if (tot > 0x7fffffffll) break; }
+    size_t free_b = 0, total_b = 0;
+    hipMemGetInfo(&free_b, &total_b);
+    if (tot > 0x7fffffffll || (size_t)tot * sizeof(int) > free_b / 4) { g->ball_list_hop = -1; return TLC_OK; }
+    sz[n] = (int)tot;
+    TLC_HIP_CHECK(hipMalloc(&g->d_bptr, ((size_t)n + 1) * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&g->d_bcol, ((size_t)tot + 8) * sizeof(int)));
+    TLC_HIP_CHECK(hipMemcpyAsync(g->d_bptr, sz.data(), ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    if ((rc = tlc_launch_ball_list(true, n, g->nw, g->d_rowptr, g->d_col, hop, nullptr, g->d_bptr, g->d_bcol, grid, s)) != TLC_OK) return rc;
+    TLC_HIP_CHECK(hipStreamSynchronize(s));                  // (sz is host memory of this frame)
+    g->ball_list_hop = hop; g->ball_entries = tot;
+    return TLC_OK;
+}
+
 extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const int32_t* h_col, const double* h_w,
                                 int device, tlc_graph** out) {
     TLC_REQUIRE(out != nullptr, "out is null");
@@ -268,6 +373,9 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     if (!g) return TLC_ERR_OUT_OF_MEMORY;
     memset(g, 0, sizeof(*g));
     g->device = device; g->n_nodes = n_nodes; g->nnz = nnz; g->nw = nw; g->vic_lds = lds;
+    auto env_on = [](const char* name) { const char* v = getenv(name); return !(v && v[0] == '0'); };
+    g->opt_extract = env_on("TLC_EXTRACT"); g->opt_heavy = env_on("TLC_HEAVY"); g->opt_tiny = env_on("TLC_TINY");
+    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
@@ -306,8 +414,12 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int per_cu = (int)std::min<size_t>(28, (160 * 1024) / std::max<size_t>(lds + 64, 1));
     if (per_cu < 1) per_cu = 1;
+    g->x_lds64 = tlc_extract_lds_bytes(nw, 64);
+    g->x_lds512 = tlc_extract_lds_bytes(nw, 512);
+    // (the extraction kernel's workgroups are smaller: the scratch slots cover whichever kernel runs more of them)
+    per_cu = std::max(per_cu, (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(g->x_lds64 + 64, 1)));
     g->vic_slots = cus * per_cu;
-    (void)rc;
+    if ((rc = build_heavy_set(g, h_rowptr, h_col, h_w)) != TLC_OK) return fail(rc);
     *out = g;
     return TLC_OK;
 }
@@ -318,10 +430,11 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     hipDeviceSynchronize();
     hipFree(g->d_rowptr); hipFree(g->d_col); hipFree(g->d_w);
     hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
-    hipFree(g->dc_lists);
+    hipFree(g->dc_lists); hipFree(g->big_lists);
     hipFree(g->d_ctl); hipFree(g->d_block_sums); hipFree(g->d_totals);
     if (g->h_sync) hipHostFree(g->h_sync);
-    hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->S_dir); hipFree(g->S_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch); hipFree(g->handoff); hipFree(g->handoff_large); hipFree(g->d_phase);
+    hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->S_dir); hipFree(g->S_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch); hipFree(g->handoff); hipFree(g->handoff_large); hipFree(g->d_phase); hipFree(g->d_pair_t);
+    hipFree(g->d_bptr); hipFree(g->d_bcol); hipFree(g->d_hidx); hipFree(g->d_hh_w);
     hipFree(g->d_ball_ub[0]); hipFree(g->d_ball_ub[1]); hipFree(g->d_cand_list); hipFree(g->d_early_list); hipFree(g->E_dir); hipFree(g->E_lw);
     if (g->ev_early) hipEventDestroy(g->ev_early);
     if (g->ev_scan) hipEventDestroy(g->ev_scan);
@@ -363,20 +476,27 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     int rc;
     if ((rc = ensure_pairs(g, (size_t)n_pairs)) != TLC_OK) return rc;
     if ((rc = ensure_vic_scratch(g, hop)) != TLC_OK) return rc;
-    if ((rc = ensure_small(g, (size_t)n_pairs)) != TLC_OK) return rc;
     TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl, 0, (64 + 1024 + 8) * sizeof(int), s));       // control words, scan flags, statistics
 
     TlcVicParams vp;
     memset(&vp, 0, sizeof(vp));
     vp.n_nodes = g->n_nodes; vp.nw = g->nw; vp.rowptr = g->d_rowptr; vp.col = g->d_col; vp.w = g->d_w;
     vp.dbg = g->d_phase ? g->d_phase + 32 * TLC_TIER_HUGE : nullptr;   // (diagnostics share the HUGE tier's counter row)
+    if (g->d_phase) {
+        if (g->cap_pair_t < (size_t)n_pairs) {
+            hipFree(g->d_pair_t); g->d_pair_t = nullptr; g->cap_pair_t = 0;
+            TLC_HIP_CHECK(hipMalloc(&g->d_pair_t, (size_t)n_pairs * 4 * sizeof(unsigned long long)));
+            g->cap_pair_t = (size_t)n_pairs;
+        }
+        TLC_HIP_CHECK(hipMemsetAsync(g->d_pair_t, 0, (size_t)n_pairs * 4 * sizeof(unsigned long long), s));
+        vp.dbg_pair_t = g->d_pair_t;
+    }
     vp.pairs = d_pairs; vp.n_pairs = n_pairs; vp.hop = hop; vp.flags = flags; vp.res = res;
     vp.scratch = g->vic_scratch; vp.scratch_stride = g->vic_stride;
     vp.hdr_n = g->hdr_n; vp.hdr_m2 = g->hdr_m2; vp.hdr_lu = g->hdr_lu; vp.hdr_lv = g->hdr_lv;
     vp.out_pi = d_out_pi; vp.out_status = d_out_status; vp.out_n = d_out_n; vp.out_m = d_out_m;
     vp.edge_off = g->edge_off; vp.A_dir = nullptr; vp.A_lw = nullptr;
     vp.ids_off = (const long long*)d_ids_off; vp.out_ids = d_out_ids;
-    vp.small_dir = g->S_dir; vp.small_lw = g->S_lw;
 
     // (the attribute is per device and per size: tracked in the handle, which is bound to one device and one graph size)
     if (!g->lds_attr_set && g->vic_lds > 64 * 1024) {
@@ -416,13 +536,35 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     const bool bump = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges;
     unsigned long long* d_bump_top = reinterpret_cast<unsigned long long*>(g->d_ctl + 20);
     int* d_bump_overflow = g->d_ctl + 22;
+    const bool early = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges && hop <= 2 && n_pairs >= TLC_EARLY_MIN_PAIRS;
+    // hop <= 2, plain image batch: the extraction runs from the ball lists (extract.hip); otherwise the breadth-first kernels
+    bool use_x = bump && hop <= 2 && !(flags & TLC_INCLUDE_ROOTS) && g->opt_extract;
+    if (use_x) {
+        if ((rc = ensure_ball_lists(g, hop, s)) != TLC_OK) return rc;
+        use_x = g->ball_list_hop == hop;
+    }
+    const int xgrid = std::min(n_pairs, g->vic_slots);
+    long long bump_base = 0;
+    if (use_x) {
+        // arena = one region per workgroup of the extraction (main pass, then the early pass), then the bump area
+        const long long regions = (long long)xgrid + (early ? TLC_EARLY_WG : 0);
+        bump_base = regions * g->opt_x_region;
+        const size_t want = (size_t)bump_base + std::max<size_t>(std::max<size_t>((size_t)n_pairs * 32, (size_t)g->opt_x_bump_min), g->x_entries_hint + g->x_entries_hint / 2);
+        if (g->cap_entries < want && (rc = ensure_arena(g, want)) != TLC_OK) return rc;
+        vp.small_dir = nullptr; vp.small_lw = nullptr;
+        vp.bptr = g->d_bptr; vp.bcol = g->d_bcol;
+        if (g->hh_k > 0 && g->opt_heavy) { vp.hidx = g->d_hidx; vp.hh_w = g->d_hh_w; vp.hh_k = g->hh_k; }
+        vp.region_entries = g->opt_x_region; vp.bump_base = bump_base; vp.region_base_wg = 0;
+    } else {
+        if ((rc = ensure_small(g, (size_t)n_pairs)) != TLC_OK) return rc;
+        vp.small_dir = g->S_dir; vp.small_lw = g->S_lw;
+    }
     if (bump) {
         if (g->cap_entries == 0 &&
             (rc = ensure_arena(g, std::min<size_t>((size_t)n_pairs * 128, (size_t)1 << 23))) != TLC_OK) return rc;
         vp.A_dir = g->A_dir; vp.A_lw = g->A_lw;
         vp.bump_top = d_bump_top; vp.bump_cap = (long long)g->cap_entries; vp.bump_overflow = d_bump_overflow;
     }
-    const bool early = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges && hop <= 2 && n_pairs >= TLC_EARLY_MIN_PAIRS;
     int* d_cand_count = g->d_ctl + 16;
     int* d_early_count = g->d_ctl + 17;
     int* d_early_started = g->d_ctl + 18;
@@ -431,7 +573,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     memset(&pp, 0, sizeof(pp));
     pp.hdr_n = g->hdr_n; pp.hdr_m2 = g->hdr_m2; pp.hdr_lu = g->hdr_lu; pp.hdr_lv = g->hdr_lv;
     pp.edge_off = g->edge_off;
-    pp.small_dir = g->S_dir; pp.small_lw = g->S_lw;
+    pp.small_dir = use_x ? nullptr : g->S_dir; pp.small_lw = use_x ? nullptr : g->S_lw;
     pp.flags = flags; pp.res = res; pp.out_pi = d_out_pi; pp.out_status = d_out_status;
     pp.ids_off = (const long long*)d_ids_off; pp.out_f = d_out_f; pp.out_n = d_out_n; pp.pi_enabled = pi_enabled;
     pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
@@ -450,20 +592,33 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s));                  // after the memsets (and the one-off bounds)
         TLC_HIP_CHECK(hipStreamWaitEvent(es, g->ev_fork, 0));
         // (TLC_INCLUDE_ROOTS adds at most the two roots to a vicinity)
-        if ((rc = tlc_launch_select_heavy(n_pairs, d_pairs, g->n_nodes, g->d_ball_ub[(hop - 1) & 1], TLC_M_NMAX - 1, TLC_EARLY_CAND,
-                                          d_cand_count, g->d_cand_list, es)) != TLC_OK) return rc;
+        if (use_x) {
+            // exact ball sizes: the candidates of the early pass and the bins the main pass takes first
+            if ((rc = tlc_launch_classify(n_pairs, d_pairs, g->n_nodes, g->d_bptr, TLC_M_NMAX - 1, TLC_EARLY_CAND, d_cand_count,
+                                          g->d_cand_list, g->d_ctl + 32, g->big_lists, es)) != TLC_OK) return rc;
+        } else if ((rc = tlc_launch_select_heavy(n_pairs, d_pairs, g->n_nodes, g->d_ball_ub[(hop - 1) & 1], TLC_M_NMAX - 1, TLC_EARLY_CAND,
+                                                 d_cand_count, g->d_cand_list, es)) != TLC_OK) return rc;
         TlcVicParams ep = vp;
-        ep.bump_top = nullptr;
         ep.fill_mode = 1; ep.fill_list = g->d_cand_list; ep.fill_count = TLC_EARLY_CAND; ep.work_count_dev = d_cand_count;
         ep.scratch_base_slot = g->vic_slots;
-        ep.out_pi = nullptr; ep.out_status = nullptr; ep.out_n = nullptr; ep.out_m = nullptr;   // the main COUNT reports
-        ep.small_dir = nullptr; ep.small_lw = nullptr;
         ep.dbg = g->d_phase ? g->d_phase + 32 * TLC_N_TIERS : nullptr;        // (diagnostics: the early pass has its own row)
         ep.early_list = g->d_early_list; ep.early_count = d_early_count; ep.early_cap = TLC_EARLY_SLOTS;
         ep.early_dir = g->E_dir; ep.early_lw = g->E_lw;
         ep.started = d_cand_started;
-        hipLaunchKernelGGL((tlc_vicinity_kernel<false, 512>), dim3(TLC_EARLY_WG), dim3(512), g->vic_lds, es, ep);
-        TLC_HIP_CHECK(hipGetLastError());
+        if (use_x) {
+            // the early pass OWNS its candidates: headers, status bytes, zero rows, slots and bump-allocated vicinities are all
+            // its own, and the main COUNT leaves those pairs out (same predicate as the selection, see TlcVicParams::skip_ub)
+            ep.region_base_wg = xgrid;
+            if ((rc = tlc_launch_extract(512, TLC_EARLY_WG, g->x_lds512, ep, es)) != TLC_OK) return rc;
+            vp.skip_threshold = TLC_M_NMAX - 1; vp.skip_count = d_cand_count; vp.skip_cap = TLC_EARLY_CAND;
+            vp.big_count = g->d_ctl + 32; vp.big_list = g->big_lists;
+        } else {
+            ep.bump_top = nullptr;
+            ep.out_pi = nullptr; ep.out_status = nullptr; ep.out_n = nullptr; ep.out_m = nullptr;   // the main COUNT reports
+            ep.small_dir = nullptr; ep.small_lw = nullptr;
+            hipLaunchKernelGGL((tlc_vicinity_kernel<false, 512>), dim3(TLC_EARLY_WG), dim3(512), g->vic_lds, es, ep);
+            TLC_HIP_CHECK(hipGetLastError());
+        }
         TLC_HIP_CHECK(hipEventRecord(g->ev_early, es));
         TlcPdParams lp = pp;
         lp.tier_list = g->d_early_list; lp.tier_count = TLC_EARLY_SLOTS; lp.tier_count_dev = d_early_count;
@@ -493,9 +648,14 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     vp.work_counter = g->d_ctl + 24;
     vp.work_chunk = std::max(4, n_pairs / 8192);
     T0(0, s);
-    hipLaunchKernelGGL((tlc_vicinity_kernel<false, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
+    if (use_x) {
+        if ((rc = tlc_launch_extract(64, xgrid, g->x_lds64, vp, s)) != TLC_OK) return rc;
+    } else {
+        hipLaunchKernelGGL((tlc_vicinity_kernel<false, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
+    }
     T1(0, s);
     vp.work_counter = nullptr;
+    vp.skip_count = nullptr; vp.big_count = nullptr;      // (the FILL launches below are list-driven)
     TLC_HIP_CHECK(hipGetLastError());
     if (early) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_early, 0));   // the scan reads the early list
 
@@ -506,19 +666,20 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     TlcScanParams sp;
     sp.n_pairs = n_pairs; sp.hdr_n = g->hdr_n; sp.hdr_m2 = g->hdr_m2;
     sp.block_agg = g->d_block_sums; sp.block_flag = g->d_ctl + 64; sp.sync = g->d_ctl + 10; sp.totals = g->d_totals;
-    sp.edge_off = g->edge_off; sp.tier_count = g->d_ctl; sp.tier_list = g->tier_list; sp.small_arena = 1;
+    sp.edge_off = g->edge_off; sp.tier_count = g->d_ctl; sp.tier_list = g->tier_list; sp.small_arena = use_x ? 0 : 1;
     // the plain TLC-GNN image batch at resolution 5: the smallest vicinities go to the lane-per-subgraph kernel (pd_tiny.hip)
-    static const bool tiny_env_off = getenv("TLC_TINY") && getenv("TLC_TINY")[0] == '0';        // (development switch)
-    sp.tiny_ok = (!tiny_env_off && pi_enabled && flags == 0u && res == 5 && !d_out_ids && !d_out_f && !d_out_edges) ? 1 : 0;
+    sp.tiny_ok = (g->opt_tiny && pi_enabled && flags == 0u && res == 5 && !d_out_ids && !d_out_f && !d_out_edges) ? 1 : 0;
     sp.early_list = early ? g->d_early_list : nullptr; sp.early_count = d_early_count; sp.early_cap = TLC_EARLY_SLOTS;
     sp.h_early = const_cast<int*>(&g->h_sync_dev->pub_early);
-    sp.bump_top = bump ? d_bump_top : nullptr; sp.bump_overflow = d_bump_overflow;
+    sp.bump_top = bump ? d_bump_top : nullptr; sp.bump_overflow = d_bump_overflow; sp.bump_base = bump_base;
     sp.h_overflow = const_cast<int*>(&g->h_sync_dev->pub_overflow);
     // The arena size and the tier counts come back through mapped host memory: the last block of the scan stores them,
     // fences at system scope and bumps a sequence number the host polls -- no copy kernels, no stream synchronisation on
     // the critical path.  The poll gives up after 200 us and falls back to synchronising the stream (which also surfaces
     // a kernel fault).
     sp.h_total = const_cast<long long*>(&g->h_sync_dev->pub_total);
+    sp.h_entries = const_cast<long long*>(&g->h_sync_dev->pub_entries);
+    sp.entries_sum = reinterpret_cast<unsigned long long*>(g->d_ctl + 36);
     sp.h_tier = const_cast<int*>(g->h_sync_dev->pub_tier);
     sp.h_seq = const_cast<unsigned*>(&g->h_sync_dev->pub_seq);
     sp.seq = seq;
@@ -590,6 +751,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     for (int t = 0; t < TLC_N_TIERS; ++t) tc[t] = g->h_sync->pub_tier[t];
     // (COUNT's writes stand unless the chunk overflowed the arena: then everything is laid out by the scan and written by FILL)
     const bool bumped = bump && g->h_sync->pub_overflow == 0;
+    if (use_x) g->x_entries_hint = std::max(g->x_entries_hint, (size_t)std::max<long long>(total - (bumped ? bump_base : 0), 0));
     if ((rc = ensure_arena(g, (size_t)total, bumped ? (size_t)std::min<long long>(total, (long long)g->cap_entries) : 0, s)) != TLC_OK) return rc;
     if (tc[TLC_TIER_HUGE] > 0 && (rc = ensure_huge(g)) != TLC_OK) return rc;
 
@@ -603,6 +765,15 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         pp.huge_scratch = g->huge_scratch; pp.huge_stride = (long long)g->huge_stride;
         pp.huge_nmax = std::min(g->n_nodes, TLC_MAX_SUBGRAPH_NODES); pp.huge_mmax = (int)std::min<long long>(g->nnz / 2 + 1, TLC_MAX_SUBGRAPH_EDGES); pp.huge_slots = g->huge_slots;
         pp.started = (int*)(g->d_stats + 2);
+        // The extraction ran out of arena: every vicinity below the heavy tiers is laid out by the scan and written by the
+        // breadth-first FILL -- before any tier kernel may read it (that includes the SMALL tier, which has no slots of its own here)
+        bool filled_all = false;
+        if (use_x && !bumped && tc[0] + tc[1] + tc[4] + tc[5] + tc[6] > 0) {
+            vp.fill_mode = (tc[TLC_TIER_LARGE] + tc[TLC_TIER_HUGE] > 0 || n_early > 0) ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
+            vp.x_fill = 1; vp.bump_top = nullptr; vp.work_count_dev = nullptr;
+            if ((rc = tlc_launch_extract(64, xgrid, g->x_lds64, vp, s)) != TLC_OK) return rc;
+            filled_all = true;
+        }
         // hand-off slots (images only): the tiers with long serial tails run their cycle swap in a second, one-wavefront kernel
         size_t hand_base[TLC_N_TIERS] = {0, 0, 0, 0, 0, 0, 0};
         if (pi_enabled && !spec_done) {
@@ -660,7 +831,11 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
             if (tc[t] <= 0) continue;
             vp.fill_mode = 1; vp.fill_list = g->tier_list + (size_t)t * n_pairs; vp.fill_count = tc[t];
             // the heavy vicinities get 8 wavefronts each (hop <= 2), so that their many long CSR rows are in flight together
-            if (hop <= 2)
+            if (use_x) {
+                // (same entry order as the early pass's slots: rows do not depend on which way a vicinity took)
+                vp.x_fill = 1; vp.bump_top = nullptr; vp.work_count_dev = nullptr;
+                if ((rc = tlc_launch_extract(512, std::min(tc[t], TLC_EARLY_WG), g->x_lds512, vp, s)) != TLC_OK) return rc;
+            } else if (hop <= 2)
                 hipLaunchKernelGGL((tlc_vicinity_kernel<true, 512>), dim3(std::min(tc[t], g->vic_slots)), dim3(512), g->vic_lds, s, vp);
             else
                 hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(std::min(tc[t], g->vic_slots)), dim3(TLC_WAVE), g->vic_lds, s, vp);
@@ -696,7 +871,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
 
         // 2. the MEDIUM tier
         if (tc[TLC_TIER_MEDIUM] + tc[TLC_TIER_MEDHI] + tc[TLC_TIER_MID] > 0) {
-            if (!bumped) {
+            if (!bumped && !filled_all) {
                 vp.fill_mode = (heavy > 0 || n_early > 0) ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
                 hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
                 TLC_HIP_CHECK(hipGetLastError());
@@ -720,7 +895,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     g->last_stats[8] += tc[TLC_TIER_TINY];
     g->last_stats[TLC_TIER_LARGE] += n_early;
     g->last_stats[7] += tc[TLC_TIER_MID];
-    g->last_stats[4] += total;
+    g->last_stats[4] += g->h_sync->pub_entries;
     g->last_stats[6] += 1;
     return TLC_OK;
 }
@@ -849,15 +1024,49 @@ extern "C" int tlc_pi_raster(int32_t n_dgms, const int64_t* d_offs, const double
     return tlc_launch_pi_raster(n_dgms, (const long long*)d_offs, d_pts, res, d_out, stream);
 }
 
-// ---- diagnostics (not part of include/tlcgnn.h): per-phase cycle counters of the PD tier kernels -------------------
-extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out /* [TLC_N_TIERS + 1][32] or null */) {
+// ---- diagnostics (declared in include/tlcgnn.h, "diagnostics" section): per-phase cycle counters of the PD tier kernels --
+// Rows of 32 u64: one per tier (TLC_N_TIERS; the HUGE tier's row doubles as the main COUNT pass's), then the early pass.
+// `cap_u64` = how many u64 the caller allocated at h_out: never more than that is written; *n_rows (may be null) = rows the
+// library keeps, so a tool can size its buffer by asking first (h_out null).
+extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out, int64_t cap_u64, int32_t* n_rows) {
     TLC_REQUIRE(g != nullptr, "null graph");
+    TLC_REQUIRE(h_out == nullptr || cap_u64 >= 0, "cap_u64 < 0");
+    TLC_ON_DEVICE(g->device);
+    const size_t rows = (size_t)TLC_N_TIERS + 1;
+    if (n_rows) *n_rows = (int32_t)rows;
+    TLC_HIP_CHECK(hipDeviceSynchronize());
+    if (h_out && g->d_phase) {
+        const size_t k = std::min<size_t>(rows * 32, (size_t)cap_u64);
+        TLC_HIP_CHECK(hipMemcpy(h_out, g->d_phase, k * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    if (enable && !g->d_phase) TLC_HIP_CHECK(hipMalloc(&g->d_phase, rows * 32 * sizeof(unsigned long long)));
+    if (g->d_phase) TLC_HIP_CHECK(hipMemset(g->d_phase, 0, rows * 32 * sizeof(unsigned long long)));
+    if (!enable && g->d_phase) { hipFree(g->d_phase); g->d_phase = nullptr; }
+    return TLC_OK;
+}
+
+// diagnostics (PHASE_DEBUG builds): wall-clock stamps (100 MHz ticks) of the extraction per pair of the last chunk, [n][4]
+extern "C" int tlc_debug_pair_times(tlc_graph* g, unsigned long long* h_out, int64_t n_pairs) {
+    TLC_REQUIRE(g && h_out, "null argument");
     TLC_ON_DEVICE(g->device);
     TLC_HIP_CHECK(hipDeviceSynchronize());
-    if (h_out && g->d_phase) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_phase, (size_t)(TLC_N_TIERS + 1) * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (enable && !g->d_phase) TLC_HIP_CHECK(hipMalloc(&g->d_phase, (size_t)(TLC_N_TIERS + 1) * 32 * sizeof(unsigned long long)));
-    if (g->d_phase) TLC_HIP_CHECK(hipMemset(g->d_phase, 0, (size_t)(TLC_N_TIERS + 1) * 32 * sizeof(unsigned long long)));
-    if (!enable && g->d_phase) { hipFree(g->d_phase); g->d_phase = nullptr; }
+    const size_t k = std::min<size_t>((size_t)std::max<int64_t>(n_pairs, 0), g->d_pair_t ? g->cap_pair_t : 0);
+    if (k) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_pair_t, k * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return TLC_OK;
+}
+
+// development / test switches of one handle: "extract" (ball-list extraction, extract.hip), "heavy" (its heavy-row skipping),
+// "tiny" (lane-per-subgraph kernel, pd_tiny.hip); 1 = on (default), 0 = off.  "x_region" / "x_bump_min": arena entries of a
+// workgroup's region / of the bump area behind the regions (tests shrink them to reach the overflow path).  Results must not
+// depend on any of them.
+extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
+    TLC_REQUIRE(g && name, "null argument");
+    if (!strcmp(name, "extract")) g->opt_extract = value != 0;
+    else if (!strcmp(name, "heavy")) g->opt_heavy = value != 0;
+    else if (!strcmp(name, "tiny")) g->opt_tiny = value != 0;
+    else if (!strcmp(name, "x_region")) g->opt_x_region = std::max(value, 0);
+    else if (!strcmp(name, "x_bump_min")) g->opt_x_bump_min = std::max(value, 0);
+    else { tlc_set_error("tlc_debug_set_option: unknown option '%s'", name); return TLC_ERR_INVALID_ARG; }
     return TLC_OK;
 }
 

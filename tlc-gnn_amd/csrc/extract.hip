@@ -1,0 +1,663 @@
+// extract.hip -- P4 of the hot path for hop <= 2 (the only values the reference uses, TLCGNN.py:102), second form:
+// S = ball(u) & ball(v) from PRECOMPUTED BALL LISTS, the induced subgraph in one sweep that skips hub rows.
+//
+// Replaces sg2dgm_accelerate's BFS + set intersection + graph.subgraph (sg2dgm/riccidist2dgm.py:311-316), like
+// vicinity.hip (which stays for hop >= 3, the FILL pass of the heavy tiers and the variant entry points).
+//
+// What the per-phase counters of the first form said (PubMed-shaped batch, 37 676 pairs): 28 % of COUNT is the two
+// breadth-first searches, 70 % the two sweeps over the CSR rows of the members of S -- and 80 % of the entries those
+// sweeps read are not in S: half of them sit in the rows of a few dozen hub nodes that happen to be members.
+//   * ball_hop(x) is a property of the graph: it is listed once per (graph, hop) as sorted node ids (1.06 M entries =
+//     4 MB for PubMed, hop 2).  A pair marks the larger list in an LDS bitmap and filters the smaller one through it:
+//     two coalesced streams instead of a two-level row expansion, S comes out as an ascending id list (= local ids).
+//   * the order of the packed directed entries carries no meaning downstream (the tier kernels run Bellman-Ford over the
+//     entry list and sort the undirected edges by key), so an entry y -> x need not come from row y.  Rows of HEAVY
+//     members (the <= 256 highest degrees >= 32, fixed per graph; the two roots excepted -- all of N(u) lies in S when
+//     v is adjacent) are not read at all: a scanned row that finds a heavy member emits both directions, and
+//     heavy-heavy entries come from a dense K x K weight table.
+//   * one sweep: entries are written as they are found (positions from wave scans) at the cursor of an arena region
+//     that belongs to the workgroup (a fixed region per workgroup, further blocks from a bump counter when it is full): the
+//     place is known before the size is, so no vicinity up to the MEDIUM tier is swept twice, no per-pair allocation
+//     atomic, and the fixed 3 KB slots of the SMALL tier are gone (every tier kernel reads arena + edge_off).
+//   * longest first: per-pair wall-clock stamps (tools/pair_times.py) showed 90 % of the pairs done after 55 % of the
+//     kernel's time, the rest being a thin tail of MEDIUM-tier vicinities (50-70 us on one wavefront) that started late.
+//     min(|ball(u)|, |ball(v)|) bounds |S| and predicts it well, so tlc_classify_kernel bins the pairs by it ahead of
+//     the extraction and the workgroups take the bins in descending order before the rest.
+#include "vicinity_dev.h"
+
+#define TLC_X_HV_CAP 2048     /* local ids covered by the heavy-member bits; larger vicinities scan every row */
+#define TLC_X_H_CAP 128       /* heavy members listed per vicinity; more: every row is scanned */
+#define TLC_X_BLOCK 4096      /* arena entries a workgroup takes from the bump counter when its region is full (>= 2 * TLC_M_MMAX) */
+#define TLC_X_BIN_MIN 64      /* pairs whose smaller ball has at least this many nodes are binned and extracted first */
+
+namespace {
+
+template <int BW>
+struct XCfg {
+    static constexpr int SID_CAP = (BW == 64) ? 256 : 2048;   // member ids kept in LDS; beyond: the global scratch slot
+};
+
+#define TLC_X_UNITS (1024 + TLC_X_H_CAP * TLC_X_H_CAP / 64)    /* units of a sweep: 64-member batches + 64-pair heavy chunks */
+struct XLayout {
+    size_t o_pref, o_sid, o_hvy, o_hl, o_ctl, o_ucnt, total;
+};
+__host__ __device__ constexpr XLayout x_layout(int nw, int sid_cap, int bw) {
+    XLayout L{};
+    const size_t nw4 = (size_t)((nw + 3) & ~3);
+    L.o_pref = nw4 * 4;
+    L.o_sid = (L.o_pref + nw4 * 2 + 15) & ~(size_t)15;
+    L.o_hvy = L.o_sid + (size_t)sid_cap * 4;
+    L.o_hl = L.o_hvy + TLC_X_HV_CAP / 8;
+    L.o_ctl = L.o_hl + (size_t)TLC_X_H_CAP * 4;
+    L.o_ucnt = L.o_ctl + 64 + (size_t)(bw / 64) * 4 + 16;
+    L.total = L.o_ucnt + (bw > 64 ? (size_t)TLC_X_UNITS * 4 : 0);
+    return L;
+}
+
+struct XState {
+    unsigned* bits;
+    unsigned short* pref;
+    unsigned* hvy;
+    unsigned* hl;          // (local id << 16) | heavy index
+    int* ucnt;             // several wavefronts: entries / first entry number of every unit of a sweep
+    int* ctl;              // [0] lu [1] lv [2] entry counter (BW > 64) [3] heavy members [4] early slot [6..7] block grab; [8..11] region cursor / end (2 x i64, live across pairs)
+    int* xw;
+};
+
+__device__ __forceinline__ bool x_member(const XState& X, int y, int& ly) {
+    const unsigned word = X.bits[y >> 5];
+    const unsigned bit = 1u << (y & 31);
+    if (!(word & bit)) return false;
+    ly = (int)X.pref[y >> 5] + __popc(word & (bit - 1u));
+    return true;
+}
+__device__ __forceinline__ bool x_heavy(const XState& X, int ly) { return (X.hvy[ly >> 5] >> (ly & 31)) & 1u; }
+
+// One sweep over the rows of the members ids[0..n): every directed entry of the induced subgraph exactly once, as
+// (src local id << 16 | dst local id, weight).
+//
+// The ORDER of the entries carries no meaning downstream, but it decides how equal sort keys fall and with that the last bits
+// of an image, so it is made canonical: the same for every workgroup width, for the early pass, the main pass and the FILL
+// pass.  The sweep is a sequence of UNITS -- batch b of 64 consecutive members, then chunk c of 64 consecutive ordered pairs of
+// heavy members -- and a unit's entries are numbered the way ONE wavefront finds them (short rows by eight-entry round,
+// lane-major inside a round; then the long rows in lane order).  A single wavefront walks the units in order and writes as
+// it counts.  Several wavefronts take the units round-robin: they count every unit into ucnt[], a prefix over the units
+// places them, and a second walk writes.
+// Walks the units of this wavefront; ucnt (several wavefronts): WR ? the first entry number of every unit : receives the
+// count of every unit.  Returns the entries this wavefront counted.
+template <int BW, bool WR>
+__device__ __forceinline__ int x_sweep_wave(const TlcVicParams& p, const int* ids, int n, const XState& X, bool use_hvy, int nH,
+                                            unsigned* dir, double* lw, int cap, int* ucnt) {
+    const int lane = tlc_lane(), wv = (int)(threadIdx.x >> 6);
+    constexpr int NW = BW / 64;
+    int run = 0, counted = 0;
+    const int nb = (n + 63) >> 6;
+    for (int b = wv; b < nb; b += NW) {
+        if (NW > 1) { if (WR) run = ucnt[b]; else run = 0; }
+        const int k = (b << 6) + lane;
+        const bool act = k < n;
+        int rb = 0, re = 0;
+        if (act && !(use_hvy && x_heavy(X, k))) row_bounds(p.rowptr, ids[k], rb, re);
+        const bool big = (re - rb) >= 32;
+        // ---- short rows: a lane scans its own row, eight entries per round trip -------------------------------------
+        int j0 = big ? re : rb;
+        while (__any(j0 < re)) {
+            int bb[8], ly[8];
+            double ww[8];
+            unsigned hit = 0u, rev = 0u;
+            if (j0 < re) {
+                load_row8(p.col, j0, bb);
+                if (WR) load_row8w(p.w, j0, ww);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    ly[q] = 0;
+                    if (j0 + q < re && x_member(X, bb[q], ly[q])) {
+                        hit |= 1u << q;
+                        if (use_hvy && x_heavy(X, ly[q])) rev |= 1u << q;
+                    }
+                }
+            }
+            const int cnt = __popc(hit) + __popc(rev);
+            const int incl = tlc_wave_iscan_i32(cnt);
+            int off = run + incl - cnt;
+            run += __builtin_amdgcn_readlane(incl, 63);
+            if (WR && cnt) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if ((hit >> q) & 1u) {
+                        if (off < cap) { dir[off] = ((unsigned)k << 16) | (unsigned)ly[q]; lw[off] = ww[q]; }
+                        ++off;
+                        if ((rev >> q) & 1u) {
+                            if (off < cap) { dir[off] = ((unsigned)ly[q] << 16) | (unsigned)k; lw[off] = ww[q]; }
+                            ++off;
+                        }
+                    }
+                }
+            }
+            j0 += 8;
+        }
+        // ---- long scanned rows (a root that is a hub; a high degree outside the heavy set): the wavefront streams the row,
+        //      four 64-entry chunks in flight ---------------------------------------------------------------------------
+        unsigned long long mask = __ballot(act && big);
+        while (mask) {
+            const int L = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int jb = __builtin_amdgcn_readlane(rb, L), je = __builtin_amdgcn_readlane(re, L);
+            const int kk = (b << 6) + L;
+            for (int j = jb; j < je; j += 4 * TLC_WAVE) {
+                int cv[4];
+                double wvv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jj = j + r * TLC_WAVE + lane;
+                    cv[r] = jj < je ? p.col[jj] : -1;
+                    wvv[r] = (WR && jj < je) ? p.w[jj] : 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (j + r * TLC_WAVE >= je) break;                 // (uniform)
+                    int l = 0;
+                    const bool h = cv[r] >= 0 && x_member(X, cv[r], l);
+                    const bool rv = h && use_hvy && x_heavy(X, l);
+                    const unsigned long long m1 = __ballot(h), m2 = __ballot(rv);
+                    const int c1 = __popcll(m1);
+                    if (WR && h) {
+                        const int o1 = run + __popcll(m1 & tlc_lanemask_lt());
+                        if (o1 < cap) { dir[o1] = ((unsigned)kk << 16) | (unsigned)l; lw[o1] = wvv[r]; }
+                        if (rv) {
+                            const int o2 = run + c1 + __popcll(m2 & tlc_lanemask_lt());
+                            if (o2 < cap) { dir[o2] = ((unsigned)l << 16) | (unsigned)kk; lw[o2] = wvv[r]; }
+                        }
+                    }
+                    run += c1 + __popcll(m2);
+                }
+            }
+        }
+        if (NW > 1) {
+            if (!WR) { if (lane == 0) ucnt[b] = run; counted += run; }
+        }
+    }
+    // ---- heavy x heavy: ordered pairs of listed heavy members through the dense weight table (0 = not adjacent) ------------
+    if (use_hvy && nH > 0) {
+        const int np = nH * nH, nc = (np + 63) >> 6;
+        for (int c = wv; c < nc; c += NW) {
+            if (NW > 1) { if (WR) run = ucnt[nb + c]; else run = 0; }
+            const int t = (c << 6) + lane;
+            double w = 0.0;
+            unsigned ea = 0u, eb = 0u;
+            if (t < np) {
+                ea = X.hl[t / nH]; eb = X.hl[t % nH];
+                w = p.hh_w[(size_t)(ea & 0xffffu) * p.hh_k + (eb & 0xffffu)];
+            }
+            const bool h = w > 0.0;
+            const unsigned long long m1 = __ballot(h);
+            if (WR && h) {
+                const int o1 = run + __popcll(m1 & tlc_lanemask_lt());
+                if (o1 < cap) { dir[o1] = ((ea >> 16) << 16) | (eb >> 16); lw[o1] = w; }
+            }
+            run += __popcll(m1);
+            if (NW > 1 && !WR) { if (lane == 0) ucnt[nb + c] = run; counted += run; }
+        }
+    }
+    return NW > 1 ? counted : run;
+}
+
+// The sweep of a workgroup; dir may be null (count only).  Returns the number of entries (uniform over the workgroup).
+template <int BW>
+__device__ __forceinline__ int x_sweep(const TlcVicParams& p, const int* ids, int n, const XState& X, bool use_hvy, int nH,
+                                       unsigned* dir, double* lw, int cap) {
+    if (BW == 64) {
+        if (dir) return x_sweep_wave<BW, true>(p, ids, n, X, use_hvy, nH, dir, lw, cap, nullptr);
+        return x_sweep_wave<BW, false>(p, ids, n, X, use_hvy, nH, nullptr, nullptr, 0, nullptr);
+    }
+    int* ucnt = X.ucnt;
+    x_sweep_wave<BW, false>(p, ids, n, X, use_hvy, nH, nullptr, nullptr, 0, ucnt);
+    __syncthreads();
+    // exclusive prefix over the units (at most TLC_X_UNITS of them), a few consecutive units per thread
+    const int nu = ((n + 63) >> 6) + ((use_hvy && nH > 0) ? ((nH * nH + 63) >> 6) : 0);
+    const int per = (nu + BW - 1) / BW;
+    const int u0 = (int)threadIdx.x * per;
+    int mine = 0;
+    for (int q = 0; q < per; ++q) if (u0 + q < nu) mine += ucnt[u0 + q];
+    int total = 0;
+    int off = block_escan_i32<BW>(mine, X.xw, &total);
+    for (int q = 0; q < per; ++q) if (u0 + q < nu) { const int c = ucnt[u0 + q]; ucnt[u0 + q] = off; off += c; }
+    __syncthreads();
+    if (dir) x_sweep_wave<BW, true>(p, ids, n, X, use_hvy, nH, dir, lw, cap, ucnt);
+    __syncthreads();
+    return total;
+}
+
+template <int BW>
+__device__ __forceinline__ void x_zero_row(const TlcVicParams& p, int i, int status, int n_report, int lu, int lv) {
+    const int tid = threadIdx.x, res2 = p.res * p.res;
+    if (tid == 0) {
+        p.hdr_n[i] = 0; p.hdr_m2[i] = 0; p.hdr_lu[i] = lu; p.hdr_lv[i] = lv;
+        if (p.out_status) p.out_status[i] = (unsigned char)status;
+        if (p.out_n) p.out_n[i] = n_report;
+        if (p.out_m) p.out_m[i] = 0;
+    }
+    if (p.out_pi) for (int c = tid; c < res2; c += BW) p.out_pi[(size_t)i * res2 + c] = 0.0;
+}
+
+// One pair.  The bitmap is all zero on entry and on exit.
+template <int BW>
+__device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool from_rest, unsigned char* lds, int* slot) {
+    constexpr int SID_CAP = XCfg<BW>::SID_CAP;
+    const XLayout L = x_layout(p.nw, SID_CAP, BW);
+    const int nw4 = (p.nw + 3) & ~3;
+    XState X;
+    X.bits = (unsigned*)lds;
+    X.pref = (unsigned short*)(lds + L.o_pref);
+    int* sid = (int*)(lds + L.o_sid);
+    X.hvy = (unsigned*)(lds + L.o_hvy);
+    X.hl = (unsigned*)(lds + L.o_hl);
+    X.ctl = (int*)(lds + L.o_ctl);
+    X.xw = X.ctl + 16;
+    X.ucnt = (int*)(lds + L.o_ucnt);
+    const int tid = threadIdx.x;
+#ifdef TLC_PAIR_TIMES
+    // (per-pair wall-clock stamps only: sums through global atomics on one address would serialise the whole kernel)
+#define XSTAMP(k) do { if (p.dbg_pair_t && tid == 0 && (k) != 1) p.dbg_pair_t[4 * (size_t)i + ((k) == 0 ? 1 : (k))] = wall_clock64(); } while (0)
+#else
+#define XSTAMP(k) do { } while (0)
+#endif
+#ifdef TLC_PAIR_TIMES
+    const unsigned long long t_start = wall_clock64();
+#endif
+    const int u = p.pairs[2 * (size_t)i], v = p.pairs[2 * (size_t)i + 1];
+    // KeyError on dict_node (riccidist2dgm.py:353): ids the edge-built graph does not contain
+    bool missing = u < 0 || v < 0 || u >= p.n_nodes || v >= p.n_nodes;
+    int a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (!missing) {
+        int ru0, ru1, rv0, rv1;
+        row_bounds(p.rowptr, u, ru0, ru1);
+        row_bounds(p.rowptr, v, rv0, rv1);
+        row_bounds(p.bptr, u, a0, a1);
+        row_bounds(p.bptr, v, b0, b1);
+        missing = (ru1 == ru0) || (rv1 == rv0);
+        if (!missing && from_rest) {
+            const int na = a1 - a0, nb = b1 - b0, mn = na < nb ? na : nb;
+            // same predicates as tlc_classify_kernel: the early pass owns its candidates (as long as its list held them all;
+            // else they are extracted here); a binned pair was taken from its bin
+            if (p.skip_count && mn >= p.skip_threshold) {
+                if (*p.skip_count <= p.skip_cap) return;
+            } else if (p.big_count && mn >= TLC_X_BIN_MIN) return;
+        }
+    }
+    // FILL pass (the scan has laid the chunk out after an arena overflow; a heavy tier the early pass did not take): the
+    // headers exist, the entries go to edge_off[i] -- in the same canonical order as everywhere else
+    int fill_m2 = 0;
+    if (p.x_fill) {
+        const int hn = p.hdr_n[i];
+        if (hn <= 0) return;                                             // finished by the COUNT pass
+        fill_m2 = p.hdr_m2[i];
+        if (p.fill_mode == 2 && (hn > TLC_M_NMAX || (fill_m2 >> 1) > TLC_M_MMAX)) return;   // filled from the heavy tiers' lists
+    }
+    if (missing) {
+        x_zero_row<BW>(p, i, TLC_ST_MISSING_NODE, 0, -1, -1);
+        return;
+    }
+#ifdef TLC_PAIR_TIMES
+    if (p.dbg_pair_t && tid == 0) p.dbg_pair_t[4 * (size_t)i] = t_start;
+#endif
+    if (a1 - a0 < b1 - b0) { int t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; }    // [a0,a1): the larger ball
+    const int nA = a1 - a0, nB = b1 - b0;
+    // ---- S = ball(u) & ball(v) (:315): the smaller list filtered through a bitmap of the larger -----------------------------
+    int bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                       // (the first chunks of the smaller list are in flight while the larger is marked)
+        const int j = r * BW + tid;
+        bv[r] = j < nB ? p.bcol[b0 + j] : -1;
+    }
+    for (int j = tid; j < nA; j += 4 * BW) {
+        int av[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[r] = (j + r * BW < nA) ? p.bcol[a0 + j + r * BW] : -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (av[r] >= 0) atomicOr(&X.bits[av[r] >> 5], 1u << (av[r] & 31));
+    }
+    if (tid == 0) { X.ctl[0] = -1; X.ctl[1] = -1; }
+    __syncthreads();
+    const int capg = p.n_nodes < TLC_MAX_SUBGRAPH_NODES + 1 ? p.n_nodes : TLC_MAX_SUBGRAPH_NODES + 1;
+    int* ids = nB <= SID_CAP ? sid : slot;
+    const int cap_ids = nB <= SID_CAP ? SID_CAP : capg;
+    int n = 0;
+    for (int base = 0; base < nB; base += 4 * BW) {
+        if (base > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = base + r * BW + tid;
+                bv[r] = j < nB ? p.bcol[b0 + j] : -1;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (base + r * BW >= nB) break;                              // (uniform)
+            const int b = bv[r];
+            const bool h = b >= 0 && bit_test(X.bits, b);
+            int pos, tot;
+            if (BW == 64) {
+                const unsigned long long m = __ballot(h);
+                pos = n + __popcll(m & tlc_lanemask_lt());
+                tot = __popcll(m);
+            } else {
+                pos = n + block_escan_i32<BW>(h ? 1 : 0, X.xw, &tot);
+            }
+            if (h) {
+                if (pos < cap_ids) ids[pos] = b;
+                if (b == u) X.ctl[0] = pos;
+                if (b == v) X.ctl[1] = pos;
+            }
+            n += tot;
+        }
+    }
+    __syncthreads();
+    // the marks of the larger ball go (by list when that is the shorter way)
+    if (nA * 8 < nw4) {
+        for (int j = tid; j < nA; j += BW) X.bits[p.bcol[a0 + j] >> 5] = 0u;
+    } else {
+        uint4* z = reinterpret_cast<uint4*>(X.bits);
+        for (int w = tid; w < nw4 / 4; w += BW) z[w] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int lu = X.ctl[0], lv = X.ctl[1];
+    __syncthreads();
+    XSTAMP(0);
+    if (n == 0 || n > TLC_MAX_SUBGRAPH_NODES) {
+        // n == 0: AssertionError, zero connected components (:318).  n > 65535 does not fit the packed local ids: its own status
+        x_zero_row<BW>(p, i, n == 0 ? TLC_ST_DISCONNECTED : TLC_ST_TOO_LARGE, n == 0 ? 0 : -n, lu, lv);
+        return;
+    }
+    // ---- member bits, the rank of the first member of every touched bitmap word, heavy members ------------------------------
+    const bool heavy_ok = p.hidx != nullptr && n <= TLC_X_HV_CAP;
+    if (heavy_ok) for (int w = tid; w < TLC_X_HV_CAP / 32; w += BW) X.hvy[w] = 0u;
+    __syncthreads();
+    int nH = 0;
+    for (int base = 0; base < n; base += BW) {
+        const int k = base + tid;
+        int hi = -1;
+        if (k < n) {
+            const int x = ids[k];
+            if (heavy_ok && x != u && x != v) hi = p.hidx[x];
+            const int w = x >> 5;
+            atomicOr(&X.bits[w], 1u << (x & 31));
+            if (k == 0 || (ids[k - 1] >> 5) != w) X.pref[w] = (unsigned short)k;
+        }
+        if (heavy_ok) {                                      // (uniform) the heavy members, listed in member order
+            int q, tot;
+            if (BW == 64) {
+                const unsigned long long mk = __ballot(hi >= 0);
+                q = nH + __popcll(mk & tlc_lanemask_lt());
+                tot = __popcll(mk);
+            } else {
+                q = nH + block_escan_i32<BW>(hi >= 0 ? 1 : 0, X.xw, &tot);
+            }
+            if (hi >= 0) {
+                atomicOr(&X.hvy[k >> 5], 1u << (k & 31));
+                if (q < TLC_X_H_CAP) X.hl[q] = ((unsigned)k << 16) | (unsigned)hi;
+            }
+            nH += tot;
+        }
+    }
+    __syncthreads();
+    const bool use_hvy = heavy_ok && nH <= TLC_X_H_CAP;      // (more heavy members than the list holds: every row is scanned)
+    XSTAMP(1);
+    if (p.x_fill) {
+        const long long eo = p.edge_off[i];
+        x_sweep<BW>(p, ids, n, X, use_hvy, nH, p.A_dir + eo, p.A_lw + eo, fill_m2);
+        __syncthreads();
+        for (int k = tid; k < n; k += BW) X.bits[ids[k] >> 5] = 0u;
+        __syncthreads();
+        return;
+    }
+    // ---- induced subgraph (graph.subgraph(nodes), :316): one sweep, written at the cursor of this workgroup's arena region ----
+    // (room for the largest vicinity the region serves -- the MEDIUM tier's 2 x 1024 entries, or n^2 -- is secured first)
+    long long* cur = (long long*)(X.ctl + 8);            // [0] cursor [1] end of the current block
+    unsigned* wdir = nullptr;
+    double* wlw = nullptr;
+    int cap = 0;
+    long long at = -1;
+    const bool early_large_ok = p.early_list != nullptr && n <= TLC_L_NMAX;
+    if (p.bump_top && n <= TLC_M_NMAX) {
+        const long long nn = (long long)n * n;
+        cap = nn < 2 * TLC_M_MMAX ? (int)nn : 2 * TLC_M_MMAX;
+        if (cur[1] - cur[0] < cap) {                     // (uniform: LDS state)
+            __syncthreads();
+            if (tid == 0) {
+                long long off = p.bump_base + (long long)atomicAdd(p.bump_top, (unsigned long long)TLC_X_BLOCK);
+                if (off + TLC_X_BLOCK > p.bump_cap) { off = -1; atomicAdd(p.bump_overflow, 1); }
+                cur[0] = off; cur[1] = off < 0 ? -1 : off + TLC_X_BLOCK;
+            }
+            __syncthreads();
+        }
+        at = cur[1] - cur[0] >= cap ? cur[0] : -1;
+        if (at >= 0) { wdir = p.A_dir + at; wlw = p.A_lw + at; } else cap = 0;
+    }
+    int es = -1;
+    if (!wdir && early_large_ok && n > TLC_M_NMAX) {
+        // early pass: a vicinity beyond the MEDIUM tier takes a slot of the early arena and is written right away
+        if (tid == 0) X.ctl[4] = atomicAdd(p.early_count, 1);
+        __syncthreads();
+        es = X.ctl[4];
+        if (es < p.early_cap) {
+            wdir = p.early_dir + (size_t)es * (2 * TLC_L_MMAX);
+            wlw = p.early_lw + (size_t)es * (2 * TLC_L_MMAX);
+            cap = 2 * TLC_L_MMAX;
+        }
+    }
+    const int m2 = x_sweep<BW>(p, ids, n, X, use_hvy, nH, wdir, wlw, cap);
+    XSTAMP(2);
+    const int m = m2 >> 1;
+    if (m > TLC_MAX_SUBGRAPH_EDGES) {                     // edge ranks are packed in 24 bits (pd_pipeline.hip, cycle swap)
+        x_zero_row<BW>(p, i, TLC_ST_TOO_LARGE, -n, lu, lv);
+    } else {
+        if (tid == 0) { p.hdr_n[i] = n; p.hdr_m2[i] = m2; p.hdr_lu[i] = lu; p.hdr_lv[i] = lv; }
+        if (at >= 0 && m <= TLC_M_MMAX) {
+            // the entries stand where they were written
+            if (tid == 0) { p.edge_off[i] = at; cur[0] = at + m2; }
+        } else if (p.bump_top && n <= TLC_M_NMAX && m <= TLC_M_MMAX) {
+            if (tid == 0) p.edge_off[i] = -1;             // (no room: the overflow flag is up, the chunk is redone by scan + FILL)
+        } else if (n <= TLC_M_NMAX && m > TLC_M_MMAX && early_large_ok && m <= TLC_L_MMAX) {
+            // few nodes, many edges: beyond the MEDIUM tier by its edge count only -- swept again into an early slot
+            if (tid == 0) X.ctl[4] = atomicAdd(p.early_count, 1);
+            __syncthreads();
+            es = X.ctl[4];
+            if (es < p.early_cap) {
+                x_sweep<BW>(p, ids, n, X, use_hvy, nH, p.early_dir + (size_t)es * (2 * TLC_L_MMAX),
+                            p.early_lw + (size_t)es * (2 * TLC_L_MMAX), 2 * TLC_L_MMAX);
+                if (tid == 0) p.early_list[es] = i;
+            }
+        } else if (es >= 0 && es < p.early_cap) {
+            // (an early slot holds a vicinity of the LARGE tier only; one that turned out HUGE by its edges leaves the slot unused)
+            if (m <= TLC_L_MMAX) { if (tid == 0) p.early_list[es] = i; }
+            else if (tid == 0) p.early_list[es] = -1;
+        }
+    }
+    // ---- the member bits go, by list -----------------------------------------------------------------------------------------
+    __syncthreads();
+    for (int k = tid; k < n; k += BW) X.bits[ids[k] >> 5] = 0u;
+    __syncthreads();
+    XSTAMP(3);
+#undef XSTAMP
+}
+
+}  // namespace
+
+template <int BW>
+__global__ __launch_bounds__(BW) void tlc_extract_kernel(TlcVicParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xlds[];
+    int* slot = p.scratch + (size_t)(p.scratch_base_slot + blockIdx.x) * p.scratch_stride;
+    {
+        const int nw4 = (p.nw + 3) & ~3;
+        uint4* z = reinterpret_cast<uint4*>(xlds);
+        for (int w = threadIdx.x; w < nw4 / 4; w += BW) z[w] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+    }
+    // this workgroup's arena region (cursor / end live in LDS across its pairs)
+    {
+        const XLayout L = x_layout(p.nw, XCfg<BW>::SID_CAP, BW);
+        long long* cur = (long long*)((int*)(xlds + L.o_ctl) + 8);
+        if (threadIdx.x == 0) {
+            const long long b = (long long)(p.region_base_wg + (int)blockIdx.x) * p.region_entries;
+            cur[0] = b; cur[1] = b + p.region_entries;
+            if (!p.bump_top) cur[1] = cur[0] = 0;
+        }
+        __syncthreads();
+    }
+    // Work order.  Early pass: the candidate list (length on the device).  Main pass: the bins of tlc_classify_kernel in
+    // descending order, then every pair by index (binned pairs and the early pass's candidates drop out at once); items are
+    // dealt in strided chunks, the first chunk of a workgroup being its own index and the rest coming from a counter (one
+    // dequeue per chunk: a single counter serves ~90 dequeues/us, MI355X_MICROARCH.md) -- so the big items, which sit at
+    // the lowest item numbers, are the FIRST item of the first workgroups.
+    int c0 = 0, c1 = 0, c2 = 0;
+    int n_work = p.n_pairs;
+    if (p.fill_mode == 1) {
+        n_work = p.fill_count;
+        if (p.work_count_dev) { const int c = *p.work_count_dev; n_work = c < n_work ? c : n_work; }
+    } else if (p.big_count) {
+        c0 = p.big_count[0]; c1 = p.big_count[1]; c2 = p.big_count[2];
+        n_work += c0 + c1 + c2;
+    }
+    // (one call site of extract_pair: several would stop the compiler from inlining it, and the parameter block would go
+    // through scratch memory)
+    auto run_item = [&](int w) {
+        int i;
+        bool from_rest = false;
+        if (p.fill_mode == 1) i = p.fill_list[w];
+        else if (w < c0) i = p.big_list[w];
+        else if (w < c0 + c1) i = p.big_list[(size_t)p.n_pairs + (w - c0)];
+        else if (w < c0 + c1 + c2) i = p.big_list[2 * (size_t)p.n_pairs + (w - c0 - c1)];
+        else { i = w - c0 - c1 - c2; from_rest = true; }
+        extract_pair<BW>(p, i, from_rest, xlds, slot);
+    };
+    if (p.started && threadIdx.x == 0 && (int)blockIdx.x < n_work) atomicAdd(p.started, 1);
+    // (one loop for both schedules -- static: a chunk is one item and the next chunk is gridDim.x further on)
+    __shared__ int s_chunk;
+    const bool dyn = p.work_counter != nullptr;
+    const int n_chunks = dyn ? (n_work + p.work_chunk - 1) / p.work_chunk : n_work;
+    for (int c = blockIdx.x; c < n_chunks;) {
+        for (int wi = c; wi < n_work; wi += n_chunks) run_item(wi);
+        if (!dyn) { c += gridDim.x; continue; }
+        if (threadIdx.x == 0) s_chunk = (int)gridDim.x + atomicAdd(p.work_counter, 1);
+        __syncthreads();
+        c = s_chunk;
+        __syncthreads();
+    }
+}
+
+template __global__ void tlc_extract_kernel<64>(TlcVicParams);
+template __global__ void tlc_extract_kernel<512>(TlcVicParams);
+
+size_t tlc_extract_lds_bytes(int nw, int bw) { return x_layout(nw, bw == 64 ? XCfg<64>::SID_CAP : XCfg<512>::SID_CAP, bw).total; }
+
+int tlc_launch_extract(int bw, int grid, size_t lds, const TlcVicParams& p, void* stream) {
+    if (grid <= 0) return TLC_OK;
+    if (bw == 64) {
+        if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_extract_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((tlc_extract_kernel<64>), dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
+    } else {
+        if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_extract_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((tlc_extract_kernel<512>), dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+    }
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
+// ---- which pairs go first ------------------------------------------------------------------------------------------------
+// k = min(|ball(u)|, |ball(v)|) >= |S|.  k >= cand_threshold: candidate of the early pass (at most cand_cap are listed; the
+// count keeps running so that the main pass knows whether the list is complete).  Else k >= 256 / 128 / 64: bins 0 / 1 / 2.
+__global__ void tlc_classify_kernel(int n_pairs, const int* __restrict__ pairs, int n_nodes, const int* __restrict__ bptr,
+                                    int cand_threshold, int cand_cap, int* __restrict__ cand_count, int* __restrict__ cand_list,
+                                    int* __restrict__ big_count, int* __restrict__ big_list) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1;                                         // 3 = candidate, 0..2 = bin
+    if (i < n_pairs) {
+        const int u = pairs[2 * (size_t)i], v = pairs[2 * (size_t)i + 1];
+        if (u >= 0 && v >= 0 && u < n_nodes && v < n_nodes) {
+            const int a = bptr[u + 1] - bptr[u], b = bptr[v + 1] - bptr[v];
+            const int k = a < b ? a : b;
+            if (cand_list && k >= cand_threshold) cls = 3;
+            else if (k >= 256) cls = 0;
+            else if (k >= 128) cls = 1;
+            else if (k >= TLC_X_BIN_MIN) cls = 2;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned long long mk = __ballot(cls == c);
+        if (mk == 0ull) continue;
+        int base = 0;
+        const int leader = __builtin_ctzll(mk);
+        if (tlc_lane() == leader) base = atomicAdd(c == 3 ? cand_count : &big_count[c], __popcll(mk));
+        base = __builtin_amdgcn_readlane(base, leader);
+        const int pos = base + __popcll(mk & tlc_lanemask_lt());
+        if (cls == c) {
+            if (c == 3) { if (pos < cand_cap) cand_list[pos] = i; }
+            else big_list[(size_t)c * n_pairs + pos] = i;
+        }
+    }
+}
+int tlc_launch_classify(int n_pairs, const int* pairs, int n_nodes, const int* bptr, int cand_threshold, int cand_cap,
+                        int* cand_count, int* cand_list, int* big_count, int* big_list, void* stream) {
+    if (n_pairs <= 0) return TLC_OK;
+    hipLaunchKernelGGL(tlc_classify_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_pairs, pairs, n_nodes,
+                       bptr, cand_threshold, cand_cap, cand_count, cand_list, big_count, big_list);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
+// ---- the ball lists: ball_hop(x) for every node, hop <= 2, ascending ids, x itself included ---------------------------------
+// One wavefront per node (grid-stride): x, its row and (hop 2) the rows of its neighbours are marked in an LDS bitmap;
+// COUNT stores the population, FILL the ids from bptr[x] on.  One-off per (graph, hop).
+template <bool FILL>
+__global__ __launch_bounds__(64) void tlc_ball_list_kernel(int n_nodes, int nw, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                           int hop, int* __restrict__ bsize, const int* __restrict__ bptr, int* __restrict__ bcol) {
+    extern __shared__ __attribute__((aligned(16))) unsigned bbits[];
+    const int lane = tlc_lane();
+    const int wpl = (nw + 63) / 64;
+    const int w0 = lane * wpl < nw ? lane * wpl : nw, w1 = (w0 + wpl) < nw ? (w0 + wpl) : nw;
+    for (int w = w0; w < w1; ++w) bbits[w] = 0u;
+    __syncthreads();
+    for (int x = blockIdx.x; x < n_nodes; x += gridDim.x) {
+        const int rb = rowptr[x], re = rowptr[x + 1];
+        if (lane == 0) atomicOr(&bbits[x >> 5], 1u << (x & 31));
+        for (int j = rb + lane; j < re; j += TLC_WAVE) {
+            const int a = col[j];
+            atomicOr(&bbits[a >> 5], 1u << (a & 31));
+            if (hop >= 2) {
+                const int ab = rowptr[a], ae = rowptr[a + 1];
+                for (int t = ab; t < ae; ++t) { const int c = col[t]; atomicOr(&bbits[c >> 5], 1u << (c & 31)); }
+            }
+        }
+        __syncthreads();
+        int cnt = 0;
+        for (int w = w0; w < w1; ++w) cnt += __popc(bbits[w]);
+        const int incl = tlc_wave_iscan_i32(cnt);
+        if (!FILL) {
+            if (lane == 63) bsize[x] = incl;
+        } else {
+            int o = bptr[x] + incl - cnt;
+            for (int w = w0; w < w1; ++w) {
+                unsigned s = bbits[w];
+                while (s) { bcol[o++] = (w << 5) + __builtin_ctz(s); s &= s - 1; }
+            }
+        }
+        for (int w = w0; w < w1; ++w) bbits[w] = 0u;
+        __syncthreads();
+    }
+}
+
+int tlc_launch_ball_list(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, int hop, int* bsize, const int* bptr,
+                         int* bcol, int grid, void* stream) {
+    if (n_nodes <= 0) return TLC_OK;
+    const size_t lds = (size_t)nw * 4 + 16;
+    if (fill) {
+        if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_ball_list_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((tlc_ball_list_kernel<true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, n_nodes, nw, rowptr, col, hop, bsize, bptr, bcol);
+    } else {
+        if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_ball_list_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((tlc_ball_list_kernel<false>), dim3(grid), dim3(64), lds, (hipStream_t)stream, n_nodes, nw, rowptr, col, hop, bsize, bptr, bcol);
+    }
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}

@@ -1344,15 +1344,16 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) vo
     if (NM == TLC_L_NMAX && !HUGE && p.started && tid == 0 && (int)blockIdx.x < tier_count) atomicAdd(p.started, 1);
     for (int wi = blockIdx.x; wi < tier_count; wi += gridDim.x) {
         const int i = p.tier_list[wi];
+        // hand-off slot of this subgraph (tiers whose cycle swap runs in tlc_pd_swap_kernel); "nothing pending" until decided
+        unsigned char* slot = (!HUGE && p.handoff && wi < p.handoff_cap) ? p.handoff + (size_t)wi * (size_t)p.handoff_stride : nullptr;
+        bool deferred = false;
+        if (slot && tid == 0) *(int*)slot = 0;
+        if (i < 0) continue;              // (a slot of the early arena whose vicinity turned out not to be of this tier: extract.hip)
         const int n = p.hdr_n[i], m2 = p.hdr_m2[i], lu = p.hdr_lu[i], lv = p.hdr_lv[i];
         const long long eo = p.slot_entries ? (long long)wi * p.slot_entries : p.edge_off[i];
         const int m = m2 >> 1;
         const bool far = (lu < 0);        // u in S <=> v in S <=> d(u,v) <= hop  
         int status = TLC_ST_OK;
-        // hand-off slot of this subgraph (tiers whose cycle swap runs in tlc_pd_swap_kernel); "nothing pending" until decided
-        unsigned char* slot = (!HUGE && p.handoff && wi < p.handoff_cap) ? p.handoff + (size_t)wi * (size_t)p.handoff_stride : nullptr;
-        bool deferred = false;
-        if (slot && tid == 0) *(int*)slot = 0;
 #ifdef TLC_PHASE_DEBUG
         ull* pc = p.phase_cycles;
         ull t_prev = pc ? clock64() : 0ull;

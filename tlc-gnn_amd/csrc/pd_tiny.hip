@@ -131,8 +131,9 @@ __global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
     if (wi >= tier_count) return;
     const int i = p.tier_list[wi];
     const int n = p.hdr_n[i], m2 = p.hdr_m2[i], lu = p.hdr_lu[i], lv = p.hdr_lv[i];
-    const unsigned* adir = p.small_dir + (size_t)i * (2 * TLC_S_MMAX);
-    const double* alw = p.small_lw + (size_t)i * (2 * TLC_S_MMAX);
+    // (fixed slots written by the breadth-first COUNT pass, or wherever the extraction left the subgraph in the arena)
+    const unsigned* adir = p.small_dir ? p.small_dir + (size_t)i * (2 * TLC_S_MMAX) : p.A_dir + p.edge_off[i];
+    const double* alw = p.small_dir ? p.small_lw + (size_t)i * (2 * TLC_S_MMAX) : p.A_lw + p.edge_off[i];
     int status = TLC_ST_OK;
     TinyImage img;
     img.clear();
@@ -364,6 +365,9 @@ int tlc_launch_pd_tiny(const TlcPdParams& p, void* stream) {
     if (p.tier_count <= 0) return TLC_OK;
     const size_t lds = TINY_LANE_BYTES * 64;
     const int grid = (p.tier_count + 63) / 64;
+    // (above the 64 KiB default of dynamic LDS; the attribute is per device, so it is set per launch: ~1 us)
+    if (lds > 64 * 1024)
+        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_pd_tiny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(tlc_pd_tiny_kernel, dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;

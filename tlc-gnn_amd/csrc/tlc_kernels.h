@@ -102,6 +102,27 @@ struct TlcVicParams {
     unsigned* small_dir;
     double* small_lw;
     unsigned long long* dbg;   // PHASE_DEBUG builds: per-phase cycle sums of the COUNT pass (null otherwise)
+    unsigned long long* dbg_pair_t;   // PHASE_DEBUG builds: [n_pairs][4] wall clock (100 MHz) at start / S known / swept / end of a pair
+    // ---- tlc_extract_kernel (extract.hip; hop <= 2): precomputed structure of the graph ---------------------------------------
+    const int* bptr;            // [n_nodes + 1] ball lists: ball_hop(x) = bcol[bptr[x] .. bptr[x+1]), ascending ids, x included
+    const int* bcol;
+    const int* hidx;            // [n_nodes] index of a HEAVY node (one of the hh_k highest degrees >= 32) or -1; null: none
+    const double* hh_w;         // [hh_k][hh_k] weight of the entry a -> b between heavy nodes, 0 = not adjacent
+    int hh_k;
+    // main pass beside an early pass: a pair whose smaller ball has at least skip_threshold nodes belongs to the early pass as
+    // long as the candidate list held every such pair (*skip_count <= skip_cap); null: no early pass
+    int skip_threshold;
+    const int* skip_count;
+    int skip_cap;
+    // pairs binned by tlc_classify_kernel (smaller ball >= 256 / 128 / 64 nodes): extracted first, in that order
+    const int* big_count;       // [3] on the device; null: no bins
+    const int* big_list;        // [3][n_pairs]
+    // arena regions: workgroup b writes its vicinities from (region_base_wg + b) * region_entries on, then into blocks taken from
+    // bump_top (relative to bump_base)
+    int x_fill;                 // 1: FILL pass of tlc_extract_kernel (headers exist, entries go to edge_off[i])
+    int region_base_wg;
+    long long region_entries;
+    long long bump_base;
 };
 
 struct TlcScanParams {
@@ -120,6 +141,7 @@ struct TlcScanParams {
     // COUNT wrote the MID / MEDIUM vicinities at bump-allocated offsets (TlcVicParams::bump_top): unless *bump_overflow, only
     // the heavy tiers still need arena space, handed out above *bump_top; null: every vicinity outside the SMALL tier does
     const unsigned long long* bump_top;
+    long long bump_base;    // arena entries in front of the bump area (the extraction's per-workgroup regions)
     const int* bump_overflow;
     int* h_overflow;        // mapped host memory: *bump_overflow
     // pairs the early pass has already written (they are left out of the arena and of the tier lists); null: none
@@ -129,6 +151,8 @@ struct TlcScanParams {
     int* h_early;           // mapped host memory: number of early pairs (statistics)
     // mapped host memory the last block publishes into (api.hip, HostSync)
     long long* h_total;
+    long long* h_entries;   // mapped host memory: sum of the induced directed entries of all vicinities (statistics)
+    unsigned long long* entries_sum;   // device accumulator of the former (zeroed per launch)
     int* h_tier;
     unsigned* h_seq;
     unsigned seq;
@@ -232,6 +256,12 @@ int tlc_launch_pd_tiny(const TlcPdParams& p, void* stream);
 int tlc_launch_pdf_tier(int tier, const TlcPdfParams& p, void* stream);
 int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long* edge_offs, int* counts, int* tier_count,
                        int* tier_list, void* stream);
+size_t tlc_extract_lds_bytes(int nw, int bw);
+int tlc_launch_extract(int bw, int grid, size_t lds, const TlcVicParams& p, void* stream);
+int tlc_launch_classify(int n_pairs, const int* pairs, int n_nodes, const int* bptr, int cand_threshold, int cand_cap,
+                        int* cand_count, int* cand_list, int* big_count, int* big_list, void* stream);
+int tlc_launch_ball_list(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, int hop, int* bsize, const int* bptr,
+                         int* bcol, int grid, void* stream);
 int tlc_launch_ball_bound(int n_nodes, const int* rowptr, const int* col, const int* prev, int* out, void* stream);
 int tlc_launch_select_heavy(int n_pairs, const int* pairs, int n_nodes, const int* ub, int threshold, int cap, int* count,
                             int* list, void* stream);

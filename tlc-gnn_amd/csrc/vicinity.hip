@@ -99,7 +99,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
     const int n = i < p.n_pairs ? p.hdr_n[i] : 0;
     const int m2v = i < p.n_pairs ? p.hdr_m2[i] : 0;
     const bool bumped = p.bump_top != nullptr && *p.bump_overflow == 0;
-    const long long arena_base = bumped ? (long long)*p.bump_top : 0;
+    const long long arena_base = bumped ? p.bump_base + (long long)*p.bump_top : 0;
     const long long own = (i < p.n_pairs && !pre) ? arena_entries(n, m2v, p.small_arena, bumped) : 0;
     // inclusive scan inside the wavefront, then over the 16 wavefront totals
     // (sizes are < 2^25 per pair, so a wavefront's running sum fits 32 bits)
@@ -164,6 +164,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
     if (tier >= 0) p.tier_list[(size_t)tier * p.n_pairs + s_tbase[tier] + s_tc[tier][wave] + my_rank] = i;
     // the last block to get here publishes the sizes
     __syncthreads();
+    // (statistics: the entries of every vicinity, wherever they were written)
+    {
+        long long e = (i < p.n_pairs && n > 0) ? (long long)m2v : 0;
+        e = tlc_wave_sum_i64(e);
+        if (lane == 0 && e && p.entries_sum) atomicAdd(p.entries_sum, (unsigned long long)e);
+    }
+    __syncthreads();
     if (t == 0) {
         atomicAdd(reinterpret_cast<unsigned long long*>(p.sync + 2), (unsigned long long)btotal);   // running arena total
         __threadfence();
@@ -173,7 +180,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
             if (p.h_overflow) *p.h_overflow = p.bump_overflow ? *p.bump_overflow : 0;
             p.totals[0] = total;
             *p.h_total = total;
-            if (p.h_early) *p.h_early = n_early;
+            if (p.h_entries) *p.h_entries = p.entries_sum ? (long long)__hip_atomic_load(p.entries_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : total;
+            if (p.h_early) {
+                int valid = 0;                            // (a slot may be empty: extract.hip)
+                for (int k = 0; k < n_early; ++k) valid += p.early_list[k] >= 0 ? 1 : 0;
+                *p.h_early = valid;
+            }
             for (int tt = 0; tt < TLC_N_TIERS; ++tt)
                 p.h_tier[tt] = __hip_atomic_load(&p.tier_count[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence_system();

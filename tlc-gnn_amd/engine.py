@@ -70,6 +70,19 @@ class DeviceGraph:
                 "tier_mid": v[7], "tier_tiny": v[8], "tier_medium_many_pos": v[9],
                 "induced_entries": v[4], "tie_fallback_sources": v[5], "chunks": v[6]}
 
+    # ---- diagnostics (tests, A/B timing) --------------------------------------------------------------------------
+    def set_option(self, name, value):
+        """'extract' (ball-list extraction, hop <= 2) / 'heavy' (its hub-row skipping) / 'tiny' (lane-per-subgraph kernel):
+        1 on (default), 0 off.  Results do not depend on them (tests/test_gpu_extract.py)."""
+        _lib.check(_lib.lib().tlc_debug_set_option(self._h, name.encode(), C.c_int(int(value))), "tlc_debug_set_option")
+
+    def dc_stats(self):
+        """(subgraphs whose cycle swap ran as the divide and conquer, subgraphs it gave back to the serial walk) since the last
+        pd_pi_batch call began."""
+        out = (C.c_longlong * 2)()
+        _lib.check(_lib.lib().tlc_debug_dc_stats(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr(self.device)), "tlc_debug_dc_stats")
+        return int(out[0]), int(out[1])
+
     # ---- measurement helpers (bench.py) -----------------------------------------------------------------------
     KERNELS = ["vicinity_count", "scan_bin", "vicinity_fill", "pd_tier_small", "pd_tier_medium", "pd_tier_large", "pd_tier_huge",
                "pd_tier_mid"]

@@ -1,4 +1,6 @@
 #!/bin/bash
+# one parity test (or a -k selection) on the GPU box: bash tools/gpu_one_test.sh <pytest args>
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_pd_parity.py -x -q -m gpu -k "${1:-power_of_two}" --durations=5 2>&1 | tail -15 | tee gpurun_out/pytest_one.log
+timeout -k 10 600 python -m pytest -m gpu -x -q "$@" > gpurun_out/pytest_one.log 2>&1; echo "pytest rc=$?"
+grep -v "^  File\|^Extension modules" gpurun_out/pytest_one.log | tail -60

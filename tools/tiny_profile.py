@@ -8,13 +8,13 @@ wl = bench.build_workload(0)
 g = engine.DeviceGraph(wl["rowptr"], wl["col"], wl["w"])
 pairs = torch.as_tensor(wl["pi_pairs"]).cuda()
 L = _lib.lib()
-L.tlc_debug_phase_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+L.tlc_debug_phase_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
 g.pd_pi_batch(pairs, 2)
-L.tlc_debug_phase_profile(g._h, 1, None)
+L.tlc_debug_phase_profile(g._h, 1, None, 0, None)
 g.pd_pi_batch(pairs, 2)
-buf = (C.c_uint64 * 224)()
-L.tlc_debug_phase_profile(g._h, 0, C.cast(buf, C.c_void_p))
-a = np.array(list(buf), dtype=np.float64).reshape(7, 32)
+buf = (C.c_uint64 * 256)()        # (TLC_N_TIERS + 1) rows of 32; the library writes at most what is passed as capacity
+L.tlc_debug_phase_profile(g._h, 0, C.cast(buf, C.c_void_p), 256, None)
+a = np.array(list(buf), dtype=np.float64).reshape(8, 32)
 r = a[5]
 names = ["load slot", "filtration", "sort+asc pass", "sort+desc pass", "tree+cycle swap", "image", "store"]
 print("tiny kernel: %d wavefronts; mean cycles per wavefront:" % r[14], {nm: int(r[k] / max(r[14], 1)) for k, nm in enumerate(names)}, "total", int(r[:7].sum() / max(r[14], 1)))
