@@ -265,6 +265,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="rehearsal only: 'gloo' lets N ranks share ONE GPU with --single-device "
                     "(RCCL refuses two ranks on a device); the measured configuration is always nccl = RCCL, one rank per GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--sync-batches", action="store_true",
+                    help="timed region with stream-ordered tlc_pd_pi_batch calls (one batch at a time) instead of "
+                         "tlc_pd_pi_batch_async + one join (two batches in flight)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="development: no per-kernel HIP events in the timed region (the roofline block is then meaningless)")
     args = ap.parse_args()
@@ -378,6 +381,17 @@ def main():
     def leg_pi(step=0):
         g.pd_pi_batch(rot[step % len(rot)] if args.rotate_batches else pi_pairs, hop, out=pi_out, status=pi_status)
 
+    # The timed region submits its K image batches with tlc_pd_pi_batch_async and joins once behind the last one: the
+    # library keeps two batches in flight on its two workspaces, so the lead-in of a batch (classification, early extraction,
+    # the main extraction: latency-bound, half-empty machine) runs under the tier kernels of the batch before.  Three output
+    # buffers in turn: a batch in flight owns its buffers until the join.  --sync-batches: stream-ordered calls instead.
+    pi_outs = [pi_out] + [torch.empty_like(pi_out) for _ in range(2)]
+    pi_sts = [pi_status] + [torch.empty_like(pi_status) for _ in range(2)]
+
+    def leg_pi_submit(step, rotate):
+        g.pd_pi_batch(rot[step % len(rot)] if rotate else pi_pairs, hop, out=pi_outs[step % 3], status=pi_sts[step % 3],
+                      async_=not args.sync_batches)
+
     # ---- warm-up + latency line -------------------------------------------------------------------------------------------
     # Per-kernel HIP events (recorded inside the library on the stream each kernel runs on) cost time themselves: all eight
     # pairs add 48 us to the 1.06 ms batch.  Every kernel is timed during the warm-up steps (-> `kernel_ms` and which kernel
@@ -407,6 +421,12 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         lat_plain.append(e0.elapsed_time(e1))
+    if not args.sync_batches:
+        # the second workspace of the handle (buffers, streams) comes into being with the first batch that lands on it
+        for s in range(4):
+            leg_pi_submit(s, args.rotate_batches)
+        g.join()
+        torch.cuda.synchronize()
     if not args.no_kernel_events:
         g.set_timing(True, only=[dom_warm])
 
@@ -419,8 +439,12 @@ def main():
     t0 = time.perf_counter()
     ev_pi[0].record()
     for s in range(K):
-        leg_pi(s)
-        ev_pi[s + 1].record()
+        leg_pi_submit(s, args.rotate_batches)
+        if args.sync_batches:
+            ev_pi[s + 1].record()
+    if not args.sync_batches:
+        g.join()                                                        # the stream waits for the batches in flight
+        ev_pi[K].record()
     for s in range(K):
         leg_lp()
         ev_lp[s].record()
@@ -428,7 +452,7 @@ def main():
     wall = time.perf_counter() - t0
     t_pi = ev_pi[0].elapsed_time(ev_pi[K]) * 1e-3
     t_lp = ev_pi[K].elapsed_time(ev_lp[K - 1]) * 1e-3
-    pi_steps = [ev_pi[s].elapsed_time(ev_pi[s + 1]) for s in range(K)]
+    pi_steps = [ev_pi[s].elapsed_time(ev_pi[s + 1]) for s in range(K)] if args.sync_batches else [t_pi * 1e3 / K]
     lp_steps = [(ev_pi[K] if s == 0 else ev_lp[s - 1]).elapsed_time(ev_lp[s]) for s in range(K)]
     ktimes_timed = [] if args.no_kernel_events else g.timing_history(dom_warm, cap=min(K, 64))
     if world > 1:
@@ -444,7 +468,9 @@ def main():
         barrier()
         ev0.record()
         for s in range(K):
-            g.pd_pi_batch(rot[s % len(rot)] if rotate else pi_pairs, hop, out=pi_out, status=pi_status)
+            leg_pi_submit(s, rotate)
+        if not args.sync_batches:
+            g.join()
         ev1.record()
         barrier()
         t = torch.tensor([ev0.elapsed_time(ev1) * 1e-3], dtype=torch.float64, device=dev)
@@ -723,8 +749,12 @@ def main():
                                    "(GCN 500->100->16 encode + fused decode of %d pairs, image rows resident)"
                                    % ("a different %d-pair sample of the graph's positive pairs every step (--rotate-batches)" % E
                                       if args.rotate_batches else "all %d train-positive pairs" % E, dec_pairs.shape[0]),
-                       "timed_region": "K image batches enqueued back to back, then K forwards, no host synchronisation inside "
-                                       "(throughput); pi_latency_ms = one batch with a synchronisation after it",
+                       "timed_region": ("K image batches as stream-ordered tlc_pd_pi_batch calls (one at a time), " if args.sync_batches else
+                                        "K image batches submitted with tlc_pd_pi_batch_async (two in flight on the handle's two "
+                                        "workspaces, three output buffers in turn) and ONE join behind the last, ") +
+                                       "then K forwards, no host synchronisation inside (throughput); pi_latency_ms = one "
+                                       "stream-ordered batch with a synchronisation after it",
+                       "pi_submit": "sync" if args.sync_batches else "async",
                        "pairs_per_gpu": E, "decode_pairs_per_gpu": int(dec_pairs.shape[0]), "rotate_batches": bool(args.rotate_batches),
                        "parallelism": "every rank its own batch (weak; no collective in the image leg); encoder: " + enc_mode,
                        "vicinity_tiers": {k: int(v) for k, v in stats.items() if k.startswith("tier")},

@@ -111,6 +111,16 @@ int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int64_t n_pair
                             int32_t* d_out_n, uint8_t* d_out_status,
                             const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m, void* stream);
 
+/* The same batch WITHOUT the final join -- for a caller that submits batch after batch (the reference's sweep over its pair
+ * lists, sg2dgm/riccidist2dgm.py:362-370 over loaddatas.py:44-53) and wants them to overlap: the batch is ordered after what
+ * `stream` holds at the time of the call (its inputs may be produced there), runs on streams of the handle, and `stream` does
+ * NOT wait for it.  The outputs are complete for work that follows a tlc_pd_pi_batch_join() on its stream.  A handle keeps two
+ * batches in flight; submitting a third waits ON THE HOST for the first.  tlc_pd_pi_batch == async + join.
+ * Buffers (pairs, out_pi, out_status) of a batch in flight must stay valid and must not be written until joined. */
+int tlc_pd_pi_batch_async(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags,
+                          int res, double* d_out_pi, uint8_t* d_out_status, void* stream);
+int tlc_pd_pi_batch_join(tlc_graph* g, void* stream);
+
 /* Counters of the last tlc_pd_pi_batch on this handle (synchronises the stream):
  * h_out[0..3] = pairs in tier small / medium / large / huge, [4] = induced directed entries (arena size),
  * [5] = sources that needed the exact tie fallback, [6] = chunks, [7] = pairs in tier mid (between small and medium),

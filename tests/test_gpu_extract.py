@@ -142,3 +142,46 @@ def test_asymmetric_or_repeated_heavy_rows_switch_the_heavy_set_off():
     g.close()
     assert np.array_equal(new[1], old[1]) and np.array_equal(new[2], old[2]) and np.array_equal(new[3], old[3])
     assert np.abs(new[0] - old[0]).max() <= 1e-12
+
+
+def test_async_batches_overlap_and_equal_the_stream_ordered_call():
+    """tlc_pd_pi_batch_async + tlc_pd_pi_batch_join: batches submitted back to back run on the handle's two workspaces (a third
+    submission waits on the host for the first) and must give, bit for bit, what the stream-ordered call gives for the same
+    pairs -- whatever workspace a batch lands on, whatever is in flight beside it."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    n, edges, kappa, _, _ = synth.shaped_graph("PubMed", scale=0.3)
+    rowptr, col, w = synth.edges_to_csr(n, edges, kappa)
+    rs = np.random.RandomState(12)
+    g = engine.DeviceGraph(rowptr, col, w)
+    batches = []
+    for k in range(7):
+        m = [6000, 300, 5000, 4100, 17, 7000, 4500][k]                  # with and without the early pass (>= 4 096 pairs)
+        b = np.concatenate([edges[rs.permutation(len(edges))[:m]], rs.randint(0, n, size=(m // 5 + 1, 2))]).astype(np.int32)
+        batches.append(torch.as_tensor(b[rs.permutation(len(b))]).cuda())
+    want = []
+    for b in batches:
+        o, s = g.pd_pi_batch(b, 2)
+        want.append((o.clone(), s.clone()))
+    torch.cuda.synchronize()
+    got = [g.pd_pi_batch(b, 2, async_=True) for b in batches]           # seven in a row: the host waits for the oldest as needed
+    g.join()
+    torch.cuda.synchronize()
+    for k, ((o, s), (wo, wst)) in enumerate(zip(got, want)):
+        assert torch.equal(s, wst), k
+        assert torch.equal(o, wo), k
+    # a consumer on the stream after join() sees complete rows without any host synchronisation in between
+    o2, s2 = g.pd_pi_batch(batches[0], 2, async_=True)
+    o3, s3 = g.pd_pi_batch(batches[2], 2, async_=True)
+    g.join()
+    tot = o2.sum() + o3.sum()
+    assert abs(float(tot) - float(want[0][0].sum() + want[2][0].sum())) <= 1e-9 * abs(float(tot))
+    # the stream-ordered call still works with batches in flight, and statistics follow the last call
+    o4, _ = g.pd_pi_batch(batches[1], 2, async_=True)
+    o5, s5 = g.pd_pi_batch(batches[3], 2)
+    assert torch.equal(o5, want[3][0]) and torch.equal(s5, want[3][1])
+    g.join()
+    torch.cuda.synchronize()
+    assert torch.equal(o4, want[1][0])
+    assert g.stats()["chunks"] == 1
+    g.close()

@@ -24,7 +24,7 @@ DESCRIPTOR_FLAG = {"sum": 0, "min": DESC_MIN, "max": DESC_MAX}      # the three 
 # every symbol include/tlcgnn.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "tlc_version", "tlc_last_error", "tlc_device_count", "tlc_graph_create", "tlc_graph_destroy",
-    "tlc_pd_pi_batch", "tlc_vicinity_filtration", "tlc_pd_pi_batch_stats", "tlc_pd_pi_batch_set_timing",
+    "tlc_pd_pi_batch", "tlc_pd_pi_batch_async", "tlc_pd_pi_batch_join", "tlc_vicinity_filtration", "tlc_pd_pi_batch_stats", "tlc_pd_pi_batch_set_timing",
     "tlc_pd_pi_batch_timings", "tlc_pd_pi_batch_timing_history", "tlc_pd_pi_batch_sizes", "tlc_pd_pi_algorithmic_bytes", "tlc_pd_from_filtration",
     "tlc_pi_raster", "tlc_gcn_norm_csr", "tlc_gemm_f32", "tlc_spgemm_csr_dense_f32", "tlc_spmm_csr_f32", "tlc_renorm_rows_f32",
     "tlc_lp_decode_fused", "tlc_gat_layer_fwd", "tlc_scatter_f32", "tlc_edge_head_fwd",
@@ -69,6 +69,8 @@ def lib():
         L.tlc_graph_destroy.argtypes = [C.c_void_p]
         L.tlc_pd_pi_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
+        L.tlc_pd_pi_batch_async.argtypes = L.tlc_pd_pi_batch.argtypes
+        L.tlc_pd_pi_batch_join.argtypes = [C.c_void_p, C.c_void_p]
         L.tlc_vicinity_filtration.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p]

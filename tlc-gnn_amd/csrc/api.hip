@@ -57,24 +57,23 @@ struct HostSync {
     volatile unsigned pub_seq;
 };
 
-struct tlc_graph {
-    int device;
-    int n_nodes;
-    long long nnz;
-    int nw;
-    int *d_rowptr, *d_col;
-    double* d_w;
-    // per-chunk workspace
+#define TLC_N_WS 2                /* workspaces of a handle: chunks (and asynchronous batches) alternate between them */
+
+// Everything one chunk of pairs writes while it is in flight.  A handle has TLC_N_WS of them, taken in turn, each with its own
+// streams: the chunks of one call, and the batches of tlc_pd_pi_batch_async, overlap -- the lead-in of one (selection, early
+// extraction, the main extraction, all latency-bound) runs under the tail of the tier kernels of the one before.
+struct Workspace {
     size_t cap_pairs;
     int *hdr_n, *hdr_m2, *hdr_lu, *hdr_lv, *tier_list;
-    int* dc_lists;             // [4][cap_pairs]: MEDIUM / LARGE lists for tlc_pd_dc_kernel, and what it left for the serial kernel
+    int* dc_lists;             // [6][cap_pairs + TLC_EARLY_SLOTS]: list positions a tier kernel hands to tlc_pd_dc_kernel
     int* big_lists;            // [3][cap_pairs]: the bins of tlc_classify_kernel (extract.hip)
     long long* edge_off;
-    // small device block: [0..3] tier counts
+    // small device block: [0..6] tier counts, [10..13] scan, [16..19] early pass, [20..22] bump allocator, [24] work counter,
+    // [26..31] divide-and-conquer lists, [32..34] bins, [36..37] entry sum
     int* d_ctl;
     long long* d_block_sums;   // 1024
     long long* d_totals;       // 1
-    unsigned long long* d_stats;  // [0] tie-fallback sources, [2] (as int) LARGE workgroups started
+    unsigned long long* d_stats;  // [0] tie-fallback sources, [1] divide-and-conquer swaps, [2] (as int) LARGE workgroups started, [3] swaps given back
     HostSync* h_sync;          // pinned
     HostSync* h_sync_dev;      // the same block as the device sees it
     unsigned pub_seq;          // sequence number of the last size publication
@@ -82,38 +81,59 @@ struct tlc_graph {
     size_t cap_entries;
     unsigned* A_dir;
     double* A_lw;
-    // fixed-size slots of the SMALL tier (written by the COUNT pass)
+    // fixed-size slots of the SMALL tier (breadth-first COUNT pass only)
     size_t cap_small;
     unsigned* S_dir;
     double* S_lw;
     // vicinity scratch
-    int vic_slots;
     int vic_hop_cap;           // frontiers allocated for hop >= 3 ?
     int* vic_scratch;
     long long vic_stride;
-    size_t vic_lds;
-    int lds_attr_set;          // hipFuncAttributeMaxDynamicSharedMemorySize raised for this handle's device and vic_lds
     // HUGE tier scratch
     int huge_slots;
     unsigned char* huge_scratch;
-    // early pass: ball-size bounds per node for one hop value, candidate / early lists, the early arena
-    int ball_hop;
-    int* d_ball_ub[2];
+    size_t huge_stride;
+    // early pass: candidate / early lists, the early arena
     int* d_cand_list;
     int* d_early_list;
     unsigned* E_dir;
     double* E_lw;
-    hipEvent_t ev_early, ev_scan;
     unsigned char* handoff;        // hand-off slots between the tier kernels and tlc_pd_swap_kernel
     size_t cap_handoff;
     unsigned char* handoff_large;  // the LARGE tier's own slots (only subgraphs meant for tlc_pd_dc_kernel use theirs)
     size_t cap_handoff_large;
-    size_t huge_stride;
+    hipStream_t main;              // the chunk's own "caller's stream": everything the caller's stream used to carry
     hipStream_t side[TLC_N_SIDE];
-    hipEvent_t ev_fork, ev_join[TLC_N_SIDE];
+    hipEvent_t ev_in, ev_done;     // fork from / join into the caller's stream
+    hipEvent_t ev_fork, ev_join[TLC_N_SIDE], ev_early, ev_scan;
+    int prev_tc[TLC_N_TIERS];      // tier counts of the previous chunk (sizes of the speculative launches)
+    size_t x_entries_hint;         // induced entries of the largest chunk seen (sizes the bump area of the next one)
+    int busy;                      // a chunk was submitted and ev_done has not been waited for on the host
+    int in_call;                   // ... by the call in progress (its statistics are still to be collected)
+    int n_pairs;                   // pairs of that chunk
+};
+
+struct tlc_graph {
+    int device;
+    int n_nodes;
+    long long nnz;
+    int nw;
+    int *d_rowptr, *d_col;
+    double* d_w;
+    Workspace ws[TLC_N_WS];
+    unsigned long long next_ws;    // chunks submitted so far
+    Workspace* last_ws;            // workspace of the most recent chunk (sizes / divide-and-conquer statistics)
+    // vicinity kernels
+    int vic_slots;
+    size_t vic_lds;
+    int lds_attr_set;          // hipFuncAttributeMaxDynamicSharedMemorySize raised for this handle's device and vic_lds
+    // early pass of the breadth-first kernels: ball-size bounds per node for one hop value
+    int ball_hop;
+    int* d_ball_ub[2];
     long long last_stats[10];
+    long long acc_tie;             // tie-fallback sources of the chunks whose workspace was taken again within the call
     unsigned long long* d_phase;   // diagnostics: [TLC_N_TIERS][32] cycle counters, null unless enabled
-    unsigned long long* d_pair_t;  // diagnostics (PHASE_DEBUG builds): [cap][4] wall-clock stamps per pair of the extraction
+    unsigned long long* d_pair_t;  // diagnostics (PAIR_TIMES builds): [cap][4] wall-clock stamps per pair of the extraction
     size_t cap_pair_t;
     // optional per-kernel timing (tlc_pd_pi_batch_set_timing): events bracket each launch on its own stream
     int timing;
@@ -126,118 +146,127 @@ struct tlc_graph {
     hipEvent_t* ev_t;              // the current set
     unsigned char* ev_used;
     int last_n_pairs;
-    int prev_tc[TLC_N_TIERS];      // tier counts of the previous chunk (sizes of the speculative launches)
     // tlc_extract_kernel (extract.hip, hop <= 2): ball lists of one hop value (built on first use), the heavy set (fixed)
     int ball_list_hop;             // 0: none yet; -1: lists do not fit (the breadth-first kernels are used)
     int* d_bptr;
     int* d_bcol;
     long long ball_entries;
-    int* d_hidx;
+    TlcNodeRec* d_nrec;            // node records (extract.hip)
     double* d_hh_w;
     int hh_k;
     size_t x_lds64, x_lds512;
-    size_t x_entries_hint;         // induced entries of the largest chunk seen (sizes the bump area of the next one)
     // development / test switches (tlc_debug_set_option; initial values from the environment: TLC_EXTRACT, TLC_HEAVY, TLC_TINY)
     int opt_extract, opt_heavy, opt_tiny;
+    int opt_tier_mask;                  // development: which tier kernels are launched at all (timing a tier alone; rows of the others are garbage)
     int opt_x_region, opt_x_bump_min;   // arena entries per workgroup region / minimum bump area of the extraction (tests shrink them)
 };
 
-static int ensure_pairs(tlc_graph* g, size_t n) {
-    if (n <= g->cap_pairs) return TLC_OK;
-    hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
-    hipFree(g->dc_lists); hipFree(g->big_lists);
-    g->hdr_n = g->hdr_m2 = g->hdr_lu = g->hdr_lv = g->tier_list = g->dc_lists = g->big_lists = nullptr;
-    g->edge_off = nullptr;
-    g->cap_pairs = 0;
-    TLC_HIP_CHECK(hipMalloc(&g->hdr_n, n * sizeof(int)));
-    TLC_HIP_CHECK(hipMalloc(&g->hdr_m2, n * sizeof(int)));
-    TLC_HIP_CHECK(hipMalloc(&g->hdr_lu, n * sizeof(int)));
-    TLC_HIP_CHECK(hipMalloc(&g->hdr_lv, n * sizeof(int)));
-    TLC_HIP_CHECK(hipMalloc(&g->tier_list, n * TLC_N_TIERS * sizeof(int)));
-    TLC_HIP_CHECK(hipMalloc(&g->edge_off, (n + 1) * sizeof(long long)));
-    TLC_HIP_CHECK(hipMalloc(&g->dc_lists, 6 * (n + TLC_EARLY_SLOTS) * sizeof(int)));
-    TLC_HIP_CHECK(hipMalloc(&g->big_lists, 3 * n * sizeof(int)));
-    g->cap_pairs = n;
+// host-side wait for every chunk in flight on this handle (before shared, read-only-while-running structures change)
+static int quiesce(tlc_graph* g) {
+    for (int k = 0; k < TLC_N_WS; ++k)
+        if (g->ws[k].busy) { TLC_HIP_CHECK(hipEventSynchronize(g->ws[k].ev_done)); g->ws[k].busy = 0; }
+    return TLC_OK;
+}
+
+static int ensure_pairs(tlc_graph* g, Workspace* ws, size_t n) {
+    if (n <= ws->cap_pairs) return TLC_OK;
+    hipFree(ws->hdr_n); hipFree(ws->hdr_m2); hipFree(ws->hdr_lu); hipFree(ws->hdr_lv); hipFree(ws->tier_list); hipFree(ws->edge_off);
+    hipFree(ws->dc_lists); hipFree(ws->big_lists);
+    ws->hdr_n = ws->hdr_m2 = ws->hdr_lu = ws->hdr_lv = ws->tier_list = ws->dc_lists = ws->big_lists = nullptr;
+    ws->edge_off = nullptr;
+    ws->cap_pairs = 0;
+    TLC_HIP_CHECK(hipMalloc(&ws->hdr_n, n * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&ws->hdr_m2, n * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&ws->hdr_lu, n * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&ws->hdr_lv, n * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&ws->tier_list, n * TLC_N_TIERS * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&ws->edge_off, (n + 1) * sizeof(long long)));
+    TLC_HIP_CHECK(hipMalloc(&ws->dc_lists, 6 * (n + TLC_EARLY_SLOTS) * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&ws->big_lists, 3 * n * sizeof(int)));
+    ws->cap_pairs = n;
     return TLC_OK;
 }
 
 // `keep` > 0: the first `keep` entries hold vicinities already written on stream s and survive the growth
-static int ensure_arena(tlc_graph* g, size_t entries, size_t keep = 0, hipStream_t s = nullptr) {
-    if (entries <= g->cap_entries) return TLC_OK;
+static int ensure_arena(tlc_graph* g, Workspace* ws, size_t entries, size_t keep = 0, hipStream_t s = nullptr) {
+    if (entries <= ws->cap_entries) return TLC_OK;
     size_t want = std::max(entries + entries / 4, (size_t)1 << 16);
-    unsigned* old_dir = g->A_dir;
-    double* old_lw = g->A_lw;
-    g->A_dir = nullptr; g->A_lw = nullptr; g->cap_entries = 0;
+    unsigned* old_dir = ws->A_dir;
+    double* old_lw = ws->A_lw;
+    ws->A_dir = nullptr; ws->A_lw = nullptr; ws->cap_entries = 0;
     if (keep == 0) { hipFree(old_dir); hipFree(old_lw); old_dir = nullptr; old_lw = nullptr; }
-    TLC_HIP_CHECK(hipMalloc(&g->A_dir, want * sizeof(unsigned)));
-    TLC_HIP_CHECK(hipMalloc(&g->A_lw, want * sizeof(double)));
+    TLC_HIP_CHECK(hipMalloc(&ws->A_dir, want * sizeof(unsigned)));
+    TLC_HIP_CHECK(hipMalloc(&ws->A_lw, want * sizeof(double)));
     if (keep > 0) {
-        TLC_HIP_CHECK(hipMemcpyAsync(g->A_dir, old_dir, keep * sizeof(unsigned), hipMemcpyDeviceToDevice, s));
-        TLC_HIP_CHECK(hipMemcpyAsync(g->A_lw, old_lw, keep * sizeof(double), hipMemcpyDeviceToDevice, s));
+        TLC_HIP_CHECK(hipMemcpyAsync(ws->A_dir, old_dir, keep * sizeof(unsigned), hipMemcpyDeviceToDevice, s));
+        TLC_HIP_CHECK(hipMemcpyAsync(ws->A_lw, old_lw, keep * sizeof(double), hipMemcpyDeviceToDevice, s));
         TLC_HIP_CHECK(hipDeviceSynchronize());          // (speculatively launched tier kernels may still read the old arena)
         hipFree(old_dir); hipFree(old_lw);
     }
-    g->cap_entries = want;
+    ws->cap_entries = want;
     return TLC_OK;
 }
 
-static int ensure_handoff(tlc_graph* g, size_t bytes) {
-    if (bytes <= g->cap_handoff) return TLC_OK;
+static int ensure_handoff(tlc_graph* g, Workspace* ws, size_t bytes) {
+    if (bytes <= ws->cap_handoff) return TLC_OK;
     const size_t want = std::max(bytes + bytes / 4, (size_t)1 << 20);
-    hipFree(g->handoff);
-    g->handoff = nullptr; g->cap_handoff = 0;
-    TLC_HIP_CHECK(hipMalloc(&g->handoff, want));
-    g->cap_handoff = want;
+    hipFree(ws->handoff);
+    ws->handoff = nullptr; ws->cap_handoff = 0;
+    TLC_HIP_CHECK(hipMalloc(&ws->handoff, want));
+    ws->cap_handoff = want;
     return TLC_OK;
 }
 
-static int ensure_handoff_large(tlc_graph* g, size_t slots) {
+static int ensure_handoff_large(tlc_graph* g, Workspace* ws, size_t slots) {
     const size_t bytes = slots * tlc_handoff_slot_bytes(TLC_TIER_LARGE);
-    if (bytes <= g->cap_handoff_large) return TLC_OK;
-    hipFree(g->handoff_large);
-    g->handoff_large = nullptr; g->cap_handoff_large = 0;
-    TLC_HIP_CHECK(hipMalloc(&g->handoff_large, bytes));
-    g->cap_handoff_large = bytes;
+    if (bytes <= ws->cap_handoff_large) return TLC_OK;
+    hipFree(ws->handoff_large);
+    ws->handoff_large = nullptr; ws->cap_handoff_large = 0;
+    TLC_HIP_CHECK(hipMalloc(&ws->handoff_large, bytes));
+    ws->cap_handoff_large = bytes;
     return TLC_OK;
 }
 
-static int ensure_small(tlc_graph* g, size_t n_pairs) {
-    if (n_pairs <= g->cap_small) return TLC_OK;
-    hipFree(g->S_dir); hipFree(g->S_lw);
-    g->S_dir = nullptr; g->S_lw = nullptr; g->cap_small = 0;
-    TLC_HIP_CHECK(hipMalloc(&g->S_dir, n_pairs * (2 * TLC_S_MMAX) * sizeof(unsigned)));
-    TLC_HIP_CHECK(hipMalloc(&g->S_lw, n_pairs * (2 * TLC_S_MMAX) * sizeof(double)));
-    g->cap_small = n_pairs;
+static int ensure_small(tlc_graph* g, Workspace* ws, size_t n_pairs) {
+    if (n_pairs <= ws->cap_small) return TLC_OK;
+    hipFree(ws->S_dir); hipFree(ws->S_lw);
+    ws->S_dir = nullptr; ws->S_lw = nullptr; ws->cap_small = 0;
+    TLC_HIP_CHECK(hipMalloc(&ws->S_dir, n_pairs * (2 * TLC_S_MMAX) * sizeof(unsigned)));
+    TLC_HIP_CHECK(hipMalloc(&ws->S_lw, n_pairs * (2 * TLC_S_MMAX) * sizeof(double)));
+    ws->cap_small = n_pairs;
     return TLC_OK;
 }
 
-static int ensure_vic_scratch(tlc_graph* g, int hop) {
+static int ensure_vic_scratch(tlc_graph* g, Workspace* ws, int hop) {
     const int need_front = hop >= 3 ? 1 : 0;
-    if (g->vic_scratch && g->vic_hop_cap >= need_front) return TLC_OK;
-    hipFree(g->vic_scratch);
-    g->vic_scratch = nullptr;
+    if (ws->vic_scratch && ws->vic_hop_cap >= need_front) return TLC_OK;
+    hipFree(ws->vic_scratch);
+    ws->vic_scratch = nullptr;
     // slot = [ids | lrow | frontA | frontB]: the id list and the row offsets of one vicinity (at most 65 535 nodes, whatever
     // the graph's size), and for hop >= 3 the two BFS frontiers (up to n_nodes each)
     const long long cap = std::min<long long>(g->n_nodes, TLC_MAX_SUBGRAPH_NODES + 1);
-    g->vic_stride = 2 * cap + (need_front ? 2ll * g->n_nodes : 0) + 16;
-    TLC_HIP_CHECK(hipMalloc(&g->vic_scratch, (size_t)(g->vic_slots + TLC_EARLY_WG) * g->vic_stride * sizeof(int)));
-    g->vic_hop_cap = need_front;
+    ws->vic_stride = 2 * cap + (need_front ? 2ll * g->n_nodes : 0) + 16;
+    TLC_HIP_CHECK(hipMalloc(&ws->vic_scratch, (size_t)(g->vic_slots + TLC_EARLY_WG) * ws->vic_stride * sizeof(int)));
+    ws->vic_hop_cap = need_front;
     return TLC_OK;
 }
 
 // per-node upper bound of |ball_hop(x)| (vicinity.hip, tlc_ball_bound_kernel) and the early pass's buffers; one-off per
 // (graph, hop)
-static int ensure_early(tlc_graph* g, int hop, hipStream_t s) {
-    if (!g->d_cand_list) {
+static int ensure_early(tlc_graph* g, Workspace* ws, int hop, hipStream_t s) {
+    if (!g->d_ball_ub[0]) {
         TLC_HIP_CHECK(hipMalloc(&g->d_ball_ub[0], (size_t)g->n_nodes * sizeof(int)));
         TLC_HIP_CHECK(hipMalloc(&g->d_ball_ub[1], (size_t)g->n_nodes * sizeof(int)));
-        TLC_HIP_CHECK(hipMalloc(&g->d_early_list, TLC_EARLY_SLOTS * sizeof(int)));
-        TLC_HIP_CHECK(hipMalloc(&g->E_dir, (size_t)TLC_EARLY_SLOTS * 2 * TLC_L_MMAX * sizeof(unsigned)));
-        TLC_HIP_CHECK(hipMalloc(&g->E_lw, (size_t)TLC_EARLY_SLOTS * 2 * TLC_L_MMAX * sizeof(double)));
-        TLC_HIP_CHECK(hipMalloc(&g->d_cand_list, TLC_EARLY_CAND * sizeof(int)));
+    }
+    if (!ws->d_cand_list) {
+        TLC_HIP_CHECK(hipMalloc(&ws->d_early_list, TLC_EARLY_SLOTS * sizeof(int)));
+        TLC_HIP_CHECK(hipMalloc(&ws->E_dir, (size_t)TLC_EARLY_SLOTS * 2 * TLC_L_MMAX * sizeof(unsigned)));
+        TLC_HIP_CHECK(hipMalloc(&ws->E_lw, (size_t)TLC_EARLY_SLOTS * 2 * TLC_L_MMAX * sizeof(double)));
+        TLC_HIP_CHECK(hipMalloc(&ws->d_cand_list, TLC_EARLY_CAND * sizeof(int)));
     }
     if (g->ball_hop != hop) {
         int rc;
+        if ((rc = quiesce(g)) != TLC_OK) return rc;          // (a chunk in flight on another workspace may be reading the bounds)
         for (int h = 1; h <= hop; ++h) {
             // the result of round h lands in buffer (h - 1) & 1 ... the caller reads buffer (hop - 1) & 1
             if ((rc = tlc_launch_ball_bound(g->n_nodes, g->d_rowptr, g->d_col, h == 1 ? nullptr : g->d_ball_ub[h & 1],
@@ -248,13 +277,13 @@ static int ensure_early(tlc_graph* g, int hop, hipStream_t s) {
     return TLC_OK;
 }
 
-static int ensure_huge(tlc_graph* g) {
-    if (g->huge_scratch) return TLC_OK;
+static int ensure_huge(tlc_graph* g, Workspace* ws) {
+    if (ws->huge_scratch) return TLC_OK;
     const int nmax = std::min(g->n_nodes, 65535);
     const long long mmax = g->nnz / 2 + 1;
-    g->huge_stride = tlc_huge_slot_bytes(nmax, (int)mmax);
-    g->huge_slots = 64;
-    TLC_HIP_CHECK(hipMalloc(&g->huge_scratch, g->huge_stride * (size_t)g->huge_slots));
+    ws->huge_stride = tlc_huge_slot_bytes(nmax, (int)mmax);
+    ws->huge_slots = 64;
+    TLC_HIP_CHECK(hipMalloc(&ws->huge_scratch, ws->huge_stride * (size_t)ws->huge_slots));
     return TLC_OK;
 }
 
@@ -266,7 +295,7 @@ static int ensure_huge(tlc_graph* g) {
 // between two heavy nodes cannot be represented).  Whatever fails switches the heavy set off; the sweep then reads every row.
 #define TLC_HEAVY_MIN_DEG 32
 #define TLC_HEAVY_MAX 256
-static int build_heavy_set(tlc_graph* g, const int32_t* rp, const int32_t* col, const double* w) {
+static int build_heavy_set(tlc_graph* g, const int32_t* rp, const int32_t* col, const double* w, std::vector<int>* hidx_out) {
     const int n = g->n_nodes;
     std::vector<int> cand;
     for (int x = 0; x < n; ++x) if (rp[x + 1] - rp[x] >= TLC_HEAVY_MIN_DEG) cand.push_back(x);
@@ -303,12 +332,29 @@ static int build_heavy_set(tlc_graph* g, const int32_t* rp, const int32_t* col, 
     }
     for (int a = 0; a < K && ok; ++a)
         for (int b = 0; b < K && ok; ++b) if ((hh[(size_t)a * K + b] != 0.0) != (hh[(size_t)b * K + a] != 0.0) || hh[(size_t)a * K + b] != hh[(size_t)b * K + a]) ok = false;
-    if (!ok) return TLC_OK;                                   // (not an error: the sweep reads every row)
-    TLC_HIP_CHECK(hipMalloc(&g->d_hidx, (size_t)n * sizeof(int)));
-    TLC_HIP_CHECK(hipMalloc(&g->d_hh_w, (size_t)K * K * sizeof(double)));
-    TLC_HIP_CHECK(hipMemcpy(g->d_hidx, hidx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-    TLC_HIP_CHECK(hipMemcpy(g->d_hh_w, hh.data(), (size_t)K * K * sizeof(double), hipMemcpyHostToDevice));
-    g->hh_k = K;
+    if (ok) {
+        TLC_HIP_CHECK(hipMalloc(&g->d_hh_w, (size_t)K * K * sizeof(double)));
+        TLC_HIP_CHECK(hipMemcpy(g->d_hh_w, hh.data(), (size_t)K * K * sizeof(double), hipMemcpyHostToDevice));
+        g->hh_k = K;
+        *hidx_out = hidx;
+    }
+    return TLC_OK;                                            // (not ok: no heavy set, the sweep reads every row)
+}
+
+// the node records of the extraction (TlcNodeRec, tlc_kernels.h)
+static int build_node_records(tlc_graph* g, const int32_t* rp, const int32_t* col, const double* w, const std::vector<int>& hidx) {
+    const int n = g->n_nodes;
+    std::vector<TlcNodeRec> rec((size_t)n);
+    for (int x = 0; x < n; ++x) {
+        TlcNodeRec& r = rec[x];
+        memset(&r, 0, sizeof(r));
+        r.row_start = rp[x]; r.deg = rp[x + 1] - rp[x];
+        r.hidx = hidx.empty() ? -1 : hidx[x];
+        r.n_in = r.deg < 4 ? r.deg : 4;
+        for (int q = 0; q < r.n_in; ++q) { r.col[q] = col[rp[x] + q]; r.w[q] = w[rp[x] + q]; }
+    }
+    TLC_HIP_CHECK(hipMalloc(&g->d_nrec, (size_t)n * sizeof(TlcNodeRec)));
+    TLC_HIP_CHECK(hipMemcpy(g->d_nrec, rec.data(), (size_t)n * sizeof(TlcNodeRec), hipMemcpyHostToDevice));
     return TLC_OK;
 }
 
@@ -317,6 +363,10 @@ static int build_heavy_set(tlc_graph* g, const int32_t* rp, const int32_t* col, 
 // ball_list_hop = -1 and the caller uses the breadth-first kernels.
 static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
     if (g->ball_list_hop == hop) return TLC_OK;
+    {
+        const int rq = quiesce(g);                            // (a chunk in flight on another workspace may be reading the lists)
+        if (rq != TLC_OK) return rq;
+    }
     hipFree(g->d_bptr); hipFree(g->d_bcol);
     g->d_bptr = g->d_bcol = nullptr; g->ball_list_hop = 0; g->ball_entries = 0;
     const int n = g->n_nodes;
@@ -375,7 +425,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     g->device = device; g->n_nodes = n_nodes; g->nnz = nnz; g->nw = nw; g->vic_lds = lds;
     auto env_on = [](const char* name) { const char* v = getenv(name); return !(v && v[0] == '0'); };
     g->opt_extract = env_on("TLC_EXTRACT"); g->opt_heavy = env_on("TLC_HEAVY"); g->opt_tiny = env_on("TLC_TINY");
-    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20;
+    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = 0x7f;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
@@ -388,25 +438,45 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     CK(hipMemcpy(g->d_rowptr, h_rowptr, (size_t)(n_nodes + 1) * sizeof(int), hipMemcpyHostToDevice));
     CK(hipMemcpy(g->d_col, h_col, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
     CK(hipMemcpy(g->d_w, h_w, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
-    CK(hipMalloc(&g->d_ctl, (64 + 1024 + 8) * sizeof(int)));   // counters, the scan's per-block flags, 4 x u64 statistics
-    g->d_stats = reinterpret_cast<unsigned long long*>(g->d_ctl + 64 + 1024);      // (8-byte aligned: hipMalloc is 256-byte aligned)
-    CK(hipMalloc(&g->d_block_sums, 1024 * sizeof(long long)));
-    CK(hipMalloc(&g->d_totals, 2 * sizeof(long long)));
-    CK(hipHostMalloc((void**)&g->h_sync, sizeof(HostSync), hipHostMallocMapped | hipHostMallocCoherent));
-    memset(g->h_sync, 0, sizeof(HostSync));
-    CK(hipHostGetDevicePointer((void**)&g->h_sync_dev, g->h_sync, 0));
+    // Streams.  The runtime maps streams onto a pool of 4 hardware queues PER PRIORITY, least-shared first, and a stream that
+    // is blocked on an event stalls whatever shares its queue; so the handle keeps within 4 streams per priority, the caller's
+    // own stream included (normal priority):
+    //   per workspace: main (normal; carries what the caller's stream carries for a single stream-ordered chunk) and
+    //                  side[4], the early chain (high) -- the lead-in of the next chunk must not queue behind this chunk's tiers;
+    //   shared by the workspaces (a chunk's tier kernels queue behind the previous chunk's, which is the order they finish in
+    //                  anyway): side[0] SMALL, side[5] TINY (low), side[3] MID, side[6] MEDIUM and its rarely used twin
+    //                  side[2] (normal), side[1] the heavy tiers the early pass did not take (high).
+    // (Dedicated queues through hipExtStreamCreateWithCUMask -- with a full mask, or with CUs reserved for the whole-CU
+    // workgroups of the LARGE tier -- were measured: 1.2 - 3.3 ms per batch instead of 0.9.  tools/probes/cumask_probe.hip.)
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    for (int k = 0; k < TLC_N_SIDE; ++k) {
-        // side[1] carries the heavy tiers (the critical path): highest priority; side[2] (MEDIUM, the second longest
-        // chain) sits between it and side[0] (SMALL, which only has to finish before the other two do)
-        const int prio = (k == 1 || k == 4) ? prio_hi : (((k >= 2 && k <= 3) || k == 6) ? (prio_lo + prio_hi) / 2 : prio_lo);
-        CK(hipStreamCreateWithPriority(&g->side[k], hipStreamNonBlocking, prio));
-        CK(hipEventCreateWithFlags(&g->ev_join[k], hipEventDisableTiming));
+    const int prio_mid = (prio_lo + prio_hi) / 2;
+    for (int i = 0; i < TLC_N_WS; ++i) {
+        Workspace* ws = &g->ws[i];
+        CK(hipMalloc(&ws->d_ctl, (64 + 1024 + 8) * sizeof(int)));   // counters, the scan's per-block flags, 4 x u64 statistics
+        ws->d_stats = reinterpret_cast<unsigned long long*>(ws->d_ctl + 64 + 1024);      // (8-byte aligned: hipMalloc is 256-byte aligned)
+        CK(hipMalloc(&ws->d_block_sums, 1024 * sizeof(long long)));
+        CK(hipMalloc(&ws->d_totals, 2 * sizeof(long long)));
+        CK(hipHostMalloc((void**)&ws->h_sync, sizeof(HostSync), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(ws->h_sync, 0, sizeof(HostSync));
+        CK(hipHostGetDevicePointer((void**)&ws->h_sync_dev, ws->h_sync, 0));
+        // (workspace 1's own two streams are created when the first chunk lands on it: a caller that never has two chunks in
+        // flight keeps the hardware queues to itself)
+        if (i == 0) CK(hipStreamCreateWithPriority(&ws->main, hipStreamNonBlocking, prio_mid));
+        for (int k = 0; k < TLC_N_SIDE; ++k) {
+            if (k == 4) { if (i == 0) CK(hipStreamCreateWithPriority(&ws->side[k], hipStreamNonBlocking, prio_hi)); }
+            else if (i > 0) ws->side[k] = g->ws[0].side[k];
+            else if (k == 2) ws->side[k] = nullptr;                      // (= side[6], set below)
+            else CK(hipStreamCreateWithPriority(&ws->side[k], hipStreamNonBlocking, k == 1 ? prio_hi : ((k == 6 || k == 3) ? prio_mid : prio_lo)));
+            CK(hipEventCreateWithFlags(&ws->ev_join[k], hipEventDisableTiming));
+        }
+        if (i == 0) ws->side[2] = ws->side[6];
+        CK(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&ws->ev_early, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&ws->ev_scan, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&ws->ev_in, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&ws->ev_done, hipEventDisableTiming));
     }
-    CK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
-    CK(hipEventCreateWithFlags(&g->ev_early, hipEventDisableTiming));
-    CK(hipEventCreateWithFlags(&g->ev_scan, hipEventDisableTiming));
 #undef CK
     // concurrent vicinity workgroups worth launching: LDS-bound per CU, 256 CUs
     hipDeviceProp_t prop;
@@ -419,7 +489,11 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     // (the extraction kernel's workgroups are smaller: the scratch slots cover whichever kernel runs more of them)
     per_cu = std::max(per_cu, (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(g->x_lds64 + 64, 1)));
     g->vic_slots = cus * per_cu;
-    if ((rc = build_heavy_set(g, h_rowptr, h_col, h_w)) != TLC_OK) return fail(rc);
+    {
+        std::vector<int> hidx;
+        if ((rc = build_heavy_set(g, h_rowptr, h_col, h_w, &hidx)) != TLC_OK) return fail(rc);
+        if ((rc = build_node_records(g, h_rowptr, h_col, h_w, hidx)) != TLC_OK) return fail(rc);
+    }
     *out = g;
     return TLC_OK;
 }
@@ -429,20 +503,26 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     TlcDeviceScope scope(g->device);
     hipDeviceSynchronize();
     hipFree(g->d_rowptr); hipFree(g->d_col); hipFree(g->d_w);
-    hipFree(g->hdr_n); hipFree(g->hdr_m2); hipFree(g->hdr_lu); hipFree(g->hdr_lv); hipFree(g->tier_list); hipFree(g->edge_off);
-    hipFree(g->dc_lists); hipFree(g->big_lists);
-    hipFree(g->d_ctl); hipFree(g->d_block_sums); hipFree(g->d_totals);
-    if (g->h_sync) hipHostFree(g->h_sync);
-    hipFree(g->A_dir); hipFree(g->A_lw); hipFree(g->S_dir); hipFree(g->S_lw); hipFree(g->vic_scratch); hipFree(g->huge_scratch); hipFree(g->handoff); hipFree(g->handoff_large); hipFree(g->d_phase); hipFree(g->d_pair_t);
-    hipFree(g->d_bptr); hipFree(g->d_bcol); hipFree(g->d_hidx); hipFree(g->d_hh_w);
-    hipFree(g->d_ball_ub[0]); hipFree(g->d_ball_ub[1]); hipFree(g->d_cand_list); hipFree(g->d_early_list); hipFree(g->E_dir); hipFree(g->E_lw);
-    if (g->ev_early) hipEventDestroy(g->ev_early);
-    if (g->ev_scan) hipEventDestroy(g->ev_scan);
-    for (int k = 0; k < TLC_N_SIDE; ++k) {
-        if (g->side[k]) hipStreamDestroy(g->side[k]);
-        if (g->ev_join[k]) hipEventDestroy(g->ev_join[k]);
+    for (int i = 0; i < TLC_N_WS; ++i) {
+        Workspace* ws = &g->ws[i];
+        hipFree(ws->hdr_n); hipFree(ws->hdr_m2); hipFree(ws->hdr_lu); hipFree(ws->hdr_lv); hipFree(ws->tier_list); hipFree(ws->edge_off);
+        hipFree(ws->dc_lists); hipFree(ws->big_lists);
+        hipFree(ws->d_ctl); hipFree(ws->d_block_sums); hipFree(ws->d_totals);
+        if (ws->h_sync) hipHostFree(ws->h_sync);
+        hipFree(ws->A_dir); hipFree(ws->A_lw); hipFree(ws->S_dir); hipFree(ws->S_lw); hipFree(ws->vic_scratch); hipFree(ws->huge_scratch);
+        hipFree(ws->handoff); hipFree(ws->handoff_large);
+        hipFree(ws->d_cand_list); hipFree(ws->d_early_list); hipFree(ws->E_dir); hipFree(ws->E_lw);
+        if (ws->main) hipStreamDestroy(ws->main);
+        for (int k = 0; k < TLC_N_SIDE; ++k) {
+            const bool own = (k == 4) || (i == 0 && k != 2);             // (the rest are workspace 0's, see tlc_graph_create)
+            if (own && ws->side[k]) hipStreamDestroy(ws->side[k]);
+            if (ws->ev_join[k]) hipEventDestroy(ws->ev_join[k]);
+        }
+        for (hipEvent_t e : {ws->ev_fork, ws->ev_early, ws->ev_scan, ws->ev_in, ws->ev_done}) if (e) hipEventDestroy(e);
     }
-    if (g->ev_fork) hipEventDestroy(g->ev_fork);
+    hipFree(g->d_phase); hipFree(g->d_pair_t);
+    hipFree(g->d_bptr); hipFree(g->d_bcol); hipFree(g->d_nrec); hipFree(g->d_hh_w);
+    hipFree(g->d_ball_ub[0]); hipFree(g->d_ball_ub[1]);
     if (g->ev_ring_ready)
         for (int r = 0; r < TLC_TIMING_RING; ++r)
             for (int k = 0; k < 16; ++k) if (g->ev_ring[r][k]) hipEventDestroy(g->ev_ring[r][k]);
@@ -469,14 +549,14 @@ __global__ void tlc_wait_started_dev(const int* counter, const int* target, int 
         __builtin_amdgcn_s_sleep(8);
 }
 
-static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop, uint32_t flags, int res,
+static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_pairs, int hop, uint32_t flags, int res,
                      double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
                      double* d_out_f, int32_t* d_out_n, const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m,
                      int pi_enabled, hipStream_t s) {
     int rc;
-    if ((rc = ensure_pairs(g, (size_t)n_pairs)) != TLC_OK) return rc;
-    if ((rc = ensure_vic_scratch(g, hop)) != TLC_OK) return rc;
-    TLC_HIP_CHECK(hipMemsetAsync(g->d_ctl, 0, (64 + 1024 + 8) * sizeof(int), s));       // control words, scan flags, statistics
+    if ((rc = ensure_pairs(g, ws, (size_t)n_pairs)) != TLC_OK) return rc;
+    if ((rc = ensure_vic_scratch(g, ws, hop)) != TLC_OK) return rc;
+    TLC_HIP_CHECK(hipMemsetAsync(ws->d_ctl, 0, (64 + 1024 + 8) * sizeof(int), s));       // control words, scan flags, statistics
 
     TlcVicParams vp;
     memset(&vp, 0, sizeof(vp));
@@ -485,17 +565,17 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     if (g->d_phase) {
         if (g->cap_pair_t < (size_t)n_pairs) {
             hipFree(g->d_pair_t); g->d_pair_t = nullptr; g->cap_pair_t = 0;
-            TLC_HIP_CHECK(hipMalloc(&g->d_pair_t, (size_t)n_pairs * 4 * sizeof(unsigned long long)));
+            TLC_HIP_CHECK(hipMalloc(&g->d_pair_t, (size_t)n_pairs * 16 * sizeof(unsigned long long)));
             g->cap_pair_t = (size_t)n_pairs;
         }
-        TLC_HIP_CHECK(hipMemsetAsync(g->d_pair_t, 0, (size_t)n_pairs * 4 * sizeof(unsigned long long), s));
+        TLC_HIP_CHECK(hipMemsetAsync(g->d_pair_t, 0, (size_t)n_pairs * 16 * sizeof(unsigned long long), s));
         vp.dbg_pair_t = g->d_pair_t;
     }
     vp.pairs = d_pairs; vp.n_pairs = n_pairs; vp.hop = hop; vp.flags = flags; vp.res = res;
-    vp.scratch = g->vic_scratch; vp.scratch_stride = g->vic_stride;
-    vp.hdr_n = g->hdr_n; vp.hdr_m2 = g->hdr_m2; vp.hdr_lu = g->hdr_lu; vp.hdr_lv = g->hdr_lv;
+    vp.scratch = ws->vic_scratch; vp.scratch_stride = ws->vic_stride;
+    vp.hdr_n = ws->hdr_n; vp.hdr_m2 = ws->hdr_m2; vp.hdr_lu = ws->hdr_lu; vp.hdr_lv = ws->hdr_lv;
     vp.out_pi = d_out_pi; vp.out_status = d_out_status; vp.out_n = d_out_n; vp.out_m = d_out_m;
-    vp.edge_off = g->edge_off; vp.A_dir = nullptr; vp.A_lw = nullptr;
+    vp.edge_off = ws->edge_off; vp.A_dir = nullptr; vp.A_lw = nullptr;
     vp.ids_off = (const long long*)d_ids_off; vp.out_ids = d_out_ids;
 
     // (the attribute is per device and per size: tracked in the handle, which is bound to one device and one graph size)
@@ -534,8 +614,8 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     // before the sizes are known, so it starts from a guess and grows when a chunk overflows it (that chunk falls back to the
     // scan + FILL path below)
     const bool bump = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges;
-    unsigned long long* d_bump_top = reinterpret_cast<unsigned long long*>(g->d_ctl + 20);
-    int* d_bump_overflow = g->d_ctl + 22;
+    unsigned long long* d_bump_top = reinterpret_cast<unsigned long long*>(ws->d_ctl + 20);
+    int* d_bump_overflow = ws->d_ctl + 22;
     const bool early = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges && hop <= 2 && n_pairs >= TLC_EARLY_MIN_PAIRS;
     // hop <= 2, plain image batch: the extraction runs from the ball lists (extract.hip); otherwise the breadth-first kernels
     bool use_x = bump && hop <= 2 && !(flags & TLC_INCLUDE_ROOTS) && g->opt_extract;
@@ -549,61 +629,62 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         // arena = one region per workgroup of the extraction (main pass, then the early pass), then the bump area
         const long long regions = (long long)xgrid + (early ? TLC_EARLY_WG : 0);
         bump_base = regions * g->opt_x_region;
-        const size_t want = (size_t)bump_base + std::max<size_t>(std::max<size_t>((size_t)n_pairs * 32, (size_t)g->opt_x_bump_min), g->x_entries_hint + g->x_entries_hint / 2);
-        if (g->cap_entries < want && (rc = ensure_arena(g, want)) != TLC_OK) return rc;
+        const size_t want = (size_t)bump_base + std::max<size_t>(std::max<size_t>((size_t)n_pairs * 32, (size_t)g->opt_x_bump_min), ws->x_entries_hint + ws->x_entries_hint / 2);
+        if (ws->cap_entries < want && (rc = ensure_arena(g, ws, want)) != TLC_OK) return rc;
         vp.small_dir = nullptr; vp.small_lw = nullptr;
         vp.bptr = g->d_bptr; vp.bcol = g->d_bcol;
-        if (g->hh_k > 0 && g->opt_heavy) { vp.hidx = g->d_hidx; vp.hh_w = g->d_hh_w; vp.hh_k = g->hh_k; }
+        vp.nrec = g->d_nrec;
+        if (g->hh_k > 0 && g->opt_heavy) { vp.hh_w = g->d_hh_w; vp.hh_k = g->hh_k; }
         vp.region_entries = g->opt_x_region; vp.bump_base = bump_base; vp.region_base_wg = 0;
     } else {
-        if ((rc = ensure_small(g, (size_t)n_pairs)) != TLC_OK) return rc;
-        vp.small_dir = g->S_dir; vp.small_lw = g->S_lw;
+        if ((rc = ensure_small(g, ws, (size_t)n_pairs)) != TLC_OK) return rc;
+        vp.small_dir = ws->S_dir; vp.small_lw = ws->S_lw;
     }
     if (bump) {
-        if (g->cap_entries == 0 &&
-            (rc = ensure_arena(g, std::min<size_t>((size_t)n_pairs * 128, (size_t)1 << 23))) != TLC_OK) return rc;
-        vp.A_dir = g->A_dir; vp.A_lw = g->A_lw;
-        vp.bump_top = d_bump_top; vp.bump_cap = (long long)g->cap_entries; vp.bump_overflow = d_bump_overflow;
+        if (ws->cap_entries == 0 &&
+            (rc = ensure_arena(g, ws, std::min<size_t>((size_t)n_pairs * 128, (size_t)1 << 23))) != TLC_OK) return rc;
+        vp.A_dir = ws->A_dir; vp.A_lw = ws->A_lw;
+        vp.bump_top = d_bump_top; vp.bump_cap = (long long)ws->cap_entries; vp.bump_overflow = d_bump_overflow;
     }
-    int* d_cand_count = g->d_ctl + 16;
-    int* d_early_count = g->d_ctl + 17;
-    int* d_early_started = g->d_ctl + 18;
-    int* d_cand_started = g->d_ctl + 19;
+    int* d_cand_count = ws->d_ctl + 16;
+    int* d_early_count = ws->d_ctl + 17;
+    int* d_early_started = ws->d_ctl + 18;
+    int* d_cand_started = ws->d_ctl + 19;
     TlcPdParams pp;
     memset(&pp, 0, sizeof(pp));
-    pp.hdr_n = g->hdr_n; pp.hdr_m2 = g->hdr_m2; pp.hdr_lu = g->hdr_lu; pp.hdr_lv = g->hdr_lv;
-    pp.edge_off = g->edge_off;
-    pp.small_dir = use_x ? nullptr : g->S_dir; pp.small_lw = use_x ? nullptr : g->S_lw;
+    pp.hdr_n = ws->hdr_n; pp.hdr_m2 = ws->hdr_m2; pp.hdr_lu = ws->hdr_lu; pp.hdr_lv = ws->hdr_lv;
+    pp.edge_off = ws->edge_off;
+    pp.small_dir = use_x ? nullptr : ws->S_dir; pp.small_lw = use_x ? nullptr : ws->S_lw;
     pp.flags = flags; pp.res = res; pp.out_pi = d_out_pi; pp.out_status = d_out_status;
     pp.ids_off = (const long long*)d_ids_off; pp.out_f = d_out_f; pp.out_n = d_out_n; pp.pi_enabled = pi_enabled;
     pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
-    pp.stats = g->d_stats;
+    pp.stats = ws->d_stats;
     // lists for tlc_pd_dc_kernel: counters in the control block (zeroed with it), [d_ctl + 26 + 2k] count / [.. + 1] left over;
     // k = 0 MEDIUM, 1 LARGE (regular launch), 2 LARGE (early launch)
     auto dc_lists_for = [&](TlcPdParams& q, int k) {
-        const size_t cap = g->cap_pairs + TLC_EARLY_SLOTS;
-        q.dc_count = g->d_ctl + 26 + 2 * k; q.dcf_count = g->d_ctl + 27 + 2 * k;
-        q.dc_list = g->dc_lists + (size_t)k * cap;
-        q.dcf_list = g->dc_lists + (size_t)(3 + k) * cap;
+        const size_t cap = ws->cap_pairs + TLC_EARLY_SLOTS;
+        q.dc_count = ws->d_ctl + 26 + 2 * k; q.dcf_count = ws->d_ctl + 27 + 2 * k;
+        q.dc_list = ws->dc_lists + (size_t)k * cap;
+        q.dcf_list = ws->dc_lists + (size_t)(3 + k) * cap;
     };
     if (early) {
-        if ((rc = ensure_early(g, hop, s)) != TLC_OK) return rc;
-        hipStream_t es = g->side[4];
-        TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s));                  // after the memsets (and the one-off bounds)
-        TLC_HIP_CHECK(hipStreamWaitEvent(es, g->ev_fork, 0));
+        if ((rc = ensure_early(g, ws, hop, s)) != TLC_OK) return rc;
+        hipStream_t es = ws->side[4];
+        TLC_HIP_CHECK(hipEventRecord(ws->ev_fork, s));                  // after the memsets (and the one-off bounds)
+        TLC_HIP_CHECK(hipStreamWaitEvent(es, ws->ev_fork, 0));
         // (TLC_INCLUDE_ROOTS adds at most the two roots to a vicinity)
         if (use_x) {
             // exact ball sizes: the candidates of the early pass and the bins the main pass takes first
             if ((rc = tlc_launch_classify(n_pairs, d_pairs, g->n_nodes, g->d_bptr, TLC_M_NMAX - 1, TLC_EARLY_CAND, d_cand_count,
-                                          g->d_cand_list, g->d_ctl + 32, g->big_lists, es)) != TLC_OK) return rc;
+                                          ws->d_cand_list, ws->d_ctl + 32, ws->big_lists, es)) != TLC_OK) return rc;
         } else if ((rc = tlc_launch_select_heavy(n_pairs, d_pairs, g->n_nodes, g->d_ball_ub[(hop - 1) & 1], TLC_M_NMAX - 1, TLC_EARLY_CAND,
-                                                 d_cand_count, g->d_cand_list, es)) != TLC_OK) return rc;
+                                                 d_cand_count, ws->d_cand_list, es)) != TLC_OK) return rc;
         TlcVicParams ep = vp;
-        ep.fill_mode = 1; ep.fill_list = g->d_cand_list; ep.fill_count = TLC_EARLY_CAND; ep.work_count_dev = d_cand_count;
+        ep.fill_mode = 1; ep.fill_list = ws->d_cand_list; ep.fill_count = TLC_EARLY_CAND; ep.work_count_dev = d_cand_count;
         ep.scratch_base_slot = g->vic_slots;
         ep.dbg = g->d_phase ? g->d_phase + 32 * TLC_N_TIERS : nullptr;        // (diagnostics: the early pass has its own row)
-        ep.early_list = g->d_early_list; ep.early_count = d_early_count; ep.early_cap = TLC_EARLY_SLOTS;
-        ep.early_dir = g->E_dir; ep.early_lw = g->E_lw;
+        ep.early_list = ws->d_early_list; ep.early_count = d_early_count; ep.early_cap = TLC_EARLY_SLOTS;
+        ep.early_dir = ws->E_dir; ep.early_lw = ws->E_lw;
         ep.started = d_cand_started;
         if (use_x) {
             // the early pass OWNS its candidates: headers, status bytes, zero rows, slots and bump-allocated vicinities are all
@@ -611,7 +692,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
             ep.region_base_wg = xgrid;
             if ((rc = tlc_launch_extract(512, TLC_EARLY_WG, g->x_lds512, ep, es)) != TLC_OK) return rc;
             vp.skip_threshold = TLC_M_NMAX - 1; vp.skip_count = d_cand_count; vp.skip_cap = TLC_EARLY_CAND;
-            vp.big_count = g->d_ctl + 32; vp.big_list = g->big_lists;
+            vp.big_count = ws->d_ctl + 32; vp.big_list = ws->big_lists;
         } else {
             ep.bump_top = nullptr;
             ep.out_pi = nullptr; ep.out_status = nullptr; ep.out_n = nullptr; ep.out_m = nullptr;   // the main COUNT reports
@@ -619,33 +700,33 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
             hipLaunchKernelGGL((tlc_vicinity_kernel<false, 512>), dim3(TLC_EARLY_WG), dim3(512), g->vic_lds, es, ep);
             TLC_HIP_CHECK(hipGetLastError());
         }
-        TLC_HIP_CHECK(hipEventRecord(g->ev_early, es));
+        TLC_HIP_CHECK(hipEventRecord(ws->ev_early, es));
         TlcPdParams lp = pp;
-        lp.tier_list = g->d_early_list; lp.tier_count = TLC_EARLY_SLOTS; lp.tier_count_dev = d_early_count;
-        lp.slot_entries = 2 * TLC_L_MMAX; lp.A_dir = g->E_dir; lp.A_lw = g->E_lw;
+        lp.tier_list = ws->d_early_list; lp.tier_count = TLC_EARLY_SLOTS; lp.tier_count_dev = d_early_count;
+        lp.slot_entries = 2 * TLC_L_MMAX; lp.A_dir = ws->E_dir; lp.A_lw = ws->E_lw;
         lp.started = d_early_started;
         if (tlc_handoff_slot_bytes(TLC_TIER_LARGE) != 0) {
-            if ((rc = ensure_handoff_large(g, TLC_EARLY_SLOTS)) != TLC_OK) return rc;
-            lp.handoff = g->handoff_large; lp.handoff_stride = (long long)tlc_handoff_slot_bytes(TLC_TIER_LARGE);
+            if ((rc = ensure_handoff_large(g, ws, TLC_EARLY_SLOTS)) != TLC_OK) return rc;
+            lp.handoff = ws->handoff_large; lp.handoff_stride = (long long)tlc_handoff_slot_bytes(TLC_TIER_LARGE);
             lp.handoff_cap = TLC_EARLY_SLOTS;
             dc_lists_for(lp, 2);
         }
         lp.phase_cycles = g->d_phase ? g->d_phase + 32 * TLC_TIER_LARGE : nullptr;
         T0(5, es);
-        if ((rc = tlc_launch_pd_tier(TLC_TIER_LARGE, lp, es)) != TLC_OK) return rc;
+        if (((g->opt_tier_mask >> TLC_TIER_LARGE) & 1) && (rc = tlc_launch_pd_tier(TLC_TIER_LARGE, lp, es)) != TLC_OK) return rc;
         T1(5, es);
-        TLC_HIP_CHECK(hipEventRecord(g->ev_join[4], es));
+        TLC_HIP_CHECK(hipEventRecord(ws->ev_join[4], es));
         // The workgroups of the main COUNT are persistent (each strides over its share of the pairs) and fill every wavefront
         // slot and most of the LDS of the machine: once they are running, a 512-thread workgroup of the early pass -- let alone
         // one of its tier kernel, which needs a whole CU's LDS -- is placed only as they drain (measured: the early tier kernel
         // then runs 1.05 instead of 0.88 ms because its last workgroups start ~0.15 ms late).  So the main COUNT is held until
         // the early COUNT is done and the early tier kernel's workgroups are resident (bounded: 50 us after the former).
-        TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_early, 0));
+        TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_early, 0));
         hipLaunchKernelGGL(tlc_wait_started_dev, dim3(1), dim3(TLC_WAVE), 0, s, (const int*)d_early_started, (const int*)d_early_count,
                            192, 5000ll);
         TLC_HIP_CHECK(hipGetLastError());
     }
-    vp.work_counter = g->d_ctl + 24;
+    vp.work_counter = ws->d_ctl + 24;
     vp.work_chunk = std::max(4, n_pairs / 8192);
     T0(0, s);
     if (use_x) {
@@ -657,31 +738,31 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     vp.work_counter = nullptr;
     vp.skip_count = nullptr; vp.big_count = nullptr;      // (the FILL launches below are list-driven)
     TLC_HIP_CHECK(hipGetLastError());
-    if (early) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_early, 0));   // the scan reads the early list
+    if (early) TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_early, 0));   // the scan reads the early list
 
     // exclusive scan of the induced entry counts + tier binning
     const int nb = (n_pairs + 1023) / 1024;
     T0(1, s);
-    const unsigned seq = ++g->pub_seq;
+    const unsigned seq = ++ws->pub_seq;
     TlcScanParams sp;
-    sp.n_pairs = n_pairs; sp.hdr_n = g->hdr_n; sp.hdr_m2 = g->hdr_m2;
-    sp.block_agg = g->d_block_sums; sp.block_flag = g->d_ctl + 64; sp.sync = g->d_ctl + 10; sp.totals = g->d_totals;
-    sp.edge_off = g->edge_off; sp.tier_count = g->d_ctl; sp.tier_list = g->tier_list; sp.small_arena = use_x ? 0 : 1;
+    sp.n_pairs = n_pairs; sp.hdr_n = ws->hdr_n; sp.hdr_m2 = ws->hdr_m2;
+    sp.block_agg = ws->d_block_sums; sp.block_flag = ws->d_ctl + 64; sp.sync = ws->d_ctl + 10; sp.totals = ws->d_totals;
+    sp.edge_off = ws->edge_off; sp.tier_count = ws->d_ctl; sp.tier_list = ws->tier_list; sp.small_arena = use_x ? 0 : 1;
     // the plain TLC-GNN image batch at resolution 5: the smallest vicinities go to the lane-per-subgraph kernel (pd_tiny.hip)
     sp.tiny_ok = (g->opt_tiny && pi_enabled && flags == 0u && res == 5 && !d_out_ids && !d_out_f && !d_out_edges) ? 1 : 0;
-    sp.early_list = early ? g->d_early_list : nullptr; sp.early_count = d_early_count; sp.early_cap = TLC_EARLY_SLOTS;
-    sp.h_early = const_cast<int*>(&g->h_sync_dev->pub_early);
+    sp.early_list = early ? ws->d_early_list : nullptr; sp.early_count = d_early_count; sp.early_cap = TLC_EARLY_SLOTS;
+    sp.h_early = const_cast<int*>(&ws->h_sync_dev->pub_early);
     sp.bump_top = bump ? d_bump_top : nullptr; sp.bump_overflow = d_bump_overflow; sp.bump_base = bump_base;
-    sp.h_overflow = const_cast<int*>(&g->h_sync_dev->pub_overflow);
+    sp.h_overflow = const_cast<int*>(&ws->h_sync_dev->pub_overflow);
     // The arena size and the tier counts come back through mapped host memory: the last block of the scan stores them,
     // fences at system scope and bumps a sequence number the host polls -- no copy kernels, no stream synchronisation on
     // the critical path.  The poll gives up after 200 us and falls back to synchronising the stream (which also surfaces
     // a kernel fault).
-    sp.h_total = const_cast<long long*>(&g->h_sync_dev->pub_total);
-    sp.h_entries = const_cast<long long*>(&g->h_sync_dev->pub_entries);
-    sp.entries_sum = reinterpret_cast<unsigned long long*>(g->d_ctl + 36);
-    sp.h_tier = const_cast<int*>(g->h_sync_dev->pub_tier);
-    sp.h_seq = const_cast<unsigned*>(&g->h_sync_dev->pub_seq);
+    sp.h_total = const_cast<long long*>(&ws->h_sync_dev->pub_total);
+    sp.h_entries = const_cast<long long*>(&ws->h_sync_dev->pub_entries);
+    sp.entries_sum = reinterpret_cast<unsigned long long*>(ws->d_ctl + 36);
+    sp.h_tier = const_cast<int*>(ws->h_sync_dev->pub_tier);
+    sp.h_seq = const_cast<unsigned*>(&ws->h_sync_dev->pub_seq);
     sp.seq = seq;
     hipLaunchKernelGGL(tlc_scan_bin, dim3(nb), dim3(1024), 0, s, sp);
     T1(1, s);
@@ -698,32 +779,32 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     size_t spec_base[TLC_N_TIERS] = {0, 0, 0, 0, 0, 0, 0};
     int spec_cap[TLC_N_TIERS] = {0, 0, 0, 0, 0, 0, 0};
     if (spec) {
-        spec_cap[TLC_TIER_MID] = std::min(n_pairs, std::max(4096, g->prev_tc[TLC_TIER_MID] + g->prev_tc[TLC_TIER_MID] / 4));
-        spec_cap[TLC_TIER_MEDIUM] = std::min(n_pairs, std::max(2048, g->prev_tc[TLC_TIER_MEDIUM] + g->prev_tc[TLC_TIER_MEDIUM] / 4));
-        spec_cap[TLC_TIER_MEDHI] = std::min(n_pairs, std::max(1024, g->prev_tc[TLC_TIER_MEDHI] + g->prev_tc[TLC_TIER_MEDHI] / 4));
+        spec_cap[TLC_TIER_MID] = std::min(n_pairs, std::max(4096, ws->prev_tc[TLC_TIER_MID] + ws->prev_tc[TLC_TIER_MID] / 4));
+        spec_cap[TLC_TIER_MEDIUM] = std::min(n_pairs, std::max(2048, ws->prev_tc[TLC_TIER_MEDIUM] + ws->prev_tc[TLC_TIER_MEDIUM] / 4));
+        spec_cap[TLC_TIER_MEDHI] = std::min(n_pairs, std::max(1024, ws->prev_tc[TLC_TIER_MEDHI] + ws->prev_tc[TLC_TIER_MEDHI] / 4));
         // hand-off buffer: [MID | MEDHI (speculative launch) | MEDIUM]
         spec_base[TLC_TIER_MEDHI] = (size_t)spec_cap[TLC_TIER_MID] * tlc_handoff_slot_bytes(TLC_TIER_MID);
         spec_base[TLC_TIER_MEDIUM] = spec_base[TLC_TIER_MEDHI] + (size_t)spec_cap[TLC_TIER_MEDHI] * tlc_handoff_slot_bytes(TLC_TIER_MEDHI);
-        if ((rc = ensure_handoff(g, spec_base[TLC_TIER_MEDIUM] +
+        if ((rc = ensure_handoff(g, ws, spec_base[TLC_TIER_MEDIUM] +
                                         (size_t)spec_cap[TLC_TIER_MEDIUM] * tlc_handoff_slot_bytes(TLC_TIER_MEDIUM))) != TLC_OK) return rc;
-        pp.A_dir = g->A_dir; pp.A_lw = g->A_lw;
+        pp.A_dir = ws->A_dir; pp.A_lw = ws->A_lw;
         // On the caller's stream itself, tier kernels first, then their swap kernels.  (On side streams they would sit behind
         // event waits until the scan is done, and a blocked stream stalls whatever shares its hardware queue -- ROCm maps all
         // streams onto 4 by default: measured, the scan then started 0.1 ms late and took 55 instead of 11 us.)  The fork
         // point of the side-stream launches below is the event recorded here, ahead of these kernels.
-        TLC_HIP_CHECK(hipEventRecord(g->ev_scan, s));
+        TLC_HIP_CHECK(hipEventRecord(ws->ev_scan, s));
         // (only the MEDIUM-sized vicinities with many Pos edges, whose tier kernel + long serial swaps are the longest chain of
         // the small tiers: kernels on one stream do not overlap, and another tier's pair of kernels between that tier kernel and
         // its swap kernel costs more than the host round trip saves -- measured)
         {
             const int t = TLC_TIER_MEDHI;
-            pp.tier_list = g->tier_list + (size_t)t * n_pairs; pp.tier_count = n_pairs; pp.tier_count_dev = g->d_ctl + t;
+            pp.tier_list = ws->tier_list + (size_t)t * n_pairs; pp.tier_count = n_pairs; pp.tier_count_dev = ws->d_ctl + t;
             pp.grid = spec_cap[t]; pp.handoff_cap = spec_cap[t]; pp.phase = 0;
-            pp.handoff = g->handoff + spec_base[t]; pp.handoff_stride = (long long)tlc_handoff_slot_bytes(t);
+            pp.handoff = ws->handoff + spec_base[t]; pp.handoff_stride = (long long)tlc_handoff_slot_bytes(t);
             pp.abort_flag = d_bump_overflow;
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
             T0(tslot[t], s);
-            if ((rc = tlc_launch_pd_tier(t, pp, s)) != TLC_OK) return rc;
+            if (((g->opt_tier_mask >> t) & 1) && (rc = tlc_launch_pd_tier(t, pp, s)) != TLC_OK) return rc;
             T1(tslot[t], s);
         }
         pp.phase = 0;
@@ -734,37 +815,37 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         // then, so that a fault surfaces instead of a spin)
         const auto t0 = std::chrono::steady_clock::now();
         bool seen = false;
-        for (unsigned it = 1; !(seen = (g->h_sync->pub_seq == seq)); ++it) {
+        for (unsigned it = 1; !(seen = (ws->h_sync->pub_seq == seq)); ++it) {
             if ((it & 0x3ff) != 0) continue;
             const auto el = std::chrono::steady_clock::now() - t0;
             if (el < std::chrono::microseconds(300)) continue;
             const hipError_t q = hipStreamQuery(s);
-            if (q == hipSuccess) { seen = (g->h_sync->pub_seq == seq); break; }
+            if (q == hipSuccess) { seen = (ws->h_sync->pub_seq == seq); break; }
             if (q != hipErrorNotReady) { tlc_set_error(hipGetErrorString(q)); return TLC_ERR_HIP; }
             if (el > std::chrono::seconds(20)) break;
         }
         TLC_REQUIRE(seen, "size publication did not arrive");
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    const long long total = g->h_sync->pub_total;
+    const long long total = ws->h_sync->pub_total;
     int tc[TLC_N_TIERS];
-    for (int t = 0; t < TLC_N_TIERS; ++t) tc[t] = g->h_sync->pub_tier[t];
+    for (int t = 0; t < TLC_N_TIERS; ++t) tc[t] = ws->h_sync->pub_tier[t];
     // (COUNT's writes stand unless the chunk overflowed the arena: then everything is laid out by the scan and written by FILL)
-    const bool bumped = bump && g->h_sync->pub_overflow == 0;
-    if (use_x) g->x_entries_hint = std::max(g->x_entries_hint, (size_t)std::max<long long>(total - (bumped ? bump_base : 0), 0));
-    if ((rc = ensure_arena(g, (size_t)total, bumped ? (size_t)std::min<long long>(total, (long long)g->cap_entries) : 0, s)) != TLC_OK) return rc;
-    if (tc[TLC_TIER_HUGE] > 0 && (rc = ensure_huge(g)) != TLC_OK) return rc;
+    const bool bumped = bump && ws->h_sync->pub_overflow == 0;
+    if (use_x) ws->x_entries_hint = std::max(ws->x_entries_hint, (size_t)std::max<long long>(total - (bumped ? bump_base : 0), 0));
+    if ((rc = ensure_arena(g, ws, (size_t)total, bumped ? (size_t)std::min<long long>(total, (long long)ws->cap_entries) : 0, s)) != TLC_OK) return rc;
+    if (tc[TLC_TIER_HUGE] > 0 && (rc = ensure_huge(g, ws)) != TLC_OK) return rc;
 
-    const int n_early = early ? g->h_sync->pub_early : 0;
+    const int n_early = early ? ws->h_sync->pub_early : 0;
     const int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4] + tc[5] + tc[6];
     const bool spec_done = spec && bumped;          // the MID / MEDIUM tiers are already running
-    g->prev_tc[TLC_TIER_MID] = tc[TLC_TIER_MID]; g->prev_tc[TLC_TIER_MEDIUM] = tc[TLC_TIER_MEDIUM]; g->prev_tc[TLC_TIER_MEDHI] = tc[TLC_TIER_MEDHI];
+    ws->prev_tc[TLC_TIER_MID] = tc[TLC_TIER_MID]; ws->prev_tc[TLC_TIER_MEDIUM] = tc[TLC_TIER_MEDIUM]; ws->prev_tc[TLC_TIER_MEDHI] = tc[TLC_TIER_MEDHI];
     if (todo > 0) {
-        vp.A_dir = g->A_dir; vp.A_lw = g->A_lw;
-        pp.A_dir = g->A_dir; pp.A_lw = g->A_lw;
-        pp.huge_scratch = g->huge_scratch; pp.huge_stride = (long long)g->huge_stride;
-        pp.huge_nmax = std::min(g->n_nodes, TLC_MAX_SUBGRAPH_NODES); pp.huge_mmax = (int)std::min<long long>(g->nnz / 2 + 1, TLC_MAX_SUBGRAPH_EDGES); pp.huge_slots = g->huge_slots;
-        pp.started = (int*)(g->d_stats + 2);
+        vp.A_dir = ws->A_dir; vp.A_lw = ws->A_lw;
+        pp.A_dir = ws->A_dir; pp.A_lw = ws->A_lw;
+        pp.huge_scratch = ws->huge_scratch; pp.huge_stride = (long long)ws->huge_stride;
+        pp.huge_nmax = std::min(g->n_nodes, TLC_MAX_SUBGRAPH_NODES); pp.huge_mmax = (int)std::min<long long>(g->nnz / 2 + 1, TLC_MAX_SUBGRAPH_EDGES); pp.huge_slots = ws->huge_slots;
+        pp.started = (int*)(ws->d_stats + 2);
         // The extraction ran out of arena: every vicinity below the heavy tiers is laid out by the scan and written by the
         // breadth-first FILL -- before any tier kernel may read it (that includes the SMALL tier, which has no slots of its own here)
         bool filled_all = false;
@@ -783,7 +864,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
                 hand_base[t] = hand_total;
                 hand_total += (size_t)tc[t] * tlc_handoff_slot_bytes(t);
             }
-            if ((rc = ensure_handoff(g, hand_total)) != TLC_OK) return rc;
+            if ((rc = ensure_handoff(g, ws, hand_total)) != TLC_OK) return rc;
         } else if (pi_enabled) {
             // the speculative launch in flight owns its part of the buffer, which must not move: the MID tier's slots were
             // reserved in front of it and the MEDIUM tier's behind it, for spec_cap[] subgraphs each; beyond that a tier runs
@@ -794,32 +875,32 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         // (`behind_s`: the launch depends on what was just submitted to s, e.g. a FILL; else only on the scan)
         auto launch_side = [&](int k, int t, bool behind_s = true) -> int {
             if (spec_done && !behind_s) {
-                TLC_HIP_CHECK(hipStreamWaitEvent(g->side[k], g->ev_scan, 0));    // (not behind the speculative kernels on s)
+                TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[k], ws->ev_scan, 0));    // (not behind the speculative kernels on s)
             } else {
-                TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s));
-                TLC_HIP_CHECK(hipStreamWaitEvent(g->side[k], g->ev_fork, 0));
+                TLC_HIP_CHECK(hipEventRecord(ws->ev_fork, s));
+                TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[k], ws->ev_fork, 0));
             }
-            pp.tier_list = g->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
+            pp.tier_list = ws->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
             const size_t hs = pi_enabled ? tlc_handoff_slot_bytes(t) : 0;
-            pp.handoff = hs ? g->handoff + hand_base[t] : nullptr;
+            pp.handoff = hs ? ws->handoff + hand_base[t] : nullptr;
             pp.handoff_stride = (long long)hs;
             pp.handoff_cap = (spec_done && (t == TLC_TIER_MID || t == TLC_TIER_MEDIUM)) ? std::min(tc[t], spec_cap[t]) : tc[t];
             pp.dc_count = pp.dcf_count = nullptr; pp.dc_list = pp.dcf_list = nullptr;
             if (t == TLC_TIER_LARGE) dc_lists_for(pp, 1);
             if (hs && t == TLC_TIER_LARGE) {
                 // (the early launch may still be using the first TLC_EARLY_SLOTS slots: this launch takes the ones behind them)
-                int r2 = ensure_handoff_large(g, (size_t)TLC_EARLY_SLOTS + (size_t)tc[t]);
+                int r2 = ensure_handoff_large(g, ws, (size_t)TLC_EARLY_SLOTS + (size_t)tc[t]);
                 if (r2 != TLC_OK) return r2;
-                pp.handoff = g->handoff_large + (size_t)TLC_EARLY_SLOTS * hs;
+                pp.handoff = ws->handoff_large + (size_t)TLC_EARLY_SLOTS * hs;
             }
             pp.grid = 0; pp.phase = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
             const bool timed = !(early && t == TLC_TIER_LARGE) && t != TLC_TIER_MEDIUM;   // (those slots time the early launch / MEDHI)
-            if (timed) T0(tslot[t], g->side[k]);
-            int r = tlc_launch_pd_tier(t, pp, g->side[k]);
+            if (timed) T0(tslot[t], ws->side[k]);
+            int r = ((g->opt_tier_mask >> t) & 1) ? tlc_launch_pd_tier(t, pp, ws->side[k]) : TLC_OK;   // (development: tiers timed alone)
             if (r != TLC_OK) return r;
-            if (timed) T1(tslot[t], g->side[k]);
-            TLC_HIP_CHECK(hipEventRecord(g->ev_join[k], g->side[k]));
+            if (timed) T1(tslot[t], ws->side[k]);
+            TLC_HIP_CHECK(hipEventRecord(ws->ev_join[k], ws->side[k]));
             used[k] = true;
             return TLC_OK;
         };
@@ -829,7 +910,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         T0(2, s);
         for (int t = TLC_TIER_HUGE; t >= TLC_TIER_LARGE; --t) {
             if (tc[t] <= 0) continue;
-            vp.fill_mode = 1; vp.fill_list = g->tier_list + (size_t)t * n_pairs; vp.fill_count = tc[t];
+            vp.fill_mode = 1; vp.fill_list = ws->tier_list + (size_t)t * n_pairs; vp.fill_count = tc[t];
             // the heavy vicinities get 8 wavefronts each (hop <= 2), so that their many long CSR rows are in flight together
             if (use_x) {
                 // (same entry order as the early pass's slots: rows do not depend on which way a vicinity took)
@@ -856,15 +937,15 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         // the lower end of the SMALL tier first: one lane per subgraph, a few hundred latency-bound wavefronts that need 66 KB of
         // LDS each -- they must find room before the other tiers' workgroups take it
         if (tc[TLC_TIER_TINY] > 0) {
-            if (spec_done) { TLC_HIP_CHECK(hipStreamWaitEvent(g->side[5], g->ev_scan, 0)); }
-            else { TLC_HIP_CHECK(hipEventRecord(g->ev_fork, s)); TLC_HIP_CHECK(hipStreamWaitEvent(g->side[5], g->ev_fork, 0)); }
-            pp.tier_list = g->tier_list + (size_t)TLC_TIER_TINY * n_pairs; pp.tier_count = tc[TLC_TIER_TINY];
+            if (spec_done) { TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_scan, 0)); }
+            else { TLC_HIP_CHECK(hipEventRecord(ws->ev_fork, s)); TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_fork, 0)); }
+            pp.tier_list = ws->tier_list + (size_t)TLC_TIER_TINY * n_pairs; pp.tier_count = tc[TLC_TIER_TINY];
             pp.handoff = nullptr; pp.handoff_stride = 0; pp.handoff_cap = 0; pp.grid = 0; pp.phase = 0;
             pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
             pp.dc_count = pp.dcf_count = nullptr; pp.dc_list = pp.dcf_list = nullptr;
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * TLC_TIER_TINY : nullptr;
-            if ((rc = tlc_launch_pd_tiny(pp, g->side[5])) != TLC_OK) return rc;
-            TLC_HIP_CHECK(hipEventRecord(g->ev_join[5], g->side[5]));
+            if (((g->opt_tier_mask >> TLC_TIER_TINY) & 1) && (rc = tlc_launch_pd_tiny(pp, ws->side[5])) != TLC_OK) return rc;
+            TLC_HIP_CHECK(hipEventRecord(ws->ev_join[5], ws->side[5]));
             used[5] = true;
         }
         if (tc[TLC_TIER_SMALL] > 0 && (rc = launch_side(0, TLC_TIER_SMALL, false)) != TLC_OK) return rc;
@@ -885,7 +966,7 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
         }
     }
     for (int k = 0; k < TLC_N_SIDE; ++k)
-        if (used[k]) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ev_join[k], 0));
+        if (used[k]) TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_join[k], 0));
 #undef T0
 #undef T1
     for (int t = 0; t <= TLC_TIER_HUGE; ++t) g->last_stats[t] += tc[t];
@@ -895,15 +976,44 @@ static int run_chunk(tlc_graph* g, const int32_t* d_pairs, int n_pairs, int hop,
     g->last_stats[8] += tc[TLC_TIER_TINY];
     g->last_stats[TLC_TIER_LARGE] += n_early;
     g->last_stats[7] += tc[TLC_TIER_MID];
-    g->last_stats[4] += g->h_sync->pub_entries;
+    g->last_stats[4] += ws->h_sync->pub_entries;
     g->last_stats[6] += 1;
     return TLC_OK;
 }
 
+// the next workspace in turn; if a chunk is still in flight on it, the host waits for that chunk (two chunks ahead of the GPU
+// is as far as a caller can run)
+static int acquire_workspace(tlc_graph* g, Workspace** out, bool same) {
+    // (`same`: a stream-ordered single chunk -- consecutive calls cannot overlap anyway, and staying on one workspace keeps its
+    // arena, headers and lists warm in the Infinity Cache: alternating cost the back-to-back batch 0.09 ms)
+    Workspace* ws = same ? &g->ws[0] : &g->ws[g->next_ws % TLC_N_WS];
+    if (!same) ++g->next_ws;
+    if (!ws->main) {
+        int prio_lo = 0, prio_hi = 0;
+        hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        TLC_HIP_CHECK(hipStreamCreateWithPriority(&ws->main, hipStreamNonBlocking, (prio_lo + prio_hi) / 2));
+        TLC_HIP_CHECK(hipStreamCreateWithPriority(&ws->side[4], hipStreamNonBlocking, prio_hi));
+    }
+    if (ws->busy) {
+        TLC_HIP_CHECK(hipEventSynchronize(ws->ev_done));
+        ws->busy = 0;
+        if (ws->in_call) {                                    // statistics of a chunk of the call in progress
+            unsigned long long tie = 0;
+            TLC_HIP_CHECK(hipMemcpy(&tie, ws->d_stats, sizeof(tie), hipMemcpyDeviceToHost));
+            g->acc_tie += (long long)tie;
+            ws->in_call = 0;
+        }
+    }
+    *out = ws;
+    return TLC_OK;
+}
+
+// `join`: the caller's stream waits for the chunks before the call returns (the stream-ordered contract of tlc_pd_pi_batch);
+// else they are left in flight (tlc_pd_pi_batch_async) until tlc_pd_pi_batch_join.
 static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags, int res,
                      double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
                      double* d_out_f, int32_t* d_out_n, const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m,
-                     int pi_enabled, void* stream) {
+                     int pi_enabled, void* stream, bool join) {
     TLC_REQUIRE(g != nullptr, "graph handle is null");
     TLC_REQUIRE(n_pairs >= 0, "n_pairs < 0");
     TLC_REQUIRE(hop >= 1 && hop <= 64, "hop must be in 1..64");
@@ -911,24 +1021,37 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
     TLC_REQUIRE(n_pairs == 0 || d_pairs != nullptr, "pairs is null");
     TLC_ON_DEVICE(g->device);
     memset(g->last_stats, 0, sizeof(g->last_stats));
+    g->acc_tie = 0;
+    for (int k = 0; k < TLC_N_WS; ++k) g->ws[k].in_call = 0;
     hipStream_t s = (hipStream_t)stream;
+    // a single chunk of a stream-ordered call runs on the caller's stream itself (no cross-stream hops in its latency);
+    // otherwise every chunk runs on its workspace's own stream so that consecutive chunks overlap
+    const bool inline_main = join && n_pairs <= TLC_CHUNK_PAIRS;
     for (int64_t off = 0; off < n_pairs; off += TLC_CHUNK_PAIRS) {
         const int cnt = (int)std::min<int64_t>(TLC_CHUNK_PAIRS, n_pairs - off);
-        // NOTE: ids_off is indexed by the global pair index, the kernels index by chunk-local index
-        int rc = run_chunk(g, d_pairs + 2 * off, cnt, hop, flags, res,
-                           d_out_pi ? d_out_pi + (size_t)off * res * res : nullptr,
-                           d_out_status ? d_out_status + off : nullptr,
-                           d_ids_off ? d_ids_off + off : nullptr, d_out_ids, d_out_f,
-                           d_out_n ? d_out_n + off : nullptr, d_edge_offs ? d_edge_offs + off : nullptr, d_out_edges,
-                           d_out_m ? d_out_m + off : nullptr, pi_enabled, s);
+        Workspace* ws = nullptr;
+        int rc = acquire_workspace(g, &ws, inline_main);
         if (rc != TLC_OK) return rc;
-        if (off + TLC_CHUNK_PAIRS < n_pairs) {
-            // the arena and the headers are reused by the next chunk
-            TLC_HIP_CHECK(hipStreamSynchronize(s));
-            TLC_HIP_CHECK(hipMemcpy(g->h_sync->stats, g->d_stats, sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            g->last_stats[5] += (long long)g->h_sync->stats[0];
+        hipStream_t m = inline_main ? s : ws->main;
+        if (!inline_main) {
+            TLC_HIP_CHECK(hipEventRecord(ws->ev_in, s));
+            TLC_HIP_CHECK(hipStreamWaitEvent(m, ws->ev_in, 0));
         }
+        // NOTE: ids_off is indexed by the global pair index, the kernels index by chunk-local index
+        rc = run_chunk(g, ws, d_pairs + 2 * off, cnt, hop, flags, res,
+                       d_out_pi ? d_out_pi + (size_t)off * res * res : nullptr,
+                       d_out_status ? d_out_status + off : nullptr,
+                       d_ids_off ? d_ids_off + off : nullptr, d_out_ids, d_out_f,
+                       d_out_n ? d_out_n + off : nullptr, d_edge_offs ? d_edge_offs + off : nullptr, d_out_edges,
+                       d_out_m ? d_out_m + off : nullptr, pi_enabled, m);
+        if (rc != TLC_OK) return rc;
+        TLC_HIP_CHECK(hipEventRecord(ws->ev_done, m));
+        ws->busy = 1; ws->in_call = 1; ws->n_pairs = cnt;
+        g->last_ws = ws;
     }
+    if (join && !inline_main)
+        for (int k = 0; k < TLC_N_WS; ++k)
+            if (g->ws[k].busy) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ws[k].ev_done, 0));
     return TLC_OK;
 }
 
@@ -941,7 +1064,31 @@ extern "C" int tlc_pd_pi_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_p
         return TLC_ERR_UNSUPPORTED;
     }
     return run_batch(g, d_pairs, n_pairs, hop, flags, res, d_out_pi, d_out_status, nullptr, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, 1, stream);
+                     nullptr, nullptr, 1, stream, true);
+}
+
+// tlc_pd_pi_batch without the final join: the batch is ordered AFTER what `stream` holds at the time of the call (its inputs may
+// be produced there), but `stream` does not wait for it -- batches submitted back to back overlap, each on one of the handle's
+// workspaces.  Outputs are complete for work that follows a tlc_pd_pi_batch_join on its stream.  At most two batches run ahead
+// of the GPU: submitting a third waits on the host for the first.
+extern "C" int tlc_pd_pi_batch_async(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags, int res,
+                                     double* d_out_pi, uint8_t* d_out_status, void* stream) {
+    TLC_REQUIRE(n_pairs == 0 || d_out_pi != nullptr, "out_pi is null");
+    if (flags & TLC_NO_NORM) {
+        tlc_set_error("tlc_pd_pi_batch_async: TLC_NO_NORM is not supported by the fused image stage");
+        return TLC_ERR_UNSUPPORTED;
+    }
+    return run_batch(g, d_pairs, n_pairs, hop, flags, res, d_out_pi, d_out_status, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, 1, stream, false);
+}
+
+// makes `stream` wait for every batch submitted on this handle so far (asynchronous: nothing is waited for on the host)
+extern "C" int tlc_pd_pi_batch_join(tlc_graph* g, void* stream) {
+    TLC_REQUIRE(g != nullptr, "graph handle is null");
+    TLC_ON_DEVICE(g->device);
+    for (int k = 0; k < TLC_N_WS; ++k)
+        if (g->ws[k].busy) TLC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, g->ws[k].ev_done, 0));
+    return TLC_OK;
 }
 
 extern "C" int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags,
@@ -952,16 +1099,24 @@ extern "C" int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int
     const int ne = (d_edge_offs != nullptr) + (d_out_edges != nullptr) + (d_out_m != nullptr);
     TLC_REQUIRE(ne == 0 || ne == 3, "edge_offs / out_edges / out_m must be given together");
     return run_batch(g, d_pairs, n_pairs, hop, flags, 5, nullptr, d_out_status, d_node_offs, d_out_ids, d_out_f, d_out_n,
-                     d_edge_offs, d_out_edges, d_out_m, 0, stream);
+                     d_edge_offs, d_out_edges, d_out_m, 0, stream, true);
 }
 
 extern "C" int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream) {
     TLC_REQUIRE(g && h_out, "null argument");
     TLC_ON_DEVICE(g->device);
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    TLC_HIP_CHECK(hipMemcpy(g->h_sync->stats, g->d_stats, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    long long tie = g->acc_tie;
+    for (int k = 0; k < TLC_N_WS; ++k) {
+        Workspace* ws = &g->ws[k];
+        if (!ws->in_call) continue;
+        if (ws->busy) { TLC_HIP_CHECK(hipEventSynchronize(ws->ev_done)); ws->busy = 0; }   // (an asynchronous call not joined yet)
+        unsigned long long v = 0;
+        TLC_HIP_CHECK(hipMemcpy(&v, ws->d_stats, sizeof(v), hipMemcpyDeviceToHost));
+        tie += (long long)v;
+    }
     for (int k = 0; k < 10; ++k) h_out[k] = g->last_stats[k];
-    h_out[5] += (long long)g->h_sync->stats[0];
+    h_out[5] += tie;
     return TLC_OK;
 }
 
@@ -1045,13 +1200,13 @@ extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long l
     return TLC_OK;
 }
 
-// diagnostics (PHASE_DEBUG builds): wall-clock stamps (100 MHz ticks) of the extraction per pair of the last chunk, [n][4]
+// diagnostics (PHASE_DEBUG builds): wall-clock stamps (100 MHz ticks) of the extraction per pair of the last chunk, [n][8]
 extern "C" int tlc_debug_pair_times(tlc_graph* g, unsigned long long* h_out, int64_t n_pairs) {
     TLC_REQUIRE(g && h_out, "null argument");
     TLC_ON_DEVICE(g->device);
     TLC_HIP_CHECK(hipDeviceSynchronize());
     const size_t k = std::min<size_t>((size_t)std::max<int64_t>(n_pairs, 0), g->d_pair_t ? g->cap_pair_t : 0);
-    if (k) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_pair_t, k * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (k) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_pair_t, k * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return TLC_OK;
 }
 
@@ -1064,6 +1219,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     if (!strcmp(name, "extract")) g->opt_extract = value != 0;
     else if (!strcmp(name, "heavy")) g->opt_heavy = value != 0;
     else if (!strcmp(name, "tiny")) g->opt_tiny = value != 0;
+    else if (!strcmp(name, "tier_mask")) g->opt_tier_mask = value;
     else if (!strcmp(name, "x_region")) g->opt_x_region = std::max(value, 0);
     else if (!strcmp(name, "x_bump_min")) g->opt_x_bump_min = std::max(value, 0);
     else { tlc_set_error("tlc_debug_set_option: unknown option '%s'", name); return TLC_ERR_INVALID_ARG; }
@@ -1076,8 +1232,11 @@ extern "C" int tlc_debug_dc_stats(tlc_graph* g, long long* h_out, void* stream) 
     TLC_REQUIRE(g && h_out, "null argument");
     TLC_ON_DEVICE(g->device);
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    unsigned long long v[4];
-    TLC_HIP_CHECK(hipMemcpy(v, g->d_stats, sizeof(v), hipMemcpyDeviceToHost));
+    unsigned long long v[4] = {0, 0, 0, 0};
+    if (g->last_ws) {
+        if (g->last_ws->busy) { TLC_HIP_CHECK(hipEventSynchronize(g->last_ws->ev_done)); g->last_ws->busy = 0; }
+        TLC_HIP_CHECK(hipMemcpy(v, g->last_ws->d_stats, sizeof(v), hipMemcpyDeviceToHost));
+    }
     h_out[0] = (long long)v[1];
     h_out[1] = (long long)v[3];
     return TLC_OK;
@@ -1140,9 +1299,10 @@ extern "C" int tlc_pd_pi_batch_sizes(tlc_graph* g, int32_t* h_n, int32_t* h_m2, 
     TLC_ON_DEVICE(g->device);
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     const size_t k = (size_t)std::min<int64_t>(cap, g->last_n_pairs);
-    if (k) {
-        TLC_HIP_CHECK(hipMemcpy(h_n, g->hdr_n, k * sizeof(int), hipMemcpyDeviceToHost));
-        TLC_HIP_CHECK(hipMemcpy(h_m2, g->hdr_m2, k * sizeof(int), hipMemcpyDeviceToHost));
+    if (k && g->last_ws) {
+        if (g->last_ws->busy) { TLC_HIP_CHECK(hipEventSynchronize(g->last_ws->ev_done)); g->last_ws->busy = 0; }
+        TLC_HIP_CHECK(hipMemcpy(h_n, g->last_ws->hdr_n, k * sizeof(int), hipMemcpyDeviceToHost));
+        TLC_HIP_CHECK(hipMemcpy(h_m2, g->last_ws->hdr_m2, k * sizeof(int), hipMemcpyDeviceToHost));
     }
     return TLC_OK;
 }

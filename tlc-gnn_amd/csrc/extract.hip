@@ -71,6 +71,48 @@ __device__ __forceinline__ bool x_member(const XState& X, int y, int& ly) {
     ly = (int)X.pref[y >> 5] + __popc(word & (bit - 1u));
     return true;
 }
+// a member's node record in registers (one 64-byte line: four 16-byte loads).  Scalars only: a struct with arrays that is
+// assigned as a whole goes through scratch memory.
+struct XRec {
+    int rb, deg, hidx, n_in;
+    int c0, c1, c2, c3;
+    double w0, w1, w2, w3;
+    __device__ __forceinline__ int c(int q) const { return q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3)); }
+    __device__ __forceinline__ double w(int q) const { return q == 0 ? w0 : (q == 1 ? w1 : (q == 2 ? w2 : w3)); }
+};
+__device__ __forceinline__ XRec x_empty_rec() {
+    XRec R;
+    R.rb = R.deg = R.n_in = 0; R.hidx = -1;
+    R.c0 = R.c1 = R.c2 = R.c3 = 0;
+    R.w0 = R.w1 = R.w2 = R.w3 = 0.0;
+    return R;
+}
+__device__ __forceinline__ XRec x_load_rec(const TlcNodeRec* r) {
+    XRec R;
+    const TlcI4 h = *reinterpret_cast<const TlcI4*>(r), c = *reinterpret_cast<const TlcI4*>(&r->col[0]);
+    const TlcD2 wa = *reinterpret_cast<const TlcD2*>(&r->w[0]), wb = *reinterpret_cast<const TlcD2*>(&r->w[2]);
+    R.rb = h.v[0]; R.deg = h.v[1]; R.hidx = h.v[2]; R.n_in = h.v[3];
+    R.c0 = c.v[0]; R.c1 = c.v[1]; R.c2 = c.v[2]; R.c3 = c.v[3];
+    R.w0 = wa.v[0]; R.w1 = wa.v[1]; R.w2 = wb.v[0]; R.w3 = wb.v[1];
+    return R;
+}
+
+// Workgroup-wide ordering of LDS traffic.  A single wavefront executes its LDS instructions in issue order, so it needs neither
+// a barrier nor -- what __syncthreads() also costs -- an s_waitcnt vmcnt(0): the global stores of one pair's entries would be
+// waited for (0.7 us under load) at every synchronisation point of the next one.  Only the compiler must keep the order.
+template <int BW>
+__device__ __forceinline__ void x_sync() {
+    if (BW == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+// arena entries are written once and read once, by another kernel: stored past the caches' allocation policy so that the
+// graph's arrays (ball lists, rows, weights: 6 MB against a 4 MB L2 per XCD) are not evicted by 37 MB of output per batch
+template <typename T>
+__device__ __forceinline__ void x_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ bool x_heavy(const XState& X, int ly) { return (X.hvy[ly >> 5] >> (ly & 31)) & 1u; }
 
 // One sweep over the rows of the members ids[0..n): every directed entry of the induced subgraph exactly once, as
@@ -87,20 +129,66 @@ __device__ __forceinline__ bool x_heavy(const XState& X, int ly) { return (X.hvy
 // count of every unit.  Returns the entries this wavefront counted.
 template <int BW, bool WR>
 __device__ __forceinline__ int x_sweep_wave(const TlcVicParams& p, const int* ids, int n, const XState& X, bool use_hvy, int nH,
-                                            unsigned* dir, double* lw, int cap, int* ucnt) {
+                                            unsigned* dir, double* lw, int cap, int* ucnt, const XRec pre, bool has_pre, int dbg_i = -1) {
     const int lane = tlc_lane(), wv = (int)(threadIdx.x >> 6);
     constexpr int NW = BW / 64;
     int run = 0, counted = 0;
+#ifdef TLC_PAIR_TIMES
+#define SSTAMP(k) do { if (WR && dbg_i >= 0 && p.dbg_pair_t && threadIdx.x == 0) p.dbg_pair_t[16 * (size_t)dbg_i + (k)] = wall_clock64(); } while (0)
+#else
+#define SSTAMP(k) do { } while (0)
+#endif
+    SSTAMP(8);
     const int nb = (n + 63) >> 6;
     for (int b = wv; b < nb; b += NW) {
         if (NW > 1) { if (WR) run = ucnt[b]; else run = 0; }
         const int k = (b << 6) + lane;
         const bool act = k < n;
-        int rb = 0, re = 0;
-        if (act && !(use_hvy && x_heavy(X, k))) row_bounds(p.rowptr, ids[k], rb, re);
+        // the member's node record: row start, degree and its first four entries in one 64-byte line (most nodes have no more);
+        // batch 0 of a single wavefront arrives with it (loaded when the member bits were set)
+        int rb = 0, re = 0, n_in = 0;
+        XRec R = x_empty_rec();
+        if (act && !(use_hvy && x_heavy(X, k))) {
+            if (has_pre && b == 0) R = pre; else R = x_load_rec(p.nrec + ids[k]);
+            rb = R.rb; re = rb + R.deg; n_in = R.n_in;
+        }
         const bool big = (re - rb) >= 32;
-        // ---- short rows: a lane scans its own row, eight entries per round trip -------------------------------------
-        int j0 = big ? re : rb;
+        // ---- short rows, round 0: the entries held in the record --------------------------------------------------------
+        {
+            int ly[4];
+            unsigned hit = 0u, rev = 0u;
+            if (!big) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ly[q] = 0;
+                    if (q < n_in && x_member(X, R.c(q), ly[q])) {
+                        hit |= 1u << q;
+                        if (use_hvy && x_heavy(X, ly[q])) rev |= 1u << q;
+                    }
+                }
+            }
+            const int cnt = __popc(hit) + __popc(rev);
+            const int incl = tlc_wave_iscan_i32(cnt);
+            int off = run + incl - cnt;
+            run += __builtin_amdgcn_readlane(incl, 63);
+            if (WR && cnt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((hit >> q) & 1u) {
+                        const double wq = R.w(q);
+                        if (off < cap) { x_store(&dir[off], ((unsigned)k << 16) | (unsigned)ly[q]); x_store(&lw[off], wq); }
+                        ++off;
+                        if ((rev >> q) & 1u) {
+                            if (off < cap) { x_store(&dir[off], ((unsigned)ly[q] << 16) | (unsigned)k); x_store(&lw[off], wq); }
+                            ++off;
+                        }
+                    }
+                }
+            }
+        }
+        SSTAMP(10);
+        // ---- short rows beyond the record: a lane scans the rest of its own row, eight entries and weights per round trip ----
+        int j0 = big ? re : rb + n_in;
         while (__any(j0 < re)) {
             int bb[8], ly[8];
             double ww[8];
@@ -125,10 +213,10 @@ __device__ __forceinline__ int x_sweep_wave(const TlcVicParams& p, const int* id
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if ((hit >> q) & 1u) {
-                        if (off < cap) { dir[off] = ((unsigned)k << 16) | (unsigned)ly[q]; lw[off] = ww[q]; }
+                        if (off < cap) { x_store(&dir[off], ((unsigned)k << 16) | (unsigned)ly[q]); x_store(&lw[off], ww[q]); }
                         ++off;
                         if ((rev >> q) & 1u) {
-                            if (off < cap) { dir[off] = ((unsigned)ly[q] << 16) | (unsigned)k; lw[off] = ww[q]; }
+                            if (off < cap) { x_store(&dir[off], ((unsigned)ly[q] << 16) | (unsigned)k); x_store(&lw[off], ww[q]); }
                             ++off;
                         }
                     }
@@ -136,6 +224,7 @@ __device__ __forceinline__ int x_sweep_wave(const TlcVicParams& p, const int* id
             }
             j0 += 8;
         }
+        SSTAMP(11);
         // ---- long scanned rows (a root that is a hub; a high degree outside the heavy set): the wavefront streams the row,
         //      four 64-entry chunks in flight ---------------------------------------------------------------------------
         unsigned long long mask = __ballot(act && big);
@@ -162,11 +251,12 @@ __device__ __forceinline__ int x_sweep_wave(const TlcVicParams& p, const int* id
                     const unsigned long long m1 = __ballot(h), m2 = __ballot(rv);
                     const int c1 = __popcll(m1);
                     if (WR && h) {
+                        const double wq = wvv[r];
                         const int o1 = run + __popcll(m1 & tlc_lanemask_lt());
-                        if (o1 < cap) { dir[o1] = ((unsigned)kk << 16) | (unsigned)l; lw[o1] = wvv[r]; }
+                        if (o1 < cap) { x_store(&dir[o1], ((unsigned)kk << 16) | (unsigned)l); x_store(&lw[o1], wq); }
                         if (rv) {
                             const int o2 = run + c1 + __popcll(m2 & tlc_lanemask_lt());
-                            if (o2 < cap) { dir[o2] = ((unsigned)l << 16) | (unsigned)kk; lw[o2] = wvv[r]; }
+                            if (o2 < cap) { x_store(&dir[o2], ((unsigned)l << 16) | (unsigned)kk); x_store(&lw[o2], wq); }
                         }
                     }
                     run += c1 + __popcll(m2);
@@ -177,6 +267,7 @@ __device__ __forceinline__ int x_sweep_wave(const TlcVicParams& p, const int* id
             if (!WR) { if (lane == 0) ucnt[b] = run; counted += run; }
         }
     }
+    SSTAMP(12);
     // ---- heavy x heavy: ordered pairs of listed heavy members through the dense weight table (0 = not adjacent) ------------
     if (use_hvy && nH > 0) {
         const int np = nH * nH, nc = (np + 63) >> 6;
@@ -193,26 +284,28 @@ __device__ __forceinline__ int x_sweep_wave(const TlcVicParams& p, const int* id
             const unsigned long long m1 = __ballot(h);
             if (WR && h) {
                 const int o1 = run + __popcll(m1 & tlc_lanemask_lt());
-                if (o1 < cap) { dir[o1] = ((ea >> 16) << 16) | (eb >> 16); lw[o1] = w; }
+                if (o1 < cap) { x_store(&dir[o1], ((ea >> 16) << 16) | (eb >> 16)); x_store(&lw[o1], w); }
             }
             run += __popcll(m1);
             if (NW > 1 && !WR) { if (lane == 0) ucnt[nb + c] = run; counted += run; }
         }
     }
+    SSTAMP(13);
+#undef SSTAMP
     return NW > 1 ? counted : run;
 }
 
 // The sweep of a workgroup; dir may be null (count only).  Returns the number of entries (uniform over the workgroup).
 template <int BW>
 __device__ __forceinline__ int x_sweep(const TlcVicParams& p, const int* ids, int n, const XState& X, bool use_hvy, int nH,
-                                       unsigned* dir, double* lw, int cap) {
+                                       unsigned* dir, double* lw, int cap, const XRec pre, bool has_pre, int dbg_i = -1) {
     if (BW == 64) {
-        if (dir) return x_sweep_wave<BW, true>(p, ids, n, X, use_hvy, nH, dir, lw, cap, nullptr);
-        return x_sweep_wave<BW, false>(p, ids, n, X, use_hvy, nH, nullptr, nullptr, 0, nullptr);
+        if (dir) return x_sweep_wave<BW, true>(p, ids, n, X, use_hvy, nH, dir, lw, cap, nullptr, pre, has_pre, dbg_i);
+        return x_sweep_wave<BW, false>(p, ids, n, X, use_hvy, nH, nullptr, nullptr, 0, nullptr, pre, has_pre);
     }
     int* ucnt = X.ucnt;
-    x_sweep_wave<BW, false>(p, ids, n, X, use_hvy, nH, nullptr, nullptr, 0, ucnt);
-    __syncthreads();
+    x_sweep_wave<BW, false>(p, ids, n, X, use_hvy, nH, nullptr, nullptr, 0, ucnt, pre, false);
+    x_sync<BW>();
     // exclusive prefix over the units (at most TLC_X_UNITS of them), a few consecutive units per thread
     const int nu = ((n + 63) >> 6) + ((use_hvy && nH > 0) ? ((nH * nH + 63) >> 6) : 0);
     const int per = (nu + BW - 1) / BW;
@@ -222,9 +315,9 @@ __device__ __forceinline__ int x_sweep(const TlcVicParams& p, const int* ids, in
     int total = 0;
     int off = block_escan_i32<BW>(mine, X.xw, &total);
     for (int q = 0; q < per; ++q) if (u0 + q < nu) { const int c = ucnt[u0 + q]; ucnt[u0 + q] = off; off += c; }
-    __syncthreads();
-    if (dir) x_sweep_wave<BW, true>(p, ids, n, X, use_hvy, nH, dir, lw, cap, ucnt);
-    __syncthreads();
+    x_sync<BW>();
+    if (dir) x_sweep_wave<BW, true>(p, ids, n, X, use_hvy, nH, dir, lw, cap, ucnt, pre, false);
+    x_sync<BW>();
     return total;
 }
 
@@ -258,7 +351,7 @@ __device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool 
     const int tid = threadIdx.x;
 #ifdef TLC_PAIR_TIMES
     // (per-pair wall-clock stamps only: sums through global atomics on one address would serialise the whole kernel)
-#define XSTAMP(k) do { if (p.dbg_pair_t && tid == 0 && (k) != 1) p.dbg_pair_t[4 * (size_t)i + ((k) == 0 ? 1 : (k))] = wall_clock64(); } while (0)
+#define XSTAMP(k) do { if (p.dbg_pair_t && tid == 0) p.dbg_pair_t[16 * (size_t)i + (k)] = wall_clock64(); } while (0)
 #else
 #define XSTAMP(k) do { } while (0)
 #endif
@@ -299,7 +392,7 @@ __device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool 
         return;
     }
 #ifdef TLC_PAIR_TIMES
-    if (p.dbg_pair_t && tid == 0) p.dbg_pair_t[4 * (size_t)i] = t_start;
+    if (p.dbg_pair_t && tid == 0) { p.dbg_pair_t[16 * (size_t)i] = t_start; p.dbg_pair_t[16 * (size_t)i + 1] = wall_clock64(); }
 #endif
     if (a1 - a0 < b1 - b0) { int t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; }    // [a0,a1): the larger ball
     const int nA = a1 - a0, nB = b1 - b0;
@@ -318,7 +411,8 @@ __device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool 
         for (int r = 0; r < 4; ++r) if (av[r] >= 0) atomicOr(&X.bits[av[r] >> 5], 1u << (av[r] & 31));
     }
     if (tid == 0) { X.ctl[0] = -1; X.ctl[1] = -1; }
-    __syncthreads();
+    x_sync<BW>();
+    XSTAMP(2);
     const int capg = p.n_nodes < TLC_MAX_SUBGRAPH_NODES + 1 ? p.n_nodes : TLC_MAX_SUBGRAPH_NODES + 1;
     int* ids = nB <= SID_CAP ? sid : slot;
     const int cap_ids = nB <= SID_CAP ? SID_CAP : capg;
@@ -352,33 +446,38 @@ __device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool 
             n += tot;
         }
     }
-    __syncthreads();
+    x_sync<BW>();
+    XSTAMP(3);
     // the marks of the larger ball go (by list when that is the shorter way)
-    if (nA * 8 < nw4) {
+    if (nw4 > 4096 && nA * 8 < nw4) {                     // (re-reading the list is a global round trip: only for a large bitmap)
         for (int j = tid; j < nA; j += BW) X.bits[p.bcol[a0 + j] >> 5] = 0u;
     } else {
         uint4* z = reinterpret_cast<uint4*>(X.bits);
         for (int w = tid; w < nw4 / 4; w += BW) z[w] = make_uint4(0u, 0u, 0u, 0u);
     }
     const int lu = X.ctl[0], lv = X.ctl[1];
-    __syncthreads();
-    XSTAMP(0);
+    x_sync<BW>();
+    XSTAMP(4);
     if (n == 0 || n > TLC_MAX_SUBGRAPH_NODES) {
         // n == 0: AssertionError, zero connected components (:318).  n > 65535 does not fit the packed local ids: its own status
         x_zero_row<BW>(p, i, n == 0 ? TLC_ST_DISCONNECTED : TLC_ST_TOO_LARGE, n == 0 ? 0 : -n, lu, lv);
         return;
     }
     // ---- member bits, the rank of the first member of every touched bitmap word, heavy members ------------------------------
-    const bool heavy_ok = p.hidx != nullptr && n <= TLC_X_HV_CAP;
+    const bool heavy_ok = p.hh_k > 0 && n <= TLC_X_HV_CAP;
     if (heavy_ok) for (int w = tid; w < TLC_X_HV_CAP / 32; w += BW) X.hvy[w] = 0u;
-    __syncthreads();
+    x_sync<BW>();
     int nH = 0;
+    XRec rec0 = x_empty_rec();
     for (int base = 0; base < n; base += BW) {
         const int k = base + tid;
         int hi = -1;
         if (k < n) {
             const int x = ids[k];
-            if (heavy_ok && x != u && x != v) hi = p.hidx[x];
+            if (BW == 64 && base == 0) {                       // (kept for the sweep)
+                rec0 = x_load_rec(p.nrec + x);
+                if (heavy_ok && x != u && x != v) hi = rec0.hidx;
+            } else if (heavy_ok && x != u && x != v) hi = p.nrec[x].hidx;
             const int w = x >> 5;
             atomicOr(&X.bits[w], 1u << (x & 31));
             if (k == 0 || (ids[k - 1] >> 5) != w) X.pref[w] = (unsigned short)k;
@@ -399,15 +498,15 @@ __device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool 
             nH += tot;
         }
     }
-    __syncthreads();
+    x_sync<BW>();
     const bool use_hvy = heavy_ok && nH <= TLC_X_H_CAP;      // (more heavy members than the list holds: every row is scanned)
-    XSTAMP(1);
+    XSTAMP(5);
     if (p.x_fill) {
         const long long eo = p.edge_off[i];
-        x_sweep<BW>(p, ids, n, X, use_hvy, nH, p.A_dir + eo, p.A_lw + eo, fill_m2);
-        __syncthreads();
+        x_sweep<BW>(p, ids, n, X, use_hvy, nH, p.A_dir + eo, p.A_lw + eo, fill_m2, rec0, BW == 64);
+        x_sync<BW>();
         for (int k = tid; k < n; k += BW) X.bits[ids[k] >> 5] = 0u;
-        __syncthreads();
+        x_sync<BW>();
         return;
     }
     // ---- induced subgraph (graph.subgraph(nodes), :316): one sweep, written at the cursor of this workgroup's arena region ----
@@ -422,13 +521,13 @@ __device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool 
         const long long nn = (long long)n * n;
         cap = nn < 2 * TLC_M_MMAX ? (int)nn : 2 * TLC_M_MMAX;
         if (cur[1] - cur[0] < cap) {                     // (uniform: LDS state)
-            __syncthreads();
+            x_sync<BW>();
             if (tid == 0) {
                 long long off = p.bump_base + (long long)atomicAdd(p.bump_top, (unsigned long long)TLC_X_BLOCK);
                 if (off + TLC_X_BLOCK > p.bump_cap) { off = -1; atomicAdd(p.bump_overflow, 1); }
                 cur[0] = off; cur[1] = off < 0 ? -1 : off + TLC_X_BLOCK;
             }
-            __syncthreads();
+            x_sync<BW>();
         }
         at = cur[1] - cur[0] >= cap ? cur[0] : -1;
         if (at >= 0) { wdir = p.A_dir + at; wlw = p.A_lw + at; } else cap = 0;
@@ -437,7 +536,7 @@ __device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool 
     if (!wdir && early_large_ok && n > TLC_M_NMAX) {
         // early pass: a vicinity beyond the MEDIUM tier takes a slot of the early arena and is written right away
         if (tid == 0) X.ctl[4] = atomicAdd(p.early_count, 1);
-        __syncthreads();
+        x_sync<BW>();
         es = X.ctl[4];
         if (es < p.early_cap) {
             wdir = p.early_dir + (size_t)es * (2 * TLC_L_MMAX);
@@ -445,8 +544,8 @@ __device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool 
             cap = 2 * TLC_L_MMAX;
         }
     }
-    const int m2 = x_sweep<BW>(p, ids, n, X, use_hvy, nH, wdir, wlw, cap);
-    XSTAMP(2);
+    const int m2 = x_sweep<BW>(p, ids, n, X, use_hvy, nH, wdir, wlw, cap, rec0, BW == 64, i);
+    XSTAMP(6);
     const int m = m2 >> 1;
     if (m > TLC_MAX_SUBGRAPH_EDGES) {                     // edge ranks are packed in 24 bits (pd_pipeline.hip, cycle swap)
         x_zero_row<BW>(p, i, TLC_ST_TOO_LARGE, -n, lu, lv);
@@ -460,11 +559,11 @@ __device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool 
         } else if (n <= TLC_M_NMAX && m > TLC_M_MMAX && early_large_ok && m <= TLC_L_MMAX) {
             // few nodes, many edges: beyond the MEDIUM tier by its edge count only -- swept again into an early slot
             if (tid == 0) X.ctl[4] = atomicAdd(p.early_count, 1);
-            __syncthreads();
+            x_sync<BW>();
             es = X.ctl[4];
             if (es < p.early_cap) {
                 x_sweep<BW>(p, ids, n, X, use_hvy, nH, p.early_dir + (size_t)es * (2 * TLC_L_MMAX),
-                            p.early_lw + (size_t)es * (2 * TLC_L_MMAX), 2 * TLC_L_MMAX);
+                            p.early_lw + (size_t)es * (2 * TLC_L_MMAX), 2 * TLC_L_MMAX, rec0, BW == 64);
                 if (tid == 0) p.early_list[es] = i;
             }
         } else if (es >= 0 && es < p.early_cap) {
@@ -474,17 +573,20 @@ __device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool 
         }
     }
     // ---- the member bits go, by list -----------------------------------------------------------------------------------------
-    __syncthreads();
+    x_sync<BW>();
     for (int k = tid; k < n; k += BW) X.bits[ids[k] >> 5] = 0u;
-    __syncthreads();
-    XSTAMP(3);
+    x_sync<BW>();
+    XSTAMP(7);
 #undef XSTAMP
 }
 
 }  // namespace
 
+#ifndef TLC_X_WPE
+#define TLC_X_WPE 4
+#endif
 template <int BW>
-__global__ __launch_bounds__(BW) void tlc_extract_kernel(TlcVicParams p) {
+__global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kernel(TlcVicParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xlds[];
     int* slot = p.scratch + (size_t)(p.scratch_base_slot + blockIdx.x) * p.scratch_stride;
     {

@@ -40,6 +40,14 @@
 #define TLC_L_THREADS 512   /* 1024 measured slower (0.99 vs 0.94 ms): barriers over 16 wavefronts, 128-VGPR cap */
 #define TLC_HUGE_MIN_TABLE 16384  /* bytes reserved for the image table in a HUGE scratch slot */
 
+// Node record of tlc_extract_kernel (extract.hip): what a sweep needs of a member node in ONE 64-byte line -- where its CSR row
+// starts, its degree, its index in the heavy set (or -1) and its first four entries (n_in = min(degree, 4) of them)
+struct __attribute__((aligned(64))) TlcNodeRec {
+    int row_start, deg, hidx, n_in;
+    int col[4];
+    double w[4];
+};
+
 struct TlcVicParams {
     // graph (device CSR)
     int n_nodes;
@@ -102,11 +110,11 @@ struct TlcVicParams {
     unsigned* small_dir;
     double* small_lw;
     unsigned long long* dbg;   // PHASE_DEBUG builds: per-phase cycle sums of the COUNT pass (null otherwise)
-    unsigned long long* dbg_pair_t;   // PHASE_DEBUG builds: [n_pairs][4] wall clock (100 MHz) at start / S known / swept / end of a pair
+    unsigned long long* dbg_pair_t;   // PAIR_TIMES builds: [n_pairs][16] wall-clock stamps (100 MHz) along a pair's way through tlc_extract_kernel
     // ---- tlc_extract_kernel (extract.hip; hop <= 2): precomputed structure of the graph ---------------------------------------
     const int* bptr;            // [n_nodes + 1] ball lists: ball_hop(x) = bcol[bptr[x] .. bptr[x+1]), ascending ids, x included
     const int* bcol;
-    const int* hidx;            // [n_nodes] index of a HEAVY node (one of the hh_k highest degrees >= 32) or -1; null: none
+    const TlcNodeRec* nrec;     // [n_nodes] node records; hidx = index of a HEAVY node (one of the hh_k highest degrees >= 32) or -1
     const double* hh_w;         // [hh_k][hh_k] weight of the entry a -> b between heavy nodes, 0 = not adjacent
     int hh_k;
     // main pass beside an early pass: a pair whose smaller ball has at least skip_threshold nodes belongs to the early pass as

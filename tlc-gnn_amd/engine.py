@@ -32,6 +32,7 @@ class DeviceGraph:
                                          C.c_int(self.device), C.byref(h))
         _lib.check(rc, "tlc_graph_create")
         self._h = h
+        self._inflight = []
 
     def close(self):
         if getattr(self, "_h", None):
@@ -45,8 +46,10 @@ class DeviceGraph:
             pass
 
     # ---- P2-P9 -------------------------------------------------------------------------------------------
-    def pd_pi_batch(self, pairs, hop, flags=0, res=5, out=None, status=None):
-        """pairs: int32 CUDA tensor [E,2] -> (pi float64[E,res*res], status uint8[E]) on the current stream."""
+    def pd_pi_batch(self, pairs, hop, flags=0, res=5, out=None, status=None, async_=False):
+        """pairs: int32 CUDA tensor [E,2] -> (pi float64[E,res*res], status uint8[E]) on the current stream.
+        async_: submit without making the current stream wait (tlc_pd_pi_batch_async): batches submitted back to back overlap;
+        the outputs are complete for work that follows join() on its stream."""
         import torch
         assert pairs.is_cuda and pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2
         assert pairs.device.index == self.device, "pairs live on cuda:%s, the graph on cuda:%d" % (pairs.device.index, self.device)
@@ -56,10 +59,18 @@ class DeviceGraph:
             out = torch.empty((E, res * res), dtype=torch.float64, device=pairs.device)
         if status is None:
             status = torch.empty((E,), dtype=torch.uint8, device=pairs.device)
-        rc = _lib.lib().tlc_pd_pi_batch(self._h, _lib.ptr(pairs), C.c_int64(E), C.c_int(hop), C.c_uint32(flags),
-                                        C.c_int(res), _lib.ptr(out), _lib.ptr(status), _lib.stream_ptr(self.device))
+        fn = _lib.lib().tlc_pd_pi_batch_async if async_ else _lib.lib().tlc_pd_pi_batch
+        rc = fn(self._h, _lib.ptr(pairs), C.c_int64(E), C.c_int(hop), C.c_uint32(flags),
+                C.c_int(res), _lib.ptr(out), _lib.ptr(status), _lib.stream_ptr(self.device))
         _lib.check(rc, "tlc_pd_pi_batch")
+        if async_:
+            self._inflight.append((pairs, out, status))          # (the buffers of a batch in flight must stay alive)
+            del self._inflight[:-4]
         return out, status
+
+    def join(self):
+        """The current stream waits for every batch submitted with async_=True (nothing is waited for on the host)."""
+        _lib.check(_lib.lib().tlc_pd_pi_batch_join(self._h, _lib.stream_ptr(self.device)), "tlc_pd_pi_batch_join")
 
     def stats(self):
         out = (C.c_int64 * 10)()

@@ -33,7 +33,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
     d["active_valu_share"] = v.get("SQ_ACTIVE_INST_VALU", 0) / wc
     d["lds_conflict_share"] = v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_LDS_IDX_ACTIVE", 0), 1)
     out[k] = d
-json.dump(out, open("gpurun_out/r02_pmc_issue.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/pmc_issue_now.json", "w"), indent=1)
 for k, d in list(out.items())[1:12]:
     print("%-70s wait %.2f stall %.2f active %.2f (lds %.2f valu %.2f) lds-conflict %.2f" % (k, d["wait_share"], d["issue_stall_share"], d["active_share"], d["active_lds_share"], d["active_valu_share"], d["lds_conflict_share"]))
 PY

@@ -14,7 +14,7 @@ L.tlc_debug_phase_profile(g._h, 1, None, 0, None)
 g.pd_pi_batch(pairs, 2)
 torch.cuda.synchronize()
 E = len(W["pi_pairs"])
-buf = np.zeros((E, 4), dtype=np.uint64)
+buf = np.zeros((E, 16), dtype=np.uint64)
 L.tlc_debug_pair_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 L.tlc_debug_pair_times(g._h, buf.ctypes.data_as(C.c_void_p), E)
 n, m2 = g.sizes(E)
@@ -25,22 +25,28 @@ c = a[3]
 t = buf.astype(np.float64) / 100.0                                  # us
 ok = t[:, 0] > 0
 t0 = t[ok, 0].min()
-print("pairs stamped %d of %d; kernel span %.1f us" % (ok.sum(), E, t[ok, 3].max() - t0))
-dur = t[:, 3] - t[:, 0]
+print("pairs stamped %d of %d; kernel span %.1f us" % (ok.sum(), E, t[ok, 7].max() - t0))
+dur = t[:, 7] - t[:, 0]
 for name, sel in (("n<=16", ok & (n <= 16)), ("16<n<=64", ok & (n > 16) & (n <= 64)), ("64<n<=128", ok & (n > 64) & (n <= 128)), ("128<n<=512", ok & (n > 128) & (n <= 512)), ("n>512", ok & (n > 512))):
     if sel.sum():
         d = dur[sel]
-        print("%-12s %6d pairs  mean %.1f us  p50 %.1f  p99 %.1f  max %.1f | S %.1f  sweep %.1f  rest %.1f   sum %.0f us" % (
-            name, sel.sum(), d.mean(), np.median(d), np.percentile(d, 99), d.max(), (t[sel, 1] - t[sel, 0]).mean(), (t[sel, 2] - t[sel, 1]).mean(),
-            (t[sel, 3] - t[sel, 2]).mean(), d.sum()))
+        seg = [(t[sel, k + 1] - t[sel, k]).mean() for k in range(7)]
+        print("%-12s %6d pairs  mean %.1f us  p50 %.1f  p99 %.1f  max %.1f | bounds %.1f  lists+mark %.1f  filter %.1f  unmark %.1f  member bits %.1f  sweep %.1f  end %.1f   sum %.0f us" % (
+            (name, sel.sum(), d.mean(), np.median(d), np.percentile(d, 99), d.max()) + tuple(seg) + (d.sum(),)))
+# inside the sweep (single-wavefront pairs that wrote their entries): record wait | round 0 | rest of short rows | long rows | heavy pairs
+sw = ok & (t[:, 13] > 0)
+for name, sel in (("n<=16", sw & (n <= 16)), ("16<n<=64", sw & (n > 16) & (n <= 64))):
+    if sel.sum():
+        print("   sweep of %-9s (%d pairs): sweep entry %.2f | record arrives %.2f | round 0 %.2f | more short rows %.2f | long rows %.2f | heavy pairs %.2f | return %.2f us" % (
+            (name, sel.sum(), (t[sel, 8] - t[sel, 5]).mean()) + tuple((t[sel, k + 1] - t[sel, k]).mean() for k in range(8, 13)) + ((t[sel, 6] - t[sel, 13]).mean(),)))
 # how many pairs are in flight over time, when the last pair of each size class ends
-end = t[ok, 3] - t0
+end = t[ok, 7] - t0
 for q in (50, 90, 99, 100):
     print("  %3d %% of the pairs ended by %.1f us" % (q, np.percentile(end, q)))
 # concurrency: pairs in flight, sampled every 10 us
-st, en = t[ok, 0] - t0, t[ok, 3] - t0
+st, en = t[ok, 0] - t0, t[ok, 7] - t0
 for x in range(0, int(en.max()) + 1, 20):
     print("  t=%4d us: %5d pairs in flight" % (x, int(((st <= x) & (en > x)).sum())), end="")
 print()
-late = np.argsort(-t[:, 3] * ok)[:10]
+late = np.argsort(-t[:, 7] * ok)[:10]
 print("last to end:", [(int(n[i]), int(m2[i]), round(float(t[i, 0] - t0), 1), round(float(dur[i]), 1)) for i in late])

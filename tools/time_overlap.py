@@ -4,14 +4,14 @@ import numpy as np, torch
 sys.path.insert(0, ".")
 from tlc_gnn_amd import engine, synth
 
-n, e, k, hop, _ = synth.shaped_graph("PubMed")
-rowptr, col, w = synth.edges_to_csr(n, e, k)
+import bench
+W = bench.build_workload(0)                      # the bench's own graph and batch
+rowptr, col, w = W["rowptr"], W["col"], W["w"]
 NH = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 gs = [engine.DeviceGraph(rowptr, col, w) for _ in range(NH)]
 streams = [torch.cuda.Stream() for _ in range(NH)]
-rs = np.random.RandomState(7)
-pairs = torch.as_tensor(e[rs.permutation(len(e))[:37676]].astype(np.int32)).cuda()
+pairs = torch.as_tensor(W["pi_pairs"]).cuda()
 outs = [torch.empty((len(pairs), 25), dtype=torch.float64, device="cuda") for _ in range(NH)]
 sts = [torch.empty(len(pairs), dtype=torch.uint8, device="cuda") for _ in range(NH)]
 for i in range(NH):
