@@ -50,7 +50,6 @@ struct HostSync {
     unsigned long long stats[2];
     // written by tlc_scan_bin straight into this (pinned, device-mapped) block; seq last, after a system-scope fence
     volatile long long pub_total;
-    volatile long long pub_entries;
     volatile int pub_tier[TLC_N_TIERS];
     volatile int pub_early;
     volatile int pub_overflow;
@@ -131,7 +130,7 @@ struct tlc_graph {
     int ball_hop;
     int* d_ball_ub[2];
     long long last_stats[10];
-    long long acc_tie;             // tie-fallback sources of the chunks whose workspace was taken again within the call
+    long long acc_tie, acc_entries; // tie-fallback sources / induced entries of the chunks whose workspace was taken again within the call
     unsigned long long* d_phase;   // diagnostics: [TLC_N_TIERS][32] cycle counters, null unless enabled
     unsigned long long* d_pair_t;  // diagnostics (PAIR_TIMES builds): [cap][4] wall-clock stamps per pair of the extraction
     size_t cap_pair_t;
@@ -759,8 +758,6 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
     // the critical path.  The poll gives up after 200 us and falls back to synchronising the stream (which also surfaces
     // a kernel fault).
     sp.h_total = const_cast<long long*>(&ws->h_sync_dev->pub_total);
-    sp.h_entries = const_cast<long long*>(&ws->h_sync_dev->pub_entries);
-    sp.entries_sum = reinterpret_cast<unsigned long long*>(ws->d_ctl + 36);
     sp.h_tier = const_cast<int*>(ws->h_sync_dev->pub_tier);
     sp.h_seq = const_cast<unsigned*>(&ws->h_sync_dev->pub_seq);
     sp.seq = seq;
@@ -976,8 +973,20 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
     g->last_stats[8] += tc[TLC_TIER_TINY];
     g->last_stats[TLC_TIER_LARGE] += n_early;
     g->last_stats[7] += tc[TLC_TIER_MID];
-    g->last_stats[4] += ws->h_sync->pub_entries;
     g->last_stats[6] += 1;
+    return TLC_OK;
+}
+
+// statistics: induced directed entries of the chunk a (finished) workspace holds -- summed on the host when somebody asks
+static int chunk_entries(Workspace* ws, long long* out) {
+    std::vector<int> n((size_t)ws->n_pairs), m2((size_t)ws->n_pairs);
+    *out = 0;
+    if (ws->n_pairs <= 0) return TLC_OK;
+    TLC_HIP_CHECK(hipMemcpy(n.data(), ws->hdr_n, n.size() * sizeof(int), hipMemcpyDeviceToHost));
+    TLC_HIP_CHECK(hipMemcpy(m2.data(), ws->hdr_m2, m2.size() * sizeof(int), hipMemcpyDeviceToHost));
+    long long e = 0;
+    for (size_t k = 0; k < n.size(); ++k) if (n[k] > 0) e += m2[k];
+    *out = e;
     return TLC_OK;
 }
 
@@ -1001,6 +1010,10 @@ static int acquire_workspace(tlc_graph* g, Workspace** out, bool same) {
             unsigned long long tie = 0;
             TLC_HIP_CHECK(hipMemcpy(&tie, ws->d_stats, sizeof(tie), hipMemcpyDeviceToHost));
             g->acc_tie += (long long)tie;
+            long long e = 0;
+            int rc = chunk_entries(ws, &e);
+            if (rc != TLC_OK) return rc;
+            g->acc_entries += e;
             ws->in_call = 0;
         }
     }
@@ -1021,7 +1034,7 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
     TLC_REQUIRE(n_pairs == 0 || d_pairs != nullptr, "pairs is null");
     TLC_ON_DEVICE(g->device);
     memset(g->last_stats, 0, sizeof(g->last_stats));
-    g->acc_tie = 0;
+    g->acc_tie = 0; g->acc_entries = 0;
     for (int k = 0; k < TLC_N_WS; ++k) g->ws[k].in_call = 0;
     hipStream_t s = (hipStream_t)stream;
     // a single chunk of a stream-ordered call runs on the caller's stream itself (no cross-stream hops in its latency);
@@ -1106,7 +1119,7 @@ extern "C" int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream)
     TLC_REQUIRE(g && h_out, "null argument");
     TLC_ON_DEVICE(g->device);
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    long long tie = g->acc_tie;
+    long long tie = g->acc_tie, entries = g->acc_entries;
     for (int k = 0; k < TLC_N_WS; ++k) {
         Workspace* ws = &g->ws[k];
         if (!ws->in_call) continue;
@@ -1114,8 +1127,13 @@ extern "C" int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream)
         unsigned long long v = 0;
         TLC_HIP_CHECK(hipMemcpy(&v, ws->d_stats, sizeof(v), hipMemcpyDeviceToHost));
         tie += (long long)v;
+        long long e = 0;
+        int rc = chunk_entries(ws, &e);
+        if (rc != TLC_OK) return rc;
+        entries += e;
     }
     for (int k = 0; k < 10; ++k) h_out[k] = g->last_stats[k];
+    h_out[4] = entries;
     h_out[5] += tie;
     return TLC_OK;
 }

@@ -676,7 +676,10 @@ __global__ void tlc_classify_kernel(int n_pairs, const int* __restrict__ pairs, 
     if (i < n_pairs) {
         const int u = pairs[2 * (size_t)i], v = pairs[2 * (size_t)i + 1];
         if (u >= 0 && v >= 0 && u < n_nodes && v < n_nodes) {
-            const int a = bptr[u + 1] - bptr[u], b = bptr[v + 1] - bptr[v];
+            int a0, a1, b0, b1;
+            row_bounds(bptr, u, a0, a1);
+            row_bounds(bptr, v, b0, b1);
+            const int a = a1 - a0, b = b1 - b0;
             const int k = a < b ? a : b;
             if (cand_list && k >= cand_threshold) cls = 3;
             else if (k >= 256) cls = 0;
@@ -684,16 +687,21 @@ __global__ void tlc_classify_kernel(int n_pairs, const int* __restrict__ pairs, 
             else if (k >= TLC_X_BIN_MIN) cls = 2;
         }
     }
+    // one round of atomics per wavefront: lane c reserves the room of class c, then the bases go round
+    unsigned long long mk[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mk[c] = __ballot(cls == c);
+    const int lane = tlc_lane();
+    int base = 0;
+    if (lane < 4) {
+        const unsigned long long m = lane == 0 ? mk[0] : (lane == 1 ? mk[1] : (lane == 2 ? mk[2] : mk[3]));
+        if (m) base = atomicAdd(lane == 3 ? cand_count : &big_count[lane], __popcll(m));
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const unsigned long long mk = __ballot(cls == c);
-        if (mk == 0ull) continue;
-        int base = 0;
-        const int leader = __builtin_ctzll(mk);
-        if (tlc_lane() == leader) base = atomicAdd(c == 3 ? cand_count : &big_count[c], __popcll(mk));
-        base = __builtin_amdgcn_readlane(base, leader);
-        const int pos = base + __popcll(mk & tlc_lanemask_lt());
+        const int bc = __builtin_amdgcn_readlane(base, c);
         if (cls == c) {
+            const int pos = bc + __popcll(mk[c] & tlc_lanemask_lt());
             if (c == 3) { if (pos < cand_cap) cand_list[pos] = i; }
             else big_list[(size_t)c * n_pairs + pos] = i;
         }

@@ -1315,7 +1315,10 @@ template <int NM, int MM, int W, bool LWL, bool HUGE>
 __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {       // (the counters need the registers)
 #else
 // 128 VGPRs for the SMALL and MEDIUM tiers: four wavefronts per SIMD (16 resp. 4 workgroups per CU)
-__global__ __launch_bounds__(W, (W == 256 && !HUGE ? 4 : (W <= 128 ? 4 : 1))) void tlc_pd_tier_kernel(TlcPdParams p) {
+#ifndef TLC_M_WPE
+#define TLC_M_WPE 4
+#endif
+__global__ __launch_bounds__(W, (W == 256 && !HUGE ? TLC_M_WPE : (W <= 128 ? 4 : 1))) void tlc_pd_tier_kernel(TlcPdParams p) {
 #endif
     typedef unsigned short idx_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];

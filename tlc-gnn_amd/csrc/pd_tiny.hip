@@ -28,6 +28,17 @@ struct LaneArr {
     __device__ __forceinline__ T& operator[](int k) const { return base[k * 64]; }
 };
 
+// byte j of a lane inside the lane's own 8 bytes of every row of an f64 lane-interleaved array (row = 64 lanes x 8 bytes)
+struct LaneBytes8 {
+    unsigned char* base;       // the lane's first byte of row 0
+    __device__ __forceinline__ unsigned char& operator[](int j) const { return base[(j >> 3) * 512 + (j & 7)]; }
+};
+struct LaneBytes8Slice {
+    LaneBytes8 b;
+    int off;
+    __device__ __forceinline__ unsigned char& operator[](int j) const { return b[off + j]; }
+};
+
 __device__ __forceinline__ double tiny_key_asc(double fa, double fb) {
     const double hi = fa > fb ? fa : fb, lo = fa < fb ? fa : fb;
     return hi + (lo + 1.0) * 1e-6;
@@ -92,37 +103,54 @@ struct TinyImage {
 };
 
 constexpr int TN = TLC_T_NMAX, TM = TLC_T_MMAX;
-// bytes of LDS per lane: undirected edges (u16 + f64), Bellman-Ford distances, f, sort keys, and the small index arrays
 constexpr int TP = TLC_T_NMAX + TLC_T_MMAX;          // diagram points with a weight: < n from the ascending pass, [min,max], <= m - n + 1 loops
-constexpr size_t TINY_LANE_BYTES = (size_t)TM * 2 + (size_t)TM * 8 + 4 * (size_t)TN * 8 + (size_t)TM + 8 * (size_t)TN + 2 * (size_t)TM + 2 * (size_t)TP;
+// LDS per workgroup, regions reused as the stages go by (576 bytes per lane = 36 KB: four workgroups per CU; the first layout,
+// one region per array, took 66 KB -- two per CU -- and its workgroups waited for the other tiers to drain, 0.44 ms for
+// 0.15 ms of work):
+//   A  weights -> sort keys                                    f64[TM]
+//   B  distances from u -> filtration values f                 f64[TN]   (the chain walks read the tight-successor tables only)
+//   C  distances from v -> per-source fallback search; then    f64[TN]
+//      points (birth node, death node), tree parent / parent edge          u8[TP] x 2, u8[TN] x 2
+//   D  edge endpoints                                          u16[TM]
+//   E  tight-successor counts / entries, ambiguous sources; then sorted order, components, Pos (front) / Neg (back) list
+constexpr size_t T_OA = 0;
+constexpr size_t T_OB = T_OA + (size_t)TM * 64 * 8;
+constexpr size_t T_OC = T_OB + (size_t)TN * 64 * 8;
+constexpr size_t T_OD = T_OC + (size_t)TN * 64 * 8;
+constexpr size_t T_OE = T_OD + (size_t)TM * 64 * 2;
+constexpr size_t TINY_WG_BYTES = T_OE + 5 * (size_t)TN * 64;
+static_assert(2 * TP + 2 * TN <= TN * 8, "points + tree tables alias the second distance array (8 bytes per lane and row)");
+static_assert(2 * (size_t)TM * 64 + (size_t)TN * 64 <= 5 * (size_t)TN * 64, "order / components / Pos-Neg list alias the tight-successor tables");
 
 }  // namespace
 
 __global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = (int)(threadIdx.x & 63);
-    // carve: arrays of 8-byte elements first (alignment), then 2-byte, then bytes
-    size_t o = 0;
-    LaneArr<double> ew{(double*)(lds + o) + lane};    o += (size_t)TM * 64 * 8;
-    LaneArr<double> dist{(double*)(lds + o) + lane};  o += (size_t)TN * 64 * 8;
-    LaneArr<double> du{(double*)(lds + o) + lane};    o += (size_t)TN * 64 * 8;
-    LaneArr<double> dv{(double*)(lds + o) + lane};    o += (size_t)TN * 64 * 8;
-    LaneArr<double> f{(double*)(lds + o) + lane};     o += (size_t)TN * 64 * 8;
+    // carve (see the region table above)
+    LaneArr<double> ew{(double*)(lds + T_OA) + lane};
     const LaneArr<double>& key = ew;                  // (the sort keys take the weights' place once f is final)
-    LaneArr<unsigned short> eab{(unsigned short*)(lds + o) + lane}; o += (size_t)TM * 64 * 2;
-    LaneArr<unsigned char> ord{lds + o + lane};       o += (size_t)TM * 64;
-    LaneArr<unsigned char> comp{lds + o + lane};      o += (size_t)TN * 64;
-    LaneArr<unsigned char> par{lds + o + lane};       o += (size_t)TN * 64;
-    LaneArr<unsigned char> pedge{lds + o + lane};     o += (size_t)TN * 64;
-    LaneArr<unsigned char> posl{lds + o + lane};      o += (size_t)TM * 64;
-    LaneArr<unsigned char> negl{lds + o + lane};      o += (size_t)TM * 64;
-    LaneArr<unsigned char> cntU{lds + o + lane};      o += (size_t)TN * 64;
-    LaneArr<unsigned char> nxtU{lds + o + lane};      o += (size_t)TN * 64;
-    LaneArr<unsigned char> cntV{lds + o + lane};      o += (size_t)TN * 64;
-    LaneArr<unsigned char> nxtV{lds + o + lane};      o += (size_t)TN * 64;
-    LaneArr<unsigned char> ambl{lds + o + lane};      o += (size_t)TN * 64;    // sources whose tight chain is ambiguous
-    LaneArr<unsigned char> ptb{lds + o + lane};       o += (size_t)TP * 64;    // diagram points as (birth node, death node):
-    LaneArr<unsigned char> ptd{lds + o + lane};       o += (size_t)TP * 64;    // every coordinate is a copy of some f[node]
+    LaneArr<double> du{(double*)(lds + T_OB) + lane};
+    const LaneArr<double>& f = du;                    // (f[x] is written while the walks read cnt / nxt / eab / ew only)
+    LaneArr<double> dv{(double*)(lds + T_OC) + lane};
+    const LaneArr<double>& dist = dv;                 // (per-source searches run after the tight-successor tables are built)
+    // (byte arrays inside the lane's OWN eight bytes of each f64 row of region C: a byte array interleaved one byte per lane would
+    // spread over the doubles of other lanes, and lanes are not always in the same stage -- the lanes of far pairs run their
+    // one search after the others have been through every stage)
+    LaneBytes8 cbytes{lds + T_OC + 8 * (size_t)lane};
+    LaneBytes8Slice ptb{cbytes, 0};                                             // diagram points as (birth node, death node):
+    LaneBytes8Slice ptd{cbytes, TP};                                            // every coordinate is a copy of some f[node]
+    LaneBytes8Slice par{cbytes, 2 * TP};
+    LaneBytes8Slice pedge{cbytes, 2 * TP + TN};
+    LaneArr<unsigned short> eab{(unsigned short*)(lds + T_OD) + lane};
+    LaneArr<unsigned char> cntU{lds + T_OE + lane};
+    LaneArr<unsigned char> nxtU{lds + T_OE + (size_t)TN * 64 + lane};
+    LaneArr<unsigned char> cntV{lds + T_OE + 2 * (size_t)TN * 64 + lane};
+    LaneArr<unsigned char> nxtV{lds + T_OE + 3 * (size_t)TN * 64 + lane};
+    LaneArr<unsigned char> ambl{lds + T_OE + 4 * (size_t)TN * 64 + lane};    // sources whose tight chain is ambiguous
+    LaneArr<unsigned char> ord{lds + T_OE + lane};
+    LaneArr<unsigned char> comp{lds + T_OE + (size_t)TM * 64 + lane};
+    LaneArr<unsigned char> pn{lds + T_OE + (size_t)TM * 64 + (size_t)TN * 64 + lane};   // Pos edges from the front, Neg edges from the back
     int npts = 0;
 
     int tier_count = p.tier_count;
@@ -285,11 +313,11 @@ __global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
                 const unsigned ab = eab[e];
                 const int pu = find((int)(ab >> 8)), pv = find((int)(ab & 0xffu));
                 if (pu != pv) {
-                    negl[nneg++] = (unsigned char)e;
+                    pn[TM - 1 - nneg++] = (unsigned char)e;
                     const int small = (f[pu] <= f[pv]) ? pu : pv, large = pu + pv - small;     // (:101-102)
                     comp[small] = (unsigned char)large;
                 } else {
-                    posl[npos++] = (unsigned char)e;
+                    pn[npos++] = (unsigned char)e;
                 }
             }
             TINY_STAMP(3);
@@ -297,12 +325,12 @@ __global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
             else if (npos > 0) {
                 // ---- P8 (:115-178): spanning tree of the Neg edges, rooted at the first endpoint of the first one -------------
                 for (int y = 0; y < n; ++y) par[y] = 0xFFu;
-                const int root = (int)(eab[negl[0]] >> 8);
+                const int root = (int)(eab[pn[TM - 1]] >> 8);
                 par[root] = (unsigned char)root;
                 for (int round = 0; round < n; ++round) {
                     bool ch = false;
                     for (int t = 0; t < nneg; ++t) {
-                        const int e = negl[t];
+                        const int e = pn[TM - 1 - t];
                         const unsigned ab = eab[e];
                         const int a = (int)(ab >> 8), b = (int)(ab & 0xffu);
                         const unsigned pa = par[a], pb = par[b];
@@ -313,7 +341,7 @@ __global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
                 }
                 for (int e = 0; e < m; ++e) { const unsigned ab = eab[e]; key[e] = tiny_key_asc(f[ab >> 8], f[ab & 0xffu]); }
                 for (int t = 0; t < npos; ++t) {
-                    const int e = posl[t];
+                    const int e = pn[t];
                     const unsigned ab = eab[e];
                     const int pnode = (int)(ab >> 8), q = (int)(ab & 0xffu);
                     if (par[pnode] == 0xFFu || par[q] == 0xFFu) continue;      // (other component: cannot happen, the vicinity is connected)
@@ -363,7 +391,7 @@ __global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
 
 int tlc_launch_pd_tiny(const TlcPdParams& p, void* stream) {
     if (p.tier_count <= 0) return TLC_OK;
-    const size_t lds = TINY_LANE_BYTES * 64;
+    const size_t lds = TINY_WG_BYTES;
     const int grid = (p.tier_count + 63) / 64;
     // (above the 64 KiB default of dynamic LDS; the attribute is per device, so it is set per launch: ~1 us)
     if (lds > 64 * 1024)

@@ -159,8 +159,6 @@ struct TlcScanParams {
     int* h_early;           // mapped host memory: number of early pairs (statistics)
     // mapped host memory the last block publishes into (api.hip, HostSync)
     long long* h_total;
-    long long* h_entries;   // mapped host memory: sum of the induced directed entries of all vicinities (statistics)
-    unsigned long long* entries_sum;   // device accumulator of the former (zeroed per launch)
     int* h_tier;
     unsigned* h_seq;
     unsigned seq;

@@ -164,13 +164,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
     if (tier >= 0) p.tier_list[(size_t)tier * p.n_pairs + s_tbase[tier] + s_tc[tier][wave] + my_rank] = i;
     // the last block to get here publishes the sizes
     __syncthreads();
-    // (statistics: the entries of every vicinity, wherever they were written)
-    {
-        long long e = (i < p.n_pairs && n > 0) ? (long long)m2v : 0;
-        e = tlc_wave_sum_i64(e);
-        if (lane == 0 && e && p.entries_sum) atomicAdd(p.entries_sum, (unsigned long long)e);
-    }
-    __syncthreads();
     if (t == 0) {
         atomicAdd(reinterpret_cast<unsigned long long*>(p.sync + 2), (unsigned long long)btotal);   // running arena total
         __threadfence();
@@ -180,7 +173,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
             if (p.h_overflow) *p.h_overflow = p.bump_overflow ? *p.bump_overflow : 0;
             p.totals[0] = total;
             *p.h_total = total;
-            if (p.h_entries) *p.h_entries = p.entries_sum ? (long long)__hip_atomic_load(p.entries_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : total;
             if (p.h_early) {
                 int valid = 0;                            // (a slot may be empty: extract.hip)
                 for (int k = 0; k < n_early; ++k) valid += p.early_list[k] >= 0 ? 1 : 0;
