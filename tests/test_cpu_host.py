@@ -107,9 +107,14 @@ def test_tier_classification_mirrors_kernel_constants():
                                   ("pd_tier_mid", vals["TLC_D_NMAX"], vals["TLC_D_MMAX"]),
                                   ("pd_tier_medium", vals["TLC_M_NMAX"], vals["TLC_M_MMAX"]),
                                   ("pd_tier_large", vals["TLC_L_NMAX"], vals["TLC_L_MMAX"])]
-    t = engine.tier_of(np.array([0, 10, 64, 65, 128, 129, 512, 513, 3000]), np.array([0, 20, 256, 10, 512, 10, 2048, 10, 10]))
-    assert t.tolist() == ["", "pd_tier_small", "pd_tier_small", "pd_tier_mid", "pd_tier_mid", "pd_tier_medium", "pd_tier_medium",
-                          "pd_tier_large", "pd_tier_huge"]
+    tiny = {k: int(v) for k, v in re.findall(r"#define (TLC_T_[NM]MAX|TLC_MH_MIN_POS) (\d+)", hdr)}
+    assert engine.TINY_LIMITS == (tiny["TLC_T_NMAX"], tiny["TLC_T_MMAX"]) and engine.MEDIUM_MANY_POS == tiny["TLC_MH_MIN_POS"]
+    n = np.array([0, 10, 16, 17, 16, 64, 65, 128, 129, 512, 300, 300, 513, 3000])
+    m2 = np.array([0, 20, 48, 48, 50, 256, 10, 512, 10, 2048, 2 * (299 + 119), 2 * (299 + 120), 10, 10])
+    t = engine.tier_of(n, m2)
+    assert t.tolist() == ["", "pd_tier_tiny", "pd_tier_tiny", "pd_tier_small", "pd_tier_small", "pd_tier_small", "pd_tier_mid", "pd_tier_mid",
+                          "pd_tier_medium_rest", "pd_tier_medium", "pd_tier_medium_rest", "pd_tier_medium", "pd_tier_large", "pd_tier_huge"]
+    assert engine.tier_of(n, m2, tiny=False).tolist()[1:3] == ["pd_tier_small", "pd_tier_small"]
 
 
 def test_shard_helpers():

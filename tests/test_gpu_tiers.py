@@ -1,0 +1,203 @@
+"""GPU: the tier plumbing of the PD/PI batch at its thresholds -- which kernel a vicinity takes must never change its row.
+
+  * the divide-and-conquer cycle swap (tlc_pd_dc_kernel, csrc/ext1_dc.h): LARGE-tier vicinities with 159 / 160 / 161 Pos edges
+    (TLC_DC_MIN_POS = 160), with long runs of equal keys (not attempted), and with every solve forced to fail (the give-back
+    to the serial walk) -- asserted through tlc_debug_dc_stats, rows against the oracle;
+  * the MEDIUM tier's cut by Pos-edge count (TLC_MH_MIN_POS = 120): 119 / 120 / 121;
+  * the lane-per-subgraph kernel (pd_tiny.hip): vicinities at 16 / 17 nodes and 24 / 25 edges, tied weights, on and off;
+  * a seeded random sweep over graph families, weight styles, hops and flags (the former tests/aids/fuzz_parity.py).
+Every vicinity here is built as "hub + leaves + chords": the pair (hub, leaf) sees the whole component at hop 2, so its node,
+edge and Pos-edge (= m - n + 1) counts are what the test asks for."""
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def hub_component(n, m, rs, base=0):
+    """a hub, n - 1 leaves and m - (n - 1) distinct chords among the leaves; ids from `base` on; returns edges int64[m, 2]"""
+    assert m >= n - 1 and m <= (n - 1) + (n - 1) * (n - 2) // 2
+    e = set((0, k) for k in range(1, n))
+    while len(e) < m:
+        a, b = rs.randint(1, n, size=2)
+        if a != b:
+            e.add((min(a, b), max(a, b)))
+    return np.array(sorted(e), dtype=np.int64) + base
+
+
+def _check(g, torch, rowptr, col, w, pairs, hop=2, tol=1e-8):
+    from oracle import oracle
+    out, st = g.pd_pi_batch(torch.as_tensor(np.ascontiguousarray(pairs, dtype=np.int32)).cuda(), hop)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    uniq, inv = np.unique(pairs, axis=0, return_inverse=True)
+    ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, uniq.astype(np.int32), hop, n_threads=0)
+    ref, rst = ref[inv.ravel()], rst[inv.ravel()]
+    assert np.array_equal(st, rst)
+    assert np.array_equal(out == 0, ref == 0)
+    nz = ref != 0
+    if nz.any():
+        assert rel_err(out[nz], ref[nz]).max() < tol
+    return out, st
+
+
+@pytest.mark.parametrize("k_pos,expect_dc", [(159, False), (160, True), (161, True), (700, True)])
+@pytest.mark.parametrize("n_pairs", [8, 4608])
+def test_divide_and_conquer_threshold(k_pos, expect_dc, n_pairs):
+    """LARGE-tier vicinities (601 nodes) around TLC_DC_MIN_POS: below it the tier kernel keeps its serial walk, from it on every
+    subgraph goes through tlc_pd_dc_kernel -- on the ordinary heavy path (8 pairs) and through the early pass (4 608 pairs)."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    rs = np.random.RandomState(k_pos)
+    n = 601
+    e = hub_component(n, n - 1 + k_pos, rs)
+    rowptr, col, w = synth.edges_to_csr(n, e, rs.uniform(-0.5, 0.9, size=len(e)))
+    pairs = np.tile(np.array([[0, 1], [0, 2], [3, 0], [0, 7], [5, 0], [0, 11], [0, 13], [2, 0]]), (n_pairs // 8, 1))
+    g = engine.DeviceGraph(rowptr, col, w)
+    _check(g, torch, rowptr, col, w, pairs)
+    ran, back = g.dc_stats()
+    stats = g.stats()
+    assert stats["tier_large"] == len(pairs)
+    assert (ran, back) == ((len(pairs), 0) if expect_dc else (0, 0))
+    g.close()
+
+
+def test_divide_and_conquer_give_back_and_long_tie_runs():
+    """(i) Every solve forced to fail (debug option dc_force_fail): tlc_pd_dc_kernel gives each subgraph back to the serial walk it
+    carries -- same rows.  The real trigger, ranks that are no minimum-spanning-tree order because of keys that differ in the
+    last bits only, was not reached by 40 constructed weight families (tools/explore_dc.py), so the path is driven this way.
+    (ii) Unit weights: hundreds of equal keys in a row (> TLC_DC_MAX_TIE_RUN) -- the divide and conquer is not attempted."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    rs = np.random.RandomState(3)
+    n = 701
+    e = hub_component(n, n - 1 + 400, rs)
+    pairs = np.array([[0, k] for k in range(1, 25)])
+    rowptr, col, w = synth.edges_to_csr(n, e, rs.uniform(-0.5, 0.9, size=len(e)))
+    g = engine.DeviceGraph(rowptr, col, w)
+    a, _ = _check(g, torch, rowptr, col, w, pairs)
+    assert g.dc_stats() == (len(pairs), 0)
+    g.set_option("dc_force_fail", 1)
+    b, _ = _check(g, torch, rowptr, col, w, pairs)
+    assert g.dc_stats() == (0, len(pairs))
+    g.set_option("dc_force_fail", 0)
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    g.close()
+    rowptr, col, w = synth.edges_to_csr(n, e, np.zeros(len(e)))
+    g = engine.DeviceGraph(rowptr, col, w)
+    _check(g, torch, rowptr, col, w, pairs)
+    assert g.dc_stats() == (0, 0) and g.stats()["tier_large"] == len(pairs)
+    g.close()
+
+
+@pytest.mark.parametrize("k_pos,many", [(119, False), (120, True), (121, True)])
+def test_medium_tier_cut_by_pos_edges(k_pos, many):
+    """MEDIUM-sized vicinities (301 nodes) around TLC_MH_MIN_POS: from 120 Pos edges on they go to the list that is launched
+    first; either way the same kernels, the same rows."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    rs = np.random.RandomState(k_pos)
+    n = 301
+    e = hub_component(n, n - 1 + k_pos, rs)
+    rowptr, col, w = synth.edges_to_csr(n, e, rs.uniform(-0.5, 0.9, size=len(e)))
+    pairs = np.array([[0, k] for k in range(1, 41)] + [[k, 0] for k in range(41, 61)])
+    g = engine.DeviceGraph(rowptr, col, w)
+    _check(g, torch, rowptr, col, w, pairs)
+    stats = g.stats()
+    assert stats["tier_medium"] == len(pairs)
+    assert stats["tier_medium_many_pos"] == (len(pairs) if many else 0)
+    g.close()
+
+
+@pytest.mark.parametrize("decimals", [None, 1])
+def test_tiny_tier_boundaries_on_and_off(decimals):
+    """Components at the limits of the lane-per-subgraph kernel (16 nodes / 24 edges) and just beyond, and the smallest ones:
+    the kernel takes exactly the vicinities within both limits; switched off, the wavefront-per-subgraph kernel gives the same
+    rows (the two break ties between equal keys differently: 1e-12, and 1e-8 against the oracle).  decimals=1: weights with
+    one decimal, i.e. many tied paths and keys."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    rs = np.random.RandomState(5)
+    shapes = [(16, 24), (17, 24), (16, 25), (17, 25), (16, 15), (15, 24), (12, 16), (3, 3), (3, 2), (2, 1), (4, 6), (9, 20), (16, 23), (10, 9)]
+    shapes = shapes * 6
+    edges, pairs, base, expect_tiny = [], [], 0, 0
+    for (n, m) in shapes:
+        edges.append(hub_component(n, m, rs, base))
+        pairs.append([base, base + 1 + rs.randint(n - 1)])
+        if n >= 3:
+            pairs.append([base + 1, base])
+            expect_tiny += 1 if (n <= 16 and m <= 24) else 0
+        expect_tiny += 1 if (n <= 16 and m <= 24) else 0
+        base += n
+    e = np.concatenate(edges)
+    kappa = rs.uniform(-0.5, 0.9, size=len(e))
+    if decimals is not None:
+        kappa = np.round(kappa, decimals)
+    rowptr, col, w = synth.edges_to_csr(base, e, kappa)
+    pairs = np.array(pairs)
+    g = engine.DeviceGraph(rowptr, col, w)
+    on, st_on = _check(g, torch, rowptr, col, w, pairs)
+    assert g.stats()["tier_tiny"] == expect_tiny
+    g.set_option("tiny", 0)
+    off, st_off = _check(g, torch, rowptr, col, w, pairs)
+    assert g.stats()["tier_tiny"] == 0
+    g.set_option("tiny", 1)
+    assert np.array_equal(st_on, st_off)
+    assert np.abs(on - off).max() <= 1e-12 * max(1.0, np.abs(off).max())
+    g.close()
+
+
+def _family(kind, n, rs):
+    from tlc_gnn_amd import synth
+    if kind == "er":
+        e = rs.randint(0, n, size=(int(n * rs.uniform(1.0, 6.0)), 2))
+    elif kind == "ba":
+        return synth.holme_kim_edges(n, int(n * rs.uniform(1.5, 5.0)), triad_p=rs.uniform(0, 0.8), seed=int(rs.randint(1 << 30)))
+    elif kind == "grid":
+        w = int(np.sqrt(n)); idx = np.arange(w * w).reshape(w, w)
+        e = np.concatenate([np.stack([idx[:, :-1].ravel(), idx[:, 1:].ravel()], 1), np.stack([idx[:-1].ravel(), idx[1:].ravel()], 1),
+                            rs.randint(0, w * w, size=(w, 2))])
+    elif kind == "caveman":
+        k = 12; c = n // k
+        e = np.array([(q * k + i, q * k + j) for q in range(c) for i in range(k) for j in range(i + 1, k) if rs.rand() < 0.7] +
+                     [(q * k, ((q + 1) % c) * k + 1) for q in range(c)])
+    else:                                                   # star: a few hubs
+        hubs = rs.randint(0, n, size=5)
+        e = np.concatenate([np.stack([rs.choice(hubs, size=3 * n), rs.randint(0, n, size=3 * n)], 1), rs.randint(0, n, size=(n, 2))])
+    e = e[e[:, 0] != e[:, 1]]
+    return np.unique(np.sort(e, 1), axis=0).astype(np.int64)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_seeded_random_sweep_vs_oracle(seed):
+    """graph family x weight style (continuous / one decimal / unweighted) x hop 1-3 x flags (0, NO_EXT1): status bytes equal,
+    images within 1e-8 of the oracle; batches of > 4 096 pairs where the graph has them (early pass, bins, divide and conquer)."""
+    import torch
+    from tlc_gnn_amd import engine, synth, _lib
+    from oracle import oracle
+    rs = np.random.RandomState(1000 + seed)
+    kind = ["er", "ba", "grid", "caveman", "star"][seed % 5]
+    n = int(rs.choice([150, 600, 2500]))
+    e = _family(kind, n, rs)
+    n = int(e.max()) + 1
+    kappa = rs.uniform(-0.5, 0.9, size=len(e))
+    if seed % 3 == 1:
+        kappa = np.round(kappa, 1)
+    if seed % 3 == 2:
+        kappa = np.zeros(len(e))
+    rowptr, col, w = synth.edges_to_csr(n, e, kappa)
+    g = engine.DeviceGraph(rowptr, col, w)
+    for hop in (1, 2, 3):
+        if hop == 3 and n > 700:
+            continue
+        pos = e[rs.permutation(len(e))[:4500]]
+        pairs = np.concatenate([pos, rs.randint(0, n, size=(300, 2)), [[0, 0], [n + 5, 1], [-1, 2]]]).astype(np.int32)
+        for flags in (0, _lib.NO_EXT1):
+            got, st = g.pd_pi_batch(torch.as_tensor(pairs).cuda(), hop, flags=flags)
+            got, st = got.cpu().numpy(), st.cpu().numpy()
+            ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, hop, flags=flags, n_threads=0)
+            assert np.array_equal(st, rst), (kind, hop, flags)
+            scale = np.abs(ref).max(axis=1, keepdims=True) + 1e-300
+            assert (np.abs(got - ref) / scale).max() < 1e-8, (kind, hop, flags)
+    g.close()

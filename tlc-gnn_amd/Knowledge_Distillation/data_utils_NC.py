@@ -31,12 +31,25 @@ class NodeVicinities(Vicinities):
 _CACHE = {}
 
 
+def _graph_stamp(g, ricci_curv):
+    """Cheap content stamp of what the device copy was built from: node / edge counts, the length of the curvature list and its
+    first and last 64 rows.  (The function is called once per node: a full hash of a 44 000-edge graph per call would cost
+    more than the vicinities.)"""
+    k = 0 if ricci_curv is None else len(ricci_curv)
+    sample = () if not k else tuple(tuple(float(x) for x in row) for row in (list(ricci_curv[:64]) + list(ricci_curv[-64:])))
+    return (g.number_of_nodes(), g.number_of_edges(), k, hash(sample))
+
+
 def _vicinities(g, ricci_curv):
-    key = (id(g), id(ricci_curv))
-    if key not in _CACHE:
-        _CACHE.clear()
-        _CACHE[key] = NodeVicinities(g, ricci_curv)
-    return _CACHE[key]
+    """One device graph is kept between calls (the reference rebuilds everything per call, :95-187).  It is reused only for
+    the SAME graph and curvature objects (held here, so that their ids cannot be handed to other objects) whose stamp has not
+    changed; a caller that edits a graph in place without changing any count should build `NodeVicinities(g, ricci_curv)`
+    itself and call `.batch(nodes, hop)` -- which is also the faster way: many nodes per launch."""
+    ent = _CACHE.get("entry")
+    stamp = _graph_stamp(g, ricci_curv)
+    if ent is None or ent[0] is not g or ent[1] is not ricci_curv or ent[2] != stamp:
+        _CACHE["entry"] = ent = (g, ricci_curv, stamp, NodeVicinities(g, ricci_curv))
+    return ent[3]
 
 
 def compute_persistence_image(g, u, filt='hks', hks_time=0.1, hop=2, ricci_curv=None, mode='PI', num_models=5, max_loop_len=10,

@@ -64,7 +64,7 @@ struct HostSync {
 struct Workspace {
     size_t cap_pairs;
     int *hdr_n, *hdr_m2, *hdr_lu, *hdr_lv, *tier_list;
-    int* dc_lists;             // [6][cap_pairs + TLC_EARLY_SLOTS]: list positions a tier kernel hands to tlc_pd_dc_kernel
+    int* dc_lists;             // [3][cap_pairs + TLC_EARLY_SLOTS]: list positions a tier kernel hands to tlc_pd_dc_kernel (MEDIUM / LARGE / early LARGE)
     int* big_lists;            // [3][cap_pairs]: the bins of tlc_classify_kernel (extract.hip)
     long long* edge_off;
     // small device block: [0..6] tier counts, [10..13] scan, [16..19] early pass, [20..22] bump allocator, [24] work counter,
@@ -156,6 +156,7 @@ struct tlc_graph {
     size_t x_lds64, x_lds512;
     // development / test switches (tlc_debug_set_option; initial values from the environment: TLC_EXTRACT, TLC_HEAVY, TLC_TINY)
     int opt_extract, opt_heavy, opt_tiny;
+    int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
     int opt_tier_mask;                  // development: which tier kernels are launched at all (timing a tier alone; rows of the others are garbage)
     int opt_x_region, opt_x_bump_min;   // arena entries per workgroup region / minimum bump area of the extraction (tests shrink them)
 };
@@ -180,7 +181,7 @@ static int ensure_pairs(tlc_graph* g, Workspace* ws, size_t n) {
     TLC_HIP_CHECK(hipMalloc(&ws->hdr_lv, n * sizeof(int)));
     TLC_HIP_CHECK(hipMalloc(&ws->tier_list, n * TLC_N_TIERS * sizeof(int)));
     TLC_HIP_CHECK(hipMalloc(&ws->edge_off, (n + 1) * sizeof(long long)));
-    TLC_HIP_CHECK(hipMalloc(&ws->dc_lists, 6 * (n + TLC_EARLY_SLOTS) * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&ws->dc_lists, 3 * (n + TLC_EARLY_SLOTS) * sizeof(int)));
     TLC_HIP_CHECK(hipMalloc(&ws->big_lists, 3 * n * sizeof(int)));
     ws->cap_pairs = n;
     return TLC_OK;
@@ -658,13 +659,13 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
     pp.ids_off = (const long long*)d_ids_off; pp.out_f = d_out_f; pp.out_n = d_out_n; pp.pi_enabled = pi_enabled;
     pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
     pp.stats = ws->d_stats;
-    // lists for tlc_pd_dc_kernel: counters in the control block (zeroed with it), [d_ctl + 26 + 2k] count / [.. + 1] left over;
+    pp.dc_force_fail = g->opt_dc_force_fail;
+    // lists for tlc_pd_dc_kernel: counters in the control block (zeroed with it), [d_ctl + 26 + 2k];
     // k = 0 MEDIUM, 1 LARGE (regular launch), 2 LARGE (early launch)
     auto dc_lists_for = [&](TlcPdParams& q, int k) {
         const size_t cap = ws->cap_pairs + TLC_EARLY_SLOTS;
-        q.dc_count = ws->d_ctl + 26 + 2 * k; q.dcf_count = ws->d_ctl + 27 + 2 * k;
+        q.dc_count = ws->d_ctl + 26 + 2 * k;
         q.dc_list = ws->dc_lists + (size_t)k * cap;
-        q.dcf_list = ws->dc_lists + (size_t)(3 + k) * cap;
     };
     if (early) {
         if ((rc = ensure_early(g, ws, hop, s)) != TLC_OK) return rc;
@@ -882,7 +883,7 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
             pp.handoff = hs ? ws->handoff + hand_base[t] : nullptr;
             pp.handoff_stride = (long long)hs;
             pp.handoff_cap = (spec_done && (t == TLC_TIER_MID || t == TLC_TIER_MEDIUM)) ? std::min(tc[t], spec_cap[t]) : tc[t];
-            pp.dc_count = pp.dcf_count = nullptr; pp.dc_list = pp.dcf_list = nullptr;
+            pp.dc_count = nullptr; pp.dc_list = nullptr;
             if (t == TLC_TIER_LARGE) dc_lists_for(pp, 1);
             if (hs && t == TLC_TIER_LARGE) {
                 // (the early launch may still be using the first TLC_EARLY_SLOTS slots: this launch takes the ones behind them)
@@ -939,7 +940,7 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
             pp.tier_list = ws->tier_list + (size_t)TLC_TIER_TINY * n_pairs; pp.tier_count = tc[TLC_TIER_TINY];
             pp.handoff = nullptr; pp.handoff_stride = 0; pp.handoff_cap = 0; pp.grid = 0; pp.phase = 0;
             pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
-            pp.dc_count = pp.dcf_count = nullptr; pp.dc_list = pp.dcf_list = nullptr;
+            pp.dc_count = nullptr; pp.dc_list = nullptr;
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * TLC_TIER_TINY : nullptr;
             if (((g->opt_tier_mask >> TLC_TIER_TINY) & 1) && (rc = tlc_launch_pd_tiny(pp, ws->side[5])) != TLC_OK) return rc;
             TLC_HIP_CHECK(hipEventRecord(ws->ev_join[5], ws->side[5]));
@@ -1238,6 +1239,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "heavy")) g->opt_heavy = value != 0;
     else if (!strcmp(name, "tiny")) g->opt_tiny = value != 0;
     else if (!strcmp(name, "tier_mask")) g->opt_tier_mask = value;
+    else if (!strcmp(name, "dc_force_fail")) g->opt_dc_force_fail = value != 0;
     else if (!strcmp(name, "x_region")) g->opt_x_region = std::max(value, 0);
     else if (!strcmp(name, "x_bump_min")) g->opt_x_bump_min = std::max(value, 0);
     else { tlc_set_error("tlc_debug_set_option: unknown option '%s'", name); return TLC_ERR_INVALID_ARG; }

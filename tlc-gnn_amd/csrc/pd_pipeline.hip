@@ -1761,7 +1761,7 @@ __global__ __launch_bounds__(W, (W <= 256 ? 4 : 1)) void tlc_pd_dc_kernel(TlcPdP
         __syncthreads();
         unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const unsigned long long t_begin = p.phase_cycles ? clock64() : 0ull;
-        const bool ok = ext1_dc_solve<W>(src, n, K, n, ctl, wcnt, lds_raw, o_pts - hin_bytes, hin, p.phase_cycles ? prof : nullptr);
+        const bool ok = ext1_dc_solve<W>(src, n, K, n, ctl, wcnt, lds_raw, o_pts - hin_bytes, hin, p.phase_cycles ? prof : nullptr) && !p.dc_force_fail;
         if (p.phase_cycles && tid == 0) {                             // diagnostics: the slowest subgraph's split
             const unsigned long long tot = clock64() - t_begin;
             if (atomicMax(&p.phase_cycles[13], tot) < tot) {

@@ -215,13 +215,11 @@ struct TlcPdParams {
     // arena: the chunk is redone by the scan + FILL path) makes every workgroup return at once
     // subgraphs a tier kernel hands to tlc_pd_dc_kernel (many Pos edges: the cycle swap as a divide and conquer): their list
     // positions are appended to dc_list (*dc_count entries, zeroed per chunk) so that the kernel runs with a small grid and costs
-    // nothing when there are none; what it cannot finish goes to dcf_list for tlc_pd_swap_kernel (LARGE tier: the serial
-    // kernel runs over that list only; the other tiers' serial kernel visits every slot anyway)
+    // nothing when there are none; what it cannot finish (ranks that are no minimum-spanning-tree order) it finishes itself with
+    // the serial walk
     int* dc_count;
     int* dc_list;
-    int* dcf_count;
-    int* dcf_list;
-    int swap_from_list;          // tlc_pd_swap_kernel: 1 = only the slots in dcf_list
+    int dc_force_fail;           // tests: tlc_pd_dc_kernel treats every solve as failed (the give-back path to the serial walk)
     int grid;
     int phase;                   // 0 = tier kernel + its swap kernel, 1 = tier kernel only, 2 = swap kernel only
     int handoff_cap;

@@ -130,7 +130,9 @@ class PaddedRows:
         """[hi-lo, k] view to write the local rows into (the pad rows of the block were zeroed once).  `key` names the buffer
         pair: one per exchange step of a forward, so that a block is never rewritten while a later kernel still reads it."""
         import torch
-        if key not in self._send:
+        buf = self._send.get(key)
+        if buf is None or buf.shape[1] != k or buf.dtype != like.dtype or buf.device != like.device:
+            # (a buffer is tied to the width, dtype and device it was made for: a later call with others gets its own)
             self._send[key] = torch.zeros((self.blk, k), dtype=like.dtype, device=like.device)
             self._recv[key] = torch.empty((self.world * self.blk, k), dtype=like.dtype, device=like.device)
         return self._send[key][:self.hi - self.lo]

@@ -196,17 +196,27 @@ def pi_raster(offs, pts, res=5):
     return out[:B]
 
 
-# size tiers of the PD kernel (csrc/tlc_kernels.h)
+# size tiers of the PD kernel (csrc/tlc_kernels.h) and what the library's timing slots bracket
 TIER_LIMITS = [("pd_tier_small", 64, 128), ("pd_tier_mid", 128, 256), ("pd_tier_medium", 512, 1024), ("pd_tier_large", 2048, 4096)]
+TINY_LIMITS = (16, 24)          # TLC_T_NMAX / TLC_T_MMAX: lane-per-subgraph kernel (plain image batches at resolution 5)
+MEDIUM_MANY_POS = 120           # TLC_MH_MIN_POS: MEDIUM-sized vicinities with at least this many Pos edges (m - n + 1)
 
 
-def tier_of(n, m2):
-    """tier name per pair from (|S|, induced directed entries), mirroring tlc_scan_bin; '' for pairs finished early."""
+def tier_of(n, m2, tiny=True):
+    """Which kernel's TIMING SLOT covers each pair, from (|S|, induced directed entries), mirroring tlc_scan_bin and run_chunk:
+    'pd_tier_small' = the wavefront-per-subgraph SMALL kernel only -- the pairs of the lane-per-subgraph kernel are
+    'pd_tier_tiny' (no slot of its own); 'pd_tier_medium' = the MEDIUM-sized vicinities with many Pos edges (the launch that
+    slot brackets), the rest of the MEDIUM tier is 'pd_tier_medium_rest' (not bracketed); '' for pairs finished early.
+    So bytes summed over the pairs of a name and the time of that name's slot cover the same work."""
     n = np.asarray(n)
     m = np.asarray(m2) // 2
     out = np.full(n.shape, "pd_tier_huge", dtype=object)
     for name, nm, mm in reversed(TIER_LIMITS):
         out[(n <= nm) & (m <= mm)] = name
+    med = out == "pd_tier_medium"
+    out[med & (m - n + 1 < MEDIUM_MANY_POS)] = "pd_tier_medium_rest"
+    if tiny:
+        out[(n <= TINY_LIMITS[0]) & (m <= TINY_LIMITS[1])] = "pd_tier_tiny"
     out[n <= 0] = ""
     return out
 
