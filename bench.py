@@ -495,24 +495,40 @@ def main():
             cost = tdist.pair_cost(tdist.ball_bound(wl["rowptr"], wl["col"], hop), near_np)
             run = lambda shard: g.pd_pi_batch(shard.contiguous(), hop)
             gather = tdist.gather_shards if world > 1 else None
-            reps = []
+            reps, dev_ms = [], []
+
+            def run_timed(shard):                                   # the rank's own device time, beside the host wall clock
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                res = run(shard)
+                e1.record()
+                dev_ms.append((e0, e1))
+                return res
             for it in range(4):
                 barrier()
                 c0 = time.perf_counter()
-                rows_s, st_s, (slo, shi) = tdist.pd_pi_batch_sharded(run, near, world, rank, cost=cost, gather=gather)
+                rows_s, st_s, part = tdist.pd_pi_batch_sharded(run_timed, near, world, rank, cost=cost, gather=gather)
                 barrier()
                 reps.append(time.perf_counter() - c0)
+            my_ms = float(np.median([a.elapsed_time(b) for a, b in dev_ms[1:]]))
             tt = torch.tensor([float(np.median(reps[1:]))], dtype=torch.float64, device=dev)
+            per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
+            per_rank[rank] = my_ms
             if world > 1:
                 import torch.distributed as dist
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
             sdt = float(tt.item())
-            bounds = tdist.shard_pairs_by_cost(cost, world)
+            parts = tdist.shard_pairs_interleaved(cost, world) if world > 1 else [np.arange(len(near_np))]
             strong = {"pairs": int(len(near_np)), "seconds": sdt, "images_per_sec": len(near_np) / sdt,
-                      "shard_pairs": [int(bounds[r + 1] - bounds[r]) for r in range(world)],
+                      "shard_pairs": [int(len(p_)) for p_ in parts],
+                      "shard_cost": [float(cost[p_].sum()) for p_ in parts],
+                      "rank_device_ms": [float(v) for v in per_rank.tolist()],
                       "rows_gathered_on_every_rank": bool(world > 1), "nonzero_rows": int((rows_s.abs().sum(1) > 0).sum()),
-                      "note": "strong scaling: fixed list (all non-adjacent pairs with d(u,v) <= hop), cost-balanced contiguous "
-                              "shards (cost = smaller ball-size bound of the endpoints), host wall clock, median of 3, max over ranks"}
+                      "note": "strong scaling: fixed list (all non-adjacent pairs with d(u,v) <= hop) dealt to the ranks by descending "
+                              "estimated cost (cost = smaller ball-size bound of the endpoints; boustrophedon, so no rank owns the "
+                              "heavy tail), rows gathered back to list order with one all-gather; `seconds`: host wall clock, median "
+                              "of 3, max over ranks; rank_device_ms: every rank's own HIP-event time of its shard"}
             del rows_s, st_s, near, ranks, ci
             g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)
             torch.cuda.synchronize()

@@ -98,8 +98,17 @@ def _worker(rank, world, port, q):
         return torch.from_numpy(r_), torch.from_numpy(s_)
 
     cost = tdist.pair_cost(tdist.ball_bound(rp, cl, 2), pr)
-    rows, st, (slo, shi) = tdist.pd_pi_batch_sharded(run, pr, world, rank, cost=cost, gather=tdist.gather_shards)
+    rows, st, (slo, shi) = tdist.pd_pi_batch_sharded(run, pr, world, rank, cost=cost, gather=tdist.gather_shards, scheme="contiguous")
     assert 0 < shi - slo < len(pr)
+    assert np.array_equal(rows.numpy(), single_rows) and np.array_equal(st.numpy(), single_st)      # bit for bit
+    # the default: pairs dealt to the ranks by descending cost; the rows come back to list order through the index arrays
+    rows, st, mine = tdist.pd_pi_batch_sharded(run, pr, world, rank, cost=cost, gather=tdist.gather_shards)
+    parts = tdist.shard_pairs_interleaved(cost, world)
+    assert np.array_equal(mine, parts[rank]) and 0 < len(mine) < len(pr)
+    assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(len(pr)))                       # a partition of the list
+    heavy = np.argsort(-cost, kind="stable")[:world]                                                 # the heaviest pairs: one per rank
+    assert sorted(int(np.flatnonzero([h in p for p in parts])[0]) for h in heavy) == list(range(world))
+    assert abs(cost[parts[0]].sum() - cost[parts[1]].sum()) <= cost.max()
     assert np.array_equal(rows.numpy(), single_rows) and np.array_equal(st.numpy(), single_st)      # bit for bit
     q.put((rank, float((emb - full).abs().max()), float((prob - prob_full[lo:hi]).abs().max()), tuple(emb.shape)))
     dist.barrier()

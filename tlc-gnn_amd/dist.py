@@ -3,8 +3,8 @@
 The reference is single-process, single-device (no torch.distributed, no DataParallel: SURVEY.md §2.1), so this is
 new design, kept to what the path needs:
 
-  * PD/PI per pair and the decode are independent units: the pair list is cut into contiguous shards, the (tiny) CSR is
-    replicated, NO data-path collective.
+  * PD/PI per pair and the decode are independent units: the pair list is dealt to the ranks by descending estimated cost
+    (or cut into contiguous shards), the (tiny) CSR is replicated, NO data-path collective.
   * The GCN encoder is node-row sharded: every rank projects and aggregates its block of rows and the blocks are
     exchanged with ONE all-gather per layer ([N,100] and [N,16] fp32: ~1 MB per link on PubMed, latency-bound on the
     7 point-to-point xGMI links, hence a single fused collective per layer rather than per-bucket traffic).
@@ -61,20 +61,67 @@ def pair_cost(ub, pairs):
     return 8.0 + np.minimum(ub[pairs[:, 0]], ub[pairs[:, 1]])
 
 
-def pd_pi_batch_sharded(run, pairs, world, rank, cost=None, gather=None):
-    """The pair list of get_pimg_for_all_edges (sg2dgm/riccidist2dgm.py:362-370; the reference maps its ThreadPool over exactly
-    this list) cut into `world` contiguous shards of equal summed cost; rank `rank` runs its own shard, no data-path collective.
+def shard_pairs_interleaved(cost, world):
+    """Deal the pair list to `world` ranks by DESCENDING cost, boustrophedon (0 1 .. w-1 w-1 .. 1 0 0 1 ..): every rank gets
+    its share of the heavy tail instead of whoever owns the stretch of the list where the hub pairs sit -- a contiguous cut of
+    504 514 near pairs at equal summed cost gave the ranks 218 090 / 286 424 pairs and very different slowest vicinities.
+    Returns `world` ascending index arrays (a partition of range(len(cost))); deterministic, so every rank computes all of them."""
+    cost = np.asarray(cost, dtype=np.float64)
+    order = np.argsort(-cost, kind="stable")
+    pos = np.arange(len(order))
+    lap, k = np.divmod(pos, world)
+    owner = np.where(lap % 2 == 0, k, world - 1 - k)
+    return [np.sort(order[owner == r]) for r in range(world)]
 
+
+def pd_pi_batch_sharded(run, pairs, world, rank, cost=None, gather=None, scheme="interleaved"):
+    """The pair list of get_pimg_for_all_edges (sg2dgm/riccidist2dgm.py:362-370; the reference maps its ThreadPool over exactly
+    this list) cut into `world` shards; rank `rank` runs its own shard, no data-path collective.
+
+    scheme "interleaved" (with a cost): shard_pairs_interleaved, the rows come back to list order through the index arrays;
+    "contiguous": contiguous shards of equal summed cost (or of equal length without a cost).
     run(pairs_shard) -> (rows [k, 25], status [k]) is the per-GPU path (DeviceGraph.pd_pi_batch in the product).
-    Returns (rows, status, (lo, hi)); with gather=callable the shards of all ranks are exchanged by it (see gather_shards)
-    and the full arrays come back in list order."""
+    Returns (rows, status, part) with part = the (lo, hi) of a contiguous shard or the index array of an interleaved one; with
+    gather=callable the shards of all ranks are exchanged by it (gather_shards / gather_shards_indexed, chosen by the
+    scheme) and the full arrays come back in list order."""
     n = len(pairs)
+    if cost is not None and scheme == "interleaved" and world > 1:
+        parts = shard_pairs_interleaved(cost, world)
+        mine = parts[rank]
+        import torch
+        idx = torch.as_tensor(mine, device=pairs.device) if type(pairs).__module__.startswith("torch") else mine
+        rows, status = run(pairs[idx])
+        if gather is None:
+            return rows, status, mine
+        g = gather_shards_indexed if gather is gather_shards else gather
+        return g(rows, parts), g(status, parts), mine
     bounds = shard_pairs_by_cost(cost, world) if cost is not None else [shard_bounds(n, world, r)[0] for r in range(world)] + [n]
     lo, hi = bounds[rank], bounds[rank + 1]
     rows, status = run(pairs[lo:hi])
     if gather is None:
         return rows, status, (lo, hi)
     return gather(rows, bounds), gather(status, bounds), (lo, hi)
+
+
+def gather_shards_indexed(local, parts, group=None):
+    """Interleaved shards -> the whole array in list order on every rank: ONE all_gather_into_tensor over blocks padded to the
+    largest shard, then every block is scattered to its rows' list positions (parts[r] = the positions of rank r's rows)."""
+    import torch
+    import torch.distributed as dist
+    world = len(parts)
+    if world == 1:
+        return local
+    sizes = [len(p) for p in parts]
+    blk = max(max(sizes), 1)
+    tail = tuple(local.shape[1:])
+    send = torch.zeros((blk,) + tail, dtype=local.dtype, device=local.device)
+    send[:local.shape[0]] = local
+    recv = torch.empty((world * blk,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    out = torch.empty((sum(sizes),) + tail, dtype=local.dtype, device=local.device)
+    for r in range(world):
+        out[torch.as_tensor(parts[r], device=local.device)] = recv[r * blk:r * blk + sizes[r]]
+    return out
 
 
 def gather_shards(local, bounds, group=None):
