@@ -242,6 +242,25 @@ int tlc_gat_layer_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d
                       const float* d_Wl, const float* d_att, const float* d_Wij, const float* d_bias,
                       float prelu_slope, float* d_work, float* d_out, void* stream);
 
+/* ---- the diagram loss of PDGNN training ------------------------------------------------------------
+ * `wasserstein_distance(X, Y, order=p, internal_p=inf, enable_autodiff=True, num_models=1)` of
+ * Knowledge_Distillation/wasserstein.py:198-379, as called by Teacher_model.py:131 (compute_PD_loss, kernel='wasserstein'),
+ * for a batch of diagram pairs: problem b has predicted points X[xoff[b] .. xoff[b+1]) and target points Y[yoff[b] .. yoff[b+1]),
+ * (birth, death) float64 pairs.  Every predicted point goes to a target point (each target takes exactly one) or to the diagonal;
+ * cost = ||X_i - Y_j||_inf ^ p, resp. ((death - birth) / 2) ^ p (:45-67); the optimum is found by the Hungarian method on the
+ * device, one wavefront per problem (the reference calls POT's ot.emd: third-party, parity unpinned -- the optimal cost is
+ * unique, the choice among tied optima is not reproduced).
+ *   d_loss[b] = (sum over the matched distances d_k of |d_k|^p)^(1/p)   (:303-372; order p = 1 or 2)
+ *   d_wxy / d_wxd[b] = the same norm over the point-point pairs / the points sent to the diagonal (what the reference logs)
+ *   d_assign[i] = problem-local target index of predicted point i, -1 = diagonal
+ *   d_gradX[i] (may be null) = d loss[b] / d X_i: what `loss.backward()` leaves on the predicted diagram
+ *   d_status[b]: 0 ok; 1 = fewer predicted than target points (the reference's transport has negative diagonal mass: no
+ *   result, loss 0); 2 = more than 512 predicted points (not supported: loss 0).  max_points: an upper bound of the predicted
+ *   points of one problem (selects the kernel variant). */
+int tlc_w2_partial_matching(int32_t n_problems, const int64_t* d_xoff, const double* d_X, const int64_t* d_yoff,
+                            const double* d_Y, int order, int32_t max_points, double* d_loss, double* d_wxy, double* d_wxd,
+                            int32_t* d_assign, double* d_gradX, uint8_t* d_status, void* stream);
+
 /* MessagePassing.aggregate (Knowledge_Distillation/message_passing.py:275-293): torch_scatter.scatter(inputs, index, dim=0,
  * dim_size=n_out, reduce) with reduce 0 = sum, 1 = mean, 2 = min, 3 = max; empty segments give 0, as torch_scatter does.
  *   d_index int64[n_src]; d_src float32[n_src,k]; d_out float32[n_out,k]; d_count_work int32[n_out] (not needed for sum).

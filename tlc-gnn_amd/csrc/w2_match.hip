@@ -1,0 +1,220 @@
+// w2_match.hip -- the diagram loss of PDGNN training: partial-matching Wasserstein distance between a predicted and a target
+// persistence diagram.
+//
+// Replaces Knowledge_Distillation/wasserstein.py:198-379 (`wasserstein_distance(X, Y, order=p, enable_autodiff=True,
+// num_models=1)`, called from Teacher_model.py:107-139 `compute_PD_loss(kernel='wasserstein')`): the reference builds the
+// cost matrix  C[i, j] = ||X_i - Y_j||_inf ^ p,  C[i, m] = ((X_i.y - X_i.x) / 2) ^ p  (:45-67), gives every predicted point
+// mass 1, every target point mass 1 and the diagonal mass n - m (:262-264), solves the transport with POT's `ot.emd`
+// (third-party, absent here), and sums the matched distances:  loss = (sum_k |d_k|^p)^(1/p)  over the X-Y pairs and the
+// points sent to the diagonal (:303-372; with num_models = 1 every diagonal point is kept, :329-337).
+//
+// With unit masses the transport is an ASSIGNMENT: n rows (predicted points) onto m target columns plus n - m copies of the
+// diagonal.  One wavefront per diagram pair solves it with the shortest-augmenting-path (Hungarian) method, lanes = columns:
+// the cost of (row, column) is recomputed from the two points (no matrix is stored), column duals / slack in registers, row
+// duals, the column -> row map and the alternating-path links in LDS; O(n^2) wavefront steps of ~60 instructions (n <= 512).
+// Also returned: which target every predicted point went to, the two partial sums the reference logs (wxy, wxd) and the
+// gradient of the loss with respect to the predicted points (what `loss.backward()` would put on PD-hat).
+//
+// PARITY UNPINNED: `ot.emd` is not available; the optimal COST is unique and is checked against
+// scipy.optimize.linear_sum_assignment (oracle/w2_ref.py, tests/test_gpu_train.py); among several optimal assignments
+// (ties) `ot.emd` may pick another one than this kernel.
+#include "tlc_common.h"
+
+namespace {
+
+struct W2Params {
+    int n_pairs;
+    const long long* xoff;     // [B+1] rows of X per problem
+    const double* X;           // [sum n, 2] predicted (birth, death)
+    const long long* yoff;     // [B+1]
+    const double* Y;           // [sum m, 2] target
+    int order;                 // p: 1 or 2
+    double* loss;              // [B]
+    double* wxy;               // [B]
+    double* wxd;               // [B]
+    int* assign;               // [sum n]: target index (problem-local), -1 = diagonal
+    double* gradX;             // [sum n, 2] or null
+    unsigned char* status;     // [B]: 0 ok, 1 fewer predicted than target points, 2 more than 64 * CPL predicted points
+};
+
+__device__ __forceinline__ double w2_pow(double d, int order) { return order == 2 ? d * d : d; }
+
+template <int CPL>
+__global__ __launch_bounds__(64) void tlc_w2_match_kernel(W2Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char w2_lds[];
+    constexpr int NMAX = 64 * CPL;
+    double* xs = (double*)w2_lds;              // [NMAX] predicted births
+    double* ys = xs + NMAX;                    // [NMAX] predicted deaths
+    double* cxd = ys + NMAX;                   // [NMAX] cost of the diagonal for row i
+    double* u = cxd + NMAX;                    // [NMAX] row duals
+    int* pcol = (int*)(u + NMAX);              // [NMAX] row assigned to column j, -1 = free
+    int* way = pcol + NMAX;                    // [NMAX] previous column on the alternating path, -1 = the start
+    const int lane = tlc_lane();
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    auto fence = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    for (int b = blockIdx.x; b < p.n_pairs; b += gridDim.x) {
+        const long long x0 = p.xoff[b], y0 = p.yoff[b];
+        const int n = (int)(p.xoff[b + 1] - x0), m = (int)(p.yoff[b + 1] - y0);
+        if (n < m || n > NMAX) {
+            // (n < m: the diagonal would need negative mass, wasserstein.py:264 -- the reference's transport has no solution)
+            if (lane == 0) { p.status[b] = n < m ? 1 : 2; p.loss[b] = 0.0; p.wxy[b] = 0.0; p.wxd[b] = 0.0; }
+            for (int i = lane; i < n; i += 64) { p.assign[x0 + i] = -1; if (p.gradX) { p.gradX[2 * (x0 + i)] = 0.0; p.gradX[2 * (x0 + i) + 1] = 0.0; } }
+            continue;
+        }
+        for (int i = lane; i < n; i += 64) {
+            const double bx = p.X[2 * (x0 + i)], by = p.X[2 * (x0 + i) + 1];
+            xs[i] = bx; ys[i] = by;
+            cxd[i] = w2_pow((by - bx) * 0.5, p.order);        // _dist_to_diag, internal_p = inf (:30-42)
+            u[i] = 0.0; pcol[i] = -1;
+        }
+        double yx[CPL], yy[CPL], v[CPL], minv[CPL];
+        bool used[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = lane + 64 * c;
+            yx[c] = yy[c] = 0.0;
+            if (j < m) { yx[c] = p.Y[2 * (y0 + j)]; yy[c] = p.Y[2 * (y0 + j) + 1]; }
+            v[c] = 0.0;
+        }
+        fence();
+        for (int i = 0; i < n; ++i) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) { minv[c] = INF; used[c] = false; }
+            int i0 = i, j0 = -1;
+            for (;;) {
+                const double xi = xs[i0], yi = ys[i0], ui = u[i0], cd = cxd[i0];
+                double best = INF;
+                int bj = -1;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const int j = lane + 64 * c;
+                    if (j < n && !used[c]) {
+                        double cost = cd;
+                        if (j < m) {
+                            const double dx = fabs(xi - yx[c]), dy = fabs(yi - yy[c]);
+                            cost = w2_pow(dx > dy ? dx : dy, p.order);             // chebyshev ^ order (:59-60)
+                        }
+                        const double cur = cost - ui - v[c];
+                        if (cur < minv[c]) { minv[c] = cur; way[j] = j0; }
+                        if (minv[c] < best) { best = minv[c]; bj = j; }
+                    }
+                }
+                const double delta = tlc_wave_min_f64(best);
+                const unsigned long long who = __ballot(best == delta && bj >= 0);
+                const int j1 = __builtin_amdgcn_readlane(bj, __builtin_ctzll(who));
+                // dual update: rows of the used columns and the row that started the path go up, used columns go down,
+                // the slack of the others shrinks
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const int j = lane + 64 * c;
+                    if (j < n) {
+                        if (used[c]) { u[pcol[j]] += delta; v[c] -= delta; }
+                        else minv[c] -= delta;
+                    }
+                }
+                if (lane == 0) u[i] += delta;
+                j0 = j1;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) if (lane + 64 * c == j1) used[c] = true;
+                fence();
+                i0 = pcol[j1];
+                if (i0 < 0) break;
+            }
+            // augment along the alternating path (one lane: at most n links)
+            if (lane == 0) {
+                int j = j0;
+                while (j >= 0) {
+                    const int jp = way[j];
+                    pcol[j] = jp < 0 ? i : pcol[jp];
+                    j = jp;
+                }
+            }
+            fence();
+        }
+        // ---- the loss and its pieces (:303-372): matched distances d_k, loss = (sum |d_k|^p)^(1/p) -----------------------
+        double sxy = 0.0, sxd = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = lane + 64 * c;
+            if (j < n) {
+                const int i = pcol[j];
+                if (j < m) {
+                    const double dx = fabs(xs[i] - yx[c]), dy = fabs(ys[i] - yy[c]);
+                    const double d = dx > dy ? dx : dy;
+                    sxy += p.order == 2 ? d * d : d;
+                    p.assign[x0 + i] = j;
+                } else {
+                    const double d = fabs((ys[i] - xs[i]) * 0.5);
+                    sxd += p.order == 2 ? d * d : d;
+                    p.assign[x0 + i] = -1;
+                }
+            }
+        }
+        for (int o = 32; o; o >>= 1) { sxy += __shfl_xor(sxy, o); sxd += __shfl_xor(sxd, o); }
+        const double tot = sxy + sxd;
+        const double L = p.order == 2 ? sqrt(tot) : tot;
+        if (lane == 0) {
+            p.status[b] = 0;
+            p.loss[b] = L;
+            p.wxy[b] = p.order == 2 ? sqrt(sxy) : sxy;
+            p.wxd[b] = p.order == 2 ? sqrt(sxd) : sxd;
+        }
+        // ---- d loss / d X: through the matched distances only (the matching is piecewise constant) -------------------------
+        if (p.gradX) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int j = lane + 64 * c;
+                if (j < n) {
+                    const int i = pcol[j];
+                    double gx = 0.0, gy = 0.0;
+                    if (j < m) {
+                        const double ex = yx[c] - xs[i], ey = yy[c] - ys[i];          // Y - X (:311)
+                        const double ax = fabs(ex), ay = fabs(ey);
+                        const double d = ax > ay ? ax : ay;
+                        const double w = p.order == 2 ? (L > 0.0 ? d / L : 0.0) : 1.0;   // dL/dd
+                        if (ax >= ay) gx = -w * (ex > 0.0 ? 1.0 : (ex < 0.0 ? -1.0 : 0.0));
+                        else gy = -w * (ey > 0.0 ? 1.0 : (ey < 0.0 ? -1.0 : 0.0));
+                    } else {
+                        const double s = (ys[i] - xs[i]) * 0.5;                          // signed distance to the diagonal
+                        const double w = p.order == 2 ? (L > 0.0 ? s / L : 0.0) : (s > 0.0 ? 1.0 : (s < 0.0 ? -1.0 : 0.0));
+                        gx = -0.5 * w; gy = 0.5 * w;
+                    }
+                    p.gradX[2 * (x0 + i)] = gx;
+                    p.gradX[2 * (x0 + i) + 1] = gy;
+                }
+            }
+        }
+        fence();
+    }
+}
+
+template <int CPL>
+static int launch_w2(const W2Params& p, hipStream_t s) {
+    const size_t lds = (size_t)64 * CPL * (4 * 8 + 2 * 4);
+    if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_w2_match_kernel<CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = p.n_pairs < 16384 ? p.n_pairs : 16384;
+    hipLaunchKernelGGL((tlc_w2_match_kernel<CPL>), dim3(grid), dim3(64), lds, s, p);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
+}  // namespace
+
+// max_points: an upper bound of the predicted points of one problem (the caller knows its offsets): picks the kernel variant
+// (64 / 128 / 256 / 512 columns); problems beyond 512 predicted points get status 2.
+extern "C" int tlc_w2_partial_matching(int32_t n_problems, const int64_t* d_xoff, const double* d_X, const int64_t* d_yoff,
+                                       const double* d_Y, int order, int32_t max_points, double* d_loss, double* d_wxy,
+                                       double* d_wxd, int32_t* d_assign, double* d_gradX, uint8_t* d_status, void* stream) {
+    TLC_REQUIRE(n_problems >= 0, "n_problems < 0");
+    TLC_REQUIRE(order == 1 || order == 2, "order must be 1 or 2");
+    if (n_problems == 0) return TLC_OK;
+    TLC_REQUIRE(d_xoff && d_yoff && d_loss && d_wxy && d_wxd && d_assign && d_status, "null pointer");
+    W2Params p;
+    p.n_pairs = n_problems; p.xoff = (const long long*)d_xoff; p.X = d_X; p.yoff = (const long long*)d_yoff; p.Y = d_Y;
+    p.order = order; p.loss = d_loss; p.wxy = d_wxy; p.wxd = d_wxd; p.assign = d_assign; p.gradX = d_gradX; p.status = d_status;
+    hipStream_t s = (hipStream_t)stream;
+    if (max_points <= 64) return launch_w2<1>(p, s);
+    if (max_points <= 128) return launch_w2<2>(p, s);
+    if (max_points <= 256) return launch_w2<4>(p, s);
+    return launch_w2<8>(p, s);
+}

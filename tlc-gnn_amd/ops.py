@@ -202,6 +202,33 @@ def scatter(src, index, dim_size, reduce="sum"):
     return out
 
 
+@_lib.on_device_of
+def w2_partial_matching(xoff, X, yoff, Y, order=2, want_grad=True, max_points=None):
+    """PDGNN's diagram loss for a batch of (predicted, target) diagram pairs (Knowledge_Distillation/wasserstein.py:198-379 with
+    num_models = 1): xoff / yoff int64[B+1] offsets, X / Y float64[., 2] CUDA tensors.
+    -> dict(loss[B], wxy[B], wxd[B], assign[sum n] (target index or -1 = diagonal), grad[sum n, 2] (d loss / d X), status[B])."""
+    torch = _lib.require_gpu()
+    B = xoff.numel() - 1
+    dev = X.device
+    X = X.to(torch.float64).contiguous()
+    Y = Y.to(torch.float64).contiguous()
+    nx = int(X.shape[0])
+    if max_points is None:
+        max_points = int((xoff[1:] - xoff[:-1]).max().item()) if B > 0 else 0
+    loss = torch.zeros(max(B, 1), dtype=torch.float64, device=dev)
+    wxy = torch.zeros_like(loss)
+    wxd = torch.zeros_like(loss)
+    assign = torch.full((max(nx, 1),), -1, dtype=torch.int32, device=dev)
+    grad = torch.zeros((max(nx, 1), 2), dtype=torch.float64, device=dev) if want_grad else None
+    status = torch.zeros(max(B, 1), dtype=torch.uint8, device=dev)
+    rc = _lib.lib().tlc_w2_partial_matching(C.c_int32(B), _lib.ptr(xoff.to(torch.int64).contiguous()), _lib.ptr(X) if nx else None,
+                                            _lib.ptr(yoff.to(torch.int64).contiguous()), _lib.ptr(Y) if Y.numel() else None,
+                                            C.c_int(order), C.c_int32(max_points), _lib.ptr(loss), _lib.ptr(wxy), _lib.ptr(wxd),
+                                            _lib.ptr(assign), _lib.ptr(grad), _lib.ptr(status), _lib.stream_ptr())
+    _lib.check(rc, "tlc_w2_partial_matching")
+    return dict(loss=loss[:B], wxy=wxy[:B], wxd=wxd[:B], assign=assign[:nx], grad=None if grad is None else grad[:nx], status=status[:B])
+
+
 def capture(fn, warmup=2):
     """HIP graph of a forward closure: `fn` (C-ABI launches on the current stream, outputs in caller-held or graph-pool buffers,
     no host synchronisation inside) is warmed up on a side stream, captured once, and replayed with `.replay()`.
