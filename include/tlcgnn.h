@@ -261,6 +261,29 @@ int tlc_w2_partial_matching(int32_t n_problems, const int64_t* d_xoff, const dou
                             const double* d_Y, int order, int32_t max_points, double* d_loss, double* d_wxy, double* d_wxd,
                             int32_t* d_assign, double* d_gradX, uint8_t* d_status, void* stream);
 
+/* ---- what `loss.backward()` runs through the PDGNN layer and the edge head ---------------------------
+ * (Knowledge_Distillation/train_Teacher_Model.py:55-62 through gat_conv.py:113-216 and Teacher_model.py:53-59.)
+ * tlc_gat_layer_bwd: gradients of one layer, same operands as tlc_gat_layer_fwd.  Nothing of the forward is kept: the node rows,
+ * the row softmax and the channel-wise minima / maxima are recomputed (one wavefront per target row).  A tied minimum / maximum
+ * sends its gradient to the first edge of the row that attains it.
+ *   d_out  float32[n, 2*c_out]: the forward's output, read only when prelu_slope >= 0 (sign of the pre-activation); else may be NULL
+ *   d_gout float32[n, 2*c_out]: d loss / d out
+ *   d_gX   float32[n, c_in] or NULL (first layer);  d_gWl [c_out, c_in], d_gatt [c_out], d_gWij [c_out, 2*c_out], d_gbias [2*c_out]:
+ *   OVERWRITTEN.   d_work float32[n * (8*c_out + 2) + 2*c_out*c_out] scratch.   c_out in {8,16,32,64}, c_in <= 64.
+ * Float atomics towards the sources of the edges and in the weight reductions: the summation order is not fixed. */
+int tlc_gat_layer_bwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_src, const float* d_X, int32_t c_in,
+                      int32_t c_out, const float* d_Wl, const float* d_att, const float* d_Wij, float prelu_slope,
+                      const float* d_out, const float* d_gout, float* d_gX, float* d_gWl, float* d_gatt, float* d_gWij,
+                      float* d_gbias, float* d_work, void* stream);
+
+/* tlc_edge_head_bwd: gradients of tlc_edge_head_fwd.  d_gpd float32[n_edges, 2] = d loss / d pd.
+ *   d_gX float32[n_nodes, c] is ADDED to (the caller zeroes it); d_gW5 [hidden, 2c], d_gb5 [hidden], d_gW6 [2, hidden], d_gb6 [2]:
+ *   OVERWRITTEN.   d_work float32[n_edges * (2*c + 2*hidden)] scratch.   hidden in {16,32,64}. */
+int tlc_edge_head_bwd(int64_t n_edges, const int32_t* d_src, const int32_t* d_dst, const float* d_X, int32_t c,
+                      const float* d_W5, const float* d_b5, int32_t hidden, float prelu_slope, const float* d_W6,
+                      const float* d_gpd, float* d_gX, float* d_gW5, float* d_gb5, float* d_gW6, float* d_gb6,
+                      float* d_work, void* stream);
+
 /* MessagePassing.aggregate (Knowledge_Distillation/message_passing.py:275-293): torch_scatter.scatter(inputs, index, dim=0,
  * dim_size=n_out, reduce) with reduce 0 = sum, 1 = mean, 2 = min, 3 = max; empty segments give 0, as torch_scatter does.
  *   d_index int64[n_src]; d_src float32[n_src,k]; d_out float32[n_out,k]; d_count_work int32[n_out] (not needed for sum).

@@ -83,3 +83,161 @@ def test_partial_matching_status_codes_and_empty_diagrams():
     assert loss[1] == 0.0
     d = (X[2][:, 1] - X[2][:, 0]) * 0.5
     assert abs(loss[2] - np.sqrt((d ** 2).sum())) < 1e-14 and (r["assign"].cpu().numpy()[3:8] == -1).all()
+
+
+# ---- backward of the PDGNN layer, the edge head and the whole training step -------------------------------------------------
+# against torch.autograd of the CPU restatement (oracle/lp_forward_ref.py), fp32, tolerance 1e-4 of the gradient's largest entry
+# (float atomics on the device, a different summation order on the CPU).
+def _rel(a, b):
+    a = a.detach().cpu().double().reshape(-1); b = b.detach().cpu().double().reshape(-1)
+    return float((a - b).abs().max() / max(1e-12, float(b.abs().max())))
+
+
+def _random_graph(rs, n, m, torch):
+    s = rs.randint(0, n, size=m); t = rs.randint(0, n, size=m)
+    keep = s != t
+    e = np.unique(np.stack([s[keep], t[keep]]), axis=1)          # no duplicate edges (add_self_loops convention of the callers)
+    loops = np.arange(n)
+    return torch.tensor(np.concatenate([e, np.stack([loops, loops])], axis=1), dtype=torch.int64)
+
+
+@pytest.mark.parametrize("c_in,c_out,slope", [(1, 32, 0.1), (64, 32, 0.1), (64, 16, -1.0), (5, 8, 0.1), (64, 64, -1.0)])
+@pytest.mark.parametrize("n,m", [(300, 2400), (7, 12), (1, 0)])
+def test_gat_layer_backward_matches_autograd_of_the_restatement(c_in, c_out, slope, n, m):
+    import torch
+    import torch.nn.functional as F
+    from oracle import lp_forward_ref as ref
+    from tlc_gnn_amd import ops
+    from tlc_gnn_amd.Knowledge_Distillation.gat_conv import GATConv
+    rs = np.random.RandomState(c_in * 100 + c_out + n)
+    torch.manual_seed(c_in + c_out + n)
+    ei = _random_graph(rs, n, m, torch)
+    x = torch.randn(n, c_in)
+    wl = (torch.randn(c_out, c_in) * (0.5 / np.sqrt(c_in))).requires_grad_()
+    att = (torch.randn(c_out) * 0.5).requires_grad_()
+    wij = (torch.randn(c_out, 2 * c_out) * (0.7 / np.sqrt(c_out))).requires_grad_()
+    bias = (torch.randn(2 * c_out) * 0.2).requires_grad_()
+    xr = x.clone().requires_grad_()
+    out_ref = ref.gat_conv(xr, ei, wl, att, wij, bias)
+    if slope >= 0:
+        out_ref = F.prelu(out_ref, torch.tensor(slope))
+    G = torch.randn(n, 2 * c_out)
+    (out_ref * G).sum().backward()
+    rowptr, col = GATConv.csr_by_target(ei.cuda(), n)
+    out = ops.gat_layer(rowptr, col, x.cuda(), wl.detach().cuda(), att.detach().cuda(), wij.detach().cuda(), bias.detach().cuda(), prelu_slope=slope)
+    assert _rel(out, out_ref) <= 2e-5
+    gx, gwl, gatt, gwij, gbias = ops.gat_layer_bwd(rowptr, col, x.cuda(), wl.detach().cuda(), att.detach().cuda(), wij.detach().cuda(),
+                                                   slope, out, G.cuda())
+    for name, got, want in (("x", gx, xr.grad), ("lin_l", gwl, wl.grad), ("att", gatt, att.grad), ("lin_ij", gwij, wij.grad),
+                            ("bias", gbias, bias.grad)):
+        assert got.shape == want.shape, name
+        assert _rel(got, want) <= 1e-4, (name, _rel(got, want))
+
+
+@pytest.mark.parametrize("n,m,c,hidden", [(200, 1500, 32, 32), (9, 20, 32, 32), (50, 300, 16, 16), (5, 0, 32, 32)])
+def test_edge_head_backward_matches_autograd(n, m, c, hidden):
+    import torch
+    import torch.nn.functional as F
+    from tlc_gnn_amd import ops
+    rs = np.random.RandomState(n + m)
+    torch.manual_seed(n + m)
+    src = torch.tensor(rs.randint(0, n, size=m), dtype=torch.int64); dst = torch.tensor(rs.randint(0, n, size=m), dtype=torch.int64)
+    x = torch.randn(n, c, requires_grad=True)
+    w5 = (torch.randn(hidden, 2 * c) * 0.2).requires_grad_(); b5 = (torch.randn(hidden) * 0.2).requires_grad_()
+    w6 = (torch.randn(2, hidden) * 0.3).requires_grad_(); b6 = (torch.randn(2) * 0.1).requires_grad_()
+    h = F.prelu(F.linear(torch.cat((x[src], x[dst]), dim=1), w5, b5), torch.tensor(0.1))      # Teacher_model.py:54-59
+    pd = F.linear(h, w6, b6)
+    G = torch.randn(m, 2)
+    (pd * G).sum().backward()
+    d = lambda t: t.detach().cuda()
+    got = ops.edge_head_bwd(src.to(torch.int32).cuda(), dst.to(torch.int32).cuda(), d(x), d(w5), d(b5), 0.1, d(w6), G.cuda())
+    for name, g, want in zip(("x", "lin5.weight", "lin5.bias", "lin6.weight", "lin6.bias"), got, (x.grad, w5.grad, b5.grad, w6.grad, b6.grad)):
+        if m == 0:
+            assert float(g.abs().max()) == 0.0, name
+        else:
+            assert _rel(g, want) <= 1e-4, (name, _rel(g, want))
+
+
+def _teacher_params(model, torch):
+    params = {"prelu": torch.tensor(0.1)}
+    leaves = {}
+    for name in ("conv1", "conv2", "conv3", "conv4"):
+        c = getattr(model.DIM0_Model, name)
+        params[name] = {"lin_l": c.lin_l.weight.detach().clone().requires_grad_(), "att_l": c.att_l.detach().reshape(-1).clone().requires_grad_(),
+                        "lin_ij": c.lin_ij.weight.detach().clone().requires_grad_(), "bias": c.bias.detach().clone().requires_grad_()}
+        leaves["DIM0_Model.%s.lin_l.weight" % name] = params[name]["lin_l"]
+        leaves["DIM0_Model.%s.att_l" % name] = params[name]["att_l"]
+        leaves["DIM0_Model.%s.lin_ij.weight" % name] = params[name]["lin_ij"]
+        leaves["DIM0_Model.%s.bias" % name] = params[name]["bias"]
+    for k, mod, attr in (("lin5_w", "lin5", "weight"), ("lin5_b", "lin5", "bias"), ("lin6_w", "lin6", "weight"), ("lin6_b", "lin6", "bias")):
+        params[k] = getattr(getattr(model, mod), attr).detach().clone().requires_grad_()
+        leaves["%s.%s" % (mod, attr)] = params[k]
+    return params, leaves
+
+
+@pytest.mark.parametrize("order", [2, 1])
+def test_teacher_training_step_gradients_match_autograd_of_the_restatement(order):
+    """model(filt, edge_index, PD, p, kernel='wasserstein', grad_PI=False); loss_0.backward() (train_Teacher_Model.py:51-62):
+    every parameter's .grad against autograd through oracle/lp_forward_ref.teacher_forward and the restated loss expression
+    evaluated on the matching the device found (the matching is a constant of the differentiation, wasserstein.py:303-372)."""
+    import torch
+    from oracle import lp_forward_ref as ref
+    from oracle import w2_ref
+    from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
+    torch.manual_seed(3)
+    rs = np.random.RandomState(3)
+    n, m = 60, 170
+    ei = _random_graph(rs, n, m, torch)
+    m = ei.shape[1] - n
+    f = torch.rand(n, 1)
+    b = rs.rand(m)
+    PD = torch.tensor(np.stack([b, b + rs.uniform(0, 0.6, size=m)], 1), dtype=torch.float32)
+    model = Teacher_Model(type='GAT', dropout=0.0)
+    with torch.no_grad():
+        for conv in (model.DIM0_Model.conv1, model.DIM0_Model.conv2, model.DIM0_Model.conv3, model.DIM0_Model.conv4):
+            conv.bias.uniform_(-0.2, 0.2)
+            torch.nn.init.xavier_uniform_(conv.lin_ij.weight)
+    params, leaves = _teacher_params(model, torch)
+    model = model.cuda().train()
+    x0, img, loss0, lxy, lxd, lyd, _, _ = model(f.cuda(), ei.cuda(), PD.cuda(), kernel='wasserstein', p=order, grad_PI=False)
+    assert loss0.shape == (1,) and loss0.requires_grad and img.shape == (25,) and not img.requires_grad
+    loss0.backward()
+    # the restatement: same forward, the loss expression on the device's matching
+    _, pd_ref = ref.teacher_forward(f, ei, params)
+    assert _rel(x0, pd_ref) <= 2e-5
+    from tlc_gnn_amd import ops
+    r = ops.w2_partial_matching(torch.tensor([0, m]).cuda(), x0.detach().double(), torch.tensor([0, m]).cuda(), PD.double().cuda(), order=order)
+    assign = r["assign"].cpu().numpy()
+    loss_ref = w2_ref.loss_torch(pd_ref, PD, assign, order)
+    want_cost = w2_ref.partial_matching(pd_ref.detach().double().numpy(), PD.double().numpy(), order)[0]
+    assert abs(float(loss0.detach()) - float(want_cost)) <= 1e-5 * max(1.0, abs(float(want_cost)))          # the optimum (scipy), not just this matching
+    assert abs(float(loss0.detach()) - float(loss_ref.detach())) <= 1e-5 * max(1.0, abs(float(loss_ref.detach())))
+    loss_ref.backward()
+    named = dict(model.named_parameters())
+    checked = 0
+    for name, leaf in leaves.items():
+        got = named[name].grad
+        assert got is not None, name
+        assert _rel(got.reshape(leaf.shape), leaf.grad) <= 1e-4, (name, _rel(got.reshape(leaf.shape), leaf.grad))
+        checked += 1
+    assert checked == 20
+    for name in ("lin1.weight", "lin2.weight", "DIM0_Model.conv5.bias"):                             # not on the path (:86-101 commented out)
+        assert named[name].grad is None
+
+
+def test_teacher_train_mode_refuses_what_is_not_implemented():
+    import torch
+    from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
+    ei = torch.tensor([[0, 1, 0, 1], [1, 0, 0, 1]]).cuda()
+    f = torch.rand(2, 1).cuda()
+    PD = torch.tensor([[0.1, 0.5], [0.2, 0.3]]).cuda()
+    m = Teacher_Model(type='GAT').cuda().train()                       # dropout 0.2
+    with pytest.raises(NotImplementedError):
+        m(f, ei, PD, kernel='wasserstein', p=2, grad_PI=False)
+    m = Teacher_Model(type='GAT', dropout=0.0).cuda().train()
+    with pytest.raises(NotImplementedError):
+        m(f, ei, PD, kernel='sliced', grad_PI=False)
+    with pytest.raises(NotImplementedError):
+        m(f, ei, PD, kernel='wasserstein', grad_PI=True)
+    out = m(f, ei, PD, kernel='wasserstein', p=2, grad_PI=False)
+    assert out[2].requires_grad

@@ -1,11 +1,17 @@
-"""Drop-in for the forward of the reference's Knowledge_Distillation/Teacher_model.py (PDGNN), type='GAT'.
+"""Drop-in for the reference's Knowledge_Distillation/Teacher_model.py (PDGNN), type='GAT'.
 
-  Teacher_Model.__init__ :21-44, forward :46-104 (compute_loss=False, grad_PI=False: :53-59, :83-84),
+  Teacher_Model.__init__ :21-44, forward :46-104 (grad_PI=False: :53-59, :83-84), compute_PD_loss :106-137 (kernel='wasserstein'),
   Base_Model.__init__ :146-211 (GAT branch :182-189), Base_Model.forward :213-229.
 
 The whole forward stays on the GPU: four fused GAT layers, the edge head and the persistence image raster
 (`tlc_gat_layer_fwd`, `tlc_edge_head_fwd`, `tlc_pi_raster`); the reference copies the predicted diagram to the host and
-rasterises it with the Cython CPU code (:84).  Losses (Wasserstein / sliced) are training-only and out of scope.
+rasterises it with the Cython CPU code (:84).
+
+Training: with `compute_loss=True, kernel='wasserstein'` the diagram loss is the device matching
+(`tlc_w2_partial_matching`; the reference calls POT's ot.emd on the host, wasserstein.py:303) and `loss.backward()` runs
+`tlc_edge_head_bwd` and `tlc_gat_layer_bwd` (autograd.py).  What is NOT here: dropout (train mode needs dropout=0: a dropout
+mask cannot be checked against the reference's RNG stream), the 'sliced' kernel, grad_PI=True (the differentiable imager of
+:76-77; the training script passes grad_PI=False, train_Teacher_Model.py:51) and draw_fig.
 """
 import time
 
@@ -13,7 +19,7 @@ import torch
 import torch.nn.functional as F
 from torch.nn import Linear
 
-from .. import ops, engine
+from .. import ops, engine, autograd
 from .gat_conv import GATConv
 
 
@@ -34,8 +40,8 @@ class Base_Model(torch.nn.Module):
     def forward(self, x, edge_index):
         if x.size()[0] == 0:
             return torch.zeros([0, 2], device=x.device)
-        if self.training:
-            raise NotImplementedError("Base_Model (HIP): forward/eval only (dropout is the identity)")
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("Base_Model (HIP): train mode needs dropout=0 (F.dropout of :217-225 is not implemented)")
         csr = GATConv.csr_by_target(edge_index, x.shape[0])            # one CSR for the four layers of THIS call
         x = self.conv1(x, edge_index, prelu_slope=0.1, csr=csr)       # conv -> F.prelu(0.1) fused (:218-219)
         x = self.conv2(x, edge_index, prelu_slope=0.1, csr=csr)
@@ -61,29 +67,46 @@ class Teacher_Model(torch.nn.Module):
 
     def forward(self, x0, edge_index0, PD, kernel='sliced', M=50, p=1, pair_diagonal=False, draw_fig=False, fig_name='',
                 compute_loss=True, grad_PI=True, graph_ptr=None, edge_ptr=None):
-        """Reference signature; compute_loss / grad_PI must be False (forward only).
+        """Reference signature.  grad_PI must be False; compute_loss=True needs kernel='wasserstein' (p = 1 or 2) and returns
+        loss0 (differentiable), loss_xy0, loss_xd0, loss_yd0 like :63-64 (loss_yd0 is 0: with num_models=1 every target
+        point is matched, wasserstein.py:330-372).
 
         x0 [n,1] filtration, edge_index0 [2, m+n] with the n self loops LAST (train_Teacher_Model.py:43-44).
         Block-diagonal batches: pass graph_ptr (int64 [B+1] node offsets) and edge_ptr (int64 [B+1] offsets into the
         non-self-loop edges) to get one image per graph [B,25]; otherwise one image [25] for the whole input.
         """
-        if compute_loss or grad_PI or draw_fig:
-            raise NotImplementedError("Teacher_Model (HIP): forward only (compute_loss=False, grad_PI=False)")
+        if grad_PI or draw_fig:
+            raise NotImplementedError("Teacher_Model (HIP): grad_PI=False, draw_fig=False only")
+        if compute_loss and kernel != 'wasserstein':
+            raise NotImplementedError("Teacher_Model (HIP): compute_loss needs kernel='wasserstein'")
+        if compute_loss and pair_diagonal:
+            raise NotImplementedError("Teacher_Model (HIP): pair_diagonal (wasserstein_distance_inference) is not implemented")
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("Teacher_Model (HIP): train mode needs dropout=0")
         t1 = time.time()
         x = self.DIM0_Model(x0, edge_index0)
         n = x0.shape[0]
         m = edge_index0.shape[1] - n
         src = edge_index0[0, :m].to(torch.int32).contiguous()         # strips the appended self loops (:54-55)
         dst = edge_index0[1, :m].to(torch.int32).contiguous()
-        x = ops.edge_head(src, dst, x, self.lin5.weight.detach(), self.lin5.bias.detach(), 0.1,
-                          self.lin6.weight.detach(), self.lin6.bias.detach())                      # :56-59 (eval: no dropout)
+        if torch.is_grad_enabled() and (x.requires_grad or self.lin5.weight.requires_grad or self.lin6.weight.requires_grad):
+            x = autograd.edge_head(x, self.lin5.weight, self.lin5.bias, self.lin6.weight, self.lin6.bias, src, dst, 0.1)
+        else:
+            x = ops.edge_head(src, dst, x, self.lin5.weight.detach(), self.lin5.bias.detach(), 0.1,
+                              self.lin6.weight.detach(), self.lin6.bias.detach())                  # :56-59 (no dropout)
         t2 = time.time()
+        loss0 = loss_xy0 = loss_xd0 = loss_yd0 = None
+        if compute_loss:                                                                           # :61-64, compute_PD_loss :124-133
+            xoff = None if edge_ptr is None else edge_ptr.to(torch.int64)
+            loss, wxy, wxd = autograd.diagram_loss(x, PD.to(torch.float64), order=p, xoff=xoff, yoff=xoff)   # one point per edge
+            loss0, loss_xy0, loss_xd0 = loss.sum().reshape(1), wxy.sum().reshape(1), wxd.sum().reshape(1)
+            loss_yd0 = torch.zeros(1, dtype=loss0.dtype, device=loss0.device)
         x0_out = x
-        pts = x.to(torch.float64)
+        pts = x.detach().to(torch.float64)
         if edge_ptr is None:
             offs = torch.tensor([0, m], dtype=torch.int64, device=x.device)
             img = engine.pi_raster(offs, pts, 5)[0]                                                # :84, on the device
         else:
             img = engine.pi_raster(edge_ptr.to(torch.int64), pts, 5)
         t3 = time.time()
-        return x0_out, img, None, None, None, None, t2 - t1, t3 - t2
+        return x0_out, img, loss0, loss_xy0, loss_xd0, loss_yd0, t2 - t1, t3 - t2

@@ -1,16 +1,17 @@
-"""Drop-in for the reference's Knowledge_Distillation/gat_conv.py ("the PDGNN layer", README.md:70), forward only.
+"""Drop-in for the reference's Knowledge_Distillation/gat_conv.py ("the PDGNN layer", README.md:70).
 
   GATConv.__init__ :62-104, forward :113-181, message :183-200, aggregate :202-216.
 
 Tensor input, heads=1, new_node_feat=True, use_edge_attn=True, add_self_loops=True (what Teacher_model.py:182-189 builds)
-run as two HIP kernels behind `tlc_gat_layer_fwd` (include/tlcgnn.h); other configurations raise.
+run as two HIP kernels behind `tlc_gat_layer_fwd` (include/tlcgnn.h); other configurations raise.  With gradients enabled and
+an input or parameter that requires them the call goes through `autograd.GatLayer`, whose backward is `tlc_gat_layer_bwd`.
 """
 import math
 
 import torch
 from torch.nn import Linear, Parameter
 
-from .. import ops
+from .. import ops, autograd
 
 
 def glorot(tensor):
@@ -62,8 +63,11 @@ class GATConv(torch.nn.Module):
             raise NotImplementedError("GATConv (HIP): tensor input, size=None, return_attention_weights=None only")
         assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
         if self.training and self.dropout > 0:
-            raise NotImplementedError("GATConv (HIP): attention dropout in training mode is not implemented (forward/eval only)")
+            raise NotImplementedError("GATConv (HIP): attention dropout in training mode is not implemented")
         rowptr, col = csr if csr is not None else self.csr_by_target(edge_index, x.shape[0])
+        if torch.is_grad_enabled() and (x.requires_grad or self.lin_l.weight.requires_grad or self.att_l.requires_grad
+                                        or self.lin_ij.weight.requires_grad or self.bias.requires_grad):
+            return autograd.gat_layer(x, self.lin_l.weight, self.att_l, self.lin_ij.weight, self.bias, rowptr, col, prelu_slope)
         return ops.gat_layer(rowptr, col, x, self.lin_l.weight.detach(), self.att_l.detach().reshape(-1),
                              self.lin_ij.weight.detach(), self.bias.detach(), prelu_slope=prelu_slope)
 

@@ -1,0 +1,87 @@
+"""Autograd glue for PDGNN training: `loss.backward()` of the reference's training loop
+(Knowledge_Distillation/train_Teacher_Model.py:55-62) through the HIP kernels.
+
+torch.autograd only carries the graph: every forward and every backward below is one C-ABI call (`tlc_gat_layer_fwd/_bwd`,
+`tlc_edge_head_fwd/_bwd`, `tlc_w2_partial_matching`); nothing is recomputed with torch ops and there is no CPU path.
+"""
+import torch
+
+from . import ops
+
+
+class GatLayer(torch.autograd.Function):
+    """One PDGNN layer (gat_conv.py:113-216) with the PReLU that follows it in Base_Model.forward (Teacher_model.py:218-219)."""
+
+    @staticmethod
+    def forward(ctx, x, wl, att, wij, bias, rowptr, src, prelu_slope):
+        out = ops.gat_layer(rowptr, src, x, wl, att, wij, bias, prelu_slope=prelu_slope)
+        ctx.save_for_backward(x, wl, att, wij, out, rowptr, src)
+        ctx.prelu_slope = prelu_slope
+        ctx.att_shape = att.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, wl, att, wij, out, rowptr, src = ctx.saved_tensors
+        gx, gwl, gatt, gwij, gbias = ops.gat_layer_bwd(rowptr, src, x, wl, att, wij, ctx.prelu_slope, out, gout.contiguous(),
+                                                       need_gx=ctx.needs_input_grad[0])
+        return gx, gwl, gatt.reshape(ctx.att_shape), gwij, gbias, None, None, None
+
+
+class EdgeHead(torch.autograd.Function):
+    """lin6(prelu(lin5([x_s || x_t]))) per edge (Teacher_model.py:54-59)."""
+
+    @staticmethod
+    def forward(ctx, x, w5, b5, w6, b6, src, dst, prelu_slope):
+        pd = ops.edge_head(src, dst, x, w5, b5, prelu_slope, w6, b6)
+        ctx.save_for_backward(x, w5, b5, w6, src, dst)
+        ctx.prelu_slope = prelu_slope
+        return pd
+
+    @staticmethod
+    def backward(ctx, gpd):
+        x, w5, b5, w6, src, dst = ctx.saved_tensors
+        gx, gw5, gb5, gw6, gb6 = ops.edge_head_bwd(src, dst, x, w5, b5, ctx.prelu_slope, w6, gpd.contiguous())
+        return gx, gw5, gb5, gw6, gb6, None, None, None
+
+
+class DiagramLoss(torch.autograd.Function):
+    """`wasserstein_distance(PD_hat, PD, order=p, enable_autodiff=True, num_models=1)` (wasserstein.py:198-379) of one or more
+    (predicted, target) pairs: -> (loss [B], wxy [B], wxd [B]); only `loss` carries a gradient, like the reference's
+    (wxy / wxd are the logged parts)."""
+
+    @staticmethod
+    def forward(ctx, pd_hat, xoff, target, yoff, order):
+        r = ops.w2_partial_matching(xoff, pd_hat.detach(), yoff, target, order=order, want_grad=True)
+        bad = r["status"] != 0
+        if bool(bad.any()):
+            raise ValueError("diagram loss: status %s (1 = fewer predicted than target points, 2 = more than 512 predicted points)"
+                             % r["status"].tolist())
+        ctx.save_for_backward(r["grad"], xoff)
+        ctx.dtype = pd_hat.dtype
+        ctx.mark_non_differentiable(r["wxy"], r["wxd"])
+        return r["loss"].to(pd_hat.dtype), r["wxy"].to(pd_hat.dtype), r["wxd"].to(pd_hat.dtype)
+
+    @staticmethod
+    def backward(ctx, gloss, _gwxy, _gwxd):
+        grad, xoff = ctx.saved_tensors
+        cnt = xoff[1:] - xoff[:-1]
+        per_point = torch.repeat_interleave(gloss.to(torch.float64), cnt)          # d total / d loss[b] for each predicted point
+        return (grad * per_point.unsqueeze(1)).to(ctx.dtype), None, None, None, None
+
+
+def gat_layer(x, wl, att, wij, bias, rowptr, src, prelu_slope=-1.0):
+    return GatLayer.apply(x, wl, att, wij, bias, rowptr, src, float(prelu_slope))
+
+
+def edge_head(x, w5, b5, w6, b6, src, dst, prelu_slope):
+    return EdgeHead.apply(x, w5, b5, w6, b6, src, dst, float(prelu_slope))
+
+
+def diagram_loss(pd_hat, target, order=2, xoff=None, yoff=None):
+    dev = pd_hat.device
+    if xoff is None:
+        xoff = torch.tensor([0, pd_hat.shape[0]], dtype=torch.int64, device=dev)
+    if yoff is None:
+        yoff = torch.tensor([0, target.shape[0]], dtype=torch.int64, device=dev)
+    return DiagramLoss.apply(pd_hat, xoff, target, yoff, int(order))

@@ -16,7 +16,7 @@
 // gradient of the loss with respect to the predicted points (what `loss.backward()` would put on PD-hat).
 //
 // PARITY UNPINNED: `ot.emd` is not available; the optimal COST is unique and is checked against
-// scipy.optimize.linear_sum_assignment (oracle/w2_ref.py, tests/test_gpu_train.py); among several optimal assignments
+// scipy.optimize.linear_sum_assignment (tests/test_gpu_train.py); among several optimal assignments
 // (ties) `ot.emd` may pick another one than this kernel.
 #include "tlc_common.h"
 

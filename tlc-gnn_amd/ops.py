@@ -177,6 +177,51 @@ def edge_head(src, dst, x, w5, b5, prelu_slope, w6, b6, out=None):
     return out
 
 
+@_lib.on_device_of
+def gat_layer_bwd(rowptr, src, x, wl, att, wij, prelu_slope, out, gout, need_gx=True):
+    """Gradients of `gat_layer` (what autograd runs through Knowledge_Distillation/gat_conv.py:113-216):
+    -> (gX or None, gWl, gatt, gWij, gbias).  `out` is the forward's output (read for the fused PReLU only)."""
+    torch = _lib.require_gpu()
+    x = _f32(x)
+    n, c_in = x.shape
+    c_out = wl.shape[0]
+    dev = x.device
+    gx = torch.empty((n, c_in), dtype=torch.float32, device=dev) if need_gx else None
+    gwl = torch.empty((c_out, c_in), dtype=torch.float32, device=dev)
+    gatt = torch.empty(c_out, dtype=torch.float32, device=dev)
+    gwij = torch.empty((c_out, 2 * c_out), dtype=torch.float32, device=dev)
+    gbias = torch.empty(2 * c_out, dtype=torch.float32, device=dev)
+    work = torch.empty(max(n, 1) * (8 * c_out + 2) + 2 * c_out * c_out, dtype=torch.float32, device=dev)
+    rc = _lib.lib().tlc_gat_layer_bwd(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(src), _lib.ptr(x), C.c_int32(c_in), C.c_int32(c_out),
+                                      _lib.ptr(_f32(wl)), _lib.ptr(_f32(att).reshape(-1)), _lib.ptr(_f32(wij)), C.c_float(prelu_slope),
+                                      _lib.ptr(_f32(out)) if out is not None else None, _lib.ptr(_f32(gout)), _lib.ptr(gx),
+                                      _lib.ptr(gwl), _lib.ptr(gatt), _lib.ptr(gwij), _lib.ptr(gbias), _lib.ptr(work), _lib.stream_ptr())
+    _lib.check(rc, "tlc_gat_layer_bwd")
+    return gx, gwl, gatt, gwij, gbias
+
+
+@_lib.on_device_of
+def edge_head_bwd(src, dst, x, w5, b5, prelu_slope, w6, gpd):
+    """Gradients of `edge_head` (Teacher_model.py:54-59): -> (gX, gW5, gb5, gW6, gb6)."""
+    torch = _lib.require_gpu()
+    x = _f32(x)
+    E = src.numel()
+    n, c, hidden = x.shape[0], x.shape[1], w5.shape[0]
+    dev = x.device
+    gx = torch.zeros((n, c), dtype=torch.float32, device=dev)
+    gw5 = torch.empty((hidden, 2 * c), dtype=torch.float32, device=dev)
+    gb5 = torch.empty(hidden, dtype=torch.float32, device=dev)
+    gw6 = torch.empty((2, hidden), dtype=torch.float32, device=dev)
+    gb6 = torch.empty(2, dtype=torch.float32, device=dev)
+    work = torch.empty(max(E, 1) * (2 * c + 2 * hidden), dtype=torch.float32, device=dev)
+    rc = _lib.lib().tlc_edge_head_bwd(C.c_int64(E), _lib.ptr(src), _lib.ptr(dst), _lib.ptr(x), C.c_int32(c), _lib.ptr(_f32(w5)),
+                                      _lib.ptr(_f32(b5)), C.c_int32(hidden), C.c_float(prelu_slope), _lib.ptr(_f32(w6)),
+                                      _lib.ptr(_f32(gpd)), _lib.ptr(gx), _lib.ptr(gw5), _lib.ptr(gb5), _lib.ptr(gw6), _lib.ptr(gb6),
+                                      _lib.ptr(work), _lib.stream_ptr())
+    _lib.check(rc, "tlc_edge_head_bwd")
+    return gx, gw5, gb5, gw6, gb6
+
+
 REDUCE = {"add": 0, "sum": 0, "mean": 1, "min": 2, "max": 3}
 
 
