@@ -110,6 +110,33 @@ def test_medium_tier_cut_by_pos_edges(k_pos, many):
     g.close()
 
 
+def test_speculative_launches_beyond_their_reserved_slots():
+    """The MEDIUM-many-Pos tier kernel is submitted before the tier sizes are known, one workgroup per slot reserved from the
+    previous chunk's count; list positions beyond the slots are completed by a second launch, and MEDIUM / MID vicinities beyond
+    theirs run their cycle swap inside the tier kernel.  `spec_cap` = 8 slots puts most of this batch on those paths: same rows,
+    bit for bit, as with the slots of the default sizing -- and the oracle's."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    rs = np.random.RandomState(77)
+    comps, pairs, base = [], [], 0
+    for n, k_pos in ((301, 130), (301, 50), (100, 30)):          # MEDIUM with many Pos edges, MEDIUM, MID
+        comps.append(hub_component(n, n - 1 + k_pos, rs, base))
+        pairs += [[base, base + k] for k in range(1, 31)]
+        base += n
+    e = np.concatenate(comps)
+    rowptr, col, w = synth.edges_to_csr(base, e, rs.uniform(-0.5, 0.9, size=len(e)))
+    pairs = np.array(pairs)[rs.permutation(len(pairs))]
+    g = engine.DeviceGraph(rowptr, col, w)
+    ref_out, ref_st = _check(g, torch, rowptr, col, w, pairs)
+    stats = g.stats()
+    assert stats["tier_medium_many_pos"] == 30 and stats["tier_medium"] == 60 and stats["tier_mid"] == 30
+    g.set_option("spec_cap", 8)
+    for _ in range(2):                                           # (twice: the second chunk sizes its launch from the first)
+        out, st = _check(g, torch, rowptr, col, w, pairs)
+        assert np.array_equal(out, ref_out) and np.array_equal(st, ref_st)
+    g.close()
+
+
 @pytest.mark.parametrize("decimals", [None, 1])
 def test_tiny_tier_boundaries_on_and_off(decimals):
     """Components at the limits of the lane-per-subgraph kernel (16 nodes / 24 edges) and just beyond, and the smallest ones:

@@ -157,6 +157,9 @@ struct tlc_graph {
     // development / test switches (tlc_debug_set_option; initial values from the environment: TLC_EXTRACT, TLC_HEAVY, TLC_TINY)
     int opt_extract, opt_heavy, opt_tiny;
     int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
+    int opt_spec_cap;                   // tests: upper bound of the slots reserved for the speculative launches (0 = none)
+    int opt_timing_every;               // measurement: kernel events on every n-th chunk only
+    unsigned timing_seq;
     int opt_tier_mask;                  // development: which tier kernels are launched at all (timing a tier alone; rows of the others are garbage)
     int opt_x_region, opt_x_bump_min;   // arena entries per workgroup region / minimum bump area of the extraction (tests shrink them)
 };
@@ -425,7 +428,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     g->device = device; g->n_nodes = n_nodes; g->nnz = nnz; g->nw = nw; g->vic_lds = lds;
     auto env_on = [](const char* name) { const char* v = getenv(name); return !(v && v[0] == '0'); };
     g->opt_extract = env_on("TLC_EXTRACT"); g->opt_heavy = env_on("TLC_HEAVY"); g->opt_tiny = env_on("TLC_TINY");
-    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = 0x7f;
+    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = 0x7f; g->opt_timing_every = 1;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
@@ -444,8 +447,12 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     //   per workspace: main (normal; carries what the caller's stream carries for a single stream-ordered chunk) and
     //                  side[4], the early chain (high) -- the lead-in of the next chunk must not queue behind this chunk's tiers;
     //   shared by the workspaces (a chunk's tier kernels queue behind the previous chunk's, which is the order they finish in
-    //                  anyway): side[0] SMALL, side[5] TINY (low), side[3] MID, side[6] MEDIUM and its rarely used twin
+    //                  anyway): side[0] SMALL, side[5] TINY, side[3] MID (low), side[6] MEDIUM and its rarely used twin
     //                  side[2] (normal), side[1] the heavy tiers the early pass did not take (high).
+    // Normal priority then holds the caller's stream, the two main streams and MEDIUM: four.  With MID there as well (round 2)
+    // the second workspace's main stream shared a hardware queue with the MID chain, and the lead-in of every other pipelined
+    // batch sat behind ~0.3 ms of tier + swap kernel: 45.8 -> 48.4 M images/s pipelined, 0.833 -> 0.840 ms for one batch alone
+    // (profiles/r03_async_timeline.txt shows the queue ids).
     // (Dedicated queues through hipExtStreamCreateWithCUMask -- with a full mask, or with CUs reserved for the whole-CU
     // workgroups of the LARGE tier -- were measured: 1.2 - 3.3 ms per batch instead of 0.9.  tools/probes/cumask_probe.hip.)
     int prio_lo = 0, prio_hi = 0;
@@ -467,7 +474,13 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
             if (k == 4) { if (i == 0) CK(hipStreamCreateWithPriority(&ws->side[k], hipStreamNonBlocking, prio_hi)); }
             else if (i > 0) ws->side[k] = g->ws[0].side[k];
             else if (k == 2) ws->side[k] = nullptr;                      // (= side[6], set below)
-            else CK(hipStreamCreateWithPriority(&ws->side[k], hipStreamNonBlocking, k == 1 ? prio_hi : ((k == 6 || k == 3) ? prio_mid : prio_lo)));
+            else {
+                int pr = k == 1 ? prio_hi : (k == 6 ? prio_mid : prio_lo);
+                // (development A/B, tools/gpu_prio_ab.sh: 0 low, 1 normal, 2 high)
+                const char* ev = k == 3 ? getenv("TLC_MID_PRIO") : (k == 6 ? getenv("TLC_MEDIUM_PRIO") : nullptr);
+                if (ev) pr = atoi(ev) == 0 ? prio_lo : (atoi(ev) == 1 ? prio_mid : prio_hi);
+                CK(hipStreamCreateWithPriority(&ws->side[k], hipStreamNonBlocking, pr));
+            }
             CK(hipEventCreateWithFlags(&ws->ev_join[k], hipEventDisableTiming));
         }
         if (i == 0) ws->side[2] = ws->side[6];
@@ -554,6 +567,11 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
                      double* d_out_f, int32_t* d_out_n, const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m,
                      int pi_enabled, hipStream_t s) {
     int rc;
+    // (development: TLC_HOST_TRACE=1 prints where the submitting thread spends a chunk -- front submitted, sizes seen, tiers submitted)
+    static const bool host_trace = getenv("TLC_HOST_TRACE") != nullptr;
+    const auto ht0 = std::chrono::steady_clock::now();
+    auto ht_us = [&]() { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - ht0).count() * 1e-3; };
+    double ht_front = 0, ht_seen = 0;
     if ((rc = ensure_pairs(g, ws, (size_t)n_pairs)) != TLC_OK) return rc;
     if ((rc = ensure_vic_scratch(g, ws, hop)) != TLC_OK) return rc;
     TLC_HIP_CHECK(hipMemsetAsync(ws->d_ctl, 0, (64 + 1024 + 8) * sizeof(int), s));       // control words, scan flags, statistics
@@ -587,7 +605,9 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         g->lds_attr_set = 1;
     }
     const int vgrid = std::min(n_pairs, g->vic_slots);
-    if (g->timing) {
+    // (opt_timing_every = n: only every n-th chunk carries the event records -- each costs the stream it is recorded on a few us)
+    const int tmask = (g->timing && (g->timing_seq++ % (unsigned)std::max(g->opt_timing_every, 1)) == 0) ? g->timing : 0;
+    if (tmask) {
         if (!g->ev_ring_ready) {
             for (int r = 0; r < TLC_TIMING_RING; ++r)
                 for (int k = 0; k < 16; ++k) TLC_HIP_CHECK(hipEventCreate(&g->ev_ring[r][k]));
@@ -599,8 +619,8 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         memset(g->ev_used, 0, 8);
     }
     g->last_n_pairs = n_pairs;
-#define T0(k, st) do { if ((g->timing >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k)], st)); } } while (0)
-#define T1(k, st) do { if ((g->timing >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k) + 1], st)); g->ev_used[k] = 1; } } while (0)
+#define T0(k, st) do { if ((tmask >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k)], st)); } } while (0)
+#define T1(k, st) do { if ((tmask >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k) + 1], st)); g->ev_used[k] = 1; } } while (0)
     // ---- early pass --------------------------------------------------------------------------------------------------------
     // The batch waits for its largest vicinity: 0.9 ms of mostly serial work that used to start only after COUNT, the scan,
     // the size publication and the heavy FILL (0.31 ms into the batch).  The pairs that can be that large are known up
@@ -780,6 +800,8 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         spec_cap[TLC_TIER_MID] = std::min(n_pairs, std::max(4096, ws->prev_tc[TLC_TIER_MID] + ws->prev_tc[TLC_TIER_MID] / 4));
         spec_cap[TLC_TIER_MEDIUM] = std::min(n_pairs, std::max(2048, ws->prev_tc[TLC_TIER_MEDIUM] + ws->prev_tc[TLC_TIER_MEDIUM] / 4));
         spec_cap[TLC_TIER_MEDHI] = std::min(n_pairs, std::max(1024, ws->prev_tc[TLC_TIER_MEDHI] + ws->prev_tc[TLC_TIER_MEDHI] / 4));
+        if (g->opt_spec_cap > 0)                                        // (tests: reach the paths beyond the reserved slots)
+            for (int t : {TLC_TIER_MID, TLC_TIER_MEDIUM, TLC_TIER_MEDHI}) spec_cap[t] = std::min(spec_cap[t], g->opt_spec_cap);
         // hand-off buffer: [MID | MEDHI (speculative launch) | MEDIUM]
         spec_base[TLC_TIER_MEDHI] = (size_t)spec_cap[TLC_TIER_MID] * tlc_handoff_slot_bytes(TLC_TIER_MID);
         spec_base[TLC_TIER_MEDIUM] = spec_base[TLC_TIER_MEDHI] + (size_t)spec_cap[TLC_TIER_MEDHI] * tlc_handoff_slot_bytes(TLC_TIER_MEDHI);
@@ -808,6 +830,7 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         pp.phase = 0;
         pp.grid = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr; pp.handoff = nullptr; pp.handoff_cap = 0;
     }
+    ht_front = ht_us();
     {
         // (hipStreamSynchronize would also wait for the kernels submitted behind the scan; the stream is only queried, now and
         // then, so that a fault surfaces instead of a spin)
@@ -824,6 +847,7 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         }
         TLC_REQUIRE(seen, "size publication did not arrive");
     }
+    ht_seen = ht_us();
     std::atomic_thread_fence(std::memory_order_acquire);
     const long long total = ws->h_sync->pub_total;
     int tc[TLC_N_TIERS];
@@ -869,6 +893,18 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
             // its cycle swap itself
             hand_base[TLC_TIER_MID] = 0;
             hand_base[TLC_TIER_MEDIUM] = spec_base[TLC_TIER_MEDIUM];
+        }
+        // the speculative launch had one workgroup per reserved slot: list positions beyond them get a launch of their own,
+        // behind it on s (tier kernel only: without a slot a subgraph's cycle swap runs in the tier kernel itself)
+        if (spec_done && tc[TLC_TIER_MEDHI] > spec_cap[TLC_TIER_MEDHI]) {
+            const int t = TLC_TIER_MEDHI;
+            pp.tier_list = ws->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t]; pp.tier_count_dev = nullptr;
+            pp.wi_base = spec_cap[t]; pp.grid = tc[t] - spec_cap[t]; pp.handoff_cap = spec_cap[t]; pp.phase = 1;
+            pp.handoff = ws->handoff + spec_base[t]; pp.handoff_stride = (long long)tlc_handoff_slot_bytes(t);
+            pp.abort_flag = nullptr; pp.dc_count = nullptr; pp.dc_list = nullptr;
+            pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
+            if (((g->opt_tier_mask >> t) & 1) && (rc = tlc_launch_pd_tier(t, pp, s)) != TLC_OK) return rc;
+            pp.wi_base = 0; pp.grid = 0; pp.phase = 0; pp.handoff = nullptr; pp.handoff_cap = 0;
         }
         // (`behind_s`: the launch depends on what was just submitted to s, e.g. a FILL; else only on the scan)
         auto launch_side = [&](int k, int t, bool behind_s = true) -> int {
@@ -975,6 +1011,13 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
     g->last_stats[TLC_TIER_LARGE] += n_early;
     g->last_stats[7] += tc[TLC_TIER_MID];
     g->last_stats[6] += 1;
+    if (host_trace) {
+        static std::chrono::steady_clock::time_point last_end;
+        const double gap = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(ht0 - last_end).count() * 1e-3;
+        fprintf(stderr, "[tlc host] ws%d since-last-chunk %.0f us | front submitted %.0f | sizes seen %.0f | tiers submitted %.0f\n",
+                (int)(ws - g->ws), gap, ht_front, ht_seen, ht_us());
+        last_end = std::chrono::steady_clock::now();
+    }
     return TLC_OK;
 }
 
@@ -1239,6 +1282,8 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "heavy")) g->opt_heavy = value != 0;
     else if (!strcmp(name, "tiny")) g->opt_tiny = value != 0;
     else if (!strcmp(name, "tier_mask")) g->opt_tier_mask = value;
+    else if (!strcmp(name, "spec_cap")) g->opt_spec_cap = std::max(value, 0);
+    else if (!strcmp(name, "timing_every")) { g->opt_timing_every = std::max(value, 1); g->timing_seq = 0; }
     else if (!strcmp(name, "dc_force_fail")) g->opt_dc_force_fail = value != 0;
     else if (!strcmp(name, "x_region")) g->opt_x_region = std::max(value, 0);
     else if (!strcmp(name, "x_bump_min")) g->opt_x_bump_min = std::max(value, 0);

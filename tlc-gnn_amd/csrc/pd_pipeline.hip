@@ -352,6 +352,9 @@ __device__ __forceinline__ void bitonic_sort(ull* key, unsigned* val, int P) {
     }
 }
 
+// a tier sorts at most MM (a power of two) edges: runs of P/2 and at most P/4 elements, 3 MM / 4 in all; HUGE (MM = 0): 8
+__host__ __device__ constexpr int sort_hold(int MM, int W) { return MM <= 0 ? 8 : ((3 * MM / 4 + W - 1) / W < 1 ? 1 : ((3 * MM / 4 + W - 1) / W > 8 ? 8 : (3 * MM / 4 + W - 1) / W)); }
+
 // Sort of `cnt` pairs whose array is padded with ~0 keys up to P = pow2ceil(cnt) (callers read the first cnt positions).
 // The bitonic network costs P log^2 P whatever cnt is, and a count just above a power of two pays for twice its size (the
 // batch's heaviest vicinity has 2 270 edges: P = 4 096).  When the part above P/2 fits a quarter of P, the two parts are
@@ -359,23 +362,24 @@ __device__ __forceinline__ void bitonic_sort(ull* key, unsigned* val, int P) {
 // its own run plus the number of elements of the other run ordered before it (binary search in LDS; equal keys: the lower
 // run first), elements held in registers across the barrier.  Falls back to the plain network when the runs do not pay
 // or a thread would have to hold more than eight elements (HUGE tier).
-template <int W>
+// QS: the most elements a thread can be asked to hold (8 unless the caller knows its cap: 3/4 of the largest P over W)
+template <int W, int QS = 8>
 __device__ __forceinline__ void sort_padded(ull* key, unsigned* val, int cnt) {
     const int P = pow2ceil(cnt < 2 ? 2 : cnt);
     const int H = P >> 1, r = cnt - H;
     const int R = r > 0 ? pow2ceil(r < 2 ? 2 : r) : P;
     const int total = H + R;
-    if (P < 256 || 4 * R > P || total > 8 * W) {
+    if (P < 256 || 4 * R > P || total > QS * W) {
         bitonic_sort<W>(key, val, P);
         return;
     }
     bitonic_sort<W>(key, val, H);
     bitonic_sort<W>(key + H, val + H, R);
-    ull kk[8];
-    unsigned vv[8];
-    int pp[8];
+    ull kk[QS];
+    unsigned vv[QS];
+    int pp[QS];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < QS; ++q) {
         const int i = (int)threadIdx.x + q * W;
         pp[q] = -1;
         if (i < total) {
@@ -396,7 +400,7 @@ __device__ __forceinline__ void sort_padded(ull* key, unsigned* val, int cnt) {
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < QS; ++q)
         if (pp[q] >= 0) { key[pp[q]] = kk[q]; val[pp[q]] = vv[q]; }
     __syncthreads();
 }
@@ -502,7 +506,7 @@ __device__ __forceinline__ void relabel_by_rank(Mem<idx_t>& M, int n, int m) {
 }
 
 // sort the m edges by the ascending (DESC=false) or descending (DESC=true) perturbed key; valS[pos] = edge id
-template <int W, typename idx_t, bool DESC>
+template <int W, typename idx_t, bool DESC, int QS = 8>
 __device__ __forceinline__ void sort_edges(Mem<idx_t>& M, int m) {
     const int tid = threadIdx.x;
     const int P = pow2ceil(m < 2 ? 2 : m);
@@ -517,7 +521,7 @@ __device__ __forceinline__ void sort_edges(Mem<idx_t>& M, int m) {
         M.valS[e] = (unsigned)e;
     }
     __syncthreads();
-    sort_padded<W>(M.keyS, M.valS, m);
+    sort_padded<W, QS>(M.keyS, M.valS, m);
 }
 
 // ---- one filtration pass as a minimum-spanning-forest computation in sorted-position order -----------------------------
@@ -1156,12 +1160,12 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
 
 // All PD stages on a subgraph whose f[0..n) is final and whose m undirected edges sit in M.dir[0..m) as node-id pairs.
 // `slot` != null: a subgraph with Pos edges leaves its cycle swap to tlc_pd_swap_kernel (deferred = true).
-template <int W, typename idx_t, class Sink>
+template <int W, int QS = 8, typename idx_t, class Sink>
 __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, int m, unsigned flags, int MMcap, int NMcap,
                                             ull* pc, ull& t_prev, ull* ph, unsigned char* slot, bool& deferred,
                                             int dc_mode = 0, bool handoff_all = true) {
     relabel_by_rank<W>(M, n, m);
-    sort_edges<W, idx_t, false>(M, m);
+    sort_edges<W, idx_t, false, QS>(M, m);
     for (int pos = threadIdx.x; pos < m; pos += W) M.arank[M.valS[pos]] = (unsigned)pos;
     __syncthreads();
     TLC_STAMP(5);
@@ -1186,7 +1190,7 @@ __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, i
         for (int w = threadIdx.x; w < (m + 31) / 32; w += W) finb[w] = M.tbits[w];
         __syncthreads();
     }
-    sort_edges<W, idx_t, true>(M, m);
+    sort_edges<W, idx_t, true, QS>(M, m);
     if (dc) dc = fix_desc_ties<W>(M, m);
     TLC_STAMP(7);
     if (Sink::want_down) mst_pass<W, idx_t, true, true>(M, sink, n, m, flags);
@@ -1345,7 +1349,13 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? TLC_M_WPE : (W <= 128 ? 4 :
     int tier_count = p.tier_count;
     if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
     if (NM == TLC_L_NMAX && !HUGE && p.started && tid == 0 && (int)blockIdx.x < tier_count) atomicAdd(p.started, 1);
-    for (int wi = blockIdx.x; wi < tier_count; wi += gridDim.x) {
+    // HUGE: the workgroups stride over the list (one scratch slot each).  The LDS tiers: ONE subgraph per workgroup, list position
+    // wi_base + blockIdx.x -- no loop around the body, so that nothing of it is hoisted in front of it and kept in registers
+    // across all of its phases (that was the tiers' register spilling: thread-id arithmetic and image constants of every phase,
+    // live from the first line on); a launch with fewer workgroups than subgraphs is completed by a second launch (api.hip).
+    int wi = HUGE ? (int)blockIdx.x : p.wi_base + (int)blockIdx.x;
+    if (wi >= tier_count) return;
+    do {
         const int i = p.tier_list[wi];
         // hand-off slot of this subgraph (tiers whose cycle swap runs in tlc_pd_swap_kernel); "nothing pending" until decided
         unsigned char* slot = (!HUGE && p.handoff && wi < p.handoff_cap) ? p.handoff + (size_t)wi * (size_t)p.handoff_stride : nullptr;
@@ -1587,7 +1597,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? TLC_M_WPE : (W <= 128 ? 4 :
             __syncthreads();
             PtsSink sink{M.pts, M.ctl};
             TLC_STAMP(4);
-            status = pd_all_stages<W>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, slot, deferred,
+            status = pd_all_stages<W, sort_hold(MM, W)>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, slot, deferred,
                                       /*dc_mode=*/(!HUGE && NM == TLC_L_NMAX) ? TLC_DC_LARGE_MODE : 0,
                                       /*handoff_all=*/NM != TLC_L_NMAX);
             if (deferred && slot && tid == 0 && p.dc_count && ((const int*)slot)[6] != 0) {
@@ -1629,7 +1639,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? TLC_M_WPE : (W <= 128 ? 4 :
             if (p.out_status && tid == 0) p.out_status[i] = (unsigned char)status;
         }
         __syncthreads();
-    }
+    } while (HUGE && (wi += (int)gridDim.x) < tier_count);
 }
 
 // ======================================================================================================================
@@ -1746,7 +1756,10 @@ __global__ __launch_bounds__(W, (W <= 256 ? 4 : 1)) void tlc_pd_dc_kernel(TlcPdP
     // of the other tiers that share the CU
     __builtin_amdgcn_s_setprio(3);
     const int n_list = p.dc_count ? *p.dc_count : 0;
-    for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+    // (one subgraph per workgroup and no loop around the body, like the tier kernels: see tlc_pd_tier_kernel)
+    const int li = blockIdx.x;
+    if (li >= n_list) return;
+    do {
         const int wi = p.dc_list[li];
         if (wi < 0 || wi >= tier_count) continue;
         const Handoff H = carve_handoff(p.handoff + (size_t)wi * (size_t)p.handoff_stride, NM);
@@ -1759,16 +1772,21 @@ __global__ __launch_bounds__(W, (W <= 256 ? 4 : 1)) void tlc_pd_dc_kernel(TlcPdP
         unsigned short* hin = (unsigned short*)(lds_raw + (o_pts - hin_bytes));
         const HandoffSrc src{H.par, H.key, H.query};
         __syncthreads();
+#ifdef TLC_PHASE_DEBUG
+        // (diagnostics build only: an array whose address is passed on lives in scratch, 80 bytes per lane)
         unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const unsigned long long t_begin = p.phase_cycles ? clock64() : 0ull;
         const bool ok = ext1_dc_solve<W>(src, n, K, n, ctl, wcnt, lds_raw, o_pts - hin_bytes, hin, p.phase_cycles ? prof : nullptr) && !p.dc_force_fail;
-        if (p.phase_cycles && tid == 0) {                             // diagnostics: the slowest subgraph's split
+        if (p.phase_cycles && tid == 0) {                             // the slowest subgraph's split
             const unsigned long long tot = clock64() - t_begin;
             if (atomicMax(&p.phase_cycles[13], tot) < tot) {
                 for (int k = 0; k < 6; ++k) p.phase_cycles[16 + k] = prof[k];
                 p.phase_cycles[22] = tot; p.phase_cycles[28] = (unsigned long long)n; p.phase_cycles[29] = (unsigned long long)K;
             }
         }
+#else
+        const bool ok = ext1_dc_solve<W>(src, n, K, n, ctl, wcnt, lds_raw, o_pts - hin_bytes, hin, nullptr) && !p.dc_force_fail;
+#endif
         if (!ok) {
             if (p.stats && tid == 0) atomicAdd(&p.stats[3], 1ull);
             __syncthreads();
@@ -1804,7 +1822,7 @@ __global__ __launch_bounds__(W, (W <= 256 ? 4 : 1)) void tlc_pd_dc_kernel(TlcPdP
             H.hdr[0] = 0;                                             // nothing pending for tlc_pd_swap_kernel
         }
         __syncthreads();
-    }
+    } while (false);
 }
 
 // ======================================================================================================================
@@ -2176,7 +2194,10 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
         case TLC_TIER_LARGE: {
             constexpr Layout L = make_layout(TLC_L_NMAX, TLC_L_MMAX, false, 2);
             // the whole CU: no SMALL workgroup beside the wavefront that carries the batch's longest serial chain
-            constexpr size_t lds_bytes = L.total > 156 * 1024 ? L.total : 156 * 1024;
+            // (bit 0: this kernel, bit 1: the divide-and-conquer kernel behind it.  The latter no longer does: with 107 of 160 KB a
+            // TINY workgroup fits beside it, 0.838 -> 0.818 ms for the PubMed batch; development A/B: tools/gpu_large_excl.sh)
+            static const int excl = getenv("TLC_LARGE_EXCL") ? atoi(getenv("TLC_LARGE_EXCL")) : 1;
+            const size_t lds_bytes = (L.total > 156 * 1024 || !(excl & 1)) ? L.total : 156 * 1024;
             int rc = set_lds_limit(tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>, lds_bytes);
             if (rc) return rc;
             hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>), dim3(p.tier_count),
@@ -2184,12 +2205,13 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             if (deferring) {
                 // (only the subgraphs marked for the divide and conquer were handed off; the serial kernel is their fallback)
                 constexpr SwapLayout SL = make_swap_layout(TLC_L_NMAX, TLC_L_MMAX);
-                // (like the tier kernel: the whole CU's LDS, so that no throughput workgroup shares the CU with the longest chain)
-                constexpr size_t dcl = dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX) > 156 * 1024 ? dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX) : 156 * 1024;
+                // (its own 107 KB only, see above)
+                const size_t dcl = (dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX) > 156 * 1024 || !(excl & 2)) ? dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX) : 156 * 1024;
+                if (getenv("TLC_HOST_TRACE")) { static int once = 0; if (!once++) fprintf(stderr, "[tlc] LARGE tier LDS %zu (layout %zu), dc %zu (layout %zu)\n", lds_bytes, (size_t)L.total, dcl, (size_t)dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX)); }
                 rc = set_lds_limit(tlc_pd_dc_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS>, dcl);
                 if (rc) return rc;
                 if (p.dc_count)
-                    hipLaunchKernelGGL((tlc_pd_dc_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS>), dim3(p.tier_count < 128 ? p.tier_count : 128),
+                    hipLaunchKernelGGL((tlc_pd_dc_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS>), dim3(p.tier_count),
                                        dim3(TLC_L_THREADS), dcl, s, p);
             }
             break;

@@ -221,6 +221,7 @@ struct TlcPdParams {
     int* dc_list;
     int dc_force_fail;           // tests: tlc_pd_dc_kernel treats every solve as failed (the give-back path to the serial walk)
     int grid;
+    int wi_base;                   // LDS tiers: list position of workgroup 0 (a launch that completes a shorter one)
     int phase;                   // 0 = tier kernel + its swap kernel, 1 = tier kernel only, 2 = swap kernel only
     int handoff_cap;
     const int* abort_flag;
