@@ -109,10 +109,16 @@ __device__ __forceinline__ void x_sync() {
         __syncthreads();
     }
 }
-// arena entries are written once and read once, by another kernel: stored past the caches' allocation policy so that the
-// graph's arrays (ball lists, rows, weights: 6 MB against a 4 MB L2 per XCD) are not evicted by 37 MB of output per batch
+// arena entries: ordinary stores.  (Nontemporal stores -- the entries are written once and read once, by another kernel, and
+// 37 MB of them per batch pass through a 4 MB L2 beside the graph's 6 MB of lists and rows -- were measured: same kernel time,
+// but WRITE_SIZE 142 MB instead of 51 MB per batch: the partial lines a wavefront's few entries make are not merged on the way
+// out.  make X_NT=1 brings them back for an A/B.)
 template <typename T>
+#ifdef TLC_X_NT_STORE
 __device__ __forceinline__ void x_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
+#else
+__device__ __forceinline__ void x_store(T* p, T v) { *p = v; }
+#endif
 __device__ __forceinline__ bool x_heavy(const XState& X, int ly) { return (X.hvy[ly >> 5] >> (ly & 31)) & 1u; }
 
 // One sweep over the rows of the members ids[0..n): every directed entry of the induced subgraph exactly once, as

@@ -2161,6 +2161,15 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
     // tiers with a hand-off buffer leave the cycle swap + image of their subgraphs to tlc_pd_swap_kernel, same stream
     const bool deferring = p.handoff != nullptr && p.pi_enabled && !(p.flags & TLC_NO_EXT1);
     const int grid = p.grid > 0 ? p.grid : p.tier_count;
+    if (getenv("TLC_HOST_TRACE")) {                   // (development: LDS bytes per workgroup of every kernel of the tiers)
+        static int once = 0;
+        if (!once++)
+            fprintf(stderr, "[tlc] LDS per workgroup: SMALL %zu | MEDIUM tier %zu swap %zu | MID tier %zu swap %zu | LARGE tier %zu dc %zu\n",
+                    (size_t)make_layout(TLC_S_NMAX, TLC_S_MMAX, true, 2).total, (size_t)make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2).total,
+                    (size_t)make_swap_layout(TLC_M_NMAX, TLC_M_MMAX).total, (size_t)make_layout(TLC_D_NMAX, TLC_D_MMAX, false, 2).total,
+                    (size_t)make_swap_layout(TLC_D_NMAX, TLC_D_MMAX).total, (size_t)make_layout(TLC_L_NMAX, TLC_L_MMAX, false, 2).total,
+                    (size_t)dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX));
+    }
     switch (tier) {
         case TLC_TIER_SMALL: {
             constexpr Layout L = make_layout(TLC_S_NMAX, TLC_S_MMAX, true, 2);

@@ -10,4 +10,5 @@ cp $(find gpurun_out/prof/kt -name "*kernel_stats.csv" | head -1) gpurun_out/${R
 python tools/timeline.py gpurun_out/prof/kt 6 > gpurun_out/${R}_bench_timeline.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > gpurun_out/prof/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > gpurun_out/prof/pmc_write.log 2>&1
+mkdir -p profiles && python tools/pmc_to_traffic.py $R > gpurun_out/${R}_traffic.log 2>&1; cp profiles/pmc_traffic.json gpurun_out/${R}_pmc_traffic.json; cp profiles/${R}_pmc_raw.json gpurun_out/
 head -14 gpurun_out/${R}_bench_kernel_stats.csv

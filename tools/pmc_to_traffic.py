@@ -7,7 +7,8 @@ NAMES = [("tlc_pd_tier_kernel<2048", "pd_tier_large"), ("tlc_pd_dc_kernel<2048",
          ("tlc_pd_tier_kernel<128", "pd_tier_mid"), ("tlc_pd_swap_kernel<512", "pd_swap_medium"),
          ("tlc_pd_swap_kernel<128", "pd_swap_mid"),
          ("tlc_pd_tier_kernel<64", "pd_tier_small"), ("tlc_pd_tier_kernel<0", "pd_tier_huge"),
-         ("tlc_vicinity_kernel<true", "vicinity_fill"), ("tlc_vicinity_kernel<false, 512", "vicinity_count_early"),
+         ("tlc_extract_kernel<512", "vicinity_count_early"), ("tlc_extract_kernel<64", "vicinity_count"),
+         ("tlc_classify", "classify"), ("tlc_vicinity_kernel<true", "vicinity_fill"), ("tlc_vicinity_kernel<false, 512", "vicinity_count_early"),
          ("tlc_vicinity_kernel<false", "vicinity_count"),
          ("tlc_scan_", "scan_bin"), ("gemm16_f32_kernel", "gemm_f32"), ("spmm_csr", "spmm_csr"), ("lp_decode", "lp_decode")]
 raw = {}
@@ -40,7 +41,7 @@ for cname in raw:
                     out[nm]["launches_per_step"] += per_step
                 break
 import datetime
-res = {"_collected": "%s, round-2 code (%s)" % (tag, datetime.date.today().isoformat()),
+res = {"_collected": "%s code (%s)" % (tag, datetime.date.today().isoformat()),
        "_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1 --no-sweep` "
                 "(raw per-kernel sums and medians in profiles/%s_pmc_raw.json); bytes per batch = (FETCH_SIZE + WRITE_SIZE) * 1024 "
                 "summed over the pass / batches in the pass (one of them is the 75 352-pair set-up batch of the decode table). "
