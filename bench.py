@@ -725,6 +725,7 @@ def main():
         used = [rot[j] for j in range(min(K, len(rot)))] if args.rotate_batches else [pi_pairs]
         weight = [len(range(j, K, len(rot))) for j in range(len(used))] if args.rotate_batches else [K]
         dom = dom_warm
+        live = [x for x in ktimes_timed if x >= 0]
         dom_bytes = dom_units = all_bytes = 0.0
         for b_dev, wgt in zip(used, weight):
             g.pd_pi_batch(b_dev, hop, out=pi_out, status=pi_status)
@@ -732,13 +733,15 @@ def main():
             tiers = engine.tier_of(n_sz, m2_sz)
             bpp = engine.algorithmic_bytes(wl["rowptr"], wl["col"], b_dev.cpu().numpy(), hop)
             sel = (tiers == dom) if dom.startswith("pd_tier") else np.ones(E, dtype=bool)
+            if dom == "pd_tier_medium" and not args.sync_batches and live:
+                # (pipelined chunks do not split the MEDIUM tier by Pos-edge count: the timed launches took all of it)
+                sel = (tiers == "pd_tier_medium") | (tiers == "pd_tier_medium_rest")
             dom_bytes += wgt * float(bpp[sel].sum()) / K
             dom_units += wgt * float(sel.sum()) / K
             all_bytes += wgt * float(bpp.sum()) / K
         g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)
         stats = g.stats()
         kavg = dict(warm_avg)                                   # all kernels: warm-up steps (every kernel carried events there)
-        live = [x for x in ktimes_timed if x >= 0]
         if live:
             kavg[dom] = float(np.mean(live))                    # the dominant kernel: live, inside the timed region
         achieved = dom_bytes / (kavg[dom] * 1e-3) / 1e9

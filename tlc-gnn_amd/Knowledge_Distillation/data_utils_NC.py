@@ -37,7 +37,11 @@ def _graph_stamp(g, ricci_curv):
     more than the vicinities.)"""
     k = 0 if ricci_curv is None else len(ricci_curv)
     sample = () if not k else tuple(tuple(float(x) for x in row) for row in (list(ricci_curv[:64]) + list(ricci_curv[-64:])))
-    return (g.number_of_nodes(), g.number_of_edges(), k, hash(sample))
+    if hasattr(g, "number_of_nodes"):
+        counts = (g.number_of_nodes(), g.number_of_edges())
+    else:                                                  # an edge array [m, 2] (what Vicinities also accepts)
+        counts = tuple(np.asarray(g).shape)
+    return counts + (k, hash(sample))
 
 
 def _vicinities(g, ricci_curv):

@@ -157,6 +157,7 @@ struct tlc_graph {
     // development / test switches (tlc_debug_set_option; initial values from the environment: TLC_EXTRACT, TLC_HEAVY, TLC_TINY)
     int opt_extract, opt_heavy, opt_tiny;
     int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
+    int opt_mh_always;                  // tests: split the MEDIUM tier by Pos-edge count in pipelined chunks too
     int opt_spec_cap;                   // tests: upper bound of the slots reserved for the speculative launches (0 = none)
     int opt_timing_every;               // measurement: kernel events on every n-th chunk only
     unsigned timing_seq;
@@ -565,7 +566,7 @@ __global__ void tlc_wait_started_dev(const int* counter, const int* target, int 
 static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_pairs, int hop, uint32_t flags, int res,
                      double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
                      double* d_out_f, int32_t* d_out_n, const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m,
-                     int pi_enabled, hipStream_t s) {
+                     int pi_enabled, hipStream_t s, bool pipelined) {
     int rc;
     // (development: TLC_HOST_TRACE=1 prints where the submitting thread spends a chunk -- front submitted, sizes seen, tiers submitted)
     static const bool host_trace = getenv("TLC_HOST_TRACE") != nullptr;
@@ -769,6 +770,13 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
     sp.block_agg = ws->d_block_sums; sp.block_flag = ws->d_ctl + 64; sp.sync = ws->d_ctl + 10; sp.totals = ws->d_totals;
     sp.edge_off = ws->edge_off; sp.tier_count = ws->d_ctl; sp.tier_list = ws->tier_list; sp.small_arena = use_x ? 0 : 1;
     // the plain TLC-GNN image batch at resolution 5: the smallest vicinities go to the lane-per-subgraph kernel (pd_tiny.hip)
+    // The MEDIUM tier's split by Pos-edge count exists for the LATENCY of one chunk: the vicinities with the longest serial swaps
+    // are submitted behind the scan at once, so that chain starts 50 us earlier (0.79 -> 0.76 ms).  With chunks in flight on both
+    // workspaces the machine is full either way and the split only costs: a second pair of kernels per chunk, and the MEDIUM chain's
+    // hardest part ahead of the main stream's join (tools/ab_option.py mh_always 1 0, one process: rotating batches 0.718 -> 0.700 ms,
+    // the fixed batch 0.729 vs 0.734; profiles/r03_threshold_sweep.txt has the curve over the cut).  So a pipelined chunk does not split.
+    const bool mh_split = !pipelined || g->opt_mh_always;
+    sp.mh_min_pos = mh_split ? TLC_MH_MIN_POS : 0x7fffffff;
     sp.tiny_ok = (g->opt_tiny && pi_enabled && flags == 0u && res == 5 && !d_out_ids && !d_out_f && !d_out_edges) ? 1 : 0;
     sp.early_list = early ? ws->d_early_list : nullptr; sp.early_count = d_early_count; sp.early_cap = TLC_EARLY_SLOTS;
     sp.h_early = const_cast<int*>(&ws->h_sync_dev->pub_early);
@@ -793,7 +801,12 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
     // (abort flag) and the chunk is redone below.
     static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4};   // timing slot of each tier kernel (TINY is reported with SMALL, MEDHI as MEDIUM)
     bool used[TLC_N_SIDE] = {false, false, false, false, early, false, false};
-    const bool spec = bump;
+    // The fork point of the side-stream launches that need nothing but the scan.  Recorded here, it is long complete when the
+    // host has seen the sizes and submits them, and a wait on a complete event is no command at all -- an event recorded at
+    // submission time costs every side stream a barrier packet on a signal that is still in flight: 60 us per chunk (measured:
+    // 0.796 -> 0.733 ms per pipelined batch, tools/ab_option.py mh_always 0 3 before this was unconditional).
+    TLC_HIP_CHECK(hipEventRecord(ws->ev_scan, s));
+    const bool spec = bump && mh_split;
     size_t spec_base[TLC_N_TIERS] = {0, 0, 0, 0, 0, 0, 0};
     int spec_cap[TLC_N_TIERS] = {0, 0, 0, 0, 0, 0, 0};
     if (spec) {
@@ -812,7 +825,6 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         // event waits until the scan is done, and a blocked stream stalls whatever shares its hardware queue -- ROCm maps all
         // streams onto 4 by default: measured, the scan then started 0.1 ms late and took 55 instead of 11 us.)  The fork
         // point of the side-stream launches below is the event recorded here, ahead of these kernels.
-        TLC_HIP_CHECK(hipEventRecord(ws->ev_scan, s));
         // (only the MEDIUM-sized vicinities with many Pos edges, whose tier kernel + long serial swaps are the longest chain of
         // the small tiers: kernels on one stream do not overlap, and another tier's pair of kernels between that tier kernel and
         // its swap kernel costs more than the host round trip saves -- measured)
@@ -908,7 +920,7 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         }
         // (`behind_s`: the launch depends on what was just submitted to s, e.g. a FILL; else only on the scan)
         auto launch_side = [&](int k, int t, bool behind_s = true) -> int {
-            if (spec_done && !behind_s) {
+            if (bumped && !behind_s) {
                 TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[k], ws->ev_scan, 0));    // (not behind the speculative kernels on s)
             } else {
                 TLC_HIP_CHECK(hipEventRecord(ws->ev_fork, s));
@@ -929,7 +941,7 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
             }
             pp.grid = 0; pp.phase = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
-            const bool timed = !(early && t == TLC_TIER_LARGE) && t != TLC_TIER_MEDIUM;   // (those slots time the early launch / MEDHI)
+            const bool timed = !(early && t == TLC_TIER_LARGE) && !(t == TLC_TIER_MEDIUM && spec);   // (those slots time the early launch / MEDHI)
             if (timed) T0(tslot[t], ws->side[k]);
             int r = ((g->opt_tier_mask >> t) & 1) ? tlc_launch_pd_tier(t, pp, ws->side[k]) : TLC_OK;   // (development: tiers timed alone)
             if (r != TLC_OK) return r;
@@ -971,7 +983,7 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         // the lower end of the SMALL tier first: one lane per subgraph, a few hundred latency-bound wavefronts that need 66 KB of
         // LDS each -- they must find room before the other tiers' workgroups take it
         if (tc[TLC_TIER_TINY] > 0) {
-            if (spec_done) { TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_scan, 0)); }
+            if (bumped) { TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_scan, 0)); }
             else { TLC_HIP_CHECK(hipEventRecord(ws->ev_fork, s)); TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_fork, 0)); }
             pp.tier_list = ws->tier_list + (size_t)TLC_TIER_TINY * n_pairs; pp.tier_count = tc[TLC_TIER_TINY];
             pp.handoff = nullptr; pp.handoff_stride = 0; pp.handoff_cap = 0; pp.grid = 0; pp.phase = 0;
@@ -1100,7 +1112,7 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
                        d_out_status ? d_out_status + off : nullptr,
                        d_ids_off ? d_ids_off + off : nullptr, d_out_ids, d_out_f,
                        d_out_n ? d_out_n + off : nullptr, d_edge_offs ? d_edge_offs + off : nullptr, d_out_edges,
-                       d_out_m ? d_out_m + off : nullptr, pi_enabled, m);
+                       d_out_m ? d_out_m + off : nullptr, pi_enabled, m, !inline_main);
         if (rc != TLC_OK) return rc;
         TLC_HIP_CHECK(hipEventRecord(ws->ev_done, m));
         ws->busy = 1; ws->in_call = 1; ws->n_pairs = cnt;
@@ -1283,6 +1295,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "tiny")) g->opt_tiny = value != 0;
     else if (!strcmp(name, "tier_mask")) g->opt_tier_mask = value;
     else if (!strcmp(name, "spec_cap")) g->opt_spec_cap = std::max(value, 0);
+    else if (!strcmp(name, "mh_always")) g->opt_mh_always = value != 0;
     else if (!strcmp(name, "timing_every")) { g->opt_timing_every = std::max(value, 1); g->timing_seq = 0; }
     else if (!strcmp(name, "dc_force_fail")) g->opt_dc_force_fail = value != 0;
     else if (!strcmp(name, "x_region")) g->opt_x_region = std::max(value, 0);

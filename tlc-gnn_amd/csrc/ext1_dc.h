@@ -19,7 +19,9 @@
 // the last bits) some query ends without its edge: the stage reports failure and the caller runs the serial walk.
 #pragma once
 
+#ifndef TLC_DC_MIN_POS             /* (overridable for the threshold sweep: tools/gpu_threshold_sweep.sh) */
 #define TLC_DC_MIN_POS 160          /* below this many Pos edges the serial walk wins (a workgroup with a CU to itself) */
+#endif
 /* 256-thread tiers (MEDIUM): measured on the PubMed batch, a level costs ~30k cycles there as well (phases of two or three
  * dependent LDS round trips, no latency hiding) -- 8 levels = 100 us for 190 queries against 185 us for the serial walk in
  * tlc_pd_swap_kernel, and the kernel sits between the tier kernel and the serial kernel on the same stream: the chain gets

@@ -2173,8 +2173,11 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
     switch (tier) {
         case TLC_TIER_SMALL: {
             constexpr Layout L = make_layout(TLC_S_NMAX, TLC_S_MMAX, true, 2);
+            // (development: TLC_SMALL_LDS_PAD=bytes inflates this tier's footprint -- the experiment behind DESIGN.md's "the tier
+            // phase is bound by LDS capacity x time": +4 KB here costs the batch 2.5 %, +16 KB 20 %)
+            static const size_t pad = getenv("TLC_SMALL_LDS_PAD") ? (size_t)atoi(getenv("TLC_SMALL_LDS_PAD")) : 0;
             hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_S_NMAX, TLC_S_MMAX, 64, true, false>), dim3(p.tier_count), dim3(64),
-                               L.total, s, p);
+                               L.total + pad, s, p);
             break;
         }
         case TLC_TIER_MEDHI:

@@ -19,7 +19,9 @@
 #define TLC_TIER_MID 4      /* the lower end of MEDIUM (reported with it): 128 threads, ~10 KB of LDS, 8 workgroups per CU */
 #define TLC_TIER_MEDHI 6    /* MEDIUM-sized vicinities with many Pos edges (reported with MEDIUM): same kernels, launched FIRST and on the
                                critical stream, so that their long serial cycle swaps overlap the rest of the MEDIUM tier */
+#ifndef TLC_MH_MIN_POS             /* (overridable for the threshold sweep: tools/gpu_threshold_sweep.sh) */
 #define TLC_MH_MIN_POS 120
+#endif
 #define TLC_TIER_TINY 5     /* the lower end of SMALL (reported with it): ONE LANE per subgraph, 64 subgraphs per wavefront (pd_tiny.hip) */
 // hard limits of one subgraph: local node ids are packed in 16 bits, edge ranks + 1 in 24
 #define TLC_MAX_SUBGRAPH_NODES 65535
@@ -28,6 +30,13 @@
 
 #define TLC_T_NMAX 16
 #define TLC_T_MMAX 24
+/* which SMALL-tier vicinities the scan sends there (<= the kernel's capacity above; overridable for the sweep) */
+#ifndef TLC_T_NCUT
+#define TLC_T_NCUT TLC_T_NMAX
+#endif
+#ifndef TLC_T_MCUT
+#define TLC_T_MCUT TLC_T_MMAX
+#endif
 #define TLC_S_NMAX 64
 #define TLC_S_MMAX 128
 #define TLC_D_NMAX 128
@@ -145,6 +154,7 @@ struct TlcScanParams {
     int* tier_count;  // [TLC_N_TIERS]
     int* tier_list;   // [TLC_N_TIERS][n_pairs]
     int small_arena;
+    int mh_min_pos;         // MEDIUM-sized vicinities with at least this many Pos edges go to the MEDHI list (TLC_MH_MIN_POS; INT_MAX: none)
     int tiny_ok;            // the SMALL-tier vicinities of at most TLC_T_NMAX nodes / TLC_T_MMAX edges get a list of their own
     // COUNT wrote the MID / MEDIUM vicinities at bump-allocated offsets (TlcVicParams::bump_top): unless *bump_overflow, only
     // the heavy tiers still need arena space, handed out above *bump_top; null: every vicinity outside the SMALL tier does

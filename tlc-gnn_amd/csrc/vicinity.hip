@@ -138,10 +138,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
         if (n > 0 && !pre) {
             const int m = m2v >> 1;
             tier = TLC_TIER_HUGE;
-            if (p.tiny_ok && n <= TLC_T_NMAX && m <= TLC_T_MMAX) tier = TLC_TIER_TINY;
+            if (p.tiny_ok && n <= TLC_T_NCUT && m <= TLC_T_MCUT) tier = TLC_TIER_TINY;
             else if (n <= TLC_S_NMAX && m <= TLC_S_MMAX) tier = TLC_TIER_SMALL;
             else if (n <= TLC_D_NMAX && m <= TLC_D_MMAX) tier = TLC_TIER_MID;
-            else if (n <= TLC_M_NMAX && m <= TLC_M_MMAX) tier = (m - n + 1 >= TLC_MH_MIN_POS) ? TLC_TIER_MEDHI : TLC_TIER_MEDIUM;
+            else if (n <= TLC_M_NMAX && m <= TLC_M_MMAX) tier = (m - n + 1 >= p.mh_min_pos) ? TLC_TIER_MEDHI : TLC_TIER_MEDIUM;
             else if (n <= TLC_L_NMAX && m <= TLC_L_MMAX) tier = TLC_TIER_LARGE;
         }
     }
