@@ -1723,8 +1723,8 @@ __global__ __launch_bounds__(64, 4) void tlc_pd_swap_kernel(TlcPdParams p) {
     int tier_count = p.tier_count;
     if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
     if (tier_count > p.handoff_cap) tier_count = p.handoff_cap;       // (list positions beyond it were not handed off)
-    for (int wi = blockIdx.x; wi < tier_count; wi += gridDim.x)       // (one subgraph per workgroup unless the grid was capped)
-        swap_subgraph<NM, MM, 64>(p, wi, lds_raw);
+    // (one subgraph per workgroup -- every launch has at least min(tier_count, handoff_cap) of them -- and no loop: see tlc_pd_tier_kernel)
+    if ((int)blockIdx.x < tier_count) swap_subgraph<NM, MM, 64>(p, (int)blockIdx.x, lds_raw);
 }
 
 // ======================================================================================================================
@@ -1847,7 +1847,10 @@ __global__ __launch_bounds__(W) void tlc_pdf_tier_kernel(TlcPdfParams p) {
         base = lds_raw;
     }
     Mem<idx_t> M = carve<idx_t>(base, L, NMr, MMr, false);
-    for (int wi = blockIdx.x; wi < p.count; wi += gridDim.x) {
+    // (no loop around the body for the LDS tiers, whose launches have one workgroup per graph: see tlc_pd_tier_kernel)
+    int wi = blockIdx.x;
+    if (wi >= p.count) return;
+    do {
         const int g = p.list[wi];
         const long long no = p.node_offs[g], eo = p.edge_offs[g];
         const int n = (int)(p.node_offs[g + 1] - no), m = (int)(p.edge_offs[g + 1] - eo);
@@ -1882,7 +1885,7 @@ __global__ __launch_bounds__(W) void tlc_pdf_tier_kernel(TlcPdfParams p) {
             for (int k = tid; k < nneg; k += W) p.edge_rank[eo + M.pn[MMr - 1 - k]] = -k - 1;
         }
         __syncthreads();
-    }
+    } while (HUGE && (wi += (int)gridDim.x) < p.count);
 }
 
 // tier binning for tlc_pd_from_filtration
