@@ -13,7 +13,12 @@
  *   - pointers prefixed d_ are DEVICE pointers, h_ are HOST pointers;
  *   - the caller allocates every buffer; the library keeps nothing beyond the call except the
  *     `tlc_graph` handle (which owns a device copy of the CSR and the kernels' scratch);
- *   - every call is stream-ordered and asynchronous unless stated otherwise; outputs are fully
+ *   - every call is stream-ordered: its work is ordered after what `stream` holds and later work on `stream` sees its
+ *     outputs.  The calls RETURN before that work is done, with one documented exception: tlc_pd_pi_batch,
+ *     tlc_pd_pi_batch_async and tlc_vicinity_filtration hold the calling thread, once per chunk of 2^20 pairs, until the
+ *     chunk's extraction and size scan have run on the device (~0.3 ms for 37 676 pairs; the sizes come back through
+ *     mapped host memory and size the tier launches that follow) -- nothing is synchronised and `stream` is not drained,
+ *     but the call is not free of host waiting; the statistics / timing / sizes getters synchronise `stream`.  Outputs are fully
  *     overwritten (zero rows are written explicitly, mirroring `pi_sg = np.zeros(...)`,
  *     sg2dgm/riccidist2dgm.py:363);
  *   - a tlc_graph handle owns mutable scratch: calls on the SAME handle must not overlap (use one handle per

@@ -1,7 +1,7 @@
 // lp_forward.hip -- M1..M3: the TLCGNN link-prediction forward (baselines/TLCGNN.py:19-62).
 //
 //   tlc_gcn_norm_csr     gcn_norm of GCNConv(cached=True)         (spec in-tree: Knowledge_Distillation/PD_conv.py:35-70)
-//   tlc_gemm_f32         x @ W on the f32 MFMA (v_mfma_f32_32x32x2_f32), bias/ReLU fused   (PD_conv.py:179-181)
+//   tlc_gemm_f32         x @ W on the f32 MFMA (v_mfma_f32_16x16x4_f32), bias/ReLU fused   (PD_conv.py:179-181)
 //   tlc_spmm_csr_f32     propagate = normalised scatter-add at the target, as a row-owned CSR SpMM,
 //                        bias + ReLU fused (PD_conv.py:183-188; message_passing.py:275-293 aggr='add')
 //   tlc_renorm_rows_f32  emb.renorm_(2, 0, 1)                      (TLCGNN.py:48)
