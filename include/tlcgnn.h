@@ -260,7 +260,8 @@ int tlc_gat_layer_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d
  *   d_assign[i] = problem-local target index of predicted point i, -1 = diagonal
  *   d_gradX[i] (may be null) = d loss[b] / d X_i: what `loss.backward()` leaves on the predicted diagram
  *   d_status[b]: 0 ok; 1 = fewer predicted than target points (the reference's transport has negative diagonal mass: no
- *   result, loss 0); 2 = more than 512 predicted points (not supported: loss 0).  max_points: an upper bound of the predicted
+ *   result, loss 0); 2 = more than 4 096 predicted points (not supported: loss 0).  Problems of up to 512 predicted points take one
+ *   wavefront each, larger ones a 512-thread workgroup each (a second launch when max_points > 512).  max_points: an upper bound of the predicted
  *   points of one problem (selects the kernel variant). */
 int tlc_w2_partial_matching(int32_t n_problems, const int64_t* d_xoff, const double* d_X, const int64_t* d_yoff,
                             const double* d_Y, int order, int32_t max_points, double* d_loss, double* d_wxy, double* d_wxd,

@@ -71,7 +71,7 @@ def test_partial_matching_status_codes_and_empty_diagrams():
     import torch
     from tlc_gnn_amd import ops
     rs = np.random.RandomState(1)
-    X = [rs.rand(3, 2), np.zeros((0, 2)), rs.rand(5, 2), rs.rand(600, 2), np.zeros((0, 2))]
+    X = [rs.rand(3, 2), np.zeros((0, 2)), rs.rand(5, 2), rs.rand(4100, 2), np.zeros((0, 2))]
     Y = [rs.rand(5, 2), np.zeros((0, 2)), np.zeros((0, 2)), rs.rand(2, 2), rs.rand(2, 2)]
     xoff = np.concatenate([[0], np.cumsum([len(x) for x in X])]).astype(np.int64)
     yoff = np.concatenate([[0], np.cumsum([len(y) for y in Y])]).astype(np.int64)
@@ -83,6 +83,43 @@ def test_partial_matching_status_codes_and_empty_diagrams():
     assert loss[1] == 0.0
     d = (X[2][:, 1] - X[2][:, 0]) * 0.5
     assert abs(loss[2] - np.sqrt((d ** 2).sum())) < 1e-14 and (r["assign"].cpu().numpy()[3:8] == -1).all()
+    assert loss[3] == 0.0 and (r["assign"].cpu().numpy()[8:8 + 4100] == -1).all()          # more than 4 096 predicted points: refused
+
+
+@pytest.mark.parametrize("order", [2, 1])
+def test_partial_matching_above_512_points_takes_a_workgroup_per_problem(order):
+    """513 .. 4 096 predicted points: the second launch (512 threads per problem); small problems of the same batch still take the
+    one-wavefront kernel.  Optimal cost against scipy, loss pieces and gradient against the restated expression."""
+    import torch
+    from tlc_gnn_amd import ops
+    from oracle import w2_ref
+    rs = np.random.RandomState(90 + order)
+    sizes = [(513, 513), (40, 11), (700, 350), (1500, 1499), (0, 0), (2300, 2300), (512, 100), (1024, 0)]
+    xs, ys = [], []
+    for n, m in sizes:
+        b0 = rs.rand(n); xs.append(np.stack([b0, b0 + rs.uniform(-0.1, 0.6, size=n)], 1))
+        b1 = rs.rand(m); ys.append(np.stack([b1, b1 + rs.uniform(0.0, 0.7, size=m)], 1))
+    xoff = np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.int64)
+    yoff = np.concatenate([[0], np.cumsum([len(y) for y in ys])]).astype(np.int64)
+    r = ops.w2_partial_matching(torch.as_tensor(xoff).cuda(), torch.as_tensor(np.concatenate(xs)).cuda(), torch.as_tensor(yoff).cuda(),
+                                torch.as_tensor(np.concatenate(ys)).cuda(), order=order)
+    assert (r["status"].cpu().numpy() == 0).all()
+    loss, assign, grad = r["loss"].cpu().numpy(), r["assign"].cpu().numpy(), r["grad"].cpu().numpy()
+    for b, (n, m) in enumerate(sizes):
+        a = assign[xoff[b]:xoff[b + 1]]
+        assert sorted(a[a >= 0].tolist()) == list(range(m)) and (a >= -1).all()
+        if n == 0:
+            assert loss[b] == 0.0
+            continue
+        ref_cost = w2_ref.partial_matching(xs[b], ys[b], order)[4]
+        M = w2_ref.cost_matrix(xs[b], ys[b], order)
+        cost = float(M[np.arange(n), np.where(a >= 0, a, m)].sum())
+        assert abs(cost - ref_cost) <= 1e-9 * max(1.0, abs(ref_cost)), (b, n, m, cost, ref_cost)
+        l2 = w2_ref.loss_from_assignment(xs[b], ys[b], a, order)[0]
+        assert abs(loss[b] - l2) <= 1e-12 * max(1.0, l2)
+        Xt = torch.tensor(xs[b], requires_grad=True)
+        w2_ref.loss_torch(Xt, torch.tensor(ys[b]), a, order).backward()
+        assert np.abs(grad[xoff[b]:xoff[b + 1]] - Xt.grad.numpy()).max() <= 1e-12, b
 
 
 # ---- backward of the PDGNN layer, the edge head and the whole training step -------------------------------------------------

@@ -55,7 +55,7 @@ class DiagramLoss(torch.autograd.Function):
         r = ops.w2_partial_matching(xoff, pd_hat.detach(), yoff, target, order=order, want_grad=True)
         bad = r["status"] != 0
         if bool(bad.any()):
-            raise ValueError("diagram loss: status %s (1 = fewer predicted than target points, 2 = more than 512 predicted points)"
+            raise ValueError("diagram loss: status %s (1 = fewer predicted than target points, 2 = more than 4096 predicted points)"
                              % r["status"].tolist())
         ctx.save_for_backward(r["grad"], xoff)
         ctx.dtype = pd_hat.dtype

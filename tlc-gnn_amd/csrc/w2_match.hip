@@ -11,7 +11,8 @@
 // With unit masses the transport is an ASSIGNMENT: n rows (predicted points) onto m target columns plus n - m copies of the
 // diagonal.  One wavefront per diagram pair solves it with the shortest-augmenting-path (Hungarian) method, lanes = columns:
 // the cost of (row, column) is recomputed from the two points (no matrix is stored), column duals / slack in registers, row
-// duals, the column -> row map and the alternating-path links in LDS; O(n^2) wavefront steps of ~60 instructions (n <= 512).
+// duals, the column -> row map and the alternating-path links in LDS; O(n^2) wavefront steps of ~60 instructions (n <= 512;
+// 513 .. 4 096 points: the same with a workgroup per problem, tlc_w2_match_wide_kernel).
 // Also returned: which target every predicted point went to, the two partial sums the reference logs (wxy, wxd) and the
 // gradient of the loss with respect to the predicted points (what `loss.backward()` would put on PD-hat).
 //
@@ -34,7 +35,8 @@ struct W2Params {
     double* wxd;               // [B]
     int* assign;               // [sum n]: target index (problem-local), -1 = diagonal
     double* gradX;             // [sum n, 2] or null
-    unsigned char* status;     // [B]: 0 ok, 1 fewer predicted than target points, 2 more than 64 * CPL predicted points
+    unsigned char* status;     // [B]: 0 ok, 1 fewer predicted than target points, 2 too many predicted points
+    int leave_big;             // problems beyond this kernel's capacity are left alone (the workgroup kernel takes them)
 };
 
 __device__ __forceinline__ double w2_pow(double d, int order) { return order == 2 ? d * d : d; }
@@ -55,6 +57,7 @@ __global__ __launch_bounds__(64) void tlc_w2_match_kernel(W2Params p) {
     for (int b = blockIdx.x; b < p.n_pairs; b += gridDim.x) {
         const long long x0 = p.xoff[b], y0 = p.yoff[b];
         const int n = (int)(p.xoff[b + 1] - x0), m = (int)(p.yoff[b + 1] - y0);
+        if (n > NMAX && p.leave_big) continue;
         if (n < m || n > NMAX) {
             // (n < m: the diagonal would need negative mass, wasserstein.py:264 -- the reference's transport has no solution)
             if (lane == 0) { p.status[b] = n < m ? 1 : 2; p.loss[b] = 0.0; p.wxy[b] = 0.0; p.wxd[b] = 0.0; }
@@ -188,6 +191,189 @@ __global__ __launch_bounds__(64) void tlc_w2_match_kernel(W2Params p) {
     }
 }
 
+// ---- the same method for up to 4 096 predicted points: one WORKGROUP per problem -------------------------------------------
+// 512 threads x 8 columns; a step's minimum is found per wavefront (DPP), then over the eight wavefronts through LDS: two barriers
+// per step instead of none, ~1.5 us per step -- a 2 000-point problem takes a few hundred thousand steps at worst.  Everything
+// else (costs recomputed from the points, duals, links, the loss and its gradient) as above, so that a problem gives the same
+// numbers whichever kernel takes it.
+constexpr int W2_WIDE_THREADS = 512, W2_WIDE_CPL = 8, W2_WIDE_NMAX = W2_WIDE_THREADS * W2_WIDE_CPL;
+__global__ __launch_bounds__(W2_WIDE_THREADS) void tlc_w2_match_wide_kernel(W2Params p, int min_points) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char w2_lds[];
+    constexpr int NMAX = W2_WIDE_NMAX, CPL = W2_WIDE_CPL, W = W2_WIDE_THREADS, NWV = W / 64;
+    double* xs = (double*)w2_lds;              // [NMAX] predicted births
+    double* ys = xs + NMAX;                    // [NMAX] predicted deaths
+    double* u = ys + NMAX;                     // [NMAX] row duals
+    int* pcol = (int*)(u + NMAX);              // [NMAX] row assigned to column j, -1 = free
+    int* way = pcol + NMAX;                    // [NMAX] previous column on the alternating path, -1 = the start
+    double* red = (double*)(way + NMAX);       // [2 NWV] wavefront minima (at the end: the two partial sums per wavefront)
+    double* sums = red + 2 * NWV;              // [2]
+    int* redj = (int*)(sums + 2);              // [NWV] the columns of the minima
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double INF = __longlong_as_double(0x7FF0000000000000ll);
+    const int b = blockIdx.x;
+    if (b >= p.n_pairs) return;
+    const long long x0 = p.xoff[b], y0 = p.yoff[b];
+    const int n = (int)(p.xoff[b + 1] - x0), m = (int)(p.yoff[b + 1] - y0);
+    if (n <= min_points) return;                                      // (the one-wavefront kernel took it)
+    if (n < m || n > NMAX) {
+        if (tid == 0) { p.status[b] = n < m ? 1 : 2; p.loss[b] = 0.0; p.wxy[b] = 0.0; p.wxd[b] = 0.0; }
+        for (int i = tid; i < n; i += W) { p.assign[x0 + i] = -1; if (p.gradX) { p.gradX[2 * (x0 + i)] = 0.0; p.gradX[2 * (x0 + i) + 1] = 0.0; } }
+        return;
+    }
+    for (int i = tid; i < n; i += W) {
+        xs[i] = p.X[2 * (x0 + i)]; ys[i] = p.X[2 * (x0 + i) + 1];
+        u[i] = 0.0; pcol[i] = -1;
+    }
+    double yx[CPL], yy[CPL], v[CPL], minv[CPL];
+    bool used[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int j = tid + W * c;
+        yx[c] = yy[c] = 0.0;
+        if (j < m) { yx[c] = p.Y[2 * (y0 + j)]; yy[c] = p.Y[2 * (y0 + j) + 1]; }
+        v[c] = 0.0;
+    }
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { minv[c] = INF; used[c] = false; }
+        int i0 = i, j0 = -1;
+        for (;;) {
+            const double xi = xs[i0], yi = ys[i0], ui = u[i0];
+            const double cd = w2_pow((yi - xi) * 0.5, p.order);
+            double best = INF;
+            int bj = -1;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int j = tid + W * c;
+                if (j < n && !used[c]) {
+                    double cost = cd;
+                    if (j < m) {
+                        const double dx = fabs(xi - yx[c]), dy = fabs(yi - yy[c]);
+                        cost = w2_pow(dx > dy ? dx : dy, p.order);
+                    }
+                    const double cur = cost - ui - v[c];
+                    if (cur < minv[c]) { minv[c] = cur; way[j] = j0; }
+                    if (minv[c] < best) { best = minv[c]; bj = j; }
+                }
+            }
+            // the minimum over the workgroup; among equal minima the lowest column (the one-wavefront kernel's rule)
+            const double wmin = tlc_wave_min_f64(best);
+            unsigned long long who = __ballot(best == wmin && bj >= 0);
+            int wj = 0x7fffffff;
+            if (who) {
+                // lowest column among the wavefront's candidates
+                int cand = (best == wmin && bj >= 0) ? bj : 0x7fffffff;
+                for (int o = 32; o; o >>= 1) { const int t = __shfl_xor(cand, o); cand = t < cand ? t : cand; }
+                wj = cand;
+            }
+            if (lane == 0) { red[wave] = wmin; redj[wave] = wj; }
+            __syncthreads();
+            double delta = red[0];
+            int j1 = redj[0];
+#pragma unroll
+            for (int k = 1; k < NWV; ++k) {
+                const double d = red[k];
+                const int jj = redj[k];
+                if (d < delta || (d == delta && jj < j1)) { delta = d; j1 = jj; }
+            }
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int j = tid + W * c;
+                if (j < n) {
+                    if (used[c]) { u[pcol[j]] += delta; v[c] -= delta; }
+                    else minv[c] -= delta;
+                }
+            }
+            if (tid == 0) u[i] += delta;
+            j0 = j1;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) if (tid + W * c == j1) used[c] = true;
+            __syncthreads();
+            i0 = pcol[j1];
+            if (i0 < 0) break;
+        }
+        if (tid == 0) {
+            int j = j0;
+            while (j >= 0) {
+                const int jp = way[j];
+                pcol[j] = jp < 0 ? i : pcol[jp];
+                j = jp;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the loss and its pieces ------------------------------------------------------------------------------------------
+    double sxy = 0.0, sxd = 0.0;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int j = tid + W * c;
+        if (j < n) {
+            const int i = pcol[j];
+            if (j < m) {
+                const double dx = fabs(xs[i] - yx[c]), dy = fabs(ys[i] - yy[c]);
+                const double d = dx > dy ? dx : dy;
+                sxy += p.order == 2 ? d * d : d;
+                p.assign[x0 + i] = j;
+            } else {
+                const double d = fabs((ys[i] - xs[i]) * 0.5);
+                sxd += p.order == 2 ? d * d : d;
+                p.assign[x0 + i] = -1;
+            }
+        }
+    }
+    for (int o = 32; o; o >>= 1) { sxy += __shfl_xor(sxy, o); sxd += __shfl_xor(sxd, o); }
+    if (lane == 0) { red[wave] = sxy; red[NWV + wave] = sxd; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, d = 0.0;
+        for (int k = 0; k < NWV; ++k) { a += red[k]; d += red[NWV + k]; }
+        sums[0] = a; sums[1] = d;
+    }
+    __syncthreads();
+    sxy = sums[0]; sxd = sums[1];
+    const double tot = sxy + sxd;
+    const double L = p.order == 2 ? sqrt(tot) : tot;
+    if (tid == 0) {
+        p.status[b] = 0;
+        p.loss[b] = L;
+        p.wxy[b] = p.order == 2 ? sqrt(sxy) : sxy;
+        p.wxd[b] = p.order == 2 ? sqrt(sxd) : sxd;
+    }
+    if (p.gradX) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = tid + W * c;
+            if (j < n) {
+                const int i = pcol[j];
+                double gx = 0.0, gy = 0.0;
+                if (j < m) {
+                    const double ex = yx[c] - xs[i], ey = yy[c] - ys[i];
+                    const double ax = fabs(ex), ay = fabs(ey);
+                    const double d = ax > ay ? ax : ay;
+                    const double w = p.order == 2 ? (L > 0.0 ? d / L : 0.0) : 1.0;
+                    if (ax >= ay) gx = -w * (ex > 0.0 ? 1.0 : (ex < 0.0 ? -1.0 : 0.0));
+                    else gy = -w * (ey > 0.0 ? 1.0 : (ey < 0.0 ? -1.0 : 0.0));
+                } else {
+                    const double s = (ys[i] - xs[i]) * 0.5;
+                    const double w = p.order == 2 ? (L > 0.0 ? s / L : 0.0) : (s > 0.0 ? 1.0 : (s < 0.0 ? -1.0 : 0.0));
+                    gx = -0.5 * w; gy = 0.5 * w;
+                }
+                p.gradX[2 * (x0 + i)] = gx;
+                p.gradX[2 * (x0 + i) + 1] = gy;
+            }
+        }
+    }
+}
+
+static int launch_w2_wide(const W2Params& p, int min_points, hipStream_t s) {
+    const size_t lds = (size_t)W2_WIDE_NMAX * (3 * 8 + 2 * 4) + 64 * 8;
+    TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_w2_match_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(tlc_w2_match_wide_kernel, dim3(p.n_pairs), dim3(W2_WIDE_THREADS), lds, s, p, min_points);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
 template <int CPL>
 static int launch_w2(const W2Params& p, hipStream_t s) {
     const size_t lds = (size_t)64 * CPL * (4 * 8 + 2 * 4);
@@ -201,7 +387,8 @@ static int launch_w2(const W2Params& p, hipStream_t s) {
 }  // namespace
 
 // max_points: an upper bound of the predicted points of one problem (the caller knows its offsets): picks the kernel variant
-// (64 / 128 / 256 / 512 columns); problems beyond 512 predicted points get status 2.
+// (64 / 128 / 256 / 512 columns per wavefront); above 512 a second launch gives every larger problem a 512-thread workgroup
+// (up to 4 096 predicted points); beyond that status 2.
 extern "C" int tlc_w2_partial_matching(int32_t n_problems, const int64_t* d_xoff, const double* d_X, const int64_t* d_yoff,
                                        const double* d_Y, int order, int32_t max_points, double* d_loss, double* d_wxy,
                                        double* d_wxd, int32_t* d_assign, double* d_gradX, uint8_t* d_status, void* stream) {
@@ -213,8 +400,11 @@ extern "C" int tlc_w2_partial_matching(int32_t n_problems, const int64_t* d_xoff
     p.n_pairs = n_problems; p.xoff = (const long long*)d_xoff; p.X = d_X; p.yoff = (const long long*)d_yoff; p.Y = d_Y;
     p.order = order; p.loss = d_loss; p.wxy = d_wxy; p.wxd = d_wxd; p.assign = d_assign; p.gradX = d_gradX; p.status = d_status;
     hipStream_t s = (hipStream_t)stream;
+    p.leave_big = max_points > 512;
     if (max_points <= 64) return launch_w2<1>(p, s);
     if (max_points <= 128) return launch_w2<2>(p, s);
     if (max_points <= 256) return launch_w2<4>(p, s);
-    return launch_w2<8>(p, s);
+    int rc = launch_w2<8>(p, s);
+    if (rc != TLC_OK || max_points <= 512) return rc;
+    return launch_w2_wide(p, 512, s);           // problems of 513 .. 4 096 predicted points: a workgroup each; beyond: status 2
 }
