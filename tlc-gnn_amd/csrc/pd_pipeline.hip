@@ -38,6 +38,11 @@
 #define TLC_STAMP(k) do { } while (0)
 #endif
 #define TLC_NONE16 0xFFFFu
+// the SMALL tier keeps its entry weights in LDS (true) or reads them from the arena like the larger tiers (false: 6.9 -> 4.8 KB per
+// workgroup; A/B on one box, tools/gpu_build_ab.sh: pipelined batch 0.744 -> 0.736 ms, one batch alone 0.804 -> 0.792 ms)
+#ifndef TLC_SMALL_LWL
+#define TLC_SMALL_LWL false
+#endif
 
 namespace {
 
@@ -2168,18 +2173,18 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
         static int once = 0;
         if (!once++)
             fprintf(stderr, "[tlc] LDS per workgroup: SMALL %zu | MEDIUM tier %zu swap %zu | MID tier %zu swap %zu | LARGE tier %zu dc %zu\n",
-                    (size_t)make_layout(TLC_S_NMAX, TLC_S_MMAX, true, 2).total, (size_t)make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2).total,
+                    (size_t)make_layout(TLC_S_NMAX, TLC_S_MMAX, TLC_SMALL_LWL, 2).total, (size_t)make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2).total,
                     (size_t)make_swap_layout(TLC_M_NMAX, TLC_M_MMAX).total, (size_t)make_layout(TLC_D_NMAX, TLC_D_MMAX, false, 2).total,
                     (size_t)make_swap_layout(TLC_D_NMAX, TLC_D_MMAX).total, (size_t)make_layout(TLC_L_NMAX, TLC_L_MMAX, false, 2).total,
                     (size_t)dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX));
     }
     switch (tier) {
         case TLC_TIER_SMALL: {
-            constexpr Layout L = make_layout(TLC_S_NMAX, TLC_S_MMAX, true, 2);
+            constexpr Layout L = make_layout(TLC_S_NMAX, TLC_S_MMAX, TLC_SMALL_LWL, 2);
             // (development: TLC_SMALL_LDS_PAD=bytes inflates this tier's footprint -- the experiment behind DESIGN.md's "the tier
             // phase is bound by LDS capacity x time": +4 KB here costs the batch 2.5 %, +16 KB 20 %)
             static const size_t pad = getenv("TLC_SMALL_LDS_PAD") ? (size_t)atoi(getenv("TLC_SMALL_LDS_PAD")) : 0;
-            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_S_NMAX, TLC_S_MMAX, 64, true, false>), dim3(p.tier_count), dim3(64),
+            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_S_NMAX, TLC_S_MMAX, 64, TLC_SMALL_LWL, false>), dim3(p.tier_count), dim3(64),
                                L.total + pad, s, p);
             break;
         }
