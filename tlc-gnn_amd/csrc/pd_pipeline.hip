@@ -2169,7 +2169,8 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
     // tiers with a hand-off buffer leave the cycle swap + image of their subgraphs to tlc_pd_swap_kernel, same stream
     const bool deferring = p.handoff != nullptr && p.pi_enabled && !(p.flags & TLC_NO_EXT1);
     const int grid = p.grid > 0 ? p.grid : p.tier_count;
-    if (getenv("TLC_HOST_TRACE")) {                   // (development: LDS bytes per workgroup of every kernel of the tiers)
+    static const bool host_trace = getenv("TLC_HOST_TRACE") != nullptr;
+    if (host_trace) {                                 // (development: LDS bytes per workgroup of every kernel of the tiers)
         static int once = 0;
         if (!once++)
             fprintf(stderr, "[tlc] LDS per workgroup: SMALL %zu | MEDIUM tier %zu swap %zu | MID tier %zu swap %zu | LARGE tier %zu dc %zu\n",
@@ -2227,7 +2228,7 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
                 constexpr SwapLayout SL = make_swap_layout(TLC_L_NMAX, TLC_L_MMAX);
                 // (its own 107 KB only, see above)
                 const size_t dcl = (dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX) > 156 * 1024 || !(excl & 2)) ? dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX) : 156 * 1024;
-                if (getenv("TLC_HOST_TRACE")) { static int once = 0; if (!once++) fprintf(stderr, "[tlc] LARGE tier LDS %zu (layout %zu), dc %zu (layout %zu)\n", lds_bytes, (size_t)L.total, dcl, (size_t)dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX)); }
+                if (host_trace) { static int once = 0; if (!once++) fprintf(stderr, "[tlc] LARGE tier LDS %zu (layout %zu), dc %zu (layout %zu)\n", lds_bytes, (size_t)L.total, dcl, (size_t)dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX)); }
                 rc = set_lds_limit(tlc_pd_dc_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS>, dcl);
                 if (rc) return rc;
                 if (p.dc_count)
