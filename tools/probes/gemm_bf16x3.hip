@@ -7,7 +7,13 @@
 // Why (per-step stamps, one wavefront per SIMD because M / 16 = 1 233 row tiles meet 1 024 SIMDs): a k step of 42 MFMAs (672
 // cycles) takes 0.85 us = 2 000 cycles -- the 21 ds_read_b128 of the step's B fragments are waited for in front of the MFMAs
 // and nothing else runs on the SIMD; interleaving the accumulators did not change it (it is not MFMA dependency); the C store
-// at the end costs another 3.9 us.  Two workgroups per CU overlap perfectly (two waves per SIMD: same time for twice the rows), so
+// at the end costs another 3.9 us.  A later ablation of a fourth variant (A in a ring of six steps, all of a step's fragments read
+// before its products; 29.9 us) with rocprofv3 kernel times on a one-round launch (64 workgroups): everything 23.2 us; without
+// the MFMAs 19.8; without the B copies, the barriers and the A ring 15.7; without the MFMAs as well 12.8 -- i.e. the 672 MFMAs of
+// a wavefront cost 3 us, the per-step copy + barrier 7 us, and 11-13 us are launch, the first HBM round trip, the piece cutting
+// and the C store drain of a kernel that lives for one round.  The f32 kernel pays the same fixed costs inside its 30 us; a
+// bf16-pieces kernel only wins if those are overlapped (several short-lived workgroups per CU), which PubMed's 1 233 row tiles
+// do not give with B shared through LDS.  Two workgroups per CU overlap perfectly (two waves per SIMD: same time for twice the rows), so
 // the kernel needs either (row tile, column half) wavefronts -- 2 466 of them, two per SIMD -- or the next group's fragments
 // prefetched under the current group's MFMAs (36 more VGPRs: past 256 with the whole A row tile in registers).  Estimated
 // 15-17 us with either; not done.  What cost most before that: cutting B in every workgroup (VALU: 1.8 us per step), loads behind
