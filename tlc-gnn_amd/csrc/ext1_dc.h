@@ -26,7 +26,9 @@
  * dependent LDS round trips, no latency hiding) -- 8 levels = 100 us for 190 queries against 185 us for the serial walk in
  * tlc_pd_swap_kernel, and the kernel sits between the tier kernel and the serial kernel on the same stream: the chain gets
  * longer, not shorter.  Only the sizes the tier cannot reach in this batch take it. */
+#ifndef TLC_DC_MIN_POS_SHARED
 #define TLC_DC_MIN_POS_SHARED 320
+#endif
 #define TLC_DC_LARGE_MODE 2          /* LARGE tier: 1 = in the tier kernel, 2 = hand the subgraph to tlc_pd_dc_kernel */
 #define TLC_DC_MAX_TIE_RUN 64       /* longer runs of equal descending keys: no fix-up, serial walk */
 
