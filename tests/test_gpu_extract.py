@@ -184,4 +184,19 @@ def test_async_batches_overlap_and_equal_the_stream_ordered_call():
     torch.cuda.synchronize()
     assert torch.equal(o4, want[1][0])
     assert g.stats()["chunks"] == 1
+    # pipelined chunks do not split the MEDIUM tier by Pos-edge count (no speculative launch either); with the split forced, with
+    # its reserved slots cut to 8 and with kernel events on every 2nd chunk only, the rows are the same
+    for opts in ({"mh_always": 1}, {"mh_always": 1, "spec_cap": 8}, {"timing_every": 2}):
+        for k, v in opts.items():
+            g.set_option(k, v)
+        if "timing_every" in opts:
+            g.set_timing(True)
+        got = [g.pd_pi_batch(b, 2, async_=True) for b in batches]
+        g.join()
+        torch.cuda.synchronize()
+        for k, ((o, s), (wo, wst)) in enumerate(zip(got, want)):
+            assert torch.equal(s, wst) and torch.equal(o, wo), (opts, k)
+        g.set_timing(False)
+        for k in opts:
+            g.set_option(k, 1 if k == "timing_every" else 0)
     g.close()
