@@ -157,6 +157,7 @@ struct tlc_graph {
     // development / test switches (tlc_debug_set_option; initial values from the environment: TLC_EXTRACT, TLC_HEAVY, TLC_TINY)
     int opt_extract, opt_heavy, opt_tiny;
     int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
+    int opt_gate_ticks;                 // development: bound of the residency gate of pipelined chunks (-1: the default 50 us)
     int opt_mh_always;                  // tests: split the MEDIUM tier by Pos-edge count in pipelined chunks too
     int opt_spec_cap;                   // tests: upper bound of the slots reserved for the speculative launches (0 = none)
     int opt_timing_every;               // measurement: kernel events on every n-th chunk only
@@ -429,7 +430,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     g->device = device; g->n_nodes = n_nodes; g->nnz = nnz; g->nw = nw; g->vic_lds = lds;
     auto env_on = [](const char* name) { const char* v = getenv(name); return !(v && v[0] == '0'); };
     g->opt_extract = env_on("TLC_EXTRACT"); g->opt_heavy = env_on("TLC_HEAVY"); g->opt_tiny = env_on("TLC_TINY");
-    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = 0x7f; g->opt_timing_every = 1;
+    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = 0x7f; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
@@ -743,8 +744,12 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         // then runs 1.05 instead of 0.88 ms because its last workgroups start ~0.15 ms late).  So the main COUNT is held until
         // the early COUNT is done and the early tier kernel's workgroups are resident (bounded: 50 us after the former).
         TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_early, 0));
-        hipLaunchKernelGGL(tlc_wait_started_dev, dim3(1), dim3(TLC_WAVE), 0, s, (const int*)d_early_started, (const int*)d_early_count,
-                           192, 5000ll);
+        // (opt_gate_ticks: the bound in 10 ns ticks, 0 = no gate at all; development A/B of the pipelined case, where the machine
+        // is full of the previous chunk's tier kernels whatever this chunk's extraction does)
+        const long long gate = pipelined && g->opt_gate_ticks >= 0 ? (long long)g->opt_gate_ticks : 5000ll;
+        if (gate > 0)
+            hipLaunchKernelGGL(tlc_wait_started_dev, dim3(1), dim3(TLC_WAVE), 0, s, (const int*)d_early_started, (const int*)d_early_count,
+                               192, gate);
         TLC_HIP_CHECK(hipGetLastError());
     }
     vp.work_counter = ws->d_ctl + 24;
@@ -1296,6 +1301,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "tier_mask")) g->opt_tier_mask = value;
     else if (!strcmp(name, "spec_cap")) g->opt_spec_cap = std::max(value, 0);
     else if (!strcmp(name, "mh_always")) g->opt_mh_always = value != 0;
+    else if (!strcmp(name, "gate_ticks")) g->opt_gate_ticks = value;
     else if (!strcmp(name, "timing_every")) { g->opt_timing_every = std::max(value, 1); g->timing_seq = 0; }
     else if (!strcmp(name, "dc_force_fail")) g->opt_dc_force_fail = value != 0;
     else if (!strcmp(name, "x_region")) g->opt_x_region = std::max(value, 0);
