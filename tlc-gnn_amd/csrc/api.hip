@@ -157,6 +157,7 @@ struct tlc_graph {
     // development / test switches (tlc_debug_set_option; initial values from the environment: TLC_EXTRACT, TLC_HEAVY, TLC_TINY)
     int opt_extract, opt_heavy, opt_tiny;
     int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
+    int opt_x_grid, opt_x_chunk_div;    // development: extraction workgroups / work-queue granularity (0: the defaults)
     int opt_gate_ticks;                 // development: bound of the residency gate of pipelined chunks (-1: the default 50 us)
     int opt_mh_always;                  // tests: split the MEDIUM tier by Pos-edge count in pipelined chunks too
     int opt_spec_cap;                   // tests: upper bound of the slots reserved for the speculative launches (0 = none)
@@ -645,7 +646,8 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         if ((rc = ensure_ball_lists(g, hop, s)) != TLC_OK) return rc;
         use_x = g->ball_list_hop == hop;
     }
-    const int xgrid = std::min(n_pairs, g->vic_slots);
+    // (opt_x_grid: development A/B of the number of extraction workgroups; never more than the scratch slots there are)
+    const int xgrid = std::min(n_pairs, g->opt_x_grid > 0 ? std::min(g->opt_x_grid, g->vic_slots) : g->vic_slots);
     long long bump_base = 0;
     if (use_x) {
         // arena = one region per workgroup of the extraction (main pass, then the early pass), then the bump area
@@ -753,7 +755,10 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         TLC_HIP_CHECK(hipGetLastError());
     }
     vp.work_counter = ws->d_ctl + 24;
-    vp.work_chunk = std::max(4, n_pairs / 8192);
+    // (about one chunk per RESIDENT extraction wavefront -- 16 per CU, 4 096 -- so that the counter is hardly used: in-process A/B
+    // against twice as many chunks, tools/ab_option.py x_chunk_div 0 8192: -1 % per pipelined batch; half as many leaves half of the
+    // machine without a first chunk: +6 %)
+    vp.work_chunk = std::max(4, n_pairs / (g->opt_x_chunk_div > 0 ? g->opt_x_chunk_div : 4096));
     T0(0, s);
     if (use_x) {
         if ((rc = tlc_launch_extract(64, xgrid, g->x_lds64, vp, s)) != TLC_OK) return rc;
@@ -1302,6 +1307,8 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "spec_cap")) g->opt_spec_cap = std::max(value, 0);
     else if (!strcmp(name, "mh_always")) g->opt_mh_always = value != 0;
     else if (!strcmp(name, "gate_ticks")) g->opt_gate_ticks = value;
+    else if (!strcmp(name, "x_grid")) g->opt_x_grid = std::max(value, 0);
+    else if (!strcmp(name, "x_chunk_div")) g->opt_x_chunk_div = std::max(value, 0);
     else if (!strcmp(name, "timing_every")) { g->opt_timing_every = std::max(value, 1); g->timing_seq = 0; }
     else if (!strcmp(name, "dc_force_fail")) g->opt_dc_force_fail = value != 0;
     else if (!strcmp(name, "x_region")) g->opt_x_region = std::max(value, 0);
