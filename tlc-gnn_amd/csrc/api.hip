@@ -158,6 +158,7 @@ struct tlc_graph {
     int opt_extract, opt_heavy, opt_tiny;
     int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
     int opt_x_grid, opt_x_chunk_div;    // development: extraction workgroups / work-queue granularity (0: the defaults)
+    int opt_medium_first;               // development: submit the MEDIUM / MID tiers ahead of TINY / SMALL
     int opt_gate_ticks;                 // development: bound of the residency gate of pipelined chunks (-1: the default 50 us)
     int opt_mh_always;                  // tests: split the MEDIUM tier by Pos-edge count in pipelined chunks too
     int opt_spec_cap;                   // tests: upper bound of the slots reserved for the speculative launches (0 = none)
@@ -990,35 +991,50 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         }
         // 0. the SMALL tier needs nothing more (its subgraphs were written by the COUNT pass); it is submitted after the
         //    heavy chain so that its many workgroups do not delay that chain's start
-        // the lower end of the SMALL tier first: one lane per subgraph, a few hundred latency-bound wavefronts that need 66 KB of
+        // the lower end of the SMALL tier first: one lane per subgraph, a few hundred latency-bound wavefronts that need 36 KB of
         // LDS each -- they must find room before the other tiers' workgroups take it
-        if (tc[TLC_TIER_TINY] > 0) {
-            if (bumped) { TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_scan, 0)); }
-            else { TLC_HIP_CHECK(hipEventRecord(ws->ev_fork, s)); TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_fork, 0)); }
-            pp.tier_list = ws->tier_list + (size_t)TLC_TIER_TINY * n_pairs; pp.tier_count = tc[TLC_TIER_TINY];
-            pp.handoff = nullptr; pp.handoff_stride = 0; pp.handoff_cap = 0; pp.grid = 0; pp.phase = 0;
-            pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
-            pp.dc_count = nullptr; pp.dc_list = nullptr;
-            pp.phase_cycles = g->d_phase ? g->d_phase + 32 * TLC_TIER_TINY : nullptr;
-            if (((g->opt_tier_mask >> TLC_TIER_TINY) & 1) && (rc = tlc_launch_pd_tiny(pp, ws->side[5])) != TLC_OK) return rc;
-            TLC_HIP_CHECK(hipEventRecord(ws->ev_join[5], ws->side[5]));
-            used[5] = true;
-        }
-        if (tc[TLC_TIER_SMALL] > 0 && (rc = launch_side(0, TLC_TIER_SMALL, false)) != TLC_OK) return rc;
-
-        // 2. the MEDIUM tier
-        if (tc[TLC_TIER_MEDIUM] + tc[TLC_TIER_MEDHI] + tc[TLC_TIER_MID] > 0) {
-            if (!bumped && !filled_all) {
-                vp.fill_mode = (heavy > 0 || n_early > 0) ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
-                hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
-                TLC_HIP_CHECK(hipGetLastError());
+        auto launch_tiny_small = [&]() -> int {
+            if (tc[TLC_TIER_TINY] > 0) {
+                if (bumped) { TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_scan, 0)); }
+                else { TLC_HIP_CHECK(hipEventRecord(ws->ev_fork, s)); TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_fork, 0)); }
+                pp.tier_list = ws->tier_list + (size_t)TLC_TIER_TINY * n_pairs; pp.tier_count = tc[TLC_TIER_TINY];
+                pp.handoff = nullptr; pp.handoff_stride = 0; pp.handoff_cap = 0; pp.grid = 0; pp.phase = 0;
+                pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
+                pp.dc_count = nullptr; pp.dc_list = nullptr;
+                pp.phase_cycles = g->d_phase ? g->d_phase + 32 * TLC_TIER_TINY : nullptr;
+                int r = ((g->opt_tier_mask >> TLC_TIER_TINY) & 1) ? tlc_launch_pd_tiny(pp, ws->side[5]) : TLC_OK;
+                if (r != TLC_OK) return r;
+                TLC_HIP_CHECK(hipEventRecord(ws->ev_join[5], ws->side[5]));
+                used[5] = true;
             }
-            T1(2, s);
-            if (!spec_done && tc[TLC_TIER_MEDHI] > 0 && (rc = launch_side(2, TLC_TIER_MEDHI)) != TLC_OK) return rc;
-            if (tc[TLC_TIER_MEDIUM] > 0 && (rc = launch_side(6, TLC_TIER_MEDIUM, !bumped)) != TLC_OK) return rc;
-            if (tc[TLC_TIER_MID] > 0 && (rc = launch_side(3, TLC_TIER_MID, !bumped)) != TLC_OK) return rc;
+            if (tc[TLC_TIER_SMALL] > 0) return launch_side(0, TLC_TIER_SMALL, false);
+            return TLC_OK;
+        };
+        // 2. the MEDIUM-sized tiers
+        auto launch_medium_mid = [&]() -> int {
+            int r;
+            if (tc[TLC_TIER_MEDIUM] + tc[TLC_TIER_MEDHI] + tc[TLC_TIER_MID] > 0) {
+                if (!bumped && !filled_all) {
+                    vp.fill_mode = (heavy > 0 || n_early > 0) ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
+                    hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
+                    TLC_HIP_CHECK(hipGetLastError());
+                }
+                T1(2, s);
+                if (!spec_done && tc[TLC_TIER_MEDHI] > 0 && (r = launch_side(2, TLC_TIER_MEDHI)) != TLC_OK) return r;
+                if (tc[TLC_TIER_MEDIUM] > 0 && (r = launch_side(6, TLC_TIER_MEDIUM, !bumped)) != TLC_OK) return r;
+                if (tc[TLC_TIER_MID] > 0 && (r = launch_side(3, TLC_TIER_MID, !bumped)) != TLC_OK) return r;
+            } else {
+                T1(2, s);
+            }
+            return TLC_OK;
+        };
+        // (opt_medium_first: development A/B of the submission order -- the MEDIUM chain is the longest of a pipelined chunk)
+        if (g->opt_medium_first) {
+            if ((rc = launch_medium_mid()) != TLC_OK) return rc;
+            if ((rc = launch_tiny_small()) != TLC_OK) return rc;
         } else {
-            T1(2, s);
+            if ((rc = launch_tiny_small()) != TLC_OK) return rc;
+            if ((rc = launch_medium_mid()) != TLC_OK) return rc;
         }
     }
     for (int k = 0; k < TLC_N_SIDE; ++k)
@@ -1307,6 +1323,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "spec_cap")) g->opt_spec_cap = std::max(value, 0);
     else if (!strcmp(name, "mh_always")) g->opt_mh_always = value != 0;
     else if (!strcmp(name, "gate_ticks")) g->opt_gate_ticks = value;
+    else if (!strcmp(name, "medium_first")) g->opt_medium_first = value != 0;
     else if (!strcmp(name, "x_grid")) g->opt_x_grid = std::max(value, 0);
     else if (!strcmp(name, "x_chunk_div")) g->opt_x_chunk_div = std::max(value, 0);
     else if (!strcmp(name, "timing_every")) { g->opt_timing_every = std::max(value, 1); g->timing_seq = 0; }
