@@ -158,6 +158,7 @@ struct tlc_graph {
     int opt_extract, opt_heavy, opt_tiny;
     int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
     int opt_x_grid, opt_x_chunk_div;    // development: extraction workgroups / work-queue granularity (0: the defaults)
+    int opt_chunk_pairs;                // development: pairs per chunk (0: TLC_CHUNK_PAIRS)
     int opt_medium_first;               // development: submit the MEDIUM / MID tiers ahead of TINY / SMALL
     int opt_gate_ticks;                 // development: bound of the residency gate of pipelined chunks (-1: the default 50 us)
     int opt_mh_always;                  // tests: split the MEDIUM tier by Pos-edge count in pipelined chunks too
@@ -1121,9 +1122,11 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
     hipStream_t s = (hipStream_t)stream;
     // a single chunk of a stream-ordered call runs on the caller's stream itself (no cross-stream hops in its latency);
     // otherwise every chunk runs on its workspace's own stream so that consecutive chunks overlap
-    const bool inline_main = join && n_pairs <= TLC_CHUNK_PAIRS;
-    for (int64_t off = 0; off < n_pairs; off += TLC_CHUNK_PAIRS) {
-        const int cnt = (int)std::min<int64_t>(TLC_CHUNK_PAIRS, n_pairs - off);
+    // (opt_chunk_pairs: development A/B -- a long list cut into more, pipelined chunks)
+    const int64_t chunk_pairs = g->opt_chunk_pairs > 0 ? std::min<int64_t>(g->opt_chunk_pairs, TLC_CHUNK_PAIRS) : TLC_CHUNK_PAIRS;
+    const bool inline_main = join && n_pairs <= chunk_pairs;
+    for (int64_t off = 0; off < n_pairs; off += chunk_pairs) {
+        const int cnt = (int)std::min<int64_t>(chunk_pairs, n_pairs - off);
         Workspace* ws = nullptr;
         int rc = acquire_workspace(g, &ws, inline_main);
         if (rc != TLC_OK) return rc;
@@ -1324,6 +1327,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "mh_always")) g->opt_mh_always = value != 0;
     else if (!strcmp(name, "gate_ticks")) g->opt_gate_ticks = value;
     else if (!strcmp(name, "medium_first")) g->opt_medium_first = value != 0;
+    else if (!strcmp(name, "chunk_pairs")) g->opt_chunk_pairs = std::max(value, 0);
     else if (!strcmp(name, "x_grid")) g->opt_x_grid = std::max(value, 0);
     else if (!strcmp(name, "x_chunk_div")) g->opt_x_chunk_div = std::max(value, 0);
     else if (!strcmp(name, "timing_every")) { g->opt_timing_every = std::max(value, 1); g->timing_seq = 0; }

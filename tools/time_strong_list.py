@@ -1,0 +1,25 @@
+"""development: the strong-scaling list (non-edges within hop distance, 504 514 pairs on the PubMed-shaped graph) in one call,
+cut into chunks of different sizes (handle option chunk_pairs): do pipelined chunks help a long list?"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from tlc_gnn_amd import engine
+import bench
+wl = bench.build_workload(0)
+g = engine.DeviceGraph(wl["rowptr"], wl["col"], wl["w"])
+ci = engine.ComplementIndex(wl["rowptr"], wl["col"], device=0)
+near, ranks = engine.near_pairs(ci, wl["hop"])
+near = near[torch.argsort(ranks)].contiguous()
+E = len(near)
+out = torch.empty((E, 25), dtype=torch.float64, device="cuda"); st = torch.empty(E, dtype=torch.uint8, device="cuda")
+ref = None
+for cp in (0, 1 << 18, 1 << 17, 1 << 16, 1 << 15, 0):
+    g.set_option("chunk_pairs", cp)
+    ts = []
+    for _ in range(5):
+        torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.pd_pi_batch(near, wl["hop"], out=out, status=st); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    if ref is None: ref = (out.clone(), st.clone())
+    same = bool(torch.equal(out, ref[0]) and torch.equal(st, ref[1]))
+    print("chunk_pairs=%8d  %d pairs: median %.2f ms (%.2f M images/s)  runs %s  rows equal: %s" % (cp, E, float(np.median(ts[1:])), E / float(np.median(ts[1:])) / 1e3, " ".join("%.1f" % t for t in ts), same))
