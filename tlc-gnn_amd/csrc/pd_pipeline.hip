@@ -2192,9 +2192,11 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
         case TLC_TIER_MEDHI:
         case TLC_TIER_MEDIUM: {
             constexpr Layout L = make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2);
+            // (development: TLC_MEDIUM_LDS_PAD=bytes -- how much does this tier's footprint cost?  37.5 KB = four workgroups per CU)
+            static const size_t mpad = getenv("TLC_MEDIUM_LDS_PAD") ? (size_t)atoi(getenv("TLC_MEDIUM_LDS_PAD")) : 0;
             if (p.phase != 2)
                 hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, false, false>), dim3(grid),
-                                   dim3(256), L.total, s, p);
+                                   dim3(256), L.total + mpad, s, p);
             if (deferring && p.phase != 1) {
                 constexpr SwapLayout SL = make_swap_layout(TLC_M_NMAX, TLC_M_MMAX);
                 hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_M_NMAX, TLC_M_MMAX>), dim3(grid), dim3(64), SL.total, s, p);
