@@ -161,7 +161,12 @@ int tlc_pd_pi_algorithmic_bytes(int32_t n_nodes, const int32_t* h_rowptr, const 
  * set_option(): switches of one handle for A/B timing and for the tests that check that results do not depend on them:
  * "extract" (ball-list extraction of the vicinities, hop <= 2), "heavy" (its hub-row skipping), "tiny" (lane-per-subgraph
  * kernel for vicinities of at most 16 nodes / 24 edges); 1 = on (default; the environment variables TLC_EXTRACT / TLC_HEAVY /
- * TLC_TINY = 0 switch them off at handle creation). */
+ * TLC_TINY = 0 switch them off at handle creation).  Test hooks: "tier_mask" (bit t: tier t's kernels are launched at all),
+ * "dc_force_fail", "x_region" / "x_bump_min" (arena entries per extraction workgroup / bump area: reach the overflow paths),
+ * "spec_cap" (slots reserved for speculative launches), "mh_always" (split the MEDIUM tier in pipelined chunks too).
+ * Measurement / A-B: "timing_every" (kernel events on every n-th chunk), "x_grid", "x_chunk_div", "gate_ticks", "medium_first",
+ * "chunk_pairs" (0 = the defaults).  Results never depend on any of them (tests/test_gpu_extract.py, tests/test_gpu_tiers.py);
+ * an unknown name is TLC_ERR_INVALID_ARG. */
 int tlc_debug_set_option(tlc_graph* g, const char* name, int value);
 int tlc_debug_dc_stats(tlc_graph* g, long long* h_out, void* stream);
 int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out, int64_t cap_u64, int32_t* n_rows);
