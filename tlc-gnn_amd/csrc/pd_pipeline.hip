@@ -38,7 +38,7 @@
 #define TLC_STAMP(k) do { } while (0)
 #endif
 #define TLC_NONE16 0xFFFFu
-// the SMALL tier keeps its entry weights in LDS (true) or reads them from the arena like the larger tiers (false: 6.9 -> 4.8 KB per
+// the SMALL tier keeps its entry weights in LDS (true) or reads them from the arena like the larger tiers (false: 6.9 -> 6.0 KB per
 // workgroup; A/B on one box, tools/gpu_build_ab.sh: pipelined batch 0.744 -> 0.736 ms, one batch alone 0.804 -> 0.792 ms)
 #ifndef TLC_SMALL_LWL
 #define TLC_SMALL_LWL false
