@@ -278,3 +278,62 @@ def test_teacher_train_mode_refuses_what_is_not_implemented():
         m(f, ei, PD, kernel='wasserstein', grad_PI=True)
     out = m(f, ei, PD, kernel='wasserstein', p=2, grad_PI=False)
     assert out[2].requires_grad
+
+
+def test_teacher_training_step_on_a_block_diagonal_batch_equals_the_sum_over_its_graphs():
+    """The reference steps graph by graph and lets the gradients of `batch_size` samples accumulate before `optimizer.step()`
+    (train_Teacher_Model.py:35-64).  The drop-in takes the same graphs as ONE block-diagonal batch (graph_ptr / edge_ptr): its loss
+    is the sum of the per-graph losses and its gradients are the accumulated ones -- checked against autograd of the restatement run
+    graph by graph."""
+    import torch
+    from oracle import lp_forward_ref as ref
+    from oracle import w2_ref
+    from tlc_gnn_amd import ops
+    from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
+    torch.manual_seed(11)
+    rs = np.random.RandomState(11)
+    graphs, fs, pds = [], [], []
+    for b in range(6):
+        n = int(rs.randint(5, 40))
+        ei = _random_graph(rs, n, int(rs.randint(n, 4 * n)), torch)
+        m = ei.shape[1] - n
+        graphs.append((n, ei[:, :m]))
+        fs.append(torch.rand(n, 1))
+        bb = rs.rand(m)
+        pds.append(torch.tensor(np.stack([bb, bb + rs.uniform(0, 0.6, size=m)], 1), dtype=torch.float32))
+    gptr = np.concatenate([[0], np.cumsum([g[0] for g in graphs])])
+    eptr = np.concatenate([[0], np.cumsum([g[1].shape[1] for g in graphs])])
+    N = int(gptr[-1])
+    ei_all = torch.cat([g[1] + int(gptr[b]) for b, g in enumerate(graphs)], dim=1)
+    loops = torch.arange(N, dtype=torch.int64)
+    ei_full = torch.cat([ei_all, torch.stack([loops, loops])], dim=1)                  # self loops LAST (train_Teacher_Model.py:43-44)
+    model = Teacher_Model(type='GAT', dropout=0.0)
+    with torch.no_grad():
+        for conv in (model.DIM0_Model.conv1, model.DIM0_Model.conv2, model.DIM0_Model.conv3, model.DIM0_Model.conv4):
+            conv.bias.uniform_(-0.2, 0.2)
+            torch.nn.init.xavier_uniform_(conv.lin_ij.weight)
+    params, leaves = _teacher_params(model, torch)
+    model = model.cuda().train()
+    x0, img, loss0, lxy, lxd, lyd, _, _ = model(torch.cat(fs).cuda(), ei_full.cuda(), torch.cat(pds).cuda(), kernel='wasserstein', p=2, grad_PI=False,
+                                                graph_ptr=torch.tensor(gptr).cuda(), edge_ptr=torch.tensor(eptr).cuda())
+    assert img.shape == (6, 25) and loss0.shape == (1,)
+    loss0.backward()
+    # graph by graph through the restatement, the loss expression on the device's matching of that graph
+    xoff = torch.tensor(eptr).cuda()
+    r = ops.w2_partial_matching(xoff, x0.detach().double(), xoff, torch.cat(pds).double().cuda(), order=2)
+    assign = r["assign"].cpu().numpy()
+    total = 0.0
+    for b, (n, e) in enumerate(graphs):
+        m = e.shape[1]
+        lp = torch.arange(n, dtype=torch.int64)
+        _, pd_ref = ref.teacher_forward(fs[b], torch.cat([e, torch.stack([lp, lp])], dim=1), params)
+        assert _rel(x0[eptr[b]:eptr[b + 1]], pd_ref) <= 5e-5, b
+        lb = w2_ref.loss_torch(pd_ref, pds[b], assign[eptr[b]:eptr[b + 1]], 2)
+        total = total + lb
+    assert abs(float(loss0.detach()) - float(total.detach())) <= 1e-5 * max(1.0, abs(float(total.detach())))
+    total.backward()
+    named = dict(model.named_parameters())
+    for name, leaf in leaves.items():
+        got = named[name].grad
+        assert got is not None, name
+        assert _rel(got.reshape(leaf.shape), leaf.grad) <= 1e-4, (name, _rel(got.reshape(leaf.shape), leaf.grad))
