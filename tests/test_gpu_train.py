@@ -337,3 +337,33 @@ def test_teacher_training_step_on_a_block_diagonal_batch_equals_the_sum_over_its
         got = named[name].grad
         assert got is not None, name
         assert _rel(got.reshape(leaf.shape), leaf.grad) <= 1e-4, (name, _rel(got.reshape(leaf.shape), leaf.grad))
+
+
+def test_gat_layer_backward_with_tied_minima_and_maxima():
+    """Several in-neighbours of a node with the same input row send the same message: the minimum / maximum is attained more than
+    once.  The kernel gives the tied gradient to the first edge of the row, torch's scatter-reduce splits it evenly -- the inputs'
+    gradients then differ between the tied sources, but every PARAMETER gradient is the same (tied sources have equal x_l rows)."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import lp_forward_ref as ref
+    from tlc_gnn_amd import ops
+    from tlc_gnn_amd.Knowledge_Distillation.gat_conv import GATConv
+    rs = np.random.RandomState(4)
+    torch.manual_seed(4)
+    n, c_in, c_out = 120, 1, 32                               # the first layer: the filtration value is the only input
+    ei = _random_graph(rs, n, 900, torch)
+    x = torch.tensor(rs.randint(0, 4, size=(n, 1)) / 4.0, dtype=torch.float32)        # four distinct values: ties everywhere
+    wl = (torch.randn(c_out, c_in) * 0.5).requires_grad_()
+    att = (torch.randn(c_out) * 0.5).requires_grad_()
+    wij = (torch.randn(c_out, 2 * c_out) * 0.15).requires_grad_()
+    bias = (torch.randn(2 * c_out) * 0.2).requires_grad_()
+    out_ref = F.prelu(ref.gat_conv(x, ei, wl, att, wij, bias), torch.tensor(0.1))
+    G = torch.randn(n, 2 * c_out)
+    (out_ref * G).sum().backward()
+    rowptr, col = GATConv.csr_by_target(ei.cuda(), n)
+    d = lambda t: t.detach().cuda()
+    out = ops.gat_layer(rowptr, col, x.cuda(), d(wl), d(att), d(wij), d(bias), prelu_slope=0.1)
+    assert _rel(out, out_ref) <= 2e-5
+    _, gwl, gatt, gwij, gbias = ops.gat_layer_bwd(rowptr, col, x.cuda(), d(wl), d(att), d(wij), 0.1, out, G.cuda(), need_gx=False)
+    for name, got, want in (("lin_l", gwl, wl.grad), ("att", gatt, att.grad), ("lin_ij", gwij, wij.grad), ("bias", gbias, bias.grad)):
+        assert _rel(got, want) <= 1e-4, (name, _rel(got, want))
