@@ -367,3 +367,29 @@ def test_gat_layer_backward_with_tied_minima_and_maxima():
     _, gwl, gatt, gwij, gbias = ops.gat_layer_bwd(rowptr, col, x.cuda(), d(wl), d(att), d(wij), 0.1, out, G.cuda(), need_gx=False)
     for name, got, want in (("lin_l", gwl, wl.grad), ("att", gatt, att.grad), ("lin_ij", gwij, wij.grad), ("bias", gbias, bias.grad)):
         assert _rel(got, want) <= 1e-4, (name, _rel(got, want))
+
+
+def test_a_few_optimizer_steps_reduce_the_diagram_loss():
+    """The reference's loop (train_Teacher_Model.py:30-66: forward, loss_0.backward(), optimizer.step()) on one small batch: with the
+    gradients coming from the device kernels Adam brings the diagram loss down."""
+    import torch
+    from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
+    torch.manual_seed(5)
+    rs = np.random.RandomState(5)
+    n = 50
+    ei = _random_graph(rs, n, 160, torch)
+    m = ei.shape[1] - n
+    f = torch.rand(n, 1).cuda()
+    bb = rs.rand(m)
+    PD = torch.tensor(np.stack([bb, bb + rs.uniform(0, 0.5, size=m)], 1), dtype=torch.float32).cuda()
+    model = Teacher_Model(type='GAT', dropout=0.0).cuda().train()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    losses = []
+    for step in range(25):
+        opt.zero_grad()
+        _, _, loss0, _, _, _, _, _ = model(f, ei.cuda(), PD, kernel='wasserstein', p=2, grad_PI=False)
+        loss0.backward()
+        opt.step()
+        losses.append(float(loss0.detach()))
+    assert all(np.isfinite(losses))
+    assert min(losses[-5:]) < 0.7 * losses[0], losses
