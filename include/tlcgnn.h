@@ -280,7 +280,7 @@ int tlc_w2_partial_matching(int32_t n_problems, const int64_t* d_xoff, const dou
  *   d_out  float32[n, 2*c_out]: the forward's output, read only when prelu_slope >= 0 (sign of the pre-activation); else may be NULL
  *   d_gout float32[n, 2*c_out]: d loss / d out
  *   d_gX   float32[n, c_in] or NULL (first layer);  d_gWl [c_out, c_in], d_gatt [c_out], d_gWij [c_out, 2*c_out], d_gbias [2*c_out]:
- *   OVERWRITTEN.   d_work float32[n * (8*c_out + 2) + 2*c_out*c_out] scratch.   c_out in {8,16,32,64}, c_in <= 64.
+ *   OVERWRITTEN.   d_work float32[n * (8*c_out + 5) + 2*c_out*c_out + c_in*c_out + 4 + c_out*(2*c_out + 4)] scratch.   c_out in {8,16,32,64}, c_in <= 64.
  * Float atomics towards the sources of the edges and in the weight reductions: the summation order is not fixed. */
 int tlc_gat_layer_bwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_src, const float* d_X, int32_t c_in,
                       int32_t c_out, const float* d_Wl, const float* d_att, const float* d_Wij, float prelu_slope,

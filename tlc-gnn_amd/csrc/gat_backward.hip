@@ -14,6 +14,9 @@
 // fp32 throughout, like the forward; FMA contraction welcome (Makefile).
 #include "tlc_common.h"
 
+extern "C" int tlc_gemm_f32(int32_t M, int32_t N, int32_t K, const float* d_A, const float* d_B, const float* d_bias, int relu,
+                            float* d_C, void* stream);
+
 namespace {
 
 __device__ __forceinline__ float lrelu(float x, float s) { return x > 0.f ? x : s * x; }
@@ -26,50 +29,71 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return v;
 }
 
-// out[a][b] += sum_i A[i][a] * B[i][b]   (A [n, lda >= na], B [n, ldb >= nb]; out [na, nb] zeroed by the caller)
+// out[a][b] += sum_i A[i][a] * B[i][b]   (A [n, lda >= na], B [n, ldb >= nb]; out [na, nb] zeroed by the caller; na, nb <= 64)
+// A workgroup takes slabs of 1 024 rows, 32 at a time through LDS; its 256 threads are four row groups (eight of the 32 rows each) of
+// 64 threads, and a thread owns 4 x 4 blocks of the output: four values of A and four of B per row feed sixteen FMAs (one value
+// of each per FMA made the kernel LDS-bound: 0.2 ms per call on 200 k rows).  Partial sums leave by float atomics.
 __global__ __launch_bounds__(256) void xty_kernel(long long n, const float* __restrict__ A, int lda, int na, const float* __restrict__ B,
                                                   int ldb, int nb, float* __restrict__ out) {
-    extern __shared__ float sm[];                 // 32 rows of A | 32 rows of B
-    float* sa = sm;
-    float* sb = sm + 32 * na;
-    const int tid = threadIdx.x;
-    const int nout = na * nb;
-    float acc[16];
+    __shared__ float sa[32][68], sb[32][68];            // (rows padded: 68 floats keep the float4 reads 16-byte aligned and off one bank)
+    const int tid = threadIdx.x, grp = tid >> 6, t64 = tid & 63;
+    const int ba = (na + 3) >> 2, bb = (nb + 3) >> 2, nblk = ba * bb;         // <= 256 blocks of 4 x 4
+    float acc[4][16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
     const long long slab = 1024;
     for (long long r0 = (long long)blockIdx.x * slab; r0 < n; r0 += (long long)gridDim.x * slab) {
         const long long r1 = r0 + slab < n ? r0 + slab : n;
         for (long long t0 = r0; t0 < r1; t0 += 32) {
             const int rows = (int)(r1 - t0 < 32 ? r1 - t0 : 32);
             __syncthreads();
-            for (int k = tid; k < rows * na; k += 256) sa[k] = A[(t0 + k / na) * lda + k % na];
-            for (int k = tid; k < rows * nb; k += 256) sb[k] = B[(t0 + k / nb) * ldb + k % nb];
+            for (int k = tid; k < 32 * 64; k += 256) {
+                const int r = k >> 6, c = k & 63;
+                sa[r][c] = (r < rows && c < na) ? A[(t0 + r) * lda + c] : 0.f;
+                sb[r][c] = (r < rows && c < nb) ? B[(t0 + r) * ldb + c] : 0.f;
+            }
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int o = tid + 256 * q;
-                if (o < nout) {
-                    const int a = o / nb, b = o % nb;
-                    float s = 0.f;
-                    for (int r = 0; r < rows; ++r) s += sa[r * na + a] * sb[r * nb + b];
-                    acc[q] += s;
+            for (int j = 0; j < 4; ++j) {
+                const int blk = t64 + 64 * j;
+                if (blk < nblk) {                                           // (uniform per j beyond the last full 64)
+                    const int a0 = (blk / bb) * 4, b0 = (blk % bb) * 4;
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        const int r = grp * 8 + rr;
+                        const float4 av = *reinterpret_cast<const float4*>(&sa[r][a0]);
+                        const float4 bv = *reinterpret_cast<const float4*>(&sb[r][b0]);
+                        const float a4[4] = {av.x, av.y, av.z, av.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                        for (int x = 0; x < 4; ++x)
+#pragma unroll
+                            for (int y = 0; y < 4; ++y) acc[j][x * 4 + y] += a4[x] * b4[y];
+                    }
                 }
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int o = tid + 256 * q;
-        if (o < nout && acc[q] != 0.f) atomicAdd(&out[o], acc[q]);
+    for (int j = 0; j < 4; ++j) {
+        const int blk = t64 + 64 * j;
+        if (blk < nblk) {
+            const int a0 = (blk / bb) * 4, b0 = (blk % bb) * 4;
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+                    if (a0 + x < na && b0 + y < nb && acc[j][x * 4 + y] != 0.f) atomicAdd(&out[(a0 + x) * nb + b0 + y], acc[j][x * 4 + y]);
+        }
     }
 }
 
 static int xty(long long n, const float* A, int lda, int na, const float* B, int ldb, int nb, float* out, hipStream_t s) {
     if (n <= 0 || na <= 0 || nb <= 0) return TLC_OK;
-    if (na * nb > 4096) { tlc_set_error("xty: %d x %d outputs (max 4096)", na, nb); return TLC_ERR_UNSUPPORTED; }
+    if (na > 64 || nb > 64) { tlc_set_error("xty: %d x %d outputs (at most 64 x 64)", na, nb); return TLC_ERR_UNSUPPORTED; }
     const int grid = (int)std::min<long long>((n + 1023) / 1024, 1024);
-    hipLaunchKernelGGL(xty_kernel, dim3(grid), dim3(256), (size_t)32 * (na + nb) * sizeof(float), s, n, A, lda, na, B, ldb, nb, out);
+    hipLaunchKernelGGL(xty_kernel, dim3(grid), dim3(256), 0, s, n, A, lda, na, B, ldb, nb, out);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }
@@ -86,7 +110,7 @@ __global__ void gatb_xl_kernel(int n, int C, int c_in, const float* __restrict__
 }
 __global__ void gatb_pqa_kernel(int n, int C, const float* __restrict__ xl, const float* __restrict__ att, const float* __restrict__ Wij,
                                 float* __restrict__ pqa) {
-    const int S = 2 * C + 1;
+    const int S = 2 * C + 1;                              // (the fallback's rows are unpadded)
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)n * S) return;
     const int i = (int)(t / S), j = (int)(t % S);
@@ -98,16 +122,28 @@ __global__ void gatb_pqa_kernel(int n, int C, const float* __restrict__ xl, cons
     pqa[t] = s;
 }
 
+// the layer's weights as the right-hand sides of the two products that recompute the node rows:
+//   Bt1 [c_in, C] = Wl^T;   Bt2 [C, 2C + 4] = [Wij[:, :C]^T | Wij[:, C:]^T | att | 0 0 0]
+__global__ void gatb_pack_kernel(int C, int c_in, const float* __restrict__ Wl, const float* __restrict__ att, const float* __restrict__ Wij,
+                                 float* __restrict__ Bt1, float* __restrict__ Bt2) {
+    const int N2 = 2 * C + 4;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < c_in * C) { const int q = t / C, c = t % C; Bt1[t] = Wl[c * c_in + q]; }
+    if (t < C * N2) {
+        const int k = t / N2, j = t % N2;
+        Bt2[t] = j < C ? Wij[j * 2 * C + k] : (j < 2 * C ? Wij[(j - C) * 2 * C + C + k] : (j == 2 * C ? att[k] : 0.f));
+    }
+}
+
 // One wavefront per target row.  G = d loss / d out [n, 2C] (of the layer's OUTPUT: with a fused PReLU its derivative is taken
 // here from the sign of out).  Writes gP [n, C] (row-owned), adds into gQ [n, C] and gAlpha [n] (atomics: a node is the source of
 // many edges), and stores the activated gradient Gz [n, 2C] (= d loss / d (pre-activation), whose column sums are d bias).
 template <int C>
 __global__ __launch_bounds__(64) void gatb_edge_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ src,
-                                                       const float* __restrict__ pqa, const float* __restrict__ out, float prelu_slope,
+                                                       const float* __restrict__ pqa, int S, const float* __restrict__ out, float prelu_slope,
                                                        const float* __restrict__ G, float* __restrict__ Gz, float* __restrict__ gP,
                                                        float* __restrict__ gQ, float* __restrict__ gAlpha) {
-    const int S = 2 * C + 1;
-    const int lane = tlc_lane();
+    const int lane = tlc_lane();                      // (S: floats per row of pqa = [P | Q | alpha | padding])
     const bool ch = lane < C;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const int rb = rowptr[i], re = rowptr[i + 1];
@@ -207,23 +243,42 @@ template <int C>
 static int launch_gat_bwd(int n, const int* rowptr, const int* src, const float* X, int c_in, const float* Wl, const float* att,
                           const float* Wij, float prelu_slope, const float* out, const float* G, float* gX, float* gWl, float* gAtt,
                           float* gWij, float* gBias, float* work, hipStream_t s) {
-    // work: xl [n,C] | pqa [n,2C+1] | gP [n,C] | gQ [n,C] | gAlpha [n] | gxl [n,C] | Gz [n,2C] | tmp [2,C,C]
+    // work: xl [n,C] | pqa [n,2C+4] | gP [n,C] | gQ [n,C] | gxl [n,C] | Gz [n,2C] | tmp [2,C,C] | Bt1 [c_in,C] | Bt2 [C,2C+4] | gAlpha [n]
+    // (S = 2C + 4 when the rows come from the MFMA product -- the forward's layout -- else 2C + 1)
+    const bool by_gemm = 2 * C + 4 <= 128;
+    const int S = by_gemm ? 2 * C + 4 : 2 * C + 1;
     float* xl = work;
     float* pqa = xl + (size_t)n * C;
-    float* gP = pqa + (size_t)n * (2 * C + 1);
+    float* gP = pqa + (size_t)n * (2 * C + 4);
     float* gQ = gP + (size_t)n * C;
-    float* gAl = gQ + (size_t)n * C;
-    float* gxl = gAl + (size_t)n;
+    float* gxl = gQ + (size_t)n * C;
     float* Gz = gxl + (size_t)n * C;
-    TLC_HIP_CHECK(hipMemsetAsync(gQ, 0, ((size_t)n * C + (size_t)n) * sizeof(float), s));          // gQ and gAlpha (adjacent)
+    float* tmp0 = Gz + (size_t)n * 2 * C;
+    float* Bt1 = tmp0 + (size_t)2 * C * C;
+    float* Bt2 = Bt1 + (((size_t)c_in * C + 3) & ~(size_t)3);
+    float* gAl = Bt2 + (size_t)C * (2 * C + 4);              // (last: n floats would put what follows off its 16-byte alignment)
+    TLC_HIP_CHECK(hipMemsetAsync(gQ, 0, (size_t)n * C * sizeof(float), s));
+    TLC_HIP_CHECK(hipMemsetAsync(gAl, 0, (size_t)n * sizeof(float), s));
     TLC_HIP_CHECK(hipMemsetAsync(gWl, 0, (size_t)C * c_in * sizeof(float), s));
     TLC_HIP_CHECK(hipMemsetAsync(gAtt, 0, (size_t)C * sizeof(float), s));
     TLC_HIP_CHECK(hipMemsetAsync(gWij, 0, (size_t)C * 2 * C * sizeof(float), s));
     TLC_HIP_CHECK(hipMemsetAsync(gBias, 0, (size_t)2 * C * sizeof(float), s));
     auto blocks = [](long long t) { return dim3((unsigned)((t + 255) / 256)); };
-    hipLaunchKernelGGL(gatb_xl_kernel, blocks((long long)n * C), dim3(256), 0, s, n, C, c_in, X, Wl, xl);
-    hipLaunchKernelGGL(gatb_pqa_kernel, blocks((long long)n * (2 * C + 1)), dim3(256), 0, s, n, C, (const float*)xl, att, Wij, pqa);
-    hipLaunchKernelGGL((gatb_edge_kernel<C>), dim3(std::min(n, 65536)), dim3(64), 0, s, n, rowptr, src, (const float*)pqa, out, prelu_slope, G,
+    // the node rows again: x_l = X Wl^T and [P | Q | alpha] = x_l Bt2, on the f32 MFMA like the forward (per node on the vector ALU
+    // these two took 1.2 ms of a layer's backward on 200 k nodes)
+    if (by_gemm) {
+        const int np = std::max(c_in * C, C * (2 * C + 4));
+        hipLaunchKernelGGL(gatb_pack_kernel, blocks(np), dim3(256), 0, s, C, c_in, Wl, att, Wij, Bt1, Bt2);
+        TLC_HIP_CHECK(hipGetLastError());
+        int rc2;
+        if (c_in >= 16 && c_in % 4 == 0) { if ((rc2 = tlc_gemm_f32(n, C, c_in, X, Bt1, nullptr, 0, xl, s)) != TLC_OK) return rc2; }
+        else hipLaunchKernelGGL(gatb_xl_kernel, blocks((long long)n * C), dim3(256), 0, s, n, C, c_in, X, Wl, xl);
+        if ((rc2 = tlc_gemm_f32(n, 2 * C + 4, C, xl, Bt2, nullptr, 0, pqa, s)) != TLC_OK) return rc2;
+    } else {
+        hipLaunchKernelGGL(gatb_xl_kernel, blocks((long long)n * C), dim3(256), 0, s, n, C, c_in, X, Wl, xl);
+        hipLaunchKernelGGL(gatb_pqa_kernel, blocks((long long)n * (2 * C + 1)), dim3(256), 0, s, n, C, (const float*)xl, att, Wij, pqa);
+    }
+    hipLaunchKernelGGL((gatb_edge_kernel<C>), dim3(std::min(n, 65536)), dim3(64), 0, s, n, rowptr, src, (const float*)pqa, S, out, prelu_slope, G,
                        Gz, gP, gQ, gAl);
     hipLaunchKernelGGL(gatb_gxl_kernel, blocks((long long)n * C), dim3(256), 0, s, n, C, (const float*)gP, (const float*)gQ,
                        (const float*)gAl, Wij, att, gxl);
@@ -231,7 +286,7 @@ static int launch_gat_bwd(int n, const int* rowptr, const int* src, const float*
     TLC_HIP_CHECK(hipGetLastError());
     int rc;
     // d Wij[c][k] = sum_i gP[i][c] xl[i][k];  d Wij[c][C + k] = sum_i gQ[i][c] xl[i][k]: two [C, C] blocks of the [C, 2C] matrix
-    float* tmp = Gz + (size_t)n * 2 * C;              // [C, C] x 2: the two halves, interleaved into gWij below
+    float* tmp = tmp0;                                // [C, C] x 2: the two halves, interleaved into gWij below
     TLC_HIP_CHECK(hipMemsetAsync(tmp, 0, (size_t)2 * C * C * sizeof(float), s));
     if ((rc = xty(n, gP, C, C, xl, C, C, tmp, s)) != TLC_OK) return rc;
     if ((rc = xty(n, gQ, C, C, xl, C, C, tmp + C * C, s)) != TLC_OK) return rc;
@@ -296,7 +351,7 @@ __global__ __launch_bounds__(128) void edge_head_bwd_kernel(long long n_edges, c
 
 }  // namespace
 
-// d_work: float32[n * (8 * c_out + 2) + 2 * c_out * c_out] scratch.  d_out: the layer's forward output (only read when prelu_slope >= 0: the sign of the
+// d_work: float32[n * (8 * c_out + 5) + 2 * c_out * c_out + c_in * c_out + 4 + c_out * (2 * c_out + 4)] scratch, 16-byte aligned.  d_out: the layer's forward output (only read when prelu_slope >= 0: the sign of the
 // output is the sign of the pre-activation).  d_gX may be null (first layer: the input is data).
 extern "C" int tlc_gat_layer_bwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_src, const float* d_X, int32_t c_in,
                                  int32_t c_out, const float* d_Wl, const float* d_att, const float* d_Wij, float prelu_slope,

@@ -191,7 +191,7 @@ def gat_layer_bwd(rowptr, src, x, wl, att, wij, prelu_slope, out, gout, need_gx=
     gatt = torch.empty(c_out, dtype=torch.float32, device=dev)
     gwij = torch.empty((c_out, 2 * c_out), dtype=torch.float32, device=dev)
     gbias = torch.empty(2 * c_out, dtype=torch.float32, device=dev)
-    work = torch.empty(max(n, 1) * (8 * c_out + 2) + 2 * c_out * c_out, dtype=torch.float32, device=dev)
+    work = torch.empty(max(n, 1) * (8 * c_out + 5) + 2 * c_out * c_out + c_in * c_out + 4 + c_out * (2 * c_out + 4), dtype=torch.float32, device=dev)
     rc = _lib.lib().tlc_gat_layer_bwd(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(src), _lib.ptr(x), C.c_int32(c_in), C.c_int32(c_out),
                                       _lib.ptr(_f32(wl)), _lib.ptr(_f32(att).reshape(-1)), _lib.ptr(_f32(wij)), C.c_float(prelu_slope),
                                       _lib.ptr(_f32(out)) if out is not None else None, _lib.ptr(_f32(gout)), _lib.ptr(gx),
