@@ -68,6 +68,49 @@ def build_workload(rank, seed=1234):
                 pi_pairs=np.ascontiguousarray(pi_pairs, dtype=np.int32), neg=neg, x=x)
 
 
+def measure_traffic():
+    """roofline.traffic measured INSIDE this run: two child processes of this script under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE need a pass each: MI355X_MICROARCH.md, HBM / counters), 3 batches each, folded by tools/pmc_to_traffic.fold into
+    bytes per batch of every kernel's launches -> (dict, detail) or (None, reason); the caller then falls back to
+    profiles/pmc_traffic.json.  Called BEFORE this process touches the GPU (a process that has initialised the GPU must not start
+    other programs on this pool); the children run one after the other and are killed as a process group on time-out."""
+    import shutil, signal, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_to_traffic
+    except Exception as ex:
+        return None, "tools/pmc_to_traffic.py not importable: %r" % (ex,)
+    tmp = tempfile.mkdtemp(prefix="tlc_pmc_")
+    env = dict(os.environ, TLC_BENCH_CHILD="1")
+    try:
+        for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            cmd = [exe, "--pmc", cname, "--output-format", "csv", "-d", os.path.join(tmp, sub), "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-sweep"]
+            pr = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except Exception:
+                    pass
+                pr.wait()
+                return None, "the %s pass timed out" % cname
+            if rc != 0:
+                return None, "the %s pass failed (rc %d)" % (cname, rc)
+        res, detail, _ = pmc_to_traffic.fold(os.path.join(tmp, "fetch"), os.path.join(tmp, "write"))
+        if not res:
+            return None, "no counter rows collected"
+        return res, detail
+    except Exception as ex:
+        return None, repr(ex)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def pdgnn_aux(torch, dev, n_graphs=41127, seed=1234):
     """PDGNN forward vs exact PD on HIV-shaped molecules -- as many graphs as ogbg-molhiv holds (41 127, data_utils_GC.py:284; config 5
     of BASELINE.json): graphs/s of each (device-resident inputs, median of 5)."""
@@ -268,12 +311,20 @@ def main():
     ap.add_argument("--sync-batches", action="store_true",
                     help="timed region with stream-ordered tlc_pd_pi_batch calls (one batch at a time) instead of "
                          "tlc_pd_pi_batch_async + one join (two batches in flight)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic (it is then read from profiles/)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="development: no per-kernel HIP events in the timed region (the roofline block is then meaningless)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(args.gpus, sys.argv[1:]))
+
+    # roofline.traffic: two child passes of this script under rocprofv3 --pmc, BEFORE this process initialises the GPU
+    pre_traffic, pre_traffic_detail = None, "not attempted"
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_sweep and not args.no_traffic \
+            and not os.environ.get("TLC_BENCH_CHILD"):
+        pre_traffic, pre_traffic_detail = measure_traffic()
 
     import torch
     from tlc_gnn_amd import engine, ops, dist as tdist, _lib
@@ -746,13 +797,23 @@ def main():
             kavg[dom] = float(np.mean(live))                    # the dominant kernel: live, inside the timed region
         achieved = dom_bytes / (kavg[dom] * 1e-3) / 1e9
         traffic, traffic_source = None, None
+        if pre_traffic is not None and dom in pre_traffic:
+            d_ = pre_traffic_detail[dom]
+            traffic = float(pre_traffic[dom])
+            traffic_source = ("measured in this run: two child passes of this script under rocprofv3 --pmc before the timed region "
+                              "(FETCH_SIZE, WRITE_SIZE; 3 batches each); bytes per batch of this kernel's launches = (FETCH_SIZE %.0f KB + "
+                              "WRITE_SIZE %.0f KB) * 1024; gfx950: FETCH_SIZE tallies 64 B per 128-B request of a wide stream and is "
+                              "uncalibrated for 4/8-byte gathers, so the read side is a lower bound" % (d_["FETCH_SIZE_KB"], d_["WRITE_SIZE_KB"]))
+        elif pre_traffic is None:
+            traffic_source = str(pre_traffic_detail)
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):
+        if traffic is None and os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
                 traffic = tj.get(dom)
+                why = (" [in-run measurement: %s]" % traffic_source) if traffic_source else ""
                 traffic_source = "NOT measured in this run: profiles/pmc_traffic.json (%s), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE " \
-                                 "passes over this command; bytes per launch" % tj.get("_collected", "round-1 profile")
+                                 "passes over this command; bytes per launch%s" % (tj.get("_collected", "round-1 profile"), why)
             except Exception:
                 traffic = None
         out = {
