@@ -62,11 +62,14 @@ _CACHE = {}
 
 
 def _vicinities(g, ricci_curv):
-    key = (id(g), id(ricci_curv))
-    if key not in _CACHE:
-        _CACHE.clear()
-        _CACHE[key] = Vicinities(g, ricci_curv)
-    return _CACHE[key]
+    """One device graph kept between calls, reused only for the SAME graph and curvature objects (held here, so their ids
+    cannot pass to other objects) with an unchanged content stamp -- the rule of data_utils_NC._vicinities."""
+    from .data_utils_NC import _graph_stamp
+    ent = _CACHE.get("entry")
+    stamp = _graph_stamp(g, ricci_curv)
+    if ent is None or ent[0] is not g or ent[1] is not ricci_curv or ent[2] != stamp:
+        _CACHE["entry"] = ent = (g, ricci_curv, stamp, Vicinities(g, ricci_curv))
+    return ent[3]
 
 
 def compute_persistence_image(g, u, v, filt='hks', hks_time=0.1, hop=2, ricci_curv=None, mode='PI', num_models=5,
