@@ -56,11 +56,32 @@ struct HostSync {
     volatile unsigned pub_seq;
 };
 
-#define TLC_N_WS 2                /* workspaces of a handle: chunks (and asynchronous batches) alternate between them */
+#define TLC_N_WS 4                /* workspaces of a handle: chunks (and asynchronous batches) take them in turn */
 
 // Everything one chunk of pairs writes while it is in flight.  A handle has TLC_N_WS of them, taken in turn, each with its own
 // streams: the chunks of one call, and the batches of tlc_pd_pi_batch_async, overlap -- the lead-in of one (selection, early
 // extraction, the main extraction, all latency-bound) runs under the tail of the tier kernels of the one before.
+// What the second half of a chunk (everything behind the size publication: run_chunk_back) needs from the first.  A pipelined
+// chunk's second half is submitted one call later (see run_batch), so this lives in the workspace.
+struct ChunkCtx {
+    TlcVicParams vp;
+    TlcPdParams pp;
+    hipStream_t s;
+    int n_pairs, hop, pi_enabled;
+    bool bump, use_x, early, spec;
+    long long bump_base;
+    int xgrid, vgrid, tmask;
+    unsigned seq;
+    size_t spec_base[TLC_N_TIERS];
+    int spec_cap[TLC_N_TIERS];
+    bool used[TLC_N_SIDE];
+    hipEvent_t* ev_t;              // the chunk's set of timing events (tmask != 0)
+    unsigned char* ev_used;
+    std::chrono::steady_clock::time_point ht0;
+    double ht_front;
+    unsigned long long call_seq;   // the call the chunk belongs to (its statistics count only while that call is the last one)
+};
+
 struct Workspace {
     size_t cap_pairs;
     int *hdr_n, *hdr_m2, *hdr_lu, *hdr_lv, *tier_list;
@@ -110,6 +131,8 @@ struct Workspace {
     int busy;                      // a chunk was submitted and ev_done has not been waited for on the host
     int in_call;                   // ... by the call in progress (its statistics are still to be collected)
     int n_pairs;                   // pairs of that chunk
+    ChunkCtx ctx;                  // the chunk in flight
+    int back_pending;              // its second half has not been submitted yet
 };
 
 struct tlc_graph {
@@ -122,6 +145,8 @@ struct tlc_graph {
     Workspace ws[TLC_N_WS];
     unsigned long long next_ws;    // chunks submitted so far
     Workspace* last_ws;            // workspace of the most recent chunk (sizes / divide-and-conquer statistics)
+    unsigned long long call_seq;   // calls of run_batch so far
+    Workspace* pending;            // the chunk whose second half is still to be submitted (deferred, see run_batch)
     // vicinity kernels
     int vic_slots;
     size_t vic_lds;
@@ -160,6 +185,8 @@ struct tlc_graph {
     int opt_x_grid, opt_x_chunk_div;    // development: extraction workgroups / work-queue granularity (0: the defaults)
     int opt_chunk_pairs;                // development: pairs per chunk (0: TLC_CHUNK_PAIRS)
     int opt_medium_first;               // development: submit the MEDIUM / MID tiers ahead of TINY / SMALL
+    int opt_n_ws;                       // workspaces taken in turn (2..TLC_N_WS, default 3)
+    int opt_defer;                      // a pipelined chunk's second half is submitted behind the NEXT chunk's first half (default 1)
     int opt_gate_ticks;                 // development: bound of the residency gate of pipelined chunks (-1: the default 50 us)
     int opt_mh_always;                  // tests: split the MEDIUM tier by Pos-edge count in pipelined chunks too
     int opt_spec_cap;                   // tests: upper bound of the slots reserved for the speculative launches (0 = none)
@@ -433,6 +460,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     g->device = device; g->n_nodes = n_nodes; g->nnz = nnz; g->nw = nw; g->vic_lds = lds;
     auto env_on = [](const char* name) { const char* v = getenv(name); return !(v && v[0] == '0'); };
     g->opt_extract = env_on("TLC_EXTRACT"); g->opt_heavy = env_on("TLC_HEAVY"); g->opt_tiny = env_on("TLC_TINY");
+    g->opt_defer = env_on("TLC_DEFER"); g->opt_n_ws = 3;
     g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = 0x7f; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
@@ -567,21 +595,19 @@ __global__ void tlc_wait_started_dev(const int* counter, const int* target, int 
         __builtin_amdgcn_s_sleep(8);
 }
 
-static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_pairs, int hop, uint32_t flags, int res,
+static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_pairs, int hop, uint32_t flags, int res,
                      double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
                      double* d_out_f, int32_t* d_out_n, const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m,
                      int pi_enabled, hipStream_t s, bool pipelined) {
     int rc;
-    // (development: TLC_HOST_TRACE=1 prints where the submitting thread spends a chunk -- front submitted, sizes seen, tiers submitted)
-    static const bool host_trace = getenv("TLC_HOST_TRACE") != nullptr;
-    const auto ht0 = std::chrono::steady_clock::now();
-    auto ht_us = [&]() { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - ht0).count() * 1e-3; };
-    double ht_front = 0, ht_seen = 0;
+    ChunkCtx& c = ws->ctx;
+    c.ht0 = std::chrono::steady_clock::now();
+    c.s = s; c.n_pairs = n_pairs; c.hop = hop; c.pi_enabled = pi_enabled; c.call_seq = g->call_seq;
     if ((rc = ensure_pairs(g, ws, (size_t)n_pairs)) != TLC_OK) return rc;
     if ((rc = ensure_vic_scratch(g, ws, hop)) != TLC_OK) return rc;
     TLC_HIP_CHECK(hipMemsetAsync(ws->d_ctl, 0, (64 + 1024 + 8) * sizeof(int), s));       // control words, scan flags, statistics
 
-    TlcVicParams vp;
+    TlcVicParams& vp = c.vp;
     memset(&vp, 0, sizeof(vp));
     vp.n_nodes = g->n_nodes; vp.nw = g->nw; vp.rowptr = g->d_rowptr; vp.col = g->d_col; vp.w = g->d_w;
     vp.dbg = g->d_phase ? g->d_phase + 32 * TLC_TIER_HUGE : nullptr;   // (diagnostics share the HUGE tier's counter row)
@@ -622,10 +648,12 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         g->ev_t = g->ev_ring[set];
         g->ev_used = g->ev_ring_used[set];
         memset(g->ev_used, 0, 8);
+        c.ev_t = g->ev_t; c.ev_used = g->ev_used;
     }
+    c.tmask = tmask; c.vgrid = vgrid;
     g->last_n_pairs = n_pairs;
-#define T0(k, st) do { if ((tmask >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k)], st)); } } while (0)
-#define T1(k, st) do { if ((tmask >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(g->ev_t[2 * (k) + 1], st)); g->ev_used[k] = 1; } } while (0)
+#define T0(k, st) do { if ((tmask >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(c.ev_t[2 * (k)], st)); } } while (0)
+#define T1(k, st) do { if ((tmask >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(c.ev_t[2 * (k) + 1], st)); c.ev_used[k] = 1; } } while (0)
     // ---- early pass --------------------------------------------------------------------------------------------------------
     // The batch waits for its largest vicinity: 0.9 ms of mostly serial work that used to start only after COUNT, the scan,
     // the size publication and the heavy FILL (0.31 ms into the batch).  The pairs that can be that large are known up
@@ -676,7 +704,7 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
     int* d_early_count = ws->d_ctl + 17;
     int* d_early_started = ws->d_ctl + 18;
     int* d_cand_started = ws->d_ctl + 19;
-    TlcPdParams pp;
+    TlcPdParams& pp = c.pp;
     memset(&pp, 0, sizeof(pp));
     pp.hdr_n = ws->hdr_n; pp.hdr_m2 = ws->hdr_m2; pp.hdr_lu = ws->hdr_lu; pp.hdr_lv = ws->hdr_lv;
     pp.edge_off = ws->edge_off;
@@ -812,15 +840,17 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
     // between the scan and the batch's second-longest chain.  If COUNT overflowed the arena the kernels return at once
     // (abort flag) and the chunk is redone below.
     static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4};   // timing slot of each tier kernel (TINY is reported with SMALL, MEDHI as MEDIUM)
-    bool used[TLC_N_SIDE] = {false, false, false, false, early, false, false};
+    bool (&used)[TLC_N_SIDE] = c.used;
+    for (int k = 0; k < TLC_N_SIDE; ++k) used[k] = (k == 4) && early;
     // The fork point of the side-stream launches that need nothing but the scan.  Recorded here, it is long complete when the
     // host has seen the sizes and submits them, and a wait on a complete event is no command at all -- an event recorded at
     // submission time costs every side stream a barrier packet on a signal that is still in flight: 60 us per chunk (measured:
     // 0.796 -> 0.733 ms per pipelined batch, tools/ab_option.py mh_always 0 3 before this was unconditional).
     TLC_HIP_CHECK(hipEventRecord(ws->ev_scan, s));
     const bool spec = bump && mh_split;
-    size_t spec_base[TLC_N_TIERS] = {0, 0, 0, 0, 0, 0, 0};
-    int spec_cap[TLC_N_TIERS] = {0, 0, 0, 0, 0, 0, 0};
+    size_t (&spec_base)[TLC_N_TIERS] = c.spec_base;
+    int (&spec_cap)[TLC_N_TIERS] = c.spec_cap;
+    for (int t = 0; t < TLC_N_TIERS; ++t) { spec_base[t] = 0; spec_cap[t] = 0; }
     if (spec) {
         spec_cap[TLC_TIER_MID] = std::min(n_pairs, std::max(4096, ws->prev_tc[TLC_TIER_MID] + ws->prev_tc[TLC_TIER_MID] / 4));
         spec_cap[TLC_TIER_MEDIUM] = std::min(n_pairs, std::max(2048, ws->prev_tc[TLC_TIER_MEDIUM] + ws->prev_tc[TLC_TIER_MEDIUM] / 4));
@@ -854,7 +884,43 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         pp.phase = 0;
         pp.grid = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr; pp.handoff = nullptr; pp.handoff_cap = 0;
     }
-    ht_front = ht_us();
+    c.bump = bump; c.use_x = use_x; c.early = early; c.spec = spec; c.bump_base = bump_base; c.xgrid = xgrid; c.seq = seq;
+    c.ht_front = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c.ht0).count() * 1e-3;
+    ws->back_pending = 1;
+    return TLC_OK;
+}
+
+// has the scan of the workspace's chunk published its sizes?
+static inline bool sizes_published(const Workspace* ws) { return ws->h_sync->pub_seq == ws->ctx.seq; }
+
+// The second half of a chunk: waits (on the host) for the sizes the scan publishes, then submits every launch whose grid or
+// buffers depend on them, and joins the side streams into the chunk's stream.
+static int run_chunk_back(tlc_graph* g, Workspace* ws) {
+    int rc;
+    ChunkCtx& c = ws->ctx;
+    // (development: TLC_HOST_TRACE=1 prints where the submitting thread spends a chunk -- front submitted, sizes seen, tiers submitted)
+    static const bool host_trace = getenv("TLC_HOST_TRACE") != nullptr;
+    const auto ht0 = c.ht0;
+    auto ht_us = [&]() { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - ht0).count() * 1e-3; };
+    const double ht_front = c.ht_front;
+    double ht_seen = 0;
+    TlcVicParams& vp = c.vp;
+    TlcPdParams& pp = c.pp;
+    hipStream_t s = c.s;
+    const int n_pairs = c.n_pairs, hop = c.hop, pi_enabled = c.pi_enabled, xgrid = c.xgrid, vgrid = c.vgrid, tmask = c.tmask;
+    const bool bump = c.bump, use_x = c.use_x, early = c.early, spec = c.spec;
+    const long long bump_base = c.bump_base;
+    const unsigned seq = c.seq;
+    size_t (&spec_base)[TLC_N_TIERS] = c.spec_base;
+    int (&spec_cap)[TLC_N_TIERS] = c.spec_cap;
+    bool (&used)[TLC_N_SIDE] = c.used;
+    static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4};   // timing slot of each tier kernel (TINY is reported with SMALL, MEDHI as MEDIUM)
+    auto dc_lists_for = [&](TlcPdParams& q, int k) {
+        const size_t cap = ws->cap_pairs + TLC_EARLY_SLOTS;
+        q.dc_count = ws->d_ctl + 26 + 2 * k;
+        q.dc_list = ws->dc_lists + (size_t)k * cap;
+    };
+    ws->back_pending = 0;
     {
         // (hipStreamSynchronize would also wait for the kernels submitted behind the scan; the stream is only queried, now and
         // then, so that a fault surfaces instead of a spin)
@@ -1042,6 +1108,7 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
         if (used[k]) TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_join[k], 0));
 #undef T0
 #undef T1
+    if (c.call_seq == g->call_seq) {      // (a deferred second half submitted by a LATER call does not count into that call's statistics)
     for (int t = 0; t <= TLC_TIER_HUGE; ++t) g->last_stats[t] += tc[t];
     g->last_stats[TLC_TIER_MEDIUM] += tc[TLC_TIER_MEDHI];              // (reported with MEDIUM; on its own in [9])
     g->last_stats[9] += tc[TLC_TIER_MEDHI];
@@ -1050,6 +1117,7 @@ static int run_chunk(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_
     g->last_stats[TLC_TIER_LARGE] += n_early;
     g->last_stats[7] += tc[TLC_TIER_MID];
     g->last_stats[6] += 1;
+    }
     if (host_trace) {
         static std::chrono::steady_clock::time_point last_end;
         const double gap = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(ht0 - last_end).count() * 1e-3;
@@ -1073,12 +1141,23 @@ static int chunk_entries(Workspace* ws, long long* out) {
     return TLC_OK;
 }
 
+// submits the second half of the chunk whose first half is in flight (tlc_pd_pi_batch_async defers it, see run_batch)
+static int finish_pending(tlc_graph* g) {
+    Workspace* ws = g->pending;
+    if (!ws) return TLC_OK;
+    g->pending = nullptr;
+    int rc = run_chunk_back(g, ws);
+    if (rc != TLC_OK) return rc;
+    TLC_HIP_CHECK(hipEventRecord(ws->ev_done, ws->ctx.s));
+    return TLC_OK;
+}
+
 // the next workspace in turn; if a chunk is still in flight on it, the host waits for that chunk (two chunks ahead of the GPU
 // is as far as a caller can run)
 static int acquire_workspace(tlc_graph* g, Workspace** out, bool same) {
     // (`same`: a stream-ordered single chunk -- consecutive calls cannot overlap anyway, and staying on one workspace keeps its
     // arena, headers and lists warm in the Infinity Cache: alternating cost the back-to-back batch 0.09 ms)
-    Workspace* ws = same ? &g->ws[0] : &g->ws[g->next_ws % TLC_N_WS];
+    Workspace* ws = same ? &g->ws[0] : &g->ws[g->next_ws % (unsigned)g->opt_n_ws];
     if (!same) ++g->next_ws;
     if (!ws->main) {
         int prio_lo = 0, prio_hi = 0;
@@ -1118,6 +1197,7 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
     TLC_ON_DEVICE(g->device);
     memset(g->last_stats, 0, sizeof(g->last_stats));
     g->acc_tie = 0; g->acc_entries = 0;
+    ++g->call_seq;
     for (int k = 0; k < TLC_N_WS; ++k) g->ws[k].in_call = 0;
     hipStream_t s = (hipStream_t)stream;
     // a single chunk of a stream-ordered call runs on the caller's stream itself (no cross-stream hops in its latency);
@@ -1125,10 +1205,21 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
     // (opt_chunk_pairs: development A/B -- a long list cut into more, pipelined chunks)
     const int64_t chunk_pairs = g->opt_chunk_pairs > 0 ? std::min<int64_t>(g->opt_chunk_pairs, TLC_CHUNK_PAIRS) : TLC_CHUNK_PAIRS;
     const bool inline_main = join && n_pairs <= chunk_pairs;
+    // Deferred second halves (asynchronous batches and the chunks of a long list): a chunk's tier launches need the sizes its scan
+    // publishes, ~0.3 ms after the chunk was submitted.  A host that waits for them before it submits the NEXT chunk's first half
+    // (selection, early pass, extraction, scan: a 0.5 ms chain of its own) serialises the two chains: chunk period = first half +
+    // host round trip.  So the next chunk's first half goes in first, and then the host waits for this chunk's sizes: the first
+    // half of chunk i+1 runs under the tier kernels of chunk i.  The last chunk's second half is submitted by the join
+    // (tlc_pd_pi_batch_join, or the end of this call).
+    const bool defer = !inline_main && g->opt_defer;
+    int rc;
+    if (!defer && (rc = finish_pending(g)) != TLC_OK) return rc;
     for (int64_t off = 0; off < n_pairs; off += chunk_pairs) {
         const int cnt = (int)std::min<int64_t>(chunk_pairs, n_pairs - off);
         Workspace* ws = nullptr;
-        int rc = acquire_workspace(g, &ws, inline_main);
+        // (sizes already there: nothing to wait for, and the tier kernels should not queue behind another extraction)
+        if (g->pending && sizes_published(g->pending) && (rc = finish_pending(g)) != TLC_OK) return rc;
+        rc = acquire_workspace(g, &ws, inline_main);
         if (rc != TLC_OK) return rc;
         hipStream_t m = inline_main ? s : ws->main;
         if (!inline_main) {
@@ -1136,17 +1227,20 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
             TLC_HIP_CHECK(hipStreamWaitEvent(m, ws->ev_in, 0));
         }
         // NOTE: ids_off is indexed by the global pair index, the kernels index by chunk-local index
-        rc = run_chunk(g, ws, d_pairs + 2 * off, cnt, hop, flags, res,
+        rc = run_chunk_front(g, ws, d_pairs + 2 * off, cnt, hop, flags, res,
                        d_out_pi ? d_out_pi + (size_t)off * res * res : nullptr,
                        d_out_status ? d_out_status + off : nullptr,
                        d_ids_off ? d_ids_off + off : nullptr, d_out_ids, d_out_f,
                        d_out_n ? d_out_n + off : nullptr, d_edge_offs ? d_edge_offs + off : nullptr, d_out_edges,
                        d_out_m ? d_out_m + off : nullptr, pi_enabled, m, !inline_main);
         if (rc != TLC_OK) return rc;
-        TLC_HIP_CHECK(hipEventRecord(ws->ev_done, m));
         ws->busy = 1; ws->in_call = 1; ws->n_pairs = cnt;
         g->last_ws = ws;
+        if ((rc = finish_pending(g)) != TLC_OK) return rc;      // the previous chunk's second half (none unless deferred)
+        g->pending = ws;
+        if (!defer && (rc = finish_pending(g)) != TLC_OK) return rc;
     }
+    if (join && (rc = finish_pending(g)) != TLC_OK) return rc;
     if (join && !inline_main)
         for (int k = 0; k < TLC_N_WS; ++k)
             if (g->ws[k].busy) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ws[k].ev_done, 0));
@@ -1184,6 +1278,8 @@ extern "C" int tlc_pd_pi_batch_async(tlc_graph* g, const int32_t* d_pairs, int64
 extern "C" int tlc_pd_pi_batch_join(tlc_graph* g, void* stream) {
     TLC_REQUIRE(g != nullptr, "graph handle is null");
     TLC_ON_DEVICE(g->device);
+    int rc = finish_pending(g);
+    if (rc != TLC_OK) return rc;
     for (int k = 0; k < TLC_N_WS; ++k)
         if (g->ws[k].busy) TLC_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, g->ws[k].ev_done, 0));
     return TLC_OK;
@@ -1203,6 +1299,7 @@ extern "C" int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int
 extern "C" int tlc_pd_pi_batch_stats(tlc_graph* g, int64_t* h_out, void* stream) {
     TLC_REQUIRE(g && h_out, "null argument");
     TLC_ON_DEVICE(g->device);
+    { int rc = finish_pending(g); if (rc != TLC_OK) return rc; }
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     long long tie = g->acc_tie, entries = g->acc_entries;
     for (int k = 0; k < TLC_N_WS; ++k) {
@@ -1290,6 +1387,7 @@ extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long l
     TLC_REQUIRE(g != nullptr, "null graph");
     TLC_REQUIRE(h_out == nullptr || cap_u64 >= 0, "cap_u64 < 0");
     TLC_ON_DEVICE(g->device);
+    { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; }
     const size_t rows = (size_t)TLC_N_TIERS + 1;
     if (n_rows) *n_rows = (int32_t)rows;
     TLC_HIP_CHECK(hipDeviceSynchronize());
@@ -1307,6 +1405,7 @@ extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long l
 extern "C" int tlc_debug_pair_times(tlc_graph* g, unsigned long long* h_out, int64_t n_pairs) {
     TLC_REQUIRE(g && h_out, "null argument");
     TLC_ON_DEVICE(g->device);
+    { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; }
     TLC_HIP_CHECK(hipDeviceSynchronize());
     const size_t k = std::min<size_t>((size_t)std::max<int64_t>(n_pairs, 0), g->d_pair_t ? g->cap_pair_t : 0);
     if (k) TLC_HIP_CHECK(hipMemcpy(h_out, g->d_pair_t, k * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1327,6 +1426,8 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "mh_always")) g->opt_mh_always = value != 0;
     else if (!strcmp(name, "gate_ticks")) g->opt_gate_ticks = value;
     else if (!strcmp(name, "medium_first")) g->opt_medium_first = value != 0;
+    else if (!strcmp(name, "n_ws")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_n_ws = std::min(std::max(value, 2), TLC_N_WS); }
+    else if (!strcmp(name, "defer")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_defer = value != 0; }
     else if (!strcmp(name, "chunk_pairs")) g->opt_chunk_pairs = std::max(value, 0);
     else if (!strcmp(name, "x_grid")) g->opt_x_grid = std::max(value, 0);
     else if (!strcmp(name, "x_chunk_div")) g->opt_x_chunk_div = std::max(value, 0);
@@ -1343,6 +1444,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
 extern "C" int tlc_debug_dc_stats(tlc_graph* g, long long* h_out, void* stream) {
     TLC_REQUIRE(g && h_out, "null argument");
     TLC_ON_DEVICE(g->device);
+    { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; }
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     unsigned long long v[4] = {0, 0, 0, 0};
     if (g->last_ws) {
@@ -1368,6 +1470,7 @@ extern "C" int tlc_pd_pi_batch_set_timing(tlc_graph* g, int enable) {
 extern "C" int tlc_pd_pi_batch_timings(tlc_graph* g, double* h_ms, void* stream) {
     TLC_REQUIRE(g && h_ms, "null argument");
     TLC_ON_DEVICE(g->device);
+    { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; }
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     for (int k = 0; k < 8; ++k) {
         h_ms[k] = -1.0;
@@ -1388,6 +1491,7 @@ extern "C" int tlc_pd_pi_batch_timing_history(tlc_graph* g, int slot, double* h_
     TLC_REQUIRE(g && h_ms && n_out, "null argument");
     TLC_REQUIRE(slot >= 0 && slot < 8 && cap >= 0, "slot must be in 0..7");
     TLC_ON_DEVICE(g->device);
+    { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; }
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     const unsigned long long have = std::min<unsigned long long>(g->ring_pos, TLC_TIMING_RING);
     const int n = (int)std::min<unsigned long long>(have, (unsigned long long)cap);
@@ -1409,6 +1513,7 @@ extern "C" int tlc_pd_pi_batch_timing_history(tlc_graph* g, int slot, double* h_
 extern "C" int tlc_pd_pi_batch_sizes(tlc_graph* g, int32_t* h_n, int32_t* h_m2, int64_t cap, void* stream) {
     TLC_REQUIRE(g && h_n && h_m2, "null argument");
     TLC_ON_DEVICE(g->device);
+    { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; }
     TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     const size_t k = (size_t)std::min<int64_t>(cap, g->last_n_pairs);
     if (k && g->last_ws) {

@@ -65,7 +65,7 @@ class DeviceGraph:
         _lib.check(rc, "tlc_pd_pi_batch")
         if async_:
             self._inflight.append((pairs, out, status))          # (the buffers of a batch in flight must stay alive)
-            del self._inflight[:-4]
+            del self._inflight[:-6]
         return out, status
 
     def join(self):
