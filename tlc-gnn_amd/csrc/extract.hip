@@ -133,8 +133,8 @@ __device__ __forceinline__ bool x_heavy(const XState& X, int ly) { return (X.hvy
 // places them, and a second walk writes.
 // Walks the units of this wavefront; ucnt (several wavefronts): WR ? the first entry number of every unit : receives the
 // count of every unit.  Returns the entries this wavefront counted.
-template <int BW, bool WR>
-__device__ __forceinline__ int x_sweep_wave(const TlcVicParams& p, const int* ids, int n, const XState& X, bool use_hvy, int nH,
+template <int BW, bool WR, class PB>
+__device__ __forceinline__ int x_sweep_wave(const PB& p, const int* ids, int n, const XState& X, bool use_hvy, int nH,
                                             unsigned* dir, double* lw, int cap, int* ucnt, const XRec pre, bool has_pre, int dbg_i = -1) {
     const int lane = tlc_lane(), wv = (int)(threadIdx.x >> 6);
     constexpr int NW = BW / 64;
@@ -302,8 +302,8 @@ __device__ __forceinline__ int x_sweep_wave(const TlcVicParams& p, const int* id
 }
 
 // The sweep of a workgroup; dir may be null (count only).  Returns the number of entries (uniform over the workgroup).
-template <int BW>
-__device__ __forceinline__ int x_sweep(const TlcVicParams& p, const int* ids, int n, const XState& X, bool use_hvy, int nH,
+template <int BW, class PB>
+__device__ __forceinline__ int x_sweep(const PB& p, const int* ids, int n, const XState& X, bool use_hvy, int nH,
                                        unsigned* dir, double* lw, int cap, const XRec pre, bool has_pre, int dbg_i = -1) {
     if (BW == 64) {
         if (dir) return x_sweep_wave<BW, true>(p, ids, n, X, use_hvy, nH, dir, lw, cap, nullptr, pre, has_pre, dbg_i);
@@ -327,8 +327,8 @@ __device__ __forceinline__ int x_sweep(const TlcVicParams& p, const int* ids, in
     return total;
 }
 
-template <int BW>
-__device__ __forceinline__ void x_zero_row(const TlcVicParams& p, int i, int status, int n_report, int lu, int lv) {
+template <int BW, class PB>
+__device__ __forceinline__ void x_zero_row(const PB& p, int i, int status, int n_report, int lu, int lv) {
     const int tid = threadIdx.x, res2 = p.res * p.res;
     if (tid == 0) {
         p.hdr_n[i] = 0; p.hdr_m2[i] = 0; p.hdr_lu[i] = lu; p.hdr_lv[i] = lv;
@@ -340,8 +340,14 @@ __device__ __forceinline__ void x_zero_row(const TlcVicParams& p, int i, int sta
 }
 
 // One pair.  The bitmap is all zero on entry and on exit.
-template <int BW>
-__device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool from_rest, unsigned char* lds, int* slot) {
+// The head of an item -- the pair and the bounds of its rows and ball lists -- as scalars: loaded by the kernel's loop one item
+// ahead of the item's body (tlc_extract_kernel).  Bounds are zero for a pair with an id out of range.
+struct XHead {
+    int u, v;
+    int ru0, ru1, rv0, rv1, a0, a1, b0, b1;
+};
+template <int BW, class PB>
+__device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest, const XHead& H, unsigned char* lds, int* slot) {
     constexpr int SID_CAP = XCfg<BW>::SID_CAP;
     const XLayout L = x_layout(p.nw, SID_CAP, BW);
     const int nw4 = (p.nw + 3) & ~3;
@@ -364,17 +370,13 @@ __device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool 
 #ifdef TLC_PAIR_TIMES
     const unsigned long long t_start = wall_clock64();
 #endif
-    const int u = p.pairs[2 * (size_t)i], v = p.pairs[2 * (size_t)i + 1];
+    const int u = H.u, v = H.v;
     // KeyError on dict_node (riccidist2dgm.py:353): ids the edge-built graph does not contain
     bool missing = u < 0 || v < 0 || u >= p.n_nodes || v >= p.n_nodes;
     int a0 = 0, a1 = 0, b0 = 0, b1 = 0;
     if (!missing) {
-        int ru0, ru1, rv0, rv1;
-        row_bounds(p.rowptr, u, ru0, ru1);
-        row_bounds(p.rowptr, v, rv0, rv1);
-        row_bounds(p.bptr, u, a0, a1);
-        row_bounds(p.bptr, v, b0, b1);
-        missing = (ru1 == ru0) || (rv1 == rv0);
+        a0 = H.a0; a1 = H.a1; b0 = H.b0; b1 = H.b1;
+        missing = (H.ru1 == H.ru0) || (H.rv1 == H.rv0);
         if (!missing && from_rest) {
             const int na = a1 - a0, nb = b1 - b0, mn = na < nb ? na : nb;
             // same predicates as tlc_classify_kernel: the early pass owns its candidates (as long as its list held them all;
@@ -591,6 +593,8 @@ __device__ __forceinline__ void extract_pair(const TlcVicParams& p, int i, bool 
 #ifndef TLC_X_WPE
 #define TLC_X_WPE 4
 #endif
+typedef const __attribute__((address_space(4))) TlcVicParams XParams;
+typedef const __attribute__((address_space(4))) int XCInt;
 template <int BW>
 __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kernel(TlcVicParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xlds[];
@@ -626,17 +630,34 @@ __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kern
         c0 = p.big_count[0]; c1 = p.big_count[1]; c2 = p.big_count[2];
         n_work += c0 + c1 + c2;
     }
-    // (one call site of extract_pair: several would stop the compiler from inlining it, and the parameter block would go
-    // through scratch memory)
-    auto run_item = [&](int w) {
-        int i;
-        bool from_rest = false;
-        if (p.fill_mode == 1) i = p.fill_list[w];
-        else if (w < c0) i = p.big_list[w];
-        else if (w < c0 + c1) i = p.big_list[(size_t)p.n_pairs + (w - c0)];
-        else if (w < c0 + c1 + c2) i = p.big_list[2 * (size_t)p.n_pairs + (w - c0 - c1)];
-        else { i = w - c0 - c1 - c2; from_rest = true; }
-        extract_pair<BW>(p, i, from_rest, xlds, slot);
+    // The parameter block is read through the kernel-argument segment pointer, laundered per item: every field is a scalar load
+    // inside the body instead of a value hoisted in front of the persistent loop (which had cost 110 spilled SGPRs).
+    // The head of an item is a chain of dependent loads -- list position -> pair index -> pair -> four row bounds -- in front of the
+    // first byte of the ball lists: three round trips of ~1-2 us under load in an item of ~12 us.  All of it is uniform over the
+    // workgroup, so it is read with SCALAR loads (constant address space: the lists, the pairs and the row pointers do not change
+    // while this kernel runs), one stage per item ahead: while item k runs, its own bounds, the pair of item k+1 and the list
+    // entry of item k+2 are fetched together -- one exposed round trip per item instead of three.
+    XParams* kp = (XParams*)__builtin_amdgcn_kernarg_segment_ptr();   // (p is the kernel's only argument: offset 0)
+    auto idx_of = [&](XParams* q, int w, bool& from_rest) -> int {
+        from_rest = false;
+        if (q->fill_mode == 1) return ((XCInt*)q->fill_list)[w];
+        if (w < c0) return ((XCInt*)q->big_list)[w];
+        if (w < c0 + c1) return ((XCInt*)q->big_list)[(size_t)q->n_pairs + (w - c0)];
+        if (w < c0 + c1 + c2) return ((XCInt*)q->big_list)[2 * (size_t)q->n_pairs + (w - c0 - c1)];
+        from_rest = true;
+        return w - c0 - c1 - c2;
+    };
+    auto pair_of = [&](XParams* q, int i, int& u, int& v) {
+        XCInt* pr = (XCInt*)q->pairs + 2 * (size_t)i;
+        u = pr[0]; v = pr[1];
+    };
+    auto bounds_of = [&](XParams* q, XHead& H) {
+        H.ru0 = H.ru1 = H.rv0 = H.rv1 = H.a0 = H.a1 = H.b0 = H.b1 = 0;
+        if (H.u < 0 || H.v < 0 || H.u >= q->n_nodes || H.v >= q->n_nodes) return;
+        XCInt* rp = (XCInt*)q->rowptr;
+        XCInt* bp = (XCInt*)q->bptr;
+        H.ru0 = rp[H.u]; H.ru1 = rp[H.u + 1]; H.rv0 = rp[H.v]; H.rv1 = rp[H.v + 1];
+        H.a0 = bp[H.u]; H.a1 = bp[H.u + 1]; H.b0 = bp[H.v]; H.b1 = bp[H.v + 1];
     };
     if (p.started && threadIdx.x == 0 && (int)blockIdx.x < n_work) atomicAdd(p.started, 1);
     // (one loop for both schedules -- static: a chunk is one item and the next chunk is gridDim.x further on)
@@ -644,11 +665,34 @@ __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kern
     const bool dyn = p.work_counter != nullptr;
     const int n_chunks = dyn ? (n_work + p.work_chunk - 1) / p.work_chunk : n_work;
     for (int c = blockIdx.x; c < n_chunks;) {
-        for (int wi = c; wi < n_work; wi += n_chunks) run_item(wi);
+        // the items of a chunk: c, c + n_chunks, ...; stage registers: [0] the item about to run, [1] the one after it
+        bool fr0 = false, fr1 = false;
+        int i0 = -1, i1 = -1, u0 = -1, v0 = -1;
+        {
+            XParams* q = kp;
+            asm volatile("" : "+s"(q));
+            i0 = idx_of(q, c, fr0);
+            if (c + n_chunks < n_work) i1 = idx_of(q, c + n_chunks, fr1);
+            pair_of(q, i0, u0, v0);
+        }
+        for (int w = c; w < n_work; w += n_chunks) {
+            XParams* q = kp;
+            asm volatile("" : "+s"(q));
+            bool fr2 = false;
+            int i2 = -1, u1 = -1, v1 = -1;
+            if (w + 2 * n_chunks < n_work) i2 = idx_of(q, w + 2 * n_chunks, fr2);
+            if (w + n_chunks < n_work) pair_of(q, i1, u1, v1);
+            XHead H;
+            H.u = u0; H.v = v0;
+            bounds_of(q, H);
+            extract_pair<BW>(*q, i0, fr0, H, xlds, slot);
+            i0 = i1; fr0 = fr1; u0 = u1; v0 = v1;
+            i1 = i2; fr1 = fr2;
+        }
         if (!dyn) { c += gridDim.x; continue; }
         if (threadIdx.x == 0) s_chunk = (int)gridDim.x + atomicAdd(p.work_counter, 1);
         __syncthreads();
-        c = s_chunk;
+        c = __builtin_amdgcn_readfirstlane(s_chunk);
         __syncthreads();
     }
 }
