@@ -310,7 +310,7 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--sync-batches", action="store_true",
                     help="timed region with stream-ordered tlc_pd_pi_batch calls (one batch at a time) instead of "
-                         "tlc_pd_pi_batch_async + one join (two batches in flight)")
+                         "tlc_pd_pi_batch_async + one join (three batches in flight)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic (it is then read from profiles/)")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -433,8 +433,9 @@ def main():
         g.pd_pi_batch(rot[step % len(rot)] if args.rotate_batches else pi_pairs, hop, out=pi_out, status=pi_status)
 
     # The timed region submits its K image batches with tlc_pd_pi_batch_async and joins once behind the last one: the
-    # library keeps two batches in flight on its two workspaces, so the lead-in of a batch (classification, early extraction,
-    # the main extraction: latency-bound, half-empty machine) runs under the tier kernels of the batch before.  Three output
+    # library keeps three batches in flight on its workspaces and submits a batch's tier launches behind the NEXT batch's first
+    # half, so the lead-in of a batch (classification, early extraction, the main extraction: latency-bound, half-empty machine)
+    # runs under the tier kernels of the batch before.  Three output
     # buffers in turn: a batch in flight owns its buffers until the join.  --sync-batches: stream-ordered calls instead.
     pi_outs = [pi_out] + [torch.empty_like(pi_out) for _ in range(2)]
     pi_sts = [pi_status] + [torch.empty_like(pi_status) for _ in range(2)]
@@ -834,8 +835,8 @@ def main():
                                    % ("a different %d-pair sample of the graph's positive pairs every step (--rotate-batches)" % E
                                       if args.rotate_batches else "all %d train-positive pairs" % E, dec_pairs.shape[0]),
                        "timed_region": ("K image batches as stream-ordered tlc_pd_pi_batch calls (one at a time), " if args.sync_batches else
-                                        "K image batches submitted with tlc_pd_pi_batch_async (two in flight on the handle's two "
-                                        "workspaces, three output buffers in turn) and ONE join behind the last, ") +
+                                        "K image batches submitted with tlc_pd_pi_batch_async (three in flight on the handle's "
+                                        "workspaces, a batch's tier launches submitted behind the next batch's first half; three output buffers in turn) and ONE join behind the last, ") +
                                        "then K forwards, no host synchronisation inside (throughput); pi_latency_ms = one "
                                        "stream-ordered batch with a synchronisation after it",
                        "pi_submit": "sync" if args.sync_batches else "async",

@@ -15,10 +15,12 @@
  *     `tlc_graph` handle (which owns a device copy of the CSR and the kernels' scratch);
  *   - every call is stream-ordered: its work is ordered after what `stream` holds and later work on `stream` sees its
  *     outputs.  The calls RETURN before that work is done, with one documented exception: tlc_pd_pi_batch,
- *     tlc_pd_pi_batch_async and tlc_vicinity_filtration hold the calling thread, once per chunk of 2^20 pairs, until the
+ *     tlc_pd_pi_batch_async and tlc_vicinity_filtration hold the calling thread, once per chunk of 2^20 pairs, until a
  *     chunk's extraction and size scan have run on the device (~0.3 ms for 37 676 pairs; the sizes come back through
  *     mapped host memory and size the tier launches that follow) -- nothing is synchronised and `stream` is not drained,
- *     but the call is not free of host waiting; the statistics / timing / sizes getters synchronise `stream`.  Outputs are fully
+ *     but the call is not free of host waiting.  A pipelined chunk (tlc_pd_pi_batch_async, or a list of several chunks) waits
+ *     for the PREVIOUS chunk's sizes, after it has submitted its own first half: the tier launches of a chunk go in one call
+ *     later, those of the last chunk with the join.  The statistics / timing / sizes getters synchronise `stream`.  Outputs are fully
  *     overwritten (zero rows are written explicitly, mirroring `pi_sg = np.zeros(...)`,
  *     sg2dgm/riccidist2dgm.py:363);
  *   - a tlc_graph handle owns mutable scratch: calls on the SAME handle must not overlap (use one handle per
@@ -119,8 +121,10 @@ int tlc_vicinity_filtration(tlc_graph* g, const int32_t* d_pairs, int64_t n_pair
 /* The same batch WITHOUT the final join -- for a caller that submits batch after batch (the reference's sweep over its pair
  * lists, sg2dgm/riccidist2dgm.py:362-370 over loaddatas.py:44-53) and wants them to overlap: the batch is ordered after what
  * `stream` holds at the time of the call (its inputs may be produced there), runs on streams of the handle, and `stream` does
- * NOT wait for it.  The outputs are complete for work that follows a tlc_pd_pi_batch_join() on its stream.  A handle keeps two
- * batches in flight; submitting a third waits ON THE HOST for the first.  tlc_pd_pi_batch == async + join.
+ * NOT wait for it.  The outputs are complete for work that follows a tlc_pd_pi_batch_join() on its stream -- and only then:
+ * the second half of the most recent batch (the launches sized by its vicinity counts) is submitted by the next
+ * tlc_pd_pi_batch_async, by the join, or by any other call on the handle, whichever comes first.  A handle keeps three
+ * batches in flight; submitting a fourth waits ON THE HOST for the first.  tlc_pd_pi_batch == async + join.
  * Buffers (pairs, out_pi, out_status) of a batch in flight must stay valid and must not be written until joined. */
 int tlc_pd_pi_batch_async(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags,
                           int res, double* d_out_pi, uint8_t* d_out_status, void* stream);

@@ -145,9 +145,10 @@ def test_asymmetric_or_repeated_heavy_rows_switch_the_heavy_set_off():
 
 
 def test_async_batches_overlap_and_equal_the_stream_ordered_call():
-    """tlc_pd_pi_batch_async + tlc_pd_pi_batch_join: batches submitted back to back run on the handle's two workspaces (a third
-    submission waits on the host for the first) and must give, bit for bit, what the stream-ordered call gives for the same
-    pairs -- whatever workspace a batch lands on, whatever is in flight beside it."""
+    """tlc_pd_pi_batch_async + tlc_pd_pi_batch_join: batches submitted back to back run on the handle's workspaces in turn (three;
+    a fourth submission waits on the host for the first) and must give, bit for bit, what the stream-ordered call gives for the
+    same pairs -- whatever workspace a batch lands on, whatever is in flight beside it.  A batch's tier launches are submitted
+    behind the NEXT batch's first half (or by the join): the rows must not depend on that either (options defer / n_ws)."""
     import torch
     from tlc_gnn_amd import engine, synth
     n, edges, kappa, _, _ = synth.shaped_graph("PubMed", scale=0.3)
@@ -186,7 +187,7 @@ def test_async_batches_overlap_and_equal_the_stream_ordered_call():
     assert g.stats()["chunks"] == 1
     # pipelined chunks do not split the MEDIUM tier by Pos-edge count (no speculative launch either); with the split forced, with
     # its reserved slots cut to 8 and with kernel events on every 2nd chunk only, the rows are the same
-    for opts in ({"mh_always": 1}, {"mh_always": 1, "spec_cap": 8}, {"timing_every": 2}):
+    for opts in ({"mh_always": 1}, {"mh_always": 1, "spec_cap": 8}, {"timing_every": 2}, {"defer": 0}, {"n_ws": 2}, {"n_ws": 4}):
         for k, v in opts.items():
             g.set_option(k, v)
         if "timing_every" in opts:
@@ -198,5 +199,19 @@ def test_async_batches_overlap_and_equal_the_stream_ordered_call():
             assert torch.equal(s, wst) and torch.equal(o, wo), (opts, k)
         g.set_timing(False)
         for k in opts:
-            g.set_option(k, 1 if k == "timing_every" else 0)
+            g.set_option(k, {"timing_every": 1, "defer": 1, "n_ws": 3}.get(k, 0))
+    # a batch whose second half is still owed: statistics and sizes ask for it themselves, a stream-ordered call submits it first,
+    # and a handle may be closed with one pending
+    o6, s6 = g.pd_pi_batch(batches[0], 2, async_=True)
+    assert g.stats()["chunks"] == 1
+    torch.cuda.synchronize()
+    assert torch.equal(o6, want[0][0]) and torch.equal(s6, want[0][1])
+    o7, _ = g.pd_pi_batch(batches[2], 2, async_=True)
+    o8, s8 = g.pd_pi_batch(batches[5], 2)                                # (stream-ordered: behind the pending one)
+    torch.cuda.synchronize()
+    assert torch.equal(o8, want[5][0]) and torch.equal(s8, want[5][1])
+    g.join()
+    torch.cuda.synchronize()
+    assert torch.equal(o7, want[2][0])
+    g.pd_pi_batch(batches[3], 2, async_=True)
     g.close()

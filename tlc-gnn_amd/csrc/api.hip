@@ -1261,8 +1261,8 @@ extern "C" int tlc_pd_pi_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_p
 
 // tlc_pd_pi_batch without the final join: the batch is ordered AFTER what `stream` holds at the time of the call (its inputs may
 // be produced there), but `stream` does not wait for it -- batches submitted back to back overlap, each on one of the handle's
-// workspaces.  Outputs are complete for work that follows a tlc_pd_pi_batch_join on its stream.  At most two batches run ahead
-// of the GPU: submitting a third waits on the host for the first.
+// workspaces.  Outputs are complete for work that follows a tlc_pd_pi_batch_join on its stream.  At most three batches run ahead
+// of the GPU: submitting a fourth waits on the host for the first.  (The batch's second half is deferred, see run_batch.)
 extern "C" int tlc_pd_pi_batch_async(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags, int res,
                                      double* d_out_pi, uint8_t* d_out_status, void* stream) {
     TLC_REQUIRE(n_pairs == 0 || d_out_pi != nullptr, "out_pi is null");
