@@ -193,42 +193,74 @@ __device__ __forceinline__ int x_sweep_wave(const PB& p, const int* ids, int n, 
             }
         }
         SSTAMP(10);
-        // ---- short rows beyond the record: a lane scans the rest of its own row, eight entries and weights per round trip ----
-        int j0 = big ? re : rb + n_in;
-        while (__any(j0 < re)) {
-            int bb[8], ly[8];
-            double ww[8];
-            unsigned hit = 0u, rev = 0u;
-            if (j0 < re) {
-                load_row8(p.col, j0, bb);
-                if (WR) load_row8w(p.w, j0, ww);
+        // ---- short rows beyond the record, in eight-entry SEGMENTS (segment r of a member = entries 8r .. 8r+7 behind the record's;
+        //      a short row has at most four).  The entries are numbered by round r, by member inside a round, by position inside
+        //      a segment (what a lane that walks its own row round after round finds).  That walk costs one global round trip per
+        //      round of the LONGEST row while most lanes idle (per-pair stamps: 2.8 of the 8.3 us of a <= 16-node vicinity, 5.6 of
+        //      12 us up to 64 nodes), so the segments of the whole batch of members are dealt to the lanes in exactly that order
+        //      -- lane s takes the s-th segment -- and a plain scan over the lanes numbers the entries: one round trip per 64
+        //      segments, typically one per batch of members.
+        {
+            const int rest0 = big ? re : rb + n_in;                       // (heavy / inactive members: rb == re == 0)
+            const int segs = (re - rest0 + 7) >> 3;
+            const unsigned long long m0 = __ballot(segs > 0), m1 = __ballot(segs > 1), m2 = __ballot(segs > 2), m3 = __ballot(segs > 3);
+            const int b1 = __popcll(m0), b2 = b1 + __popcll(m1), b3 = b2 + __popcll(m2), total = b3 + __popcll(m3);
+            for (int s0 = 0; s0 < total; s0 += TLC_WAVE) {
+                const int sx = s0 + lane;
+                const bool have = sx < total;
+                const int r = (sx >= b1) + (sx >= b2) + (sx >= b3);
+                const unsigned long long mm = r == 0 ? m0 : (r == 1 ? m1 : (r == 2 ? m2 : m3));
+                int kth = sx - (r == 0 ? 0 : (r == 1 ? b1 : (r == 2 ? b2 : b3)));
+                // the lane of the kth member that has a segment r: kth set bit of mm
+                int src = 0;
+                {
+                    unsigned w32 = (unsigned)mm;
+                    const int c32 = __popc(w32);
+                    if (kth >= c32) { kth -= c32; src = 32; w32 = (unsigned)(mm >> 32); }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    ly[q] = 0;
-                    if (j0 + q < re && x_member(X, bb[q], ly[q])) {
-                        hit |= 1u << q;
-                        if (use_hvy && x_heavy(X, ly[q])) rev |= 1u << q;
+                    for (int sh = 16; sh; sh >>= 1) {
+                        const unsigned low = w32 & ((1u << sh) - 1u);
+                        const int c = __popc(low);
+                        if (kth >= c) { kth -= c; w32 >>= sh; src += sh; } else w32 = low;
                     }
                 }
-            }
-            const int cnt = __popc(hit) + __popc(rev);
-            const int incl = tlc_wave_iscan_i32(cnt);
-            int off = run + incl - cnt;
-            run += __builtin_amdgcn_readlane(incl, 63);
-            if (WR && cnt) {
+                if (!have) src = lane;
+                const int m_rest = __shfl(rest0, src), m_re = __shfl(re, src);
+                const int kk = (b << 6) + src;
+                const int j0 = m_rest + 8 * r;
+                int bb[8], ly[8];
+                double ww[8];
+                unsigned hit = 0u, rev = 0u;
+                if (have) {
+                    load_row8(p.col, j0, bb);
+                    if (WR) load_row8w(p.w, j0, ww);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if ((hit >> q) & 1u) {
-                        if (off < cap) { x_store(&dir[off], ((unsigned)k << 16) | (unsigned)ly[q]); x_store(&lw[off], ww[q]); }
-                        ++off;
-                        if ((rev >> q) & 1u) {
-                            if (off < cap) { x_store(&dir[off], ((unsigned)ly[q] << 16) | (unsigned)k); x_store(&lw[off], ww[q]); }
+                    for (int q = 0; q < 8; ++q) {
+                        ly[q] = 0;
+                        if (j0 + q < m_re && x_member(X, bb[q], ly[q])) {
+                            hit |= 1u << q;
+                            if (use_hvy && x_heavy(X, ly[q])) rev |= 1u << q;
+                        }
+                    }
+                }
+                const int cnt = __popc(hit) + __popc(rev);
+                const int incl = tlc_wave_iscan_i32(cnt);
+                int off = run + incl - cnt;
+                run += __builtin_amdgcn_readlane(incl, 63);
+                if (WR && cnt) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if ((hit >> q) & 1u) {
+                            if (off < cap) { x_store(&dir[off], ((unsigned)kk << 16) | (unsigned)ly[q]); x_store(&lw[off], ww[q]); }
                             ++off;
+                            if ((rev >> q) & 1u) {
+                                if (off < cap) { x_store(&dir[off], ((unsigned)ly[q] << 16) | (unsigned)kk); x_store(&lw[off], ww[q]); }
+                                ++off;
+                            }
                         }
                     }
                 }
             }
-            j0 += 8;
         }
         SSTAMP(11);
         // ---- long scanned rows (a root that is a hub; a high degree outside the heavy set): the wavefront streams the row,
