@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 R=${1:-r01}
 rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
-python bench.py --steps 20 --warmup 3 > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err
 cat gpurun_out/bench_$R.json
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sweep > gpurun_out/prof/kt.log 2>&1
 cp $(find gpurun_out/prof/kt -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_bench_kernel_stats.csv
