@@ -311,7 +311,9 @@ def main():
     ap.add_argument("--sync-batches", action="store_true",
                     help="timed region with stream-ordered tlc_pd_pi_batch calls (one batch at a time) instead of "
                          "tlc_pd_pi_batch_async + one join (three batches in flight)")
-    ap.add_argument("--no-lp-graph", action="store_true", help="submit the LP forward kernel by kernel instead of replaying its HIP graph")
+    ap.add_argument("--lp-graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the LP forward from a HIP graph (one launch per step); auto = only when the host needs more than "
+                         "85 %% of a forward's device time to submit it kernel by kernel")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic (it is then read from profiles/)")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -399,8 +401,14 @@ def main():
         box["x"], box["xs"] = x_local, (xs_local if xs_local.density < TLCGNN.Net.SPARSE_FEATURES_BELOW and x_local.shape[1] <= ops.SPARSE_GEMM_MAX_K else None)
         pairs_mapped = enc.row_map(dec_pairs.long()).to(torch.int32).contiguous()      # decode pairs index encode()'s layout
 
+        fused = enc.rows is None and box["xs"] is None                  # no exchange step, dense features: one call for the encoder
+        emb_buf = torch.empty((n, w2.shape[1]), dtype=torch.float32, device=dev) if fused else None
+
         def leg():
-            emb = enc.encode(x_local, w1, b1, w2, b2, renorm=True)     # renorm_ of TLCGNN.py:48 fused into the last SpMM
+            if fused:
+                emb = ops.gcn2_encode(rowptr_n, col_n, val_n, x_local, w1, b1, w2, b2, relu=True, renorm=True, out=emb_buf)
+            else:
+                emb = enc.encode(x_local, w1, b1, w2, b2, renorm=True)  # renorm_ of TLCGNN.py:48 fused into the last SpMM
             ops.lp_decode(pairs_mapped, emb, dec_pi, l1w, l1b, l2w, l2b, out=prob)
         return leg
 
@@ -430,11 +438,22 @@ def main():
     enc_mode = min(encoder_ms, key=lambda k: encoder_ms[k])
     leg_lp = legs[enc_mode]
     # The forward is five small kernels (79 us on the device): submitted one by one through the Python wrappers it needs a host
-    # that keeps up (a box with a slow host measured 0.18 ms per forward, submission-bound).  Without a collective inside, the
-    # whole forward is captured once into a HIP graph -- same kernels, same buffers, one launch per step -- and replayed; kept only
-    # if it reproduces the eager output bit for bit and is within 5 % of the eager time on the device.
+    # that keeps up (a box with a slow host measured 0.18 ms per forward, submission-bound).  On such a host, and without a
+    # collective inside, the whole forward is captured once into a HIP graph -- same kernels, same buffers, one launch per step --
+    # and replayed; kept only if it reproduces the eager output bit for bit and is within 5 % of the eager time on the device.
     lp_submit = "eager"
-    if enc_mode == "replicated" and not args.no_lp_graph:
+    # (how long the host takes to SUBMIT a forward, without waiting for it)
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()
+    for _ in range(10):
+        leg_lp()
+    lp_host_ms = (time.perf_counter() - h0) * 1e2
+    torch.cuda.synchronize()
+    encoder_ms["host submission, eager"] = lp_host_ms
+    # Only when the host is that slow: the capture brings two more streams into the process, and the image pipeline's eleven
+    # streams then share hardware queues (measured: -6 % images/s with the graph in use on a box whose host kept up).
+    want_graph = args.lp_graph == "on" or (args.lp_graph == "auto" and lp_host_ms > 0.85 * encoder_ms[enc_mode])
+    if enc_mode == "replicated" and want_graph:
         try:
             leg_lp()
             torch.cuda.synchronize()

@@ -231,6 +231,14 @@ int tlc_spmm_csr_f32(int32_t n_rows, const int32_t* d_rowptr, const int32_t* d_c
 /* emb.renorm_(2, 0, 1) (TLCGNN.py:48): rows with L2 norm > 1 are scaled by 1/(norm + 1e-7), in place. */
 int tlc_renorm_rows_f32(int32_t n_rows, int32_t k, float* d_emb, void* stream);
 
+/* Net.encode in eval mode (baselines/TLCGNN.py:19-26: conv1 -> ReLU -> conv2 on the normalised adjacency of tlc_gcn_norm_csr)
+ * as ONE call: tlc_gemm_f32, tlc_spmm_csr_f32 (+ b1, ReLU), tlc_gemm_f32, tlc_spmm_csr_f32 (+ b2; `flags` bit 0 = ReLU, bit 1 =
+ * the emb.renorm_(2, 0, 1) of TLCGNN.py:48) submitted back to back.  d_ws: scratch of (2 * hidden + out_dim) * n_nodes + 12
+ * floats; d_emb: [n_nodes, out_dim].  hidden, out_dim <= 128. */
+int tlc_gcn2_encode_f32(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
+                        const float* d_x, int32_t f_in, const float* d_w1, const float* d_b1, int32_t hidden,
+                        const float* d_w2, const float* d_b2, int32_t out_dim, int flags, float* d_ws, float* d_emb, void* stream);
+
 /* Net.decode after the renorm (TLCGNN.py:52-61), one fused pass per pair:
  *   h = LeakyReLU_0.2( W1 @ [ (emb[u]-emb[v])^2 || PI ] + b1 );  d = clamp(|W2 @ h + b2|, 0, 40);
  *   prob = 1 / (exp(d - 2) + 1)

@@ -420,6 +420,32 @@ def test_spmm_fused_renorm_equals_separate_pass(setup):
         assert float(fused.norm(dim=1).max()) <= 1.0 + 1e-5
 
 
+def test_gcn2_encode_one_call_equals_the_four_calls(setup):
+    """tlc_gcn2_encode_f32 (Net.encode in eval mode behind one library call, TLCGNN.py:19-26,48) submits the same four kernels
+    as gemm / spmm / gemm / spmm: identical bits, with and without the fused renorm_, for sizes whose scratch blocks need padding."""
+    torch = setup[0]
+    from tlc_gnn_amd import ops
+    rs = np.random.RandomState(21)
+    for n, f_in, hidden, d in ((3001, 500, 100, 16), (517, 33, 12, 7), (64, 8, 128, 16)):
+        deg = rs.randint(1, 7, size=n)
+        deg[:3] = [min(n - 1, 300), 40, 1]
+        rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+        col = np.concatenate([np.sort(rs.choice(n, size=k, replace=False)) for k in deg]).astype(np.int32)
+        val = (rs.rand(len(col)).astype(np.float32) * 0.5)
+        rp, c, v = [torch.from_numpy(a).cuda() for a in (rowptr, col, val)]
+        x = torch.from_numpy((rs.rand(n, f_in) < 0.1).astype(np.float32) * rs.rand(n, f_in).astype(np.float32)).cuda()
+        w1 = torch.from_numpy((rs.randn(f_in, hidden) / np.sqrt(f_in)).astype(np.float32)).cuda()
+        b1 = torch.from_numpy((0.1 * rs.randn(hidden)).astype(np.float32)).cuda()
+        w2 = torch.from_numpy((rs.randn(hidden, d) / np.sqrt(hidden) * 3).astype(np.float32)).cuda()
+        b2 = torch.from_numpy((0.1 * rs.randn(d)).astype(np.float32)).cuda()
+        for renorm in (False, True):
+            h = ops.spmm(rp, c, v, ops.gemm(x, w1), bias=b1, relu=True)
+            want = ops.spmm(rp, c, v, ops.gemm(h, w2), bias=b2, relu=True, renorm=renorm)
+            got = ops.gcn2_encode(rp, c, v, x, w1, b1, w2, b2, relu=True, renorm=renorm)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (n, f_in, hidden, d, renorm, float((got - want).abs().max()))
+
+
 def test_hip_graph_replay_equals_eager_forward(setup):
     """ops.capture: the encode + decode chain as one HIP graph; replays give the eager launch's bits, also after the inputs
     held in the captured buffers change."""

@@ -920,6 +920,29 @@ extern "C" int tlc_renorm_rows_f32(int32_t n_rows, int32_t k, float* d_emb, void
     return TLC_OK;
 }
 
+// The whole two-layer encoder of Net.encode in eval mode (baselines/TLCGNN.py:19-26: conv1 -> ReLU -> conv2, dropout off) behind
+// ONE call: four launches (x@W1, aggregate + b1 + ReLU, h@W2, aggregate + b2 with `flags` as in tlc_spmm_csr_f32: bit 0 ReLU,
+// bit 1 the renorm_ of TLCGNN.py:48) submitted back to back -- the same kernels as the separate calls, without five trips
+// through the caller's language between them (a Python host needs ~70 us to submit what the device runs in 79 us).
+// d_ws: (2 * hidden + out_dim) * n floats (+ 12) of scratch.
+extern "C" int tlc_gcn2_encode_f32(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
+                                   const float* d_x, int32_t f_in, const float* d_w1, const float* d_b1, int32_t hidden,
+                                   const float* d_w2, const float* d_b2, int32_t out_dim, int flags, float* d_ws, float* d_emb,
+                                   void* stream) {
+    TLC_REQUIRE(n_nodes >= 0 && f_in > 0 && hidden > 0 && out_dim > 0, "bad sizes");
+    if (n_nodes == 0) return TLC_OK;
+    TLC_REQUIRE(d_rowptr && d_col && d_val && d_x && d_w1 && d_w2 && d_ws && d_emb, "null pointer");
+    auto pad4 = [](size_t v) { return (v + 3) & ~(size_t)3; };
+    float* t1 = d_ws;
+    float* t2 = t1 + pad4((size_t)n_nodes * hidden);
+    float* t3 = t2 + pad4((size_t)n_nodes * hidden);
+    int rc;
+    if ((rc = tlc_gemm_f32(n_nodes, hidden, f_in, d_x, d_w1, nullptr, 0, t1, stream)) != TLC_OK) return rc;
+    if ((rc = tlc_spmm_csr_f32(n_nodes, d_rowptr, d_col, d_val, t1, hidden, d_b1, 1, t2, stream)) != TLC_OK) return rc;
+    if ((rc = tlc_gemm_f32(n_nodes, out_dim, hidden, t2, d_w2, nullptr, 0, t3, stream)) != TLC_OK) return rc;
+    return tlc_spmm_csr_f32(n_nodes, d_rowptr, d_col, d_val, t3, out_dim, d_b2, flags, d_emb, stream);
+}
+
 extern "C" int tlc_lp_decode_fused(int64_t n_pairs, const int32_t* d_pairs, const float* d_emb, int32_t emb_dim, const double* d_pi,
                                    int32_t pi_dim, const float* d_W1, const float* d_b1, const float* d_W2, const float* d_b2,
                                    float* d_prob, void* stream) {

@@ -116,6 +116,33 @@ def spmm(rowptr, col, val, x, bias=None, relu=False, out=None, renorm=False):
     return out
 
 
+_GCN2_WS = {}
+
+
+def gcn2_encode(rowptr, col, val, x, w1, b1, w2, b2, relu=True, renorm=False, out=None):
+    """Net.encode in eval mode behind one library call (tlc_gcn2_encode_f32): relu(A (relu(A (x w1) + b1)) w2 + b2), rows
+    renormalised when renorm=True (TLCGNN.py:19-26,48).  Same four kernels as gemm / spmm / gemm / spmm; the scratch for
+    the intermediates is kept per (device, sizes)."""
+    torch = _lib.require_gpu()
+    x, w1, w2 = _f32(x), _f32(w1), _f32(w2)
+    n, f_in, hidden, d = x.shape[0], x.shape[1], w1.shape[1], w2.shape[1]
+    key = (x.device, n, hidden, d)
+    ws = _GCN2_WS.get(key)
+    if ws is None:
+        _GCN2_WS.clear()
+        ws = _GCN2_WS[key] = torch.empty(((2 * hidden + d) * n + 12,), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().tlc_gcn2_encode_f32(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.ptr(x), C.c_int32(f_in),
+                                            _lib.ptr(w1), _lib.ptr(_f32(b1)) if b1 is not None else None, C.c_int32(hidden),
+                                            _lib.ptr(w2), _lib.ptr(_f32(b2)) if b2 is not None else None, C.c_int32(d),
+                                            C.c_int((1 if relu else 0) | (2 if renorm else 0)), _lib.ptr(ws), _lib.ptr(out),
+                                            _lib.stream_ptr(x.device))
+    _lib.check(rc, "tlc_gcn2_encode_f32")
+    return out
+
+
 @_lib.on_device_of
 def renorm_rows_(emb):
     """emb.renorm_(2, 0, 1) in place (baselines/TLCGNN.py:48)."""
