@@ -491,6 +491,11 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     const int prio_mid = (prio_lo + prio_hi) / 2;
+    // The streams of the three workspaces in use exist from the start: the runtime deals hardware queues to streams as they are
+    // created, and streams that come into being later -- a framework's capture streams, a communicator's -- would otherwise take
+    // the queues the second and third workspace get with their first chunk (measured: a HIP graph captured between the handle's
+    // creation and its first pipelined batch cost 6 % images/s; none with the streams created here).  TLC_LAZY_STREAMS=1: as before.
+    const bool eager_streams = getenv("TLC_LAZY_STREAMS") == nullptr;
     for (int i = 0; i < TLC_N_WS; ++i) {
         Workspace* ws = &g->ws[i];
         CK(hipMalloc(&ws->d_ctl, (64 + 1024 + 8) * sizeof(int)));   // counters, the scan's per-block flags, 4 x u64 statistics
@@ -500,11 +505,10 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
         CK(hipHostMalloc((void**)&ws->h_sync, sizeof(HostSync), hipHostMallocMapped | hipHostMallocCoherent));
         memset(ws->h_sync, 0, sizeof(HostSync));
         CK(hipHostGetDevicePointer((void**)&ws->h_sync_dev, ws->h_sync, 0));
-        // (workspace 1's own two streams are created when the first chunk lands on it: a caller that never has two chunks in
-        // flight keeps the hardware queues to itself)
-        if (i == 0) CK(hipStreamCreateWithPriority(&ws->main, hipStreamNonBlocking, prio_mid));
+        // (the fourth workspace's own two streams are created when the first chunk lands on it: option n_ws = 4 only)
+        if (i == 0 || (eager_streams && i < 3)) CK(hipStreamCreateWithPriority(&ws->main, hipStreamNonBlocking, prio_mid));
         for (int k = 0; k < TLC_N_SIDE; ++k) {
-            if (k == 4) { if (i == 0) CK(hipStreamCreateWithPriority(&ws->side[k], hipStreamNonBlocking, prio_hi)); }
+            if (k == 4) { if (i == 0 || (eager_streams && i < 3)) CK(hipStreamCreateWithPriority(&ws->side[k], hipStreamNonBlocking, prio_hi)); }
             else if (i > 0) ws->side[k] = g->ws[0].side[k];
             else if (k == 2) ws->side[k] = nullptr;                      // (= side[6], set below)
             else {
