@@ -342,16 +342,23 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    wl = build_workload(rank)
+    n, hop = wl["n"], wl["hop"]
+    # (the handle -- and with it its streams -- ahead of the communicator: hardware queues are dealt to streams in creation order,
+    # and the image pipeline wants one queue per stream; RCCL's own streams then take what is left)
+    if args.single_device and world > 1:
+        # (rehearsal: several ranks on ONE card.  A process holds up to twelve hardware queues; two such processes oversubscribe
+        # the card's queue slots and the firmware time-slices them -- seconds per batch.  Two workspaces, streams on demand.)
+        os.environ["TLC_LAZY_STREAMS"] = "1"
+    g = engine.DeviceGraph(wl["rowptr"], wl["col"], wl["w"], device=local_rank)
+    if args.single_device and world > 1:
+        g.set_option("n_ws", 2)
     if world > 1:
         import torch.distributed as dist
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=args.dist_backend)
-
-    wl = build_workload(rank)
-    n, hop = wl["n"], wl["hop"]
-    g = engine.DeviceGraph(wl["rowptr"], wl["col"], wl["w"], device=local_rank)
     pi_pairs = torch.from_numpy(wl["pi_pairs"]).to(dev)
     E = pi_pairs.shape[0]
     pi_out = torch.empty((E, 25), dtype=torch.float64, device=dev)
