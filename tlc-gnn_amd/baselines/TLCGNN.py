@@ -120,6 +120,13 @@ class Net(torch.nn.Module):
         # can set p = 0.8 for Cora and Citeseer, the results can be higher   (reference comment, TLCGNN.py:20)
         x, edge_index = data.x, data.edge_index
         xs = None if self.training else self._sparse_features(x)      # (training: dropout makes a new x every step)
+        if not self.training and xs is None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+            # eval mode, dense features: both layers behind one library call (the same four kernels, ops.gcn2_encode)
+            rowptr, col, val = self.conv1.norm_csr(edge_index, x.shape[0])
+            self.conv2._cache = self.conv2._cache or self.conv1._cache            # (one graph: conv2 would build the same operator)
+            with torch.no_grad():
+                return ops.gcn2_encode(rowptr, col, val, x, self.conv1.weight.detach(), self.conv1.bias.detach(),
+                                       self.conv2.weight.detach(), self.conv2.bias.detach(), relu=True)
         x = F.dropout(x, p=0.5, training=self.training)
         x = self.conv1(x, edge_index, relu=not self.training, x_sparse=xs)   # ReLU fused into the aggregate in eval mode
         if self.training:
