@@ -901,7 +901,11 @@ def main():
                        "tie_fallback_sources": int(stats["tie_fallback_sources"])},
             "roofline": {"bound": "hbm", "kernel": dom, "kernel_ms": kavg[dom], "launches_timed": len(live), "units_per_launch": dom_units,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source},
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel_ms_one_batch_alone": warm_avg.get(dom, -1.0),
+                         "note": "kernel_ms: this kernel chain's launches INSIDE the timed region, where three batches are in flight and "
+                                 "its whole-CU workgroups wait for room among the other batches' kernels; kernel_ms_one_batch_alone: "
+                                 "the same chain in a stream-ordered batch with the machine to itself (warm-up steps)"},
             "roofline_chain": {"bound": "hbm", "algorithmic_bytes_per_pi": all_bytes / E,
                                "achieved": all_bytes * world * K / t_pi / 1e9, "peak": HBM_PEAK_GBS * world,
                                "unit": "GB/s", "frac": all_bytes * K / t_pi / 1e9 / HBM_PEAK_GBS},
