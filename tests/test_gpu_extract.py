@@ -64,6 +64,35 @@ def test_extraction_modes_agree_and_match_the_oracle(shape, scale, hop):
     assert (rst == 1).sum() >= 2 and (rst == 0).sum() > 1000
 
 
+@pytest.mark.parametrize("n,reach,hop", [(60, 12, 2), (150, -8, 2), (70, 15, 1)])
+def test_sweep_segments_of_dense_vicinities(n, reach, hop):
+    """The sweep deals the eight-entry segments behind the node records of a batch of 64 members to the lanes: circulant graphs
+    (every node 2 * reach neighbours, 20 - 30: three or four segments per member, up to 250 per batch of members, several batches)
+    make it go round more than once per batch.  Same rows as the breadth-first kernels, which walk row by row, and as the oracle."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    rs = np.random.RandomState(n)
+    # (reach < 0: offsets 1..8 and 20..26 instead of 1..reach -- 30 neighbours again, but hop-2 balls of more than 64 nodes)
+    offs = list(range(1, reach + 1)) if reach > 0 else list(range(1, 9)) + list(range(20, 27))
+    edges = np.array([(i, (i + d) % n) for i in range(n) for d in offs], dtype=np.int64)
+    kappa = rs.rand(len(edges)) * 1.6 - 0.8
+    rowptr, col, w = synth.edges_to_csr(n, edges, kappa)
+    assert 20 <= int(np.diff(rowptr).max()) == 2 * len(offs) < 32
+    pairs = np.concatenate([edges[rs.permutation(len(edges))[:300]], rs.randint(0, n, size=(100, 2))]).astype(np.int32)
+    g = engine.DeviceGraph(rowptr, col, w)
+    new = _run(g, torch, pairs, hop)
+    old = _run(g, torch, pairs, hop, extract=0)
+    g.close()
+    assert np.array_equal(new[1], old[1]) and np.array_equal(new[2], old[2]) and np.array_equal(new[3], old[3])
+    assert int(new[2].max()) > (64 if reach < 0 else 25)                 # vicinities of that many such members
+    assert np.abs(new[0] - old[0]).max() <= 1e-12 * max(1.0, np.abs(old[0]).max())
+    ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, hop, n_threads=0)
+    assert np.array_equal(new[1], rst)
+    nz = ref != 0
+    assert np.array_equal(new[0] == 0, ref == 0) and rel_err(new[0][nz], ref[nz]).max() < 1e-8
+
+
 def test_heavy_rows_hub_vicinities_and_dense_heavy_core():
     """A graph built around the heavy-row path: a clique-like core of 40 hubs (every heavy-heavy entry comes from the dense
     table), each hub with a fan of leaves, leaves cross-linked (light rows that find several heavy members), pairs hub-hub,
