@@ -459,7 +459,7 @@ def main():
     encoder_ms["host submission, eager"] = lp_host_ms
     # Only when the host is that slow: replayed from a graph the forward takes 85 instead of 79 us on the device.
     want_graph = args.lp_graph == "on" or (args.lp_graph == "auto" and lp_host_ms > 0.85 * encoder_ms[enc_mode])
-    if enc_mode == "replicated" and want_graph:
+    if enc_mode == "replicated" and want_graph and world == 1:       # (N > 1: the communicator's watchdog thread must not meet a capture)
         try:
             leg_lp()
             torch.cuda.synchronize()

@@ -38,6 +38,14 @@ for rep in range(3):
     for k, v in dev.items():
         res[k].append(region([v]))
     res["rotating"].append(region(rot))
+g.set_option("tier_mask", 0)
+front = {}
+for rep in range(3):
+    for k in ("as given", "heaviest first", "lightest first"):
+        front.setdefault(k, []).append(region([dev[k]]))
+g.set_option("tier_mask", 127)
+for k, v in front.items():
+    print("first halves only (tier_mask 0)  %-16s %.4f ms   runs %s" % (k, np.median(v), " ".join("%.3f" % x for x in v)))
 for k, v in res.items():
     print("%-16s %.4f ms (%.2f M/s)   runs %s" % (k, np.median(v), E / np.median(v) / 1e3, " ".join("%.3f" % x for x in v)))
 print("first pairs as given:", base[:6].tolist())
