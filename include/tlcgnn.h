@@ -169,11 +169,14 @@ int tlc_pd_pi_algorithmic_bytes(int32_t n_nodes, const int32_t* h_rowptr, const 
  * "dc_force_fail", "x_region" / "x_bump_min" (arena entries per extraction workgroup / bump area: reach the overflow paths),
  * "spec_cap" (slots reserved for speculative launches), "mh_always" (split the MEDIUM tier in pipelined chunks too).
  * Measurement / A-B: "timing_every" (kernel events on every n-th chunk), "x_grid", "x_chunk_div", "gate_ticks", "medium_first",
- * "chunk_pairs" (0 = the defaults).  Results never depend on any of them (tests/test_gpu_extract.py, tests/test_gpu_tiers.py);
+ * "chunk_pairs" (0 = the defaults), "defer" (1: a pipelined chunk's second half behind the next chunk's first half), "n_ws"
+ * (workspaces taken in turn, 2..4, default 3).  Results never depend on any of them (tests/test_gpu_extract.py, tests/test_gpu_tiers.py);
  * an unknown name is TLC_ERR_INVALID_ARG. */
 int tlc_debug_set_option(tlc_graph* g, const char* name, int value);
 int tlc_debug_dc_stats(tlc_graph* g, long long* h_out, void* stream);
 int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out, int64_t cap_u64, int32_t* n_rows);
+/* (builds with PAIR_TIMES=1 only: wall-clock stamps of the extraction, h_out[n_pairs][16] ticks of 10 ns; zeros otherwise) */
+int tlc_debug_pair_times(tlc_graph* g, unsigned long long* h_out, int64_t n_pairs);
 
 /* ---- P6-P8: perturb_filter_function / Union_find / Accelerate_PD ---------------------------------
  * (sg2dgm/accelerated_PD.py:6-178 and the Knowledge_Distillation fork, selected by TLC_KEEP_ZERO_PERS)
