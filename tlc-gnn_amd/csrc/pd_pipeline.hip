@@ -470,7 +470,7 @@ struct PtsSink {
 // development check (TLC_DC_VERIFY): the higher endpoint per query
 struct VerifySink {
     unsigned short* o;
-    static constexpr bool want_down = false, is_global = false;
+    [[maybe_unused]] static constexpr bool want_down = false, is_global = false;
     __device__ __forceinline__ void one_at(const double*, int, int k, int, int d) { o[k] = (unsigned short)d; }
 };
 // tlc_pd_from_filtration: values straight to the caller's arrays.
@@ -2226,8 +2226,8 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>), dim3(p.tier_count),
                                dim3(TLC_L_THREADS), lds_bytes, s, p);
             if (deferring) {
-                // (only the subgraphs marked for the divide and conquer were handed off; the serial kernel is their fallback)
-                constexpr SwapLayout SL = make_swap_layout(TLC_L_NMAX, TLC_L_MMAX);
+                // (only the subgraphs marked for the divide and conquer were handed off; tlc_pd_dc_kernel runs the serial walk itself
+                // for those it gives back)
                 // (its own 107 KB only, see above)
                 const size_t dcl = (dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX) > 156 * 1024 || !(excl & 2)) ? dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX) : 156 * 1024;
                 if (host_trace) { static int once = 0; if (!once++) fprintf(stderr, "[tlc] LARGE tier LDS %zu (layout %zu), dc %zu (layout %zu)\n", lds_bytes, (size_t)L.total, dcl, (size_t)dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX)); }
