@@ -132,6 +132,7 @@ struct Workspace {
     int in_call;                   // ... by the call in progress (its statistics are still to be collected)
     int n_pairs;                   // pairs of that chunk
     ChunkCtx ctx;                  // the chunk in flight
+    int own_early;                 // side[4] is this workspace's own stream
     int back_pending;              // its second half has not been submitted yet
 };
 
@@ -496,6 +497,12 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     // the queues the second and third workspace get with their first chunk (measured: a HIP graph captured between the handle's
     // creation and its first pipelined batch cost 6 % images/s; none with the streams created here).  TLC_LAZY_STREAMS=1: as before.
     const bool eager_streams = getenv("TLC_LAZY_STREAMS") == nullptr;
+    // (Four workspaces within the same eleven streams -- early streams shared by workspaces i and i + 2, MEDIUM's side stream in
+    // the low-priority pool -- were measured: 0.655 vs 0.643 ms per pipelined batch; the LARGE chains of two chunks on one stream
+    // cost more than the fourth chunk in flight gains.  With three workspaces the submitting thread does wait 0.1 - 0.4 ms for a
+    // workspace in most calls (TLC_HOST_TRACE), but a fourth with streams of its own -- thirteen in all -- is no faster either:
+    // the wait is the machine's queue, not a missing slot.)
+    const int n_eager = 3;
     for (int i = 0; i < TLC_N_WS; ++i) {
         Workspace* ws = &g->ws[i];
         CK(hipMalloc(&ws->d_ctl, (64 + 1024 + 8) * sizeof(int)));   // counters, the scan's per-block flags, 4 x u64 statistics
@@ -506,9 +513,11 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
         memset(ws->h_sync, 0, sizeof(HostSync));
         CK(hipHostGetDevicePointer((void**)&ws->h_sync_dev, ws->h_sync, 0));
         // (the fourth workspace's own two streams are created when the first chunk lands on it: option n_ws = 4 only)
-        if (i == 0 || (eager_streams && i < 3)) CK(hipStreamCreateWithPriority(&ws->main, hipStreamNonBlocking, prio_mid));
+        if (i == 0 || (eager_streams && i < n_eager)) CK(hipStreamCreateWithPriority(&ws->main, hipStreamNonBlocking, prio_mid));
         for (int k = 0; k < TLC_N_SIDE; ++k) {
-            if (k == 4) { if (i == 0 || (eager_streams && i < 3)) CK(hipStreamCreateWithPriority(&ws->side[k], hipStreamNonBlocking, prio_hi)); }
+            if (k == 4) {
+                if (i == 0 || (eager_streams && i < n_eager)) { CK(hipStreamCreateWithPriority(&ws->side[k], hipStreamNonBlocking, prio_hi)); ws->own_early = 1; }
+            }
             else if (i > 0) ws->side[k] = g->ws[0].side[k];
             else if (k == 2) ws->side[k] = nullptr;                      // (= side[6], set below)
             else {
@@ -564,7 +573,7 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
         hipFree(ws->d_cand_list); hipFree(ws->d_early_list); hipFree(ws->E_dir); hipFree(ws->E_lw);
         if (ws->main) hipStreamDestroy(ws->main);
         for (int k = 0; k < TLC_N_SIDE; ++k) {
-            const bool own = (k == 4) || (i == 0 && k != 2);             // (the rest are workspace 0's, see tlc_graph_create)
+            const bool own = (k == 4 && ws->own_early) || (i == 0 && k != 2);   // (the rest are workspace 0's, see tlc_graph_create)
             if (own && ws->side[k]) hipStreamDestroy(ws->side[k]);
             if (ws->ev_join[k]) hipEventDestroy(ws->ev_join[k]);
         }
@@ -1168,9 +1177,16 @@ static int acquire_workspace(tlc_graph* g, Workspace** out, bool same) {
         hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         TLC_HIP_CHECK(hipStreamCreateWithPriority(&ws->main, hipStreamNonBlocking, (prio_lo + prio_hi) / 2));
         TLC_HIP_CHECK(hipStreamCreateWithPriority(&ws->side[4], hipStreamNonBlocking, prio_hi));
+        ws->own_early = 1;
     }
     if (ws->busy) {
+        // (development: TLC_HOST_TRACE=1 also prints how long the submitting thread waits here for the workspace's previous chunk)
+        static const bool host_trace = getenv("TLC_HOST_TRACE") != nullptr;
+        const auto w0 = std::chrono::steady_clock::now();
         TLC_HIP_CHECK(hipEventSynchronize(ws->ev_done));
+        if (host_trace)
+            fprintf(stderr, "[tlc host] ws%d waited %.0f us for its previous chunk\n", (int)(ws - g->ws),
+                    (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count() * 1e-3);
         ws->busy = 0;
         if (ws->in_call) {                                    // statistics of a chunk of the call in progress
             unsigned long long tie = 0;
