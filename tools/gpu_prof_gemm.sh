@@ -27,6 +27,6 @@ for d in ("pmc", "pmc2"):
 k = "gemm16_f32_kernel<7,true,2,32> (mean over M=19717 K=500 and M=13752 K=768, N=100)"
 if k in res and "SQ_VALU_MFMA_BUSY_CYCLES" in res[k] and "SQ_BUSY_CU_CYCLES" in res[k]:
     res[k]["mfma_pipe_utilisation"] = res[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * res[k]["SQ_BUSY_CU_CYCLES"])
-json.dump(res, open("gpurun_out/r01_gemm_pmc.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/gemm_pmc.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
