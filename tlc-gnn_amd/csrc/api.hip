@@ -39,7 +39,9 @@ extern "C" int tlc_device_count(void) {
 #define TLC_EARLY_CAND 512
 #define TLC_EARLY_SLOTS 256
 #define TLC_EARLY_WG 256          /* workgroups (and scratch slots) of the early COUNT */
+#ifndef TLC_EARLY_MIN_PAIRS
 #define TLC_EARLY_MIN_PAIRS 4096  /* smaller batches gain nothing from a second COUNT launch */
+#endif
 #define TLC_TIMING_RING 64        /* chunks whose kernel events are kept */
 #define TLC_X_REGION 4096         /* arena entries of the region each workgroup of the extraction starts with (extract.hip) */
 
