@@ -280,12 +280,30 @@ int tlc_gat_layer_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d
  *   d_assign[i] = problem-local target index of predicted point i, -1 = diagonal
  *   d_gradX[i] (may be null) = d loss[b] / d X_i: what `loss.backward()` leaves on the predicted diagram
  *   d_status[b]: 0 ok; 1 = fewer predicted than target points (the reference's transport has negative diagonal mass: no
- *   result, loss 0); 2 = more than 4 096 predicted points (not supported: loss 0).  Problems of up to 512 predicted points take one
+ *   result, loss 0); 2 = more than 4 096 predicted points (not supported: loss 0); 3 = a NaN / Inf coordinate (loss NaN, zero
+ *   gradient: the augmenting search cannot run on it).  Problems of up to 512 predicted points take one
  *   wavefront each, larger ones a 512-thread workgroup each (a second launch when max_points > 512).  max_points: an upper bound of the predicted
  *   points of one problem (selects the kernel variant). */
 int tlc_w2_partial_matching(int32_t n_problems, const int64_t* d_xoff, const double* d_X, const int64_t* d_yoff,
                             const double* d_Y, int order, int32_t max_points, double* d_loss, double* d_wxy, double* d_wxd,
                             int32_t* d_assign, double* d_gradX, uint8_t* d_status, void* stream);
+
+/* The evaluation form: `wasserstein_distance_inference(X, Y, order=p, internal_p=inf, enable_autodiff=True)` of
+ * Knowledge_Distillation/wasserstein.py:93-195, reached with `pair_diagonal=True` (train_Teacher_Model.py:99 ->
+ * Teacher_model.py:66 -> compute_PD_loss(type='inference') :134-136).  The classic transport in which BOTH diagrams may use the
+ * diagonal (masses [1]*n + [m] against [1]*m + [n], (n+1) x (m+1) costs, C[n, j] = ((Y_j.death - Y_j.birth) / 2) ^ p,
+ * C[n, m] = 0 :127-131) = the assignment of n + m rows onto n + m columns; same kernels as tlc_w2_partial_matching.
+ *   d_loss[b] = (sum |d_k|^p)^(1/p) over point-point pairs, predicted points sent to the diagonal and target points sent to the
+ *   diagonal (:140-181); d_wxy / d_wxd / d_wyd[b]: the same norm over each of the three groups (the reference's five return
+ *   values are (loss, None, wxy, wxd, wyd)).  An empty diagram on either side: loss = total persistence of the other one and
+ *   the three parts 0 (:98-113).
+ *   d_assign_x[i] = target index of predicted point i or -1 = diagonal; d_assign_y[j] = predicted index of target j or -1.
+ *   d_gradX (may be null): d loss[b] / d X_i.  d_status[b]: 0 ok; 2 = n + m > 4 096; 3 = non-finite coordinates (loss NaN).
+ *   max_points: an upper bound of n + m of one problem.  Parity unpinned like tlc_w2_partial_matching (POT absent). */
+int tlc_w2_inference_matching(int32_t n_problems, const int64_t* d_xoff, const double* d_X, const int64_t* d_yoff,
+                              const double* d_Y, int order, int32_t max_points, double* d_loss, double* d_wxy, double* d_wxd,
+                              double* d_wyd, int32_t* d_assign_x, int32_t* d_assign_y, double* d_gradX, uint8_t* d_status,
+                              void* stream);
 
 /* ---- what `loss.backward()` runs through the PDGNN layer and the edge head ---------------------------
  * (Knowledge_Distillation/train_Teacher_Model.py:55-62 through gat_conv.py:113-216 and Teacher_model.py:53-59.)

@@ -1,4 +1,4 @@
-"""CPU, 2 processes, gloo: the N>1 layout of the LP forward (node-row sharded encoder + one all-gather per layer,
+"""CPU, 2 / 3 / 8 processes, gloo: the N>1 layout of the LP forward (node-row sharded encoder + one all-gather per layer,
 pair-sharded decode) reproduces the single-rank result.  The compute callables are the torch fp32 restatement
 (the checker) because HIP kernels cannot run here; what is under test is the sharding/exchange logic of dist.py."""
 import os
@@ -99,34 +99,55 @@ def _worker(rank, world, port, q):
 
     cost = tdist.pair_cost(tdist.ball_bound(rp, cl, 2), pr)
     rows, st, (slo, shi) = tdist.pd_pi_batch_sharded(run, pr, world, rank, cost=cost, gather=tdist.gather_shards, scheme="contiguous")
-    assert 0 < shi - slo < len(pr)
+    assert 0 <= shi - slo < len(pr)
     assert np.array_equal(rows.numpy(), single_rows) and np.array_equal(st.numpy(), single_st)      # bit for bit
     # the default: pairs dealt to the ranks by descending cost; the rows come back to list order through the index arrays
     rows, st, mine = tdist.pd_pi_batch_sharded(run, pr, world, rank, cost=cost, gather=tdist.gather_shards)
     parts = tdist.shard_pairs_interleaved(cost, world)
     assert np.array_equal(mine, parts[rank]) and 0 < len(mine) < len(pr)
+    sizes = [len(q_) for q_ in parts]
+    assert max(sizes) - min(sizes) <= 1                                                              # uneven remainders: at most one apart
     assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(len(pr)))                       # a partition of the list
     heavy = np.argsort(-cost, kind="stable")[:world]                                                 # the heaviest pairs: one per rank
     assert sorted(int(np.flatnonzero([h in p for p in parts])[0]) for h in heavy) == list(range(world))
-    assert abs(cost[parts[0]].sum() - cost[parts[1]].sum()) <= cost.max()
+    sums = [cost[q_].sum() for q_ in parts]
+    assert max(sums) - min(sums) <= cost.max()
     assert np.array_equal(rows.numpy(), single_rows) and np.array_equal(st.numpy(), single_st)      # bit for bit
+    # fewer pairs than ranks: some shards are EMPTY (their run() sees zero pairs, their block of the gather is all padding)
+    few = pr[:2] if world > 2 else pr[:1]
+    few_rows, few_st, _ = oracle.pd_pi_batch(rp, cl, ww, few, 2, n_threads=1)
+    for scheme in ("interleaved", "contiguous"):
+        rows, st, part = tdist.pd_pi_batch_sharded(run, few, world, rank, cost=cost[:len(few)], gather=tdist.gather_shards, scheme=scheme)
+        assert rows.shape == (len(few), 25) and np.array_equal(rows.numpy(), few_rows) and np.array_equal(st.numpy(), few_st), scheme
+    # PaddedRows with rem != 0 (211 rows over 2 / 3 / 8 ranks): the padded row of every node is inside its owner's block
+    pr_rows = tdist.PaddedRows(n, world, rank)
+    padded = pr_rows.remap(torch.arange(n))
+    for r_ in range(world):
+        lo_r, hi_r = tdist.shard_bounds(n, world, r_)
+        assert padded[lo_r:hi_r].equal(torch.arange(hi_r - lo_r) + r_ * pr_rows.blk)
     q.put((rank, float((emb - full).abs().max()), float((prob - prob_full[lo:hi]).abs().max()), tuple(emb.shape)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_sharded_forward_world2_gloo():
-    world = 2
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_forward_gloo(world):
+    """world 3 and 8: uneven interleaved shards, node blocks with a remainder (211 rows), empty pair shards."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    try:
+        res = [q.get(timeout=600) for _ in range(world)]
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
     for p in procs:
-        p.join(60)
         assert p.exitcode == 0
     for rank, e_emb, e_prob, shape in res:
         assert shape == (211, 16)

@@ -183,3 +183,12 @@ def test_pipelines_test_and_train_forward():
     assert torch.allclose(xx.cpu(), p, rtol=1e-5, atol=1e-6) and torch.equal(yy.cpu(), y[idx].float())
     xt, yt, loss = pipelines.train_forward(model, data)
     assert xt.shape == (600,) and yt.shape == (600,) and bool(torch.isfinite(loss))
+    # the reference's train() (pipelines.py:10-18) records autograd through encode / decode and calls loss.backward(): the HIP
+    # forward has no backward, and says so at the first call instead of failing inside backward()
+    model.train()
+    with pytest.raises(RuntimeError, match="forward only"):
+        model.encode(data)
+    with pytest.raises(RuntimeError, match="forward only"):
+        model.decode(data, torch.zeros(n, 16, device="cuda"))
+    model.eval()
+    model.decode(data, model.encode(data), "val")               # eval mode needs no no_grad()

@@ -244,3 +244,43 @@ def test_async_batches_overlap_and_equal_the_stream_ordered_call():
     assert torch.equal(o7, want[2][0])
     g.pd_pi_batch(batches[3], 2, async_=True)
     g.close()
+
+
+def test_async_batches_of_alternating_hop_rebuild_the_ball_lists_behind_the_pending_chunk():
+    """A pipelined chunk's second half is deferred; the ball lists belong to ONE hop value and are rebuilt when the next batch
+    asks for another.  The rebuild must first submit the pending chunk's second half and wait for it: that half may relaunch
+    the extraction (arena overflow -> FILL from the lists the chunk was started with).  Arena regions shrunk so that every
+    chunk overflows; with and without the ball-list extraction (the breadth-first path rebuilds the ball-size bounds)."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    n, edges, kappa, _, _ = synth.shaped_graph("PubMed", scale=0.3)
+    rowptr, col, w = synth.edges_to_csr(n, edges, kappa)
+    rs = np.random.RandomState(21)
+    g = engine.DeviceGraph(rowptr, col, w)
+    batches = []
+    for k in range(6):
+        b = np.concatenate([edges[rs.permutation(len(edges))[:4500]], rs.randint(0, n, size=(600, 2))]).astype(np.int32)
+        batches.append((torch.as_tensor(b[rs.permutation(len(b))]).cuda(), 2 if k % 2 == 0 else 1))
+    want = []
+    for b, hop in batches:
+        o, s = g.pd_pi_batch(b, hop)
+        want.append((o.clone(), s.clone()))
+    torch.cuda.synchronize()
+    for opts in ({"x_region": 64, "x_bump_min": 4096}, {"extract": 0}, {}):
+        for k, v in opts.items():
+            g.set_option(k, v)
+        got = [g.pd_pi_batch(b, hop, async_=True) for b, hop in batches]
+        g.join()
+        torch.cuda.synchronize()
+        for k, ((o, s), (wo, wst)) in enumerate(zip(got, want)):
+            assert torch.equal(s, wst), (opts, k)
+            assert (o - wo).abs().max() <= 1e-12, (opts, k)
+        g.set_option("x_region", 4096); g.set_option("x_bump_min", 1 << 20); g.set_option("extract", 1)
+    # tlc_pd_pi_batch == async + join: a stream-ordered call also makes the stream wait for batches still in flight
+    o1, s1 = g.pd_pi_batch(batches[0][0], 2, async_=True)
+    o2, s2 = g.pd_pi_batch(batches[2][0], 2, async_=True)
+    o3, s3 = g.pd_pi_batch(batches[1][0], 1)
+    tot = (o1.sum() + o2.sum() + o3.sum()).item()                      # (.item(): a read on the current stream, no device-wide sync before it)
+    ref_tot = (want[0][0].sum() + want[2][0].sum() + want[1][0].sum()).item()
+    assert abs(tot - ref_tot) <= 1e-9 * abs(ref_tot)
+    g.close()

@@ -393,3 +393,160 @@ def test_a_few_optimizer_steps_reduce_the_diagram_loss():
         losses.append(float(loss0.detach()))
     assert all(np.isfinite(losses))
     assert min(losses[-5:]) < 0.7 * losses[0], losses
+
+
+# ---- the evaluation distance: pair_diagonal=True -> wasserstein_distance_inference (wasserstein.py:93-195) ------------------
+def _free_problems(rs, B, nmax, style):
+    """like _problems but with no relation between n and m (either diagram may be the longer one, either may be empty)"""
+    xs, ys = [], []
+    for b in range(B):
+        n = int(rs.randint(0, nmax + 1)); m = int(rs.randint(0, nmax + 1))
+        if style == "grid":
+            X = rs.randint(0, 6, size=(n, 2)) / 5.0; Y = rs.randint(0, 6, size=(m, 2)) / 5.0
+        else:
+            b0 = rs.rand(n); X = np.stack([b0, b0 + rs.uniform(-0.1, 0.6, size=n)], 1)
+            b1 = rs.rand(m); Y = np.stack([b1, b1 + rs.uniform(0.0, 0.7, size=m)], 1)
+        xs.append(X.astype(np.float64)); ys.append(Y.astype(np.float64))
+    return xs, ys
+
+
+@pytest.mark.parametrize("order", [2, 1])
+@pytest.mark.parametrize("style,nmax", [("random", 20), ("grid", 14), ("random", 70), ("random", 200), ("random", 330)])
+def test_inference_matching_cost_pieces_and_gradient(order, style, nmax):
+    """tlc_w2_inference_matching against scipy's assignment solver on the (n + m)-square expansion of the reference's
+    (n+1) x (m+1) transport (oracle/w2_ref.inference_matching): optimal cost, the four returned norms, both maps, the gradient.
+    330 points a side: n + m > 512 takes the workgroup-per-problem kernel."""
+    import torch
+    from tlc_gnn_amd import ops
+    from oracle import w2_ref
+    rs = np.random.RandomState(7 * nmax + order)
+    B = 50 if nmax <= 20 else (10 if nmax <= 70 else 4)
+    xs, ys = _free_problems(rs, B, nmax, style)
+    xoff = np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.int64)
+    yoff = np.concatenate([[0], np.cumsum([len(y) for y in ys])]).astype(np.int64)
+    X = torch.as_tensor(np.concatenate(xs)).cuda()
+    Y = torch.as_tensor(np.concatenate(ys)).cuda()
+    r = ops.w2_inference_matching(torch.as_tensor(xoff).cuda(), X, torch.as_tensor(yoff).cuda(), Y, order=order, want_grad=True)
+    assert (r["status"].cpu().numpy() == 0).all()
+    loss, wxy, wxd, wyd = (r[k].cpu().numpy() for k in ("loss", "wxy", "wxd", "wyd"))
+    ax_all, ay_all, grad = r["assign_x"].cpu().numpy(), r["assign_y"].cpu().numpy(), r["grad"].cpu().numpy()
+    for b in range(B):
+        Xb, Yb = xs[b], ys[b]
+        n, m = len(Xb), len(Yb)
+        ax, ay = ax_all[xoff[b]:xoff[b + 1]], ay_all[yoff[b]:yoff[b + 1]]
+        ref = w2_ref.inference_matching(Xb, Yb, order)
+        if n == 0 or m == 0:
+            # (:98-113) total persistence of the other diagram, the parts reported as 0, nothing matched
+            assert abs(loss[b] - ref[0]) <= 1e-12 * max(1.0, ref[0]) and wxy[b] == 0 and wxd[b] == 0 and wyd[b] == 0
+            assert (ax == -1).all() and (ay == -1).all()
+            continue
+        # the two maps are each other's inverse on the matched points
+        on = ax >= 0
+        assert (ay[ax[on]] == np.flatnonzero(on)).all() and (ay >= 0).sum() == on.sum()
+        # optimal: the transport cost of the device's matching equals scipy's optimum
+        C = w2_ref.inference_cost_matrix(Xb, Yb, order)
+        cost = float(C[np.flatnonzero(on), ax[on]].sum() + C[np.flatnonzero(~on), m].sum() + C[n, np.flatnonzero(ay < 0)].sum())
+        assert abs(cost - ref[6]) <= 1e-9 * max(1.0, abs(ref[6])), (b, n, m, cost, ref[6])
+        # the returned norms are those of the restated expression on the device's matching
+        l2, a2, d2, e2 = w2_ref.inference_loss_from_assignment(Xb, Yb, ax, ay, order)
+        for got, want in ((loss[b], l2), (wxy[b], a2), (wxd[b], d2), (wyd[b], e2)):
+            assert abs(got - want) <= 1e-12 * max(1.0, want)
+        if order == 2 and style != "grid":
+            assert abs(loss[b] - ref[0]) <= 1e-9 * max(1.0, ref[0])                 # sqrt(optimal cost): unique (no point below the diagonal counts negative at p = 2)
+        if style != "grid":
+            Xt = torch.tensor(Xb, requires_grad=True)
+            Yt = torch.tensor(Yb)
+            parts = []
+            if on.any():
+                parts.append((Yt[torch.as_tensor(ax[on]).long()] - Xt[torch.as_tensor(on)]).abs().amax(dim=1))
+            if (~on).any():
+                q = Xt[torch.as_tensor(~on)]
+                parts.append(((q[:, 1] - q[:, 0]) * 0.5).abs())
+            if (ay < 0).any():
+                q = Yt[torch.as_tensor(ay < 0)]
+                parts.append(((q[:, 1] - q[:, 0]) * 0.5).abs())
+            ((torch.cat(parts) ** order).sum() ** (1.0 / order)).backward()
+            assert np.abs(grad[xoff[b]:xoff[b + 1]] - Xt.grad.numpy()).max() <= 1e-12, b
+
+
+def test_matching_refuses_non_finite_points_and_too_many_points():
+    """A NaN / Inf coordinate (a diverging training step) used to leave no column as the minimum of a step: status 3, loss NaN, no
+    matching, zero gradient -- and the other problems of the batch are untouched.  n + m > 4 096 in the evaluation form: status 2."""
+    import torch
+    from tlc_gnn_amd import ops
+    rs = np.random.RandomState(5)
+    X = [rs.rand(6, 2), rs.rand(5, 2), rs.rand(700, 2), rs.rand(4, 2), rs.rand(3000, 2)]
+    Y = [rs.rand(4, 2), rs.rand(5, 2), rs.rand(600, 2), rs.rand(2, 2), rs.rand(1200, 2)]
+    X[0][2, 1] = np.nan; Y[1][0, 0] = np.inf; X[2][650, 0] = -np.inf
+    xoff = torch.as_tensor(np.concatenate([[0], np.cumsum([len(x) for x in X])]).astype(np.int64)).cuda()
+    yoff = torch.as_tensor(np.concatenate([[0], np.cumsum([len(y) for y in Y])]).astype(np.int64)).cuda()
+    Xc, Yc = torch.as_tensor(np.concatenate(X)).cuda(), torch.as_tensor(np.concatenate(Y)).cuda()
+    r = ops.w2_partial_matching(xoff, Xc, yoff, Yc, order=2)
+    torch.cuda.synchronize()
+    assert r["status"].cpu().tolist() == [3, 3, 3, 0, 0]
+    loss = r["loss"].cpu().numpy()
+    assert np.isnan(loss[:3]).all() and np.isfinite(loss[3:]).all() and loss[3] > 0
+    assert (r["assign"].cpu().numpy()[:6 + 5 + 700] == -1).all() and float(r["grad"][:6 + 5 + 700].abs().max()) == 0.0
+    r = ops.w2_inference_matching(xoff, Xc, yoff, Yc, order=1, want_grad=True)
+    torch.cuda.synchronize()
+    assert r["status"].cpu().tolist() == [3, 3, 3, 0, 2]
+    assert np.isnan(r["loss"].cpu().numpy()[:3]).all() and float(r["loss"][4]) == 0.0
+    with pytest.raises(ValueError):                                    # offsets beyond the arrays never reach the device
+        ops.w2_partial_matching(xoff, Xc[:100], yoff, Yc, order=2)
+
+
+def test_teacher_evaluation_with_pair_diagonal_and_target_offsets():
+    """The reference scores a trained model with pair_diagonal=True (train_Teacher_Model.py:99 -> Teacher_model.py:66 ->
+    wasserstein_distance_inference): loss_0 and the three logged parts against the restatement on the predicted diagram.
+    Also: a block-diagonal batch whose targets are NOT one point per edge needs pd_ptr (shorter targets used to be read out of
+    bounds), and the per-graph sums equal the graph-by-graph calls."""
+    import torch
+    from oracle import w2_ref
+    from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
+    torch.manual_seed(5)
+    rs = np.random.RandomState(5)
+    model = Teacher_Model(type='GAT', dropout=0.2).cuda().eval()
+    graphs, fs, pds = [], [], []
+    for b in range(5):
+        n = int(rs.randint(4, 30))
+        ei = _random_graph(rs, n, int(rs.randint(n, 3 * n)), torch)
+        m = ei.shape[1] - n
+        graphs.append((n, ei[:, :m])); fs.append(torch.rand(n, 1))
+        k = int(rs.randint(0, m + 6))                                   # more or fewer target points than edges, or none
+        bb = rs.rand(k)
+        pds.append(torch.tensor(np.stack([bb, bb + rs.uniform(0, 0.6, size=k)], 1).reshape(k, 2), dtype=torch.float32))
+    per_graph = []
+    with torch.no_grad():
+        for (n, e), f, PD in zip(graphs, fs, pds):
+            lp = torch.arange(n, dtype=torch.int64)
+            ei = torch.cat([e, torch.stack([lp, lp])], dim=1).cuda()
+            for p in (1, 2):
+                x0, img, l0, lxy, lxd, lyd, _, _ = model(f.cuda(), ei, PD.cuda(), kernel='wasserstein', p=p, pair_diagonal=True, grad_PI=False)
+                want = w2_ref.inference_matching(x0.double().cpu().numpy(), PD.double().numpy(), p)
+                assert abs(float(l0) - want[0]) <= 1e-5 * max(1.0, want[0]), (p, float(l0), want[0])
+                if p == 2:
+                    per_graph.append([float(l0), float(lxy), float(lxd), float(lyd)])
+                    tot = float(lxy) ** 2 + float(lxd) ** 2 + float(lyd) ** 2
+                    assert abs(tot - float(l0) ** 2) <= 1e-5 * max(1.0, tot)
+        gptr = np.concatenate([[0], np.cumsum([g[0] for g in graphs])])
+        eptr = np.concatenate([[0], np.cumsum([g[1].shape[1] for g in graphs])])
+        pptr = np.concatenate([[0], np.cumsum([len(q) for q in pds])])
+        N = int(gptr[-1])
+        ei_all = torch.cat([g[1] + int(gptr[b]) for b, g in enumerate(graphs)], dim=1)
+        loops = torch.arange(N, dtype=torch.int64)
+        ei_full = torch.cat([ei_all, torch.stack([loops, loops])], dim=1).cuda()
+        kw = dict(kernel='wasserstein', p=2, pair_diagonal=True, grad_PI=False, graph_ptr=torch.tensor(gptr).cuda(), edge_ptr=torch.tensor(eptr).cuda())
+        if int(pptr[-1]) != int(eptr[-1]):
+            with pytest.raises(ValueError):
+                model(torch.cat(fs).cuda(), ei_full, torch.cat(pds).cuda(), **kw)
+        out = model(torch.cat(fs).cuda(), ei_full, torch.cat(pds).cuda(), pd_ptr=torch.tensor(pptr).cuda(), **kw)
+        want = np.array(per_graph).sum(axis=0)
+        for got, w in zip(out[2:6], want):
+            assert abs(float(got) - w) <= 1e-4 * max(1.0, w)
+    # the training form cannot take fewer predicted than target points: a clear error, not a device fault
+    short = [i for i, (g, q) in enumerate(zip(graphs, pds)) if len(q) > g[1].shape[1]]
+    if short:
+        n, e = graphs[short[0]]
+        lp = torch.arange(n, dtype=torch.int64)
+        with pytest.raises(ValueError):
+            model(fs[short[0]].cuda(), torch.cat([e, torch.stack([lp, lp])], dim=1).cuda(), pds[short[0]].cuda(), kernel='wasserstein', p=2, grad_PI=False)

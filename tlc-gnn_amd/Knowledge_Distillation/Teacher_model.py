@@ -12,6 +12,10 @@ Training: with `compute_loss=True, kernel='wasserstein'`
 `tlc_edge_head_bwd` and `tlc_gat_layer_bwd` (autograd.py).  What is NOT here: dropout (train mode needs dropout=0: a dropout
 mask cannot be checked against the reference's RNG stream), the 'sliced' kernel, grad_PI=True (the differentiable imager of
 :76-77; the training script passes grad_PI=False, train_Teacher_Model.py:51) and draw_fig.
+
+Evaluation (train_Teacher_Model.py:85-113: `model(filt, edge_index, PD, p=p, kernel=kernel, pair_diagonal=True, grad_PI=False)`):
+pair_diagonal=True -> compute_PD_loss(type='inference') :66,134-136 -> `wasserstein_distance_inference` (wasserstein.py:93-195)
+-> `tlc_w2_inference_matching`; loss_yd0 is then the targets left to the diagonal.
 """
 import time
 
@@ -66,21 +70,22 @@ class Teacher_Model(torch.nn.Module):
         self.dropout = dropout
 
     def forward(self, x0, edge_index0, PD, kernel='sliced', M=50, p=1, pair_diagonal=False, draw_fig=False, fig_name='',
-                compute_loss=True, grad_PI=True, graph_ptr=None, edge_ptr=None):
+                compute_loss=True, grad_PI=True, graph_ptr=None, edge_ptr=None, pd_ptr=None):
         """Reference signature.  grad_PI must be False; compute_loss=True needs kernel='wasserstein' (p = 1 or 2) and returns
-        loss0 (differentiable), loss_xy0, loss_xd0, loss_yd0 like :63-64 (loss_yd0 is 0: with num_models=1 every target
-        point is matched, wasserstein.py:330-372).
+        loss0 (differentiable), loss_xy0, loss_xd0, loss_yd0 like :63-66.  pair_diagonal=False (training, :64): every target
+        point is matched, loss_yd0 is 0 (wasserstein.py:330-372, num_models=1); pair_diagonal=True (evaluation, :66): the
+        distance in which both diagrams may use the diagonal, loss_yd0 = the targets left to it.
 
         x0 [n,1] filtration, edge_index0 [2, m+n] with the n self loops LAST (train_Teacher_Model.py:43-44).
         Block-diagonal batches: pass graph_ptr (int64 [B+1] node offsets) and edge_ptr (int64 [B+1] offsets into the
-        non-self-loop edges) to get one image per graph [B,25]; otherwise one image [25] for the whole input.
+        non-self-loop edges) to get one image per graph [B,25]; otherwise one image [25] for the whole input.  With a loss,
+        pd_ptr (int64 [B+1]) gives the rows of PD that belong to each graph; without it every graph must have exactly as
+        many target points as edges (PD = Ord0 + Ext1 of the same graph: n - 1 + m - n + 1 = m points, data_utils_GC.py:166).
         """
         if grad_PI or draw_fig:
             raise NotImplementedError("Teacher_Model (HIP): grad_PI=False, draw_fig=False only")
         if compute_loss and kernel != 'wasserstein':
             raise NotImplementedError("Teacher_Model (HIP): compute_loss needs kernel='wasserstein'")
-        if compute_loss and pair_diagonal:
-            raise NotImplementedError("Teacher_Model (HIP): pair_diagonal (wasserstein_distance_inference) is not implemented")
         if self.training and self.dropout > 0:
             raise NotImplementedError("Teacher_Model (HIP): train mode needs dropout=0")
         t1 = time.time()
@@ -96,11 +101,17 @@ class Teacher_Model(torch.nn.Module):
                               self.lin6.weight.detach(), self.lin6.bias.detach())                  # :56-59 (no dropout)
         t2 = time.time()
         loss0 = loss_xy0 = loss_xd0 = loss_yd0 = None
-        if compute_loss:                                                                           # :61-64, compute_PD_loss :124-133
+        if compute_loss:                                                                           # :61-66, compute_PD_loss :124-136
             xoff = None if edge_ptr is None else edge_ptr.to(torch.int64)
-            loss, wxy, wxd = autograd.diagram_loss(x, PD.to(torch.float64), order=p, xoff=xoff, yoff=xoff)   # one point per edge
-            loss0, loss_xy0, loss_xd0 = loss.sum().reshape(1), wxy.sum().reshape(1), wxd.sum().reshape(1)
-            loss_yd0 = torch.zeros(1, dtype=loss0.dtype, device=loss0.device)
+            yoff = xoff if pd_ptr is None else pd_ptr.to(torch.int64)
+            if pd_ptr is None and edge_ptr is not None and int(PD.shape[0]) != m:
+                # (one target point per edge is what makes edge_ptr double as the target offsets)
+                raise ValueError("Teacher_Model: PD has %d points for %d edges; pass pd_ptr (target offsets per graph)" % (int(PD.shape[0]), m))
+            if pd_ptr is not None and (edge_ptr is None or pd_ptr.numel() != edge_ptr.numel()):
+                raise ValueError("Teacher_Model: pd_ptr needs edge_ptr with the same number of graphs")
+            parts = autograd.diagram_loss(x, PD.to(torch.float64), order=p, xoff=xoff, yoff=yoff, infer=bool(pair_diagonal))
+            loss0, loss_xy0, loss_xd0 = parts[0].sum().reshape(1), parts[1].sum().reshape(1), parts[2].sum().reshape(1)
+            loss_yd0 = parts[3].sum().reshape(1) if pair_diagonal else torch.zeros(1, dtype=loss0.dtype, device=loss0.device)
         x0_out = x
         pts = x.detach().to(torch.float64)
         if edge_ptr is None:

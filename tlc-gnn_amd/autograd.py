@@ -45,29 +45,40 @@ class EdgeHead(torch.autograd.Function):
         return gx, gw5, gb5, gw6, gb6, None, None, None
 
 
+_W2_STATUS = "1 = fewer predicted than target points, 2 = too many points for one problem (4096), 3 = NaN / Inf coordinates"
+
+
 class DiagramLoss(torch.autograd.Function):
     """`wasserstein_distance(PD_hat, PD, order=p, enable_autodiff=True, num_models=1)` (wasserstein.py:198-379) of one or more
     (predicted, target) pairs: -> (loss [B], wxy [B], wxd [B]); only `loss` carries a gradient, like the reference's
-    (wxy / wxd are the logged parts)."""
+    (wxy / wxd are the logged parts).
+
+    infer=True: `wasserstein_distance_inference` (wasserstein.py:93-195, both diagrams may use the diagonal)
+    -> (loss, wxy, wxd, wyd)."""
 
     @staticmethod
-    def forward(ctx, pd_hat, xoff, target, yoff, order):
-        r = ops.w2_partial_matching(xoff, pd_hat.detach(), yoff, target, order=order, want_grad=True)
+    def forward(ctx, pd_hat, xoff, target, yoff, order, infer):
+        if infer:
+            r = ops.w2_inference_matching(xoff, pd_hat.detach(), yoff, target, order=order, want_grad=True)
+        else:
+            r = ops.w2_partial_matching(xoff, pd_hat.detach(), yoff, target, order=order, want_grad=True)
         bad = r["status"] != 0
         if bool(bad.any()):
-            raise ValueError("diagram loss: status %s (1 = fewer predicted than target points, 2 = more than 4096 predicted points)"
-                             % r["status"].tolist())
+            raise ValueError("diagram loss: status %s (%s)" % (r["status"].tolist(), _W2_STATUS))
         ctx.save_for_backward(r["grad"], xoff)
-        ctx.dtype = pd_hat.dtype
-        ctx.mark_non_differentiable(r["wxy"], r["wxd"])
-        return r["loss"].to(pd_hat.dtype), r["wxy"].to(pd_hat.dtype), r["wxd"].to(pd_hat.dtype)
+        dt = pd_hat.dtype
+        ctx.dtype = dt
+        # (the tensors RETURNED are marked: a cast makes new ones, and a mark on the float64 originals would be lost)
+        parts = [r[k].to(dt) for k in (("wxy", "wxd", "wyd") if infer else ("wxy", "wxd"))]
+        ctx.mark_non_differentiable(*parts)
+        return (r["loss"].to(dt),) + tuple(parts)
 
     @staticmethod
-    def backward(ctx, gloss, _gwxy, _gwxd):
+    def backward(ctx, gloss, *_unused):
         grad, xoff = ctx.saved_tensors
         cnt = xoff[1:] - xoff[:-1]
         per_point = torch.repeat_interleave(gloss.to(torch.float64), cnt)          # d total / d loss[b] for each predicted point
-        return (grad * per_point.unsqueeze(1)).to(ctx.dtype), None, None, None, None
+        return (grad * per_point.unsqueeze(1)).to(ctx.dtype), None, None, None, None, None
 
 
 def gat_layer(x, wl, att, wij, bias, rowptr, src, prelu_slope=-1.0):
@@ -78,10 +89,11 @@ def edge_head(x, w5, b5, w6, b6, src, dst, prelu_slope):
     return EdgeHead.apply(x, w5, b5, w6, b6, src, dst, float(prelu_slope))
 
 
-def diagram_loss(pd_hat, target, order=2, xoff=None, yoff=None):
+def diagram_loss(pd_hat, target, order=2, xoff=None, yoff=None, infer=False):
+    """-> (loss, wxy, wxd) per problem; infer=True: (loss, wxy, wxd, wyd) of the evaluation distance."""
     dev = pd_hat.device
     if xoff is None:
         xoff = torch.tensor([0, pd_hat.shape[0]], dtype=torch.int64, device=dev)
     if yoff is None:
         yoff = torch.tensor([0, target.shape[0]], dtype=torch.int64, device=dev)
-    return DiagramLoss.apply(pd_hat, xoff, target, yoff, int(order))
+    return DiagramLoss.apply(pd_hat, xoff, target, yoff, int(order), bool(infer))

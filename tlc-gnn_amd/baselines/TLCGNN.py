@@ -116,8 +116,18 @@ class Net(torch.nn.Module):
             self._pairs_src, self._pairs_stamp = te, self._stamp(te, device)
         return self._pi_dev, self._pairs_dev
 
+    def _forward_only(self, what):
+        """The HIP forward runs on detached weights: a training step (`pipelines.py:10-18`: model.train(); encode / decode with
+        autograd recording; loss.backward()) would fail late, inside backward, with torch's generic "does not require grad".
+        Refuse at the first call instead.  train mode under torch.no_grad() (pipelines.train_forward) is fine."""
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("TLCGNN.Net (HIP) is forward only: Net.%s in train mode with autograd enabled would build no graph and "
+                               "loss.backward() would fail -- wrap the forward in torch.no_grad() (pipelines.train_forward) or call "
+                               "model.eval(); the optimiser loop of pipelines.py:10-18 is out of scope (SURVEY.md 8f)" % what)
+
     def encode(self, data):
         # can set p = 0.8 for Cora and Citeseer, the results can be higher   (reference comment, TLCGNN.py:20)
+        self._forward_only("encode")
         x, edge_index = data.x, data.edge_index
         xs = None if self.training else self._sparse_features(x)      # (training: dropout makes a new x every step)
         if not self.training and xs is None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
@@ -135,6 +145,7 @@ class Net(torch.nn.Module):
         return x
 
     def decode(self, data, emb, type="train"):
+        self._forward_only("decode")
         device = emb.device
         pi_all, pairs_all = self._tables(data, device)
         tp, tn, vp, vn = data.train_pos, data.train_neg, data.val_pos, data.val_neg

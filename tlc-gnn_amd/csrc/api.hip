@@ -199,8 +199,12 @@ struct tlc_graph {
     int opt_x_region, opt_x_bump_min;   // arena entries per workgroup region / minimum bump area of the extraction (tests shrink them)
 };
 
-// host-side wait for every chunk in flight on this handle (before shared, read-only-while-running structures change)
+static int finish_pending(tlc_graph* g);
+// host-side wait for every chunk in flight on this handle (before shared, read-only-while-running structures change).
+// A deferred chunk's second half goes in first: its ev_done is only recorded there, and its saved ChunkCtx holds pointers
+// into the structures the caller is about to rebuild (ball lists of another hop, the ball-size bounds).
 static int quiesce(tlc_graph* g) {
+    { const int rp = finish_pending(g); if (rp != TLC_OK) return rp; }
     for (int k = 0; k < TLC_N_WS; ++k)
         if (g->ws[k].busy) { TLC_HIP_CHECK(hipEventSynchronize(g->ws[k].ev_done)); g->ws[k].busy = 0; }
     return TLC_OK;
@@ -1263,9 +1267,11 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
         if (!defer && (rc = finish_pending(g)) != TLC_OK) return rc;
     }
     if (join && (rc = finish_pending(g)) != TLC_OK) return rc;
-    if (join && !inline_main)
+    // tlc_pd_pi_batch == async + join: the caller's stream also waits for asynchronous batches still in flight on the other
+    // workspaces (a single stream-ordered chunk runs on `s` itself; a wait on a complete event is no command at all)
+    if (join)
         for (int k = 0; k < TLC_N_WS; ++k)
-            if (g->ws[k].busy) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ws[k].ev_done, 0));
+            if (g->ws[k].busy && !(inline_main && &g->ws[k] == g->last_ws)) TLC_HIP_CHECK(hipStreamWaitEvent(s, g->ws[k].ev_done, 0));
     return TLC_OK;
 }
 

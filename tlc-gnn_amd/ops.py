@@ -285,8 +285,16 @@ def w2_partial_matching(xoff, X, yoff, Y, order=2, want_grad=True, max_points=No
     X = X.to(torch.float64).contiguous()
     Y = Y.to(torch.float64).contiguous()
     nx = int(X.shape[0])
-    if max_points is None:
-        max_points = int((xoff[1:] - xoff[:-1]).max().item()) if B > 0 else 0
+    if B > 0:
+        # (offsets beyond the arrays would be read out of bounds on the device; one host read, with max_points below)
+        ends = torch.stack([xoff[-1], yoff[-1], (xoff[1:] - xoff[:-1]).max()]).tolist()
+        if ends[0] > nx or ends[1] > int(Y.shape[0]):
+            raise ValueError("w2_partial_matching: offsets end at (%d, %d) but X / Y hold (%d, %d) points"
+                             % (ends[0], ends[1], nx, int(Y.shape[0])))
+        if max_points is None:
+            max_points = int(ends[2])
+    elif max_points is None:
+        max_points = 0
     loss = torch.zeros(max(B, 1), dtype=torch.float64, device=dev)
     wxy = torch.zeros_like(loss)
     wxd = torch.zeros_like(loss)
@@ -299,6 +307,40 @@ def w2_partial_matching(xoff, X, yoff, Y, order=2, want_grad=True, max_points=No
                                             _lib.ptr(assign), _lib.ptr(grad), _lib.ptr(status), _lib.stream_ptr())
     _lib.check(rc, "tlc_w2_partial_matching")
     return dict(loss=loss[:B], wxy=wxy[:B], wxd=wxd[:B], assign=assign[:nx], grad=None if grad is None else grad[:nx], status=status[:B])
+
+
+@_lib.on_device_of
+def w2_inference_matching(xoff, X, yoff, Y, order=2, want_grad=False, max_points=None):
+    """The evaluation distance of PDGNN (`wasserstein_distance_inference`, Knowledge_Distillation/wasserstein.py:93-195: both
+    diagrams may use the diagonal) for a batch of (predicted, target) pairs.
+    -> dict(loss[B], wxy[B], wxd[B], wyd[B], assign_x[sum n], assign_y[sum m], grad or None, status[B])."""
+    torch = _lib.require_gpu()
+    B = xoff.numel() - 1
+    dev = X.device
+    X = X.to(torch.float64).contiguous()
+    Y = Y.to(torch.float64).contiguous()
+    xoff = xoff.to(torch.int64).contiguous()
+    yoff = yoff.to(torch.int64).contiguous()
+    nx, ny = int(X.shape[0]), int(Y.shape[0])
+    if B > 0:
+        ends = torch.stack([xoff[-1], yoff[-1]]).tolist()
+        if ends[0] > nx or ends[1] > ny:
+            raise ValueError("w2_inference_matching: offsets end at (%d, %d) but X / Y hold (%d, %d) points" % (ends[0], ends[1], nx, ny))
+    if max_points is None:
+        max_points = int(((xoff[1:] - xoff[:-1]) + (yoff[1:] - yoff[:-1])).max().item()) if B > 0 else 0
+    loss = torch.zeros(max(B, 1), dtype=torch.float64, device=dev)
+    wxy, wxd, wyd = torch.zeros_like(loss), torch.zeros_like(loss), torch.zeros_like(loss)
+    ax = torch.full((max(nx, 1),), -1, dtype=torch.int32, device=dev)
+    ay = torch.full((max(ny, 1),), -1, dtype=torch.int32, device=dev)
+    grad = torch.zeros((max(nx, 1), 2), dtype=torch.float64, device=dev) if want_grad else None
+    status = torch.zeros(max(B, 1), dtype=torch.uint8, device=dev)
+    rc = _lib.lib().tlc_w2_inference_matching(C.c_int32(B), _lib.ptr(xoff), _lib.ptr(X) if nx else None, _lib.ptr(yoff),
+                                              _lib.ptr(Y) if ny else None, C.c_int(order), C.c_int32(max_points), _lib.ptr(loss),
+                                              _lib.ptr(wxy), _lib.ptr(wxd), _lib.ptr(wyd), _lib.ptr(ax), _lib.ptr(ay), _lib.ptr(grad),
+                                              _lib.ptr(status), _lib.stream_ptr())
+    _lib.check(rc, "tlc_w2_inference_matching")
+    return dict(loss=loss[:B], wxy=wxy[:B], wxd=wxd[:B], wyd=wyd[:B], assign_x=ax[:nx], assign_y=ay[:ny],
+                grad=None if grad is None else grad[:nx], status=status[:B])
 
 
 def capture(fn, warmup=2):
