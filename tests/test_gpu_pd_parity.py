@@ -166,19 +166,23 @@ def test_pubmed_sample_vs_reference(torch_cuda):
 
 
 def test_full_pubmed_batch_vs_oracle(torch_cuda):
-    """BASELINE configs[1] at full size: all train-positive pairs of the PubMed-shaped graph, hop 2."""
+    """BASELINE configs[1] at full size: bench.py's own PI-A batch (bench.build_workload(0): the training graph of the PubMed-shaped
+    synthetic, all 37 676 train-positive pairs, hop 2) -- the stream-ordered call against the oracle, and then the PIPELINED mode
+    the bench's timed region uses: seven batches through tlc_pd_pi_batch_async (three workspaces in turn, second halves deferred,
+    early pass + LARGE tier + divide and conquer active) + one join, every output buffer bit-equal to the stream-ordered rows."""
     torch = torch_cuda
-    from tlc_gnn_amd import engine, synth
+    import bench
+    from tlc_gnn_amd import engine
     from oracle import oracle
-    n, e, k, hop, _ = synth.shaped_graph("PubMed")
-    rowptr, col, w = synth.edges_to_csr(n, e, k)
+    wl = bench.build_workload(0)
+    rowptr, col, w, pairs = wl["rowptr"], wl["col"], wl["w"], wl["pi_pairs"]
+    assert pairs.shape == (37676, 2) and wl["hop"] == 2
     g = engine.DeviceGraph(rowptr, col, w)
-    rs = np.random.RandomState(7)
-    pairs = e[rs.permutation(len(e))[:37676]].astype(np.int32)
-    out, st = g.pd_pi_batch(_dev(torch, pairs, torch.int32), 2)
-    out2, st2 = g.pd_pi_batch(_dev(torch, pairs, torch.int32), 2)
-    assert torch.equal(out, out2) and torch.equal(st, st2)                  # deterministic, bit for bit
-    out, st = out.cpu().numpy(), st.cpu().numpy()
+    d_pairs = _dev(torch, pairs, torch.int32)
+    out_t, st_t = g.pd_pi_batch(d_pairs, 2)
+    out2, st2 = g.pd_pi_batch(d_pairs, 2)
+    assert torch.equal(out_t, out2) and torch.equal(st_t, st2)              # deterministic, bit for bit
+    out, st = out_t.cpu().numpy(), st_t.cpu().numpy()
     ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, 2, n_threads=0)
     assert np.array_equal(st, rst)
     assert np.array_equal(out == 0, ref == 0)
@@ -186,6 +190,21 @@ def test_full_pubmed_batch_vs_oracle(torch_cuda):
     assert rel_err(out[nz], ref[nz]).max() < 1e-8
     stats = g.stats()
     assert stats["tier_small"] + stats["tier_mid"] + stats["tier_medium"] + stats["tier_large"] + stats["tier_huge"] == len(pairs)
+    assert stats["tier_large"] > 0 and g.dc_stats()[0] > 0                  # the LARGE tier and its divide and conquer are in play
+    # pipelined: seven batches in a row, a buffer of its own each (a batch in flight owns its buffers until the join)
+    bufs = [(torch.empty_like(out_t), torch.empty_like(st_t)) for _ in range(7)]
+    for o, s in bufs:
+        o.fill_(-1.0); s.fill_(77)
+    torch.cuda.synchronize()
+    for o, s in bufs:
+        g.pd_pi_batch(d_pairs, 2, out=o, status=s, async_=True)
+    g.join()
+    torch.cuda.synchronize()
+    for k, (o, s) in enumerate(bufs):
+        assert torch.equal(s, st_t), k
+        assert torch.equal(o, out_t), k                                     # bit for bit == the stream-ordered call (<= 1e-8 of the oracle above)
+    got = bufs[-1][0].cpu().numpy()
+    assert rel_err(got[nz], ref[nz]).max() < 1e-8
     g.close()
 
 

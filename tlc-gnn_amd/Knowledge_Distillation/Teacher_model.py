@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from torch.nn import Linear
 
 from .. import ops, engine, autograd
-from .gat_conv import GATConv
+from .gat_conv import GATConv, GraphBatch
 
 
 class Base_Model(torch.nn.Module):
@@ -41,12 +41,17 @@ class Base_Model(torch.nn.Module):
         self.type = type
         self.out_dim = out_dim
 
-    def forward(self, x, edge_index):
+    def forward(self, x, edge_index, csr=None):
+        """csr: a `GraphBatch` of this edge_index held by the caller (a loop that runs the model on the same batch again, e.g.
+        evaluate_time of train_Teacher_Model.py:124-151, builds it once); default: built here, once for the four layers."""
         if x.size()[0] == 0:
             return torch.zeros([0, 2], device=x.device)
         if self.training and self.dropout > 0:
             raise NotImplementedError("Base_Model (HIP): train mode needs dropout=0 (F.dropout of :217-225 is not implemented)")
-        csr = GATConv.csr_by_target(edge_index, x.shape[0])            # one CSR for the four layers of THIS call
+        if csr is None:
+            csr = GATConv.csr_by_target(edge_index, x.shape[0])        # one CSR for the four layers of THIS call
+        elif isinstance(csr, GraphBatch):
+            csr = csr.check(edge_index, x.shape[0])
         x = self.conv1(x, edge_index, prelu_slope=0.1, csr=csr)       # conv -> F.prelu(0.1) fused (:218-219)
         x = self.conv2(x, edge_index, prelu_slope=0.1, csr=csr)
         x = self.conv4(x, edge_index, prelu_slope=0.1, csr=csr)
@@ -70,7 +75,7 @@ class Teacher_Model(torch.nn.Module):
         self.dropout = dropout
 
     def forward(self, x0, edge_index0, PD, kernel='sliced', M=50, p=1, pair_diagonal=False, draw_fig=False, fig_name='',
-                compute_loss=True, grad_PI=True, graph_ptr=None, edge_ptr=None, pd_ptr=None):
+                compute_loss=True, grad_PI=True, graph_ptr=None, edge_ptr=None, pd_ptr=None, csr=None):
         """Reference signature.  grad_PI must be False; compute_loss=True needs kernel='wasserstein' (p = 1 or 2) and returns
         loss0 (differentiable), loss_xy0, loss_xd0, loss_yd0 like :63-66.  pair_diagonal=False (training, :64): every target
         point is matched, loss_yd0 is 0 (wasserstein.py:330-372, num_models=1); pair_diagonal=True (evaluation, :66): the
@@ -81,6 +86,7 @@ class Teacher_Model(torch.nn.Module):
         non-self-loop edges) to get one image per graph [B,25]; otherwise one image [25] for the whole input.  With a loss,
         pd_ptr (int64 [B+1]) gives the rows of PD that belong to each graph; without it every graph must have exactly as
         many target points as edges (PD = Ord0 + Ext1 of the same graph: n - 1 + m - n + 1 = m points, data_utils_GC.py:166).
+        csr: a `GraphBatch(edge_index0, n)` the caller built once for this batch (else the CSR by target is built per call).
         """
         if grad_PI or draw_fig:
             raise NotImplementedError("Teacher_Model (HIP): grad_PI=False, draw_fig=False only")
@@ -89,7 +95,7 @@ class Teacher_Model(torch.nn.Module):
         if self.training and self.dropout > 0:
             raise NotImplementedError("Teacher_Model (HIP): train mode needs dropout=0")
         t1 = time.time()
-        x = self.DIM0_Model(x0, edge_index0)
+        x = self.DIM0_Model(x0, edge_index0, csr=csr)
         n = x0.shape[0]
         m = edge_index0.shape[1] - n
         src = edge_index0[0, :m].to(torch.int32).contiguous()         # strips the appended self loops (:54-55)

@@ -20,6 +20,26 @@ def glorot(tensor):
         tensor.data.uniform_(-stdv, stdv)
 
 
+class GraphBatch:
+    """The graph structure of one (block-diagonal) batch, built ONCE and held by the caller: remove_self_loops + add_self_loops
+    (:146-152) grouped by target (`GATConv.csr_by_target`).  The reference rebuilds nothing here because its layers gather through
+    edge_index directly; the HIP layers read a CSR by target, and building it (a sort of 2 M edges for ogbg-molhiv's 41 127 graphs:
+    0.45 ms) on every forward of an evaluate-time loop (train_Teacher_Model.py:124-151) costs a quarter of the forward.
+
+    Reuse rule (the one data_utils_NC._vicinities uses): the object holds the edge_index tensor it was built from, so that
+    tensor's storage cannot pass to another tensor, and compares its `_version` (in-place edits) -- `check()` raises on a
+    different or edited tensor instead of silently using a stale structure."""
+
+    def __init__(self, edge_index, n):
+        self.edge_index, self.n, self.version = edge_index, int(n), edge_index._version
+        self.rowptr, self.col = GATConv.csr_by_target(edge_index, n)
+
+    def check(self, edge_index, n):
+        if edge_index is not self.edge_index or edge_index._version != self.version or int(n) != self.n:
+            raise ValueError("GraphBatch: built for another (or since edited) edge_index / node count; build a new one")
+        return self.rowptr, self.col
+
+
 class GATConv(torch.nn.Module):
     def __init__(self, in_channels, out_channels, double_input=False, new_node_feat=True, use_edge_attn=True, heads=1,
                  concat=True, negative_slope=0.2, dropout=0., add_self_loops=True, bias=True, **kwargs):
@@ -64,6 +84,8 @@ class GATConv(torch.nn.Module):
         assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
         if self.training and self.dropout > 0:
             raise NotImplementedError("GATConv (HIP): attention dropout in training mode is not implemented")
+        if isinstance(csr, GraphBatch):
+            csr = csr.check(edge_index, x.shape[0])
         rowptr, col = csr if csr is not None else self.csr_by_target(edge_index, x.shape[0])
         if torch.is_grad_enabled() and (x.requires_grad or self.lin_l.weight.requires_grad or self.att_l.requires_grad
                                         or self.lin_ij.weight.requires_grad or self.bias.requires_grad):
