@@ -174,6 +174,11 @@ int tlc_pd_pi_algorithmic_bytes(int32_t n_nodes, const int32_t* h_rowptr, const 
  * an unknown name is TLC_ERR_INVALID_ARG. */
 int tlc_debug_set_option(tlc_graph* g, const char* name, int value);
 int tlc_debug_dc_stats(tlc_graph* g, long long* h_out, void* stream);
+/* The lane-per-pair extraction (csrc/extract_lane.hip; replaces sg2dgm_accelerate's BFS + intersection + subgraph,
+ * sg2dgm/riccidist2dgm.py:310-316, for pairs whose smaller hop-ball has at most "xl_cut" nodes, default 24, 0 = off) in the last
+ * chunk: h_out[0] = candidates, h_out[1] = pairs it finished as records for the lane-per-subgraph kernel.  Options "xl_cut",
+ * "xl_ncut", "xl_mcut" (tests: what it keeps, <= 16 nodes / 24 edges) through tlc_debug_set_option. */
+int tlc_debug_xl_stats(tlc_graph* g, long long* h_out, void* stream);
 int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out, int64_t cap_u64, int32_t* n_rows);
 /* (builds with PAIR_TIMES=1 only: wall-clock stamps of the extraction, h_out[n_pairs][16] ticks of 10 ns; zeros otherwise) */
 int tlc_debug_pair_times(tlc_graph* g, unsigned long long* h_out, int64_t n_pairs);

@@ -228,3 +228,110 @@ def test_seeded_random_sweep_vs_oracle(seed):
             scale = np.abs(ref).max(axis=1, keepdims=True) + 1e-300
             assert (np.abs(got - ref) / scale).max() < 1e-8, (kind, hop, flags)
     g.close()
+
+
+# ---- the lane-per-pair extraction (csrc/extract_lane.hip): pairs whose smaller ball has <= xl_cut nodes never enter the wavefront
+# extraction; their records feed the lane-per-subgraph kernel directly -------------------------------------------------------------
+def _lane_batch(rs):
+    """hub components around the limits (16 / 17 nodes, 24 / 25 edges, smaller balls at 24 / 25 / 32 / 33 nodes), a chain of leaves
+    behind some hubs (so that the larger ball of a pair is much larger than the smaller), isolated nodes, far pairs, self pairs."""
+    shapes = [(16, 24), (17, 24), (16, 25), (17, 25), (16, 15), (15, 24), (12, 16), (3, 3), (3, 2), (2, 1), (4, 6), (9, 20), (16, 23),
+              (10, 9), (24, 23), (25, 24), (24, 40), (32, 31), (33, 32), (33, 60), (40, 39), (70, 80)]
+    edges, pairs, base = [], [], 0
+    for rep in range(5):
+        for (n, m) in shapes:
+            edges.append(hub_component(n, m, rs, base))
+            pairs += [[base, base + 1 + rs.randint(n - 1)], [base + 1 + rs.randint(n - 1), base]]
+            if n >= 4:
+                a, b = 1 + rs.randint(n - 1), 1 + rs.randint(n - 1)
+                pairs.append([base + a, base + b])                          # leaf - leaf (adjacent or at distance 2), or a self pair
+            base += n
+    n_iso = 3
+    iso = [base + k for k in range(n_iso)]
+    base += n_iso
+    e = np.concatenate(edges)
+    pairs += [[iso[0], 1], [2, iso[1]], [iso[2], iso[2]], [0, shapes[0][0]], [5, base - 10]]        # KeyError rows, far pairs
+    return base, e, np.array(pairs)
+
+
+@pytest.mark.parametrize("decimals", [None, 1])
+def test_lane_extraction_matches_the_wavefront_extraction_and_the_oracle(decimals):
+    """Batches of >= 4 096 pairs (the lane pass rides on the early pass's classification).  With the pass on (cuts 16 / 24 / 32) and off:
+    status bytes, |S| and entry counts equal, rows within 1e-12 of each other and 1e-8 of the oracle; the same set of vicinities
+    ends in the lane-per-subgraph kernel; forced give-backs (xl_ncut / xl_mcut) change nothing."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    rs = np.random.RandomState(17)
+    n, e, base_pairs = _lane_batch(rs)
+    kappa = rs.uniform(-0.5, 0.9, size=len(e))
+    if decimals is not None:
+        kappa = np.round(kappa, decimals)
+    rowptr, col, w = synth.edges_to_csr(n, e, kappa)
+    reps = 4096 // len(base_pairs) + 1
+    pairs = np.concatenate([base_pairs[rs.permutation(len(base_pairs))] for _ in range(reps)])
+    assert len(pairs) >= 4096
+    g = engine.DeviceGraph(rowptr, col, w)
+    runs = {}
+    for name, opts in (("off", {"xl_cut": 0}), ("cut16", {"xl_cut": 16}), ("cut24", {"xl_cut": 24}), ("cut32", {"xl_cut": 32}),
+                       ("give_back_nodes", {"xl_cut": 32, "xl_ncut": 9}), ("give_back_edges", {"xl_cut": 32, "xl_mcut": 10}),
+                       ("no_heavy", {"xl_cut": 32, "heavy": 0})):
+        for k, v in opts.items():
+            g.set_option(k, v)
+        out, st = _check(g, torch, rowptr, col, w, pairs)
+        runs[name] = (out, st) + g.sizes(len(pairs)) + (g.stats(), g.xl_stats())
+        g.set_option("xl_cut", 24); g.set_option("xl_ncut", 16); g.set_option("xl_mcut", 24); g.set_option("heavy", 1)
+    ref = runs["off"]
+    assert ref[5] == (0, 0)
+    assert 0 < runs["cut16"][5][0] < runs["cut24"][5][0] < runs["cut32"][5][0] and runs["cut16"][5][1] > 0
+    assert runs["cut32"][5][1] == runs["cut32"][4]["tier_tiny"]              # every tiny vicinity of this batch has a ball <= 32 at one end
+    assert runs["give_back_nodes"][5][1] < runs["cut32"][5][1] and runs["give_back_edges"][5][1] < runs["cut32"][5][1]
+    for name, r in runs.items():
+        assert np.array_equal(r[1], ref[1]), name
+        assert np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3]), name          # |S|, induced directed entries
+        assert np.abs(r[0] - ref[0]).max() <= 1e-12 * max(1.0, np.abs(ref[0]).max()), name
+        assert r[4]["tier_small"] == ref[4]["tier_small"] and r[4]["tier_mid"] == ref[4]["tier_mid"], name
+        if name not in ("give_back_nodes", "give_back_edges"):
+            assert r[4]["tier_tiny"] == ref[4]["tier_tiny"], name
+    g.close()
+
+
+def test_lane_extraction_on_a_pubmed_shaped_batch_with_hubs_and_negatives():
+    """The heavy-member mirroring, heavy x heavy entries through the dense table and long rows given back, on a preferential-
+    attachment graph: positives, reversed positives, random (mostly far) pairs and self pairs; pipelined as well."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    n, edges, kappa, _, _ = synth.shaped_graph("PubMed", scale=0.5)
+    rowptr, col, w = synth.edges_to_csr(n, edges, kappa)
+    rs = np.random.RandomState(23)
+    pos = edges[rs.permutation(len(edges))[:9000]]
+    pairs = np.concatenate([pos, pos[:1500, ::-1], rs.randint(0, n, size=(3000, 2)), np.stack([np.arange(0, n, 37)] * 2, 1)]).astype(np.int32)
+    pairs = pairs[rs.permutation(len(pairs))]
+    d_pairs = torch.as_tensor(pairs).cuda()
+    g = engine.DeviceGraph(rowptr, col, w)
+    g.set_option("xl_pipelined", 1)                 # (by default the lane pass serves stream-ordered single chunks only)
+    g.set_option("xl_cut", 0)
+    off, st_off = g.pd_pi_batch(d_pairs, 2)
+    n_off, m_off = g.sizes(len(pairs))
+    tiny_off = g.stats()["tier_tiny"]
+    for cut in (24, 32):
+        g.set_option("xl_cut", cut)
+        on, st_on = g.pd_pi_batch(d_pairs, 2)
+        n_on, m_on = g.sizes(len(pairs))
+        assert torch.equal(st_on, st_off) and np.array_equal(n_on, n_off) and np.array_equal(m_on, m_off), cut
+        assert float((on - off).abs().max()) <= 1e-12, cut
+        assert g.stats()["tier_tiny"] == tiny_off, cut
+        cand, done = g.xl_stats()
+        assert 0 < done <= cand and done <= tiny_off, (cut, cand, done)
+        # pipelined: three in flight, bit-equal to the stream-ordered rows of the same mode
+        got = [g.pd_pi_batch(d_pairs, 2, async_=True) for _ in range(4)]
+        g.join()
+        torch.cuda.synchronize()
+        for o, s in got:
+            assert torch.equal(o, on) and torch.equal(s, st_on), cut
+    ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, 2, n_threads=0)
+    assert np.array_equal(st_on.cpu().numpy(), rst)
+    out = on.cpu().numpy()
+    nz = ref != 0
+    assert np.array_equal(out == 0, ref == 0) and rel_err(out[nz], ref[nz]).max() < 1e-8
+    g.close()

@@ -43,6 +43,8 @@ extern "C" int tlc_device_count(void) {
 #define TLC_EARLY_MIN_PAIRS 4096  /* smaller batches gain nothing from a second COUNT launch */
 #endif
 #define TLC_TIMING_RING 64        /* chunks whose kernel events are kept */
+#define TLC_XL_GB_WG 256          /* workgroups (arena regions, scratch slots) of the launch that extracts what the lane-per-pair pass gave back */
+#define TLC_XL_GB_REGION 1024     /* entries per region there (a vicinity of <= 32 nodes has at most 32 * 31 directed entries) */
 #define TLC_X_REGION 4096         /* arena entries of the region each workgroup of the extraction starts with (extract.hip) */
 
 struct HostSync {
@@ -54,6 +56,7 @@ struct HostSync {
     volatile long long pub_total;
     volatile int pub_tier[TLC_N_TIERS];
     volatile int pub_early;
+    volatile int pub_xl[2];        // lane-per-pair extraction: candidates listed, pairs finished as records
     volatile int pub_overflow;
     volatile unsigned pub_seq;
 };
@@ -70,7 +73,7 @@ struct ChunkCtx {
     TlcPdParams pp;
     hipStream_t s;
     int n_pairs, hop, pi_enabled;
-    bool bump, use_x, early, spec;
+    bool bump, use_x, early, spec, xlane;
     long long bump_base;
     int xgrid, vgrid, tmask;
     unsigned seq;
@@ -88,10 +91,16 @@ struct Workspace {
     size_t cap_pairs;
     int *hdr_n, *hdr_m2, *hdr_lu, *hdr_lv, *tier_list;
     int* dc_lists;             // [3][cap_pairs + TLC_EARLY_SLOTS]: list positions a tier kernel hands to tlc_pd_dc_kernel (MEDIUM / LARGE / early LARGE)
-    int* big_lists;            // [3][cap_pairs]: the bins of tlc_classify_kernel (extract.hip)
+    int* big_lists;            // [4][cap_pairs]: the bins of tlc_classify_kernel (extract.hip); [3]: pairs the lane-per-pair pass gave back
+    int* xl_list;              // [cap_pairs] candidates of the lane-per-pair extraction (extract_lane.hip)
+    unsigned char* xl_rec;     // their records, one per slot of 64 candidates
+    size_t cap_xl_slots;
+    hipEvent_t ev_cls;         // the classification is done (recorded on the early stream)
+    hipEvent_t ev_xl;          // the lane-per-pair extraction is done (recorded on its side stream)
+    int prev_xl_cand;          // its candidates in the previous chunk (sizes the launch of the lane-per-subgraph kernel behind it)
     long long* edge_off;
     // small device block: [0..6] tier counts, [10..13] scan, [16..19] early pass, [20..22] bump allocator, [24] work counter,
-    // [26..31] divide-and-conquer lists, [32..34] bins, [36..37] entry sum
+    // [26..31] divide-and-conquer lists, [32..35] bins, [36..37] entry sum, [40..41] lane-per-pair extraction (candidates, finished)
     int* d_ctl;
     long long* d_block_sums;   // 1024
     long long* d_totals;       // 1
@@ -177,10 +186,13 @@ struct tlc_graph {
     int ball_list_hop;             // 0: none yet; -1: lists do not fit (the breadth-first kernels are used)
     int* d_bptr;
     int* d_bcol;
+    long long* d_hptr;             // membership tables of the ball lists (extract_lane.hip); null: none (the lane-per-pair pass is off)
+    int* d_htab;
     long long ball_entries;
     TlcNodeRec* d_nrec;            // node records (extract.hip)
     double* d_hh_w;
     int hh_k;
+    int hh_diag;                   // some heavy node has a self loop
     size_t x_lds64, x_lds512;
     // development / test switches (tlc_debug_set_option; initial values from the environment: TLC_EXTRACT, TLC_HEAVY, TLC_TINY)
     int opt_extract, opt_heavy, opt_tiny;
@@ -197,6 +209,9 @@ struct tlc_graph {
     unsigned timing_seq;
     int opt_tier_mask;                  // development: which tier kernels are launched at all (timing a tier alone; rows of the others are garbage)
     int opt_x_region, opt_x_bump_min;   // arena entries per workgroup region / minimum bump area of the extraction (tests shrink them)
+    int opt_xl_cut;                     // lane-per-pair extraction: largest smaller-ball size it takes (0: off; <= TLC_XL_MAXCUT)
+    int opt_xl_pipelined;               // tests: the lane-per-pair extraction in pipelined chunks too
+    int opt_xl_ncut, opt_xl_mcut;       // tests: what the lane-per-pair extraction keeps (<= TLC_T_NCUT nodes / TLC_T_MCUT edges)
 };
 
 static int finish_pending(tlc_graph* g);
@@ -213,8 +228,8 @@ static int quiesce(tlc_graph* g) {
 static int ensure_pairs(tlc_graph* g, Workspace* ws, size_t n) {
     if (n <= ws->cap_pairs) return TLC_OK;
     hipFree(ws->hdr_n); hipFree(ws->hdr_m2); hipFree(ws->hdr_lu); hipFree(ws->hdr_lv); hipFree(ws->tier_list); hipFree(ws->edge_off);
-    hipFree(ws->dc_lists); hipFree(ws->big_lists);
-    ws->hdr_n = ws->hdr_m2 = ws->hdr_lu = ws->hdr_lv = ws->tier_list = ws->dc_lists = ws->big_lists = nullptr;
+    hipFree(ws->dc_lists); hipFree(ws->big_lists); hipFree(ws->xl_list);
+    ws->hdr_n = ws->hdr_m2 = ws->hdr_lu = ws->hdr_lv = ws->tier_list = ws->dc_lists = ws->big_lists = ws->xl_list = nullptr;
     ws->edge_off = nullptr;
     ws->cap_pairs = 0;
     TLC_HIP_CHECK(hipMalloc(&ws->hdr_n, n * sizeof(int)));
@@ -224,7 +239,8 @@ static int ensure_pairs(tlc_graph* g, Workspace* ws, size_t n) {
     TLC_HIP_CHECK(hipMalloc(&ws->tier_list, n * TLC_N_TIERS * sizeof(int)));
     TLC_HIP_CHECK(hipMalloc(&ws->edge_off, (n + 1) * sizeof(long long)));
     TLC_HIP_CHECK(hipMalloc(&ws->dc_lists, 3 * (n + TLC_EARLY_SLOTS) * sizeof(int)));
-    TLC_HIP_CHECK(hipMalloc(&ws->big_lists, 3 * n * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&ws->big_lists, 4 * n * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&ws->xl_list, n * sizeof(int)));
     ws->cap_pairs = n;
     return TLC_OK;
 }
@@ -246,6 +262,17 @@ static int ensure_arena(tlc_graph* g, Workspace* ws, size_t entries, size_t keep
         hipFree(old_dir); hipFree(old_lw);
     }
     ws->cap_entries = want;
+    return TLC_OK;
+}
+
+// records of the lane-per-pair extraction: one slot per 64 candidates, at most every pair of the chunk is one
+static int ensure_xl(tlc_graph* g, Workspace* ws, size_t n_pairs) {
+    const size_t slots = (n_pairs + 63) / 64;
+    if (slots <= ws->cap_xl_slots) return TLC_OK;
+    hipFree(ws->xl_rec);
+    ws->xl_rec = nullptr; ws->cap_xl_slots = 0;
+    TLC_HIP_CHECK(hipMalloc(&ws->xl_rec, slots * (size_t)TLC_XL_REC_BYTES));
+    ws->cap_xl_slots = slots;
     return TLC_OK;
 }
 
@@ -288,7 +315,7 @@ static int ensure_vic_scratch(tlc_graph* g, Workspace* ws, int hop) {
     // the graph's size), and for hop >= 3 the two BFS frontiers (up to n_nodes each)
     const long long cap = std::min<long long>(g->n_nodes, TLC_MAX_SUBGRAPH_NODES + 1);
     ws->vic_stride = 2 * cap + (need_front ? 2ll * g->n_nodes : 0) + 16;
-    TLC_HIP_CHECK(hipMalloc(&ws->vic_scratch, (size_t)(g->vic_slots + TLC_EARLY_WG) * ws->vic_stride * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&ws->vic_scratch, (size_t)(g->vic_slots + TLC_EARLY_WG + TLC_XL_GB_WG) * ws->vic_stride * sizeof(int)));
     ws->vic_hop_cap = need_front;
     return TLC_OK;
 }
@@ -378,6 +405,7 @@ static int build_heavy_set(tlc_graph* g, const int32_t* rp, const int32_t* col, 
         TLC_HIP_CHECK(hipMalloc(&g->d_hh_w, (size_t)K * K * sizeof(double)));
         TLC_HIP_CHECK(hipMemcpy(g->d_hh_w, hh.data(), (size_t)K * K * sizeof(double), hipMemcpyHostToDevice));
         g->hh_k = K;
+        for (int a = 0; a < K; ++a) if (hh[(size_t)a * K + a] != 0.0) g->hh_diag = 1;
         *hidx_out = hidx;
     }
     return TLC_OK;                                            // (not ok: no heavy set, the sweep reads every row)
@@ -409,8 +437,8 @@ static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
         const int rq = quiesce(g);                            // (a chunk in flight on another workspace may be reading the lists)
         if (rq != TLC_OK) return rq;
     }
-    hipFree(g->d_bptr); hipFree(g->d_bcol);
-    g->d_bptr = g->d_bcol = nullptr; g->ball_list_hop = 0; g->ball_entries = 0;
+    hipFree(g->d_bptr); hipFree(g->d_bcol); hipFree(g->d_hptr); hipFree(g->d_htab);
+    g->d_bptr = g->d_bcol = g->d_htab = nullptr; g->d_hptr = nullptr; g->ball_list_hop = 0; g->ball_entries = 0;
     const int n = g->n_nodes;
     int* d_size = nullptr;
     TLC_HIP_CHECK(hipMalloc(&d_size, (size_t)n * sizeof(int)));
@@ -433,6 +461,41 @@ static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
     if ((rc = tlc_launch_ball_list(true, n, g->nw, g->d_rowptr, g->d_col, hop, nullptr, g->d_bptr, g->d_bcol, grid, s)) != TLC_OK) return rc;
     TLC_HIP_CHECK(hipStreamSynchronize(s));                  // (sz is host memory of this frame)
     g->ball_list_hop = hop; g->ball_entries = tot;
+    if (g->opt_xl_cut <= 0) return TLC_OK;                   // (no lane-per-pair extraction: no tables; the option rebuilds the lists)
+    // membership tables for the lane-per-pair extraction: per node a power of two >= |ball| of four-id buckets, two choices per
+    // id; descriptor = first bucket << 6 | log2(buckets), 63 = no table (a bucket pair overflowed while filling: the pairs that
+    // would look something up there are given back to the wavefront extraction).  Skipped altogether when the tables would not
+    // fit an eighth of the free memory.
+    {
+        std::vector<long long> hd((size_t)n);
+        long long nb = 0;
+        for (int x = 0; x < n; ++x) {
+            const int sx = sz[x + 1] - sz[x];
+            int lg = 0;
+            while ((1ll << lg) < sx) ++lg;
+            hd[x] = (nb << 6) | lg;
+            nb += 1ll << lg;
+        }
+        hipMemGetInfo(&free_b, &total_b);
+        if ((size_t)nb * 16 <= free_b / 8 && nb < (1ll << 40)) {
+            int* d_fail = nullptr;
+            std::vector<int> fail((size_t)n, 0);
+            TLC_HIP_CHECK(hipMalloc(&g->d_hptr, (size_t)n * sizeof(long long)));
+            TLC_HIP_CHECK(hipMalloc(&g->d_htab, (size_t)nb * 16 + 16));
+            TLC_HIP_CHECK(hipMalloc(&d_fail, (size_t)n * sizeof(int)));
+            TLC_HIP_CHECK(hipMemsetAsync(d_fail, 0, (size_t)n * sizeof(int), s));
+            TLC_HIP_CHECK(hipMemsetAsync(g->d_htab, 0xff, (size_t)nb * 16 + 16, s));
+            TLC_HIP_CHECK(hipMemcpyAsync(g->d_hptr, hd.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, s));
+            rc = tlc_launch_ball_hash(n, g->d_bptr, g->d_bcol, g->d_hptr, g->d_htab, d_fail, s);
+            if (rc == TLC_OK && hipMemcpyAsync(fail.data(), d_fail, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) rc = TLC_ERR_HIP;
+            if (rc == TLC_OK && hipStreamSynchronize(s) != hipSuccess) rc = TLC_ERR_HIP;
+            hipFree(d_fail);
+            if (rc != TLC_OK) return rc;
+            bool any = false;
+            for (int x = 0; x < n; ++x) if (fail[x]) { hd[x] |= 63; any = true; }
+            if (any) TLC_HIP_CHECK(hipMemcpy(g->d_hptr, hd.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice));
+        }
+    }
     return TLC_OK;
 }
 
@@ -468,6 +531,10 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     auto env_on = [](const char* name) { const char* v = getenv(name); return !(v && v[0] == '0'); };
     g->opt_extract = env_on("TLC_EXTRACT"); g->opt_heavy = env_on("TLC_HEAVY"); g->opt_tiny = env_on("TLC_TINY");
     g->opt_defer = env_on("TLC_DEFER"); g->opt_n_ws = 3;
+    // (off unless asked for: in-process A/Bs on the PubMed-shaped batch, tools/ab_option.py xl_cut 0 {16,24,32}, show no gain for
+    // one batch alone and a loss for pipelined batches -- see the note at `xlane` in run_chunk_front and DESIGN.md)
+    { const char* v = getenv("TLC_XL_CUT"); g->opt_xl_cut = v ? std::min(std::max(atoi(v), 0), TLC_XL_MAXCUT) : 0; }
+    g->opt_xl_ncut = TLC_T_NCUT; g->opt_xl_mcut = TLC_T_MCUT;
     g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = 0x7f; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
@@ -539,6 +606,8 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
         CK(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ws->ev_early, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ws->ev_scan, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&ws->ev_cls, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&ws->ev_xl, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ws->ev_in, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ws->ev_done, hipEventDisableTiming));
     }
@@ -571,7 +640,7 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     for (int i = 0; i < TLC_N_WS; ++i) {
         Workspace* ws = &g->ws[i];
         hipFree(ws->hdr_n); hipFree(ws->hdr_m2); hipFree(ws->hdr_lu); hipFree(ws->hdr_lv); hipFree(ws->tier_list); hipFree(ws->edge_off);
-        hipFree(ws->dc_lists); hipFree(ws->big_lists);
+        hipFree(ws->dc_lists); hipFree(ws->big_lists); hipFree(ws->xl_list); hipFree(ws->xl_rec);
         hipFree(ws->d_ctl); hipFree(ws->d_block_sums); hipFree(ws->d_totals);
         if (ws->h_sync) hipHostFree(ws->h_sync);
         hipFree(ws->A_dir); hipFree(ws->A_lw); hipFree(ws->S_dir); hipFree(ws->S_lw); hipFree(ws->vic_scratch); hipFree(ws->huge_scratch);
@@ -583,10 +652,10 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
             if (own && ws->side[k]) hipStreamDestroy(ws->side[k]);
             if (ws->ev_join[k]) hipEventDestroy(ws->ev_join[k]);
         }
-        for (hipEvent_t e : {ws->ev_fork, ws->ev_early, ws->ev_scan, ws->ev_in, ws->ev_done}) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : {ws->ev_fork, ws->ev_early, ws->ev_scan, ws->ev_in, ws->ev_done, ws->ev_cls, ws->ev_xl}) if (e) hipEventDestroy(e);
     }
     hipFree(g->d_phase); hipFree(g->d_pair_t);
-    hipFree(g->d_bptr); hipFree(g->d_bcol); hipFree(g->d_nrec); hipFree(g->d_hh_w);
+    hipFree(g->d_bptr); hipFree(g->d_bcol); hipFree(g->d_hptr); hipFree(g->d_htab); hipFree(g->d_nrec); hipFree(g->d_hh_w);
     hipFree(g->d_ball_ub[0]); hipFree(g->d_ball_ub[1]);
     if (g->ev_ring_ready)
         for (int r = 0; r < TLC_TIMING_RING; ++r)
@@ -695,13 +764,24 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         if ((rc = ensure_ball_lists(g, hop, s)) != TLC_OK) return rc;
         use_x = g->ball_list_hop == hop;
     }
+    // The smallest vicinities one LANE per pair (extract_lane.hip) -- the plain image batch at resolution 5 with the
+    // lane-per-subgraph PD kernel on, behind the classification of the early pass
+    // Measured (tools/ab_option.py xl_cut 0 24, one process): it shortens ONE batch (the main pass loses a third of its pairs and the
+    // lane-per-subgraph kernel starts 0.3 ms earlier) but costs pipelined batches 4 - 8 %: with three chunks in flight every kernel
+    // costs what it occupies, the wavefront extraction spends only ~35 us of machine time per chunk on these pairs, and the lane
+    // kernel's ~80 workgroups of 138 KB LDS + the extra launches and cross-stream waits cost more than that.  So: stream-ordered
+    // single chunks only (option "xl_pipelined" forces it for pipelined chunks: tests).
+    const bool xlane = use_x && early && g->opt_xl_cut > 0 && g->opt_tiny && flags == 0u && res == 5 && g->d_hptr != nullptr &&
+                       (!pipelined || g->opt_xl_pipelined);
     // (opt_x_grid: development A/B of the number of extraction workgroups; never more than the scratch slots there are)
     const int xgrid = std::min(n_pairs, g->opt_x_grid > 0 ? std::min(g->opt_x_grid, g->vic_slots) : g->vic_slots);
     long long bump_base = 0;
     if (use_x) {
         // arena = one region per workgroup of the extraction (main pass, then the early pass), then the bump area
-        const long long regions = (long long)xgrid + (early ? TLC_EARLY_WG : 0);
-        bump_base = regions * g->opt_x_region;
+        // (main pass, early pass; then the launch that extracts what the lane-per-pair pass gave back: vicinities of <= 32 nodes, so
+        // many small workgroup regions)
+        const long long regions = (long long)xgrid + TLC_EARLY_WG;
+        bump_base = regions * g->opt_x_region + (long long)TLC_XL_GB_WG * TLC_XL_GB_REGION;
         const size_t want = (size_t)bump_base + std::max<size_t>(std::max<size_t>((size_t)n_pairs * 32, (size_t)g->opt_x_bump_min), ws->x_entries_hint + ws->x_entries_hint / 2);
         if (ws->cap_entries < want && (rc = ensure_arena(g, ws, want)) != TLC_OK) return rc;
         vp.small_dir = nullptr; vp.small_lw = nullptr;
@@ -747,9 +827,57 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         TLC_HIP_CHECK(hipStreamWaitEvent(es, ws->ev_fork, 0));
         // (TLC_INCLUDE_ROOTS adds at most the two roots to a vicinity)
         if (use_x) {
-            // exact ball sizes: the candidates of the early pass and the bins the main pass takes first
+            // exact ball sizes: the candidates of the early pass, the bins the main pass takes first, and the candidates of the
+            // lane-per-pair pass (smaller ball <= xl_cut nodes)
+            if (xlane && (rc = ensure_xl(g, ws, (size_t)n_pairs)) != TLC_OK) return rc;
             if ((rc = tlc_launch_classify(n_pairs, d_pairs, g->n_nodes, g->d_bptr, TLC_M_NMAX - 1, TLC_EARLY_CAND, d_cand_count,
-                                          ws->d_cand_list, ws->d_ctl + 32, ws->big_lists, es)) != TLC_OK) return rc;
+                                          ws->d_cand_list, ws->d_ctl + 32, ws->big_lists, xlane ? g->opt_xl_cut : 0, ws->d_ctl + 40,
+                                          ws->xl_list, es)) != TLC_OK) return rc;
+            if (xlane) {
+                // The lane-per-pair pass needs the classification only.  It is one wavefront per 64 pairs, ~300 wavefronts that each
+                // run ~80 us of serial lane code: cheap for the machine, long for a chain -- so it runs on a side stream beside the
+                // early pass and the main pass.  Behind it on that stream: a small launch of tlc_extract_kernel for what it gave
+                // back (its own arena regions and scratch slots: the main pass is running), then the lane-per-subgraph kernel for its
+                // records (grid from the previous chunk's count, the workgroups stride over the slots there are).  The main stream
+                // waits for the first two before the scan.
+                hipStream_t xs = ws->side[1];
+                TLC_HIP_CHECK(hipEventRecord(ws->ev_cls, es));
+                TLC_HIP_CHECK(hipStreamWaitEvent(xs, ws->ev_cls, 0));
+                TlcXlParams xp;
+                memset(&xp, 0, sizeof(xp));
+                xp.n_nodes = g->n_nodes; xp.rowptr = g->d_rowptr; xp.col = g->d_col; xp.w = g->d_w; xp.pairs = d_pairs;
+                xp.bptr = g->d_bptr; xp.bcol = g->d_bcol; xp.hptr = g->d_hptr; xp.htab = g->d_htab; xp.nrec = g->d_nrec;
+                if (g->hh_k > 0 && g->opt_heavy) { xp.hh_w = g->d_hh_w; xp.hh_k = g->hh_k; xp.hh_diag = g->hh_diag; }
+                xp.xl_list = ws->xl_list; xp.xl_count = ws->d_ctl + 40; xp.xl_cap = n_pairs;
+                xp.ncut = std::min(g->opt_xl_ncut, TLC_T_NCUT); xp.mcut = std::min(g->opt_xl_mcut, TLC_T_MCUT);
+                xp.hdr_n = ws->hdr_n; xp.hdr_m2 = ws->hdr_m2; xp.hdr_lu = ws->hdr_lu; xp.hdr_lv = ws->hdr_lv;
+                xp.out_pi = d_out_pi; xp.out_status = d_out_status; xp.rec = ws->xl_rec;
+                xp.dbg = g->d_phase ? g->d_phase + 32 * (TLC_N_TIERS + 1) : nullptr;
+                xp.ovf_count = ws->d_ctl + 35; xp.ovf_list = ws->big_lists + 3 * (size_t)n_pairs; xp.done_count = ws->d_ctl + 41;
+                if ((rc = tlc_launch_xlane(xp, std::min((n_pairs + 63) / 64, 2048), xs)) != TLC_OK) return rc;
+                {
+                    TlcVicParams gp = vp;
+                    gp.fill_mode = 1; gp.fill_list = ws->big_lists + 3 * (size_t)n_pairs; gp.fill_count = n_pairs; gp.work_count_dev = ws->d_ctl + 35;
+                    gp.region_base_wg = 0; gp.region_entries = TLC_XL_GB_REGION;
+                    gp.region_base_entries = ((long long)xgrid + TLC_EARLY_WG) * g->opt_x_region;
+                    gp.scratch_base_slot = g->vic_slots + TLC_EARLY_WG;
+                    gp.started = nullptr; gp.early_list = nullptr; gp.early_count = nullptr;
+                    gp.skip_count = nullptr; gp.big_count = nullptr; gp.xl_cut = 0; gp.work_counter = nullptr;
+                    if ((rc = tlc_launch_extract(64, TLC_XL_GB_WG, g->x_lds64, gp, xs)) != TLC_OK) return rc;
+                }
+                TLC_HIP_CHECK(hipEventRecord(ws->ev_xl, xs));
+                {
+                    TlcPdParams tp = pp;
+                    tp.xl_rec = ws->xl_rec; tp.xl_list = ws->xl_list;
+                    tp.tier_count = n_pairs; tp.tier_count_dev = ws->d_ctl + 40;
+                    const int all_slots = (n_pairs + 63) / 64;
+                    tp.xl_slots = ws->prev_xl_cand > 0 ? std::min(all_slots, (ws->prev_xl_cand + 63) / 64 + 8) : all_slots;
+                    tp.phase_cycles = g->d_phase ? g->d_phase + 32 * TLC_TIER_TINY : nullptr;
+                    if (((g->opt_tier_mask >> TLC_TIER_TINY) & 1) && (rc = tlc_launch_pd_tiny_rec(tp, xs)) != TLC_OK) return rc;
+                }
+                TLC_HIP_CHECK(hipEventRecord(ws->ev_join[1], xs));
+                vp.xl_cut = g->opt_xl_cut;
+            }
         } else if ((rc = tlc_launch_select_heavy(n_pairs, d_pairs, g->n_nodes, g->d_ball_ub[(hop - 1) & 1], TLC_M_NMAX - 1, TLC_EARLY_CAND,
                                                  d_cand_count, ws->d_cand_list, es)) != TLC_OK) return rc;
         TlcVicParams ep = vp;
@@ -816,8 +944,9 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     }
     T1(0, s);
     vp.work_counter = nullptr;
-    vp.skip_count = nullptr; vp.big_count = nullptr;      // (the FILL launches below are list-driven)
+    vp.skip_count = nullptr; vp.big_count = nullptr; vp.xl_cut = 0;      // (the FILL launches below are list-driven)
     TLC_HIP_CHECK(hipGetLastError());
+    if (xlane) TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_xl, 0));    // the scan reads the headers of the lane pass and of what it gave back
     if (early) TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_early, 0));   // the scan reads the early list
 
     // exclusive scan of the induced entry counts + tier binning
@@ -839,6 +968,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     sp.tiny_ok = (g->opt_tiny && pi_enabled && flags == 0u && res == 5 && !d_out_ids && !d_out_f && !d_out_edges) ? 1 : 0;
     sp.early_list = early ? ws->d_early_list : nullptr; sp.early_count = d_early_count; sp.early_cap = TLC_EARLY_SLOTS;
     sp.h_early = const_cast<int*>(&ws->h_sync_dev->pub_early);
+    sp.xl_counts = xlane ? ws->d_ctl + 40 : nullptr; sp.h_xl = const_cast<int*>(ws->h_sync_dev->pub_xl);
     sp.bump_top = bump ? d_bump_top : nullptr; sp.bump_overflow = d_bump_overflow; sp.bump_base = bump_base;
     sp.h_overflow = const_cast<int*>(&ws->h_sync_dev->pub_overflow);
     // The arena size and the tier counts come back through mapped host memory: the last block of the scan stores them,
@@ -860,7 +990,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     // (abort flag) and the chunk is redone below.
     static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4};   // timing slot of each tier kernel (TINY is reported with SMALL, MEDHI as MEDIUM)
     bool (&used)[TLC_N_SIDE] = c.used;
-    for (int k = 0; k < TLC_N_SIDE; ++k) used[k] = (k == 4) && early;
+    for (int k = 0; k < TLC_N_SIDE; ++k) used[k] = ((k == 4) && early) || ((k == 1) && xlane);
     // The fork point of the side-stream launches that need nothing but the scan.  Recorded here, it is long complete when the
     // host has seen the sizes and submits them, and a wait on a complete event is no command at all -- an event recorded at
     // submission time costs every side stream a barrier packet on a signal that is still in flight: 60 us per chunk (measured:
@@ -903,7 +1033,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         pp.phase = 0;
         pp.grid = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr; pp.handoff = nullptr; pp.handoff_cap = 0;
     }
-    c.bump = bump; c.use_x = use_x; c.early = early; c.spec = spec; c.bump_base = bump_base; c.xgrid = xgrid; c.seq = seq;
+    c.bump = bump; c.use_x = use_x; c.early = early; c.spec = spec; c.xlane = xlane; c.bump_base = bump_base; c.xgrid = xgrid; c.seq = seq;
     c.ht_front = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c.ht0).count() * 1e-3;
     ws->back_pending = 1;
     return TLC_OK;
@@ -968,7 +1098,9 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
     if (tc[TLC_TIER_HUGE] > 0 && (rc = ensure_huge(g, ws)) != TLC_OK) return rc;
 
     const int n_early = early ? ws->h_sync->pub_early : 0;
+    const int n_xl_cand = c.xlane ? ws->h_sync->pub_xl[0] : 0, n_xl_done = c.xlane ? ws->h_sync->pub_xl[1] : 0;
     const int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4] + tc[5] + tc[6];
+    if (c.xlane) ws->prev_xl_cand = n_xl_cand;
     const bool spec_done = spec && bumped;          // the MID / MEDIUM tiers are already running
     ws->prev_tc[TLC_TIER_MID] = tc[TLC_TIER_MID]; ws->prev_tc[TLC_TIER_MEDIUM] = tc[TLC_TIER_MEDIUM]; ws->prev_tc[TLC_TIER_MEDHI] = tc[TLC_TIER_MEDHI];
     if (todo > 0) {
@@ -1133,6 +1265,8 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
     g->last_stats[9] += tc[TLC_TIER_MEDHI];
     g->last_stats[TLC_TIER_SMALL] += tc[TLC_TIER_TINY];                 // (reported with SMALL; on its own in [8])
     g->last_stats[8] += tc[TLC_TIER_TINY];
+    g->last_stats[TLC_TIER_SMALL] += n_xl_done;                         // (finished as records by the lane-per-pair extraction)
+    g->last_stats[8] += n_xl_done;
     g->last_stats[TLC_TIER_LARGE] += n_early;
     g->last_stats[7] += tc[TLC_TIER_MID];
     g->last_stats[6] += 1;
@@ -1155,7 +1289,7 @@ static int chunk_entries(Workspace* ws, long long* out) {
     TLC_HIP_CHECK(hipMemcpy(n.data(), ws->hdr_n, n.size() * sizeof(int), hipMemcpyDeviceToHost));
     TLC_HIP_CHECK(hipMemcpy(m2.data(), ws->hdr_m2, m2.size() * sizeof(int), hipMemcpyDeviceToHost));
     long long e = 0;
-    for (size_t k = 0; k < n.size(); ++k) if (n[k] > 0) e += m2[k];
+    for (size_t k = 0; k < n.size(); ++k) if (n[k] > 0) e += m2[k] & ~TLC_XL_DONE_FLAG;
     *out = e;
     return TLC_OK;
 }
@@ -1408,7 +1542,8 @@ extern "C" int tlc_pi_raster(int32_t n_dgms, const int64_t* d_offs, const double
 }
 
 // ---- diagnostics (declared in include/tlcgnn.h, "diagnostics" section): per-phase cycle counters of the PD tier kernels --
-// Rows of 32 u64: one per tier (TLC_N_TIERS; the HUGE tier's row doubles as the main COUNT pass's), then the early pass.
+// Rows of 32 u64: one per tier (TLC_N_TIERS; the HUGE tier's row doubles as the main COUNT pass's), then the early pass, then the
+// lane-per-pair extraction.
 // `cap_u64` = how many u64 the caller allocated at h_out: never more than that is written; *n_rows (may be null) = rows the
 // library keeps, so a tool can size its buffer by asking first (h_out null).
 extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out, int64_t cap_u64, int32_t* n_rows) {
@@ -1416,7 +1551,7 @@ extern "C" int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long l
     TLC_REQUIRE(h_out == nullptr || cap_u64 >= 0, "cap_u64 < 0");
     TLC_ON_DEVICE(g->device);
     { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; }
-    const size_t rows = (size_t)TLC_N_TIERS + 1;
+    const size_t rows = (size_t)TLC_N_TIERS + 2;      // (the last row: the lane-per-pair extraction)
     if (n_rows) *n_rows = (int32_t)rows;
     TLC_HIP_CHECK(hipDeviceSynchronize());
     if (h_out && g->d_phase) {
@@ -1461,6 +1596,18 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "x_chunk_div")) g->opt_x_chunk_div = std::max(value, 0);
     else if (!strcmp(name, "timing_every")) { g->opt_timing_every = std::max(value, 1); g->timing_seq = 0; }
     else if (!strcmp(name, "dc_force_fail")) g->opt_dc_force_fail = value != 0;
+    else if (!strcmp(name, "xl_cut")) {
+        g->opt_xl_cut = std::min(std::max(value, 0), TLC_XL_MAXCUT);
+        if (g->opt_xl_cut > 0 && !g->d_hptr && g->ball_list_hop > 0) {
+            // the membership tables are built with the ball lists: have them rebuilt by the next batch
+            int rc_p = quiesce(g);
+            if (rc_p != TLC_OK) return rc_p;
+            g->ball_list_hop = 0;
+        }
+    }
+    else if (!strcmp(name, "xl_pipelined")) g->opt_xl_pipelined = value != 0;
+    else if (!strcmp(name, "xl_ncut")) g->opt_xl_ncut = std::min(std::max(value, 1), TLC_T_NCUT);
+    else if (!strcmp(name, "xl_mcut")) g->opt_xl_mcut = std::min(std::max(value, 0), TLC_T_MCUT);
     else if (!strcmp(name, "x_region")) g->opt_x_region = std::max(value, 0);
     else if (!strcmp(name, "x_bump_min")) g->opt_x_bump_min = std::max(value, 0);
     else { tlc_set_error("tlc_debug_set_option: unknown option '%s'", name); return TLC_ERR_INVALID_ARG; }
@@ -1481,6 +1628,22 @@ extern "C" int tlc_debug_dc_stats(tlc_graph* g, long long* h_out, void* stream) 
     }
     h_out[0] = (long long)v[1];
     h_out[1] = (long long)v[3];
+    return TLC_OK;
+}
+
+// diagnostics: the lane-per-pair extraction in the last chunk -- h_out[0] candidates (smaller ball <= the cut), h_out[1] pairs it
+// finished as records for the lane-per-subgraph kernel (the rest were zero rows or given back to the wavefront extraction)
+extern "C" int tlc_debug_xl_stats(tlc_graph* g, long long* h_out, void* stream) {
+    TLC_REQUIRE(g && h_out, "null argument");
+    TLC_ON_DEVICE(g->device);
+    { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; }
+    TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    h_out[0] = h_out[1] = 0;
+    if (g->last_ws && g->last_ws->ctx.xlane) {
+        if (g->last_ws->busy) { TLC_HIP_CHECK(hipEventSynchronize(g->last_ws->ev_done)); g->last_ws->busy = 0; }
+        h_out[0] = g->last_ws->h_sync->pub_xl[0];
+        h_out[1] = g->last_ws->h_sync->pub_xl[1];
+    }
     return TLC_OK;
 }
 
@@ -1548,6 +1711,7 @@ extern "C" int tlc_pd_pi_batch_sizes(tlc_graph* g, int32_t* h_n, int32_t* h_m2, 
         if (g->last_ws->busy) { TLC_HIP_CHECK(hipEventSynchronize(g->last_ws->ev_done)); g->last_ws->busy = 0; }
         TLC_HIP_CHECK(hipMemcpy(h_n, g->last_ws->hdr_n, k * sizeof(int), hipMemcpyDeviceToHost));
         TLC_HIP_CHECK(hipMemcpy(h_m2, g->last_ws->hdr_m2, k * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < k; ++q) h_m2[q] &= ~TLC_XL_DONE_FLAG;     // (the mark of the lane-per-pair extraction is not a size)
     }
     return TLC_OK;
 }

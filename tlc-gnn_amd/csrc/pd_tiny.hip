@@ -124,9 +124,11 @@ static_assert(2 * (size_t)TM * 64 + (size_t)TN * 64 <= 5 * (size_t)TN * 64, "ord
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int lane = (int)(threadIdx.x & 63);
+// REC: the subgraphs come as records of the lane-per-pair extraction (extract_lane.hip; slot = 64 candidates, lane = lane), else
+// from the arena through a tier list (slot = 64 list positions).
+// one slot of 64 subgraphs on one wavefront; `lds`: the wavefront's TINY_WG_BYTES
+template <bool REC>
+__device__ __forceinline__ void tiny_slot(const TlcPdParams& p, unsigned char* lds, int lane, int slot) {
     // carve (see the region table above)
     LaneArr<double> ew{(double*)(lds + T_OA) + lane};
     const LaneArr<double>& key = ew;                  // (the sort keys take the weights' place once f is final)
@@ -152,16 +154,28 @@ __global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
     LaneArr<unsigned char> comp{lds + T_OE + (size_t)TM * 64 + lane};
     LaneArr<unsigned char> pn{lds + T_OE + (size_t)TM * 64 + (size_t)TN * 64 + lane};   // Pos edges from the front, Neg edges from the back
     int npts = 0;
-
-    int tier_count = p.tier_count;
-    if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
-    const int wi = (int)blockIdx.x * 64 + lane;
-    if (wi >= tier_count) return;
-    const int i = p.tier_list[wi];
-    const int n = p.hdr_n[i], m2 = p.hdr_m2[i], lu = p.hdr_lu[i], lv = p.hdr_lv[i];
-    // (fixed slots written by the breadth-first COUNT pass, or wherever the extraction left the subgraph in the arena)
-    const unsigned* adir = p.small_dir ? p.small_dir + (size_t)i * (2 * TLC_S_MMAX) : p.A_dir + p.edge_off[i];
-    const double* alw = p.small_dir ? p.small_lw + (size_t)i * (2 * TLC_S_MMAX) : p.A_lw + p.edge_off[i];
+    int i, n, m2 = 0, lu, lv, m = 0;
+    const unsigned* adir = nullptr;
+    const double* alw = nullptr;
+    const unsigned char* rec = nullptr;
+    if (REC) {
+        rec = p.xl_rec + (size_t)slot * TLC_XL_REC_BYTES;
+        const unsigned hdr = ((const unsigned*)rec)[lane];
+        if (hdr == 0xffffffffu) return;                   // no pair in this lane, or finished / given back by the extraction
+        i = p.xl_list[slot * 64 + lane];
+        n = (int)(hdr & 0xffu); m = (int)((hdr >> 8) & 0xffu);
+        lu = (int)(signed char)((hdr >> 16) & 0xffu); lv = (int)(signed char)(hdr >> 24);
+    } else {
+        int tier_count = p.tier_count;
+        if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
+        const int wi = slot * 64 + lane;
+        if (wi >= tier_count) return;
+        i = p.tier_list[wi];
+        n = p.hdr_n[i]; m2 = p.hdr_m2[i]; lu = p.hdr_lu[i]; lv = p.hdr_lv[i];
+        // (fixed slots written by the breadth-first COUNT pass, or wherever the extraction left the subgraph in the arena)
+        adir = p.small_dir ? p.small_dir + (size_t)i * (2 * TLC_S_MMAX) : p.A_dir + p.edge_off[i];
+        alw = p.small_dir ? p.small_lw + (size_t)i * (2 * TLC_S_MMAX) : p.A_lw + p.edge_off[i];
+    }
     int status = TLC_ST_OK;
     TinyImage img;
     img.clear();
@@ -169,12 +183,18 @@ __global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
     unsigned long long* pc = p.phase_cycles;
     unsigned long long t_prev = pc ? clock64() : 0ull;
 #define TINY_STAMP(k) do { if (pc) { const unsigned long long _t = clock64(); if (lane == 0) atomicAdd(&pc[(k)], _t - t_prev); t_prev = _t; } } while (0)
-    // undirected edge list: the directed entries with src < dst, in CSR order
-    int m = 0;
-    for (int j = 0; j < m2; ++j) {
-        const unsigned e = adir[j];
-        const unsigned a = e >> 16, b = e & 0xffffu;
-        if (a < b && m < TM) { eab[m] = (unsigned short)((a << 8) | b); ew[m] = alw[j]; ++m; }
+    if (REC) {
+        // the record holds the undirected edge list itself (lower local id first), in the order the arena entries would have had
+        const unsigned* re_ = (const unsigned*)(rec + TLC_XL_REC_EDGE_OFF) + lane;
+        const double* rw_ = (const double*)(rec + TLC_XL_REC_W_OFF) + lane;
+        for (int e = 0; e < m; ++e) { eab[e] = (unsigned short)re_[e * 64]; ew[e] = rw_[e * 64]; }
+    } else {
+        // undirected edge list: the directed entries with src < dst, in CSR order
+        for (int j = 0; j < m2; ++j) {
+            const unsigned e = adir[j];
+            const unsigned a = e >> 16, b = e & 0xffffu;
+            if (a < b && m < TM) { eab[m] = (unsigned short)((a << 8) | b); ew[m] = alw[j]; ++m; }
+        }
     }
     TINY_STAMP(0);
     const double INF = __longlong_as_double(0x7FF0000000000000ll);
@@ -389,6 +409,32 @@ __global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
 #undef TINY_STAMP
 }
 
+// from the arena through a tier list: one workgroup = one wavefront = 64 list positions, no loop around the body
+__global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    tiny_slot<false>(p, lds_all, (int)(threadIdx.x & 63), (int)blockIdx.x);
+}
+
+// from the records of the lane-per-pair extraction (extract_lane.hip): slot = 64 candidates, lane = lane.  WPB wavefronts per
+// workgroup, each with its own LDS rows (no barrier anywhere), so that a chunk's ~300 wavefronts fill ~80 CUs (one per SIMD) and leave
+// the others' LDS whole for the LARGE tier; the launch is sized from the PREVIOUS chunk's count (this chunk's is on the device only,
+// in *tier_count_dev), so the wavefronts stride over the slots there are.
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void tlc_pd_tiny_rec_kernel(TlcPdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    unsigned char* lds = lds_all + (size_t)(threadIdx.x >> 6) * TINY_WG_BYTES;
+    int c = *p.tier_count_dev;
+    c = c < p.tier_count ? c : p.tier_count;
+    const int n_slots = (c + 63) >> 6;
+    for (int slot = (int)blockIdx.x * WPB + (int)(threadIdx.x >> 6); slot < n_slots; slot += (int)gridDim.x * WPB)
+        tiny_slot<true>(p, lds, (int)(threadIdx.x & 63), slot);
+}
+
+#ifndef TLC_TINY_REC_WPB
+#define TLC_TINY_REC_WPB 4
+#endif
+template __global__ void tlc_pd_tiny_rec_kernel<TLC_TINY_REC_WPB>(TlcPdParams);
+
 int tlc_launch_pd_tiny(const TlcPdParams& p, void* stream) {
     if (p.tier_count <= 0) return TLC_OK;
     const size_t lds = TINY_WG_BYTES;
@@ -397,6 +443,19 @@ int tlc_launch_pd_tiny(const TlcPdParams& p, void* stream) {
     if (lds > 64 * 1024)
         TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_pd_tiny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(tlc_pd_tiny_kernel, dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
+// the records of the lane-per-pair extraction: wavefronts for p.xl_slots slots stride over the slots there turn out to be
+// (candidates in *p.tier_count_dev, at most p.tier_count)
+int tlc_launch_pd_tiny_rec(const TlcPdParams& p, void* stream) {
+    if (p.xl_slots <= 0) return TLC_OK;
+    constexpr int WPB = TLC_TINY_REC_WPB;
+    const size_t lds = TINY_WG_BYTES * WPB;
+    if (lds > 64 * 1024)
+        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_pd_tiny_rec_kernel<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((tlc_pd_tiny_rec_kernel<WPB>), dim3((p.xl_slots + WPB - 1) / WPB), dim3(64 * WPB), lds, (hipStream_t)stream, p);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }
