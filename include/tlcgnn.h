@@ -380,6 +380,17 @@ int tlc_near_pairs(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_co
  * d_status_hist uint64[8] (may be NULL; the caller zeroes it once per store).  *d_count (uint64, device; the caller zeroes it
  * per call) is advanced by the number of kept rows even beyond `cap` (rows past the capacity are not written: re-run the block
  * with a larger store, and a fresh histogram).  Append order is not fixed. */
+/* The caller side of the PDGNN fork's vicinity extraction (Knowledge_Distillation/data_utils_LP.py:105-200 returns one
+ * (filtration values, edge_index) per candidate edge; gcn_LP_GIN.Net.compute_PI :43-64 feeds them to the model one by one): the
+ * per-pair capacity slots tlc_vicinity_filtration wrote -> ONE packed block-diagonal batch.  d_node_ptr / d_edge_ptr int64[n+1]:
+ * the packed offsets (exclusive prefix sums of the node and edge counts the caller wants kept -- a pair's slice may be empty);
+ * d_out_ids int64 = d_label[id] (NULL: the id itself), d_out_f, d_out_edges int32[.,2] (local ids, as written), and the owner
+ * pair of every packed node / edge (either may be NULL).  One wavefront per pair, coalesced both ways. */
+int tlc_pack_vicinities(int64_t n_pairs, const int64_t* d_node_offs, const int32_t* d_ids, const double* d_f,
+                        const int64_t* d_edge_offs, const int32_t* d_edges, const int64_t* d_node_ptr, const int64_t* d_edge_ptr,
+                        const int64_t* d_label, int64_t* d_out_ids, double* d_out_f, int32_t* d_out_edges,
+                        int64_t* d_pair_of_node, int64_t* d_pair_of_edge, void* stream);
+
 #define TLC_SELECT_KEEP_FAILED 0x1u
 int tlc_select_rows(int64_t n_rows, int32_t width, const double* d_pi, const uint8_t* d_status, int64_t index_base, int64_t cap,
                     uint32_t flags, uint64_t* d_count, uint64_t* d_status_hist, int64_t* d_out_idx, uint8_t* d_out_status,

@@ -37,25 +37,22 @@ class Vicinities:
         n_cap = dev_graph.n_nodes if node_cap is None else int(node_cap)
         e_cap = max(dev_graph.nnz // 2, 1) if edge_cap is None else int(edge_cap)
         offs, ids, f, n, st, eoffs, edges, m = dev_graph.vicinity_filtration(mapped, hop, flags=KD_LP_FLAGS if flags is None else flags,
-                                                                             cap=n_cap, edge_cap=e_cap)
-        if bool((n < 0).any()) or bool((m < 0).any()):
+                                                                             cap=n_cap, edge_cap=e_cap, zero=False)
+        # packed offsets on the device; ONE host read: the two totals (to size the packed arrays) and the two capacity checks
+        E = len(n)
+        keep_n = torch.where(m > 0, n, torch.zeros_like(n)).long()         # no edge -> (None, None): an empty slice
+        node_ptr = torch.zeros(E + 1, dtype=torch.int64, device=n.device)
+        edge_ptr = torch.zeros(E + 1, dtype=torch.int64, device=n.device)
+        torch.cumsum(keep_n, 0, out=node_ptr[1:])
+        torch.cumsum(m.clamp(min=0).long(), 0, out=edge_ptr[1:])
+        lo_n, lo_m, tot_n, tot_m = torch.stack([n.min().long(), m.min().long(), node_ptr[-1], edge_ptr[-1]]).tolist() if E else (0, 0, 0, 0)
+        if lo_n < 0 or lo_m < 0:
             raise RuntimeError("vicinity larger than the requested node_cap / edge_cap")
-        n = torch.where(m > 0, n, torch.zeros_like(n))              # no edge -> (None, None)
-        node_ptr = torch.zeros(len(n) + 1, dtype=torch.int64, device=n.device)
-        node_ptr[1:] = torch.cumsum(n.long(), 0)
-        edge_ptr = torch.zeros(len(m) + 1, dtype=torch.int64, device=m.device)
-        edge_ptr[1:] = torch.cumsum(m.clamp(min=0).long(), 0)
-        # compact the capacity layout (device-side index arithmetic only)
-        tot_n, tot_m = int(node_ptr[-1]), int(edge_ptr[-1])
-        pair_of_node = torch.repeat_interleave(torch.arange(len(n), device=n.device), n.long())
-        k_node = torch.arange(tot_n, device=n.device) - node_ptr[pair_of_node]
-        src_n = offs[pair_of_node] + k_node
-        pair_of_edge = torch.repeat_interleave(torch.arange(len(m), device=m.device), m.clamp(min=0).long())
-        k_edge = torch.arange(tot_m, device=m.device) - edge_ptr[pair_of_edge]
-        src_e = eoffs[pair_of_edge] + k_edge
-        inv = torch.from_numpy(self.inv).to(n.device)
-        return dict(node_ptr=node_ptr, edge_ptr=edge_ptr, ids=inv[ids[src_n].long()], f=f[src_n], edges=edges[src_e],
-                    status=st, pair_of_node=pair_of_node, pair_of_edge=pair_of_edge)
+        if getattr(self, "_inv_dev", None) is None or self._inv_dev.device != n.device:
+            self._inv_dev = torch.from_numpy(self.inv).to(n.device)
+        out_ids, out_f, out_e, pn, pe = engine.pack_vicinities(offs, ids, f, eoffs, edges, node_ptr, edge_ptr, int(tot_n), int(tot_m),
+                                                               label=self._inv_dev)
+        return dict(node_ptr=node_ptr, edge_ptr=edge_ptr, ids=out_ids, f=out_f, edges=out_e, status=st, pair_of_node=pn, pair_of_edge=pe)
 
 
 _CACHE = {}

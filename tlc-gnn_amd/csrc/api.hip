@@ -754,12 +754,16 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     // COUNT writes the MID / MEDIUM vicinities itself at bump-allocated arena offsets (images only): the arena has to exist
     // before the sizes are known, so it starts from a guess and grows when a chunk overflows it (that chunk falls back to the
     // scan + FILL path below)
-    const bool bump = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges;
+    // (round 4: tlc_vicinity_filtration as well -- its id / f / edge outputs have caller-given offsets, so COUNT can finish the
+    // MID / MEDIUM vicinities too, ids included; the 64-thread FILL pass over a handful of MEDIUM pairs was 0.15 - 0.22 ms of a
+    // 0.45 ms call on 4 096 Amazon-shaped pairs)
+    const bool plain = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges;
+    const bool bump = true;
     unsigned long long* d_bump_top = reinterpret_cast<unsigned long long*>(ws->d_ctl + 20);
     int* d_bump_overflow = ws->d_ctl + 22;
     const bool early = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges && hop <= 2 && n_pairs >= TLC_EARLY_MIN_PAIRS;
     // hop <= 2, plain image batch: the extraction runs from the ball lists (extract.hip); otherwise the breadth-first kernels
-    bool use_x = bump && hop <= 2 && !(flags & TLC_INCLUDE_ROOTS) && g->opt_extract;
+    bool use_x = plain && hop <= 2 && !(flags & TLC_INCLUDE_ROOTS) && g->opt_extract;
     if (use_x) {
         if ((rc = ensure_ball_lists(g, hop, s)) != TLC_OK) return rc;
         use_x = g->ball_list_hop == hop;
@@ -996,7 +1000,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     // submission time costs every side stream a barrier packet on a signal that is still in flight: 60 us per chunk (measured:
     // 0.796 -> 0.733 ms per pipelined batch, tools/ab_option.py mh_always 0 3 before this was unconditional).
     TLC_HIP_CHECK(hipEventRecord(ws->ev_scan, s));
-    const bool spec = bump && mh_split;
+    const bool spec = plain && mh_split;
     size_t (&spec_base)[TLC_N_TIERS] = c.spec_base;
     int (&spec_cap)[TLC_N_TIERS] = c.spec_cap;
     for (int t = 0; t < TLC_N_TIERS; ++t) { spec_base[t] = 0; spec_cap[t] = 0; }

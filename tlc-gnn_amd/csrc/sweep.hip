@@ -299,3 +299,53 @@ extern "C" int tlc_near_pairs(int32_t n_nodes, const int32_t* d_rowptr, const in
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }
+
+// ---- tlc_pack_vicinities: the capacity layout of tlc_vicinity_filtration -> one packed block-diagonal batch ------------------
+namespace {
+// one wavefront per vicinity: its n ids (through the label table), n values and m edges from the per-pair capacity slots to
+// the packed arrays at node_ptr[i] / edge_ptr[i]; the owner of every node / edge beside them
+__global__ __launch_bounds__(256) void pack_vicinities_kernel(long long n_pairs, const long long* __restrict__ node_offs,
+                                                            const int* __restrict__ ids, const double* __restrict__ f,
+                                                            const long long* __restrict__ edge_offs, const int* __restrict__ edges,
+                                                            const long long* __restrict__ node_ptr, const long long* __restrict__ edge_ptr,
+                                                            const long long* __restrict__ label, long long* __restrict__ out_ids,
+                                                            double* __restrict__ out_f, int* __restrict__ out_edges,
+                                                            long long* __restrict__ pair_of_node, long long* __restrict__ pair_of_edge) {
+    const int lane = (int)(threadIdx.x & 63);
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwave = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long i = wave; i < n_pairs; i += nwave) {
+        const long long no = node_ptr[i], eo = edge_ptr[i];
+        const int n = (int)(node_ptr[i + 1] - no), m = (int)(edge_ptr[i + 1] - eo);
+        const long long so = node_offs[i], se = edge_offs[i];
+        for (int k = lane; k < n; k += 64) {
+            const int x = ids[so + k];
+            out_ids[no + k] = label ? label[x] : (long long)x;
+            out_f[no + k] = f[so + k];
+            if (pair_of_node) pair_of_node[no + k] = i;
+        }
+        const int2* src = reinterpret_cast<const int2*>(edges) + se;
+        int2* dst = reinterpret_cast<int2*>(out_edges) + eo;
+        for (int k = lane; k < m; k += 64) {
+            dst[k] = src[k];
+            if (pair_of_edge) pair_of_edge[eo + k] = i;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int tlc_pack_vicinities(int64_t n_pairs, const int64_t* d_node_offs, const int32_t* d_ids, const double* d_f,
+                                   const int64_t* d_edge_offs, const int32_t* d_edges, const int64_t* d_node_ptr,
+                                   const int64_t* d_edge_ptr, const int64_t* d_label, int64_t* d_out_ids, double* d_out_f,
+                                   int32_t* d_out_edges, int64_t* d_pair_of_node, int64_t* d_pair_of_edge, void* stream) {
+    TLC_REQUIRE(n_pairs >= 0, "n_pairs < 0");
+    if (n_pairs == 0) return TLC_OK;
+    TLC_REQUIRE(d_node_offs && d_edge_offs && d_node_ptr && d_edge_ptr, "null offsets");
+    long long blocks = (n_pairs + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_vicinities_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long long)n_pairs,
+                       (const long long*)d_node_offs, d_ids, d_f, (const long long*)d_edge_offs, d_edges, (const long long*)d_node_ptr,
+                       (const long long*)d_edge_ptr, (const long long*)d_label, (long long*)d_out_ids, d_out_f, d_out_edges,
+                       (long long*)d_pair_of_node, (long long*)d_pair_of_edge);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}

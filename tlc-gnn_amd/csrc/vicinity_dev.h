@@ -453,8 +453,9 @@ __device__ __forceinline__ void vicinity_pair(const TlcVicParams& p, int i, unsi
         if (tid == 0) { p.hdr_lu[i] = lu; p.hdr_lv[i] = lv; }
     }
     if (p.out_ids && (FILL || p.small_dir)) {
-        // id output of tlc_vicinity_filtration: by whichever pass finishes the pair's subgraph
-        const bool mine = FILL ? true : (n <= TLC_S_NMAX);
+        // id output of tlc_vicinity_filtration: by whichever pass finishes the pair's subgraph (COUNT: the SMALL tier's, and with a
+        // bump allocator every vicinity up to the MEDIUM tier's node count -- one whose edges then do not fit is written again by FILL)
+        const bool mine = FILL ? true : (n <= TLC_S_NMAX || (p.bump_top != nullptr && n <= TLC_M_NMAX));
         if (mine) {
             const long long no = p.ids_off[i];
             const long long cap = p.ids_off[i + 1] - no;

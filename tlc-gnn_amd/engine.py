@@ -132,24 +132,27 @@ class DeviceGraph:
                                                     C.c_int64(n_pairs), _lib.stream_ptr(self.device)), "sizes")
         return n, m2
 
-    def vicinity_filtration(self, pairs, hop, flags=0, cap=None, edge_cap=None):
+    def vicinity_filtration(self, pairs, hop, flags=0, cap=None, edge_cap=None, zero=True):
         """-> (node_offs int64[E+1], ids int32[E*cap], f float64[E*cap], n int32[E], status uint8[E])
-        with edge_cap: additionally (edge_offs int64[E+1], edges int32[E*edge_cap,2] local ids, m int32[E])"""
+        with edge_cap: additionally (edge_offs int64[E+1], edges int32[E*edge_cap,2] local ids, m int32[E]).
+        zero=False: the capacity buffers are not zero-filled (what lies beyond a pair's n / m entries is never read by a caller
+        that slices by n / m: 290 MB of fill per 4 096 pairs at node_cap 512 / edge_cap 8 192)."""
         import torch
         assert pairs.device.index == self.device, "pairs live on cuda:%s, the graph on cuda:%d" % (pairs.device.index, self.device)
         pairs = pairs.contiguous()
         E = pairs.shape[0]
         cap = self.n_nodes if cap is None else int(cap)
         dev = pairs.device
+        mk = torch.zeros if zero else torch.empty
         offs = torch.arange(E + 1, dtype=torch.int64, device=dev) * cap
-        ids = torch.zeros(max(E * cap, 1), dtype=torch.int32, device=dev)
-        f = torch.zeros(max(E * cap, 1), dtype=torch.float64, device=dev)
+        ids = mk(max(E * cap, 1), dtype=torch.int32, device=dev)
+        f = mk(max(E * cap, 1), dtype=torch.float64, device=dev)
         n = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
         st = torch.zeros(max(E, 1), dtype=torch.uint8, device=dev)
         eoffs = edges = m = None
         if edge_cap is not None:
             eoffs = torch.arange(E + 1, dtype=torch.int64, device=dev) * int(edge_cap)
-            edges = torch.zeros((max(E * int(edge_cap), 1), 2), dtype=torch.int32, device=dev)
+            edges = mk((max(E * int(edge_cap), 1), 2), dtype=torch.int32, device=dev)
             m = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
         rc = _lib.lib().tlc_vicinity_filtration(self._h, _lib.ptr(pairs), C.c_int64(E), C.c_int(hop), C.c_uint32(flags),
                                                 _lib.ptr(offs), _lib.ptr(ids), _lib.ptr(f), _lib.ptr(n), _lib.ptr(st),
@@ -158,6 +161,25 @@ class DeviceGraph:
         if edge_cap is not None:
             return offs, ids, f, n[:E], st[:E], eoffs, edges, m[:E]
         return offs, ids, f, n[:E], st[:E]
+
+
+@_lib.on_device_of
+def pack_vicinities(node_offs, ids, f, edge_offs, edges, node_ptr, edge_ptr, tot_n, tot_m, label=None, owners=True):
+    """The capacity layout of vicinity_filtration -> packed (ids int64 [tot_n], f [tot_n], edges int32 [tot_m, 2], pair_of_node,
+    pair_of_edge) at node_ptr / edge_ptr (tlc_pack_vicinities: one kernel, no host synchronisation)."""
+    torch = _lib.require_gpu()
+    dev = f.device
+    E = node_ptr.numel() - 1
+    out_ids = torch.empty(max(tot_n, 1), dtype=torch.int64, device=dev)
+    out_f = torch.empty(max(tot_n, 1), dtype=torch.float64, device=dev)
+    out_e = torch.empty((max(tot_m, 1), 2), dtype=torch.int32, device=dev)
+    pn = torch.empty(max(tot_n, 1), dtype=torch.int64, device=dev) if owners else None
+    pe = torch.empty(max(tot_m, 1), dtype=torch.int64, device=dev) if owners else None
+    rc = _lib.lib().tlc_pack_vicinities(C.c_int64(E), _lib.ptr(node_offs), _lib.ptr(ids), _lib.ptr(f), _lib.ptr(edge_offs),
+                                        _lib.ptr(edges), _lib.ptr(node_ptr), _lib.ptr(edge_ptr), _lib.ptr(label), _lib.ptr(out_ids),
+                                        _lib.ptr(out_f), _lib.ptr(out_e), _lib.ptr(pn), _lib.ptr(pe), _lib.stream_ptr())
+    _lib.check(rc, "tlc_pack_vicinities")
+    return out_ids[:tot_n], out_f[:tot_n], out_e[:tot_m], (pn[:tot_n] if owners else None), (pe[:tot_m] if owners else None)
 
 
 @_lib.on_device_of

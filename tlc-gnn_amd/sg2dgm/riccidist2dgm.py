@@ -40,6 +40,17 @@ class graph2pi():
                     self.dict_node[b] = len(self.dict_node)
             n = len(self.dict_node)
         self.n_nodes = n
+        # label -> node id as an array when the labels are small non-negative integers (the usual case): _map_pairs is then one
+        # numpy gather instead of a Python loop over the pair list (1 ms per 4 096 pairs, 9 ms for PubMed's 37 676)
+        self._lut = None
+        try:
+            keys = np.fromiter(self.dict_node.keys(), dtype=np.int64, count=len(self.dict_node))
+            if len(keys) and keys.min() >= 0 and keys.max() < 8 * max(len(keys), 1024) and all(isinstance(k, (int, np.integer)) for k in list(self.dict_node)[:64]):
+                lut = np.full(int(keys.max()) + 1, -1, dtype=np.int32)
+                lut[keys] = np.fromiter(self.dict_node.values(), dtype=np.int32, count=len(self.dict_node))
+                self._lut = lut
+        except (TypeError, ValueError):
+            self._lut = None
         # ricci_curv: [[u, v, kappa], ...] with both directions (:221-226); edge weight = kappa + 1
         self.ricci_curv = {}
         for i in ricci_curv:
@@ -77,6 +88,10 @@ class graph2pi():
 
     def _map_pairs(self, total_edges):
         te = np.asarray(total_edges).reshape(-1, 2)
+        if self._lut is not None and te.dtype.kind in "iu":
+            te = te.astype(np.int64, copy=False)
+            ok = (te >= 0) & (te < len(self._lut))
+            return np.where(ok, self._lut[np.where(ok, te, 0)], -1).astype(np.int32)
         get = self.dict_node.get
         return np.array([[get(int(a), -1), get(int(b), -1)] for a, b in te.tolist()], dtype=np.int32).reshape(-1, 2)
 

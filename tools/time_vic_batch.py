@@ -1,0 +1,35 @@
+"""Development aid: where Vicinities.batch (PDGNN fork's vicinity extraction, data_utils_LP.py:105-200) spends its time on the Amazon-shaped graphs."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from tlc_gnn_amd import synth, _lib
+from tlc_gnn_amd.Knowledge_Distillation.data_utils_LP import Vicinities, KD_LP_FLAGS
+def med(fn, reps=7):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e3
+for shape in ("Photo", "Computers"):
+    n, edges, kappa, hop, _ = synth.shaped_graph(shape)
+    ricci = np.concatenate([np.concatenate([edges, kappa[:, None]], 1), np.concatenate([edges[:, ::-1], kappa[:, None]], 1)]).tolist()
+    vic = Vicinities(edges, ricci)
+    rs = np.random.RandomState(1234)
+    pairs = edges[rs.permutation(len(edges))[:4096]]
+    g = vic._g2p._device_graph()
+    mapped = torch.from_numpy(vic._g2p._map_pairs(pairs)).cuda()
+    t_batch = med(lambda: vic.batch(pairs, hop, node_cap=512, edge_cap=8192))
+    t_call = med(lambda: g.vicinity_filtration(mapped, hop, flags=KD_LP_FLAGS, cap=512, edge_cap=8192))
+    t_map = med(lambda: torch.from_numpy(vic._g2p._map_pairs(pairs)).cuda())
+    def alloc():
+        E = 4096
+        torch.zeros(E * 512, dtype=torch.int32, device="cuda"); torch.zeros(E * 512, dtype=torch.float64, device="cuda")
+        torch.zeros((E * 8192, 2), dtype=torch.int32, device="cuda")
+    t_alloc = med(alloc)
+    b = vic.batch(pairs, hop, node_cap=512, edge_cap=8192)
+    print(shape, "batch %.3f ms | C call incl. buffers %.3f | zero-filled buffers alone %.3f | pair mapping + H2D %.3f | nodes %d edges %d" % (
+        t_batch, t_call, t_alloc, t_map, int(b["node_ptr"][-1]), int(b["edge_ptr"][-1])), flush=True)
+    g.set_timing(True)
+    g.vicinity_filtration(mapped, hop, flags=KD_LP_FLAGS, cap=512, edge_cap=8192)
+    print("   kernels:", {k: round(v, 4) for k, v in g.timings().items() if v >= 0}, g.stats())
+    g.set_timing(False)
