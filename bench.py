@@ -111,6 +111,50 @@ def measure_traffic():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def measure_issue():
+    """roofline_issue measured INSIDE this run: one more child pass of this script under `rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS
+    SQ_INSTS_SALU` (counters only, program directly behind `--`), 3 batches; -> (dict of wave-instructions per image batch summed
+    over the PD/PI kernels, detail) or (None, reason).  Called BEFORE this process touches the GPU, like measure_traffic."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="tlc_pmc_issue_")
+    env = dict(os.environ, TLC_BENCH_CHILD="1")
+    try:
+        cmd = [exe, "--pmc", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "--output-format", "csv", "-d", os.path.join(tmp, "issue"), "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-sweep"]
+        pr = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = pr.wait(timeout=240)
+        except subprocess.TimeoutExpired:
+            os.killpg(pr.pid, signal.SIGKILL)
+            pr.wait()
+            return None, "the SQ_INSTS pass timed out"
+        if rc != 0:
+            return None, "the SQ_INSTS pass failed (rc %d)" % rc
+        tot, per_kernel, scans = {}, {}, 0
+        for f in glob.glob(os.path.join(tmp, "issue") + "/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                k, c = row["Kernel_Name"], row.get("Counter_Name")
+                if not k.startswith(("tlc_", "void tlc_")) or "tlc_pi_raster" in k or "ball_" in k:
+                    continue                                      # (the image batch's kernels; the one-off ball lists are set-up)
+                v = float(row["Counter_Value"])
+                tot[c] = tot.get(c, 0.0) + v
+                per_kernel.setdefault(k[:60], {}).setdefault(c, 0.0)
+                per_kernel[k[:60]][c] += v
+                if c == "SQ_INSTS_VALU" and "tlc_scan_bin" in k:
+                    scans += 1
+        if not tot or scans == 0:
+            return None, "no counter rows collected"
+        return {c: v / scans for c, v in tot.items()}, {"batches_in_pass": scans,
+                                                        "per_kernel_valu": {k: v.get("SQ_INSTS_VALU", 0.0) / scans for k, v in per_kernel.items()}}
+    except Exception as ex:
+        return None, repr(ex)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def pdgnn_aux(torch, dev, n_graphs=41127, seed=1234):
     """PDGNN forward vs exact PD on HIV-shaped molecules -- as many graphs as ogbg-molhiv holds (41 127, data_utils_GC.py:284; config 5
     of BASELINE.json): graphs/s of each (device-resident inputs, median of 5)."""
@@ -332,9 +376,11 @@ def main():
 
     # roofline.traffic: two child passes of this script under rocprofv3 --pmc, BEFORE this process initialises the GPU
     pre_traffic, pre_traffic_detail = None, "not attempted"
+    pre_issue, pre_issue_detail = None, "not attempted"
     if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_sweep and not args.no_traffic \
             and not os.environ.get("TLC_BENCH_CHILD"):
         pre_traffic, pre_traffic_detail = measure_traffic()
+        pre_issue, pre_issue_detail = measure_issue()
 
     import torch
     from tlc_gnn_amd import engine, ops, dist as tdist, _lib
@@ -911,6 +957,28 @@ def main():
                                  "passes over this command; bytes per launch%s" % (tj.get("_collected", "round-1 profile"), why)
             except Exception:
                 traffic = None
+        # what actually bounds the image leg: vector issue.  VALU wave-instructions per batch (counter pass above) x 4 cycles (a
+        # wave64 instruction occupies its SIMD16 for four cycles) against the 1 024 SIMDs x clock x the time a batch takes.
+        roofline_issue = None
+        if pre_issue is not None:
+            props = torch.cuda.get_device_properties(dev)
+            clk = float(getattr(props, "clock_rate", 2400000)) * 1e3                      # Hz (the device's maximum shader clock)
+            simds = int(props.multi_processor_count) * 4
+            valu = float(pre_issue.get("SQ_INSTS_VALU", 0.0))
+            per_batch_s = t_pi / K
+            roofline_issue = {"bound": "valu-issue", "valu_wave_insts_per_batch": valu, "lds_wave_insts_per_batch": pre_issue.get("SQ_INSTS_LDS"),
+                              "salu_wave_insts_per_batch": pre_issue.get("SQ_INSTS_SALU"), "cycles_per_wave_inst": 4,
+                              "simds": simds, "clock_hz": clk, "clock_source": "device property (maximum shader clock)",
+                              "achieved": valu * 4.0 / per_batch_s, "peak": simds * clk, "unit": "SIMD-cycles/s",
+                              "frac": valu * 4.0 / (simds * clk * per_batch_s),
+                              "frac_one_batch_alone": valu * 4.0 / (simds * clk * float(np.median(lat_plain)) * 1e-3),
+                              "source": "measured in this run: child pass under rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU, "
+                                        "%d batches; sums over every kernel of the image batch" % pre_issue_detail["batches_in_pass"],
+                              "per_kernel_valu_wave_insts": pre_issue_detail["per_kernel_valu"],
+                              "note": "share of the machine's vector issue slots the image leg uses in the timed region (pipelined) / for one "
+                                      "batch alone; the rest is dependent-latency time (LDS / L2 round trips of serial graph code)"}
+        else:
+            roofline_issue = {"error": str(pre_issue_detail)}
         out = {
             "metric": "persistence-images/sec + LP-forward edges/sec, PubMed-scale, 1/2/4/8 GPU",
             "value": world * E * K / t_pi,
@@ -947,6 +1015,7 @@ def main():
                          "note": "kernel_ms: this kernel chain's launches INSIDE the timed region, where three batches are in flight and "
                                  "its whole-CU workgroups wait for room among the other batches' kernels; kernel_ms_one_batch_alone: "
                                  "the same chain in a stream-ordered batch with the machine to itself (warm-up steps)"},
+            "roofline_issue": roofline_issue,
             "roofline_chain": {"bound": "hbm", "algorithmic_bytes_per_pi": all_bytes / E,
                                "achieved": all_bytes * world * K / t_pi / 1e9, "peak": HBM_PEAK_GBS * world,
                                "unit": "GB/s", "frac": all_bytes * K / t_pi / 1e9 / HBM_PEAK_GBS},
