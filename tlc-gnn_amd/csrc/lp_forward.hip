@@ -378,6 +378,229 @@ static hipError_t gemm16_launch(int M, int N, int K, const float* A, const float
 }
 
 // ======================================================================================================================
+// Round 4: the same product with B RESIDENT in LDS and no barrier inside the K loop.  (gemm16_f32_kernel above synchronises its
+// eight wavefronts after every 32-k chunk -- one 16-k block of MFMAs per wavefront between barriers -- and stages A through
+// LDS although every A row tile belongs to exactly one wavefront: its matrix pipes were busy 58 % of the time a CU was busy,
+// 31 us = 40 % of the f32 MFMA peak on PubMed's 19 717 x 500 x 100.)  Same workgroup tile (80 rows x NT*16 columns, eight
+// wavefronts = two K groups of four, 247 workgroups = one round on 256 CUs), same accumulator layout and epilogue, but:
+//   * K runs in PHASES of 128: the phase's slice of B (128 x NP, stored [k/4][col][k%4] so that a lane's four MFMA steps of a
+//     column tile are ONE ds_read_b128) sits in one of two LDS buffers; the next phase's slice goes from global memory STRAIGHT
+//     into the other buffer (buffer_load ... lds, no registers) while this phase's MFMAs run: one barrier per 128 k, four for K = 500;
+//   * A never touches LDS: lane (row, g) loads the 16 bytes  A[row][16 kb + 4 g ..]  of each of its blocks straight into the
+//     MFMA operand registers, a whole phase ahead (row tile w of the wavefront and the shared fifth row tile);
+//   * inside a phase a wavefront runs its four 16-k blocks back to back: nine ds_read_b128 (read one block ahead) and 36 MFMAs
+//     per block, with the other wavefront of its SIMD filling the gaps.
+// ======================================================================================================================
+#define GBR_KH 128                                           /* k per phase */
+#ifdef TLC_GBR_DEBUG
+__device__ unsigned long long g_gbr_dbg[16];                 // cycle sums of wavefront 0 of every workgroup: see GBR_STAMP
+#define GBR_STAMP(k) do { const unsigned long long _t = clock64(); if (tid == 0) atomicAdd(&g_gbr_dbg[(k)], _t - t_prev); t_prev = _t; } while (0)
+#else
+#define GBR_STAMP(k) do { } while (0)
+#endif
+template <int NT>
+struct GbrLayout {
+    static constexpr int NP = NT * 16;
+    // one phase of B = the 128 rows of the slice exactly as they lie in global memory (row stride N <= NP), rounded up to the 1 KiB
+    // pieces it arrives in, plus the reach of the last row's column tiles beyond N
+    static constexpr int B_WORDS = ((GBR_KH * NP * 4 + 1023) / 1024) * 256 + 64;
+    static constexpr int SB = NP + 4, C_WORDS = G16_BM * SB;
+    static constexpr int LDS_BYTES = 4 * (2 * B_WORDS > C_WORDS ? 2 * B_WORDS : C_WORDS);
+};
+
+template <int NT, int KS>
+__global__ __launch_bounds__(256 * KS) void gemm_bres_f32_kernel(int M, int N, int K, const float* __restrict__ A, const float* __restrict__ B,
+                                                            const float* __restrict__ bias, int relu, float* __restrict__ C) {
+    using L = GbrLayout<NT>;
+    constexpr int TH = 256 * KS, NP = L::NP, SB = L::SB;
+    constexpr int XT = (NT + 3) / 4;                        // column tiles of the fifth row tile per wave
+    constexpr int NB = NT + XT;
+    constexpr int BLK = GBR_KH / 16 / KS;                   // 16-k blocks per wavefront and phase (KS K groups)
+    constexpr int NWV = 4 * KS;                             // wavefronts of the workgroup
+    constexpr int BITEMS = (GBR_KH / 4) * NP;               // (k-quad, column) items of one phase of B
+    constexpr int BQ = (BITEMS + TH - 1) / TH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, ks = tid >> 8;
+    const int l16 = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * G16_BM;
+
+#ifdef TLC_GBR_DEBUG
+    unsigned long long t_prev = clock64();
+#endif
+    f32x4 acc[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int xcol[XT];                                           // clamped: a wave without a real extra tile repeats the last one
+#pragma unroll
+    for (int x = 0; x < XT; ++x) xcol[x] = (wave * XT + x < NT ? wave * XT + x : NT - 1) * 16;
+
+    const int rows_here = min(G16_BM, M - row0);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (size_t)row0 * K), 0, rows_here * K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, K * N * 4, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+    const int nph = (K + GBR_KH - 1) / GBR_KH;
+    // A operands of one phase: blocks ks*BLK .. of the phase, row tile `wave` (a0) and the fifth row tile (a1)
+    const int ra0 = (wave * 16 + l16) * K, ra1 = (64 + l16) * K;
+    auto load_a0 = [&](int ph, int i) __attribute__((always_inline)) -> u32x4 {                        // block i of this wavefront's share of phase ph: row tile `wave`
+        const int k = ph * GBR_KH + (ks * BLK + i) * 16 + g * 4;
+        return __builtin_amdgcn_raw_buffer_load_b128(rsA, k < K ? (ra0 + k) * 4 : OOB, 0, 0);
+    };
+    auto load_a1 = [&](int ph, int i) __attribute__((always_inline)) -> u32x4 {                        // ... the shared fifth row tile
+        const int k = ph * GBR_KH + (ks * BLK + i) * 16 + g * 4;
+        return __builtin_amdgcn_raw_buffer_load_b128(rsA, k < K ? (ra1 + k) * 4 : OOB, 0, 0);
+    };
+    // One phase of B straight from global memory into LDS (buffer_load_dwordx4 ... lds: no registers in between, so the whole next
+    // slice is requested at the start of a phase and lands under its MFMAs).  The slice's 128 rows are contiguous in global memory
+    // (B is row-major [K][N]) and are copied as they are, in 1 KiB pieces (64 lanes x 16 bytes): ceil(N / 2) pieces per slice, dealt
+    // to the wavefronts round-robin.  (Dword pieces into a [k/4][col][k%4] image -- one ds_read_b128 per operand tile -- were
+    // measured first: 224 pieces per slice at ~100 cycles of issue each, the wavefronts waited 6 500 cycles per phase for them.)
+    // Rows >= K fall behind the descriptor: zeros.  Columns >= N of an operand tile read the next row's start: never stored.
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int npieces = (GBR_KH * N * 4 + 1023) >> 10;
+    auto issue_b = [&](int ph, int buf) __attribute__((always_inline)) {
+        const int vbase = ph * GBR_KH * N * 4 + lane * 16;
+        for (int q = wave8; q < npieces; q += NWV)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)&smem[buf * L::B_WORDS + q * 256], 16, vbase, q * 1024, 0, 0);
+    };
+    constexpr int BQ_UNUSED = BQ;
+    (void)BQ_UNUSED;
+    struct Bops { f32x4 b[NB]; };
+    auto read_b = [&](Bops& o, int buf, int blk) __attribute__((always_inline)) {           // blk: block of the phase (0 .. KH/16)
+        const float* base = &smem[buf * L::B_WORDS + (blk * 16 + g * 4) * N + l16];
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o.b[t][sidx] = base[sidx * N + t * 16];
+#pragma unroll
+            for (int x = 0; x < XT; ++x) o.b[NT + x][sidx] = base[sidx * N + xcol[x]];
+        }
+    };
+
+    // Two named operand sets (an array indexed by the phase parity would go to scratch).  A phase's A operands are requested TOGETHER
+    // at the start of the phase before it: the BLK loads of a row are 64 BLK contiguous bytes issued back to back (one DRAM page
+    // while it is open); issued one per block, 0.5 us apart, every 64-byte piece paid an activation of its own and the wavefronts
+    // waited 6 500 cycles per phase for them.
+    u32x4 xa0[BLK], xa1[BLK], ya0[BLK], ya1[BLK];
+    auto phase = [&](int ph, int buf, const u32x4 (&ca0)[BLK], const u32x4 (&ca1)[BLK], u32x4 (&na0)[BLK], u32x4 (&na1)[BLK]) __attribute__((always_inline)) {
+#ifndef TLC_GBR_SKIP_B                                       /* (diagnostic builds: which operand stream the wavefronts wait for) */
+        issue_b(ph + 1, buf ^ 1);                            // (the other buffer: its last readers passed the barrier of the phase before)
+#endif
+#ifndef TLC_GBR_SKIP_A
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) { na0[i] = load_a0(ph + 1, i); na1[i] = load_a1(ph + 1, i); }
+#else
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) { na0[i] = ca0[i]; na1[i] = ca1[i]; }
+#endif
+        constexpr int NO = KS <= 2 ? 2 : 1;                  // (four wavefronts per SIMD hide an LDS round trip themselves: one operand set)
+        Bops o[NO];
+        read_b(o[0], buf, ks * BLK);
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) {
+            if (NO == 2 && i + 1 < BLK) read_b(o[(i + 1) & 1], buf, ks * BLK + i + 1);
+            if (NO == 1 && i > 0) read_b(o[0], buf, ks * BLK + i);
+            const f32x4 fa0 = __builtin_bit_cast(f32x4, ca0[i]), fa1 = __builtin_bit_cast(f32x4, ca1[i]);
+            __builtin_amdgcn_sched_barrier(0);              // keep the reads and requests ahead of the matrix pipe
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[sidx], o[i & (NO - 1)].b[t][sidx], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int x = 0; x < XT; ++x) acc[NT + x] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[sidx], o[i & (NO - 1)].b[NT + x][sidx], acc[NT + x], 0, 0, 0);
+            }
+        }
+        GBR_STAMP(1);                                        // [1] a phase's MFMAs issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wavefront's part of the next slice is in LDS ...
+        GBR_STAMP(2);                                        // [2] waiting for its own loads
+        __syncthreads();                                     // ... and everybody's
+        GBR_STAMP(3);                                        // [3] barrier
+    };
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) { xa0[i] = load_a0(0, i); xa1[i] = load_a1(0, i); }
+    issue_b(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    GBR_STAMP(0);                                            // [0] prologue: first operands in
+    for (int ph = 0; ph < nph; ph += 2) {
+        phase(ph, 0, xa0, xa1, ya0, ya1);
+        if (ph + 1 < nph) phase(ph + 1, 1, ya0, ya1, xa0, xa1);      // (uniform)
+    }
+    // accumulators -> LDS tile (C/D layout of 16x16x4: col = lane&15, row = 4*(lane>>4) + reg), summed over the two K groups,
+    // then streamed out as whole rows (as in gemm16_f32_kernel)
+    float* const Cs = smem;
+    auto tile_rows = [&](auto&& fn) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fn(acc[t][r], (wave * 16 + 4 * g + r) * SB + t * 16 + l16);
+#pragma unroll
+        for (int x = 0; x < XT; ++x)
+            if (wave * XT + x < NT)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fn(acc[NT + x][r], (64 + 4 * g + r) * SB + xcol[x] + l16);
+    };
+#pragma unroll
+    for (int part = KS - 1; part >= 0; --part) {
+        if (ks == part) {
+            if (part == KS - 1) tile_rows([&](float v, int off) { Cs[off] = v; });
+            else tile_rows([&](float v, int off) { Cs[off] += v; });
+        }
+        __syncthreads();
+    }
+    const int n4 = N >> 2;
+    for (int idx = tid; idx < G16_BM * n4; idx += TH) {
+        const int r = idx / n4, c = (idx - r * n4) * 4;
+        if (row0 + r >= M) break;
+        float4 v = *reinterpret_cast<const float4*>(&Cs[r * SB + c]);
+        if (bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(C + (size_t)(row0 + r) * N + c) = v;
+    }
+    GBR_STAMP(4);                                            // [4] epilogue (K-group sums through LDS, row stores issued)
+#ifdef TLC_GBR_DEBUG
+    if (tid == 0) atomicAdd(&g_gbr_dbg[15], 1ull);
+#endif
+}
+
+#ifndef TLC_GBR_KS
+#define TLC_GBR_KS 2
+#endif
+template <int NT>
+static hipError_t gemm_bres_launch(int M, int N, int K, const float* A, const float* B, const float* bias, int relu, float* C, hipStream_t s) {
+    static bool attr_set[64] = {};
+    constexpr int KS = TLC_GBR_KS;
+    auto kern = gemm_bres_f32_kernel<NT, KS>;
+    constexpr int lds = GbrLayout<NT>::LDS_BYTES;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((M + G16_BM - 1) / G16_BM), dim3(256 * KS), lds, s, M, N, K, A, B, bias, relu, C);
+#ifdef TLC_GBR_DEBUG
+    {
+        static int calls = 0;
+        if (++calls == 50) {                                  // (one report, once warm)
+            unsigned long long h[16], z[16] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gbr_dbg), z, sizeof(z));
+            hipLaunchKernelGGL(kern, dim3((M + G16_BM - 1) / G16_BM), dim3(256 * KS), lds, s, M, N, K, A, B, bias, relu, C);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gbr_dbg), sizeof(h));
+            const double w = (double)(h[15] ? h[15] : 1);
+            fprintf(stderr, "[gemm_bres %d x %d x %d] cycles of wavefront 0, mean over %llu workgroups: prologue %.0f | MFMA phases %.0f | own loads %.0f | barrier %.0f | epilogue %.0f\n",
+                    M, K, N, h[15], h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w);
+        }
+    }
+#endif
+    return hipGetLastError();
+}
+
+// ======================================================================================================================
 // Skinny-K variant of the same product: K = 16 / 32 / 64 (the PDGNN layers: x_l, [P|Q|alpha], the edge head), M in the millions.
 // With one or two K chunks the tiled kernel above is all prologue and epilogue (274 us for [1M,32] @ [32,68], 1.5 TB/s of its
 // 411 MB); here nothing goes through LDS: the whole B sits in registers in MFMA operand layout (K/4 x NT floats per lane),
@@ -758,6 +981,19 @@ extern "C" int tlc_gemm_f32(int32_t M, int32_t N, int32_t K, const float* d_A, c
         }
     }
     hipError_t le = hipSuccess;
+    // enough K for phases of 128 and 16-byte operands: B resident in LDS, no barrier inside the K loop (TLC_GEMM_BRES=0: the chunked kernel)
+    static const bool bres_on = !(getenv("TLC_GEMM_BRES") && getenv("TLC_GEMM_BRES")[0] == '0');
+    if (bres_on && vec && K >= 128 && (long long)G16_BM * K * 4 < (1ll << 31)) {
+#define TLC_GBR(NT_) case NT_: le = gemm_bres_launch<NT_>(M, N, K, d_A, d_B, d_bias, relu, d_C, s); break;
+        switch ((N + 15) / 16) {
+            TLC_GBR(1) TLC_GBR(2) TLC_GBR(3) TLC_GBR(4) TLC_GBR(5) TLC_GBR(6) TLC_GBR(7) TLC_GBR(8)
+            default: break;
+        }
+#undef TLC_GBR
+        TLC_HIP_CHECK(le);
+        TLC_HIP_CHECK(hipGetLastError());
+        return TLC_OK;
+    }
 #define TLC_G16(NT_)                                                                              \
     case NT_:                                                                                     \
         le = vec ? gemm16_launch<NT_, true, 2, 32>(M, N, K, d_A, d_B, d_bias, relu, d_C, s)       \
