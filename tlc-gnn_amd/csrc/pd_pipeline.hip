@@ -2050,8 +2050,15 @@ __device__ __forceinline__ void raster_fold(const double (&acc)[R2], double (*st
     }
 }
 
+// (three workgroups per CU need <= 168 VGPRs: at resolution 5 that costs 18 spilled VGPRs and 176 B of scratch per lane.  Two per CU
+// and no scratch -- make EXTRA=-DTLC_RASTER_OCC3_MAXRES=4 -- was measured in round 4 (tools/time_raster.py, same box): uniform
+// 48-point diagrams 39.1 vs 38.8 us, the batch-shaped mix 86.0 vs 81.1, the erfc range 334 vs 300: the spills sit outside the
+// series loops and the third workgroup hides more latency than they cost.  Three stay.)
+#ifndef TLC_RASTER_OCC3_MAXRES
+#define TLC_RASTER_OCC3_MAXRES 5
+#endif
 template <int RES>
-__global__ __launch_bounds__(256, (RES <= 5 ? 3 : 2)) void tlc_pi_raster_kernel(int n_dgms, int dpb, const long long* __restrict__ offs,
+__global__ __launch_bounds__(256, (RES <= TLC_RASTER_OCC3_MAXRES ? 3 : 2)) void tlc_pi_raster_kernel(int n_dgms, int dpb, const long long* __restrict__ offs,
                                                             const double* __restrict__ pts, double* __restrict__ out) {
     constexpr int R2 = RES * RES;
     __shared__ long long s_k[16], s_o[16];
