@@ -128,7 +128,7 @@ static_assert(2 * (size_t)TM * 64 + (size_t)TN * 64 <= 5 * (size_t)TN * 64, "ord
 // from the arena through a tier list (slot = 64 list positions).
 // one slot of 64 subgraphs on one wavefront; `lds`: the wavefront's TINY_WG_BYTES
 template <bool REC>
-__device__ __forceinline__ void tiny_slot(const TlcPdParams& p, unsigned char* lds, int lane, int slot) {
+__device__ __forceinline__ void tiny_slot(const TlcPdParams p, unsigned char* lds, int lane, int slot) {
     // carve (see the region table above)
     LaneArr<double> ew{(double*)(lds + T_OA) + lane};
     const LaneArr<double>& key = ew;                  // (the sort keys take the weights' place once f is final)
