@@ -700,13 +700,14 @@ def main():
                 e1.record()
                 dev_ms.append((e0, e1))
                 return res
-            for it in range(4):
+            for it in range(6):
                 barrier()
                 c0 = time.perf_counter()
                 rows_s, st_s, part = tdist.pd_pi_batch_sharded(run_timed, near, world, rank, cost=cost, gather=gather)
                 barrier()
                 reps.append(time.perf_counter() - c0)
             my_ms = float(np.median([a.elapsed_time(b) for a, b in dev_ms[1:]]))
+            strong_runs = [float(r) for r in reps]
             tt = torch.tensor([float(np.median(reps[1:]))], dtype=torch.float64, device=dev)
             per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
             per_rank[rank] = my_ms
@@ -719,12 +720,12 @@ def main():
             strong = {"pairs": int(len(near_np)), "seconds": sdt, "images_per_sec": len(near_np) / sdt,
                       "shard_pairs": [int(len(p_)) for p_ in parts],
                       "shard_cost": [float(cost[p_].sum()) for p_ in parts],
-                      "rank_device_ms": [float(v) for v in per_rank.tolist()],
+                      "rank_device_ms": [float(v) for v in per_rank.tolist()], "runs_s": strong_runs,
                       "rows_gathered_on_every_rank": bool(world > 1), "nonzero_rows": int((rows_s.abs().sum(1) > 0).sum()),
                       "note": "strong scaling: fixed list (all non-adjacent pairs with d(u,v) <= hop) dealt to the ranks by descending "
                               "estimated cost (cost = smaller ball-size bound of the endpoints; boustrophedon, so no rank owns the "
                               "heavy tail), rows gathered back to list order with one all-gather; `seconds`: host wall clock, median "
-                              "of 3, max over ranks; rank_device_ms: every rank's own HIP-event time of its shard"}
+                              "of 5 (the first call, which sizes the buffers, left out; `runs_s` has all six of rank 0), max over ranks; rank_device_ms: every rank's own HIP-event time of its shard"}
             del rows_s, st_s, near, ranks, ci
             g.pd_pi_batch(pi_pairs, hop, out=pi_out, status=pi_status)
             torch.cuda.synchronize()

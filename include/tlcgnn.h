@@ -179,6 +179,10 @@ int tlc_debug_dc_stats(tlc_graph* g, long long* h_out, void* stream);
  * chunk: h_out[0] = candidates, h_out[1] = pairs it finished as records for the lane-per-subgraph kernel.  Options "xl_cut",
  * "xl_ncut", "xl_mcut" (tests: what it keeps, <= 16 nodes / 24 edges) through tlc_debug_set_option. */
 int tlc_debug_xl_stats(tlc_graph* g, long long* h_out, void* stream);
+/* The tier lists of the last tlc_pd_pi_batch call as the device cut them, h_out[8]: small, medium (the compact kernel configuration,
+ * <= 384 nodes / 512 edges), large, huge, mid, tiny, medium with many Pos edges, medium beyond the compact configuration (<= 512 /
+ * 1024).  tlc_pd_pi_batch_stats reports tiny with small and the three medium lists as one. */
+int tlc_debug_tier_counts(tlc_graph* g, long long* h_out, void* stream);
 int tlc_debug_phase_profile(tlc_graph* g, int enable, unsigned long long* h_out, int64_t cap_u64, int32_t* n_rows);
 /* (builds with PAIR_TIMES=1 only: wall-clock stamps of the extraction, h_out[n_pairs][16] ticks of 10 ns; zeros otherwise) */
 int tlc_debug_pair_times(tlc_graph* g, unsigned long long* h_out, int64_t n_pairs);

@@ -109,11 +109,15 @@ def test_tier_classification_mirrors_kernel_constants():
                                   ("pd_tier_large", vals["TLC_L_NMAX"], vals["TLC_L_MMAX"])]
     tiny = {k: int(v) for k, v in re.findall(r"#define (TLC_T_[NM]MAX|TLC_MH_MIN_POS) (\d+)", hdr)}
     assert engine.TINY_LIMITS == (tiny["TLC_T_NMAX"], tiny["TLC_T_MMAX"]) and engine.MEDIUM_MANY_POS == tiny["TLC_MH_MIN_POS"]
-    n = np.array([0, 10, 16, 17, 16, 64, 65, 128, 129, 512, 300, 300, 513, 3000])
-    m2 = np.array([0, 20, 48, 48, 50, 256, 10, 512, 10, 2048, 2 * (299 + 119), 2 * (299 + 120), 10, 10])
+    comp = {k: int(v) for k, v in re.findall(r"#define (TLC_C_[NM]MAX) (\d+)", hdr)}
+    assert engine.MEDIUM_COMPACT == (comp["TLC_C_NMAX"], comp["TLC_C_MMAX"])
+    n = np.array([0, 10, 16, 17, 16, 64, 65, 128, 129, 512, 300, 300, 513, 3000, 384, 385, 300])
+    m2 = np.array([0, 20, 48, 48, 50, 256, 10, 512, 10, 2048, 2 * (299 + 119), 2 * (299 + 120), 10, 10, 2 * 512, 2 * 512, 2 * 513])
     t = engine.tier_of(n, m2)
+    # (the vicinities beyond the compact configuration -- 512 nodes, 385 nodes, 513 edges -- go with the many-Pos ones)
     assert t.tolist() == ["", "pd_tier_tiny", "pd_tier_tiny", "pd_tier_small", "pd_tier_small", "pd_tier_small", "pd_tier_mid", "pd_tier_mid",
-                          "pd_tier_medium_rest", "pd_tier_medium", "pd_tier_medium_rest", "pd_tier_medium", "pd_tier_large", "pd_tier_huge"]
+                          "pd_tier_medium_rest", "pd_tier_medium", "pd_tier_medium_rest", "pd_tier_medium", "pd_tier_large", "pd_tier_huge",
+                          "pd_tier_medium", "pd_tier_medium", "pd_tier_medium"]
     assert engine.tier_of(n, m2, tiny=False).tolist()[1:3] == ["pd_tier_small", "pd_tier_small"]
 
 

@@ -3,7 +3,8 @@
   * the divide-and-conquer cycle swap (tlc_pd_dc_kernel, csrc/ext1_dc.h): LARGE-tier vicinities with 159 / 160 / 161 Pos edges
     (TLC_DC_MIN_POS = 160), with long runs of equal keys (not attempted), and with every solve forced to fail (the give-back
     to the serial walk) -- asserted through tlc_debug_dc_stats, rows against the oracle;
-  * the MEDIUM tier's cut by Pos-edge count (TLC_MH_MIN_POS = 120): 119 / 120 / 121;
+  * the MEDIUM tier's cut by Pos-edge count (TLC_MH_MIN_POS = 120): 119 / 120 / 121; its compact / wide kernel configurations at
+    384 | 385 nodes and 512 | 513 edges;
   * the lane-per-subgraph kernel (pd_tiny.hip): vicinities at 16 / 17 nodes and 24 / 25 edges, tied weights, on and off;
   * a seeded random sweep over graph families, weight styles, hops and flags (the former tests/aids/fuzz_parity.py).
 Every vicinity here is built as "hub + leaves + chords": the pair (hub, leaf) sees the whole component at hop 2, so its node,
@@ -107,6 +108,52 @@ def test_medium_tier_cut_by_pos_edges(k_pos, many):
     stats = g.stats()
     assert stats["tier_medium"] == len(pairs)
     assert stats["tier_medium_many_pos"] == (len(pairs) if many else 0)
+    g.close()
+
+
+@pytest.mark.parametrize("n,m", [(384, 512), (385, 512), (384, 513), (300, 513), (512, 1024), (450, 600)])
+def test_medium_compact_and_wide_configurations(n, m):
+    """The MEDIUM tier runs kernels sized for 384 nodes / 512 edges (26 KB of LDS, six workgroups per CU); one node or one edge
+    more and a vicinity goes to a list of the 512 / 1024 configuration (the many-Pos list of a chunk on its own, a list of its own
+    in pipelined chunks).  At the cut, either way the oracle's rows -- and in one batch with the other kind, in pipelined chunks
+    and with the speculative slots exhausted."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    rs = np.random.RandomState(n * 7 + m)
+    other = (450, 640) if (n <= 384 and m <= 512) else (301, 420)
+    comps, pairs, base = [], [], 0
+    for nn, mm, cnt in ((n, m, 24), (other[0], other[1], 8)):
+        comps.append(hub_component(nn, mm, rs, base))
+        pairs += [[base, base + k] for k in range(1, cnt + 1)]
+        base += nn
+    e = np.concatenate(comps)
+    rowptr, col, w = synth.edges_to_csr(base, e, rs.uniform(-0.5, 0.9, size=len(e)))
+    pairs = np.array(pairs)[rs.permutation(len(pairs))]
+    g = engine.DeviceGraph(rowptr, col, w)
+    ref_out, ref_st = _check(g, torch, rowptr, col, w, pairs)
+    tc = g.tier_counts()
+    wide = 24 if (n > 384 or m > 512) else 8
+    many = 24 if (n <= 384 and m <= 512 and m - n + 1 >= 120) else (8 if (other[0] <= 384 and other[1] - other[0] + 1 >= 120) else 0)
+    # a chunk on its own: the wide ones go with the many-Pos ones (the first, speculative launch; the wide kernels)
+    assert tc["medium_wide"] == 0 and tc["medium_many_pos"] == wide + many and tc["medium"] == 32 - wide - many, tc
+    assert g.stats()["tier_medium"] == 32
+    g.set_option("spec_cap", 4)                                  # most of both lists beyond their reserved hand-off slots
+    for _ in range(2):
+        out, st = _check(g, torch, rowptr, col, w, pairs)
+        assert np.array_equal(out, ref_out) and np.array_equal(st, ref_st)
+    g.set_option("spec_cap", 0)
+    # pipelined chunks (no split by Pos edges, no speculative launch): the same rows
+    dev = torch.as_tensor(np.ascontiguousarray(pairs, dtype=np.int32)).cuda()
+    outs = [torch.empty((len(pairs), 25), dtype=torch.float64, device="cuda") for _ in range(3)]
+    sts = [torch.empty(len(pairs), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    for k in range(3):
+        g.pd_pi_batch(dev, 2, out=outs[k], status=sts[k], async_=True)
+    g.join()
+    torch.cuda.synchronize()
+    tc = g.tier_counts()                                         # (of the last call = the last chunk submitted)
+    assert tc["medium_wide"] == wide and tc["medium"] == 32 - wide and tc["medium_many_pos"] == 0, tc
+    for k in range(3):
+        assert np.array_equal(outs[k].cpu().numpy(), ref_out) and np.array_equal(sts[k].cpu().numpy(), ref_st)
     g.close()
 
 

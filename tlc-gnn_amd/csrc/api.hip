@@ -33,7 +33,7 @@ extern "C" int tlc_device_count(void) {
 }
 
 #define TLC_CHUNK_PAIRS (1 << 20)
-#define TLC_N_SIDE 7
+#define TLC_N_SIDE 8
 // early pass (run_chunk): at most this many predicted-heavy pairs are counted ahead of the batch, at most this many LARGE-tier
 // vicinities among them get a slot of the early arena (12 B x 2*TLC_L_MMAX entries each)
 #define TLC_EARLY_CAND 512
@@ -167,6 +167,7 @@ struct tlc_graph {
     int ball_hop;
     int* d_ball_ub[2];
     long long last_stats[10];
+    long long last_tc[TLC_N_TIERS];    // the scan's own tier counts of the last call (tlc_debug_tier_counts)
     long long acc_tie, acc_entries; // tie-fallback sources / induced entries of the chunks whose workspace was taken again within the call
     unsigned long long* d_phase;   // diagnostics: [TLC_N_TIERS][32] cycle counters, null unless enabled
     unsigned long long* d_pair_t;  // diagnostics (PAIR_TIMES builds): [cap][4] wall-clock stamps per pair of the extraction
@@ -287,8 +288,10 @@ static int ensure_handoff(tlc_graph* g, Workspace* ws, size_t bytes) {
 }
 
 static int ensure_handoff_large(tlc_graph* g, Workspace* ws, size_t slots) {
-    const size_t bytes = slots * tlc_handoff_slot_bytes(TLC_TIER_LARGE);
-    if (bytes <= ws->cap_handoff_large) return TLC_OK;
+    if (slots * tlc_handoff_slot_bytes(TLC_TIER_LARGE) <= ws->cap_handoff_large) return TLC_OK;
+    // (a quarter more than asked for: how many LARGE vicinities the early pass leaves to the main launch differs from call to call
+    // on the same list, and hipFree waits for everything on the device -- see the caller)
+    const size_t bytes = (slots + slots / 4) * tlc_handoff_slot_bytes(TLC_TIER_LARGE);
     hipFree(ws->handoff_large);
     ws->handoff_large = nullptr; ws->cap_handoff_large = 0;
     TLC_HIP_CHECK(hipMalloc(&ws->handoff_large, bytes));
@@ -535,7 +538,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     // one batch alone and a loss for pipelined batches -- see the note at `xlane` in run_chunk_front and DESIGN.md)
     { const char* v = getenv("TLC_XL_CUT"); g->opt_xl_cut = v ? std::min(std::max(atoi(v), 0), TLC_XL_MAXCUT) : 0; }
     g->opt_xl_ncut = TLC_T_NCUT; g->opt_xl_mcut = TLC_T_MCUT;
-    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = 0x7f; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
+    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
@@ -555,7 +558,11 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     //                  side[4], the early chain (high) -- the lead-in of the next chunk must not queue behind this chunk's tiers;
     //   shared by the workspaces (a chunk's tier kernels queue behind the previous chunk's, which is the order they finish in
     //                  anyway): side[0] SMALL, side[5] TINY, side[3] MID (low), side[6] MEDIUM and its rarely used twin
-    //                  side[2] (normal), side[1] the heavy tiers the early pass did not take (high).
+    //                  side[2], side[7] MEDWIDE (normal), side[1] the heavy tiers the early pass did not take (high).
+    // (MEDWIDE, pipelined chunks only: on MEDIUM's stream the few hundred largest MEDIUM-sized vicinities of a batch, 0.38 ms of
+    // tier + swap kernel, ran in front of the MEDIUM chain instead of beside it.  A fifth stream of normal priority shares a
+    // queue with another one; in-process A/B, tools/gpu_env_ab3.sh TLC_MEDWIDE_PRIO=0|1|2: 0.683 / 0.651 / 0.703 ms per pipelined
+    // batch -- as the fourth stream of the low pool it starts too late, in the high pool it delays the early chains.)
     // Normal priority then holds the caller's stream, the two main streams and MEDIUM: four.  With MID there as well (round 2)
     // the second workspace's main stream shared a hardware queue with the MID chain, and the lead-in of every other pipelined
     // batch sat behind ~0.3 ms of tier + swap kernel: 45.8 -> 48.4 M images/s pipelined, 0.833 -> 0.840 ms for one batch alone
@@ -578,7 +585,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     const int n_eager = 3;
     for (int i = 0; i < TLC_N_WS; ++i) {
         Workspace* ws = &g->ws[i];
-        CK(hipMalloc(&ws->d_ctl, (64 + 1024 + 8) * sizeof(int)));   // counters, the scan's per-block flags, 4 x u64 statistics
+        CK(hipMalloc(&ws->d_ctl, (64 + 1024 + 8 + 8 * 64) * sizeof(int)));   // counters, the scan's per-block flags, 4 x u64 statistics
         ws->d_stats = reinterpret_cast<unsigned long long*>(ws->d_ctl + 64 + 1024);      // (8-byte aligned: hipMalloc is 256-byte aligned)
         CK(hipMalloc(&ws->d_block_sums, 1024 * sizeof(long long)));
         CK(hipMalloc(&ws->d_totals, 2 * sizeof(long long)));
@@ -594,9 +601,9 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
             else if (i > 0) ws->side[k] = g->ws[0].side[k];
             else if (k == 2) ws->side[k] = nullptr;                      // (= side[6], set below)
             else {
-                int pr = k == 1 ? prio_hi : (k == 6 ? prio_mid : prio_lo);
+                int pr = k == 1 ? prio_hi : ((k == 6 || k == 7) ? prio_mid : prio_lo);
                 // (development A/B, tools/gpu_prio_ab.sh: 0 low, 1 normal, 2 high)
-                const char* ev = k == 3 ? getenv("TLC_MID_PRIO") : (k == 6 ? getenv("TLC_MEDIUM_PRIO") : nullptr);
+                const char* ev = k == 3 ? getenv("TLC_MID_PRIO") : (k == 6 ? getenv("TLC_MEDIUM_PRIO") : (k == 7 ? getenv("TLC_MEDWIDE_PRIO") : nullptr));
                 if (ev) pr = atoi(ev) == 0 ? prio_lo : (atoi(ev) == 1 ? prio_mid : prio_hi);
                 CK(hipStreamCreateWithPriority(&ws->side[k], hipStreamNonBlocking, pr));
             }
@@ -693,7 +700,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     c.s = s; c.n_pairs = n_pairs; c.hop = hop; c.pi_enabled = pi_enabled; c.call_seq = g->call_seq;
     if ((rc = ensure_pairs(g, ws, (size_t)n_pairs)) != TLC_OK) return rc;
     if ((rc = ensure_vic_scratch(g, ws, hop)) != TLC_OK) return rc;
-    TLC_HIP_CHECK(hipMemsetAsync(ws->d_ctl, 0, (64 + 1024 + 8) * sizeof(int), s));       // control words, scan flags, statistics
+    TLC_HIP_CHECK(hipMemsetAsync(ws->d_ctl, 0, (64 + 1024 + 8 + 8 * 64) * sizeof(int), s));       // control words, scan flags, statistics
 
     TlcVicParams& vp = c.vp;
     memset(&vp, 0, sizeof(vp));
@@ -935,11 +942,12 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
                                192, gate);
         TLC_HIP_CHECK(hipGetLastError());
     }
-    vp.work_counter = ws->d_ctl + 24;
-    // (about one chunk per RESIDENT extraction wavefront -- 16 per CU, 4 096 -- so that the counter is hardly used: in-process A/B
-    // against twice as many chunks, tools/ab_option.py x_chunk_div 0 8192: -1 % per pipelined batch; half as many leaves half of the
-    // machine without a first chunk: +6 %)
-    vp.work_chunk = std::max(4, n_pairs / (g->opt_x_chunk_div > 0 ? g->opt_x_chunk_div : 4096));
+    vp.work_counter = ws->d_ctl + 64 + 1024 + 8;         // TLC_X_COUNTERS (8) counters, 64 ints apart, behind the statistics
+    // (about one chunk per RESIDENT extraction wavefront -- 16 per CU, 4 096 -- when batches are pipelined: the machine is full of
+    // other chunks' kernels then and the extraction's own tail costs nothing; twice as many for a lone batch.  In-process A/B,
+    // tools/gpu_chunk_ab.sh, x_chunk_div 4096 against 8192 / 16384 / 32768: pipelined batch +0.4 / +2.2 / +2.7 %, latency of one
+    // batch -1.9 / -1.1 / -1.7 %.  Half as many leaves half of the machine without a first chunk: +6 %)
+    vp.work_chunk = std::max(2, n_pairs / (g->opt_x_chunk_div > 0 ? g->opt_x_chunk_div : pipelined ? 4096 : 8192));
     T0(0, s);
     if (use_x) {
         if ((rc = tlc_launch_extract(64, xgrid, g->x_lds64, vp, s)) != TLC_OK) return rc;
@@ -992,7 +1000,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     // previous chunk: the ~50 us the host needs to see the published sizes and issue a dozen launch calls are no longer
     // between the scan and the batch's second-longest chain.  If COUNT overflowed the arena the kernels return at once
     // (abort flag) and the chunk is redone below.
-    static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4};   // timing slot of each tier kernel (TINY is reported with SMALL, MEDHI as MEDIUM)
+    static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4, 4};   // timing slot of each tier kernel (TINY is reported with SMALL, MEDHI / MEDWIDE as MEDIUM)
     bool (&used)[TLC_N_SIDE] = c.used;
     for (int k = 0; k < TLC_N_SIDE; ++k) used[k] = ((k == 4) && early) || ((k == 1) && xlane);
     // The fork point of the side-stream launches that need nothing but the scan.  Recorded here, it is long complete when the
@@ -1008,13 +1016,15 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         spec_cap[TLC_TIER_MID] = std::min(n_pairs, std::max(4096, ws->prev_tc[TLC_TIER_MID] + ws->prev_tc[TLC_TIER_MID] / 4));
         spec_cap[TLC_TIER_MEDIUM] = std::min(n_pairs, std::max(2048, ws->prev_tc[TLC_TIER_MEDIUM] + ws->prev_tc[TLC_TIER_MEDIUM] / 4));
         spec_cap[TLC_TIER_MEDHI] = std::min(n_pairs, std::max(1024, ws->prev_tc[TLC_TIER_MEDHI] + ws->prev_tc[TLC_TIER_MEDHI] / 4));
+        spec_cap[TLC_TIER_MEDWIDE] = std::min(n_pairs, std::max(512, ws->prev_tc[TLC_TIER_MEDWIDE] + ws->prev_tc[TLC_TIER_MEDWIDE] / 4));
         if (g->opt_spec_cap > 0)                                        // (tests: reach the paths beyond the reserved slots)
-            for (int t : {TLC_TIER_MID, TLC_TIER_MEDIUM, TLC_TIER_MEDHI}) spec_cap[t] = std::min(spec_cap[t], g->opt_spec_cap);
-        // hand-off buffer: [MID | MEDHI (speculative launch) | MEDIUM]
+            for (int t : {TLC_TIER_MID, TLC_TIER_MEDIUM, TLC_TIER_MEDHI, TLC_TIER_MEDWIDE}) spec_cap[t] = std::min(spec_cap[t], g->opt_spec_cap);
+        // hand-off buffer: [MID | MEDHI (speculative launch) | MEDIUM | MEDWIDE]
         spec_base[TLC_TIER_MEDHI] = (size_t)spec_cap[TLC_TIER_MID] * tlc_handoff_slot_bytes(TLC_TIER_MID);
         spec_base[TLC_TIER_MEDIUM] = spec_base[TLC_TIER_MEDHI] + (size_t)spec_cap[TLC_TIER_MEDHI] * tlc_handoff_slot_bytes(TLC_TIER_MEDHI);
-        if ((rc = ensure_handoff(g, ws, spec_base[TLC_TIER_MEDIUM] +
-                                        (size_t)spec_cap[TLC_TIER_MEDIUM] * tlc_handoff_slot_bytes(TLC_TIER_MEDIUM))) != TLC_OK) return rc;
+        spec_base[TLC_TIER_MEDWIDE] = spec_base[TLC_TIER_MEDIUM] + (size_t)spec_cap[TLC_TIER_MEDIUM] * tlc_handoff_slot_bytes(TLC_TIER_MEDIUM);
+        if ((rc = ensure_handoff(g, ws, spec_base[TLC_TIER_MEDWIDE] +
+                                        (size_t)spec_cap[TLC_TIER_MEDWIDE] * tlc_handoff_slot_bytes(TLC_TIER_MEDWIDE))) != TLC_OK) return rc;
         pp.A_dir = ws->A_dir; pp.A_lw = ws->A_lw;
         // On the caller's stream itself, tier kernels first, then their swap kernels.  (On side streams they would sit behind
         // event waits until the scan is done, and a blocked stream stalls whatever shares its hardware queue -- ROCm maps all
@@ -1067,7 +1077,7 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
     size_t (&spec_base)[TLC_N_TIERS] = c.spec_base;
     int (&spec_cap)[TLC_N_TIERS] = c.spec_cap;
     bool (&used)[TLC_N_SIDE] = c.used;
-    static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4};   // timing slot of each tier kernel (TINY is reported with SMALL, MEDHI as MEDIUM)
+    static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4, 4};   // timing slot of each tier kernel (TINY is reported with SMALL, MEDHI / MEDWIDE as MEDIUM)
     auto dc_lists_for = [&](TlcPdParams& q, int k) {
         const size_t cap = ws->cap_pairs + TLC_EARLY_SLOTS;
         q.dc_count = ws->d_ctl + 26 + 2 * k;
@@ -1103,10 +1113,11 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
 
     const int n_early = early ? ws->h_sync->pub_early : 0;
     const int n_xl_cand = c.xlane ? ws->h_sync->pub_xl[0] : 0, n_xl_done = c.xlane ? ws->h_sync->pub_xl[1] : 0;
-    const int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4] + tc[5] + tc[6];
+    const int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4] + tc[5] + tc[6] + tc[7];
     if (c.xlane) ws->prev_xl_cand = n_xl_cand;
     const bool spec_done = spec && bumped;          // the MID / MEDIUM tiers are already running
     ws->prev_tc[TLC_TIER_MID] = tc[TLC_TIER_MID]; ws->prev_tc[TLC_TIER_MEDIUM] = tc[TLC_TIER_MEDIUM]; ws->prev_tc[TLC_TIER_MEDHI] = tc[TLC_TIER_MEDHI];
+    ws->prev_tc[TLC_TIER_MEDWIDE] = tc[TLC_TIER_MEDWIDE];
     if (todo > 0) {
         vp.A_dir = ws->A_dir; vp.A_lw = ws->A_lw;
         pp.A_dir = ws->A_dir; pp.A_lw = ws->A_lw;
@@ -1116,14 +1127,14 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
         // The extraction ran out of arena: every vicinity below the heavy tiers is laid out by the scan and written by the
         // breadth-first FILL -- before any tier kernel may read it (that includes the SMALL tier, which has no slots of its own here)
         bool filled_all = false;
-        if (use_x && !bumped && tc[0] + tc[1] + tc[4] + tc[5] + tc[6] > 0) {
+        if (use_x && !bumped && tc[0] + tc[1] + tc[4] + tc[5] + tc[6] + tc[7] > 0) {
             vp.fill_mode = (tc[TLC_TIER_LARGE] + tc[TLC_TIER_HUGE] > 0 || n_early > 0) ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
             vp.x_fill = 1; vp.bump_top = nullptr; vp.work_count_dev = nullptr;
             if ((rc = tlc_launch_extract(64, xgrid, g->x_lds64, vp, s)) != TLC_OK) return rc;
             filled_all = true;
         }
         // hand-off slots (images only): the tiers with long serial tails run their cycle swap in a second, one-wavefront kernel
-        size_t hand_base[TLC_N_TIERS] = {0, 0, 0, 0, 0, 0, 0};
+        size_t hand_base[TLC_N_TIERS] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (pi_enabled && !spec_done) {
             size_t hand_total = 0;
             for (int t = 0; t < TLC_N_TIERS; ++t) {
@@ -1138,6 +1149,7 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
             // its cycle swap itself
             hand_base[TLC_TIER_MID] = 0;
             hand_base[TLC_TIER_MEDIUM] = spec_base[TLC_TIER_MEDIUM];
+            hand_base[TLC_TIER_MEDWIDE] = spec_base[TLC_TIER_MEDWIDE];
         }
         // the speculative launch had one workgroup per reserved slot: list positions beyond them get a launch of their own,
         // behind it on s (tier kernel only: without a slot a subgraph's cycle swap runs in the tier kernel itself)
@@ -1163,7 +1175,7 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
             const size_t hs = pi_enabled ? tlc_handoff_slot_bytes(t) : 0;
             pp.handoff = hs ? ws->handoff + hand_base[t] : nullptr;
             pp.handoff_stride = (long long)hs;
-            pp.handoff_cap = (spec_done && (t == TLC_TIER_MID || t == TLC_TIER_MEDIUM)) ? std::min(tc[t], spec_cap[t]) : tc[t];
+            pp.handoff_cap = (spec_done && (t == TLC_TIER_MID || t == TLC_TIER_MEDIUM || t == TLC_TIER_MEDWIDE)) ? std::min(tc[t], spec_cap[t]) : tc[t];
             pp.dc_count = nullptr; pp.dc_list = nullptr;
             if (t == TLC_TIER_LARGE) dc_lists_for(pp, 1);
             if (hs && t == TLC_TIER_LARGE) {
@@ -1174,7 +1186,7 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
             }
             pp.grid = 0; pp.phase = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
-            const bool timed = !(early && t == TLC_TIER_LARGE) && !(t == TLC_TIER_MEDIUM && spec);   // (those slots time the early launch / MEDHI)
+            const bool timed = !(early && t == TLC_TIER_LARGE) && !(t == TLC_TIER_MEDIUM && spec) && t != TLC_TIER_MEDWIDE;   // (those slots time the early launch / MEDHI / MEDIUM)
             if (timed) T0(tslot[t], ws->side[k]);
             int r = ((g->opt_tier_mask >> t) & 1) ? tlc_launch_pd_tier(t, pp, ws->side[k]) : TLC_OK;   // (development: tiers timed alone)
             if (r != TLC_OK) return r;
@@ -1186,6 +1198,10 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
         // 1. the heavy tiers first: their subgraphs are filled by a small early pass (8 wavefronts per pair) so that the
         //    long serial tails of the largest vicinities start as soon as possible and overlap everything else
         const int heavy = tc[TLC_TIER_LARGE] + tc[TLC_TIER_HUGE];
+        // (the LARGE tier's hand-off slots BEFORE anything heavy is submitted: growing them frees the old buffer, and hipFree waits
+        // for the device -- behind the HUGE tier kernel that was 6.3 ms in which the host submitted nothing: the long list of the
+        // strong-scaling leg took 33 instead of 26 ms in every call that needed a few slots more than the one before)
+        if (pi_enabled && tc[TLC_TIER_LARGE] > 0 && (rc = ensure_handoff_large(g, ws, (size_t)TLC_EARLY_SLOTS + (size_t)tc[TLC_TIER_LARGE])) != TLC_OK) return rc;
         T0(2, s);
         for (int t = TLC_TIER_HUGE; t >= TLC_TIER_LARGE; --t) {
             if (tc[t] <= 0) continue;
@@ -1235,13 +1251,15 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
         // 2. the MEDIUM-sized tiers
         auto launch_medium_mid = [&]() -> int {
             int r;
-            if (tc[TLC_TIER_MEDIUM] + tc[TLC_TIER_MEDHI] + tc[TLC_TIER_MID] > 0) {
+            if (tc[TLC_TIER_MEDIUM] + tc[TLC_TIER_MEDHI] + tc[TLC_TIER_MEDWIDE] + tc[TLC_TIER_MID] > 0) {
                 if (!bumped && !filled_all) {
                     vp.fill_mode = (heavy > 0 || n_early > 0) ? 2 : 0; vp.fill_list = nullptr; vp.fill_count = 0;
                     hipLaunchKernelGGL((tlc_vicinity_kernel<true, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
                     TLC_HIP_CHECK(hipGetLastError());
                 }
                 T1(2, s);
+                // (the few vicinities beyond the compact configuration first: the largest of the MEDIUM-sized ones, the longest swaps)
+                if (tc[TLC_TIER_MEDWIDE] > 0 && (r = launch_side(7, TLC_TIER_MEDWIDE, !bumped)) != TLC_OK) return r;
                 if (!spec_done && tc[TLC_TIER_MEDHI] > 0 && (r = launch_side(2, TLC_TIER_MEDHI)) != TLC_OK) return r;
                 if (tc[TLC_TIER_MEDIUM] > 0 && (r = launch_side(6, TLC_TIER_MEDIUM, !bumped)) != TLC_OK) return r;
                 if (tc[TLC_TIER_MID] > 0 && (r = launch_side(3, TLC_TIER_MID, !bumped)) != TLC_OK) return r;
@@ -1265,6 +1283,8 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
 #undef T1
     if (c.call_seq == g->call_seq) {      // (a deferred second half submitted by a LATER call does not count into that call's statistics)
     for (int t = 0; t <= TLC_TIER_HUGE; ++t) g->last_stats[t] += tc[t];
+    for (int t = 0; t < TLC_N_TIERS; ++t) g->last_tc[t] += tc[t];
+    g->last_stats[TLC_TIER_MEDIUM] += tc[TLC_TIER_MEDWIDE];            // (reported with MEDIUM)
     g->last_stats[TLC_TIER_MEDIUM] += tc[TLC_TIER_MEDHI];              // (reported with MEDIUM; on its own in [9])
     g->last_stats[9] += tc[TLC_TIER_MEDHI];
     g->last_stats[TLC_TIER_SMALL] += tc[TLC_TIER_TINY];                 // (reported with SMALL; on its own in [8])
@@ -1360,6 +1380,7 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
     TLC_REQUIRE(n_pairs == 0 || d_pairs != nullptr, "pairs is null");
     TLC_ON_DEVICE(g->device);
     memset(g->last_stats, 0, sizeof(g->last_stats));
+    memset(g->last_tc, 0, sizeof(g->last_tc));
     g->acc_tie = 0; g->acc_entries = 0;
     ++g->call_seq;
     for (int k = 0; k < TLC_N_WS; ++k) g->ws[k].in_call = 0;
@@ -1632,6 +1653,18 @@ extern "C" int tlc_debug_dc_stats(tlc_graph* g, long long* h_out, void* stream) 
     }
     h_out[0] = (long long)v[1];
     h_out[1] = (long long)v[3];
+    return TLC_OK;
+}
+
+// diagnostics: the tier lists of the last call as the scan cut them (tlc_kernels.h: TLC_TIER_*), h_out[TLC_N_TIERS = 8]:
+// small, medium (compact configuration, few Pos edges), large, huge, mid, tiny, medium with many Pos edges, medium beyond the compact
+// configuration.  (tlc_pd_pi_batch_stats reports tiny with small and the three medium lists together.)
+extern "C" int tlc_debug_tier_counts(tlc_graph* g, long long* h_out, void* stream) {
+    TLC_REQUIRE(g && h_out, "null argument");
+    TLC_ON_DEVICE(g->device);
+    { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; }
+    TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    for (int t = 0; t < TLC_N_TIERS; ++t) h_out[t] = g->last_tc[t];
     return TLC_OK;
 }
 

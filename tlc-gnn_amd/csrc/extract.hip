@@ -29,6 +29,8 @@
 #define TLC_X_H_CAP 128       /* heavy members listed per vicinity; more: every row is scanned */
 #define TLC_X_BLOCK 4096      /* arena entries a workgroup takes from the bump counter when its region is full (>= 2 * TLC_M_MMAX) */
 #define TLC_X_BIN_MIN 64      /* pairs whose smaller ball has at least this many nodes are binned and extracted first */
+#define TLC_X_COUNTERS 8      /* work counters of the main pass (tlc_extract_kernel) */
+#define TLC_X_COUNTER_STRIDE 64 /* ints between them: atomics on ONE 128-byte line are served one after the other (~90/us) */
 
 namespace {
 
@@ -698,10 +700,18 @@ __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kern
     };
     if (p.started && threadIdx.x == 0 && (int)blockIdx.x < n_work) atomicAdd(p.started, 1);
     // (one loop for both schedules -- static: a chunk is one item and the next chunk is gridDim.x further on)
+    // Dynamic: the first chunk of a workgroup is its own index; the rest come from TLC_X_COUNTERS counters (256 bytes apart), counter k handing out the
+    // chunks gridDim.x + k, + TLC_X_COUNTERS, ... -- a workgroup starts at counter blockIdx % TLC_X_COUNTERS and moves on when one runs
+    // dry.  (One counter serves ~90 dequeues/us: with it the chunks had to be ~9 pairs = ~100 us, about one per resident wavefront,
+    // i.e. no balancing at all -- per-pair stamps showed the last 30 % of the kernel's span at under half occupancy.  Eight counters
+    // carry chunks of two pairs.)  The next chunk is requested BEFORE the current one is worked on: its round trip is hidden.
     __shared__ int s_chunk;
     const bool dyn = p.work_counter != nullptr;
     const int n_chunks = dyn ? (n_work + p.work_chunk - 1) / p.work_chunk : n_work;
+    int ck = (int)(blockIdx.x % TLC_X_COUNTERS), dry = 0;
     for (int c = blockIdx.x; c < n_chunks;) {
+        int nxt = 0;
+        if (dyn && BW == 64 && threadIdx.x == 0) nxt = atomicAdd(p.work_counter + ck * TLC_X_COUNTER_STRIDE, 1);
         // the items of a chunk: c, c + n_chunks, ...; stage registers: [0] the item about to run, [1] the one after it
         bool fr0 = false, fr1 = false;
         int i0 = -1, i1 = -1, u0 = -1, v0 = -1;
@@ -727,10 +737,25 @@ __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kern
             i1 = i2; fr1 = fr2;
         }
         if (!dyn) { c += gridDim.x; continue; }
-        if (threadIdx.x == 0) s_chunk = (int)gridDim.x + atomicAdd(p.work_counter, 1);
-        __syncthreads();
-        c = __builtin_amdgcn_readfirstlane(s_chunk);
-        __syncthreads();
+        if (BW == 64) {
+            c = (int)gridDim.x + TLC_X_COUNTERS * __builtin_amdgcn_readfirstlane(nxt) + ck;
+            // this counter is dry: the next one (at most once round), looked at with a plain load first -- at the end of the kernel
+            // every wavefront comes through here, and 4 096 x 7 atomics on dry counters took longer than the extraction itself
+            while (c >= n_chunks && ++dry < TLC_X_COUNTERS) {
+                ck = (ck + 1) % TLC_X_COUNTERS;
+                int* cnt = p.work_counter + ck * TLC_X_COUNTER_STRIDE;
+                int t = 0;
+                if (threadIdx.x == 0) t = __atomic_load_n(cnt, __ATOMIC_RELAXED);
+                if ((int)gridDim.x + TLC_X_COUNTERS * __builtin_amdgcn_readfirstlane(t) + ck >= n_chunks) continue;
+                if (threadIdx.x == 0) t = atomicAdd(cnt, 1);
+                c = (int)gridDim.x + TLC_X_COUNTERS * __builtin_amdgcn_readfirstlane(t) + ck;
+            }
+        } else {
+            if (threadIdx.x == 0) s_chunk = (int)gridDim.x + atomicAdd(p.work_counter, 1);
+            __syncthreads();
+            c = __builtin_amdgcn_readfirstlane(s_chunk);
+            __syncthreads();
+        }
     }
 }
 

@@ -92,8 +92,9 @@ __host__ __device__ constexpr Layout make_layout(int NM, int MM, bool lwl, int i
     L.o_amb = o;  o += al16((size_t)NM * idxb);                         // tie-fallback list, then union-find parents
     L.o_par = o;  o += al16((size_t)NM * idxb);                         // spanning-tree parents
     L.o_mark = o; o += al16((size_t)NM * idxb);                         // node ranks, then path stamps
-    L.o_pn = o;   o += al16((size_t)MM * 4);                            // Pos from the front, Neg from the back (edge ids)
-    L.o_pts = o;  o += al16((size_t)(MM + 2) * 4);                      // diagram points (birth node<<16 | death node)
+    // (both also host one tight-successor weight table of the filtration stage, NM doubles, when the weights are not in LDS)
+    L.o_pn = o;   o += al16(smax((size_t)MM * 4, lwl ? 0 : (size_t)NM * 8));             // Pos from the front, Neg from the back (edge ids)
+    L.o_pts = o;  o += al16(smax((size_t)(MM + 2) * 4, lwl ? 0 : (size_t)NM * 8));       // diagram points (birth node<<16 | death node)
     L.o_ctl = o;  o += 320;                                             // 16 ints | 16 doubles | 32 ints
     // cycle swap: the two walks' path records, [2][65] nodes + [2][65] keys (the entry weights are dead by then)
     if (lwl && (size_t)2 * MM * 8 >= 1280) L.o_rec = L.o_lw;
@@ -1323,11 +1324,12 @@ template <int NM, int MM, int W, bool LWL, bool HUGE>
 #ifdef TLC_PHASE_DEBUG
 __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {       // (the counters need the registers)
 #else
-// 128 VGPRs for the SMALL and MEDIUM tiers: four wavefronts per SIMD (16 resp. 4 workgroups per CU)
+// 128 VGPRs for the SMALL and MEDWIDE tiers: four wavefronts per SIMD (16 resp. 4 workgroups per CU); 80 for the compact MEDIUM
+// configuration: six (its 26 KB of LDS let six workgroups share a CU)
 #ifndef TLC_M_WPE
 #define TLC_M_WPE 4
 #endif
-__global__ __launch_bounds__(W, (W == 256 && !HUGE ? TLC_M_WPE : (W <= 128 ? 4 : 1))) void tlc_pd_tier_kernel(TlcPdParams p) {
+__global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC_M_WPE) : (W <= 128 ? 4 : 1))) void tlc_pd_tier_kernel(TlcPdParams p) {
 #endif
     typedef unsigned short idx_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1402,8 +1404,8 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? TLC_M_WPE : (W <= 128 ? 4 :
         constexpr int BF_CE = (!LWL && !HUGE) ? (2 * MM + W - 1) / W : 0;
         constexpr bool WTAB = !LWL && !HUGE;
         // image slicing: the tiers that may hand a subgraph to tlc_pd_swap_kernel slice like that kernel does
-        constexpr int PSW = (!HUGE && (NM == TLC_D_NMAX || NM == TLC_M_NMAX)) ? 64 : W;
-        static_assert(HUGE || LWL || ((size_t)MM * 4 >= (size_t)NM * 8), "tight-successor weight tables alias pn / pts");
+        constexpr int PSW = (!HUGE && (NM == TLC_D_NMAX || NM == TLC_M_NMAX || NM == TLC_C_NMAX)) ? 64 : W;
+        // (the tight-successor weight tables alias pn / pts: make_layout gives both NM doubles at least)
         double* wU = (double*)M.pn;
         double* wV = (double*)M.pts;
 
@@ -2153,8 +2155,9 @@ __global__ __launch_bounds__(256, (RES <= TLC_RASTER_OCC3_MAXRES ? 3 : 2)) void 
 size_t tlc_handoff_slot_bytes(int tier) {
     switch (tier) {
         case TLC_TIER_MID: return handoff_bytes(TLC_D_NMAX, TLC_D_MMAX);
+        case TLC_TIER_MEDIUM: return handoff_bytes(TLC_C_NMAX, TLC_C_MMAX);
         case TLC_TIER_MEDHI:
-        case TLC_TIER_MEDIUM: return handoff_bytes(TLC_M_NMAX, TLC_M_MMAX);
+        case TLC_TIER_MEDWIDE: return handoff_bytes(TLC_M_NMAX, TLC_M_MMAX);
         // (LARGE keeps the serial cycle swap of its subgraphs with few Pos edges: they are few and the batch waits for the
         // slowest of them, which runs fastest with a CU to itself -- measured 0.91 vs 1.07 ms with the swap in the shared
         // one-wavefront kernel; only the subgraphs meant for tlc_pd_dc_kernel are handed off, into a buffer of their own)
@@ -2180,8 +2183,9 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
     if (host_trace) {                                 // (development: LDS bytes per workgroup of every kernel of the tiers)
         static int once = 0;
         if (!once++)
-            fprintf(stderr, "[tlc] LDS per workgroup: SMALL %zu | MEDIUM tier %zu swap %zu | MID tier %zu swap %zu | LARGE tier %zu dc %zu\n",
-                    (size_t)make_layout(TLC_S_NMAX, TLC_S_MMAX, TLC_SMALL_LWL, 2).total, (size_t)make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2).total,
+            fprintf(stderr, "[tlc] LDS per workgroup: SMALL %zu | MEDIUM tier %zu swap %zu | MEDWIDE tier %zu swap %zu | MID tier %zu swap %zu | LARGE tier %zu dc %zu\n",
+                    (size_t)make_layout(TLC_S_NMAX, TLC_S_MMAX, TLC_SMALL_LWL, 2).total, (size_t)make_layout(TLC_C_NMAX, TLC_C_MMAX, false, 2).total,
+                    (size_t)make_swap_layout(TLC_C_NMAX, TLC_C_MMAX).total, (size_t)make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2).total,
                     (size_t)make_swap_layout(TLC_M_NMAX, TLC_M_MMAX).total, (size_t)make_layout(TLC_D_NMAX, TLC_D_MMAX, false, 2).total,
                     (size_t)make_swap_layout(TLC_D_NMAX, TLC_D_MMAX).total, (size_t)make_layout(TLC_L_NMAX, TLC_L_MMAX, false, 2).total,
                     (size_t)dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX));
@@ -2196,8 +2200,20 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
                                L.total + pad, s, p);
             break;
         }
-        case TLC_TIER_MEDHI:
         case TLC_TIER_MEDIUM: {
+            constexpr Layout L = make_layout(TLC_C_NMAX, TLC_C_MMAX, false, 2);
+            static const size_t mpad = getenv("TLC_MEDIUM_LDS_PAD") ? (size_t)atoi(getenv("TLC_MEDIUM_LDS_PAD")) : 0;
+            if (p.phase != 2)
+                hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_C_NMAX, TLC_C_MMAX, 256, false, false>), dim3(grid),
+                                   dim3(256), L.total + mpad, s, p);
+            if (deferring && p.phase != 1) {
+                constexpr SwapLayout SL = make_swap_layout(TLC_C_NMAX, TLC_C_MMAX);
+                hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_C_NMAX, TLC_C_MMAX>), dim3(grid), dim3(64), SL.total, s, p);
+            }
+            break;
+        }
+        case TLC_TIER_MEDHI:
+        case TLC_TIER_MEDWIDE: {
             constexpr Layout L = make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2);
             // (development: TLC_MEDIUM_LDS_PAD=bytes -- how much does this tier's footprint cost?  37.5 KB = four workgroups per CU)
             static const size_t mpad = getenv("TLC_MEDIUM_LDS_PAD") ? (size_t)atoi(getenv("TLC_MEDIUM_LDS_PAD")) : 0;

@@ -17,16 +17,21 @@
 #define TLC_TIER_LARGE 2
 #define TLC_TIER_HUGE 3
 #define TLC_TIER_MID 4      /* the lower end of MEDIUM (reported with it): 128 threads, ~10 KB of LDS, 8 workgroups per CU */
-#define TLC_TIER_MEDHI 6    /* MEDIUM-sized vicinities with many Pos edges (reported with MEDIUM): same kernels, launched FIRST and on the
-                               critical stream, so that their long serial cycle swaps overlap the rest of the MEDIUM tier */
+#define TLC_TIER_MEDHI 6    /* a chunk on its own only: the MEDIUM-sized vicinities with many Pos edges or beyond the compact configuration
+                               (reported with MEDIUM): the wide kernels, launched FIRST and on the critical stream, so that their long
+                               serial cycle swaps overlap the rest of the MEDIUM tier */
 #ifndef TLC_MH_MIN_POS             /* (overridable for the threshold sweep: tools/gpu_threshold_sweep.sh) */
 #define TLC_MH_MIN_POS 120
 #endif
 #define TLC_TIER_TINY 5     /* the lower end of SMALL (reported with it): ONE LANE per subgraph, 64 subgraphs per wavefront (pd_tiny.hip) */
+#define TLC_TIER_MEDWIDE 7  /* pipelined chunks only (no MEDHI list there): the upper end of MEDIUM (reported with it), more than TLC_C_NMAX
+                               nodes or TLC_C_MMAX edges.  MEDIUM runs the kernels sized for TLC_C_NMAX / TLC_C_MMAX (26 KB of LDS, six
+                               workgroups per CU; cycle swap 14 KB, eleven wavefronts per CU), MEDHI and this tier the ones sized for
+                               TLC_M_NMAX / TLC_M_MMAX (37 KB, four; 20 KB, eight) */
 // hard limits of one subgraph: local node ids are packed in 16 bits, edge ranks + 1 in 24
 #define TLC_MAX_SUBGRAPH_NODES 65535
 #define TLC_MAX_SUBGRAPH_EDGES ((1 << 24) - 2)
-#define TLC_N_TIERS 7
+#define TLC_N_TIERS 8
 
 #define TLC_T_NMAX 16
 #define TLC_T_MMAX 24
@@ -57,6 +62,12 @@
 #define TLC_D_THREADS 128
 #define TLC_M_NMAX 512
 #define TLC_M_MMAX 1024
+/* the compact configuration of the MEDIUM-sized tiers (99.6 % of the MEDIUM-sized vicinities of the PubMed-shaped graph's non-edge
+   list fit, 86 % of its edge batch's: tools/strong_stats.py) */
+#ifndef TLC_C_NMAX                 /* (overridable: -DTLC_C_NMAX=512 -DTLC_C_MMAX=1024 is the build without the compact configuration) */
+#define TLC_C_NMAX 384
+#define TLC_C_MMAX 512
+#endif
 #define TLC_L_NMAX 2048
 #define TLC_L_MMAX 4096
 #define TLC_L_THREADS 512   /* 1024 measured slower (0.99 vs 0.94 ms): barriers over 16 wavefronts, 128-VGPR cap */

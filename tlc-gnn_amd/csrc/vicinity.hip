@@ -142,7 +142,15 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
             if (p.tiny_ok && n <= TLC_T_NCUT && m <= TLC_T_MCUT) tier = TLC_TIER_TINY;
             else if (n <= TLC_S_NMAX && m <= TLC_S_MMAX) tier = TLC_TIER_SMALL;
             else if (n <= TLC_D_NMAX && m <= TLC_D_MMAX) tier = TLC_TIER_MID;
-            else if (n <= TLC_M_NMAX && m <= TLC_M_MMAX) tier = (m - n + 1 >= p.mh_min_pos) ? TLC_TIER_MEDHI : TLC_TIER_MEDIUM;
+            else if (n <= TLC_M_NMAX && m <= TLC_M_MMAX) {
+                // the MEDIUM-sized vicinities: those within the compact configuration -> MEDIUM; the rest -> MEDWIDE.  With the split
+                // by Pos edges on (a chunk on its own: mh_min_pos < INT_MAX) the ones with many Pos edges AND the wide ones are one
+                // list, MEDHI: the longest chains of these tiers, launched first (speculatively) with the wide kernels
+                const bool wide = n > TLC_C_NMAX || m > TLC_C_MMAX;
+                const bool split = p.mh_min_pos != 0x7fffffff;
+                if (split && (wide || m - n + 1 >= p.mh_min_pos)) tier = TLC_TIER_MEDHI;
+                else tier = wide ? TLC_TIER_MEDWIDE : TLC_TIER_MEDIUM;
+            }
             else if (n <= TLC_L_NMAX && m <= TLC_L_MMAX) tier = TLC_TIER_LARGE;
         }
     }

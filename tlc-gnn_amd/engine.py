@@ -94,6 +94,12 @@ class DeviceGraph:
         _lib.check(_lib.lib().tlc_debug_dc_stats(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr(self.device)), "tlc_debug_dc_stats")
         return int(out[0]), int(out[1])
 
+    def tier_counts(self):
+        """The tier lists of the last pd_pi_batch call as the device cut them (tlc_debug_tier_counts)."""
+        out = (C.c_longlong * 8)()
+        _lib.check(_lib.lib().tlc_debug_tier_counts(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr(self.device)), "tlc_debug_tier_counts")
+        return dict(zip(("small", "medium", "large", "huge", "mid", "tiny", "medium_many_pos", "medium_wide"), (int(v) for v in out)))
+
     def xl_stats(self):
         """(candidates of the lane-per-pair extraction, pairs it finished as records) in the last chunk."""
         out = (C.c_longlong * 2)()
@@ -228,13 +234,15 @@ def pi_raster(offs, pts, res=5):
 TIER_LIMITS = [("pd_tier_small", 64, 128), ("pd_tier_mid", 128, 256), ("pd_tier_medium", 512, 1024), ("pd_tier_large", 2048, 4096)]
 TINY_LIMITS = (16, 24)          # TLC_T_NMAX / TLC_T_MMAX: lane-per-subgraph kernel (plain image batches at resolution 5)
 MEDIUM_MANY_POS = 120           # TLC_MH_MIN_POS: MEDIUM-sized vicinities with at least this many Pos edges (m - n + 1)
+MEDIUM_COMPACT = (384, 512)     # TLC_C_NMAX / TLC_C_MMAX: the compact configuration of the MEDIUM-sized tiers (beyond it: MEDWIDE)
 
 
 def tier_of(n, m2, tiny=True):
     """Which kernel's TIMING SLOT covers each pair, from (|S|, induced directed entries), mirroring tlc_scan_bin and run_chunk:
     'pd_tier_small' = the wavefront-per-subgraph SMALL kernel only -- the pairs of the lane-per-subgraph kernel are
-    'pd_tier_tiny' (no slot of its own); 'pd_tier_medium' = the MEDIUM-sized vicinities with many Pos edges (the launch that
-    slot brackets), the rest of the MEDIUM tier is 'pd_tier_medium_rest' (not bracketed); '' for pairs finished early.
+    'pd_tier_tiny' (no slot of its own); 'pd_tier_medium' = the MEDIUM-sized vicinities with many Pos edges or beyond the compact
+    kernel configuration (the launch that slot brackets), the rest of the MEDIUM tier is 'pd_tier_medium_rest' (not bracketed);
+    '' for pairs finished early.
     So bytes summed over the pairs of a name and the time of that name's slot cover the same work."""
     n = np.asarray(n)
     m = np.asarray(m2) // 2
@@ -242,7 +250,7 @@ def tier_of(n, m2, tiny=True):
     for name, nm, mm in reversed(TIER_LIMITS):
         out[(n <= nm) & (m <= mm)] = name
     med = out == "pd_tier_medium"
-    out[med & (m - n + 1 < MEDIUM_MANY_POS)] = "pd_tier_medium_rest"
+    out[med & (m - n + 1 < MEDIUM_MANY_POS) & (n <= MEDIUM_COMPACT[0]) & (m <= MEDIUM_COMPACT[1])] = "pd_tier_medium_rest"
     if tiny:
         out[(n <= TINY_LIMITS[0]) & (m <= TINY_LIMITS[1])] = "pd_tier_tiny"
     out[n <= 0] = ""

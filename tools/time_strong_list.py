@@ -13,10 +13,11 @@ near = near[torch.argsort(ranks)].contiguous()
 E = len(near)
 out = torch.empty((E, 25), dtype=torch.float64, device="cuda"); st = torch.empty(E, dtype=torch.uint8, device="cuda")
 ref = None
-for cp in (0, 1 << 18, 1 << 17, 1 << 16, 1 << 15, 0):
+seq = [int(a) for a in sys.argv[1:]] or [0, 1 << 18, 1 << 17, 1 << 16, 1 << 15, 0]
+for cp in seq:
     g.set_option("chunk_pairs", cp)
     ts = []
-    for _ in range(5):
+    for _ in range(5 if cp >= 0 else 12):
         torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); g.pd_pi_batch(near, wl["hop"], out=out, status=st); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))

@@ -13,10 +13,10 @@ for cut in ([int(a) for a in sys.argv[1:]] or [24]):
     g.pd_pi_batch(pairs, 2)
     L.tlc_debug_phase_profile(g._h, 1, None, 0, None)
     g.pd_pi_batch(pairs, 2)
-    buf = (C.c_uint64 * 288)()
-    L.tlc_debug_phase_profile(g._h, 0, C.cast(buf, C.c_void_p), 288, None)
-    a = np.array(list(buf), dtype=np.float64).reshape(9, 32)
-    r = a[8]
+    buf = (C.c_uint64 * 320)()
+    L.tlc_debug_phase_profile(g._h, 0, C.cast(buf, C.c_void_p), 320, None)
+    a = np.array(list(buf), dtype=np.float64).reshape(10, 32)
+    r = a[9]
     names = ["head", "intersection", "compaction", "record heads", "round 0", "segments", "heavy x heavy", "verdict"]
     nw = max(r[15], 1)
     print("cut %d: %s; %d wavefronts; mean cycles per wavefront:" % (cut, g.xl_stats(), r[15]), {nm: int(r[k] / nw) for k, nm in enumerate(names)},
