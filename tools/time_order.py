@@ -43,7 +43,7 @@ front = {}
 for rep in range(3):
     for k in ("as given", "heaviest first", "lightest first"):
         front.setdefault(k, []).append(region([dev[k]]))
-g.set_option("tier_mask", 127)
+g.set_option("tier_mask", 255)
 for k, v in front.items():
     print("first halves only (tier_mask 0)  %-16s %.4f ms   runs %s" % (k, np.median(v), " ".join("%.3f" % x for x in v)))
 for k, v in res.items():

@@ -30,6 +30,6 @@ for t, nm in names.items():
     v = run(1 << t)
     tot += v - base
     print("only %-6s: %.3f ms  (+%.3f)" % (nm, v, v - base))
-print("all tiers: %.3f ms; sum of the stand-alone increments %.3f ms" % (run(0x7f), tot))
+print("all tiers: %.3f ms; sum of the stand-alone increments %.3f ms" % (run(0xff), tot))
 print("no LARGE: %.3f ms;  no TINY: %.3f;  no MEDIUM/MEDHI: %.3f;  no SMALL: %.3f;  TINY+SMALL only: %.3f;  MEDIUM+MEDHI+MID only: %.3f" % (
-    run(0x7f & ~4), run(0x7f & ~32), run(0x7f & ~(2 | 64)), run(0x7f & ~1), run(33), run(2 | 64 | 16)))
+    run(0xff & ~4), run(0xff & ~32), run(0xff & ~(2 | 64 | 128)), run(0xff & ~1), run(33), run(2 | 64 | 128 | 16)))
