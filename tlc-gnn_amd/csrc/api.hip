@@ -769,8 +769,11 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     unsigned long long* d_bump_top = reinterpret_cast<unsigned long long*>(ws->d_ctl + 20);
     int* d_bump_overflow = ws->d_ctl + 22;
     const bool early = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges && hop <= 2 && n_pairs >= TLC_EARLY_MIN_PAIRS;
-    // hop <= 2, plain image batch: the extraction runs from the ball lists (extract.hip); otherwise the breadth-first kernels
-    bool use_x = plain && hop <= 2 && !(flags & TLC_INCLUDE_ROOTS) && g->opt_extract;
+    // hop <= 2: the extraction runs from the ball lists (extract.hip); hop >= 3: the breadth-first kernels.  (Round 4: also with the
+    // id / f / edge outputs of tlc_vicinity_filtration and with TLC_INCLUDE_ROOTS, the PDGNN fork's vicinities -- the breadth-first
+    // COUNT pays two bitmaps of N bits per pair whatever the vicinity's size: 0.18 - 0.25 ms of a 0.37 ms call on 4 096 Amazon-shaped
+    // pairs at hop 1.)
+    bool use_x = hop <= 2 && g->opt_extract;
     if (use_x) {
         if ((rc = ensure_ball_lists(g, hop, s)) != TLC_OK) return rc;
         use_x = g->ball_list_hop == hop;

@@ -458,8 +458,11 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
     x_sync<BW>();
     XSTAMP(2);
     const int capg = p.n_nodes < TLC_MAX_SUBGRAPH_NODES + 1 ? p.n_nodes : TLC_MAX_SUBGRAPH_NODES + 1;
-    int* ids = nB <= SID_CAP ? sid : slot;
-    const int cap_ids = nB <= SID_CAP ? SID_CAP : capg;
+    // (TLC_INCLUDE_ROOTS may add the two roots to the list: room for them)
+    const bool incl = (p.flags & TLC_INCLUDE_ROOTS) != 0u;
+    const bool in_lds = nB + (incl ? 2 : 0) <= SID_CAP;
+    int* ids = in_lds ? sid : slot;
+    const int cap_ids = in_lds ? SID_CAP : capg;
     int n = 0;
     for (int base = 0; base < nB; base += 4 * BW) {
         if (base > 0) {
@@ -499,13 +502,51 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
         uint4* z = reinterpret_cast<uint4*>(X.bits);
         for (int w = tid; w < nw4 / 4; w += BW) z[w] = make_uint4(0u, 0u, 0u, 0u);
     }
-    const int lu = X.ctl[0], lv = X.ctl[1];
+    int lu = X.ctl[0], lv = X.ctl[1];
     x_sync<BW>();
+    if (incl && lu < 0 && u != v) {
+        // data_utils_LP.py:111, nodes + [u, v]: u is in ball(v) exactly when v is in ball(u), so either both roots are members
+        // already or neither is (d(u, v) > hop) -- then both go into the ascending list: element k moves up by the number of roots
+        // below it (top chunk first: a chunk is read, then written, and lands on slots whose elements have moved already)
+        const int r1 = u < v ? u : v, r2 = u < v ? v : u;
+        int c1 = 0, c2 = 0;
+        for (int k = tid; k < n && k < cap_ids; k += BW) { const int x = ids[k]; c1 += x < r1 ? 1 : 0; c2 += x < r2 ? 1 : 0; }
+        if (BW == 64) { c1 = tlc_wave_sum_i32(c1); c2 = tlc_wave_sum_i32(c2); }
+        else {
+            int t1, t2;
+            block_escan_i32<BW>(c1, X.xw, &t1);
+            x_sync<BW>();
+            block_escan_i32<BW>(c2, X.xw, &t2);
+            x_sync<BW>();
+            c1 = t1; c2 = t2;
+        }
+        if (n + 2 <= cap_ids) {
+            for (int base = n > 0 ? ((n - 1) / BW) * BW : -1; base >= 0; base -= BW) {
+                const int k = base + tid;
+                const int x = k < n ? ids[k] : 0;
+                x_sync<BW>();
+                if (k < n) ids[k + (x > r1 ? 1 : 0) + (x > r2 ? 1 : 0)] = x;
+                x_sync<BW>();
+            }
+            if (tid == 0) { ids[c1] = r1; ids[c2 + 1] = r2; }
+        }
+        n += 2;
+        lu = u < v ? c1 : c2 + 1;
+        lv = u < v ? c2 + 1 : c1;
+        x_sync<BW>();
+    }
     XSTAMP(4);
     if (n == 0 || n > TLC_MAX_SUBGRAPH_NODES) {
         // n == 0: AssertionError, zero connected components (:318).  n > 65535 does not fit the packed local ids: its own status
         x_zero_row<BW>(p, i, n == 0 ? TLC_ST_DISCONNECTED : TLC_ST_TOO_LARGE, n == 0 ? 0 : -n, lu, lv);
         return;
+    }
+    // id output of tlc_vicinity_filtration: by whichever pass finishes the pair's subgraph -- this one every vicinity up to the
+    // MEDIUM tier's node count (one whose edges then do not fit is written again by the FILL pass), FILL all of its own
+    if (p.out_ids && (p.x_fill || n <= TLC_M_NMAX)) {
+        const long long no = p.ids_off[i];
+        const long long cap_o = p.ids_off[i + 1] - no;
+        if (n <= cap_o) for (int k = tid; k < n; k += BW) p.out_ids[no + k] = ids[k];
     }
     // ---- member bits, the rank of the first member of every touched bitmap word, heavy members ------------------------------
     const bool heavy_ok = p.hh_k > 0 && n <= TLC_X_HV_CAP;
