@@ -64,6 +64,57 @@ def test_extraction_modes_agree_and_match_the_oracle(shape, scale, hop):
     assert (rst == 1).sum() >= 2 and (rst == 0).sum() > 1000
 
 
+@pytest.mark.parametrize("shape,scale,hop", [("Photo", 0.3, 1), ("PubMed", 0.3, 2), ("Cora", 1.0, 2)])
+@pytest.mark.parametrize("kd", [True, False])
+def test_filtration_outputs_through_the_extraction(shape, scale, hop, kd):
+    """tlc_vicinity_filtration (ids, f, induced edges; the PDGNN fork's flags: roots always members, sentinel 100, eps
+    normalisation -- data_utils_LP.py:35-65,105-118) through the ball-list extraction and through the breadth-first kernels
+    (option extract=0): every output array bit for bit, and the oracle's.  Pairs: edges, far pairs (roots not in the intersection:
+    merged into the id list), (u, u), ids outside the graph."""
+    import torch
+    from tlc_gnn_amd import engine, synth, _lib
+    from oracle import oracle
+    n, edges, kappa, _, _ = synth.shaped_graph(shape, scale=scale)
+    rowptr, col, w = synth.edges_to_csr(n, edges, kappa)
+    rs = np.random.RandomState(11)
+    pairs = np.concatenate([_mixed_pairs(n, edges, rs, 1500, 1200), np.array([[-1, 3], [n, 0]], dtype=np.int32)])
+    flags = (_lib.INCLUDE_ROOTS | _lib.NORM_EPS | _lib.UNREACHABLE_100) if kd else 0
+    oflags = (oracle.INCLUDE_ROOTS | oracle.NORM_EPS | oracle.UNREACHABLE_100) if kd else 0
+    g = engine.DeviceGraph(rowptr, col, w)
+    dev = torch.as_tensor(pairs).cuda()
+    res = {}
+    for x in (1, 0):
+        g.set_option("extract", x)
+        res[x] = [t.cpu().numpy() for t in g.vicinity_filtration(dev, hop, flags=flags, cap=600, edge_cap=6000)]
+    g.set_option("extract", 1)
+    g.close()
+    offs, ids, f, nn, st, eoffs, e, mm = res[1]
+    for a, b, name in zip(res[1], res[0], ("offs", "ids", "f", "n", "status", "eoffs", "edges", "m")):
+        if name in ("ids", "f"):
+            for k in range(len(pairs)):
+                if nn[k] > 0:
+                    assert np.array_equal(a[offs[k]:offs[k] + nn[k]], b[offs[k]:offs[k] + nn[k]]), (name, k)
+        elif name == "edges":
+            # (the two kernels list a vicinity's edges in different orders: compared as sorted sets)
+            for k in range(len(pairs)):
+                if mm[k] > 0:
+                    ea = a[eoffs[k]:eoffs[k] + mm[k]]; eb = b[eoffs[k]:eoffs[k] + mm[k]]
+                    assert np.array_equal(ea[np.lexsort((ea[:, 1], ea[:, 0]))], eb[np.lexsort((eb[:, 1], eb[:, 0]))]), (name, k)
+        else:
+            assert np.array_equal(a, b), name
+    o_offs, o_ids, o_f, o_n, o_m, o_st, o_eoffs, o_e = oracle.vicinity_filtration(rowptr, col, w, pairs, hop, oflags, edge_cap=6000)
+    assert np.array_equal(st, o_st)
+    fits = (o_n <= 600) & (o_m <= 6000)
+    okm = fits & (st == 0)                                                 # (a failed pair's edge count is reported as 0 here)
+    assert np.array_equal(nn[fits], o_n[fits]) and np.array_equal(mm[okm], o_m[okm]) and fits.sum() > 2000
+    for k in np.flatnonzero(fits & (o_n > 0))[:1500]:
+        assert np.array_equal(ids[offs[k]:offs[k] + nn[k]], o_ids[o_offs[k]:o_offs[k] + o_n[k]]), k
+        assert np.array_equal(f[offs[k]:offs[k] + nn[k]], o_f[o_offs[k]:o_offs[k] + o_n[k]]), k
+    if kd:
+        far = np.flatnonzero((nn == 2) & (mm == 0) & (pairs[:, 0] != pairs[:, 1]))
+        assert len(far) > 20                                              # two isolated roots: nothing in the intersection
+
+
 @pytest.mark.parametrize("n,reach,hop", [(60, 12, 2), (150, -8, 2), (70, 15, 1)])
 def test_sweep_segments_of_dense_vicinities(n, reach, hop):
     """The sweep deals the eight-entry segments behind the node records of a batch of 64 members to the lanes: circulant graphs
