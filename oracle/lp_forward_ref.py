@@ -115,21 +115,27 @@ def gat_conv(x, edge_index, lin_l_w, att_l, lin_ij_w, bias, negative_slope=0.2):
     return out + bias                                            # mean over 1 head, + bias (:166-172)
 
 
-def teacher_forward(f, edge_index, params):
+def teacher_forward(f, edge_index, params, masks=None):
     """Teacher_Model.forward with type='GAT', compute_loss=False, grad_PI=False (Teacher_model.py:46-59,213-229).
 
     f: [n,1] filtration; edge_index: [2, m+n] with the n self loops appended at the end (the caller convention of
     train_Teacher_Model.py:43-44).  Returns (x [n,32], pd_hat [m,2]).
+    masks (train mode, dropout > 0): the five F.dropout masks in call order, already scaled by 1 / (1 - p) -- on the input
+    (:218), after the prelu of conv1 / conv2 / conv4 (:221,224,227) and between lin5 and lin6 (:58); None = eval mode.
     """
     n = f.shape[0]
-    x = f
-    for name in ("conv1", "conv2", "conv4"):
+    x = f if masks is None else f * masks[0]
+    for k, name in enumerate(("conv1", "conv2", "conv4")):
         p = params[name]
         x = F.prelu(gat_conv(x, edge_index, p["lin_l"], p["att_l"], p["lin_ij"], p["bias"]), params["prelu"])
+        if masks is not None:
+            x = x * masks[1 + k]
     p = params["conv3"]
     x = gat_conv(x, edge_index, p["lin_l"], p["att_l"], p["lin_ij"], p["bias"])
     ei = edge_index[:, :-n]                                       # :54-55  strips the appended self loops
     x_in, x_out = x[ei[0]], x[ei[1]]
     h = F.prelu(F.linear(torch.cat((x_in, x_out), dim=1), params["lin5_w"], params["lin5_b"]), params["prelu"])
+    if masks is not None:
+        h = h * masks[4]
     pd_hat = F.linear(h, params["lin6_w"], params["lin6_b"])
     return x, pd_hat

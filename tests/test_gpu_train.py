@@ -268,9 +268,6 @@ def test_teacher_train_mode_refuses_what_is_not_implemented():
     ei = torch.tensor([[0, 1, 0, 1], [1, 0, 0, 1]]).cuda()
     f = torch.rand(2, 1).cuda()
     PD = torch.tensor([[0.1, 0.5], [0.2, 0.3]]).cuda()
-    m = Teacher_Model(type='GAT').cuda().train()                       # dropout 0.2
-    with pytest.raises(NotImplementedError):
-        m(f, ei, PD, kernel='wasserstein', p=2, grad_PI=False)
     m = Teacher_Model(type='GAT', dropout=0.0).cuda().train()
     with pytest.raises(NotImplementedError):
         m(f, ei, PD, kernel='sliced', grad_PI=False)
@@ -278,6 +275,54 @@ def test_teacher_train_mode_refuses_what_is_not_implemented():
         m(f, ei, PD, kernel='wasserstein', grad_PI=True)
     out = m(f, ei, PD, kernel='wasserstein', p=2, grad_PI=False)
     assert out[2].requires_grad
+
+
+def test_teacher_train_mode_dropout_draws_the_masks_of_the_same_seed():
+    """Train mode with dropout 0.2 (Teacher_model.py:58, :218-227): F.dropout at the reference's five points on tensors of the
+    same shapes.  The forward and every gradient against the restatement with the masks the same seed draws (F.dropout on ones
+    of those shapes, in call order, from the same generator state)."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import lp_forward_ref as ref
+    from oracle import w2_ref
+    from tlc_gnn_amd import ops
+    from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
+    torch.manual_seed(5)
+    rs = np.random.RandomState(5)
+    n, m = 50, 140
+    ei = _random_graph(rs, n, m, torch)
+    m = ei.shape[1] - n
+    f = torch.rand(n, 1)
+    b = rs.rand(m)
+    PD = torch.tensor(np.stack([b, b + rs.uniform(0, 0.6, size=m)], 1), dtype=torch.float32)
+    model = Teacher_Model(type='GAT', dropout=0.2)
+    params, leaves = _teacher_params(model, torch)
+    model = model.cuda().train()
+    torch.cuda.manual_seed(1234)
+    x0, img, loss0, _, _, _, _, _ = model(f.cuda(), ei.cuda(), PD.cuda(), kernel='wasserstein', p=2, grad_PI=False)
+    loss0.backward()
+    torch.cuda.manual_seed(1234)
+    masks = [F.dropout(torch.ones(shape, device="cuda"), p=0.2, training=True).cpu() for shape in ((n, 1), (n, 64), (n, 64), (n, 64), (m, 32))]
+    assert all(0.05 < float((mk == 0).float().mean()) < 0.5 for mk in masks[1:])
+    _, pd_ref = ref.teacher_forward(f, ei, params, masks=masks)
+    assert _rel(x0, pd_ref) <= 2e-5
+    _, pd_eval = ref.teacher_forward(f, ei, params)
+    assert _rel(x0, pd_eval) > 1e-2                                     # (the masks did something)
+    r = ops.w2_partial_matching(torch.tensor([0, m]).cuda(), x0.detach().double(), torch.tensor([0, m]).cuda(), PD.double().cuda(), order=2)
+    loss_ref = w2_ref.loss_torch(pd_ref, PD, r["assign"].cpu().numpy(), 2)
+    assert abs(float(loss0.detach()) - float(loss_ref.detach())) <= 1e-5 * max(1.0, abs(float(loss_ref.detach())))
+    loss_ref.backward()
+    named = dict(model.named_parameters())
+    for name, leaf in leaves.items():
+        got = named[name].grad
+        assert got is not None, name
+        # (fp32 sums in another order, scaled by 1 / (1 - p) five times over: 5e-4 of the largest entry; a wrong mask is off by 1e-1)
+        assert _rel(got.reshape(leaf.shape), leaf.grad) <= 5e-4, (name, _rel(got.reshape(leaf.shape), leaf.grad))
+    # eval mode: no mask, the fused head
+    model.eval()
+    with torch.no_grad():
+        xe = model(f.cuda(), ei.cuda(), PD.cuda(), compute_loss=False, grad_PI=False)[0]
+    assert _rel(xe, pd_eval) <= 2e-5
 
 
 def test_teacher_training_step_on_a_block_diagonal_batch_equals_the_sum_over_its_graphs():

@@ -9,9 +9,12 @@ rasterises it with the Cython CPU code (:84).
 
 Training: with `compute_loss=True, kernel='wasserstein'` the diagram loss is the device matching
 (`tlc_w2_partial_matching`; the reference calls POT's ot.emd on the host, wasserstein.py:303) and `loss.backward()` runs
-`tlc_edge_head_bwd` and `tlc_gat_layer_bwd` (autograd.py).  What is NOT here: dropout (train mode needs dropout=0: a dropout
-mask cannot be checked against the reference's RNG stream), the 'sliced' kernel, grad_PI=True (the differentiable imager of
-:76-77; the training script passes grad_PI=False, train_Teacher_Model.py:51) and draw_fig.
+`tlc_edge_head_bwd` and `tlc_gat_layer_bwd` (autograd.py).  Train mode with dropout > 0 (the shipped script trains with dropout = 0,
+train_Teacher_Model.py:163): torch's F.dropout at the reference's five points (:58, :218-227), on tensors of the same shapes, so a seed
+draws the reference's masks; the edge head then runs unfused (the mask sits between its two GEMMs).  What is NOT here: the 'sliced'
+kernel (the reference's own branch cannot run: it ends in `return loss, ind_tmp_test, loss_xy, ...` with those names never bound,
+:110-123,137, and hands lists of CUDA tensors to scipy's cityblock), grad_PI=True (the differentiable imager of :76-77; the training
+script passes grad_PI=False, train_Teacher_Model.py:51) and draw_fig.
 
 Evaluation (train_Teacher_Model.py:85-113: `model(filt, edge_index, PD, p=p, kernel=kernel, pair_diagonal=True, grad_PI=False)`):
 pair_diagonal=True -> compute_PD_loss(type='inference') :66,134-136 -> `wasserstein_distance_inference` (wasserstein.py:93-195)
@@ -46,16 +49,17 @@ class Base_Model(torch.nn.Module):
         evaluate_time of train_Teacher_Model.py:124-151, builds it once); default: built here, once for the four layers."""
         if x.size()[0] == 0:
             return torch.zeros([0, 2], device=x.device)
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("Base_Model (HIP): train mode needs dropout=0 (F.dropout of :217-225 is not implemented)")
+        # F.dropout of :218-227 (train mode only): on the input and behind the prelu of conv1 / conv2 / conv4.  torch's own op, at the
+        # same points and on tensors of the same shapes as the reference, so the same seed draws the same masks
+        drop = (lambda t: F.dropout(t, p=self.dropout, training=True)) if (self.training and self.dropout > 0) else (lambda t: t)
         if csr is None:
             csr = GATConv.csr_by_target(edge_index, x.shape[0])        # one CSR for the four layers of THIS call
         elif isinstance(csr, GraphBatch):
             csr = csr.check(edge_index, x.shape[0])
-        x = self.conv1(x, edge_index, prelu_slope=0.1, csr=csr)       # conv -> F.prelu(0.1) fused (:218-219)
-        x = self.conv2(x, edge_index, prelu_slope=0.1, csr=csr)
-        x = self.conv4(x, edge_index, prelu_slope=0.1, csr=csr)
-        x = self.conv3(x, edge_index, csr=csr)
+        x = self.conv1(drop(x), edge_index, prelu_slope=0.1, csr=csr)  # conv -> F.prelu(0.1) fused (:218-219)
+        x = self.conv2(drop(x), edge_index, prelu_slope=0.1, csr=csr)
+        x = self.conv4(drop(x), edge_index, prelu_slope=0.1, csr=csr)
+        x = self.conv3(drop(x), edge_index, csr=csr)
         return x
 
 
@@ -91,16 +95,21 @@ class Teacher_Model(torch.nn.Module):
         if grad_PI or draw_fig:
             raise NotImplementedError("Teacher_Model (HIP): grad_PI=False, draw_fig=False only")
         if compute_loss and kernel != 'wasserstein':
-            raise NotImplementedError("Teacher_Model (HIP): compute_loss needs kernel='wasserstein'")
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("Teacher_Model (HIP): train mode needs dropout=0")
+            raise NotImplementedError("Teacher_Model (HIP): compute_loss needs kernel='wasserstein' (the reference's 'sliced' branch cannot "
+                                      "run either: Teacher_model.py:110-123 ends in names that were never bound, :137)")
         t1 = time.time()
         x = self.DIM0_Model(x0, edge_index0, csr=csr)
         n = x0.shape[0]
         m = edge_index0.shape[1] - n
         src = edge_index0[0, :m].to(torch.int32).contiguous()         # strips the appended self loops (:54-55)
         dst = edge_index0[1, :m].to(torch.int32).contiguous()
-        if torch.is_grad_enabled() and (x.requires_grad or self.lin5.weight.requires_grad or self.lin6.weight.requires_grad):
+        if self.training and self.dropout > 0:
+            # :56-59 with the dropout mask between the head's two GEMMs: the fused kernel (tlc_edge_head) has no place for it, so this
+            # one case runs lin5 -> prelu -> F.dropout -> lin6 as separate device ops (torch's linear = rocBLAS; its autograd)
+            h = F.linear(torch.cat((x[src.long()], x[dst.long()]), dim=-1), self.lin5.weight, self.lin5.bias)
+            h = F.dropout(F.prelu(h, torch.tensor(0.1, device=h.device, dtype=h.dtype)), p=self.dropout, training=True)
+            x = F.linear(h, self.lin6.weight, self.lin6.bias)
+        elif torch.is_grad_enabled() and (x.requires_grad or self.lin5.weight.requires_grad or self.lin6.weight.requires_grad):
             x = autograd.edge_head(x, self.lin5.weight, self.lin5.bias, self.lin6.weight, self.lin6.bias, src, dst, 0.1)
         else:
             x = ops.edge_head(src, dst, x, self.lin5.weight.detach(), self.lin5.bias.detach(), 0.1,

@@ -1019,9 +1019,9 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         spec_cap[TLC_TIER_MID] = std::min(n_pairs, std::max(4096, ws->prev_tc[TLC_TIER_MID] + ws->prev_tc[TLC_TIER_MID] / 4));
         spec_cap[TLC_TIER_MEDIUM] = std::min(n_pairs, std::max(2048, ws->prev_tc[TLC_TIER_MEDIUM] + ws->prev_tc[TLC_TIER_MEDIUM] / 4));
         spec_cap[TLC_TIER_MEDHI] = std::min(n_pairs, std::max(1024, ws->prev_tc[TLC_TIER_MEDHI] + ws->prev_tc[TLC_TIER_MEDHI] / 4));
-        spec_cap[TLC_TIER_MEDWIDE] = std::min(n_pairs, std::max(512, ws->prev_tc[TLC_TIER_MEDWIDE] + ws->prev_tc[TLC_TIER_MEDWIDE] / 4));
+        spec_cap[TLC_TIER_MEDWIDE] = 0;       // (the scan fills that list only when the split by Pos edges is off, i.e. never beside a speculative launch)
         if (g->opt_spec_cap > 0)                                        // (tests: reach the paths beyond the reserved slots)
-            for (int t : {TLC_TIER_MID, TLC_TIER_MEDIUM, TLC_TIER_MEDHI, TLC_TIER_MEDWIDE}) spec_cap[t] = std::min(spec_cap[t], g->opt_spec_cap);
+            for (int t : {TLC_TIER_MID, TLC_TIER_MEDIUM, TLC_TIER_MEDHI}) spec_cap[t] = std::min(spec_cap[t], g->opt_spec_cap);
         // hand-off buffer: [MID | MEDHI (speculative launch) | MEDIUM | MEDWIDE]
         spec_base[TLC_TIER_MEDHI] = (size_t)spec_cap[TLC_TIER_MID] * tlc_handoff_slot_bytes(TLC_TIER_MID);
         spec_base[TLC_TIER_MEDIUM] = spec_base[TLC_TIER_MEDHI] + (size_t)spec_cap[TLC_TIER_MEDHI] * tlc_handoff_slot_bytes(TLC_TIER_MEDHI);
