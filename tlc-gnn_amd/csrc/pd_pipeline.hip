@@ -129,6 +129,9 @@ struct Mem {
     unsigned char* xbase;  // everything between the edge tables and the Pos/Neg lists: free once the passes are done
     size_t xbytes;
     unsigned long long* stats;   // batch statistics (device, may be null): [1] subgraphs whose cycle swap ran as a divide and conquer, [3] fell back
+    // HUGE tier (state in an HBM scratch slot): LDS for the tables of the serial cycle swap when they fit (else null / 0)
+    unsigned char* lds_swap;
+    size_t lds_swap_bytes;
     int P;
 };
 
@@ -167,6 +170,7 @@ __device__ __forceinline__ Mem<idx_t> carve(unsigned char* base, const Layout& L
     m.xbase = base + L.o_x;
     m.xbytes = L.o_pn - L.o_x;
     m.stats = nullptr;
+    m.lds_swap = nullptr; m.lds_swap_bytes = 0;
     m.P = L.P;
     return m;
 }
@@ -1150,13 +1154,41 @@ __device__ __forceinline__ void ext1_stage(Mem<idx_t>& M, Sink& sink, int n, uns
         }
         __syncthreads();
     }
-    const SwapTables T = carve_swap(M.keyS, NMcap);
-    const bool any_unreached = ext1_build_tree<W>(M, T, n, MMcap, NMcap);
+    // HUGE tier: everything of the subgraph lives in HBM, and the walk below is a chain of dependent reads and exchanges on the
+    // per-node tables -- 4.7 of the 6.8 ms of a 4 000-node vicinity with ~1 800 Pos edges went there at L2 latency.  The tables (28
+    // bytes per node) and the path records take the workgroup's LDS when they fit (n <= ~5 200 with 144 KB), sized for n itself.
+    const bool t_lds = M.lds_swap != nullptr && al16(swap_table_bytes(n)) + 1280 <= M.lds_swap_bytes;
+    const int NMs = t_lds ? n : NMcap;
+    const SwapTables T = carve_swap(t_lds ? (void*)M.lds_swap : (void*)M.keyS, NMs);
+    ull* recs = t_lds ? (ull*)(M.lds_swap + al16(swap_table_bytes(n))) : (ull*)M.rec;
+    const bool any_unreached = ext1_build_tree<W>(M, T, n, MMcap, NMs);
+    if (t_lds) {
+        // (and the queries: Pos list -> edge -> endpoints / rank are three dependent reads per query in HBM, two queries of
+        // look-ahead do not cover them.  Packed by all threads into the sort keys' region, which the tables no longer use, the walk
+        // reads them 64 at a time -- the form tlc_pd_swap_kernel takes them in.)
+        ull* qg = M.keyS;
+        const int npos = M.ctl[3];
+        for (int k = threadIdx.x; k < npos; k += W) {
+            const unsigned e = M.pn[k];
+            qg[k] = ((ull)((M.arank[e] + 1u) << 8) << 32) | (ull)M.dir[e];
+        }
+        __syncthreads();
+        TLC_STAMP(9);
+        if (threadIdx.x < 64) {
+            QueryGlobal qs{qg, npos, 0u, 0u, 0u, 0u, 0u, 0u};
+            const int out0 = M.ctl[2];
+            const int n_out = ext1_walk(T, recs, qs, npos, NMs, any_unreached, sink, M.f, (flags & TLC_KEEP_ZERO_PERS) != 0, out0, pc);
+            if (threadIdx.x == 0) { M.ctl[2] = out0 + n_out; M.ctl[8] = n_out; }
+        }
+        __syncthreads();
+        TLC_STAMP(10);
+        return;
+    }
     TLC_STAMP(9);
     if (threadIdx.x < 64) {                                          // first wavefront
         QueryLds qs{M.pn, M.dir, M.arank, M.ctl[3], 0u, 0u, 0u};
         const int out0 = M.ctl[2];
-        const int n_out = ext1_walk(T, (ull*)M.rec, qs, M.ctl[3], NMcap, any_unreached, sink, M.f,
+        const int n_out = ext1_walk(T, recs, qs, M.ctl[3], NMs, any_unreached, sink, M.f,
                                     (flags & TLC_KEEP_ZERO_PERS) != 0, out0, pc);
         if (threadIdx.x == 0) { M.ctl[2] = out0 + n_out; M.ctl[8] = n_out; }
     }
@@ -1349,6 +1381,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
     }
     Mem<idx_t> M = carve<idx_t>(base, L, NMr, MMr, LWL);
     M.stats = p.stats;
+    if constexpr (HUGE) { M.lds_swap = p.huge_lds > 0 ? lds_raw : nullptr; M.lds_swap_bytes = (size_t)p.huge_lds; }
     const int res = p.res, res2 = res * res;
 
     // this workgroup is resident: tell the launcher's gate (api.hip, tlc_wait_started)
@@ -2265,7 +2298,13 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
         case TLC_TIER_HUGE: {
             if (p.huge_slots <= 0 || !p.huge_scratch) { tlc_set_error("HUGE tier without scratch"); return TLC_ERR_INVALID_ARG; }
             const int grid = p.tier_count < p.huge_slots ? p.tier_count : p.huge_slots;
-            hipLaunchKernelGGL((tlc_pd_tier_kernel<0, 0, 256, false, true>), dim3(grid), dim3(256), 0, s, p);
+            // (LDS for the cycle swap's tables: a HUGE workgroup takes a CU's LDS -- there are a handful of them in a batch, each
+            // the longest serial chain of it; TLC_HUGE_LDS=0: the tables stay in the scratch slot, development A/B)
+            static const int huge_lds = getenv("TLC_HUGE_LDS") ? atoi(getenv("TLC_HUGE_LDS")) : 144 * 1024;
+            TlcPdParams q = p;
+            q.huge_lds = huge_lds;
+            if (huge_lds > 0) { int rc = set_lds_limit(tlc_pd_tier_kernel<0, 0, 256, false, true>, (size_t)huge_lds); if (rc) return rc; }
+            hipLaunchKernelGGL((tlc_pd_tier_kernel<0, 0, 256, false, true>), dim3(grid), dim3(256), (size_t)huge_lds, s, q);
             break;
         }
         default:

@@ -237,6 +237,7 @@ struct TlcPdParams {
     int huge_nmax;
     int huge_mmax;
     int huge_slots;
+    int huge_lds;           // HUGE tier: dynamic LDS bytes of the launch (tables of the serial cycle swap), 0 = none
     // statistics: [0] sources that took the exact tie fallback
     unsigned long long* stats;
     // diagnostics (null in production): per tier 16 accumulated cycle counts of thread 0, see pd_pipeline.hip
