@@ -211,6 +211,13 @@ int tlc_pd_from_filtration(int32_t n_graphs, const int64_t* d_node_offs, const i
  *   d_offs int64[n_dgms+1];  d_pts float64[sum k, 2];  d_out float64[n_dgms, res*res] */
 int tlc_pi_raster(int32_t n_dgms, const int64_t* d_offs, const double* d_pts, int res, double* d_out,
                   void* stream);
+/* Backward of the DIFFERENTIABLE imager, Knowledge_Distillation/pimg.py:354-400 (Teacher_Model.forward(grad_PI=True),
+ * Teacher_model.py:80-81).  The reference computes a point's two normal-CDF factors from detached coordinates (:392,395), so a
+ * point reaches the image through its weight alone, linear_ramp(death - birth) (:11-30, :371): d_grad_pts[i] = (-g, +g) with
+ * g = sum_pixels d_grad_img[diagram of i] * (dPhi_b * dPhi_p of point i) for 0 <= death - birth <= 1, else 0.
+ *   d_grad_img float64[n_dgms, res*res];  d_grad_pts float64[n_pts, 2] (every row written) */
+int tlc_pi_raster_wgrad(int32_t n_dgms, int64_t n_pts, const int64_t* d_offs, const double* d_pts, int res,
+                        const double* d_grad_img, double* d_grad_pts, void* stream);
 
 /* ---- M1-M3: TLCGNN forward (baselines/TLCGNN.py:19-62) ------------------------------------------- */
 

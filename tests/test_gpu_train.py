@@ -272,9 +272,64 @@ def test_teacher_train_mode_refuses_what_is_not_implemented():
     with pytest.raises(NotImplementedError):
         m(f, ei, PD, kernel='sliced', grad_PI=False)
     with pytest.raises(NotImplementedError):
-        m(f, ei, PD, kernel='wasserstein', grad_PI=True)
+        m(f, ei, PD, kernel='wasserstein', draw_fig=True)
     out = m(f, ei, PD, kernel='wasserstein', p=2, grad_PI=False)
-    assert out[2].requires_grad
+    assert out[2].requires_grad and not out[1].requires_grad
+    out = m(f, ei, PD, kernel='wasserstein', p=2)                       # grad_PI=True, the signature's default
+    assert out[1].requires_grad and out[1].dtype == torch.float32 and out[1].shape == (25,)
+
+
+def test_differentiable_imager_gradient_goes_through_the_weights_only():
+    """Teacher_Model.forward(grad_PI=True) -> pimg.PersistenceImager.transform (pimg.py:354-400): the image of the nograd imager,
+    and a gradient that reaches a point through linear_ramp(death - birth) alone -- the reference detaches the coordinates inside
+    the normal CDFs (:392,395).  autograd.diagram_image against that expression written in torch (float64), single diagram and a
+    batch; points with pers < 0 and pers > 1 get no gradient."""
+    import torch
+    from tlc_gnn_amd import autograd, engine
+
+    def ncdf(x):
+        return 0.5 * torch.erfc(-x / np.sqrt(2.0))
+
+    def restated(pd):
+        b, pers = pd[:, 0], pd[:, 1] - pd[:, 0]
+        inside = (pers >= 0) & (pers <= 1)
+        w = torch.where(inside, pers, (pers > 1).to(pd.dtype).detach())
+        grid = torch.arange(6, dtype=pd.dtype) * 0.2
+        cb = ncdf(grid[None, :] - b.detach()[:, None])
+        cp = ncdf(grid[None, :] - pers.detach()[:, None])
+        return torch.einsum('k,ki,kj->ij', w, cb[:, 1:] - cb[:, :-1], cp[:, 1:] - cp[:, :-1]).reshape(-1)
+
+    rs = np.random.RandomState(2)
+    counts = [37, 0, 5, 120]
+    pts = rs.uniform(0, 1, size=(sum(counts), 2))
+    pts[:, 1] = pts[:, 0] + rs.uniform(-0.2, 1.3, size=len(pts))          # some below the diagonal, some with persistence above 1
+    pts[3] = [0.25, 0.25]; pts[4] = [0.0, 1.0]                             # persistence exactly 0 and exactly 1: the linear branch
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    coef = rs.uniform(-1, 1, size=(len(counts), 25))
+    x = torch.tensor(pts, dtype=torch.float64, device="cuda", requires_grad=True)
+    img = autograd.diagram_image(x, torch.tensor(offs, dtype=torch.int64, device="cuda"), 5)
+    assert img.shape == (4, 25) and bool((img[1] == 0).all())
+    assert torch.equal(img.detach(), engine.pi_raster(torch.tensor(offs, dtype=torch.int64, device="cuda"), x.detach(), 5))
+    (img * torch.tensor(coef, device="cuda")).sum().backward()
+    xr = torch.tensor(pts, dtype=torch.float64, requires_grad=True)
+    total = 0
+    for k in range(len(counts)):
+        seg = xr[offs[k]:offs[k + 1]]
+        im = restated(seg) if counts[k] else torch.zeros(25, dtype=torch.float64)
+        assert (im.detach() - img[k].detach().cpu()).abs().max() <= 1e-12 * max(1.0, float(im.detach().abs().max()))
+        total = total + (im * torch.tensor(coef[k])).sum()
+    total.backward()
+    assert (x.grad.cpu() - xr.grad).abs().max() <= 1e-12 * float(xr.grad.abs().max())
+    pers = pts[:, 1] - pts[:, 0]
+    out = (pers < 0) | (pers > 1)
+    assert out.sum() > 10 and bool((x.grad.cpu()[torch.tensor(out)] == 0).all())
+    assert bool((x.grad[:, 0] == -x.grad[:, 1]).all()) and float(x.grad[3].abs().sum()) > 0 and float(x.grad[4].abs().sum()) > 0
+    # float32 points (the model's): the image and the gradient in float32
+    x32 = torch.tensor(pts[:37], dtype=torch.float32, device="cuda", requires_grad=True)
+    im32 = autograd.diagram_image(x32)
+    assert im32.dtype == torch.float32 and im32.shape == (1, 25)
+    im32.sum().backward()
+    assert x32.grad.dtype == torch.float32 and bool(torch.isfinite(x32.grad).all())
 
 
 def test_teacher_train_mode_dropout_draws_the_masks_of_the_same_seed():

@@ -13,8 +13,10 @@ Training: with `compute_loss=True, kernel='wasserstein'`
 train_Teacher_Model.py:163): torch's F.dropout at the reference's five points (:58, :218-227), on tensors of the same shapes, so a seed
 draws the reference's masks; the edge head then runs unfused (the mask sits between its two GEMMs).  What is NOT here: the 'sliced'
 kernel (the reference's own branch cannot run: it ends in `return loss, ind_tmp_test, loss_xy, ...` with those names never bound,
-:110-123,137, and hands lists of CUDA tensors to scipy's cityblock), grad_PI=True (the differentiable imager of :76-77; the training
-script passes grad_PI=False, train_Teacher_Model.py:51) and draw_fig.
+:110-123,137, and hands lists of CUDA tensors to scipy's cityblock) and draw_fig.  grad_PI=True (the signature's default; the
+training script passes False, train_Teacher_Model.py:51): the image of the differentiable imager (pimg.py:354-400) with its gradient
+-- through the points' weights only, because the reference detaches the coordinates inside the normal-CDF factors (:392,395);
+`tlc_pi_raster_wgrad` (autograd.DiagramImage).
 
 Evaluation (train_Teacher_Model.py:85-113: `model(filt, edge_index, PD, p=p, kernel=kernel, pair_diagonal=True, grad_PI=False)`):
 pair_diagonal=True -> compute_PD_loss(type='inference') :66,134-136 -> `wasserstein_distance_inference` (wasserstein.py:93-195)
@@ -80,7 +82,7 @@ class Teacher_Model(torch.nn.Module):
 
     def forward(self, x0, edge_index0, PD, kernel='sliced', M=50, p=1, pair_diagonal=False, draw_fig=False, fig_name='',
                 compute_loss=True, grad_PI=True, graph_ptr=None, edge_ptr=None, pd_ptr=None, csr=None):
-        """Reference signature.  grad_PI must be False; compute_loss=True needs kernel='wasserstein' (p = 1 or 2) and returns
+        """Reference signature.  compute_loss=True needs kernel='wasserstein' (p = 1 or 2) and returns
         loss0 (differentiable), loss_xy0, loss_xd0, loss_yd0 like :63-66.  pair_diagonal=False (training, :64): every target
         point is matched, loss_yd0 is 0 (wasserstein.py:330-372, num_models=1); pair_diagonal=True (evaluation, :66): the
         distance in which both diagrams may use the diagonal, loss_yd0 = the targets left to it.
@@ -92,8 +94,8 @@ class Teacher_Model(torch.nn.Module):
         many target points as edges (PD = Ord0 + Ext1 of the same graph: n - 1 + m - n + 1 = m points, data_utils_GC.py:166).
         csr: a `GraphBatch(edge_index0, n)` the caller built once for this batch (else the CSR by target is built per call).
         """
-        if grad_PI or draw_fig:
-            raise NotImplementedError("Teacher_Model (HIP): grad_PI=False, draw_fig=False only")
+        if draw_fig:
+            raise NotImplementedError("Teacher_Model (HIP): draw_fig=False only")
         if compute_loss and kernel != 'wasserstein':
             raise NotImplementedError("Teacher_Model (HIP): compute_loss needs kernel='wasserstein' (the reference's 'sliced' branch cannot "
                                       "run either: Teacher_model.py:110-123 ends in names that were never bound, :137)")
@@ -128,11 +130,15 @@ class Teacher_Model(torch.nn.Module):
             loss0, loss_xy0, loss_xd0 = parts[0].sum().reshape(1), parts[1].sum().reshape(1), parts[2].sum().reshape(1)
             loss_yd0 = parts[3].sum().reshape(1) if pair_diagonal else torch.zeros(1, dtype=loss0.dtype, device=loss0.device)
         x0_out = x
-        pts = x.detach().to(torch.float64)
-        if edge_ptr is None:
-            offs = torch.tensor([0, m], dtype=torch.int64, device=x.device)
-            img = engine.pi_raster(offs, pts, 5)[0]                                                # :84, on the device
+        offs = torch.tensor([0, m], dtype=torch.int64, device=x.device) if edge_ptr is None else edge_ptr.to(torch.int64)
+        if grad_PI:
+            # :80-81, the differentiable imager (pimg.py:354-400): the same image, float32 like the reference's, with the gradient the
+            # reference's graph carries -- through the points' weights only (it detaches the CDF factors)
+            img = autograd.diagram_image(x, offs, 5) if (torch.is_grad_enabled() and x.requires_grad) else \
+                engine.pi_raster(offs, x.detach().to(torch.float64), 5).to(x.dtype)
         else:
-            img = engine.pi_raster(edge_ptr.to(torch.int64), pts, 5)
+            img = engine.pi_raster(offs, x.detach().to(torch.float64), 5)                          # :84, on the device
+        if edge_ptr is None:
+            img = img[0]
         t3 = time.time()
         return x0_out, img, loss0, loss_xy0, loss_xd0, loss_yd0, t2 - t1, t3 - t2

@@ -2,11 +2,11 @@
 (Knowledge_Distillation/train_Teacher_Model.py:55-62) through the HIP kernels.
 
 torch.autograd only carries the graph: every forward and every backward below is one C-ABI call (`tlc_gat_layer_fwd/_bwd`,
-`tlc_edge_head_fwd/_bwd`, `tlc_w2_partial_matching`); nothing is recomputed with torch ops and there is no CPU path.
+`tlc_edge_head_fwd/_bwd`, `tlc_w2_partial_matching`, `tlc_pi_raster` / `tlc_pi_raster_wgrad`); nothing is recomputed with torch ops and there is no CPU path.
 """
 import torch
 
-from . import ops
+from . import ops, engine
 
 
 class GatLayer(torch.autograd.Function):
@@ -79,6 +79,31 @@ class DiagramLoss(torch.autograd.Function):
         cnt = xoff[1:] - xoff[:-1]
         per_point = torch.repeat_interleave(gloss.to(torch.float64), cnt)          # d total / d loss[b] for each predicted point
         return (grad * per_point.unsqueeze(1)).to(ctx.dtype), None, None, None, None, None
+
+
+class DiagramImage(torch.autograd.Function):
+    """The differentiable imager of Teacher_Model.forward(grad_PI=True) (Teacher_model.py:80-81 -> pimg.py:354-400): images of one
+    or more predicted diagrams, [B, res*res] in the diagrams' dtype.  The reference detaches the coordinates inside the two
+    normal-CDF factors (:392,395), so the gradient reaches a point through its weight only (`tlc_pi_raster_wgrad`)."""
+
+    @staticmethod
+    def forward(ctx, pd_hat, offs, res):
+        pts = pd_hat.detach().to(torch.float64).contiguous()
+        ctx.save_for_backward(pts, offs)
+        ctx.res, ctx.dtype = res, pd_hat.dtype
+        return engine.pi_raster(offs, pts, res).to(pd_hat.dtype)
+
+    @staticmethod
+    def backward(ctx, gimg):
+        pts, offs = ctx.saved_tensors
+        g = engine.pi_raster_wgrad(offs, pts, gimg.to(torch.float64), ctx.res)
+        return g.to(ctx.dtype), None, None
+
+
+def diagram_image(pd_hat, offs=None, res=5):
+    if offs is None:
+        offs = torch.tensor([0, pd_hat.shape[0]], dtype=torch.int64, device=pd_hat.device)
+    return DiagramImage.apply(pd_hat, offs, int(res))
 
 
 def gat_layer(x, wl, att, wij, bias, rowptr, src, prelu_slope=-1.0):

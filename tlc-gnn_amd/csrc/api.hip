@@ -1569,6 +1569,17 @@ extern "C" int tlc_pi_raster(int32_t n_dgms, const int64_t* d_offs, const double
     return tlc_launch_pi_raster(n_dgms, (const long long*)d_offs, d_pts, res, d_out, stream);
 }
 
+// gradient of tlc_pi_raster's images with respect to the points, as the reference's differentiable imager defines it (through the
+// weights only: pd_pipeline.hip, tlc_pi_raster_wgrad_kernel)
+extern "C" int tlc_pi_raster_wgrad(int32_t n_dgms, int64_t n_pts, const int64_t* d_offs, const double* d_pts, int res,
+                                   const double* d_grad_img, double* d_grad_pts, void* stream) {
+    TLC_REQUIRE(n_dgms >= 0 && n_pts >= 0, "negative count");
+    TLC_REQUIRE(res >= 1 && res <= 8, "res must be in 1..8");
+    if (n_pts == 0) return TLC_OK;
+    TLC_REQUIRE(n_dgms > 0 && d_offs && d_pts && d_grad_img && d_grad_pts, "null pointer");
+    return tlc_launch_pi_raster_wgrad(n_dgms, (long long)n_pts, (const long long*)d_offs, d_pts, res, d_grad_img, d_grad_pts, stream);
+}
+
 // ---- diagnostics (declared in include/tlcgnn.h, "diagnostics" section): per-phase cycle counters of the PD tier kernels --
 // Rows of 32 u64: one per tier (TLC_N_TIERS; the HUGE tier's row doubles as the main COUNT pass's), then the early pass, then the
 // lane-per-pair extraction.

@@ -2368,6 +2368,45 @@ static void launch_pi_raster(int n_dgms, const long long* offs, const double* pt
     hipLaunchKernelGGL(tlc_pi_raster_kernel<RES>, dim3((unsigned)blocks), dim3(256), 0, s, n_dgms, dpb, offs, pts, out);
 }
 
+// d image / d points of the DIFFERENTIABLE imager, Knowledge_Distillation/pimg.py:354-400 (Teacher_Model.forward(grad_PI=True),
+// Teacher_model.py:80-81): there the two normal-CDF factors of a point are computed from detached coordinates (`.detach()`, :392,395),
+// so the only path from a point to the image is its weight, linear_ramp(pers) (:11-30): slope 1 for 0 <= pers <= 1, constant outside.
+// Hence d L / d pers_i = sum over the pixels of dL/d image x (dPhi_b x dPhi_p of point i), and with pers = death - birth (:371)
+// d L / d death_i = that, d L / d birth_i = minus that.  One thread per point; its diagram by bisection in offs.
+__global__ void tlc_pi_raster_wgrad_kernel(int n_dgms, long long n_pts, const long long* __restrict__ offs, const double* __restrict__ pts,
+                                           int res, const double* __restrict__ grad_img, double* __restrict__ grad_pts) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pts) return;
+    const double b = pts[2 * i], pers = pts[2 * i + 1] - pts[2 * i];
+    double g = 0.0;
+    if (pers >= 0.0 && pers <= 1.0) {
+        int lo = 0, hi = n_dgms;                                   // offs[lo] <= i < offs[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= i) lo = mid; else hi = mid; }
+        const double* gi = grad_img + (size_t)lo * res * res;
+        const double step = (1.0 + 1.0 / (double)res) / (double)(res + 1);        // _create_mesh (:304-316)
+        double cp[9];
+        for (int q = 0; q <= res; ++q) cp[q] = tlc_norm_cdf<false>((double)q * step - pers);
+        double cb0 = tlc_norm_cdf<false>(0.0 - b);
+        for (int pi = 0; pi < res; ++pi) {
+            const double cb1 = tlc_norm_cdf<false>((double)(pi + 1) * step - b);
+            const double db = cb1 - cb0;
+            for (int pj = 0; pj < res; ++pj) g += gi[pi * res + pj] * (db * (cp[pj + 1] - cp[pj]));
+            cb0 = cb1;
+        }
+    }
+    grad_pts[2 * i] = -g;
+    grad_pts[2 * i + 1] = g;
+}
+
+int tlc_launch_pi_raster_wgrad(int n_dgms, long long n_pts, const long long* offs, const double* pts, int res, const double* grad_img,
+                               double* grad_pts, void* stream) {
+    if (n_pts <= 0) return TLC_OK;
+    hipLaunchKernelGGL(tlc_pi_raster_wgrad_kernel, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       n_dgms, n_pts, offs, pts, res, grad_img, grad_pts);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
 int tlc_launch_pi_raster(int n_dgms, const long long* offs, const double* pts, int res, double* out, void* stream) {
     if (n_dgms <= 0) return TLC_OK;
     hipStream_t s = (hipStream_t)stream;

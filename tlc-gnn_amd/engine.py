@@ -230,6 +230,21 @@ def pi_raster(offs, pts, res=5):
     return out[:B]
 
 
+@_lib.on_device_of
+def pi_raster_wgrad(offs, pts, grad_img, res=5):
+    """d images / d points of the reference's differentiable imager (pimg.py:354-400: through the weights only) contracted with
+    grad_img float64[B, res*res] -> float64[N, 2] (tlc_pi_raster_wgrad)."""
+    torch = _lib.require_gpu()
+    B = offs.numel() - 1
+    pts = pts.contiguous()
+    grad_img = grad_img.contiguous()
+    out = torch.zeros((max(pts.shape[0], 1), 2), dtype=torch.float64, device=offs.device)
+    rc = _lib.lib().tlc_pi_raster_wgrad(C.c_int32(B), C.c_int64(pts.shape[0]), _lib.ptr(offs.contiguous()), _lib.ptr(pts) if pts.numel() else None,
+                                        C.c_int(res), _lib.ptr(grad_img), _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "tlc_pi_raster_wgrad")
+    return out[:pts.shape[0]]
+
+
 # size tiers of the PD kernel (csrc/tlc_kernels.h) and what the library's timing slots bracket
 TIER_LIMITS = [("pd_tier_small", 64, 128), ("pd_tier_mid", 128, 256), ("pd_tier_medium", 512, 1024), ("pd_tier_large", 2048, 4096)]
 TINY_LIMITS = (16, 24)          # TLC_T_NMAX / TLC_T_MMAX: lane-per-subgraph kernel (plain image batches at resolution 5)
