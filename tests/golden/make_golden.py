@@ -21,6 +21,8 @@ Fixtures:
   G7 adj_split.npz       get_adj_split outputs, seed 1234         (loaddatas.py:38-54)
   G8 variants.npz        descriptor 'min' / 'max' and norm=False of sg2dgm_accelerate: f[n] + image rows + exception class
                          (sg2dgm/riccidist2dgm.py:20-61,310-329)
+  G4d kd_struct.npz      PDGNN fork, structural filtrations: data_utils_NC filt 'degree' / 'centrality' / 'clustering' (:124-135),
+                         data_utils_LP filt 'degree' (:131-133): values, Ord0 / Ext1, images
   G4c kd_nc.npz          PDGNN node-centred vicinity: ball(u), single root, f = d(x,u)/(max + 1e-10); Ord0 / Ext1 / images
                          (Knowledge_Distillation/data_utils_NC.py:27-50,95-187)
   G10 decode.npz         Net.decode('train' | 'val' | 'test') of the imported baselines/TLCGNN.py on seeded embeddings (rows with
@@ -673,15 +675,76 @@ def make_g10(mods):
     np.savez_compressed(os.path.join(HERE, "decode.npz"), **out)
 
 
+def make_g4d(mods):
+    """The structural filtrations of the PDGNN fork: data_utils_NC.compute_persistence_image with filt 'degree' / 'centrality' /
+    'clustering' (:124-135; the last two are what train_Teacher_Model.py:158-159 trains on) and data_utils_LP with filt 'degree'
+    (:131-133): filtration values, Ord0 / Ext1 and the three images per vicinity."""
+    import networkx as nx
+    kd_nc, kd_lp = mods["kd_nc"], mods["kd_lp"]
+    if kd_nc is None or kd_lp is None:
+        print("G4d skipped")
+        return
+    d = np.load(os.path.join(HERE, "e2e.npz"))
+    edges = d["edges"]
+    g = nx.Graph()
+    g.add_edges_from([(int(a), int(b)) for a, b in edges])
+    rs = np.random.RandomState(91)
+    roots = sorted(rs.choice(sorted(g.nodes()), size=24, replace=False).tolist())
+    pairs = [tuple(int(x) for x in edges[i]) for i in rs.choice(len(edges), size=16, replace=False)] + \
+            [tuple(int(x) for x in rs.choice(sorted(g.nodes()), size=2, replace=False)) for _ in range(8)]
+    out = dict(kind=[], hop=[], u=[], v=[])
+    ids_l, f_l, o0_l, e1_l, pis, pi0s, pi1s = [], [], [], [], [], [], []
+
+    def take(kind, hop, u, v, nodes, fv, res):
+        sub = nx.convert_node_labels_to_integers(g.subgraph(nodes), label_attribute="old_label")
+        old = np.array([sub._node[k]["old_label"] for k in range(len(sub))], dtype=np.int64)
+        order = np.argsort(old)
+        ids_l.append(old[order]); f_l.append(np.asarray(fv, dtype=np.float64)[order])
+        o0_l.append(np.asarray(res[0], dtype=np.float64).reshape(-1, 2)); e1_l.append(np.asarray(res[1], dtype=np.float64).reshape(-1, 2))
+        pis.append(np.asarray(res[2], dtype=np.float64).reshape(-1)); pi0s.append(np.asarray(res[5], dtype=np.float64).reshape(-1))
+        pi1s.append(np.asarray(res[6], dtype=np.float64).reshape(-1))
+        out["kind"].append(kind); out["hop"].append(hop); out["u"].append(u); out["v"].append(v)
+
+    for ki, filt in enumerate(("degree", "centrality", "clustering")):
+        for hop in (1, 2):
+            for u in roots:
+                fv, ei = kd_nc.compute_persistence_image(g, u, filt=filt, hop=hop, mode="filtration")
+                if fv is None or max(fv) == 0:       # (clustering of a tree is all zero: every key ties, nothing to compare)
+                    continue
+                res = kd_nc.compute_persistence_image(g, u, filt=filt, hop=hop, mode="PI")
+                nodes = [u] + [x for _, x in nx.bfs_edges(g, u, depth_limit=hop)]
+                take(ki, hop, u, -1, nodes, fv, res)
+    for hop in (1, 2):
+        for (u, v) in pairs:
+            fv, ei = kd_lp.compute_persistence_image(g, u, v, filt="degree", hop=hop, mode="filtration")
+            if fv is None:
+                continue
+            res = kd_lp.compute_persistence_image(g, u, v, filt="degree", hop=hop, mode="PI")
+            nu = [u] + [x for _, x in nx.bfs_edges(g, u, depth_limit=hop)]
+            nv = [v] + [x for _, x in nx.bfs_edges(g, v, depth_limit=hop)]
+            # data_utils_LP.py:107-111, the very expression: a subgraph view iterates the SET built from this list, whose order
+            # depends on the insertion order where hashes collide -- and `fv` is listed in that order
+            nodes = list(set(nu) & set(nv)) + [u] + [v]
+            take(3, hop, u, v, nodes, fv, res)
+    ids_flat, offs = ragged(ids_l, 0, np.int64)
+    f_flat, _ = ragged(f_l, 0, np.float64)
+    o0, o0_offs = ragged(o0_l, 2)
+    e1, e1_offs = ragged(e1_l, 2)
+    np.savez_compressed(os.path.join(HERE, "kd_struct.npz"), kind=np.array(out["kind"]), hop=np.array(out["hop"]), u=np.array(out["u"]),
+                        v=np.array(out["v"]), ids=ids_flat, f=f_flat, offs=offs, ord0=o0, ord0_offs=o0_offs, ext1=e1, ext1_offs=e1_offs,
+                        pi=np.stack(pis), pi0=np.stack(pi0s), pi1=np.stack(pi1s))
+    print("G4d cases:", len(out["kind"]), "by kind:", np.bincount(out["kind"]).tolist(), "largest:", max(len(x) for x in ids_l))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true", help="also time the reference on the PubMed-shaped graph")
-    ap.add_argument("--only", default="", help="regenerate a single fixture (g4b | g8 | g4c | g10)")
+    ap.add_argument("--only", default="", help="regenerate a single fixture (g4b | g8 | g4c | g4d | g10)")
     args = ap.parse_args()
     assert sys.version_info[:2] < (3, 12), "python>=3.12 sums with compensation: goldens would differ (SURVEY A.2)"
     mods = import_reference()
     if args.only:
-        {"g4b": make_g4b, "g8": make_g8, "g4c": make_g4c, "g10": make_g10}[args.only](mods)
+        {"g4b": make_g4b, "g8": make_g8, "g4c": make_g4c, "g4d": make_g4d, "g10": make_g10}[args.only](mods)
         return
     make_g1_g2(mods)
     make_g3(mods)
@@ -691,6 +754,7 @@ def main():
     make_g7(mods)
     make_g8(mods)
     make_g4c(mods)
+    make_g4d(mods)
     make_g10(mods)
 
 

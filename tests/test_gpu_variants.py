@@ -143,3 +143,47 @@ def test_kd_nc_node_centred_vicinities_golden_g4c():
     assert np.array_equal(np.array(fv), ragged_slice(d["f"], d["offs"], 0))
     with pytest.raises(NotImplementedError):
         kd.compute_persistence_image(edges, 0, filt='hks', ricci_curv=ricci)
+
+
+def test_kd_structural_filtrations_golden_g4d():
+    """data_utils_NC.py:124-135 (filt 'degree' / 'centrality' / 'clustering': the last two are the shipped training script's,
+    train_Teacher_Model.py:158-159) and data_utils_LP.py:131-133 (filt 'degree'): the vicinities from the device, the node
+    function from `structural_filtration` -- values bit-exact against the imported reference (G4d), then Ord0 / Ext1 as multisets
+    and the three images; single calls through the reference signatures and one batched call per (kind, hop)."""
+    from tlc_gnn_amd.Knowledge_Distillation import data_utils_NC as kd_nc, data_utils_LP as kd_lp
+    d, g5 = np.load(os.path.join(G, "kd_struct.npz")), np.load(os.path.join(G, "e2e.npz"))
+    edges = g5["edges"]
+    names = ("degree", "centrality", "clustering", "degree")
+    checked = 0
+    for gi in range(0, len(d["kind"]), 3):
+        kind, hop, u, v = int(d["kind"][gi]), int(d["hop"][gi]), int(d["u"][gi]), int(d["v"][gi])
+        if kind < 3:
+            res = kd_nc.compute_persistence_image(edges, u, filt=names[kind], hop=hop, mode='PI')
+        else:
+            res = kd_lp.compute_persistence_image(edges, u, v, filt='degree', hop=hop, mode='PI')
+        o0, e1, img, fv, ei, pi0, pi1, _, _ = res
+        assert np.array_equal(np.array(fv), ragged_slice(d["f"], d["offs"], gi)), (gi, kind)        # bit-exact f (ascending-id order)
+        assert same_multiset(o0, ragged_slice(d["ord0"], d["ord0_offs"], gi)), gi
+        assert same_multiset(e1, ragged_slice(d["ext1"], d["ext1_offs"], gi)), gi
+        for got, ref in ((img, d["pi"][gi]), (pi0, d["pi0"][gi]), (pi1, d["pi1"][gi])):
+            assert np.array_equal(np.asarray(got) == 0, ref == 0)
+            nz = ref != 0
+            if nz.any():
+                assert rel_err(np.asarray(got)[nz], ref[nz]).max() < 1e-8
+        checked += 1
+    assert checked >= 50
+    # batched: every case of a (kind, hop) in one call
+    vic_n, vic_l = kd_nc.NodeVicinities(edges, None), kd_lp.Vicinities(edges, None)
+    for kind in range(4):
+        for hop in (1, 2):
+            sel = np.nonzero((d["kind"] == kind) & (d["hop"] == hop))[0]
+            if not len(sel):
+                continue
+            b = vic_n.batch(d["u"][sel], hop, filt=names[kind]) if kind < 3 else \
+                vic_l.batch(np.stack([d["u"][sel], d["v"][sel]], 1), hop, filt='degree')
+            node_ptr, ids, f = b["node_ptr"].cpu().numpy(), b["ids"].cpu().numpy(), b["f"].cpu().numpy()
+            for k, gi in enumerate(sel):
+                assert np.array_equal(ids[node_ptr[k]:node_ptr[k + 1]], ragged_slice(d["ids"], d["offs"], gi)), (kind, hop, k)
+                assert np.array_equal(f[node_ptr[k]:node_ptr[k + 1]], ragged_slice(d["f"], d["offs"], gi)), (kind, hop, k)
+    with pytest.raises(NotImplementedError):
+        kd_lp.compute_persistence_image(edges, 0, 1, filt='hks')

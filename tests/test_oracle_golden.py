@@ -166,6 +166,35 @@ def test_kd_lp_filtration_g4b():
             assert (mm == 0).all()
 
 
+def test_kd_structural_filtrations_g4d():
+    """G4d (data_utils_NC.py:124-135 'degree' / 'centrality' / 'clustering', data_utils_LP.py:131-133 'degree', from the imported
+    reference): the host function `structural_filtration` on the induced subgraph of the golden node set -- bit-exact -- and the
+    oracle's Ord0 / Ext1 / images from those values.  The far pairs of the LP cases are disconnected subgraphs: the reference
+    walks the Pos edges of the component of its first Neg edge (accelerated_PD.py:126-127), so must the oracle."""
+    from tlc_gnn_amd.Knowledge_Distillation.data_utils_LP import structural_filtration
+    d, g5 = np.load(os.path.join(G, "kd_struct.npz")), np.load(os.path.join(G, "e2e.npz"))
+    E = np.sort(g5["edges"].astype(np.int64), axis=1)
+    names = ("degree", "centrality", "clustering", "degree")
+    n_disc = 0
+    for gi in range(len(d["kind"])):
+        ids = ragged_slice(d["ids"], d["offs"], gi)
+        pos = {int(x): k for k, x in enumerate(ids)}
+        keep = np.isin(E[:, 0], ids) & np.isin(E[:, 1], ids)
+        loc = np.array([[pos[int(a)], pos[int(b)]] for a, b in E[keep]], dtype=np.int64).reshape(-1, 2)
+        f = structural_filtration(names[int(d["kind"][gi])], [0, len(ids)], [0, len(loc)], loc)
+        assert np.array_equal(f, ragged_slice(d["f"], d["offs"], gi)), gi
+        r = oracle.pd_from_filtration([0, len(ids)], [0, len(loc)], loc, f, oracle.KEEP_ZERO_PERS)
+        c = r["counts"][0]
+        n_disc += int(c[3] != 1)
+        up, one = r["up"][:c[0]], r["one"][:c[2]]
+        assert same_multiset(up, ragged_slice(d["ord0"], d["ord0_offs"], gi)), gi
+        assert same_multiset(one, ragged_slice(d["ext1"], d["ext1_offs"], gi)), gi
+        pts = np.concatenate([up, one])
+        if len(up) and len(one):
+            assert np.abs(oracle.pi_raster([0, len(pts)], pts, 5)[0] - d["pi"][gi]).max() < 1e-12
+    assert n_disc >= 3
+
+
 def test_decode_restatement_g10():
     """oracle/lp_forward_ref.tlcgnn_decode against Net.decode of the imported reference (baselines/TLCGNN.py:27-62, G10):
     this pins the decoder half of the model-side restatement (M3 / the decode of H3) with the reference's own outputs."""

@@ -7,7 +7,8 @@ Differences from the TLC-GNN vicinity (sg2dgm/riccidist2dgm.py) that the HIP ker
 part of the subgraph (:111), there is no connectivity assert (an unreachable root costs the sentinel 100, :41-49) and the
 normalisation divides by max + 1e-10 (:64).  Node labels of a vicinity are positions in ASCENDING original id (the reference's
 `convert_node_labels_to_integers` order is arbitrary); edges are listed once, lower label first.
-HKS / degree filtrations, the CBGNN cycle helpers (:256-448, dead code in the reference) and `call` are not reproduced.
+filt='degree' (:131-133): the same vicinities, f from `structural_filtration` (host side, networkx's arithmetic).  The HKS filtration
+(a dense eigendecomposition per vicinity), the CBGNN cycle helpers (:256-448, dead code in the reference) and `call` are not reproduced.
 """
 import numpy as np
 
@@ -16,21 +17,67 @@ from .. import engine, _lib
 KD_LP_FLAGS = _lib.INCLUDE_ROOTS | _lib.NORM_EPS | _lib.UNREACHABLE_100
 
 
+STRUCTURAL_FILTS = ("degree", "centrality", "clustering")
+
+
+def structural_filtration(kind, node_ptr, edge_ptr, edges):
+    """The node functions of the induced subgraph that the reference computes with networkx (data_utils_LP.py:131-133 'degree';
+    data_utils_NC.py:124-135 'centrality', 'clustering', 'degree'), each divided by (max + 1e-10), for a packed batch of
+    vicinities: node_ptr / edge_ptr int64[B+1], edges int[sum m, 2] local ids -> float64[sum n].  Host side (numpy + scipy.sparse):
+    they are functions of a few hundred nodes; the vicinities themselves come from the device.  Same operations in the same
+    order as networkx, so the values are the reference's bit for bit:
+      degree      d                                  (subgraph.degree())
+      centrality  d * (1.0 / (n - 1.0))              (nx.degree_centrality)
+      clustering  t / (d * (d - 1)), t = sum over the neighbours w of |N(v) & N(w)| (each triangle twice), 0 where t == 0
+                                                      (nx.clustering, unweighted)"""
+    import scipy.sparse as sp
+    if kind not in STRUCTURAL_FILTS:
+        raise ValueError("filt should be one of %s" % (STRUCTURAL_FILTS,))
+    node_ptr = np.asarray(node_ptr, dtype=np.int64)
+    edge_ptr = np.asarray(edge_ptr, dtype=np.int64)
+    edges = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+    N = int(node_ptr[-1])
+    owner = np.repeat(np.arange(len(node_ptr) - 1), np.diff(node_ptr))
+    base = np.repeat(node_ptr[:-1], np.diff(edge_ptr))
+    a, b = edges[:, 0] + base, edges[:, 1] + base
+    deg = np.bincount(np.concatenate([a, b]), minlength=N).astype(np.int64)
+    if kind == "degree":
+        raw = deg.astype(np.float64)
+    elif kind == "centrality":
+        n_of = np.diff(node_ptr)[owner].astype(np.float64)
+        raw = deg.astype(np.float64) * (1.0 / (n_of - 1.0))
+    else:
+        A = sp.csr_matrix((np.ones(2 * len(a), dtype=np.int64), (np.concatenate([a, b]), np.concatenate([b, a]))), shape=(N, N))
+        t = np.asarray((A @ A).multiply(A).sum(axis=1)).reshape(-1).astype(np.int64)
+        den = (deg * (deg - 1)).astype(np.float64)
+        raw = np.where(t > 0, t.astype(np.float64) / np.where(den > 0, den, 1.0), 0.0)
+    mx = np.zeros(len(node_ptr) - 1, dtype=np.float64)
+    if N:
+        np.maximum.at(mx, owner, raw)
+    return raw / (mx[owner] + 1e-10) if N else raw
+
+
 class Vicinities:
-    """Device-resident weighted graph for PDGNN's edge-centred vicinities; build once, query many pairs."""
+    """Device-resident weighted graph for PDGNN's edge-centred vicinities; build once, query many pairs.
+    ricci_curv=None: no curvature (the structural filtrations need only the vicinities): unit edge weights."""
 
     def __init__(self, g, ricci_curv):
-        from ..sg2dgm.riccidist2dgm import graph2pi
+        from ..sg2dgm.riccidist2dgm import graph2pi, _edge_array
+        if ricci_curv is None:
+            e = _edge_array(g)
+            ricci_curv = np.concatenate([np.concatenate([e, e[:, ::-1]]).astype(np.float64), np.zeros((2 * len(e), 1))], axis=1)
         self._g2p = graph2pi(g, ricci_curv, keep_labels=True)   # kappa+1 weights (riccidist2dgm.py:216-226)
         self.dict_node = self._g2p.dict_node
         self.inv = np.arange(self._g2p.n_nodes, dtype=np.int64)
         for old, new in self.dict_node.items():
             self.inv[new] = old
 
-    def batch(self, pairs, hop, node_cap=None, edge_cap=None, flags=None):
+    def batch(self, pairs, hop, node_cap=None, edge_cap=None, flags=None, filt='ricci'):
         """pairs: [E,2] original labels -> dict of CUDA tensors: node_ptr int64[E+1], edge_ptr int64[E+1], ids int64 (original
         labels, ascending inside a vicinity), f float64, edges int32 [sum m, 2] (local ids, lower first), status uint8[E].
-        Vicinities without an edge have empty slices (the reference returns (None, None) for them, :117-118)."""
+        Vicinities without an edge have empty slices (the reference returns (None, None) for them, :117-118).
+        filt: 'ricci' (the weighted-distance filtration of the device kernels) or one of STRUCTURAL_FILTS (f replaced by
+        `structural_filtration` of the extracted vicinities)."""
         import torch
         dev_graph = self._g2p._device_graph()
         mapped = torch.from_numpy(self._g2p._map_pairs(pairs)).cuda()
@@ -52,6 +99,8 @@ class Vicinities:
             self._inv_dev = torch.from_numpy(self.inv).to(n.device)
         out_ids, out_f, out_e, pn, pe = engine.pack_vicinities(offs, ids, f, eoffs, edges, node_ptr, edge_ptr, int(tot_n), int(tot_m),
                                                                label=self._inv_dev)
+        if filt != 'ricci':
+            out_f = torch.from_numpy(structural_filtration(filt, node_ptr.cpu().numpy(), edge_ptr.cpu().numpy(), out_e.cpu().numpy())).to(out_f.device)
         return dict(node_ptr=node_ptr, edge_ptr=edge_ptr, ids=out_ids, f=out_f, edges=out_e, status=st, pair_of_node=pn, pair_of_edge=pe)
 
 
@@ -71,12 +120,12 @@ def _vicinities(g, ricci_curv):
 
 def compute_persistence_image(g, u, v, filt='hks', hks_time=0.1, hop=2, ricci_curv=None, mode='PI', num_models=5,
                               max_loop_len=10, cycle_the=2):
-    """Reference signature (:105).  filt='ricci' only; mode 'filtration' -> (filtration_val list, edge_index LongTensor[2,m])
-    or (None, None); mode 'PI' -> the reference's 9-tuple (times are 0)."""
+    """Reference signature (:105).  filt='ricci' or 'degree' (:131-133); mode 'filtration' -> (filtration_val list, edge_index
+    LongTensor[2,m]) or (None, None); mode 'PI' -> the reference's 9-tuple (times are 0)."""
     import torch
-    if filt != 'ricci':
-        raise NotImplementedError("data_utils_LP (HIP): only filt='ricci' is implemented (hks / degree filtrations are host-side inputs)")
-    b = _vicinities(g, ricci_curv).batch([[u, v]], hop)
+    if filt not in ('ricci', 'degree'):
+        raise NotImplementedError("data_utils_LP (HIP): filt='ricci' and 'degree' are implemented ('hks' needs a dense eigh of every vicinity: a host-side input)")
+    b = _vicinities(g, ricci_curv).batch([[u, v]], hop, filt=filt)
     if int(b["edge_ptr"][-1]) == 0:
         return None, None
     fv = b["f"].cpu().numpy()
@@ -98,8 +147,12 @@ def diagrams_and_images(b, fv, edge_index):
                                   torch.tensor([0, m], dtype=torch.int64, device="cuda"),
                                   b["edges"].contiguous(), b["f"].contiguous(), _lib.KEEP_ZERO_PERS)
     c = r["counts"][0].cpu().numpy()
-    if c[3] != 1:
-        raise KeyError("vicinity is not connected: the reference's Accelerate_PD raises here (accelerated_PD.py:132-148)")
+    if c[3] != 1 and int(c[2]) != m - n + int(c[3]):
+        # not connected, and a Pos edge lies outside the component of the tree's root: Parent[...] of the reference's walk has no
+        # such node (accelerated_PD.py:132-148, KeyError).  (Components without a cycle -- the isolated roots of a far pair -- are
+        # no obstacle there either: every one of the m - n + #components Pos edges was walked.)
+        raise KeyError("vicinity is not connected and a cycle lies outside the root's component: the reference's Accelerate_PD raises "
+                       "here (accelerated_PD.py:132-148)")
     ord0, ext1 = r["up"][:c[0]], r["one"][:c[2]]
 
     def img(pts):

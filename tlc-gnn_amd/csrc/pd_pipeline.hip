@@ -769,72 +769,79 @@ __device__ __forceinline__ bool ext1_build_tree(Mem<idx_t>& M, const SwapTables&
     const int nneg = M.ctl[4];
     const unsigned* ends = M.dir;
     unsigned *par = T.par, *key = T.key, *mark = T.mark;
-    // spanning tree of the Neg edges (:119-125).  Any root gives the same diagram; rank 0 (a root of the vicinity) keeps
-    // the tree shallow.  If rank 0 is not incident to a Neg edge (disconnected input) fall back to the reference's choice.
-    // (the Neg list in M.pn and the edge tables in M.dir are outside the regions re-used here)
-    __syncthreads();
-    for (int i = tid; i < n; i += W) { par[i] = NONE; key[i] = 0u; mark[i] = 0u; }
-    __syncthreads();
+    // spanning tree of the Neg edges (:119-125).  In a connected subgraph any root gives the same diagram; rank 0 (a root of the
+    // vicinity) keeps the tree shallow.  The reference roots it at the first endpoint of its FIRST Neg edge (:126-127): in a
+    // disconnected subgraph that decides which component's Pos edges can be walked at all (the others raise KeyError there), so
+    // when rank 0 turns out to sit in another component than that edge -- or is not incident to a Neg edge -- the tree is built
+    // again from the reference's choice.  (the Neg list in M.pn and the edge tables in M.dir are outside the regions re-used here)
+    const int ref_root = (int)(ends[M.pn[MMcap - 1]] >> 16);
     int root = 0;
     {
-        const unsigned ab = ends[M.pn[MMcap - 1]];
         bool has0 = false;
         for (int k = tid; k < nneg; k += W) has0 |= ((ends[M.pn[MMcap - 1 - k]] >> 16) == 0u);
-        if (!block_any<W>(has0, M.ctl, 5)) root = ab >> 16;
+        if (!block_any<W>(has0, M.ctl, 5)) root = ref_root;
     }
-    if (tid == 0) par[root] = (unsigned)root;
-    __syncthreads();
-    if (nneg <= 4 * W) {
-        // (every LDS tier: at most four Neg edges per thread) the edges stay in registers over the rounds and retire once
-        // oriented, so a round costs the two parent reads of the edges still open, not the whole list again
-        unsigned eab[4], ekey[4];
-        bool open[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = tid + q * W;
-            open[q] = k < nneg;
-            eab[q] = 0u; ekey[q] = 0u;
-            if (open[q]) {
-                const unsigned eid = M.pn[MMcap - 1 - k];
-                eab[q] = ends[eid];
-                ekey[q] = (M.arank[eid] + 1u) << 8;
-            }
-        }
-        for (int round = 0; round <= n; ++round) {
-            bool prog = false;
+    bool any_unreached = false;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        __syncthreads();
+        for (int i = tid; i < n; i += W) { par[i] = NONE; key[i] = 0u; mark[i] = 0u; }
+        __syncthreads();
+        if (tid == 0) par[root] = (unsigned)root;
+        __syncthreads();
+        if (nneg <= 4 * W) {
+            // (every LDS tier: at most four Neg edges per thread) the edges stay in registers over the rounds and retire once
+            // oriented, so a round costs the two parent reads of the edges still open, not the whole list again
+            unsigned eab[4], ekey[4];
+            bool open[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                const int k = tid + q * W;
+                open[q] = k < nneg;
+                eab[q] = 0u; ekey[q] = 0u;
                 if (open[q]) {
-                    const int a = eab[q] >> 16, b = eab[q] & 0xffffu;
-                    const unsigned pa = par[a], pb = par[b];
-                    if (pa != NONE && pb == NONE) { par[b] = (unsigned)a; key[b] = ekey[q]; prog = true; open[q] = false; }
-                    else if (pb != NONE && pa == NONE) { par[a] = (unsigned)b; key[a] = ekey[q]; prog = true; open[q] = false; }
+                    const unsigned eid = M.pn[MMcap - 1 - k];
+                    eab[q] = ends[eid];
+                    ekey[q] = (M.arank[eid] + 1u) << 8;
                 }
             }
-            __syncthreads();
-            if (!block_any<W>(prog, M.ctl, 5)) break;
-        }
-    } else {
-        for (int round = 0; round <= n; ++round) {
-            bool prog = false;
-            for (int k = tid; k < nneg; k += W) {
-                const unsigned eid = M.pn[MMcap - 1 - k];
-                const unsigned ab = ends[eid];
-                const int a = ab >> 16, b = ab & 0xffffu;
-                const unsigned pa = par[a], pb = par[b];
-                if (pa != NONE && pb == NONE) { par[b] = (unsigned)a; key[b] = (M.arank[eid] + 1u) << 8; prog = true; }
-                else if (pb != NONE && pa == NONE) { par[a] = (unsigned)b; key[a] = (M.arank[eid] + 1u) << 8; prog = true; }
+            for (int round = 0; round <= n; ++round) {
+                bool prog = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (open[q]) {
+                        const int a = eab[q] >> 16, b = eab[q] & 0xffffu;
+                        const unsigned pa = par[a], pb = par[b];
+                        if (pa != NONE && pb == NONE) { par[b] = (unsigned)a; key[b] = ekey[q]; prog = true; open[q] = false; }
+                        else if (pb != NONE && pa == NONE) { par[a] = (unsigned)b; key[a] = ekey[q]; prog = true; open[q] = false; }
+                    }
+                }
+                __syncthreads();
+                if (!block_any<W>(prog, M.ctl, 5)) break;
             }
-            __syncthreads();
-            if (!block_any<W>(prog, M.ctl, 5)) break;
+        } else {
+            for (int round = 0; round <= n; ++round) {
+                bool prog = false;
+                for (int k = tid; k < nneg; k += W) {
+                    const unsigned eid = M.pn[MMcap - 1 - k];
+                    const unsigned ab = ends[eid];
+                    const int a = ab >> 16, b = ab & 0xffffu;
+                    const unsigned pa = par[a], pb = par[b];
+                    if (pa != NONE && pb == NONE) { par[b] = (unsigned)a; key[b] = (M.arank[eid] + 1u) << 8; prog = true; }
+                    else if (pb != NONE && pa == NONE) { par[a] = (unsigned)b; key[a] = (M.arank[eid] + 1u) << 8; prog = true; }
+                }
+                __syncthreads();
+                if (!block_any<W>(prog, M.ctl, 5)) break;
+            }
         }
+        // nodes the tree did not reach (disconnected input): only then does a query have to test its endpoints
+        bool unreached = false;
+        for (int i = tid; i < n; i += W) unreached |= (par[i] == NONE);
+        any_unreached = block_any<W>(unreached, M.ctl, 5);
+        if (!any_unreached || root == ref_root || par[ref_root] != NONE) break;      // (uniform)
+        root = ref_root;
     }
     // above the root sits the spare slot, its own parent, behind edges of key 0: a walk that passes the root keeps
     // stepping in place there, so a step needs no "at the root" case
-    // nodes the tree did not reach (disconnected input): only then does a query have to test its endpoints
-    bool unreached = false;
-    for (int i = tid; i < n; i += W) unreached |= (par[i] == NONE);
-    const bool any_unreached = block_any<W>(unreached, M.ctl, 5);
     if (tid == 0) { par[root] = (unsigned)NMcap; key[root] = 0u; par[NMcap] = (unsigned)NMcap; key[NMcap] = 0u; mark[NMcap] = 0u; }
     __syncthreads();
     return any_unreached;
