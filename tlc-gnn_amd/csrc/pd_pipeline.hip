@@ -1391,6 +1391,26 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
     if constexpr (HUGE) { M.lds_swap = p.huge_lds > 0 ? lds_raw : nullptr; M.lds_swap_bytes = (size_t)p.huge_lds; }
     const int res = p.res, res2 = res * res;
 
+    // Issue priority by LDS per wavefront (development A/B, make EXTRA="-DTLC_PRIO_LARGE=3 ..."; default 0 = none): in a pipelined
+    // batch a tier costs LDS capacity x time, so a wavefront that holds much LDS should get through first.  Measured
+    // (tools/gpu_build_ab3.sh, TINY 3 / LARGE 3 / MEDIUM 2 / MID 1 / SMALL 1 and subsets, four builds in turn): 0.649 - 0.664 ms per
+    // pipelined batch whatever the setting -- the SIMDs are not contended enough for issue arbitration to matter
+#ifndef TLC_PRIO_LARGE
+#define TLC_PRIO_LARGE 0
+#endif
+#ifndef TLC_PRIO_MEDIUM
+#define TLC_PRIO_MEDIUM 0
+#endif
+#ifndef TLC_PRIO_MID
+#define TLC_PRIO_MID 0
+#endif
+#ifndef TLC_PRIO_SMALL
+#define TLC_PRIO_SMALL 0
+#endif
+    if constexpr (!HUGE) {
+        constexpr int prio = NM == TLC_L_NMAX ? TLC_PRIO_LARGE : ((NM == TLC_M_NMAX || NM == TLC_C_NMAX) ? TLC_PRIO_MEDIUM : (NM == TLC_D_NMAX ? TLC_PRIO_MID : TLC_PRIO_SMALL));
+        if constexpr (prio > 0) __builtin_amdgcn_s_setprio(prio);
+    }
     // this workgroup is resident: tell the launcher's gate (api.hip, tlc_wait_started)
     if (p.abort_flag && *p.abort_flag) return;
     int tier_count = p.tier_count;

@@ -412,6 +412,10 @@ __device__ __forceinline__ void tiny_slot(const TlcPdParams p, unsigned char* ld
 // from the arena through a tier list: one workgroup = one wavefront = 64 list positions, no loop around the body
 __global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+#ifndef TLC_PRIO_TINY
+#define TLC_PRIO_TINY 0
+#endif
+    if (TLC_PRIO_TINY > 0) __builtin_amdgcn_s_setprio(TLC_PRIO_TINY);      // (development A/B: 36 KB of LDS on one wavefront)
     tiny_slot<false>(p, lds_all, (int)(threadIdx.x & 63), (int)blockIdx.x);
 }
 
