@@ -157,6 +157,50 @@ def test_medium_compact_and_wide_configurations(n, m):
     g.close()
 
 
+@pytest.mark.parametrize("n,m", [(1024, 2048), (1025, 1500), (900, 2049), (601, 900)])
+@pytest.mark.parametrize("n_pairs", [8, 4608])
+def test_large_tier_split_into_compact_and_wide_kernels(n, m, n_pairs):
+    """Option large_split (off by default: measured slower): the LARGE tier as two launches over one list, kernels sized for 1 024
+    nodes / 2 048 edges (72 KB tier, 54 KB divide and conquer) for the vicinities that fit, the 2 048 / 4 096 ones for the rest.  At
+    the cut, on the ordinary heavy path (8 pairs) and through the early pass (4 608), alone and in one batch with the other kind:
+    the rows of the unsplit tier bit for bit -- and the oracle's; then in pipelined chunks."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    rs = np.random.RandomState(n + m)
+    other = (1100, 2300) if (n <= 1024 and m <= 2048) else (700, 1000)
+    comps, base, pairs = [], 0, []
+    for nn, mm, reps in ((n, m, 6), (other[0], other[1], 2)):
+        comps.append(hub_component(nn, mm, rs, base))
+        pairs += [[base, base + k] for k in range(1, reps + 1)]
+        base += nn
+    e = np.concatenate(comps)
+    rowptr, col, w = synth.edges_to_csr(base, e, rs.uniform(-0.5, 0.9, size=len(e)))
+    pairs = np.tile(np.array(pairs), (n_pairs // 8, 1))
+    g = engine.DeviceGraph(rowptr, col, w)
+    g.set_option("large_split", 0)
+    ref_out, ref_st = _check(g, torch, rowptr, col, w, pairs)
+    assert g.stats()["tier_large"] == len(pairs)
+    g.set_option("large_split", 2)
+    for _ in range(2):
+        out, st = _check(g, torch, rowptr, col, w, pairs)
+        assert np.array_equal(out, ref_out) and np.array_equal(st, ref_st)
+    g.set_option("dc_force_fail", 1)                                # every divide and conquer given back to the serial walk it carries
+    out, st = _check(g, torch, rowptr, col, w, pairs)
+    assert np.abs(out - ref_out).max() <= 1e-12 * np.abs(ref_out).max() and np.array_equal(st, ref_st)
+    g.set_option("dc_force_fail", 0)
+    g.set_option("large_split", 1)                                  # pipelined chunks only (the default is 0: measured slower)
+    dev = torch.as_tensor(np.ascontiguousarray(pairs, dtype=np.int32)).cuda()
+    outs = [torch.empty((len(pairs), 25), dtype=torch.float64, device="cuda") for _ in range(3)]
+    sts = [torch.empty(len(pairs), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    for k in range(3):
+        g.pd_pi_batch(dev, 2, out=outs[k], status=sts[k], async_=True)
+    g.join()
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert np.array_equal(outs[k].cpu().numpy(), ref_out) and np.array_equal(sts[k].cpu().numpy(), ref_st)
+    g.close()
+
+
 def test_speculative_launches_beyond_their_reserved_slots():
     """The MEDIUM-many-Pos tier kernel is submitted before the tier sizes are known, one workgroup per slot reserved from the
     previous chunk's count; list positions beyond the slots are completed by a second launch, and MEDIUM / MID vicinities beyond

@@ -201,6 +201,11 @@ struct tlc_graph {
     int opt_x_grid, opt_x_chunk_div;    // development: extraction workgroups / work-queue granularity (0: the defaults)
     int opt_chunk_pairs;                // development: pairs per chunk (0: TLC_CHUNK_PAIRS)
     int opt_medium_first;               // development: submit the MEDIUM / MID tiers ahead of TINY / SMALL
+    // LARGE tier as two launches over one list (compact kernels, 72 / 54 KB of LDS, for the vicinities of <= 1 024 nodes / 2 048 edges): 0 never
+    // (default), 1 pipelined chunks, 2 always.  Measured, tools/ab_option.py large_split 0 1: 0.652 -> 0.677 ms per pipelined batch -- the
+    // LDS capacity x time it saves does not pay for a LARGE chain that is two kernels longer and whose workgroups share their CU: the
+    // chunk completes when its LARGE chain does, and only three chunks are in flight.  Rows are bit-equal either way (tests/test_gpu_tiers.py).
+    int opt_large_split;
     int opt_n_ws;                       // workspaces taken in turn (2..TLC_N_WS, default 3)
     int opt_defer;                      // a pipelined chunk's second half is submitted behind the NEXT chunk's first half (default 1)
     int opt_gate_ticks;                 // development: bound of the residency gate of pipelined chunks (-1: the default 50 us)
@@ -538,7 +543,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     // one batch alone and a loss for pipelined batches -- see the note at `xlane` in run_chunk_front and DESIGN.md)
     { const char* v = getenv("TLC_XL_CUT"); g->opt_xl_cut = v ? std::min(std::max(atoi(v), 0), TLC_XL_MAXCUT) : 0; }
     g->opt_xl_ncut = TLC_T_NCUT; g->opt_xl_mcut = TLC_T_MCUT;
-    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
+    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_large_split = 0; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
@@ -827,6 +832,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
     pp.stats = ws->d_stats;
     pp.dc_force_fail = g->opt_dc_force_fail;
+    pp.large_split = ((pipelined && g->opt_large_split == 1) || g->opt_large_split == 2) ? 1 : 0;
     // lists for tlc_pd_dc_kernel: counters in the control block (zeroed with it), [d_ctl + 26 + 2k];
     // k = 0 MEDIUM, 1 LARGE (regular launch), 2 LARGE (early launch)
     auto dc_lists_for = [&](TlcPdParams& q, int k) {
@@ -1628,6 +1634,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "mh_always")) g->opt_mh_always = value != 0;
     else if (!strcmp(name, "gate_ticks")) g->opt_gate_ticks = value;
     else if (!strcmp(name, "medium_first")) g->opt_medium_first = value != 0;
+    else if (!strcmp(name, "large_split")) g->opt_large_split = value;
     else if (!strcmp(name, "n_ws")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_n_ws = std::min(std::max(value, 2), TLC_N_WS); }
     else if (!strcmp(name, "defer")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_defer = value != 0; }
     else if (!strcmp(name, "chunk_pairs")) g->opt_chunk_pairs = std::max(value, 0);

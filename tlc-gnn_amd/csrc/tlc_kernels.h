@@ -70,6 +70,11 @@
 #endif
 #define TLC_L_NMAX 2048
 #define TLC_L_MMAX 4096
+/* LARGE-tier vicinities of at most this size take kernels with half the footprint (72 KB tier, 54 KB divide and conquer) when the launcher
+   splits the tier (pipelined chunks: TlcPdParams::large_split) -- a LARGE workgroup otherwise holds a whole CU's LDS for a vicinity of
+   typically 600 - 700 nodes */
+#define TLC_LC_NMAX 1024
+#define TLC_LC_MMAX 2048
 #define TLC_L_THREADS 512   /* 1024 measured slower (0.99 vs 0.94 ms): barriers over 16 wavefronts, 128-VGPR cap */
 #define TLC_HUGE_MIN_TABLE 16384  /* bytes reserved for the image table in a HUGE scratch slot */
 
@@ -238,6 +243,7 @@ struct TlcPdParams {
     int huge_mmax;
     int huge_slots;
     int huge_lds;           // HUGE tier: dynamic LDS bytes of the launch (tables of the serial cycle swap), 0 = none
+    int large_split;        // LARGE tier: two launches over the same list, the TLC_LC_* kernels for the vicinities that fit them, the TLC_L_* ones for the rest
     // statistics: [0] sources that took the exact tie fallback
     unsigned long long* stats;
     // diagnostics (null in production): per tier 16 accumulated cycle counts of thread 0, see pd_pipeline.hip
