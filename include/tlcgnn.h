@@ -391,6 +391,12 @@ int tlc_near_pairs(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_co
  * d_status_hist uint64[8] (may be NULL; the caller zeroes it once per store).  *d_count (uint64, device; the caller zeroes it
  * per call) is advanced by the number of kept rows even beyond `cap` (rows past the capacity are not written: re-run the block
  * with a larger store, and a fresh histogram).  Append order is not fixed. */
+/* The offsets of that packed batch from the per-pair counts of tlc_vicinity_filtration, one launch: d_node_ptr / d_edge_ptr int64[n_pairs+1]
+ * = exclusive prefix sums of (m > 0 ? n : 0) and max(m, 0) -- a vicinity without an edge is left out, the reference returns (None, None)
+ * for it (data_utils_LP.py:117-118) -- and d_totals int64[4] = {min n, min m, sum n, sum m} (a negative minimum: some vicinity did not
+ * fit the capacity it was given). */
+int tlc_pack_offsets(int64_t n_pairs, const int32_t* d_n, const int32_t* d_m, int64_t* d_node_ptr, int64_t* d_edge_ptr,
+                     int64_t* d_totals, void* stream);
 /* The caller side of the PDGNN fork's vicinity extraction (Knowledge_Distillation/data_utils_LP.py:105-200 returns one
  * (filtration values, edge_index) per candidate edge; gcn_LP_GIN.Net.compute_PI :43-64 feeds them to the model one by one): the
  * per-pair capacity slots tlc_vicinity_filtration wrote -> ONE packed block-diagonal batch.  d_node_ptr / d_edge_ptr int64[n+1]:

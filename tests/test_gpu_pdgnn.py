@@ -362,3 +362,21 @@ def test_data_utils_gc_dropin_matches_reference_golden_g6():
     assert img.shape == (len(graphs) - 1, 25) and 5 not in kept and bool(torch.isfinite(img).all())
     img1, _ = gc.evaluate_batch(model, [res[0]])
     assert torch.allclose(img1[0], img[0], rtol=1e-4, atol=1e-7)
+
+
+def test_pack_offsets_against_numpy():
+    """tlc_pack_offsets: prefix sums of (m > 0 ? n : 0) and max(m, 0), minima and totals, at sizes around the 1 024 slices."""
+    import torch
+    from tlc_gnn_amd import engine
+    rs = np.random.RandomState(4)
+    for E in (1, 7, 1023, 1024, 1025, 4096, 50001):
+        n = rs.randint(0, 300, size=E).astype(np.int32)
+        m = rs.randint(0, 900, size=E).astype(np.int32)
+        m[rs.rand(E) < 0.2] = 0
+        if E > 100:
+            n[5] = -17; m[9] = -3                                     # "did not fit" markers
+        node_ptr, edge_ptr, totals = engine.pack_offsets(torch.from_numpy(n).cuda(), torch.from_numpy(m).cuda())
+        keep = np.where(m > 0, np.maximum(n, 0), 0).astype(np.int64)
+        want_n = np.concatenate([[0], np.cumsum(keep)]); want_m = np.concatenate([[0], np.cumsum(np.maximum(m, 0).astype(np.int64))])
+        assert np.array_equal(node_ptr.cpu().numpy(), want_n) and np.array_equal(edge_ptr.cpu().numpy(), want_m), E
+        assert totals.tolist() == [int(n.min()), int(m.min()), int(want_n[-1]), int(want_m[-1])], E

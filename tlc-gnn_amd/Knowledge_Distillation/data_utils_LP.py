@@ -85,14 +85,11 @@ class Vicinities:
         e_cap = max(dev_graph.nnz // 2, 1) if edge_cap is None else int(edge_cap)
         offs, ids, f, n, st, eoffs, edges, m = dev_graph.vicinity_filtration(mapped, hop, flags=KD_LP_FLAGS if flags is None else flags,
                                                                              cap=n_cap, edge_cap=e_cap, zero=False)
-        # packed offsets on the device; ONE host read: the two totals (to size the packed arrays) and the two capacity checks
+        # packed offsets on the device (one kernel; no edge -> (None, None): an empty slice); ONE host read: the two totals (to size
+        # the packed arrays) and the two capacity checks
         E = len(n)
-        keep_n = torch.where(m > 0, n, torch.zeros_like(n)).long()         # no edge -> (None, None): an empty slice
-        node_ptr = torch.zeros(E + 1, dtype=torch.int64, device=n.device)
-        edge_ptr = torch.zeros(E + 1, dtype=torch.int64, device=n.device)
-        torch.cumsum(keep_n, 0, out=node_ptr[1:])
-        torch.cumsum(m.clamp(min=0).long(), 0, out=edge_ptr[1:])
-        lo_n, lo_m, tot_n, tot_m = torch.stack([n.min().long(), m.min().long(), node_ptr[-1], edge_ptr[-1]]).tolist() if E else (0, 0, 0, 0)
+        node_ptr, edge_ptr, totals = engine.pack_offsets(n, m)
+        lo_n, lo_m, tot_n, tot_m = totals.tolist() if E else (0, 0, 0, 0)
         if lo_n < 0 or lo_m < 0:
             raise RuntimeError("vicinity larger than the requested node_cap / edge_cap")
         if getattr(self, "_inv_dev", None) is None or self._inv_dev.device != n.device:

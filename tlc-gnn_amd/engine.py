@@ -138,6 +138,19 @@ class DeviceGraph:
                                                     C.c_int64(n_pairs), _lib.stream_ptr(self.device)), "sizes")
         return n, m2
 
+    def _capacity_offsets(self, E, cap, dev):
+        """arange(E + 1) * cap, kept for the last few (E, cap): a loop over equally sized chunks asks for the same two tensors every time
+        (read-only: callers get the cached tensor itself)."""
+        cache = self.__dict__.setdefault("_cap_offs", {})
+        key = (E, cap, str(dev))
+        t = cache.get(key)
+        if t is None:
+            import torch
+            if len(cache) >= 8:
+                cache.clear()
+            t = cache[key] = torch.arange(E + 1, dtype=torch.int64, device=dev) * cap
+        return t
+
     def vicinity_filtration(self, pairs, hop, flags=0, cap=None, edge_cap=None, zero=True):
         """-> (node_offs int64[E+1], ids int32[E*cap], f float64[E*cap], n int32[E], status uint8[E])
         with edge_cap: additionally (edge_offs int64[E+1], edges int32[E*edge_cap,2] local ids, m int32[E]).
@@ -150,14 +163,14 @@ class DeviceGraph:
         cap = self.n_nodes if cap is None else int(cap)
         dev = pairs.device
         mk = torch.zeros if zero else torch.empty
-        offs = torch.arange(E + 1, dtype=torch.int64, device=dev) * cap
+        offs = self._capacity_offsets(E, cap, dev)
         ids = mk(max(E * cap, 1), dtype=torch.int32, device=dev)
         f = mk(max(E * cap, 1), dtype=torch.float64, device=dev)
         n = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
         st = torch.zeros(max(E, 1), dtype=torch.uint8, device=dev)
         eoffs = edges = m = None
         if edge_cap is not None:
-            eoffs = torch.arange(E + 1, dtype=torch.int64, device=dev) * int(edge_cap)
+            eoffs = self._capacity_offsets(E, int(edge_cap), dev)
             edges = mk((max(E * int(edge_cap), 1), 2), dtype=torch.int32, device=dev)
             m = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
         rc = _lib.lib().tlc_vicinity_filtration(self._h, _lib.ptr(pairs), C.c_int64(E), C.c_int(hop), C.c_uint32(flags),
@@ -186,6 +199,22 @@ def pack_vicinities(node_offs, ids, f, edge_offs, edges, node_ptr, edge_ptr, tot
                                         _lib.ptr(out_f), _lib.ptr(out_e), _lib.ptr(pn), _lib.ptr(pe), _lib.stream_ptr())
     _lib.check(rc, "tlc_pack_vicinities")
     return out_ids[:tot_n], out_f[:tot_n], out_e[:tot_m], (pn[:tot_n] if owners else None), (pe[:tot_m] if owners else None)
+
+
+@_lib.on_device_of
+def pack_offsets(n, m):
+    """Per-pair counts of vicinity_filtration (int32[E], negative = did not fit) -> (node_ptr int64[E+1], edge_ptr int64[E+1],
+    totals int64[4] = min n, min m, sum n, sum m): tlc_pack_offsets, one launch; vicinities without an edge are left out."""
+    torch = _lib.require_gpu()
+    E = n.numel()
+    dev = n.device
+    node_ptr = torch.empty(E + 1, dtype=torch.int64, device=dev)
+    edge_ptr = torch.empty(E + 1, dtype=torch.int64, device=dev)
+    totals = torch.empty(4, dtype=torch.int64, device=dev)
+    rc = _lib.lib().tlc_pack_offsets(C.c_int64(E), _lib.ptr(n.contiguous()), _lib.ptr(m.contiguous()), _lib.ptr(node_ptr), _lib.ptr(edge_ptr),
+                                     _lib.ptr(totals), _lib.stream_ptr())
+    _lib.check(rc, "tlc_pack_offsets")
+    return node_ptr, edge_ptr, totals
 
 
 @_lib.on_device_of
