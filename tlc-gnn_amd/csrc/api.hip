@@ -201,6 +201,7 @@ struct tlc_graph {
     int opt_x_grid, opt_x_chunk_div;    // development: extraction workgroups / work-queue granularity (0: the defaults)
     int opt_chunk_pairs;                // development: pairs per chunk (0: TLC_CHUNK_PAIRS)
     int opt_medium_first;               // development: submit the MEDIUM / MID tiers ahead of TINY / SMALL
+    int opt_early_wait;                 // development: 0 = the main COUNT of a pipelined chunk does not wait for the early pass (default 1)
     // LARGE tier as two launches over one list (compact kernels, 72 / 54 KB of LDS, for the vicinities of <= 1 024 nodes / 2 048 edges): 0 never
     // (default), 1 pipelined chunks, 2 always.  Measured, tools/ab_option.py large_split 0 1: 0.652 -> 0.677 ms per pipelined batch -- the
     // LDS capacity x time it saves does not pay for a LARGE chain that is two kernels longer and whose workgroups share their CU: the
@@ -543,7 +544,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     // one batch alone and a loss for pipelined batches -- see the note at `xlane` in run_chunk_front and DESIGN.md)
     { const char* v = getenv("TLC_XL_CUT"); g->opt_xl_cut = v ? std::min(std::max(atoi(v), 0), TLC_XL_MAXCUT) : 0; }
     g->opt_xl_ncut = TLC_T_NCUT; g->opt_xl_mcut = TLC_T_MCUT;
-    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_large_split = 0; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
+    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_large_split = 0; g->opt_early_wait = 1; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
@@ -853,6 +854,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
             if ((rc = tlc_launch_classify(n_pairs, d_pairs, g->n_nodes, g->d_bptr, TLC_M_NMAX - 1, TLC_EARLY_CAND, d_cand_count,
                                           ws->d_cand_list, ws->d_ctl + 32, ws->big_lists, xlane ? g->opt_xl_cut : 0, ws->d_ctl + 40,
                                           ws->xl_list, es)) != TLC_OK) return rc;
+            if (!xlane) TLC_HIP_CHECK(hipEventRecord(ws->ev_cls, es));
             if (xlane) {
                 // The lane-per-pair pass needs the classification only.  It is one wavefront per 64 pairs, ~300 wavefronts that each
                 // run ~80 us of serial lane code: cheap for the machine, long for a chain -- so it runs on a side stream beside the
@@ -942,10 +944,14 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         // one of its tier kernel, which needs a whole CU's LDS -- is placed only as they drain (measured: the early tier kernel
         // then runs 1.05 instead of 0.88 ms because its last workgroups start ~0.15 ms late).  So the main COUNT is held until
         // the early COUNT is done and the early tier kernel's workgroups are resident (bounded: 50 us after the former).
-        TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_early, 0));
+        // (opt_early_wait = 0, pipelined chunks, development A/B: the main COUNT waits for the classification only and runs beside the
+        // early pass instead of behind it -- tools/ab_option.py early_wait 1 0: 0.6625 / 0.6604 ms per pipelined batch, rotating 0.619 /
+        // 0.629: no gain, the early pass's 58 us in front of every extraction are not what the pipelined batch pays for)
+        const bool beside = pipelined && use_x && !g->opt_early_wait;
+        TLC_HIP_CHECK(hipStreamWaitEvent(s, beside ? ws->ev_cls : ws->ev_early, 0));
         // (opt_gate_ticks: the bound in 10 ns ticks, 0 = no gate at all; development A/B of the pipelined case, where the machine
         // is full of the previous chunk's tier kernels whatever this chunk's extraction does)
-        const long long gate = pipelined && g->opt_gate_ticks >= 0 ? (long long)g->opt_gate_ticks : 5000ll;
+        const long long gate = beside ? 0ll : (pipelined && g->opt_gate_ticks >= 0 ? (long long)g->opt_gate_ticks : 5000ll);
         if (gate > 0)
             hipLaunchKernelGGL(tlc_wait_started_dev, dim3(1), dim3(TLC_WAVE), 0, s, (const int*)d_early_started, (const int*)d_early_count,
                                192, gate);
@@ -1635,6 +1641,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "gate_ticks")) g->opt_gate_ticks = value;
     else if (!strcmp(name, "medium_first")) g->opt_medium_first = value != 0;
     else if (!strcmp(name, "large_split")) g->opt_large_split = value;
+    else if (!strcmp(name, "early_wait")) g->opt_early_wait = value != 0;
     else if (!strcmp(name, "n_ws")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_n_ws = std::min(std::max(value, 2), TLC_N_WS); }
     else if (!strcmp(name, "defer")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_defer = value != 0; }
     else if (!strcmp(name, "chunk_pairs")) g->opt_chunk_pairs = std::max(value, 0);
