@@ -62,6 +62,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise TlcError("libtlcgnn_hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the product path)")
+        # torch first: it ships its own libamdhip64, and a process must end up with ONE HIP runtime -- with this library (linked
+        # against /opt/rocm's) loaded before torch, the two copies each initialise and the second sees no device
+        # (`build()` followed by `smoke()` in one process: TLC_ERR_NO_DEVICE)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.tlc_version.restype = C.c_char_p
         L.tlc_last_error.restype = C.c_char_p
