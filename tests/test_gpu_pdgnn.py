@@ -380,3 +380,26 @@ def test_pack_offsets_against_numpy():
         want_n = np.concatenate([[0], np.cumsum(keep)]); want_m = np.concatenate([[0], np.cumsum(np.maximum(m, 0).astype(np.int64))])
         assert np.array_equal(node_ptr.cpu().numpy(), want_n) and np.array_equal(edge_ptr.cpu().numpy(), want_m), E
         assert totals.tolist() == [int(n.min()), int(m.min()), int(want_n[-1]), int(want_m[-1])], E
+
+
+def test_empty_inputs_of_the_packed_vicinity_path():
+    """No pairs, and pairs without any vicinity edge: empty packed batches, no launch with a zero grid, no host read of garbage."""
+    import torch
+    from tlc_gnn_amd import engine, autograd
+    from tlc_gnn_amd.Knowledge_Distillation import data_utils_LP as kd
+    z = torch.zeros(0, dtype=torch.int32, device="cuda")
+    node_ptr, edge_ptr, totals = engine.pack_offsets(z, z)
+    assert node_ptr.tolist() == [0] and edge_ptr.tolist() == [0] and totals[2:].tolist() == [0, 0]
+    g5 = np.load(os.path.join(G, "e2e.npz"))
+    vic = kd.Vicinities(g5["edges"], None)
+    b = vic.batch(np.zeros((0, 2), dtype=np.int64), 1)
+    assert int(b["node_ptr"][-1]) == 0 and b["ids"].numel() == 0 and b["edges"].numel() == 0
+    for filt in ("ricci", "degree"):
+        far = vic.batch([[int(g5["edges"][0, 0]), int(g5["edges"][0, 0])]], 0 + 1, filt=filt)     # (u, u): its closed neighbourhood
+        assert int(far["node_ptr"][-1]) >= 1
+    # an image of no points, and its gradient
+    x = torch.zeros((0, 2), dtype=torch.float32, device="cuda", requires_grad=True)
+    img = autograd.diagram_image(x)
+    assert img.shape == (1, 25) and bool((img == 0).all())
+    img.sum().backward()
+    assert x.grad.shape == (0, 2)
