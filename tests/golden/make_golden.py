@@ -21,6 +21,8 @@ Fixtures:
   G7 adj_split.npz       get_adj_split outputs, seed 1234         (loaddatas.py:38-54)
   G8 variants.npz        descriptor 'min' / 'max' and norm=False of sg2dgm_accelerate: f[n] + image rows + exception class
                          (sg2dgm/riccidist2dgm.py:20-61,310-329)
+  G4e kd_hks.npz         filt='hks' (the signatures' default): data_utils_GC :114-116 (times 0.1 / 10), data_utils_NC :120-122, data_utils_LP
+                         :128-130: values, Ord0 / Ext1, images
   G4d kd_struct.npz      PDGNN fork, structural filtrations: data_utils_NC filt 'degree' / 'centrality' / 'clustering' (:124-135),
                          data_utils_LP filt 'degree' (:131-133): values, Ord0 / Ext1, images
   G4c kd_nc.npz          PDGNN node-centred vicinity: ball(u), single root, f = d(x,u)/(max + 1e-10); Ord0 / Ext1 / images
@@ -736,15 +738,86 @@ def make_g4d(mods):
     print("G4d cases:", len(out["kind"]), "by kind:", np.bincount(out["kind"]).tolist(), "largest:", max(len(x) for x in ids_l))
 
 
+def make_g4e(mods):
+    """filt='hks' -- the default of all three compute_persistence_image signatures (data_utils_GC.py:114-116 with the shipped
+    loop's times 0.1 and 10, :315-319; data_utils_NC.py:120-122; data_utils_LP.py:128-130): values, Ord0 / Ext1, images.
+    GC graphs have nodes 0..n-1 (values comparable bit for bit); NC / LP values are stored in ascending-id order."""
+    import networkx as nx
+    kd_gc, kd_nc, kd_lp = mods["kd_gc"], mods["kd_nc"], mods["kd_lp"]
+    if kd_gc is None or kd_nc is None or kd_lp is None:
+        print("G4e skipped")
+        return
+    d = np.load(os.path.join(HERE, "e2e.npz"))
+    edges = d["edges"]
+    g = nx.Graph()
+    g.add_edges_from([(int(a), int(b)) for a, b in edges])
+    rs = np.random.RandomState(17)
+    meta = dict(kind=[], hop=[], u=[], v=[], time=[], n=[])
+    ids_l, f_l, e_l, o0_l, e1_l, pis, pi0s, pi1s = [], [], [], [], [], [], [], []
+
+    def take(kind, hop, u, v, t, old, fv, ei_old, res):
+        order = np.argsort(old)
+        ids_l.append(old[order]); f_l.append(np.asarray(fv, dtype=np.float64)[order]); e_l.append(ei_old)
+        o0_l.append(np.asarray(res[0], dtype=np.float64).reshape(-1, 2)); e1_l.append(np.asarray(res[1], dtype=np.float64).reshape(-1, 2))
+        pis.append(np.asarray(res[2], dtype=np.float64).reshape(-1)); pi0s.append(np.asarray(res[5], dtype=np.float64).reshape(-1))
+        pi1s.append(np.asarray(res[6], dtype=np.float64).reshape(-1))
+        for k, x in zip(("kind", "hop", "u", "v", "time", "n"), (kind, hop, u, v, t, len(old))):
+            meta[k].append(x)
+
+    for gi in range(24):                                                  # GC: whole graphs, nodes 0..n-1
+        n = int(max(3, rs.poisson(22)))
+        ee = random_connected_graph(rs, n, int(rs.randint(0, 4)))
+        gg = nx.Graph()
+        gg.add_nodes_from(range(n))
+        gg.add_edges_from([(int(a), int(b)) for a, b in ee])
+        for t in (0.1, 10):
+            res = kd_gc.compute_persistence_image(gg, filt="hks", hks_time=t, mode="PI")
+            take(2, 0, -1, -1, t, np.arange(n), res[3], np.asarray(res[4]).T.astype(np.int64), res)
+    roots = sorted(rs.choice(sorted(g.nodes()), size=10, replace=False).tolist())
+    for hop in (1, 2):
+        for u in roots:
+            for t in (0.1, 10):
+                fv, ei = kd_nc.compute_persistence_image(g, u, filt="hks", hks_time=t, hop=hop, mode="filtration")
+                if fv is None:
+                    continue
+                res = kd_nc.compute_persistence_image(g, u, filt="hks", hks_time=t, hop=hop, mode="PI")
+                nodes = [u] + [x for _, x in nx.bfs_edges(g, u, depth_limit=hop)]
+                sub = nx.convert_node_labels_to_integers(g.subgraph(nodes), label_attribute="old_label")
+                old = np.array([sub._node[k]["old_label"] for k in range(len(sub))], dtype=np.int64)
+                take(0, hop, u, -1, t, old, fv, np.zeros((0, 2), dtype=np.int64), res)
+    pairs = [tuple(int(x) for x in edges[i]) for i in rs.choice(len(edges), size=10, replace=False)]
+    for hop in (1, 2):
+        for (u, v) in pairs:
+            fv, ei = kd_lp.compute_persistence_image(g, u, v, filt="hks", hks_time=0.1, hop=hop, mode="filtration")
+            if fv is None:
+                continue
+            res = kd_lp.compute_persistence_image(g, u, v, filt="hks", hks_time=0.1, hop=hop, mode="PI")
+            nu = [u] + [x for _, x in nx.bfs_edges(g, u, depth_limit=hop)]
+            nv = [v] + [x for _, x in nx.bfs_edges(g, v, depth_limit=hop)]
+            nodes = list(set(nu) & set(nv)) + [u] + [v]
+            sub = nx.convert_node_labels_to_integers(g.subgraph(nodes), label_attribute="old_label")
+            old = np.array([sub._node[k]["old_label"] for k in range(len(sub))], dtype=np.int64)
+            take(1, hop, u, v, 0.1, old, fv, np.zeros((0, 2), dtype=np.int64), res)
+    ids_flat, offs = ragged(ids_l, 0, np.int64)
+    f_flat, _ = ragged(f_l, 0, np.float64)
+    e_flat, e_offs = ragged(e_l, 2, np.int64)
+    o0, o0_offs = ragged(o0_l, 2)
+    e1, e1_offs = ragged(e1_l, 2)
+    np.savez_compressed(os.path.join(HERE, "kd_hks.npz"), ids=ids_flat, f=f_flat, offs=offs, edges=e_flat, e_offs=e_offs, ord0=o0,
+                        ord0_offs=o0_offs, ext1=e1, ext1_offs=e1_offs, pi=np.stack(pis), pi0=np.stack(pi0s), pi1=np.stack(pi1s),
+                        **{k: np.array(v) for k, v in meta.items()})
+    print("G4e cases:", len(meta["kind"]), "by kind (NC, LP, GC):", np.bincount(meta["kind"]).tolist(), "largest:", max(meta["n"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true", help="also time the reference on the PubMed-shaped graph")
-    ap.add_argument("--only", default="", help="regenerate a single fixture (g4b | g8 | g4c | g4d | g10)")
+    ap.add_argument("--only", default="", help="regenerate a single fixture (g4b | g8 | g4c | g4d | g4e | g10)")
     args = ap.parse_args()
     assert sys.version_info[:2] < (3, 12), "python>=3.12 sums with compensation: goldens would differ (SURVEY A.2)"
     mods = import_reference()
     if args.only:
-        {"g4b": make_g4b, "g8": make_g8, "g4c": make_g4c, "g4d": make_g4d, "g10": make_g10}[args.only](mods)
+        {"g4b": make_g4b, "g8": make_g8, "g4c": make_g4c, "g4d": make_g4d, "g4e": make_g4e, "g10": make_g10}[args.only](mods)
         return
     make_g1_g2(mods)
     make_g3(mods)
@@ -755,6 +828,7 @@ def main():
     make_g8(mods)
     make_g4c(mods)
     make_g4d(mods)
+    make_g4e(mods)
     make_g10(mods)
 
 

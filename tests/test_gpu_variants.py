@@ -141,8 +141,8 @@ def test_kd_nc_node_centred_vicinities_golden_g4c():
         assert np.array_equal(np.array(fv), ragged_slice(d["f"], d["offs"], gi)) and tuple(ei.shape) == (2, len(ragged_slice(d["edges"], d["e_offs"], gi)))
     fv, ei = kd.compute_persistence_image(edges, int(d["roots"][0]), filt='ricci', hop=int(d["hop"][0]), ricci_curv=ricci, mode='filtration')
     assert np.array_equal(np.array(fv), ragged_slice(d["f"], d["offs"], 0))
-    with pytest.raises(NotImplementedError):
-        kd.compute_persistence_image(edges, 0, filt='hks', ricci_curv=ricci)
+    with pytest.raises(SystemExit):                                       # the reference prints and calls sys.exit() (:154-155)
+        kd.compute_persistence_image(edges, 0, filt='no such filtration', ricci_curv=ricci)
 
 
 def test_kd_structural_filtrations_golden_g4d():
@@ -185,5 +185,42 @@ def test_kd_structural_filtrations_golden_g4d():
             for k, gi in enumerate(sel):
                 assert np.array_equal(ids[node_ptr[k]:node_ptr[k + 1]], ragged_slice(d["ids"], d["offs"], gi)), (kind, hop, k)
                 assert np.array_equal(f[node_ptr[k]:node_ptr[k + 1]], ragged_slice(d["f"], d["offs"], gi)), (kind, hop, k)
-    with pytest.raises(NotImplementedError):
-        kd_lp.compute_persistence_image(edges, 0, 1, filt='hks')
+    with pytest.raises(SystemExit):                                       # the reference prints and calls sys.exit() (:152-153)
+        kd_lp.compute_persistence_image(edges, 0, 1, filt='no such filtration')
+
+
+def test_kd_hks_filtration_golden_g4e():
+    """filt='hks', the default of the three compute_persistence_image signatures (data_utils_GC.py:114-116, data_utils_NC.py:
+    120-122, data_utils_LP.py:128-130): vicinities from the device, `hks_signature` on the host (scipy's eigh, like the reference),
+    diagrams and images on the device.  Values bit-exact for whole graphs (same node order), 1e-11 for vicinities; images 1e-7
+    (symmetric nodes tie up to rounding: which of them a pair lands on is noise on either side)."""
+    from tlc_gnn_amd.Knowledge_Distillation import data_utils_NC as kd_nc, data_utils_LP as kd_lp, data_utils_GC as kd_gc
+    d, g5 = np.load(os.path.join(G, "kd_hks.npz")), np.load(os.path.join(G, "e2e.npz"))
+    edges = g5["edges"]
+    n_done = [0, 0, 0]
+    for gi in range(0, len(d["kind"]), 2):
+        kind, hop, u, v, t = int(d["kind"][gi]), int(d["hop"][gi]), int(d["u"][gi]), int(d["v"][gi]), float(d["time"][gi])
+        ref_f = ragged_slice(d["f"], d["offs"], gi)
+        if kind == 2:
+            res = kd_gc.compute_persistence_image((int(d["n"][gi]), ragged_slice(d["edges"], d["e_offs"], gi)), filt='hks', hks_time=t, mode='PI')
+        elif kind == 0:
+            res = kd_nc.compute_persistence_image(edges, u, filt='hks', hks_time=t, hop=hop, mode='PI')
+        else:
+            res = kd_lp.compute_persistence_image(edges, u, v, filt='hks', hks_time=t, hop=hop, mode='PI')
+        o0, e1, img, fv, ei, pi0, pi1, _, _ = res
+        if kind == 2:
+            assert np.array_equal(np.array(fv), ref_f), gi
+        else:
+            assert np.abs(np.array(fv) - ref_f).max() <= 1e-11, gi
+        assert len(o0) == len(ragged_slice(d["ord0"], d["ord0_offs"], gi)) and len(e1) == len(ragged_slice(d["ext1"], d["ext1_offs"], gi)), gi
+        for got, ref in ((img, d["pi"][gi]), (pi0, d["pi0"][gi]), (pi1, d["pi1"][gi])):
+            assert np.abs(np.asarray(got) - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max()), (gi, kind)
+        n_done[kind] += 1
+    assert min(n_done) >= 8
+    # batched GC call == single calls
+    sel = [gi for gi in range(len(d["kind"])) if int(d["kind"][gi]) == 2 and float(d["time"][gi]) == 10.0][:12]
+    graphs = [(int(d["n"][gi]), ragged_slice(d["edges"], d["e_offs"], gi)) for gi in sel]
+    outs = kd_gc.compute_persistence_image_batch(graphs, filt='hks', hks_time=10.0)
+    for gi, o in zip(sel, outs):
+        assert np.array_equal(np.array(o[3]), ragged_slice(d["f"], d["offs"], gi))
+        assert np.abs(np.asarray(o[2]) - d["pi"][gi]).max() <= 1e-7

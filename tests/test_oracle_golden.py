@@ -195,6 +195,56 @@ def test_kd_structural_filtrations_g4d():
     assert n_disc >= 3
 
 
+def _close_multiset(a, b, tol):
+    """two point sets equal as multisets up to `tol`: same count, and the lexicographically sorted arrays agree within tol after
+    rounding both to a grid of 10 x tol (near-equal points may swap places in the sort, rounding puts them on the same key)"""
+    a, b = np.asarray(a, dtype=np.float64).reshape(-1, 2), np.asarray(b, dtype=np.float64).reshape(-1, 2)
+    if len(a) != len(b):
+        return False
+    if not len(a):
+        return True
+    key = lambda x: np.lexsort((np.round(x[:, 1] / (10 * tol)), np.round(x[:, 0] / (10 * tol))))
+    return bool(np.abs(np.sort(a[:, 0]) - np.sort(b[:, 0])).max() <= tol and np.abs(np.sort(a[:, 1]) - np.sort(b[:, 1])).max() <= tol
+                and np.abs(a.sum(0) - b.sum(0)).max() <= tol * len(a))
+
+
+def test_kd_hks_g4e():
+    """G4e (filt='hks', the signatures' default; from the imported reference): `hks_signature` -- bit-exact where the node order
+    is the reference's (data_utils_GC: nodes 0..n-1), to rounding otherwise (the eigenproblem of a permuted matrix) -- then the
+    oracle's diagrams and images from those values.  HKS values of symmetric nodes tie up to rounding, so which of two such nodes
+    a pair lands on is noise on either side: diagrams are compared as multisets of VALUES within 1e-9, images within 1e-7."""
+    from tlc_gnn_amd.Knowledge_Distillation.data_utils_LP import hks_signature
+    d, g5 = np.load(os.path.join(G, "kd_hks.npz")), np.load(os.path.join(G, "e2e.npz"))
+    E = np.sort(g5["edges"].astype(np.int64), axis=1)
+    n_exact = 0
+    for gi in range(len(d["kind"])):
+        kind, t = int(d["kind"][gi]), float(d["time"][gi])
+        ids = ragged_slice(d["ids"], d["offs"], gi)
+        if kind == 2:
+            loc = ragged_slice(d["edges"], d["e_offs"], gi)
+        else:
+            pos = {int(x): k for k, x in enumerate(ids)}
+            keep = np.isin(E[:, 0], ids) & np.isin(E[:, 1], ids)
+            loc = np.array([[pos[int(a)], pos[int(b)]] for a, b in E[keep]], dtype=np.int64).reshape(-1, 2)
+        v = hks_signature(len(ids), loc, t)
+        f = v / (max(v) + 1e-10)
+        ref_f = ragged_slice(d["f"], d["offs"], gi)
+        if kind == 2:
+            assert np.array_equal(f, ref_f), gi
+            n_exact += 1
+        else:
+            assert np.abs(f - ref_f).max() <= 1e-11, (gi, np.abs(f - ref_f).max())
+        r = oracle.pd_from_filtration([0, len(ids)], [0, len(loc)], loc, f, oracle.KEEP_ZERO_PERS)
+        c = r["counts"][0]
+        up, one = r["up"][:c[0]], r["one"][:c[2]]
+        assert _close_multiset(up, ragged_slice(d["ord0"], d["ord0_offs"], gi), 1e-9), gi
+        assert _close_multiset(one, ragged_slice(d["ext1"], d["ext1_offs"], gi), 1e-9), gi
+        pts = np.concatenate([up, one])
+        if len(up) and len(one):
+            assert np.abs(oracle.pi_raster([0, len(pts)], pts, 5)[0] - d["pi"][gi]).max() < 1e-7
+    assert n_exact == 48
+
+
 def test_decode_restatement_g10():
     """oracle/lp_forward_ref.tlcgnn_decode against Net.decode of the imported reference (baselines/TLCGNN.py:27-62, G10):
     this pins the decoder half of the model-side restatement (M3 / the decode of H3) with the reference's own outputs."""

@@ -1,7 +1,7 @@
 """Drop-in for the ground-truth generation of the reference's Knowledge_Distillation/data_utils_GC.py (PDGNN, graph
 classification: whole graph = one diagram) and for the forward-only loop of train_Teacher_Model_GC.evaluate_time.
 
-  compute_persistence_image :98-170 (filt='degree'; HKS needs a dense eigendecomposition and stays a host-side input),
+  compute_persistence_image :98-170 (filt='degree' and 'hks': node functions on the host, the reference's own numpy / scipy calls),
   original_extended_persistence :78-82, call :228-279 (largest connected component, relabel), evaluate_time :118-143.
 
 The extended persistence of every graph runs in `tlc_pd_from_filtration` (Knowledge_Distillation fork: zero-persistence pairs
@@ -43,13 +43,20 @@ def _connected(n, edges):
     return len({find(i) for i in range(n)}) == 1
 
 
-def compute_persistence_image_batch(graphs, filt='degree', filtrations=None):
+def hks_filtration(n, edges, hks_time):
+    """:114-116  hks_signature / (max + 1e-10): the reference's scipy calls on the same matrix (nodes 0..n-1), host side."""
+    from .data_utils_LP import hks_signature
+    v = hks_signature(n, edges, hks_time)
+    return v / (max(v) + 1e-10)
+
+
+def compute_persistence_image_batch(graphs, filt='degree', filtrations=None, hks_time=0.1):
     """graphs: list of networkx-like graphs with nodes 0..n-1, or (n, edges[m,2]) tuples.
     Returns a list with the reference's 9-tuple per graph (:166), or (None, None) for graphs without an edge / not
-    connected (:101-103).  `filtrations` supplies f per graph for filt != 'degree' (e.g. precomputed HKS)."""
+    connected (:101-103).  filt: 'degree' or 'hks' (host side, :114-119); `filtrations` supplies f per graph for anything else."""
     import torch
-    if filt != 'degree' and filtrations is None:
-        raise NotImplementedError("data_utils_GC (HIP): filt='degree' is computed here; pass `filtrations` for anything else")
+    if filt not in ('degree', 'hks') and filtrations is None:
+        raise NotImplementedError("data_utils_GC (HIP): filt='degree' and 'hks' are computed here; pass `filtrations` for anything else")
     parsed, keep = [], []
     for gi, g in enumerate(graphs):
         n, e = _edges_nodes(g)
@@ -60,7 +67,8 @@ def compute_persistence_image_batch(graphs, filt='degree', filtrations=None):
     out = [(None, None)] * len(graphs)
     if not keep:
         return out
-    fs = [np.asarray(filtrations[gi], dtype=np.float64) if filtrations is not None else degree_filtration(*parsed[gi]) for gi in keep]
+    fs = [np.asarray(filtrations[gi], dtype=np.float64) if filtrations is not None else
+          (hks_filtration(parsed[gi][0], parsed[gi][1], hks_time) if filt == 'hks' else degree_filtration(*parsed[gi])) for gi in keep]
     node_offs = np.concatenate([[0], np.cumsum([parsed[gi][0] for gi in keep])]).astype(np.int64)
     edge_offs = np.concatenate([[0], np.cumsum([len(parsed[gi][1]) for gi in keep])]).astype(np.int64)
     edges = np.concatenate([parsed[gi][1] for gi in keep]).astype(np.int32)
@@ -101,16 +109,19 @@ def compute_persistence_image_batch(graphs, filt='degree', filtrations=None):
 
 def compute_persistence_image(g, filt='hks', hks_time=0.1, hop=2, ricci_curv=None, mode='PI', num_models=5, max_loop_len=10,
                               cycle_the=2):
-    """Reference signature (:98).  filt='degree' only; mode 'PI' -> 9-tuple, 'filtration' -> (filtration_val, edge_index)."""
+    """Reference signature (:98).  filt='hks' (the default) or 'degree' ('ricci' needs curvatures per graph: pass `filtrations`
+    to compute_persistence_image_batch); mode 'PI' -> 9-tuple, 'filtration' -> (filtration_val, edge_index)."""
     import torch
-    if filt != 'degree':
-        raise NotImplementedError("data_utils_GC (HIP): only filt='degree' is implemented ('hks' needs a dense eigh: host-side input)")
+    if filt not in ('degree', 'hks'):
+        raise NotImplementedError("data_utils_GC (HIP): filt='hks' and 'degree' are implemented; for 'ricci' pass the values as "
+                                  "`filtrations` to compute_persistence_image_batch")
     n, e = _edges_nodes(g)
     if len(e) == 0 or not _connected(n, e):
         return None, None
     if mode == 'filtration':
-        return degree_filtration(n, e).tolist(), torch.from_numpy(e.T.copy()).long()
-    return compute_persistence_image_batch([(n, e)], filt='degree')[0]
+        f = hks_filtration(n, e, hks_time) if filt == 'hks' else degree_filtration(n, e)
+        return f.tolist(), torch.from_numpy(e.T.copy()).long()
+    return compute_persistence_image_batch([(n, e)], filt=filt, hks_time=hks_time)[0]
 
 
 def evaluate_batch(model, samples):

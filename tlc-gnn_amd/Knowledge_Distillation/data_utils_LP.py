@@ -7,9 +7,11 @@ Differences from the TLC-GNN vicinity (sg2dgm/riccidist2dgm.py) that the HIP ker
 part of the subgraph (:111), there is no connectivity assert (an unreachable root costs the sentinel 100, :41-49) and the
 normalisation divides by max + 1e-10 (:64).  Node labels of a vicinity are positions in ASCENDING original id (the reference's
 `convert_node_labels_to_integers` order is arbitrary); edges are listed once, lower label first.
-filt='degree' (:131-133): the same vicinities, f from `structural_filtration` (host side, networkx's arithmetic).  The HKS filtration
-(a dense eigendecomposition per vicinity), the CBGNN cycle helpers (:256-448, dead code in the reference) and `call` are not reproduced.
+filt='degree' (:131-133) and 'hks' (:128-130, the signature's default): the same vicinities, f from `structural_filtration` (host side:
+networkx's arithmetic, scipy's eigh).  The CBGNN cycle helpers (:256-448, dead code in the reference) and `call` are not reproduced.
 """
+import sys
+
 import numpy as np
 
 from .. import engine, _lib
@@ -17,10 +19,26 @@ from .. import engine, _lib
 KD_LP_FLAGS = _lib.INCLUDE_ROOTS | _lib.NORM_EPS | _lib.UNREACHABLE_100
 
 
-STRUCTURAL_FILTS = ("degree", "centrality", "clustering")
+STRUCTURAL_FILTS = ("degree", "centrality", "clustering", "hks")
 
 
-def structural_filtration(kind, node_ptr, edge_ptr, edges):
+def hks_signature(n, edges, time):
+    """hks_signature of the reference (data_utils_LP.py:96-100, data_utils_NC.py:88-92, data_utils_GC.py:90-94): the heat-kernel
+    signature sum_k exp(-t lambda_k) phi_k(x)^2 of the normalised Laplacian -- the same scipy calls on the same kind of matrix
+    (`csgraph.laplacian(A, normed=True)`, dense `eigh`), n nodes, edges int[m, 2] local ids.  Host side: a dense symmetric
+    eigenproblem per graph.  Node order: ascending id here, networkx's subgraph order there -- the values of a node agree to
+    rounding (1e-12), bit for bit when the orders coincide (data_utils_GC: nodes 0..n-1)."""
+    import scipy.sparse as sp
+    from scipy.sparse import csgraph
+    from scipy.linalg import eigh
+    e = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+    A = sp.csr_matrix((np.ones(2 * len(e), dtype=np.int64), (np.concatenate([e[:, 0], e[:, 1]]), np.concatenate([e[:, 1], e[:, 0]]))), shape=(n, n))
+    L = csgraph.laplacian(A, normed=True)
+    egvals, egvectors = eigh(L.toarray())
+    return np.square(egvectors).dot(np.diag(np.exp(-time * egvals))).sum(axis=1)
+
+
+def structural_filtration(kind, node_ptr, edge_ptr, edges, hks_time=0.1):
     """The node functions of the induced subgraph that the reference computes with networkx (data_utils_LP.py:131-133 'degree';
     data_utils_NC.py:124-135 'centrality', 'clustering', 'degree'), each divided by (max + 1e-10), for a packed batch of
     vicinities: node_ptr / edge_ptr int64[B+1], edges int[sum m, 2] local ids -> float64[sum n].  Host side (numpy + scipy.sparse):
@@ -29,7 +47,8 @@ def structural_filtration(kind, node_ptr, edge_ptr, edges):
       degree      d                                  (subgraph.degree())
       centrality  d * (1.0 / (n - 1.0))              (nx.degree_centrality)
       clustering  t / (d * (d - 1)), t = sum over the neighbours w of |N(v) & N(w)| (each triangle twice), 0 where t == 0
-                                                      (nx.clustering, unweighted)"""
+                                                      (nx.clustering, unweighted)
+      hks         `hks_signature` at time hks_time    (a dense eigenproblem per vicinity)"""
     import scipy.sparse as sp
     if kind not in STRUCTURAL_FILTS:
         raise ValueError("filt should be one of %s" % (STRUCTURAL_FILTS,))
@@ -37,6 +56,14 @@ def structural_filtration(kind, node_ptr, edge_ptr, edges):
     edge_ptr = np.asarray(edge_ptr, dtype=np.int64)
     edges = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
     N = int(node_ptr[-1])
+    if kind == "hks":                                        # (:128-130 / :120-122: hks_signature, then /= max + 1e-10, per graph)
+        out = np.zeros(N, dtype=np.float64)
+        for k in range(len(node_ptr) - 1):
+            a, b = int(node_ptr[k]), int(node_ptr[k + 1])
+            if b > a:
+                v = hks_signature(b - a, edges[int(edge_ptr[k]):int(edge_ptr[k + 1])], hks_time)
+                out[a:b] = v / (max(v) + 1e-10)
+        return out
     owner = np.repeat(np.arange(len(node_ptr) - 1), np.diff(node_ptr))
     base = np.repeat(node_ptr[:-1], np.diff(edge_ptr))
     a, b = edges[:, 0] + base, edges[:, 1] + base
@@ -72,7 +99,7 @@ class Vicinities:
         for old, new in self.dict_node.items():
             self.inv[new] = old
 
-    def batch(self, pairs, hop, node_cap=None, edge_cap=None, flags=None, filt='ricci'):
+    def batch(self, pairs, hop, node_cap=None, edge_cap=None, flags=None, filt='ricci', hks_time=0.1):
         """pairs: [E,2] original labels -> dict of CUDA tensors: node_ptr int64[E+1], edge_ptr int64[E+1], ids int64 (original
         labels, ascending inside a vicinity), f float64, edges int32 [sum m, 2] (local ids, lower first), status uint8[E].
         Vicinities without an edge have empty slices (the reference returns (None, None) for them, :117-118).
@@ -97,7 +124,8 @@ class Vicinities:
         out_ids, out_f, out_e, pn, pe = engine.pack_vicinities(offs, ids, f, eoffs, edges, node_ptr, edge_ptr, int(tot_n), int(tot_m),
                                                                label=self._inv_dev)
         if filt != 'ricci':
-            out_f = torch.from_numpy(structural_filtration(filt, node_ptr.cpu().numpy(), edge_ptr.cpu().numpy(), out_e.cpu().numpy())).to(out_f.device)
+            out_f = torch.from_numpy(structural_filtration(filt, node_ptr.cpu().numpy(), edge_ptr.cpu().numpy(), out_e.cpu().numpy(),
+                                                           hks_time=hks_time)).to(out_f.device)
         return dict(node_ptr=node_ptr, edge_ptr=edge_ptr, ids=out_ids, f=out_f, edges=out_e, status=st, pair_of_node=pn, pair_of_edge=pe)
 
 
@@ -117,12 +145,13 @@ def _vicinities(g, ricci_curv):
 
 def compute_persistence_image(g, u, v, filt='hks', hks_time=0.1, hop=2, ricci_curv=None, mode='PI', num_models=5,
                               max_loop_len=10, cycle_the=2):
-    """Reference signature (:105).  filt='ricci' or 'degree' (:131-133); mode 'filtration' -> (filtration_val list, edge_index
-    LongTensor[2,m]) or (None, None); mode 'PI' -> the reference's 9-tuple (times are 0)."""
+    """Reference signature (:105).  filt='hks' (:128-130), 'degree' (:131-133) or 'ricci'; mode 'filtration' -> (filtration_val
+    list, edge_index LongTensor[2,m]) or (None, None); mode 'PI' -> the reference's 9-tuple (times are 0)."""
     import torch
-    if filt not in ('ricci', 'degree'):
-        raise NotImplementedError("data_utils_LP (HIP): filt='ricci' and 'degree' are implemented ('hks' needs a dense eigh of every vicinity: a host-side input)")
-    b = _vicinities(g, ricci_curv).batch([[u, v]], hop, filt=filt)
+    if filt not in ('ricci', 'degree', 'hks'):
+        print("Error: 'filt' should be 'hks', 'degree' or 'ricci'! ")          # :152-153
+        sys.exit()
+    b = _vicinities(g, ricci_curv).batch([[u, v]], hop, filt=filt, hks_time=hks_time)
     if int(b["edge_ptr"][-1]) == 0:
         return None, None
     fv = b["f"].cpu().numpy()

@@ -9,9 +9,12 @@ device that is the pair (u, u) -- ball(u) & ball(u) -- with TLC_DESC_ROOT1 | TLC
 TLC_UNREACHABLE_100.  Node labels of a vicinity are positions in ASCENDING original id (the reference's
 `convert_node_labels_to_integers` order is arbitrary); edges are listed once, lower label first.
 filt='degree' / 'centrality' / 'clustering' (:124-135; the shipped training script's filtrations, train_Teacher_Model.py:158-159): the
-same vicinities from the device, f from `data_utils_LP.structural_filtration` (host side, networkx's arithmetic: bit-equal values).
-The HKS filtration (a dense eigendecomposition per vicinity) and `call` are not reproduced.
+same vicinities from the device, f from `data_utils_LP.structural_filtration` (host side, networkx's arithmetic: bit-equal values);
+filt='hks' (:120-122): `hks_signature` with scipy's eigh, host side (values to rounding: the node order inside a vicinity differs).
+`call` is not reproduced.
 """
+import sys
+
 import numpy as np
 
 from .. import _lib
@@ -23,11 +26,11 @@ KD_NC_FLAGS = _lib.INCLUDE_ROOTS | _lib.NORM_EPS | _lib.UNREACHABLE_100 | _lib.D
 class NodeVicinities(Vicinities):
     """Device-resident weighted graph for PDGNN's node-centred vicinities; build once, query many nodes."""
 
-    def batch(self, nodes, hop, node_cap=None, edge_cap=None, filt='ricci'):
+    def batch(self, nodes, hop, node_cap=None, edge_cap=None, filt='ricci', hks_time=0.1):
         """nodes: [B] original labels -> the dict of Vicinities.batch (one vicinity per node).  filt: 'ricci', or 'degree' /
         'centrality' / 'clustering' (:124-135; `data_utils_LP.structural_filtration`)."""
         nodes = np.asarray(nodes, dtype=np.int64).reshape(-1)
-        return super().batch(np.stack([nodes, nodes], 1), hop, node_cap=node_cap, edge_cap=edge_cap, flags=KD_NC_FLAGS, filt=filt)
+        return super().batch(np.stack([nodes, nodes], 1), hop, node_cap=node_cap, edge_cap=edge_cap, flags=KD_NC_FLAGS, filt=filt, hks_time=hks_time)
 
 
 _CACHE = {}
@@ -60,14 +63,14 @@ def _vicinities(g, ricci_curv):
 
 def compute_persistence_image(g, u, filt='hks', hks_time=0.1, hop=2, ricci_curv=None, mode='PI', num_models=5, max_loop_len=10,
                               cycle_the=2):
-    """Reference signature (:95).  filt='ricci', 'degree', 'centrality' or 'clustering' (the last two are what the shipped
+    """Reference signature (:95).  filt='hks' (the default), 'ricci', 'degree', 'centrality' or 'clustering' (the last two are what the shipped
     train_Teacher_Model.py:158-159 trains on); mode 'filtration' -> (filtration_val list, edge_index LongTensor[2,m]) or
     (None, None) for a ball without an edge (:103-104); mode 'PI' -> the reference's 9-tuple (:183; times are 0)."""
     from .data_utils_LP import STRUCTURAL_FILTS
     if filt != 'ricci' and filt not in STRUCTURAL_FILTS:
-        raise NotImplementedError("data_utils_NC (HIP): filt='ricci', 'degree', 'centrality', 'clustering' are implemented ('hks' needs a "
-                                  "dense eigh of every vicinity: a host-side input)")
-    b = _vicinities(g, ricci_curv).batch([u], hop, filt=filt)
+        print("Error: 'filt' should be 'hks', 'clustering',' centrality', 'degree' or 'ricci'! ")      # :154-155
+        sys.exit()
+    b = _vicinities(g, ricci_curv).batch([u], hop, filt=filt, hks_time=hks_time)
     if int(b["edge_ptr"][-1]) == 0:
         return None, None
     fv = b["f"].cpu().numpy()
