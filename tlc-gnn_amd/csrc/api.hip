@@ -568,7 +568,9 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     // (MEDWIDE, pipelined chunks only: on MEDIUM's stream the few hundred largest MEDIUM-sized vicinities of a batch, 0.38 ms of
     // tier + swap kernel, ran in front of the MEDIUM chain instead of beside it.  A fifth stream of normal priority shares a
     // queue with another one; in-process A/B, tools/gpu_env_ab3.sh TLC_MEDWIDE_PRIO=0|1|2: 0.683 / 0.651 / 0.703 ms per pipelined
-    // batch -- as the fourth stream of the low pool it starts too late, in the high pool it delays the early chains.)
+    // batch -- as the fourth stream of the low pool it starts too late, in the high pool it delays the early chains.
+    // TINY or SMALL in the normal pool (TLC_TINY_PRIO / TLC_SMALL_PRIO = 1): 0.81 / 0.75 ms.  More hardware queues for the runtime
+    // (GPU_MAX_HW_QUEUES=6 / 8, its environment variable; 4 is the default this layout was tuned for): 0.69 ms; 2: 0.95 ms.)
     // Normal priority then holds the caller's stream, the two main streams and MEDIUM: four.  With MID there as well (round 2)
     // the second workspace's main stream shared a hardware queue with the MID chain, and the lead-in of every other pipelined
     // batch sat behind ~0.3 ms of tier + swap kernel: 45.8 -> 48.4 M images/s pipelined, 0.833 -> 0.840 ms for one batch alone
@@ -609,7 +611,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
             else {
                 int pr = k == 1 ? prio_hi : ((k == 6 || k == 7) ? prio_mid : prio_lo);
                 // (development A/B, tools/gpu_prio_ab.sh: 0 low, 1 normal, 2 high)
-                const char* ev = k == 3 ? getenv("TLC_MID_PRIO") : (k == 6 ? getenv("TLC_MEDIUM_PRIO") : (k == 7 ? getenv("TLC_MEDWIDE_PRIO") : nullptr));
+                const char* ev = k == 3 ? getenv("TLC_MID_PRIO") : (k == 6 ? getenv("TLC_MEDIUM_PRIO") : (k == 7 ? getenv("TLC_MEDWIDE_PRIO") : (k == 5 ? getenv("TLC_TINY_PRIO") : (k == 0 ? getenv("TLC_SMALL_PRIO") : nullptr))));
                 if (ev) pr = atoi(ev) == 0 ? prio_lo : (atoi(ev) == 1 ? prio_mid : prio_hi);
                 CK(hipStreamCreateWithPriority(&ws->side[k], hipStreamNonBlocking, pr));
             }
