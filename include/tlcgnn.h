@@ -391,6 +391,12 @@ int tlc_near_pairs(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_co
  * d_status_hist uint64[8] (may be NULL; the caller zeroes it once per store).  *d_count (uint64, device; the caller zeroes it
  * per call) is advanced by the number of kept rows even beyond `cap` (rows past the capacity are not written: re-run the block
  * with a larger store, and a fresh histogram).  Append order is not fixed. */
+/* |S| and the number of induced edges of every pair's vicinity, nothing else (the extraction of tlc_vicinity_filtration without the
+ * filtration): d_n / d_m int32[n_pairs], n = 0 for a pair without a vicinity; same hop / flags as the tlc_vicinity_filtration call
+ * that follows.  With tlc_pack_offsets a caller gets exact offsets from them: no per-pair capacity to guess (replaces the sizing
+ * the reference does implicitly by building Python lists, data_utils_LP.py:107-125). */
+int tlc_vicinity_sizes(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags, int32_t* d_n, int32_t* d_m,
+                       void* stream);
 /* The offsets of that packed batch from the per-pair counts of tlc_vicinity_filtration, one launch: d_node_ptr / d_edge_ptr int64[n_pairs+1]
  * = exclusive prefix sums of (m > 0 ? n : 0) and max(m, 0) -- a vicinity without an edge is left out, the reference returns (None, None)
  * for it (data_utils_LP.py:117-118) -- and d_totals int64[4] = {min n, min m, sum n, sum m} (a negative minimum: some vicinity did not

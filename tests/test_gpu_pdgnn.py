@@ -403,3 +403,33 @@ def test_empty_inputs_of_the_packed_vicinity_path():
     assert img.shape == (1, 25) and bool((img == 0).all())
     img.sum().backward()
     assert x.grad.shape == (0, 2)
+
+
+def test_vicinity_batch_exact_offsets_equal_the_capacity_layout():
+    """Vicinities.batch without capacities (tlc_vicinity_sizes -> tlc_pack_offsets -> tlc_vicinity_filtration into exact offsets)
+    == with per-pair capacities (one extraction + tlc_pack_vicinities): every array; and the sizes against the oracle."""
+    import torch
+    from oracle import oracle
+    from tlc_gnn_amd import synth
+    from tlc_gnn_amd.Knowledge_Distillation import data_utils_LP as kd
+    n, edges, kappa, _, _ = synth.shaped_graph("Photo", scale=0.3)
+    ricci = np.concatenate([np.concatenate([edges, kappa[:, None]], 1), np.concatenate([edges[:, ::-1], kappa[:, None]], 1)]).tolist()
+    vic = kd.Vicinities(edges, ricci)
+    rs = np.random.RandomState(8)
+    pairs = np.concatenate([edges[rs.permutation(len(edges))[:1500]], rs.randint(0, n, size=(500, 2))])
+    for hop in (1, 2):
+        a = vic.batch(pairs, hop)
+        b = vic.batch(pairs, hop, node_cap=n, edge_cap=len(edges))
+        for k in ("node_ptr", "edge_ptr", "ids", "f", "status", "pair_of_node", "pair_of_edge"):
+            assert torch.equal(a[k], b[k]), (hop, k)
+        ea, eb = a["edges"].cpu().numpy(), b["edges"].cpu().numpy()
+        ep = a["edge_ptr"].cpu().numpy()
+        for i in range(0, len(pairs), 7):                                 # (edge order inside a vicinity: as sets)
+            x, y = ea[ep[i]:ep[i + 1]], eb[ep[i]:ep[i + 1]]
+            assert np.array_equal(x[np.lexsort((x[:, 1], x[:, 0]))], y[np.lexsort((y[:, 1], y[:, 0]))]), (hop, i)
+        n_dev, m_dev = vic._g2p._device_graph().vicinity_sizes(torch.from_numpy(vic._g2p._map_pairs(pairs)).cuda(), hop, flags=kd.KD_LP_FLAGS)
+        rowptr, col, w = vic._g2p._csr
+        _, _, _, o_n, o_m, o_st = oracle.vicinity_filtration(rowptr, col, w, vic._g2p._map_pairs(pairs), hop,
+                                                            oracle.INCLUDE_ROOTS | oracle.NORM_EPS | oracle.UNREACHABLE_100, cap=n)
+        ok = o_st == 0
+        assert np.array_equal(n_dev.cpu().numpy()[ok], o_n[ok]) and np.array_equal(m_dev.cpu().numpy()[ok], o_m[ok]) and ok.sum() > 1500

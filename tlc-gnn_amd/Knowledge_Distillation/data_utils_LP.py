@@ -104,14 +104,37 @@ class Vicinities:
         labels, ascending inside a vicinity), f float64, edges int32 [sum m, 2] (local ids, lower first), status uint8[E].
         Vicinities without an edge have empty slices (the reference returns (None, None) for them, :117-118).
         filt: 'ricci' (the weighted-distance filtration of the device kernels) or one of STRUCTURAL_FILTS (f replaced by
-        `structural_filtration` of the extracted vicinities)."""
+        `structural_filtration` of the extracted vicinities).
+        node_cap / edge_cap: per-pair capacities of an intermediate layout (one extraction; raises if a vicinity is larger); neither
+        given: sizes first, exact offsets, two extractions (`tlc_vicinity_sizes` + `tlc_pack_offsets`)."""
         import torch
         dev_graph = self._g2p._device_graph()
         mapped = torch.from_numpy(self._g2p._map_pairs(pairs)).cuda()
+        fl = KD_LP_FLAGS if flags is None else flags
+        if getattr(self, "_inv_dev", None) is None or self._inv_dev.device != mapped.device:
+            self._inv_dev = torch.from_numpy(self.inv).to(mapped.device)
+        if node_cap is None and edge_cap is None:
+            # no capacities given: sizes first (the extraction alone), exact offsets from them, then the filtration writes the packed
+            # batch directly -- nothing to guess, nothing to overflow (a capacity of "whole graph" per pair would be 60 GB for 100 000
+            # PubMed pairs), at the price of extracting twice
+            n0, m0 = dev_graph.vicinity_sizes(mapped, hop, flags=fl)
+            node_ptr, edge_ptr, totals = engine.pack_offsets(n0, m0)
+            E = len(n0)
+            _, _, tot_n, tot_m = totals.tolist() if E else (0, 0, 0, 0)
+            _, ids, f, n, st, _, edges, m = dev_graph.vicinity_filtration(mapped, hop, flags=fl, zero=False,
+                                                                         offsets=(node_ptr, edge_ptr, tot_n, tot_m))
+            counts_n, counts_m = node_ptr[1:] - node_ptr[:-1], edge_ptr[1:] - edge_ptr[:-1]
+            owner = torch.arange(E, device=mapped.device)
+            pn = torch.repeat_interleave(owner, counts_n, output_size=int(tot_n))
+            pe = torch.repeat_interleave(owner, counts_m, output_size=int(tot_m))
+            out_ids, out_f, out_e = self._inv_dev[ids[:int(tot_n)].long()], f[:int(tot_n)], edges[:int(tot_m)]
+            if filt != 'ricci':
+                out_f = torch.from_numpy(structural_filtration(filt, node_ptr.cpu().numpy(), edge_ptr.cpu().numpy(), out_e.cpu().numpy(),
+                                                               hks_time=hks_time)).to(out_f.device)
+            return dict(node_ptr=node_ptr, edge_ptr=edge_ptr, ids=out_ids, f=out_f, edges=out_e, status=st, pair_of_node=pn, pair_of_edge=pe)
         n_cap = dev_graph.n_nodes if node_cap is None else int(node_cap)
         e_cap = max(dev_graph.nnz // 2, 1) if edge_cap is None else int(edge_cap)
-        offs, ids, f, n, st, eoffs, edges, m = dev_graph.vicinity_filtration(mapped, hop, flags=KD_LP_FLAGS if flags is None else flags,
-                                                                             cap=n_cap, edge_cap=e_cap, zero=False)
+        offs, ids, f, n, st, eoffs, edges, m = dev_graph.vicinity_filtration(mapped, hop, flags=fl, cap=n_cap, edge_cap=e_cap, zero=False)
         # packed offsets on the device (one kernel; no edge -> (None, None): an empty slice); ONE host read: the two totals (to size
         # the packed arrays) and the two capacity checks
         E = len(n)
@@ -119,8 +142,6 @@ class Vicinities:
         lo_n, lo_m, tot_n, tot_m = totals.tolist() if E else (0, 0, 0, 0)
         if lo_n < 0 or lo_m < 0:
             raise RuntimeError("vicinity larger than the requested node_cap / edge_cap")
-        if getattr(self, "_inv_dev", None) is None or self._inv_dev.device != n.device:
-            self._inv_dev = torch.from_numpy(self.inv).to(n.device)
         out_ids, out_f, out_e, pn, pe = engine.pack_vicinities(offs, ids, f, eoffs, edges, node_ptr, edge_ptr, int(tot_n), int(tot_m),
                                                                label=self._inv_dev)
         if filt != 'ricci':

@@ -73,7 +73,7 @@ struct ChunkCtx {
     TlcPdParams pp;
     hipStream_t s;
     int n_pairs, hop, pi_enabled;
-    bool bump, use_x, early, spec, xlane;
+    bool bump, use_x, early, spec, xlane, count_only;
     long long bump_base;
     int xgrid, vgrid, tmask;
     unsigned seq;
@@ -202,6 +202,7 @@ struct tlc_graph {
     int opt_chunk_pairs;                // development: pairs per chunk (0: TLC_CHUNK_PAIRS)
     int opt_medium_first;               // development: submit the MEDIUM / MID tiers ahead of TINY / SMALL
     int opt_early_wait;                 // development: 0 = the main COUNT of a pipelined chunk does not wait for the early pass (default 1)
+    int count_only;                     // set by tlc_vicinity_sizes around its run_batch: chunks stop after the scan, their sizes are copied out
     // LARGE tier as two launches over one list (compact kernels, 72 / 54 KB of LDS, for the vicinities of <= 1 024 nodes / 2 048 edges): 0 never
     // (default), 1 pipelined chunks, 2 always.  Measured, tools/ab_option.py large_split 0 1: 0.652 -> 0.677 ms per pipelined batch -- the
     // LDS capacity x time it saves does not pay for a LARGE chain that is two kernels longer and whose workgroups share their CU: the
@@ -1065,6 +1066,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         pp.grid = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr; pp.handoff = nullptr; pp.handoff_cap = 0;
     }
     c.bump = bump; c.use_x = use_x; c.early = early; c.spec = spec; c.xlane = xlane; c.bump_base = bump_base; c.xgrid = xgrid; c.seq = seq;
+    c.count_only = g->count_only != 0;
     c.ht_front = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c.ht0).count() * 1e-3;
     ws->back_pending = 1;
     return TLC_OK;
@@ -1130,7 +1132,12 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
 
     const int n_early = early ? ws->h_sync->pub_early : 0;
     const int n_xl_cand = c.xlane ? ws->h_sync->pub_xl[0] : 0, n_xl_done = c.xlane ? ws->h_sync->pub_xl[1] : 0;
-    const int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4] + tc[5] + tc[6] + tc[7];
+    int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4] + tc[5] + tc[6] + tc[7];
+    if (c.count_only) {
+        // tlc_vicinity_sizes: the headers are all it asks for (pp.out_n / out_m: the caller's arrays at this chunk's offset)
+        if ((rc = tlc_launch_copy_sizes(n_pairs, ws->hdr_n, ws->hdr_m2, pp.out_n, pp.out_m, s)) != TLC_OK) return rc;
+        todo = 0;
+    }
     if (c.xlane) ws->prev_xl_cand = n_xl_cand;
     const bool spec_done = spec && bumped;          // the MID / MEDIUM tiers are already running
     ws->prev_tc[TLC_TIER_MID] = tc[TLC_TIER_MID]; ws->prev_tc[TLC_TIER_MEDIUM] = tc[TLC_TIER_MEDIUM]; ws->prev_tc[TLC_TIER_MEDHI] = tc[TLC_TIER_MEDHI];
@@ -1581,6 +1588,20 @@ extern "C" int tlc_pi_raster(int32_t n_dgms, const int64_t* d_offs, const double
     if (n_dgms == 0) return TLC_OK;
     TLC_REQUIRE(d_offs && d_out, "null pointer");
     return tlc_launch_pi_raster(n_dgms, (const long long*)d_offs, d_pts, res, d_out, stream);
+}
+
+// |S| and the induced edge count of every pair's vicinity, nothing else: the extraction and the scan of tlc_vicinity_filtration without
+// its tier kernels.  A caller sizes exact offsets from them (tlc_pack_offsets) and calls tlc_vicinity_filtration with those -- no
+// per-pair capacity to guess.  d_n / d_m int32[n_pairs] (n = 0 for a pair without a vicinity; same flags as the call that follows).
+extern "C" int tlc_vicinity_sizes(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags, int32_t* d_n, int32_t* d_m,
+                                  void* stream) {
+    TLC_REQUIRE(g != nullptr, "graph handle is null");
+    TLC_REQUIRE(n_pairs == 0 || (d_n && d_m), "null output");
+    g->count_only = 1;
+    const int rc = run_batch(g, d_pairs, n_pairs, hop, flags, 5, nullptr, nullptr, nullptr, nullptr, nullptr, d_n, nullptr, nullptr, d_m,
+                             0, stream, true);
+    g->count_only = 0;
+    return rc;
 }
 
 // gradient of tlc_pi_raster's images with respect to the points, as the reference's differentiable imager defines it (through the

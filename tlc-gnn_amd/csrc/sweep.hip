@@ -333,6 +333,23 @@ __global__ __launch_bounds__(256) void pack_vicinities_kernel(long long n_pairs,
 }
 }  // namespace
 
+// ---- the per-pair sizes of a chunk from its headers (tlc_vicinity_sizes): n as counted, m = directed entries / 2 -------------------
+namespace {
+__global__ void copy_sizes_kernel(int n_pairs, const int* __restrict__ hdr_n, const int* __restrict__ hdr_m2, int* __restrict__ out_n,
+                                  int* __restrict__ out_m) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    if (out_n) out_n[i] = hdr_n[i];
+    if (out_m) out_m[i] = hdr_n[i] > 0 ? (hdr_m2[i] >> 1) : 0;
+}
+}  // namespace
+int tlc_launch_copy_sizes(int n_pairs, const int* hdr_n, const int* hdr_m2, int* out_n, int* out_m, void* stream) {
+    if (n_pairs <= 0) return TLC_OK;
+    hipLaunchKernelGGL(copy_sizes_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_pairs, hdr_n, hdr_m2, out_n, out_m);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
 // ---- tlc_pack_offsets: the packed batch's offsets from the per-pair counts of tlc_vicinity_filtration, ONE launch ----------------
 // node_ptr / edge_ptr = exclusive prefix sums of (m > 0 ? n : 0) and max(m, 0) -- a vicinity without an edge is left out of the packed
 // batch, the reference returns (None, None) for it (data_utils_LP.py:117-118) -- and totals = {min n, min m, sum n, sum m}: a negative

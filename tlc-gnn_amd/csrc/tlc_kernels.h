@@ -365,6 +365,7 @@ int tlc_launch_select_heavy(int n_pairs, const int* pairs, int n_nodes, const in
                             int* list, void* stream);
 size_t tlc_huge_slot_bytes(int nmax, int mmax);
 size_t tlc_handoff_slot_bytes(int tier);   // 0: the tier has no hand-off (its kernel runs the cycle swap itself)
+int tlc_launch_copy_sizes(int n_pairs, const int* hdr_n, const int* hdr_m2, int* out_n, int* out_m, void* stream);
 int tlc_launch_pi_raster_wgrad(int n_dgms, long long n_pts, const long long* offs, const double* pts, int res, const double* grad_img,
                                double* grad_pts, void* stream);
 int tlc_launch_pi_raster(int n_dgms, const long long* offs, const double* pts, int res, double* out, void* stream);

@@ -151,18 +151,46 @@ class DeviceGraph:
             t = cache[key] = torch.arange(E + 1, dtype=torch.int64, device=dev) * cap
         return t
 
-    def vicinity_filtration(self, pairs, hop, flags=0, cap=None, edge_cap=None, zero=True):
-        """-> (node_offs int64[E+1], ids int32[E*cap], f float64[E*cap], n int32[E], status uint8[E])
-        with edge_cap: additionally (edge_offs int64[E+1], edges int32[E*edge_cap,2] local ids, m int32[E]).
-        zero=False: the capacity buffers are not zero-filled (what lies beyond a pair's n / m entries is never read by a caller
-        that slices by n / m: 290 MB of fill per 4 096 pairs at node_cap 512 / edge_cap 8 192)."""
+    def vicinity_sizes(self, pairs, hop, flags=0):
+        """-> (n int32[E], m int32[E]) CUDA tensors: |S| and the induced edge count of every pair's vicinity (tlc_vicinity_sizes)."""
         import torch
         assert pairs.device.index == self.device, "pairs live on cuda:%s, the graph on cuda:%d" % (pairs.device.index, self.device)
         pairs = pairs.contiguous()
         E = pairs.shape[0]
-        cap = self.n_nodes if cap is None else int(cap)
+        n = torch.zeros(max(E, 1), dtype=torch.int32, device=pairs.device)
+        m = torch.zeros(max(E, 1), dtype=torch.int32, device=pairs.device)
+        rc = _lib.lib().tlc_vicinity_sizes(self._h, _lib.ptr(pairs), C.c_int64(E), C.c_int(hop), C.c_uint32(flags), _lib.ptr(n), _lib.ptr(m),
+                                           _lib.stream_ptr(self.device))
+        _lib.check(rc, "tlc_vicinity_sizes")
+        return n[:E], m[:E]
+
+    def vicinity_filtration(self, pairs, hop, flags=0, cap=None, edge_cap=None, zero=True, offsets=None):
+        """-> (node_offs int64[E+1], ids int32[E*cap], f float64[E*cap], n int32[E], status uint8[E])
+        with edge_cap: additionally (edge_offs int64[E+1], edges int32[E*edge_cap,2] local ids, m int32[E]).
+        zero=False: the capacity buffers are not zero-filled (what lies beyond a pair's n / m entries is never read by a caller
+        that slices by n / m: 290 MB of fill per 4 096 pairs at node_cap 512 / edge_cap 8 192).
+        offsets=(node_offs, edge_offs, total_nodes, total_edges): the caller's own offsets (e.g. exact ones from vicinity_sizes +
+        pack_offsets) instead of a capacity per pair; the outputs then have total_nodes / total_edges rows."""
+        import torch
+        assert pairs.device.index == self.device, "pairs live on cuda:%s, the graph on cuda:%d" % (pairs.device.index, self.device)
+        pairs = pairs.contiguous()
+        E = pairs.shape[0]
         dev = pairs.device
         mk = torch.zeros if zero else torch.empty
+        if offsets is not None:
+            offs, eoffs_x, tot_n, tot_m = offsets
+            ids = mk(max(int(tot_n), 1), dtype=torch.int32, device=dev)
+            f = mk(max(int(tot_n), 1), dtype=torch.float64, device=dev)
+            n = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
+            st = torch.zeros(max(E, 1), dtype=torch.uint8, device=dev)
+            edges = mk((max(int(tot_m), 1), 2), dtype=torch.int32, device=dev)
+            m = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
+            rc = _lib.lib().tlc_vicinity_filtration(self._h, _lib.ptr(pairs), C.c_int64(E), C.c_int(hop), C.c_uint32(flags),
+                                                    _lib.ptr(offs), _lib.ptr(ids), _lib.ptr(f), _lib.ptr(n), _lib.ptr(st),
+                                                    _lib.ptr(eoffs_x), _lib.ptr(edges), _lib.ptr(m), _lib.stream_ptr(self.device))
+            _lib.check(rc, "tlc_vicinity_filtration")
+            return offs, ids, f, n[:E], st[:E], eoffs_x, edges, m[:E]
+        cap = self.n_nodes if cap is None else int(cap)
         offs = self._capacity_offsets(E, cap, dev)
         ids = mk(max(E * cap, 1), dtype=torch.int32, device=dev)
         f = mk(max(E * cap, 1), dtype=torch.float64, device=dev)
