@@ -189,11 +189,23 @@ __device__ __forceinline__ void tiny_slot(const TlcPdParams p, unsigned char* ld
         const double* rw_ = (const double*)(rec + TLC_XL_REC_W_OFF) + lane;
         for (int e = 0; e < m; ++e) { eab[e] = (unsigned short)re_[e * 64]; ew[e] = rw_[e * 64]; }
     } else {
-        // undirected edge list: the directed entries with src < dst, in CSR order
-        for (int j = 0; j < m2; ++j) {
-            const unsigned e = adir[j];
-            const unsigned a = e >> 16, b = e & 0xffffu;
-            if (a < b && m < TM) { eab[m] = (unsigned short)((a << 8) | b); ew[m] = alw[j]; ++m; }
+        // undirected edge list: the directed entries with src < dst, in CSR order.  Eight entries (and their weights, wanted or not)
+        // are requested before the first is looked at: every lane reads its own subgraph, so a load is 64 scattered lines, and one
+        // entry per round trip made this loop 22 % of the kernel (tools/tiny_profile.py: 105 k of 479 k cycles per wavefront)
+        for (int j0 = 0; j0 < m2; j0 += 8) {
+            unsigned ee[8];
+            double wq[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool in = j0 + q < m2;
+                ee[q] = in ? adir[j0 + q] : 0u;
+                wq[q] = in ? alw[j0 + q] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned a = ee[q] >> 16, b = ee[q] & 0xffffu;
+                if (j0 + q < m2 && a < b && m < TM) { eab[m] = (unsigned short)((a << 8) | b); ew[m] = wq[q]; ++m; }
+            }
         }
     }
     TINY_STAMP(0);
