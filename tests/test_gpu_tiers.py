@@ -201,6 +201,35 @@ def test_large_tier_split_into_compact_and_wide_kernels(n, m, n_pairs):
     g.close()
 
 
+def test_tier_lists_sorted_by_size_give_the_same_rows():
+    """The TINY list goes to the lane-per-subgraph kernel by descending size (a wavefront waits for its slowest lane; option
+    tiny_sort, default on), the other lists can (option tier_sort, development): every pair's row is its own -- bit-equal rows
+    whatever the order, stream-ordered and pipelined."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    n, edges, kappa, hop, _ = synth.shaped_graph("PubMed", scale=0.3)
+    rowptr, col, w = synth.edges_to_csr(n, edges, kappa)
+    rs = np.random.RandomState(12)
+    pairs = torch.as_tensor(edges[rs.permutation(len(edges))[:9000]].astype(np.int32)).cuda()
+    g = engine.DeviceGraph(rowptr, col, w)
+    g.set_option("tiny_sort", 0)
+    ref, rst = g.pd_pi_batch(pairs, hop)
+    assert g.stats()["tier_tiny"] > 3000
+    for ts, tt in ((1, 0), (1, 19), (0, 19)):
+        g.set_option("tiny_sort", ts); g.set_option("tier_sort", tt)
+        out, st = g.pd_pi_batch(pairs, hop)
+        assert torch.equal(out, ref) and torch.equal(st, rst), (ts, tt)
+        outs = [torch.empty_like(ref) for _ in range(3)]
+        sts = [torch.empty_like(rst) for _ in range(3)]
+        for k in range(3):
+            g.pd_pi_batch(pairs, hop, out=outs[k], status=sts[k], async_=True)
+        g.join()
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert torch.equal(outs[k], ref) and torch.equal(sts[k], rst), (ts, tt, k)
+    g.close()
+
+
 def test_speculative_launches_beyond_their_reserved_slots():
     """The MEDIUM-many-Pos tier kernel is submitted before the tier sizes are known, one workgroup per slot reserved from the
     previous chunk's count; list positions beyond the slots are completed by a second launch, and MEDIUM / MID vicinities beyond

@@ -202,6 +202,8 @@ struct tlc_graph {
     int opt_chunk_pairs;                // development: pairs per chunk (0: TLC_CHUNK_PAIRS)
     int opt_medium_first;               // development: submit the MEDIUM / MID tiers ahead of TINY / SMALL
     int opt_early_wait;                 // development: 0 = the main COUNT of a pipelined chunk does not wait for the early pass (default 1)
+    int opt_tiny_sort;                  // the TINY list by descending size before the lane-per-subgraph kernel (default 1; 0: list order, A/B)
+    int opt_tier_sort;                  // development: bit t = the list of tier t (SMALL / MID / MEDIUM) by descending size as well
     int count_only;                     // set by tlc_vicinity_sizes around its run_batch: chunks stop after the scan, their sizes are copied out
     // LARGE tier as two launches over one list (compact kernels, 72 / 54 KB of LDS, for the vicinities of <= 1 024 nodes / 2 048 edges): 0 never
     // (default), 1 pipelined chunks, 2 always.  Measured, tools/ab_option.py large_split 0 1: 0.652 -> 0.677 ms per pipelined batch -- the
@@ -545,7 +547,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     // one batch alone and a loss for pipelined batches -- see the note at `xlane` in run_chunk_front and DESIGN.md)
     { const char* v = getenv("TLC_XL_CUT"); g->opt_xl_cut = v ? std::min(std::max(atoi(v), 0), TLC_XL_MAXCUT) : 0; }
     g->opt_xl_ncut = TLC_T_NCUT; g->opt_xl_mcut = TLC_T_MCUT;
-    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_large_split = 0; g->opt_early_wait = 1; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
+    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_large_split = 0; g->opt_early_wait = 1; g->opt_tiny_sort = 1; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
@@ -1196,6 +1198,14 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
                 TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[k], ws->ev_fork, 0));
             }
             pp.tier_list = ws->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
+            // (opt_tier_sort, development A/B: this tier's list by descending size too -- largest workgroups first)
+            if (((g->opt_tier_sort >> t) & 1) && tc[t] > 64 && (t == TLC_TIER_SMALL || t == TLC_TIER_MID || t == TLC_TIER_MEDIUM)) {
+                const int bin = t == TLC_TIER_SMALL ? 1 : (t == TLC_TIER_MID ? 2 : 3), shift = t == TLC_TIER_SMALL ? 2 : (t == TLC_TIER_MID ? 3 : 4);
+                int* dst = ws->big_lists + (size_t)bin * n_pairs;
+                int r2 = tlc_launch_tiny_sort(tc[t], pp.tier_list, ws->hdr_n, ws->hdr_m2, dst, ws->side[k], shift);
+                if (r2 != TLC_OK) return r2;
+                pp.tier_list = dst;
+            }
             const size_t hs = pi_enabled ? tlc_handoff_slot_bytes(t) : 0;
             pp.handoff = hs ? ws->handoff + hand_base[t] : nullptr;
             pp.handoff_stride = (long long)hs;
@@ -1260,6 +1270,13 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
                 if (bumped) { TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_scan, 0)); }
                 else { TLC_HIP_CHECK(hipEventRecord(ws->ev_fork, s)); TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_fork, 0)); }
                 pp.tier_list = ws->tier_list + (size_t)TLC_TIER_TINY * n_pairs; pp.tier_count = tc[TLC_TIER_TINY];
+                // (by descending size first, into the first of the classification's lists -- the extraction that read them is done:
+                // a wavefront of that kernel waits for its slowest lane)
+                if (g->opt_tiny_sort && tc[TLC_TIER_TINY] > 64) {
+                    int r2 = tlc_launch_tiny_sort(tc[TLC_TIER_TINY], pp.tier_list, ws->hdr_n, ws->hdr_m2, ws->big_lists, ws->side[5]);
+                    if (r2 != TLC_OK) return r2;
+                    pp.tier_list = ws->big_lists;
+                }
                 pp.handoff = nullptr; pp.handoff_stride = 0; pp.handoff_cap = 0; pp.grid = 0; pp.phase = 0;
                 pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
                 pp.dc_count = nullptr; pp.dc_list = nullptr;
@@ -1665,6 +1682,8 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "medium_first")) g->opt_medium_first = value != 0;
     else if (!strcmp(name, "large_split")) g->opt_large_split = value;
     else if (!strcmp(name, "early_wait")) g->opt_early_wait = value != 0;
+    else if (!strcmp(name, "tiny_sort")) g->opt_tiny_sort = value != 0;
+    else if (!strcmp(name, "tier_sort")) g->opt_tier_sort = value;
     else if (!strcmp(name, "n_ws")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_n_ws = std::min(std::max(value, 2), TLC_N_WS); }
     else if (!strcmp(name, "defer")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_defer = value != 0; }
     else if (!strcmp(name, "chunk_pairs")) g->opt_chunk_pairs = std::max(value, 0);

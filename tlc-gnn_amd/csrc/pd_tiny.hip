@@ -463,6 +463,41 @@ int tlc_launch_pd_tiny(const TlcPdParams& p, void* stream) {
     return TLC_OK;
 }
 
+// The TINY list by descending size.  A wavefront of the lane-per-subgraph kernel takes as long as its slowest lane, and in list
+// (= pair) order a 16-node vicinity sits in nearly every wavefront: summed over the wavefronts, the maxima of n + m are 1.85 times,
+// of (n + m)^2 3 times what they are with equals side by side (tools/tiny_binning_model.py on the PubMed-shaped batch).  Counting sort
+// by n + m (<= 40) in one workgroup: histogram, prefix, scatter; which of two equal-sized vicinities comes first is left to the
+// atomics -- every vicinity's row is its own.
+__global__ __launch_bounds__(1024) void tlc_tiny_sort_kernel(int count, const int* __restrict__ list, const int* __restrict__ hdr_n,
+                                                            const int* __restrict__ hdr_m2, int* __restrict__ out, int shift) {
+    __shared__ int hist[64], base[64];
+    const int tid = (int)threadIdx.x;
+    if (tid < 64) hist[tid] = 0;
+    __syncthreads();
+    for (int k = tid; k < count; k += 1024) {
+        const int i = list[k];
+        int key = (hdr_n[i] + (hdr_m2[i] >> 1)) >> shift;
+        key = key < 0 ? 0 : (key > 63 ? 63 : key);
+        atomicAdd(&hist[63 - key], 1);                         // (largest first)
+    }
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int b = 0; b < 64; ++b) { base[b] = run; run += hist[b]; } }
+    __syncthreads();
+    for (int k = tid; k < count; k += 1024) {
+        const int i = list[k];
+        int key = (hdr_n[i] + (hdr_m2[i] >> 1)) >> shift;
+        key = key < 0 ? 0 : (key > 63 ? 63 : key);
+        out[atomicAdd(&base[63 - key], 1)] = i;
+    }
+}
+
+int tlc_launch_tiny_sort(int count, const int* list, const int* hdr_n, const int* hdr_m2, int* out, void* stream, int shift) {
+    if (count <= 0) return TLC_OK;
+    hipLaunchKernelGGL(tlc_tiny_sort_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, count, list, hdr_n, hdr_m2, out, shift);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
 // the records of the lane-per-pair extraction: wavefronts for p.xl_slots slots stride over the slots there turn out to be
 // (candidates in *p.tier_count_dev, at most p.tier_count)
 int tlc_launch_pd_tiny_rec(const TlcPdParams& p, void* stream) {

@@ -358,6 +358,7 @@ int tlc_launch_classify(int n_pairs, const int* pairs, int n_nodes, const int* b
 int tlc_launch_xlane(const TlcXlParams& p, int grid, void* stream);
 int tlc_launch_ball_hash(int n_nodes, const int* bptr, const int* bcol, const long long* hptr, int* htab, int* fail, void* stream);
 int tlc_launch_pd_tiny_rec(const TlcPdParams& p, void* stream);
+int tlc_launch_tiny_sort(int count, const int* list, const int* hdr_n, const int* hdr_m2, int* out, void* stream, int shift = 0);
 int tlc_launch_ball_list(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, int hop, int* bsize, const int* bptr,
                          int* bcol, int grid, void* stream);
 int tlc_launch_ball_bound(int n_nodes, const int* rowptr, const int* col, const int* prev, int* out, void* stream);
