@@ -202,9 +202,9 @@ def test_large_tier_split_into_compact_and_wide_kernels(n, m, n_pairs):
 
 
 def test_tier_lists_sorted_by_size_give_the_same_rows():
-    """The TINY list goes to the lane-per-subgraph kernel by descending size (a wavefront waits for its slowest lane; option
-    tiny_sort, default on), the other lists can (option tier_sort, development): every pair's row is its own -- bit-equal rows
-    whatever the order, stream-ordered and pipelined."""
+    """The TINY list goes to the lane-per-subgraph kernel in size classes, largest first (tlc_scan_bin's bins: a wavefront waits for
+    its slowest lane; option tiny_sort, default on), the other lists can be sorted (option tier_sort, development): every pair's
+    row is its own -- bit-equal rows whatever the order, stream-ordered and pipelined."""
     import torch
     from tlc_gnn_amd import engine, synth
     n, edges, kappa, hop, _ = synth.shaped_graph("PubMed", scale=0.3)

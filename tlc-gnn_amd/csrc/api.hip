@@ -55,6 +55,7 @@ struct HostSync {
     // written by tlc_scan_bin straight into this (pinned, device-mapped) block; seq last, after a system-scope fence
     volatile long long pub_total;
     volatile int pub_tier[TLC_N_TIERS];
+    volatile int pub_tiny[TLC_TINY_BINS];     // the TINY list's size classes
     volatile int pub_early;
     volatile int pub_xl[2];        // lane-per-pair extraction: candidates listed, pairs finished as records
     volatile int pub_overflow;
@@ -73,7 +74,7 @@ struct ChunkCtx {
     TlcPdParams pp;
     hipStream_t s;
     int n_pairs, hop, pi_enabled;
-    bool bump, use_x, early, spec, xlane, count_only;
+    bool bump, use_x, early, spec, xlane, count_only, tiny_bins, pipelined;
     long long bump_base;
     int xgrid, vgrid, tmask;
     unsigned seq;
@@ -91,6 +92,7 @@ struct Workspace {
     size_t cap_pairs;
     int *hdr_n, *hdr_m2, *hdr_lu, *hdr_lv, *tier_list;
     int* dc_lists;             // [3][cap_pairs + TLC_EARLY_SLOTS]: list positions a tier kernel hands to tlc_pd_dc_kernel (MEDIUM / LARGE / early LARGE)
+    int* tiny_bins;            // [TLC_TINY_BINS][cap_pairs]: the TINY list by size class (tlc_scan_bin)
     int* big_lists;            // [4][cap_pairs]: the bins of tlc_classify_kernel (extract.hip); [3]: pairs the lane-per-pair pass gave back
     int* xl_list;              // [cap_pairs] candidates of the lane-per-pair extraction (extract_lane.hip)
     unsigned char* xl_rec;     // their records, one per slot of 64 candidates
@@ -200,9 +202,9 @@ struct tlc_graph {
     int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
     int opt_x_grid, opt_x_chunk_div;    // development: extraction workgroups / work-queue granularity (0: the defaults)
     int opt_chunk_pairs;                // development: pairs per chunk (0: TLC_CHUNK_PAIRS)
-    int opt_medium_first;               // development: submit the MEDIUM / MID tiers ahead of TINY / SMALL
+    int opt_medium_first;               // submit the MEDIUM / MID tiers ahead of TINY / SMALL: -1 a chunk on its own (default), 0 never, 1 always
     int opt_early_wait;                 // development: 0 = the main COUNT of a pipelined chunk does not wait for the early pass (default 1)
-    int opt_tiny_sort;                  // the TINY list by descending size before the lane-per-subgraph kernel (default 1; 0: list order, A/B)
+    int opt_tiny_sort;                  // the TINY list in size classes, largest first (tlc_scan_bin; default 1; 0: pair order, A/B)
     int opt_tier_sort;                  // development: bit t = the list of tier t (SMALL / MID / MEDIUM) by descending size as well
     int count_only;                     // set by tlc_vicinity_sizes around its run_batch: chunks stop after the scan, their sizes are copied out
     // LARGE tier as two launches over one list (compact kernels, 72 / 54 KB of LDS, for the vicinities of <= 1 024 nodes / 2 048 edges): 0 never
@@ -238,8 +240,8 @@ static int quiesce(tlc_graph* g) {
 static int ensure_pairs(tlc_graph* g, Workspace* ws, size_t n) {
     if (n <= ws->cap_pairs) return TLC_OK;
     hipFree(ws->hdr_n); hipFree(ws->hdr_m2); hipFree(ws->hdr_lu); hipFree(ws->hdr_lv); hipFree(ws->tier_list); hipFree(ws->edge_off);
-    hipFree(ws->dc_lists); hipFree(ws->big_lists); hipFree(ws->xl_list);
-    ws->hdr_n = ws->hdr_m2 = ws->hdr_lu = ws->hdr_lv = ws->tier_list = ws->dc_lists = ws->big_lists = ws->xl_list = nullptr;
+    hipFree(ws->dc_lists); hipFree(ws->big_lists); hipFree(ws->xl_list); hipFree(ws->tiny_bins);
+    ws->hdr_n = ws->hdr_m2 = ws->hdr_lu = ws->hdr_lv = ws->tier_list = ws->dc_lists = ws->big_lists = ws->xl_list = ws->tiny_bins = nullptr;
     ws->edge_off = nullptr;
     ws->cap_pairs = 0;
     TLC_HIP_CHECK(hipMalloc(&ws->hdr_n, n * sizeof(int)));
@@ -250,6 +252,7 @@ static int ensure_pairs(tlc_graph* g, Workspace* ws, size_t n) {
     TLC_HIP_CHECK(hipMalloc(&ws->edge_off, (n + 1) * sizeof(long long)));
     TLC_HIP_CHECK(hipMalloc(&ws->dc_lists, 3 * (n + TLC_EARLY_SLOTS) * sizeof(int)));
     TLC_HIP_CHECK(hipMalloc(&ws->big_lists, 4 * n * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&ws->tiny_bins, (size_t)TLC_TINY_BINS * n * sizeof(int)));
     TLC_HIP_CHECK(hipMalloc(&ws->xl_list, n * sizeof(int)));
     ws->cap_pairs = n;
     return TLC_OK;
@@ -547,7 +550,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     // one batch alone and a loss for pipelined batches -- see the note at `xlane` in run_chunk_front and DESIGN.md)
     { const char* v = getenv("TLC_XL_CUT"); g->opt_xl_cut = v ? std::min(std::max(atoi(v), 0), TLC_XL_MAXCUT) : 0; }
     g->opt_xl_ncut = TLC_T_NCUT; g->opt_xl_mcut = TLC_T_MCUT;
-    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_large_split = 0; g->opt_early_wait = 1; g->opt_tiny_sort = 1; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
+    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_large_split = 0; g->opt_early_wait = 1; g->opt_tiny_sort = 1; g->opt_medium_first = -1; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
@@ -658,7 +661,7 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     for (int i = 0; i < TLC_N_WS; ++i) {
         Workspace* ws = &g->ws[i];
         hipFree(ws->hdr_n); hipFree(ws->hdr_m2); hipFree(ws->hdr_lu); hipFree(ws->hdr_lv); hipFree(ws->tier_list); hipFree(ws->edge_off);
-        hipFree(ws->dc_lists); hipFree(ws->big_lists); hipFree(ws->xl_list); hipFree(ws->xl_rec);
+        hipFree(ws->dc_lists); hipFree(ws->big_lists); hipFree(ws->xl_list); hipFree(ws->xl_rec); hipFree(ws->tiny_bins);
         hipFree(ws->d_ctl); hipFree(ws->d_block_sums); hipFree(ws->d_totals);
         if (ws->h_sync) hipHostFree(ws->h_sync);
         hipFree(ws->A_dir); hipFree(ws->A_lw); hipFree(ws->S_dir); hipFree(ws->S_lw); hipFree(ws->vic_scratch); hipFree(ws->huge_scratch);
@@ -986,6 +989,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     T0(1, s);
     const unsigned seq = ++ws->pub_seq;
     TlcScanParams sp;
+    memset(&sp, 0, sizeof(sp));                              // (every optional pointer null unless set below)
     sp.n_pairs = n_pairs; sp.hdr_n = ws->hdr_n; sp.hdr_m2 = ws->hdr_m2;
     sp.block_agg = ws->d_block_sums; sp.block_flag = ws->d_ctl + 64; sp.sync = ws->d_ctl + 10; sp.totals = ws->d_totals;
     sp.edge_off = ws->edge_off; sp.tier_count = ws->d_ctl; sp.tier_list = ws->tier_list; sp.small_arena = use_x ? 0 : 1;
@@ -998,6 +1002,8 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     const bool mh_split = !pipelined || g->opt_mh_always;
     sp.mh_min_pos = mh_split ? TLC_MH_MIN_POS : 0x7fffffff;
     sp.tiny_ok = (g->opt_tiny && pi_enabled && flags == 0u && res == 5 && !d_out_ids && !d_out_f && !d_out_edges) ? 1 : 0;
+    // (the TINY list by size class as well: d_ctl[48..55] count, zeroed with the control block)
+    if (sp.tiny_ok && g->opt_tiny_sort) { sp.tiny_bin_count = ws->d_ctl + 48; sp.tiny_bin_list = ws->tiny_bins; sp.h_tiny_bins = const_cast<int*>(ws->h_sync_dev->pub_tiny); }
     sp.early_list = early ? ws->d_early_list : nullptr; sp.early_count = d_early_count; sp.early_cap = TLC_EARLY_SLOTS;
     sp.h_early = const_cast<int*>(&ws->h_sync_dev->pub_early);
     sp.xl_counts = xlane ? ws->d_ctl + 40 : nullptr; sp.h_xl = const_cast<int*>(ws->h_sync_dev->pub_xl);
@@ -1069,6 +1075,8 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     }
     c.bump = bump; c.use_x = use_x; c.early = early; c.spec = spec; c.xlane = xlane; c.bump_base = bump_base; c.xgrid = xgrid; c.seq = seq;
     c.count_only = g->count_only != 0;
+    c.tiny_bins = sp.tiny_bin_count != nullptr;
+    c.pipelined = pipelined;
     c.ht_front = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c.ht0).count() * 1e-3;
     ws->back_pending = 1;
     return TLC_OK;
@@ -1270,12 +1278,11 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
                 if (bumped) { TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_scan, 0)); }
                 else { TLC_HIP_CHECK(hipEventRecord(ws->ev_fork, s)); TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[5], ws->ev_fork, 0)); }
                 pp.tier_list = ws->tier_list + (size_t)TLC_TIER_TINY * n_pairs; pp.tier_count = tc[TLC_TIER_TINY];
-                // (by descending size first, into the first of the classification's lists -- the extraction that read them is done:
-                // a wavefront of that kernel waits for its slowest lane)
-                if (g->opt_tiny_sort && tc[TLC_TIER_TINY] > 64) {
-                    int r2 = tlc_launch_tiny_sort(tc[TLC_TIER_TINY], pp.tier_list, ws->hdr_n, ws->hdr_m2, ws->big_lists, ws->side[5]);
-                    if (r2 != TLC_OK) return r2;
-                    pp.tier_list = ws->big_lists;
+                // (by size class, largest first, as the scan binned it: a wavefront of that kernel waits for its slowest lane)
+                pp.tiny_bin_list = nullptr;
+                if (c.tiny_bins) {
+                    pp.tiny_bin_list = ws->tiny_bins; pp.tiny_bin_stride = n_pairs;
+                    for (int b = 0; b < TLC_TINY_BINS; ++b) pp.tiny_bin_cnt[b] = ws->h_sync->pub_tiny[b];
                 }
                 pp.handoff = nullptr; pp.handoff_stride = 0; pp.handoff_cap = 0; pp.grid = 0; pp.phase = 0;
                 pp.tier_count_dev = nullptr; pp.abort_flag = nullptr;
@@ -1309,8 +1316,11 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
             }
             return TLC_OK;
         };
-        // (opt_medium_first: development A/B of the submission order -- the MEDIUM chain is the longest of a pipelined chunk)
-        if (g->opt_medium_first) {
+        // Submission order.  A chunk on its own with the TINY list in size classes: MEDIUM / MID first -- their tier kernels have a
+        // serial second kernel behind them and the lane-per-subgraph kernel, no longer the last to finish, only takes LDS from them
+        // when it starts alongside (tools/ab_option.py medium_first 0 1: one batch alone 0.7605 -> 0.7325 ms, pipelined batches equal;
+        // with the TINY kernel held back 110 us by an explicit sort it was 0.696).  opt_medium_first: -1 this rule, 0 / 1 forced.
+        if (g->opt_medium_first > 0 || (g->opt_medium_first < 0 && !c.pipelined && c.tiny_bins)) {
             if ((rc = launch_medium_mid()) != TLC_OK) return rc;
             if ((rc = launch_tiny_small()) != TLC_OK) return rc;
         } else {
@@ -1679,7 +1689,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "spec_cap")) g->opt_spec_cap = std::max(value, 0);
     else if (!strcmp(name, "mh_always")) g->opt_mh_always = value != 0;
     else if (!strcmp(name, "gate_ticks")) g->opt_gate_ticks = value;
-    else if (!strcmp(name, "medium_first")) g->opt_medium_first = value != 0;
+    else if (!strcmp(name, "medium_first")) g->opt_medium_first = value;
     else if (!strcmp(name, "large_split")) g->opt_large_split = value;
     else if (!strcmp(name, "early_wait")) g->opt_early_wait = value != 0;
     else if (!strcmp(name, "tiny_sort")) g->opt_tiny_sort = value != 0;

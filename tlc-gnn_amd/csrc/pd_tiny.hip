@@ -166,11 +166,20 @@ __device__ __forceinline__ void tiny_slot(const TlcPdParams p, unsigned char* ld
         n = (int)(hdr & 0xffu); m = (int)((hdr >> 8) & 0xffu);
         lu = (int)(signed char)((hdr >> 16) & 0xffu); lv = (int)(signed char)(hdr >> 24);
     } else {
-        int tier_count = p.tier_count;
-        if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
-        const int wi = slot * 64 + lane;
-        if (wi >= tier_count) return;
-        i = p.tier_list[wi];
+        if (p.tiny_bin_list) {
+            // the list by size class: this wavefront's 64 entries come from ONE bin (slots are dealt to the bins in order, largest first)
+            int s = slot, b = 0;
+            while (b < TLC_TINY_BINS - 1 && s >= ((p.tiny_bin_cnt[b] + 63) >> 6)) { s -= (p.tiny_bin_cnt[b] + 63) >> 6; ++b; }
+            const int wi = s * 64 + lane;
+            if (wi >= p.tiny_bin_cnt[b]) return;
+            i = p.tiny_bin_list[(size_t)b * p.tiny_bin_stride + wi];
+        } else {
+            int tier_count = p.tier_count;
+            if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
+            const int wi = slot * 64 + lane;
+            if (wi >= tier_count) return;
+            i = p.tier_list[wi];
+        }
         n = p.hdr_n[i]; m2 = p.hdr_m2[i]; lu = p.hdr_lu[i]; lv = p.hdr_lv[i];
         // (fixed slots written by the breadth-first COUNT pass, or wherever the extraction left the subgraph in the arena)
         adir = p.small_dir ? p.small_dir + (size_t)i * (2 * TLC_S_MMAX) : p.A_dir + p.edge_off[i];
@@ -454,7 +463,12 @@ template __global__ void tlc_pd_tiny_rec_kernel<TLC_TINY_REC_WPB>(TlcPdParams);
 int tlc_launch_pd_tiny(const TlcPdParams& p, void* stream) {
     if (p.tier_count <= 0) return TLC_OK;
     const size_t lds = TINY_WG_BYTES;
-    const int grid = (p.tier_count + 63) / 64;
+    int grid = (p.tier_count + 63) / 64;
+    if (p.tiny_bin_list) {                    // one wavefront per 64 entries of a size bin
+        grid = 0;
+        for (int b = 0; b < TLC_TINY_BINS; ++b) grid += (p.tiny_bin_cnt[b] + 63) / 64;
+        if (grid == 0) return TLC_OK;
+    }
     // (above the 64 KiB default of dynamic LDS; the attribute is per device, so it is set per launch: ~1 us)
     if (lds > 64 * 1024)
         TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_pd_tiny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -463,11 +477,10 @@ int tlc_launch_pd_tiny(const TlcPdParams& p, void* stream) {
     return TLC_OK;
 }
 
-// The TINY list by descending size.  A wavefront of the lane-per-subgraph kernel takes as long as its slowest lane, and in list
-// (= pair) order a 16-node vicinity sits in nearly every wavefront: summed over the wavefronts, the maxima of n + m are 1.85 times,
-// of (n + m)^2 3 times what they are with equals side by side (tools/tiny_binning_model.py on the PubMed-shaped batch).  Counting sort
-// by n + m (<= 40) in one workgroup: histogram, prefix, scatter; which of two equal-sized vicinities comes first is left to the
-// atomics -- every vicinity's row is its own.
+// A tier list by descending size: counting sort by (n + m) >> shift in one workgroup (histogram, prefix, scatter; which of two
+// equal-sized vicinities comes first is left to the atomics -- every vicinity's row is its own).  Development option tier_sort of
+// the SMALL / MID / MEDIUM lists (no gain there); the TINY list gets its size classes from the scan itself (TLC_TINY_BINS:
+// this kernel took 110 us in front of the lane-per-subgraph kernel, one workgroup fighting over twenty LDS counters).
 __global__ __launch_bounds__(1024) void tlc_tiny_sort_kernel(int count, const int* __restrict__ list, const int* __restrict__ hdr_n,
                                                             const int* __restrict__ hdr_m2, int* __restrict__ out, int shift) {
     __shared__ int hist[64], base[64];

@@ -32,6 +32,10 @@
 #define TLC_MAX_SUBGRAPH_NODES 65535
 #define TLC_MAX_SUBGRAPH_EDGES ((1 << 24) - 2)
 #define TLC_N_TIERS 8
+/* the TINY list once more, by size class: bin b holds the vicinities with (n + m) / TLC_TINY_BIN_W == TLC_TINY_BINS - 1 - b (largest
+   first); the lane-per-subgraph kernel takes 64 consecutive entries of ONE bin per wavefront (it waits for its slowest lane) */
+#define TLC_TINY_BINS 8
+#define TLC_TINY_BIN_W 5
 
 #define TLC_T_NMAX 16
 #define TLC_T_MMAX 24
@@ -189,6 +193,9 @@ struct TlcScanParams {
     int small_arena;
     int mh_min_pos;         // MEDIUM-sized vicinities with at least this many Pos edges go to the MEDHI list (TLC_MH_MIN_POS; INT_MAX: none)
     int tiny_ok;            // the SMALL-tier vicinities of at most TLC_T_NMAX nodes / TLC_T_MMAX edges get a list of their own
+    int* tiny_bin_count;    // [TLC_TINY_BINS] device counters (zeroed per chunk), null: no size bins
+    int* tiny_bin_list;     // [TLC_TINY_BINS][n_pairs]
+    int* h_tiny_bins;       // mapped host memory: the bin counts
     // COUNT wrote the MID / MEDIUM vicinities at bump-allocated offsets (TlcVicParams::bump_top): unless *bump_overflow, only
     // the heavy tiers still need arena space, handed out above *bump_top; null: every vicinity outside the SMALL tier does
     const unsigned long long* bump_top;
@@ -243,6 +250,10 @@ struct TlcPdParams {
     int huge_mmax;
     int huge_slots;
     int huge_lds;           // HUGE tier: dynamic LDS bytes of the launch (tables of the serial cycle swap), 0 = none
+    // lane-per-subgraph kernel: the TINY list by size class (null: the plain tier list)
+    const int* tiny_bin_list;   // [TLC_TINY_BINS][tiny_bin_stride]
+    int tiny_bin_stride;
+    int tiny_bin_cnt[TLC_TINY_BINS];
     int large_split;        // LARGE tier: two launches over the same list, the TLC_LC_* kernels for the vicinities that fit them, the TLC_L_* ones for the rest
     // statistics: [0] sources that took the exact tie fallback
     unsigned long long* stats;

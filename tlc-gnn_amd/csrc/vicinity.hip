@@ -79,6 +79,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
     __shared__ unsigned s_pre[SCAN_BLOCK / 32];       // pairs of this block that the early pass has already written
     __shared__ int s_tc[TLC_N_TIERS][SCAN_BLOCK / TLC_WAVE];
     __shared__ int s_tbase[TLC_N_TIERS];
+    __shared__ int s_bc[TLC_TINY_BINS][SCAN_BLOCK / TLC_WAVE];
+    __shared__ int s_bbase[TLC_TINY_BINS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) s_bid = atomicAdd(&p.sync[0], 1);
     if (t < SCAN_BLOCK / 32) s_pre[t] = 0u;
@@ -171,6 +173,29 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
     }
     __syncthreads();
     if (tier >= 0) p.tier_list[(size_t)tier * p.n_pairs + s_tbase[tier] + s_tc[tier][wave] + my_rank] = i;
+    // the TINY pairs once more, by size class (same block-aggregated append)
+    if (p.tiny_bin_count) {
+        int bin = -1;
+        if (tier == TLC_TIER_TINY) {
+            const int c = (n + (m2v >> 1)) / TLC_TINY_BIN_W;
+            bin = TLC_TINY_BINS - 1 - (c < TLC_TINY_BINS - 1 ? c : TLC_TINY_BINS - 1);
+        }
+        int brank = 0;
+#pragma unroll
+        for (int b = 0; b < TLC_TINY_BINS; ++b) {
+            const unsigned long long mk = __ballot(bin == b);
+            if (lane == 0) s_bc[b][wave] = __popcll(mk);
+            if (bin == b) brank = __popcll(mk & tlc_lanemask_lt());
+        }
+        __syncthreads();
+        if (t < TLC_TINY_BINS) {
+            int tot = 0;
+            for (int k = 0; k < SCAN_BLOCK / TLC_WAVE; ++k) { const int c = s_bc[t][k]; s_bc[t][k] = tot; tot += c; }
+            s_bbase[t] = tot > 0 ? atomicAdd(&p.tiny_bin_count[t], tot) : 0;
+        }
+        __syncthreads();
+        if (bin >= 0) p.tiny_bin_list[(size_t)bin * p.n_pairs + s_bbase[bin] + s_bc[bin][wave] + brank] = i;
+    }
     // the last block to get here publishes the sizes
     __syncthreads();
     if (t == 0) {
@@ -190,6 +215,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
             }
             for (int tt = 0; tt < TLC_N_TIERS; ++tt)
                 p.h_tier[tt] = __hip_atomic_load(&p.tier_count[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.tiny_bin_count && p.h_tiny_bins)
+                for (int b = 0; b < TLC_TINY_BINS; ++b)
+                    p.h_tiny_bins[b] = __hip_atomic_load(&p.tiny_bin_count[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence_system();
             __hip_atomic_store(p.h_seq, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
