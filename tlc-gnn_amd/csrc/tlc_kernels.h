@@ -34,8 +34,10 @@
 #define TLC_N_TIERS 8
 /* the TINY list once more, by size class: bin b holds the vicinities with (n + m) / TLC_TINY_BIN_W == TLC_TINY_BINS - 1 - b (largest
    first); the lane-per-subgraph kernel takes 64 consecutive entries of ONE bin per wavefront (it waits for its slowest lane) */
+#ifndef TLC_TINY_BINS            /* (overridable for an A/B of the bin width) */
 #define TLC_TINY_BINS 8
 #define TLC_TINY_BIN_W 5
+#endif
 
 #define TLC_T_NMAX 16
 #define TLC_T_MMAX 24
