@@ -1002,7 +1002,8 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     const bool mh_split = !pipelined || g->opt_mh_always;
     sp.mh_min_pos = mh_split ? TLC_MH_MIN_POS : 0x7fffffff;
     sp.tiny_ok = (g->opt_tiny && pi_enabled && flags == 0u && res == 5 && !d_out_ids && !d_out_f && !d_out_edges) ? 1 : 0;
-    // (the TINY list by size class as well: d_ctl[48..55] count, zeroed with the control block)
+    // (the TINY list by size class as well: d_ctl[48..63] count, zeroed with the control block; the scan's flags start at 64)
+    static_assert(TLC_TINY_BINS <= 16, "the size-class counters of the TINY list live in d_ctl[48..63]");
     if (sp.tiny_ok && g->opt_tiny_sort) { sp.tiny_bin_count = ws->d_ctl + 48; sp.tiny_bin_list = ws->tiny_bins; sp.h_tiny_bins = const_cast<int*>(ws->h_sync_dev->pub_tiny); }
     sp.early_list = early ? ws->d_early_list : nullptr; sp.early_count = d_early_count; sp.early_cap = TLC_EARLY_SLOTS;
     sp.h_early = const_cast<int*>(&ws->h_sync_dev->pub_early);
