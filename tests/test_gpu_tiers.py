@@ -201,6 +201,44 @@ def test_large_tier_split_into_compact_and_wide_kernels(n, m, n_pairs):
     g.close()
 
 
+@pytest.mark.parametrize("n,k_pos", [(301, 319), (301, 320), (301, 400), (83, 600), (450, 560)])
+def test_divide_and_conquer_of_the_wide_medium_configuration(n, k_pos):
+    """MEDIUM-sized vicinities with hundreds of Pos edges (the dense hop-1 vicinities of the Amazon shapes: 83 nodes / 680 edges)
+    sit in the 512 / 1 024 configuration for their edge count; from TLC_DC_MIN_POS_SHARED = 320 Pos edges the scan counts them and
+    tlc_pd_dc_kernel goes between their tier and swap kernels -- in the chain of a lone chunk from the second call on (the
+    speculative launch goes by the previous chunk's count), in pipelined chunks at once.  Rows: the oracle's, and bit-equal to the
+    serial walk's (option dcm = 0)."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    rs = np.random.RandomState(n + k_pos)
+    m = n - 1 + k_pos
+    comps = [hub_component(n, m, rs, 0), hub_component(200, 260, rs, n)]                 # (and MEDIUM vicinities beside them)
+    e = np.concatenate(comps)
+    rowptr, col, w = synth.edges_to_csr(n + 200, e, rs.uniform(-0.5, 0.9, size=len(e)))
+    pairs = np.array([[0, k] for k in range(1, 25)] + [[n, n + k] for k in range(1, 9)])
+    g = engine.DeviceGraph(rowptr, col, w)
+    g.set_option("dcm", 0)
+    ref_out, ref_st = _check(g, torch, rowptr, col, w, pairs)
+    assert g.dc_stats() == (0, 0)
+    g.set_option("dcm", 1)
+    expect = 24 if k_pos >= 320 else 0
+    _check(g, torch, rowptr, col, w, pairs)                            # (first call: the previous chunk's count is that of dcm = 0 ...)
+    for _ in range(2):
+        out, st = _check(g, torch, rowptr, col, w, pairs)
+        assert np.array_equal(st, ref_st) and np.abs(out - ref_out).max() <= 1e-12 * np.abs(ref_out).max()
+        assert g.dc_stats() == (expect, 0), g.dc_stats()
+    dev = torch.as_tensor(np.ascontiguousarray(pairs, dtype=np.int32)).cuda()
+    outs = [torch.empty((len(pairs), 25), dtype=torch.float64, device="cuda") for _ in range(3)]
+    sts = [torch.empty(len(pairs), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    for k in range(3):
+        g.pd_pi_batch(dev, 2, out=outs[k], status=sts[k], async_=True)
+    g.join()
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert np.array_equal(sts[k].cpu().numpy(), ref_st) and np.abs(outs[k].cpu().numpy() - ref_out).max() <= 1e-12 * np.abs(ref_out).max()
+    g.close()
+
+
 def test_tier_lists_sorted_by_size_give_the_same_rows():
     """The TINY list goes to the lane-per-subgraph kernel in size classes, largest first (tlc_scan_bin's bins: a wavefront waits for
     its slowest lane; option tiny_sort, default on), the other lists can be sorted (option tier_sort, development): every pair's

@@ -56,6 +56,7 @@ struct HostSync {
     volatile long long pub_total;
     volatile int pub_tier[TLC_N_TIERS];
     volatile int pub_tiny[TLC_TINY_BINS];     // the TINY list's size classes
+    volatile int pub_dcm;                     // MEDHI / MEDWIDE vicinities with Pos edges enough for the divide and conquer
     volatile int pub_early;
     volatile int pub_xl[2];        // lane-per-pair extraction: candidates listed, pairs finished as records
     volatile int pub_overflow;
@@ -99,6 +100,7 @@ struct Workspace {
     size_t cap_xl_slots;
     hipEvent_t ev_cls;         // the classification is done (recorded on the early stream)
     hipEvent_t ev_xl;          // the lane-per-pair extraction is done (recorded on its side stream)
+    int prev_dcm;              // the previous chunk's count of MEDHI vicinities for the divide and conquer (decides the speculative chain)
     int prev_xl_cand;          // its candidates in the previous chunk (sizes the launch of the lane-per-subgraph kernel behind it)
     long long* edge_off;
     // small device block: [0..6] tier counts, [10..13] scan, [16..19] early pass, [20..22] bump allocator, [24] work counter,
@@ -204,6 +206,7 @@ struct tlc_graph {
     int opt_chunk_pairs;                // development: pairs per chunk (0: TLC_CHUNK_PAIRS)
     int opt_medium_first;               // submit the MEDIUM / MID tiers ahead of TINY / SMALL: -1 a chunk on its own (default), 0 never, 1 always
     int opt_early_wait;                 // development: 0 = the main COUNT of a pipelined chunk does not wait for the early pass (default 1)
+    int opt_dcm;                        // the divide and conquer for the wide MEDIUM configuration when the scan counted vicinities for it (default 1)
     int opt_tiny_sort;                  // the TINY list in size classes, largest first (tlc_scan_bin; default 1; 0: pair order, A/B)
     int opt_tier_sort;                  // development: bit t = the list of tier t (SMALL / MID / MEDIUM) by descending size as well
     int count_only;                     // set by tlc_vicinity_sizes around its run_batch: chunks stop after the scan, their sizes are copied out
@@ -550,7 +553,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     // one batch alone and a loss for pipelined batches -- see the note at `xlane` in run_chunk_front and DESIGN.md)
     { const char* v = getenv("TLC_XL_CUT"); g->opt_xl_cut = v ? std::min(std::max(atoi(v), 0), TLC_XL_MAXCUT) : 0; }
     g->opt_xl_ncut = TLC_T_NCUT; g->opt_xl_mcut = TLC_T_MCUT;
-    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_large_split = 0; g->opt_early_wait = 1; g->opt_tiny_sort = 1; g->opt_medium_first = -1; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
+    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_large_split = 0; g->opt_early_wait = 1; g->opt_tiny_sort = 1; g->opt_medium_first = -1; g->opt_dcm = 1; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
@@ -1002,6 +1005,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     const bool mh_split = !pipelined || g->opt_mh_always;
     sp.mh_min_pos = mh_split ? TLC_MH_MIN_POS : 0x7fffffff;
     sp.tiny_ok = (g->opt_tiny && pi_enabled && flags == 0u && res == 5 && !d_out_ids && !d_out_f && !d_out_edges) ? 1 : 0;
+    sp.dcm_count = ws->d_ctl + 44; sp.h_dcm = const_cast<int*>(&ws->h_sync_dev->pub_dcm);
     // (the TINY list by size class as well: d_ctl[48..63] count, zeroed with the control block; the scan's flags start at 64)
     static_assert(TLC_TINY_BINS <= 16, "the size-class counters of the TINY list live in d_ctl[48..63]");
     if (sp.tiny_ok && g->opt_tiny_sort) { sp.tiny_bin_count = ws->d_ctl + 48; sp.tiny_bin_list = ws->tiny_bins; sp.h_tiny_bins = const_cast<int*>(ws->h_sync_dev->pub_tiny); }
@@ -1067,9 +1071,13 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
             pp.handoff = ws->handoff + spec_base[t]; pp.handoff_stride = (long long)tlc_handoff_slot_bytes(t);
             pp.abort_flag = d_bump_overflow;
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
+            // (the divide and conquer in this chain only if the previous chunk had vicinities for it: the count is not known yet)
+            pp.dc_count = nullptr; pp.dc_list = nullptr;
+            if (ws->prev_dcm > 0 && g->opt_dcm) dc_lists_for(pp, 0);
             T0(tslot[t], s);
             if (((g->opt_tier_mask >> t) & 1) && (rc = tlc_launch_pd_tier(t, pp, s)) != TLC_OK) return rc;
             T1(tslot[t], s);
+            pp.dc_count = nullptr; pp.dc_list = nullptr;
         }
         pp.phase = 0;
         pp.grid = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr; pp.handoff = nullptr; pp.handoff_cap = 0;
@@ -1142,6 +1150,8 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
     if (tc[TLC_TIER_HUGE] > 0 && (rc = ensure_huge(g, ws)) != TLC_OK) return rc;
 
     const int n_early = early ? ws->h_sync->pub_early : 0;
+    const int n_dcm = ws->h_sync->pub_dcm;
+    ws->prev_dcm = n_dcm;
     const int n_xl_cand = c.xlane ? ws->h_sync->pub_xl[0] : 0, n_xl_done = c.xlane ? ws->h_sync->pub_xl[1] : 0;
     int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4] + tc[5] + tc[6] + tc[7];
     if (c.count_only) {
@@ -1221,6 +1231,7 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
             pp.handoff_cap = (spec_done && (t == TLC_TIER_MID || t == TLC_TIER_MEDIUM || t == TLC_TIER_MEDWIDE)) ? std::min(tc[t], spec_cap[t]) : tc[t];
             pp.dc_count = nullptr; pp.dc_list = nullptr;
             if (t == TLC_TIER_LARGE) dc_lists_for(pp, 1);
+            if ((t == TLC_TIER_MEDHI || t == TLC_TIER_MEDWIDE) && n_dcm > 0 && g->opt_dcm) dc_lists_for(pp, 0);
             if (hs && t == TLC_TIER_LARGE) {
                 // (the early launch may still be using the first TLC_EARLY_SLOTS slots: this launch takes the ones behind them)
                 int r2 = ensure_handoff_large(g, ws, (size_t)TLC_EARLY_SLOTS + (size_t)tc[t]);
@@ -1694,6 +1705,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "large_split")) g->opt_large_split = value;
     else if (!strcmp(name, "early_wait")) g->opt_early_wait = value != 0;
     else if (!strcmp(name, "tiny_sort")) g->opt_tiny_sort = value != 0;
+    else if (!strcmp(name, "dcm")) g->opt_dcm = value != 0;
     else if (!strcmp(name, "tier_sort")) g->opt_tier_sort = value;
     else if (!strcmp(name, "n_ws")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_n_ws = std::min(std::max(value, 2), TLC_N_WS); }
     else if (!strcmp(name, "defer")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_defer = value != 0; }

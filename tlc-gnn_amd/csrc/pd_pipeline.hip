@@ -1227,16 +1227,19 @@ __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, i
     // order with its ties fixed
     // dc_mode 1: here, in this workgroup (LARGE: a CU to itself);  2: through the hand-off record, by tlc_pd_dc_kernel
     const int k_pos = m - n + 1;
-    bool dc = dc_mode != 0 && !(flags & TLC_NO_EXT1) && k_pos >= (W >= 512 ? TLC_DC_MIN_POS : TLC_DC_MIN_POS_SHARED) && m <= 8 * W &&
-              m < 65536 && (size_t)((m + 31) / 32) * 4 <= 1280 && (dc_mode == 1 || slot != nullptr) &&
-              (dc_mode == 2 || dc_bytes(k_pos, n > 2 * k_pos + 2 ? n : 2 * k_pos + 2) + al16((size_t)k_pos * 2) < M.xbytes);
-    if (dc) {
+    // (`elig` is a property of the subgraph alone: the tie fix-up below changes the order of equal descending keys, and a row must not
+    // depend on whether this launch had a hand-off slot for the subgraph -- a speculative launch runs out of slots, another does not)
+    bool elig = dc_mode != 0 && !(flags & TLC_NO_EXT1) && k_pos >= (W >= 512 ? TLC_DC_MIN_POS : TLC_DC_MIN_POS_SHARED) && m <= 8 * W &&
+                m < 65536 && (size_t)((m + 31) / 32) * 4 <= 1280 &&
+                (dc_mode == 2 || dc_bytes(k_pos, n > 2 * k_pos + 2 ? n : 2 * k_pos + 2) + al16((size_t)k_pos * 2) < M.xbytes);
+    if (elig) {
         unsigned* finb = (unsigned*)M.rec;                            // the tree bitmap is indexed by ascending position = rank
         for (int w = threadIdx.x; w < (m + 31) / 32; w += W) finb[w] = M.tbits[w];
         __syncthreads();
     }
     sort_edges<W, idx_t, true, QS>(M, m);
-    if (dc) dc = fix_desc_ties<W>(M, m);
+    if (elig) elig = fix_desc_ties<W>(M, m);
+    const bool dc = elig && (dc_mode == 1 || slot != nullptr);
     TLC_STAMP(7);
     if (Sink::want_down) mst_pass<W, idx_t, true, true>(M, sink, n, m, flags);
     else mst_pass<W, idx_t, true, false>(M, sink, n, m, flags);
@@ -1675,7 +1678,10 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
             // (the compact LARGE kernels sort like the wide ones -- same run / merge decisions, so a vicinity's row does not depend on which of
             // the two took it)
             status = pd_all_stages<W, sort_hold(NM == TLC_LC_NMAX ? TLC_L_MMAX : MM, W)>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, slot, deferred,
-                                      /*dc_mode=*/(!HUGE && (NM == TLC_L_NMAX || NM == TLC_LC_NMAX)) ? TLC_DC_LARGE_MODE : 0,
+                                      /*dc_mode=*/(!HUGE && (NM == TLC_L_NMAX || NM == TLC_LC_NMAX)) ? TLC_DC_LARGE_MODE
+                                                  : ((!HUGE && NM == TLC_M_NMAX) ? 2 : 0),     // (whether or not the launch carries a
+                                      // dc list: marking a subgraph for the divide and conquer fixes the order of its tied descending
+                                      // keys, and a row must not depend on whether tlc_pd_dc_kernel or the serial walk then answers)
                                       /*handoff_all=*/NM != TLC_L_NMAX && NM != TLC_LC_NMAX);
             if (deferred && slot && tid == 0 && p.dc_count && ((const int*)slot)[6] != 0) {
                 const int li = atomicAdd(p.dc_count, 1);              // meant for tlc_pd_dc_kernel
@@ -1812,8 +1818,10 @@ __global__ __launch_bounds__(64, 4) void tlc_pd_swap_kernel(TlcPdParams p) {
 // ======================================================================================================================
 __host__ __device__ constexpr size_t dc_kernel_lds(int NM, int MM) {
     // LDS budget: the solver's arrays for a subgraph of the tier's typical heavy shape (K = MM/2 queries on NM nodes), the
-    // answers, the points; f and the image table re-use the solver's arrays afterwards
-    const size_t dc = al16(dc_bytes(MM / 2, NM > MM + 2 ? NM : MM + 2) + (size_t)MM + 16) + al16((size_t)(MM + 2) * 4) + 256;
+    // answers, the points; f and the image table re-use the solver's arrays afterwards.  The wide MEDIUM configuration: K = 7/8 MM --
+    // what it gets are dense little vicinities, 600 Pos edges on 80 nodes (52 KB; there are a few dozen of them in a batch)
+    const int KB = NM <= TLC_M_NMAX ? (MM / 8) * 7 : MM / 2;
+    const size_t dc = al16(dc_bytes(KB, NM > 2 * KB + 2 ? NM : 2 * KB + 2) + (size_t)MM + 16) + al16((size_t)(MM + 2) * 4) + 256;
     return dc > make_swap_layout(NM, MM).total ? dc : make_swap_layout(NM, MM).total;     // (the serial fallback's layout fits too)
 }
 template <int NM, int MM, int W>
@@ -2296,6 +2304,12 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             if (p.phase != 2)
                 hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, false, false>), dim3(grid),
                                    dim3(256), L.total + mpad, s, p);
+            // (a dc list on the launch: the scan counted vicinities with Pos edges enough -- dense hop-1 vicinities of the Amazon
+            // shapes, 600 Pos edges on 80 nodes -- and the tier kernel marked them; the rest stay for the swap kernel behind)
+            if (deferring && p.phase != 1 && p.dc_count) {
+                constexpr size_t dcm = dc_kernel_lds(TLC_M_NMAX, TLC_M_MMAX);
+                hipLaunchKernelGGL((tlc_pd_dc_kernel<TLC_M_NMAX, TLC_M_MMAX, 256>), dim3(grid), dim3(256), dcm, s, p);
+            }
             if (deferring && p.phase != 1) {
                 constexpr SwapLayout SL = make_swap_layout(TLC_M_NMAX, TLC_M_MMAX);
                 hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_M_NMAX, TLC_M_MMAX>), dim3(grid), dim3(64), SL.total, s, p);

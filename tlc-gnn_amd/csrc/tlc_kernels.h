@@ -34,6 +34,10 @@
 #define TLC_N_TIERS 8
 /* the TINY list once more, by size class: bin b holds the vicinities with (n + m) / TLC_TINY_BIN_W == TLC_TINY_BINS - 1 - b (largest
    first); the lane-per-subgraph kernel takes 64 consecutive entries of ONE bin per wavefront (it waits for its slowest lane) */
+/* Pos edges from which a vicinity of a 256-thread tier takes the divide and conquer (ext1_dc.h has the measurements); the scan counts them */
+#ifndef TLC_DC_MIN_POS_SHARED
+#define TLC_DC_MIN_POS_SHARED 320
+#endif
 #ifndef TLC_TINY_BINS            /* (overridable for an A/B of the bin width) */
 #define TLC_TINY_BINS 8
 #define TLC_TINY_BIN_W 5
@@ -195,6 +199,8 @@ struct TlcScanParams {
     int small_arena;
     int mh_min_pos;         // MEDIUM-sized vicinities with at least this many Pos edges go to the MEDHI list (TLC_MH_MIN_POS; INT_MAX: none)
     int tiny_ok;            // the SMALL-tier vicinities of at most TLC_T_NMAX nodes / TLC_T_MMAX edges get a list of their own
+    int* dcm_count;         // device counter (zeroed per chunk): MEDHI / MEDWIDE vicinities with enough Pos edges for the divide and conquer
+    int* h_dcm;             // mapped host memory: that count
     int* tiny_bin_count;    // [TLC_TINY_BINS] device counters (zeroed per chunk), null: no size bins
     int* tiny_bin_list;     // [TLC_TINY_BINS][n_pairs]
     int* h_tiny_bins;       // mapped host memory: the bin counts

@@ -173,6 +173,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
     }
     __syncthreads();
     if (tier >= 0) p.tier_list[(size_t)tier * p.n_pairs + s_tbase[tier] + s_tc[tier][wave] + my_rank] = i;
+    // how many vicinities of the wide MEDIUM configuration have Pos edges enough for the divide and conquer (the host puts
+    // tlc_pd_dc_kernel into that tier's chain only when there are any: an idle kernel there costs a full machine 70 - 85 us)
+    if (p.dcm_count) {
+        const int mm = m2v >> 1;
+        const bool big = (tier == TLC_TIER_MEDHI || tier == TLC_TIER_MEDWIDE) && mm - n + 1 >= TLC_DC_MIN_POS_SHARED && mm <= 8 * 256;
+        const unsigned long long mk = __ballot(big);
+        if (lane == 0 && mk) atomicAdd(p.dcm_count, __popcll(mk));
+    }
     // the TINY pairs once more, by size class (same block-aggregated append)
     if (p.tiny_bin_count) {
         int bin = -1;
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
             }
             for (int tt = 0; tt < TLC_N_TIERS; ++tt)
                 p.h_tier[tt] = __hip_atomic_load(&p.tier_count[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.dcm_count && p.h_dcm) *p.h_dcm = __hip_atomic_load(p.dcm_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (p.tiny_bin_count && p.h_tiny_bins)
                 for (int b = 0; b < TLC_TINY_BINS; ++b)
                     p.h_tiny_bins[b] = __hip_atomic_load(&p.tiny_bin_count[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

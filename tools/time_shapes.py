@@ -20,4 +20,7 @@ for name in sys.argv[1:] or ["Cora", "Photo", "Computers"]:
     nn, m2 = g.sizes(len(sel))
     print(name, "n=%d m=%d hop=%d pairs=%d: %.2f ms (%.2f M PI/s)" % (n, len(e), hop, len(sel), dt * 1e3, len(sel) / dt / 1e6),
           {k2: v for k2, v in g.stats().items() if k2.startswith("tier")}, "max n/m:", nn.max(), m2.max() // 2,
-          {k2: round(v, 2) for k2, v in g.timings().items() if v >= 0})
+          {k2: round(v, 2) for k2, v in g.timings().items() if v >= 0}, "dc (ran, gave back):", g.dc_stats())
+    K = (m2 // 2 - nn + 1)
+    big = (m2 // 2 > 256) | (nn > 128)
+    print("   MEDIUM-sized: %d, of them Pos edges >= 320: %d; Pos edges of the ten largest: %s" % (big.sum(), (big & (K >= 320)).sum(), np.sort(K[big])[-10:].tolist()))
