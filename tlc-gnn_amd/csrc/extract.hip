@@ -40,8 +40,11 @@ struct XCfg {
 };
 
 #define TLC_X_UNITS (1024 + TLC_X_H_CAP * TLC_X_H_CAP / 64)    /* units of a sweep: 64-member batches + 64-pair heavy chunks */
+#ifndef TLC_X_STAGE
+#define TLC_X_STAGE 128       /* entries a wavefront stages in LDS before it writes them out in order (0: every lane stores its own) */
+#endif
 struct XLayout {
-    size_t o_pref, o_sid, o_hvy, o_hl, o_ctl, o_ucnt, total;
+    size_t o_pref, o_sid, o_hvy, o_hl, o_ctl, o_ucnt, o_stage, total;
 };
 __host__ __device__ constexpr XLayout x_layout(int nw, int sid_cap, int bw) {
     XLayout L{};
@@ -52,7 +55,8 @@ __host__ __device__ constexpr XLayout x_layout(int nw, int sid_cap, int bw) {
     L.o_hl = L.o_hvy + TLC_X_HV_CAP / 8;
     L.o_ctl = L.o_hl + (size_t)TLC_X_H_CAP * 4;
     L.o_ucnt = L.o_ctl + 64 + (size_t)(bw / 64) * 4 + 16;
-    L.total = L.o_ucnt + (bw > 64 ? (size_t)TLC_X_UNITS * 4 : 0);
+    L.o_stage = (L.o_ucnt + (bw > 64 ? (size_t)TLC_X_UNITS * 4 : 0) + 15) & ~(size_t)15;
+    L.total = L.o_stage + (size_t)(bw / 64) * TLC_X_STAGE * 12;      // per wavefront: [TLC_X_STAGE doubles | TLC_X_STAGE words]
     return L;
 }
 
@@ -62,6 +66,7 @@ struct XState {
     unsigned* hvy;
     unsigned* hl;          // (local id << 16) | heavy index
     int* ucnt;             // several wavefronts: entries / first entry number of every unit of a sweep
+    unsigned char* stage;  // the wavefronts' staging buffers (x_sweep_wave)
     int* ctl;              // [0] lu [1] lv [2] entry counter (BW > 64) [3] heavy members [4] early slot [6..7] block grab; [8..11] region cursor / end (2 x i64, live across pairs)
     int* xw;
 };
@@ -147,6 +152,38 @@ __device__ __forceinline__ int x_sweep_wave(const PB& p, const int* ids, int n, 
 #define SSTAMP(k) do { } while (0)
 #endif
     SSTAMP(8);
+    // Staged writes.  A lane that finds q entries in its row writes them at ITS offsets: one store instruction per position of the
+    // row round, every active lane at an address of its own -- and the texture addresser takes one cycle per such lane (counters:
+    // 41.6 M store lane-accesses per batch, half of everything the kernel asks of it, at 0.85 lane-accesses per cycle and CU).  So the
+    // entries of the short-row rounds go to an LDS buffer at their entry number and leave it in order, 64 consecutive entries per
+    // store.  [st_fb, st_fb + st_fill) are the entry numbers the buffer holds; the dense paths (long rows, heavy pairs) number
+    // their entries by ballot already and store directly.
+    double* const st_w = reinterpret_cast<double*>(X.stage + (size_t)wv * TLC_X_STAGE * 12);
+    unsigned* const st_d = reinterpret_cast<unsigned*>(st_w + TLC_X_STAGE);
+    int st_fb = 0, st_fill = 0;
+    auto st_flush = [&]() {
+        if (!WR || TLC_X_STAGE == 0 || st_fill == 0) return;
+        x_sync<64>();
+        for (int k = lane; k < st_fill; k += TLC_WAVE) {
+            const int e = st_fb + k;
+            if (e < cap) { x_store(&dir[e], st_d[k]); x_store(&lw[e], st_w[k]); }
+        }
+        x_sync<64>();
+        st_fill = 0;
+    };
+    // the round's entries are numbered [r0, r0 + tot): true = they go through the buffer
+    auto st_round = [&](int r0, int tot) -> bool {
+        if (!WR || TLC_X_STAGE == 0) return false;
+        if (st_fill && (r0 != st_fb + st_fill || st_fill + tot > TLC_X_STAGE)) st_flush();
+        if (tot > TLC_X_STAGE) return false;
+        if (!st_fill) st_fb = r0;
+        st_fill += tot;
+        return true;
+    };
+    auto st_put = [&](bool staged, int off, unsigned d, double w) {
+        if (staged) { st_d[off - st_fb] = d; st_w[off - st_fb] = w; }
+        else if (off < cap) { x_store(&dir[off], d); x_store(&lw[off], w); }
+    };
     const int nb = (n + 63) >> 6;
     for (int b = wv; b < nb; b += NW) {
         if (NW > 1) { if (WR) run = ucnt[b]; else run = 0; }
@@ -178,16 +215,18 @@ __device__ __forceinline__ int x_sweep_wave(const PB& p, const int* ids, int n, 
             const int cnt = __popc(hit) + __popc(rev);
             const int incl = tlc_wave_iscan_i32(cnt);
             int off = run + incl - cnt;
-            run += __builtin_amdgcn_readlane(incl, 63);
+            const int tot = __builtin_amdgcn_readlane(incl, 63);
+            const bool staged = st_round(run, tot);
+            run += tot;
             if (WR && cnt) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if ((hit >> q) & 1u) {
                         const double wq = R.w(q);
-                        if (off < cap) { x_store(&dir[off], ((unsigned)k << 16) | (unsigned)ly[q]); x_store(&lw[off], wq); }
+                        st_put(staged, off, ((unsigned)k << 16) | (unsigned)ly[q], wq);
                         ++off;
                         if ((rev >> q) & 1u) {
-                            if (off < cap) { x_store(&dir[off], ((unsigned)ly[q] << 16) | (unsigned)k); x_store(&lw[off], wq); }
+                            st_put(staged, off, ((unsigned)ly[q] << 16) | (unsigned)k, wq);
                             ++off;
                         }
                     }
@@ -248,15 +287,17 @@ __device__ __forceinline__ int x_sweep_wave(const PB& p, const int* ids, int n, 
                 const int cnt = __popc(hit) + __popc(rev);
                 const int incl = tlc_wave_iscan_i32(cnt);
                 int off = run + incl - cnt;
-                run += __builtin_amdgcn_readlane(incl, 63);
+                const int tot = __builtin_amdgcn_readlane(incl, 63);
+                const bool staged = st_round(run, tot);
+                run += tot;
                 if (WR && cnt) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         if ((hit >> q) & 1u) {
-                            if (off < cap) { x_store(&dir[off], ((unsigned)kk << 16) | (unsigned)ly[q]); x_store(&lw[off], ww[q]); }
+                            st_put(staged, off, ((unsigned)kk << 16) | (unsigned)ly[q], ww[q]);
                             ++off;
                             if ((rev >> q) & 1u) {
-                                if (off < cap) { x_store(&dir[off], ((unsigned)ly[q] << 16) | (unsigned)kk); x_store(&lw[off], ww[q]); }
+                                st_put(staged, off, ((unsigned)ly[q] << 16) | (unsigned)kk, ww[q]);
                                 ++off;
                             }
                         }
@@ -307,6 +348,7 @@ __device__ __forceinline__ int x_sweep_wave(const PB& p, const int* ids, int n, 
             if (!WR) { if (lane == 0) ucnt[b] = run; counted += run; }
         }
     }
+    st_flush();
     SSTAMP(12);
     // ---- heavy x heavy: ordered pairs of listed heavy members through the dense weight table (0 = not adjacent) ------------
     if (use_hvy && nH > 0) {
@@ -380,8 +422,16 @@ struct XHead {
     int u, v;
     int ru0, ru1, rv0, rv1, a0, a1, b0, b1;
 };
-template <int BW, class PB>
-__device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest, const XHead& H, unsigned char* lds, int* slot) {
+// The first chunks of a pair's two ball lists, asked for while the pair BEFORE it is swept (single-wavefront workgroups): lane l
+// holds entry l of the smaller list (b) and entries l, 64 + l of the larger one (a), -1 beyond their ends.  (Three registers: with
+// four chunks of each the kernel spilled 40 -- and a spilled prefetch register is a wait for the load in front of the sweep.)
+struct XNoPrefetch {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int BW, class PB, class PF = XNoPrefetch>
+__device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest, const XHead& H, unsigned char* lds, int* slot,
+                                             bool has_pre = false, int pb0 = -1, int pa0 = -1, int pa1 = -1,
+                                             const PF& prefetch_next = PF()) {
     constexpr int SID_CAP = XCfg<BW>::SID_CAP;
     const XLayout L = x_layout(p.nw, SID_CAP, BW);
     const int nw4 = (p.nw + 3) & ~3;
@@ -394,7 +444,12 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
     X.ctl = (int*)(lds + L.o_ctl);
     X.xw = X.ctl + 16;
     X.ucnt = (int*)(lds + L.o_ucnt);
-    const int tid = threadIdx.x;
+    X.stage = lds + L.o_stage;
+    // (laundered: values derived from the thread index -- shifted copies, list addresses -- are otherwise computed once in front of
+    // the item loop and held in registers across the whole body, where the sweep then spills)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
 #ifdef TLC_PAIR_TIMES
     // (per-pair wall-clock stamps only: sums through global atomics on one address would serialise the whole kernel)
 #define XSTAMP(k) do { if (p.dbg_pair_t && tid == 0) p.dbg_pair_t[16 * (size_t)i + (k)] = wall_clock64(); } while (0)
@@ -445,12 +500,18 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                       // (the first chunks of the smaller list are in flight while the larger is marked)
         const int j = r * BW + tid;
-        bv[r] = j < nB ? p.bcol[b0 + j] : -1;
+        if (has_pre && r == 0) bv[r] = pb0;             // (uniform) came with the call
+        else bv[r] = j < nB ? p.bcol[b0 + j] : -1;
     }
+    bool first = has_pre;
     for (int j = tid; j < nA; j += 4 * BW) {
         int av[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) av[r] = (j + r * BW < nA) ? p.bcol[a0 + j + r * BW] : -1;
+        for (int r = 0; r < 4; ++r) {
+            if (first && r < 2) av[r] = r == 0 ? pa0 : pa1;
+            else av[r] = (j + r * BW < nA) ? p.bcol[a0 + j + r * BW] : -1;
+        }
+        first = false;
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (av[r] >= 0) atomicOr(&X.bits[av[r] >> 5], 1u << (av[r] & 31));
     }
@@ -629,6 +690,7 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
             cap = 2 * TLC_L_MMAX;
         }
     }
+    prefetch_next();                                      // (the next pair's ball lists travel while this one's rows are swept)
     const int m2 = x_sweep<BW>(p, ids, n, X, use_hvy, nH, wdir, wlw, cap, rec0, BW == 64, i);
     XSTAMP(6);
     const int m = m2 >> 1;
@@ -669,6 +731,12 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
 
 #ifndef TLC_X_WPE
 #define TLC_X_WPE 4
+#endif
+#ifndef TLC_X_NOPF
+#define TLC_X_NOPF 0
+#endif
+#ifndef TLC_X_PIPE
+#define TLC_X_PIPE 0          /* 0: the item loop without the stream / list prefetch (A/B) */
 #endif
 typedef const __attribute__((address_space(4))) TlcVicParams XParams;
 typedef const __attribute__((address_space(4))) int XCInt;
@@ -750,6 +818,102 @@ __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kern
     const bool dyn = p.work_counter != nullptr;
     const int n_chunks = dyn ? (n_work + p.work_chunk - 1) / p.work_chunk : n_work;
     int ck = (int)(blockIdx.x % TLC_X_COUNTERS), dry = 0;
+    if constexpr (BW == 64 && TLC_X_PIPE != 0) {
+        // Single-wavefront workgroups: the items of this workgroup form ONE stream (its chunks one after the other) and the stages
+        // run across chunk boundaries, three items ahead: while item k is extracted, the list entry of item k+3, the pair of k+2 and
+        // the row bounds of k+1 are fetched (scalar loads), and once item k's own lists have been consumed -- in front of its
+        // sweep -- the first 64 / 128 entries of the two ball lists of item k+1 are asked for (vector loads that nobody waits for
+        // before the next item starts).  Per-pair stamps had shown 2.4 of the 9.8 us of a <= 16-node pair in front of the first
+        // list entry, and the three-load chain at the head of every CHUNK (two pairs) exposed.
+        int g_c = (int)blockIdx.x;
+        int g_w = g_c < n_chunks ? g_c : -1;                   // the next item the stream hands out
+        int g_nxt = 0;                                        // (lane 0) the counter's answer for the chunk after g_c
+        if (dyn && g_w >= 0 && threadIdx.x == 0) g_nxt = atomicAdd(p.work_counter + ck * TLC_X_COUNTER_STRIDE, 1);
+        auto gen = [&]() -> int {
+            const int w = g_w;
+            if (w < 0) return -1;
+            if (w + n_chunks < n_work) { g_w = w + n_chunks; return w; }
+            if (!dyn) g_c += (int)gridDim.x;
+            else {
+                g_c = (int)gridDim.x + TLC_X_COUNTERS * __builtin_amdgcn_readfirstlane(g_nxt) + ck;
+                while (g_c >= n_chunks && ++dry < TLC_X_COUNTERS) {          // (dry counters: see the loop below)
+                    ck = (ck + 1) % TLC_X_COUNTERS;
+                    int* cnt = p.work_counter + ck * TLC_X_COUNTER_STRIDE;
+                    int t = 0;
+                    if (threadIdx.x == 0) t = __atomic_load_n(cnt, __ATOMIC_RELAXED);
+                    if ((int)gridDim.x + TLC_X_COUNTERS * __builtin_amdgcn_readfirstlane(t) + ck >= n_chunks) continue;
+                    if (threadIdx.x == 0) t = atomicAdd(cnt, 1);
+                    g_c = (int)gridDim.x + TLC_X_COUNTERS * __builtin_amdgcn_readfirstlane(t) + ck;
+                }
+            }
+            g_w = g_c < n_chunks ? g_c : -1;
+            if (dyn && g_w >= 0 && threadIdx.x == 0) g_nxt = atomicAdd(p.work_counter + ck * TLC_X_COUNTER_STRIDE, 1);
+            return w;
+        };
+        bool fr0 = false, fr1 = false, fr2 = false;
+        int i0 = -1, i1 = -1, i2 = -1, u1 = -1, v1 = -1;
+        XHead H0;
+        H0.u = H0.v = -1;
+        {
+            XParams* q = kp;
+            asm volatile("" : "+s"(q));
+            const int w0 = gen(), w1 = gen(), w2 = gen();
+            if (w0 >= 0) i0 = idx_of(q, w0, fr0);
+            if (w1 >= 0) i1 = idx_of(q, w1, fr1);
+            if (w2 >= 0) i2 = idx_of(q, w2, fr2);
+            if (i0 >= 0) pair_of(q, i0, H0.u, H0.v);
+            if (i1 >= 0) pair_of(q, i1, u1, v1);
+            bounds_of(q, H0);
+        }
+        bool pre_ok = false;
+        int pb0 = -1, pa0 = -1, pa1 = -1;
+        while (i0 >= 0) {
+            XParams* q = kp;
+            asm volatile("" : "+s"(q));
+            bool fr3 = false;
+            int i3 = -1, u2 = -1, v2 = -1;
+            const int w3 = gen();
+            if (w3 >= 0) i3 = idx_of(q, w3, fr3);
+            if (i2 >= 0) pair_of(q, i2, u2, v2);
+            XHead H1;
+            H1.u = u1; H1.v = v1;
+            bounds_of(q, H1);
+            bool pf_done = false, pre_n = false;
+            int npb0 = -1, npa0 = -1, npa1 = -1;
+            auto pf = [&]() {
+                pf_done = true;
+                if (TLC_X_NOPF || i1 < 0 || q->x_fill) return;
+                int a0 = H1.a0, a1 = H1.a1, b0 = H1.b0, b1 = H1.b1;          // (all zero for ids outside the graph)
+                if (a1 - a0 < b1 - b0) { int t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; }
+                const int nA = a1 - a0, nB = b1 - b0;
+                if (fr1) {                                                   // (a pair another pass owns: extract_pair's predicates)
+                    if (q->skip_count && nB >= q->skip_threshold) return;
+                    else if (q->big_count && nB >= TLC_X_BIN_MIN) return;
+                    else if (nB <= q->xl_cut) return;
+                }
+                const int* bc = q->bcol;
+                const int j = (int)threadIdx.x;
+                npb0 = j < nB ? bc[b0 + j] : -1;
+                npa0 = j < nA ? bc[a0 + j] : -1;
+                npa1 = j + 64 < nA ? bc[a0 + j + 64] : -1;
+                pre_n = true;
+            };
+            extract_pair<BW>(*q, i0, fr0, H0, xlds, slot, pre_ok, pb0, pa0, pa1, pf);
+            if (!pf_done) pf();
+            pre_ok = pre_n;
+            pb0 = npb0; pa0 = npa0; pa1 = npa1;
+            // (the carried heads are uniform; said explicitly, or the compiler keeps the eight bounds in vector registers across the body)
+#define XU(x) __builtin_amdgcn_readfirstlane(x)
+            i0 = XU(i1); fr0 = fr1;
+            H0.u = XU(H1.u); H0.v = XU(H1.v);
+            H0.ru0 = XU(H1.ru0); H0.ru1 = XU(H1.ru1); H0.rv0 = XU(H1.rv0); H0.rv1 = XU(H1.rv1);
+            H0.a0 = XU(H1.a0); H0.a1 = XU(H1.a1); H0.b0 = XU(H1.b0); H0.b1 = XU(H1.b1);
+            i1 = XU(i2); fr1 = fr2; u1 = XU(u2); v1 = XU(v2);
+            i2 = XU(i3); fr2 = fr3;
+#undef XU
+        }
+        return;
+    }
     for (int c = blockIdx.x; c < n_chunks;) {
         int nxt = 0;
         if (dyn && BW == 64 && threadIdx.x == 0) nxt = atomicAdd(p.work_counter + ck * TLC_X_COUNTER_STRIDE, 1);
