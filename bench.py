@@ -975,6 +975,11 @@ def main():
                               "frac_one_batch_alone": valu * 4.0 / (simds * clk * float(np.median(lat_plain)) * 1e-3),
                               "source": "measured in this run: child pass under rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU, "
                                         "%d batches; sums over every kernel of the image batch" % pre_issue_detail["batches_in_pass"],
+                              # issue rates measured on this GPU with tools/probes/salu_probe.hip (profiles/r04_issue_rates_probe.txt):
+                              # 1.33 vector and 0.86 scalar-ALU wave-instructions per cycle and CU (one scalar unit per CU), independent
+                              "measured_issue_rates_per_cycle_and_cu": {"valu": 1.33, "salu": 0.86},
+                              "frac_valu_of_measured_rate": valu / (1.33 * (simds / 4) * clk * per_batch_s),
+                              "frac_salu_of_measured_rate": float(pre_issue.get("SQ_INSTS_SALU", 0.0)) / (0.86 * (simds / 4) * clk * per_batch_s),
                               "per_kernel_valu_wave_insts": pre_issue_detail["per_kernel_valu"],
                               "note": "share of the machine's vector issue slots the image leg uses in the timed region (pipelined) / for one "
                                       "batch alone; the rest is dependent-latency time (LDS / L2 round trips of serial graph code)"}
