@@ -5,10 +5,7 @@ cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 rm -rf gpurun_out/prof_vmem; mkdir -p gpurun_out/prof_vmem
 rocprofv3 --list-avail > gpurun_out/prof_vmem/avail.txt 2>&1
 run() { d=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/prof_vmem/$d -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > gpurun_out/prof_vmem/$d.log 2>&1 || echo "pass $d failed"; }
-run a TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum
-run b TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_UTCL1_SERIALIZATION_STALL_sum
-run c TCP_UTCL1_STALL_LFIFO_NO_RES_sum TCP_UTCL1_THRASHING_STALL_sum TCP_UTCL1_PERMISSION_MISS_sum GRBM_GUI_ACTIVE
-run d TCP_CLIENT_UTCL1_INFLIGHT_sum TCP_UTCL1_LFIFO_FULL_sum TCP_TOTAL_WRITE_sum TCP_TOTAL_READ_sum
+run a TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum
 python3 - <<'PY'
 import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
