@@ -94,23 +94,9 @@ __device__ __forceinline__ XRec x_empty_rec() {
     R.w0 = R.w1 = R.w2 = R.w3 = 0.0;
     return R;
 }
-// TLC_X_DEP: the second and later 16-byte loads of ONE cache line are issued only when the first has come back (a made-up
-// dependence of their address on its value).  Asked for together, the later ones find the line "pending" in the L1, which then
-// stalls -- for every wavefront of the CU -- until the line is there (TCP_PENDING_STALL_CYCLES: 0.55 of the kernel's cycles).
-#ifndef TLC_X_DEP
-#define TLC_X_DEP 1
-#endif
-template <typename P, typename V>
-__device__ __forceinline__ void x_after(P*& ptr, V first) {
-#if TLC_X_DEP
-    asm volatile("" : "+v"(ptr) : "v"(first));
-#endif
-}
 __device__ __forceinline__ XRec x_load_rec(const TlcNodeRec* r) {
     XRec R;
-    const TlcI4 h = *reinterpret_cast<const TlcI4*>(r);
-    x_after(r, h.v[0]);
-    const TlcI4 c = *reinterpret_cast<const TlcI4*>(&r->col[0]);
+    const TlcI4 h = *reinterpret_cast<const TlcI4*>(r), c = *reinterpret_cast<const TlcI4*>(&r->col[0]);
     const TlcD2 wa = *reinterpret_cast<const TlcD2*>(&r->w[0]), wb = *reinterpret_cast<const TlcD2*>(&r->w[2]);
     R.rb = h.v[0]; R.deg = h.v[1]; R.hidx = h.v[2]; R.n_in = h.v[3];
     R.c0 = c.v[0]; R.c1 = c.v[1]; R.c2 = c.v[2]; R.c3 = c.v[3];
@@ -287,25 +273,8 @@ __device__ __forceinline__ int x_sweep_wave(const PB& p, const int* ids, int n, 
                 double ww[8];
                 unsigned hit = 0u, rev = 0u;
                 if (have) {
-                    {
-                        const int* cp = p.col + j0;
-                        const TlcI4 a = *reinterpret_cast<const TlcI4*>(cp);
-                        x_after(cp, a.v[0]);
-                        const TlcI4 b4 = *reinterpret_cast<const TlcI4*>(cp + 4);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { bb[q] = a.v[q]; bb[4 + q] = b4.v[q]; }
-                    }
-                    if (WR) {
-                        const double* wp = p.w + j0;
-                        const TlcD2 d0 = *reinterpret_cast<const TlcD2*>(wp);
-                        x_after(wp, d0.v[0]);
-                        ww[0] = d0.v[0]; ww[1] = d0.v[1];
-#pragma unroll
-                        for (int q = 1; q < 4; ++q) {
-                            const TlcD2 d = *reinterpret_cast<const TlcD2*>(wp + 2 * q);
-                            ww[2 * q] = d.v[0]; ww[2 * q + 1] = d.v[1];
-                        }
-                    }
+                    load_row8(p.col, j0, bb);
+                    if (WR) load_row8w(p.w, j0, ww);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         ly[q] = 0;
