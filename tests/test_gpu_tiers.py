@@ -201,7 +201,7 @@ def test_large_tier_split_into_compact_and_wide_kernels(n, m, n_pairs):
     g.close()
 
 
-@pytest.mark.parametrize("n,k_pos", [(301, 319), (301, 320), (301, 400), (83, 600), (450, 560)])
+@pytest.mark.parametrize("n,k_pos", [(301, 319), (301, 320), (301, 400), (83, 600), (450, 560), (100, 350), (150, 330)])
 def test_divide_and_conquer_of_the_wide_medium_configuration(n, k_pos):
     """MEDIUM-sized vicinities with hundreds of Pos edges (the dense hop-1 vicinities of the Amazon shapes: 83 nodes / 680 edges)
     sit in the 512 / 1 024 configuration for their edge count; from TLC_DC_MIN_POS_SHARED = 320 Pos edges the scan counts them and
@@ -236,6 +236,9 @@ def test_divide_and_conquer_of_the_wide_medium_configuration(n, k_pos):
     torch.cuda.synchronize()
     for k in range(3):
         assert np.array_equal(sts[k].cpu().numpy(), ref_st) and np.abs(outs[k].cpu().numpy() - ref_out).max() <= 1e-12 * np.abs(ref_out).max()
+        # (100, 350), (150, 330): small enough for the compact kernels, which do not mark -- routed to the wide ones by their Pos edges,
+        # alone and pipelined alike: the same row, bit for bit
+        assert np.array_equal(outs[k].cpu().numpy(), out), np.abs(outs[k].cpu().numpy() - out).max()
     g.close()
 
 

@@ -148,7 +148,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
                 // the MEDIUM-sized vicinities: those within the compact configuration -> MEDIUM; the rest -> MEDWIDE.  With the split
                 // by Pos edges on (a chunk on its own: mh_min_pos < INT_MAX) the ones with many Pos edges AND the wide ones are one
                 // list, MEDHI: the longest chains of these tiers, launched first (speculatively) with the wide kernels
-                const bool wide = n > TLC_C_NMAX || m > TLC_C_MMAX;
+                // (a vicinity with Pos edges enough for the divide and conquer is "wide" whatever its size: only the wide kernels mark
+                // for it, and marking fixes the order of tied descending keys -- a row must not depend on whether its chunk was alone,
+                // where the many-Pos list takes it with the wide kernels, or pipelined)
+                const bool wide = n > TLC_C_NMAX || m > TLC_C_MMAX || m - n + 1 >= TLC_DC_MIN_POS_SHARED;
                 const bool split = p.mh_min_pos != 0x7fffffff;
                 if (split && (wide || m - n + 1 >= p.mh_min_pos)) tier = TLC_TIER_MEDHI;
                 else tier = wide ? TLC_TIER_MEDWIDE : TLC_TIER_MEDIUM;
