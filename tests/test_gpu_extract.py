@@ -335,3 +335,36 @@ def test_async_batches_of_alternating_hop_rebuild_the_ball_lists_behind_the_pend
     ref_tot = (want[0][0].sum() + want[2][0].sum() + want[1][0].sum()).item()
     assert abs(tot - ref_tot) <= 1e-9 * abs(ref_tot)
     g.close()
+
+
+@pytest.mark.parametrize("N", [400_000, 1_000_000])
+def test_graphs_of_several_hundred_thousand_nodes(N):
+    """The vicinity kernels keep bitmaps of N bits in LDS.  400 000 nodes: the extraction asks for more than 64 KB per workgroup
+    (80 KB: the opt-in for large dynamic LDS) and its rows are the oracle's.  A million nodes do not fit the 160 KB of a CU:
+    tlc_graph_create says so (TLC_ERR_UNSUPPORTED) instead of a failed launch later."""
+    import torch
+    from tlc_gnn_amd import engine, synth, _lib
+    from oracle import oracle
+    i = np.arange(N - 1, dtype=np.int64)
+    ring = np.stack([i, i + 1], 1)
+    j = np.arange(0, N - 7, 3, dtype=np.int64)
+    chords = np.stack([j, j + 7], 1)
+    e = np.concatenate([ring, chords])
+    rs = np.random.RandomState(5)
+    rowptr, col, w = synth.edges_to_csr(N, e, rs.uniform(-0.5, 0.9, size=len(e)))
+    if N > 500_000:
+        with pytest.raises(_lib.TlcError, match="UNSUPPORTED"):
+            engine.DeviceGraph(rowptr, col, w)
+        return
+    g = engine.DeviceGraph(rowptr, col, w)
+    pairs = e[rs.permutation(len(e))[:96]].astype(np.int32)
+    pairs = np.concatenate([pairs, [[0, 1], [N - 2, N - 1], [5, 5], [10, N // 2]]]).astype(np.int32)
+    for hop in (2, 1):
+        out, st = g.pd_pi_batch(torch.as_tensor(pairs).cuda(), hop)
+        out, st = out.cpu().numpy(), st.cpu().numpy()
+        ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, hop, n_threads=0)
+        assert np.array_equal(st, rst)
+        assert np.array_equal(out == 0, ref == 0)
+        nz = ref != 0
+        assert rel_err(out[nz], ref[nz]).max() < 1e-8
+    g.close()

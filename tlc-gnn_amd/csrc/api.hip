@@ -790,7 +790,8 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     // id / f / edge outputs of tlc_vicinity_filtration and with TLC_INCLUDE_ROOTS, the PDGNN fork's vicinities -- the breadth-first
     // COUNT pays two bitmaps of N bits per pair whatever the vicinity's size: 0.18 - 0.25 ms of a 0.37 ms call on 4 096 Amazon-shaped
     // pairs at hop 1.)
-    bool use_x = hop <= 2 && g->opt_extract;
+    // (its member bitmap of N bits lives in LDS: a graph beyond ~1 M nodes keeps the breadth-first kernels, whose bitmaps are in HBM)
+    bool use_x = hop <= 2 && g->opt_extract && g->x_lds512 <= (size_t)160 * 1024 && g->x_lds64 <= (size_t)160 * 1024;
     if (use_x) {
         if ((rc = ensure_ball_lists(g, hop, s)) != TLC_OK) return rc;
         use_x = g->ball_list_hop == hop;
