@@ -219,6 +219,7 @@ struct tlc_graph {
     int opt_defer;                      // a pipelined chunk's second half is submitted behind the NEXT chunk's first half (default 1)
     int opt_gate_ticks;                 // development: bound of the residency gate of pipelined chunks (-1: the default 50 us)
     int opt_mh_always;                  // tests: split the MEDIUM tier by Pos-edge count in pipelined chunks too
+    int opt_split_launch;               // the tier kernels of all lists are submitted before their second kernels (1)
     int opt_spec_cap;                   // tests: upper bound of the slots reserved for the speculative launches (0 = none)
     int opt_timing_every;               // measurement: kernel events on every n-th chunk only
     unsigned timing_seq;
@@ -553,7 +554,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     // one batch alone and a loss for pipelined batches -- see the note at `xlane` in run_chunk_front and DESIGN.md)
     { const char* v = getenv("TLC_XL_CUT"); g->opt_xl_cut = v ? std::min(std::max(atoi(v), 0), TLC_XL_MAXCUT) : 0; }
     g->opt_xl_ncut = TLC_T_NCUT; g->opt_xl_mcut = TLC_T_MCUT;
-    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_large_split = 0; g->opt_early_wait = 1; g->opt_tiny_sort = 1; g->opt_medium_first = -1; g->opt_dcm = 1; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
+    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_large_split = 0; g->opt_early_wait = 1; g->opt_tiny_sort = 1; g->opt_medium_first = -1; g->opt_dcm = 1; g->opt_split_launch = 1; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
@@ -1209,6 +1210,24 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
             if (((g->opt_tier_mask >> t) & 1) && (rc = tlc_launch_pd_tier(t, pp, s)) != TLC_OK) return rc;
             pp.wi_base = 0; pp.grid = 0; pp.phase = 0; pp.handoff = nullptr; pp.handoff_cap = 0;
         }
+        // The tier kernels of all lists first, their second kernels (cycle swap / divide and conquer, same stream, behind a tier kernel
+        // that runs > 100 us) afterwards: a launch costs the host 3 - 4 us, and with both kernels of a tier submitted together the last
+        // list's tier kernel started 84 us after the scan had ended (profiles/r04_bench_timeline.txt).  Option split_launch, default on.
+        struct PendingSwap { bool on; int t; bool timed; TlcPdParams pp; };
+        PendingSwap pend[TLC_N_SIDE];
+        for (int k = 0; k < TLC_N_SIDE; ++k) pend[k].on = false;
+        auto finish_pending_swaps = [&]() -> int {
+            for (int k = 0; k < TLC_N_SIDE; ++k) {
+                if (!pend[k].on) continue;
+                pend[k].on = false;
+                const int t = pend[k].t;
+                int r = ((g->opt_tier_mask >> t) & 1) ? tlc_launch_pd_tier(t, pend[k].pp, ws->side[k]) : TLC_OK;
+                if (r != TLC_OK) return r;
+                if (pend[k].timed) T1(tslot[t], ws->side[k]);
+                TLC_HIP_CHECK(hipEventRecord(ws->ev_join[k], ws->side[k]));
+            }
+            return TLC_OK;
+        };
         // (`behind_s`: the launch depends on what was just submitted to s, e.g. a FILL; else only on the scan)
         auto launch_side = [&](int k, int t, bool behind_s = true) -> int {
             if (bumped && !behind_s) {
@@ -1243,11 +1262,19 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
             const bool timed = !(early && t == TLC_TIER_LARGE) && !(t == TLC_TIER_MEDIUM && spec) && t != TLC_TIER_MEDWIDE;   // (those slots time the early launch / MEDHI / MEDIUM)
             if (timed) T0(tslot[t], ws->side[k]);
+            const bool two = g->opt_split_launch && hs && !(pp.flags & TLC_NO_EXT1) &&
+                             (t == TLC_TIER_MEDIUM || t == TLC_TIER_MID || t == TLC_TIER_MEDHI || t == TLC_TIER_MEDWIDE);
+            if (two) pp.phase = 1;                                                                      // (the tier kernel only)
             int r = ((g->opt_tier_mask >> t) & 1) ? tlc_launch_pd_tier(t, pp, ws->side[k]) : TLC_OK;   // (development: tiers timed alone)
+            pp.phase = 0;
             if (r != TLC_OK) return r;
+            used[k] = true;
+            if (two) {
+                pend[k].on = true; pend[k].t = t; pend[k].timed = timed; pend[k].pp = pp; pend[k].pp.phase = 2;
+                return TLC_OK;
+            }
             if (timed) T1(tslot[t], ws->side[k]);
             TLC_HIP_CHECK(hipEventRecord(ws->ev_join[k], ws->side[k]));
-            used[k] = true;
             return TLC_OK;
         };
         // 1. the heavy tiers first: their subgraphs are filled by a small early pass (8 wavefronts per pair) so that the
@@ -1340,6 +1367,7 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
             if ((rc = launch_tiny_small()) != TLC_OK) return rc;
             if ((rc = launch_medium_mid()) != TLC_OK) return rc;
         }
+        if ((rc = finish_pending_swaps()) != TLC_OK) return rc;
     }
     for (int k = 0; k < TLC_N_SIDE; ++k)
         if (used[k]) TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_join[k], 0));
@@ -1700,6 +1728,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "tiny")) g->opt_tiny = value != 0;
     else if (!strcmp(name, "tier_mask")) g->opt_tier_mask = value;
     else if (!strcmp(name, "spec_cap")) g->opt_spec_cap = std::max(value, 0);
+    else if (!strcmp(name, "split_launch")) g->opt_split_launch = value != 0;
     else if (!strcmp(name, "mh_always")) g->opt_mh_always = value != 0;
     else if (!strcmp(name, "gate_ticks")) g->opt_gate_ticks = value;
     else if (!strcmp(name, "medium_first")) g->opt_medium_first = value;
