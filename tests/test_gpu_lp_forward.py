@@ -369,6 +369,30 @@ def test_decode_generic_dims(setup):
     assert ok, worst
 
 
+def test_decode_float32_table_equals_float64_table(setup):
+    """tlc_lp_decode_fused_f32 on an image table cast once (Net._tables; the reference's `torch.Tensor(PI)` of TLCGNN.py:52-53
+    hoisted out of the decode) gives the bits of tlc_lp_decode_fused on the float64 table, for pair counts around the sixteen-pair
+    tiles of the MFMA kernel and for the generic dimensions; both within the bar of the restatement."""
+    torch = setup[0]
+    from tlc_gnn_amd import ops
+    from oracle import lp_forward_ref as ref
+    g = torch.Generator().manual_seed(3)
+    for n, D, P, E in ((300, 16, 25, 1), (300, 16, 25, 15), (300, 16, 25, 16), (300, 16, 25, 17), (300, 16, 25, 70001), (40, 8, 9, 100)):
+        emb = torch.randn(n, D, generator=g) * 0.3
+        pairs = torch.randint(0, n, (E, 2), generator=g)
+        pi = torch.rand(E, P, generator=g, dtype=torch.float64) * 3.0
+        w1, b1 = torch.randn(P, D + P, generator=g) * 0.3, torch.randn(P, generator=g) * 0.1
+        w2, b2 = torch.randn(1, P, generator=g) * 0.3, torch.randn(1, generator=g) * 0.1
+        emb_d = ops.renorm_rows_(emb.cuda())
+        args = (w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+        o64 = ops.lp_decode(pairs.int().cuda(), emb_d, pi.cuda(), *args)
+        o32 = ops.lp_decode(pairs.int().cuda(), emb_d, pi.cuda().float(), *args)
+        assert torch.equal(o64, o32), (E, float((o64 - o32).abs().max()))
+        r = ref.tlcgnn_decode(emb.clone(), pairs, pi, w1, b1, w2, b2)
+        ok, worst = _close(o32, r)
+        assert ok, (E, worst)
+
+
 def test_spmm_hub_rows_and_clustered_hubs(setup):
     """Rows longer than the per-group limit (32) go through the cooperative hub path; one row is longer than its 2048-entry
     staging chunk; hubs have neighbouring ids (they must not serialise in one workgroup); k covers every lane-group width."""
@@ -421,8 +445,10 @@ def test_spmm_fused_renorm_equals_separate_pass(setup):
 
 
 def test_gcn2_encode_one_call_equals_the_four_calls(setup):
-    """tlc_gcn2_encode_f32 (Net.encode in eval mode behind one library call, TLCGNN.py:19-26,48) submits the same four kernels
-    as gemm / spmm / gemm / spmm: identical bits, with and without the fused renorm_, for sizes whose scratch blocks need padding."""
+    """tlc_gcn2_encode_f32 (Net.encode in eval mode behind one library call, TLCGNN.py:19-26,48) against gemm / spmm / gemm / spmm,
+    with and without the fused renorm_, for sizes whose scratch blocks need padding: identical bits where it submits the same four
+    kernels; for out_dim == 16 (round 5: conv2's projection runs in the epilogue of conv1's aggregate, fp32 sums in another
+    order) within 1e-5 relative + 1e-6."""
     torch = setup[0]
     from tlc_gnn_amd import ops
     rs = np.random.RandomState(21)
@@ -443,7 +469,10 @@ def test_gcn2_encode_one_call_equals_the_four_calls(setup):
             want = ops.spmm(rp, c, v, ops.gemm(h, w2), bias=b2, relu=True, renorm=renorm)
             got = ops.gcn2_encode(rp, c, v, x, w1, b1, w2, b2, relu=True, renorm=renorm)
             torch.cuda.synchronize()
-            assert torch.equal(got, want), (n, f_in, hidden, d, renorm, float((got - want).abs().max()))
+            if d == 16 and hidden % 4 == 0:
+                assert bool(((got - want).abs() <= 1e-5 * want.abs() + 1e-6).all()), (n, f_in, hidden, d, renorm, float((got - want).abs().max()))
+            else:
+                assert torch.equal(got, want), (n, f_in, hidden, d, renorm, float((got - want).abs().max()))
 
 
 def test_hip_graph_replay_equals_eager_forward(setup):

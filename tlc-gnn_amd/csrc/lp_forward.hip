@@ -786,6 +786,212 @@ __global__ __launch_bounds__(256) void spmm_csr_v4_kernel(int n_rows, const int*
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Round 5: the same aggregate for k == 16 (the second GCN layer: 64-byte rows) with SIXTEEN lanes per row -- four entry slots x
+// four 16-byte column lanes -- four rows per wavefront, no LDS and no barrier.  (spmm_csr_v4_kernel<4> gave a row four lanes:
+// 308 workgroups for PubMed's 19 717 rows = 1.2 wavefronts per SIMD, every row's entries staged through LDS behind a barrier and
+// every hub row walked by its whole workgroup, one after the other: 10.4 us for 8.7 MB, 0.10 of HBM.)  A lane loads the indices
+// and values of its slot's entries itself (the four column lanes of a slot read the same words: one request) and has eight
+// gathers in flight; rows above 64 entries are taken by the whole wavefront afterwards (sixteen slots: 128 entries per round
+// trip).  The sums are folded over the slots in a fixed order, so the result depends on the row alone.
+// ----------------------------------------------------------------------------------------------------------------------
+#define SPMM16_WAVE_ROW 64
+template <int J>
+__device__ __forceinline__ float lane_xor_f32(float v) { return __builtin_bit_cast(float, tlc_lane_xor_u32<J>(__builtin_bit_cast(unsigned, v))); }
+template <int J>
+__device__ __forceinline__ float4 fold4(float4 a) {                   // a += the value of lane ^ J (vector-ALU lane exchanges, no LDS crossbar)
+    a.x += lane_xor_f32<J>(a.x); a.y += lane_xor_f32<J>(a.y); a.z += lane_xor_f32<J>(a.z); a.w += lane_xor_f32<J>(a.w);
+    return a;
+}
+__global__ __launch_bounds__(256) void spmm16_kernel(int n_rows, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                     const float* __restrict__ val, const float* __restrict__ X,
+                                                     const float* __restrict__ bias, int relu, float* __restrict__ Y) {
+    const int tid = threadIdx.x, lane = tid & 63, cl = lane & 3, c = cl * 4;
+    const int row = (tid >> 4) * gridDim.x + blockIdx.x;                 // rows dealt round-robin (hubs with neighbouring ids spread out)
+    int b = 0, d = 0;
+    if (row < n_rows) { b = rowptr[row]; d = rowptr[row + 1] - b; }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // entries j0 + slot, + nslot, ... of row segment [rb, rb + rd): eight gathers in flight, tail predicated
+    auto gather = [&](float4 acc, int rb, int rd, int slot, int nslot) {
+        for (int j = slot; j < rd; j += 8 * nslot) {
+            int cj[8];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int jj = j + u * nslot;
+                const bool ok = jj < rd;
+                cj[u] = col[rb + (ok ? jj : j)];
+                v[u] = ok ? val[rb + jj] : 0.0f;
+            }
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(X + (size_t)cj[u] * 16 + c);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u] * x[u].x; acc.y += v[u] * x[u].y; acc.z += v[u] * x[u].z; acc.w += v[u] * x[u].w; }
+        }
+        return acc;
+    };
+    // bias, ReLU (relu & 1), emb.renorm_(2, 0, 1) (relu & 2; TLCGNN.py:48): the four column lanes hold the row
+    auto finish = [&](float4 acc, int r, bool store) {
+        if (bias) { acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3]; }
+        if (relu & 1) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        if (relu & 2) {
+            float ss = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+            ss += __builtin_bit_cast(float, tlc_lane_xor_u32<1>(__builtin_bit_cast(unsigned, ss)));
+            ss += __builtin_bit_cast(float, tlc_lane_xor_u32<2>(__builtin_bit_cast(unsigned, ss)));
+            const float nrm = sqrtf(ss);
+            if (nrm > 1.0f) {
+                const float sc = 1.0f / (nrm + 1e-7f);
+                acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
+            }
+        }
+        if (store) *reinterpret_cast<float4*>(Y + (size_t)r * 16 + c) = acc;
+    };
+    const bool wide = d > SPMM16_WAVE_ROW;
+    {
+        float4 acc = gather(zero4, b, wide ? 0 : d, (lane >> 2) & 3, 4);
+        acc = fold4<8>(fold4<4>(acc));
+        finish(acc, row, row < n_rows && !wide && (lane & 12) == 0);
+    }
+    if (__ballot(wide)) {                                            // (rare: a wavefront that owns a hub row)
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            const int dq = __builtin_amdgcn_readlane(d, q * 16);
+            if (dq <= SPMM16_WAVE_ROW) continue;                         // (uniform)
+            const int bq = __builtin_amdgcn_readlane(b, q * 16), rq = __builtin_amdgcn_readlane(row, q * 16);
+            float4 acc = gather(zero4, bq, dq, lane >> 2, 16);
+            acc = fold4<32>(fold4<16>(fold4<8>(fold4<4>(acc))));
+            finish(acc, rq, lane < 4);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Round 5: the first GCN layer's aggregate with the second layer's projection in its epilogue (TLCGNN.py:22-25:
+// conv2's  x @ W  applied to  relu(conv1(x))  row by row):  Y2[i, :] = relu(sum_j val[j] X[col[j], :] + bias) @ W2,  W2 [k, 16].
+// The gather is spmm_csr_v4_kernel<32>'s (32 lanes per row, four columns per lane); the 100-wide activation row never leaves the
+// registers: lane gl multiplies its four values with rows 4 gl .. of W2 (in LDS, lane stride 68 words: conflict-free 16-byte
+// reads) into sixteen partial outputs, and a halving butterfly over the 32 lanes (8 + 4 + 2 + 1 + 1 exchanges instead of 16 x 5)
+// leaves output o on the lane whose low four bits are o reversed.  Saves the separate 19 717 x 100 x 16 product's launch and the
+// 15.8 MB that the activation matrix cost to write and read back.
+// ----------------------------------------------------------------------------------------------------------------------
+#define SPMM_W2_CAP 512
+__global__ __launch_bounds__(256) void spmm_w2_kernel(int n_rows, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                      const float* __restrict__ val, const float* __restrict__ X, int k,
+                                                      const float* __restrict__ bias, const float* __restrict__ W2, float* __restrict__ Y2) {
+    constexpr int G = 32, NG = 256 / G, WS = 68;
+    __shared__ int s_col[NG * SPMM_HUB];
+    __shared__ float s_val[NG * SPMM_HUB];
+    __shared__ int h_col[SPMM_W2_CAP];
+    __shared__ float h_val[SPMM_W2_CAP];
+    __shared__ int hub_flag[NG];                         // the group's row if it is a hub row, else -1
+    __shared__ float4 part[NG][G];
+    __shared__ __attribute__((aligned(16))) float s_w2[G * WS];
+    const int tid = threadIdx.x, grp = tid / G, gl = tid % G;
+    const int row = grp * gridDim.x + blockIdx.x;
+    const int c = gl * 4;
+    const bool lane_ok = c < k;
+    // one barrier in the common case: row bounds -> the row's entries into LDS, W2 into LDS beside them (its loads depend on
+    // nothing and are in flight with the row bounds), hub rows flagged per group
+    int b = 0, e = 0;
+    if (row < n_rows) { b = rowptr[row]; e = rowptr[row + 1]; }
+    float wreg[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                                        // W2 rows 4 gl + a -> s_w2[gl][a][0..16); rows >= k: zeros
+        const int i = tid + q * 256, r = i >> 4;
+        wreg[q] = r < k ? W2[i] : 0.0f;
+    }
+    const int d = e - b;
+    const bool hub = d > SPMM_HUB;
+    if (gl == 0) hub_flag[grp] = hub ? row : -1;
+    if (!hub)
+        for (int i = gl; i < d; i += G) { s_col[grp * SPMM_HUB + i] = col[b + i]; s_val[grp * SPMM_HUB + i] = val[b + i]; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = tid + q * 256, r = i >> 4, o = i & 15;
+        s_w2[(r >> 2) * WS + (r & 3) * 16 + o] = wreg[q];
+    }
+    __syncthreads();
+    auto gather = [&](float4 acc, const int* sc, const float* sv, int j0, int j1, int step) {
+        for (int j = j0; j < j1; j += 8 * step) {
+            float4 x[8];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int jj = j + u * step;
+                const bool ok = jj < j1;
+                const int js = ok ? jj : j;
+                v[u] = ok ? sv[js] : 0.0f;
+                x[u] = *reinterpret_cast<const float4*>(X + (size_t)sc[js] * k + c);
+                if (!ok) x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u] * x[u].x; acc.y += v[u] * x[u].y; acc.z += v[u] * x[u].z; acc.w += v[u] * x[u].w; }
+        }
+        return acc;
+    };
+    // called by all 32 lanes of a group (lanes past k carry zeros): bias + ReLU, the row times W2, store by the low sixteen lanes
+    auto finish = [&](float4 acc, int r, bool store) {
+        if (lane_ok) {
+            if (bias) { acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3]; }
+            acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        } else {
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float hv[4] = {acc.x, acc.y, acc.z, acc.w};
+        float p[16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) p[o] = 0.0f;
+        const float* wr = s_w2 + gl * WS;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int o4 = 0; o4 < 4; ++o4) {
+                const float4 w = *reinterpret_cast<const float4*>(wr + a * 16 + o4 * 4);
+                p[o4 * 4] += hv[a] * w.x; p[o4 * 4 + 1] += hv[a] * w.y; p[o4 * 4 + 2] += hv[a] * w.z; p[o4 * 4 + 3] += hv[a] * w.w;
+            }
+        // halving butterfly: after the step with mask m a lane keeps the half of its outputs selected by its bit m
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const bool hi = gl & 1; const float snd = hi ? p[j] : p[j + 8], kp = hi ? p[j + 8] : p[j]; p[j] = kp + __builtin_bit_cast(float, tlc_lane_xor_u32<1>(__builtin_bit_cast(unsigned, snd))); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const bool hi = gl & 2; const float snd = hi ? p[j] : p[j + 4], kp = hi ? p[j + 4] : p[j]; p[j] = kp + __builtin_bit_cast(float, tlc_lane_xor_u32<2>(__builtin_bit_cast(unsigned, snd))); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const bool hi = gl & 4; const float snd = hi ? p[j] : p[j + 2], kp = hi ? p[j + 2] : p[j]; p[j] = kp + __builtin_bit_cast(float, tlc_lane_xor_u32<4>(__builtin_bit_cast(unsigned, snd))); }
+        { const bool hi = gl & 8; const float snd = hi ? p[0] : p[1], kp = hi ? p[1] : p[0]; p[0] = kp + __builtin_bit_cast(float, tlc_lane_xor_u32<8>(__builtin_bit_cast(unsigned, snd))); }
+        p[0] += __builtin_bit_cast(float, tlc_lane_xor_u32<16>(__builtin_bit_cast(unsigned, p[0])));
+        const int o = ((gl & 1) << 3) | ((gl & 2) << 1) | ((gl & 4) >> 1) | ((gl & 8) >> 3);
+        if (store && gl < 16) Y2[(size_t)r * 16 + o] = p[0];
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const bool mine = row < n_rows && !hub;             // (uniform over the group)
+        float4 acc = zero4;
+        if (mine && lane_ok) acc = gather(zero4, s_col + grp * SPMM_HUB, s_val + grp * SPMM_HUB, 0, d, 1);
+        finish(acc, row, mine);                             // (every lane takes part in the exchanges)
+    }
+    for (int h = 0; h < NG; ++h) {
+        const int r = hub_flag[h];
+        if (r < 0) continue;                                // (uniform over the workgroup)
+        const int hb = rowptr[r], he = rowptr[r + 1];
+        float4 acc = zero4;
+        for (int cb = hb; cb < he; cb += SPMM_W2_CAP) {
+            const int cn = min(SPMM_W2_CAP, he - cb);
+            __syncthreads();
+            for (int i = tid; i < cn; i += 256) { h_col[i] = col[cb + i]; h_val[i] = val[cb + i]; }
+            __syncthreads();
+            if (lane_ok) acc = gather(acc, h_col, h_val, grp, cn, NG);
+        }
+        part[grp][gl] = acc;
+        __syncthreads();
+        if (grp == 0) {                                     // (a whole wavefront half: uniform for the exchanges of its 32 lanes)
+            float4 t = part[0][gl];
+#pragma unroll
+            for (int q = 1; q < NG; ++q) { const float4 pq = part[q][gl]; t.x += pq.x; t.y += pq.y; t.z += pq.z; t.w += pq.w; }
+            finish(t, r, true);
+        }
+    }
+}
+
 // scalar fallback (k not a multiple of 4): G lanes per row, one column per lane and pass
 template <int G>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(int n_rows, const int* __restrict__ rowptr, const int* __restrict__ col,
@@ -826,76 +1032,114 @@ __global__ void renorm_rows_kernel(int n_rows, int k, float* __restrict__ emb) {
     }
 }
 
-// Net.decode after the renorm (baselines/TLCGNN.py:52-61), emb 16 / image 25, eight lanes per pair: one lane per pair leaves one wavefront per SIMD and every one of its
-// 25 x 41 multiply-adds waits on a scalar weight load.  Here a workgroup stages W1 (rows padded to 44), b1 and W2 in LDS once,
-// the eight lanes of a pair load its 41 inputs together (each input once) and share them through LDS, lane g computes the
-// hidden units g, g+8, g+16 (and 24 for g = 0) in the reference's accumulation order, and the eight partial sums of W2 . h are
-// folded with DPP row shifts.  Nine wavefronts per SIMD instead of one.
-__global__ __launch_bounds__(256) void lp_decode8_kernel(long long n_pairs, const int* __restrict__ pairs, const float* __restrict__ emb,
-                                                         const double* __restrict__ pi, const float* __restrict__ W1,
-                                                         const float* __restrict__ b1, const float* __restrict__ W2,
-                                                         const float* __restrict__ b2, float* __restrict__ prob) {
-    constexpr int ED = 16, PD = 25, IN = ED + PD, INP = 44;
-    __shared__ __attribute__((aligned(16))) float s_w1[PD * INP];
-    __shared__ float s_b1[PD + 7], s_w2[PD + 7];
-    __shared__ __attribute__((aligned(16))) float s_in[32 * INP];
-    const int tid = threadIdx.x, g = tid & 7, pl = tid >> 3;           // lane in the pair's group, pair in the workgroup
-    for (int k = tid; k < PD * INP; k += 256) { const int o = k / INP, c = k - o * INP; s_w1[k] = c < IN ? W1[o * IN + c] : 0.0f; }
-    if (tid < PD + 7) { s_b1[tid] = tid < PD ? b1[tid] : 0.0f; s_w2[tid] = tid < PD ? W2[tid] : 0.0f; }
-    const long long i = (long long)blockIdx.x * 32 + pl;
-    const bool live = i < n_pairs;
-    float* in = s_in + pl * INP;
-    if (live) {
-        const int u = pairs[2 * i], v = pairs[2 * i + 1];
-        if (g < 4) {                                                  // (emb_in - emb_out).pow(2)  (:57): four columns per lane
-            const float4 a = *reinterpret_cast<const float4*>(emb + (size_t)u * ED + 4 * g);
-            const float4 b = *reinterpret_cast<const float4*>(emb + (size_t)v * ED + 4 * g);
-            float4 d;
-            d.x = (a.x - b.x) * (a.x - b.x); d.y = (a.y - b.y) * (a.y - b.y);
-            d.z = (a.z - b.z) * (a.z - b.z); d.w = (a.w - b.w) * (a.w - b.w);
-            *reinterpret_cast<float4*>(in + 4 * g) = d;
-        }
-        const double* pr = pi + (size_t)i * PD;
-        for (int c = g; c < PD; c += 8) in[ED + c] = (float)pr[c];    // torch.Tensor(PI): float64 -> float32 (:52-53)
-        if (g < INP - IN) in[IN + g] = 0.0f;
+// Net.decode after the renorm (baselines/TLCGNN.py:52-61), emb 16 / image 25, on the f32 MFMA (round 5; rounds 1-4: eight lanes per
+// pair with W1 staged in LDS by each of 2 355 workgroups behind a barrier, 15.9 us).  One LANE per pair, 64 pairs per wavefront:
+// the hidden layer is 41 rank-one updates  H[32 x 64] += W1[:, k] (x) X[k, :]  of v_mfma_f32_32x32x1_2b_f32 (two 32 x 32 blocks:
+// rows = hidden units, columns = the pairs of lanes 0..31 / 32..63).  A K = 1 instruction is one fused multiply-add per element, so
+// hidden unit o of a pair is accumulated as  b1[o], += W1[o][0] x[0], += W1[o][1] x[1], ...  -- the reference's (and the earlier
+// kernel's) order, bit for bit, which a K = 4 tile would not give (the G10 fixture holds image rows of 1e2..1e3 whose terms cancel:
+// another order moves the result by more than the 1e-5 bar).  Operands, with no LDS at all:
+//   * B operand k of lane l = input k of ITS pair: (emb[u] - emb[v])^2 from eight 16-byte gathers, the image row from 100
+//     contiguous bytes;
+//   * A operand k of lane l = W1[l % 32][k] (zero for rows >= 25), 41 registers loaded once per wavefront from the 4 KB matrix;
+//   * accumulators start at b1.  A block's 32 x 32 result is spread over the two half-wavefronts (rows 8 a + 4 half + b); sixteen
+//     v_permlane32_swap leave every lane with all 32 rows of its own pair; LeakyReLU, W2 . h in the earlier kernel's summation
+//     tree (eight strided partial sums folded 4, 2, 1), |.|, clamp, Fermi-Dirac, one coalesced 256-byte store per wavefront.
+// PT: the image table's type -- float when the caller cast it once at set-up (what the reference's torch.Tensor(PI) does on every
+// decode, :52-53), double for the raw output of tlc_pd_pi_batch.
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+template <typename PT>
+__global__ __launch_bounds__(256) void lp_decode_mfma_kernel(long long n_pairs, const int* __restrict__ pairs, const float* __restrict__ emb,
+                                                             const PT* __restrict__ pi, const float* __restrict__ W1,
+                                                             const float* __restrict__ b1, const float* __restrict__ W2,
+                                                             const float* __restrict__ b2, float* __restrict__ prob) {
+    constexpr int ED = 16, PD = 25, IN = ED + PD;
+    const int lane = threadIdx.x & 63, hrow = lane & 31, hf = lane >> 5;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long n_tiles = (n_pairs + 63) >> 6;
+    float a[IN];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) {
+        const float w = W1[(hrow < PD ? hrow : 0) * IN + k];
+        a[k] = hrow < PD ? w : 0.0f;
     }
-    __syncthreads();
-    float part = 0.0f;
-    if (live) {
-        float x[INP];
+    f32x32 acc0;                                                    // register v of the result: row 8 ((v % 16) / 4) + 4 half + v % 4 of block v / 16
 #pragma unroll
-        for (int c = 0; c < INP; c += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(in + c);
-            x[c] = t.x; x[c + 1] = t.y; x[c + 2] = t.z; x[c + 3] = t.w;
+    for (int v = 0; v < 32; ++v) {
+        const int o = 8 * ((v & 15) >> 2) + 4 * hf + (v & 3);
+        const float bv = b1[o < PD ? o : 0];
+        acc0[v] = o < PD ? bv : 0.0f;
+    }
+    const float bias2 = b2[0];
+    for (long long tile = wave; tile < n_tiles; tile += n_waves) {
+        const long long i = tile * 64 + lane;
+        const bool live = i < n_pairs;
+        const long long ic = live ? i : n_pairs - 1;              // (pairs past the end: computed on the last pair, not stored)
+        const int2 uv = *reinterpret_cast<const int2*>(pairs + 2 * ic);
+        const float4* eu = reinterpret_cast<const float4*>(emb + (size_t)uv.x * ED);
+        const float4* ev = reinterpret_cast<const float4*>(emb + (size_t)uv.y * ED);
+        const PT* pr = pi + (size_t)ic * PD;
+        float x[IN];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                              // (emb_in - emb_out).pow(2)  (:57)
+            const float4 ea = eu[q], eb = ev[q];
+            x[4 * q] = (ea.x - eb.x) * (ea.x - eb.x); x[4 * q + 1] = (ea.y - eb.y) * (ea.y - eb.y);
+            x[4 * q + 2] = (ea.z - eb.z) * (ea.z - eb.z); x[4 * q + 3] = (ea.w - eb.w) * (ea.w - eb.w);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int o = g + 8 * q;                                   // (o >= 25: zero weights, contributes 0)
-            if (o < PD) {
-                const float* wr = s_w1 + o * INP;
-                float h = s_b1[o];
+        for (int c = 0; c < PD; ++c) x[ED + c] = (float)pr[c];      // torch.Tensor(PI): float64 -> float32 (:52-53)
+        // every load of the tile is requested before the first MFMA (left alone the scheduler dealt the loads out between the
+        // MFMAs, eight exposed round trips in a row: 15 us)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x32 acc = acc0;
 #pragma unroll
-                for (int c = 0; c < IN; ++c) h += wr[c] * x[c];
-                h = h > 0.0f ? h : 0.2f * h;                          // LeakyReLU(0.2) (:58)
-                part += s_w2[o] * h;
+        for (int k = 0; k < IN; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x1f32(a[k], x[k], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // lower half keeps block 0 (its own pairs), upper half block 1: each sends the other half's rows across (one
+        // v_permlane32_swap per register pair; the two-operand form of the builtin was miscompiled by this toolchain -- every
+        // element read from acc[0] -- so the exchange goes through the one-operand helper and two selects)
+        float hr[32];                                              // (scalars: element inserts into the 32-wide vector copied all of it)
+#pragma unroll
+        for (int v = 0; v < 32; ++v) hr[v] = acc[v];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const float keep = hf ? hr[16 + w] : hr[w], send = hf ? hr[w] : hr[16 + w];
+            const float recv = lane_xor_f32<32>(send);
+            hr[w] = hf ? recv : keep;
+            hr[16 + w] = hf ? keep : recv;
+        }
+        // now hr[w], w < 16, is row 8 (w / 4) + w % 4 of the lane's own pair and hr[16 + w] row 8 (w / 4) + 4 + w % 4
+        float pg[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            float part = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = g + 8 * q;
+                if (o < PD) {
+                    float h = hr[(g < 4 ? 0 : 16) + 4 * q + (g & 3)];
+                    h = h > 0.0f ? h : 0.2f * h;                  // LeakyReLU(0.2) (:58)
+                    part += W2[o] * h;
+                }
             }
+            pg[g] = part;
         }
-    }
-    // fold the eight lanes of a group (row_shr 4, 2, 1 inside a DPP row of 16: groups are aligned to 8)
-    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x104, 0xF, 0xF, true));   // row_shl:4
-    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x102, 0xF, 0xF, true));   // row_shl:2
-    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x101, 0xF, 0xF, true));   // row_shl:1
-    if (live && g == 0) {
-        float d = b2[0] + part;
-        d = fabsf(d);                                                 // :59
-        d = d < 0.0f ? 0.0f : (d > 40.0f ? 40.0f : d);                // clamp (:60)
-        prob[i] = 1.0f / (expf((d - 2.0f) / 1.0f) + 1.0f);            // Fermi-Dirac (:61)
+        const float s40 = pg[0] + pg[4], s41 = pg[1] + pg[5], s42 = pg[2] + pg[6], s43 = pg[3] + pg[7];
+        const float s20 = s40 + s42, s21 = s41 + s43;
+        if (live) {
+            float d = bias2 + (s20 + s21);
+            d = fabsf(d);                                         // :59
+            d = d < 0.0f ? 0.0f : (d > 40.0f ? 40.0f : d);        // clamp (:60)
+            prob[i] = 1.0f / (expf((d - 2.0f) / 1.0f) + 1.0f);    // Fermi-Dirac (:61)
+        }
     }
 }
 
 // generic fallback for other dimensions: one thread per pair, everything from global
+template <typename PT>
 __global__ __launch_bounds__(256) void lp_decode_generic_kernel(long long n_pairs, const int* __restrict__ pairs,
-                                                                const float* __restrict__ emb, int ED, const double* __restrict__ pi,
+                                                                const float* __restrict__ emb, int ED, const PT* __restrict__ pi,
                                                                 int PD, const float* __restrict__ W1, const float* __restrict__ b1,
                                                                 const float* __restrict__ W2, const float* __restrict__ b2,
                                                                 float* __restrict__ prob) {
@@ -904,7 +1148,7 @@ __global__ __launch_bounds__(256) void lp_decode_generic_kernel(long long n_pair
     const int u = pairs[2 * i], v = pairs[2 * i + 1];
     const float* eu = emb + (size_t)u * ED;
     const float* ev = emb + (size_t)v * ED;
-    const double* pr = pi + (size_t)i * PD;
+    const PT* pr = pi + (size_t)i * PD;
     float d = b2[0];
     for (int o = 0; o < PD; ++o) {
         const float* wr = W1 + (size_t)o * (ED + PD);
@@ -1124,7 +1368,9 @@ extern "C" int tlc_spmm_csr_f32(int32_t n_rows, const int32_t* d_rowptr, const i
     TLC_REQUIRE(d_rowptr && d_col && d_val && d_X && d_Y, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (k % 4) == 0 && k <= 256 && ((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_Y)) & 15) == 0;
-    if (vec && k <= 16) {
+    if (vec && k == 16) {
+        hipLaunchKernelGGL(spmm16_kernel, dim3((unsigned)((n_rows + 15) / 16)), dim3(256), 0, s, n_rows, d_rowptr, d_col, d_val, d_X, d_bias, relu, d_Y);
+    } else if (vec && k <= 16) {
         hipLaunchKernelGGL(spmm_csr_v4_kernel<4>, dim3((unsigned)(((size_t)n_rows * 4 + 255) / 256)), dim3(256), 0, s, n_rows, d_rowptr, d_col, d_val, d_X, k, d_bias, relu, d_Y);
     } else if (vec && k <= 32) {
         hipLaunchKernelGGL(spmm_csr_v4_kernel<8>, dim3((unsigned)(((size_t)n_rows * 8 + 255) / 256)), dim3(256), 0, s, n_rows, d_rowptr, d_col, d_val, d_X, k, d_bias, relu, d_Y);
@@ -1157,9 +1403,11 @@ extern "C" int tlc_renorm_rows_f32(int32_t n_rows, int32_t k, float* d_emb, void
 }
 
 // The whole two-layer encoder of Net.encode in eval mode (baselines/TLCGNN.py:19-26: conv1 -> ReLU -> conv2, dropout off) behind
-// ONE call: four launches (x@W1, aggregate + b1 + ReLU, h@W2, aggregate + b2 with `flags` as in tlc_spmm_csr_f32: bit 0 ReLU,
-// bit 1 the renorm_ of TLCGNN.py:48) submitted back to back -- the same kernels as the separate calls, without five trips
-// through the caller's language between them (a Python host needs ~70 us to submit what the device runs in 79 us).
+// ONE call: x@W1, aggregate + b1 + ReLU, h@W2, aggregate + b2 with `flags` as in tlc_spmm_csr_f32 (bit 0 ReLU, bit 1 the renorm_ of
+// TLCGNN.py:48) submitted back to back, without five trips through the caller's language between them (a Python host needs ~70 us
+// to submit what the device runs in 79 us).  For out_dim == 16 (TLCGNN) the second and third step are ONE kernel (spmm_w2_kernel:
+// h@W2 in the aggregate's epilogue, fp32 sums in another order than the separate product's); otherwise the four kernels of the
+// separate calls.
 // d_ws: (2 * hidden + out_dim) * n floats (+ 12) of scratch.
 extern "C" int tlc_gcn2_encode_f32(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
                                    const float* d_x, int32_t f_in, const float* d_w1, const float* d_b1, int32_t hidden,
@@ -1174,24 +1422,49 @@ extern "C" int tlc_gcn2_encode_f32(int32_t n_nodes, const int32_t* d_rowptr, con
     float* t3 = t2 + pad4((size_t)n_nodes * hidden);
     int rc;
     if ((rc = tlc_gemm_f32(n_nodes, hidden, f_in, d_x, d_w1, nullptr, 0, t1, stream)) != TLC_OK) return rc;
-    if ((rc = tlc_spmm_csr_f32(n_nodes, d_rowptr, d_col, d_val, t1, hidden, d_b1, 1, t2, stream)) != TLC_OK) return rc;
-    if ((rc = tlc_gemm_f32(n_nodes, out_dim, hidden, t2, d_w2, nullptr, 0, t3, stream)) != TLC_OK) return rc;
+    if (out_dim == 16 && hidden % 4 == 0 && hidden <= 128 && (reinterpret_cast<uintptr_t>(t1) & 15) == 0) {
+        // conv2's projection in the epilogue of conv1's aggregate: three launches, the [n, hidden] activations stay in registers
+        hipLaunchKernelGGL(spmm_w2_kernel, dim3((unsigned)((n_nodes + 7) / 8)), dim3(256), 0, (hipStream_t)stream, n_nodes, d_rowptr, d_col, d_val,
+                           t1, hidden, d_b1, d_w2, t3);
+        TLC_HIP_CHECK(hipGetLastError());
+    } else {
+        if ((rc = tlc_spmm_csr_f32(n_nodes, d_rowptr, d_col, d_val, t1, hidden, d_b1, 1, t2, stream)) != TLC_OK) return rc;
+        if ((rc = tlc_gemm_f32(n_nodes, out_dim, hidden, t2, d_w2, nullptr, 0, t3, stream)) != TLC_OK) return rc;
+    }
     return tlc_spmm_csr_f32(n_nodes, d_rowptr, d_col, d_val, t3, out_dim, d_b2, flags, d_emb, stream);
+}
+
+template <typename PT>
+static int lp_decode_launch(int64_t n_pairs, const int32_t* d_pairs, const float* d_emb, int32_t emb_dim, const PT* d_pi,
+                            int32_t pi_dim, const float* d_W1, const float* d_b1, const float* d_W2, const float* d_b2,
+                            float* d_prob, void* stream) {
+    TLC_REQUIRE(n_pairs >= 0 && emb_dim > 0 && pi_dim > 0, "bad sizes");
+    if (n_pairs == 0) return TLC_OK;
+    TLC_REQUIRE(d_pairs && d_emb && d_pi && d_W1 && d_b1 && d_W2 && d_b2 && d_prob, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(d_emb) & 15) | (reinterpret_cast<uintptr_t>(d_pairs) & 7)) == 0;
+    if (emb_dim == 16 && pi_dim == 25 && aligned) {
+        const long long tiles = (n_pairs + 63) / 64;
+        long long blocks = (tiles + 3) / 4;                       // one 64-pair tile per wavefront up to eight workgroups per CU
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(lp_decode_mfma_kernel<PT>, dim3((unsigned)blocks), dim3(256), 0, s, (long long)n_pairs, d_pairs, d_emb, d_pi,
+                           d_W1, d_b1, d_W2, d_b2, d_prob);
+    } else {
+        hipLaunchKernelGGL(lp_decode_generic_kernel<PT>, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, (long long)n_pairs, d_pairs,
+                           d_emb, emb_dim, d_pi, pi_dim, d_W1, d_b1, d_W2, d_b2, d_prob);
+    }
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
 }
 
 extern "C" int tlc_lp_decode_fused(int64_t n_pairs, const int32_t* d_pairs, const float* d_emb, int32_t emb_dim, const double* d_pi,
                                    int32_t pi_dim, const float* d_W1, const float* d_b1, const float* d_W2, const float* d_b2,
                                    float* d_prob, void* stream) {
-    TLC_REQUIRE(n_pairs >= 0 && emb_dim > 0 && pi_dim > 0, "bad sizes");
-    if (n_pairs == 0) return TLC_OK;
-    TLC_REQUIRE(d_pairs && d_emb && d_pi && d_W1 && d_b1 && d_W2 && d_b2 && d_prob, "null pointer");
-    hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)((n_pairs + 255) / 256)), block(256);
-    if (emb_dim == 16 && pi_dim == 25)
-        hipLaunchKernelGGL(lp_decode8_kernel, dim3((unsigned)((n_pairs + 31) / 32)), block, 0, s, (long long)n_pairs, d_pairs, d_emb, d_pi,
-                           d_W1, d_b1, d_W2, d_b2, d_prob);
-    else
-        hipLaunchKernelGGL(lp_decode_generic_kernel, grid, block, 0, s, (long long)n_pairs, d_pairs, d_emb, emb_dim, d_pi, pi_dim, d_W1, d_b1, d_W2, d_b2, d_prob);
-    TLC_HIP_CHECK(hipGetLastError());
-    return TLC_OK;
+    return lp_decode_launch<double>(n_pairs, d_pairs, d_emb, emb_dim, d_pi, pi_dim, d_W1, d_b1, d_W2, d_b2, d_prob, stream);
+}
+
+extern "C" int tlc_lp_decode_fused_f32(int64_t n_pairs, const int32_t* d_pairs, const float* d_emb, int32_t emb_dim, const float* d_pi,
+                                       int32_t pi_dim, const float* d_W1, const float* d_b1, const float* d_W2, const float* d_b2,
+                                       float* d_prob, void* stream) {
+    return lp_decode_launch<float>(n_pairs, d_pairs, d_emb, emb_dim, d_pi, pi_dim, d_W1, d_b1, d_W2, d_b2, d_prob, stream);
 }

@@ -155,15 +155,18 @@ def renorm_rows_(emb):
 
 @_lib.on_device_of
 def lp_decode(pairs, emb, pi, w1, b1, w2, b2, out=None):
-    """Fused Net.decode tail (baselines/TLCGNN.py:52-61).  pairs int32 [E,2], emb f32 [N,D], pi f64 [E,P]."""
+    """Fused Net.decode tail (baselines/TLCGNN.py:52-61).  pairs int32 [E,2], emb f32 [N,D], pi [E,P] float64 (the raw output of
+    pd_pi_batch: cast to float32 on load) or float32 (cast once by the caller, as Net._tables does: the reference's
+    torch.Tensor(PI) of :52-53 hoisted out of the per-decode path; same values, half the bytes)."""
     torch = _lib.require_gpu()
-    assert pairs.dtype == torch.int32 and pi.dtype == torch.float64
+    assert pairs.dtype == torch.int32 and pi.dtype in (torch.float64, torch.float32)
     E = pairs.shape[0]
     if out is None:
         out = torch.empty(E, dtype=torch.float32, device=emb.device)
-    rc = _lib.lib().tlc_lp_decode_fused(C.c_int64(E), _lib.ptr(pairs.contiguous()), _lib.ptr(_f32(emb)), C.c_int32(emb.shape[1]),
-                                        _lib.ptr(pi.contiguous()), C.c_int32(pi.shape[1]), _lib.ptr(_f32(w1)), _lib.ptr(_f32(b1)),
-                                        _lib.ptr(_f32(w2).reshape(-1)), _lib.ptr(_f32(b2)), _lib.ptr(out), _lib.stream_ptr())
+    fn = _lib.lib().tlc_lp_decode_fused if pi.dtype == torch.float64 else _lib.lib().tlc_lp_decode_fused_f32
+    rc = fn(C.c_int64(E), _lib.ptr(pairs.contiguous()), _lib.ptr(_f32(emb)), C.c_int32(emb.shape[1]),
+            _lib.ptr(pi.contiguous()), C.c_int32(pi.shape[1]), _lib.ptr(_f32(w1)), _lib.ptr(_f32(b1)),
+            _lib.ptr(_f32(w2).reshape(-1)), _lib.ptr(_f32(b2)), _lib.ptr(out), _lib.stream_ptr())
     _lib.check(rc, "tlc_lp_decode_fused")
     return out
 
