@@ -191,6 +191,10 @@ struct tlc_graph {
     int ball_list_hop;             // 0: none yet; -1: lists do not fit (the breadth-first kernels are used)
     int* d_bptr;
     int* d_bcol;
+    int* d_be_ptr;                 // ball subgraphs (TlcVicParams::be_ptr ...); null: not built
+    unsigned short* d_be_pos;
+    double* d_be_w;
+    long long be_entries;
     long long* d_hptr;             // membership tables of the ball lists (extract_lane.hip); null: none (the lane-per-pair pass is off)
     int* d_htab;
     long long ball_entries;
@@ -201,6 +205,8 @@ struct tlc_graph {
     size_t x_lds64, x_lds512;
     // development / test switches (tlc_debug_set_option; initial values from the environment: TLC_EXTRACT, TLC_HEAVY, TLC_TINY)
     int opt_extract, opt_heavy, opt_tiny;
+    int opt_dc_inplace;            // LARGE tier: divide and conquer by the tier kernel's own workgroup (TlcPdParams::dc_inplace)
+    int opt_ball_edges;            // the extraction filters the smaller ball's subgraph list where there is one (extract.hip, x_sweep_ball)
     int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
     int opt_x_grid, opt_x_chunk_div;    // development: extraction workgroups / work-queue granularity (0: the defaults)
     int opt_chunk_pairs;                // development: pairs per chunk (0: TLC_CHUNK_PAIRS)
@@ -457,7 +463,9 @@ static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
         if (rq != TLC_OK) return rq;
     }
     hipFree(g->d_bptr); hipFree(g->d_bcol); hipFree(g->d_hptr); hipFree(g->d_htab);
+    hipFree(g->d_be_ptr); hipFree(g->d_be_pos); hipFree(g->d_be_w);
     g->d_bptr = g->d_bcol = g->d_htab = nullptr; g->d_hptr = nullptr; g->ball_list_hop = 0; g->ball_entries = 0;
+    g->d_be_ptr = nullptr; g->d_be_pos = nullptr; g->d_be_w = nullptr; g->be_entries = 0;
     const int n = g->n_nodes;
     int* d_size = nullptr;
     TLC_HIP_CHECK(hipMalloc(&d_size, (size_t)n * sizeof(int)));
@@ -480,6 +488,35 @@ static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
     if ((rc = tlc_launch_ball_list(true, n, g->nw, g->d_rowptr, g->d_col, hop, nullptr, g->d_bptr, g->d_bcol, grid, s)) != TLC_OK) return rc;
     TLC_HIP_CHECK(hipStreamSynchronize(s));                  // (sz is host memory of this frame)
     g->ball_list_hop = hop; g->ball_entries = tot;
+    // the ball subgraphs (nodes whose ball has at most TLC_BE_CAP members): count, prefix on the host, fill.  Built into locals and
+    // published on success only; without them the extraction sweeps the members' rows as before.
+    {
+        int* d_es = nullptr;
+        int* d_bp = nullptr;
+        unsigned short* d_pos = nullptr;
+        double* d_bw = nullptr;
+        std::vector<int> es((size_t)n + 1, 0);
+        bool ok = hipMalloc(&d_es, (size_t)n * sizeof(int)) == hipSuccess;
+        ok = ok && tlc_launch_ball_edges(false, n, g->nw, g->d_rowptr, g->d_col, g->d_w, g->d_bptr, g->d_bcol, d_es, nullptr, nullptr, nullptr, grid, s) == TLC_OK;
+        ok = ok && hipMemcpyAsync(es.data(), d_es, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess;
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+        long long et = 0;
+        if (ok) for (int x = 0; x < n; ++x) { const int c = es[x]; es[x] = (int)et; et += c; if (et > 0x7fffffffll) { ok = false; break; } }
+        if (ok) {
+            es[n] = (int)et;
+            size_t fb = 0, tb = 0;
+            ok = hipMemGetInfo(&fb, &tb) == hipSuccess && (size_t)et * 10 <= fb / 8;
+        }
+        ok = ok && hipMalloc(&d_bp, ((size_t)n + 1) * sizeof(int)) == hipSuccess;
+        ok = ok && hipMalloc(&d_pos, ((size_t)et + 64) * sizeof(unsigned short)) == hipSuccess;
+        ok = ok && hipMalloc(&d_bw, ((size_t)et + 64) * sizeof(double)) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d_bp, es.data(), ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && tlc_launch_ball_edges(true, n, g->nw, g->d_rowptr, g->d_col, g->d_w, g->d_bptr, g->d_bcol, nullptr, d_bp, d_pos, d_bw, grid, s) == TLC_OK;
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;                 // (es is host memory of this frame)
+        hipFree(d_es);
+        if (ok) { g->d_be_ptr = d_bp; g->d_be_pos = d_pos; g->d_be_w = d_bw; g->be_entries = et; }
+        else { hipFree(d_bp); hipFree(d_pos); hipFree(d_bw); (void)hipGetLastError(); }
+    }
     if (g->opt_xl_cut <= 0) return TLC_OK;                   // (no lane-per-pair extraction: no tables; the option rebuilds the lists)
     // membership tables for the lane-per-pair extraction: per node a power of two >= |ball| of four-id buckets, two choices per
     // id; descriptor = first bucket << 6 | log2(buckets), 63 = no table (a bucket pair overflowed while filling: the pairs that
@@ -549,6 +586,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     g->device = device; g->n_nodes = n_nodes; g->nnz = nnz; g->nw = nw; g->vic_lds = lds;
     auto env_on = [](const char* name) { const char* v = getenv(name); return !(v && v[0] == '0'); };
     g->opt_extract = env_on("TLC_EXTRACT"); g->opt_heavy = env_on("TLC_HEAVY"); g->opt_tiny = env_on("TLC_TINY");
+    g->opt_ball_edges = env_on("TLC_BALL_EDGES"); g->opt_dc_inplace = env_on("TLC_DC_INPLACE") ? 1 : 0;
     g->opt_defer = env_on("TLC_DEFER"); g->opt_n_ws = 3;
     // (off unless asked for: in-process A/Bs on the PubMed-shaped batch, tools/ab_option.py xl_cut 0 {16,24,32}, show no gain for
     // one batch alone and a loss for pipelined batches -- see the note at `xlane` in run_chunk_front and DESIGN.md)
@@ -681,6 +719,7 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     }
     hipFree(g->d_phase); hipFree(g->d_pair_t);
     hipFree(g->d_bptr); hipFree(g->d_bcol); hipFree(g->d_hptr); hipFree(g->d_htab); hipFree(g->d_nrec); hipFree(g->d_hh_w);
+    hipFree(g->d_be_ptr); hipFree(g->d_be_pos); hipFree(g->d_be_w);
     hipFree(g->d_ball_ub[0]); hipFree(g->d_ball_ub[1]);
     if (g->ev_ring_ready)
         for (int r = 0; r < TLC_TIMING_RING; ++r)
@@ -819,6 +858,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         if (ws->cap_entries < want && (rc = ensure_arena(g, ws, want)) != TLC_OK) return rc;
         vp.small_dir = nullptr; vp.small_lw = nullptr;
         vp.bptr = g->d_bptr; vp.bcol = g->d_bcol;
+        if (g->opt_ball_edges) { vp.be_ptr = g->d_be_ptr; vp.be_pos = g->d_be_pos; vp.be_w = g->d_be_w; }
         vp.nrec = g->d_nrec;
         if (g->hh_k > 0 && g->opt_heavy) { vp.hh_w = g->d_hh_w; vp.hh_k = g->hh_k; }
         vp.region_entries = g->opt_x_region; vp.bump_base = bump_base; vp.region_base_wg = 0;
@@ -946,6 +986,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
             lp.handoff = ws->handoff_large; lp.handoff_stride = (long long)tlc_handoff_slot_bytes(TLC_TIER_LARGE);
             lp.handoff_cap = TLC_EARLY_SLOTS;
             dc_lists_for(lp, 2);
+            lp.dc_inplace = g->opt_dc_inplace;
         }
         lp.phase_cycles = g->d_phase ? g->d_phase + 32 * TLC_TIER_LARGE : nullptr;
         T0(5, es);
@@ -1249,8 +1290,8 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
             pp.handoff = hs ? ws->handoff + hand_base[t] : nullptr;
             pp.handoff_stride = (long long)hs;
             pp.handoff_cap = (spec_done && (t == TLC_TIER_MID || t == TLC_TIER_MEDIUM || t == TLC_TIER_MEDWIDE)) ? std::min(tc[t], spec_cap[t]) : tc[t];
-            pp.dc_count = nullptr; pp.dc_list = nullptr;
-            if (t == TLC_TIER_LARGE) dc_lists_for(pp, 1);
+            pp.dc_count = nullptr; pp.dc_list = nullptr; pp.dc_inplace = 0;
+            if (t == TLC_TIER_LARGE) { dc_lists_for(pp, 1); pp.dc_inplace = g->opt_dc_inplace; }
             if ((t == TLC_TIER_MEDHI || t == TLC_TIER_MEDWIDE) && n_dcm > 0 && g->opt_dcm) dc_lists_for(pp, 0);
             if (hs && t == TLC_TIER_LARGE) {
                 // (the early launch may still be using the first TLC_EARLY_SLOTS slots: this launch takes the ones behind them)
@@ -1726,6 +1767,8 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     if (!strcmp(name, "extract")) g->opt_extract = value != 0;
     else if (!strcmp(name, "heavy")) g->opt_heavy = value != 0;
     else if (!strcmp(name, "tiny")) g->opt_tiny = value != 0;
+    else if (!strcmp(name, "ball_edges")) g->opt_ball_edges = value != 0;
+    else if (!strcmp(name, "dc_inplace")) g->opt_dc_inplace = value != 0;
     else if (!strcmp(name, "tier_mask")) g->opt_tier_mask = value;
     else if (!strcmp(name, "spec_cap")) g->opt_spec_cap = std::max(value, 0);
     else if (!strcmp(name, "split_launch")) g->opt_split_launch = value != 0;

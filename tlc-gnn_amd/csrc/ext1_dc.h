@@ -29,7 +29,9 @@
 #ifndef TLC_DC_MIN_POS_SHARED
 #define TLC_DC_MIN_POS_SHARED 320
 #endif
+#ifndef TLC_DC_LARGE_MODE
 #define TLC_DC_LARGE_MODE 2          /* LARGE tier: 1 = in the tier kernel, 2 = hand the subgraph to tlc_pd_dc_kernel */
+#endif
 #define TLC_DC_MAX_TIE_RUN 64       /* longer runs of equal descending keys: no fix-up, serial walk */
 
 namespace {

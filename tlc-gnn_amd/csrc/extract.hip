@@ -377,6 +377,41 @@ __device__ __forceinline__ int x_sweep_wave(const PB& p, const int* ids, int n, 
     return NW > 1 ? counted : run;
 }
 
+// Round 5.  The same entries from the SUBGRAPH LIST of the smaller ball (TlcVicParams::be_ptr): S is a subset of that ball, so
+// the induced subgraph is the list's entries whose two ends are members -- M0, M1 hold the members as bit masks over the positions
+// of the ball list (|ball| <= TLC_BE_CAP = 128: the two ballots of the filter), a local id is the number of members below a position.  One coalesced
+// 2 + 8-byte stream instead of a node record per member, its row segments, the heavy-member bookkeeping and the member bitmap:
+// a lane's entry is kept or dropped by two bit tests, numbered by a ballot and stored -- 93 % of the PubMed batch's pairs
+// (smaller ball <= 128 nodes; for the 84 % up to 64 nodes: 51 directed list entries on average).  Order: sources ascending, a source's
+// entries in CSR order -- a function of the pair alone, whichever pass (main, FILL) sweeps it.  One wavefront; dir may be null.
+__device__ __forceinline__ int x_sweep_ball(const unsigned short* __restrict__ be_pos, const double* __restrict__ be_w, int e0, int e1,
+                                            unsigned long long M0, unsigned long long M1, unsigned* dir, double* lw, int cap) {
+    const int lane = tlc_lane();
+    const unsigned c0 = (unsigned)__popcll(M0);
+    int run = 0;
+    // position p of the ball list: is it a member, and how many members stand below it (its local id)
+    auto member = [&](unsigned p) -> bool { return ((((p & 64u) ? M1 : M0) >> (p & 63u)) & 1ull) != 0ull; };
+    auto rank = [&](unsigned p) -> unsigned {
+        const unsigned long long below = (1ull << (p & 63u)) - 1ull;
+        return (p & 64u) ? c0 + (unsigned)__popcll(M1 & below) : (unsigned)__popcll(M0 & below);
+    };
+    for (int j0 = e0; j0 < e1; j0 += TLC_WAVE) {
+        const int j = j0 + lane;
+        const bool in = j < e1;
+        const unsigned pos = in ? (unsigned)be_pos[j] : 0u;
+        const double w = (in && dir) ? be_w[j] : 0.0;
+        const unsigned pa = pos >> 8, pb = pos & 0xffu;
+        const bool keep = in && member(pa) && member(pb);
+        const unsigned long long K = __ballot(keep);
+        if (dir && keep) {
+            const int o = run + __popcll(K & tlc_lanemask_lt());
+            if (o < cap) { x_store(&dir[o], (rank(pa) << 16) | rank(pb)); x_store(&lw[o], w); }
+        }
+        run += __popcll(K);
+    }
+    return run;
+}
+
 // The sweep of a workgroup; dir may be null (count only).  Returns the number of entries (uniform over the workgroup).
 template <int BW, class PB>
 __device__ __forceinline__ int x_sweep(const PB& p, const int* ids, int n, const XState& X, bool use_hvy, int nH,
@@ -421,6 +456,7 @@ __device__ __forceinline__ void x_zero_row(const PB& p, int i, int status, int n
 struct XHead {
     int u, v;
     int ru0, ru1, rv0, rv1, a0, a1, b0, b1;
+    int eu0, eu1, ev0, ev1;            // the ball-subgraph lists of u and v (TlcVicParams::be_ptr; zero without them)
 };
 // The first chunks of a pair's two ball lists, asked for while the pair BEFORE it is swept (single-wavefront workgroups): lane l
 // holds entry l of the smaller list (b) and entries l, 64 + l of the larger one (a), -1 beyond their ends.  (Three registers: with
@@ -491,10 +527,21 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
         return;
     }
 #ifdef TLC_PAIR_TIMES
-    if (p.dbg_pair_t && tid == 0) { p.dbg_pair_t[16 * (size_t)i] = t_start; p.dbg_pair_t[16 * (size_t)i + 1] = wall_clock64(); }
+    if (p.dbg_pair_t && tid == 0) { p.dbg_pair_t[16 * (size_t)i] = t_start; p.dbg_pair_t[16 * (size_t)i + 1] = wall_clock64(); p.dbg_pair_t[16 * (size_t)i + 14] = blockIdx.x; }
 #endif
     if (a1 - a0 < b1 - b0) { int t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; }    // [a0,a1): the larger ball
     const int nA = a1 - a0, nB = b1 - b0;
+    // the subgraph list of the smaller ball's node (b is v's list unless u's is strictly shorter), when there is one: x_sweep_ball
+    int be0 = 0, be1 = 0;
+    bool fast = false;
+    if constexpr (BW == 64) {
+        if (p.be_ptr && nB <= TLC_BE_CAP && !(p.flags & TLC_INCLUDE_ROOTS)) {
+            const bool b_is_u = (H.a1 - H.a0) < (H.b1 - H.b0);
+            be0 = b_is_u ? H.eu0 : H.ev0; be1 = b_is_u ? H.eu1 : H.ev1;
+            fast = true;
+        }
+    }
+    unsigned long long M0 = 0ull, M1 = 0ull;               // (fast) the members of S as a mask over the smaller ball's positions
     // ---- S = ball(u) & ball(v) (:315): the smaller list filtered through a bitmap of the larger -----------------------------
     int bv[4];
 #pragma unroll
@@ -543,6 +590,8 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
                 const unsigned long long m = __ballot(h);
                 pos = n + __popcll(m & tlc_lanemask_lt());
                 tot = __popcll(m);
+                if (base == 0 && r == 0) M0 = m;
+                if (base == 0 && r == 1) M1 = m;
             } else {
                 pos = n + block_escan_i32<BW>(h ? 1 : 0, X.xw, &tot);
             }
@@ -610,12 +659,12 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
         if (n <= cap_o) for (int k = tid; k < n; k += BW) p.out_ids[no + k] = ids[k];
     }
     // ---- member bits, the rank of the first member of every touched bitmap word, heavy members ------------------------------
-    const bool heavy_ok = p.hh_k > 0 && n <= TLC_X_HV_CAP;
+    const bool heavy_ok = !fast && p.hh_k > 0 && n <= TLC_X_HV_CAP;
     if (heavy_ok) for (int w = tid; w < TLC_X_HV_CAP / 32; w += BW) X.hvy[w] = 0u;
     x_sync<BW>();
     int nH = 0;
     XRec rec0 = x_empty_rec();
-    for (int base = 0; base < n; base += BW) {
+    for (int base = 0; base < (fast ? 0 : n); base += BW) {
         const int k = base + tid;
         int hi = -1;
         if (k < n) {
@@ -647,9 +696,15 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
     x_sync<BW>();
     const bool use_hvy = heavy_ok && nH <= TLC_X_H_CAP;      // (more heavy members than the list holds: every row is scanned)
     XSTAMP(5);
+    // (one place for the two forms of the sweep)
+    auto sweep = [&](unsigned* d_, double* w_, int cap_, int dbg_i) -> int {
+        if (fast) return x_sweep_ball(p.be_pos, p.be_w, be0, be1, M0, M1, d_, w_, cap_);
+        return x_sweep<BW>(p, ids, n, X, use_hvy, nH, d_, w_, cap_, rec0, BW == 64, dbg_i);
+    };
     if (p.x_fill) {
         const long long eo = p.edge_off[i];
-        x_sweep<BW>(p, ids, n, X, use_hvy, nH, p.A_dir + eo, p.A_lw + eo, fill_m2, rec0, BW == 64);
+        sweep(p.A_dir + eo, p.A_lw + eo, fill_m2, -1);
+        if (fast) return;                                                // (no member bits were set)
         x_sync<BW>();
         for (int k = tid; k < n; k += BW) X.bits[ids[k] >> 5] = 0u;
         x_sync<BW>();
@@ -691,7 +746,7 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
         }
     }
     prefetch_next();                                      // (the next pair's ball lists travel while this one's rows are swept)
-    const int m2 = x_sweep<BW>(p, ids, n, X, use_hvy, nH, wdir, wlw, cap, rec0, BW == 64, i);
+    const int m2 = sweep(wdir, wlw, cap, i);
     XSTAMP(6);
     const int m = m2 >> 1;
     if (m > TLC_MAX_SUBGRAPH_EDGES) {                     // edge ranks are packed in 24 bits (pd_pipeline.hip, cycle swap)
@@ -709,8 +764,7 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
             x_sync<BW>();
             es = X.ctl[4];
             if (es < p.early_cap) {
-                x_sweep<BW>(p, ids, n, X, use_hvy, nH, p.early_dir + (size_t)es * (2 * TLC_L_MMAX),
-                            p.early_lw + (size_t)es * (2 * TLC_L_MMAX), 2 * TLC_L_MMAX, rec0, BW == 64);
+                sweep(p.early_dir + (size_t)es * (2 * TLC_L_MMAX), p.early_lw + (size_t)es * (2 * TLC_L_MMAX), 2 * TLC_L_MMAX, -1);
                 if (tid == 0) p.early_list[es] = i;
             }
         } else if (es >= 0 && es < p.early_cap) {
@@ -720,9 +774,11 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
         }
     }
     // ---- the member bits go, by list -----------------------------------------------------------------------------------------
-    x_sync<BW>();
-    for (int k = tid; k < n; k += BW) X.bits[ids[k] >> 5] = 0u;
-    x_sync<BW>();
+    if (!fast) {
+        x_sync<BW>();
+        for (int k = tid; k < n; k += BW) X.bits[ids[k] >> 5] = 0u;
+        x_sync<BW>();
+    }
     XSTAMP(7);
 #undef XSTAMP
 }
@@ -801,11 +857,16 @@ __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kern
     };
     auto bounds_of = [&](XParams* q, XHead& H) {
         H.ru0 = H.ru1 = H.rv0 = H.rv1 = H.a0 = H.a1 = H.b0 = H.b1 = 0;
+        H.eu0 = H.eu1 = H.ev0 = H.ev1 = 0;
         if (H.u < 0 || H.v < 0 || H.u >= q->n_nodes || H.v >= q->n_nodes) return;
         XCInt* rp = (XCInt*)q->rowptr;
         XCInt* bp = (XCInt*)q->bptr;
         H.ru0 = rp[H.u]; H.ru1 = rp[H.u + 1]; H.rv0 = rp[H.v]; H.rv1 = rp[H.v + 1];
         H.a0 = bp[H.u]; H.a1 = bp[H.u + 1]; H.b0 = bp[H.v]; H.b1 = bp[H.v + 1];
+        if (BW == 64 && q->be_ptr) {
+            XCInt* ep = (XCInt*)q->be_ptr;
+            H.eu0 = ep[H.u]; H.eu1 = ep[H.u + 1]; H.ev0 = ep[H.v]; H.ev1 = ep[H.v + 1];
+        }
     };
     if (p.started && threadIdx.x == 0 && (int)blockIdx.x < n_work) atomicAdd(p.started, 1);
     // (one loop for both schedules -- static: a chunk is one item and the next chunk is gridDim.x further on)
@@ -908,6 +969,7 @@ __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kern
             H0.u = XU(H1.u); H0.v = XU(H1.v);
             H0.ru0 = XU(H1.ru0); H0.ru1 = XU(H1.ru1); H0.rv0 = XU(H1.rv0); H0.rv1 = XU(H1.rv1);
             H0.a0 = XU(H1.a0); H0.a1 = XU(H1.a1); H0.b0 = XU(H1.b0); H0.b1 = XU(H1.b1);
+            H0.eu0 = XU(H1.eu0); H0.eu1 = XU(H1.eu1); H0.ev0 = XU(H1.ev0); H0.ev1 = XU(H1.ev1);
             i1 = XU(i2); fr1 = fr2; u1 = XU(u2); v1 = XU(v2);
             i2 = XU(i3); fr2 = fr3;
 #undef XU
@@ -1077,6 +1139,79 @@ __global__ __launch_bounds__(64) void tlc_ball_list_kernel(int n_nodes, int nw, 
         for (int w = w0; w < w1; ++w) bbits[w] = 0u;
         __syncthreads();
     }
+}
+
+// ---- the ball subgraphs: for every node x with |ball(x)| <= TLC_BE_CAP, the directed entries a -> b of the graph with a and b in
+// ball(x), as positions in the (ascending) ball list, sources ascending, a source's entries in CSR order.  One wavefront per node
+// (grid-stride): the members are marked in an LDS bitmap with the rank of every word's first member beside it (as the extraction
+// marks a vicinity), then member after member the wavefront streams the member's row, 64 entries per step, and keeps the entries
+// whose column is a member.  COUNT stores the number of entries, FILL writes them from be_ptr[x] on.  One-off per (graph, hop).
+template <bool FILL>
+__global__ __launch_bounds__(64) void tlc_ball_edges_kernel(int n_nodes, int nw, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                            const double* __restrict__ w, const int* __restrict__ bptr,
+                                                            const int* __restrict__ bcol, int* __restrict__ esize,
+                                                            const int* __restrict__ be_ptr, unsigned short* __restrict__ be_pos,
+                                                            double* __restrict__ be_w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ebits[];
+    const int lane = tlc_lane();
+    unsigned short* pref = (unsigned short*)(ebits + ((nw + 3) & ~3));
+    __shared__ int eid[TLC_BE_CAP];
+    for (int k = lane; k < nw; k += TLC_WAVE) ebits[k] = 0u;
+    __syncthreads();
+    for (int x = blockIdx.x; x < n_nodes; x += gridDim.x) {
+        const int b0 = bptr[x], nb = bptr[x + 1] - b0;
+        if (nb > TLC_BE_CAP) { if (!FILL && lane == 0) esize[x] = 0; continue; }        // (uniform)
+        for (int k = lane; k < nb; k += TLC_WAVE) eid[k] = bcol[b0 + k];
+        __syncthreads();
+        for (int k = lane; k < nb; k += TLC_WAVE) {
+            const int id = eid[k];
+            atomicOr(&ebits[id >> 5], 1u << (id & 31));
+            if (k == 0 || (eid[k - 1] >> 5) != (id >> 5)) pref[id >> 5] = (unsigned short)k;
+        }
+        __syncthreads();
+        int run = FILL ? be_ptr[x] : 0;
+        for (int k = 0; k < nb; ++k) {
+            const int y = eid[k];
+            const int rb = rowptr[y], re = rowptr[y + 1];
+            for (int j = rb; j < re; j += TLC_WAVE) {
+                const int jj = j + lane;
+                const int c = jj < re ? col[jj] : -1;
+                bool h = false;
+                int pos = 0;
+                if (c >= 0) {
+                    const unsigned word = ebits[c >> 5], bit = 1u << (c & 31);
+                    h = (word & bit) != 0u;
+                    pos = (int)pref[c >> 5] + __popc(word & (bit - 1u));
+                }
+                const unsigned long long m = __ballot(h);
+                if (FILL && h) {
+                    const int o = run + __popcll(m & tlc_lanemask_lt());
+                    be_pos[o] = (unsigned short)((k << 8) | pos);
+                    be_w[o] = w[jj];
+                }
+                run += __popcll(m);
+            }
+        }
+        if (!FILL && lane == 0) esize[x] = run;
+        __syncthreads();
+        for (int k = lane; k < nb; k += TLC_WAVE) ebits[eid[k] >> 5] = 0u;
+        __syncthreads();
+    }
+}
+
+int tlc_launch_ball_edges(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, const double* w, const int* bptr, const int* bcol,
+                          int* esize, const int* be_ptr, unsigned short* be_pos, double* be_w, int grid, void* stream) {
+    if (n_nodes <= 0) return TLC_OK;
+    const size_t lds = (size_t)((nw + 3) & ~3) * 6 + 16;
+    if (fill) {
+        if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_ball_edges_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((tlc_ball_edges_kernel<true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, n_nodes, nw, rowptr, col, w, bptr, bcol, esize, be_ptr, be_pos, be_w);
+    } else {
+        if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_ball_edges_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((tlc_ball_edges_kernel<false>), dim3(grid), dim3(64), lds, (hipStream_t)stream, n_nodes, nw, rowptr, col, w, bptr, bcol, esize, be_ptr, be_pos, be_w);
+    }
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
 }
 
 int tlc_launch_ball_list(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, int hop, int* bsize, const int* bptr,

@@ -1359,6 +1359,10 @@ __device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get 
 
 }  // namespace
 
+// (defined behind tlc_pd_swap_kernel: one subgraph of a divide-and-conquer list from its hand-off record)
+template <int NM, int MM, int W>
+__device__ __forceinline__ void dc_subgraph(const TlcPdParams& p, int wi, unsigned char* lds_raw);
+
 // ======================================================================================================================
 // Batch kernel: one workgroup per vicinity subgraph of one size tier.
 // ======================================================================================================================
@@ -1683,9 +1687,16 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
                                       // dc list: marking a subgraph for the divide and conquer fixes the order of its tied descending
                                       // keys, and a row must not depend on whether tlc_pd_dc_kernel or the serial walk then answers)
                                       /*handoff_all=*/NM != TLC_L_NMAX && NM != TLC_LC_NMAX);
-            if (deferred && slot && tid == 0 && p.dc_count && ((const int*)slot)[6] != 0) {
+            bool dc_here = false;
+            if constexpr (!HUGE && NM == TLC_L_NMAX) dc_here = p.dc_inplace != 0;
+            if (deferred && slot && !dc_here && tid == 0 && p.dc_count && ((const int*)slot)[6] != 0) {
                 const int li = atomicAdd(p.dc_count, 1);              // meant for tlc_pd_dc_kernel
                 p.dc_list[li] = wi;
+            }
+            if constexpr (!HUGE && NM == TLC_L_NMAX) {
+                // the divide and conquer of this subgraph by this workgroup, from the record it has just written (ext1_handoff ends
+                // with a barrier; the layout of tlc_pd_dc_kernel fits the tier's LDS): no second launch, no second placement
+                if (deferred && slot && dc_here && ((const int*)slot)[6] != 0) dc_subgraph<NM, MM, W>(p, wi, lds_raw);
             }
             if (status == TLC_ST_OK && !deferred) {
                 const int np = M.ctl[2], n_up = M.ctl[6];
@@ -1824,35 +1835,20 @@ __host__ __device__ constexpr size_t dc_kernel_lds(int NM, int MM) {
     const size_t dc = al16(dc_bytes(KB, NM > 2 * KB + 2 ? NM : 2 * KB + 2) + (size_t)MM + 16) + al16((size_t)(MM + 2) * 4) + 256;
     return dc > make_swap_layout(NM, MM).total ? dc : make_swap_layout(NM, MM).total;     // (the serial fallback's layout fits too)
 }
+// One subgraph (position wi of the launch's list) from its hand-off record: the divide and conquer, its points, the image; what the
+// solver cannot take goes through the serial walk here.  Called by tlc_pd_dc_kernel, and by the LARGE tier kernel IN PLACE
+// (TlcPdParams::dc_inplace, round 5: the workgroup that wrote the record re-carves its own LDS and carries on -- the separate
+// launch had to find 71 CUs with 107 KB of free LDS again while the other tiers' kernels were being placed: 262 -> 523 us for one
+// batch alone once the extraction in front of them got shorter).  lds_raw: at least dc_kernel_lds(NM, MM) bytes.
 template <int NM, int MM, int W>
-__global__ __launch_bounds__(W, (W <= 256 ? 4 : 1)) void tlc_pd_dc_kernel(TlcPdParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+__device__ __forceinline__ void dc_subgraph(const TlcPdParams& p, int wi, unsigned char* lds_raw) {
     constexpr size_t total = dc_kernel_lds(NM, MM);
     constexpr size_t o_pts = total - 256 - al16((size_t)(MM + 2) * 4), o_ctl = total - 256;
     const int tid = threadIdx.x;
-    if (p.abort_flag && *p.abort_flag) return;
-    int tier_count = p.tier_count;
-    if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
-    if (tier_count > p.handoff_cap) tier_count = p.handoff_cap;
     unsigned* pts = (unsigned*)(lds_raw + o_pts);
     int* ctl = (int*)(lds_raw + o_ctl);               // 16 ints, then 32 ints for block scans
     int* wcnt = ctl + 16;
-    // a chain of short barrier-separated phases: its wavefronts should win issue arbitration against the throughput kernels
-    // of the other tiers that share the CU
-    __builtin_amdgcn_s_setprio(3);
-    const int n_list = p.dc_count ? *p.dc_count : 0;
-    // (one subgraph per workgroup and no loop around the body, like the tier kernels: see tlc_pd_tier_kernel)
-    const int li = blockIdx.x;
-    if (li >= n_list) return;
     do {
-        const int wi = p.dc_list[li];
-        if (wi < 0 || wi >= tier_count) continue;
-        if (p.large_split) {                  // (split LARGE tier: the record was written by the tier kernel of the same configuration)
-            const int ii = p.tier_list[wi];
-            if (ii < 0) continue;
-            const bool fits = p.hdr_n[ii] <= TLC_LC_NMAX && (p.hdr_m2[ii] >> 1) <= TLC_LC_MMAX;
-            if ((NM == TLC_LC_NMAX) != fits) continue;
-        }
         const Handoff H = carve_handoff(p.handoff + (size_t)wi * (size_t)p.handoff_stride, NM);
         if (H.hdr[0] == 0 || H.hdr[6] == 0) continue;                 // finished by the tier kernel / not meant for this kernel
         const int i = p.tier_list[wi];
@@ -1914,6 +1910,31 @@ __global__ __launch_bounds__(W, (W <= 256 ? 4 : 1)) void tlc_pd_dc_kernel(TlcPdP
         }
         __syncthreads();
     } while (false);
+}
+
+template <int NM, int MM, int W>
+__global__ __launch_bounds__(W, (W <= 256 ? 4 : 1)) void tlc_pd_dc_kernel(TlcPdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (p.abort_flag && *p.abort_flag) return;
+    int tier_count = p.tier_count;
+    if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
+    if (tier_count > p.handoff_cap) tier_count = p.handoff_cap;
+    // a chain of short barrier-separated phases: its wavefronts should win issue arbitration against the throughput kernels
+    // of the other tiers that share the CU
+    __builtin_amdgcn_s_setprio(3);
+    const int n_list = p.dc_count ? *p.dc_count : 0;
+    // (one subgraph per workgroup and no loop around the body, like the tier kernels: see tlc_pd_tier_kernel)
+    const int li = blockIdx.x;
+    if (li >= n_list) return;
+    const int wi = p.dc_list[li];
+    if (wi < 0 || wi >= tier_count) return;
+    if (p.large_split) {                  // (split LARGE tier: the record was written by the tier kernel of the same configuration)
+        const int ii = p.tier_list[wi];
+        if (ii < 0) return;
+        const bool fits = p.hdr_n[ii] <= TLC_LC_NMAX && (p.hdr_m2[ii] >> 1) <= TLC_LC_MMAX;
+        if ((NM == TLC_LC_NMAX) != fits) return;
+    }
+    dc_subgraph<NM, MM, W>(p, wi, lds_raw);
 }
 
 // ======================================================================================================================
@@ -2362,7 +2383,7 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
                     hipLaunchKernelGGL((tlc_pd_dc_kernel<TLC_LC_NMAX, TLC_LC_MMAX, TLC_L_THREADS>), dim3(p.tier_count),
                                        dim3(TLC_L_THREADS), dcc, s, p);
                 }
-                if (p.dc_count)
+                if (p.dc_count && !p.dc_inplace)
                     hipLaunchKernelGGL((tlc_pd_dc_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS>), dim3(p.tier_count),
                                        dim3(TLC_L_THREADS), dcl, s, p);
             }

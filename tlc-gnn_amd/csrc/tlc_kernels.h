@@ -183,7 +183,15 @@ struct TlcVicParams {
     long long region_entries;
     long long region_base_entries;   // arena entries in front of this launch's regions
     long long bump_base;
+    // ---- ball subgraphs (round 5): for every node x whose ball has at most TLC_BE_CAP nodes, the directed entries of the graph
+    // with BOTH ends in ball(x), as (position of the source in the ball list << 8 | position of the target) and the weight, sources
+    // ascending, a source's entries in CSR order.  A vicinity is a subset of the smaller ball of its pair, so its induced subgraph
+    // is a filter over that list (extract.hip, x_sweep_ball).  Null: not built.
+    const int* be_ptr;          // [n_nodes + 1]; be_ptr[x] == be_ptr[x + 1] for a node whose ball is larger
+    const unsigned short* be_pos;
+    const double* be_w;
 };
+#define TLC_BE_CAP 128
 
 struct TlcScanParams {
     int n_pairs;
@@ -286,6 +294,7 @@ struct TlcPdParams {
     // the serial walk
     int* dc_count;
     int* dc_list;
+    int dc_inplace;              // LARGE tier: the tier kernel's own workgroup runs the divide and conquer from the record (no tlc_pd_dc_kernel launch)
     int dc_force_fail;           // tests: tlc_pd_dc_kernel treats every solve as failed (the give-back path to the serial walk)
     // lane-per-subgraph kernel fed from the records of the lane-per-pair extraction: slot b = pairs xl_list[64 b ..], record b
     const unsigned char* xl_rec;
@@ -378,6 +387,8 @@ int tlc_launch_xlane(const TlcXlParams& p, int grid, void* stream);
 int tlc_launch_ball_hash(int n_nodes, const int* bptr, const int* bcol, const long long* hptr, int* htab, int* fail, void* stream);
 int tlc_launch_pd_tiny_rec(const TlcPdParams& p, void* stream);
 int tlc_launch_tiny_sort(int count, const int* list, const int* hdr_n, const int* hdr_m2, int* out, void* stream, int shift = 0);
+int tlc_launch_ball_edges(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, const double* w, const int* bptr, const int* bcol,
+                          int* esize, const int* be_ptr, unsigned short* be_pos, double* be_w, int grid, void* stream);
 int tlc_launch_ball_list(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, int hop, int* bsize, const int* bptr,
                          int* bcol, int grid, void* stream);
 int tlc_launch_ball_bound(int n_nodes, const int* rowptr, const int* col, const int* prev, int* out, void* stream);

@@ -1,24 +1,22 @@
-"""Vicinity size distribution of the bench batch per tier -- development aid."""
+"""Node / edge counts of the bench batch's vicinities: how the SMALL tier's population (17..64 nodes) is distributed."""
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")
-import bench
 from tlc_gnn_amd import engine
-wl = bench.build_workload(0)
-g = engine.DeviceGraph(wl["rowptr"], wl["col"], wl["w"])
-pairs = wl["pi_pairs"]
-g.pd_pi_batch(torch.as_tensor(pairs).cuda(), wl["hop"])
-nn, m2 = g.sizes(len(pairs))
-tiers = engine.tier_of(nn, m2)
-for name in ("pd_tier_small", "pd_tier_medium", "pd_tier_large"):
-    sel = tiers == name
-    n, m = nn[sel], m2[sel] // 2
-    print(name, sel.sum(), "n pct 10/50/90/99/max:", np.percentile(n, [10, 50, 90, 99, 100]).astype(int), " m pct:", np.percentile(m, [10, 50, 90, 99, 100]).astype(int))
-    if name == "pd_tier_medium":
-        for nc, mc in ((128, 256), (192, 384), (256, 512), (384, 768)):
-            print("   n<=%d & m<=%d: %.1f%%  (sum m share %.1f%%)" % (nc, mc, 100 * ((n <= nc) & (m <= mc)).mean(), 100 * m[(n <= nc) & (m <= mc)].sum() / m.sum()))
-m_all = m2 // 2
-ok = nn > 0
-print("trees (m == n-1): %.1f%% of all pairs; by tier:" % (100 * (m_all[ok] == nn[ok] - 1).mean()),
-      {t: round(100 * float(((m_all == nn - 1) & (tiers == t)).sum()) / max(1, int((tiers == t).sum())), 1) for t in ("pd_tier_small", "pd_tier_medium", "pd_tier_large")})
-print("m - n + 1 (number of Pos edges) percentiles over small tier:", np.percentile((m_all - nn + 1)[tiers == "pd_tier_small"], [10, 25, 50, 75, 90]))
+import bench
+W = bench.build_workload(0)
+g = engine.DeviceGraph(W["rowptr"], W["col"], W["w"])
+pairs = torch.as_tensor(W["pi_pairs"]).cuda()
+E = len(pairs)
+g.pd_pi_batch(pairs, 2)
+n, m2 = g.sizes(E)
+m = m2 // 2
+print("tiers", g.tier_counts())
+tiny = (n <= 16) & (m <= 24)
+print("TINY (n<=16, m<=24): %d" % tiny.sum())
+rest = ~tiny & (n <= 64) & (m <= 128)
+print("SMALL rest: %d; n mean %.1f m mean %.1f" % (rest.sum(), n[rest].mean(), m[rest].mean()))
+for nc, mc in ((20, 32), (24, 40), (24, 48), (32, 48), (32, 64), (40, 64), (48, 96)):
+    s = rest & (n <= nc) & (m <= mc)
+    print("  n<=%d m<=%d: %5d (%.1f %% of the SMALL tier's)  mean n %.1f m %.1f" % (nc, mc, s.sum(), 100.0 * s.sum() / rest.sum(), n[s].mean() if s.sum() else 0, m[s].mean() if s.sum() else 0))
+print("m - n + 1 (independent cycles) among SMALL rest: mean %.1f p50 %d p90 %d" % ((m - n + 1)[rest].mean(), np.median((m - n + 1)[rest]), np.percentile((m - n + 1)[rest], 90)))
