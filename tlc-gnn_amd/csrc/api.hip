@@ -202,9 +202,10 @@ struct tlc_graph {
     double* d_hh_w;
     int hh_k;
     int hh_diag;                   // some heavy node has a self loop
-    size_t x_lds64, x_lds512;
+    size_t x_lds64, x_lds512, x_lds64f;
     // development / test switches (tlc_debug_set_option; initial values from the environment: TLC_EXTRACT, TLC_HEAVY, TLC_TINY)
     int opt_extract, opt_heavy, opt_tiny;
+    int opt_fast_split, opt_xf_grid;   // the subgraph-list pairs in a launch of their own (run_chunk_front), its workgroups (0: 4096)
     int opt_dc_inplace;            // LARGE tier: divide and conquer by the tier kernel's own workgroup (TlcPdParams::dc_inplace)
     int opt_ball_edges;            // the extraction filters the smaller ball's subgraph list where there is one (extract.hip, x_sweep_ball)
     int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
@@ -587,6 +588,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     auto env_on = [](const char* name) { const char* v = getenv(name); return !(v && v[0] == '0'); };
     g->opt_extract = env_on("TLC_EXTRACT"); g->opt_heavy = env_on("TLC_HEAVY"); g->opt_tiny = env_on("TLC_TINY");
     g->opt_ball_edges = env_on("TLC_BALL_EDGES"); g->opt_dc_inplace = env_on("TLC_DC_INPLACE") ? 1 : 0;
+    g->opt_fast_split = env_on("TLC_FAST_SPLIT") ? 1 : 0;
     g->opt_defer = env_on("TLC_DEFER"); g->opt_n_ws = 3;
     // (off unless asked for: in-process A/Bs on the PubMed-shaped batch, tools/ab_option.py xl_cut 0 {16,24,32}, show no gain for
     // one batch alone and a loss for pipelined batches -- see the note at `xlane` in run_chunk_front and DESIGN.md)
@@ -683,6 +685,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     if (per_cu < 1) per_cu = 1;
     g->x_lds64 = tlc_extract_lds_bytes(nw, 64);
     g->x_lds512 = tlc_extract_lds_bytes(nw, 512);
+    g->x_lds64f = tlc_extract_lds_bytes(nw, 64, true);
     // (the extraction kernel's workgroups are smaller: the scratch slots cover whichever kernel runs more of them)
     per_cu = std::max(per_cu, (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(g->x_lds64 + 64, 1)));
     g->vic_slots = cus * per_cu;
@@ -847,12 +850,19 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
                        (!pipelined || g->opt_xl_pipelined);
     // (opt_x_grid: development A/B of the number of extraction workgroups; never more than the scratch slots there are)
     const int xgrid = std::min(n_pairs, g->opt_x_grid > 0 ? std::min(g->opt_x_grid, g->vic_slots) : g->vic_slots);
+    // The pairs whose vicinity is a filter over the smaller ball's subgraph list (extract.hip, x_sweep_ball: smaller ball <= 128
+    // nodes, 93 % of a PubMed batch) get a launch of their own, tlc_extract_kernel<64, true>: no row sweep in it, so half the
+    // registers, twice the wavefronts, 3.6 KB of LDS -- and it needs nothing from the classification, so it is the FIRST thing on the
+    // chunk's main stream and runs beside the classification and the early pass, in front of the residency gate.  The general launch
+    // behind the gate leaves those pairs alone (TlcVicParams::fast_split).
+    const bool fsplit = use_x && g->opt_fast_split && g->opt_ball_edges && g->d_be_ptr != nullptr && !(flags & TLC_INCLUDE_ROOTS);
+    const int xfgrid = fsplit ? std::min(n_pairs, g->opt_xf_grid > 0 ? g->opt_xf_grid : 4096) : 0;
     long long bump_base = 0;
     if (use_x) {
         // arena = one region per workgroup of the extraction (main pass, then the early pass), then the bump area
         // (main pass, early pass; then the launch that extracts what the lane-per-pair pass gave back: vicinities of <= 32 nodes, so
         // many small workgroup regions)
-        const long long regions = (long long)xgrid + TLC_EARLY_WG;
+        const long long regions = (long long)xgrid + TLC_EARLY_WG + xfgrid;
         bump_base = regions * g->opt_x_region + (long long)TLC_XL_GB_WG * TLC_XL_GB_REGION;
         const size_t want = (size_t)bump_base + std::max<size_t>(std::max<size_t>((size_t)n_pairs * 32, (size_t)g->opt_x_bump_min), ws->x_entries_hint + ws->x_entries_hint / 2);
         if (ws->cap_entries < want && (rc = ensure_arena(g, ws, want)) != TLC_OK) return rc;
@@ -871,6 +881,20 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
             (rc = ensure_arena(g, ws, std::min<size_t>((size_t)n_pairs * 128, (size_t)1 << 23))) != TLC_OK) return rc;
         vp.A_dir = ws->A_dir; vp.A_lw = ws->A_lw;
         vp.bump_top = d_bump_top; vp.bump_cap = (long long)ws->cap_entries; vp.bump_overflow = d_bump_overflow;
+    }
+    if (early) {
+        // (the fork of the early chain: ahead of the FAST launch, which runs beside it; the one-off ball bounds go in front of it)
+        if ((rc = ensure_early(g, ws, hop, s)) != TLC_OK) return rc;
+        TLC_HIP_CHECK(hipEventRecord(ws->ev_fork, s));                  // after the memsets (and the one-off bounds)
+        TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[4], ws->ev_fork, 0));
+    }
+    if (fsplit) {
+        TlcVicParams fp = vp;                                 // (no bins, no early list, no work counter: every pair by index, statically strided)
+        fp.region_base_wg = xgrid + TLC_EARLY_WG;
+        fp.scratch_base_slot = 0;                             // (never used: its member lists fit the LDS)
+        fp.work_counter = nullptr;
+        if ((rc = tlc_launch_extract(64, xfgrid, g->x_lds64f, fp, s, true)) != TLC_OK) return rc;
+        vp.fast_split = 1;
     }
     int* d_cand_count = ws->d_ctl + 16;
     int* d_early_count = ws->d_ctl + 17;
@@ -897,8 +921,6 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     if (early) {
         if ((rc = ensure_early(g, ws, hop, s)) != TLC_OK) return rc;
         hipStream_t es = ws->side[4];
-        TLC_HIP_CHECK(hipEventRecord(ws->ev_fork, s));                  // after the memsets (and the one-off bounds)
-        TLC_HIP_CHECK(hipStreamWaitEvent(es, ws->ev_fork, 0));
         // (TLC_INCLUDE_ROOTS adds at most the two roots to a vicinity)
         if (use_x) {
             // exact ball sizes: the candidates of the early pass, the bins the main pass takes first, and the candidates of the
@@ -1017,8 +1039,13 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     // tools/gpu_chunk_ab.sh, x_chunk_div 4096 against 8192 / 16384 / 32768: pipelined batch +0.4 / +2.2 / +2.7 %, latency of one
     // batch -1.9 / -1.1 / -1.7 %.  Half as many leaves half of the machine without a first chunk: +6 %)
     vp.work_chunk = std::max(2, n_pairs / (g->opt_x_chunk_div > 0 ? g->opt_x_chunk_div : pipelined ? 4096 : 8192));
+    // (behind a FAST launch the work list is the two top bins only -- a few thousand pairs of 20 - 80 us: one pair per chunk)
+    if (fsplit && early) vp.work_chunk = 1;
     T0(0, s);
     if (use_x) {
+        // (behind a FAST launch this one is left with the pairs whose smaller ball has more than 128 nodes -- a few thousand, 20 - 80 us
+        // each on one wavefront.  512-thread workgroups for them instead -- 256 / 512 / 1024 of them -- measured: pipelined batch
+        // 0.576 -> 0.62 - 0.63 ms, one batch alone 0.68 -> 0.74 ms; the count-prefix-write form of the sweep costs more than it spreads)
         if ((rc = tlc_launch_extract(64, xgrid, g->x_lds64, vp, s)) != TLC_OK) return rc;
     } else {
         hipLaunchKernelGGL((tlc_vicinity_kernel<false, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
@@ -1769,6 +1796,8 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "tiny")) g->opt_tiny = value != 0;
     else if (!strcmp(name, "ball_edges")) g->opt_ball_edges = value != 0;
     else if (!strcmp(name, "dc_inplace")) g->opt_dc_inplace = value != 0;
+    else if (!strcmp(name, "fast_split")) g->opt_fast_split = value != 0;
+    else if (!strcmp(name, "xf_grid")) g->opt_xf_grid = std::max(value, 0);
     else if (!strcmp(name, "tier_mask")) g->opt_tier_mask = value;
     else if (!strcmp(name, "spec_cap")) g->opt_spec_cap = std::max(value, 0);
     else if (!strcmp(name, "split_launch")) g->opt_split_launch = value != 0;

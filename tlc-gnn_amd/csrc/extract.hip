@@ -46,9 +46,20 @@ struct XCfg {
 struct XLayout {
     size_t o_pref, o_sid, o_hvy, o_hl, o_ctl, o_ucnt, o_stage, total;
 };
-__host__ __device__ constexpr XLayout x_layout(int nw, int sid_cap, int bw) {
+__host__ __device__ constexpr XLayout x_layout(int nw, int sid_cap, int bw, bool fast = false) {
     XLayout L{};
     const size_t nw4 = (size_t)((nw + 3) & ~3);
+    if (fast) {
+        // tlc_extract_kernel<64, true>: the bitmap of the larger ball, the member ids, the control words -- no word ranks, no heavy
+        // bits, no staging buffer (x_sweep_ball needs none of them): 3.6 KB for PubMed, so that LDS does not cap its wavefronts
+        L.o_pref = nw4 * 4;
+        L.o_sid = (L.o_pref + 15) & ~(size_t)15;
+        L.o_hvy = L.o_hl = L.o_ctl = L.o_sid + (size_t)sid_cap * 4;
+        L.o_ucnt = L.o_ctl + 64 + 4 + 16;
+        L.o_stage = (L.o_ucnt + 15) & ~(size_t)15;
+        L.total = L.o_stage;
+        return L;
+    }
     L.o_pref = nw4 * 4;
     L.o_sid = (L.o_pref + nw4 * 2 + 15) & ~(size_t)15;
     L.o_hvy = L.o_sid + (size_t)sid_cap * 4;
@@ -464,12 +475,15 @@ struct XHead {
 struct XNoPrefetch {
     __device__ __forceinline__ void operator()() const {}
 };
-template <int BW, class PB, class PF = XNoPrefetch>
+// FAST (BW == 64): the launch that takes the pairs x_sweep_ball serves (TlcVicParams::fast_split) and nothing else -- the general
+// sweep, the member bitmap and the heavy-member bookkeeping are compiled out, which is what lets it run at twice the wavefronts.
+template <int BW, bool FAST = false, class PB, class PF = XNoPrefetch>
 __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest, const XHead& H, unsigned char* lds, int* slot,
                                              bool has_pre = false, int pb0 = -1, int pa0 = -1, int pa1 = -1,
                                              const PF& prefetch_next = PF()) {
+    static_assert(!FAST || BW == 64, "the FAST launch is one wavefront per pair");
     constexpr int SID_CAP = XCfg<BW>::SID_CAP;
-    const XLayout L = x_layout(p.nw, SID_CAP, BW);
+    const XLayout L = x_layout(p.nw, SID_CAP, BW, FAST);
     const int nw4 = (p.nw + 3) & ~3;
     XState X;
     X.bits = (unsigned*)lds;
@@ -502,7 +516,7 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
     if (!missing) {
         a0 = H.a0; a1 = H.a1; b0 = H.b0; b1 = H.b1;
         missing = (H.ru1 == H.ru0) || (H.rv1 == H.rv0);
-        if (!missing && from_rest) {
+        if (!missing && from_rest && !FAST) {
             const int na = a1 - a0, nb = b1 - b0, mn = na < nb ? na : nb;
             // same predicates as tlc_classify_kernel: the early pass owns its candidates (as long as its list held them all;
             // else they are extracted here); a binned pair was taken from its bin
@@ -523,7 +537,8 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
         if (p.fill_mode == 2 && (hn > TLC_M_NMAX || (fill_m2 >> 1) > TLC_M_MMAX)) return;   // filled from the heavy tiers' lists
     }
     if (missing) {
-        x_zero_row<BW>(p, i, TLC_ST_MISSING_NODE, 0, -1, -1);
+        // (one owner: the FAST launch when the chunk has one)
+        if (FAST || !p.fast_split || p.x_fill) x_zero_row<BW>(p, i, TLC_ST_MISSING_NODE, 0, -1, -1);
         return;
     }
 #ifdef TLC_PAIR_TIMES
@@ -541,6 +556,10 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
             fast = true;
         }
     }
+    // two launches share a chunk's pairs (fast_split): the FAST one takes exactly the pairs the subgraph lists serve, whatever bin
+    // they are in; this one the rest (and, as the FILL pass, everything: x_fill)
+    if constexpr (FAST) { if (!fast) return; }
+    else if (fast && p.fast_split && !p.x_fill) return;
     unsigned long long M0 = 0ull, M1 = 0ull;               // (fast) the members of S as a mask over the smaller ball's positions
     // ---- S = ball(u) & ball(v) (:315): the smaller list filtered through a bitmap of the larger -----------------------------
     int bv[4];
@@ -659,12 +678,12 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
         if (n <= cap_o) for (int k = tid; k < n; k += BW) p.out_ids[no + k] = ids[k];
     }
     // ---- member bits, the rank of the first member of every touched bitmap word, heavy members ------------------------------
-    const bool heavy_ok = !fast && p.hh_k > 0 && n <= TLC_X_HV_CAP;
+    const bool heavy_ok = !FAST && !fast && p.hh_k > 0 && n <= TLC_X_HV_CAP;
     if (heavy_ok) for (int w = tid; w < TLC_X_HV_CAP / 32; w += BW) X.hvy[w] = 0u;
     x_sync<BW>();
     int nH = 0;
     XRec rec0 = x_empty_rec();
-    for (int base = 0; base < (fast ? 0 : n); base += BW) {
+    for (int base = 0; base < ((FAST || fast) ? 0 : n); base += BW) {
         const int k = base + tid;
         int hi = -1;
         if (k < n) {
@@ -698,8 +717,9 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
     XSTAMP(5);
     // (one place for the two forms of the sweep)
     auto sweep = [&](unsigned* d_, double* w_, int cap_, int dbg_i) -> int {
-        if (fast) return x_sweep_ball(p.be_pos, p.be_w, be0, be1, M0, M1, d_, w_, cap_);
-        return x_sweep<BW>(p, ids, n, X, use_hvy, nH, d_, w_, cap_, rec0, BW == 64, dbg_i);
+        if (FAST || fast) return x_sweep_ball(p.be_pos, p.be_w, be0, be1, M0, M1, d_, w_, cap_);
+        if constexpr (!FAST) return x_sweep<BW>(p, ids, n, X, use_hvy, nH, d_, w_, cap_, rec0, BW == 64, dbg_i);
+        return 0;
     };
     if (p.x_fill) {
         const long long eo = p.edge_off[i];
@@ -774,7 +794,7 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
         }
     }
     // ---- the member bits go, by list -----------------------------------------------------------------------------------------
-    if (!fast) {
+    if (!FAST && !fast) {
         x_sync<BW>();
         for (int k = tid; k < n; k += BW) X.bits[ids[k] >> 5] = 0u;
         x_sync<BW>();
@@ -796,8 +816,8 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
 #endif
 typedef const __attribute__((address_space(4))) TlcVicParams XParams;
 typedef const __attribute__((address_space(4))) int XCInt;
-template <int BW>
-__global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kernel(TlcVicParams p) {
+template <int BW, bool FAST>
+__global__ __launch_bounds__(BW, BW == 64 ? (FAST ? 8 : TLC_X_WPE) : 1) void tlc_extract_kernel(TlcVicParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xlds[];
     int* slot = p.scratch + (size_t)(p.scratch_base_slot + blockIdx.x) * p.scratch_stride;
     {
@@ -808,7 +828,7 @@ __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kern
     }
     // this workgroup's arena region (cursor / end live in LDS across its pairs)
     {
-        const XLayout L = x_layout(p.nw, XCfg<BW>::SID_CAP, BW);
+        const XLayout L = x_layout(p.nw, XCfg<BW>::SID_CAP, BW, FAST);
         long long* cur = (long long*)((int*)(xlds + L.o_ctl) + 8);
         if (threadIdx.x == 0) {
             const long long b = p.region_base_entries + (long long)(p.region_base_wg + (int)blockIdx.x) * p.region_entries;
@@ -827,8 +847,12 @@ __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kern
     if (p.fill_mode == 1) {
         n_work = p.fill_count;
         if (p.work_count_dev) { const int c = *p.work_count_dev; n_work = c < n_work ? c : n_work; }
-    } else if (p.big_count) {
+    } else if (p.big_count && !FAST) {
         c0 = p.big_count[0]; c1 = p.big_count[1]; c2 = p.big_count[2];
+        // behind a FAST launch only the pairs of bins 0 and 1 are left (smaller ball >= 128 nodes): bin 2 and every pair outside
+        // the bins have a smaller ball of < 128 nodes, which the FAST launch owns (TLC_BE_CAP = 128 >= TLC_X_BIN_MIN)
+        // (unless the early pass's candidate list overflowed: the candidates it could not hold are reached by index only)
+        if (p.fast_split && !p.x_fill && !(p.skip_count && *p.skip_count > p.skip_cap)) { c2 = 0; n_work = 0; }
         // (bin 3 -- what the lane-per-pair pass gave back -- is NOT taken here: that pass runs beside this one; a launch of its own
         // goes through that list afterwards, fill_mode 1)
         n_work += c0 + c1 + c2 + c3;
@@ -959,7 +983,7 @@ __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kern
                 npa1 = j + 64 < nA ? bc[a0 + j + 64] : -1;
                 pre_n = true;
             };
-            extract_pair<BW>(*q, i0, fr0, H0, xlds, slot, pre_ok, pb0, pa0, pa1, pf);
+            extract_pair<BW, FAST>(*q, i0, fr0, H0, xlds, slot, pre_ok, pb0, pa0, pa1, pf);
             if (!pf_done) pf();
             pre_ok = pre_n;
             pb0 = npb0; pa0 = npa0; pa1 = npa1;
@@ -999,7 +1023,7 @@ __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kern
             XHead H;
             H.u = u0; H.v = v0;
             bounds_of(q, H);
-            extract_pair<BW>(*q, i0, fr0, H, xlds, slot);
+            extract_pair<BW, FAST>(*q, i0, fr0, H, xlds, slot);
             i0 = i1; fr0 = fr1; u0 = u1; v0 = v1;
             i1 = i2; fr1 = fr2;
         }
@@ -1026,19 +1050,23 @@ __global__ __launch_bounds__(BW, BW == 64 ? TLC_X_WPE : 1) void tlc_extract_kern
     }
 }
 
-template __global__ void tlc_extract_kernel<64>(TlcVicParams);
-template __global__ void tlc_extract_kernel<512>(TlcVicParams);
+template __global__ void tlc_extract_kernel<64, false>(TlcVicParams);
+template __global__ void tlc_extract_kernel<64, true>(TlcVicParams);
+template __global__ void tlc_extract_kernel<512, false>(TlcVicParams);
 
-size_t tlc_extract_lds_bytes(int nw, int bw) { return x_layout(nw, bw == 64 ? XCfg<64>::SID_CAP : XCfg<512>::SID_CAP, bw).total; }
+size_t tlc_extract_lds_bytes(int nw, int bw, bool fast) { return x_layout(nw, bw == 64 ? XCfg<64>::SID_CAP : XCfg<512>::SID_CAP, bw, fast).total; }
 
-int tlc_launch_extract(int bw, int grid, size_t lds, const TlcVicParams& p, void* stream) {
+int tlc_launch_extract(int bw, int grid, size_t lds, const TlcVicParams& p, void* stream, bool fast) {
     if (grid <= 0) return TLC_OK;
-    if (bw == 64) {
-        if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_extract_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((tlc_extract_kernel<64>), dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
+    if (fast) {
+        if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_extract_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((tlc_extract_kernel<64, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
+    } else if (bw == 64) {
+        if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_extract_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((tlc_extract_kernel<64, false>), dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
     } else {
-        if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_extract_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((tlc_extract_kernel<512>), dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+        if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_extract_kernel<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((tlc_extract_kernel<512, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
     }
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;

@@ -190,6 +190,7 @@ struct TlcVicParams {
     const int* be_ptr;          // [n_nodes + 1]; be_ptr[x] == be_ptr[x + 1] for a node whose ball is larger
     const unsigned short* be_pos;
     const double* be_w;
+    int fast_split;             // 1: a launch of tlc_extract_kernel<64, true> takes the pairs the subgraph lists serve; this one leaves them alone
 };
 #define TLC_BE_CAP 128
 
@@ -378,8 +379,8 @@ int tlc_launch_pd_tiny(const TlcPdParams& p, void* stream);
 int tlc_launch_pdf_tier(int tier, const TlcPdfParams& p, void* stream);
 int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long* edge_offs, int* counts, int* tier_count,
                        int* tier_list, void* stream);
-size_t tlc_extract_lds_bytes(int nw, int bw);
-int tlc_launch_extract(int bw, int grid, size_t lds, const TlcVicParams& p, void* stream);
+size_t tlc_extract_lds_bytes(int nw, int bw, bool fast = false);
+int tlc_launch_extract(int bw, int grid, size_t lds, const TlcVicParams& p, void* stream, bool fast = false);
 int tlc_launch_classify(int n_pairs, const int* pairs, int n_nodes, const int* bptr, int cand_threshold, int cand_cap,
                         int* cand_count, int* cand_list, int* big_count, int* big_list, int xl_cut, int* xl_count, int* xl_list,
                         void* stream);
