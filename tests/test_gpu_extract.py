@@ -368,3 +368,39 @@ def test_graphs_of_several_hundred_thousand_nodes(N):
         nz = ref != 0
         assert rel_err(out[nz], ref[nz]).max() < 1e-8
     g.close()
+
+
+@pytest.mark.parametrize("shape,scale,hop,n_pos", [("PubMed", 0.35, 2, 5000), ("PubMed", 0.2, 2, 900), ("Photo", 0.2, 1, 5000), ("Computers", 0.1, 1, 4500)])
+def test_subgraph_list_extraction_equals_the_row_sweep(shape, scale, hop, n_pos):
+    """Round 5: a pair whose smaller ball has <= 128 nodes takes its vicinity from that ball's SUBGRAPH LIST (x_sweep_ball) instead
+    of sweeping the members' rows, in a launch of its own (tlc_extract_kernel<64, true>) when the batch has an early pass; the
+    LARGE tier runs its divide and conquer in place.  Against the row sweep (ball_edges=0): status bytes, |S| and entry counts
+    equal, images within 1e-12 (the entries of a vicinity come in another order); fast_split=0 (the same lists inside the general
+    launch) and dc_inplace=0 (tlc_pd_dc_kernel from the same record): the SAME bits.  Batches above and below the early pass's
+    minimum size, hop 1 and 2, sparse and dense graphs; and against the oracle."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    n, edges, kappa, _, _ = synth.shaped_graph(shape, scale=scale)
+    rowptr, col, w = synth.edges_to_csr(n, edges, kappa)
+    rs = np.random.RandomState(11)
+    pairs = _mixed_pairs(n, edges, rs, n_pos, n_pos // 4)
+    pairs = np.concatenate([pairs, np.array([[-1, 3], [n, 0]], dtype=np.int32)])
+    g = engine.DeviceGraph(rowptr, col, w)
+    new = _run(g, torch, pairs, hop)
+    sweep = _run(g, torch, pairs, hop, ball_edges=0)
+    one = _run(g, torch, pairs, hop, fast_split=0)
+    dck = _run(g, torch, pairs, hop, dc_inplace=0)
+    g.close()
+    for other, name, bits in ((sweep, "ball_edges=0", False), (one, "fast_split=0", True), (dck, "dc_inplace=0", True)):
+        assert np.array_equal(new[1], other[1]), name
+        assert np.array_equal(new[2], other[2]), name
+        assert np.array_equal(new[3], other[3]), name
+        if bits:
+            assert np.array_equal(new[0], other[0]), name
+        else:
+            assert np.abs(new[0] - other[0]).max() <= 1e-12 * max(1.0, np.abs(other[0]).max()), name
+    ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, hop, n_threads=0)
+    assert np.array_equal(new[1], rst)
+    nz = ref != 0
+    assert np.array_equal(new[0] == 0, ref == 0) and rel_err(new[0][nz], ref[nz]).max() < 1e-8
