@@ -160,22 +160,10 @@ def pdgnn_aux(torch, dev, n_graphs=41127, seed=1234):
     of BASELINE.json): graphs/s of each (device-resident inputs, median of 5)."""
     from tlc_gnn_amd import engine
     from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
-    rs = np.random.RandomState(seed)
-    ns = np.maximum(3, rs.poisson(25, size=n_graphs))
-    edges, fs, node_offs, edge_offs = [], [], [0], [0]
-    for n in ns:
-        par = np.array([rs.randint(0, k) for k in range(1, n)])
-        e = np.stack([par, np.arange(1, n)], 1)
-        extra = rs.randint(0, n, size=(int(rs.randint(0, 4)), 2))
-        extra = extra[extra[:, 0] != extra[:, 1]]
-        e = np.unique(np.sort(np.concatenate([e, extra]), 1), axis=0)
-        deg = np.bincount(e.ravel(), minlength=n).astype(np.float64)
-        fs.append(deg / (deg.max() + 1e-10))
-        edges.append(e)
-        node_offs.append(node_offs[-1] + n)
-        edge_offs.append(edge_offs[-1] + len(e))
-    f = np.concatenate(fs)
-    e_all = np.concatenate(edges).astype(np.int32)
+    from tlc_gnn_amd import synth
+    e_all, f, node_offs, edge_offs = synth.hiv_shaped_molecules(n_graphs, seed)
+    node_offs, edge_offs = node_offs.tolist(), edge_offs.tolist()
+    edges = [e_all[edge_offs[k]:edge_offs[k + 1]].astype(np.int64) for k in range(n_graphs)]
     d_no = torch.tensor(node_offs, dtype=torch.int64, device=dev)
     d_eo = torch.tensor(edge_offs, dtype=torch.int64, device=dev)
     d_e = torch.from_numpy(e_all).to(dev)

@@ -19,6 +19,7 @@ Fixtures:
   G4b kd_lp_filtration.npz  PDGNN LP vicinity: ids, f, induced edges  (Knowledge_Distillation/data_utils_LP.py:105-200)
   G6 kd_gc.npz           PDGNN ground-truth tuples, degree filtration (Knowledge_Distillation/data_utils_GC.py:98-166)
   G7 adj_split.npz       get_adj_split outputs, seed 1234         (loaddatas.py:38-54)
+  G7b adj_split_ppi.npz  get_adj_split with the PPI configuration's proportions (0.2 / 0.2), three graphs (baselines/TLCGNN.py:73-75)
   G8 variants.npz        descriptor 'min' / 'max' and norm=False of sg2dgm_accelerate: f[n] + image rows + exception class
                          (sg2dgm/riccidist2dgm.py:20-61,310-329)
   G4e kd_hks.npz         filt='hks' (the signatures' default): data_utils_GC :114-116 (times 0.1 / 10), data_utils_NC :120-122, data_utils_LP
@@ -505,6 +506,31 @@ def make_g7(mods):
     print("G7 sizes:", [len(p) for p in parts])
 
 
+# ----------------------------------------------------------------------------------------------- G7b
+def make_g7b(mods):
+    """The PPI configuration's split (baselines/TLCGNN.py:73-75: val_prop = test_prop = 0.2) of get_adj_split, on three small
+    PPI-shaped graphs (the reference loops over PPI's 20 graphs, pipelines.py:81-111), seed 1234 as everywhere."""
+    import scipy.sparse as sp
+    lds = mods["lds"]
+    if lds is None:
+        print("G7b skipped")
+        return
+    from tlc_gnn_amd import synth
+    out = {}
+    for gi, (n, m, seed) in enumerate(((260, 1900, 21), (300, 2600, 22), (220, 1500, 23))):
+        edges = synth.holme_kim_edges(n, m, triad_p=0.5, seed=seed)
+        a = sp.coo_matrix((np.ones(len(edges)), (edges[:, 0], edges[:, 1])), shape=(n, n))
+        adj = sp.csr_matrix(a + a.T)
+        parts = lds.get_adj_split(adj, val_prop=0.2, test_prop=0.2, seed=1234)
+        names = ["train_edges", "train_edges_false", "val_edges", "val_edges_false", "test_edges", "test_edges_false"]
+        out["g%d_n_nodes" % gi] = n
+        out["g%d_edges" % gi] = edges
+        for k, v in zip(names, parts):
+            out["g%d_%s" % (gi, k)] = np.asarray(v, dtype=np.int64)
+        print("G7b graph %d sizes:" % gi, [len(p) for p in parts])
+    np.savez_compressed(os.path.join(HERE, "adj_split_ppi.npz"), n_graphs=3, **out)
+
+
 # ----------------------------------------------------------------------------------------------- G8 / G4c
 def make_g8(mods):
     """descriptor 'min' / 'max' (and 'sum') with norm=True, and norm=False, of sg2dgm_accelerate on the G5 graph: the node
@@ -812,12 +838,12 @@ def make_g4e(mods):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true", help="also time the reference on the PubMed-shaped graph")
-    ap.add_argument("--only", default="", help="regenerate a single fixture (g4b | g8 | g4c | g4d | g4e | g10)")
+    ap.add_argument("--only", default="", help="regenerate a single fixture (g4b | g7b | g8 | g4c | g4d | g4e | g10)")
     args = ap.parse_args()
     assert sys.version_info[:2] < (3, 12), "python>=3.12 sums with compensation: goldens would differ (SURVEY A.2)"
     mods = import_reference()
     if args.only:
-        {"g4b": make_g4b, "g8": make_g8, "g4c": make_g4c, "g4d": make_g4d, "g4e": make_g4e, "g10": make_g10}[args.only](mods)
+        {"g4b": make_g4b, "g7b": make_g7b, "g8": make_g8, "g4c": make_g4c, "g4d": make_g4d, "g4e": make_g4e, "g10": make_g10}[args.only](mods)
         return
     make_g1_g2(mods)
     make_g3(mods)
@@ -825,6 +851,7 @@ def main():
     make_g4b(mods)
     make_g6(mods)
     make_g7(mods)
+    make_g7b(mods)
     make_g8(mods)
     make_g4c(mods)
     make_g4d(mods)

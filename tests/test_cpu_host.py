@@ -62,6 +62,20 @@ def test_get_adj_split_matches_reference_golden_g7():
         assert np.array_equal(np.asarray(p), d[name]), name
 
 
+def test_get_adj_split_ppi_proportions_match_reference_golden_g7b():
+    """The PPI configuration's split (val_prop = test_prop = 0.2, baselines/TLCGNN.py:73-75) on the three graphs of golden G7b."""
+    import scipy.sparse as sp
+    from tlc_gnn_amd import loaddatas
+    d = np.load(os.path.join(G, "adj_split_ppi.npz"))
+    names = ["train_edges", "train_edges_false", "val_edges", "val_edges_false", "test_edges", "test_edges_false"]
+    for gi in range(int(d["n_graphs"])):
+        n, edges = int(d["g%d_n_nodes" % gi]), d["g%d_edges" % gi]
+        a = sp.coo_matrix((np.ones(len(edges)), (edges[:, 0], edges[:, 1])), shape=(n, n))
+        parts = loaddatas.get_adj_split(sp.csr_matrix(a + a.T), val_prop=0.2, test_prop=0.2, seed=1234)
+        for name, p in zip(names, parts):
+            assert np.array_equal(np.asarray(p), d["g%d_%s" % (gi, name)]), (gi, name)
+
+
 def test_remove_pairs_both_directions_like_list_remove():
     import torch
     from tlc_gnn_amd.baselines.TLCGNN import remove_pairs_both_directions

@@ -192,3 +192,66 @@ def test_pipelines_test_and_train_forward():
         model.decode(data, torch.zeros(n, 16, device="cuda"))
     model.eval()
     model.decode(data, model.encode(data), "val")               # eval mode needs no no_grad()
+
+
+def test_tlcgnn_call_ppi_configuration_over_several_graphs():
+    """BASELINE config 4 on one GPU: TLCGNN.call(data, 'PPI', ...) looped over graphs as pipelines.py:81-111 does -- the 'PPI'
+    branches of call (val_prop = test_prop = 0.2, baselines/TLCGNN.py:73-75; the image cache named per graph, :104-105; hop 1,
+    :102), 50 node features.  The split == the imported reference's get_adj_split on the same graphs (golden G7b,
+    tests/golden/adj_split_ppi.npz), the image rows == the CPU oracle on the training graph, Net.encode (F = 50) and
+    Net.decode('val' / 'test') == the torch restatement within 1e-5."""
+    import tempfile
+    import torch
+    from tlc_gnn_amd import synth, pipelines
+    from tlc_gnn_amd.baselines import TLCGNN
+    from tlc_gnn_amd.data import Data
+    from oracle import oracle, lp_forward_ref as ref
+    d = np.load(os.path.join(G, "adj_split_ppi.npz"))
+    F_ = 50
+    cwd = os.getcwd()
+    for gi in range(int(d["n_graphs"])):
+        n, edges = int(d["g%d_n_nodes" % gi]), d["g%d_edges" % gi]
+        ei = torch.from_numpy(np.concatenate([edges, edges[:, ::-1]]).T.copy()).long()
+        data = Data(x=torch.from_numpy(synth.synthetic_features(n, F_, seed=30 + gi)), edge_index=ei, y=torch.zeros(n, dtype=torch.long))
+        data.ricci_list = synth.synthetic_curvature(edges, seed=40 + gi)
+        pipelines.setup_seed(gi)
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                model, data = TLCGNN.call(data, "PPI", F_, 2, gi)
+            finally:
+                os.chdir(cwd)
+        names = ["train_edges", "train_edges_false", "val_edges", "val_edges_false", "test_edges", "test_edges_false"]
+        want_total = np.concatenate([d["g%d_%s" % (gi, k)] for k in names])
+        assert np.array_equal(np.asarray(data.total_edges.cpu() if hasattr(data.total_edges, "cpu") else data.total_edges), want_total), gi
+        m = len(edges)
+        assert (data.val_pos, data.test_pos, data.train_pos) == (int(m * 0.2), int(m * 0.2), m - 2 * int(m * 0.2))
+        assert (data.train_neg, data.val_neg, data.test_neg) == tuple(len(d["g%d_%s" % (gi, k)]) for k in names[1::2])
+        assert data.edge_index.shape[1] == 2 * data.train_pos                 # the val / test positives are gone, both directions
+        # image rows: hop 1 on the training graph, against the oracle
+        tr = d["g%d_train_edges" % gi]
+        kap = {(int(a), int(b)): float(k) for a, b, k in data.ricci_list}
+        und = np.unique(np.sort(tr, axis=1), axis=0)
+        rowptr, col, w = synth.edges_to_csr(n, und, np.array([kap[(int(a), int(b))] for a, b in und.tolist()]))
+        sel = np.concatenate([np.arange(0, 400), np.arange(len(want_total) - 400, len(want_total))])
+        want_pi, want_st, _ = oracle.pd_pi_batch(rowptr, col, w, want_total[sel].astype(np.int32), 1, n_threads=0)
+        got_pi = np.asarray(model.PI)[sel]
+        nz = want_pi != 0
+        assert np.array_equal(got_pi == 0, want_pi == 0), gi
+        assert (np.abs(got_pi[nz] - want_pi[nz]) / np.abs(want_pi[nz])).max() < 1e-8, gi
+        assert (np.abs(np.asarray(model.PI)[:data.train_pos]).sum(1) > 0).mean() > 0.3
+        # forward: F = 50 encode, decode of the val and test slices
+        model.apply(pipelines.weights_init)
+        model = model.cuda().eval()
+        wts = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            emb = model.encode(data)
+            emb_ref = ref.tlcgnn_encode(data.x.cpu(), data.edge_index.cpu(), wts["conv1.weight"], wts["conv1.bias"], wts["conv2.weight"], wts["conv2.bias"])
+            assert torch.allclose(emb.cpu(), emb_ref, rtol=1e-5, atol=1e-6), gi
+            tp, tn, vp, vn = data.train_pos, data.train_neg, data.val_pos, data.val_neg
+            for kind, lo, hi in (("val", tp + tn, tp + tn + vp + vn), ("test", tp + tn + vp + vn, len(want_total))):
+                prob, y = model.decode(data, emb.clone(), kind)
+                p = ref.tlcgnn_decode(emb_ref.clone(), torch.from_numpy(want_total[lo:hi]), torch.from_numpy(np.asarray(model.PI)[lo:hi]),
+                                      wts["linear_1.weight"], wts["linear_1.bias"], wts["linear.weight"], wts["linear.bias"])
+                assert torch.allclose(prob.cpu(), p, rtol=1e-5, atol=1e-6), (gi, kind)
+                assert y.shape[0] == hi - lo and float(y.sum()) == (vp if kind == "val" else data.test_pos)

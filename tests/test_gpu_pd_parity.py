@@ -603,3 +603,28 @@ def test_variant_flags_through_the_early_and_handoff_paths(torch_cuda, res):
         assert rel_err(out[nz], ref[nz]).max() < 1e-8
     assert seen_large
     g.close()
+
+
+def test_hiv_sized_batch_of_molecule_graphs_vs_oracle(torch_cuda):
+    """BASELINE config 5 at its real size outside bench.py: 41 127 HIV-shaped molecule graphs (synth.hiv_shaped_molecules, the batch of
+    bench.py's pdgnn block; Knowledge_Distillation/data_utils_GC.py:98-170, degree filtration) in ONE tlc_pd_from_filtration call,
+    both forks' flags: the counts of every graph equal the oracle's, and the diagrams of 2 000 graphs spread over the batch --
+    Ord0 / Rel1 / Ext0 / Ext1 -- are the oracle's as sorted multisets, bit for bit."""
+    torch = torch_cuda
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    edges, f, node_offs, edge_offs = synth.hiv_shaped_molecules(41127, 1234)
+    assert len(node_offs) == 41128 and node_offs[-1] > 1000000
+    d_no, d_eo = _dev(torch, node_offs, torch.int64), _dev(torch, edge_offs, torch.int64)
+    d_e, d_f = _dev(torch, edges, torch.int32), _dev(torch, f, torch.float64)
+    check = np.random.RandomState(0).permutation(41127)[:2000]
+    for flags in (0, engine.KEEP_ZERO_PERS):
+        ref = oracle.pd_from_filtration(node_offs, edge_offs, edges, f, flags)
+        got = {k: v.cpu().numpy() for k, v in engine.pd_from_filtration(d_no, d_eo, d_e, d_f, flags).items()}
+        assert np.array_equal(got["counts"], ref["counts"]), flags
+        assert np.array_equal(got["ext0"], ref["ext0"]), flags
+        for gph in check.tolist():
+            no, eo = node_offs[gph], edge_offs[gph]
+            c = ref["counts"][gph]
+            for key, base, cnt in (("up", no, c[0]), ("down", no, c[1]), ("one", eo, c[2])):
+                assert same_multiset(got[key][base:base + cnt], ref[key][base:base + cnt]), (flags, gph, key)

@@ -103,13 +103,14 @@ def pd_pi_batch_sharded(run, pairs, world, rank, cost=None, gather=None, scheme=
     return gather(rows, bounds), gather(status, bounds), (lo, hi)
 
 
-def gather_shards_indexed(local, parts, group=None):
+def gather_shards_indexed(local, parts, group=None, always_collective=False):
     """Interleaved shards -> the whole array in list order on every rank: ONE all_gather_into_tensor over blocks padded to the
-    largest shard, then every block is scattered to its rows' list positions (parts[r] = the positions of rank r's rows)."""
+    largest shard, then every block is scattered to its rows' list positions (parts[r] = the positions of rank r's rows).
+    always_collective: a one-rank group goes through the collective too (the RCCL test on the one-GPU box)."""
     import torch
     import torch.distributed as dist
     world = len(parts)
-    if world == 1:
+    if world == 1 and not always_collective:
         return local
     sizes = [len(p) for p in parts]
     blk = max(max(sizes), 1)

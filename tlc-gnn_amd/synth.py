@@ -127,3 +127,25 @@ def shaped_graph(name="PubMed", seed=1234, scale=1.0):
     edges = holme_kim_edges(n, m, triad_p=tp, seed=seed)
     kappa = curvature_array(edges, seed=seed)
     return n, edges, kappa, hop, f
+
+
+def hiv_shaped_molecules(n_graphs=41127, seed=1234):
+    """As many small sparse graphs as ogbg-molhiv holds (41 127, Knowledge_Distillation/data_utils_GC.py:284; config 5 of
+    BASELINE.json): a random tree of ~25 nodes plus up to three extra edges each, degree filtration normalised per graph
+    (data_utils_GC.py:118-121).  Returns (edges int32 [M,2] in graph-local ids, f float64 [N], node_offs, edge_offs int64)."""
+    rs = np.random.RandomState(seed)
+    ns = np.maximum(3, rs.poisson(25, size=n_graphs))
+    edges, fs, node_offs, edge_offs = [], [], [0], [0]
+    for n in ns:
+        par = np.array([rs.randint(0, k) for k in range(1, n)])
+        e = np.stack([par, np.arange(1, n)], 1)
+        extra = rs.randint(0, n, size=(int(rs.randint(0, 4)), 2))
+        extra = extra[extra[:, 0] != extra[:, 1]]
+        e = np.unique(np.sort(np.concatenate([e, extra]), 1), axis=0)
+        deg = np.bincount(e.ravel(), minlength=n).astype(np.float64)
+        fs.append(deg / (deg.max() + 1e-10))
+        edges.append(e)
+        node_offs.append(node_offs[-1] + n)
+        edge_offs.append(edge_offs[-1] + len(e))
+    return (np.concatenate(edges).astype(np.int32), np.concatenate(fs), np.asarray(node_offs, dtype=np.int64),
+            np.asarray(edge_offs, dtype=np.int64))
