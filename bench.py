@@ -112,9 +112,10 @@ def measure_traffic():
 
 
 def measure_issue():
-    """roofline_issue measured INSIDE this run: one more child pass of this script under `rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS
-    SQ_INSTS_SALU` (counters only, program directly behind `--`), 3 batches; -> (dict of wave-instructions per image batch summed
-    over the PD/PI kernels, detail) or (None, reason).  Called BEFORE this process touches the GPU, like measure_traffic."""
+    """roofline_issue measured INSIDE this run: two more child passes of this script under `rocprofv3 --pmc` (counters only, program
+    directly behind `--`), 3 batches each -- SQ_INSTS_VALU / _LDS / _SALU, then SQ_INSTS (every instruction) / _SMEM / _VMEM_RD /
+    _VMEM_WR / _BRANCH; -> (dict of wave-instructions per image batch summed over the PD/PI kernels, detail) or (None, reason).
+    Called BEFORE this process touches the GPU, like measure_traffic."""
     import csv, glob, shutil, signal, subprocess, tempfile
     exe = shutil.which("rocprofv3")
     if exe is None:
@@ -122,33 +123,45 @@ def measure_issue():
     tmp = tempfile.mkdtemp(prefix="tlc_pmc_issue_")
     env = dict(os.environ, TLC_BENCH_CHILD="1")
     try:
-        cmd = [exe, "--pmc", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "--output-format", "csv", "-d", os.path.join(tmp, "issue"), "--",
-               sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-sweep"]
-        pr = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
-        try:
-            rc = pr.wait(timeout=240)
-        except subprocess.TimeoutExpired:
-            os.killpg(pr.pid, signal.SIGKILL)
-            pr.wait()
-            return None, "the SQ_INSTS pass timed out"
-        if rc != 0:
-            return None, "the SQ_INSTS pass failed (rc %d)" % rc
-        tot, per_kernel, scans = {}, {}, 0
-        for f in glob.glob(os.path.join(tmp, "issue") + "/**/*counter_collection.csv", recursive=True):
-            for row in csv.DictReader(open(f)):
-                k, c = row["Kernel_Name"], row.get("Counter_Name")
-                if not k.startswith(("tlc_", "void tlc_")) or "tlc_pi_raster" in k or "ball_" in k:
-                    continue                                      # (the image batch's kernels; the one-off ball lists are set-up)
-                v = float(row["Counter_Value"])
-                tot[c] = tot.get(c, 0.0) + v
-                per_kernel.setdefault(k[:60], {}).setdefault(c, 0.0)
-                per_kernel[k[:60]][c] += v
-                if c == "SQ_INSTS_VALU" and "tlc_scan_bin" in k:
-                    scans += 1
-        if not tot or scans == 0:
-            return None, "no counter rows collected"
-        return {c: v / scans for c, v in tot.items()}, {"batches_in_pass": scans,
-                                                        "per_kernel_valu": {k: v.get("SQ_INSTS_VALU", 0.0) / scans for k, v in per_kernel.items()}}
+        out, per_kernel_valu, batches = {}, {}, 0
+        for pi_, counters in enumerate((("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU"),
+                                        ("SQ_INSTS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH"))):
+            sub = os.path.join(tmp, "issue%d" % pi_)
+            cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", sub, "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-sweep"]
+            pr = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                return (out or None), ("the %s pass timed out" % counters[0] if not out else {"batches_in_pass": batches, "per_kernel_valu": per_kernel_valu,
+                                                                                               "second_pass": "timed out"})
+            if rc != 0:
+                if out:
+                    return out, {"batches_in_pass": batches, "per_kernel_valu": per_kernel_valu, "second_pass": "failed (rc %d)" % rc}
+                return None, "the %s pass failed (rc %d)" % (counters[0], rc)
+            tot, per_kernel, scans = {}, {}, 0
+            for f in glob.glob(sub + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k, c = row["Kernel_Name"], row.get("Counter_Name")
+                    if not k.startswith(("tlc_", "void tlc_")) or "tlc_pi_raster" in k or "ball_" in k:
+                        continue                                      # (the image batch's kernels; the one-off ball lists are set-up)
+                    v = float(row["Counter_Value"])
+                    tot[c] = tot.get(c, 0.0) + v
+                    per_kernel.setdefault(k[:60], {}).setdefault(c, 0.0)
+                    per_kernel[k[:60]][c] += v
+                    if c == counters[0] and "tlc_scan_bin" in k:
+                        scans += 1
+            if not tot or scans == 0:
+                if out:
+                    return out, {"batches_in_pass": batches, "per_kernel_valu": per_kernel_valu, "second_pass": "no counter rows"}
+                return None, "no counter rows collected"
+            out.update({c: v / scans for c, v in tot.items()})
+            if pi_ == 0:
+                batches = scans
+                per_kernel_valu = {k: v.get("SQ_INSTS_VALU", 0.0) / scans for k, v in per_kernel.items()}
+        return out, {"batches_in_pass": batches, "per_kernel_valu": per_kernel_valu}
     except Exception as ex:
         return None, repr(ex)
     finally:
@@ -997,6 +1010,22 @@ def main():
                               "frac_valu_of_measured_rate": valu / (1.33 * (simds / 4) * clk * per_batch_s),
                               "frac_salu_of_measured_rate": float(pre_issue.get("SQ_INSTS_SALU", 0.0)) / (0.86 * (simds / 4) * clk * per_batch_s),
                               "per_kernel_valu_wave_insts": pre_issue_detail["per_kernel_valu"],
+                              # every instruction class (second counter pass): SQ_INSTS counts all wave-instructions; the classes do
+                              # not share one issue port (a SIMD issues up to one instruction PER CLASS per cycle, from different
+                              # wavefronts), so this fraction is an upper bound of how full any one port can be
+                              "all_wave_insts_per_batch": pre_issue.get("SQ_INSTS"),
+                              "smem_wave_insts_per_batch": pre_issue.get("SQ_INSTS_SMEM"),
+                              "vmem_rd_wave_insts_per_batch": pre_issue.get("SQ_INSTS_VMEM_RD"),
+                              "vmem_wr_wave_insts_per_batch": pre_issue.get("SQ_INSTS_VMEM_WR"),
+                              "branch_wave_insts_per_batch": pre_issue.get("SQ_INSTS_BRANCH"),
+                              "frac_all_classes": (float(pre_issue["SQ_INSTS"]) * 4.0 / (simds * clk * per_batch_s)) if pre_issue.get("SQ_INSTS") else None,
+                              "second_pass": pre_issue_detail.get("second_pass", "ok"),
+                              # tools/probes/mix_probe.hip (profiles/r05_mix_probe.txt): a loop with the extraction's own instruction mix
+                              # issues 0.37 / 0.73 / 1.30 / 1.72 wave-instructions per cycle and CU at 1 / 2 / 4 / 8 wavefronts per SIMD --
+                              # the CU's ceiling for such code is ~1.75, and below ~6 wavefronts per SIMD the rate is latency, not a port
+                              "measured_mix_ceiling_per_cycle_and_cu": 1.75,
+                              "all_classes_per_cycle_and_cu": (float(pre_issue["SQ_INSTS"]) / ((simds / 4) * clk * per_batch_s)) if pre_issue.get("SQ_INSTS") else None,
+                              "frac_all_classes_of_measured_ceiling": (float(pre_issue["SQ_INSTS"]) / (1.75 * (simds / 4) * clk * per_batch_s)) if pre_issue.get("SQ_INSTS") else None,
                               "note": "share of the machine's vector issue slots the image leg uses in the timed region (pipelined) / for one "
                                       "batch alone; the rest is dependent-latency time (LDS / L2 round trips of serial graph code)"}
         else:
@@ -1034,6 +1063,12 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms_one_batch_alone": warm_avg.get(dom, -1.0),
+                         # busy time of the chain (review of round 4: the span of a two-kernel chain held the queueing between its
+                         # kernels).  Since round 5 the LARGE tier runs its divide and conquer in place: the chain IS one kernel, and the
+                         # events bracket that one launch on the stream it runs on.
+                         "kernel_busy_ms": kavg[dom], "chain_kernels": 1 if dom == "pd_tier_large" else None,
+                         "batches_in_flight": 1 if args.sync_batches else 3,
+                         "busy_within_batches_in_flight": bool(kavg[dom] <= (t_pi / K * 1e3) * (1 if args.sync_batches else 3)),
                          "note": "kernel_ms: this kernel chain's launches INSIDE the timed region, where three batches are in flight and "
                                  "its whole-CU workgroups wait for room among the other batches' kernels; kernel_ms_one_batch_alone: "
                                  "the same chain in a stream-ordered batch with the machine to itself (warm-up steps)"},
