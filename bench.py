@@ -216,7 +216,23 @@ def pdgnn_aux(torch, dev, n_graphs=41127, seed=1234):
         pd_ms = med_ms(lambda: model(x, ei, None, compute_loss=False, grad_PI=False, graph_ptr=gptr, edge_ptr=d_eptr, csr=gb))
         pd_build_ms = med_ms(lambda: model(x, ei, None, compute_loss=False, grad_PI=False, graph_ptr=gptr, edge_ptr=d_eptr))
         csr_ms = med_ms(lambda: GraphBatch(ei, n_tot))
-    return {"graphs": int(n_graphs), "nodes": int(n_tot), "edges": int(len(e_all)),
+    # roofline of the forward (review of round 4, item 3): algorithmic bytes per layer from DESIGN.md's formula
+    # 4n(c_in + 3C + 4) + nnz(4 + 4(C + 1)) + 8nC (node rows in, [P|Q|alpha] out and gathered per in-edge, the 2C-wide output), the
+    # edge head 4n(c + 2h) + E(8 + 8h + 8), the raster 16 per point + 8 res^2 per graph; f32 MFMA flops of the node products
+    nnz = int(ei.shape[1])
+    E_dir = int(2 * len(e_all))
+    layers = [(1, 32), (64, 32), (64, 32), (64, 16)]
+    lay_bytes = [4.0 * n_tot * (ci + 3 * C_ + 4) + nnz * (4.0 + 4.0 * (C_ + 1)) + 8.0 * n_tot * C_ for ci, C_ in layers]
+    head_bytes = 4.0 * n_tot * (32 + 2 * 32) + E_dir * (8.0 + 8.0 * 32 + 8.0)
+    raster_bytes = 16.0 * len(e_all) + 8.0 * 25 * n_graphs
+    alg_bytes = sum(lay_bytes) + head_bytes + raster_bytes
+    flops = sum(2.0 * n_tot * ci * (2 * C_ + 1) for ci, C_ in layers[1:]) + 2.0 * n_tot * 32 * 64
+    roof = {"bound": "hbm", "algorithmic_bytes": alg_bytes, "bytes_per_layer": lay_bytes, "edge_head_bytes": head_bytes,
+            "achieved": alg_bytes / (pd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (pd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "node_product_flops": flops, "node_product_time_at_f32_mfma_peak_ms": flops / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3,
+            "note": "whole forward (4 layers + edge head + raster) against HBM; the f32 node products alone would take the time given at the "
+                    "157.3 TF f32 MFMA peak; per-kernel durations: profiles/r05_pdgnn_kernel_stats*.csv"}
+    return {"graphs": int(n_graphs), "nodes": int(n_tot), "edges": int(len(e_all)), "roofline_pdgnn": roof,
             "pdgnn_forward_graphs_per_sec": n_graphs / (pd_ms * 1e-3), "pdgnn_forward_ms": pd_ms,
             "pdgnn_forward_ms_with_csr_build": pd_build_ms, "csr_by_target_build_ms": csr_ms,
             "exact_pd_graphs_per_sec": n_graphs / (exact_ms * 1e-3), "exact_pd_ms": exact_ms,

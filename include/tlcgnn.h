@@ -289,6 +289,18 @@ int tlc_gat_layer_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d
                       const float* d_X, int32_t c_in, int32_t c_out,
                       const float* d_Wl, const float* d_att, const float* d_Wij, const float* d_bias,
                       float prelu_slope, float* d_work, float* d_out, void* stream);
+/* The same layer on a BLOCK-DIAGONAL batch cut into self-contained tiles (round 5; gat_forward.hip, gat_tile_kernel): d_tile_ptr
+ * int32[n_tiles + 1] = node offsets of tiles of at most 192 consecutive nodes such that every in-edge of a node has its source in the
+ * node's own tile (a batch of small graphs cut at positions no edge crosses: Knowledge_Distillation/gat_conv.py, GraphBatch).  The node
+ * rows [P | Q | alpha] are computed on the f32 MFMA into LDS and aggregated from there: they never reach HBM.  c_in = 1 or 64 with
+ * c_out = 32 or 16 (the PDGNN layers of Teacher_model.py:182-189); other shapes: TLC_ERR_UNSUPPORTED (take tlc_gat_layer_fwd).
+ * d_work: float32[c_in*c_out + c_out*(2*c_out + 4) + c_in*(2*c_out + 4) + 2*c_out + 8].  Results equal tlc_gat_layer_fwd's up to the
+ * rounding of fp32 sums. */
+int tlc_gat_layer_tiled_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_src, int32_t n_tiles,
+                            const int32_t* d_tile_ptr, const float* d_X, int32_t c_in, int32_t c_out,
+                            const float* d_Wl, const float* d_att, const float* d_Wij, const float* d_bias,
+                            float prelu_slope, float* d_work, float* d_out, void* stream);
+
 
 /* ---- the diagram loss of PDGNN training ------------------------------------------------------------
  * `wasserstein_distance(X, Y, order=p, internal_p=inf, enable_autodiff=True, num_models=1)` of

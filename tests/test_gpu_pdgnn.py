@@ -433,3 +433,65 @@ def test_vicinity_batch_exact_offsets_equal_the_capacity_layout():
                                                             oracle.INCLUDE_ROOTS | oracle.NORM_EPS | oracle.UNREACHABLE_100, cap=n)
         ok = o_st == 0
         assert np.array_equal(n_dev.cpu().numpy()[ok], o_n[ok]) and np.array_equal(m_dev.cpu().numpy()[ok], o_m[ok]) and ok.sum() > 1500
+
+
+def test_tiled_gat_layer_equals_the_two_kernel_layer():
+    """Round 5: tlc_gat_layer_tiled_fwd (a block-diagonal batch cut into self-contained tiles, the node rows [P | Q | alpha] in LDS,
+    gat_forward.hip gat_tile_kernel) against tlc_gat_layer_fwd on the same batch -- the four layer shapes of the PDGNN stack
+    (c_in 1 / 64, C 32 / 16), with and without the fused PReLU, on HIV-shaped molecules (thousands of tiles), on a batch with dense
+    graphs (nodes of more than eight in-edges, tiles whose in-edges exceed the staged 2 048 slots) and on empty-ish corners; and the
+    cut itself: no edge crosses a tile boundary, no tile is larger than 192 nodes.  One big connected graph gets no tiles."""
+    import torch
+    from tlc_gnn_amd import ops, synth
+    from tlc_gnn_amd.Knowledge_Distillation.gat_conv import GraphBatch
+    dev = torch.device("cuda")
+    rs = np.random.RandomState(4)
+
+    def block_batch(graphs):
+        offs, parts = 0, []
+        for nn, e in graphs:
+            parts.append(e + offs)
+            offs += nn
+        e = np.concatenate(parts)
+        both = np.concatenate([e, e[:, ::-1]])
+        loops = np.arange(offs)
+        return offs, torch.from_numpy(np.concatenate([both, np.stack([loops, loops], 1)]).T.copy()).to(dev)
+
+    # (a) molecules
+    e_all, f, node_offs, edge_offs = synth.hiv_shaped_molecules(3000, 7)
+    mol = [(int(node_offs[k + 1] - node_offs[k]), e_all[edge_offs[k]:edge_offs[k + 1]].astype(np.int64)) for k in range(3000)]
+    # (b) dense little graphs: 40 - 90 nodes, ~12 edges per node
+    dense = []
+    for _ in range(60):
+        nn = int(rs.randint(40, 90))
+        e = rs.randint(0, nn, size=(nn * 12, 2))
+        e = np.unique(np.sort(e[e[:, 0] != e[:, 1]], 1), axis=0)
+        dense.append((nn, e))
+    for name, graphs in (("molecules", mol), ("dense", dense), ("mixed", dense[:5] + mol[:40] + dense[5:9])):
+        n, ei = block_batch(graphs)
+        gb = GraphBatch(ei, n)
+        assert gb.tiles is not None, name
+        tiles = gb.tiles.cpu().numpy()
+        assert tiles[0] == 0 and tiles[-1] == n and (np.diff(tiles) > 0).all() and np.diff(tiles).max() <= 192, name
+        s_, t_ = ei.cpu().numpy()
+        assert np.array_equal(np.searchsorted(tiles, s_, side="right"), np.searchsorted(tiles, t_, side="right")), name
+        for c_in, C_ in ((1, 32), (64, 32), (64, 16)):
+            g = torch.Generator().manual_seed(c_in + C_)
+            x = (torch.randn(n, c_in, generator=g) * 0.7).to(dev)
+            wl = (torch.randn(C_, c_in, generator=g) * 0.4).to(dev)
+            att = (torch.randn(C_, generator=g) * 0.4).to(dev)
+            wij = (torch.randn(C_, 2 * C_, generator=g) * 0.3).to(dev)
+            bias = (torch.randn(2 * C_, generator=g) * 0.1).to(dev)
+            for slope in (-1.0, 0.1):
+                want = ops.gat_layer(gb.rowptr, gb.col, x, wl, att, wij, bias, prelu_slope=slope)
+                got = ops.gat_layer_tiled(gb.rowptr, gb.col, gb.tiles, x, wl, att, wij, bias, prelu_slope=slope)
+                torch.cuda.synchronize()
+                err = (got - want).abs()
+                # (two fp32 evaluations in different summation orders: the bar is relative to the row's scale -- a dense graph's
+                # node sums two dozen terms of either sign)
+                scale = want.abs().amax(dim=1, keepdim=True).clamp_(min=1.0)
+                assert bool((err <= 1e-5 * scale).all()), (name, c_in, C_, slope, float(err.max()))
+    # one big connected graph: no cut closer than 128 nodes -> no tiles, the two-kernel layer serves it
+    ring = np.stack([np.arange(2000), (np.arange(2000) + 1) % 2000], 1)
+    n, ei = block_batch([(2000, ring)])
+    assert GraphBatch(ei, n).tiles is None

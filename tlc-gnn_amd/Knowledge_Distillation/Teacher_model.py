@@ -55,9 +55,9 @@ class Base_Model(torch.nn.Module):
         # same points and on tensors of the same shapes as the reference, so the same seed draws the same masks
         drop = (lambda t: F.dropout(t, p=self.dropout, training=True)) if (self.training and self.dropout > 0) else (lambda t: t)
         if csr is None:
-            csr = GATConv.csr_by_target(edge_index, x.shape[0])        # one CSR for the four layers of THIS call
+            csr = GraphBatch(edge_index, x.shape[0])                   # one CSR (and tile cut) for the four layers of THIS call
         elif isinstance(csr, GraphBatch):
-            csr = csr.check(edge_index, x.shape[0])
+            csr.check(edge_index, x.shape[0])                          # (handed down whole: the layers take its tiles)
         x = self.conv1(drop(x), edge_index, prelu_slope=0.1, csr=csr)  # conv -> F.prelu(0.1) fused (:218-219)
         x = self.conv2(drop(x), edge_index, prelu_slope=0.1, csr=csr)
         x = self.conv4(drop(x), edge_index, prelu_slope=0.1, csr=csr)
@@ -103,8 +103,11 @@ class Teacher_Model(torch.nn.Module):
         x = self.DIM0_Model(x0, edge_index0, csr=csr)
         n = x0.shape[0]
         m = edge_index0.shape[1] - n
-        src = edge_index0[0, :m].to(torch.int32).contiguous()         # strips the appended self loops (:54-55)
-        dst = edge_index0[1, :m].to(torch.int32).contiguous()
+        if isinstance(csr, GraphBatch):
+            src, dst = csr.edge_ends(m)                               # (int32 copies made once per batch, like its CSR)
+        else:
+            src = edge_index0[0, :m].to(torch.int32).contiguous()     # strips the appended self loops (:54-55)
+            dst = edge_index0[1, :m].to(torch.int32).contiguous()
         if self.training and self.dropout > 0:
             # :56-59 with the dropout mask between the head's two GEMMs: the fused kernel (tlc_edge_head) has no place for it, so this
             # one case runs lin5 -> prelu -> F.dropout -> lin6 as separate device ops (torch's linear = rocBLAS; its autograd)

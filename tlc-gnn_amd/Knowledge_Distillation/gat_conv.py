@@ -30,9 +30,20 @@ class GraphBatch:
     tensor's storage cannot pass to another tensor, and compares its `_version` (in-place edits) -- `check()` raises on a
     different or edited tensor instead of silently using a stale structure."""
 
-    def __init__(self, edge_index, n):
+    def __init__(self, edge_index, n, tiled=True):
         self.edge_index, self.n, self.version = edge_index, int(n), edge_index._version
         self.rowptr, self.col = GATConv.csr_by_target(edge_index, n)
+        # a batch of small graphs is cut into self-contained tiles (ops.gat_tiles): its layers then run as one kernel each with the
+        # node rows in LDS (tlc_gat_layer_tiled_fwd); None for a batch without close enough cuts (one big graph)
+        self.tiles = ops.gat_tiles(self.rowptr, self.col, self.n) if (tiled and edge_index.is_cuda) else None
+
+    def edge_ends(self, m):
+        """int32 (src, dst) of the first m edges -- the batch without the self loops appended last (train_Teacher_Model.py:43-44,
+        Teacher_model.py:54-55): the edge head's operands, converted once per batch instead of once per forward."""
+        if getattr(self, "_ends", None) is None or self._ends[0] != m:
+            ei = self.edge_index
+            self._ends = (m, ei[0, :m].to(torch.int32).contiguous(), ei[1, :m].to(torch.int32).contiguous())
+        return self._ends[1], self._ends[2]
 
     def check(self, edge_index, n):
         if edge_index is not self.edge_index or edge_index._version != self.version or int(n) != self.n:
@@ -84,12 +95,17 @@ class GATConv(torch.nn.Module):
         assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
         if self.training and self.dropout > 0:
             raise NotImplementedError("GATConv (HIP): attention dropout in training mode is not implemented")
+        tiles = None
         if isinstance(csr, GraphBatch):
+            tiles = csr.tiles
             csr = csr.check(edge_index, x.shape[0])
         rowptr, col = csr if csr is not None else self.csr_by_target(edge_index, x.shape[0])
         if torch.is_grad_enabled() and (x.requires_grad or self.lin_l.weight.requires_grad or self.att_l.requires_grad
                                         or self.lin_ij.weight.requires_grad or self.bias.requires_grad):
             return autograd.gat_layer(x, self.lin_l.weight, self.att_l, self.lin_ij.weight, self.bias, rowptr, col, prelu_slope)
+        if tiles is not None and ops.gat_tiled_ok(x.shape[1], self.out_channels):
+            return ops.gat_layer_tiled(rowptr, col, tiles, x, self.lin_l.weight.detach(), self.att_l.detach().reshape(-1),
+                                       self.lin_ij.weight.detach(), self.bias.detach(), prelu_slope=prelu_slope)
         return ops.gat_layer(rowptr, col, x, self.lin_l.weight.detach(), self.att_l.detach().reshape(-1),
                              self.lin_ij.weight.detach(), self.bias.detach(), prelu_slope=prelu_slope)
 

@@ -10,6 +10,7 @@
 // collapses to leaky_relu(P_i + Q_j) * softmax weight.  The three scatters (sum, min, max at the target,
 // gat_conv.py:216) become one pass over a CSR row per target: every output row has one owner, no atomics.
 #include <algorithm>
+#include <type_traits>
 
 #include "tlc_common.h"
 
@@ -344,6 +345,247 @@ int launch_gat(int n, const int* rowptr, const int* src, const float* X, int c_i
     return TLC_OK;
 }
 
+// ======================================================================================================================
+// Round 5: the layer on a BLOCK-DIAGONAL batch in one kernel, tile by tile, with [P | Q | alpha] never leaving the CU.
+//
+// The two-kernel form writes the node rows [P | Q | alpha] (272 B per node) to HBM and gathers them back per in-edge: for
+// ogbg-molhiv's million nodes that is 280 MB out, ~1 GB of 128-byte lines in, and an aggregation whose every node waits for
+// three dependent global round trips (row bounds -> source ids -> rows): 183 + 231 us per layer.  In a batch of small graphs
+// every in-edge of a node comes from its own graph, so a TILE of consecutive whole graphs (tile_ptr: node offsets, at most
+// GT_TM nodes, closed under in-edges -- the caller cuts the batch at positions no edge crosses) is self-contained:
+//   phase 0  the tile's row bounds and source ids (as tile-local ids) go to LDS: one coalesced pass;
+//   phase 1  [P | Q | alpha] = X_tile (Wl^T [Wij_t^T | Wij_s^T | att]) on the f32 MFMA, 16-row tiles dealt to the wavefronts, A
+//            straight from global memory (lane (row, g) reads the sixteen contiguous floats k = 16 g .. of its row), the combined
+//            weights in registers for the workgroup's whole life, results into the LDS tile (row stride 2C + 4 words);
+//            c_in == 1 (first layer): the row is f_i * v, written by the vector ALU;
+//   phase 2  a group of C lanes per node: softmax statistics, sum / min / max of leaky_relu(P_i + Q_j) * a over the in-edges --
+//            every operand an LDS read -- bias, PReLU, the 2C-wide output row in two coalesced stores.
+// Persistent workgroups (two per CU: 78 KB of LDS each, so that one's MFMA phase runs under the other's aggregation), tiles strided;
+// the combined weights sit in LDS in MFMA operand layout for the workgroup's whole life.
+// ======================================================================================================================
+#define GT_TM 192            /* nodes per tile (twelve 16-row MFMA tiles) */
+#define GT_EM 2048           /* in-edge slots of a tile staged in LDS; a tile with more reads its source ids from global memory */
+#define GT_THREADS 512
+typedef float gt_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int C, int CIN>
+__global__ __launch_bounds__(GT_THREADS, 4) void gat_tile_kernel(int n_tiles, const int* __restrict__ tile_ptr, const int* __restrict__ rowptr,
+                                                              const int* __restrict__ src, const float* __restrict__ X,
+                                                              const float* __restrict__ Wf, const float* __restrict__ vec,
+                                                              const float* __restrict__ bias, float prelu_slope, float* __restrict__ out) {
+    constexpr int N2 = 2 * C + 4, NT = (N2 + 15) / 16, KQ = CIN >= 16 ? CIN / 4 : 1;
+    static_assert(CIN == 1 || (CIN % 16 == 0 && CIN <= 64), "c_in: 1 (rank-one rows) or a multiple of 16 up to 64");
+    extern __shared__ __attribute__((aligned(16))) float gt_lds[];
+    float* const pqa = gt_lds;                                   // [GT_TM][N2]
+    int* const rp = (int*)(gt_lds + GT_TM * N2);                 // [GT_TM + 1] row bounds relative to the tile's first in-edge slot
+    unsigned short* const ls = (unsigned short*)(rp + GT_TM + 4); // [GT_EM] tile-local source ids
+    // [GT_TM] node values (c_in == 1) | the combined weights in MFMA operand layout (c_in >= 16): [t][k / 16][lane][4] -- lane
+    // (l16, g) reads the four steps k = 16 q + 4 g .. of column tile t in one ds_read_b128
+    float* const wop = reinterpret_cast<float*>(ls + GT_EM);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    constexpr int NW = GT_THREADS / 64;
+    if constexpr (CIN >= 16) {
+        // step s of lane group g consumes k = 16 q + 4 g + (s & 3), q = s >> 2, for A and B alike (a sum over k does not care)
+        for (int i = tid; i < NT * (CIN / 16) * 64 * 4; i += GT_THREADS) {
+            const int e = i & 3, ln = (i >> 2) & 63, q = (i >> 8) % (CIN / 16), t = (i >> 8) / (CIN / 16);
+            const int k = 16 * q + 4 * (ln >> 4) + e, c = 16 * t + (ln & 15);
+            wop[i] = c < N2 ? Wf[(size_t)k * N2 + c] : 0.0f;
+        }
+        __syncthreads();
+    }
+    // the head of a tile -- its node range and first in-edge slot: two dependent loads -- is fetched one tile ahead
+    int nx_base = 0, nx_tn = 0, nx_eb0 = 0, nx_ne = 0;
+    auto head = [&](int t) {
+        if (t < n_tiles) {
+            nx_base = tile_ptr[t]; nx_tn = tile_ptr[t + 1] - nx_base;
+            nx_eb0 = rowptr[nx_base]; nx_ne = rowptr[nx_base + nx_tn] - nx_eb0;
+        }
+    };
+    head(blockIdx.x);
+    // What phase 0 and the first MFMA row tile need from global memory is requested one tile AHEAD, into registers, at the start of
+    // the tile before's aggregation (six registers, + the first A operands): a tile's stores drain behind a barrier anyway, and the
+    // next tile's loads now travel beside them instead of behind them.
+    constexpr int NQ_ = CIN >= 16 ? CIN / 16 : 1;
+    int st_rp = 0, st_ls[4] = {0, 0, 0, 0};
+    float st_fl = 0.0f;
+    gt_f32x4 st_a[NQ_];
+    auto load_a0 = [&](int base_, int tn_, int rt, gt_f32x4 (&a)[NQ_]) {
+        if constexpr (CIN >= 16) {
+            int row = rt * 16 + l16;
+            if (row >= tn_) row = tn_ - 1;                        // (rows past the tile: computed, not stored)
+            const gt_f32x4* ap = reinterpret_cast<const gt_f32x4*>(X + (size_t)(base_ + row) * CIN + 4 * g);
+#pragma unroll
+            for (int q = 0; q < NQ_; ++q) a[q] = ap[4 * q];
+        }
+    };
+    // (every load unconditional at a clamped index, the raw value kept: a load inside `if (k < ne)` is waited for inside its own
+    // branch, and the six loads of a tile's phase 0 became six round trips one after the other)
+    auto fetch = [&]() {                                          // (of the tile whose head is in nx_*)
+        st_rp = rowptr[nx_base + (tid <= nx_tn ? tid : nx_tn)];
+        if (nx_ne > 0 && nx_ne <= GT_EM) {                        // (uniform)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = tid + q * GT_THREADS;
+                st_ls[q] = src[nx_eb0 + (k < nx_ne ? k : nx_ne - 1)];
+            }
+        }
+        if constexpr (CIN == 1) st_fl = X[nx_base + (tid < nx_tn ? tid : nx_tn - 1)];
+        else load_a0(nx_base, nx_tn, wave < ((nx_tn + 15) >> 4) ? wave : 0, st_a);
+    };
+    if ((int)blockIdx.x < n_tiles) fetch();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int base = nx_base, tn = nx_tn, eb0 = nx_eb0, ne = nx_ne;
+        const bool staged = ne <= GT_EM;
+        // ---- phase 0: row bounds and tile-local source ids (fetched during the tile before) --------------------------------
+        if (tid <= tn) rp[tid] = st_rp - eb0;
+        if (staged) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int k = tid + q * GT_THREADS; if (k < ne) ls[k] = (unsigned short)(st_ls[q] - base); }
+        }
+        if constexpr (CIN == 1) { if (tid < tn) wop[tid] = st_fl; }
+        head(tile + (int)gridDim.x);
+        __syncthreads();
+        // ---- phase 1: the tile's node rows ----------------------------------------------------------------------------------
+        if constexpr (CIN == 1) {
+            // (rows dealt to the wavefronts, lane j writes columns j and 64 + j: no division per element)
+            const float v0 = lane <= 2 * C ? vec[lane] : 0.0f, v1 = 64 + lane <= 2 * C ? vec[64 + lane] : 0.0f;
+            const float* const fl = wop;                                // [GT_TM] the tile's node values
+            for (int li = wave; li < tn; li += NW) {
+                const float fi = fl[li];
+                if (lane <= 2 * C) pqa[li * N2 + lane] = fi * v0;
+                if (64 + lane <= 2 * C) pqa[li * N2 + 64 + lane] = fi * v1;
+            }
+        } else {
+            // 16-row tiles dealt to the wavefronts; lane (row l16, g) holds A[row][16 q + 4 g ..] for q = 0 .. CIN/16 (one 16-byte load
+            // each), the NEXT row tile's loads are in flight during this one's MFMAs; B comes from LDS, one 16-byte read per four MFMAs
+            const int nrt = (tn + 15) >> 4;
+            constexpr int NQ = CIN / 16;
+            auto load_a = [&](int rt, gt_f32x4 (&a)[NQ]) { load_a0(base, tn, rt, a); };
+            gt_f32x4 a_cur[NQ], a_nxt[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) a_cur[q] = st_a[q];
+
+            for (int rt = wave; rt < nrt; rt += NW) {
+                if (rt + NW < nrt) load_a(rt + NW, a_nxt);
+                gt_f32x4 acc[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = (gt_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    gt_f32x4 bq[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bq[t] = *reinterpret_cast<const gt_f32x4*>(wop + ((t * NQ + q) * 64 + lane) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[q][e], bq[t][e], acc[t], 0, 0, 0);
+                }
+                // C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int c = t * 16 + l16;
+                    if (c < N2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int lr = rt * 16 + 4 * g + r;
+                            if (lr < tn) pqa[lr * N2 + c] = acc[t][r];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) a_cur[q] = a_nxt[q];
+            }
+        }
+        __syncthreads();
+        fetch();                                                  // the next tile's phase-0 data: in flight during this aggregation
+        // ---- phase 2: one group of C / 4 lanes per node, four channels per lane ----------------------------------------------
+        // (a lane per channel made all C lanes of a node compute the same attention logits, exponentials and denominator: 27 of
+        // its ~35 instructions per in-edge; with four channels per lane that part is shared four ways and every LDS read is 16 bytes)
+        {
+            constexpr int LPN = C / 4, NG = GT_THREADS / LPN;
+            const int grp = tid / LPN, c = 4 * (tid % LPN);
+            const gt_f32x4 bs = *reinterpret_cast<const gt_f32x4*>(bias + c), bm = *reinterpret_cast<const gt_f32x4*>(bias + C + c);
+            auto nodes = [&](auto staged_c) {
+                constexpr bool ST = decltype(staged_c)::value;
+                for (int li = grp; li < tn; li += NG) {
+                    const int bq = rp[li], eq = rp[li + 1], d = eq - bq;
+                    const float* const ri = pqa + __mul24(li, N2);        // (24-bit multiplies: v_mul_lo_u32 is a quarter-rate instruction)
+                    const float ai = ri[2 * C];
+                    const gt_f32x4 pi = *reinterpret_cast<const gt_f32x4*>(ri + c);
+                    float mx = -INFINITY, den = 0.0f;
+                    gt_f32x4 sum = {0.f, 0.f, 0.f, 0.f}, mn = {INFINITY, INFINITY, INFINITY, INFINITY}, mxv = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    auto slot = [&](int j) -> int { return ST ? (int)ls[j] : src[eb0 + j] - base; };
+                    // two walks over the node's in-edges (a molecule's node has three or four): the largest logit, then the weights
+                    for (int j = bq; j < eq; ++j) {
+                        const float t0 = pqa[__mul24(slot(j), N2) + 2 * C] + ai;      // alpha_j + alpha_i  (gat_conv.py:184)
+                        mx = fmaxf(mx, fmaxf(t0, 0.2f * t0));                         // leaky_relu(negative_slope=0.2) (:185)
+                    }
+                    for (int j = bq; j < eq; ++j) {
+                        const float* const rj = pqa + __mul24(slot(j), N2);
+                        const float t0 = rj[2 * C] + ai;
+                        const float ex = __expf(fmaxf(t0, 0.2f * t0) - mx);           // (argument <= 0: one v_exp_f32)
+                        den += ex;
+                        const gt_f32x4 q = *reinterpret_cast<const gt_f32x4*>(rj + C + c);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float m = pi[k] + q[k];                                   // lin_ij([x_i || x_j]) (:193-194)
+                            m = fmaxf(m, 0.2f * m) * ex;                              // leaky_relu (:195) * alpha (:198-200), normalised below
+                            sum[k] += m;
+                            mn[k] = fminf(mn[k], m);
+                            mxv[k] = fmaxf(mxv[k], m);
+                        }
+                    }
+                    gt_f32x4 o_sum = {0.f, 0.f, 0.f, 0.f}, o_mm = {0.f, 0.f, 0.f, 0.f};   // empty segment: scatter leaves zeros
+                    if (d > 0) {
+                        const float inv = 1.0f / (den + 1e-16f);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { o_sum[k] = sum[k] * inv; o_mm[k] = mn[k] * inv + mxv[k] * inv; }   // scatter min + scatter max (:216)
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        o_sum[k] += bs[k];                                    // mean over the single head, + bias (:166-172)
+                        o_mm[k] += bm[k];
+                        if (prelu_slope >= 0.0f) {                            // F.prelu(x, 0.1) between layers (Teacher_model.py:219-227)
+                            o_sum[k] = o_sum[k] > 0.0f ? o_sum[k] : prelu_slope * o_sum[k];
+                            o_mm[k] = o_mm[k] > 0.0f ? o_mm[k] : prelu_slope * o_mm[k];
+                        }
+                    }
+                    *reinterpret_cast<gt_f32x4*>(out + (size_t)(base + li) * 2 * C + c) = o_sum;
+                    *reinterpret_cast<gt_f32x4*>(out + (size_t)(base + li) * 2 * C + C + c) = o_mm;
+                }
+            };
+            if (staged) nodes(std::true_type{}); else nodes(std::false_type{});
+        }
+        __syncthreads();                                                 // (the next tile overwrites the LDS tile)
+    }
+}
+
+template <int C, int CIN>
+static int launch_gat_tiled(int n_tiles, const int* tile_ptr, const int* rowptr, const int* src, const float* X, const float* Wf,
+                            const float* vec, const float* bias, float slope, float* out, hipStream_t s) {
+    constexpr int N2 = 2 * C + 4;
+    constexpr int NT = (N2 + 15) / 16;
+    const size_t wop_bytes = CIN >= 16 ? (size_t)NT * (CIN / 16) * 64 * 16 : (size_t)GT_TM * 4;
+    const size_t lds = (size_t)GT_TM * N2 * 4 + (size_t)(GT_TM + 4) * 4 + (size_t)GT_EM * 2 + wop_bytes + 16;
+    auto kern = gat_tile_kernel<C, CIN>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TLC_ERR_HIP;
+    if (!attr_set[dev]) {
+        TLC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev] = true;
+    }
+    hipDeviceProp_t prop;
+    static int cus = 0;
+    if (!cus) { TLC_HIP_CHECK(hipGetDeviceProperties(&prop, dev)); cus = prop.multiProcessorCount; }
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+    const int grid = std::min(n_tiles, cus * per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GT_THREADS), lds, s, n_tiles, tile_ptr, rowptr, src, X, Wf, vec, bias, slope, out);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+
 // ---- generic scatter (message_passing.py:275-293 -> torch_scatter.scatter, reduce sum / mean / min / max) ----------------
 // float atomics at the memory side; min / max order floats through their monotone integer image.
 __device__ __forceinline__ int f32_ord(float x) {
@@ -450,4 +692,39 @@ extern "C" int tlc_edge_head_fwd(int64_t n_edges, const int32_t* d_src, const in
                        (long long)n_edges, d_src, d_dst, d_X, c, d_W5, d_b5, hidden, prelu_slope, d_W6, d_b6, d_pd);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
+}
+
+// One PDGNN layer on a block-diagonal batch cut into self-contained tiles (see gat_tile_kernel): d_tile_ptr int32[n_tiles + 1], node
+// offsets of tiles of at most 192 consecutive nodes such that every in-edge of a tile's node has its source in the same tile (the
+// caller's business: Knowledge_Distillation/gat_conv.py, GraphBatch).  c_in = 1 or 64 with c_out = 32, 16 (the PDGNN layers); any
+// other shape: TLC_ERR_UNSUPPORTED (the caller takes tlc_gat_layer_fwd).  d_work: float32[c_in * c_out + c_out * (2 c_out + 4) +
+// c_in * (2 c_out + 4) + 2 c_out + 8] of scratch for the packed and combined weights.  Same results as tlc_gat_layer_fwd up to the
+// rounding of the node rows' fp32 sums.
+extern "C" int tlc_gat_layer_tiled_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_src, int32_t n_tiles,
+                                       const int32_t* d_tile_ptr, const float* d_X, int32_t c_in, int32_t c_out, const float* d_Wl,
+                                       const float* d_att, const float* d_Wij, const float* d_bias, float prelu_slope, float* d_work,
+                                       float* d_out, void* stream) {
+    TLC_REQUIRE(n_nodes >= 0 && c_in > 0 && n_tiles >= 0, "bad sizes");
+    if (n_nodes == 0 || n_tiles == 0) return TLC_OK;
+    TLC_REQUIRE(d_rowptr && d_src && d_tile_ptr && d_X && d_Wl && d_att && d_Wij && d_bias && d_work && d_out, "null pointer");
+    if (!((c_in == 1 || c_in == 64) && (c_out == 32 || c_out == 16))) { tlc_set_error("tlc_gat_layer_tiled_fwd: c_in %d / c_out %d not built", c_in, c_out); return TLC_ERR_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    const int C = c_out, N2 = 2 * C + 4;
+    if (c_in == 1) {
+        float* vec = d_work;                                  // [2C + 1] = Wl[:, 0]^T [Wij_t^T | Wij_s^T | att]
+        hipLaunchKernelGGL(gat_rank1_vec_kernel, dim3(1), dim3(256), 0, s, C, d_Wl, d_att, d_Wij, vec);
+        TLC_HIP_CHECK(hipGetLastError());
+        return C == 32 ? launch_gat_tiled<32, 1>(n_tiles, d_tile_ptr, d_rowptr, d_src, d_X, nullptr, vec, d_bias, prelu_slope, d_out, s)
+                       : launch_gat_tiled<16, 1>(n_tiles, d_tile_ptr, d_rowptr, d_src, d_X, nullptr, vec, d_bias, prelu_slope, d_out, s);
+    }
+    float* Bt1 = d_work;                                      // [c_in][C]
+    float* Bt2 = Bt1 + (size_t)c_in * C;                      // [C][N2]
+    float* Wf = Bt2 + (size_t)C * N2;                         // [c_in][N2] = Bt1 Bt2
+    const int np = std::max(c_in * C, C * N2);
+    hipLaunchKernelGGL(gat_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, C, c_in, d_Wl, d_att, d_Wij, Bt1, Bt2);
+    TLC_HIP_CHECK(hipGetLastError());
+    int rc = tlc_gemm_f32(c_in, N2, C, Bt1, Bt2, nullptr, 0, Wf, s);
+    if (rc != TLC_OK) return rc;
+    return C == 32 ? launch_gat_tiled<32, 64>(n_tiles, d_tile_ptr, d_rowptr, d_src, d_X, Wf, nullptr, d_bias, prelu_slope, d_out, s)
+                   : launch_gat_tiled<16, 64>(n_tiles, d_tile_ptr, d_rowptr, d_src, d_X, Wf, nullptr, d_bias, prelu_slope, d_out, s);
 }

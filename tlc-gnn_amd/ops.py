@@ -189,6 +189,67 @@ def gat_layer(rowptr, src, x, wl, att, wij, bias, prelu_slope=-1.0, out=None):
     return out
 
 
+GAT_TILE_NODES = 192          # GT_TM of csrc/gat_forward.hip
+
+
+def gat_tiles(rowptr, col, n, tile_nodes=GAT_TILE_NODES):
+    """Cuts a block-diagonal batch (CSR by target: rowptr int32 [n+1], col = the sources) into self-contained tiles for
+    tlc_gat_layer_tiled_fwd: int32 [T+1] node offsets of tiles of at most `tile_nodes` consecutive nodes, cut only at positions no
+    edge crosses -- or None when the batch has no such cuts close enough together (one big graph: the two-kernel layer serves it).
+    All on the device: an edge (s, t) forbids the cuts in (min, max]; a running sum of +1 / -1 marks leaves the positions that
+    are free; the first free position at or behind every multiple of (tile_nodes - largest gap) starts a tile."""
+    torch = _lib.require_gpu()
+    n = int(n)
+    if n == 0:
+        return None
+    dev = rowptr.device
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    tgt = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+    srcs = col.long()
+    lo, hi = torch.minimum(srcs, tgt), torch.maximum(srcs, tgt)
+    mark = torch.zeros(n + 2, dtype=torch.int32, device=dev)
+    ones = torch.ones_like(lo, dtype=torch.int32)
+    mark.index_add_(0, lo + 1, ones)
+    mark.index_add_(0, hi + 1, -ones)
+    free = torch.nonzero(torch.cumsum(mark[:n + 1], 0) == 0).reshape(-1)      # positions 0 .. n where a tile may start / end
+    if free.numel() < 2:
+        return None
+    gap = int((free[1:] - free[:-1]).max())
+    if 2 * gap > tile_nodes:
+        return None
+    step = tile_nodes - gap
+    starts = torch.arange(0, n, step, device=dev)
+    picks = free[torch.searchsorted(free, starts).clamp_(max=free.numel() - 1)]
+    picks = torch.unique_consecutive(torch.cat([picks[picks < n], free.new_tensor([n])]))
+    if int(picks[0]) != 0 or int((picks[1:] - picks[:-1]).max()) > tile_nodes:
+        return None
+    return picks.to(torch.int32).contiguous()
+
+
+@_lib.on_device_of
+def gat_layer_tiled(rowptr, src, tiles, x, wl, att, wij, bias, prelu_slope=-1.0, out=None):
+    """One PDGNN layer (gat_conv.py:113-216) on a block-diagonal batch cut by gat_tiles: the node rows stay in LDS
+    (tlc_gat_layer_tiled_fwd).  Shapes it does not take raise _lib.TlcError(TLC_ERR_UNSUPPORTED): callers check `gat_tiled_ok`."""
+    torch = _lib.require_gpu()
+    x = _f32(x)
+    n, c_in = x.shape
+    c_out = wl.shape[0]
+    if out is None:
+        out = torch.empty((n, 2 * c_out), dtype=torch.float32, device=x.device)
+    n2 = 2 * c_out + 4
+    work = torch.empty(c_in * c_out + c_out * n2 + c_in * n2 + 2 * c_out + 8, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().tlc_gat_layer_tiled_fwd(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(src), C.c_int32(tiles.numel() - 1), _lib.ptr(tiles),
+                                            _lib.ptr(x), C.c_int32(c_in), C.c_int32(c_out), _lib.ptr(_f32(wl)),
+                                            _lib.ptr(_f32(att).reshape(-1)), _lib.ptr(_f32(wij)), _lib.ptr(_f32(bias)),
+                                            C.c_float(prelu_slope), _lib.ptr(work), _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "tlc_gat_layer_tiled_fwd")
+    return out
+
+
+def gat_tiled_ok(c_in, c_out):
+    return c_in in (1, 64) and c_out in (16, 32)
+
+
 @_lib.on_device_of
 def edge_head(src, dst, x, w5, b5, prelu_slope, w6, b6, out=None):
     """Edge head of Teacher_Model.forward (Knowledge_Distillation/Teacher_model.py:54-59) -> f32 [E,2]."""
