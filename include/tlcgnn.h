@@ -301,6 +301,11 @@ int tlc_gat_layer_tiled_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int3
                             const float* d_Wl, const float* d_att, const float* d_Wij, const float* d_bias,
                             float prelu_slope, float* d_work, float* d_out, void* stream);
 
+/* Smallest and largest column of every CSR row, the row index itself included (int32[n_rows] each): the host side of
+ * tlc_gat_layer_tiled_fwd's tile cut (Knowledge_Distillation/gat_conv.py GraphBatch -> ops.gat_tiles) -- a position k of a batch is
+ * free of crossing edges iff max_{i<k} hi[i] < k and min_{i>=k} lo[i] >= k. */
+int tlc_csr_row_minmax(int32_t n_rows, const int32_t* d_rowptr, const int32_t* d_col, int32_t* d_lo, int32_t* d_hi, void* stream);
+
 
 /* ---- the diagram loss of PDGNN training ------------------------------------------------------------
  * `wasserstein_distance(X, Y, order=p, internal_p=inf, enable_autodiff=True, num_models=1)` of

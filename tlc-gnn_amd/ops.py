@@ -196,22 +196,26 @@ def gat_tiles(rowptr, col, n, tile_nodes=GAT_TILE_NODES):
     """Cuts a block-diagonal batch (CSR by target: rowptr int32 [n+1], col = the sources) into self-contained tiles for
     tlc_gat_layer_tiled_fwd: int32 [T+1] node offsets of tiles of at most `tile_nodes` consecutive nodes, cut only at positions no
     edge crosses -- or None when the batch has no such cuts close enough together (one big graph: the two-kernel layer serves it).
-    All on the device: an edge (s, t) forbids the cuts in (min, max]; a running sum of +1 / -1 marks leaves the positions that
-    are free; the first free position at or behind every multiple of (tile_nodes - largest gap) starts a tile."""
+    All on the device; the first free position at or behind every multiple of (tile_nodes - largest gap) starts a tile."""
     torch = _lib.require_gpu()
     n = int(n)
     if n == 0:
         return None
     dev = rowptr.device
-    deg = (rowptr[1:] - rowptr[:-1]).long()
-    tgt = torch.repeat_interleave(torch.arange(n, device=dev), deg)
-    srcs = col.long()
-    lo, hi = torch.minimum(srcs, tgt), torch.maximum(srcs, tgt)
+    # an edge into node i from s forbids the cuts in (min(s, i), max(s, i)]: per target the smallest and largest source
+    # (tlc_csr_row_minmax)
+    lo = torch.empty(n, dtype=torch.int32, device=dev)
+    hi = torch.empty(n, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().tlc_csr_row_minmax(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(lo), _lib.ptr(hi),
+                                                 _lib.stream_ptr(dev)), "tlc_csr_row_minmax")
+    # node i forbids the cuts k with lo[i] < k <= hi[i]: +1 at lo + 1, -1 at hi + 1, a running sum, and the zeros are free
     mark = torch.zeros(n + 2, dtype=torch.int32, device=dev)
-    ones = torch.ones_like(lo, dtype=torch.int32)
-    mark.index_add_(0, lo + 1, ones)
-    mark.index_add_(0, hi + 1, -ones)
-    free = torch.nonzero(torch.cumsum(mark[:n + 1], 0) == 0).reshape(-1)      # positions 0 .. n where a tile may start / end
+    ones = torch.ones(n, dtype=torch.int32, device=dev)
+    mark.index_add_(0, (lo + 1).long(), ones)
+    mark.index_add_(0, (hi + 1).long(), -ones)
+    ok = torch.cumsum(mark[:n + 1], 0) == 0
+    free = torch.nonzero(ok).reshape(-1)                                  # positions 0 .. n where a tile may start / end
     if free.numel() < 2:
         return None
     gap = int((free[1:] - free[:-1]).max())
