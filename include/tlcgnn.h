@@ -162,23 +162,23 @@ int tlc_pd_pi_algorithmic_bytes(int32_t n_nodes, const int32_t* h_rowptr, const 
  * phase_profile(): per-phase cycle counters of the tier kernels in a library built with `make PHASE_DEBUG=1` (all zero
  * otherwise): rows of 32 u64, one per tier and one for the early pass; at most cap_u64 values are written to h_out (may be
  * null), *n_rows (may be null) = rows kept.  enable != 0 starts counting, 0 stops and frees the counters.
- * set_option(): switches of one handle for A/B timing and for the tests that check that results do not depend on them:
- * "extract" (ball-list extraction of the vicinities, hop <= 2), "heavy" (its hub-row skipping), "tiny" (lane-per-subgraph
- * kernel for vicinities of at most 16 nodes / 24 edges); 1 = on (default; the environment variables TLC_EXTRACT / TLC_HEAVY /
- * TLC_TINY = 0 switch them off at handle creation).  Test hooks: "tier_mask" (bit t: tier t's kernels are launched at all),
- * "dc_force_fail", "x_region" / "x_bump_min" (arena entries per extraction workgroup / bump area: reach the overflow paths),
- * "spec_cap" (slots reserved for speculative launches), "mh_always" (split the MEDIUM tier in pipelined chunks too).
- * Measurement / A-B: "timing_every" (kernel events on every n-th chunk), "x_grid", "x_chunk_div", "gate_ticks", "medium_first",
- * "chunk_pairs" (0 = the defaults), "defer" (1: a pipelined chunk's second half behind the next chunk's first half), "n_ws"
- * (workspaces taken in turn, 2..4, default 3).  Results never depend on any of them (tests/test_gpu_extract.py, tests/test_gpu_tiers.py);
- * an unknown name is TLC_ERR_INVALID_ARG. */
+ * set_option(): the twelve switches of one handle, each exercised by a test that checks that results do not depend on it
+ * (tests/test_gpu_extract.py, tests/test_gpu_tiers.py, tests/test_gpu_pd_parity.py); 1 = on is the default of the first six:
+ *   "extract"      ball-list extraction of the vicinities at hop <= 2 (0: the breadth-first kernels; TLC_EXTRACT=0 at creation)
+ *   "heavy"        its hub-row skipping (TLC_HEAVY=0)
+ *   "tiny"         lane-per-subgraph kernel for vicinities of at most 16 nodes / 24 edges (TLC_TINY=0)
+ *   "ball_edges"   vicinities of pairs whose smaller ball has <= 128 nodes from that ball's subgraph list (TLC_BALL_EDGES=0)
+ *   "fast_split"   ... in a launch of their own beside the classification and the early pass (TLC_FAST_SPLIT=0)
+ *   "dc_inplace"   the LARGE tier's divide and conquer by the tier kernel's own workgroup (0: tlc_pd_dc_kernel; TLC_DC_INPLACE=0)
+ *   "dc_force_fail" every divide-and-conquer solve given back to the serial walk (test hook)
+ *   "spec_cap"     slots reserved for the speculative tier launches (test hook: beyond them the second-launch / in-kernel paths)
+ *   "x_arena"      arena entries per extraction workgroup and of the bump area (test hook: reach the overflow paths; 0 = defaults)
+ *   "tier_mask"    bit t: tier t's kernels are launched at all (cost tables under profiles/)
+ *   "n_ws"         workspaces taken in turn by pipelined chunks (2..4, default 3)
+ *   "timing_every" kernel events on every n-th chunk only
+ * An unknown name is TLC_ERR_INVALID_ARG. */
 int tlc_debug_set_option(tlc_graph* g, const char* name, int value);
 int tlc_debug_dc_stats(tlc_graph* g, long long* h_out, void* stream);
-/* The lane-per-pair extraction (csrc/extract_lane.hip; replaces sg2dgm_accelerate's BFS + intersection + subgraph,
- * sg2dgm/riccidist2dgm.py:310-316, for pairs whose smaller hop-ball has at most "xl_cut" nodes, default 24, 0 = off) in the last
- * chunk: h_out[0] = candidates, h_out[1] = pairs it finished as records for the lane-per-subgraph kernel.  Options "xl_cut",
- * "xl_ncut", "xl_mcut" (tests: what it keeps, <= 16 nodes / 24 edges) through tlc_debug_set_option. */
-int tlc_debug_xl_stats(tlc_graph* g, long long* h_out, void* stream);
 /* The tier lists of the last tlc_pd_pi_batch call as the device cut them, h_out[8]: small, medium (the compact kernel configuration,
  * <= 384 nodes / 512 edges), large, huge, mid, tiny, medium with many Pos edges, medium beyond the compact configuration (<= 512 /
  * 1024).  tlc_pd_pi_batch_stats reports tiny with small and the three medium lists as one. */

@@ -265,9 +265,9 @@ def test_async_batches_overlap_and_equal_the_stream_ordered_call():
     torch.cuda.synchronize()
     assert torch.equal(o4, want[1][0])
     assert g.stats()["chunks"] == 1
-    # pipelined chunks do not split the MEDIUM tier by Pos-edge count (no speculative launch either); with the split forced, with
-    # its reserved slots cut to 8 and with kernel events on every 2nd chunk only, the rows are the same
-    for opts in ({"mh_always": 1}, {"mh_always": 1, "spec_cap": 8}, {"timing_every": 2}, {"defer": 0}, {"n_ws": 2}, {"n_ws": 4}):
+    # with the speculative launches' reserved slots cut to 8, with kernel events on every 2nd chunk only and with two or four
+    # workspaces in turn, the rows are the same
+    for opts in ({"spec_cap": 8}, {"timing_every": 2}, {"n_ws": 2}, {"n_ws": 4}):
         for k, v in opts.items():
             g.set_option(k, v)
         if "timing_every" in opts:
@@ -279,7 +279,7 @@ def test_async_batches_overlap_and_equal_the_stream_ordered_call():
             assert torch.equal(s, wst) and torch.equal(o, wo), (opts, k)
         g.set_timing(False)
         for k in opts:
-            g.set_option(k, {"timing_every": 1, "defer": 1, "n_ws": 3}.get(k, 0))
+            g.set_option(k, {"timing_every": 1, "n_ws": 3}.get(k, 0))
     # a batch whose second half is still owed: statistics and sizes ask for it themselves, a stream-ordered call submits it first,
     # and a handle may be closed with one pending
     o6, s6 = g.pd_pi_batch(batches[0], 2, async_=True)
@@ -317,7 +317,7 @@ def test_async_batches_of_alternating_hop_rebuild_the_ball_lists_behind_the_pend
         o, s = g.pd_pi_batch(b, hop)
         want.append((o.clone(), s.clone()))
     torch.cuda.synchronize()
-    for opts in ({"x_region": 64, "x_bump_min": 4096}, {"extract": 0}, {}):
+    for opts in ({"x_arena": 64}, {"extract": 0}, {}):
         for k, v in opts.items():
             g.set_option(k, v)
         got = [g.pd_pi_batch(b, hop, async_=True) for b, hop in batches]
@@ -326,7 +326,7 @@ def test_async_batches_of_alternating_hop_rebuild_the_ball_lists_behind_the_pend
         for k, ((o, s), (wo, wst)) in enumerate(zip(got, want)):
             assert torch.equal(s, wst), (opts, k)
             assert (o - wo).abs().max() <= 1e-12, (opts, k)
-        g.set_option("x_region", 4096); g.set_option("x_bump_min", 1 << 20); g.set_option("extract", 1)
+        g.set_option("x_arena", 0); g.set_option("extract", 1)
     # tlc_pd_pi_batch == async + join: a stream-ordered call also makes the stream wait for batches still in flight
     o1, s1 = g.pd_pi_batch(batches[0][0], 2, async_=True)
     o2, s2 = g.pd_pi_batch(batches[2][0], 2, async_=True)

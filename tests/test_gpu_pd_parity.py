@@ -557,8 +557,7 @@ def test_count_pass_arena_overflow_falls_back_to_scan_and_fill(torch_cuda, extra
     rowptr, col, w = synth.edges_to_csr(L + 1, e, rs.uniform(-0.5, 0.9, size=len(e)))
     g = engine.DeviceGraph(rowptr, col, w)
     g.set_option("extract", extract)
-    g.set_option("x_region", 256)                              # (extraction: 400 regions of 256 entries + a bump area of 12 800)
-    g.set_option("x_bump_min", 0)
+    g.set_option("x_arena", 256)                               # (extraction: 400 regions of 256 entries + a bump area of 12 800)
     distinct = e[rs.permutation(len(e))[:100]].astype(np.int32)
     pairs = np.tile(distinct, (4, 1))                         # 400 pairs x ~1 400 directed entries >> 65 536
     dp = _dev(torch, pairs, torch.int32)

@@ -157,57 +157,13 @@ def test_medium_compact_and_wide_configurations(n, m):
     g.close()
 
 
-@pytest.mark.parametrize("n,m", [(1024, 2048), (1025, 1500), (900, 2049), (601, 900)])
-@pytest.mark.parametrize("n_pairs", [8, 4608])
-def test_large_tier_split_into_compact_and_wide_kernels(n, m, n_pairs):
-    """Option large_split (off by default: measured slower): the LARGE tier as two launches over one list, kernels sized for 1 024
-    nodes / 2 048 edges (72 KB tier, 54 KB divide and conquer) for the vicinities that fit, the 2 048 / 4 096 ones for the rest.  At
-    the cut, on the ordinary heavy path (8 pairs) and through the early pass (4 608), alone and in one batch with the other kind:
-    the rows of the unsplit tier bit for bit -- and the oracle's; then in pipelined chunks."""
-    import torch
-    from tlc_gnn_amd import engine, synth
-    rs = np.random.RandomState(n + m)
-    other = (1100, 2300) if (n <= 1024 and m <= 2048) else (700, 1000)
-    comps, base, pairs = [], 0, []
-    for nn, mm, reps in ((n, m, 6), (other[0], other[1], 2)):
-        comps.append(hub_component(nn, mm, rs, base))
-        pairs += [[base, base + k] for k in range(1, reps + 1)]
-        base += nn
-    e = np.concatenate(comps)
-    rowptr, col, w = synth.edges_to_csr(base, e, rs.uniform(-0.5, 0.9, size=len(e)))
-    pairs = np.tile(np.array(pairs), (n_pairs // 8, 1))
-    g = engine.DeviceGraph(rowptr, col, w)
-    g.set_option("large_split", 0)
-    ref_out, ref_st = _check(g, torch, rowptr, col, w, pairs)
-    assert g.stats()["tier_large"] == len(pairs)
-    g.set_option("large_split", 2)
-    for _ in range(2):
-        out, st = _check(g, torch, rowptr, col, w, pairs)
-        assert np.array_equal(out, ref_out) and np.array_equal(st, ref_st)
-    g.set_option("dc_force_fail", 1)                                # every divide and conquer given back to the serial walk it carries
-    out, st = _check(g, torch, rowptr, col, w, pairs)
-    assert np.abs(out - ref_out).max() <= 1e-12 * np.abs(ref_out).max() and np.array_equal(st, ref_st)
-    g.set_option("dc_force_fail", 0)
-    g.set_option("large_split", 1)                                  # pipelined chunks only (the default is 0: measured slower)
-    dev = torch.as_tensor(np.ascontiguousarray(pairs, dtype=np.int32)).cuda()
-    outs = [torch.empty((len(pairs), 25), dtype=torch.float64, device="cuda") for _ in range(3)]
-    sts = [torch.empty(len(pairs), dtype=torch.uint8, device="cuda") for _ in range(3)]
-    for k in range(3):
-        g.pd_pi_batch(dev, 2, out=outs[k], status=sts[k], async_=True)
-    g.join()
-    torch.cuda.synchronize()
-    for k in range(3):
-        assert np.array_equal(outs[k].cpu().numpy(), ref_out) and np.array_equal(sts[k].cpu().numpy(), ref_st)
-    g.close()
-
-
 @pytest.mark.parametrize("n,k_pos", [(301, 319), (301, 320), (301, 400), (83, 600), (450, 560), (100, 350), (150, 330)])
 def test_divide_and_conquer_of_the_wide_medium_configuration(n, k_pos):
     """MEDIUM-sized vicinities with hundreds of Pos edges (the dense hop-1 vicinities of the Amazon shapes: 83 nodes / 680 edges)
     sit in the 512 / 1 024 configuration for their edge count; from TLC_DC_MIN_POS_SHARED = 320 Pos edges the scan counts them and
     tlc_pd_dc_kernel goes between their tier and swap kernels -- in the chain of a lone chunk from the second call on (the
-    speculative launch goes by the previous chunk's count), in pipelined chunks at once.  Rows: the oracle's, and bit-equal to the
-    serial walk's (option dcm = 0)."""
+    speculative launch goes by the previous chunk's count), in pipelined chunks at once.  Rows: the oracle's, and equal to the
+    serial walk's (option dc_force_fail = 1: every solve given back to the serial walk the kernel carries)."""
     import torch
     from tlc_gnn_amd import engine, synth
     rs = np.random.RandomState(n + k_pos)
@@ -217,12 +173,12 @@ def test_divide_and_conquer_of_the_wide_medium_configuration(n, k_pos):
     rowptr, col, w = synth.edges_to_csr(n + 200, e, rs.uniform(-0.5, 0.9, size=len(e)))
     pairs = np.array([[0, k] for k in range(1, 25)] + [[n, n + k] for k in range(1, 9)])
     g = engine.DeviceGraph(rowptr, col, w)
-    g.set_option("dcm", 0)
+    g.set_option("dc_force_fail", 1)
+    _check(g, torch, rowptr, col, w, pairs)                            # (first call: no previous chunk's count to size the launch by)
     ref_out, ref_st = _check(g, torch, rowptr, col, w, pairs)
-    assert g.dc_stats() == (0, 0)
-    g.set_option("dcm", 1)
+    assert g.dc_stats()[0] == 0
+    g.set_option("dc_force_fail", 0)
     expect = 24 if k_pos >= 320 else 0
-    _check(g, torch, rowptr, col, w, pairs)                            # (first call: the previous chunk's count is that of dcm = 0 ...)
     for _ in range(2):
         out, st = _check(g, torch, rowptr, col, w, pairs)
         assert np.array_equal(st, ref_st) and np.abs(out - ref_out).max() <= 1e-12 * np.abs(ref_out).max()
@@ -242,10 +198,10 @@ def test_divide_and_conquer_of_the_wide_medium_configuration(n, k_pos):
     g.close()
 
 
-def test_tier_lists_sorted_by_size_give_the_same_rows():
-    """The TINY list goes to the lane-per-subgraph kernel in size classes, largest first (tlc_scan_bin's bins: a wavefront waits for
-    its slowest lane; option tiny_sort, default on), the other lists can be sorted (option tier_sort, development): every pair's
-    row is its own -- bit-equal rows whatever the order, stream-ordered and pipelined."""
+def test_tier_mask_leaves_exactly_the_masked_tiers_rows_unwritten():
+    """Option tier_mask (the cost tables of profiles/: a tier's kernels are not launched): the rows and status bytes of the masked
+    tier's pairs keep what the output buffers held, every other pair's row is the unmasked call's, bit for bit -- stream-ordered
+    and pipelined.  (The TINY list goes to its kernel in size classes, largest first: every pair's row is its own whatever the order.)"""
     import torch
     from tlc_gnn_amd import engine, synth
     n, edges, kappa, hop, _ = synth.shaped_graph("PubMed", scale=0.3)
@@ -253,21 +209,30 @@ def test_tier_lists_sorted_by_size_give_the_same_rows():
     rs = np.random.RandomState(12)
     pairs = torch.as_tensor(edges[rs.permutation(len(edges))[:9000]].astype(np.int32)).cuda()
     g = engine.DeviceGraph(rowptr, col, w)
-    g.set_option("tiny_sort", 0)
     ref, rst = g.pd_pi_batch(pairs, hop)
     assert g.stats()["tier_tiny"] > 3000
-    for ts, tt in ((1, 0), (1, 19), (0, 19)):
-        g.set_option("tiny_sort", ts); g.set_option("tier_sort", tt)
-        out, st = g.pd_pi_batch(pairs, hop)
-        assert torch.equal(out, ref) and torch.equal(st, rst), (ts, tt)
-        outs = [torch.empty_like(ref) for _ in range(3)]
-        sts = [torch.empty_like(rst) for _ in range(3)]
+    nn, m2 = g.sizes(len(pairs))
+    tier = engine.tier_of(nn, m2)
+    names = {"pd_tier_tiny": 5, "pd_tier_small": 0, "pd_tier_mid": 4}
+    for name, bit in names.items():
+        sel = torch.as_tensor(tier == name).cuda() & (rst == 0)
+        assert int(sel.sum()) > 50, name
+        g.set_option("tier_mask", 255 & ~(1 << bit))
+        out = torch.full_like(ref, -7.0)
+        st = torch.full_like(rst, 99)
+        g.pd_pi_batch(pairs, hop, out=out, status=st)
+        torch.cuda.synchronize()
+        assert bool((out[sel] == -7.0).all()) and bool((st[sel] == 99).all()), name
+        assert torch.equal(out[~sel], ref[~sel]) and torch.equal(st[~sel], rst[~sel]), name
+        outs = [torch.full_like(ref, -7.0) for _ in range(3)]
+        sts = [torch.full_like(rst, 99) for _ in range(3)]
         for k in range(3):
             g.pd_pi_batch(pairs, hop, out=outs[k], status=sts[k], async_=True)
         g.join()
         torch.cuda.synchronize()
         for k in range(3):
-            assert torch.equal(outs[k], ref) and torch.equal(sts[k], rst), (ts, tt, k)
+            assert torch.equal(outs[k], out) and torch.equal(sts[k], st), (name, k)
+        g.set_option("tier_mask", 255)
     g.close()
 
 
@@ -388,111 +353,4 @@ def test_seeded_random_sweep_vs_oracle(seed):
             assert np.array_equal(st, rst), (kind, hop, flags)
             scale = np.abs(ref).max(axis=1, keepdims=True) + 1e-300
             assert (np.abs(got - ref) / scale).max() < 1e-8, (kind, hop, flags)
-    g.close()
-
-
-# ---- the lane-per-pair extraction (csrc/extract_lane.hip): pairs whose smaller ball has <= xl_cut nodes never enter the wavefront
-# extraction; their records feed the lane-per-subgraph kernel directly -------------------------------------------------------------
-def _lane_batch(rs):
-    """hub components around the limits (16 / 17 nodes, 24 / 25 edges, smaller balls at 24 / 25 / 32 / 33 nodes), a chain of leaves
-    behind some hubs (so that the larger ball of a pair is much larger than the smaller), isolated nodes, far pairs, self pairs."""
-    shapes = [(16, 24), (17, 24), (16, 25), (17, 25), (16, 15), (15, 24), (12, 16), (3, 3), (3, 2), (2, 1), (4, 6), (9, 20), (16, 23),
-              (10, 9), (24, 23), (25, 24), (24, 40), (32, 31), (33, 32), (33, 60), (40, 39), (70, 80)]
-    edges, pairs, base = [], [], 0
-    for rep in range(5):
-        for (n, m) in shapes:
-            edges.append(hub_component(n, m, rs, base))
-            pairs += [[base, base + 1 + rs.randint(n - 1)], [base + 1 + rs.randint(n - 1), base]]
-            if n >= 4:
-                a, b = 1 + rs.randint(n - 1), 1 + rs.randint(n - 1)
-                pairs.append([base + a, base + b])                          # leaf - leaf (adjacent or at distance 2), or a self pair
-            base += n
-    n_iso = 3
-    iso = [base + k for k in range(n_iso)]
-    base += n_iso
-    e = np.concatenate(edges)
-    pairs += [[iso[0], 1], [2, iso[1]], [iso[2], iso[2]], [0, shapes[0][0]], [5, base - 10]]        # KeyError rows, far pairs
-    return base, e, np.array(pairs)
-
-
-@pytest.mark.parametrize("decimals", [None, 1])
-def test_lane_extraction_matches_the_wavefront_extraction_and_the_oracle(decimals):
-    """Batches of >= 4 096 pairs (the lane pass rides on the early pass's classification).  With the pass on (cuts 16 / 24 / 32) and off:
-    status bytes, |S| and entry counts equal, rows within 1e-12 of each other and 1e-8 of the oracle; the same set of vicinities
-    ends in the lane-per-subgraph kernel; forced give-backs (xl_ncut / xl_mcut) change nothing."""
-    import torch
-    from tlc_gnn_amd import engine, synth
-    rs = np.random.RandomState(17)
-    n, e, base_pairs = _lane_batch(rs)
-    kappa = rs.uniform(-0.5, 0.9, size=len(e))
-    if decimals is not None:
-        kappa = np.round(kappa, decimals)
-    rowptr, col, w = synth.edges_to_csr(n, e, kappa)
-    reps = 4096 // len(base_pairs) + 1
-    pairs = np.concatenate([base_pairs[rs.permutation(len(base_pairs))] for _ in range(reps)])
-    assert len(pairs) >= 4096
-    g = engine.DeviceGraph(rowptr, col, w)
-    runs = {}
-    for name, opts in (("off", {"xl_cut": 0}), ("cut16", {"xl_cut": 16}), ("cut24", {"xl_cut": 24}), ("cut32", {"xl_cut": 32}),
-                       ("give_back_nodes", {"xl_cut": 32, "xl_ncut": 9}), ("give_back_edges", {"xl_cut": 32, "xl_mcut": 10}),
-                       ("no_heavy", {"xl_cut": 32, "heavy": 0})):
-        for k, v in opts.items():
-            g.set_option(k, v)
-        out, st = _check(g, torch, rowptr, col, w, pairs)
-        runs[name] = (out, st) + g.sizes(len(pairs)) + (g.stats(), g.xl_stats())
-        g.set_option("xl_cut", 24); g.set_option("xl_ncut", 16); g.set_option("xl_mcut", 24); g.set_option("heavy", 1)
-    ref = runs["off"]
-    assert ref[5] == (0, 0)
-    assert 0 < runs["cut16"][5][0] < runs["cut24"][5][0] < runs["cut32"][5][0] and runs["cut16"][5][1] > 0
-    assert runs["cut32"][5][1] == runs["cut32"][4]["tier_tiny"]              # every tiny vicinity of this batch has a ball <= 32 at one end
-    assert runs["give_back_nodes"][5][1] < runs["cut32"][5][1] and runs["give_back_edges"][5][1] < runs["cut32"][5][1]
-    for name, r in runs.items():
-        assert np.array_equal(r[1], ref[1]), name
-        assert np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3]), name          # |S|, induced directed entries
-        assert np.abs(r[0] - ref[0]).max() <= 1e-12 * max(1.0, np.abs(ref[0]).max()), name
-        assert r[4]["tier_small"] == ref[4]["tier_small"] and r[4]["tier_mid"] == ref[4]["tier_mid"], name
-        if name not in ("give_back_nodes", "give_back_edges"):
-            assert r[4]["tier_tiny"] == ref[4]["tier_tiny"], name
-    g.close()
-
-
-def test_lane_extraction_on_a_pubmed_shaped_batch_with_hubs_and_negatives():
-    """The heavy-member mirroring, heavy x heavy entries through the dense table and long rows given back, on a preferential-
-    attachment graph: positives, reversed positives, random (mostly far) pairs and self pairs; pipelined as well."""
-    import torch
-    from tlc_gnn_amd import engine, synth
-    from oracle import oracle
-    n, edges, kappa, _, _ = synth.shaped_graph("PubMed", scale=0.5)
-    rowptr, col, w = synth.edges_to_csr(n, edges, kappa)
-    rs = np.random.RandomState(23)
-    pos = edges[rs.permutation(len(edges))[:9000]]
-    pairs = np.concatenate([pos, pos[:1500, ::-1], rs.randint(0, n, size=(3000, 2)), np.stack([np.arange(0, n, 37)] * 2, 1)]).astype(np.int32)
-    pairs = pairs[rs.permutation(len(pairs))]
-    d_pairs = torch.as_tensor(pairs).cuda()
-    g = engine.DeviceGraph(rowptr, col, w)
-    g.set_option("xl_pipelined", 1)                 # (by default the lane pass serves stream-ordered single chunks only)
-    g.set_option("xl_cut", 0)
-    off, st_off = g.pd_pi_batch(d_pairs, 2)
-    n_off, m_off = g.sizes(len(pairs))
-    tiny_off = g.stats()["tier_tiny"]
-    for cut in (24, 32):
-        g.set_option("xl_cut", cut)
-        on, st_on = g.pd_pi_batch(d_pairs, 2)
-        n_on, m_on = g.sizes(len(pairs))
-        assert torch.equal(st_on, st_off) and np.array_equal(n_on, n_off) and np.array_equal(m_on, m_off), cut
-        assert float((on - off).abs().max()) <= 1e-12, cut
-        assert g.stats()["tier_tiny"] == tiny_off, cut
-        cand, done = g.xl_stats()
-        assert 0 < done <= cand and done <= tiny_off, (cut, cand, done)
-        # pipelined: three in flight, bit-equal to the stream-ordered rows of the same mode
-        got = [g.pd_pi_batch(d_pairs, 2, async_=True) for _ in range(4)]
-        g.join()
-        torch.cuda.synchronize()
-        for o, s in got:
-            assert torch.equal(o, on) and torch.equal(s, st_on), cut
-    ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, 2, n_threads=0)
-    assert np.array_equal(st_on.cpu().numpy(), rst)
-    out = on.cpu().numpy()
-    nz = ref != 0
-    assert np.array_equal(out == 0, ref == 0) and rel_err(out[nz], ref[nz]).max() < 1e-8
     g.close()

@@ -43,7 +43,9 @@ def structural_filtration(kind, node_ptr, edge_ptr, edges, hks_time=0.1):
     data_utils_NC.py:124-135 'centrality', 'clustering', 'degree'), each divided by (max + 1e-10), for a packed batch of
     vicinities: node_ptr / edge_ptr int64[B+1], edges int[sum m, 2] local ids -> float64[sum n].  Host side (numpy + scipy.sparse):
     they are functions of a few hundred nodes; the vicinities themselves come from the device.  Same operations in the same
-    order as networkx, so the values are the reference's bit for bit:
+    order as networkx, so the values are the reference's bit for bit -- for SIMPLE graphs, which is what the extraction hands over
+    (graph2pi strips self loops): an edge (a, a) would count into `degree` and the triangle counts here, networkx's clustering drops
+    it; a one-node vicinity gets centrality 1 like nx.degree_centrality (not the division by n - 1 = 0):
       degree      d                                  (subgraph.degree())
       centrality  d * (1.0 / (n - 1.0))              (nx.degree_centrality)
       clustering  t / (d * (d - 1)), t = sum over the neighbours w of |N(v) & N(w)| (each triangle twice), 0 where t == 0
@@ -72,7 +74,7 @@ def structural_filtration(kind, node_ptr, edge_ptr, edges, hks_time=0.1):
         raw = deg.astype(np.float64)
     elif kind == "centrality":
         n_of = np.diff(node_ptr)[owner].astype(np.float64)
-        raw = deg.astype(np.float64) * (1.0 / (n_of - 1.0))
+        raw = np.where(n_of > 1.0, deg.astype(np.float64) * (1.0 / np.where(n_of > 1.0, n_of - 1.0, 1.0)), 1.0)   # (n == 1: nx returns 1)
     else:
         A = sp.csr_matrix((np.ones(2 * len(a), dtype=np.int64), (np.concatenate([a, b]), np.concatenate([b, a]))), shape=(N, N))
         t = np.asarray((A @ A).multiply(A).sum(axis=1)).reshape(-1).astype(np.int64)
@@ -120,10 +122,18 @@ class Vicinities:
             n0, m0 = dev_graph.vicinity_sizes(mapped, hop, flags=fl)
             node_ptr, edge_ptr, totals = engine.pack_offsets(n0, m0)
             E = len(n0)
-            _, _, tot_n, tot_m = totals.tolist() if E else (0, 0, 0, 0)
+            lo_n, _, tot_n, tot_m = totals.tolist() if E else (0, 0, 0, 0)
+            if lo_n < 0:
+                raise RuntimeError("a vicinity has more nodes than the packed local ids hold (status TLC_ST_TOO_LARGE)")
             _, ids, f, n, st, _, edges, m = dev_graph.vicinity_filtration(mapped, hop, flags=fl, zero=False,
                                                                          offsets=(node_ptr, edge_ptr, tot_n, tot_m))
             counts_n, counts_m = node_ptr[1:] - node_ptr[:-1], edge_ptr[1:] - edge_ptr[:-1]
+            # the second pass wrote what the first one counted?  (a vicinity that fails inside the tier kernel writes no edges: its
+            # slice of the exact-size arrays would be uninitialised memory)
+            ok_n = torch.where(edge_ptr[1:] > edge_ptr[:-1], n.long() == counts_n, torch.ones_like(counts_n, dtype=torch.bool))
+            if E and not bool((ok_n & (m.long() == counts_m)).all()):
+                raise RuntimeError("Vicinities.batch: the filtration pass wrote other sizes than the sizes pass counted "
+                                   "(a vicinity failed in its tier kernel, or the graph has self loops / one-sided entries)")
             owner = torch.arange(E, device=mapped.device)
             pn = torch.repeat_interleave(owner, counts_n, output_size=int(tot_n))
             pe = torch.repeat_interleave(owner, counts_m, output_size=int(tot_m))

@@ -29,7 +29,7 @@ SYMBOLS = [
     "tlc_pi_raster", "tlc_pi_raster_wgrad", "tlc_gcn_norm_csr", "tlc_gemm_f32", "tlc_spgemm_csr_dense_f32", "tlc_spmm_csr_f32", "tlc_renorm_rows_f32", "tlc_gcn2_encode_f32",
     "tlc_lp_decode_fused", "tlc_lp_decode_fused_f32", "tlc_gat_layer_fwd", "tlc_gat_layer_tiled_fwd", "tlc_csr_row_minmax", "tlc_scatter_f32", "tlc_edge_head_fwd",
     "tlc_complement_rows", "tlc_complement_pairs", "tlc_select_rows", "tlc_pack_vicinities", "tlc_ollivier_ricci_sinkhorn",
-    "tlc_near_pairs", "tlc_w2_partial_matching", "tlc_w2_inference_matching", "tlc_gat_layer_bwd", "tlc_edge_head_bwd", "tlc_pack_offsets", "tlc_vicinity_sizes", "tlc_debug_dc_stats", "tlc_debug_xl_stats", "tlc_debug_tier_counts", "tlc_debug_phase_profile", "tlc_debug_set_option", "tlc_debug_pair_times",
+    "tlc_near_pairs", "tlc_w2_partial_matching", "tlc_w2_inference_matching", "tlc_gat_layer_bwd", "tlc_edge_head_bwd", "tlc_pack_offsets", "tlc_vicinity_sizes", "tlc_debug_dc_stats", "tlc_debug_tier_counts", "tlc_debug_phase_profile", "tlc_debug_set_option", "tlc_debug_pair_times",
 ]
 
 
@@ -137,7 +137,6 @@ def lib():
                                         C.c_float] + [C.c_void_p] * 9
         L.tlc_debug_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.tlc_debug_dc_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.tlc_debug_xl_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.tlc_debug_tier_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.tlc_debug_phase_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         _lib = L

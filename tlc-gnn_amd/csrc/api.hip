@@ -43,8 +43,6 @@ extern "C" int tlc_device_count(void) {
 #define TLC_EARLY_MIN_PAIRS 4096  /* smaller batches gain nothing from a second COUNT launch */
 #endif
 #define TLC_TIMING_RING 64        /* chunks whose kernel events are kept */
-#define TLC_XL_GB_WG 256          /* workgroups (arena regions, scratch slots) of the launch that extracts what the lane-per-pair pass gave back */
-#define TLC_XL_GB_REGION 1024     /* entries per region there (a vicinity of <= 32 nodes has at most 32 * 31 directed entries) */
 #define TLC_X_REGION 4096         /* arena entries of the region each workgroup of the extraction starts with (extract.hip) */
 
 struct HostSync {
@@ -58,7 +56,6 @@ struct HostSync {
     volatile int pub_tiny[TLC_TINY_BINS];     // the TINY list's size classes
     volatile int pub_dcm;                     // MEDHI / MEDWIDE vicinities with Pos edges enough for the divide and conquer
     volatile int pub_early;
-    volatile int pub_xl[2];        // lane-per-pair extraction: candidates listed, pairs finished as records
     volatile int pub_overflow;
     volatile unsigned pub_seq;
 };
@@ -75,7 +72,7 @@ struct ChunkCtx {
     TlcPdParams pp;
     hipStream_t s;
     int n_pairs, hop, pi_enabled;
-    bool bump, use_x, early, spec, xlane, count_only, tiny_bins, pipelined;
+    bool bump, use_x, early, spec, count_only, tiny_bins, pipelined;
     long long bump_base;
     int xgrid, vgrid, tmask;
     unsigned seq;
@@ -94,17 +91,12 @@ struct Workspace {
     int *hdr_n, *hdr_m2, *hdr_lu, *hdr_lv, *tier_list;
     int* dc_lists;             // [3][cap_pairs + TLC_EARLY_SLOTS]: list positions a tier kernel hands to tlc_pd_dc_kernel (MEDIUM / LARGE / early LARGE)
     int* tiny_bins;            // [TLC_TINY_BINS][cap_pairs]: the TINY list by size class (tlc_scan_bin)
-    int* big_lists;            // [4][cap_pairs]: the bins of tlc_classify_kernel (extract.hip); [3]: pairs the lane-per-pair pass gave back
-    int* xl_list;              // [cap_pairs] candidates of the lane-per-pair extraction (extract_lane.hip)
-    unsigned char* xl_rec;     // their records, one per slot of 64 candidates
-    size_t cap_xl_slots;
+    int* big_lists;            // [4][cap_pairs]: the bins of tlc_classify_kernel (extract.hip; three in use)
     hipEvent_t ev_cls;         // the classification is done (recorded on the early stream)
-    hipEvent_t ev_xl;          // the lane-per-pair extraction is done (recorded on its side stream)
     int prev_dcm;              // the previous chunk's count of MEDHI vicinities for the divide and conquer (decides the speculative chain)
-    int prev_xl_cand;          // its candidates in the previous chunk (sizes the launch of the lane-per-subgraph kernel behind it)
     long long* edge_off;
     // small device block: [0..6] tier counts, [10..13] scan, [16..19] early pass, [20..22] bump allocator, [24] work counter,
-    // [26..31] divide-and-conquer lists, [32..35] bins, [36..37] entry sum, [40..41] lane-per-pair extraction (candidates, finished)
+    // [26..31] divide-and-conquer lists, [32..35] bins, [36..37] entry sum
     int* d_ctl;
     long long* d_block_sums;   // 1024
     long long* d_totals;       // 1
@@ -195,8 +187,6 @@ struct tlc_graph {
     unsigned short* d_be_pos;
     double* d_be_w;
     long long be_entries;
-    long long* d_hptr;             // membership tables of the ball lists (extract_lane.hip); null: none (the lane-per-pair pass is off)
-    int* d_htab;
     long long ball_entries;
     TlcNodeRec* d_nrec;            // node records (extract.hip)
     double* d_hh_w;
@@ -205,36 +195,17 @@ struct tlc_graph {
     size_t x_lds64, x_lds512, x_lds64f;
     // development / test switches (tlc_debug_set_option; initial values from the environment: TLC_EXTRACT, TLC_HEAVY, TLC_TINY)
     int opt_extract, opt_heavy, opt_tiny;
-    int opt_fast_split, opt_xf_grid;   // the subgraph-list pairs in a launch of their own (run_chunk_front), its workgroups (0: 4096)
+    int opt_fast_split;                // the subgraph-list pairs in a launch of their own (run_chunk_front)
     int opt_dc_inplace;            // LARGE tier: divide and conquer by the tier kernel's own workgroup (TlcPdParams::dc_inplace)
     int opt_ball_edges;            // the extraction filters the smaller ball's subgraph list where there is one (extract.hip, x_sweep_ball)
     int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
-    int opt_x_grid, opt_x_chunk_div;    // development: extraction workgroups / work-queue granularity (0: the defaults)
-    int opt_chunk_pairs;                // development: pairs per chunk (0: TLC_CHUNK_PAIRS)
-    int opt_medium_first;               // submit the MEDIUM / MID tiers ahead of TINY / SMALL: -1 a chunk on its own (default), 0 never, 1 always
-    int opt_early_wait;                 // development: 0 = the main COUNT of a pipelined chunk does not wait for the early pass (default 1)
-    int opt_dcm;                        // the divide and conquer for the wide MEDIUM configuration when the scan counted vicinities for it (default 1)
-    int opt_tiny_sort;                  // the TINY list in size classes, largest first (tlc_scan_bin; default 1; 0: pair order, A/B)
-    int opt_tier_sort;                  // development: bit t = the list of tier t (SMALL / MID / MEDIUM) by descending size as well
     int count_only;                     // set by tlc_vicinity_sizes around its run_batch: chunks stop after the scan, their sizes are copied out
-    // LARGE tier as two launches over one list (compact kernels, 72 / 54 KB of LDS, for the vicinities of <= 1 024 nodes / 2 048 edges): 0 never
-    // (default), 1 pipelined chunks, 2 always.  Measured, tools/ab_option.py large_split 0 1: 0.652 -> 0.677 ms per pipelined batch -- the
-    // LDS capacity x time it saves does not pay for a LARGE chain that is two kernels longer and whose workgroups share their CU: the
-    // chunk completes when its LARGE chain does, and only three chunks are in flight.  Rows are bit-equal either way (tests/test_gpu_tiers.py).
-    int opt_large_split;
     int opt_n_ws;                       // workspaces taken in turn (2..TLC_N_WS, default 3)
-    int opt_defer;                      // a pipelined chunk's second half is submitted behind the NEXT chunk's first half (default 1)
-    int opt_gate_ticks;                 // development: bound of the residency gate of pipelined chunks (-1: the default 50 us)
-    int opt_mh_always;                  // tests: split the MEDIUM tier by Pos-edge count in pipelined chunks too
-    int opt_split_launch;               // the tier kernels of all lists are submitted before their second kernels (1)
     int opt_spec_cap;                   // tests: upper bound of the slots reserved for the speculative launches (0 = none)
     int opt_timing_every;               // measurement: kernel events on every n-th chunk only
     unsigned timing_seq;
     int opt_tier_mask;                  // development: which tier kernels are launched at all (timing a tier alone; rows of the others are garbage)
     int opt_x_region, opt_x_bump_min;   // arena entries per workgroup region / minimum bump area of the extraction (tests shrink them)
-    int opt_xl_cut;                     // lane-per-pair extraction: largest smaller-ball size it takes (0: off; <= TLC_XL_MAXCUT)
-    int opt_xl_pipelined;               // tests: the lane-per-pair extraction in pipelined chunks too
-    int opt_xl_ncut, opt_xl_mcut;       // tests: what the lane-per-pair extraction keeps (<= TLC_T_NCUT nodes / TLC_T_MCUT edges)
 };
 
 static int finish_pending(tlc_graph* g);
@@ -251,8 +222,8 @@ static int quiesce(tlc_graph* g) {
 static int ensure_pairs(tlc_graph* g, Workspace* ws, size_t n) {
     if (n <= ws->cap_pairs) return TLC_OK;
     hipFree(ws->hdr_n); hipFree(ws->hdr_m2); hipFree(ws->hdr_lu); hipFree(ws->hdr_lv); hipFree(ws->tier_list); hipFree(ws->edge_off);
-    hipFree(ws->dc_lists); hipFree(ws->big_lists); hipFree(ws->xl_list); hipFree(ws->tiny_bins);
-    ws->hdr_n = ws->hdr_m2 = ws->hdr_lu = ws->hdr_lv = ws->tier_list = ws->dc_lists = ws->big_lists = ws->xl_list = ws->tiny_bins = nullptr;
+    hipFree(ws->dc_lists); hipFree(ws->big_lists); hipFree(ws->tiny_bins);
+    ws->hdr_n = ws->hdr_m2 = ws->hdr_lu = ws->hdr_lv = ws->tier_list = ws->dc_lists = ws->big_lists = ws->tiny_bins = nullptr;
     ws->edge_off = nullptr;
     ws->cap_pairs = 0;
     TLC_HIP_CHECK(hipMalloc(&ws->hdr_n, n * sizeof(int)));
@@ -264,7 +235,6 @@ static int ensure_pairs(tlc_graph* g, Workspace* ws, size_t n) {
     TLC_HIP_CHECK(hipMalloc(&ws->dc_lists, 3 * (n + TLC_EARLY_SLOTS) * sizeof(int)));
     TLC_HIP_CHECK(hipMalloc(&ws->big_lists, 4 * n * sizeof(int)));
     TLC_HIP_CHECK(hipMalloc(&ws->tiny_bins, (size_t)TLC_TINY_BINS * n * sizeof(int)));
-    TLC_HIP_CHECK(hipMalloc(&ws->xl_list, n * sizeof(int)));
     ws->cap_pairs = n;
     return TLC_OK;
 }
@@ -289,16 +259,6 @@ static int ensure_arena(tlc_graph* g, Workspace* ws, size_t entries, size_t keep
     return TLC_OK;
 }
 
-// records of the lane-per-pair extraction: one slot per 64 candidates, at most every pair of the chunk is one
-static int ensure_xl(tlc_graph* g, Workspace* ws, size_t n_pairs) {
-    const size_t slots = (n_pairs + 63) / 64;
-    if (slots <= ws->cap_xl_slots) return TLC_OK;
-    hipFree(ws->xl_rec);
-    ws->xl_rec = nullptr; ws->cap_xl_slots = 0;
-    TLC_HIP_CHECK(hipMalloc(&ws->xl_rec, slots * (size_t)TLC_XL_REC_BYTES));
-    ws->cap_xl_slots = slots;
-    return TLC_OK;
-}
 
 static int ensure_handoff(tlc_graph* g, Workspace* ws, size_t bytes) {
     if (bytes <= ws->cap_handoff) return TLC_OK;
@@ -341,7 +301,7 @@ static int ensure_vic_scratch(tlc_graph* g, Workspace* ws, int hop) {
     // the graph's size), and for hop >= 3 the two BFS frontiers (up to n_nodes each)
     const long long cap = std::min<long long>(g->n_nodes, TLC_MAX_SUBGRAPH_NODES + 1);
     ws->vic_stride = 2 * cap + (need_front ? 2ll * g->n_nodes : 0) + 16;
-    TLC_HIP_CHECK(hipMalloc(&ws->vic_scratch, (size_t)(g->vic_slots + TLC_EARLY_WG + TLC_XL_GB_WG) * ws->vic_stride * sizeof(int)));
+    TLC_HIP_CHECK(hipMalloc(&ws->vic_scratch, (size_t)(g->vic_slots + TLC_EARLY_WG) * ws->vic_stride * sizeof(int)));
     ws->vic_hop_cap = need_front;
     return TLC_OK;
 }
@@ -463,9 +423,9 @@ static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
         const int rq = quiesce(g);                            // (a chunk in flight on another workspace may be reading the lists)
         if (rq != TLC_OK) return rq;
     }
-    hipFree(g->d_bptr); hipFree(g->d_bcol); hipFree(g->d_hptr); hipFree(g->d_htab);
+    hipFree(g->d_bptr); hipFree(g->d_bcol);
     hipFree(g->d_be_ptr); hipFree(g->d_be_pos); hipFree(g->d_be_w);
-    g->d_bptr = g->d_bcol = g->d_htab = nullptr; g->d_hptr = nullptr; g->ball_list_hop = 0; g->ball_entries = 0;
+    g->d_bptr = g->d_bcol = nullptr; g->ball_list_hop = 0; g->ball_entries = 0;
     g->d_be_ptr = nullptr; g->d_be_pos = nullptr; g->d_be_w = nullptr; g->be_entries = 0;
     const int n = g->n_nodes;
     int* d_size = nullptr;
@@ -480,7 +440,7 @@ static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
     long long tot = 0;
     for (int x = 0; x < n; ++x) { const int c = sz[x]; sz[x] = (int)tot; tot += c; if (tot > 0x7fffffffll) break; }
     size_t free_b = 0, total_b = 0;
-    hipMemGetInfo(&free_b, &total_b);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;       // (unknown: the lists are not built, the breadth-first kernels serve)
     if (tot > 0x7fffffffll || (size_t)tot * sizeof(int) > free_b / 4) { g->ball_list_hop = -1; return TLC_OK; }
     sz[n] = (int)tot;
     TLC_HIP_CHECK(hipMalloc(&g->d_bptr, ((size_t)n + 1) * sizeof(int)));
@@ -518,41 +478,6 @@ static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
         if (ok) { g->d_be_ptr = d_bp; g->d_be_pos = d_pos; g->d_be_w = d_bw; g->be_entries = et; }
         else { hipFree(d_bp); hipFree(d_pos); hipFree(d_bw); (void)hipGetLastError(); }
     }
-    if (g->opt_xl_cut <= 0) return TLC_OK;                   // (no lane-per-pair extraction: no tables; the option rebuilds the lists)
-    // membership tables for the lane-per-pair extraction: per node a power of two >= |ball| of four-id buckets, two choices per
-    // id; descriptor = first bucket << 6 | log2(buckets), 63 = no table (a bucket pair overflowed while filling: the pairs that
-    // would look something up there are given back to the wavefront extraction).  Skipped altogether when the tables would not
-    // fit an eighth of the free memory.
-    {
-        std::vector<long long> hd((size_t)n);
-        long long nb = 0;
-        for (int x = 0; x < n; ++x) {
-            const int sx = sz[x + 1] - sz[x];
-            int lg = 0;
-            while ((1ll << lg) < sx) ++lg;
-            hd[x] = (nb << 6) | lg;
-            nb += 1ll << lg;
-        }
-        hipMemGetInfo(&free_b, &total_b);
-        if ((size_t)nb * 16 <= free_b / 8 && nb < (1ll << 40)) {
-            int* d_fail = nullptr;
-            std::vector<int> fail((size_t)n, 0);
-            TLC_HIP_CHECK(hipMalloc(&g->d_hptr, (size_t)n * sizeof(long long)));
-            TLC_HIP_CHECK(hipMalloc(&g->d_htab, (size_t)nb * 16 + 16));
-            TLC_HIP_CHECK(hipMalloc(&d_fail, (size_t)n * sizeof(int)));
-            TLC_HIP_CHECK(hipMemsetAsync(d_fail, 0, (size_t)n * sizeof(int), s));
-            TLC_HIP_CHECK(hipMemsetAsync(g->d_htab, 0xff, (size_t)nb * 16 + 16, s));
-            TLC_HIP_CHECK(hipMemcpyAsync(g->d_hptr, hd.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, s));
-            rc = tlc_launch_ball_hash(n, g->d_bptr, g->d_bcol, g->d_hptr, g->d_htab, d_fail, s);
-            if (rc == TLC_OK && hipMemcpyAsync(fail.data(), d_fail, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) rc = TLC_ERR_HIP;
-            if (rc == TLC_OK && hipStreamSynchronize(s) != hipSuccess) rc = TLC_ERR_HIP;
-            hipFree(d_fail);
-            if (rc != TLC_OK) return rc;
-            bool any = false;
-            for (int x = 0; x < n; ++x) if (fail[x]) { hd[x] |= 63; any = true; }
-            if (any) TLC_HIP_CHECK(hipMemcpy(g->d_hptr, hd.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice));
-        }
-    }
     return TLC_OK;
 }
 
@@ -589,12 +514,8 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     g->opt_extract = env_on("TLC_EXTRACT"); g->opt_heavy = env_on("TLC_HEAVY"); g->opt_tiny = env_on("TLC_TINY");
     g->opt_ball_edges = env_on("TLC_BALL_EDGES"); g->opt_dc_inplace = env_on("TLC_DC_INPLACE") ? 1 : 0;
     g->opt_fast_split = env_on("TLC_FAST_SPLIT") ? 1 : 0;
-    g->opt_defer = env_on("TLC_DEFER"); g->opt_n_ws = 3;
-    // (off unless asked for: in-process A/Bs on the PubMed-shaped batch, tools/ab_option.py xl_cut 0 {16,24,32}, show no gain for
-    // one batch alone and a loss for pipelined batches -- see the note at `xlane` in run_chunk_front and DESIGN.md)
-    { const char* v = getenv("TLC_XL_CUT"); g->opt_xl_cut = v ? std::min(std::max(atoi(v), 0), TLC_XL_MAXCUT) : 0; }
-    g->opt_xl_ncut = TLC_T_NCUT; g->opt_xl_mcut = TLC_T_MCUT;
-    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_large_split = 0; g->opt_early_wait = 1; g->opt_tiny_sort = 1; g->opt_medium_first = -1; g->opt_dcm = 1; g->opt_split_launch = 1; g->opt_timing_every = 1; g->opt_gate_ticks = -1;
+    g->opt_n_ws = 3;
+    g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_timing_every = 1;
     int rc = TLC_OK;
     auto fail = [&](int code) { tlc_graph_destroy(g); return code; };
 #define CK(e) do { if ((e) != hipSuccess) { tlc_set_error("%s failed: %s", #e, hipGetErrorString(hipGetLastError())); return fail(TLC_ERR_HIP); } } while (0)
@@ -672,7 +593,6 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
         CK(hipEventCreateWithFlags(&ws->ev_early, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ws->ev_scan, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ws->ev_cls, hipEventDisableTiming));
-        CK(hipEventCreateWithFlags(&ws->ev_xl, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ws->ev_in, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ws->ev_done, hipEventDisableTiming));
     }
@@ -706,7 +626,7 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     for (int i = 0; i < TLC_N_WS; ++i) {
         Workspace* ws = &g->ws[i];
         hipFree(ws->hdr_n); hipFree(ws->hdr_m2); hipFree(ws->hdr_lu); hipFree(ws->hdr_lv); hipFree(ws->tier_list); hipFree(ws->edge_off);
-        hipFree(ws->dc_lists); hipFree(ws->big_lists); hipFree(ws->xl_list); hipFree(ws->xl_rec); hipFree(ws->tiny_bins);
+        hipFree(ws->dc_lists); hipFree(ws->big_lists); hipFree(ws->tiny_bins);
         hipFree(ws->d_ctl); hipFree(ws->d_block_sums); hipFree(ws->d_totals);
         if (ws->h_sync) hipHostFree(ws->h_sync);
         hipFree(ws->A_dir); hipFree(ws->A_lw); hipFree(ws->S_dir); hipFree(ws->S_lw); hipFree(ws->vic_scratch); hipFree(ws->huge_scratch);
@@ -718,10 +638,10 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
             if (own && ws->side[k]) hipStreamDestroy(ws->side[k]);
             if (ws->ev_join[k]) hipEventDestroy(ws->ev_join[k]);
         }
-        for (hipEvent_t e : {ws->ev_fork, ws->ev_early, ws->ev_scan, ws->ev_in, ws->ev_done, ws->ev_cls, ws->ev_xl}) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : {ws->ev_fork, ws->ev_early, ws->ev_scan, ws->ev_in, ws->ev_done, ws->ev_cls}) if (e) hipEventDestroy(e);
     }
     hipFree(g->d_phase); hipFree(g->d_pair_t);
-    hipFree(g->d_bptr); hipFree(g->d_bcol); hipFree(g->d_hptr); hipFree(g->d_htab); hipFree(g->d_nrec); hipFree(g->d_hh_w);
+    hipFree(g->d_bptr); hipFree(g->d_bcol); hipFree(g->d_nrec); hipFree(g->d_hh_w);
     hipFree(g->d_be_ptr); hipFree(g->d_be_pos); hipFree(g->d_be_w);
     hipFree(g->d_ball_ub[0]); hipFree(g->d_ball_ub[1]);
     if (g->ev_ring_ready)
@@ -839,31 +759,21 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         if ((rc = ensure_ball_lists(g, hop, s)) != TLC_OK) return rc;
         use_x = g->ball_list_hop == hop;
     }
-    // The smallest vicinities one LANE per pair (extract_lane.hip) -- the plain image batch at resolution 5 with the
-    // lane-per-subgraph PD kernel on, behind the classification of the early pass
-    // Measured (tools/ab_option.py xl_cut 0 24, one process): it shortens ONE batch (the main pass loses a third of its pairs and the
-    // lane-per-subgraph kernel starts 0.3 ms earlier) but costs pipelined batches 4 - 8 %: with three chunks in flight every kernel
-    // costs what it occupies, the wavefront extraction spends only ~35 us of machine time per chunk on these pairs, and the lane
-    // kernel's ~80 workgroups of 138 KB LDS + the extra launches and cross-stream waits cost more than that.  So: stream-ordered
-    // single chunks only (option "xl_pipelined" forces it for pipelined chunks: tests).
-    const bool xlane = use_x && early && g->opt_xl_cut > 0 && g->opt_tiny && flags == 0u && res == 5 && g->d_hptr != nullptr &&
-                       (!pipelined || g->opt_xl_pipelined);
-    // (opt_x_grid: development A/B of the number of extraction workgroups; never more than the scratch slots there are)
-    const int xgrid = std::min(n_pairs, g->opt_x_grid > 0 ? std::min(g->opt_x_grid, g->vic_slots) : g->vic_slots);
+    // (2 048 .. 6 400 extraction workgroups measured within 2 %: one per scratch slot)
+    const int xgrid = std::min(n_pairs, g->vic_slots);
     // The pairs whose vicinity is a filter over the smaller ball's subgraph list (extract.hip, x_sweep_ball: smaller ball <= 128
     // nodes, 93 % of a PubMed batch) get a launch of their own, tlc_extract_kernel<64, true>: no row sweep in it, so half the
     // registers, twice the wavefronts, 3.6 KB of LDS -- and it needs nothing from the classification, so it is the FIRST thing on the
     // chunk's main stream and runs beside the classification and the early pass, in front of the residency gate.  The general launch
     // behind the gate leaves those pairs alone (TlcVicParams::fast_split).
     const bool fsplit = use_x && g->opt_fast_split && g->opt_ball_edges && g->d_be_ptr != nullptr && !(flags & TLC_INCLUDE_ROOTS);
-    const int xfgrid = fsplit ? std::min(n_pairs, g->opt_xf_grid > 0 ? g->opt_xf_grid : 4096) : 0;
+    const int xfgrid = fsplit ? std::min(n_pairs, 8192) : 0;        // (2 048 / 4 096 / 8 192 measured: the last by 1 - 2 %)
     long long bump_base = 0;
     if (use_x) {
         // arena = one region per workgroup of the extraction (main pass, then the early pass), then the bump area
-        // (main pass, early pass; then the launch that extracts what the lane-per-pair pass gave back: vicinities of <= 32 nodes, so
-        // many small workgroup regions)
+        // (main pass, early pass, the launch of the subgraph-list pairs)
         const long long regions = (long long)xgrid + TLC_EARLY_WG + xfgrid;
-        bump_base = regions * g->opt_x_region + (long long)TLC_XL_GB_WG * TLC_XL_GB_REGION;
+        bump_base = regions * g->opt_x_region;
         const size_t want = (size_t)bump_base + std::max<size_t>(std::max<size_t>((size_t)n_pairs * 32, (size_t)g->opt_x_bump_min), ws->x_entries_hint + ws->x_entries_hint / 2);
         if (ws->cap_entries < want && (rc = ensure_arena(g, ws, want)) != TLC_OK) return rc;
         vp.small_dir = nullptr; vp.small_lw = nullptr;
@@ -910,7 +820,6 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
     pp.stats = ws->d_stats;
     pp.dc_force_fail = g->opt_dc_force_fail;
-    pp.large_split = ((pipelined && g->opt_large_split == 1) || g->opt_large_split == 2) ? 1 : 0;
     // lists for tlc_pd_dc_kernel: counters in the control block (zeroed with it), [d_ctl + 26 + 2k];
     // k = 0 MEDIUM, 1 LARGE (regular launch), 2 LARGE (early launch)
     auto dc_lists_for = [&](TlcPdParams& q, int k) {
@@ -923,58 +832,10 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         hipStream_t es = ws->side[4];
         // (TLC_INCLUDE_ROOTS adds at most the two roots to a vicinity)
         if (use_x) {
-            // exact ball sizes: the candidates of the early pass, the bins the main pass takes first, and the candidates of the
-            // lane-per-pair pass (smaller ball <= xl_cut nodes)
-            if (xlane && (rc = ensure_xl(g, ws, (size_t)n_pairs)) != TLC_OK) return rc;
+            // exact ball sizes: the candidates of the early pass and the bins the main pass takes first
             if ((rc = tlc_launch_classify(n_pairs, d_pairs, g->n_nodes, g->d_bptr, TLC_M_NMAX - 1, TLC_EARLY_CAND, d_cand_count,
-                                          ws->d_cand_list, ws->d_ctl + 32, ws->big_lists, xlane ? g->opt_xl_cut : 0, ws->d_ctl + 40,
-                                          ws->xl_list, es)) != TLC_OK) return rc;
-            if (!xlane) TLC_HIP_CHECK(hipEventRecord(ws->ev_cls, es));
-            if (xlane) {
-                // The lane-per-pair pass needs the classification only.  It is one wavefront per 64 pairs, ~300 wavefronts that each
-                // run ~80 us of serial lane code: cheap for the machine, long for a chain -- so it runs on a side stream beside the
-                // early pass and the main pass.  Behind it on that stream: a small launch of tlc_extract_kernel for what it gave
-                // back (its own arena regions and scratch slots: the main pass is running), then the lane-per-subgraph kernel for its
-                // records (grid from the previous chunk's count, the workgroups stride over the slots there are).  The main stream
-                // waits for the first two before the scan.
-                hipStream_t xs = ws->side[1];
-                TLC_HIP_CHECK(hipEventRecord(ws->ev_cls, es));
-                TLC_HIP_CHECK(hipStreamWaitEvent(xs, ws->ev_cls, 0));
-                TlcXlParams xp;
-                memset(&xp, 0, sizeof(xp));
-                xp.n_nodes = g->n_nodes; xp.rowptr = g->d_rowptr; xp.col = g->d_col; xp.w = g->d_w; xp.pairs = d_pairs;
-                xp.bptr = g->d_bptr; xp.bcol = g->d_bcol; xp.hptr = g->d_hptr; xp.htab = g->d_htab; xp.nrec = g->d_nrec;
-                if (g->hh_k > 0 && g->opt_heavy) { xp.hh_w = g->d_hh_w; xp.hh_k = g->hh_k; xp.hh_diag = g->hh_diag; }
-                xp.xl_list = ws->xl_list; xp.xl_count = ws->d_ctl + 40; xp.xl_cap = n_pairs;
-                xp.ncut = std::min(g->opt_xl_ncut, TLC_T_NCUT); xp.mcut = std::min(g->opt_xl_mcut, TLC_T_MCUT);
-                xp.hdr_n = ws->hdr_n; xp.hdr_m2 = ws->hdr_m2; xp.hdr_lu = ws->hdr_lu; xp.hdr_lv = ws->hdr_lv;
-                xp.out_pi = d_out_pi; xp.out_status = d_out_status; xp.rec = ws->xl_rec;
-                xp.dbg = g->d_phase ? g->d_phase + 32 * (TLC_N_TIERS + 1) : nullptr;
-                xp.ovf_count = ws->d_ctl + 35; xp.ovf_list = ws->big_lists + 3 * (size_t)n_pairs; xp.done_count = ws->d_ctl + 41;
-                if ((rc = tlc_launch_xlane(xp, std::min((n_pairs + 63) / 64, 2048), xs)) != TLC_OK) return rc;
-                {
-                    TlcVicParams gp = vp;
-                    gp.fill_mode = 1; gp.fill_list = ws->big_lists + 3 * (size_t)n_pairs; gp.fill_count = n_pairs; gp.work_count_dev = ws->d_ctl + 35;
-                    gp.region_base_wg = 0; gp.region_entries = TLC_XL_GB_REGION;
-                    gp.region_base_entries = ((long long)xgrid + TLC_EARLY_WG) * g->opt_x_region;
-                    gp.scratch_base_slot = g->vic_slots + TLC_EARLY_WG;
-                    gp.started = nullptr; gp.early_list = nullptr; gp.early_count = nullptr;
-                    gp.skip_count = nullptr; gp.big_count = nullptr; gp.xl_cut = 0; gp.work_counter = nullptr;
-                    if ((rc = tlc_launch_extract(64, TLC_XL_GB_WG, g->x_lds64, gp, xs)) != TLC_OK) return rc;
-                }
-                TLC_HIP_CHECK(hipEventRecord(ws->ev_xl, xs));
-                {
-                    TlcPdParams tp = pp;
-                    tp.xl_rec = ws->xl_rec; tp.xl_list = ws->xl_list;
-                    tp.tier_count = n_pairs; tp.tier_count_dev = ws->d_ctl + 40;
-                    const int all_slots = (n_pairs + 63) / 64;
-                    tp.xl_slots = ws->prev_xl_cand > 0 ? std::min(all_slots, (ws->prev_xl_cand + 63) / 64 + 8) : all_slots;
-                    tp.phase_cycles = g->d_phase ? g->d_phase + 32 * TLC_TIER_TINY : nullptr;
-                    if (((g->opt_tier_mask >> TLC_TIER_TINY) & 1) && (rc = tlc_launch_pd_tiny_rec(tp, xs)) != TLC_OK) return rc;
-                }
-                TLC_HIP_CHECK(hipEventRecord(ws->ev_join[1], xs));
-                vp.xl_cut = g->opt_xl_cut;
-            }
+                                          ws->d_cand_list, ws->d_ctl + 32, ws->big_lists, es)) != TLC_OK) return rc;
+            TLC_HIP_CHECK(hipEventRecord(ws->ev_cls, es));
         } else if ((rc = tlc_launch_select_heavy(n_pairs, d_pairs, g->n_nodes, g->d_ball_ub[(hop - 1) & 1], TLC_M_NMAX - 1, TLC_EARLY_CAND,
                                                  d_cand_count, ws->d_cand_list, es)) != TLC_OK) return rc;
         TlcVicParams ep = vp;
@@ -1020,14 +881,10 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         // one of its tier kernel, which needs a whole CU's LDS -- is placed only as they drain (measured: the early tier kernel
         // then runs 1.05 instead of 0.88 ms because its last workgroups start ~0.15 ms late).  So the main COUNT is held until
         // the early COUNT is done and the early tier kernel's workgroups are resident (bounded: 50 us after the former).
-        // (opt_early_wait = 0, pipelined chunks, development A/B: the main COUNT waits for the classification only and runs beside the
-        // early pass instead of behind it -- tools/ab_option.py early_wait 1 0: 0.6625 / 0.6604 ms per pipelined batch, rotating 0.619 /
-        // 0.629: no gain, the early pass's 58 us in front of every extraction are not what the pipelined batch pays for)
-        const bool beside = pipelined && use_x && !g->opt_early_wait;
-        TLC_HIP_CHECK(hipStreamWaitEvent(s, beside ? ws->ev_cls : ws->ev_early, 0));
-        // (opt_gate_ticks: the bound in 10 ns ticks, 0 = no gate at all; development A/B of the pipelined case, where the machine
-        // is full of the previous chunk's tier kernels whatever this chunk's extraction does)
-        const long long gate = beside ? 0ll : (pipelined && g->opt_gate_ticks >= 0 ? (long long)g->opt_gate_ticks : 5000ll);
+        // (Measured and dropped, pipelined chunks: the main COUNT beside the early pass instead of behind it, and bounds of the gate
+        // from none to 200 us: all within noise -- the machine is full of the previous chunk's tier kernels either way.)
+        TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_early, 0));
+        const long long gate = 5000ll;                                  // 10 ns ticks
         if (gate > 0)
             hipLaunchKernelGGL(tlc_wait_started_dev, dim3(1), dim3(TLC_WAVE), 0, s, (const int*)d_early_started, (const int*)d_early_count,
                                192, gate);
@@ -1038,7 +895,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     // other chunks' kernels then and the extraction's own tail costs nothing; twice as many for a lone batch.  In-process A/B,
     // tools/gpu_chunk_ab.sh, x_chunk_div 4096 against 8192 / 16384 / 32768: pipelined batch +0.4 / +2.2 / +2.7 %, latency of one
     // batch -1.9 / -1.1 / -1.7 %.  Half as many leaves half of the machine without a first chunk: +6 %)
-    vp.work_chunk = std::max(2, n_pairs / (g->opt_x_chunk_div > 0 ? g->opt_x_chunk_div : pipelined ? 4096 : 8192));
+    vp.work_chunk = std::max(2, n_pairs / (pipelined ? 4096 : 8192));
     // (behind a FAST launch the work list is the two top bins only -- a few thousand pairs of 20 - 80 us: one pair per chunk)
     if (fsplit && early) vp.work_chunk = 1;
     T0(0, s);
@@ -1052,9 +909,8 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     }
     T1(0, s);
     vp.work_counter = nullptr;
-    vp.skip_count = nullptr; vp.big_count = nullptr; vp.xl_cut = 0;      // (the FILL launches below are list-driven)
+    vp.skip_count = nullptr; vp.big_count = nullptr;      // (the FILL launches below are list-driven)
     TLC_HIP_CHECK(hipGetLastError());
-    if (xlane) TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_xl, 0));    // the scan reads the headers of the lane pass and of what it gave back
     if (early) TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_early, 0));   // the scan reads the early list
 
     // exclusive scan of the induced entry counts + tier binning
@@ -1072,16 +928,15 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     // workspaces the machine is full either way and the split only costs: a second pair of kernels per chunk, and the MEDIUM chain's
     // hardest part ahead of the main stream's join (tools/ab_option.py mh_always 1 0, one process: rotating batches 0.718 -> 0.700 ms,
     // the fixed batch 0.729 vs 0.734; profiles/r03_threshold_sweep.txt has the curve over the cut).  So a pipelined chunk does not split.
-    const bool mh_split = !pipelined || g->opt_mh_always;
+    const bool mh_split = !pipelined;
     sp.mh_min_pos = mh_split ? TLC_MH_MIN_POS : 0x7fffffff;
     sp.tiny_ok = (g->opt_tiny && pi_enabled && flags == 0u && res == 5 && !d_out_ids && !d_out_f && !d_out_edges) ? 1 : 0;
     sp.dcm_count = ws->d_ctl + 44; sp.h_dcm = const_cast<int*>(&ws->h_sync_dev->pub_dcm);
     // (the TINY list by size class as well: d_ctl[48..63] count, zeroed with the control block; the scan's flags start at 64)
     static_assert(TLC_TINY_BINS <= 16, "the size-class counters of the TINY list live in d_ctl[48..63]");
-    if (sp.tiny_ok && g->opt_tiny_sort) { sp.tiny_bin_count = ws->d_ctl + 48; sp.tiny_bin_list = ws->tiny_bins; sp.h_tiny_bins = const_cast<int*>(ws->h_sync_dev->pub_tiny); }
+    if (sp.tiny_ok) { sp.tiny_bin_count = ws->d_ctl + 48; sp.tiny_bin_list = ws->tiny_bins; sp.h_tiny_bins = const_cast<int*>(ws->h_sync_dev->pub_tiny); }
     sp.early_list = early ? ws->d_early_list : nullptr; sp.early_count = d_early_count; sp.early_cap = TLC_EARLY_SLOTS;
     sp.h_early = const_cast<int*>(&ws->h_sync_dev->pub_early);
-    sp.xl_counts = xlane ? ws->d_ctl + 40 : nullptr; sp.h_xl = const_cast<int*>(ws->h_sync_dev->pub_xl);
     sp.bump_top = bump ? d_bump_top : nullptr; sp.bump_overflow = d_bump_overflow; sp.bump_base = bump_base;
     sp.h_overflow = const_cast<int*>(&ws->h_sync_dev->pub_overflow);
     // The arena size and the tier counts come back through mapped host memory: the last block of the scan stores them,
@@ -1103,7 +958,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     // (abort flag) and the chunk is redone below.
     static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4, 4};   // timing slot of each tier kernel (TINY is reported with SMALL, MEDHI / MEDWIDE as MEDIUM)
     bool (&used)[TLC_N_SIDE] = c.used;
-    for (int k = 0; k < TLC_N_SIDE; ++k) used[k] = ((k == 4) && early) || ((k == 1) && xlane);
+    for (int k = 0; k < TLC_N_SIDE; ++k) used[k] = (k == 4) && early;
     // The fork point of the side-stream launches that need nothing but the scan.  Recorded here, it is long complete when the
     // host has seen the sizes and submits them, and a wait on a complete event is no command at all -- an event recorded at
     // submission time costs every side stream a barrier packet on a signal that is still in flight: 60 us per chunk (measured:
@@ -1143,7 +998,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
             // (the divide and conquer in this chain only if the previous chunk had vicinities for it: the count is not known yet)
             pp.dc_count = nullptr; pp.dc_list = nullptr;
-            if (ws->prev_dcm > 0 && g->opt_dcm) dc_lists_for(pp, 0);
+            if (ws->prev_dcm > 0) dc_lists_for(pp, 0);
             T0(tslot[t], s);
             if (((g->opt_tier_mask >> t) & 1) && (rc = tlc_launch_pd_tier(t, pp, s)) != TLC_OK) return rc;
             T1(tslot[t], s);
@@ -1152,7 +1007,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         pp.phase = 0;
         pp.grid = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr; pp.handoff = nullptr; pp.handoff_cap = 0;
     }
-    c.bump = bump; c.use_x = use_x; c.early = early; c.spec = spec; c.xlane = xlane; c.bump_base = bump_base; c.xgrid = xgrid; c.seq = seq;
+    c.bump = bump; c.use_x = use_x; c.early = early; c.spec = spec; c.bump_base = bump_base; c.xgrid = xgrid; c.seq = seq;
     c.count_only = g->count_only != 0;
     c.tiny_bins = sp.tiny_bin_count != nullptr;
     c.pipelined = pipelined;
@@ -1222,14 +1077,12 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
     const int n_early = early ? ws->h_sync->pub_early : 0;
     const int n_dcm = ws->h_sync->pub_dcm;
     ws->prev_dcm = n_dcm;
-    const int n_xl_cand = c.xlane ? ws->h_sync->pub_xl[0] : 0, n_xl_done = c.xlane ? ws->h_sync->pub_xl[1] : 0;
     int todo = tc[0] + tc[1] + tc[2] + tc[3] + tc[4] + tc[5] + tc[6] + tc[7];
     if (c.count_only) {
         // tlc_vicinity_sizes: the headers are all it asks for (pp.out_n / out_m: the caller's arrays at this chunk's offset)
         if ((rc = tlc_launch_copy_sizes(n_pairs, ws->hdr_n, ws->hdr_m2, pp.out_n, pp.out_m, s)) != TLC_OK) return rc;
         todo = 0;
     }
-    if (c.xlane) ws->prev_xl_cand = n_xl_cand;
     const bool spec_done = spec && bumped;          // the MID / MEDIUM tiers are already running
     ws->prev_tc[TLC_TIER_MID] = tc[TLC_TIER_MID]; ws->prev_tc[TLC_TIER_MEDIUM] = tc[TLC_TIER_MEDIUM]; ws->prev_tc[TLC_TIER_MEDHI] = tc[TLC_TIER_MEDHI];
     ws->prev_tc[TLC_TIER_MEDWIDE] = tc[TLC_TIER_MEDWIDE];
@@ -1305,21 +1158,13 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
                 TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[k], ws->ev_fork, 0));
             }
             pp.tier_list = ws->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
-            // (opt_tier_sort, development A/B: this tier's list by descending size too -- largest workgroups first)
-            if (((g->opt_tier_sort >> t) & 1) && tc[t] > 64 && (t == TLC_TIER_SMALL || t == TLC_TIER_MID || t == TLC_TIER_MEDIUM)) {
-                const int bin = t == TLC_TIER_SMALL ? 1 : (t == TLC_TIER_MID ? 2 : 3), shift = t == TLC_TIER_SMALL ? 2 : (t == TLC_TIER_MID ? 3 : 4);
-                int* dst = ws->big_lists + (size_t)bin * n_pairs;
-                int r2 = tlc_launch_tiny_sort(tc[t], pp.tier_list, ws->hdr_n, ws->hdr_m2, dst, ws->side[k], shift);
-                if (r2 != TLC_OK) return r2;
-                pp.tier_list = dst;
-            }
             const size_t hs = pi_enabled ? tlc_handoff_slot_bytes(t) : 0;
             pp.handoff = hs ? ws->handoff + hand_base[t] : nullptr;
             pp.handoff_stride = (long long)hs;
             pp.handoff_cap = (spec_done && (t == TLC_TIER_MID || t == TLC_TIER_MEDIUM || t == TLC_TIER_MEDWIDE)) ? std::min(tc[t], spec_cap[t]) : tc[t];
             pp.dc_count = nullptr; pp.dc_list = nullptr; pp.dc_inplace = 0;
             if (t == TLC_TIER_LARGE) { dc_lists_for(pp, 1); pp.dc_inplace = g->opt_dc_inplace; }
-            if ((t == TLC_TIER_MEDHI || t == TLC_TIER_MEDWIDE) && n_dcm > 0 && g->opt_dcm) dc_lists_for(pp, 0);
+            if ((t == TLC_TIER_MEDHI || t == TLC_TIER_MEDWIDE) && n_dcm > 0) dc_lists_for(pp, 0);
             if (hs && t == TLC_TIER_LARGE) {
                 // (the early launch may still be using the first TLC_EARLY_SLOTS slots: this launch takes the ones behind them)
                 int r2 = ensure_handoff_large(g, ws, (size_t)TLC_EARLY_SLOTS + (size_t)tc[t]);
@@ -1330,7 +1175,7 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
             const bool timed = !(early && t == TLC_TIER_LARGE) && !(t == TLC_TIER_MEDIUM && spec) && t != TLC_TIER_MEDWIDE;   // (those slots time the early launch / MEDHI / MEDIUM)
             if (timed) T0(tslot[t], ws->side[k]);
-            const bool two = g->opt_split_launch && hs && !(pp.flags & TLC_NO_EXT1) &&
+            const bool two = hs && !(pp.flags & TLC_NO_EXT1) &&
                              (t == TLC_TIER_MEDIUM || t == TLC_TIER_MID || t == TLC_TIER_MEDHI || t == TLC_TIER_MEDWIDE);
             if (two) pp.phase = 1;                                                                      // (the tier kernel only)
             int r = ((g->opt_tier_mask >> t) & 1) ? tlc_launch_pd_tier(t, pp, ws->side[k]) : TLC_OK;   // (development: tiers timed alone)
@@ -1427,8 +1272,8 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
         // Submission order.  A chunk on its own with the TINY list in size classes: MEDIUM / MID first -- their tier kernels have a
         // serial second kernel behind them and the lane-per-subgraph kernel, no longer the last to finish, only takes LDS from them
         // when it starts alongside (tools/ab_option.py medium_first 0 1: one batch alone 0.7605 -> 0.7325 ms, pipelined batches equal;
-        // with the TINY kernel held back 110 us by an explicit sort it was 0.696).  opt_medium_first: -1 this rule, 0 / 1 forced.
-        if (g->opt_medium_first > 0 || (g->opt_medium_first < 0 && !c.pipelined && c.tiny_bins)) {
+        // with the TINY kernel held back 110 us by an explicit sort it was 0.696).
+        if (!c.pipelined && c.tiny_bins) {
             if ((rc = launch_medium_mid()) != TLC_OK) return rc;
             if ((rc = launch_tiny_small()) != TLC_OK) return rc;
         } else {
@@ -1449,8 +1294,6 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
     g->last_stats[9] += tc[TLC_TIER_MEDHI];
     g->last_stats[TLC_TIER_SMALL] += tc[TLC_TIER_TINY];                 // (reported with SMALL; on its own in [8])
     g->last_stats[8] += tc[TLC_TIER_TINY];
-    g->last_stats[TLC_TIER_SMALL] += n_xl_done;                         // (finished as records by the lane-per-pair extraction)
-    g->last_stats[8] += n_xl_done;
     g->last_stats[TLC_TIER_LARGE] += n_early;
     g->last_stats[7] += tc[TLC_TIER_MID];
     g->last_stats[6] += 1;
@@ -1473,7 +1316,7 @@ static int chunk_entries(Workspace* ws, long long* out) {
     TLC_HIP_CHECK(hipMemcpy(n.data(), ws->hdr_n, n.size() * sizeof(int), hipMemcpyDeviceToHost));
     TLC_HIP_CHECK(hipMemcpy(m2.data(), ws->hdr_m2, m2.size() * sizeof(int), hipMemcpyDeviceToHost));
     long long e = 0;
-    for (size_t k = 0; k < n.size(); ++k) if (n[k] > 0) e += m2[k] & ~TLC_XL_DONE_FLAG;
+    for (size_t k = 0; k < n.size(); ++k) if (n[k] > 0) e += m2[k];
     *out = e;
     return TLC_OK;
 }
@@ -1529,6 +1372,17 @@ static int acquire_workspace(tlc_graph* g, Workspace** out, bool same) {
 
 // `join`: the caller's stream waits for the chunks before the call returns (the stream-ordered contract of tlc_pd_pi_batch);
 // else they are left in flight (tlc_pd_pi_batch_async) until tlc_pd_pi_batch_join.
+// An error in the middle of a batch (an allocation that failed, a launch the runtime refused): the chunks in flight are waited for
+// as far as the device still answers, and the handle forgets them -- the next call starts from a clean state instead of finishing a
+// chunk whose first half never ran (review of round 4).  Returns rc.
+static int fail_batch(tlc_graph* g, int rc) {
+    g->pending = nullptr;
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    for (int k = 0; k < TLC_N_WS; ++k) { g->ws[k].busy = 0; g->ws[k].in_call = 0; g->ws[k].back_pending = 0; }
+    return rc;
+}
+
 static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int hop, uint32_t flags, int res,
                      double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
                      double* d_out_f, int32_t* d_out_n, const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m,
@@ -1547,8 +1401,9 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
     hipStream_t s = (hipStream_t)stream;
     // a single chunk of a stream-ordered call runs on the caller's stream itself (no cross-stream hops in its latency);
     // otherwise every chunk runs on its workspace's own stream so that consecutive chunks overlap
-    // (opt_chunk_pairs: development A/B -- a long list cut into more, pipelined chunks)
-    const int64_t chunk_pairs = g->opt_chunk_pairs > 0 ? std::min<int64_t>(g->opt_chunk_pairs, TLC_CHUNK_PAIRS) : TLC_CHUNK_PAIRS;
+    // (test hook: TLC_CHUNK_PAIRS_TEST in the environment cuts a list into smaller chunks so that small inputs reach the multi-chunk path)
+    static const int64_t chunk_env = getenv("TLC_CHUNK_PAIRS_TEST") ? atoll(getenv("TLC_CHUNK_PAIRS_TEST")) : 0;
+    const int64_t chunk_pairs = chunk_env > 0 ? std::min<int64_t>(chunk_env, TLC_CHUNK_PAIRS) : TLC_CHUNK_PAIRS;
     const bool inline_main = join && n_pairs <= chunk_pairs;
     // Deferred second halves (asynchronous batches and the chunks of a long list): a chunk's tier launches need the sizes its scan
     // publishes, ~0.3 ms after the chunk was submitted.  A host that waits for them before it submits the NEXT chunk's first half
@@ -1556,20 +1411,22 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
     // host round trip.  So the next chunk's first half goes in first, and then the host waits for this chunk's sizes: the first
     // half of chunk i+1 runs under the tier kernels of chunk i.  The last chunk's second half is submitted by the join
     // (tlc_pd_pi_batch_join, or the end of this call).
-    const bool defer = !inline_main && g->opt_defer;
+    const bool defer = !inline_main;
     int rc;
-    if (!defer && (rc = finish_pending(g)) != TLC_OK) return rc;
+    if (!defer && (rc = finish_pending(g)) != TLC_OK) return fail_batch(g, rc);
     for (int64_t off = 0; off < n_pairs; off += chunk_pairs) {
         const int cnt = (int)std::min<int64_t>(chunk_pairs, n_pairs - off);
         Workspace* ws = nullptr;
         // (sizes already there: nothing to wait for, and the tier kernels should not queue behind another extraction)
-        if (g->pending && sizes_published(g->pending) && (rc = finish_pending(g)) != TLC_OK) return rc;
+        if (g->pending && sizes_published(g->pending) && (rc = finish_pending(g)) != TLC_OK) return fail_batch(g, rc);
         rc = acquire_workspace(g, &ws, inline_main);
-        if (rc != TLC_OK) return rc;
+        if (rc != TLC_OK) return fail_batch(g, rc);
         hipStream_t m = inline_main ? s : ws->main;
         if (!inline_main) {
-            TLC_HIP_CHECK(hipEventRecord(ws->ev_in, s));
-            TLC_HIP_CHECK(hipStreamWaitEvent(m, ws->ev_in, 0));
+            if (hipEventRecord(ws->ev_in, s) != hipSuccess || hipStreamWaitEvent(m, ws->ev_in, 0) != hipSuccess) {
+                tlc_set_error("run_batch: %s", hipGetErrorString(hipGetLastError()));
+                return fail_batch(g, TLC_ERR_HIP);
+            }
         }
         // NOTE: ids_off is indexed by the global pair index, the kernels index by chunk-local index
         rc = run_chunk_front(g, ws, d_pairs + 2 * off, cnt, hop, flags, res,
@@ -1578,14 +1435,14 @@ static int run_batch(tlc_graph* g, const int32_t* d_pairs, int64_t n_pairs, int 
                        d_ids_off ? d_ids_off + off : nullptr, d_out_ids, d_out_f,
                        d_out_n ? d_out_n + off : nullptr, d_edge_offs ? d_edge_offs + off : nullptr, d_out_edges,
                        d_out_m ? d_out_m + off : nullptr, pi_enabled, m, !inline_main);
-        if (rc != TLC_OK) return rc;
+        if (rc != TLC_OK) return fail_batch(g, rc);
         ws->busy = 1; ws->in_call = 1; ws->n_pairs = cnt;
         g->last_ws = ws;
-        if ((rc = finish_pending(g)) != TLC_OK) return rc;      // the previous chunk's second half (none unless deferred)
+        if ((rc = finish_pending(g)) != TLC_OK) return fail_batch(g, rc);      // the previous chunk's second half (none unless deferred)
         g->pending = ws;
-        if (!defer && (rc = finish_pending(g)) != TLC_OK) return rc;
+        if (!defer && (rc = finish_pending(g)) != TLC_OK) return fail_batch(g, rc);
     }
-    if (join && (rc = finish_pending(g)) != TLC_OK) return rc;
+    if (join && (rc = finish_pending(g)) != TLC_OK) return fail_batch(g, rc);
     // tlc_pd_pi_batch == async + join: the caller's stream also waits for asynchronous batches still in flight on the other
     // workspaces (a single stream-ordered chunk runs on `s` itself; a wait on a complete event is no command at all)
     if (join)
@@ -1797,39 +1654,12 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "ball_edges")) g->opt_ball_edges = value != 0;
     else if (!strcmp(name, "dc_inplace")) g->opt_dc_inplace = value != 0;
     else if (!strcmp(name, "fast_split")) g->opt_fast_split = value != 0;
-    else if (!strcmp(name, "xf_grid")) g->opt_xf_grid = std::max(value, 0);
     else if (!strcmp(name, "tier_mask")) g->opt_tier_mask = value;
     else if (!strcmp(name, "spec_cap")) g->opt_spec_cap = std::max(value, 0);
-    else if (!strcmp(name, "split_launch")) g->opt_split_launch = value != 0;
-    else if (!strcmp(name, "mh_always")) g->opt_mh_always = value != 0;
-    else if (!strcmp(name, "gate_ticks")) g->opt_gate_ticks = value;
-    else if (!strcmp(name, "medium_first")) g->opt_medium_first = value;
-    else if (!strcmp(name, "large_split")) g->opt_large_split = value;
-    else if (!strcmp(name, "early_wait")) g->opt_early_wait = value != 0;
-    else if (!strcmp(name, "tiny_sort")) g->opt_tiny_sort = value != 0;
-    else if (!strcmp(name, "dcm")) g->opt_dcm = value != 0;
-    else if (!strcmp(name, "tier_sort")) g->opt_tier_sort = value;
     else if (!strcmp(name, "n_ws")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_n_ws = std::min(std::max(value, 2), TLC_N_WS); }
-    else if (!strcmp(name, "defer")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_defer = value != 0; }
-    else if (!strcmp(name, "chunk_pairs")) g->opt_chunk_pairs = std::max(value, 0);
-    else if (!strcmp(name, "x_grid")) g->opt_x_grid = std::max(value, 0);
-    else if (!strcmp(name, "x_chunk_div")) g->opt_x_chunk_div = std::max(value, 0);
     else if (!strcmp(name, "timing_every")) { g->opt_timing_every = std::max(value, 1); g->timing_seq = 0; }
     else if (!strcmp(name, "dc_force_fail")) g->opt_dc_force_fail = value != 0;
-    else if (!strcmp(name, "xl_cut")) {
-        g->opt_xl_cut = std::min(std::max(value, 0), TLC_XL_MAXCUT);
-        if (g->opt_xl_cut > 0 && !g->d_hptr && g->ball_list_hop > 0) {
-            // the membership tables are built with the ball lists: have them rebuilt by the next batch
-            int rc_p = quiesce(g);
-            if (rc_p != TLC_OK) return rc_p;
-            g->ball_list_hop = 0;
-        }
-    }
-    else if (!strcmp(name, "xl_pipelined")) g->opt_xl_pipelined = value != 0;
-    else if (!strcmp(name, "xl_ncut")) g->opt_xl_ncut = std::min(std::max(value, 1), TLC_T_NCUT);
-    else if (!strcmp(name, "xl_mcut")) g->opt_xl_mcut = std::min(std::max(value, 0), TLC_T_MCUT);
-    else if (!strcmp(name, "x_region")) g->opt_x_region = std::max(value, 0);
-    else if (!strcmp(name, "x_bump_min")) g->opt_x_bump_min = std::max(value, 0);
+    else if (!strcmp(name, "x_arena")) { g->opt_x_region = value > 0 ? value : TLC_X_REGION; g->opt_x_bump_min = value > 0 ? value : (1 << 20); }
     else { tlc_set_error("tlc_debug_set_option: unknown option '%s'", name); return TLC_ERR_INVALID_ARG; }
     return TLC_OK;
 }
@@ -1863,21 +1693,6 @@ extern "C" int tlc_debug_tier_counts(tlc_graph* g, long long* h_out, void* strea
     return TLC_OK;
 }
 
-// diagnostics: the lane-per-pair extraction in the last chunk -- h_out[0] candidates (smaller ball <= the cut), h_out[1] pairs it
-// finished as records for the lane-per-subgraph kernel (the rest were zero rows or given back to the wavefront extraction)
-extern "C" int tlc_debug_xl_stats(tlc_graph* g, long long* h_out, void* stream) {
-    TLC_REQUIRE(g && h_out, "null argument");
-    TLC_ON_DEVICE(g->device);
-    { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; }
-    TLC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    h_out[0] = h_out[1] = 0;
-    if (g->last_ws && g->last_ws->ctx.xlane) {
-        if (g->last_ws->busy) { TLC_HIP_CHECK(hipEventSynchronize(g->last_ws->ev_done)); g->last_ws->busy = 0; }
-        h_out[0] = g->last_ws->h_sync->pub_xl[0];
-        h_out[1] = g->last_ws->h_sync->pub_xl[1];
-    }
-    return TLC_OK;
-}
 
 // ---- measurement helpers (declared in include/tlcgnn.h) ----------------------------------------------------------------
 extern "C" int tlc_pd_pi_batch_set_timing(tlc_graph* g, int enable) {
@@ -1943,7 +1758,6 @@ extern "C" int tlc_pd_pi_batch_sizes(tlc_graph* g, int32_t* h_n, int32_t* h_m2, 
         if (g->last_ws->busy) { TLC_HIP_CHECK(hipEventSynchronize(g->last_ws->ev_done)); g->last_ws->busy = 0; }
         TLC_HIP_CHECK(hipMemcpy(h_n, g->last_ws->hdr_n, k * sizeof(int), hipMemcpyDeviceToHost));
         TLC_HIP_CHECK(hipMemcpy(h_m2, g->last_ws->hdr_m2, k * sizeof(int), hipMemcpyDeviceToHost));
-        for (size_t q = 0; q < k; ++q) h_m2[q] &= ~TLC_XL_DONE_FLAG;     // (the mark of the lane-per-pair extraction is not a size)
     }
     return TLC_OK;
 }

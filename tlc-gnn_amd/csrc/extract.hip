@@ -523,7 +523,6 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
             if (p.skip_count && mn >= p.skip_threshold) {
                 if (*p.skip_count <= p.skip_cap) return;
             } else if (p.big_count && mn >= TLC_X_BIN_MIN) return;
-            else if (mn <= p.xl_cut) return;              // a candidate of the lane-per-pair pass (given back: bin 3, a launch of its own)
         }
     }
     // FILL pass (the scan has laid the chunk out after an arena overflow; a heavy tier the early pass did not take): the
@@ -533,7 +532,6 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
         const int hn = p.hdr_n[i];
         if (hn <= 0) return;                                             // finished by the COUNT pass
         fill_m2 = p.hdr_m2[i];
-        if (fill_m2 & TLC_XL_DONE_FLAG) return;                          // finished by the lane-per-pair pass (no arena room)
         if (p.fill_mode == 2 && (hn > TLC_M_NMAX || (fill_m2 >> 1) > TLC_M_MMAX)) return;   // filled from the heavy tiers' lists
     }
     if (missing) {
@@ -842,7 +840,7 @@ __global__ __launch_bounds__(BW, BW == 64 ? (FAST ? 8 : TLC_X_WPE) : 1) void tlc
     // dealt in strided chunks, the first chunk of a workgroup being its own index and the rest coming from a counter (one
     // dequeue per chunk: a single counter serves ~90 dequeues/us, MI355X_MICROARCH.md) -- so the big items, which sit at
     // the lowest item numbers, are the FIRST item of the first workgroups.
-    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int c0 = 0, c1 = 0, c2 = 0;
     int n_work = p.n_pairs;
     if (p.fill_mode == 1) {
         n_work = p.fill_count;
@@ -853,9 +851,7 @@ __global__ __launch_bounds__(BW, BW == 64 ? (FAST ? 8 : TLC_X_WPE) : 1) void tlc
         // the bins have a smaller ball of < 128 nodes, which the FAST launch owns (TLC_BE_CAP = 128 >= TLC_X_BIN_MIN)
         // (unless the early pass's candidate list overflowed: the candidates it could not hold are reached by index only)
         if (p.fast_split && !p.x_fill && !(p.skip_count && *p.skip_count > p.skip_cap)) { c2 = 0; n_work = 0; }
-        // (bin 3 -- what the lane-per-pair pass gave back -- is NOT taken here: that pass runs beside this one; a launch of its own
-        // goes through that list afterwards, fill_mode 1)
-        n_work += c0 + c1 + c2 + c3;
+        n_work += c0 + c1 + c2;
     }
     // The parameter block is read through the kernel-argument segment pointer, laundered per item: every field is a scalar load
     // inside the body instead of a value hoisted in front of the persistent loop (which had cost 110 spilled SGPRs).
@@ -871,9 +867,8 @@ __global__ __launch_bounds__(BW, BW == 64 ? (FAST ? 8 : TLC_X_WPE) : 1) void tlc
         if (w < c0) return ((XCInt*)q->big_list)[w];
         if (w < c0 + c1) return ((XCInt*)q->big_list)[(size_t)q->n_pairs + (w - c0)];
         if (w < c0 + c1 + c2) return ((XCInt*)q->big_list)[2 * (size_t)q->n_pairs + (w - c0 - c1)];
-        if (w < c0 + c1 + c2 + c3) return ((XCInt*)q->big_list)[3 * (size_t)q->n_pairs + (w - c0 - c1 - c2)];
         from_rest = true;
-        return w - c0 - c1 - c2 - c3;
+        return w - c0 - c1 - c2;
     };
     auto pair_of = [&](XParams* q, int i, int& u, int& v) {
         XCInt* pr = (XCInt*)q->pairs + 2 * (size_t)i;
@@ -974,7 +969,6 @@ __global__ __launch_bounds__(BW, BW == 64 ? (FAST ? 8 : TLC_X_WPE) : 1) void tlc
                 if (fr1) {                                                   // (a pair another pass owns: extract_pair's predicates)
                     if (q->skip_count && nB >= q->skip_threshold) return;
                     else if (q->big_count && nB >= TLC_X_BIN_MIN) return;
-                    else if (nB <= q->xl_cut) return;
                 }
                 const int* bc = q->bcol;
                 const int j = (int)threadIdx.x;
@@ -1075,13 +1069,11 @@ int tlc_launch_extract(int bw, int grid, size_t lds, const TlcVicParams& p, void
 // ---- which pairs go first ------------------------------------------------------------------------------------------------
 // k = min(|ball(u)|, |ball(v)|) >= |S|.  k >= cand_threshold: candidate of the early pass (at most cand_cap are listed; the
 // count keeps running so that the main pass knows whether the list is complete).  Else k >= 256 / 128 / 64: bins 0 / 1 / 2.
-// k <= xl_cut: candidate of the lane-per-pair pass (extract_lane.hip), class 4 (xl_cut = 0: none).
 __global__ void tlc_classify_kernel(int n_pairs, const int* __restrict__ pairs, int n_nodes, const int* __restrict__ bptr,
                                     int cand_threshold, int cand_cap, int* __restrict__ cand_count, int* __restrict__ cand_list,
-                                    int* __restrict__ big_count, int* __restrict__ big_list, int xl_cut, int* __restrict__ xl_count,
-                                    int* __restrict__ xl_list) {
+                                    int* __restrict__ big_count, int* __restrict__ big_list) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int cls = -1;                                         // 3 = candidate, 0..2 = bin, 4 = lane-per-pair pass
+    int cls = -1;                                         // 3 = candidate, 0..2 = bin
     if (i < n_pairs) {
         const int u = pairs[2 * (size_t)i], v = pairs[2 * (size_t)i + 1];
         if (u >= 0 && v >= 0 && u < n_nodes && v < n_nodes) {
@@ -1094,36 +1086,33 @@ __global__ void tlc_classify_kernel(int n_pairs, const int* __restrict__ pairs, 
             else if (k >= 256) cls = 0;
             else if (k >= 128) cls = 1;
             else if (k >= TLC_X_BIN_MIN) cls = 2;
-            else if (k <= xl_cut) cls = 4;
         }
     }
     // one round of atomics per wavefront: lane c reserves the room of class c, then the bases go round
-    unsigned long long mk[5];
+    unsigned long long mk[4];
 #pragma unroll
-    for (int c = 0; c < 5; ++c) mk[c] = __ballot(cls == c);
+    for (int c = 0; c < 4; ++c) mk[c] = __ballot(cls == c);
     const int lane = tlc_lane();
     int base = 0;
-    if (lane < 5) {
-        const unsigned long long m = lane == 0 ? mk[0] : (lane == 1 ? mk[1] : (lane == 2 ? mk[2] : (lane == 3 ? mk[3] : mk[4])));
-        if (m) base = atomicAdd(lane == 3 ? cand_count : (lane == 4 ? xl_count : &big_count[lane]), __popcll(m));
+    if (lane < 4) {
+        const unsigned long long m = lane == 0 ? mk[0] : (lane == 1 ? mk[1] : (lane == 2 ? mk[2] : mk[3]));
+        if (m) base = atomicAdd(lane == 3 ? cand_count : &big_count[lane], __popcll(m));
     }
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
+    for (int c = 0; c < 4; ++c) {
         const int bc = __builtin_amdgcn_readlane(base, c);
         if (cls == c) {
             const int pos = bc + __popcll(mk[c] & tlc_lanemask_lt());
             if (c == 3) { if (pos < cand_cap) cand_list[pos] = i; }
-            else if (c == 4) xl_list[pos] = i;
             else big_list[(size_t)c * n_pairs + pos] = i;
         }
     }
 }
 int tlc_launch_classify(int n_pairs, const int* pairs, int n_nodes, const int* bptr, int cand_threshold, int cand_cap,
-                        int* cand_count, int* cand_list, int* big_count, int* big_list, int xl_cut, int* xl_count, int* xl_list,
-                        void* stream) {
+                        int* cand_count, int* cand_list, int* big_count, int* big_list, void* stream) {
     if (n_pairs <= 0) return TLC_OK;
     hipLaunchKernelGGL(tlc_classify_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_pairs, pairs, n_nodes,
-                       bptr, cand_threshold, cand_cap, cand_count, cand_list, big_count, big_list, xl_cut, xl_count, xl_list);
+                       bptr, cand_threshold, cand_cap, cand_count, cand_list, big_count, big_list);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }

@@ -1415,7 +1415,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
 #define TLC_PRIO_SMALL 0
 #endif
     if constexpr (!HUGE) {
-        constexpr int prio = (NM == TLC_L_NMAX || NM == TLC_LC_NMAX) ? TLC_PRIO_LARGE : ((NM == TLC_M_NMAX || NM == TLC_C_NMAX) ? TLC_PRIO_MEDIUM : (NM == TLC_D_NMAX ? TLC_PRIO_MID : TLC_PRIO_SMALL));
+        constexpr int prio = (NM == TLC_L_NMAX) ? TLC_PRIO_LARGE : ((NM == TLC_M_NMAX || NM == TLC_C_NMAX) ? TLC_PRIO_MEDIUM : (NM == TLC_D_NMAX ? TLC_PRIO_MID : TLC_PRIO_SMALL));
         if constexpr (prio > 0) __builtin_amdgcn_s_setprio(prio);
     }
     // this workgroup is resident: tell the launcher's gate (api.hip, tlc_wait_started)
@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
     int tier_count = p.tier_count;
     if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
     // (both launches of a split LARGE tier count: the gate's target is the list's length, reached as soon as the first one is resident)
-    if ((NM == TLC_L_NMAX || NM == TLC_LC_NMAX) && !HUGE && p.started && tid == 0 && (int)blockIdx.x < tier_count) atomicAdd(p.started, 1);
+    if ((NM == TLC_L_NMAX) && !HUGE && p.started && tid == 0 && (int)blockIdx.x < tier_count) atomicAdd(p.started, 1);
     // HUGE: the workgroups stride over the list (one scratch slot each).  The LDS tiers: ONE subgraph per workgroup, list position
     // wi_base + blockIdx.x -- no loop around the body, so that nothing of it is hoisted in front of it and kept in registers
     // across all of its phases (that was the tiers' register spilling: thread-id arithmetic and image constants of every phase,
@@ -1432,13 +1432,6 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
     if (wi >= tier_count) return;
     do {
         const int i = p.tier_list[wi];
-        if constexpr (!HUGE && (NM == TLC_L_NMAX || NM == TLC_LC_NMAX)) {
-            // split LARGE tier: this launch takes the vicinities that fit the compact kernels, or the others (before the slot is touched)
-            if (p.large_split && i >= 0) {
-                const bool fits = p.hdr_n[i] <= TLC_LC_NMAX && (p.hdr_m2[i] >> 1) <= TLC_LC_MMAX;
-                if ((NM == TLC_LC_NMAX) != fits) continue;
-            }
-        }
         // hand-off slot of this subgraph (tiers whose cycle swap runs in tlc_pd_swap_kernel); "nothing pending" until decided
         unsigned char* slot = (!HUGE && p.handoff && wi < p.handoff_cap) ? p.handoff + (size_t)wi * (size_t)p.handoff_stride : nullptr;
         bool deferred = false;
@@ -1681,12 +1674,12 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
             TLC_STAMP(4);
             // (the compact LARGE kernels sort like the wide ones -- same run / merge decisions, so a vicinity's row does not depend on which of
             // the two took it)
-            status = pd_all_stages<W, sort_hold(NM == TLC_LC_NMAX ? TLC_L_MMAX : MM, W)>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, slot, deferred,
-                                      /*dc_mode=*/(!HUGE && (NM == TLC_L_NMAX || NM == TLC_LC_NMAX)) ? TLC_DC_LARGE_MODE
+            status = pd_all_stages<W, sort_hold(MM, W)>(M, sink, n, m, p.flags, MMr, NMr, pc, t_prev, ph, slot, deferred,
+                                      /*dc_mode=*/(!HUGE && (NM == TLC_L_NMAX)) ? TLC_DC_LARGE_MODE
                                                   : ((!HUGE && NM == TLC_M_NMAX) ? 2 : 0),     // (whether or not the launch carries a
                                       // dc list: marking a subgraph for the divide and conquer fixes the order of its tied descending
                                       // keys, and a row must not depend on whether tlc_pd_dc_kernel or the serial walk then answers)
-                                      /*handoff_all=*/NM != TLC_L_NMAX && NM != TLC_LC_NMAX);
+                                      /*handoff_all=*/NM != TLC_L_NMAX);
             bool dc_here = false;
             if constexpr (!HUGE && NM == TLC_L_NMAX) dc_here = p.dc_inplace != 0;
             if (deferred && slot && !dc_here && tid == 0 && p.dc_count && ((const int*)slot)[6] != 0) {
@@ -1928,12 +1921,6 @@ __global__ __launch_bounds__(W, (W <= 256 ? 4 : 1)) void tlc_pd_dc_kernel(TlcPdP
     if (li >= n_list) return;
     const int wi = p.dc_list[li];
     if (wi < 0 || wi >= tier_count) return;
-    if (p.large_split) {                  // (split LARGE tier: the record was written by the tier kernel of the same configuration)
-        const int ii = p.tier_list[wi];
-        if (ii < 0) return;
-        const bool fits = p.hdr_n[ii] <= TLC_LC_NMAX && (p.hdr_m2[ii] >> 1) <= TLC_LC_MMAX;
-        if ((NM == TLC_LC_NMAX) != fits) return;
-    }
     dc_subgraph<NM, MM, W>(p, wi, lds_raw);
 }
 
@@ -2357,15 +2344,6 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             const size_t lds_bytes = (L.total > 156 * 1024 || !(excl & 1)) ? L.total : 156 * 1024;
             int rc = set_lds_limit(tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>, lds_bytes);
             if (rc) return rc;
-            constexpr Layout LC = make_layout(TLC_LC_NMAX, TLC_LC_MMAX, false, 2);
-            if (p.large_split) {
-                // (the compact kernels first: most of the list; every workgroup of either launch looks at its vicinity's size and leaves
-                // the other launch's alone)
-                rc = set_lds_limit(tlc_pd_tier_kernel<TLC_LC_NMAX, TLC_LC_MMAX, TLC_L_THREADS, false, false>, LC.total);
-                if (rc) return rc;
-                hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_LC_NMAX, TLC_LC_MMAX, TLC_L_THREADS, false, false>), dim3(p.tier_count),
-                                   dim3(TLC_L_THREADS), LC.total, s, p);
-            }
             hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>), dim3(p.tier_count),
                                dim3(TLC_L_THREADS), lds_bytes, s, p);
             if (deferring) {
@@ -2376,13 +2354,6 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
                 if (host_trace) { static int once = 0; if (!once++) fprintf(stderr, "[tlc] LARGE tier LDS %zu (layout %zu), dc %zu (layout %zu)\n", lds_bytes, (size_t)L.total, dcl, (size_t)dc_kernel_lds(TLC_L_NMAX, TLC_L_MMAX)); }
                 rc = set_lds_limit(tlc_pd_dc_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS>, dcl);
                 if (rc) return rc;
-                if (p.dc_count && p.large_split) {
-                    constexpr size_t dcc = dc_kernel_lds(TLC_LC_NMAX, TLC_LC_MMAX);
-                    rc = set_lds_limit(tlc_pd_dc_kernel<TLC_LC_NMAX, TLC_LC_MMAX, TLC_L_THREADS>, dcc);
-                    if (rc) return rc;
-                    hipLaunchKernelGGL((tlc_pd_dc_kernel<TLC_LC_NMAX, TLC_LC_MMAX, TLC_L_THREADS>), dim3(p.tier_count),
-                                       dim3(TLC_L_THREADS), dcc, s, p);
-                }
                 if (p.dc_count && !p.dc_inplace)
                     hipLaunchKernelGGL((tlc_pd_dc_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS>), dim3(p.tier_count),
                                        dim3(TLC_L_THREADS), dcl, s, p);

@@ -124,10 +124,8 @@ static_assert(2 * (size_t)TM * 64 + (size_t)TN * 64 <= 5 * (size_t)TN * 64, "ord
 
 }  // namespace
 
-// REC: the subgraphs come as records of the lane-per-pair extraction (extract_lane.hip; slot = 64 candidates, lane = lane), else
-// from the arena through a tier list (slot = 64 list positions).
+// The subgraphs come from the arena through a tier list (slot = 64 list positions).
 // one slot of 64 subgraphs on one wavefront; `lds`: the wavefront's TINY_WG_BYTES
-template <bool REC>
 __device__ __forceinline__ void tiny_slot(const TlcPdParams p, unsigned char* lds, int lane, int slot) {
     // carve (see the region table above)
     LaneArr<double> ew{(double*)(lds + T_OA) + lane};
@@ -157,15 +155,7 @@ __device__ __forceinline__ void tiny_slot(const TlcPdParams p, unsigned char* ld
     int i, n, m2 = 0, lu, lv, m = 0;
     const unsigned* adir = nullptr;
     const double* alw = nullptr;
-    const unsigned char* rec = nullptr;
-    if (REC) {
-        rec = p.xl_rec + (size_t)slot * TLC_XL_REC_BYTES;
-        const unsigned hdr = ((const unsigned*)rec)[lane];
-        if (hdr == 0xffffffffu) return;                   // no pair in this lane, or finished / given back by the extraction
-        i = p.xl_list[slot * 64 + lane];
-        n = (int)(hdr & 0xffu); m = (int)((hdr >> 8) & 0xffu);
-        lu = (int)(signed char)((hdr >> 16) & 0xffu); lv = (int)(signed char)(hdr >> 24);
-    } else {
+    {
         if (p.tiny_bin_list) {
             // the list by size class: this wavefront's 64 entries come from ONE bin (slots are dealt to the bins in order, largest first)
             int s = slot, b = 0;
@@ -192,12 +182,7 @@ __device__ __forceinline__ void tiny_slot(const TlcPdParams p, unsigned char* ld
     unsigned long long* pc = p.phase_cycles;
     unsigned long long t_prev = pc ? clock64() : 0ull;
 #define TINY_STAMP(k) do { if (pc) { const unsigned long long _t = clock64(); if (lane == 0) atomicAdd(&pc[(k)], _t - t_prev); t_prev = _t; } } while (0)
-    if (REC) {
-        // the record holds the undirected edge list itself (lower local id first), in the order the arena entries would have had
-        const unsigned* re_ = (const unsigned*)(rec + TLC_XL_REC_EDGE_OFF) + lane;
-        const double* rw_ = (const double*)(rec + TLC_XL_REC_W_OFF) + lane;
-        for (int e = 0; e < m; ++e) { eab[e] = (unsigned short)re_[e * 64]; ew[e] = rw_[e * 64]; }
-    } else {
+    {
         // undirected edge list: the directed entries with src < dst, in CSR order.  Eight entries (and their weights, wanted or not)
         // are requested before the first is looked at: every lane reads its own subgraph, so a load is 64 scattered lines, and one
         // entry per round trip made this loop 22 % of the kernel (tools/tiny_profile.py: 105 k of 479 k cycles per wavefront)
@@ -437,28 +422,8 @@ __global__ __launch_bounds__(64) void tlc_pd_tiny_kernel(TlcPdParams p) {
 #define TLC_PRIO_TINY 0
 #endif
     if (TLC_PRIO_TINY > 0) __builtin_amdgcn_s_setprio(TLC_PRIO_TINY);      // (development A/B: 36 KB of LDS on one wavefront)
-    tiny_slot<false>(p, lds_all, (int)(threadIdx.x & 63), (int)blockIdx.x);
+    tiny_slot(p, lds_all, (int)(threadIdx.x & 63), (int)blockIdx.x);
 }
-
-// from the records of the lane-per-pair extraction (extract_lane.hip): slot = 64 candidates, lane = lane.  WPB wavefronts per
-// workgroup, each with its own LDS rows (no barrier anywhere), so that a chunk's ~300 wavefronts fill ~80 CUs (one per SIMD) and leave
-// the others' LDS whole for the LARGE tier; the launch is sized from the PREVIOUS chunk's count (this chunk's is on the device only,
-// in *tier_count_dev), so the wavefronts stride over the slots there are.
-template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void tlc_pd_tiny_rec_kernel(TlcPdParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
-    unsigned char* lds = lds_all + (size_t)(threadIdx.x >> 6) * TINY_WG_BYTES;
-    int c = *p.tier_count_dev;
-    c = c < p.tier_count ? c : p.tier_count;
-    const int n_slots = (c + 63) >> 6;
-    for (int slot = (int)blockIdx.x * WPB + (int)(threadIdx.x >> 6); slot < n_slots; slot += (int)gridDim.x * WPB)
-        tiny_slot<true>(p, lds, (int)(threadIdx.x & 63), slot);
-}
-
-#ifndef TLC_TINY_REC_WPB
-#define TLC_TINY_REC_WPB 4
-#endif
-template __global__ void tlc_pd_tiny_rec_kernel<TLC_TINY_REC_WPB>(TlcPdParams);
 
 int tlc_launch_pd_tiny(const TlcPdParams& p, void* stream) {
     if (p.tier_count <= 0) return TLC_OK;
@@ -507,19 +472,6 @@ __global__ __launch_bounds__(1024) void tlc_tiny_sort_kernel(int count, const in
 int tlc_launch_tiny_sort(int count, const int* list, const int* hdr_n, const int* hdr_m2, int* out, void* stream, int shift) {
     if (count <= 0) return TLC_OK;
     hipLaunchKernelGGL(tlc_tiny_sort_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, count, list, hdr_n, hdr_m2, out, shift);
-    TLC_HIP_CHECK(hipGetLastError());
-    return TLC_OK;
-}
-
-// the records of the lane-per-pair extraction: wavefronts for p.xl_slots slots stride over the slots there turn out to be
-// (candidates in *p.tier_count_dev, at most p.tier_count)
-int tlc_launch_pd_tiny_rec(const TlcPdParams& p, void* stream) {
-    if (p.xl_slots <= 0) return TLC_OK;
-    constexpr int WPB = TLC_TINY_REC_WPB;
-    const size_t lds = TINY_WG_BYTES * WPB;
-    if (lds > 64 * 1024)
-        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_pd_tiny_rec_kernel<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((tlc_pd_tiny_rec_kernel<WPB>), dim3((p.xl_slots + WPB - 1) / WPB), dim3(64 * WPB), lds, (hipStream_t)stream, p);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }

@@ -339,7 +339,9 @@ __global__ void copy_sizes_kernel(int n_pairs, const int* __restrict__ hdr_n, co
                                   int* __restrict__ out_m) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pairs) return;
-    if (out_n) out_n[i] = hdr_n[i];
+    // a vicinity that does not fit the packed ids (TLC_ST_TOO_LARGE) has hdr_n = 0 and its negated size in out_n already (x_zero_row /
+    // the COUNT kernels wrote it there): that marker stays, as the header documents -- it is not "no vicinity"
+    if (out_n && !(out_n[i] < 0 && hdr_n[i] == 0)) out_n[i] = hdr_n[i];
     if (out_m) out_m[i] = hdr_n[i] > 0 ? (hdr_m2[i] >> 1) : 0;
 }
 }  // namespace

@@ -52,19 +52,6 @@
 #ifndef TLC_T_MCUT
 #define TLC_T_MCUT TLC_T_MMAX
 #endif
-// Lane-per-pair extraction (extract_lane.hip): pairs whose SMALLER ball has at most `xl_cut` nodes (<= TLC_XL_MAXCUT) are
-// intersected, swept and handed to the lane-per-subgraph PD kernel as fixed-size records, one LANE per pair; hdr_m2 of a pair
-// finished that way carries TLC_XL_DONE_FLAG (the scan leaves it out of the arena and of the tier lists).
-#define TLC_XL_MAXCUT 32
-#ifndef TLC_XL_CUT
-#define TLC_XL_CUT 24
-#endif
-#define TLC_XL_DONE_FLAG 0x40000000
-/* record of one slot (64 pairs, lane-interleaved): u32 hdr[64] | u32 edge[TLC_T_MMAX][64] | f64 weight[TLC_T_MMAX][64];
-   hdr = n | m << 8 | (lu & 0xff) << 16 | (lv & 0xff) << 24, 0xffffffff = no record (pair finished, given back, or no pair) */
-#define TLC_XL_REC_EDGE_OFF 256
-#define TLC_XL_REC_W_OFF (256 + TLC_T_MMAX * 256)
-#define TLC_XL_REC_BYTES (256 + TLC_T_MMAX * 256 + TLC_T_MMAX * 512)
 #define TLC_S_NMAX 64
 #define TLC_S_MMAX 128
 #define TLC_D_NMAX 128
@@ -80,11 +67,6 @@
 #endif
 #define TLC_L_NMAX 2048
 #define TLC_L_MMAX 4096
-/* LARGE-tier vicinities of at most this size take kernels with half the footprint (72 KB tier, 54 KB divide and conquer) when the launcher
-   splits the tier (pipelined chunks: TlcPdParams::large_split) -- a LARGE workgroup otherwise holds a whole CU's LDS for a vicinity of
-   typically 600 - 700 nodes */
-#define TLC_LC_NMAX 1024
-#define TLC_LC_MMAX 2048
 #define TLC_L_THREADS 512   /* 1024 measured slower (0.99 vs 0.94 ms): barriers over 16 wavefronts, 128-VGPR cap */
 #define TLC_HUGE_MIN_TABLE 16384  /* bytes reserved for the image table in a HUGE scratch slot */
 
@@ -171,13 +153,10 @@ struct TlcVicParams {
     const int* skip_count;
     int skip_cap;
     // pairs binned by tlc_classify_kernel (smaller ball >= 256 / 128 / 64 nodes): extracted first, in that order
-    const int* big_count;       // [4] on the device; null: no bins ([3]: pairs the lane-per-pair extraction gave back)
+    const int* big_count;       // [3] on the device; null: no bins
     const int* big_list;        // [4][n_pairs]
     // arena regions: workgroup b writes its vicinities from (region_base_wg + b) * region_entries on, then into blocks taken from
     // bump_top (relative to bump_base)
-    // lane-per-pair extraction ahead of this pass (extract_lane.hip): a pair whose smaller ball has at most xl_cut nodes was a
-    // candidate there and is left out of the pass over all pairs; what the lane kernel gave back sits in bin 3 of big_list
-    int xl_cut;                 // 0: no lane pass
     int x_fill;                 // 1: FILL pass of tlc_extract_kernel (headers exist, entries go to edge_off[i])
     int region_base_wg;
     long long region_entries;
@@ -224,9 +203,6 @@ struct TlcScanParams {
     const int* early_count;
     int early_cap;
     int* h_early;           // mapped host memory: number of early pairs (statistics)
-    // lane-per-pair extraction: [0] candidates listed, [1] pairs it finished as records (device counters, may be null)
-    const int* xl_counts;
-    int* h_xl;              // mapped host memory: the two counts
     // mapped host memory the last block publishes into (api.hip, HostSync)
     long long* h_total;
     int* h_tier;
@@ -271,7 +247,6 @@ struct TlcPdParams {
     const int* tiny_bin_list;   // [TLC_TINY_BINS][tiny_bin_stride]
     int tiny_bin_stride;
     int tiny_bin_cnt[TLC_TINY_BINS];
-    int large_split;        // LARGE tier: two launches over the same list, the TLC_LC_* kernels for the vicinities that fit them, the TLC_L_* ones for the rest
     // statistics: [0] sources that took the exact tie fallback
     unsigned long long* stats;
     // diagnostics (null in production): per tier 16 accumulated cycle counts of thread 0, see pd_pipeline.hip
@@ -297,10 +272,6 @@ struct TlcPdParams {
     int* dc_list;
     int dc_inplace;              // LARGE tier: the tier kernel's own workgroup runs the divide and conquer from the record (no tlc_pd_dc_kernel launch)
     int dc_force_fail;           // tests: tlc_pd_dc_kernel treats every solve as failed (the give-back path to the serial walk)
-    // lane-per-subgraph kernel fed from the records of the lane-per-pair extraction: slot b = pairs xl_list[64 b ..], record b
-    const unsigned char* xl_rec;
-    const int* xl_list;
-    int xl_slots;
     int grid;
     int wi_base;                   // LDS tiers: list position of workgroup 0 (a launch that completes a shorter one)
     int phase;                   // 0 = tier kernel + its swap kernel, 1 = tier kernel only, 2 = swap kernel only
@@ -308,42 +279,6 @@ struct TlcPdParams {
     const int* abort_flag;
 };
 
-// Membership tables of the ball lists (extract_lane.hip): ball(x) hashed into 2^lg buckets (a power of two >= |ball(x)|) of four
-// ids (16 bytes, empty = -1), every id in one of its TWO buckets -- "is y in ball(x)" is two 16-byte loads, no dependent round.
-// Descriptor of node x: first bucket << 6 | lg; lg = 63: no table.
-#define TLC_XL_H1(y) (((unsigned)(y) * 0x9E3779B1u) >> 12)
-#define TLC_XL_H2(y) (((unsigned)(y) * 0x85EBCA6Bu) >> 11)
-// lane-per-pair extraction (extract_lane.hip)
-struct TlcXlParams {
-    int n_nodes;
-    const int* rowptr;
-    const int* col;
-    const double* w;
-    const int* pairs;
-    const int* bptr;
-    const int* bcol;
-    const long long* hptr;      // [n_nodes] descriptors of the membership tables
-    const int* htab;            // buckets of four ids
-    const TlcNodeRec* nrec;
-    const double* hh_w;
-    int hh_k;
-    int hh_diag;                // some heavy node has a self loop (an entry on the diagonal of hh_w)
-    const int* xl_list;         // candidates (tlc_classify_kernel)
-    const int* xl_count;        // on the device
-    int xl_cap;
-    int ncut, mcut;             // what the lane-per-subgraph kernel takes (<= TLC_T_NMAX / TLC_T_MMAX)
-    int* hdr_n;
-    int* hdr_m2;
-    int* hdr_lu;
-    int* hdr_lv;
-    double* out_pi;             // [n_pairs, 25]
-    unsigned char* out_status;
-    unsigned char* rec;         // [slots][TLC_XL_REC_BYTES]
-    int* ovf_count;             // pairs given back to tlc_extract_kernel
-    int* ovf_list;
-    int* done_count;            // pairs finished as records
-    unsigned long long* dbg;    // diagnostics (null in production): cycle sums per phase over the wavefronts, [15] wavefronts
-};
 
 // PD from a caller-supplied filtration (tlc_pd_from_filtration)
 struct TlcPdfParams {
@@ -382,11 +317,7 @@ int tlc_launch_pdf_bin(int n_graphs, const long long* node_offs, const long long
 size_t tlc_extract_lds_bytes(int nw, int bw, bool fast = false);
 int tlc_launch_extract(int bw, int grid, size_t lds, const TlcVicParams& p, void* stream, bool fast = false);
 int tlc_launch_classify(int n_pairs, const int* pairs, int n_nodes, const int* bptr, int cand_threshold, int cand_cap,
-                        int* cand_count, int* cand_list, int* big_count, int* big_list, int xl_cut, int* xl_count, int* xl_list,
-                        void* stream);
-int tlc_launch_xlane(const TlcXlParams& p, int grid, void* stream);
-int tlc_launch_ball_hash(int n_nodes, const int* bptr, const int* bcol, const long long* hptr, int* htab, int* fail, void* stream);
-int tlc_launch_pd_tiny_rec(const TlcPdParams& p, void* stream);
+                        int* cand_count, int* cand_list, int* big_count, int* big_list, void* stream);
 int tlc_launch_tiny_sort(int count, const int* list, const int* hdr_n, const int* hdr_m2, int* out, void* stream, int shift = 0);
 int tlc_launch_ball_edges(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, const double* w, const int* bptr, const int* bcol,
                           int* esize, const int* be_ptr, unsigned short* be_pos, double* be_w, int grid, void* stream);

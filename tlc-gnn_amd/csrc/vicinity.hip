@@ -100,7 +100,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
     const bool pre = (s_pre[t >> 5] >> (t & 31)) & 1u;
     int n = i < p.n_pairs ? p.hdr_n[i] : 0;
     const int m2v = i < p.n_pairs ? p.hdr_m2[i] : 0;
-    if (m2v & TLC_XL_DONE_FLAG) n = 0;                // finished as a record by the lane-per-pair extraction: no arena room, no tier list
     const bool bumped = p.bump_top != nullptr && *p.bump_overflow == 0;
     const long long arena_base = bumped ? p.bump_base + (long long)*p.bump_top : 0;
     const long long own = (i < p.n_pairs && !pre) ? arena_entries(n, m2v, p.small_arena, bumped) : 0;
@@ -216,7 +215,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
             const long long total = arena_base + (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(p.sync + 2),
                                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (p.h_overflow) *p.h_overflow = p.bump_overflow ? *p.bump_overflow : 0;
-            if (p.h_xl) { p.h_xl[0] = p.xl_counts ? p.xl_counts[0] : 0; p.h_xl[1] = p.xl_counts ? p.xl_counts[1] : 0; }
             p.totals[0] = total;
             *p.h_total = total;
             if (p.h_early) {

@@ -100,12 +100,6 @@ class DeviceGraph:
         _lib.check(_lib.lib().tlc_debug_tier_counts(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr(self.device)), "tlc_debug_tier_counts")
         return dict(zip(("small", "medium", "large", "huge", "mid", "tiny", "medium_many_pos", "medium_wide"), (int(v) for v in out)))
 
-    def xl_stats(self):
-        """(candidates of the lane-per-pair extraction, pairs it finished as records) in the last chunk."""
-        out = (C.c_longlong * 2)()
-        _lib.check(_lib.lib().tlc_debug_xl_stats(self._h, C.cast(out, C.c_void_p), _lib.stream_ptr(self.device)), "tlc_debug_xl_stats")
-        return int(out[0]), int(out[1])
-
     # ---- measurement helpers (bench.py) -----------------------------------------------------------------------
     KERNELS = ["vicinity_count", "scan_bin", "vicinity_fill", "pd_tier_small", "pd_tier_medium", "pd_tier_large", "pd_tier_huge",
                "pd_tier_mid"]

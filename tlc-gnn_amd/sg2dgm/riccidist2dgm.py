@@ -45,7 +45,7 @@ class graph2pi():
         self._lut = None
         try:
             keys = np.fromiter(self.dict_node.keys(), dtype=np.int64, count=len(self.dict_node))
-            if len(keys) and keys.min() >= 0 and keys.max() < 8 * max(len(keys), 1024) and all(isinstance(k, (int, np.integer)) for k in list(self.dict_node)[:64]):
+            if len(keys) and keys.min() >= 0 and keys.max() < 8 * max(len(keys), 1024) and all(isinstance(k, (int, np.integer)) for k in self.dict_node):   # (every key: a float label would be truncated by fromiter)
                 lut = np.full(int(keys.max()) + 1, -1, dtype=np.int32)
                 lut[keys] = np.fromiter(self.dict_node.values(), dtype=np.int32, count=len(self.dict_node))
                 self._lut = lut

@@ -4,6 +4,6 @@ cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 mkdir -p gpurun_out
 for rep in 1 2; do
   for v in "$@"; do
-    echo -n "$v : "; timeout -k 10 200 env $v python tools/ab_option.py mh_always 0 0 30 2>&1 | grep -v amdgpu | head -1
+    echo -n "$v : "; timeout -k 10 200 env $v python tools/ab_option.py ball_edges 1 1 30 2>&1 | grep -v amdgpu | head -1
   done
 done | tee gpurun_out/env_ab3.txt

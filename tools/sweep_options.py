@@ -6,7 +6,7 @@ import numpy as np, torch
 sys.path.insert(0, ".")
 from tlc_gnn_amd import engine
 import bench
-DEFAULTS = {"tier_mask": 255, "chunk_pairs": 0, "n_ws": 3, "defer": 1, "gate_ticks": -1, "mh_always": 0, "medium_first": -1, "x_chunk_div": 0, "x_grid": 0, "xl_cut": 0}
+DEFAULTS = {"tier_mask": 255, "n_ws": 3, "ball_edges": 1, "fast_split": 1, "dc_inplace": 1, "heavy": 1, "tiny": 1, "extract": 1}
 cfgs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",") if kv) for a in sys.argv[1:]] or [{}]
 K, REPS = 40, 3
 W = bench.build_workload(0)

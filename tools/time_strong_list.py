@@ -1,5 +1,5 @@
 """development: the strong-scaling list (non-edges within hop distance, 504 514 pairs on the PubMed-shaped graph) in one call,
-cut into chunks of different sizes (handle option chunk_pairs): do pipelined chunks help a long list?"""
+a few times (the library cuts a list above 2^20 pairs into pipelined chunks; TLC_CHUNK_PAIRS_TEST in the environment cuts smaller)."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -13,9 +13,8 @@ near = near[torch.argsort(ranks)].contiguous()
 E = len(near)
 out = torch.empty((E, 25), dtype=torch.float64, device="cuda"); st = torch.empty(E, dtype=torch.uint8, device="cuda")
 ref = None
-seq = [int(a) for a in sys.argv[1:]] or [0, 1 << 18, 1 << 17, 1 << 16, 1 << 15, 0]
+seq = [0, 0]
 for cp in seq:
-    g.set_option("chunk_pairs", cp)
     ts = []
     for _ in range(5 if cp >= 0 else 12):
         torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
