@@ -184,7 +184,7 @@ struct tlc_graph {
     int* d_bptr;
     int* d_bcol;
     int* d_be_ptr;                 // ball subgraphs (TlcVicParams::be_ptr ...); null: not built
-    unsigned short* d_be_pos;
+    unsigned* d_be_pos;
     double* d_be_w;
     long long be_entries;
     long long ball_entries;
@@ -454,7 +454,7 @@ static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
     {
         int* d_es = nullptr;
         int* d_bp = nullptr;
-        unsigned short* d_pos = nullptr;
+        unsigned* d_pos = nullptr;
         double* d_bw = nullptr;
         std::vector<int> es((size_t)n + 1, 0);
         bool ok = hipMalloc(&d_es, (size_t)n * sizeof(int)) == hipSuccess;
@@ -466,10 +466,10 @@ static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
         if (ok) {
             es[n] = (int)et;
             size_t fb = 0, tb = 0;
-            ok = hipMemGetInfo(&fb, &tb) == hipSuccess && (size_t)et * 10 <= fb / 8;
+            ok = hipMemGetInfo(&fb, &tb) == hipSuccess && (size_t)et * 12 <= fb / 8;
         }
         ok = ok && hipMalloc(&d_bp, ((size_t)n + 1) * sizeof(int)) == hipSuccess;
-        ok = ok && hipMalloc(&d_pos, ((size_t)et + 64) * sizeof(unsigned short)) == hipSuccess;
+        ok = ok && hipMalloc(&d_pos, ((size_t)et + 64) * sizeof(unsigned)) == hipSuccess;
         ok = ok && hipMalloc(&d_bw, ((size_t)et + 64) * sizeof(double)) == hipSuccess;
         ok = ok && hipMemcpyAsync(d_bp, es.data(), ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
         ok = ok && tlc_launch_ball_edges(true, n, g->nw, g->d_rowptr, g->d_col, g->d_w, g->d_bptr, g->d_bcol, nullptr, d_bp, d_pos, d_bw, grid, s) == TLC_OK;

@@ -44,8 +44,9 @@ struct XCfg {
 #define TLC_X_STAGE 128       /* entries a wavefront stages in LDS before it writes them out in order (0: every lane stores its own) */
 #endif
 struct XLayout {
-    size_t o_pref, o_sid, o_hvy, o_hl, o_ctl, o_ucnt, o_stage, total;
+    size_t o_pref, o_sid, o_hvy, o_hl, o_ctl, o_ucnt, o_stage, o_mt, total;
 };
+#define TLC_X_MT_BYTES ((TLC_BE_CAP / 64) * 16)      /* member table of x_sweep_ball: per 64 positions {mask u64, members below u32, pad} */
 __host__ __device__ constexpr XLayout x_layout(int nw, int sid_cap, int bw, bool fast = false) {
     XLayout L{};
     const size_t nw4 = (size_t)((nw + 3) & ~3);
@@ -57,7 +58,8 @@ __host__ __device__ constexpr XLayout x_layout(int nw, int sid_cap, int bw, bool
         L.o_hvy = L.o_hl = L.o_ctl = L.o_sid + (size_t)sid_cap * 4;
         L.o_ucnt = L.o_ctl + 64 + 4 + 16;
         L.o_stage = (L.o_ucnt + 15) & ~(size_t)15;
-        L.total = L.o_stage;
+        L.o_mt = L.o_stage;
+        L.total = L.o_mt + TLC_X_MT_BYTES;
         return L;
     }
     L.o_pref = nw4 * 4;
@@ -67,7 +69,8 @@ __host__ __device__ constexpr XLayout x_layout(int nw, int sid_cap, int bw, bool
     L.o_ctl = L.o_hl + (size_t)TLC_X_H_CAP * 4;
     L.o_ucnt = L.o_ctl + 64 + (size_t)(bw / 64) * 4 + 16;
     L.o_stage = (L.o_ucnt + (bw > 64 ? (size_t)TLC_X_UNITS * 4 : 0) + 15) & ~(size_t)15;
-    L.total = L.o_stage + (size_t)(bw / 64) * TLC_X_STAGE * 12;      // per wavefront: [TLC_X_STAGE doubles | TLC_X_STAGE words]
+    L.o_mt = L.o_stage + (size_t)(bw / 64) * TLC_X_STAGE * 12;       // per wavefront: [TLC_X_STAGE doubles | TLC_X_STAGE words]
+    L.total = L.o_mt + TLC_X_MT_BYTES;
     return L;
 }
 
@@ -390,33 +393,46 @@ __device__ __forceinline__ int x_sweep_wave(const PB& p, const int* ids, int n, 
 
 // Round 5.  The same entries from the SUBGRAPH LIST of the smaller ball (TlcVicParams::be_ptr): S is a subset of that ball, so
 // the induced subgraph is the list's entries whose two ends are members -- M0, M1 hold the members as bit masks over the positions
-// of the ball list (|ball| <= TLC_BE_CAP = 128: the two ballots of the filter), a local id is the number of members below a position.  One coalesced
-// 2 + 8-byte stream instead of a node record per member, its row segments, the heavy-member bookkeeping and the member bitmap:
-// a lane's entry is kept or dropped by two bit tests, numbered by a ballot and stored -- 93 % of the PubMed batch's pairs
-// (smaller ball <= 128 nodes; for the 84 % up to 64 nodes: 51 directed list entries on average).  Order: sources ascending, a source's
+// of the ball list (|ball| <= 128: the two ballots of the filter; up to TLC_BE_CAP = 512: a table of the ballots in LDS), a local id is
+// the number of members below a position.  One coalesced 4 + 8-byte stream instead of a node record per member, its row segments, the heavy-member bookkeeping and the member bitmap:
+// a lane's entry is kept or dropped by two bit tests, numbered by a ballot and stored -- 99.6 % of the PubMed batch's pairs
+// (smaller ball <= 512 nodes; for the 84 % up to 64 nodes: 51 directed list entries on average, up to ~1 300 at 512 nodes).  Order: sources ascending, a source's
 // entries in CSR order -- a function of the pair alone, whichever pass (main, FILL) sweeps it.  One wavefront; dir may be null.
-__device__ __forceinline__ int x_sweep_ball(const unsigned short* __restrict__ be_pos, const double* __restrict__ be_w, int e0, int e1,
-                                            unsigned long long M0, unsigned long long M1, unsigned* dir, double* lw, int cap) {
+// TAB: the masks come from the LDS table mt (|ball| > TLC_BE_REG_CAP: up to eight ballots): entry p >> 6 = {mask, members below}.
+template <bool TAB>
+__device__ __forceinline__ int x_sweep_ball(const unsigned* __restrict__ be_pos, const double* __restrict__ be_w, int e0, int e1,
+                                            unsigned long long M0, unsigned long long M1, const uint4* mt, unsigned* dir, double* lw, int cap) {
     const int lane = tlc_lane();
     const unsigned c0 = (unsigned)__popcll(M0);
     int run = 0;
     // position p of the ball list: is it a member, and how many members stand below it (its local id)
-    auto member = [&](unsigned p) -> bool { return ((((p & 64u) ? M1 : M0) >> (p & 63u)) & 1ull) != 0ull; };
-    auto rank = [&](unsigned p) -> unsigned {
+    auto look = [&](unsigned p, bool& mem, unsigned& rk) {
         const unsigned long long below = (1ull << (p & 63u)) - 1ull;
-        return (p & 64u) ? c0 + (unsigned)__popcll(M1 & below) : (unsigned)__popcll(M0 & below);
+        if (TAB) {
+            const uint4 e = mt[p >> 6];
+            const unsigned long long m = ((unsigned long long)e.y << 32) | e.x;
+            mem = ((m >> (p & 63u)) & 1ull) != 0ull;
+            rk = e.z + (unsigned)__popcll(m & below);
+        } else {
+            const unsigned long long m = (p & 64u) ? M1 : M0;
+            mem = ((m >> (p & 63u)) & 1ull) != 0ull;
+            rk = ((p & 64u) ? c0 : 0u) + (unsigned)__popcll(m & below);
+        }
     };
     for (int j0 = e0; j0 < e1; j0 += TLC_WAVE) {
         const int j = j0 + lane;
         const bool in = j < e1;
-        const unsigned pos = in ? (unsigned)be_pos[j] : 0u;
+        const unsigned pos = in ? be_pos[j] : 0u;
         const double w = (in && dir) ? be_w[j] : 0.0;
-        const unsigned pa = pos >> 8, pb = pos & 0xffu;
-        const bool keep = in && member(pa) && member(pb);
+        bool ma, mb;
+        unsigned ra, rb;
+        look(pos >> 16, ma, ra);
+        look(pos & 0xffffu, mb, rb);
+        const bool keep = in && ma && mb;
         const unsigned long long K = __ballot(keep);
         if (dir && keep) {
             const int o = run + __popcll(K & tlc_lanemask_lt());
-            if (o < cap) { x_store(&dir[o], (rank(pa) << 16) | rank(pb)); x_store(&lw[o], w); }
+            if (o < cap) { x_store(&dir[o], (ra << 16) | rb); x_store(&lw[o], w); }
         }
         run += __popcll(K);
     }
@@ -482,7 +498,7 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
                                              bool has_pre = false, int pb0 = -1, int pa0 = -1, int pa1 = -1,
                                              const PF& prefetch_next = PF()) {
     static_assert(!FAST || BW == 64, "the FAST launch is one wavefront per pair");
-    constexpr int SID_CAP = XCfg<BW>::SID_CAP;
+    constexpr int SID_CAP = FAST ? TLC_BE_CAP + 8 : XCfg<BW>::SID_CAP;   // (the FAST launch never touches its scratch slot)
     const XLayout L = x_layout(p.nw, SID_CAP, BW, FAST);
     const int nw4 = (p.nw + 3) & ~3;
     XState X;
@@ -559,6 +575,7 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
     if constexpr (FAST) { if (!fast) return; }
     else if (fast && p.fast_split && !p.x_fill) return;
     unsigned long long M0 = 0ull, M1 = 0ull;               // (fast) the members of S as a mask over the smaller ball's positions
+    uint4* const mtab = reinterpret_cast<uint4*>(lds + L.o_mt);
     // ---- S = ball(u) & ball(v) (:315): the smaller list filtered through a bitmap of the larger -----------------------------
     int bv[4];
 #pragma unroll
@@ -609,6 +626,8 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
                 tot = __popcll(m);
                 if (base == 0 && r == 0) M0 = m;
                 if (base == 0 && r == 1) M1 = m;
+                if (fast && nB > TLC_BE_REG_CAP && tid == 0)             // (uniform) the member table of x_sweep_ball<true>
+                    mtab[(base >> 6) + r] = make_uint4((unsigned)m, (unsigned)(m >> 32), (unsigned)n, 0u);
             } else {
                 pos = n + block_escan_i32<BW>(h ? 1 : 0, X.xw, &tot);
             }
@@ -715,7 +734,10 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
     XSTAMP(5);
     // (one place for the two forms of the sweep)
     auto sweep = [&](unsigned* d_, double* w_, int cap_, int dbg_i) -> int {
-        if (FAST || fast) return x_sweep_ball(p.be_pos, p.be_w, be0, be1, M0, M1, d_, w_, cap_);
+        if (FAST || fast) {
+            if (nB > TLC_BE_REG_CAP) return x_sweep_ball<true>(p.be_pos, p.be_w, be0, be1, 0ull, 0ull, mtab, d_, w_, cap_);
+            return x_sweep_ball<false>(p.be_pos, p.be_w, be0, be1, M0, M1, nullptr, d_, w_, cap_);
+        }
         if constexpr (!FAST) return x_sweep<BW>(p, ids, n, X, use_hvy, nH, d_, w_, cap_, rec0, BW == 64, dbg_i);
         return 0;
     };
@@ -739,6 +761,7 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
     if (p.bump_top && n <= TLC_M_NMAX) {
         const long long nn = (long long)n * n;
         cap = nn < 2 * TLC_M_MMAX ? (int)nn : 2 * TLC_M_MMAX;
+        if (fast && be1 - be0 < cap) cap = be1 - be0;     // (the subgraph list bounds the vicinity's entries: its region lasts longer)
         if (cur[1] - cur[0] < cap) {                     // (uniform: LDS state)
             x_sync<BW>();
             if (tid == 0) {
@@ -826,7 +849,7 @@ __global__ __launch_bounds__(BW, BW == 64 ? (FAST ? 8 : TLC_X_WPE) : 1) void tlc
     }
     // this workgroup's arena region (cursor / end live in LDS across its pairs)
     {
-        const XLayout L = x_layout(p.nw, XCfg<BW>::SID_CAP, BW, FAST);
+        const XLayout L = x_layout(p.nw, FAST ? TLC_BE_CAP + 8 : XCfg<BW>::SID_CAP, BW, FAST);
         long long* cur = (long long*)((int*)(xlds + L.o_ctl) + 8);
         if (threadIdx.x == 0) {
             const long long b = p.region_base_entries + (long long)(p.region_base_wg + (int)blockIdx.x) * p.region_entries;
@@ -848,7 +871,7 @@ __global__ __launch_bounds__(BW, BW == 64 ? (FAST ? 8 : TLC_X_WPE) : 1) void tlc
     } else if (p.big_count && !FAST) {
         c0 = p.big_count[0]; c1 = p.big_count[1]; c2 = p.big_count[2];
         // behind a FAST launch only the pairs of bins 0 and 1 are left (smaller ball >= 128 nodes): bin 2 and every pair outside
-        // the bins have a smaller ball of < 128 nodes, which the FAST launch owns (TLC_BE_CAP = 128 >= TLC_X_BIN_MIN)
+        // the bins have a smaller ball of < 128 nodes, which the FAST launch owns (TLC_BE_CAP >= 128 >= TLC_X_BIN_MIN)
         // (unless the early pass's candidate list overflowed: the candidates it could not hold are reached by index only)
         if (p.fast_split && !p.x_fill && !(p.skip_count && *p.skip_count > p.skip_cap)) { c2 = 0; n_work = 0; }
         n_work += c0 + c1 + c2;
@@ -1048,7 +1071,7 @@ template __global__ void tlc_extract_kernel<64, false>(TlcVicParams);
 template __global__ void tlc_extract_kernel<64, true>(TlcVicParams);
 template __global__ void tlc_extract_kernel<512, false>(TlcVicParams);
 
-size_t tlc_extract_lds_bytes(int nw, int bw, bool fast) { return x_layout(nw, bw == 64 ? XCfg<64>::SID_CAP : XCfg<512>::SID_CAP, bw, fast).total; }
+size_t tlc_extract_lds_bytes(int nw, int bw, bool fast) { return x_layout(nw, fast ? TLC_BE_CAP + 8 : (bw == 64 ? XCfg<64>::SID_CAP : XCfg<512>::SID_CAP), bw, fast).total; }
 
 int tlc_launch_extract(int bw, int grid, size_t lds, const TlcVicParams& p, void* stream, bool fast) {
     if (grid <= 0) return TLC_OK;
@@ -1167,7 +1190,7 @@ template <bool FILL>
 __global__ __launch_bounds__(64) void tlc_ball_edges_kernel(int n_nodes, int nw, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                             const double* __restrict__ w, const int* __restrict__ bptr,
                                                             const int* __restrict__ bcol, int* __restrict__ esize,
-                                                            const int* __restrict__ be_ptr, unsigned short* __restrict__ be_pos,
+                                                            const int* __restrict__ be_ptr, unsigned* __restrict__ be_pos,
                                                             double* __restrict__ be_w) {
     extern __shared__ __attribute__((aligned(16))) unsigned ebits[];
     const int lane = tlc_lane();
@@ -1203,7 +1226,7 @@ __global__ __launch_bounds__(64) void tlc_ball_edges_kernel(int n_nodes, int nw,
                 const unsigned long long m = __ballot(h);
                 if (FILL && h) {
                     const int o = run + __popcll(m & tlc_lanemask_lt());
-                    be_pos[o] = (unsigned short)((k << 8) | pos);
+                    be_pos[o] = ((unsigned)k << 16) | (unsigned)pos;
                     be_w[o] = w[jj];
                 }
                 run += __popcll(m);
@@ -1217,7 +1240,7 @@ __global__ __launch_bounds__(64) void tlc_ball_edges_kernel(int n_nodes, int nw,
 }
 
 int tlc_launch_ball_edges(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, const double* w, const int* bptr, const int* bcol,
-                          int* esize, const int* be_ptr, unsigned short* be_pos, double* be_w, int grid, void* stream) {
+                          int* esize, const int* be_ptr, unsigned* be_pos, double* be_w, int grid, void* stream) {
     if (n_nodes <= 0) return TLC_OK;
     const size_t lds = (size_t)((nw + 3) & ~3) * 6 + 16;
     if (fill) {

@@ -163,15 +163,16 @@ struct TlcVicParams {
     long long region_base_entries;   // arena entries in front of this launch's regions
     long long bump_base;
     // ---- ball subgraphs (round 5): for every node x whose ball has at most TLC_BE_CAP nodes, the directed entries of the graph
-    // with BOTH ends in ball(x), as (position of the source in the ball list << 8 | position of the target) and the weight, sources
+    // with BOTH ends in ball(x), as (position of the source in the ball list << 16 | position of the target) and the weight, sources
     // ascending, a source's entries in CSR order.  A vicinity is a subset of the smaller ball of its pair, so its induced subgraph
     // is a filter over that list (extract.hip, x_sweep_ball).  Null: not built.
     const int* be_ptr;          // [n_nodes + 1]; be_ptr[x] == be_ptr[x + 1] for a node whose ball is larger
-    const unsigned short* be_pos;
+    const unsigned* be_pos;
     const double* be_w;
     int fast_split;             // 1: a launch of tlc_extract_kernel<64, true> takes the pairs the subgraph lists serve; this one leaves them alone
 };
-#define TLC_BE_CAP 128
+#define TLC_BE_CAP 512
+#define TLC_BE_REG_CAP 128       /* up to here the member masks of a pair stay in registers (two ballots); above: a table in LDS */
 
 struct TlcScanParams {
     int n_pairs;
@@ -320,7 +321,7 @@ int tlc_launch_classify(int n_pairs, const int* pairs, int n_nodes, const int* b
                         int* cand_count, int* cand_list, int* big_count, int* big_list, void* stream);
 int tlc_launch_tiny_sort(int count, const int* list, const int* hdr_n, const int* hdr_m2, int* out, void* stream, int shift = 0);
 int tlc_launch_ball_edges(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, const double* w, const int* bptr, const int* bcol,
-                          int* esize, const int* be_ptr, unsigned short* be_pos, double* be_w, int grid, void* stream);
+                          int* esize, const int* be_ptr, unsigned* be_pos, double* be_w, int grid, void* stream);
 int tlc_launch_ball_list(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, int hop, int* bsize, const int* bptr,
                          int* bcol, int grid, void* stream);
 int tlc_launch_ball_bound(int n_nodes, const int* rowptr, const int* col, const int* prev, int* out, void* stream);
