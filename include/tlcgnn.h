@@ -301,10 +301,14 @@ int tlc_gat_layer_tiled_fwd(int32_t n_nodes, const int32_t* d_rowptr, const int3
                             const float* d_Wl, const float* d_att, const float* d_Wij, const float* d_bias,
                             float prelu_slope, float* d_work, float* d_out, void* stream);
 
-/* Smallest and largest column of every CSR row, the row index itself included (int32[n_rows] each): the host side of
- * tlc_gat_layer_tiled_fwd's tile cut (Knowledge_Distillation/gat_conv.py GraphBatch -> ops.gat_tiles) -- a position k of a batch is
- * free of crossing edges iff max_{i<k} hi[i] < k and min_{i>=k} lo[i] >= k. */
-int tlc_csr_row_minmax(int32_t n_rows, const int32_t* d_rowptr, const int32_t* d_col, int32_t* d_lo, int32_t* d_hi, void* stream);
+/* The tile cut tlc_gat_layer_tiled_fwd takes (Knowledge_Distillation/gat_conv.py GraphBatch -> ops.gat_tiles), made on the device:
+ * d_tile_ptr int32[*n_tiles + 1] = node offsets of tiles of at most tile_nodes consecutive nodes, cut only at positions no edge of
+ * the CSR (rows = targets, d_col = sources) crosses; with `gap` the largest distance between two such positions next to each other,
+ * the first of them at or behind every multiple of tile_nodes - gap starts a tile.  *n_tiles (HOST int; the call waits for the
+ * stream) = 0 when 2 gap > tile_nodes -- one big graph: the two-kernel layer (tlc_gat_layer_fwd) serves it.
+ * d_work: int32[n_nodes / 32 + 6]; d_tile_ptr: room for 2 n_nodes / tile_nodes + 3 entries. */
+int tlc_gat_tile_cut(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, int32_t tile_nodes, int32_t* d_work,
+                     int32_t* d_tile_ptr, int32_t* n_tiles, void* stream);
 
 
 /* ---- the diagram loss of PDGNN training ------------------------------------------------------------

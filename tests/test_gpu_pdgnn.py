@@ -457,6 +457,19 @@ def test_tiled_gat_layer_equals_the_two_kernel_layer():
         loops = np.arange(offs)
         return offs, torch.from_numpy(np.concatenate([both, np.stack([loops, loops], 1)]).T.copy()).to(dev)
 
+    def cut_rule(ei, n, T=192):
+        """the rule of tlc_gat_tile_cut restated: free positions, their largest distance, the first one behind every multiple"""
+        s_, t_ = ei.cpu().numpy()
+        mark = np.zeros(n + 2, np.int64)
+        np.add.at(mark, np.minimum(s_, t_) + 1, 1)
+        np.add.at(mark, np.maximum(s_, t_) + 1, -1)
+        free = np.nonzero(np.cumsum(mark)[:n + 1] == 0)[0]
+        gap = int(np.diff(free).max())
+        if 2 * gap > T:
+            return None
+        picks = free[np.searchsorted(free, np.arange(0, n, T - gap))]
+        return np.unique(np.concatenate([picks[picks < n], [n]]))
+
     # (a) molecules
     e_all, f, node_offs, edge_offs = synth.hiv_shaped_molecules(3000, 7)
     mol = [(int(node_offs[k + 1] - node_offs[k]), e_all[edge_offs[k]:edge_offs[k + 1]].astype(np.int64)) for k in range(3000)]
@@ -475,6 +488,9 @@ def test_tiled_gat_layer_equals_the_two_kernel_layer():
         assert tiles[0] == 0 and tiles[-1] == n and (np.diff(tiles) > 0).all() and np.diff(tiles).max() <= 192, name
         s_, t_ = ei.cpu().numpy()
         assert np.array_equal(np.searchsorted(tiles, s_, side="right"), np.searchsorted(tiles, t_, side="right")), name
+        assert np.array_equal(tiles, cut_rule(ei, n)), name
+        one_way = ei[:, :(ei.shape[1] - n) // 2]                          # one entry per undirected pair (gcn_LP_GIN.compute_PI), no loops
+        assert np.array_equal(GraphBatch(one_way, n).tiles.cpu().numpy(), cut_rule(one_way, n)), name
         for c_in, C_ in ((1, 32), (64, 32), (64, 16)):
             g = torch.Generator().manual_seed(c_in + C_)
             x = (torch.randn(n, c_in, generator=g) * 0.7).to(dev)
@@ -494,4 +510,10 @@ def test_tiled_gat_layer_equals_the_two_kernel_layer():
     # one big connected graph: no cut closer than 128 nodes -> no tiles, the two-kernel layer serves it
     ring = np.stack([np.arange(2000), (np.arange(2000) + 1) % 2000], 1)
     n, ei = block_batch([(2000, ring)])
-    assert GraphBatch(ei, n).tiles is None
+    assert GraphBatch(ei, n).tiles is None and cut_rule(ei, n) is None
+    # graphs of exactly 96 nodes (gap = half a tile: the last cut that works) and of 97 (none)
+    for nn, ok in ((96, True), (97, False)):
+        path = np.stack([np.arange(nn - 1), np.arange(1, nn)], 1)
+        n, ei = block_batch([(nn, path)] * 9 + [(3, path[:2])])
+        t = GraphBatch(ei, n).tiles
+        assert (t is not None) == ok and (not ok or np.array_equal(t.cpu().numpy(), cut_rule(ei, n)))

@@ -729,24 +729,99 @@ extern "C" int tlc_gat_layer_tiled_fwd(int32_t n_nodes, const int32_t* d_rowptr,
                    : launch_gat_tiled<16, 64>(n_tiles, d_tile_ptr, d_rowptr, d_src, d_X, Wf, nullptr, d_bias, prelu_slope, d_out, s);
 }
 
-// The smallest and the largest column of every CSR row, the row's own index included: what Knowledge_Distillation/gat_conv.py's
-// GraphBatch needs to find the positions of a block-diagonal batch that no edge crosses (ops.gat_tiles; a segmented reduction in
-// the host library took 8 ms for a million rows).  d_lo, d_hi int32[n_rows].
+// The tile cut of tlc_gat_layer_tiled_fwd (Knowledge_Distillation/gat_conv.py GraphBatch -> ops.gat_tiles), all on the device
+// and with ONE host read at its end (the torch formulation it replaces -- a segmented min/max, a prefix sum, nonzero, searchsorted,
+// unique -- cost 0.43 ms and four host round trips per batch, more than the four layers of a 4096-vicinity batch).
+//   position k (the cut between node k-1 and node k, k = 0 .. n) is FREE when no edge crosses it: row i with smallest / largest
+//   column a / b (i itself included) forbids a+1 .. b.  A bitmap of the forbidden positions (mark), the largest distance between
+//   consecutive free positions `gap` (gap), then with step = tile_nodes - gap the first free position at or behind every multiple
+//   of step starts a tile (pick): consecutive picks are less than step + gap = tile_nodes apart.  No cut when 2 gap > tile_nodes.
 namespace {
-__global__ void csr_row_minmax_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ col, int* __restrict__ lo, int* __restrict__ hi) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int a = i, b = i;
-    for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) { const int c = col[j]; a = c < a ? c : a; b = c > b ? c : b; }
-    lo[i] = a; hi[i] = b;
+enum { TC_BAD = 0, TC_GAP = 1, TC_NT = 2, TC_HEAD = 4 };
+constexpr int TC_HALF_MAX = 512;                               // tile_nodes <= 1024
+// 256 rows per workgroup: their forbidden positions lie within `half` of the rows, so they are OR-ed in LDS first and go out as one
+// atomic per touched word (one atomic per row and word made 80 us of same-address traffic on a million molecule nodes)
+__global__ void __launch_bounds__(256) tile_cut_mark_kernel(int n, int half, const int* __restrict__ rowptr, const int* __restrict__ col, unsigned* __restrict__ bits, int* __restrict__ st) {
+    __shared__ unsigned sb[(256 + 2 * TC_HALF_MAX) / 32 + 2];
+    const int i0 = blockIdx.x * 256, i = i0 + threadIdx.x;
+    const int wb = max(i0 - half, 0) >> 5, nw = ((min(i0 + 255, n - 1) + half) >> 5) - wb + 1;
+    if ((int)threadIdx.x < nw) sb[threadIdx.x] = 0u;
+    __syncthreads();
+    if (i < n) {
+        int a = i, b = i;
+        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) { const int c = col[j]; a = c < a ? c : a; b = c > b ? c : b; }
+        if (b - a >= half) st[TC_BAD] = 1;                     // b - a forbidden positions in a row: gap > half
+        else
+            for (int w = (a + 1) >> 5; w <= (b >> 5) && a < b; ++w) {
+                const int p0 = max(a + 1, w << 5), p1 = min(b, (w << 5) + 31), len = p1 - p0 + 1;
+                atomicOr(&sb[w - wb], (len == 32 ? ~0u : ((1u << len) - 1u)) << (p0 & 31));
+            }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nw && sb[threadIdx.x]) atomicOr(&bits[wb + threadIdx.x], sb[threadIdx.x]);
+}
+// the largest free position below f, looking back `limit` positions at most; -1 when there is none that close
+__device__ __forceinline__ int tile_cut_prev_free(const unsigned* __restrict__ bits, int f, int limit) {
+    int p = f - 1;
+    const int stop = max(f - limit, 0);
+    while (p >= stop) {
+        const int sh = p & 31;
+        const unsigned w = ~bits[p >> 5] & (sh == 31 ? ~0u : ((2u << sh) - 1u));
+        if (w) { const int q = (p & ~31) + 31 - __clz(w); return q >= stop ? q : -1; }
+        p = (p & ~31) - 1;
+    }
+    return -1;
+}
+constexpr int TC_GAP_PER_WG = 2048;
+__global__ void __launch_bounds__(256) tile_cut_gap_kernel(int n, int half, const unsigned* __restrict__ bits, int* __restrict__ st) {
+    __shared__ int wmax[4];
+    int d = 0;
+    for (int f = blockIdx.x * TC_GAP_PER_WG + threadIdx.x + 1, e = min(n, (blockIdx.x + 1) * TC_GAP_PER_WG); f <= e; f += 256)
+        if (!((bits[f >> 5] >> (f & 31)) & 1u)) {
+            const int pf = tile_cut_prev_free(bits, f, half);
+            if (pf < 0) st[TC_BAD] = 1; else d = max(d, f - pf);
+        }
+    for (int o = 32; o; o >>= 1) d = max(d, __shfl_xor(d, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = d;
+    __syncthreads();
+    // one atomic per workgroup at most, and only for a new maximum (read at the L2: a plain load stays the zero this CU cached
+    // first, and an atomic per wave on the one address took 170 us on a million nodes)
+    if (threadIdx.x == 0) {
+        d = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (d > __hip_atomic_load(&st[TC_GAP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st[TC_GAP], d);
+    }
+}
+__global__ void tile_cut_pick_kernel(int n, int tile_nodes, const unsigned* __restrict__ bits, int* __restrict__ st, int* __restrict__ tiles) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gap = st[TC_GAP];
+    if (st[TC_BAD] || 2 * gap > tile_nodes) return;            // st[TC_NT] stays 0: no cut
+    if (f > n || ((bits[f >> 5] >> (f & 31)) & 1u)) return;
+    if (f == 0) { tiles[0] = 0; return; }
+    const int step = tile_nodes - gap;
+    const int pf = tile_cut_prev_free(bits, f, gap);
+    if (f == n) { tiles[pf / step + 1] = n; st[TC_NT] = pf / step + 1; }
+    else if (f / step > pf / step) tiles[f / step] = f;
 }
 }  // namespace
-extern "C" int tlc_csr_row_minmax(int32_t n_rows, const int32_t* d_rowptr, const int32_t* d_col, int32_t* d_lo, int32_t* d_hi, void* stream) {
-    TLC_REQUIRE(n_rows >= 0, "bad sizes");
-    if (n_rows == 0) return TLC_OK;
-    TLC_REQUIRE(d_rowptr && d_col && d_lo && d_hi, "null pointer");
-    hipLaunchKernelGGL(csr_row_minmax_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_rows, d_rowptr, d_col, d_lo, d_hi);
+extern "C" int tlc_gat_tile_cut(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, int32_t tile_nodes, int32_t* d_work,
+                                int32_t* d_tile_ptr, int32_t* n_tiles, void* stream) {
+    TLC_REQUIRE(n_nodes >= 0 && tile_nodes >= 2 && tile_nodes <= 2 * TC_HALF_MAX && n_tiles, "bad sizes");
+    *n_tiles = 0;
+    if (n_nodes == 0) return TLC_OK;
+    TLC_REQUIRE(d_rowptr && d_col && d_work && d_tile_ptr, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int* st = d_work;
+    unsigned* bits = (unsigned*)(d_work + TC_HEAD);
+    const size_t words = (size_t)n_nodes / 32 + 2;
+    TLC_HIP_CHECK(hipMemsetAsync(d_work, 0, (TC_HEAD + words) * sizeof(int), s));
+    const unsigned g = (unsigned)((n_nodes + 1 + 255) / 256);
+    hipLaunchKernelGGL(tile_cut_mark_kernel, dim3(g), dim3(256), 0, s, n_nodes, tile_nodes / 2, d_rowptr, d_col, bits, st);
+    hipLaunchKernelGGL(tile_cut_gap_kernel, dim3((unsigned)(n_nodes / TC_GAP_PER_WG + 1)), dim3(256), 0, s, n_nodes, tile_nodes / 2, bits, st);
+    hipLaunchKernelGGL(tile_cut_pick_kernel, dim3(g), dim3(256), 0, s, n_nodes, tile_nodes, bits, st, d_tile_ptr);
     TLC_HIP_CHECK(hipGetLastError());
+    int h[TC_HEAD] = {0, 0, 0, 0};
+    TLC_HIP_CHECK(hipMemcpyAsync(h, st, sizeof(h), hipMemcpyDeviceToHost, s));
+    TLC_HIP_CHECK(hipStreamSynchronize(s));
+    *n_tiles = h[TC_NT];
     return TLC_OK;
 }
-

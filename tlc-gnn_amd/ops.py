@@ -196,38 +196,19 @@ def gat_tiles(rowptr, col, n, tile_nodes=GAT_TILE_NODES):
     """Cuts a block-diagonal batch (CSR by target: rowptr int32 [n+1], col = the sources) into self-contained tiles for
     tlc_gat_layer_tiled_fwd: int32 [T+1] node offsets of tiles of at most `tile_nodes` consecutive nodes, cut only at positions no
     edge crosses -- or None when the batch has no such cuts close enough together (one big graph: the two-kernel layer serves it).
-    All on the device; the first free position at or behind every multiple of (tile_nodes - largest gap) starts a tile."""
+    All on the device (tlc_gat_tile_cut; one host read, of the tile count)."""
     torch = _lib.require_gpu()
     n = int(n)
     if n == 0:
         return None
     dev = rowptr.device
-    # an edge into node i from s forbids the cuts in (min(s, i), max(s, i)]: per target the smallest and largest source
-    # (tlc_csr_row_minmax)
-    lo = torch.empty(n, dtype=torch.int32, device=dev)
-    hi = torch.empty(n, dtype=torch.int32, device=dev)
+    work = torch.empty(n // 32 + 6, dtype=torch.int32, device=dev)
+    tiles = torch.empty(2 * n // tile_nodes + 3, dtype=torch.int32, device=dev)
+    nt = C.c_int32(0)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().tlc_csr_row_minmax(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(lo), _lib.ptr(hi),
-                                                 _lib.stream_ptr(dev)), "tlc_csr_row_minmax")
-    # node i forbids the cuts k with lo[i] < k <= hi[i]: +1 at lo + 1, -1 at hi + 1, a running sum, and the zeros are free
-    mark = torch.zeros(n + 2, dtype=torch.int32, device=dev)
-    ones = torch.ones(n, dtype=torch.int32, device=dev)
-    mark.index_add_(0, (lo + 1).long(), ones)
-    mark.index_add_(0, (hi + 1).long(), -ones)
-    ok = torch.cumsum(mark[:n + 1], 0) == 0
-    free = torch.nonzero(ok).reshape(-1)                                  # positions 0 .. n where a tile may start / end
-    if free.numel() < 2:
-        return None
-    gap = int((free[1:] - free[:-1]).max())
-    if 2 * gap > tile_nodes:
-        return None
-    step = tile_nodes - gap
-    starts = torch.arange(0, n, step, device=dev)
-    picks = free[torch.searchsorted(free, starts).clamp_(max=free.numel() - 1)]
-    picks = torch.unique_consecutive(torch.cat([picks[picks < n], free.new_tensor([n])]))
-    if int(picks[0]) != 0 or int((picks[1:] - picks[:-1]).max()) > tile_nodes:
-        return None
-    return picks.to(torch.int32).contiguous()
+        _lib.check(_lib.lib().tlc_gat_tile_cut(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(col), C.c_int32(tile_nodes), _lib.ptr(work),
+                                               _lib.ptr(tiles), C.byref(nt), _lib.stream_ptr(dev)), "tlc_gat_tile_cut")
+    return tiles[:nt.value + 1] if nt.value > 0 else None
 
 
 @_lib.on_device_of

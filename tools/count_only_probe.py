@@ -2,7 +2,7 @@
 same 37 676 pairs, with the tier kernels masked out: development aid."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 import bench
 W = bench.build_workload(0)

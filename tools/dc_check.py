@@ -1,7 +1,7 @@
 """Development aid: the heavy pairs of the bench batch through tlc_pd_pi_batch several times; against the CPU checker, pair by pair."""
 import ctypes as C, sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from tlc_gnn_amd import engine, _lib
 from oracle import oracle

@@ -1,7 +1,7 @@
 """Development aid: tlc_pd_from_filtration on graphs with many Pos edges (divide-and-conquer cycle swap) vs the CPU checker."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); sys.path.insert(0, "tests")
 from tlc_gnn_amd import engine
 from oracle import oracle
 from helpers import same_multiset

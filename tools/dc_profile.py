@@ -1,7 +1,7 @@
 """Development aid: where tlc_pd_dc_kernel's slowest subgraph spends its cycles (thread 0's clock)."""
 import ctypes as C, sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from tlc_gnn_amd import engine, _lib
 wl = bench.build_workload(0)

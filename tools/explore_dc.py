@@ -1,6 +1,6 @@
 """Exploration (development aid): which constructed graphs make tlc_pd_dc_kernel give a subgraph back to the serial walk."""
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np, torch
 from tlc_gnn_amd import engine, synth
 from oracle import oracle

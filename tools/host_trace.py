@@ -3,7 +3,7 @@ python tools/host_trace.py <option> <value> [K]"""
 import os, sys
 os.environ["TLC_HOST_TRACE"] = "1"
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 import bench
 opt, val = sys.argv[1], int(sys.argv[2])

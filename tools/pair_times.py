@@ -1,7 +1,7 @@
 """Per-pair wall-clock stamps of the extraction kernel (PHASE_DEBUG build): where the COUNT pass's time goes, by vicinity size."""
 import ctypes as C, sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from tlc_gnn_amd import engine, _lib
 

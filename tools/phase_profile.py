@@ -1,7 +1,7 @@
 """Per-phase cycle shares of the PD tier kernels (diagnostic: thread 0's clock64 deltas, summed over workgroups)."""
 import ctypes as C, sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine, synth, _lib
 
 NAMES = ["load", "bellman-ford", "tight+chain", "tie fallback", "normalise+edges", "sort asc", "uf asc", "sort desc",

@@ -2,7 +2,7 @@
 chunks' kernels overlap.  python tools/pipelined_region.py K [option value ...]"""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 import bench
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 12

@@ -10,7 +10,8 @@ NAMES = [("tlc_pd_tier_kernel<2048", "pd_tier_large"), ("tlc_pd_dc_kernel<2048",
          ("tlc_extract_kernel<512", "vicinity_count_early"), ("tlc_extract_kernel<64", "vicinity_count"),
          ("tlc_classify", "classify"), ("tlc_vicinity_kernel<true", "vicinity_fill"), ("tlc_vicinity_kernel<false, 512", "vicinity_count_early"),
          ("tlc_vicinity_kernel<false", "vicinity_count"),
-         ("tlc_scan_", "scan_bin"), ("gemm16_f32_kernel", "gemm_f32"), ("spmm_csr", "spmm_csr"), ("lp_decode", "lp_decode")]
+         ("tlc_scan_", "scan_bin"), ("gemm16_f32_kernel", "gemm_f32"), ("gemm_bres_f32_kernel", "gemm_f32"), ("spmm_csr", "spmm_csr"),
+         ("spmm_w2_kernel", "spmm_w2"), ("spmm16_kernel", "spmm16"), ("lp_decode", "lp_decode")]
 
 
 def fold(fetch_dir, write_dir):

@@ -1,7 +1,7 @@
 """Node / edge counts of the bench batch's vicinities: how the SMALL tier's population (17..64 nodes) is distributed."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 import bench
 W = bench.build_workload(0)

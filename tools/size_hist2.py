@@ -1,7 +1,7 @@
 """Vicinity sizes of the bench batch per tier, with the LDS a right-sized layout would need -- development aid."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from tlc_gnn_amd import engine
 wl = bench.build_workload(0)

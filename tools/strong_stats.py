@@ -1,7 +1,7 @@
 """development: tier counts and vicinity-size histogram of the strong-scaling list (504 514 non-edges within hop distance)."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 import bench
 wl = bench.build_workload(0)

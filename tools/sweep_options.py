@@ -3,7 +3,7 @@ fixed and rotating.  python tools/sweep_options.py "n_ws=4" "n_ws=4,gate_ticks=0
 Defaults restored between settings are those in DEFAULTS below."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 import bench
 DEFAULTS = {"tier_mask": 255, "n_ws": 3, "ball_edges": 1, "fast_split": 1, "dc_inplace": 1, "heavy": 1, "tiny": 1, "extract": 1}

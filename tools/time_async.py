@@ -2,7 +2,7 @@
 TLC_CU_RESERVE=n in the environment reserves n CUs for the heavy chain (CU-masked streams)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 import bench
 W = bench.build_workload(0)

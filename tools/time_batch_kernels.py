@@ -2,7 +2,7 @@
 where does a single batch spend its time?  python tools/time_batch_kernels.py <option> <a> <b>"""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 import bench
 opt, va, vb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])

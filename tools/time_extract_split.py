@@ -2,7 +2,7 @@
 > 64: the binned pairs that sweep the members' rows) -- which part bounds tlc_extract_kernel<64>?"""
 import sys
 import numpy as np, torch, scipy.sparse as sp
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 import bench
 W = bench.build_workload(0)

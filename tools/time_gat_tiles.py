@@ -1,7 +1,7 @@
 """Times the steps of ops.gat_tiles on the HIV-shaped batch -- development aid."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import synth, ops
 from tlc_gnn_amd.Knowledge_Distillation.gat_conv import GATConv
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Times tlc_gemm_f32 on the PubMed encoder shapes against torch.mm (rocBLAS) -- diagnostic."""
 import os, sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import ops
 
 def t(fn, n=50):

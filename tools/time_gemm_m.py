@@ -1,7 +1,7 @@
 """tlc_gemm_f32 at K=500, N=100 over M (development aid: prologue vs per-tile cost of the bf16x3 kernel)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import ops
 torch.manual_seed(0)
 for M in (4096, 8192, 19717, 40000, 80000):

@@ -1,7 +1,7 @@
 """The PubMed feature projection alone (19 717 x 500 @ 500 x 100), 100 launches -- for profiler passes."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import ops
 torch.manual_seed(0)
 M, K, N = 19717, 500, 100

@@ -1,7 +1,7 @@
 """Device time of the LP leg's kernels, one process (development aid): python tools/time_lp.py"""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from tlc_gnn_amd import ops
 W = bench.build_workload(0)

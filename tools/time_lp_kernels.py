@@ -2,7 +2,7 @@
 diagnostic for the round-5 work on the leg (decode on the MFMA, conv2's projection in conv1's aggregate, the k=16 aggregate)."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from tlc_gnn_amd import ops
 

@@ -1,7 +1,7 @@
 """Timing of the pre-filtered sweep's two parts on the PubMed-shaped graph (development aid)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from tlc_gnn_amd import engine, pi_cache
 wl = bench.build_workload(0)

@@ -2,7 +2,7 @@
 ball bound (development aid; pipelined batches, one process)."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine, dist as tdist
 import bench
 K = 40

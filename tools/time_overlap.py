@@ -1,7 +1,7 @@
 """Two batches in flight: alternate two graph handles (own workspace each) on two streams (development aid)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine, synth
 
 import bench

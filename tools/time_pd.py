@@ -1,7 +1,7 @@
 """Quick timing of the PD/PI batch on the PubMed-shaped graph (development aid; bench.py is the contract)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine, synth
 
 n, e, k, hop, _ = synth.shaped_graph("PubMed")

@@ -1,7 +1,7 @@
 """The PDGNN forward of bench.py's pdgnn block with and without the tiled layers (GraphBatch(tiled=...)) -- development aid."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import synth
 from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
 from tlc_gnn_amd.Knowledge_Distillation.gat_conv import GraphBatch

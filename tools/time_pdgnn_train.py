@@ -2,7 +2,7 @@
 per-kernel via rocprofv3 if run under it.  python tools/time_pdgnn_train.py [n_graphs]"""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
 n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 rs = np.random.RandomState(1234)

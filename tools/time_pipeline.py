@@ -2,7 +2,7 @@
 chunk k's tier kernels?"""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine, synth
 for name in ("Computers", "Photo"):
     n, e, k, hop, _ = synth.shaped_graph(name)

@@ -1,7 +1,7 @@
 """Timing of the stand-alone PI raster (tlc_pi_raster) on synthetic diagram batches (development aid)."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 
 rs = np.random.RandomState(3)

@@ -1,7 +1,7 @@
 """PD/PI batch time and tier split on the other dataset shapes (Cora, CiteSeer, Photo, Computers) -- development aid."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine, synth
 for name in sys.argv[1:] or ["Cora", "Photo", "Computers"]:
     n, e, k, hop, _ = synth.shaped_graph(name)

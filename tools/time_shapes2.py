@@ -1,7 +1,7 @@
 """Per-kernel times of the PD/PI batch on the other BASELINE shapes (development aid)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine, synth
 for name in ("PPI", "Photo", "Computers"):
     n, e, k, hop, _ = synth.shaped_graph(name)

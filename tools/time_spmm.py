@@ -1,7 +1,7 @@
 """Times tlc_spmm_csr_f32 on the bench graph's normalised CSR, full and with hub rows capped -- diagnostic."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from tlc_gnn_amd import ops
 

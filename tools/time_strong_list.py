@@ -2,7 +2,7 @@
 a few times (the library cuts a list above 2^20 pairs into pipelined chunks; TLC_CHUNK_PAIRS_TEST in the environment cuts smaller)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 import bench
 wl = bench.build_workload(0)

@@ -2,7 +2,7 @@
 pairs with d(u,v) > hop: exact zero rows).  Development aid."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine, synth
 n, e, k, hop, _ = synth.shaped_graph("PubMed")
 rowptr, col, w = synth.edges_to_csr(n, e, k)

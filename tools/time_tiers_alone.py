@@ -1,7 +1,7 @@
 """Each tier kernel of the PD/PI batch alone (the others not launched): standalone durations vs the overlapped batch."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 import bench
 W = bench.build_workload(0)

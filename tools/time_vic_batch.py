@@ -1,7 +1,7 @@
 """Development aid: where Vicinities.batch (PDGNN fork's vicinity extraction, data_utils_LP.py:105-200) spends its time on the Amazon-shaped graphs."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import synth, _lib
 from tlc_gnn_amd.Knowledge_Distillation.data_utils_LP import Vicinities, KD_LP_FLAGS
 def med(fn, reps=7):

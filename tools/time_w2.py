@@ -1,7 +1,7 @@
 """development: tlc_w2_partial_matching on B random diagram pairs of n points each (m = n targets)"""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import ops
 B = 8192
 for n in (12, 25, 50, 100, 200):

@@ -3,7 +3,7 @@ list in pair order.  Model cost of a subgraph c(n, m) in {n + m, (n + m)^2, m^2}
 sorted by cost."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from tlc_gnn_amd import engine
 import bench
 wl = bench.build_workload(0)

@@ -1,7 +1,7 @@
 """Development aid: cycles per phase of tlc_pd_tiny_kernel (per wavefront, mean)."""
 import ctypes as C, sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from tlc_gnn_amd import engine, _lib
 wl = bench.build_workload(0)
