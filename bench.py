@@ -247,7 +247,7 @@ def pdgnn_amazon_aux(torch, dev, n_pairs=4096, seed=1234):
     all vicinities of the sample stacked block-diagonally, ONE Teacher_Model forward, one image per vicinity -- beside the exact
     diagrams + images of the same pairs (tlc_pd_pi_batch with the PDGNN fork's flags).  Device-resident, median of 5."""
     from tlc_gnn_amd import synth, _lib
-    from tlc_gnn_amd.Knowledge_Distillation.data_utils_LP import Vicinities, KD_LP_FLAGS
+    from tlc_gnn_amd.Knowledge_Distillation.data_utils_LP import Vicinities, KD_LP_FLAGS, stacked
     from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
     out = {}
     torch.manual_seed(seed)
@@ -277,14 +277,9 @@ def pdgnn_amazon_aux(torch, dev, n_pairs=4096, seed=1234):
 
         def forward():
             b = state["b"]
-            node_ptr, edge_ptr = b["node_ptr"], b["edge_ptr"]
-            n_tot = int(node_ptr[-1])
-            e = b["edges"].long() + node_ptr[b["pair_of_edge"]].view(-1, 1)
-            loops = torch.arange(n_tot, device=e.device)
-            ei = torch.cat([e.t(), torch.stack([loops, loops])], dim=1)
-            x = b["f"].to(torch.float32).view(-1, 1)
+            x, ei = stacked(b)                   # (the vicinities' edge_index + self loops and float32 filtration, gcn_LP_GIN.py:43-64)
             with torch.no_grad():
-                state["img"] = model(x, ei, None, compute_loss=False, grad_PI=False, graph_ptr=node_ptr, edge_ptr=edge_ptr)[1]
+                state["img"] = model(x, ei, None, compute_loss=False, grad_PI=False, graph_ptr=b["node_ptr"], edge_ptr=b["edge_ptr"])[1]
 
         ex_ms = med_ms(extract)
         fw_ms = med_ms(forward)

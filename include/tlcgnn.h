@@ -311,6 +311,31 @@ int tlc_gat_tile_cut(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_
                      int32_t* d_tile_ptr, int32_t* n_tiles, void* stream);
 
 
+/* remove_self_loops + add_self_loops + grouping by target (gat_conv.py:146-152), the structure alone and per BATCH: what
+ * tlc_gcn_norm_csr builds without its values, with the caller's temporaries -- nothing is allocated, nothing waits for the stream.
+ *   d_rowptr int32[n_nodes+1]; d_col int32[n_edges+n_nodes] (sources ascending inside a row); d_nnz int32[1];
+ *   d_work int32[3 n_nodes + n_edges]. */
+int tlc_csr_by_target(int32_t n_nodes, int64_t n_edges, const int64_t* d_edge_index, int32_t* d_rowptr, int32_t* d_col,
+                      int32_t* d_nnz, int32_t* d_work, void* stream);
+
+/* Teacher_Model.forward(compute_loss=False) without gradients (Knowledge_Distillation/Teacher_model.py:49-88) as ONE call: CSR by
+ * target + tile cut of the batch (skipped when the caller hands in d_rowptr / d_col / d_tile_ptr of a batch it holds; d_tile_ptr NULL
+ * with n_tiles 0: the two-kernel layers), conv1 -> conv2 -> conv4 -> conv3 with PReLU(0.1) behind the first three
+ * (Base_Model.forward :218-227), the edge head (:54-59) and one res x res image per graph (:84).  Same kernels, same results as the
+ * entry points above called one by one; the steps are submitted from native code out of one workspace.
+ *   d_edge_index int64[2][n_edges], the n_nodes self loops LAST (train_Teacher_Model.py:43-44); d_x float32[n_nodes] (in_dim 1);
+ *   hidden = 32; params: HOST array of 20 device pointers (float32) = for conv1, conv2, conv4, conv3 in this order
+ *   {lin_l.weight, att_l, lin_ij.weight, bias}, then lin5.weight, lin5.bias, lin6.weight, lin6.bias;
+ *   d_edge_ptr int64[n_graphs+1]: offsets into the n_edges - n_nodes edges; d_points float32[n_edges - n_nodes][2] (the predicted
+ *   diagram points); d_img float64[n_graphs][res*res]; d_work: tlc_pdgnn_forward_work_bytes(n_nodes, n_edges, hidden) bytes.
+ * The call waits for the stream once (the tile count) unless the structure is handed in. */
+int64_t tlc_pdgnn_forward_work_bytes(int32_t n_nodes, int64_t n_edges, int32_t hidden);
+int tlc_pdgnn_forward(int32_t n_nodes, int64_t n_edges, const int64_t* d_edge_index, const float* d_x, int32_t hidden,
+                      const float* const* params, int64_t n_graphs, const int64_t* d_edge_ptr, int32_t res,
+                      const int32_t* d_rowptr, const int32_t* d_col, const int32_t* d_tile_ptr, int32_t n_tiles,
+                      void* d_work, int64_t work_bytes, float* d_points, double* d_img, void* stream);
+
+
 /* ---- the diagram loss of PDGNN training ------------------------------------------------------------
  * `wasserstein_distance(X, Y, order=p, internal_p=inf, enable_autodiff=True, num_models=1)` of
  * Knowledge_Distillation/wasserstein.py:198-379, as called by Teacher_model.py:131 (compute_PD_loss, kernel='wasserstein'),
@@ -441,6 +466,13 @@ int tlc_pack_vicinities(int64_t n_pairs, const int64_t* d_node_offs, const int32
                         const int64_t* d_edge_offs, const int32_t* d_edges, const int64_t* d_node_ptr, const int64_t* d_edge_ptr,
                         const int64_t* d_label, int64_t* d_out_ids, double* d_out_f, int32_t* d_out_edges,
                         int64_t* d_pair_of_node, int64_t* d_pair_of_edge, void* stream);
+
+/* The packed batch -> the operands Teacher_Model.forward takes, one launch: what gcn_LP_GIN.py:43-64 builds per vicinity (its
+ * edge_index plus self loops, the filtration as a float32 column), for the block-diagonal batch as a whole.  d_edge_index
+ * int64[2][tot_m + tot_n]: global ids = local id + d_node_ptr[owner], the tot_n self loops LAST (train_Teacher_Model.py:43-44);
+ * d_x float32[tot_n] = (float)d_f (both may be NULL).  d_node_ptr / d_edge_ptr int64[n_graphs + 1] with totals tot_n / tot_m. */
+int tlc_stack_batch(int64_t n_graphs, const int64_t* d_node_ptr, const int64_t* d_edge_ptr, const int32_t* d_edges, const double* d_f,
+                    int64_t tot_n, int64_t tot_m, int64_t* d_edge_index, float* d_x, void* stream);
 
 #define TLC_SELECT_KEEP_FAILED 0x1u
 int tlc_select_rows(int64_t n_rows, int32_t width, const double* d_pi, const uint8_t* d_status, int64_t index_base, int64_t cap,

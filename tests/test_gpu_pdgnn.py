@@ -517,3 +517,53 @@ def test_tiled_gat_layer_equals_the_two_kernel_layer():
         n, ei = block_batch([(nn, path)] * 9 + [(3, path[:2])])
         t = GraphBatch(ei, n).tiles
         assert (t is not None) == ok and (not ok or np.array_equal(t.cpu().numpy(), cut_rule(ei, n)))
+
+
+def test_one_call_forward_equals_the_layer_by_layer_forward():
+    """Round 5: Teacher_Model.forward without gradients goes through ONE library call (tlc_pdgnn_forward: CSR by target, tile cut, four
+    layers, edge head, images, submitted natively) -- the same kernels as the layer-by-layer path, so the predicted points and the
+    images must be IDENTICAL: on a packed batch of Amazon-shaped vicinities stacked by data_utils_LP.stacked (tlc_stack_batch, itself
+    against the torch formulation of gcn_LP_GIN.py:43-64), with the batch's structure built inside the call and with a GraphBatch the
+    caller holds, with one image per graph and one for the whole input, and on one big graph (no tiles: the two-kernel layers)."""
+    import torch
+    from tlc_gnn_amd import synth
+    from tlc_gnn_amd.Knowledge_Distillation import data_utils_LP as kd
+    from tlc_gnn_amd.Knowledge_Distillation.Teacher_model import Teacher_Model
+    from tlc_gnn_amd.Knowledge_Distillation.gat_conv import GraphBatch
+    dev = torch.device("cuda")
+    n, edges, kappa, hop, _ = synth.shaped_graph("Photo", scale=0.3)
+    ricci = np.concatenate([np.concatenate([edges, kappa[:, None]], 1), np.concatenate([edges[:, ::-1], kappa[:, None]], 1)]).tolist()
+    vic = kd.Vicinities(edges, ricci)
+    pairs = edges[np.random.RandomState(3).permutation(len(edges))[:700]]
+    b = vic.batch(pairs, 1, node_cap=512, edge_cap=8192)
+    x, ei = kd.stacked(b)
+    node_ptr, edge_ptr = b["node_ptr"], b["edge_ptr"]
+    n_tot = int(node_ptr[-1])
+    e = b["edges"].long() + node_ptr[b["pair_of_edge"]].view(-1, 1)
+    loops = torch.arange(n_tot, device=dev)
+    assert torch.equal(ei, torch.cat([e.t(), torch.stack([loops, loops])], dim=1)) and torch.equal(x, b["f"].to(torch.float32).view(-1, 1))
+
+    torch.manual_seed(5)
+    model = Teacher_Model(type='GAT').eval().to(dev)
+    ring = torch.stack([torch.arange(3000), (torch.arange(3000) + 1) % 3000]).to(dev)
+    big_ei = torch.cat([ring, torch.arange(3000, device=dev).repeat(2, 1)], dim=1)
+    big_x = torch.rand(3000, 1, device=dev)
+    cases = [("vicinities", x, ei, node_ptr, edge_ptr), ("whole input", x, ei, None, None), ("one big graph", big_x, big_ei, None, None)]
+    with torch.no_grad():
+        for name, xx, ee, gp, ep in cases:
+            for held in (False, True):
+                gb = GraphBatch(ee, xx.shape[0]) if held else None
+                assert (gb is None or (gb.tiles is None) == (name == "one big graph")), name
+                assert model._one_call_ok(xx, gb)
+                got = model(xx, ee, None, compute_loss=False, grad_PI=False, graph_ptr=gp, edge_ptr=ep, csr=gb)
+                model._one_call_ok = lambda *a: False
+                try:
+                    want = model(xx, ee, None, compute_loss=False, grad_PI=False, graph_ptr=gp, edge_ptr=ep, csr=gb)
+                finally:
+                    del model._one_call_ok
+                assert got[0].shape == want[0].shape and got[1].shape == want[1].shape and got[1].dtype == want[1].dtype, (name, held)
+                assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (name, held, float((got[1] - want[1]).abs().max()))
+                g32 = model(xx, ee, None, compute_loss=False, grad_PI=True, graph_ptr=gp, edge_ptr=ep, csr=gb)[1]
+                assert g32.dtype == torch.float32 and torch.equal(g32, want[1].to(torch.float32)), (name, held)
+    # a forward that wants gradients does not take the one-call path
+    assert not model._one_call_ok(x.clone().requires_grad_(True), None) and not model.train()._one_call_ok(x, None)

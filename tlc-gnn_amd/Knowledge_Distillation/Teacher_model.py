@@ -80,6 +80,22 @@ class Teacher_Model(torch.nn.Module):
         self.lin4 = Linear(hidden_dim, hidden_dim)
         self.dropout = dropout
 
+    def _one_call_params(self):
+        d = self.DIM0_Model
+        ps = []
+        for conv in (d.conv1, d.conv2, d.conv4, d.conv3):
+            ps += [conv.lin_l.weight, conv.att_l, conv.lin_ij.weight, conv.bias]
+        return [p.detach() for p in ps + [self.lin5.weight, self.lin5.bias, self.lin6.weight, self.lin6.bias]]
+
+    def _one_call_ok(self, x0, csr):
+        """tlc_pdgnn_forward serves the reference's configuration (in_dim 1, hidden 32, float32) when no gradient is wanted and no
+        dropout is drawn; everything else takes the layer-by-layer path below."""
+        if not x0.is_cuda or x0.dim() != 2 or x0.shape[1] != 1 or x0.shape[0] == 0 or self.lin5.out_features != 32 \
+                or self.DIM0_Model.conv1.out_channels != 32 or self.DIM0_Model.conv3.out_channels != 16 or self.lin5.weight.dtype != torch.float32 \
+                or (self.training and self.dropout > 0) or not (csr is None or isinstance(csr, GraphBatch)):
+            return False
+        return not (torch.is_grad_enabled() and (x0.requires_grad or any(p.requires_grad for p in self.parameters())))
+
     def forward(self, x0, edge_index0, PD, kernel='sliced', M=50, p=1, pair_diagonal=False, draw_fig=False, fig_name='',
                 compute_loss=True, grad_PI=True, graph_ptr=None, edge_ptr=None, pd_ptr=None, csr=None):
         """Reference signature.  compute_loss=True needs kernel='wasserstein' (p = 1 or 2) and returns
@@ -100,6 +116,23 @@ class Teacher_Model(torch.nn.Module):
             raise NotImplementedError("Teacher_Model (HIP): compute_loss needs kernel='wasserstein' (the reference's 'sliced' branch cannot "
                                       "run either: Teacher_model.py:110-123 ends in names that were never bound, :137)")
         t1 = time.time()
+        if not compute_loss and self._one_call_ok(x0, csr):
+            # inference: the whole forward is one library call (tlc_pdgnn_forward: the same kernels, submitted natively)
+            n = x0.shape[0]
+            m = edge_index0.shape[1] - n
+            offs = torch.tensor([0, m], dtype=torch.int64, device=x0.device) if edge_ptr is None else edge_ptr.to(torch.int64)
+            held = csr if isinstance(csr, GraphBatch) else None
+            if held is not None:
+                held.check(edge_index0, n)
+            x, img = ops.pdgnn_forward(x0, edge_index0, self._one_call_params(), offs, res=5, hidden=self.lin5.out_features,
+                                       rowptr=None if held is None else held.rowptr, col=None if held is None else held.col,
+                                       tiles=None if held is None else held.tiles)
+            if grad_PI:
+                img = img.to(x.dtype)
+            if edge_ptr is None:
+                img = img[0]
+            t2 = time.time()
+            return x, img, None, None, None, None, t2 - t1, 0.0
         x = self.DIM0_Model(x0, edge_index0, csr=csr)
         n = x0.shape[0]
         m = edge_index0.shape[1] - n

@@ -160,6 +160,14 @@ class Vicinities:
         return dict(node_ptr=node_ptr, edge_ptr=edge_ptr, ids=out_ids, f=out_f, edges=out_e, status=st, pair_of_node=pn, pair_of_edge=pe)
 
 
+def stacked(batch):
+    """A `Vicinities.batch` result -> (x float32 [n,1], edge_index int64 [2, m+n]): all vicinities as ONE block-diagonal input of
+    Teacher_Model.forward (pass graph_ptr=batch['node_ptr'], edge_ptr=batch['edge_ptr']) -- what gcn_LP_GIN.Net.compute_PI (:43-64)
+    builds per candidate edge: the vicinity's edge_index plus self loops (last), its filtration as a float32 column."""
+    ei, x = engine.stack_batch(batch["node_ptr"], batch["edge_ptr"], batch["edges"], batch["f"])
+    return x, ei
+
+
 _CACHE = {}
 
 

@@ -86,8 +86,7 @@ class GATConv(torch.nn.Module):
         call, like the reference (no cache: an address-keyed cache is stale as soon as the allocator reuses a block or
         the caller edits edge_index in place); a caller that runs several layers on one graph builds it once and passes
         `csr=` down, as Base_Model.forward does."""
-        rowptr, col, _ = ops.gcn_norm_csr(edge_index, n)
-        return rowptr, col
+        return ops.csr_by_target(edge_index, n)
 
     def forward(self, x, edge_index, size=None, return_attention_weights=None, prelu_slope=-1.0, csr=None):
         if not isinstance(x, torch.Tensor) or size is not None or return_attention_weights is not None:

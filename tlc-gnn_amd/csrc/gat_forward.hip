@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "tlc_common.h"
+#include "gat_internal.h"
 
 namespace {
 
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(GT_THREADS, 4) void gat_tile_kernel(int n_tiles, co
                                                               const int* __restrict__ src, const float* __restrict__ X,
                                                               const float* __restrict__ Wf, const float* __restrict__ vec,
                                                               const float* __restrict__ bias, float prelu_slope, float* __restrict__ out) {
-    constexpr int N2 = 2 * C + 4, NT = (N2 + 15) / 16, KQ = CIN >= 16 ? CIN / 4 : 1;
+    constexpr int N2 = 2 * C + 4, NT = (N2 + 15) / 16;
     static_assert(CIN == 1 || (CIN % 16 == 0 && CIN <= 64), "c_in: 1 (rank-one rows) or a multiple of 16 up to 64");
     extern __shared__ __attribute__((aligned(16))) float gt_lds[];
     float* const pqa = gt_lds;                                   // [GT_TM][N2]
@@ -709,24 +710,59 @@ extern "C" int tlc_gat_layer_tiled_fwd(int32_t n_nodes, const int32_t* d_rowptr,
     TLC_REQUIRE(d_rowptr && d_src && d_tile_ptr && d_X && d_Wl && d_att && d_Wij && d_bias && d_work && d_out, "null pointer");
     if (!((c_in == 1 || c_in == 64) && (c_out == 32 || c_out == 16))) { tlc_set_error("tlc_gat_layer_tiled_fwd: c_in %d / c_out %d not built", c_in, c_out); return TLC_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
-    const int C = c_out, N2 = 2 * C + 4;
-    if (c_in == 1) {
-        float* vec = d_work;                                  // [2C + 1] = Wl[:, 0]^T [Wij_t^T | Wij_s^T | att]
-        hipLaunchKernelGGL(gat_rank1_vec_kernel, dim3(1), dim3(256), 0, s, C, d_Wl, d_att, d_Wij, vec);
-        TLC_HIP_CHECK(hipGetLastError());
-        return C == 32 ? launch_gat_tiled<32, 1>(n_tiles, d_tile_ptr, d_rowptr, d_src, d_X, nullptr, vec, d_bias, prelu_slope, d_out, s)
-                       : launch_gat_tiled<16, 1>(n_tiles, d_tile_ptr, d_rowptr, d_src, d_X, nullptr, vec, d_bias, prelu_slope, d_out, s);
-    }
-    float* Bt1 = d_work;                                      // [c_in][C]
-    float* Bt2 = Bt1 + (size_t)c_in * C;                      // [C][N2]
-    float* Wf = Bt2 + (size_t)C * N2;                         // [c_in][N2] = Bt1 Bt2
-    const int np = std::max(c_in * C, C * N2);
-    hipLaunchKernelGGL(gat_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, C, c_in, d_Wl, d_att, d_Wij, Bt1, Bt2);
-    TLC_HIP_CHECK(hipGetLastError());
-    int rc = tlc_gemm_f32(c_in, N2, C, Bt1, Bt2, nullptr, 0, Wf, s);
+    const TlcGatPrepLayer layer = {c_in, c_out, d_Wl, d_att, d_Wij, d_work};
+    const int rc = tlc_gat_tiled_prepare(1, &layer, s);
     if (rc != TLC_OK) return rc;
-    return C == 32 ? launch_gat_tiled<32, 64>(n_tiles, d_tile_ptr, d_rowptr, d_src, d_X, Wf, nullptr, d_bias, prelu_slope, d_out, s)
-                   : launch_gat_tiled<16, 64>(n_tiles, d_tile_ptr, d_rowptr, d_src, d_X, Wf, nullptr, d_bias, prelu_slope, d_out, s);
+    return tlc_gat_tiled_run(n_tiles, d_tile_ptr, d_rowptr, d_src, d_X, c_in, c_out, d_work, d_bias, prelu_slope, d_out, s);
+}
+
+// The combined weights of up to four tiled layers, one workgroup per layer (see gat_internal.h).  The products are 64 x 68 x 32 at
+// most: summed per output in LDS, in the order k = 0 .. C-1 -- a forward's weights are ready after ONE launch (the MFMA GEMM the
+// layers used before was a launch per layer behind a packing launch per layer).
+namespace {
+struct GatPrepArgs { TlcGatPrepLayer l[TLC_GAT_PREP_MAX]; };
+__global__ __launch_bounds__(256) void gat_tiled_prep_kernel(GatPrepArgs a) {
+    __shared__ float sWl[32 * 64];                             // [C][c_in], as stored
+    __shared__ float sB2[32 * 68];                             // [C][2C + 4] = [Wij_t^T | Wij_s^T | att | 0 0 0]
+    const TlcGatPrepLayer L = a.l[blockIdx.x];
+    const int C = L.c_out, N2 = 2 * C + 4, c_in = L.c_in;
+    for (int t = threadIdx.x; t < C * c_in; t += 256) sWl[t] = L.Wl[t];
+    for (int t = threadIdx.x; t < C * N2; t += 256) {
+        const int k = t / N2, j = t - k * N2;
+        sB2[t] = j < C ? L.Wij[(size_t)j * 2 * C + k] : (j < 2 * C ? L.Wij[(size_t)(j - C) * 2 * C + C + k] : (j == 2 * C ? L.att[k] : 0.0f));
+    }
+    __syncthreads();
+    const int total = c_in == 1 ? 2 * C + 1 : c_in * N2;
+    for (int t = threadIdx.x; t < total; t += 256) {
+        const int k = t / N2, j = t - k * N2;                 // (c_in == 1: k = 0, j = t)
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c) acc += sWl[c * c_in + k] * sB2[c * N2 + j];
+        L.prep[t] = acc;
+    }
+}
+}  // namespace
+int tlc_gat_tiled_prepare(int n_layers, const TlcGatPrepLayer* layers, hipStream_t s) {
+    TLC_REQUIRE(n_layers > 0 && n_layers <= TLC_GAT_PREP_MAX && layers, "bad sizes");
+    GatPrepArgs a = {};
+    for (int i = 0; i < n_layers; ++i) {
+        const TlcGatPrepLayer& L = layers[i];
+        if (!((L.c_in == 1 || L.c_in == 64) && (L.c_out == 32 || L.c_out == 16))) { tlc_set_error("tlc_gat_layer_tiled_fwd: c_in %d / c_out %d not built", L.c_in, L.c_out); return TLC_ERR_UNSUPPORTED; }
+        TLC_REQUIRE(L.Wl && L.att && L.Wij && L.prep, "null pointer");
+        a.l[i] = L;
+    }
+    hipLaunchKernelGGL(gat_tiled_prep_kernel, dim3(n_layers), dim3(256), 0, s, a);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}
+int tlc_gat_tiled_run(int n_tiles, const int* tile_ptr, const int* rowptr, const int* src, const float* X, int c_in, int c_out, const float* prep,
+                      const float* bias, float prelu_slope, float* out, hipStream_t s) {
+    if (n_tiles <= 0) return TLC_OK;
+    if (!((c_in == 1 || c_in == 64) && (c_out == 32 || c_out == 16))) { tlc_set_error("tlc_gat_layer_tiled_fwd: c_in %d / c_out %d not built", c_in, c_out); return TLC_ERR_UNSUPPORTED; }
+    if (c_in == 1)
+        return c_out == 32 ? launch_gat_tiled<32, 1>(n_tiles, tile_ptr, rowptr, src, X, nullptr, prep, bias, prelu_slope, out, s)
+                           : launch_gat_tiled<16, 1>(n_tiles, tile_ptr, rowptr, src, X, nullptr, prep, bias, prelu_slope, out, s);
+    return c_out == 32 ? launch_gat_tiled<32, 64>(n_tiles, tile_ptr, rowptr, src, X, prep, nullptr, bias, prelu_slope, out, s)
+                       : launch_gat_tiled<16, 64>(n_tiles, tile_ptr, rowptr, src, X, prep, nullptr, bias, prelu_slope, out, s);
 }
 
 // The tile cut of tlc_gat_layer_tiled_fwd (Knowledge_Distillation/gat_conv.py GraphBatch -> ops.gat_tiles), all on the device

@@ -1168,36 +1168,50 @@ __global__ __launch_bounds__(256) void lp_decode_generic_kernel(long long n_pair
 // ======================================================================================================================
 // C ABI
 // ======================================================================================================================
+// the launches of the CSR-by-target build; tmp int32[3 n + E] = [cnt n | cursor n | unsorted col E + n]; d_val NULL: structure only
+static int gcn_csr_launch(int32_t n_nodes, int64_t n_edges, const int64_t* d_edge_index, int32_t* d_rowptr, int32_t* d_col, float* d_val,
+                          int32_t* d_nnz, int* tmp, hipStream_t s) {
+    if (hipMemsetAsync(tmp, 0, 2 * (size_t)n_nodes * sizeof(int), s) != hipSuccess) return TLC_ERR_HIP;
+    const int eb = (int)((n_edges + 255) / 256), nb = (n_nodes + 255) / 256;
+    if (n_edges) hipLaunchKernelGGL(gcn_count_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, tmp);
+    if (n_nodes <= 8192) {
+        hipLaunchKernelGGL(gcn_scan_kernel, dim3(1), dim3(1024), 0, s, n_nodes, (const int*)tmp, d_rowptr, d_nnz);
+    } else {
+        // block totals in the head of d_col (written for good only by gcn_finish_kernel, after the fill)
+        const int sb = (n_nodes + 1023) / 1024;
+        hipLaunchKernelGGL(gcn_scan_block_kernel, dim3(sb), dim3(1024), 0, s, n_nodes, (const int*)tmp, d_rowptr, d_col);
+        hipLaunchKernelGGL(gcn_scan_top_kernel, dim3(1), dim3(1024), 0, s, sb, d_col, d_rowptr, d_nnz);
+        hipLaunchKernelGGL(gcn_scan_add_kernel, dim3(sb), dim3(1024), 0, s, n_nodes, d_rowptr, (const int*)d_col);
+    }
+    if (n_edges) hipLaunchKernelGGL(gcn_fill_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, (const int*)d_rowptr, tmp + n_nodes, tmp + 2 * (size_t)n_nodes);
+    hipLaunchKernelGGL(gcn_finish_short_kernel, dim3(nb), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)(tmp + 2 * (size_t)n_nodes), d_col);
+    hipLaunchKernelGGL(gcn_finish_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)(tmp + 2 * (size_t)n_nodes), d_col);
+    if (d_val) hipLaunchKernelGGL(gcn_val_kernel, dim3(nb), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)d_col, d_val);
+    return hipGetLastError() == hipSuccess ? TLC_OK : TLC_ERR_HIP;
+}
+
 extern "C" int tlc_gcn_norm_csr(int32_t n_nodes, int64_t n_edges, const int64_t* d_edge_index, int32_t* d_rowptr,
                                 int32_t* d_col, float* d_val, int32_t* d_nnz, void* stream) {
     TLC_REQUIRE(n_nodes > 0 && n_edges >= 0, "bad sizes");
     TLC_REQUIRE(d_rowptr && d_col && d_val && (n_edges == 0 || d_edge_index), "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    int* tmp = nullptr;   // [cnt n | cursor n | unsorted col n_edges + n]
+    int* tmp = nullptr;
     TLC_HIP_CHECK(hipMalloc(&tmp, (3 * (size_t)n_nodes + (size_t)n_edges) * sizeof(int)));
-    int rc = TLC_OK;
-    do {
-        if (hipMemsetAsync(tmp, 0, 2 * (size_t)n_nodes * sizeof(int), s) != hipSuccess) { rc = TLC_ERR_HIP; break; }
-        const int eb = (int)((n_edges + 255) / 256), nb = (n_nodes + 255) / 256;
-        if (n_edges) hipLaunchKernelGGL(gcn_count_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, tmp);
-        if (n_nodes <= 8192) {
-            hipLaunchKernelGGL(gcn_scan_kernel, dim3(1), dim3(1024), 0, s, n_nodes, (const int*)tmp, d_rowptr, d_nnz);
-        } else {
-            // block totals in the head of d_col (written for good only by gcn_finish_kernel, after the fill)
-            const int sb = (n_nodes + 1023) / 1024;
-            hipLaunchKernelGGL(gcn_scan_block_kernel, dim3(sb), dim3(1024), 0, s, n_nodes, (const int*)tmp, d_rowptr, d_col);
-            hipLaunchKernelGGL(gcn_scan_top_kernel, dim3(1), dim3(1024), 0, s, sb, d_col, d_rowptr, d_nnz);
-            hipLaunchKernelGGL(gcn_scan_add_kernel, dim3(sb), dim3(1024), 0, s, n_nodes, d_rowptr, (const int*)d_col);
-        }
-        if (n_edges) hipLaunchKernelGGL(gcn_fill_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, (const int*)d_rowptr, tmp + n_nodes, tmp + 2 * (size_t)n_nodes);
-        hipLaunchKernelGGL(gcn_finish_short_kernel, dim3(nb), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)(tmp + 2 * (size_t)n_nodes), d_col);
-        hipLaunchKernelGGL(gcn_finish_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)(tmp + 2 * (size_t)n_nodes), d_col);
-        hipLaunchKernelGGL(gcn_val_kernel, dim3(nb), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)d_col, d_val);
-        if (hipGetLastError() != hipSuccess) { rc = TLC_ERR_HIP; break; }
-    } while (0);
+    const int rc = gcn_csr_launch(n_nodes, n_edges, d_edge_index, d_rowptr, d_col, d_val, d_nnz, tmp, s);
     hipStreamSynchronize(s);      // cached=True: one-off preprocessing; the temporaries must outlive the kernels
     hipFree(tmp);
     if (rc != TLC_OK) tlc_set_error("tlc_gcn_norm_csr: HIP failure");
+    return rc;
+}
+
+// The structure alone, per BATCH (Knowledge_Distillation/gat_conv.py:146-152 runs remove_self_loops + add_self_loops on every forward):
+// the caller brings the temporaries, nothing is allocated and nothing waits for the stream.
+extern "C" int tlc_csr_by_target(int32_t n_nodes, int64_t n_edges, const int64_t* d_edge_index, int32_t* d_rowptr, int32_t* d_col,
+                                 int32_t* d_nnz, int32_t* d_work, void* stream) {
+    TLC_REQUIRE(n_nodes > 0 && n_edges >= 0, "bad sizes");
+    TLC_REQUIRE(d_rowptr && d_col && d_nnz && d_work && (n_edges == 0 || d_edge_index), "null pointer");
+    const int rc = gcn_csr_launch(n_nodes, n_edges, d_edge_index, d_rowptr, d_col, nullptr, d_nnz, d_work, (hipStream_t)stream);
+    if (rc != TLC_OK) tlc_set_error("tlc_csr_by_target: HIP failure");
     return rc;
 }
 

@@ -423,3 +423,45 @@ extern "C" int tlc_pack_vicinities(int64_t n_pairs, const int64_t* d_node_offs, 
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }
+
+// ---- tlc_stack_batch: the packed batch -> the model's operands (x, edge_index), ONE launch ------------------------------------------
+// What the PDGNN fork's caller does per vicinity (gcn_LP_GIN.py:43-64: edge_index of the vicinity + its self loops, the filtration as
+// a float32 column) for the whole block-diagonal batch: global node ids = local id + node_ptr[owner], the n self loops LAST
+// (train_Teacher_Model.py:43-44).  One wavefront per vicinity.  (The torch formulation -- long(), gather, add, arange, stack, cat,
+// float() -- is eight launches: 0.08 ms of a 0.5 ms forward on 4 096 vicinities.)
+namespace {
+__global__ __launch_bounds__(256) void stack_batch_kernel(long long n_graphs, const long long* __restrict__ node_ptr, const long long* __restrict__ edge_ptr,
+                                                        const int* __restrict__ edges, const double* __restrict__ f, long long tot_n, long long tot_m,
+                                                        long long* __restrict__ ei, float* __restrict__ x) {
+    const int lane = (int)(threadIdx.x & 63);
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwave = (long long)gridDim.x * (blockDim.x >> 6);
+    const long long width = tot_m + tot_n;
+    for (long long i = wave; i < n_graphs; i += nwave) {
+        const long long no = node_ptr[i], eo = edge_ptr[i];
+        const int n = (int)(node_ptr[i + 1] - no), m = (int)(edge_ptr[i + 1] - eo);
+        const int2* src = reinterpret_cast<const int2*>(edges) + eo;
+        for (int k = lane; k < m; k += 64) {
+            const int2 e = src[k];
+            ei[eo + k] = no + e.x;
+            ei[width + eo + k] = no + e.y;
+        }
+        for (int k = lane; k < n; k += 64) {
+            ei[tot_m + no + k] = no + k;
+            ei[width + tot_m + no + k] = no + k;
+            if (x) x[no + k] = (float)f[no + k];
+        }
+    }
+}
+}  // namespace
+extern "C" int tlc_stack_batch(int64_t n_graphs, const int64_t* d_node_ptr, const int64_t* d_edge_ptr, const int32_t* d_edges, const double* d_f,
+                               int64_t tot_n, int64_t tot_m, int64_t* d_edge_index, float* d_x, void* stream) {
+    TLC_REQUIRE(n_graphs >= 0 && tot_n >= 0 && tot_m >= 0, "bad sizes");
+    if (n_graphs == 0 || tot_n + tot_m == 0) return TLC_OK;
+    TLC_REQUIRE(d_node_ptr && d_edge_ptr && d_edge_index && (tot_m == 0 || d_edges) && (!d_x || d_f), "null pointer");
+    long long blocks = (n_graphs + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(stack_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long long)n_graphs, (const long long*)d_node_ptr,
+                       (const long long*)d_edge_ptr, d_edges, d_f, (long long)tot_n, (long long)tot_m, (long long*)d_edge_index, d_x);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
+}

@@ -224,6 +224,24 @@ def pack_vicinities(node_offs, ids, f, edge_offs, edges, node_ptr, edge_ptr, tot
 
 
 @_lib.on_device_of
+def stack_batch(node_ptr, edge_ptr, edges, f=None):
+    """A packed batch (node_ptr / edge_ptr int64[B+1], edges int32 [m,2] local ids, f float64 [n]) -> (edge_index int64 [2, m+n] with
+    global ids and the n self loops last, x float32 [n,1] or None): the operands of Teacher_Model.forward, one launch
+    (tlc_stack_batch); the sizes are the tensors' own, nothing is read back."""
+    torch = _lib.require_gpu()
+    B, m = node_ptr.numel() - 1, int(edges.shape[0])
+    if f is None:
+        raise ValueError("stack_batch: f (its length is the node count) is needed")
+    n = int(f.numel())
+    ei = torch.empty((2, m + n), dtype=torch.int64, device=edges.device)
+    x = torch.empty((n, 1), dtype=torch.float32, device=edges.device)
+    rc = _lib.lib().tlc_stack_batch(C.c_int64(B), _lib.ptr(node_ptr), _lib.ptr(edge_ptr), _lib.ptr(edges.contiguous()),
+                                    _lib.ptr(f.contiguous()), C.c_int64(n), C.c_int64(m), _lib.ptr(ei), _lib.ptr(x), _lib.stream_ptr())
+    _lib.check(rc, "tlc_stack_batch")
+    return ei, x
+
+
+@_lib.on_device_of
 def pack_offsets(n, m):
     """Per-pair counts of vicinity_filtration (int32[E], negative = did not fit) -> (node_ptr int64[E+1], edge_ptr int64[E+1],
     totals int64[4] = min n, min m, sum n, sum m): tlc_pack_offsets, one launch; vicinities without an edge are left out."""

@@ -37,6 +37,49 @@ def gcn_norm_csr(edge_index, num_nodes):
 
 
 @_lib.on_device_of
+def csr_by_target(edge_index, num_nodes):
+    """remove_self_loops + add_self_loops + grouping by target (Knowledge_Distillation/gat_conv.py:146-152), the structure alone:
+    (rowptr int32[N+1], col int32[E+N] of which the first rowptr[N] are written).  tlc_csr_by_target: temporaries from the caching
+    allocator, no host read -- the per-batch form of gcn_norm_csr (whose one-off build allocates, waits and frees)."""
+    torch = _lib.require_gpu()
+    assert edge_index.is_cuda and edge_index.dtype == torch.int64 and edge_index.shape[0] == 2
+    ei = edge_index.contiguous()
+    E, dev = ei.shape[1], ei.device
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(E + num_nodes, dtype=torch.int32, device=dev)
+    work = torch.empty(3 * num_nodes + E + 1, dtype=torch.int32, device=dev)             # [temporaries | nnz]
+    rc = _lib.lib().tlc_csr_by_target(C.c_int32(num_nodes), C.c_int64(E), _lib.ptr(ei), _lib.ptr(rowptr), _lib.ptr(col),
+                                      _lib.ptr(work[3 * num_nodes + E:]), _lib.ptr(work), _lib.stream_ptr())
+    _lib.check(rc, "tlc_csr_by_target")
+    return rowptr, col
+
+
+@_lib.on_device_of
+def pdgnn_forward(x, edge_index, params, edge_ptr, res=5, hidden=32, rowptr=None, col=None, tiles=None):
+    """Teacher_Model.forward(compute_loss=False) without gradients as one library call (tlc_pdgnn_forward): x float32 [n,1],
+    edge_index int64 [2, m+n] (self loops last), params = the 20 float32 tensors in the header's order, edge_ptr int64 [B+1]
+    -> (points float32 [m,2], images float64 [B, res*res]).  rowptr / col / tiles: the structure of a batch the caller holds."""
+    torch = _lib.require_gpu()
+    n, E, B = int(x.shape[0]), int(edge_index.shape[1]), int(edge_ptr.numel()) - 1
+    ei = edge_index.contiguous()
+    L = _lib.lib()
+    nbytes = int(L.tlc_pdgnn_forward_work_bytes(C.c_int32(n), C.c_int64(E), C.c_int32(hidden)))
+    if nbytes < 0:
+        raise ValueError("pdgnn_forward: edge_index must end in the n self loops (train_Teacher_Model.py:43-44)")
+    work = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    points = torch.empty((E - n, 2), dtype=torch.float32, device=x.device)
+    img = torch.empty((max(B, 1), res * res), dtype=torch.float64, device=x.device)
+    keep = [_f32(p) for p in params]
+    arr = (C.c_void_p * 20)(*[p.data_ptr() for p in keep])
+    nt = 0 if tiles is None else tiles.numel() - 1
+    rc = L.tlc_pdgnn_forward(C.c_int32(n), C.c_int64(E), _lib.ptr(ei), _lib.ptr(_f32(x)), C.c_int32(hidden), arr, C.c_int64(B),
+                             _lib.ptr(edge_ptr.contiguous()), C.c_int32(res), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(tiles), C.c_int32(nt),
+                             _lib.ptr(work), C.c_int64(nbytes), _lib.ptr(points), _lib.ptr(img), _lib.stream_ptr())
+    _lib.check(rc, "tlc_pdgnn_forward")
+    return points, img[:B]
+
+
+@_lib.on_device_of
 def gemm(a, b, bias=None, relu=False, out=None):
     """C = A @ B (+bias)(ReLU) on the f32 MFMA; A [M,K], B [K,N<=128] float32 CUDA."""
     torch = _lib.require_gpu()
