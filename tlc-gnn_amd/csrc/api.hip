@@ -577,7 +577,16 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
             if (k == 4) {
                 if (i == 0 || (eager_streams && i < n_eager)) { CK(hipStreamCreateWithPriority(&ws->side[k], hipStreamNonBlocking, prio_hi)); ws->own_early = 1; }
             }
-            else if (i > 0) ws->side[k] = g->ws[0].side[k];
+            else if (i > 0) {
+                ws->side[k] = g->ws[0].side[k];
+                // the third workspace's MEDWIDE list goes to the LARGE list's stream, which is idle while the early pass carries the
+                // LARGE list (always, in pipelined chunks): the MEDWIDE stream's queue was the busiest of a pipelined region (0.74: tier
+                // kernel + the longest serial swaps of three chunks in order, and a main stream on the same hardware queue), every
+                // chunk's LAST kernel was its MEDWIDE swap, started behind the previous chunk's.  0.576 -> 0.551 ms per pipelined batch;
+                // the other assignments (second workspace's, the MEDIUM list's, the swaps on a stream of their own) were worse
+                // (profiles/r05_stream_assignment.txt)
+                if (i == 2 && k == 7) ws->side[k] = g->ws[0].side[1];
+            }
             else if (k == 2) ws->side[k] = nullptr;                      // (= side[6], set below)
             else {
                 int pr = k == 1 ? prio_hi : ((k == 6 || k == 7) ? prio_mid : prio_lo);
@@ -1142,10 +1151,11 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
                 if (!pend[k].on) continue;
                 pend[k].on = false;
                 const int t = pend[k].t;
-                int r = ((g->opt_tier_mask >> t) & 1) ? tlc_launch_pd_tier(t, pend[k].pp, ws->side[k]) : TLC_OK;
+                hipStream_t ss = ws->side[k];
+                int r = ((g->opt_tier_mask >> t) & 1) ? tlc_launch_pd_tier(t, pend[k].pp, ss) : TLC_OK;
                 if (r != TLC_OK) return r;
-                if (pend[k].timed) T1(tslot[t], ws->side[k]);
-                TLC_HIP_CHECK(hipEventRecord(ws->ev_join[k], ws->side[k]));
+                if (pend[k].timed) T1(tslot[t], ss);
+                TLC_HIP_CHECK(hipEventRecord(ws->ev_join[k], ss));
             }
             return TLC_OK;
         };
