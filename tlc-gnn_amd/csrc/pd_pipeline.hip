@@ -1041,6 +1041,128 @@ __device__ __forceinline__ int ext1_walk(const SwapTables& T, ull* recs, Query& 
     return n_out;
 }
 
+
+// ---- the same walk on COMPACT tables (tlc_pd_swap_kernel: capacities <= 1 024 edges, so ranks and stamps fit 16 / 12 bits) ----------
+// Per node 12 bytes instead of 28, and per step three LDS instructions instead of six:
+//   pk[x]   u32 = (ascending rank + 1 of the edge x -> parent) << 16 | parent      (parent 0xffff: not in the tree; NMcap: above the root)
+//   slot[x] u64 = stamp << 52 | (heaviest key so far | step) << 32 | child << 16 | parent
+// A walker EXCHANGES its stamp and its running maximum into the node it steps on: what comes back is the other walker's stamp and
+// maximum when that one has been there (the meeting), so "publish, take the stamp, read theirs" of ext1_walk is one ds_wrxchg_rtn_b64.
+// In the swap kernels these steps are a seventh of a pipelined batch's wave-instructions (profiles/r05_stream_assignment.txt, 3).
+#ifndef TLC_SWAP_COMPACT
+#define TLC_SWAP_COMPACT 1        /* make EXTRA="-DTLC_SWAP_COMPACT=0": the swap kernels on ext1_walk's tables (A/B) */
+#endif
+struct SwapTablesC {
+    unsigned* pk;
+    ull* slot;
+};
+__host__ __device__ constexpr size_t swap_table_c_bytes(int NMcap) { return (size_t)(NMcap + 2) * 12 + 16; }
+__device__ __forceinline__ SwapTablesC carve_swap_c(void* base, int NMcap) {
+    const int NS = NMcap + 1;
+    SwapTablesC T;
+    T.slot = (ull*)base;
+    T.pk = (unsigned*)(T.slot + NS);
+    return T;
+}
+// `recs` = 2 x 65 path records u32 (rank + 1) << 16 | node.  Same contract as ext1_walk (PtsSink only: the swap kernel's).
+template <class Sink, class Query>
+__device__ __forceinline__ int ext1_walk_c(const SwapTablesC& T, unsigned* recs, Query& qs, int npos, int NMcap, bool any_unreached,
+                                           Sink& sink, int out0) {
+    const unsigned NONE16 = 0xffffu;
+    unsigned* pk = T.pk;
+    ull* slot = T.slot;
+    int n_out = 0;
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = tlc_lane();
+    const bool qside = (lane & 1) != 0;
+    unsigned* rec = recs + (qside ? 65 : 0);
+    unsigned stamp = 0;
+    qs.init(lane);
+    unsigned n_pq = qs.n_pq, n_ar = qs.n_ar;
+    const unsigned side_shift = qside ? 0u : 16u;
+    int n_cur = (int)((n_pq >> side_shift) & 0xffffu);
+    unsigned n_pk = pk[n_cur];
+    for (int pi = 0; pi < npos; ++pi) {
+        const unsigned pq = n_pq, ar = n_ar;
+        int cur = n_cur;
+        unsigned pcur = n_pk & 0xffffu, kcur = (n_pk >> 16) << 8;
+        qs.advance(pi, lane);
+        n_pq = qs.n_pq;
+        n_ar = qs.n_ar;
+        const int p = pq >> 16, q = pq & 0xffffu;
+        unsigned res_hi = 0, res_lo = 0, res_s = 0;
+        if (!any_unreached || __ballot(lane < 2 && pcur == NONE16) == 0ull) {
+            stamp += 2;                                            // <= 2 * 1 024 + 1: twelve bits
+            int fl = 0;
+            if (lane < 2) {
+                const unsigned mine = (stamp + (unsigned)(lane & 1)) << 20, theirs = stamp + (unsigned)((lane & 1) ^ 1);
+                unsigned mx_hi = 0, mx_lo = 0, step = 0;
+                ull old;
+                slot[cur] = (ull)mine << 32;
+                for (;;) {
+                    const unsigned c_hi = kcur | (step < 255u ? step : 255u);
+                    const bool upd = c_hi > mx_hi;
+                    mx_hi = upd ? c_hi : mx_hi;
+                    mx_lo = upd ? (((unsigned)cur << 16) | pcur) : mx_lo;
+                    rec[step < 64u ? step : 64u] = (kcur << 8) | (unsigned)cur;
+                    old = atomicExch(&slot[pcur], ((ull)(mine | mx_hi) << 32) | mx_lo);      // ds_wrxchg_rtn_b64
+                    unsigned pn = pk[pcur];
+                    unsigned o_st = (unsigned)(old >> 52);
+                    // one LDS round trip per step (see ext1_walk)
+                    asm volatile("" : "+v"(o_st), "+v"(pn));
+                    const ull fm = __ballot(o_st == theirs);
+                    cur = (int)pcur;
+                    pcur = pn & 0xffffu;
+                    kcur = (pn >> 16) << 8;
+                    ++step;
+                    if (fm) { fl = __builtin_ctzll(fm); break; }
+                }
+                const unsigned o_hi = (unsigned)(old >> 32) & 0xfffffu, o_lo = (unsigned)old;
+                const bool mwin = mx_hi >= o_hi;
+                res_hi = mwin ? mx_hi : o_hi;
+                res_lo = mwin ? mx_lo : o_lo;
+                res_s = (unsigned)(lane & 1) ^ (mwin ? 0u : 1u);
+            }
+            fl = __builtin_amdgcn_readfirstlane(fl);
+            res_hi = __builtin_amdgcn_readlane(res_hi, fl);
+            res_lo = __builtin_amdgcn_readlane(res_lo, fl);
+            res_s = __builtin_amdgcn_readlane(res_s, fl);
+        }
+        n_cur = (int)((n_pq >> side_shift) & 0xffffu);
+        if (res_hi == 0u) { n_pk = pk[n_cur]; continue; }
+        const int best = (int)(res_lo >> 16), bp = (int)(res_lo & 0xffffu);
+        const unsigned bstep = res_hi & 0xffu;
+        const int hin = best > bp ? best : bp;
+        if (lane == 0) sink.one_at(nullptr, out0 + n_out, n_out, p, hin);
+        ++n_out;
+        const unsigned ar16 = (ar >> 8) << 16;
+        if (bstep < 64u) {
+            const unsigned* rr = recs + (res_s ? 65 : 0);
+            const bool mine_i = (unsigned)lane <= bstep;
+            const int li = mine_i ? lane : 0;
+            const unsigned r1 = rr[li], r0 = rr[li > 0 ? li - 1 : 0];
+            const unsigned xprev = lane ? (r0 & 0xffffu) : (unsigned)(res_s == 0 ? q : p);
+            const unsigned kprev = lane ? (r0 & 0xffff0000u) : ar16;
+            if (mine_i) pk[r1 & 0xffffu] = kprev | xprev;
+        } else {
+            if (lane == 0) {
+                int node = res_s == 0 ? p : q, nodec = res_s == 0 ? q : p;
+                unsigned kin = ar16;
+                while (nodec != best) {
+                    const unsigned old_pk = pk[node];
+                    pk[node] = kin | (unsigned)nodec;
+                    nodec = node;
+                    node = (int)(old_pk & 0xffffu);
+                    kin = old_pk & 0xffff0000u;
+                }
+            }
+        }
+        n_pk = pk[n_cur];
+    }
+    __builtin_amdgcn_s_setprio(0);
+    return n_out;
+}
+
 }  // namespace
 #include "ext1_dc.h"
 namespace {
@@ -1738,7 +1860,8 @@ struct SwapLayout {
 __host__ __device__ constexpr SwapLayout make_swap_layout(int NM, int MM) {
     SwapLayout L{};
     // [0, o_rec): the swap tables; afterwards f[NM] and the image table (64 points per round at res 5)
-    size_t o = al16(smax(swap_table_bytes(NM), (size_t)8 * NM + (size_t)64 * 13 * 8));
+    // (capacities up to 1 024 edges: the compact tables of ext1_walk_c)
+    size_t o = al16(smax((MM <= 1024 && TLC_SWAP_COMPACT) ? swap_table_c_bytes(NM) : swap_table_bytes(NM), (size_t)8 * NM + (size_t)64 * 13 * 8));
     L.table_bytes = o - (size_t)8 * NM;
     L.o_rec = o;  o += 1280;
     L.o_pts = o;  o += al16((size_t)(MM + 2) * 4);
@@ -1758,22 +1881,45 @@ __device__ __forceinline__ void swap_subgraph(const TlcPdParams& p, int wi, unsi
     const int i = p.tier_list[wi];
     const int n = H.hdr[1], npos = H.hdr[2], np0 = H.hdr[3], n_up = H.hdr[4];
     const bool any_unreached = H.hdr[5] != 0;
-    const SwapTables T = carve_swap(lds_raw, NM);
-    ull* recs = (ull*)(lds_raw + L.o_rec);
     unsigned* pts = (unsigned*)(lds_raw + L.o_pts);
     int* ctl = (int*)(lds_raw + L.o_ctl);
 #ifdef TLC_PHASE_DEBUG
     const ull t_begin = clock64();
 #endif
-    for (int k = tid; k < n; k += W) { T.par[k] = H.par[k] & 0x7fffffffu; T.key[k] = H.key[k]; T.mark[k] = 0u; }
     for (int k = tid; k < np0; k += W) pts[k] = H.pts[k];
-    if (tid == 0) { T.par[NM] = (unsigned)NM; T.key[NM] = 0u; T.mark[NM] = 0u; }
-    __syncthreads();
     PtsSink sink{pts, ctl};
-    if (tid < 64) {
-        QueryGlobal qs{H.query, npos, 0u, 0u, 0u, 0u, 0u, 0u};
-        const int n_out = ext1_walk(T, recs, qs, npos, NM, any_unreached, sink, (const double*)nullptr, false, np0, nullptr);
-        if (tid == 0) ctl[2] = np0 + n_out;
+    if constexpr (MM <= 1024 && TLC_SWAP_COMPACT) {
+        // compact tables (ext1_walk_c): (rank + 1) << 16 | parent per node, "not in the tree" = 0xffff; slot NM = the spare node above the root
+        const SwapTablesC T = carve_swap_c(lds_raw, NM);
+        unsigned* recs = (unsigned*)(lds_raw + L.o_rec);
+        for (int k = tid; k < n; k += W) {
+            const unsigned pr = H.par[k];
+            T.pk[k] = ((H.key[k] >> 8) << 16) | (pr == 0xffffffffu ? 0xffffu : (pr & 0xffffu));
+            T.slot[k] = 0ull;
+        }
+        if (tid == 0) { T.pk[NM] = (unsigned)NM; T.slot[NM] = 0ull; }
+        __syncthreads();
+        if (tid < 64) {
+            QueryGlobal qs{H.query, npos, 0u, 0u, 0u, 0u, 0u, 0u};
+            const int n_out = ext1_walk_c(T, recs, qs, npos, NM, any_unreached, sink, np0);
+            if (tid == 0) ctl[2] = np0 + n_out;
+        }
+    } else {
+        const SwapTables T = carve_swap(lds_raw, NM);
+        ull* recs = (ull*)(lds_raw + L.o_rec);
+        for (int k = tid; k < n; k += W) {
+            const unsigned pr = H.par[k];
+            T.par[k] = pr == 0xffffffffu ? pr : (pr & 0x7fffffffu);
+            T.key[k] = H.key[k];
+            T.mark[k] = 0u;
+        }
+        if (tid == 0) { T.par[NM] = (unsigned)NM; T.key[NM] = 0u; T.mark[NM] = 0u; }
+        __syncthreads();
+        if (tid < 64) {
+            QueryGlobal qs{H.query, npos, 0u, 0u, 0u, 0u, 0u, 0u};
+            const int n_out = ext1_walk(T, recs, qs, npos, NM, any_unreached, sink, (const double*)nullptr, false, np0, nullptr);
+            if (tid == 0) ctl[2] = np0 + n_out;
+        }
     }
     __syncthreads();
     const int np = ctl[2];
