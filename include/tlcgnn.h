@@ -270,7 +270,8 @@ int tlc_lp_decode_fused(int64_t n_pairs, const int32_t* d_pairs, const float* d_
 /* The same pass over a float32 image table [n_pairs, pi_dim]: the reference casts the images to float32 before the layer on
  * every decode (`PI = torch.Tensor(self.PI[...])`, TLCGNN.py:35-36,52-53); a caller that casts its table ONCE at set-up hands
  * it in here -- same values (the cast is the same rounding), 100 instead of 200 bytes per pair.  Both forms run the hidden
- * layer on the f32 MFMA when emb_dim == 16 and pi_dim == 25 (sixteen pairs per wavefront, weights in registers, no LDS). */
+ * layer on the f32 MFMA when emb_dim == 16 and pi_dim == 25 (one lane per pair, K = 1 MFMAs in the reference's summation order,
+ * weights in registers, no LDS). */
 int tlc_lp_decode_fused_f32(int64_t n_pairs, const int32_t* d_pairs, const float* d_emb, int32_t emb_dim,
                             const float* d_pi, int32_t pi_dim, const float* d_W1, const float* d_b1,
                             const float* d_W2, const float* d_b2, float* d_prob, void* stream);

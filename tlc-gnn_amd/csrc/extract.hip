@@ -47,7 +47,7 @@ struct XLayout {
     size_t o_pref, o_sid, o_hvy, o_hl, o_ctl, o_ucnt, o_stage, o_mt, total;
 };
 #define TLC_X_MT_BYTES ((TLC_BE_CAP / 64) * 16)      /* member table of x_sweep_ball: per 64 positions {mask u64, members below u32, pad} */
-__host__ __device__ constexpr XLayout x_layout(int nw, int sid_cap, int bw, bool fast = false) {
+__host__ __device__ __forceinline__ constexpr XLayout x_layout(int nw, int sid_cap, int bw, bool fast = false) {
     XLayout L{};
     const size_t nw4 = (size_t)((nw + 3) & ~3);
     if (fast) {
