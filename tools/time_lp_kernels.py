@@ -50,3 +50,12 @@ d = (emb[pairs[:, 0].long()] - emb[pairs[:, 1].long()]).pow(2)
 hh = torch.nn.functional.leaky_relu(torch.cat([d, pi32], 1) @ l1w.T + l1b, 0.2)
 ref = 1.0 / (torch.exp(torch.clamp((hh @ l2w.T + l2b).abs().squeeze(1), 0, 40) - 2.0) + 1.0)
 print("decode vs torch: max abs diff %.2e" % float((ref - prob2).abs().max()))
+xs = ops.SparseRows(x)
+xws = torch.empty_like(xw)
+print("sparse feature gemm (density %.3f)  %.1f us" % (xs.density, t(lambda: ops.sparse_gemm(xs, w1, out=xws))))
+ops.gemm(x, w1, out=xw)
+print("sparse vs dense product: max abs diff %.2e (max |.| %.2e)" % (float((xw - xws).abs().max()), float(xw.abs().max())))
+for dens in (0.02, 0.05, 0.2, 0.3):
+    xd = x * 0 + (torch.rand(x.shape, device="cuda") < dens).float() * torch.rand(x.shape, device="cuda")
+    xsd = ops.SparseRows(xd)
+    print("  density %.2f: sparse %.1f us" % (xsd.density, t(lambda: ops.sparse_gemm(xsd, w1, out=xws))))
