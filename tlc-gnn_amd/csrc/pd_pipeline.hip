@@ -2486,7 +2486,10 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             // the whole CU: no SMALL workgroup beside the wavefront that carries the batch's longest serial chain
             // (bit 0: this kernel, bit 1: the divide-and-conquer kernel behind it.  The latter no longer does: with 107 of 160 KB a
             // TINY workgroup fits beside it, 0.838 -> 0.818 ms for the PubMed batch; development A/B: tools/gpu_large_excl.sh)
-            static const int excl = getenv("TLC_LARGE_EXCL") ? atoi(getenv("TLC_LARGE_EXCL")) : 1;
+            // Round 5: off by default.  With the divide and conquer in place a LARGE workgroup holds its CU for ~0.49 ms of a 0.53 ms
+            // pipelined batch (71 of them: 0.065 ms of the batch, profiles/r05_tier_cost_pipelined.txt); the 15 KB its 145 KB leave are
+            // room for two SMALL or one MID / swap workgroup: pipelined batch 0.526 -> 0.517 ms (two alternating runs), one batch alone equal.
+            static const int excl = getenv("TLC_LARGE_EXCL") ? atoi(getenv("TLC_LARGE_EXCL")) : 0;
             const size_t lds_bytes = (L.total > 156 * 1024 || !(excl & 1)) ? L.total : 156 * 1024;
             int rc = set_lds_limit(tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>, lds_bytes);
             if (rc) return rc;
