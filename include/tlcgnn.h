@@ -164,7 +164,7 @@ int tlc_pd_pi_algorithmic_bytes(int32_t n_nodes, const int32_t* h_rowptr, const 
  * null), *n_rows (may be null) = rows kept.  enable != 0 starts counting, 0 stops and frees the counters.
  * set_option(): the twelve switches of one handle, each exercised by a test that checks that results do not depend on it
  * (tests/test_gpu_extract.py, tests/test_gpu_tiers.py, tests/test_gpu_pd_parity.py); 1 = on is the default of the first six:
- *   "extract"      ball-list extraction of the vicinities at hop <= 2 (0: the breadth-first kernels; TLC_EXTRACT=0 at creation)
+ *   "extract"      ball-list extraction of the vicinities (any hop since round 5; 0: the breadth-first kernels; TLC_EXTRACT=0 at creation)
  *   "heavy"        its hub-row skipping (TLC_HEAVY=0)
  *   "tiny"         lane-per-subgraph kernel for vicinities of at most 16 nodes / 24 edges (TLC_TINY=0)
  *   "ball_edges"   vicinities of pairs whose smaller ball has <= 128 nodes from that ball's subgraph list (TLC_BALL_EDGES=0)

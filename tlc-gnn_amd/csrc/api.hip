@@ -179,7 +179,7 @@ struct tlc_graph {
     hipEvent_t* ev_t;              // the current set
     unsigned char* ev_used;
     int last_n_pairs;
-    // tlc_extract_kernel (extract.hip, hop <= 2): ball lists of one hop value (built on first use), the heavy set (fixed)
+    // tlc_extract_kernel (extract.hip): ball lists of one hop value (built on first use), the heavy set (fixed)
     int ball_list_hop;             // 0: none yet; -1: lists do not fit (the breadth-first kernels are used)
     int* d_bptr;
     int* d_bcol;
@@ -757,17 +757,19 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     const bool bump = true;
     unsigned long long* d_bump_top = reinterpret_cast<unsigned long long*>(ws->d_ctl + 20);
     int* d_bump_overflow = ws->d_ctl + 22;
-    const bool early = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges && hop <= 2 && n_pairs >= TLC_EARLY_MIN_PAIRS;
-    // hop <= 2: the extraction runs from the ball lists (extract.hip); hop >= 3: the breadth-first kernels.  (Round 4: also with the
+    // The extraction runs from the ball lists (extract.hip); rounds 3 - 4: hop <= 2 only.  (Round 4: also with the
     // id / f / edge outputs of tlc_vicinity_filtration and with TLC_INCLUDE_ROOTS, the PDGNN fork's vicinities -- the breadth-first
     // COUNT pays two bitmaps of N bits per pair whatever the vicinity's size: 0.18 - 0.25 ms of a 0.37 ms call on 4 096 Amazon-shaped
     // pairs at hop 1.)
     // (its member bitmap of N bits lives in LDS: a graph beyond ~1 M nodes keeps the breadth-first kernels, whose bitmaps are in HBM)
-    bool use_x = hop <= 2 && g->opt_extract && g->x_lds512 <= (size_t)160 * 1024 && g->x_lds64 <= (size_t)160 * 1024;
+    // (round 5: any hop -- the ball lists of hop >= 3 come from breadth-first levels; three bitmaps of N bits must fit the LDS then)
+    bool use_x = g->opt_extract && g->x_lds512 <= (size_t)160 * 1024 && g->x_lds64 <= (size_t)160 * 1024 &&
+                 (hop <= 2 || (size_t)g->nw * 12 + 16 <= (size_t)160 * 1024);
     if (use_x) {
         if ((rc = ensure_ball_lists(g, hop, s)) != TLC_OK) return rc;
         use_x = g->ball_list_hop == hop;
     }
+    const bool early = pi_enabled && !d_out_ids && !d_out_f && !d_out_edges && (hop <= 2 || use_x) && n_pairs >= TLC_EARLY_MIN_PAIRS;
     // (2 048 .. 6 400 extraction workgroups measured within 2 %: one per scratch slot)
     const int xgrid = std::min(n_pairs, g->vic_slots);
     // The pairs whose vicinity is a filter over the smaller ball's subgraph list (extract.hip, x_sweep_ball: smaller ball <= 128

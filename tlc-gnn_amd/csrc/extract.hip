@@ -1,8 +1,8 @@
-// extract.hip -- P4 of the hot path for hop <= 2 (the only values the reference uses, TLCGNN.py:102), second form:
+// extract.hip -- P4 of the hot path (hop <= 2 are the only values the reference uses, TLCGNN.py:102; round 5: any hop), second form:
 // S = ball(u) & ball(v) from PRECOMPUTED BALL LISTS, the induced subgraph in one sweep that skips hub rows.
 //
 // Replaces sg2dgm_accelerate's BFS + set intersection + graph.subgraph (sg2dgm/riccidist2dgm.py:311-316), like
-// vicinity.hip (which stays for hop >= 3, the FILL pass of the heavy tiers and the variant entry points).
+// vicinity.hip (which stays as the `extract` = 0 path, for graphs whose bitmaps do not fit the LDS, the FILL pass of the heavy tiers and the variant entry points).
 //
 // What the per-phase counters of the first form said (PubMed-shaped batch, 37 676 pairs): 28 % of COUNT is the two
 // breadth-first searches, 70 % the two sweeps over the CSR rows of the members of S -- and 80 % of the entries those
@@ -1140,7 +1140,7 @@ int tlc_launch_classify(int n_pairs, const int* pairs, int n_nodes, const int* b
     return TLC_OK;
 }
 
-// ---- the ball lists: ball_hop(x) for every node, hop <= 2, ascending ids, x itself included ---------------------------------
+// ---- the ball lists: ball_hop(x) for every node, ascending ids, x itself included ------------------------------------------------
 // One wavefront per node (grid-stride): x, its row and (hop 2) the rows of its neighbours are marked in an LDS bitmap;
 // COUNT stores the population, FILL the ids from bptr[x] on.  One-off per (graph, hop).
 template <bool FILL>
@@ -1152,16 +1152,47 @@ __global__ __launch_bounds__(64) void tlc_ball_list_kernel(int n_nodes, int nw, 
     const int w0 = lane * wpl < nw ? lane * wpl : nw, w1 = (w0 + wpl) < nw ? (w0 + wpl) : nw;
     for (int w = w0; w < w1; ++w) bbits[w] = 0u;
     __syncthreads();
+    // hop >= 3 (round 5; not a value the reference's configurations use): breadth-first levels over two more bitmaps behind the first
+    unsigned* cur = bbits + nw;
+    unsigned* nxt = cur + nw;
+    if (hop >= 3) {
+        for (int w = w0; w < w1; ++w) { cur[w] = 0u; nxt[w] = 0u; }
+        __syncthreads();
+    }
     for (int x = blockIdx.x; x < n_nodes; x += gridDim.x) {
         const int rb = rowptr[x], re = rowptr[x + 1];
         if (lane == 0) atomicOr(&bbits[x >> 5], 1u << (x & 31));
-        for (int j = rb + lane; j < re; j += TLC_WAVE) {
-            const int a = col[j];
-            atomicOr(&bbits[a >> 5], 1u << (a & 31));
-            if (hop >= 2) {
-                const int ab = rowptr[a], ae = rowptr[a + 1];
-                for (int t = ab; t < ae; ++t) { const int c = col[t]; atomicOr(&bbits[c >> 5], 1u << (c & 31)); }
+        if (hop <= 2) {
+            for (int j = rb + lane; j < re; j += TLC_WAVE) {
+                const int a = col[j];
+                atomicOr(&bbits[a >> 5], 1u << (a & 31));
+                if (hop >= 2) {
+                    const int ab = rowptr[a], ae = rowptr[a + 1];
+                    for (int t = ab; t < ae; ++t) { const int c = col[t]; atomicOr(&bbits[c >> 5], 1u << (c & 31)); }
+                }
             }
+        } else {
+            if (lane == 0) cur[x >> 5] = 1u << (x & 31);
+            __syncthreads();
+            for (int h = 0; h < hop; ++h) {
+                // every lane walks the frontier members in its words; a node enters the next frontier when its visited bit was clear
+                for (int w = w0; w < w1; ++w) {
+                    unsigned f = cur[w];
+                    while (f) {
+                        const int a = (w << 5) + __builtin_ctz(f);
+                        f &= f - 1;
+                        for (int t = rowptr[a], te = rowptr[a + 1]; t < te; ++t) {
+                            const int c = col[t];
+                            const unsigned bit = 1u << (c & 31);
+                            if (!(atomicOr(&bbits[c >> 5], bit) & bit)) atomicOr(&nxt[c >> 5], bit);
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int w = w0; w < w1; ++w) { cur[w] = nxt[w]; nxt[w] = 0u; }
+                __syncthreads();
+            }
+            for (int w = w0; w < w1; ++w) cur[w] = 0u;
         }
         __syncthreads();
         int cnt = 0;
@@ -1257,7 +1288,8 @@ int tlc_launch_ball_edges(bool fill, int n_nodes, int nw, const int* rowptr, con
 int tlc_launch_ball_list(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, int hop, int* bsize, const int* bptr,
                          int* bcol, int grid, void* stream) {
     if (n_nodes <= 0) return TLC_OK;
-    const size_t lds = (size_t)nw * 4 + 16;
+    const size_t lds = (size_t)(hop >= 3 ? 3 : 1) * nw * 4 + 16;
+    if (lds > (size_t)160 * 1024) { tlc_set_error("ball lists: %zu B of LDS bitmaps", lds); return TLC_ERR_UNSUPPORTED; }
     if (fill) {
         if (lds > 64 * 1024) TLC_HIP_CHECK(hipFuncSetAttribute((const void*)tlc_ball_list_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((tlc_ball_list_kernel<true>), dim3(grid), dim3(64), lds, (hipStream_t)stream, n_nodes, nw, rowptr, col, hop, bsize, bptr, bcol);

@@ -141,7 +141,7 @@ struct TlcVicParams {
     double* small_lw;
     unsigned long long* dbg;   // PHASE_DEBUG builds: per-phase cycle sums of the COUNT pass (null otherwise)
     unsigned long long* dbg_pair_t;   // PAIR_TIMES builds: [n_pairs][16] wall-clock stamps (100 MHz) along a pair's way through tlc_extract_kernel
-    // ---- tlc_extract_kernel (extract.hip; hop <= 2): precomputed structure of the graph ---------------------------------------
+    // ---- tlc_extract_kernel (extract.hip): precomputed structure of the graph ---------------------------------------
     const int* bptr;            // [n_nodes + 1] ball lists: ball_hop(x) = bcol[bptr[x] .. bptr[x+1]), ascending ids, x included
     const int* bcol;
     const TlcNodeRec* nrec;     // [n_nodes] node records; hidx = index of a HEAVY node (one of the hh_k highest degrees >= 32) or -1

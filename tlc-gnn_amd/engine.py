@@ -83,7 +83,7 @@ class DeviceGraph:
 
     # ---- diagnostics (tests, A/B timing) --------------------------------------------------------------------------
     def set_option(self, name, value):
-        """'extract' (ball-list extraction, hop <= 2) / 'heavy' (its hub-row skipping) / 'tiny' (lane-per-subgraph kernel):
+        """'extract' (ball-list extraction) / 'heavy' (its hub-row skipping) / 'tiny' (lane-per-subgraph kernel):
         1 on (default), 0 off.  Results do not depend on them (tests/test_gpu_extract.py)."""
         _lib.check(_lib.lib().tlc_debug_set_option(self._h, name.encode(), C.c_int(int(value))), "tlc_debug_set_option")
 
