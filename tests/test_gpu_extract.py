@@ -405,3 +405,53 @@ def test_subgraph_list_extraction_equals_the_row_sweep(shape, scale, hop, n_pos)
     assert np.array_equal(new[1], rst)
     nz = ref != 0
     assert np.array_equal(new[0] == 0, ref == 0) and rel_err(new[0][nz], ref[nz]).max() < 1e-8
+
+
+def test_pairs_at_the_early_candidate_boundary_have_one_owner():
+    """Round 5: with subgraph lists up to 512-node balls, a pair whose smaller ball has 511 or 512 nodes is served by a list AND is a
+    candidate of the early pass (smaller ball >= 511).  The subgraph-list launch runs beside the classification, so it must leave every
+    such pair alone (TlcVicParams::early_min_ball): before, both launches extracted it and wrote its header (equal sizes, two arena copies
+    -- rows came out right whichever copy the tier kernel read, but a pair has one owner).  Hubs whose hop-1 balls have 509 .. 514 nodes, each paired with a larger hub, in batches large enough for
+    the early pass, stream-ordered and pipelined, against the breadth-first kernels and the oracle."""
+    import torch
+    from tlc_gnn_amd import engine, synth
+    from oracle import oracle
+    rs = np.random.RandomState(21)
+    n_leaf, sizes, copies = 700, (509, 510, 511, 512, 513, 514), 6
+    edges, pairs, base = [], [], 0
+    for c in range(copies):
+        H = base
+        hubs = [base + 1 + k for k in range(len(sizes))]
+        leaves = np.arange(base + 1 + len(sizes), base + 1 + len(sizes) + n_leaf)
+        edges += [[H, int(x)] for x in leaves] + [[H, h] for h in hubs]
+        for h, sz in zip(hubs, sizes):
+            edges += [[h, int(x)] for x in leaves[:sz - 2]]            # ball_1(h) = h + H + (sz - 2) leaves = sz nodes
+            pairs.append([h, H])
+        pairs += [[int(x), H] for x in leaves]
+        base += 1 + len(sizes) + n_leaf
+    e = np.array(edges, dtype=np.int64)
+    rowptr, col, w = synth.edges_to_csr(base, e, rs.uniform(-0.5, 0.9, size=len(e)))
+    pairs = np.array(pairs, dtype=np.int32)[rs.permutation(len(pairs))]
+    assert len(pairs) >= 4096
+    deg = np.diff(rowptr)
+    assert sorted(set((deg[pairs[:, 0]] + 1).tolist()) & set(sizes)) == list(sizes)
+    g = engine.DeviceGraph(rowptr, col, w)
+    dev = torch.as_tensor(pairs).cuda()
+    want, want_st = g.pd_pi_batch(dev, 1)
+    ref, rst, _ = oracle.pd_pi_batch(rowptr, col, w, pairs, 1, n_threads=0)
+    assert np.array_equal(want_st.cpu().numpy(), rst)
+    nz = ref != 0
+    assert np.array_equal(want.cpu().numpy() == 0, ref == 0) and rel_err(want.cpu().numpy()[nz], ref[nz]).max() < 1e-8
+    outs = [torch.empty_like(want) for _ in range(3)]
+    sts = [torch.empty_like(want_st) for _ in range(3)]
+    for rnd in range(4):
+        for k in range(3):
+            g.pd_pi_batch(dev, 1, out=outs[k], status=sts[k], async_=True)
+        g.join()
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert torch.equal(outs[k], want) and torch.equal(sts[k], want_st), (rnd, k)
+    g.set_option("extract", 0)
+    old, old_st = g.pd_pi_batch(dev, 1)
+    assert torch.equal(old_st, want_st) and float((old - want).abs().max()) <= 1e-12
+    g.close()

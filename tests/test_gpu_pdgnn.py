@@ -567,3 +567,64 @@ def test_one_call_forward_equals_the_layer_by_layer_forward():
                 assert g32.dtype == torch.float32 and torch.equal(g32, want[1].to(torch.float32)), (name, held)
     # a forward that wants gradients does not take the one-call path
     assert not model._one_call_ok(x.clone().requires_grad_(True), None) and not model.train()._one_call_ok(x, None)
+
+
+def test_batch_structure_entry_points_edge_cases():
+    """Round 5's per-batch structure steps on their own: tlc_csr_by_target == the structure tlc_gcn_norm_csr builds (existing self loops
+    and duplicate-free rows, sources ascending), with no loop at all and with every loop present; tlc_gat_tile_cut on node counts around
+    the bitmap's word boundaries, with isolated nodes and with an empty edge list; tlc_stack_batch with empty vicinities inside the batch;
+    tlc_pdgnn_forward refuses a hidden size it is not built for and a workspace that is too small."""
+    import ctypes as C
+    import torch
+    from tlc_gnn_amd import ops, engine, _lib
+    dev = torch.device("cuda")
+    rs = np.random.RandomState(12)
+    # csr_by_target against gcn_norm_csr
+    for n, m, loops in ((50, 200, 0), (9000, 30000, 1), (300, 1, 2)):
+        e = rs.randint(0, n, size=(m, 2))
+        e = np.unique(e[e[:, 0] != e[:, 1]], axis=0)
+        if loops == 1:
+            e = np.concatenate([e, np.stack([np.arange(0, n, 3)] * 2, 1)])
+        if loops == 2:
+            e = np.concatenate([e, np.stack([np.arange(n)] * 2, 1)])
+        ei = torch.from_numpy(e.T.copy()).to(dev)
+        rp1, col1, _ = ops.gcn_norm_csr(ei, n)
+        rp2, col2 = ops.csr_by_target(ei, n)
+        assert torch.equal(rp1, rp2) and torch.equal(col1, col2[:int(rp2[-1])]), (n, m, loops)
+    # tile cut: paths of k nodes laid end to end; node counts around multiples of 32 and 192
+    for n_graphs, k in ((1, 31), (1, 32), (1, 33), (7, 27), (40, 24), (5, 96), (300, 13)):
+        n = n_graphs * k + 3                                        # three isolated nodes at the end
+        src = np.concatenate([np.arange(g * k, g * k + k - 1) for g in range(n_graphs)])
+        ei = torch.from_numpy(np.stack([src, src + 1])).to(dev)
+        rp, col = ops.csr_by_target(ei, n)
+        tiles = ops.gat_tiles(rp, col, n)
+        assert tiles is not None, (n_graphs, k)
+        t = tiles.cpu().numpy()
+        assert t[0] == 0 and t[-1] == n and (np.diff(t) > 0).all() and np.diff(t).max() <= 192
+        inner = t[1:-1]
+        assert ((inner % k == 0) | (inner >= n_graphs * k)).all(), (n_graphs, k, t)      # cuts only between graphs / isolated nodes
+    rp, col = ops.csr_by_target(torch.zeros((2, 0), dtype=torch.int64, device=dev), 500)   # no edge at all: self loops only
+    t = ops.gat_tiles(rp, col, 500).cpu().numpy()
+    assert t[0] == 0 and t[-1] == 500 and np.diff(t).max() <= 192
+    # stack_batch with empty vicinities
+    node_ptr = torch.tensor([0, 3, 3, 7, 7], dtype=torch.int64, device=dev)
+    edge_ptr = torch.tensor([0, 2, 2, 5, 5], dtype=torch.int64, device=dev)
+    edges = torch.tensor([[0, 1], [1, 2], [0, 3], [1, 2], [2, 3]], dtype=torch.int32, device=dev)
+    f = torch.arange(7, dtype=torch.float64, device=dev) * 0.25
+    ei, x = engine.stack_batch(node_ptr, edge_ptr, edges, f)
+    want = torch.tensor([[0, 1, 3, 4, 5] + list(range(7)), [1, 2, 6, 5, 6] + list(range(7))], dtype=torch.int64, device=dev)
+    assert torch.equal(ei, want) and torch.equal(x.view(-1), f.float())
+    # the one-call forward's argument checks
+    L = _lib.lib()
+    nbytes = int(L.tlc_pdgnn_forward_work_bytes(C.c_int32(7), C.c_int64(12), C.c_int32(32)))
+    assert nbytes > 0 and int(L.tlc_pdgnn_forward_work_bytes(C.c_int32(7), C.c_int64(3), C.c_int32(32))) < 0
+    ps = [torch.zeros(64, device=dev) for _ in range(20)]
+    with pytest.raises(_lib.TlcError):
+        ops.pdgnn_forward(x, ei, ps, edge_ptr, hidden=64)
+    work = torch.empty(16, dtype=torch.uint8, device=dev)
+    pts = torch.empty((5, 2), dtype=torch.float32, device=dev)
+    img = torch.empty((4, 25), dtype=torch.float64, device=dev)
+    arr = (C.c_void_p * 20)(*[p.data_ptr() for p in ps])
+    rc = L.tlc_pdgnn_forward(C.c_int32(7), C.c_int64(12), _lib.ptr(ei), _lib.ptr(x), C.c_int32(32), arr, C.c_int64(4), _lib.ptr(edge_ptr), C.c_int32(5),
+                             None, None, None, C.c_int32(0), _lib.ptr(work), C.c_int64(16), _lib.ptr(pts), _lib.ptr(img), _lib.stream_ptr())
+    assert rc != 0

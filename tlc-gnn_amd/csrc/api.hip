@@ -809,6 +809,8 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         TLC_HIP_CHECK(hipEventRecord(ws->ev_fork, s));                  // after the memsets (and the one-off bounds)
         TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[4], ws->ev_fork, 0));
     }
+    // (the early pass's candidates -- smaller ball >= 511 nodes -- are not the subgraph-list launch's, in either extraction launch)
+    vp.early_min_ball = (early && use_x) ? TLC_M_NMAX - 1 : 0;
     if (fsplit) {
         TlcVicParams fp = vp;                                 // (no bins, no early list, no work counter: every pair by index, statically strided)
         fp.region_base_wg = xgrid + TLC_EARLY_WG;

@@ -564,7 +564,9 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
     int be0 = 0, be1 = 0;
     bool fast = false;
     if constexpr (BW == 64) {
-        if (p.be_ptr && nB <= TLC_BE_CAP && !(p.flags & TLC_INCLUDE_ROOTS)) {
+        // (not a candidate of the early pass: with lists up to 512 nodes a smaller ball of 511 or 512 nodes is both -- the FAST launch runs
+        // beside the classification and cannot wait for its verdict, so it leaves every such pair to the early pass / the general launch)
+        if (p.be_ptr && nB <= TLC_BE_CAP && !(p.flags & TLC_INCLUDE_ROOTS) && !(p.early_min_ball > 0 && nB >= p.early_min_ball)) {
             const bool b_is_u = (H.a1 - H.a0) < (H.b1 - H.b0);
             be0 = b_is_u ? H.eu0 : H.ev0; be1 = b_is_u ? H.eu1 : H.ev1;
             fast = true;

@@ -170,6 +170,8 @@ struct TlcVicParams {
     const unsigned* be_pos;
     const double* be_w;
     int fast_split;             // 1: a launch of tlc_extract_kernel<64, true> takes the pairs the subgraph lists serve; this one leaves them alone
+    int early_min_ball;   // > 0: the early pass owns the pairs whose smaller ball has at least this many nodes (tlc_classify_kernel's candidates):
+                          // the subgraph-list launch leaves them alone
 };
 #define TLC_BE_CAP 512
 #define TLC_BE_REG_CAP 128       /* up to here the member masks of a pair stay in registers (two ballots); above: a table in LDS */
