@@ -222,10 +222,13 @@ __global__ void edge_head_pack_kernel(int c, int hidden, const float* __restrict
     const int k = t / (2 * hidden), j = t - k * 2 * hidden;
     Bt[t] = j < hidden ? W5[(size_t)j * 2 * c + k] : W5[(size_t)(j - hidden) * 2 * c + c + k];
 }
-__global__ __launch_bounds__(256) void edge_head_gather_kernel(long long n_edges, const int* __restrict__ src, const int* __restrict__ dst,
+// IT: int (tlc_edge_head_fwd) or long long (tlc_pdgnn_forward reads the caller's int64 edge_index as it lies); pd64 (may be null): the
+// points once more as float64, what tlc_pi_raster takes -- a conversion launch of their own cost 12.6 + 10.5 us of a 1.09 ms forward
+template <typename IT>
+__global__ __launch_bounds__(256) void edge_head_gather_kernel(long long n_edges, const IT* __restrict__ src, const IT* __restrict__ dst,
                                                                const float* __restrict__ UV, int hidden, const float* __restrict__ b5,
                                                                float slope, const float* __restrict__ W6, const float* __restrict__ b6,
-                                                               float* __restrict__ pd) {
+                                                               float* __restrict__ pd, double* __restrict__ pd64) {
     extern __shared__ float sm[];                                      // [b5 (hidden) | W6 (2*hidden)]
     for (int t = threadIdx.x; t < hidden; t += 256) sm[t] = b5[t];
     for (int t = threadIdx.x; t < 2 * hidden; t += 256) sm[hidden + t] = W6[t];
@@ -249,6 +252,44 @@ __global__ __launch_bounds__(256) void edge_head_gather_kernel(long long n_edges
     }
     pd[2 * e] = o0;
     pd[2 * e + 1] = o1;
+    if (pd64) { pd64[2 * e] = (double)o0; pd64[2 * e + 1] = (double)o1; }
+}
+
+// The same with hidden / 4 lanes per edge (hidden = 8, 16, 32, 64): a lane loads ONE float4 of U[src] and of V[dst] -- the edge's two
+// rows are two coalesced 4 * hidden-byte reads instead of 2 * hidden / 4 sixteen-byte reads of one lane (a wavefront touched 64 x 2
+// separate rows per instruction: 90 - 104 us for the million edges of 41 127 molecules) --, its four hidden units, and the two output
+// sums are folded over the lanes of the edge.
+template <typename IT, int LPE>
+__global__ __launch_bounds__(256) void edge_head_gather_lanes_kernel(long long n_edges, const IT* __restrict__ src, const IT* __restrict__ dst,
+                                                                     const float* __restrict__ UV, const float* __restrict__ b5, float slope,
+                                                                     const float* __restrict__ W6, const float* __restrict__ b6,
+                                                                     float* __restrict__ pd, double* __restrict__ pd64) {
+    constexpr int hidden = 4 * LPE;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long e = t / LPE;
+    const int q = (int)(t % LPE);
+    if (e >= n_edges) return;                                          // (256 is a multiple of LPE: an edge's lanes leave together)
+    const float4 a = reinterpret_cast<const float4*>(UV + (size_t)src[e] * 2 * hidden)[q];
+    const float4 b = reinterpret_cast<const float4*>(UV + (size_t)dst[e] * 2 * hidden + hidden)[q];
+    const float4 bb = reinterpret_cast<const float4*>(b5)[q];
+    const float4 w0 = reinterpret_cast<const float4*>(W6)[q], w1 = reinterpret_cast<const float4*>(W6 + hidden)[q];
+    float v[4] = {a.x + b.x + bb.x, a.y + b.y + bb.y, a.z + b.z + bb.z, a.w + b.w + bb.w};
+    const float ww0[4] = {w0.x, w0.y, w0.z, w0.w}, ww1[4] = {w1.x, w1.y, w1.z, w1.w};
+    float o0 = 0.0f, o1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x = v[j] > 0.0f ? v[j] : slope * v[j];             // F.prelu(x, 0.1) (Teacher_model.py:57)
+        o0 += ww0[j] * x;
+        o1 += ww1[j] * x;
+    }
+#pragma unroll
+    for (int o = LPE / 2; o; o >>= 1) { o0 += __shfl_xor(o0, o); o1 += __shfl_xor(o1, o); }
+    if (q == 0) {
+        o0 += b6[0]; o1 += b6[1];
+        pd[2 * e] = o0;
+        pd[2 * e + 1] = o1;
+        if (pd64) { pd64[2 * e] = (double)o0; pd64[2 * e + 1] = (double)o1; }
+    }
 }
 
 // weights of one layer packed for the MFMA GEMM path: Bt1[k][c] = Wl[c][k]  (c_in x C);  Bt2[k][j] (C x (2C+4), rows a multiple
@@ -666,9 +707,10 @@ extern "C" int tlc_gat_layer_fwd(int32_t n_nodes, const int32_t* d_rowptr, const
     }
 }
 
-extern "C" int tlc_edge_head_fwd(int64_t n_edges, const int32_t* d_src, const int32_t* d_dst, const float* d_X, int32_t c,
-                                 const float* d_W5, const float* d_b5, int32_t hidden, float prelu_slope, const float* d_W6,
-                                 const float* d_b6, float* d_pd, int32_t n_nodes, float* d_work, void* stream) {
+template <typename IT>
+static int edge_head_fwd_impl(int64_t n_edges, const IT* d_src, const IT* d_dst, const float* d_X, int32_t c, const float* d_W5, const float* d_b5,
+                              int32_t hidden, float prelu_slope, const float* d_W6, const float* d_b6, float* d_pd, double* d_pd64, int32_t n_nodes,
+                              float* d_work, void* stream) {
     TLC_REQUIRE(n_edges >= 0 && c > 0 && hidden > 0, "bad sizes");
     if (n_edges == 0) return TLC_OK;
     TLC_REQUIRE(d_src && d_dst && d_X && d_W5 && d_b5 && d_W6 && d_b6 && d_pd, "null pointer");
@@ -681,18 +723,47 @@ extern "C" int tlc_edge_head_fwd(int64_t n_edges, const int32_t* d_src, const in
         TLC_HIP_CHECK(hipGetLastError());
         int rc = tlc_gemm_f32(n_nodes, 2 * hidden, c, d_X, d_Bt, nullptr, 0, d_UV, stream);
         if (rc != TLC_OK) return rc;
-        hipLaunchKernelGGL(edge_head_gather_kernel, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 3 * (size_t)hidden * sizeof(float),
-                           (hipStream_t)stream, (long long)n_edges, d_src, d_dst, (const float*)d_UV, hidden, d_b5, prelu_slope, d_W6,
-                           d_b6, d_pd);
+        const bool al16 = ((reinterpret_cast<uintptr_t>(d_b5) | reinterpret_cast<uintptr_t>(d_W6) | reinterpret_cast<uintptr_t>(d_UV)) & 15) == 0;
+#define TLC_EH_LANES(LPE_)                                                                                                                   \
+    hipLaunchKernelGGL((edge_head_gather_lanes_kernel<IT, LPE_>), dim3((unsigned)((n_edges * LPE_ + 255) / 256)), dim3(256), 0, (hipStream_t)stream, \
+                       (long long)n_edges, d_src, d_dst, (const float*)d_UV, d_b5, prelu_slope, d_W6, d_b6, d_pd, d_pd64)
+        if (al16 && hidden == 32) TLC_EH_LANES(8);
+        else if (al16 && hidden == 64) TLC_EH_LANES(16);
+        else if (al16 && hidden == 16) TLC_EH_LANES(4);
+        else if (al16 && hidden == 8) TLC_EH_LANES(2);
+        else
+            hipLaunchKernelGGL(edge_head_gather_kernel<IT>, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 3 * (size_t)hidden * sizeof(float),
+                               (hipStream_t)stream, (long long)n_edges, d_src, d_dst, (const float*)d_UV, hidden, d_b5, prelu_slope, d_W6,
+                               d_b6, d_pd, d_pd64);
+#undef TLC_EH_LANES
         TLC_HIP_CHECK(hipGetLastError());
         return TLC_OK;
     }
-    const size_t lds = ((size_t)hidden * 2 * c + 2 * (size_t)hidden) * sizeof(float);
-    TLC_REQUIRE(lds <= 64 * 1024, "edge head weights do not fit LDS");
-    hipLaunchKernelGGL(edge_head_kernel, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), lds, (hipStream_t)stream,
-                       (long long)n_edges, d_src, d_dst, d_X, c, d_W5, d_b5, hidden, prelu_slope, d_W6, d_b6, d_pd);
-    TLC_HIP_CHECK(hipGetLastError());
-    return TLC_OK;
+    if constexpr (std::is_same<IT, int>::value) {
+        if (!d_pd64) {
+            const size_t lds = ((size_t)hidden * 2 * c + 2 * (size_t)hidden) * sizeof(float);
+            TLC_REQUIRE(lds <= 64 * 1024, "edge head weights do not fit LDS");
+            hipLaunchKernelGGL(edge_head_kernel, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), lds, (hipStream_t)stream,
+                               (long long)n_edges, d_src, d_dst, d_X, c, d_W5, d_b5, hidden, prelu_slope, d_W6, d_b6, d_pd);
+            TLC_HIP_CHECK(hipGetLastError());
+            return TLC_OK;
+        }
+    }
+    tlc_set_error("edge head: this form needs the per-node scratch (hidden a multiple of 4, at most 64)");
+    return TLC_ERR_UNSUPPORTED;
+}
+
+extern "C" int tlc_edge_head_fwd(int64_t n_edges, const int32_t* d_src, const int32_t* d_dst, const float* d_X, int32_t c,
+                                 const float* d_W5, const float* d_b5, int32_t hidden, float prelu_slope, const float* d_W6,
+                                 const float* d_b6, float* d_pd, int32_t n_nodes, float* d_work, void* stream) {
+    return edge_head_fwd_impl<int>(n_edges, d_src, d_dst, d_X, c, d_W5, d_b5, hidden, prelu_slope, d_W6, d_b6, d_pd, nullptr, n_nodes, d_work, stream);
+}
+// (gat_internal.h) the head over an int64 edge_index [2][width] as it lies (sources in the first row, targets in the second), the
+// points also as float64
+int tlc_edge_head_fwd_i64(int64_t n_edges, const long long* d_src, const long long* d_dst, const float* d_X, int c, const float* d_W5, const float* d_b5,
+                          int hidden, float prelu_slope, const float* d_W6, const float* d_b6, float* d_pd, double* d_pd64, int n_nodes, float* d_work,
+                          hipStream_t stream) {
+    return edge_head_fwd_impl<long long>(n_edges, d_src, d_dst, d_X, c, d_W5, d_b5, hidden, prelu_slope, d_W6, d_b6, d_pd, d_pd64, n_nodes, d_work, (void*)stream);
 }
 
 // One PDGNN layer on a block-diagonal batch cut into self-contained tiles (see gat_tile_kernel): d_tile_ptr int32[n_tiles + 1], node
@@ -721,10 +792,12 @@ extern "C" int tlc_gat_layer_tiled_fwd(int32_t n_nodes, const int32_t* d_rowptr,
 // layers used before was a launch per layer behind a packing launch per layer).
 namespace {
 struct GatPrepArgs { TlcGatPrepLayer l[TLC_GAT_PREP_MAX]; };
+constexpr int GAT_PREP_SPLIT = 8;                              // workgroups per layer (one: 19.6 us in front of the first layer)
 __global__ __launch_bounds__(256) void gat_tiled_prep_kernel(GatPrepArgs a) {
     __shared__ float sWl[32 * 64];                             // [C][c_in], as stored
     __shared__ float sB2[32 * 68];                             // [C][2C + 4] = [Wij_t^T | Wij_s^T | att | 0 0 0]
-    const TlcGatPrepLayer L = a.l[blockIdx.x];
+    const TlcGatPrepLayer L = a.l[blockIdx.x / GAT_PREP_SPLIT];
+    const int part = blockIdx.x % GAT_PREP_SPLIT;
     const int C = L.c_out, N2 = 2 * C + 4, c_in = L.c_in;
     for (int t = threadIdx.x; t < C * c_in; t += 256) sWl[t] = L.Wl[t];
     for (int t = threadIdx.x; t < C * N2; t += 256) {
@@ -733,7 +806,7 @@ __global__ __launch_bounds__(256) void gat_tiled_prep_kernel(GatPrepArgs a) {
     }
     __syncthreads();
     const int total = c_in == 1 ? 2 * C + 1 : c_in * N2;
-    for (int t = threadIdx.x; t < total; t += 256) {
+    for (int t = part * 256 + threadIdx.x; t < total; t += 256 * GAT_PREP_SPLIT) {
         const int k = t / N2, j = t - k * N2;                 // (c_in == 1: k = 0, j = t)
         float acc = 0.0f;
         for (int c = 0; c < C; ++c) acc += sWl[c * c_in + k] * sB2[c * N2 + j];
@@ -750,7 +823,7 @@ int tlc_gat_tiled_prepare(int n_layers, const TlcGatPrepLayer* layers, hipStream
         TLC_REQUIRE(L.Wl && L.att && L.Wij && L.prep, "null pointer");
         a.l[i] = L;
     }
-    hipLaunchKernelGGL(gat_tiled_prep_kernel, dim3(n_layers), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gat_tiled_prep_kernel, dim3(n_layers * GAT_PREP_SPLIT), dim3(256), 0, s, a);
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }

@@ -15,20 +15,10 @@
 #include "gat_internal.h"
 
 namespace {
-__global__ void pdgnn_edge_ends_kernel(long long m, long long width, const long long* __restrict__ ei, int* __restrict__ src, int* __restrict__ dst) {
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    src[j] = (int)ei[j];
-    dst[j] = (int)ei[width + j];
-}
-__global__ void pdgnn_widen_kernel(long long n, const float* __restrict__ a, double* __restrict__ b) {
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) b[j] = (double)a[j];
-}
 inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct PdgnnWork {
-    size_t rowptr, col, nnz, csr_tmp, cut_work, tiles, src, dst, h0, h1, layer, prep, head, pts, total;
+    size_t rowptr, col, nnz, csr_tmp, cut_work, tiles, h0, h1, layer, prep, head, pts, total;
     PdgnnWork(long long n, long long E, int hidden, int tile_nodes) {
         const long long m = E - n, C = hidden, N2 = 2 * C + 4, cin = 2 * C;
         size_t o = 0;
@@ -39,8 +29,6 @@ struct PdgnnWork {
         csr_tmp = take((size_t)(3 * n + E) * 4);
         cut_work = take((size_t)(n / 32 + 6) * 4);
         tiles = take((size_t)(2 * n / tile_nodes + 3) * 4);
-        src = take((size_t)std::max(m, 1ll) * 4);
-        dst = take((size_t)std::max(m, 1ll) * 4);
         h0 = take((size_t)n * 2 * C * 4);
         h1 = take((size_t)n * 2 * C * 4);
         const size_t tiled = (size_t)(cin * C + C * N2 + cin * N2 + 2 * C + 8), plain = (size_t)n * (3 * C + 4) + cin * C + C * (2 * C + 4);
@@ -80,18 +68,13 @@ extern "C" int tlc_pdgnn_forward(int32_t n_nodes, int64_t n_edges, const int64_t
     float* bufs[2] = {(float*)(base + w.h0), (float*)(base + w.h1)};
     float* prep = (float*)(base + w.prep);
     const size_t prep_stride = (size_t)2 * C * (2 * C + 4);
-    int *src = (int*)(base + w.src), *dst = (int*)(base + w.dst);
-    // first what needs no structure -- the combined weights of the four (tiled) layers in one launch, the edge head's int32 ends -- so
-    // that the device has work while the host waits for the tile count
+    // first what needs no structure -- the combined weights of the four (tiled) layers in one launch -- so that the device has work
+    // while the host waits for the tile count
     if (!d_rowptr || n_tiles > 0) {
         TlcGatPrepLayer pl[4];
         for (int l = 0; l < 4; ++l) pl[l] = {L[l].c_in, L[l].c_out, params[L[l].p], params[L[l].p + 1], params[L[l].p + 2], prep + l * prep_stride};
         rc = tlc_gat_tiled_prepare(4, pl, s);
         if (rc != TLC_OK) return rc;
-    }
-    if (m > 0) {
-        hipLaunchKernelGGL(pdgnn_edge_ends_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, m, (long long)n_edges, (const long long*)d_edge_index, src, dst);
-        TLC_HIP_CHECK(hipGetLastError());
     }
     // the batch's structure, unless the caller holds it (a loop over the same batch: train_Teacher_Model.py:124-151)
     const int32_t *rowptr = d_rowptr, *col = d_col, *tiles = d_tile_ptr;
@@ -118,12 +101,11 @@ extern "C" int tlc_pdgnn_forward(int32_t n_nodes, int64_t n_edges, const int64_t
         return TLC_OK;
     }
     // the edge head over the batch without its self loops (they are the LAST n columns), one image per graph
-    rc = tlc_edge_head_fwd(m, src, dst, in, C, params[16], params[17], hidden, 0.1f, params[18], params[19], d_points, n_nodes, (float*)(base + w.head), stream);
+    double* pts = n_graphs ? (double*)(base + w.pts) : nullptr;
+    rc = tlc_edge_head_fwd_i64(m, (const long long*)d_edge_index, (const long long*)d_edge_index + n_edges, in, C, params[16], params[17], hidden, 0.1f,
+                               params[18], params[19], d_points, pts, n_nodes, (float*)(base + w.head), s);
     if (rc != TLC_OK) return rc;
     if (n_graphs) {
-        double* pts = (double*)(base + w.pts);
-        hipLaunchKernelGGL(pdgnn_widen_kernel, dim3((unsigned)((2 * m + 255) / 256)), dim3(256), 0, s, 2 * m, (const float*)d_points, pts);
-        TLC_HIP_CHECK(hipGetLastError());
         rc = tlc_pi_raster((int32_t)n_graphs, d_edge_ptr, pts, res, d_img, stream);
         if (rc != TLC_OK) return rc;
     }
