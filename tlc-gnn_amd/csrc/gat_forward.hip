@@ -292,6 +292,88 @@ __global__ __launch_bounds__(256) void edge_head_gather_lanes_kernel(long long n
     }
 }
 
+// The head in ONE kernel for the PDGNN sizes (c = 32 node channels, hidden = 32; round 5): the 2c x hidden layer on the f32 MFMA with
+// the EDGES as rows -- a 16-edge tile's A operand is gathered straight from X (lane (edge r, group g) reads the sixteen contiguous
+// floats g & 1 of x[src] for g < 2, of x[dst] for g >= 2: k = 16 g + s at step s, W5 in registers in the same permuted order, as
+// gemm_skinny_f32_kernel does), 32 MFMAs per tile, then bias, PReLU, the 2 x hidden output layer and a fold over the sixteen lanes that
+// hold an edge's hidden units.  Instead of: pack W5, per-node projections U | V [n, 64] on the MFMA (131 MB read, 263 MB written for a
+// million nodes), gather of two 128-byte rows of U | V per edge -- 92 + 96 us and two launches for the 1.04 M edges of 41 127 molecules.
+typedef float eh_f32x4 __attribute__((ext_vector_type(4)));
+template <typename IT>
+__global__ __launch_bounds__(256) void edge_head_mfma_kernel(long long n_edges, const IT* __restrict__ src, const IT* __restrict__ dst,
+                                                             const float* __restrict__ X, const float* __restrict__ W5, const float* __restrict__ b5,
+                                                             float slope, const float* __restrict__ W6, const float* __restrict__ b6,
+                                                             float* __restrict__ pd, double* __restrict__ pd64) {
+    constexpr int CX = 32, H = 32, K2 = 64, KQ = 16;
+    const int lane = threadIdx.x & 63, l16 = lane & 15, g = lane >> 4;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    float b[KQ][2];
+#pragma unroll
+    for (int sidx = 0; sidx < KQ; ++sidx)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b[sidx][t] = W5[(size_t)(t * 16 + l16) * K2 + g * KQ + sidx];       // W5[h][k], k = 16 g + s
+    float bb[2], w0[2], w1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { bb[t] = b5[t * 16 + l16]; w0[t] = W6[t * 16 + l16]; w1[t] = W6[H + t * 16 + l16]; }
+    const float c0 = b6[0], c1 = b6[1];
+    const long long n_tiles = (n_edges + 15) >> 4;
+    auto node_of = [&](long long tile) -> long long {
+        long long e = tile * 16 + l16;
+        if (e >= n_edges) e = n_edges - 1;                              // (edges past the end are computed and not stored)
+        return (long long)(g < 2 ? src[e] : dst[e]);
+    };
+    auto load_tile = [&](long long node, eh_f32x4 (&a)[4]) {
+        const eh_f32x4* p = reinterpret_cast<const eh_f32x4*>(X + (size_t)node * CX + (g & 1) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = p[q];
+    };
+    eh_f32x4 a_cur[4], a_nxt[4];
+    long long tile = wave, node_nxt = 0;
+    if (tile < n_tiles) load_tile(node_of(tile), a_cur);
+    if (tile + n_waves < n_tiles) node_nxt = node_of(tile + n_waves);
+    for (; tile < n_tiles; tile += n_waves) {
+        const long long nt = tile + n_waves;
+        if (nt < n_tiles) load_tile(node_nxt, a_nxt);
+        if (nt + n_waves < n_tiles) node_nxt = node_of(nt + n_waves);
+        eh_f32x4 acc[2] = {(eh_f32x4){0.f, 0.f, 0.f, 0.f}, (eh_f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int sidx = 0; sidx < KQ; ++sidx)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[sidx >> 2][sidx & 3], b[sidx][t], acc[t], 0, 0, 0);
+        // C / D layout: column (hidden unit of tile t) = lane & 15, row (edge of the tile) = 4 * (lane >> 4) + reg
+        float o0[4], o1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o0[r] = 0.f; o1[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float v = acc[t][r] + bb[t];
+                v = v > 0.0f ? v : slope * v;                          // F.prelu(x, 0.1) (Teacher_model.py:57)
+                o0[r] += w0[t] * v;
+                o1[r] += w1[t] * v;
+            }
+        }
+#pragma unroll
+        for (int o = 8; o; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o0[r] += __shfl_xor(o0[r], o); o1[r] += __shfl_xor(o1[r], o); }
+        // lane r of the sixteen writes edge 4 g + r
+        if (l16 < 4) {
+            const long long e = tile * 16 + 4 * g + l16;
+            const float y0 = (l16 == 0 ? o0[0] : l16 == 1 ? o0[1] : l16 == 2 ? o0[2] : o0[3]) + c0;
+            const float y1 = (l16 == 0 ? o1[0] : l16 == 1 ? o1[1] : l16 == 2 ? o1[2] : o1[3]) + c1;
+            if (e < n_edges) {
+                pd[2 * e] = y0; pd[2 * e + 1] = y1;
+                if (pd64) { pd64[2 * e] = (double)y0; pd64[2 * e + 1] = (double)y1; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+    }
+}
+
 // weights of one layer packed for the MFMA GEMM path: Bt1[k][c] = Wl[c][k]  (c_in x C);  Bt2[k][j] (C x (2C+4), rows a multiple
 // of 16 bytes so that the GEMM takes its vector path): j < C: Wij[j][k] (target half), C <= j < 2C: Wij[j-C][C+k] (source
 // half), j = 2C: att[k], then zeros
@@ -714,6 +796,15 @@ static int edge_head_fwd_impl(int64_t n_edges, const IT* d_src, const IT* d_dst,
     TLC_REQUIRE(n_edges >= 0 && c > 0 && hidden > 0, "bad sizes");
     if (n_edges == 0) return TLC_OK;
     TLC_REQUIRE(d_src && d_dst && d_X && d_W5 && d_b5 && d_W6 && d_b6 && d_pd, "null pointer");
+    if (c == 32 && hidden == 32 && (reinterpret_cast<uintptr_t>(d_X) & 15) == 0) {
+        const long long tiles = (n_edges + 15) / 16;
+        long long blocks = (tiles + 3) / 4;
+        if (blocks > 256 * 4) blocks = 256 * 4;                       // persistent wavefronts: four per SIMD (98 registers)
+        hipLaunchKernelGGL(edge_head_mfma_kernel<IT>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long long)n_edges, d_src, d_dst, d_X, d_W5,
+                           d_b5, prelu_slope, d_W6, d_b6, d_pd, d_pd64);
+        TLC_HIP_CHECK(hipGetLastError());
+        return TLC_OK;
+    }
     if (d_work && n_nodes > 0 && hidden % 4 == 0 && 2 * hidden <= 128) {
         // per-node projections U | V (work[0 .. n_nodes * 2 * hidden)) on the MFMA GEMM, then the per-edge gather
         float* d_UV = d_work;
