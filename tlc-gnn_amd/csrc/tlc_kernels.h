@@ -43,8 +43,10 @@
 #define TLC_TINY_BIN_W 5
 #endif
 
+#ifndef TLC_T_NMAX               /* (overridable together: make EXTRA="-DTLC_T_NMAX=20 -DTLC_T_MMAX=32 -DTLC_TINY_BINS=8 -DTLC_TINY_BIN_W=7") */
 #define TLC_T_NMAX 16
 #define TLC_T_MMAX 24
+#endif
 /* which SMALL-tier vicinities the scan sends there (<= the kernel's capacity above; overridable for the sweep) */
 #ifndef TLC_T_NCUT
 #define TLC_T_NCUT TLC_T_NMAX
