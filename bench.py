@@ -457,8 +457,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_encoder(mode):
+    def make_encoder(mode, prob_out=None):
         box = {}
+        prob_out = prob if prob_out is None else prob_out
 
         def gemm(a, b, out=None):
             # the feature projection runs over the stored entries of the (10 % dense, never changing) feature rows, like
@@ -482,7 +483,7 @@ def main():
                 emb = ops.gcn2_encode(rowptr_n, col_n, val_n, x_local, w1, b1, w2, b2, relu=True, renorm=True, out=emb_buf)
             else:
                 emb = enc.encode(x_local, w1, b1, w2, b2, renorm=True)  # renorm_ of TLCGNN.py:48 fused into the last SpMM
-            ops.lp_decode(pairs_mapped, emb, dec_pi, l1w, l1b, l2w, l2b, out=prob)
+            ops.lp_decode(pairs_mapped, emb, dec_pi, l1w, l1b, l2w, l2b, out=prob_out)
         return leg
 
     def time_leg(fn, reps):
@@ -548,6 +549,32 @@ def main():
                     leg_lp, lp_submit = graph.replay, "hipGraph"
         except Exception as exc:                                       # (capture refused: the eager leg stays)
             lp_submit = "eager (graph capture failed: %s)" % str(exc).splitlines()[0][:120]
+            torch.cuda.synchronize()
+
+    # Beside the leg (not part of it, nothing below reads it): the same forward with TWO in flight, each on its own stream and
+    # its own buffers.  One forward is four small kernels back to back, each too short to fill 256 CUs; what two of them
+    # together take per forward says how much of the leg's time is the machine standing half empty.
+    if world == 1 and enc_mode == "replicated":
+        try:
+            prob_b = torch.empty_like(prob)
+            pair_of_legs = [legs["replicated"], make_encoder("replicated", prob_out=prob_b)]
+            lanes = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+            def two_in_flight(reps=20):
+                cur = torch.cuda.current_stream()
+                for lane in lanes:
+                    lane.wait_stream(cur)
+                for r in range(reps):
+                    with torch.cuda.stream(lanes[r & 1]):
+                        pair_of_legs[r & 1]()
+                for lane in lanes:
+                    cur.wait_stream(lane)
+            two_in_flight(4)
+            torch.cuda.synchronize()
+            if torch.equal(prob_b, prob):
+                encoder_ms["replicated, two forwards in flight (per forward)"] = time_leg(lambda: two_in_flight(20), 5) / 20
+        except Exception as exc:
+            encoder_ms["two forwards in flight"] = "failed: %s" % str(exc).splitlines()[0][:120]
             torch.cuda.synchronize()
 
     def leg_pi(step=0):

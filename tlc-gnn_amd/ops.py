@@ -165,14 +165,15 @@ _GCN2_WS = {}
 def gcn2_encode(rowptr, col, val, x, w1, b1, w2, b2, relu=True, renorm=False, out=None):
     """Net.encode in eval mode behind one library call (tlc_gcn2_encode_f32): relu(A (relu(A (x w1) + b1)) w2 + b2), rows
     renormalised when renorm=True (TLCGNN.py:19-26,48).  Same four kernels as gemm / spmm / gemm / spmm; the scratch for
-    the intermediates is kept per (device, sizes)."""
+    the intermediates is kept per (device, stream, sizes): two forwards in flight on two streams do not share it."""
     torch = _lib.require_gpu()
     x, w1, w2 = _f32(x), _f32(w1), _f32(w2)
     n, f_in, hidden, d = x.shape[0], x.shape[1], w1.shape[1], w2.shape[1]
-    key = (x.device, n, hidden, d)
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream, n, hidden, d)
     ws = _GCN2_WS.get(key)
     if ws is None:
-        _GCN2_WS.clear()
+        if len(_GCN2_WS) >= 4:
+            _GCN2_WS.clear()
         ws = _GCN2_WS[key] = torch.empty(((2 * hidden + d) * n + 12,), dtype=torch.float32, device=x.device)
     if out is None:
         out = torch.empty((n, d), dtype=torch.float32, device=x.device)
