@@ -472,15 +472,15 @@ def main():
                                       ops.spmm(rp, c, v, xx, bias=bias, relu=relu, renorm=renorm, out=out))
         x_local = x_full[enc.lo:enc.hi].contiguous()
         xs_local = ops.SparseRows(x_local)
-        box["x"], box["xs"] = x_local, (xs_local if xs_local.density < TLCGNN.Net.SPARSE_FEATURES_BELOW and x_local.shape[1] <= ops.SPARSE_GEMM_MAX_K else None)
+        box["x"], box["xs"] = x_local, (xs_local if xs_local.density < TLCGNN.Net.SPARSE_FEATURES_BELOW and ops.sparse_gemm_fits(x_local.shape[1], w1.shape[1]) else None)
         pairs_mapped = enc.row_map(dec_pairs.long()).to(torch.int32).contiguous()      # decode pairs index encode()'s layout
 
-        fused = enc.rows is None and box["xs"] is None                  # no exchange step, dense features: one call for the encoder
+        fused = enc.rows is None                                        # no exchange step: one call for the encoder
         emb_buf = torch.empty((n, w2.shape[1]), dtype=torch.float32, device=dev) if fused else None
 
         def leg():
             if fused:
-                emb = ops.gcn2_encode(rowptr_n, col_n, val_n, x_local, w1, b1, w2, b2, relu=True, renorm=True, out=emb_buf)
+                emb = ops.gcn2_encode(rowptr_n, col_n, val_n, x_local, w1, b1, w2, b2, relu=True, renorm=True, out=emb_buf, x_sparse=box["xs"])
             else:
                 emb = enc.encode(x_local, w1, b1, w2, b2, renorm=True)  # renorm_ of TLCGNN.py:48 fused into the last SpMM
             ops.lp_decode(pairs_mapped, emb, dec_pi, l1w, l1b, l2w, l2b, out=prob_out)
@@ -926,9 +926,10 @@ def main():
                                            "achieved": sp_bytes / us_sg / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": sp_bytes / us_sg / 1e3 / HBM_PEAK_GBS,
                                            "useful_tflops": 2.0 * xs_full.nnz * Nh / us_sg / 1e6,
-                                           "note": "x @ W over the stored entries of x (tlc_spgemm_csr_dense_f32); exact; bytes = CSR + W + "
-                                                   "output, each once.  Used by Net.encode / the LP leg only below %.0f %% density (the dense "
-                                                   "MFMA kernel is faster above): not on this workload" % (100 * TLCGNN.Net.SPARSE_FEATURES_BELOW)},
+                                           "note": "x @ W over the stored entries of x (tlc_spgemm_csr_dense_f32); bytes = CSR + W + "
+                                                   "output, each once (bound in fact by the LDS reads of W's slice: DESIGN.md).  Used by Net.encode / "
+                                                   "the LP leg below %.0f %% density (the dense MFMA kernel is faster above): %s on this workload"
+                                                   % (100 * TLCGNN.Net.SPARSE_FEATURES_BELOW, "used" if xs_full.density < TLCGNN.Net.SPARSE_FEATURES_BELOW else "not used")},
                    "feature_gemm": {"bound": "mfma", "shape_mkn": [int(Mr), int(Kf), int(Nh)], "kernel_us": us_g,
                                     "achieved": 2.0 * Mr * Kf * Nh / us_g / 1e6, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": 2.0 * Mr * Kf * Nh / us_g / 1e6 / MFMA_F32_PEAK_TFLOPS, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"},

@@ -236,8 +236,10 @@ int tlc_gemm_f32(int32_t M, int32_t N, int32_t K, const float* d_A, const float*
                  int relu, float* d_C, void* stream);
 
 /* The same product for a SPARSE A given as CSR (rowptr int32[M+1], col int32[nnz] < K, val f32[nnz]): the feature projection
- * x @ W of GCNConv (PD_conv.py:179-181) on bag-of-words / TF-IDF features (PubMed: 10 % non-zeros), exact (the zeros contribute
- * nothing) at a tenth of the flops.  B is staged in LDS in 64-column slices: K <= 640 (TLC_ERR_UNSUPPORTED beyond). */
+ * x @ W of GCNConv (PD_conv.py:179-181) on bag-of-words / TF-IDF features (PubMed: 10 % non-zeros): the zeros contribute
+ * nothing, a tenth of the flops.  B is staged in LDS in column slices of at most 64 (N = 100: 52 + 48): K * slice * 4 B + 1 KiB
+ * <= 160 KiB, i.e. K <= 636 for a 64-column slice (TLC_ERR_UNSUPPORTED beyond).  Sums in a fixed order of its own (within 1e-5
+ * relative of the dense product). */
 int tlc_spgemm_csr_dense_f32(int32_t M, int32_t K, int32_t N, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
                              const float* d_B, const float* d_bias, int relu, float* d_C, void* stream);
 
@@ -257,6 +259,13 @@ int tlc_renorm_rows_f32(int32_t n_rows, int32_t k, float* d_emb, void* stream);
 int tlc_gcn2_encode_f32(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
                         const float* d_x, int32_t f_in, const float* d_w1, const float* d_b1, int32_t hidden,
                         const float* d_w2, const float* d_b2, int32_t out_dim, int flags, float* d_ws, float* d_emb, void* stream);
+
+/* The same with the node features given as CSR (d_xs_rowptr int32[n_nodes+1], d_xs_col int32[nnz] < f_in, d_xs_val f32[nnz]): the
+ * first projection is tlc_spgemm_csr_dense_f32 (its limit on f_in applies).  What Net.encode runs on PubMed's TF-IDF features. */
+int tlc_gcn2_encode_csr_f32(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
+                            const int32_t* d_xs_rowptr, const int32_t* d_xs_col, const float* d_xs_val, int32_t f_in,
+                            const float* d_w1, const float* d_b1, int32_t hidden, const float* d_w2, const float* d_b2,
+                            int32_t out_dim, int flags, float* d_ws, float* d_emb, void* stream);
 
 /* Net.decode after the renorm (TLCGNN.py:52-61), one fused pass per pair:
  *   h = LeakyReLU_0.2( W1 @ [ (emb[u]-emb[v])^2 || PI ] + b1 );  d = clamp(|W2 @ h + b2|, 0, 40);

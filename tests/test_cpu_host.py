@@ -230,3 +230,13 @@ def test_message_passing_tuple_arguments_follow_the_reference():
     sq = torch.stack([ei[0] % 11, ei[1]])
     out = One().propagate(sq, x=xd, e=(xd, None))
     assert torch.allclose(out, torch.zeros(11, xd.size(1)).index_add_(0, sq[1], xd[sq[0]]))
+
+
+def test_sparse_gemm_fits_follows_the_kernels_lds_budget():
+    """ops.sparse_gemm_fits restates the launcher's rule (lp_forward.hip, tlc_spgemm_csr_dense_f32): equal column slices of at most 64,
+    a multiple of four, K * slice * 4 B + 1 KiB within 160 KiB."""
+    from tlc_gnn_amd import ops
+    assert ops.sparse_gemm_fits(500, 100) and ops.sparse_gemm_fits(640, 100)          # 52-column slices
+    assert ops.sparse_gemm_fits(636, 64) and not ops.sparse_gemm_fits(637, 64)        # a full 64-column slice
+    assert ops.sparse_gemm_fits(636, 128) and not ops.sparse_gemm_fits(1433, 100)     # Cora's 1 433 features: the dense kernel
+    assert ops.sparse_gemm_fits(ops.SPARSE_GEMM_MAX_K, 64) and not ops.sparse_gemm_fits(0, 4)

@@ -295,10 +295,12 @@ def test_full_size_pubmed_encode_decode_vs_restatement():
 
 
 @pytest.mark.parametrize("shape,density", [((19717, 500, 100), 0.1), ((2708, 640, 100), 0.013), ((777, 33, 7), 0.3), ((64, 500, 130), 0.1),
-                                           ((5, 4, 1), 0.5), ((300, 256, 64), 0.0)])
+                                           ((5, 4, 1), 0.5), ((300, 256, 64), 0.0), ((40, 600, 20), 0.5), ((300000, 8, 4), 0.5),
+                                           ((1000, 636, 64), 0.05)])
 def test_sparse_feature_projection(setup, shape, density):
     """x @ W over the stored entries of x (tlc_spgemm_csr_dense_f32): against the float64 product, element by element, and
-    against the dense MFMA kernel; empty rows, N not a multiple of 64, more than one column slice, an all-zero matrix."""
+    against the dense MFMA kernel; empty rows, N not a multiple of 64, more than one column slice, an all-zero matrix, rows of
+    several 64-entry chunks (300 entries), more than 64 rows per wavefront (300 000 rows), the largest K of a 64-column slice."""
     torch = setup[0]
     from tlc_gnn_amd import ops
     M, K, N = shape
@@ -468,6 +470,10 @@ def test_gcn2_encode_one_call_equals_the_four_calls(setup):
             h = ops.spmm(rp, c, v, ops.gemm(x, w1), bias=b1, relu=True)
             want = ops.spmm(rp, c, v, ops.gemm(h, w2), bias=b2, relu=True, renorm=renorm)
             got = ops.gcn2_encode(rp, c, v, x, w1, b1, w2, b2, relu=True, renorm=renorm)
+            # the features as CSR (tlc_gcn2_encode_csr_f32): the first projection over the stored entries, sums in another order
+            got_csr = ops.gcn2_encode(rp, c, v, None, w1, b1, w2, b2, relu=True, renorm=renorm, x_sparse=ops.SparseRows(x))
+            ok_csr, worst_csr = _close(got_csr, want)
+            assert ok_csr, (n, renorm, worst_csr)
             torch.cuda.synchronize()
             if d == 16 and hidden % 4 == 0:
                 assert bool(((got - want).abs() <= 1e-5 * want.abs() + 1e-6).all()), (n, f_in, hidden, d, renorm, float((got - want).abs().max()))

@@ -26,7 +26,7 @@ SYMBOLS = [
     "tlc_version", "tlc_last_error", "tlc_device_count", "tlc_graph_create", "tlc_graph_destroy",
     "tlc_pd_pi_batch", "tlc_pd_pi_batch_async", "tlc_pd_pi_batch_join", "tlc_vicinity_filtration", "tlc_pd_pi_batch_stats", "tlc_pd_pi_batch_set_timing",
     "tlc_pd_pi_batch_timings", "tlc_pd_pi_batch_timing_history", "tlc_pd_pi_batch_sizes", "tlc_pd_pi_algorithmic_bytes", "tlc_pd_from_filtration",
-    "tlc_pi_raster", "tlc_pi_raster_wgrad", "tlc_gcn_norm_csr", "tlc_gemm_f32", "tlc_spgemm_csr_dense_f32", "tlc_spmm_csr_f32", "tlc_renorm_rows_f32", "tlc_gcn2_encode_f32",
+    "tlc_pi_raster", "tlc_pi_raster_wgrad", "tlc_gcn_norm_csr", "tlc_gemm_f32", "tlc_spgemm_csr_dense_f32", "tlc_spmm_csr_f32", "tlc_renorm_rows_f32", "tlc_gcn2_encode_f32", "tlc_gcn2_encode_csr_f32",
     "tlc_lp_decode_fused", "tlc_lp_decode_fused_f32", "tlc_gat_layer_fwd", "tlc_gat_layer_tiled_fwd", "tlc_gat_tile_cut", "tlc_csr_by_target", "tlc_pdgnn_forward", "tlc_pdgnn_forward_work_bytes", "tlc_scatter_f32", "tlc_edge_head_fwd",
     "tlc_complement_rows", "tlc_complement_pairs", "tlc_select_rows", "tlc_pack_vicinities", "tlc_stack_batch", "tlc_ollivier_ricci_sinkhorn",
     "tlc_near_pairs", "tlc_w2_partial_matching", "tlc_w2_inference_matching", "tlc_gat_layer_bwd", "tlc_edge_head_bwd", "tlc_pack_offsets", "tlc_vicinity_sizes", "tlc_debug_dc_stats", "tlc_debug_tier_counts", "tlc_debug_phase_profile", "tlc_debug_set_option", "tlc_debug_pair_times",
@@ -100,6 +100,8 @@ def lib():
             L.tlc_renorm_rows_f32.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
             L.tlc_gcn2_encode_f32.argtypes = ([C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                               C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
+            L.tlc_gcn2_encode_csr_f32.argtypes = ([C.c_int32] + [C.c_void_p] * 6 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                                  C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
             L.tlc_lp_decode_fused.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             L.tlc_lp_decode_fused_f32.argtypes = L.tlc_lp_decode_fused.argtypes

@@ -67,16 +67,16 @@ class Net(torch.nn.Module):
         self._pi_stamp = self._pairs_stamp = None
         self._xs = None                 # (features tensor, its version, SparseRows or None): see _sparse_features
 
-    # density under which x @ W runs over the stored entries of x.  Measured on MI355X, 19 717 x 500 @ 500 x 100: the dense f32
-    # MFMA kernel takes 30 us whatever the zeros; the sparse kernel 39 us at 10 % density (PubMed-like).  That is the one point
-    # measured: "pays under ~7 %" assumes its time scales with the stored entries, which was not checked at a lower density
-    SPARSE_FEATURES_BELOW = 0.05
+    # density under which x @ W runs over the stored entries of x.  Measured on MI355X, 19 717 x 500 @ 500 x 100 (round 5's
+    # kernel, tools/time_spgemm.py): the dense f32 MFMA kernel takes 28 us whatever the zeros; the sparse kernel 9.7 / 10.1 / 11.9 /
+    # 15.9 / 24.0 us at 1 / 2 / 5 / 10 (PubMed) / 20 % density
+    SPARSE_FEATURES_BELOW = 0.2
 
     def _sparse_features(self, x):
         """The node features of the reference's datasets are bag-of-words / TF-IDF rows (PubMed: 10 % non-zeros, Cora: 1.3 %) and
         do not change between forwards: their CSR is built once and kept while `x` is the same, unmodified tensor (the entry holds
         a reference to x, so its storage cannot be handed to another tensor, and x._version exposes in-place edits)."""
-        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] <= ops.SPARSE_GEMM_MAX_K):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and ops.sparse_gemm_fits(x.shape[1], self.conv1.weight.shape[1])):
             return None
         if self._xs is None or self._xs[0] is not x or self._xs[1] != x._version:
             xs = ops.SparseRows(x)
@@ -132,13 +132,14 @@ class Net(torch.nn.Module):
         self._forward_only("encode")
         x, edge_index = data.x, data.edge_index
         xs = None if self.training else self._sparse_features(x)      # (training: dropout makes a new x every step)
-        if not self.training and xs is None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
-            # eval mode, dense features: both layers behind one library call (the same four kernels, ops.gcn2_encode)
+        if not self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+            # eval mode: both layers behind one library call (the same kernels, ops.gcn2_encode), the first projection over the
+            # stored entries of x when x is sparse enough
             rowptr, col, val = self.conv1.norm_csr(edge_index, x.shape[0])
             self.conv2._cache = self.conv2._cache or self.conv1._cache            # (one graph: conv2 would build the same operator)
             with torch.no_grad():
                 return ops.gcn2_encode(rowptr, col, val, x, self.conv1.weight.detach(), self.conv1.bias.detach(),
-                                       self.conv2.weight.detach(), self.conv2.bias.detach(), relu=True)
+                                       self.conv2.weight.detach(), self.conv2.bias.detach(), relu=True, x_sparse=xs)
         x = F.dropout(x, p=0.5, training=self.training)
         x = self.conv1(x, edge_index, relu=not self.training, x_sparse=xs)   # ReLU fused into the aggregate in eval mode
         if self.training:

@@ -1268,84 +1268,228 @@ extern "C" int tlc_gemm_f32(int32_t M, int32_t N, int32_t K, const float* d_A, c
 }
 
 // ---- C = CSR(A) @ B (+bias)(ReLU): the feature projection x @ W when x is sparse --------------------------------------------
-// PubMed's TF-IDF features are 90 % zeros (Cora's 98.7 %): the product over the stored entries alone is exact and does a tenth
-// of the flops and bytes of the dense GEMM.  B (K x N, the weight matrix: 200 KB for 500 x 100) is what every entry gathers from,
-// so a 64-column slice of it lives in LDS ([k][64]: lane c reads B[k][c], conflict-free; up to 128 KB, one workgroup per CU), and
-// a wavefront owns a row of A at a time: its lanes are the columns of the slice, the row's (column, value) pairs are loaded 64 at
-// a time (one coalesced read each) and handed round with v_readlane, four entries in flight.  gridDim.y = column slices.
-// HBM: the CSR once per slice (12 B per entry), B once per workgroup, C once.
+// PubMed's TF-IDF features are 90 % zeros (Cora's 98.7 %): the product over the stored entries alone does a tenth of the flops
+// and bytes of the dense GEMM.  B (K x N, the weight matrix: 200 KB for 500 x 100) is what every entry gathers from, so a column
+// slice of it lives in LDS (one workgroup per CU), and a wavefront owns a row of A at a time.  gridDim.y = column slices.
+// HBM: the CSR once per slice (8 B per entry), B once per workgroup (from L2), C once.
+// (Round 2's kernel -- lanes = the 64 columns of a slice, the row's entries handed round with v_readlane, one entry per step:
+// four vector instructions and a 256-byte LDS read per entry and slice, 1.97 M such steps for PubMed = 31 M SIMD cycles of
+// vector issue alone -- measured 38 us against the dense MFMA kernel's 28.5 and was used below 5 % density only; replaced by:)
+// Four entries of a row at a time (round 5): the four 16-lane rows of the wavefront work on four entries at once: lane (g, l) holds the columns 4 l .. 4 l + 3
+// of the slice (a slice is `sw` <= 64 columns, a multiple of four: 52 + 48 for N = 100, K sw 4 B = 104 KB of LDS) and adds up the
+// entries  j = g (mod 4)  of the row.  A chunk of 64 entries is loaded coalesced (lane j: entry j) and turned round once (two
+// ds_bpermute) so that lane (g, l) holds entry 4 l + g: step i of the chunk then needs, in every 16-lane row, what that row's
+// lane i holds -- one DPP row broadcast folded into the address add (v_add_u32_dpp row_newbcast:i), one for the value, one
+// ds_read_b128 and two v_pk_fma_f32 per FOUR entries: 4 vector instructions and a 1 KB LDS read where round 2's kernel needed 16
+// and four 256-byte reads.  (Loading the chunk already turned round -- lane (g, l) asks for entry 4 l + g -- was measured first:
+// every 16-lane quarter of such a load touches all of the chunk's cache lines, four times the tag look-ups, and the wavefronts
+// waited 2 000 cycles per row for their entries.)  The four partial sums of a row meet without LDS: v_permlane16_swap on (x, y)
+// and (z, w), v_permlane32_swap on the two sums -- three swaps, three adds -- leave column 4 l + g of the row in lane (g, l), and
+// the row goes out as one dword per lane, 4 sw contiguous bytes.  Sum order: entries j = g (mod 4) ascending per partial sum,
+// then (g0 + g1) + (g2 + g3) -- fixed, not the dense kernel's.
+// A row whose entry count is not a multiple of four ends in a step with idle 16-lane rows: their value is 0 and their column the
+// row's first entry's, so the only weights multiplied by that zero are ones the row uses anyway (finite weights: exact; a
+// non-finite weight the row touches gives a non-finite output either way, possibly NaN where the sum is an infinity).
+//
+// What bounds it (cycle stamps per wavefront, TLC_SQ_DEBUG): the LDS reads of the slice -- 13 ds_read_b128 of 1 KB per row of 50
+// entries, 16 wavefronts x 10 rows per CU = 16 000 cycles of the LDS pipe at 128 B per clock -- then the slice's way into LDS
+// (26 MB from L2 over all CUs, asked for with buffer_load ... lds: no registers, no ds_write, every piece in flight at once).
+// The entries of a row are requested four rows ahead into a ring of four register pairs.  The loads are issued from inline
+// assembly and the wait before a pair's first use is written by hand (vmcnt(6): vector memory loads return in order, the six
+// loads of the three rows requested since may still be in flight; anything else issued in between -- the row stores, a long
+// row's later chunks -- only makes the count conservative): the compiler's own s_waitcnt bookkeeping was tried first, in three
+// loop shapes, and always ended up waiting for all but the newest two loads.  Every path through the row loop issues the same
+// requests into the same registers (a request under a branch gets routed through a temporary the compiler copies from before
+// the data is there): a block's rows are rounded up to a multiple of four with empty ones, and loads have no branch around them
+// -- a lane without an entry asks for an offset behind the descriptor's range and gets zero.
+#ifndef TLC_SPGEMM_NW
+#define TLC_SPGEMM_NW 16
+#endif
+#ifdef TLC_SQ_DEBUG
+__device__ unsigned long long g_sq_dbg[8];                   // cycle sums over all wavefronts
+#define SQ_CLK() clock64()
+#else
+#define SQ_CLK() 0ull
+#endif
+template <int I>
+__device__ __forceinline__ int row_bcast(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x150 + I, 0xf, 0xf, true); }
+
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 1) void spgemm_csr_dense_kernel(int M, int K, int N, const int* __restrict__ rowptr,
-                                                                     const int* __restrict__ col, const float* __restrict__ val,
-                                                                     const float* __restrict__ B, const float* __restrict__ bias,
-                                                                     int relu, float* __restrict__ C) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
-    float* Bs = (float*)sp_lds;                                   // [K][64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c0 = (int)blockIdx.y * 64;
-    const int cw = N - c0 < 64 ? N - c0 : 64;
-    // the rows this wavefront owns, the first one's bounds and entries requested before the slice of B is staged
+__global__ __launch_bounds__(NW * 64, 1) void spgemm_quad_kernel(int M, int K, int N, int sw, const int* __restrict__ rowptr,
+                                                                const int* __restrict__ col, const float* __restrict__ val,
+                                                                const float* __restrict__ B, const float* __restrict__ bias,
+                                                                int relu, float* __restrict__ C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sq_lds[];
+    float* Bs = (float*)sq_lds;                                   // [K][sw] (+ 1 KB: the last piece of the staging, zeros)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l = lane & 15;
+    const int c0 = (int)blockIdx.y * sw;
+    const int cw = N - c0 < sw ? N - c0 : sw;
+    const int rb = sw * 4;                                        // bytes of a row of the slice
+    const int turn = (4 * l + g) * 4;                             // ds_bpermute address: the lane holding entry 4 l + g
+    const int loff = l * 16;
     const int stride = (int)gridDim.x * NW;
-    int r = (int)blockIdx.x * NW + wave;
-    int e0 = 0, e1 = 0, kk = 0;
-    float vv = 0.f;
-    if (r < M) {
-        e0 = rowptr[r]; e1 = rowptr[r + 1];
-        if (lane < e1 - e0) { kk = col[e0 + lane]; vv = val[e0 + lane]; }
-    }
-    int ne0 = 0, ne1 = 0;
-    if (r + stride < M) { ne0 = rowptr[r + stride]; ne1 = rowptr[r + stride + 1]; }
-    if ((N & 3) == 0 && (((uintptr_t)B) & 15) == 0) {             // 16-byte loads: a row of the slice is a multiple of four floats
-        for (int t = tid; t < K * 16; t += NW * 64) {
-            const int k = t >> 4, q = (t & 15) * 4;
-            float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < cw) v4 = *reinterpret_cast<const float4*>(B + (size_t)k * N + c0 + q);
-            *reinterpret_cast<float4*>(Bs + k * 64 + q) = v4;
+    const int r_first = (int)blockIdx.x * NW + wave;
+    // the rows of this wavefront are r_first + i stride: lane i keeps the bounds of row i (of a block of 64 rows)
+    const int n_mine = r_first < M ? (M - r_first + stride - 1) / stride : 0;
+    unsigned long long dbg_t0 = SQ_CLK(), dbg_wait = 0, dbg_chunk = 0, dbg_tail = 0, dbg_stage = 0;
+    (void)dbg_t0; (void)dbg_wait; (void)dbg_chunk; (void)dbg_tail; (void)dbg_stage;
+    int rb0 = 0, rb1 = 0;
+    if (lane < n_mine) { rb0 = rowptr[r_first + lane * stride]; rb1 = rowptr[r_first + lane * stride + 1]; }
+    constexpr int OOB = 0x7ffffff0;
+    typedef int sq_v4i __attribute__((ext_vector_type(4)));
+    const unsigned long long a_col = (unsigned long long)col, a_val = (unsigned long long)val;
+    const sq_v4i rs_col = {(int)(unsigned)a_col, (int)((unsigned)(a_col >> 32) & 0xffffu), OOB, 0x00020000};
+    const sq_v4i rs_val = {(int)(unsigned)a_val, (int)((unsigned)(a_val >> 32) & 0xffffu), OOB, 0x00020000};
+    auto request = [&](int i, int& k, int& v) __attribute__((always_inline)) {   // first chunk of row i of the block (uniform i; rows >= 64 or without bounds: empty)
+        const int b0 = __builtin_amdgcn_readlane(rb0, i & 63), b1 = __builtin_amdgcn_readlane(rb1, i & 63);
+        const int off = (i < 64 && lane < b1 - b0) ? (b0 + lane) * 4 : OOB;
+        // ("+v": the destination is the ring register itself, not a temporary the compiler would copy from before the data is there)
+        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(k) : "v"(off), "s"(rs_col) : "memory");
+        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(v) : "v"(off), "s"(rs_val) : "memory");
+    };
+    int k0 = 0, k1 = 0, k2 = 0, k3 = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0;       // the ring (value bits in v*)
+    request(0, k0, v0); request(1, k1, v1); request(2, k2, v2); request(3, k3, v3);
+
+    if ((N & 3) == 0 && (((uintptr_t)B) & 15) == 0) {
+        // The slice into LDS without registers: LDS is [k][sw] = 16-byte items in order, item id = k (sw/4) + q, and a piece is 64
+        // consecutive items (one buffer_load_dwordx4 ... lds: lane j's 16 bytes land at piece base + 16 j).  Items behind the
+        // slice, and the columns >= N of the last slice, ask for an offset out of range: zeros.
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, K * N * 4, 0x00020000);
+        const int q4 = sw >> 2, items = K * q4;
+        const unsigned inv = (1u << 20) / (unsigned)q4 + 1u;      // id / q4 = (id inv) >> 20 for id < 65 536 (q4 <= 16)
+        const int npieces = (items + 63) >> 6;
+        for (int pc = wave; pc < npieces; pc += NW) {
+            const int id = pc * 64 + lane;
+            const int k = (int)(((unsigned)id * inv) >> 20), q = id - k * q4;
+            const int goff = (id < items && 4 * q < cw) ? (k * N + c0 + 4 * q) * 4 : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(sq_lds + pc * 1024), 16, goff, 0, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         for (int t = tid; t < K * 64; t += NW * 64) {
             const int k = t >> 6, c = t & 63;
-            Bs[t] = c < cw ? B[(size_t)k * N + c0 + c] : 0.f;
+            if (c < sw) Bs[k * sw + c] = c < cw ? B[(size_t)k * N + c0 + c] : 0.f;
         }
+        if (tid < 16) Bs[K * sw + tid] = 0.f;
     }
     __syncthreads();
-    const float bv = (bias && lane < cw) ? bias[c0 + lane] : 0.f;
-    while (r < M) {
-        // one row ahead: the next row's first 64 entries; two rows ahead: its bounds -- nothing in the loop waits for HBM/L2
-        int nkk = 0;
-        float nvv = 0.f;
-        if (lane < ne1 - ne0) { nkk = col[ne0 + lane]; nvv = val[ne0 + lane]; }
-        int nne0 = 0, nne1 = 0;
-        if (r + 2 * stride < M) { nne0 = rowptr[r + 2 * stride]; nne1 = rowptr[r + 2 * stride + 1]; }
-        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    dbg_stage = SQ_CLK() - dbg_t0;
+    const int my_col = 4 * l + g;                                 // the column of the slice this lane stores
+    const float bvs = (bias && my_col < cw) ? bias[c0 + my_col] : 0.f;
+    const unsigned char* bsb = sq_lds + loff;
+
+    // one chunk (<= 64 entries, lane (g, l) holds entry 4 l + g as (column, value); lanes without one: a used column, value 0)
+    auto do_chunk = [&](int kk, int vvi, int cnt, float4& acc) __attribute__((always_inline)) {
+        kk *= rb;                                                 // column -> byte offset of its row of the slice
+        const int steps = (cnt + 3) >> 2;
+#define TLC_SQ_LOAD(I, b_, x_)                                                                                     \
+        const float4 b_ = *reinterpret_cast<const float4*>(bsb + row_bcast<I>(kk));                                \
+        const float x_ = __builtin_bit_cast(float, row_bcast<I>(vvi));
+#define TLC_SQ_FMA(b_, x_)                                                                                         \
+        acc.x = fmaf(x_, b_.x, acc.x); acc.y = fmaf(x_, b_.y, acc.y);                                              \
+        acc.z = fmaf(x_, b_.z, acc.z); acc.w = fmaf(x_, b_.w, acc.w);
+#define TLC_SQ_STEP(I) { TLC_SQ_LOAD(I, b0_, x0_) TLC_SQ_FMA(b0_, x0_) }
+        // four steps (16 entries) per block: the four LDS reads of a block are in flight together
+#define TLC_SQ_BLOCK(J)                                                                                            \
+        if (steps >= 4 * J + 4) {                                                                                  \
+            TLC_SQ_LOAD(4 * J, b0_, x0_) TLC_SQ_LOAD(4 * J + 1, b1_, x1_)                                          \
+            TLC_SQ_LOAD(4 * J + 2, b2_, x2_) TLC_SQ_LOAD(4 * J + 3, b3_, x3_)                                      \
+            TLC_SQ_FMA(b0_, x0_) TLC_SQ_FMA(b1_, x1_) TLC_SQ_FMA(b2_, x2_) TLC_SQ_FMA(b3_, x3_)                    \
+        } else {                                                                                                   \
+            if (steps > 4 * J) TLC_SQ_STEP(4 * J)                                                                  \
+            if (steps > 4 * J + 1) TLC_SQ_STEP(4 * J + 1)                                                          \
+            if (steps > 4 * J + 2) TLC_SQ_STEP(4 * J + 2)                                                          \
+            break;                                                                                                 \
+        }
+        do { TLC_SQ_BLOCK(0) TLC_SQ_BLOCK(1) TLC_SQ_BLOCK(2) TLC_SQ_BLOCK(3) } while (0);
+#undef TLC_SQ_BLOCK
+#undef TLC_SQ_STEP
+#undef TLC_SQ_FMA
+#undef TLC_SQ_LOAD
+    };
+    // a chunk as loaded (lane j: entry j) turned round: lane (g, l) gets entry 4 l + g; lanes without an entry the first one's column
+    auto turn_round = [&](int& kk, int& vvi, int cnt) __attribute__((always_inline)) {
+        const int kfirst = __builtin_amdgcn_readfirstlane(kk);
+        kk = __builtin_amdgcn_ds_bpermute(turn, kk);
+        vvi = __builtin_amdgcn_ds_bpermute(turn, vvi);
+        if (my_col >= cnt) kk = kfirst;                           // (my_col = 4 l + g is also this lane's entry number)
+    };
+
+    // one row: its first chunk in the ring pair (kr, vr), requested four rows ago; the pair then takes row i + 4
+    auto do_row = [&](int r, int i, int& kr, int& vr) __attribute__((always_inline)) {
+        const unsigned long long ta = SQ_CLK();
+        asm volatile("s_waitcnt vmcnt(6)" : "+v"(kr), "+v"(vr) : : "memory");
+        const unsigned long long tb = SQ_CLK();
+        int kk = kr, vvi = vr;
+        asm volatile("" : "+v"(kk), "+v"(vvi) : "v"(kr), "v"(vr) : "memory");   // (the copies are made here, before the pair is requested again)
+        request(i + 4, kr, vr);
+        const int e0 = __builtin_amdgcn_readlane(rb0, i), e1 = __builtin_amdgcn_readlane(rb1, i);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int base = e0; base < e1; base += 64) {
             const int cnt = e1 - base < 64 ? e1 - base : 64;
             if (base != e0) {                                     // (rows longer than 64 entries: the later chunks on demand)
-                kk = lane < cnt ? col[base + lane] : 0;
-                vv = lane < cnt ? val[base + lane] : 0.f;
+                const int off = lane < cnt ? (base + lane) * 4 : OOB;
+                asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(kk) : "v"(off), "s"(rs_col) : "memory");
+                asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(vvi) : "v"(off), "s"(rs_val) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(kk), "+v"(vvi) : : "memory");
             }
-            int j = 0;
-            for (; j + 4 <= cnt; j += 4) {
-                const int k0 = __builtin_amdgcn_readlane(kk, j), k1 = __builtin_amdgcn_readlane(kk, j + 1);
-                const int k2 = __builtin_amdgcn_readlane(kk, j + 2), k3 = __builtin_amdgcn_readlane(kk, j + 3);
-                const float b0 = Bs[k0 * 64 + lane], b1 = Bs[k1 * 64 + lane], b2 = Bs[k2 * 64 + lane], b3 = Bs[k3 * 64 + lane];
-                acc0 = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv), j)), b0, acc0);
-                acc1 = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv), j + 1)), b1, acc1);
-                acc2 = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv), j + 2)), b2, acc2);
-                acc3 = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv), j + 3)), b3, acc3);
-            }
-            for (; j < cnt; ++j) {
-                const int k0 = __builtin_amdgcn_readlane(kk, j);
-                acc0 = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv), j)), Bs[k0 * 64 + lane], acc0);
-            }
+            turn_round(kk, vvi, cnt);
+#ifdef TLC_SQ_DUMP
+            if (r == 0) { C[64 + lane] = __builtin_bit_cast(float, vvi); C[128 + lane] = (float)kk; }
+#endif
+            do_chunk(kk, vvi, cnt, acc);
         }
-        float y = ((acc0 + acc1) + (acc2 + acc3)) + bv;
-        if (relu & 1) y = y > 0.f ? y : 0.f;
-        if (lane < cw) C[(size_t)r * N + c0 + lane] = y;
-        r += stride;
-        e0 = ne0; e1 = ne1; kk = nkk; vv = nvv;
-        ne0 = nne0; ne1 = nne1;
+#ifdef TLC_SQ_DUMP
+        if (r == 0) { C[192 + lane] = acc.x; C[256 + lane] = acc.y; }
+#endif
+#ifdef TLC_SQ_DEBUG
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : : "memory");
+#endif
+        const unsigned long long tc = SQ_CLK();
+        dbg_wait += tb - ta; dbg_chunk += tc - tb;
+        if (r < M) {                                              // (uniform; the padding rows of a trip have no row)
+            // rows of 16 lanes: [x | y] -> x' = (x0, y0, x2, y2), y' = (x1, y1, x3, y3); the same for [z | w]; then the halves.
+            // (From assembly: with __builtin_amdgcn_permlane16_swap this compiler adds the FIRST result to itself -- v_add v, v9, v9.
+            // The s_nop cover the wait states between a vector write and a swap that the compiler would otherwise insert.)
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                         : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w));
+            float s_xy = acc.x + acc.y;                           // (x01, y01, x23, y23)
+            float s_zw = acc.z + acc.w;                           // (z01, w01, z23, w23)
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s_xy), "+v"(s_zw));
+            float y = (s_xy + s_zw) + bvs;                        // (x, y, z, w): column 4 l + g
+            if (relu & 1) y = y > 0.f ? y : 0.f;
+            if (my_col < cw) C[(size_t)r * N + c0 + my_col] = y;
+        }
+        dbg_tail += SQ_CLK() - tc;
+    };
+
+    for (int blk = 0; blk < n_mine; blk += 64) {                  // (more than 64 rows per wavefront: the bounds 64 rows at a time)
+        const int nrows = n_mine - blk < 64 ? n_mine - blk : 64;
+        const int rbase = r_first + blk * stride;
+#pragma unroll 1
+        for (int i = 0; i < nrows; i += 4) {
+#define TLC_SQ_ROW(J, kr, vr) do_row(i + J < nrows ? rbase + (i + J) * stride : M, i + J, kr, vr);
+            TLC_SQ_ROW(0, k0, v0) TLC_SQ_ROW(1, k1, v1) TLC_SQ_ROW(2, k2, v2) TLC_SQ_ROW(3, k3, v3)
+#undef TLC_SQ_ROW
+        }
+        // the next block's bounds and first requests, needed or not (see above)
+        const int nb = rbase + 64 * stride;
+        const int left = n_mine - blk - 64;
+        rb0 = rb1 = 0;
+        if (lane < left) { rb0 = rowptr[nb + lane * stride]; rb1 = rowptr[nb + lane * stride + 1]; }
+        request(0, k0, v0); request(1, k1, v1); request(2, k2, v2); request(3, k3, v3);
     }
+    // (the ring's last requests -- rows behind the end: empty -- land before the wavefront ends)
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#ifdef TLC_SQ_DEBUG
+    if (lane == 0) {
+        const unsigned long long whole = SQ_CLK() - dbg_t0;
+        atomicAdd(&g_sq_dbg[0], dbg_stage); atomicAdd(&g_sq_dbg[1], dbg_wait); atomicAdd(&g_sq_dbg[2], dbg_chunk);
+        atomicAdd(&g_sq_dbg[3], dbg_tail); atomicAdd(&g_sq_dbg[4], whole); atomicAdd(&g_sq_dbg[5], (unsigned long long)n_mine);
+        atomicAdd(&g_sq_dbg[7], 1ull);
+    }
+#endif
 }
 
 extern "C" int tlc_spgemm_csr_dense_f32(int32_t M, int32_t K, int32_t N, const int32_t* d_rowptr, const int32_t* d_col,
@@ -1354,23 +1498,42 @@ extern "C" int tlc_spgemm_csr_dense_f32(int32_t M, int32_t K, int32_t N, const i
     TLC_REQUIRE(M >= 0 && K > 0 && N > 0, "bad sizes");
     if (M == 0) return TLC_OK;
     TLC_REQUIRE(d_rowptr && d_col && d_val && d_B && d_C, "null pointer");
-    const size_t lds = (size_t)K * 64 * sizeof(float);
+    // column slices of equal width, a multiple of four and at most 64 (N = 100: 52 + 48)
+    const int slices = (N + 63) / 64;
+    const int sw = (((N + slices - 1) / slices) + 3) & ~3;
+    constexpr int NW = TLC_SPGEMM_NW;
+    const size_t lds = (size_t)K * sw * sizeof(float) + 1024;
     if (lds > 160 * 1024) {
-        tlc_set_error("tlc_spgemm_csr_dense_f32: K = %d needs %zu B of LDS per column slice (max 160 KiB: K <= 640)", K, lds);
+        tlc_set_error("tlc_spgemm_csr_dense_f32: K = %d needs %zu B of LDS per %d-column slice (max 160 KiB)", K, lds, sw);
         return TLC_ERR_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;
-    constexpr int NW = 16;
-    // (per call: the attribute is per device and a process may drive several; a host-side call of a few hundred nanoseconds)
-    if (lds > 64 * 1024)
-        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)spgemm_csr_dense_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int slices = (N + 63) / 64;
-    int gx = 256 / slices;                           // one workgroup per CU over all slices
+    int gx = 256 / slices;                           // one round of workgroups over all slices
     if (gx < 1) gx = 1;
     const int need = (M + NW - 1) / NW;
     if (gx > need) gx = need;
-    hipLaunchKernelGGL(spgemm_csr_dense_kernel<NW>, dim3(gx, slices), dim3(NW * 64), lds, s, M, K, N, d_rowptr, d_col, d_val, d_B,
+    // (per call: the attribute is per device and a process may drive several; a host-side call of a few hundred nanoseconds)
+    if (lds > 64 * 1024)
+        TLC_HIP_CHECK(hipFuncSetAttribute((const void*)spgemm_quad_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(spgemm_quad_kernel<NW>, dim3(gx, slices), dim3(NW * 64), lds, s, M, K, N, sw, d_rowptr, d_col, d_val, d_B,
                        d_bias, relu, d_C);
+#ifdef TLC_SQ_DEBUG
+    {
+        static int calls = 0;
+        if (++calls % 50 == 0) {                             // (a report every 50 calls, warm)
+            unsigned long long h[8], z[8] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sq_dbg), z, sizeof(z));
+            hipLaunchKernelGGL(spgemm_quad_kernel<NW>, dim3(gx, slices), dim3(NW * 64), lds, s, M, K, N, sw, d_rowptr, d_col, d_val, d_B,
+                               d_bias, relu, d_C);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sq_dbg), sizeof(h));
+            const double w = (double)(h[7] ? h[7] : 1);
+            fprintf(stderr, "[spgemm_quad %d x %d x %d] mean cycles per wavefront (%llu wavefronts, %.1f rows each): to the barrier %.0f | rows: "
+                    "waiting for entries %.0f, chunks %.0f, butterfly + store %.0f | whole %.0f\n",
+                    M, K, N, h[7], h[5] / w, h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w);
+        }
+    }
+#endif
     TLC_HIP_CHECK(hipGetLastError());
     return TLC_OK;
 }
@@ -1423,19 +1586,19 @@ extern "C" int tlc_renorm_rows_f32(int32_t n_rows, int32_t k, float* d_emb, void
 // h@W2 in the aggregate's epilogue, fp32 sums in another order than the separate product's); otherwise the four kernels of the
 // separate calls.
 // d_ws: (2 * hidden + out_dim) * n floats (+ 12) of scratch.
-extern "C" int tlc_gcn2_encode_f32(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
-                                   const float* d_x, int32_t f_in, const float* d_w1, const float* d_b1, int32_t hidden,
-                                   const float* d_w2, const float* d_b2, int32_t out_dim, int flags, float* d_ws, float* d_emb,
-                                   void* stream) {
-    TLC_REQUIRE(n_nodes >= 0 && f_in > 0 && hidden > 0 && out_dim > 0, "bad sizes");
-    if (n_nodes == 0) return TLC_OK;
-    TLC_REQUIRE(d_rowptr && d_col && d_val && d_x && d_w1 && d_w2 && d_ws && d_emb, "null pointer");
+static int gcn2_encode_impl(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
+                            const float* d_x, const int32_t* d_xs_rowptr, const int32_t* d_xs_col, const float* d_xs_val,
+                            int32_t f_in, const float* d_w1, const float* d_b1, int32_t hidden,
+                            const float* d_w2, const float* d_b2, int32_t out_dim, int flags, float* d_ws, float* d_emb,
+                            void* stream) {
     auto pad4 = [](size_t v) { return (v + 3) & ~(size_t)3; };
     float* t1 = d_ws;
     float* t2 = t1 + pad4((size_t)n_nodes * hidden);
     float* t3 = t2 + pad4((size_t)n_nodes * hidden);
     int rc;
-    if ((rc = tlc_gemm_f32(n_nodes, hidden, f_in, d_x, d_w1, nullptr, 0, t1, stream)) != TLC_OK) return rc;
+    if (d_x) rc = tlc_gemm_f32(n_nodes, hidden, f_in, d_x, d_w1, nullptr, 0, t1, stream);
+    else rc = tlc_spgemm_csr_dense_f32(n_nodes, f_in, hidden, d_xs_rowptr, d_xs_col, d_xs_val, d_w1, nullptr, 0, t1, stream);
+    if (rc != TLC_OK) return rc;
     if (out_dim == 16 && hidden % 4 == 0 && hidden <= 128 && (reinterpret_cast<uintptr_t>(t1) & 15) == 0) {
         // conv2's projection in the epilogue of conv1's aggregate: three launches, the [n, hidden] activations stay in registers
         hipLaunchKernelGGL(spmm_w2_kernel, dim3((unsigned)((n_nodes + 7) / 8)), dim3(256), 0, (hipStream_t)stream, n_nodes, d_rowptr, d_col, d_val,
@@ -1446,6 +1609,29 @@ extern "C" int tlc_gcn2_encode_f32(int32_t n_nodes, const int32_t* d_rowptr, con
         if ((rc = tlc_gemm_f32(n_nodes, out_dim, hidden, t2, d_w2, nullptr, 0, t3, stream)) != TLC_OK) return rc;
     }
     return tlc_spmm_csr_f32(n_nodes, d_rowptr, d_col, d_val, t3, out_dim, d_b2, flags, d_emb, stream);
+}
+
+extern "C" int tlc_gcn2_encode_f32(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
+                                   const float* d_x, int32_t f_in, const float* d_w1, const float* d_b1, int32_t hidden,
+                                   const float* d_w2, const float* d_b2, int32_t out_dim, int flags, float* d_ws, float* d_emb,
+                                   void* stream) {
+    TLC_REQUIRE(n_nodes >= 0 && f_in > 0 && hidden > 0 && out_dim > 0, "bad sizes");
+    if (n_nodes == 0) return TLC_OK;
+    TLC_REQUIRE(d_rowptr && d_col && d_val && d_x && d_w1 && d_w2 && d_ws && d_emb, "null pointer");
+    return gcn2_encode_impl(n_nodes, d_rowptr, d_col, d_val, d_x, nullptr, nullptr, nullptr, f_in, d_w1, d_b1, hidden, d_w2, d_b2, out_dim,
+                            flags, d_ws, d_emb, stream);
+}
+
+// The same with the features given as CSR (bag-of-words / TF-IDF rows: tlc_spgemm_csr_dense_f32 in place of the dense projection).
+extern "C" int tlc_gcn2_encode_csr_f32(int32_t n_nodes, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
+                                       const int32_t* d_xs_rowptr, const int32_t* d_xs_col, const float* d_xs_val, int32_t f_in,
+                                       const float* d_w1, const float* d_b1, int32_t hidden, const float* d_w2, const float* d_b2,
+                                       int32_t out_dim, int flags, float* d_ws, float* d_emb, void* stream) {
+    TLC_REQUIRE(n_nodes >= 0 && f_in > 0 && hidden > 0 && out_dim > 0, "bad sizes");
+    if (n_nodes == 0) return TLC_OK;
+    TLC_REQUIRE(d_rowptr && d_col && d_val && d_xs_rowptr && d_xs_col && d_xs_val && d_w1 && d_w2 && d_ws && d_emb, "null pointer");
+    return gcn2_encode_impl(n_nodes, d_rowptr, d_col, d_val, nullptr, d_xs_rowptr, d_xs_col, d_xs_val, f_in, d_w1, d_b1, hidden, d_w2, d_b2,
+                            out_dim, flags, d_ws, d_emb, stream);
 }
 
 template <typename PT>

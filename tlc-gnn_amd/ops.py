@@ -122,12 +122,21 @@ class SparseRows:
         return self.nnz / float(max(self.shape[0] * self.shape[1], 1))
 
 
-SPARSE_GEMM_MAX_K = 640          # 64-column slices of B in LDS: K * 256 B <= 160 KiB
+SPARSE_GEMM_MAX_K = 636          # a 64-column slice of B in LDS: K * 256 B + 1 KiB <= 160 KiB (narrower slices take more: sparse_gemm_fits)
+
+
+def sparse_gemm_fits(k, n):
+    """Whether tlc_spgemm_csr_dense_f32 takes a [*, k] @ [k, n] product: its column slice of B ([k][<= 64], equal widths, a
+    multiple of four: 52 + 48 for n = 100) and 1 KiB must fit the 160 KiB of LDS."""
+    slices = (n + 63) // 64
+    sw = (((n + slices - 1) // slices) + 3) & ~3
+    return k > 0 and n > 0 and k * sw * 4 + 1024 <= 160 * 1024
 
 
 @_lib.on_device_of
 def sparse_gemm(xs, b, bias=None, relu=False, out=None):
-    """C = X @ B (+bias)(ReLU) for X given as SparseRows: exact, the zeros of X cost nothing (tlc_spgemm_csr_dense_f32)."""
+    """C = X @ B (+bias)(ReLU) for X given as SparseRows: the zeros of X cost nothing (tlc_spgemm_csr_dense_f32; fp32 sums in an
+    order of its own)."""
     torch = _lib.require_gpu()
     b = _f32(b)
     M, K = xs.shape
@@ -162,28 +171,42 @@ def spmm(rowptr, col, val, x, bias=None, relu=False, out=None, renorm=False):
 _GCN2_WS = {}
 
 
-def gcn2_encode(rowptr, col, val, x, w1, b1, w2, b2, relu=True, renorm=False, out=None):
+def gcn2_encode(rowptr, col, val, x, w1, b1, w2, b2, relu=True, renorm=False, out=None, x_sparse=None):
     """Net.encode in eval mode behind one library call (tlc_gcn2_encode_f32): relu(A (relu(A (x w1) + b1)) w2 + b2), rows
     renormalised when renorm=True (TLCGNN.py:19-26,48).  Same four kernels as gemm / spmm / gemm / spmm; the scratch for
-    the intermediates is kept per (device, stream, sizes): two forwards in flight on two streams do not share it."""
+    the intermediates is kept per (device, stream, sizes): two forwards in flight on two streams do not share it.
+    x_sparse: SparseRows of x -- the first projection then runs over the stored entries (tlc_gcn2_encode_csr_f32)."""
     torch = _lib.require_gpu()
-    x, w1, w2 = _f32(x), _f32(w1), _f32(w2)
-    n, f_in, hidden, d = x.shape[0], x.shape[1], w1.shape[1], w2.shape[1]
-    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream, n, hidden, d)
+    w1, w2 = _f32(w1), _f32(w2)
+    if x_sparse is None:
+        x = _f32(x)
+        n, f_in = x.shape[0], x.shape[1]
+    else:
+        n, f_in = x_sparse.shape
+    hidden, d = w1.shape[1], w2.shape[1]
+    dev = w1.device
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, n, hidden, d)
     ws = _GCN2_WS.get(key)
     if ws is None:
         if len(_GCN2_WS) >= 4:
             _GCN2_WS.clear()
-        ws = _GCN2_WS[key] = torch.empty(((2 * hidden + d) * n + 12,), dtype=torch.float32, device=x.device)
+        ws = _GCN2_WS[key] = torch.empty(((2 * hidden + d) * n + 12,), dtype=torch.float32, device=dev)
     if out is None:
-        out = torch.empty((n, d), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        rc = _lib.lib().tlc_gcn2_encode_f32(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.ptr(x), C.c_int32(f_in),
-                                            _lib.ptr(w1), _lib.ptr(_f32(b1)) if b1 is not None else None, C.c_int32(hidden),
-                                            _lib.ptr(w2), _lib.ptr(_f32(b2)) if b2 is not None else None, C.c_int32(d),
-                                            C.c_int((1 if relu else 0) | (2 if renorm else 0)), _lib.ptr(ws), _lib.ptr(out),
-                                            _lib.stream_ptr(x.device))
-    _lib.check(rc, "tlc_gcn2_encode_f32")
+        out = torch.empty((n, d), dtype=torch.float32, device=dev)
+    flags = C.c_int((1 if relu else 0) | (2 if renorm else 0))
+    pb1 = _lib.ptr(_f32(b1)) if b1 is not None else None
+    pb2 = _lib.ptr(_f32(b2)) if b2 is not None else None
+    with torch.cuda.device(dev):
+        if x_sparse is None:
+            rc = _lib.lib().tlc_gcn2_encode_f32(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.ptr(x), C.c_int32(f_in),
+                                                _lib.ptr(w1), pb1, C.c_int32(hidden), _lib.ptr(w2), pb2, C.c_int32(d),
+                                                flags, _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr(dev))
+        else:
+            rc = _lib.lib().tlc_gcn2_encode_csr_f32(C.c_int32(n), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.ptr(x_sparse.rowptr),
+                                                    _lib.ptr(x_sparse.col), _lib.ptr(x_sparse.val), C.c_int32(f_in),
+                                                    _lib.ptr(w1), pb1, C.c_int32(hidden), _lib.ptr(w2), pb2, C.c_int32(d),
+                                                    flags, _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr(dev))
+    _lib.check(rc, "tlc_gcn2_encode_f32" if x_sparse is None else "tlc_gcn2_encode_csr_f32")
     return out
 
 

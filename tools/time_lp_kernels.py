@@ -15,6 +15,24 @@ def t(fn, n=50):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 
+def tg(fn, n=20, reps=10):
+    """the same through a captured graph of n calls: what the device takes when the host is not in the way (a Python call of a
+    wrapper is ~10 us: kernels shorter than that read as 10 us through t())"""
+    fn(); torch.cuda.synchronize()
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(n): fn()
+    gr.replay(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): gr.replay()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / (n * reps) * 1e3
+
 wl = bench.build_workload(0)
 n = wl["n"]
 te = wl["train_edges"]
@@ -52,10 +70,11 @@ ref = 1.0 / (torch.exp(torch.clamp((hh @ l2w.T + l2b).abs().squeeze(1), 0, 40) -
 print("decode vs torch: max abs diff %.2e" % float((ref - prob2).abs().max()))
 xs = ops.SparseRows(x)
 xws = torch.empty_like(xw)
-print("sparse feature gemm (density %.3f)  %.1f us" % (xs.density, t(lambda: ops.sparse_gemm(xs, w1, out=xws))))
+print("sparse feature gemm (density %.3f)  %.1f us  (from a graph: %.1f us; the dense kernel from a graph: %.1f us)"
+      % (xs.density, t(lambda: ops.sparse_gemm(xs, w1, out=xws)), tg(lambda: ops.sparse_gemm(xs, w1, out=xws)), tg(lambda: ops.gemm(x, w1, out=xw))))
 ops.gemm(x, w1, out=xw)
 print("sparse vs dense product: max abs diff %.2e (max |.| %.2e)" % (float((xw - xws).abs().max()), float(xw.abs().max())))
 for dens in (0.02, 0.05, 0.2, 0.3):
     xd = x * 0 + (torch.rand(x.shape, device="cuda") < dens).float() * torch.rand(x.shape, device="cuda")
     xsd = ops.SparseRows(xd)
-    print("  density %.2f: sparse %.1f us" % (xsd.density, t(lambda: ops.sparse_gemm(xsd, w1, out=xws))))
+    print("  density %.2f: sparse %.1f us (graph %.1f us)" % (xsd.density, t(lambda: ops.sparse_gemm(xsd, w1, out=xws)), tg(lambda: ops.sparse_gemm(xsd, w1, out=xws))))
