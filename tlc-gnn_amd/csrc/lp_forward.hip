@@ -1331,7 +1331,11 @@ __global__ __launch_bounds__(NW * 64, 1) void spgemm_quad_kernel(int M, int K, i
     const int stride = (int)gridDim.x * NW;
     const int r_first = (int)blockIdx.x * NW + wave;
     // the rows of this wavefront are r_first + i stride: lane i keeps the bounds of row i (of a block of 64 rows)
+#if defined(TLC_SQ_DIAG) && (TLC_SQ_DIAG & 1)                    /* (diagnostic builds: 1 no rows, 2 no staging, 4 no row stores) */
+    const int n_mine = 0;
+#else
     const int n_mine = r_first < M ? (M - r_first + stride - 1) / stride : 0;
+#endif
     unsigned long long dbg_t0 = SQ_CLK(), dbg_wait = 0, dbg_chunk = 0, dbg_tail = 0, dbg_stage = 0;
     (void)dbg_t0; (void)dbg_wait; (void)dbg_chunk; (void)dbg_tail; (void)dbg_stage;
     int rb0 = 0, rb1 = 0;
@@ -1359,7 +1363,11 @@ __global__ __launch_bounds__(NW * 64, 1) void spgemm_quad_kernel(int M, int K, i
         const int q4 = sw >> 2, items = K * q4;
         const unsigned inv = (1u << 20) / (unsigned)q4 + 1u;      // id / q4 = (id inv) >> 20 for id < 65 536 (q4 <= 16)
         const int npieces = (items + 63) >> 6;
+#if defined(TLC_SQ_DIAG) && (TLC_SQ_DIAG & 2)
+        for (int pc = wave; pc < 0; pc += NW) {
+#else
         for (int pc = wave; pc < npieces; pc += NW) {
+#endif
             const int id = pc * 64 + lane;
             const int k = (int)(((unsigned)id * inv) >> 20), q = id - k * q4;
             const int goff = (id < items && 4 * q < cw) ? (k * N + c0 + 4 * q) * 4 : OOB;
@@ -1459,7 +1467,11 @@ __global__ __launch_bounds__(NW * 64, 1) void spgemm_quad_kernel(int M, int K, i
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s_xy), "+v"(s_zw));
             float y = (s_xy + s_zw) + bvs;                        // (x, y, z, w): column 4 l + g
             if (relu & 1) y = y > 0.f ? y : 0.f;
+#if defined(TLC_SQ_DIAG) && (TLC_SQ_DIAG & 4)
+            if (my_col < cw && y == 123.456f) C[(size_t)r * N + c0 + my_col] = y;
+#else
             if (my_col < cw) C[(size_t)r * N + c0 + my_col] = y;
+#endif
         }
         dbg_tail += SQ_CLK() - tc;
     };
