@@ -708,6 +708,8 @@ __global__ __launch_bounds__(256) void spmm_csr_v4_kernel(int n_rows, const int*
     __syncthreads();
     int b = 0, e = 0;
     if (row < n_rows) { b = rowptr[row]; e = rowptr[row + 1]; }
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);                     // (with the first loads: read where it is added it is one more dependent trip)
+    if (bias && lane_ok) { bias4.x = bias[c]; bias4.y = bias[c + 1]; bias4.z = bias[c + 2]; bias4.w = bias[c + 3]; }
     const int d = e - b;
     // rows above SPMM_HUB entries are left to the whole workgroup below: one lane group walking a hub row alone
     // (dozens of dependent gather rounds) would be the tail of the launch
@@ -721,7 +723,7 @@ __global__ __launch_bounds__(256) void spmm_csr_v4_kernel(int n_rows, const int*
     // scaled by 1 / (norm + 1e-7); the norm is a shuffle reduction over the group
     auto finish = [&](float4 acc, int r, bool store) {
         if (store) {
-            if (bias) { acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3]; }
+            acc.x += bias4.x; acc.y += bias4.y; acc.z += bias4.z; acc.w += bias4.w;
             if (relu & 1) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
         }
         if (relu & 2) {
@@ -811,6 +813,8 @@ __global__ __launch_bounds__(256) void spmm16_kernel(int n_rows, const int* __re
     int b = 0, d = 0;
     if (row < n_rows) { b = rowptr[row]; d = rowptr[row + 1] - b; }
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bias4 = zero4;                                               // (with the first loads: read where it is added it is one more dependent trip)
+    if (bias) { bias4.x = bias[c]; bias4.y = bias[c + 1]; bias4.z = bias[c + 2]; bias4.w = bias[c + 3]; }
     // entries j0 + slot, + nslot, ... of row segment [rb, rb + rd): eight gathers in flight, tail predicated
     auto gather = [&](float4 acc, int rb, int rd, int slot, int nslot) {
         for (int j = slot; j < rd; j += 8 * nslot) {
@@ -833,7 +837,7 @@ __global__ __launch_bounds__(256) void spmm16_kernel(int n_rows, const int* __re
     };
     // bias, ReLU (relu & 1), emb.renorm_(2, 0, 1) (relu & 2; TLCGNN.py:48): the four column lanes hold the row
     auto finish = [&](float4 acc, int r, bool store) {
-        if (bias) { acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3]; }
+        acc.x += bias4.x; acc.y += bias4.y; acc.z += bias4.z; acc.w += bias4.w;
         if (relu & 1) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
         if (relu & 2) {
             float ss = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
@@ -895,6 +899,10 @@ __global__ __launch_bounds__(256) void spmm_w2_kernel(int n_rows, const int* __r
     // nothing and are in flight with the row bounds), hub rows flagged per group
     int b = 0, e = 0;
     if (row < n_rows) { b = rowptr[row]; e = rowptr[row + 1]; }
+    // (the bias with the first loads: read where it is added -- after the gather -- it was a fourth dependent trip to memory:
+    // cycle stamps per wavefront showed more than half of a wavefront's time BEHIND the gather)
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && lane_ok) bias4 = *reinterpret_cast<const float4*>(bias + c);
     float wreg[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {                                        // W2 rows 4 gl + a -> s_w2[gl][a][0..16); rows >= k: zeros
@@ -933,7 +941,7 @@ __global__ __launch_bounds__(256) void spmm_w2_kernel(int n_rows, const int* __r
     // called by all 32 lanes of a group (lanes past k carry zeros): bias + ReLU, the row times W2, store by the low sixteen lanes
     auto finish = [&](float4 acc, int r, bool store) {
         if (lane_ok) {
-            if (bias) { acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3]; }
+            acc.x += bias4.x; acc.y += bias4.y; acc.z += bias4.z; acc.w += bias4.w;
             acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
         } else {
             acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1611,7 +1619,7 @@ static int gcn2_encode_impl(int32_t n_nodes, const int32_t* d_rowptr, const int3
     if (d_x) rc = tlc_gemm_f32(n_nodes, hidden, f_in, d_x, d_w1, nullptr, 0, t1, stream);
     else rc = tlc_spgemm_csr_dense_f32(n_nodes, f_in, hidden, d_xs_rowptr, d_xs_col, d_xs_val, d_w1, nullptr, 0, t1, stream);
     if (rc != TLC_OK) return rc;
-    if (out_dim == 16 && hidden % 4 == 0 && hidden <= 128 && (reinterpret_cast<uintptr_t>(t1) & 15) == 0) {
+    if (out_dim == 16 && hidden % 4 == 0 && hidden <= 128 && ((reinterpret_cast<uintptr_t>(t1) | reinterpret_cast<uintptr_t>(d_b1)) & 15) == 0) {
         // conv2's projection in the epilogue of conv1's aggregate: three launches, the [n, hidden] activations stay in registers
         hipLaunchKernelGGL(spmm_w2_kernel, dim3((unsigned)((n_nodes + 7) / 8)), dim3(256), 0, (hipStream_t)stream, n_nodes, d_rowptr, d_col, d_val,
                            t1, hidden, d_b1, d_w2, t3);
