@@ -103,9 +103,10 @@ __global__ __launch_bounds__(1024) void gcn_scan_add_kernel(int n_nodes, int* __
 }
 
 __global__ void gcn_fill_kernel(long long n_edges, const long long* __restrict__ ei, int n_nodes,
-                                const int* __restrict__ rowptr, int* __restrict__ cursor, int* __restrict__ col) {
+                                const int* __restrict__ rowptr, int* __restrict__ cursor, int* __restrict__ col, int* __restrict__ long_count) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
+    if (e == 0) *long_count = 0;                            // (the list of long rows starts empty: see gcn_csr_launch)
     const long long r = ei[e], c = ei[n_edges + e];
     if (r != c && r >= 0 && c >= 0 && r < n_nodes && c < n_nodes) col[rowptr[c] + atomicAdd(&cursor[c], 1)] = (int)r;
 }
@@ -114,11 +115,30 @@ __global__ void gcn_fill_kernel(long long n_edges, const long long* __restrict__
 // same rank sort in registers -- a wavefront per three-entry row made the million-node PDGNN batch's build 0.2 ms
 #define GCN_SHORT_ROW 8
 __global__ __launch_bounds__(256) void gcn_finish_short_kernel(int n_nodes, const int* __restrict__ rowptr, const int* __restrict__ raw,
-                                                               int* __restrict__ col) {
+                                                               int* __restrict__ col, int* __restrict__ long_rows, int long_cap) {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_nodes) return;
-    const int b = rowptr[c], d = rowptr[c + 1] - b;
-    if (d > GCN_SHORT_ROW) return;
+    const int b = c < n_nodes ? rowptr[c] : 0, d = c < n_nodes ? rowptr[c + 1] - b : 0;
+    // the longer rows go on a list for gcn_finish_kernel (long_rows[0]: their number; one atomic per workgroup that has any): a
+    // wavefront per ROW that only finds out that its row is short was 58 us on a million-node molecule batch without one long row
+    {
+        __shared__ int s_cnt[4], s_base;
+        const bool lng = d > GCN_SHORT_ROW;
+        const unsigned long long m = __ballot(lng);
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) s_cnt[wave] = __popcll(m);
+        __syncthreads();
+        const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (total) {                                            // (uniform over the workgroup)
+            if (threadIdx.x == 0) s_base = atomicAdd(&long_rows[0], total);
+            __syncthreads();
+            if (lng) {
+                int pos = s_base + __popcll(m & ((1ull << lane) - 1ull));
+                for (int w = 0; w < wave; ++w) pos += s_cnt[w];
+                if (pos < long_cap) long_rows[1 + pos] = c;
+            }
+        }
+    }
+    if (c >= n_nodes || d > GCN_SHORT_ROW) return;
     int v[GCN_SHORT_ROW];
 #pragma unroll
     for (int i = 0; i < GCN_SHORT_ROW; ++i) v[i] = i < d - 1 ? raw[b + i] : c;      // entry d-1 is the self loop
@@ -137,19 +157,24 @@ __global__ __launch_bounds__(256) void gcn_finish_short_kernel(int n_nodes, cons
 // one wave per target row: the self loop joins the sources and the row is rank-sorted ascending out of place (every
 // lane counts the entries below its own; hub rows would serialise an in-place sort on the global-memory latency)
 __global__ __launch_bounds__(256) void gcn_finish_kernel(int n_nodes, const int* __restrict__ rowptr, const int* __restrict__ raw,
-                                                         int* __restrict__ col) {
-    const int c = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (c >= n_nodes) return;
-    const int b = rowptr[c], d = rowptr[c + 1] - b;     // entry d-1 is the self loop (add_remaining_self_loops, weight 1)
-    if (d <= GCN_SHORT_ROW) return;                     // short rows: one thread each, gcn_finish_short_kernel
-    for (int i = lane; i < d; i += 64) {
-        const int vi = i < d - 1 ? raw[b + i] : c;
-        int rank = 0;
-        for (int j = 0; j < d; ++j) {
-            const int vj = j < d - 1 ? raw[b + j] : c;
-            rank += (vj < vi) || (vj == vi && j < i);
+                                                         int* __restrict__ col, const int* __restrict__ long_rows, int long_cap) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6, lane = threadIdx.x & 63;
+    const int n_long = long_rows[0];
+    const bool listed = n_long <= long_cap;                // (more long rows than the list holds: every row is looked at)
+    const int n_items = listed ? n_long : n_nodes;
+    for (int it = wave; it < n_items; it += n_waves) {
+        const int c = listed ? long_rows[1 + it] : it;
+        const int b = rowptr[c], d = rowptr[c + 1] - b;     // entry d-1 is the self loop (add_remaining_self_loops, weight 1)
+        if (d <= GCN_SHORT_ROW) continue;                   // short rows: one thread each, gcn_finish_short_kernel
+        for (int i = lane; i < d; i += 64) {
+            const int vi = i < d - 1 ? raw[b + i] : c;
+            int rank = 0;
+            for (int j = 0; j < d; ++j) {
+                const int vj = j < d - 1 ? raw[b + j] : c;
+                rank += (vj < vi) || (vj == vi && j < i);
+            }
+            col[b + rank] = vi;
         }
-        col[b + rank] = vi;
     }
 }
 __global__ void gcn_val_kernel(int n_nodes, const int* __restrict__ rowptr, const int* __restrict__ col, float* __restrict__ val) {
@@ -1179,7 +1204,13 @@ __global__ __launch_bounds__(256) void lp_decode_generic_kernel(long long n_pair
 // the launches of the CSR-by-target build; tmp int32[3 n + E] = [cnt n | cursor n | unsorted col E + n]; d_val NULL: structure only
 static int gcn_csr_launch(int32_t n_nodes, int64_t n_edges, const int64_t* d_edge_index, int32_t* d_rowptr, int32_t* d_col, float* d_val,
                           int32_t* d_nnz, int* tmp, hipStream_t s) {
+    // tmp: [n] counts | [n] cursors | [E + n] entries as they arrive.  The counts are dead once the row pointers exist: their words
+    // then hold the list of the rows above GCN_SHORT_ROW entries (word 0: how many; zeroed by the fill kernel, which runs behind
+    // the scans and ahead of the kernel that appends)
     if (hipMemsetAsync(tmp, 0, 2 * (size_t)n_nodes * sizeof(int), s) != hipSuccess) return TLC_ERR_HIP;
+    int* long_rows = tmp;
+    const int long_cap = n_nodes - 1;
+    int* raw = tmp + 2 * (size_t)n_nodes;
     const int eb = (int)((n_edges + 255) / 256), nb = (n_nodes + 255) / 256;
     if (n_edges) hipLaunchKernelGGL(gcn_count_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, tmp);
     if (n_nodes <= 8192) {
@@ -1191,9 +1222,10 @@ static int gcn_csr_launch(int32_t n_nodes, int64_t n_edges, const int64_t* d_edg
         hipLaunchKernelGGL(gcn_scan_top_kernel, dim3(1), dim3(1024), 0, s, sb, d_col, d_rowptr, d_nnz);
         hipLaunchKernelGGL(gcn_scan_add_kernel, dim3(sb), dim3(1024), 0, s, n_nodes, d_rowptr, (const int*)d_col);
     }
-    if (n_edges) hipLaunchKernelGGL(gcn_fill_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, (const int*)d_rowptr, tmp + n_nodes, tmp + 2 * (size_t)n_nodes);
-    hipLaunchKernelGGL(gcn_finish_short_kernel, dim3(nb), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)(tmp + 2 * (size_t)n_nodes), d_col);
-    hipLaunchKernelGGL(gcn_finish_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)(tmp + 2 * (size_t)n_nodes), d_col);
+    if (n_edges) hipLaunchKernelGGL(gcn_fill_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, (const int*)d_rowptr, tmp + n_nodes, raw, long_rows);
+    hipLaunchKernelGGL(gcn_finish_short_kernel, dim3(nb), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)raw, d_col, long_rows, long_cap);
+    const int fin_wg = std::min((n_nodes + 3) / 4, 2048);
+    hipLaunchKernelGGL(gcn_finish_kernel, dim3(fin_wg), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)raw, d_col, (const int*)long_rows, long_cap);
     if (d_val) hipLaunchKernelGGL(gcn_val_kernel, dim3(nb), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)d_col, d_val);
     return hipGetLastError() == hipSuccess ? TLC_OK : TLC_ERR_HIP;
 }
