@@ -20,11 +20,12 @@
 // ======================================================================================================================
 namespace {
 
-__global__ void gcn_count_kernel(long long n_edges, const long long* __restrict__ ei, int n_nodes, int* __restrict__ cnt) {
+// (the count an edge's atomic returns is its place in its row: kept per edge, so that the fill needs no second round of atomics)
+__global__ void gcn_count_kernel(long long n_edges, const long long* __restrict__ ei, int n_nodes, int* __restrict__ cnt, int* __restrict__ place) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
     const long long r = ei[e], c = ei[n_edges + e];
-    if (r != c && r >= 0 && c >= 0 && r < n_nodes && c < n_nodes) atomicAdd(&cnt[c], 1);   // self loops are re-added once per node
+    if (r != c && r >= 0 && c >= 0 && r < n_nodes && c < n_nodes) place[e] = atomicAdd(&cnt[c], 1);   // self loops are re-added once per node
 }
 
 // rowptr[i+1] = sum_{j<=i} (cnt[j] + 1): single workgroup, chunks of 1024 with a running carry
@@ -103,12 +104,12 @@ __global__ __launch_bounds__(1024) void gcn_scan_add_kernel(int n_nodes, int* __
 }
 
 __global__ void gcn_fill_kernel(long long n_edges, const long long* __restrict__ ei, int n_nodes,
-                                const int* __restrict__ rowptr, int* __restrict__ cursor, int* __restrict__ col, int* __restrict__ long_count) {
+                                const int* __restrict__ rowptr, const int* __restrict__ place, int* __restrict__ col, int* __restrict__ long_count) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
     if (e == 0) *long_count = 0;                            // (the list of long rows starts empty: see gcn_csr_launch)
     const long long r = ei[e], c = ei[n_edges + e];
-    if (r != c && r >= 0 && c >= 0 && r < n_nodes && c < n_nodes) col[rowptr[c] + atomicAdd(&cursor[c], 1)] = (int)r;
+    if (r != c && r >= 0 && c >= 0 && r < n_nodes && c < n_nodes) col[rowptr[c] + place[e]] = (int)r;
 }
 
 // rows of at most GCN_SHORT_ROW entries (all of a molecule batch, nearly all of a citation graph): one THREAD per row, the
@@ -1204,15 +1205,18 @@ __global__ __launch_bounds__(256) void lp_decode_generic_kernel(long long n_pair
 // the launches of the CSR-by-target build; tmp int32[3 n + E] = [cnt n | cursor n | unsorted col E + n]; d_val NULL: structure only
 static int gcn_csr_launch(int32_t n_nodes, int64_t n_edges, const int64_t* d_edge_index, int32_t* d_rowptr, int32_t* d_col, float* d_val,
                           int32_t* d_nnz, int* tmp, hipStream_t s) {
-    // tmp: [n] counts | [n] cursors | [E + n] entries as they arrive.  The counts are dead once the row pointers exist: their words
+    // tmp: [n] counts | [n] unused | [E + n] entries as they arrive.  The counts are dead once the row pointers exist: their words
     // then hold the list of the rows above GCN_SHORT_ROW entries (word 0: how many; zeroed by the fill kernel, which runs behind
-    // the scans and ahead of the kernel that appends)
-    if (hipMemsetAsync(tmp, 0, 2 * (size_t)n_nodes * sizeof(int), s) != hipSuccess) return TLC_ERR_HIP;
+    // the scans and ahead of the kernel that appends).  An edge's place in its row (what its counting atomic returned: E words)
+    // waits in d_col from word n on (d_col has E + n words and is written for good only by the finish kernels; its head is the
+    // scan's scratch).
+    if (hipMemsetAsync(tmp, 0, (size_t)n_nodes * sizeof(int), s) != hipSuccess) return TLC_ERR_HIP;
     int* long_rows = tmp;
     const int long_cap = n_nodes - 1;
     int* raw = tmp + 2 * (size_t)n_nodes;
+    int* place = d_col + n_nodes;                             // (E words behind the scan's scratch: d_col holds E + n)
     const int eb = (int)((n_edges + 255) / 256), nb = (n_nodes + 255) / 256;
-    if (n_edges) hipLaunchKernelGGL(gcn_count_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, tmp);
+    if (n_edges) hipLaunchKernelGGL(gcn_count_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, tmp, place);
     if (n_nodes <= 8192) {
         hipLaunchKernelGGL(gcn_scan_kernel, dim3(1), dim3(1024), 0, s, n_nodes, (const int*)tmp, d_rowptr, d_nnz);
     } else {
@@ -1222,7 +1226,7 @@ static int gcn_csr_launch(int32_t n_nodes, int64_t n_edges, const int64_t* d_edg
         hipLaunchKernelGGL(gcn_scan_top_kernel, dim3(1), dim3(1024), 0, s, sb, d_col, d_rowptr, d_nnz);
         hipLaunchKernelGGL(gcn_scan_add_kernel, dim3(sb), dim3(1024), 0, s, n_nodes, d_rowptr, (const int*)d_col);
     }
-    if (n_edges) hipLaunchKernelGGL(gcn_fill_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, (const int*)d_rowptr, tmp + n_nodes, raw, long_rows);
+    if (n_edges) hipLaunchKernelGGL(gcn_fill_kernel, dim3(eb), dim3(256), 0, s, (long long)n_edges, (const long long*)d_edge_index, n_nodes, (const int*)d_rowptr, (const int*)place, raw, long_rows);
     hipLaunchKernelGGL(gcn_finish_short_kernel, dim3(nb), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)raw, d_col, long_rows, long_cap);
     const int fin_wg = std::min((n_nodes + 3) / 4, 2048);
     hipLaunchKernelGGL(gcn_finish_kernel, dim3(fin_wg), dim3(256), 0, s, n_nodes, (const int*)d_rowptr, (const int*)raw, d_col, (const int*)long_rows, long_cap);
