@@ -921,11 +921,21 @@ def main():
         xs_full = ops.SparseRows(x_full)
         us_sg = _avg_us(lambda: ops.sparse_gemm(xs_full, w1, out=xw))
         sp_bytes = xs_full.nnz * 8.0 + 4.0 * (Mr + 1) + 4.0 * Kf * Nh + 4.0 * Mr * Nh          # CSR once per column slice is L2 traffic
+        # what the kernel is bound by: a step of a row (four entries, one per 16-lane row) is one ds_read_b128 of the whole wavefront
+        # = 1 KiB of the weight slice in LDS, per column slice; the LDS pipe moves 128 B per clock and CU
+        row_cnt = (xs_full.rowptr[1:] - xs_full.rowptr[:-1]).long()
+        sp_slices = (Nh + 63) // 64
+        sp_lds_bytes = float(((row_cnt + 3) // 4).sum().item()) * sp_slices * 1024.0
+        LDS_PEAK_GBS = 256 * 128 * 2.4                                                          # 256 CUs x 128 B/clk x 2.4 GHz = 78.6 TB/s
         lp_roof = {"feature_gemm_sparse": {"bound": "hbm", "shape_mkn": [int(Mr), int(Kf), int(Nh)], "nnz": int(xs_full.nnz),
                                            "density": xs_full.density, "kernel_us": us_sg,
                                            "achieved": sp_bytes / us_sg / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": sp_bytes / us_sg / 1e3 / HBM_PEAK_GBS,
                                            "useful_tflops": 2.0 * xs_full.nnz * Nh / us_sg / 1e6,
+                                           "lds": {"bytes": sp_lds_bytes, "achieved": sp_lds_bytes / us_sg / 1e3, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": sp_lds_bytes / us_sg / 1e3 / LDS_PEAK_GBS,
+                                                   "note": "LDS reads of the weight slice over the WHOLE kernel time (launch, staging and the "
+                                                           "start-up chain included): the resource the kernel is bound by"},
                                            "note": "x @ W over the stored entries of x (tlc_spgemm_csr_dense_f32); bytes = CSR + W + "
                                                    "output, each once (bound in fact by the LDS reads of W's slice: DESIGN.md).  Used by Net.encode / "
                                                    "the LP leg below %.0f %% density (the dense MFMA kernel is faster above): %s on this workload"
