@@ -419,22 +419,39 @@ __device__ __forceinline__ int x_sweep_ball(const unsigned* __restrict__ be_pos,
             rk = ((p & 64u) ? c0 : 0u) + (unsigned)__popcll(m & below);
         }
     };
-    for (int j0 = e0; j0 < e1; j0 += TLC_WAVE) {
-        const int j = j0 + lane;
-        const bool in = j < e1;
-        const unsigned pos = in ? be_pos[j] : 0u;
-        const double w = (in && dir) ? be_w[j] : 0.0;
-        bool ma, mb;
-        unsigned ra, rb;
-        look(pos >> 16, ma, ra);
-        look(pos & 0xffffu, mb, rb);
-        const bool keep = in && ma && mb;
-        const unsigned long long K = __ballot(keep);
-        if (dir && keep) {
-            const int o = run + __popcll(K & tlc_lanemask_lt());
-            if (o < cap) { x_store(&dir[o], (ra << 16) | rb); x_store(&lw[o], w); }
+    // TLC_X_BALL_UNROLL chunks of 64 entries are requested together (a list of 1 300 entries was 20 trips to L2 one after the
+    // other; 84 % of the pairs have one chunk and are not touched by this)
+#ifndef TLC_X_BALL_UNROLL
+#define TLC_X_BALL_UNROLL 4
+#endif
+    constexpr int UN = TLC_X_BALL_UNROLL;
+    for (int j0 = e0; j0 < e1; j0 += UN * TLC_WAVE) {
+        unsigned pos_[UN];
+        double w_[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * TLC_WAVE + lane;
+            const bool in = j < e1;
+            pos_[u] = in ? be_pos[j] : 0u;
+            w_[u] = (in && dir) ? be_w[j] : 0.0;
         }
-        run += __popcll(K);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (j0 + u * TLC_WAVE >= e1) break;                      // (uniform)
+            const bool in = j0 + u * TLC_WAVE + lane < e1;
+            const unsigned pos = pos_[u];
+            bool ma, mb;
+            unsigned ra, rb;
+            look(pos >> 16, ma, ra);
+            look(pos & 0xffffu, mb, rb);
+            const bool keep = in && ma && mb;
+            const unsigned long long K = __ballot(keep);
+            if (dir && keep) {
+                const int o = run + __popcll(K & tlc_lanemask_lt());
+                if (o < cap) { x_store(&dir[o], (ra << 16) | rb); x_store(&lw[o], w_[u]); }
+            }
+            run += __popcll(K);
+        }
     }
     return run;
 }
