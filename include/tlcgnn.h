@@ -239,7 +239,7 @@ int tlc_gemm_f32(int32_t M, int32_t N, int32_t K, const float* d_A, const float*
  * x @ W of GCNConv (PD_conv.py:179-181) on bag-of-words / TF-IDF features (PubMed: 10 % non-zeros): the zeros contribute
  * nothing, a tenth of the flops.  B is staged in LDS in column slices of at most 64 (N = 100: 52 + 48): K * slice * 4 B + 1 KiB
  * <= 160 KiB, i.e. K <= 636 for a 64-column slice (TLC_ERR_UNSUPPORTED beyond).  Sums in a fixed order of its own (within 1e-5
- * relative of the dense product). */
+ * relative of the dense product).  nnz < 2^29 (byte offsets of the entries are 32-bit). */
 int tlc_spgemm_csr_dense_f32(int32_t M, int32_t K, int32_t N, const int32_t* d_rowptr, const int32_t* d_col, const float* d_val,
                              const float* d_B, const float* d_bias, int relu, float* d_C, void* stream);
 
