@@ -612,6 +612,11 @@ def main():
         lat.append(e0.elapsed_time(e1))
     warm_avg = {k: float(np.median([x for x in v if x >= 0])) if any(x >= 0 for x in v) else -1.0 for k, v in ktimes.items()}
     dom_warm = max(warm_avg, key=lambda k: warm_avg[k])
+    # (the LARGE tier's chain and the MEDIUM tier's are within a few per cent of each other in a batch alone -- 0.43 against 0.41 -
+    # 0.44 ms -- and took turns at being "the longest" from run to run: the LARGE chain is the roofline kernel unless another one
+    # is longer by more than a tenth, so that two runs report the same kernel)
+    if warm_avg.get("pd_tier_large", -1.0) >= 0.9 * warm_avg[dom_warm]:
+        dom_warm = "pd_tier_large"
     g.set_timing(False)
     lat_plain = []
     for s in range(5):                                                # latency without any kernel events
