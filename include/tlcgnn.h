@@ -338,7 +338,8 @@ int tlc_csr_by_target(int32_t n_nodes, int64_t n_edges, const int64_t* d_edge_in
  *   {lin_l.weight, att_l, lin_ij.weight, bias}, then lin5.weight, lin5.bias, lin6.weight, lin6.bias;
  *   d_edge_ptr int64[n_graphs+1]: offsets into the n_edges - n_nodes edges; d_points float32[n_edges - n_nodes][2] (the predicted
  *   diagram points); d_img float64[n_graphs][res*res]; d_work: tlc_pdgnn_forward_work_bytes(n_nodes, n_edges, hidden) bytes.
- * The call waits for the stream once (the tile count) unless the structure is handed in. */
+ * The call waits for the stream once (the tile count) unless the structure is handed in.
+ * Both entry points take n_nodes >= 1, n_edges >= n_nodes, hidden > 0 (work_bytes returns -1 otherwise, the forward TLC_ERR_INVALID_ARG). */
 int64_t tlc_pdgnn_forward_work_bytes(int32_t n_nodes, int64_t n_edges, int32_t hidden);
 int tlc_pdgnn_forward(int32_t n_nodes, int64_t n_edges, const int64_t* d_edge_index, const float* d_x, int32_t hidden,
                       const float* const* params, int64_t n_graphs, const int64_t* d_edge_ptr, int32_t res,

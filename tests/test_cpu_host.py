@@ -240,3 +240,15 @@ def test_sparse_gemm_fits_follows_the_kernels_lds_budget():
     assert ops.sparse_gemm_fits(636, 64) and not ops.sparse_gemm_fits(637, 64)        # a full 64-column slice
     assert ops.sparse_gemm_fits(636, 128) and not ops.sparse_gemm_fits(1433, 100)     # Cora's 1 433 features: the dense kernel
     assert ops.sparse_gemm_fits(ops.SPARSE_GEMM_MAX_K, 64) and not ops.sparse_gemm_fits(0, 4)
+
+
+def test_sparse_rows_beyond_the_kernels_offset_range_are_refused():
+    """tlc_spgemm_csr_dense_f32 addresses entries by 32-bit byte offsets (nnz < 2^29, include/tlcgnn.h): the wrappers refuse a
+    larger matrix instead of reading its tail back as zeros; gat_tiles refuses a tile wider than the kernel's LDS tile."""
+    from types import SimpleNamespace
+    from tlc_gnn_amd import ops, _lib
+    ops._check_sparse_rows(SimpleNamespace(nnz=(1 << 29) - 1))
+    with pytest.raises(_lib.TlcError):
+        ops._check_sparse_rows(SimpleNamespace(nnz=1 << 29))
+    with pytest.raises(ValueError):
+        ops.gat_tiles(None, None, 10, tile_nodes=ops.GAT_TILE_NODES + 1)

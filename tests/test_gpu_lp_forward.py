@@ -296,11 +296,14 @@ def test_full_size_pubmed_encode_decode_vs_restatement():
 
 @pytest.mark.parametrize("shape,density", [((19717, 500, 100), 0.1), ((2708, 640, 100), 0.013), ((777, 33, 7), 0.3), ((64, 500, 130), 0.1),
                                            ((5, 4, 1), 0.5), ((300, 256, 64), 0.0), ((40, 600, 20), 0.5), ((300000, 8, 4), 0.5),
-                                           ((1000, 636, 64), 0.05)])
+                                           ((1000, 636, 64), 0.05), ((64, 5000, 4), 0.02), ((64, 4500, 8), 0.02),
+                                           ((33, 10176, 4), 0.01), ((33, 4096, 4), 0.01)])
 def test_sparse_feature_projection(setup, shape, density):
     """x @ W over the stored entries of x (tlc_spgemm_csr_dense_f32): against the float64 product, element by element, and
     against the dense MFMA kernel; empty rows, N not a multiple of 64, more than one column slice, an all-zero matrix, rows of
-    several 64-entry chunks (300 entries), more than 64 rows per wavefront (300 000 rows), the largest K of a 64-column slice."""
+    several 64-entry chunks (300 entries), more than 64 rows per wavefront (300 000 rows), the largest K of a 64-column slice, and
+    narrow slices with K >= 4 096 (N = 4 / 8: the staging's item -> (row, quad) split needs a 64-bit product there; rows of the
+    weight slice from 4 096 on were staged as zeros before)."""
     torch = setup[0]
     from tlc_gnn_amd import ops
     M, K, N = shape

@@ -606,6 +606,15 @@ def test_batch_structure_entry_points_edge_cases():
     rp, col = ops.csr_by_target(torch.zeros((2, 0), dtype=torch.int64, device=dev), 500)   # no edge at all: self loops only
     t = ops.gat_tiles(rp, col, 500).cpu().numpy()
     assert t[0] == 0 and t[-1] == 500 and np.diff(t).max() <= 192
+    # a tile is at most GAT_TILE_NODES rows (the kernel's LDS tile): a wider cut is refused by the wrapper ...
+    with pytest.raises(ValueError):
+        ops.gat_tiles(rp, col, 500, tile_nodes=ops.GAT_TILE_NODES + 1)
+    # ... and a caller-made cut with a tile of 300 rows comes back as NaN rows for that tile (nothing overruns), the others computed
+    xx = torch.rand(500, 1, device=dev)
+    wl, att, wij, bb = torch.randn(32, 1, device=dev), torch.randn(32, device=dev), torch.randn(32, 64, device=dev), torch.randn(64, device=dev)
+    good = ops.gat_layer_tiled(rp, col, ops.gat_tiles(rp, col, 500), xx, wl, att, wij, bb)
+    bad = ops.gat_layer_tiled(rp, col, torch.tensor([0, 100, 400, 500], dtype=torch.int32, device=dev), xx, wl, att, wij, bb)
+    assert bool(torch.isnan(bad[100:400]).all()) and torch.equal(bad[:100], good[:100]) and torch.equal(bad[400:], good[400:])
     # stack_batch with empty vicinities
     node_ptr = torch.tensor([0, 3, 3, 7, 7], dtype=torch.int64, device=dev)
     edge_ptr = torch.tensor([0, 2, 2, 5, 5], dtype=torch.int64, device=dev)
@@ -618,6 +627,7 @@ def test_batch_structure_entry_points_edge_cases():
     L = _lib.lib()
     nbytes = int(L.tlc_pdgnn_forward_work_bytes(C.c_int32(7), C.c_int64(12), C.c_int32(32)))
     assert nbytes > 0 and int(L.tlc_pdgnn_forward_work_bytes(C.c_int32(7), C.c_int64(3), C.c_int32(32))) < 0
+    assert int(L.tlc_pdgnn_forward_work_bytes(C.c_int32(0), C.c_int64(0), C.c_int32(32))) < 0      # (n_nodes >= 1, like the forward)
     ps = [torch.zeros(64, device=dev) for _ in range(20)]
     with pytest.raises(_lib.TlcError):
         ops.pdgnn_forward(x, ei, ps, edge_ptr, hidden=64)

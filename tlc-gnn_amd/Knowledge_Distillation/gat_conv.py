@@ -33,9 +33,17 @@ class GraphBatch:
     def __init__(self, edge_index, n, tiled=True):
         self.edge_index, self.n, self.version = edge_index, int(n), edge_index._version
         self.rowptr, self.col = GATConv.csr_by_target(edge_index, n)
-        # a batch of small graphs is cut into self-contained tiles (ops.gat_tiles): its layers then run as one kernel each with the
-        # node rows in LDS (tlc_gat_layer_tiled_fwd); None for a batch without close enough cuts (one big graph)
-        self.tiles = ops.gat_tiles(self.rowptr, self.col, self.n) if (tiled and edge_index.is_cuda) else None
+        self._tiled, self._tiles, self._cut = bool(tiled and edge_index.is_cuda), None, False
+
+    @property
+    def tiles(self):
+        """A batch of small graphs cut into self-contained tiles (ops.gat_tiles): its layers then run as one kernel each with the node
+        rows in LDS (tlc_gat_layer_tiled_fwd); None for a batch without close enough cuts (one big graph).  Cut on FIRST USE by a
+        forward without gradients: the cut is three launches and one blocking host read, and the autograd path (a training step's
+        Base_Model.forward builds a GraphBatch per call) never looks at it."""
+        if self._tiled and not self._cut:
+            self._tiles, self._cut = ops.gat_tiles(self.rowptr, self.col, self.n), True
+        return self._tiles
 
     def edge_ends(self, m):
         """int32 (src, dst) of the first m edges -- the batch without the self loops appended last (train_Teacher_Model.py:43-44,
@@ -94,15 +102,16 @@ class GATConv(torch.nn.Module):
         assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
         if self.training and self.dropout > 0:
             raise NotImplementedError("GATConv (HIP): attention dropout in training mode is not implemented")
-        tiles = None
+        batch = None
         if isinstance(csr, GraphBatch):
-            tiles = csr.tiles
+            batch = csr
             csr = csr.check(edge_index, x.shape[0])
         rowptr, col = csr if csr is not None else self.csr_by_target(edge_index, x.shape[0])
         if torch.is_grad_enabled() and (x.requires_grad or self.lin_l.weight.requires_grad or self.att_l.requires_grad
                                         or self.lin_ij.weight.requires_grad or self.bias.requires_grad):
             return autograd.gat_layer(x, self.lin_l.weight, self.att_l, self.lin_ij.weight, self.bias, rowptr, col, prelu_slope)
-        if tiles is not None and ops.gat_tiled_ok(x.shape[1], self.out_channels):
+        tiles = batch.tiles if (batch is not None and ops.gat_tiled_ok(x.shape[1], self.out_channels)) else None   # (cut on first use)
+        if tiles is not None:
             return ops.gat_layer_tiled(rowptr, col, tiles, x, self.lin_l.weight.detach(), self.att_l.detach().reshape(-1),
                                        self.lin_ij.weight.detach(), self.bias.detach(), prelu_slope=prelu_slope)
         return ops.gat_layer(rowptr, col, x, self.lin_l.weight.detach(), self.att_l.detach().reshape(-1),

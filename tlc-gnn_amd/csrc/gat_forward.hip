@@ -10,6 +10,7 @@
 // collapses to leaky_relu(P_i + Q_j) * softmax weight.  The three scatters (sum, min, max at the target,
 // gat_conv.py:216) become one pass over a CSR row per target: every output row has one owner, no atomics.
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 #include "tlc_common.h"
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(GT_THREADS, 4) void gat_tile_kernel(int n_tiles, co
     // (every load unconditional at a clamped index, the raw value kept: a load inside `if (k < ne)` is waited for inside its own
     // branch, and the six loads of a tile's phase 0 became six round trips one after the other)
     auto fetch = [&]() {                                          // (of the tile whose head is in nx_*)
+        if (nx_tn < 1 || nx_tn > GT_TM) return;                   // (uniform; not a tile of tlc_gat_tile_cut: refused below)
         st_rp = rowptr[nx_base + (tid <= nx_tn ? tid : nx_tn)];
         if (nx_ne > 0 && nx_ne <= GT_EM) {                        // (uniform)
 #pragma unroll
@@ -559,6 +561,14 @@ __global__ __launch_bounds__(GT_THREADS, 4) void gat_tile_kernel(int n_tiles, co
     if ((int)blockIdx.x < n_tiles) fetch();
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int base = nx_base, tn = nx_tn, eb0 = nx_eb0, ne = nx_ne;
+        if (tn < 1 || tn > GT_TM) {
+            // (uniform) a caller-made cut with an empty tile or more rows than the LDS tile holds: its rows come back as NaN -- loud, and
+            // nothing is written past the tile's regions (a cut of tlc_gat_tile_cut never gets here)
+            for (long long i = tid; i < (long long)(tn > 0 ? tn : 0) * 2 * C; i += GT_THREADS) out[(size_t)base * 2 * C + i] = __builtin_nanf("");
+            head(tile + (int)gridDim.x);
+            fetch();
+            continue;
+        }
         const bool staged = ne <= GT_EM;
         // ---- phase 0: row bounds and tile-local source ids (fetched during the tile before) --------------------------------
         if (tid <= tn) rp[tid] = st_rp - eb0;
@@ -693,16 +703,26 @@ static int launch_gat_tiled(int n_tiles, const int* tile_ptr, const int* rowptr,
     const size_t wop_bytes = CIN >= 16 ? (size_t)NT * (CIN / 16) * 64 * 16 : (size_t)GT_TM * 4;
     const size_t lds = (size_t)GT_TM * N2 * 4 + (size_t)(GT_TM + 4) * 4 + (size_t)GT_EM * 2 + wop_bytes + 16;
     auto kern = gat_tile_kernel<C, CIN>;
+    // per device, behind a lock: a process may drive several GPUs from several threads (one CU count and one attribute flag for all of
+    // them sized every grid from the first device and raced on the bookkeeping)
+    static std::mutex mu;
     static bool attr_set[64] = {};
-    int dev = 0;
+    static int cus_of[64] = {};
+    int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TLC_ERR_HIP;
-    if (!attr_set[dev]) {
-        TLC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev] = true;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[dev]) {
+            TLC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set[dev] = true;
+        }
+        if (!cus_of[dev]) {
+            int v = 0;
+            TLC_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+            cus_of[dev] = v;
+        }
+        cus = cus_of[dev];
     }
-    hipDeviceProp_t prop;
-    static int cus = 0;
-    if (!cus) { TLC_HIP_CHECK(hipGetDeviceProperties(&prop, dev)); cus = prop.multiProcessorCount; }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
     const int grid = std::min(n_tiles, cus * per_cu);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GT_THREADS), lds, s, n_tiles, tile_ptr, rowptr, src, X, Wf, vec, bias, slope, out);

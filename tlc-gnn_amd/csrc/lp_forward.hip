@@ -1405,7 +1405,8 @@ __global__ __launch_bounds__(NW * 64, 1) void spgemm_quad_kernel(int M, int K, i
         // slice, and the columns >= N of the last slice, ask for an offset out of range: zeros.
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, K * N * 4, 0x00020000);
         const int q4 = sw >> 2, items = K * q4;
-        const unsigned inv = (1u << 20) / (unsigned)q4 + 1u;      // id / q4 = (id inv) >> 20 for id < 65 536 (q4 <= 16)
+        const unsigned inv = (1u << 20) / (unsigned)q4 + 1u;      // id / q4 = (id inv) >> 20 for id q4 < 2^20 (items <= 10 240 fit LDS, q4 <= 16);
+                                                                  // the product in 64 bits: q4 = 1 or 2 (N = 4, 8) puts inv near 2^20 and id above 4 095
         const int npieces = (items + 63) >> 6;
 #if defined(TLC_SQ_DIAG) && (TLC_SQ_DIAG & 2)
         for (int pc = wave; pc < 0; pc += NW) {
@@ -1413,7 +1414,7 @@ __global__ __launch_bounds__(NW * 64, 1) void spgemm_quad_kernel(int M, int K, i
         for (int pc = wave; pc < npieces; pc += NW) {
 #endif
             const int id = pc * 64 + lane;
-            const int k = (int)(((unsigned)id * inv) >> 20), q = id - k * q4;
+            const int k = (int)(((unsigned long long)(unsigned)id * inv) >> 20), q = id - k * q4;
             const int goff = (id < items && 4 * q < cw) ? (k * N + c0 + 4 * q) * 4 : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(sq_lds + pc * 1024), 16, goff, 0, 0, 0);
         }

@@ -42,7 +42,7 @@ struct PdgnnWork {
 }  // namespace
 
 extern "C" int64_t tlc_pdgnn_forward_work_bytes(int32_t n_nodes, int64_t n_edges, int32_t hidden) {
-    if (n_nodes < 0 || n_edges < n_nodes || hidden <= 0) return -1;
+    if (n_nodes <= 0 || n_edges < n_nodes || hidden <= 0) return -1;           // (the same sizes tlc_pdgnn_forward takes)
     return (int64_t)PdgnnWork(n_nodes, n_edges, hidden, 192).total;
 }
 

@@ -65,7 +65,7 @@ def pdgnn_forward(x, edge_index, params, edge_ptr, res=5, hidden=32, rowptr=None
     L = _lib.lib()
     nbytes = int(L.tlc_pdgnn_forward_work_bytes(C.c_int32(n), C.c_int64(E), C.c_int32(hidden)))
     if nbytes < 0:
-        raise ValueError("pdgnn_forward: edge_index must end in the n self loops (train_Teacher_Model.py:43-44)")
+        raise ValueError("pdgnn_forward: needs n >= 1 nodes and an edge_index that ends in the n self loops (train_Teacher_Model.py:43-44)")
     work = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     points = torch.empty((E - n, 2), dtype=torch.float32, device=x.device)
     img = torch.empty((max(B, 1), res * res), dtype=torch.float64, device=x.device)
@@ -123,6 +123,13 @@ class SparseRows:
 
 
 SPARSE_GEMM_MAX_K = 636          # a 64-column slice of B in LDS: K * 256 B + 1 KiB <= 160 KiB (narrower slices take more: sparse_gemm_fits)
+SPARSE_GEMM_MAX_NNZ = 1 << 29    # the kernel addresses entries by 32-bit BYTE offsets through a buffer descriptor (include/tlcgnn.h)
+
+
+def _check_sparse_rows(xs):
+    """Entries beyond 2^29 would read back as zeros (offsets behind the descriptor's range): refused, never truncated."""
+    if xs.nnz >= SPARSE_GEMM_MAX_NNZ:
+        raise _lib.TlcError("sparse feature projection: %d stored entries, the kernel takes fewer than 2^29 (use the dense ops.gemm)" % xs.nnz)
 
 
 def sparse_gemm_fits(k, n):
@@ -141,6 +148,7 @@ def sparse_gemm(xs, b, bias=None, relu=False, out=None):
     b = _f32(b)
     M, K = xs.shape
     assert b.shape[0] == K
+    _check_sparse_rows(xs)
     N = b.shape[1]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=b.device)
@@ -183,6 +191,7 @@ def gcn2_encode(rowptr, col, val, x, w1, b1, w2, b2, relu=True, renorm=False, ou
         n, f_in = x.shape[0], x.shape[1]
     else:
         n, f_in = x_sparse.shape
+        _check_sparse_rows(x_sparse)
     hidden, d = w1.shape[1], w2.shape[1]
     dev = w1.device
     key = (dev, torch.cuda.current_stream(dev).cuda_stream, n, hidden, d)
@@ -264,6 +273,8 @@ def gat_tiles(rowptr, col, n, tile_nodes=GAT_TILE_NODES):
     tlc_gat_layer_tiled_fwd: int32 [T+1] node offsets of tiles of at most `tile_nodes` consecutive nodes, cut only at positions no
     edge crosses -- or None when the batch has no such cuts close enough together (one big graph: the two-kernel layer serves it).
     All on the device (tlc_gat_tile_cut; one host read, of the tile count)."""
+    if not 2 <= int(tile_nodes) <= GAT_TILE_NODES:
+        raise ValueError("gat_tiles: tile_nodes %r; gat_tile_kernel's LDS tile holds at most %d rows" % (tile_nodes, GAT_TILE_NODES))
     torch = _lib.require_gpu()
     n = int(n)
     if n == 0:
