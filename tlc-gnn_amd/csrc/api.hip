@@ -1147,18 +1147,19 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
         // The tier kernels of all lists first, their second kernels (cycle swap / divide and conquer, same stream, behind a tier kernel
         // that runs > 100 us) afterwards: a launch costs the host 3 - 4 us, and with both kernels of a tier submitted together the last
         // list's tier kernel started 84 us after the scan had ended (profiles/r04_bench_timeline.txt).  Option split_launch, default on.
-        struct PendingSwap { bool on; int t; bool timed; TlcPdParams pp; };
-        PendingSwap pend[TLC_N_SIDE];
-        for (int k = 0; k < TLC_N_SIDE; ++k) pend[k].on = false;
+        // (per tier, not per stream: two lists may share a stream)
+        struct PendingSwap { bool on; int k; bool timed; TlcPdParams pp; };
+        PendingSwap pend[TLC_N_TIERS];
+        for (int t = 0; t < TLC_N_TIERS; ++t) pend[t].on = false;
         auto finish_pending_swaps = [&]() -> int {
-            for (int k = 0; k < TLC_N_SIDE; ++k) {
-                if (!pend[k].on) continue;
-                pend[k].on = false;
-                const int t = pend[k].t;
+            for (int t = 0; t < TLC_N_TIERS; ++t) {
+                if (!pend[t].on) continue;
+                pend[t].on = false;
+                const int k = pend[t].k;
                 hipStream_t ss = ws->side[k];
-                int r = ((g->opt_tier_mask >> t) & 1) ? tlc_launch_pd_tier(t, pend[k].pp, ss) : TLC_OK;
+                int r = ((g->opt_tier_mask >> t) & 1) ? tlc_launch_pd_tier(t, pend[t].pp, ss) : TLC_OK;
                 if (r != TLC_OK) return r;
-                if (pend[k].timed) T1(tslot[t], ss);
+                if (pend[t].timed) T1(tslot[t], ss);
                 TLC_HIP_CHECK(hipEventRecord(ws->ev_join[k], ss));
             }
             return TLC_OK;
@@ -1172,7 +1173,7 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
                 TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[k], ws->ev_fork, 0));
             }
             pp.tier_list = ws->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
-            const size_t hs = pi_enabled ? tlc_handoff_slot_bytes(t) : 0;
+            const size_t hs = pi_enabled ? tlc_handoff_slot_bytes(t) : 0;       // (0: the tier kernel runs the cycle swap itself -- SMALL, MID)
             pp.handoff = hs ? ws->handoff + hand_base[t] : nullptr;
             pp.handoff_stride = (long long)hs;
             pp.handoff_cap = (spec_done && (t == TLC_TIER_MID || t == TLC_TIER_MEDIUM || t == TLC_TIER_MEDWIDE)) ? std::min(tc[t], spec_cap[t]) : tc[t];
@@ -1197,7 +1198,7 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
             if (r != TLC_OK) return r;
             used[k] = true;
             if (two) {
-                pend[k].on = true; pend[k].t = t; pend[k].timed = timed; pend[k].pp = pp; pend[k].pp.phase = 2;
+                pend[t].on = true; pend[t].k = k; pend[t].timed = timed; pend[t].pp = pp; pend[t].pp.phase = 2;
                 return TLC_OK;
             }
             if (timed) T1(tslot[t], ws->side[k]);

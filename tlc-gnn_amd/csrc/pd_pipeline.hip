@@ -2392,7 +2392,12 @@ __global__ __launch_bounds__(256, (RES <= TLC_RASTER_OCC3_MAXRES ? 3 : 2)) void 
 // ---- host launchers ------------------------------------------------------------------------------------------------------
 size_t tlc_handoff_slot_bytes(int tier) {
     switch (tier) {
-        case TLC_TIER_MID: return handoff_bytes(TLC_D_NMAX, TLC_D_MMAX);
+        // (MID: none since round 6 -- its tier kernel walks the Pos edges itself.  A 128-thread workgroup with 10.6 KB that keeps a
+        // second wavefront waiting during the walk costs a pipelined batch and the long list nothing against the hand-off record +
+        // tlc_pd_swap_kernel<128, 256> on the same stream, and one batch alone 0.618 -> 0.589 ms: one launch and 4.6 KB out and in
+        // again per vicinity less.  The compact MEDIUM configuration the same way: pipelined batch +5 %, long list +13 %
+        // -- four wavefronts and 26 KB wait for one walker there.  gpurun_out A/Bs: profiles/r06_fused_tiers_ab.txt)
+        case TLC_TIER_MID: return 0;
         case TLC_TIER_MEDIUM: return handoff_bytes(TLC_C_NMAX, TLC_C_MMAX);
         case TLC_TIER_MEDHI:
         case TLC_TIER_MEDWIDE: return handoff_bytes(TLC_M_NMAX, TLC_M_MMAX);
@@ -2475,11 +2480,7 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             if (p.phase != 2)
                 hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_D_NMAX, TLC_D_MMAX, TLC_D_THREADS, false, false>), dim3(grid),
                                    dim3(TLC_D_THREADS), L.total, s, p);
-            if (deferring && p.phase != 1) {
-                constexpr SwapLayout SL = make_swap_layout(TLC_D_NMAX, TLC_D_MMAX);
-                hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_D_NMAX, TLC_D_MMAX>), dim3(grid), dim3(64), SL.total, s, p);
-            }
-            break;
+            break;                                                    // (no hand-off: tlc_handoff_slot_bytes)
         }
         case TLC_TIER_LARGE: {
             constexpr Layout L = make_layout(TLC_L_NMAX, TLC_L_MMAX, false, 2);

@@ -13,8 +13,11 @@ near = near[torch.argsort(ranks)].contiguous()
 E = len(near)
 out = torch.empty((E, 25), dtype=torch.float64, device="cuda"); st = torch.empty(E, dtype=torch.uint8, device="cuda")
 ref = None
-seq = [0, 0]
+# python tools/time_strong_list.py [option valueA valueB]: the list timed under the two values of a handle option in turn
+opt = sys.argv[1] if len(sys.argv) > 3 else None
+seq = [int(sys.argv[2]), int(sys.argv[3])] * 2 if opt else [0, 0]
 for cp in seq:
+    if opt: g.set_option(opt, cp)
     ts = []
     for _ in range(5 if cp >= 0 else 12):
         torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,4 +25,4 @@ for cp in seq:
         ts.append(e0.elapsed_time(e1))
     if ref is None: ref = (out.clone(), st.clone())
     same = bool(torch.equal(out, ref[0]) and torch.equal(st, ref[1]))
-    print("chunk_pairs=%8d  %d pairs: median %.2f ms (%.2f M images/s)  runs %s  rows equal: %s" % (cp, E, float(np.median(ts[1:])), E / float(np.median(ts[1:])) / 1e3, " ".join("%.1f" % t for t in ts), same))
+    print((opt or "run") + "=%8d  %d pairs: median %.2f ms (%.2f M images/s)  runs %s  rows equal: %s" % (cp, E, float(np.median(ts[1:])), E / float(np.median(ts[1:])) / 1e3, " ".join("%.1f" % t for t in ts), same))
