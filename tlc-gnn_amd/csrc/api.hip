@@ -183,6 +183,7 @@ struct tlc_graph {
     int ball_list_hop;             // 0: none yet; -1: lists do not fit (the breadth-first kernels are used)
     int* d_bptr;
     int* d_bcol;
+    unsigned* d_bbits;             // ball bitmaps (TlcVicParams::bbits: n_nodes rows of nw words); null: not built
     int* d_be_ptr;                 // ball subgraphs (TlcVicParams::be_ptr ...); null: not built
     unsigned* d_be_pos;
     double* d_be_w;
@@ -192,12 +193,13 @@ struct tlc_graph {
     double* d_hh_w;
     int hh_k;
     int hh_diag;                   // some heavy node has a self loop
-    size_t x_lds64, x_lds512, x_lds64f;
+    size_t x_lds64, x_lds512, x_lds64f, x_lds64fb;     // (x_lds64fb: the subgraph-list launch without an N-bit bitmap in LDS: ball bitmaps)
     // development / test switches (tlc_debug_set_option; initial values from the environment: TLC_EXTRACT, TLC_HEAVY, TLC_TINY)
     int opt_extract, opt_heavy, opt_tiny;
     int opt_fast_split;                // the subgraph-list pairs in a launch of their own (run_chunk_front)
     int opt_dc_inplace;            // LARGE tier: divide and conquer by the tier kernel's own workgroup (TlcPdParams::dc_inplace)
     int opt_ball_edges;            // the extraction filters the smaller ball's subgraph list where there is one (extract.hip, x_sweep_ball)
+    int opt_ball_bits;             // the subgraph-list launch tests membership in the larger ball against the per-node ball bitmaps (TlcVicParams::bbits)
     int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
     int count_only;                     // set by tlc_vicinity_sizes around its run_batch: chunks stop after the scan, their sizes are copied out
     int opt_n_ws;                       // workspaces taken in turn (2..TLC_N_WS, default 3)
@@ -424,9 +426,9 @@ static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
         if (rq != TLC_OK) return rq;
     }
     hipFree(g->d_bptr); hipFree(g->d_bcol);
-    hipFree(g->d_be_ptr); hipFree(g->d_be_pos); hipFree(g->d_be_w);
+    hipFree(g->d_be_ptr); hipFree(g->d_be_pos); hipFree(g->d_be_w); hipFree(g->d_bbits);
     g->d_bptr = g->d_bcol = nullptr; g->ball_list_hop = 0; g->ball_entries = 0;
-    g->d_be_ptr = nullptr; g->d_be_pos = nullptr; g->d_be_w = nullptr; g->be_entries = 0;
+    g->d_be_ptr = nullptr; g->d_be_pos = nullptr; g->d_be_w = nullptr; g->be_entries = 0; g->d_bbits = nullptr;
     const int n = g->n_nodes;
     int* d_size = nullptr;
     TLC_HIP_CHECK(hipMalloc(&d_size, (size_t)n * sizeof(int)));
@@ -478,6 +480,21 @@ static int ensure_ball_lists(tlc_graph* g, int hop, hipStream_t s) {
         if (ok) { g->d_be_ptr = d_bp; g->d_be_pos = d_pos; g->d_be_w = d_bw; g->be_entries = et; }
         else { hipFree(d_bp); hipFree(d_pos); hipFree(d_bw); (void)hipGetLastError(); }
     }
+    // the ball bitmaps (round 6): N rows of nw words -- N^2 / 8 bytes: 48 MB for PubMed's 19 717 nodes.  Built for the subgraph-list
+    // launch when they stay within 1 GiB (N <= ~92 000) and an eighth of the free memory; else that launch marks the larger ball in
+    // its LDS bitmap as before.  Published on success only.
+    if (g->d_be_ptr) {
+        const size_t bytes = (size_t)n * (size_t)g->nw * sizeof(unsigned);
+        size_t fb = 0, tb = 0;
+        unsigned* d_bb = nullptr;
+        bool ok = bytes <= ((size_t)1 << 30) && hipMemGetInfo(&fb, &tb) == hipSuccess && bytes <= fb / 8;
+        ok = ok && hipMalloc(&d_bb, bytes) == hipSuccess;
+        ok = ok && hipMemsetAsync(d_bb, 0, bytes, s) == hipSuccess;
+        ok = ok && tlc_launch_ball_bits(n, g->nw, g->d_bptr, g->d_bcol, d_bb, s) == TLC_OK;
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+        if (ok) g->d_bbits = d_bb;
+        else { hipFree(d_bb); (void)hipGetLastError(); }
+    }
     return TLC_OK;
 }
 
@@ -514,6 +531,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     g->opt_extract = env_on("TLC_EXTRACT"); g->opt_heavy = env_on("TLC_HEAVY"); g->opt_tiny = env_on("TLC_TINY");
     g->opt_ball_edges = env_on("TLC_BALL_EDGES"); g->opt_dc_inplace = env_on("TLC_DC_INPLACE") ? 1 : 0;
     g->opt_fast_split = env_on("TLC_FAST_SPLIT") ? 1 : 0;
+    g->opt_ball_bits = env_on("TLC_BALL_BITS") ? 1 : 0;
     g->opt_n_ws = 3;
     g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_timing_every = 1;
     int rc = TLC_OK;
@@ -615,6 +633,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     g->x_lds64 = tlc_extract_lds_bytes(nw, 64);
     g->x_lds512 = tlc_extract_lds_bytes(nw, 512);
     g->x_lds64f = tlc_extract_lds_bytes(nw, 64, true);
+    g->x_lds64fb = tlc_extract_lds_bytes(0, 64, true);
     // (the extraction kernel's workgroups are smaller: the scratch slots cover whichever kernel runs more of them)
     per_cu = std::max(per_cu, (int)std::min<size_t>(32, (160 * 1024) / std::max<size_t>(g->x_lds64 + 64, 1)));
     g->vic_slots = cus * per_cu;
@@ -651,7 +670,7 @@ extern "C" int tlc_graph_destroy(tlc_graph* g) {
     }
     hipFree(g->d_phase); hipFree(g->d_pair_t);
     hipFree(g->d_bptr); hipFree(g->d_bcol); hipFree(g->d_nrec); hipFree(g->d_hh_w);
-    hipFree(g->d_be_ptr); hipFree(g->d_be_pos); hipFree(g->d_be_w);
+    hipFree(g->d_be_ptr); hipFree(g->d_be_pos); hipFree(g->d_be_w); hipFree(g->d_bbits);
     hipFree(g->d_ball_ub[0]); hipFree(g->d_ball_ub[1]);
     if (g->ev_ring_ready)
         for (int r = 0; r < TLC_TIMING_RING; ++r)
@@ -816,7 +835,12 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         fp.region_base_wg = xgrid + TLC_EARLY_WG;
         fp.scratch_base_slot = 0;                             // (never used: its member lists fit the LDS)
         fp.work_counter = nullptr;
-        if ((rc = tlc_launch_extract(64, xfgrid, g->x_lds64f, fp, s, true)) != TLC_OK) return rc;
+        size_t flds = g->x_lds64f;
+        if (g->opt_ball_bits && g->d_bbits) {                 // (no bitmap of N bits in that launch's LDS: nw = 0 in its layout)
+            fp.bbits = g->d_bbits; fp.bb_nw = g->nw; fp.nw = 0;
+            flds = g->x_lds64fb;
+        }
+        if ((rc = tlc_launch_extract(64, xfgrid, flds, fp, s, true)) != TLC_OK) return rc;
         vp.fast_split = 1;
     }
     int* d_cand_count = ws->d_ctl + 16;
@@ -1669,6 +1693,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "ball_edges")) g->opt_ball_edges = value != 0;
     else if (!strcmp(name, "dc_inplace")) g->opt_dc_inplace = value != 0;
     else if (!strcmp(name, "fast_split")) g->opt_fast_split = value != 0;
+    else if (!strcmp(name, "ball_bits")) g->opt_ball_bits = value != 0;
     else if (!strcmp(name, "tier_mask")) g->opt_tier_mask = value;
     else if (!strcmp(name, "spec_cap")) g->opt_spec_cap = std::max(value, 0);
     else if (!strcmp(name, "n_ws")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_n_ws = std::min(std::max(value, 2), TLC_N_WS); }

@@ -603,8 +603,13 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
         if (has_pre && r == 0) bv[r] = pb0;             // (uniform) came with the call
         else bv[r] = j < nB ? p.bcol[b0 + j] : -1;
     }
+    // (FAST launch with ball bitmaps: the larger ball is not marked at all -- its row of p.bbits answers the membership test below)
+    const unsigned* bbrow = nullptr;
+    if constexpr (FAST) {
+        if (p.bbits) bbrow = p.bbits + (size_t)(((H.a1 - H.a0) < (H.b1 - H.b0)) ? v : u) * (size_t)p.bb_nw;   // (the node whose ball is [a0, a1))
+    }
     bool first = has_pre;
-    for (int j = tid; j < nA; j += 4 * BW) {
+    for (int j = tid; j < (bbrow ? 0 : nA); j += 4 * BW) {
         int av[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -637,7 +642,7 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
         for (int r = 0; r < 4; ++r) {
             if (base + r * BW >= nB) break;                              // (uniform)
             const int b = bv[r];
-            const bool h = b >= 0 && bit_test(X.bits, b);
+            const bool h = b >= 0 && (bbrow ? bit_test(bbrow, b) : bit_test(X.bits, b));
             int pos, tot;
             if (BW == 64) {
                 const unsigned long long m = __ballot(h);
@@ -661,7 +666,8 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
     x_sync<BW>();
     XSTAMP(3);
     // the marks of the larger ball go (by list when that is the shorter way)
-    if (nw4 > 4096 && nA * 8 < nw4) {                     // (re-reading the list is a global round trip: only for a large bitmap)
+    if (bbrow) {                                          // (nothing was marked)
+    } else if (nw4 > 4096 && nA * 8 < nw4) {              // (re-reading the list is a global round trip: only for a large bitmap)
         for (int j = tid; j < nA; j += BW) X.bits[p.bcol[a0 + j] >> 5] = 0u;
     } else {
         uint4* z = reinterpret_cast<uint4*>(X.bits);
@@ -1287,6 +1293,25 @@ __global__ __launch_bounds__(64) void tlc_ball_edges_kernel(int n_nodes, int nw,
         for (int k = lane; k < nb; k += TLC_WAVE) ebits[eid[k] >> 5] = 0u;
         __syncthreads();
     }
+}
+
+// ---- ball bitmaps (TlcVicParams::bbits): row x gets the bits of ball(x)'s sorted list; one wavefront per node, rows zeroed before ----
+__global__ __launch_bounds__(64) void tlc_ball_bits_kernel(int n_nodes, int nw, const int* __restrict__ bptr, const int* __restrict__ bcol,
+                                                           unsigned* __restrict__ bbits) {
+    for (int x = blockIdx.x; x < n_nodes; x += gridDim.x) {
+        const int b0 = bptr[x], b1 = bptr[x + 1];
+        unsigned* row = bbits + (size_t)x * (size_t)nw;
+        for (int j = b0 + (int)threadIdx.x; j < b1; j += 64) {
+            const int y = bcol[j];
+            atomicOr(&row[y >> 5], 1u << (y & 31));
+        }
+    }
+}
+int tlc_launch_ball_bits(int n_nodes, int nw, const int* bptr, const int* bcol, unsigned* bbits, void* stream) {
+    if (n_nodes <= 0) return TLC_OK;
+    hipLaunchKernelGGL(tlc_ball_bits_kernel, dim3(n_nodes < 16384 ? n_nodes : 16384), dim3(64), 0, (hipStream_t)stream, n_nodes, nw, bptr, bcol, bbits);
+    TLC_HIP_CHECK(hipGetLastError());
+    return TLC_OK;
 }
 
 int tlc_launch_ball_edges(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, const double* w, const int* bptr, const int* bcol,

@@ -171,6 +171,13 @@ struct TlcVicParams {
     const int* be_ptr;          // [n_nodes + 1]; be_ptr[x] == be_ptr[x + 1] for a node whose ball is larger
     const unsigned* be_pos;
     const double* be_w;
+    // ---- ball bitmaps (round 6): row x = the members of ball(x) as bb_nw words of 32 bits (n_nodes * bb_nw words: 48 MB for PubMed,
+    // resident in L2 / Infinity Cache like the lists).  The subgraph-list launch tests the smaller ball's members against the LARGER
+    // ball's row with one gather instead of marking that ball in an LDS bitmap per pair and clearing it again (half of a pair's time
+    // in that launch), and needs no N-bit bitmap in LDS: its launch runs with nw = 0.  Null: not built (a graph whose N^2 / 8 bytes
+    // are beyond the budget of api.hip: the LDS bitmap serves as before).
+    const unsigned* bbits;
+    int bb_nw;
     int fast_split;             // 1: a launch of tlc_extract_kernel<64, true> takes the pairs the subgraph lists serve; this one leaves them alone
     int early_min_ball;   // > 0: the early pass owns the pairs whose smaller ball has at least this many nodes (tlc_classify_kernel's candidates):
                           // the subgraph-list launch leaves them alone
@@ -326,6 +333,7 @@ int tlc_launch_classify(int n_pairs, const int* pairs, int n_nodes, const int* b
 int tlc_launch_tiny_sort(int count, const int* list, const int* hdr_n, const int* hdr_m2, int* out, void* stream, int shift = 0);
 int tlc_launch_ball_edges(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, const double* w, const int* bptr, const int* bcol,
                           int* esize, const int* be_ptr, unsigned* be_pos, double* be_w, int grid, void* stream);
+int tlc_launch_ball_bits(int n_nodes, int nw, const int* bptr, const int* bcol, unsigned* bbits, void* stream);   // rows zeroed by the caller
 int tlc_launch_ball_list(bool fill, int n_nodes, int nw, const int* rowptr, const int* col, int hop, int* bsize, const int* bptr,
                          int* bcol, int grid, void* stream);
 int tlc_launch_ball_bound(int n_nodes, const int* rowptr, const int* col, const int* prev, int* out, void* stream);

@@ -8,6 +8,8 @@ n, e, k, hop, _ = synth.shaped_graph("PubMed")
 rowptr, col, w = synth.edges_to_csr(n, e, k)
 g = engine.DeviceGraph(rowptr, col, w)
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+for k in range(2, len(sys.argv) - 1, 2):                  # python tools/time_sweep.py E [option value ...]
+    g.set_option(sys.argv[k], int(sys.argv[k + 1]))
 rs = np.random.RandomState(3)
 pairs = torch.as_tensor(rs.randint(0, n, size=(E, 2)).astype(np.int32)).cuda()
 out = torch.empty((E, 25), dtype=torch.float64, device="cuda")
