@@ -519,10 +519,14 @@ __global__ __launch_bounds__(GT_THREADS, 4) void gat_tile_kernel(int n_tiles, co
         __syncthreads();
     }
     // the head of a tile -- its node range and first in-edge slot: two dependent loads -- is fetched one tile ahead
-    int nx_base = 0, nx_tn = 0, nx_eb0 = 0, nx_ne = 0;
+    // (a caller-made cut with an empty tile or one of more rows than the LDS tile holds: the tile is run as ONE row -- every index below
+    // stays inside the tile's regions -- and its rows come back as NaN: loud, nothing overrun.  A cut of tlc_gat_tile_cut never has one.
+    // Kept to two scalars and one predicate on the stores: a separate path for such a tile cost the kernel 12 registers and spills.)
+    int nx_base = 0, nx_tn = 0, nx_eb0 = 0, nx_ne = 0, nx_raw = 0;
     auto head = [&](int t) {
         if (t < n_tiles) {
-            nx_base = tile_ptr[t]; nx_tn = tile_ptr[t + 1] - nx_base;
+            nx_base = tile_ptr[t]; nx_raw = tile_ptr[t + 1] - nx_base;
+            nx_tn = (nx_raw < 1 || nx_raw > GT_TM) ? 1 : nx_raw;
             nx_eb0 = rowptr[nx_base]; nx_ne = rowptr[nx_base + nx_tn] - nx_eb0;
         }
     };
@@ -546,7 +550,6 @@ __global__ __launch_bounds__(GT_THREADS, 4) void gat_tile_kernel(int n_tiles, co
     // (every load unconditional at a clamped index, the raw value kept: a load inside `if (k < ne)` is waited for inside its own
     // branch, and the six loads of a tile's phase 0 became six round trips one after the other)
     auto fetch = [&]() {                                          // (of the tile whose head is in nx_*)
-        if (nx_tn < 1 || nx_tn > GT_TM) return;                   // (uniform; not a tile of tlc_gat_tile_cut: refused below)
         st_rp = rowptr[nx_base + (tid <= nx_tn ? tid : nx_tn)];
         if (nx_ne > 0 && nx_ne <= GT_EM) {                        // (uniform)
 #pragma unroll
@@ -561,13 +564,11 @@ __global__ __launch_bounds__(GT_THREADS, 4) void gat_tile_kernel(int n_tiles, co
     if ((int)blockIdx.x < n_tiles) fetch();
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int base = nx_base, tn = nx_tn, eb0 = nx_eb0, ne = nx_ne;
-        if (tn < 1 || tn > GT_TM) {
-            // (uniform) a caller-made cut with an empty tile or more rows than the LDS tile holds: its rows come back as NaN -- loud, and
-            // nothing is written past the tile's regions (a cut of tlc_gat_tile_cut never gets here)
-            for (long long i = tid; i < (long long)(tn > 0 ? tn : 0) * 2 * C; i += GT_THREADS) out[(size_t)base * 2 * C + i] = __builtin_nanf("");
-            head(tile + (int)gridDim.x);
-            fetch();
-            continue;
+        const bool bad = nx_raw != tn;                            // (uniform)
+        if (bad) {
+            const long long left = (long long)tile_ptr[n_tiles] - base;
+            const long long rows = nx_raw < 1 ? 0 : ((long long)nx_raw < left ? (long long)nx_raw : left);
+            for (long long i = tid; i < rows * 2 * C; i += GT_THREADS) out[(size_t)base * 2 * C + i] = __builtin_nanf("");
         }
         const bool staged = ne <= GT_EM;
         // ---- phase 0: row bounds and tile-local source ids (fetched during the tile before) --------------------------------
@@ -685,8 +686,10 @@ __global__ __launch_bounds__(GT_THREADS, 4) void gat_tile_kernel(int n_tiles, co
                             o_mm[k] = o_mm[k] > 0.0f ? o_mm[k] : prelu_slope * o_mm[k];
                         }
                     }
-                    *reinterpret_cast<gt_f32x4*>(out + (size_t)(base + li) * 2 * C + c) = o_sum;
-                    *reinterpret_cast<gt_f32x4*>(out + (size_t)(base + li) * 2 * C + C + c) = o_mm;
+                    if (!bad) {
+                        *reinterpret_cast<gt_f32x4*>(out + (size_t)(base + li) * 2 * C + c) = o_sum;
+                        *reinterpret_cast<gt_f32x4*>(out + (size_t)(base + li) * 2 * C + C + c) = o_mm;
+                    }
                 }
             };
             if (staged) nodes(std::true_type{}); else nodes(std::false_type{});
