@@ -1560,6 +1560,11 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
         if (slot && tid == 0) *(int*)slot = 0;
         if (i < 0) continue;              // (a slot of the early arena whose vicinity turned out not to be of this tier: extract.hip)
         const int n = p.hdr_n[i], m2 = p.hdr_m2[i], lu = p.hdr_lu[i], lv = p.hdr_lv[i];
+#ifndef TLC_NO_SIZE_ASSUME
+        // (the scan bins a vicinity by these sizes: told to the compiler, a `for (k = tid; k < n; k += W)` of a tier with NM <= W is
+        // an `if`, and the entry loops have a known maximum trip count)
+        if constexpr (!HUGE) { __builtin_assume(n >= 1 && n <= NM); __builtin_assume(m2 >= 0 && m2 <= 2 * MM); }
+#endif
         const long long eo = p.slot_entries ? (long long)wi * p.slot_entries : p.edge_off[i];
         const int m = m2 >> 1;
         const bool far = (lu < 0);        // u in S <=> v in S <=> d(u,v) <= hop  
