@@ -1422,10 +1422,13 @@ __device__ __forceinline__ double tlc_norm_cdf(double x) {
 // SW = the width the pixel sums are sliced for (S = SW / res^2 point slices per pixel, a point's slice = its index mod S, so the
 // summation order -- and with it the last bit of the image -- depends on SW only, not on W or on the table size: the MID /
 // MEDIUM tier kernels pass 64 so that a subgraph gives the same bits whether its image is made here or in tlc_pd_swap_kernel).
-template <int W, bool BOUNDED, int SW, class Get>
-__device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get get, int first, int last, int res,
-                                           double acc) {
+// RES: the resolution as a compile-time constant (0: `res` at run time).  The stage divides by 2 res + 3, res^2 and res per table entry
+// and per thread; with the reference's resolution 5 known they are multiplications (pi_stage below picks the instance).
+template <int W, bool BOUNDED, int SW, int RES, class Get>
+__device__ __forceinline__ double pi_stage_impl(double* tbl, size_t table_bytes, Get get, int first, int last, int res_rt,
+                                                double acc) {
     const int tid = threadIdx.x;
+    const int res = RES > 0 ? RES : res_rt;
     const int G = res + 1, stride = 2 * G + 1, res2 = res * res;
     int batch = (int)(table_bytes / ((size_t)stride * 8));
     if (batch > W) batch = W;
@@ -1478,6 +1481,13 @@ __device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get 
     }
     return acc + acc_in;
 }
+template <int W, bool BOUNDED, int SW, class Get>
+__device__ __forceinline__ double pi_stage(double* tbl, size_t table_bytes, Get get, int first, int last, int res, double acc) {
+#ifndef TLC_NO_RES5
+    if (res == 5) return pi_stage_impl<W, BOUNDED, SW, 5>(tbl, table_bytes, get, first, last, res, acc);   // (uniform)
+#endif
+    return pi_stage_impl<W, BOUNDED, SW, 0>(tbl, table_bytes, get, first, last, res, acc);
+}
 
 }  // namespace
 
@@ -1488,7 +1498,10 @@ __device__ __forceinline__ void dc_subgraph(const TlcPdParams& p, int wi, unsign
 // ======================================================================================================================
 // Batch kernel: one workgroup per vicinity subgraph of one size tier.
 // ======================================================================================================================
-template <int NM, int MM, int W, bool LWL, bool HUGE>
+// PLAIN: the launch is the plain TLC-GNN image batch -- flags == 0, images at resolution 5, none of tlc_vicinity_filtration's outputs
+// (tlc_launch_pd_tier checks): those parameters are constants of the instance, and every branch on a variant flag, the filtration /
+// edge outputs and the divisions by the resolution drop out of the kernel the bench batch runs.
+template <int NM, int MM, int W, bool LWL, bool HUGE, bool PLAIN = false>
 #ifdef TLC_PHASE_DEBUG
 __global__ __launch_bounds__(W) void tlc_pd_tier_kernel(TlcPdParams p) {       // (the counters need the registers)
 #else
@@ -1501,6 +1514,10 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
 #endif
     typedef unsigned short idx_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if constexpr (PLAIN) {
+        p.flags = 0u; p.res = 5; p.pi_enabled = 1;
+        p.out_f = nullptr; p.out_n = nullptr; p.out_edges = nullptr; p.out_m = nullptr; p.ids_off = nullptr; p.edges_off = nullptr;
+    }
     const int tid = threadIdx.x;
     unsigned char* base;
     Layout L;
@@ -1954,9 +1971,10 @@ __device__ __forceinline__ void swap_subgraph(const TlcPdParams& p, int wi, unsi
     __syncthreads();
 }
 
-template <int NM, int MM>
+template <int NM, int MM, bool PLAIN = false>
 __global__ __launch_bounds__(64, 4) void tlc_pd_swap_kernel(TlcPdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if constexpr (PLAIN) { p.flags = 0u; p.res = 5; p.pi_enabled = 1; }           // (see tlc_pd_tier_kernel)
     if (p.abort_flag && *p.abort_flag) return;
     int tier_count = p.tier_count;
     if (p.tier_count_dev) { const int c = *p.tier_count_dev; tier_count = c < tier_count ? c : tier_count; }
@@ -2427,6 +2445,9 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
     // tiers with a hand-off buffer leave the cycle swap + image of their subgraphs to tlc_pd_swap_kernel, same stream
     const bool deferring = p.handoff != nullptr && p.pi_enabled && !(p.flags & TLC_NO_EXT1);
     const int grid = p.grid > 0 ? p.grid : p.tier_count;
+    // (the instances with the plain image batch's parameters as constants: tlc_pd_tier_kernel's PLAIN; TLC_PLAIN_KERNELS=0: the general ones)
+    static const bool plain_on = !(getenv("TLC_PLAIN_KERNELS") && getenv("TLC_PLAIN_KERNELS")[0] == '0');
+    const bool plain = plain_on && p.flags == 0u && p.res == 5 && p.pi_enabled && !p.out_f && !p.out_n && !p.out_edges && !p.out_m;
     static const bool host_trace = getenv("TLC_HOST_TRACE") != nullptr;
     if (host_trace) {                                 // (development: LDS bytes per workgroup of every kernel of the tiers)
         static int once = 0;
@@ -2444,19 +2465,29 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             // (development: TLC_SMALL_LDS_PAD=bytes inflates this tier's footprint -- the experiment behind DESIGN.md's "the tier
             // phase is bound by LDS capacity x time": +4 KB here costs the batch 2.5 %, +16 KB 20 %)
             static const size_t pad = getenv("TLC_SMALL_LDS_PAD") ? (size_t)atoi(getenv("TLC_SMALL_LDS_PAD")) : 0;
-            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_S_NMAX, TLC_S_MMAX, 64, TLC_SMALL_LWL, false>), dim3(p.tier_count), dim3(64),
-                               L.total + pad, s, p);
+            if (plain)
+                hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_S_NMAX, TLC_S_MMAX, 64, TLC_SMALL_LWL, false, true>), dim3(p.tier_count), dim3(64),
+                                   L.total + pad, s, p);
+            else
+                hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_S_NMAX, TLC_S_MMAX, 64, TLC_SMALL_LWL, false>), dim3(p.tier_count), dim3(64),
+                                   L.total + pad, s, p);
             break;
         }
         case TLC_TIER_MEDIUM: {
             constexpr Layout L = make_layout(TLC_C_NMAX, TLC_C_MMAX, false, 2);
             static const size_t mpad = getenv("TLC_MEDIUM_LDS_PAD") ? (size_t)atoi(getenv("TLC_MEDIUM_LDS_PAD")) : 0;
-            if (p.phase != 2)
-                hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_C_NMAX, TLC_C_MMAX, 256, false, false>), dim3(grid),
-                                   dim3(256), L.total + mpad, s, p);
+            if (p.phase != 2) {
+                if (plain)
+                    hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_C_NMAX, TLC_C_MMAX, 256, false, false, true>), dim3(grid),
+                                       dim3(256), L.total + mpad, s, p);
+                else
+                    hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_C_NMAX, TLC_C_MMAX, 256, false, false>), dim3(grid),
+                                       dim3(256), L.total + mpad, s, p);
+            }
             if (deferring && p.phase != 1) {
                 constexpr SwapLayout SL = make_swap_layout(TLC_C_NMAX, TLC_C_MMAX);
-                hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_C_NMAX, TLC_C_MMAX>), dim3(grid), dim3(64), SL.total, s, p);
+                if (plain) hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_C_NMAX, TLC_C_MMAX, true>), dim3(grid), dim3(64), SL.total, s, p);
+                else hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_C_NMAX, TLC_C_MMAX>), dim3(grid), dim3(64), SL.total, s, p);
             }
             break;
         }
@@ -2465,9 +2496,14 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             constexpr Layout L = make_layout(TLC_M_NMAX, TLC_M_MMAX, false, 2);
             // (development: TLC_MEDIUM_LDS_PAD=bytes -- how much does this tier's footprint cost?  37.5 KB = four workgroups per CU)
             static const size_t mpad = getenv("TLC_MEDIUM_LDS_PAD") ? (size_t)atoi(getenv("TLC_MEDIUM_LDS_PAD")) : 0;
-            if (p.phase != 2)
-                hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, false, false>), dim3(grid),
-                                   dim3(256), L.total + mpad, s, p);
+            if (p.phase != 2) {
+                if (plain)
+                    hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, false, false, true>), dim3(grid),
+                                       dim3(256), L.total + mpad, s, p);
+                else
+                    hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_M_NMAX, TLC_M_MMAX, 256, false, false>), dim3(grid),
+                                       dim3(256), L.total + mpad, s, p);
+            }
             // (a dc list on the launch: the scan counted vicinities with Pos edges enough -- dense hop-1 vicinities of the Amazon
             // shapes, 600 Pos edges on 80 nodes -- and the tier kernel marked them; the rest stay for the swap kernel behind)
             if (deferring && p.phase != 1 && p.dc_count) {
@@ -2476,15 +2512,21 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             }
             if (deferring && p.phase != 1) {
                 constexpr SwapLayout SL = make_swap_layout(TLC_M_NMAX, TLC_M_MMAX);
-                hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_M_NMAX, TLC_M_MMAX>), dim3(grid), dim3(64), SL.total, s, p);
+                if (plain) hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_M_NMAX, TLC_M_MMAX, true>), dim3(grid), dim3(64), SL.total, s, p);
+                else hipLaunchKernelGGL((tlc_pd_swap_kernel<TLC_M_NMAX, TLC_M_MMAX>), dim3(grid), dim3(64), SL.total, s, p);
             }
             break;
         }
         case TLC_TIER_MID: {
             constexpr Layout L = make_layout(TLC_D_NMAX, TLC_D_MMAX, false, 2);
-            if (p.phase != 2)
-                hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_D_NMAX, TLC_D_MMAX, TLC_D_THREADS, false, false>), dim3(grid),
-                                   dim3(TLC_D_THREADS), L.total, s, p);
+            if (p.phase != 2) {
+                if (plain)
+                    hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_D_NMAX, TLC_D_MMAX, TLC_D_THREADS, false, false, true>), dim3(grid),
+                                       dim3(TLC_D_THREADS), L.total, s, p);
+                else
+                    hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_D_NMAX, TLC_D_MMAX, TLC_D_THREADS, false, false>), dim3(grid),
+                                       dim3(TLC_D_THREADS), L.total, s, p);
+            }
             break;                                                    // (no hand-off: tlc_handoff_slot_bytes)
         }
         case TLC_TIER_LARGE: {
@@ -2497,10 +2539,15 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             // room for two SMALL or one MID / swap workgroup: pipelined batch 0.526 -> 0.517 ms (two alternating runs), one batch alone equal.
             static const int excl = getenv("TLC_LARGE_EXCL") ? atoi(getenv("TLC_LARGE_EXCL")) : 0;
             const size_t lds_bytes = (L.total > 156 * 1024 || !(excl & 1)) ? L.total : 156 * 1024;
-            int rc = set_lds_limit(tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>, lds_bytes);
+            int rc = plain ? set_lds_limit(tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false, true>, lds_bytes)
+                           : set_lds_limit(tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>, lds_bytes);
             if (rc) return rc;
-            hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>), dim3(p.tier_count),
-                               dim3(TLC_L_THREADS), lds_bytes, s, p);
+            if (plain)
+                hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false, true>), dim3(p.tier_count),
+                                   dim3(TLC_L_THREADS), lds_bytes, s, p);
+            else
+                hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_L_NMAX, TLC_L_MMAX, TLC_L_THREADS, false, false>), dim3(p.tier_count),
+                                   dim3(TLC_L_THREADS), lds_bytes, s, p);
             if (deferring) {
                 // (only the subgraphs marked for the divide and conquer were handed off; tlc_pd_dc_kernel runs the serial walk itself
                 // for those it gives back)
