@@ -542,6 +542,15 @@ __device__ __forceinline__ void extract_pair(const PB& p, int i, bool from_rest,
 #ifdef TLC_PAIR_TIMES
     const unsigned long long t_start = wall_clock64();
 #endif
+#ifndef TLC_NO_FAST_ASSUME
+    if constexpr (FAST) {
+        // what api.hip's subgraph-list launch always passes (run_chunk_front, `fp`): told to the compiler, the branches on them and the
+        // scalar loads of the fields behind them leave the per-pair code (every field of p is re-read per pair, see the kernel)
+        __builtin_assume(p.x_fill == 0); __builtin_assume(p.fill_mode == 0); __builtin_assume(p.early_list == nullptr);
+        __builtin_assume(p.skip_count == nullptr); __builtin_assume(p.big_count == nullptr); __builtin_assume(p.be_ptr != nullptr);
+        __builtin_assume((p.flags & TLC_INCLUDE_ROOTS) == 0u); __builtin_assume(p.bump_top != nullptr);
+    }
+#endif
     const int u = H.u, v = H.v;
     // KeyError on dict_node (riccidist2dgm.py:353): ids the edge-built graph does not contain
     bool missing = u < 0 || v < 0 || u >= p.n_nodes || v >= p.n_nodes;
