@@ -162,8 +162,8 @@ int tlc_pd_pi_algorithmic_bytes(int32_t n_nodes, const int32_t* h_rowptr, const 
  * phase_profile(): per-phase cycle counters of the tier kernels in a library built with `make PHASE_DEBUG=1` (all zero
  * otherwise): rows of 32 u64, one per tier and one for the early pass; at most cap_u64 values are written to h_out (may be
  * null), *n_rows (may be null) = rows kept.  enable != 0 starts counting, 0 stops and frees the counters.
- * set_option(): the thirteen switches of one handle, each exercised by a test that checks that results do not depend on it
- * (tests/test_gpu_extract.py, tests/test_gpu_tiers.py, tests/test_gpu_pd_parity.py); 1 = on is the default of the first seven:
+ * set_option(): the fourteen switches of one handle, each exercised by a test that checks that results do not depend on it
+ * (tests/test_gpu_extract.py, tests/test_gpu_tiers.py, tests/test_gpu_pd_parity.py); 1 = on is the default of the first eight:
  *   "extract"      ball-list extraction of the vicinities (any hop since round 5; 0: the breadth-first kernels; TLC_EXTRACT=0 at creation)
  *   "heavy"        its hub-row skipping (TLC_HEAVY=0)
  *   "tiny"         lane-per-subgraph kernel for vicinities of at most 16 nodes / 24 edges (TLC_TINY=0)
@@ -171,6 +171,8 @@ int tlc_pd_pi_algorithmic_bytes(int32_t n_nodes, const int32_t* h_rowptr, const 
  *   "fast_split"   ... in a launch of their own beside the classification and the early pass (TLC_FAST_SPLIT=0)
  *   "ball_bits"    ... which tests membership in the larger ball against per-node ball bitmaps (N^2 / 8 bytes, built up to 1 GiB)
  *                  instead of marking that ball in an LDS bitmap per pair (round 6; TLC_BALL_BITS=0)
+ *   "plain_kernels" the tier / swap kernel instances that have a plain image batch's parameters (flags 0, resolution 5, no filtration
+ *                  outputs) as compile-time constants (round 6; 0: the general instances; TLC_PLAIN_KERNELS=0)
  *   "dc_inplace"   the LARGE tier's divide and conquer by the tier kernel's own workgroup (0: tlc_pd_dc_kernel; TLC_DC_INPLACE=0)
  *   "dc_force_fail" every divide-and-conquer solve given back to the serial walk (test hook)
  *   "spec_cap"     slots reserved for the speculative tier launches (test hook: beyond them the second-launch / in-kernel paths)

@@ -378,7 +378,8 @@ def test_subgraph_list_extraction_equals_the_row_sweep(shape, scale, hop, n_pos)
     LARGE tier runs its divide and conquer in place.  Against the row sweep (ball_edges=0): status bytes, |S| and entry counts
     equal, images within 1e-12 (the entries of a vicinity come in another order); fast_split=0 (the same lists inside the general
     launch), dc_inplace=0 (tlc_pd_dc_kernel from the same record) and ball_bits=0 (round 6: that launch tests membership in the larger
-    ball against the per-node ball bitmaps instead of a bitmap it marks in LDS): the SAME bits.  Batches above and below the early pass's
+    ball against the per-node ball bitmaps instead of a bitmap it marks in LDS) and plain_kernels=0 (round 6: the tier / swap kernels without
+    the plain batch's parameters as compile-time constants): the SAME bits.  Batches above and below the early pass's
     minimum size, hop 1 and 2, sparse and dense graphs; and against the oracle."""
     import torch
     from tlc_gnn_amd import engine, synth
@@ -394,8 +395,10 @@ def test_subgraph_list_extraction_equals_the_row_sweep(shape, scale, hop, n_pos)
     one = _run(g, torch, pairs, hop, fast_split=0)
     dck = _run(g, torch, pairs, hop, dc_inplace=0)
     nbb = _run(g, torch, pairs, hop, ball_bits=0)                 # (round 6) the larger ball marked in LDS instead of the ball bitmaps
+    gen = _run(g, torch, pairs, hop, plain_kernels=0)             # (round 6) the general tier / swap kernel instances
     g.close()
-    for other, name, bits in ((sweep, "ball_edges=0", False), (one, "fast_split=0", True), (dck, "dc_inplace=0", True), (nbb, "ball_bits=0", True)):
+    for other, name, bits in ((sweep, "ball_edges=0", False), (one, "fast_split=0", True), (dck, "dc_inplace=0", True), (nbb, "ball_bits=0", True),
+                              (gen, "plain_kernels=0", True)):
         assert np.array_equal(new[1], other[1]), name
         assert np.array_equal(new[2], other[2]), name
         assert np.array_equal(new[3], other[3]), name

@@ -201,6 +201,7 @@ struct tlc_graph {
     int opt_ball_edges;            // the extraction filters the smaller ball's subgraph list where there is one (extract.hip, x_sweep_ball)
     int opt_ball_bits;             // the subgraph-list launch tests membership in the larger ball against the per-node ball bitmaps (TlcVicParams::bbits)
     int opt_dc_force_fail;              // tests: see TlcPdParams::dc_force_fail
+    int opt_plain_kernels;              // the PLAIN instances of the tier / swap kernels for plain image batches (tlc_launch_pd_tier); 0: the general ones
     int count_only;                     // set by tlc_vicinity_sizes around its run_batch: chunks stop after the scan, their sizes are copied out
     int opt_n_ws;                       // workspaces taken in turn (2..TLC_N_WS, default 3)
     int opt_spec_cap;                   // tests: upper bound of the slots reserved for the speculative launches (0 = none)
@@ -532,6 +533,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     g->opt_ball_edges = env_on("TLC_BALL_EDGES"); g->opt_dc_inplace = env_on("TLC_DC_INPLACE") ? 1 : 0;
     g->opt_fast_split = env_on("TLC_FAST_SPLIT") ? 1 : 0;
     g->opt_ball_bits = env_on("TLC_BALL_BITS") ? 1 : 0;
+    g->opt_plain_kernels = env_on("TLC_PLAIN_KERNELS") ? 1 : 0;
     g->opt_n_ws = 3;
     g->opt_x_region = TLC_X_REGION; g->opt_x_bump_min = 1 << 20; g->opt_tier_mask = (1 << TLC_N_TIERS) - 1; g->opt_timing_every = 1;
     int rc = TLC_OK;
@@ -857,6 +859,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
     pp.stats = ws->d_stats;
     pp.dc_force_fail = g->opt_dc_force_fail;
+    pp.no_plain = g->opt_plain_kernels ? 0 : 1;
     // lists for tlc_pd_dc_kernel: counters in the control block (zeroed with it), [d_ctl + 26 + 2k];
     // k = 0 MEDIUM, 1 LARGE (regular launch), 2 LARGE (early launch)
     auto dc_lists_for = [&](TlcPdParams& q, int k) {
@@ -1694,6 +1697,7 @@ extern "C" int tlc_debug_set_option(tlc_graph* g, const char* name, int value) {
     else if (!strcmp(name, "dc_inplace")) g->opt_dc_inplace = value != 0;
     else if (!strcmp(name, "fast_split")) g->opt_fast_split = value != 0;
     else if (!strcmp(name, "ball_bits")) g->opt_ball_bits = value != 0;
+    else if (!strcmp(name, "plain_kernels")) g->opt_plain_kernels = value != 0;
     else if (!strcmp(name, "tier_mask")) g->opt_tier_mask = value;
     else if (!strcmp(name, "spec_cap")) g->opt_spec_cap = std::max(value, 0);
     else if (!strcmp(name, "n_ws")) { int rc_p = finish_pending(g); if (rc_p != TLC_OK) return rc_p; g->opt_n_ws = std::min(std::max(value, 2), TLC_N_WS); }

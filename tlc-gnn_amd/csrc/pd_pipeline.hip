@@ -2448,9 +2448,8 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
     // tiers with a hand-off buffer leave the cycle swap + image of their subgraphs to tlc_pd_swap_kernel, same stream
     const bool deferring = p.handoff != nullptr && p.pi_enabled && !(p.flags & TLC_NO_EXT1);
     const int grid = p.grid > 0 ? p.grid : p.tier_count;
-    // (the instances with the plain image batch's parameters as constants: tlc_pd_tier_kernel's PLAIN; TLC_PLAIN_KERNELS=0: the general ones)
-    static const bool plain_on = !(getenv("TLC_PLAIN_KERNELS") && getenv("TLC_PLAIN_KERNELS")[0] == '0');
-    const bool plain = plain_on && p.flags == 0u && p.res == 5 && p.pi_enabled && !p.out_f && !p.out_n && !p.out_edges && !p.out_m;
+    // (the instances with the plain image batch's parameters as constants: tlc_pd_tier_kernel's PLAIN; handle option plain_kernels = 0: the general ones)
+    const bool plain = !p.no_plain && p.flags == 0u && p.res == 5 && p.pi_enabled && !p.out_f && !p.out_n && !p.out_edges && !p.out_m;
     static const bool host_trace = getenv("TLC_HOST_TRACE") != nullptr;
     if (host_trace) {                                 // (development: LDS bytes per workgroup of every kernel of the tiers)
         static int once = 0;

@@ -284,6 +284,7 @@ struct TlcPdParams {
     int* dc_list;
     int dc_inplace;              // LARGE tier: the tier kernel's own workgroup runs the divide and conquer from the record (no tlc_pd_dc_kernel launch)
     int dc_force_fail;           // tests: tlc_pd_dc_kernel treats every solve as failed (the give-back path to the serial walk)
+    int no_plain;                // 1: tlc_launch_pd_tier takes the general kernel instances even for a plain image batch (option plain_kernels = 0)
     int grid;
     int wi_base;                   // LDS tiers: list position of workgroup 0 (a launch that completes a shorter one)
     int phase;                   // 0 = tier kernel + its swap kernel, 1 = tier kernel only, 2 = swap kernel only
