@@ -2442,6 +2442,9 @@ static int set_lds_limit(K kernel, size_t bytes) {
     return TLC_OK;
 }
 
+#ifndef TLC_C_THREADS
+#define TLC_C_THREADS 256          /* threads of the compact MEDIUM tier kernel (128 measured: see DESIGN_HISTORY.md, round 6) */
+#endif
 int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (p.tier_count <= 0) return TLC_OK;
@@ -2480,11 +2483,11 @@ int tlc_launch_pd_tier(int tier, const TlcPdParams& p, void* stream) {
             static const size_t mpad = getenv("TLC_MEDIUM_LDS_PAD") ? (size_t)atoi(getenv("TLC_MEDIUM_LDS_PAD")) : 0;
             if (p.phase != 2) {
                 if (plain)
-                    hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_C_NMAX, TLC_C_MMAX, 256, false, false, true>), dim3(grid),
-                                       dim3(256), L.total + mpad, s, p);
+                    hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_C_NMAX, TLC_C_MMAX, TLC_C_THREADS, false, false, true>), dim3(grid),
+                                       dim3(TLC_C_THREADS), L.total + mpad, s, p);
                 else
-                    hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_C_NMAX, TLC_C_MMAX, 256, false, false>), dim3(grid),
-                                       dim3(256), L.total + mpad, s, p);
+                    hipLaunchKernelGGL((tlc_pd_tier_kernel<TLC_C_NMAX, TLC_C_MMAX, TLC_C_THREADS, false, false>), dim3(grid),
+                                       dim3(TLC_C_THREADS), L.total + mpad, s, p);
             }
             if (deferring && p.phase != 1) {
                 constexpr SwapLayout SL = make_swap_layout(TLC_C_NMAX, TLC_C_MMAX);

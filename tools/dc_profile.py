@@ -7,6 +7,7 @@ from tlc_gnn_amd import engine, _lib
 wl = bench.build_workload(0)
 g = engine.DeviceGraph(wl["rowptr"], wl["col"], wl["w"])
 pairs = torch.as_tensor(wl["pi_pairs"]).cuda()
+g.set_option("dc_inplace", 0)      # (the stamps are tlc_pd_dc_kernel's: in place, the tier kernel's own phase row overwrites them)
 L = _lib.lib()
 L.tlc_debug_phase_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
 g.pd_pi_batch(pairs, 2)
