@@ -11,6 +11,11 @@ rowptr, col, w = synth.edges_to_csr(n, e, k)
 g = engine.DeviceGraph(rowptr, col, w)
 rs = np.random.RandomState(7)
 pairs = torch.as_tensor(e[rs.permutation(len(e))[:37676]].astype(np.int32)).cuda()
+if len(sys.argv) > 1 and sys.argv[1] == "bench":         # the bench batch itself (bench.build_workload: the training graph, its 37 676 positives)
+    import bench
+    Wb = bench.build_workload(0)
+    g = engine.DeviceGraph(Wb["rowptr"], Wb["col"], Wb["w"])
+    pairs = torch.as_tensor(Wb["pi_pairs"]).cuda()
 if len(sys.argv) > 1 and sys.argv[1] == "near":          # the strong-scaling list: non-edges within hop distance
     ci = engine.ComplementIndex(rowptr, col, device=0)
     near, ranks = engine.near_pairs(ci, hop)
