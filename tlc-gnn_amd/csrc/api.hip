@@ -73,6 +73,8 @@ struct ChunkCtx {
     hipStream_t s;
     int n_pairs, hop, pi_enabled;
     bool bump, use_x, early, spec, count_only, tiny_bins, pipelined;
+    bool plain, fsplit;            // a plain image batch (no filtration outputs); the subgraph-list pairs have a launch of their own
+    int xfgrid;                    // ... of this many workgroups
     long long bump_base;
     int xgrid, vgrid, tmask;
     unsigned seq;
@@ -700,10 +702,29 @@ __global__ void tlc_wait_started_dev(const int* counter, const int* target, int 
         __builtin_amdgcn_s_sleep(8);
 }
 
-static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_pairs, int hop, uint32_t flags, int res,
-                     double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
-                     double* d_out_f, int32_t* d_out_n, const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m,
-                     int pi_enabled, hipStream_t s, bool pipelined) {
+// The first half of a chunk, by stage (round 6: one 350-line function before).  The stages share the chunk's context (ChunkCtx: the
+// parameter blocks of the extraction and of the tier kernels, what the preparation decided) and are submitted in this order:
+//   front_prepare      buffers, parameter blocks, which extraction serves the chunk, arena layout
+//   front_fast         the fork of the early chain, then the subgraph-list launch (needs nothing from the classification)
+//   front_early_chain  classification -> early pass -> LARGE tier kernel on the early stream; the residency gate on the chunk's stream
+//   front_main_scan    the general extraction launch and the scan that publishes the chunk's sizes
+//   front_speculative  (a chunk on its own) the many-Pos MEDIUM list behind the scan, sized from the previous chunk
+#define T0(k, st) do { if ((c.tmask >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(c.ev_t[2 * (k)], st)); } } while (0)
+#define T1(k, st) do { if ((c.tmask >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(c.ev_t[2 * (k) + 1], st)); c.ev_used[k] = 1; } } while (0)
+// lists for tlc_pd_dc_kernel: counters in the control block (zeroed with it), [d_ctl + 26 + 2k];
+// k = 0 MEDIUM, 1 LARGE (regular launch), 2 LARGE (early launch)
+static inline void dc_lists_for(Workspace* ws, TlcPdParams& q, int k) {
+    const size_t cap = ws->cap_pairs + TLC_EARLY_SLOTS;
+    q.dc_count = ws->d_ctl + 26 + 2 * k;
+    q.dc_list = ws->dc_lists + (size_t)k * cap;
+}
+// timing slot of each tier kernel (TINY is reported with SMALL, MEDHI / MEDWIDE as MEDIUM)
+static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4, 4};
+
+static int front_prepare(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_pairs, int hop, uint32_t flags, int res,
+                         double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
+                         double* d_out_f, int32_t* d_out_n, const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m,
+                         int pi_enabled, hipStream_t s, bool pipelined) {
     int rc;
     ChunkCtx& c = ws->ctx;
     c.ht0 = std::chrono::steady_clock::now();
@@ -757,8 +778,6 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     }
     c.tmask = tmask; c.vgrid = vgrid;
     g->last_n_pairs = n_pairs;
-#define T0(k, st) do { if ((tmask >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(c.ev_t[2 * (k)], st)); } } while (0)
-#define T1(k, st) do { if ((tmask >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(c.ev_t[2 * (k) + 1], st)); c.ev_used[k] = 1; } } while (0)
     // ---- early pass --------------------------------------------------------------------------------------------------------
     // The batch waits for its largest vicinity: 0.9 ms of mostly serial work that used to start only after COUNT, the scan,
     // the size publication and the heavy FILL (0.31 ms into the batch).  The pairs that can be that large are known up
@@ -824,6 +843,31 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         vp.A_dir = ws->A_dir; vp.A_lw = ws->A_lw;
         vp.bump_top = d_bump_top; vp.bump_cap = (long long)ws->cap_entries; vp.bump_overflow = d_bump_overflow;
     }
+    TlcPdParams& pp = c.pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.hdr_n = ws->hdr_n; pp.hdr_m2 = ws->hdr_m2; pp.hdr_lu = ws->hdr_lu; pp.hdr_lv = ws->hdr_lv;
+    pp.edge_off = ws->edge_off;
+    pp.small_dir = use_x ? nullptr : ws->S_dir; pp.small_lw = use_x ? nullptr : ws->S_lw;
+    pp.flags = flags; pp.res = res; pp.out_pi = d_out_pi; pp.out_status = d_out_status;
+    pp.ids_off = (const long long*)d_ids_off; pp.out_f = d_out_f; pp.out_n = d_out_n; pp.pi_enabled = pi_enabled;
+    pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
+    pp.stats = ws->d_stats;
+    pp.dc_force_fail = g->opt_dc_force_fail;
+    pp.no_plain = g->opt_plain_kernels ? 0 : 1;
+    c.bump = bump; c.use_x = use_x; c.early = early; c.bump_base = bump_base; c.xgrid = xgrid;
+    c.plain = plain; c.fsplit = fsplit; c.xfgrid = xfgrid; c.pipelined = pipelined; c.spec = false;
+    c.count_only = g->count_only != 0;
+    return TLC_OK;
+}
+
+// the fork of the early chain and the launch of the subgraph-list pairs
+static int front_fast(tlc_graph* g, Workspace* ws) {
+    int rc;
+    ChunkCtx& c = ws->ctx;
+    TlcVicParams& vp = c.vp;
+    hipStream_t s = c.s;
+    const int hop = c.hop, xgrid = c.xgrid, xfgrid = c.xfgrid;
+    const bool early = c.early, use_x = c.use_x, fsplit = c.fsplit;
     if (early) {
         // (the fork of the early chain: ahead of the FAST launch, which runs beside it; the one-off ball bounds go in front of it)
         if ((rc = ensure_early(g, ws, hop, s)) != TLC_OK) return rc;
@@ -845,28 +889,24 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         if ((rc = tlc_launch_extract(64, xfgrid, flds, fp, s, true)) != TLC_OK) return rc;
         vp.fast_split = 1;
     }
+    return TLC_OK;
+}
+
+// the early chain (classification, early pass, LARGE tier kernel) and the residency gate
+static int front_early_chain(tlc_graph* g, Workspace* ws) {
+    int rc;
+    ChunkCtx& c = ws->ctx;
+    TlcVicParams& vp = c.vp;
+    TlcPdParams& pp = c.pp;
+    hipStream_t s = c.s;
+    const int n_pairs = c.n_pairs, hop = c.hop, xgrid = c.xgrid;
+    const bool early = c.early, use_x = c.use_x;
+    const int32_t* d_pairs = vp.pairs;
+    // control words of the early pass (zeroed with the control block)
     int* d_cand_count = ws->d_ctl + 16;
     int* d_early_count = ws->d_ctl + 17;
     int* d_early_started = ws->d_ctl + 18;
     int* d_cand_started = ws->d_ctl + 19;
-    TlcPdParams& pp = c.pp;
-    memset(&pp, 0, sizeof(pp));
-    pp.hdr_n = ws->hdr_n; pp.hdr_m2 = ws->hdr_m2; pp.hdr_lu = ws->hdr_lu; pp.hdr_lv = ws->hdr_lv;
-    pp.edge_off = ws->edge_off;
-    pp.small_dir = use_x ? nullptr : ws->S_dir; pp.small_lw = use_x ? nullptr : ws->S_lw;
-    pp.flags = flags; pp.res = res; pp.out_pi = d_out_pi; pp.out_status = d_out_status;
-    pp.ids_off = (const long long*)d_ids_off; pp.out_f = d_out_f; pp.out_n = d_out_n; pp.pi_enabled = pi_enabled;
-    pp.edges_off = (const long long*)d_edge_offs; pp.out_edges = d_out_edges; pp.out_m = d_out_m;
-    pp.stats = ws->d_stats;
-    pp.dc_force_fail = g->opt_dc_force_fail;
-    pp.no_plain = g->opt_plain_kernels ? 0 : 1;
-    // lists for tlc_pd_dc_kernel: counters in the control block (zeroed with it), [d_ctl + 26 + 2k];
-    // k = 0 MEDIUM, 1 LARGE (regular launch), 2 LARGE (early launch)
-    auto dc_lists_for = [&](TlcPdParams& q, int k) {
-        const size_t cap = ws->cap_pairs + TLC_EARLY_SLOTS;
-        q.dc_count = ws->d_ctl + 26 + 2 * k;
-        q.dc_list = ws->dc_lists + (size_t)k * cap;
-    };
     if (early) {
         if ((rc = ensure_early(g, ws, hop, s)) != TLC_OK) return rc;
         hipStream_t es = ws->side[4];
@@ -908,7 +948,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
             if ((rc = ensure_handoff_large(g, ws, TLC_EARLY_SLOTS)) != TLC_OK) return rc;
             lp.handoff = ws->handoff_large; lp.handoff_stride = (long long)tlc_handoff_slot_bytes(TLC_TIER_LARGE);
             lp.handoff_cap = TLC_EARLY_SLOTS;
-            dc_lists_for(lp, 2);
+            dc_lists_for(ws, lp, 2);
             lp.dc_inplace = g->opt_dc_inplace;
         }
         lp.phase_cycles = g->d_phase ? g->d_phase + 32 * TLC_TIER_LARGE : nullptr;
@@ -930,6 +970,21 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
                                192, gate);
         TLC_HIP_CHECK(hipGetLastError());
     }
+    return TLC_OK;
+}
+
+// the general extraction launch and the scan (publishes the sizes; records the fork point of the tier launches)
+static int front_main_scan(tlc_graph* g, Workspace* ws) {
+    int rc;
+    ChunkCtx& c = ws->ctx;
+    TlcVicParams& vp = c.vp;
+    hipStream_t s = c.s;
+    const int n_pairs = c.n_pairs, xgrid = c.xgrid, vgrid = c.vgrid;
+    const bool early = c.early, use_x = c.use_x, fsplit = c.fsplit, plain = c.plain, pipelined = c.pipelined, bump = c.bump;
+    const long long bump_base = c.bump_base;
+    int* d_early_count = ws->d_ctl + 17;
+    unsigned long long* d_bump_top = reinterpret_cast<unsigned long long*>(ws->d_ctl + 20);
+    int* d_bump_overflow = ws->d_ctl + 22;
     vp.work_counter = ws->d_ctl + 64 + 1024 + 8;         // TLC_X_COUNTERS (8) counters, 64 ints apart, behind the statistics
     // (about one chunk per RESIDENT extraction wavefront -- 16 per CU, 4 096 -- when batches are pipelined: the machine is full of
     // other chunks' kernels then and the extraction's own tail costs nothing; twice as many for a lone batch.  In-process A/B,
@@ -970,7 +1025,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     // the fixed batch 0.729 vs 0.734; profiles/r03_threshold_sweep.txt has the curve over the cut).  So a pipelined chunk does not split.
     const bool mh_split = !pipelined;
     sp.mh_min_pos = mh_split ? TLC_MH_MIN_POS : 0x7fffffff;
-    sp.tiny_ok = (g->opt_tiny && pi_enabled && flags == 0u && res == 5 && !d_out_ids && !d_out_f && !d_out_edges) ? 1 : 0;
+    sp.tiny_ok = (g->opt_tiny && plain && vp.flags == 0u && vp.res == 5) ? 1 : 0;      // (plain: images and none of the filtration outputs)
     sp.dcm_count = ws->d_ctl + 44; sp.h_dcm = const_cast<int*>(&ws->h_sync_dev->pub_dcm);
     // (the TINY list by size class as well: d_ctl[48..63] count, zeroed with the control block; the scan's flags start at 64)
     static_assert(TLC_TINY_BINS <= 16, "the size-class counters of the TINY list live in d_ctl[48..63]");
@@ -990,13 +1045,26 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     hipLaunchKernelGGL(tlc_scan_bin, dim3(nb), dim3(1024), 0, s, sp);
     T1(1, s);
     TLC_HIP_CHECK(hipGetLastError());
+    c.seq = seq;
+    c.tiny_bins = sp.tiny_bin_count != nullptr;
+    return TLC_OK;
+}
+
+// the speculative launch behind the scan
+static int front_speculative(tlc_graph* g, Workspace* ws) {
+    int rc;
+    ChunkCtx& c = ws->ctx;
+    TlcPdParams& pp = c.pp;
+    hipStream_t s = c.s;
+    const int n_pairs = c.n_pairs;
+    const bool early = c.early, plain = c.plain, pipelined = c.pipelined;
+    int* d_bump_overflow = ws->d_ctl + 22;
     // ---- speculative submission of the MID / MEDIUM tiers ---------------------------------------------------------------
     // Their inputs are complete once the scan has run (COUNT wrote the vicinities, the scan the tier lists), so they are
     // submitted behind it right away, with the list lengths on the device and grids / hand-off buffers sized from the
     // previous chunk: the ~50 us the host needs to see the published sizes and issue a dozen launch calls are no longer
     // between the scan and the batch's second-longest chain.  If COUNT overflowed the arena the kernels return at once
     // (abort flag) and the chunk is redone below.
-    static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4, 4};   // timing slot of each tier kernel (TINY is reported with SMALL, MEDHI / MEDWIDE as MEDIUM)
     bool (&used)[TLC_N_SIDE] = c.used;
     for (int k = 0; k < TLC_N_SIDE; ++k) used[k] = (k == 4) && early;
     // The fork point of the side-stream launches that need nothing but the scan.  Recorded here, it is long complete when the
@@ -1004,6 +1072,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     // submission time costs every side stream a barrier packet on a signal that is still in flight: 60 us per chunk (measured:
     // 0.796 -> 0.733 ms per pipelined batch, tools/ab_option.py mh_always 0 3 before this was unconditional).
     TLC_HIP_CHECK(hipEventRecord(ws->ev_scan, s));
+    const bool mh_split = !pipelined;                               // (front_main_scan: a pipelined chunk does not split the MEDIUM tier)
     const bool spec = plain && mh_split;
     size_t (&spec_base)[TLC_N_TIERS] = c.spec_base;
     int (&spec_cap)[TLC_N_TIERS] = c.spec_cap;
@@ -1038,7 +1107,7 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
             pp.phase_cycles = g->d_phase ? g->d_phase + 32 * t : nullptr;
             // (the divide and conquer in this chain only if the previous chunk had vicinities for it: the count is not known yet)
             pp.dc_count = nullptr; pp.dc_list = nullptr;
-            if (ws->prev_dcm > 0) dc_lists_for(pp, 0);
+            if (ws->prev_dcm > 0) dc_lists_for(ws, pp, 0);
             T0(tslot[t], s);
             if (((g->opt_tier_mask >> t) & 1) && (rc = tlc_launch_pd_tier(t, pp, s)) != TLC_OK) return rc;
             T1(tslot[t], s);
@@ -1047,10 +1116,22 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
         pp.phase = 0;
         pp.grid = 0; pp.tier_count_dev = nullptr; pp.abort_flag = nullptr; pp.handoff = nullptr; pp.handoff_cap = 0;
     }
-    c.bump = bump; c.use_x = use_x; c.early = early; c.spec = spec; c.bump_base = bump_base; c.xgrid = xgrid; c.seq = seq;
-    c.count_only = g->count_only != 0;
-    c.tiny_bins = sp.tiny_bin_count != nullptr;
-    c.pipelined = pipelined;
+    c.spec = spec;
+    return TLC_OK;
+}
+
+static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, int n_pairs, int hop, uint32_t flags, int res,
+                     double* d_out_pi, uint8_t* d_out_status, const int64_t* d_ids_off, int32_t* d_out_ids,
+                     double* d_out_f, int32_t* d_out_n, const int64_t* d_edge_offs, int32_t* d_out_edges, int32_t* d_out_m,
+                     int pi_enabled, hipStream_t s, bool pipelined) {
+    int rc;
+    ChunkCtx& c = ws->ctx;
+    if ((rc = front_prepare(g, ws, d_pairs, n_pairs, hop, flags, res, d_out_pi, d_out_status, d_ids_off, d_out_ids, d_out_f, d_out_n,
+                            d_edge_offs, d_out_edges, d_out_m, pi_enabled, s, pipelined)) != TLC_OK) return rc;
+    if ((rc = front_fast(g, ws)) != TLC_OK) return rc;
+    if ((rc = front_early_chain(g, ws)) != TLC_OK) return rc;
+    if ((rc = front_main_scan(g, ws)) != TLC_OK) return rc;
+    if ((rc = front_speculative(g, ws)) != TLC_OK) return rc;
     c.ht_front = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c.ht0).count() * 1e-3;
     ws->back_pending = 1;
     return TLC_OK;
@@ -1058,6 +1139,38 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
 
 // has the scan of the workspace's chunk published its sizes?
 static inline bool sizes_published(const Workspace* ws) { return ws->h_sync->pub_seq == ws->ctx.seq; }
+
+// a chunk's tier counts into the statistics of the call it belongs to (tlc_pd_pi_batch_stats, tlc_debug_tier_counts)
+static void account_chunk(tlc_graph* g, const int (&tc)[TLC_N_TIERS], int n_early) {
+    for (int t = 0; t <= TLC_TIER_HUGE; ++t) g->last_stats[t] += tc[t];
+    for (int t = 0; t < TLC_N_TIERS; ++t) g->last_tc[t] += tc[t];
+    g->last_stats[TLC_TIER_MEDIUM] += tc[TLC_TIER_MEDWIDE];            // (reported with MEDIUM)
+    g->last_stats[TLC_TIER_MEDIUM] += tc[TLC_TIER_MEDHI];              // (reported with MEDIUM; on its own in [9])
+    g->last_stats[9] += tc[TLC_TIER_MEDHI];
+    g->last_stats[TLC_TIER_SMALL] += tc[TLC_TIER_TINY];                 // (reported with SMALL; on its own in [8])
+    g->last_stats[8] += tc[TLC_TIER_TINY];
+    g->last_stats[TLC_TIER_LARGE] += n_early;
+    g->last_stats[7] += tc[TLC_TIER_MID];
+    g->last_stats[6] += 1;
+}
+
+// The host's wait for the sizes a chunk's scan publishes (mapped memory, sequence number).  hipStreamSynchronize would also wait for
+// the kernels submitted behind the scan; the stream is only queried, now and then, so that a fault surfaces instead of a spin.
+static int wait_for_sizes(const Workspace* ws, hipStream_t s, unsigned seq) {
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (unsigned it = 1; !(seen = (ws->h_sync->pub_seq == seq)); ++it) {
+        if ((it & 0x3ff) != 0) continue;
+        const auto el = std::chrono::steady_clock::now() - t0;
+        if (el < std::chrono::microseconds(300)) continue;
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) { seen = (ws->h_sync->pub_seq == seq); break; }
+        if (q != hipErrorNotReady) { tlc_set_error(hipGetErrorString(q)); return TLC_ERR_HIP; }
+        if (el > std::chrono::seconds(20)) break;
+    }
+    TLC_REQUIRE(seen, "size publication did not arrive");
+    return TLC_OK;
+}
 
 // The second half of a chunk: waits (on the host) for the sizes the scan publishes, then submits every launch whose grid or
 // buffers depend on them, and joins the side streams into the chunk's stream.
@@ -1073,36 +1186,15 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
     TlcVicParams& vp = c.vp;
     TlcPdParams& pp = c.pp;
     hipStream_t s = c.s;
-    const int n_pairs = c.n_pairs, hop = c.hop, pi_enabled = c.pi_enabled, xgrid = c.xgrid, vgrid = c.vgrid, tmask = c.tmask;
+    const int n_pairs = c.n_pairs, hop = c.hop, pi_enabled = c.pi_enabled, xgrid = c.xgrid, vgrid = c.vgrid;
     const bool bump = c.bump, use_x = c.use_x, early = c.early, spec = c.spec;
     const long long bump_base = c.bump_base;
     const unsigned seq = c.seq;
     size_t (&spec_base)[TLC_N_TIERS] = c.spec_base;
     int (&spec_cap)[TLC_N_TIERS] = c.spec_cap;
     bool (&used)[TLC_N_SIDE] = c.used;
-    static const int tslot[TLC_N_TIERS] = {3, 4, 5, 6, 7, 3, 4, 4};   // timing slot of each tier kernel (TINY is reported with SMALL, MEDHI / MEDWIDE as MEDIUM)
-    auto dc_lists_for = [&](TlcPdParams& q, int k) {
-        const size_t cap = ws->cap_pairs + TLC_EARLY_SLOTS;
-        q.dc_count = ws->d_ctl + 26 + 2 * k;
-        q.dc_list = ws->dc_lists + (size_t)k * cap;
-    };
     ws->back_pending = 0;
-    {
-        // (hipStreamSynchronize would also wait for the kernels submitted behind the scan; the stream is only queried, now and
-        // then, so that a fault surfaces instead of a spin)
-        const auto t0 = std::chrono::steady_clock::now();
-        bool seen = false;
-        for (unsigned it = 1; !(seen = (ws->h_sync->pub_seq == seq)); ++it) {
-            if ((it & 0x3ff) != 0) continue;
-            const auto el = std::chrono::steady_clock::now() - t0;
-            if (el < std::chrono::microseconds(300)) continue;
-            const hipError_t q = hipStreamQuery(s);
-            if (q == hipSuccess) { seen = (ws->h_sync->pub_seq == seq); break; }
-            if (q != hipErrorNotReady) { tlc_set_error(hipGetErrorString(q)); return TLC_ERR_HIP; }
-            if (el > std::chrono::seconds(20)) break;
-        }
-        TLC_REQUIRE(seen, "size publication did not arrive");
-    }
+    if ((rc = wait_for_sizes(ws, s, seq)) != TLC_OK) return rc;
     ht_seen = ht_us();
     std::atomic_thread_fence(std::memory_order_acquire);
     const long long total = ws->h_sync->pub_total;
@@ -1205,8 +1297,8 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
             pp.handoff_stride = (long long)hs;
             pp.handoff_cap = (spec_done && (t == TLC_TIER_MID || t == TLC_TIER_MEDIUM || t == TLC_TIER_MEDWIDE)) ? std::min(tc[t], spec_cap[t]) : tc[t];
             pp.dc_count = nullptr; pp.dc_list = nullptr; pp.dc_inplace = 0;
-            if (t == TLC_TIER_LARGE) { dc_lists_for(pp, 1); pp.dc_inplace = g->opt_dc_inplace; }
-            if ((t == TLC_TIER_MEDHI || t == TLC_TIER_MEDWIDE) && n_dcm > 0) dc_lists_for(pp, 0);
+            if (t == TLC_TIER_LARGE) { dc_lists_for(ws, pp, 1); pp.dc_inplace = g->opt_dc_inplace; }
+            if ((t == TLC_TIER_MEDHI || t == TLC_TIER_MEDWIDE) && n_dcm > 0) dc_lists_for(ws, pp, 0);
             if (hs && t == TLC_TIER_LARGE) {
                 // (the early launch may still be using the first TLC_EARLY_SLOTS slots: this launch takes the ones behind them)
                 int r2 = ensure_handoff_large(g, ws, (size_t)TLC_EARLY_SLOTS + (size_t)tc[t]);
@@ -1328,18 +1420,7 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
         if (used[k]) TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_join[k], 0));
 #undef T0
 #undef T1
-    if (c.call_seq == g->call_seq) {      // (a deferred second half submitted by a LATER call does not count into that call's statistics)
-    for (int t = 0; t <= TLC_TIER_HUGE; ++t) g->last_stats[t] += tc[t];
-    for (int t = 0; t < TLC_N_TIERS; ++t) g->last_tc[t] += tc[t];
-    g->last_stats[TLC_TIER_MEDIUM] += tc[TLC_TIER_MEDWIDE];            // (reported with MEDIUM)
-    g->last_stats[TLC_TIER_MEDIUM] += tc[TLC_TIER_MEDHI];              // (reported with MEDIUM; on its own in [9])
-    g->last_stats[9] += tc[TLC_TIER_MEDHI];
-    g->last_stats[TLC_TIER_SMALL] += tc[TLC_TIER_TINY];                 // (reported with SMALL; on its own in [8])
-    g->last_stats[8] += tc[TLC_TIER_TINY];
-    g->last_stats[TLC_TIER_LARGE] += n_early;
-    g->last_stats[7] += tc[TLC_TIER_MID];
-    g->last_stats[6] += 1;
-    }
+    if (c.call_seq == g->call_seq) account_chunk(g, tc, n_early);      // (a deferred second half submitted by a LATER call does not count into that call's statistics)
     if (host_trace) {
         static std::chrono::steady_clock::time_point last_end;
         const double gap = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(ht0 - last_end).count() * 1e-3;
