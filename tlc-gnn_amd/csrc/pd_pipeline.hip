@@ -29,8 +29,7 @@
     do {                                                                             \
         if (pc && threadIdx.x == 0) {                                                \
             const unsigned long long _t = clock64();                                 \
-            atomicAdd(&pc[(k)], _t - t_prev);                                        \
-            ph[(k)] += _t - t_prev;                                                  \
+            ph[(k)] += _t - t_prev;             /* (summed into pc[] once, at the end) */ \
             t_prev = _t;                                                             \
         }                                                                            \
     } while (0)
@@ -166,6 +165,9 @@ __device__ __forceinline__ Mem<idx_t> carve(unsigned char* base, const Layout& L
     m.wcnt = (int*)(base + L.o_ctl + 192);
     m.rec = (unsigned*)(base + L.o_rec);
     m.table = base + L.o_dir;
+    // (round 6, measured: with the table up to the diagram points -- 33 instead of 9 points per round of the image stage in the SMALL tier --
+    // the rows are the same bits and the batch takes the same time; the whole in-kernel image stage is 1.8 % of a pipelined batch
+    // (-DTLC_SKIP_IMAGE).  The per-phase cycle stamps of the PHASE_DEBUG build had said 39 % of the SMALL kernel: not to be trusted.)
     m.table_bytes = L.o_x - L.o_dir;
     m.xbase = base + L.o_x;
     m.xbytes = L.o_pn - L.o_x;
@@ -1838,7 +1840,11 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
                 // with a barrier; the layout of tlc_pd_dc_kernel fits the tier's LDS): no second launch, no second placement
                 if (deferred && slot && dc_here && ((const int*)slot)[6] != 0) dc_subgraph<NM, MM, W>(p, wi, lds_raw);
             }
+#ifdef TLC_SKIP_IMAGE                    /* (timing experiment: what the in-kernel image stage costs; rows are garbage) */
+            if (false) {
+#else
             if (status == TLC_ST_OK && !deferred) {
+#endif
                 const int np = M.ctl[2], n_up = M.ctl[6];
                 auto get = [&](int k, double& b, double& d) {
                     const unsigned bd = M.pts[k];
@@ -1859,6 +1865,9 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
 #ifdef TLC_PHASE_DEBUG
         if (pc && tid == 0) {
             const ull tot = clock64() - t_begin;
+            // (one round of atomics per workgroup, behind its last phase: a stamp that adds to a global counter makes the phase behind it
+            // pay for the atomic at its first barrier -- with 10 000 SMALL workgroups on twelve addresses that was most of what it showed)
+            for (int k = 0; k < 12; ++k) if (ph[k]) atomicAdd(&pc[k], ph[k]);
             atomicAdd(&pc[12], tot);
             atomicAdd(&pc[14], 1ull);
             if (atomicMax(&pc[13], tot) < tot) {          // slowest workgroup so far: its own phase split, n and m
