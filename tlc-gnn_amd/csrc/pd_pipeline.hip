@@ -37,6 +37,14 @@
 #define TLC_STAMP(k) do { } while (0)
 #endif
 #define TLC_NONE16 0xFFFFu
+// Timing experiment (tools/gpu_r6_knockout.sh): -DTLC_STOP_AFTER=k compiles the tier kernels' stages behind stage k out -- 1 staging,
+// 2 Bellman-Ford, 3 tight chains (+ fallback) and normalisation, 4 edge compaction, 5 rank relabel + ascending sort, 6 ascending pass,
+// 7 descending sort, 8 descending pass + Pos / Neg split, 9 cycle swap (hand-off / walk / divide and conquer), 10 image = everything.
+// Rows are garbage below 10; what a pipelined batch then costs, stage by stage, is the cost table of DESIGN.md section 0.
+#ifndef TLC_STOP_AFTER
+#define TLC_STOP_AFTER 10
+#endif
+#define TLC_STOPPED 99          /* a status nobody tests for: every later stage is guarded by status == TLC_ST_OK */
 // the SMALL tier keeps its entry weights in LDS (true) or reads them from the arena like the larger tiers (false: 6.9 -> 6.0 KB per
 // workgroup; A/B on one box, tools/gpu_build_ab.sh: pipelined batch 0.744 -> 0.736 ms, one batch alone 0.804 -> 0.792 ms)
 #ifndef TLC_SMALL_LWL
@@ -167,7 +175,7 @@ __device__ __forceinline__ Mem<idx_t> carve(unsigned char* base, const Layout& L
     m.table = base + L.o_dir;
     // (round 6, measured: with the table up to the diagram points -- 33 instead of 9 points per round of the image stage in the SMALL tier --
     // the rows are the same bits and the batch takes the same time; the whole in-kernel image stage is 1.8 % of a pipelined batch
-    // (-DTLC_SKIP_IMAGE).  The per-phase cycle stamps of the PHASE_DEBUG build had said 39 % of the SMALL kernel: not to be trusted.)
+    // (-DTLC_STOP_AFTER=9).  The per-phase cycle stamps of the PHASE_DEBUG build had said 39 % of the SMALL kernel: not to be trusted.)
     m.table_bytes = L.o_x - L.o_dir;
     m.xbase = base + L.o_x;
     m.xbytes = L.o_pn - L.o_x;
@@ -1341,10 +1349,12 @@ __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, i
     for (int pos = threadIdx.x; pos < m; pos += W) M.arank[M.valS[pos]] = (unsigned)pos;
     __syncthreads();
     TLC_STAMP(5);
+    if (TLC_STOP_AFTER <= 5) return TLC_STOPPED;
     mst_pass<W, idx_t, false, true>(M, sink, n, m, flags);
     if (threadIdx.x == 0) sink.ext0(M.f, 0, n - 1);                  // [min, max]  (:110)
     __syncthreads();
     TLC_STAMP(6);
+    if (TLC_STOP_AFTER <= 6) return TLC_STOPPED;
     // A connected vicinity with n - 1 edges is a tree (30 % of a PubMed batch): every edge is a Neg edge, there is no Pos
     // edge and no 1-dimensional point, and the descending pass would only add Rel1 points, which weigh 0 in the image.
     // (The batch path is entered for connected vicinities only; tlc_pd_from_filtration reports Rel1 and takes the long way.)
@@ -1368,10 +1378,12 @@ __device__ __forceinline__ int pd_all_stages(Mem<idx_t>& M, Sink& sink, int n, i
     if (elig) elig = fix_desc_ties<W>(M, m);
     const bool dc = elig && (dc_mode == 1 || slot != nullptr);
     TLC_STAMP(7);
+    if (TLC_STOP_AFTER <= 7) return TLC_STOPPED;
     if (Sink::want_down) mst_pass<W, idx_t, true, true>(M, sink, n, m, flags);
     else mst_pass<W, idx_t, true, false>(M, sink, n, m, flags);
     split_pos_neg<W>(M, m, MMcap);
     TLC_STAMP(8);
+    if (TLC_STOP_AFTER <= 8) return TLC_STOPPED;
     int status = TLC_ST_OK;
     if (!(flags & TLC_NO_EXT1)) {
         if (M.ctl[4] == 0) status = TLC_ST_NO_TREE_EDGE;              // list(Nodes)[0] -> IndexError (:122)
@@ -1627,13 +1639,15 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
         double* wV = (double*)M.pts;
 
         const unsigned desc = p.flags & TLC_DESC_MASK;
-        if (!far) {
+        if (TLC_STOP_AFTER <= 1) status = TLC_STOPPED;
+        if (status == TLC_ST_OK && !far) {
             // ---- P5: filtration.build_fv, weighted branch (riccidist2dgm.py:20-61); descriptor by flag ---------------------
             if (tid == 0) { du[lu] = 0ull; M.dv[lv] = 0ull; }
             __syncthreads();
             TLC_STAMP(0);
             bellman_ford<W, true, BF_CE>(du, M.dv, M.dir, m2, n, LW, M.ctl);
             TLC_STAMP(1);
+            if (TLC_STOP_AFTER <= 2) status = TLC_STOPPED;
             // assert one connected component (:318): everything must be reachable from u
             double dmx = 0.0;
             int unreach = 0;
@@ -1739,7 +1753,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
                 }
                 __syncthreads();
             }
-        } else {
+        } else if (status == TLC_ST_OK) {
             // d(u,v) > hop: every distance is the sentinel 100 (:31-37) => f == 200/200; only connectivity matters
             if (tid == 0) du[0] = 0ull;
             __syncthreads();
@@ -1755,6 +1769,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
             for (int k = tid; k < n; k += W) M.f[k] = one;
             __syncthreads();
         }
+        if (TLC_STOP_AFTER <= 3 && status == TLC_ST_OK) status = TLC_STOPPED;
         // optional filtration output (tlc_vicinity_filtration)
         if (p.out_f) {
             const long long no = p.ids_off[i];
@@ -1799,6 +1814,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
                 __syncthreads();
             }
         }
+        if (TLC_STOP_AFTER <= 4 && status == TLC_ST_OK) status = TLC_STOPPED;
         if (want_edges) {
             const long long eo2 = p.edges_off[i];
             const long long ecap = p.edges_off[i + 1] - eo2;
@@ -1840,11 +1856,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
                 // with a barrier; the layout of tlc_pd_dc_kernel fits the tier's LDS): no second launch, no second placement
                 if (deferred && slot && dc_here && ((const int*)slot)[6] != 0) dc_subgraph<NM, MM, W>(p, wi, lds_raw);
             }
-#ifdef TLC_SKIP_IMAGE                    /* (timing experiment: what the in-kernel image stage costs; rows are garbage) */
-            if (false) {
-#else
-            if (status == TLC_ST_OK && !deferred) {
-#endif
+            if (TLC_STOP_AFTER >= 10 && status == TLC_ST_OK && !deferred) {
                 const int np = M.ctl[2], n_up = M.ctl[6];
                 auto get = [&](int k, double& b, double& d) {
                     const unsigned bd = M.pts[k];
