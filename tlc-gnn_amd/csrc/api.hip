@@ -964,7 +964,14 @@ static int front_early_chain(tlc_graph* g, Workspace* ws) {
         // (Measured and dropped, pipelined chunks: the main COUNT beside the early pass instead of behind it, and bounds of the gate
         // from none to 200 us: all within noise -- the machine is full of the previous chunk's tier kernels either way.)
         TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_early, 0));
-        const long long gate = 5000ll;                                  // 10 ns ticks
+        // (Round 6: no gate for a pipelined chunk.  With other chunks' tier kernels on every CU the LARGE workgroups are never resident
+        // within the bound, so the gate was a 50 us wait -- and a kernel of its own -- in the middle of every first half: in-region timeline
+        // profiles/r06_queue_occupancy.txt.  Two libraries in turn, three rounds: 0.5048 -> 0.4930 ms per pipelined batch (-2.3 %).
+        // -DTLC_GATE_PIPELINED=5000: as before.)
+#ifndef TLC_GATE_PIPELINED
+#define TLC_GATE_PIPELINED 0
+#endif
+        const long long gate = c.pipelined ? (long long)TLC_GATE_PIPELINED : 5000ll;   // 10 ns ticks
         if (gate > 0)
             hipLaunchKernelGGL(tlc_wait_started_dev, dim3(1), dim3(TLC_WAVE), 0, s, (const int*)d_early_started, (const int*)d_early_count,
                                192, gate);
@@ -998,6 +1005,8 @@ static int front_main_scan(tlc_graph* g, Workspace* ws) {
         // (behind a FAST launch this one is left with the pairs whose smaller ball has more than 128 nodes -- a few thousand, 20 - 80 us
         // each on one wavefront.  512-thread workgroups for them instead -- 256 / 512 / 1024 of them -- measured: pipelined batch
         // 0.576 -> 0.62 - 0.63 ms, one batch alone 0.68 -> 0.74 ms; the count-prefix-write form of the sweep costs more than it spreads)
+        // (round 6: 1 024 / 2 048 workgroups for it behind a FAST launch instead of one per scratch slot -- its work list is a few thousand
+        // pairs, and in a pipelined region the launch takes 150 us for 12 us of work -- measured: 0.4962 / 0.4991 vs 0.4994 ms, within noise)
         if ((rc = tlc_launch_extract(64, xgrid, g->x_lds64, vp, s)) != TLC_OK) return rc;
     } else {
         hipLaunchKernelGGL((tlc_vicinity_kernel<false, 64>), dim3(vgrid), dim3(TLC_WAVE), g->vic_lds, s, vp);
