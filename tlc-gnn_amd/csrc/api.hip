@@ -963,7 +963,15 @@ static int front_early_chain(tlc_graph* g, Workspace* ws) {
         // the early COUNT is done and the early tier kernel's workgroups are resident (bounded: 50 us after the former).
         // (Measured and dropped, pipelined chunks: the main COUNT beside the early pass instead of behind it, and bounds of the gate
         // from none to 200 us: all within noise -- the machine is full of the previous chunk's tier kernels either way.)
-        TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_early, 0));
+#ifndef TLC_MAIN_BESIDE_EARLY
+#define TLC_MAIN_BESIDE_EARLY 1
+#endif
+        // (Round 6, pipelined chunks: the general launch waits for the classification only -- its bins and the candidates' count are all it
+        // needs from the early stream; a pair has one owner, so the two launches write disjoint headers, regions and slots -- and runs
+        // BESIDE the early pass; the scan still waits for the early list.  Two libraries in turn, three rounds: 0.4957 -> 0.4847 ms per
+        // pipelined batch (-2.2 %), rotating batches -2.9 %.  A chunk on its own keeps the order that gets its LARGE workgroups placed first.)
+        if (TLC_MAIN_BESIDE_EARLY && c.pipelined && use_x) { TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_cls, 0)); }
+        else TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_early, 0));
         // (Round 6: no gate for a pipelined chunk.  With other chunks' tier kernels on every CU the LARGE workgroups are never resident
         // within the bound, so the gate was a 50 us wait -- and a kernel of its own -- in the middle of every first half: in-region timeline
         // profiles/r06_queue_occupancy.txt.  Two libraries in turn, three rounds: 0.5048 -> 0.4930 ms per pipelined batch (-2.3 %).
