@@ -706,7 +706,8 @@ __global__ void tlc_wait_started_dev(const int* counter, const int* target, int 
 // parameter blocks of the extraction and of the tier kernels, what the preparation decided) and are submitted in this order:
 //   front_prepare      buffers, parameter blocks, which extraction serves the chunk, arena layout
 //   front_fast         the fork of the early chain, then the subgraph-list launch (needs nothing from the classification)
-//   front_early_chain  classification -> early pass -> LARGE tier kernel on the early stream; the residency gate on the chunk's stream
+//   front_early_chain  classification -> early pass -> LARGE tier kernel on the early stream
+//   front_join_early   what the chunk's own stream waits for before the general launch (classification / early pass + residency gate)
 //   front_main_scan    the general extraction launch and the scan that publishes the chunk's sizes
 //   front_speculative  (a chunk on its own) the many-Pos MEDIUM list behind the scan, sized from the previous chunk
 #define T0(k, st) do { if ((c.tmask >> (k)) & 1) { TLC_HIP_CHECK(hipEventRecord(c.ev_t[2 * (k)], st)); } } while (0)
@@ -956,6 +957,19 @@ static int front_early_chain(tlc_graph* g, Workspace* ws) {
         if (((g->opt_tier_mask >> TLC_TIER_LARGE) & 1) && (rc = tlc_launch_pd_tier(TLC_TIER_LARGE, lp, es)) != TLC_OK) return rc;
         T1(5, es);
         TLC_HIP_CHECK(hipEventRecord(ws->ev_join[4], es));
+    }
+    return TLC_OK;
+}
+
+// ... and what the chunk's own stream waits for before its general launch: the classification (pipelined chunks) or the whole early
+// pass and the LARGE workgroups' residency (a chunk on its own)
+static int front_join_early(tlc_graph* g, Workspace* ws) {
+    ChunkCtx& c = ws->ctx;
+    hipStream_t s = c.s;
+    const bool use_x = c.use_x;
+    int* d_early_count = ws->d_ctl + 17;
+    int* d_early_started = ws->d_ctl + 18;
+    if (c.early) {
         // The workgroups of the main COUNT are persistent (each strides over its share of the pairs) and fill every wavefront
         // slot and most of the LDS of the machine: once they are running, a 512-thread workgroup of the early pass -- let alone
         // one of its tier kernel, which needs a whole CU's LDS -- is placed only as they drain (measured: the early tier kernel
@@ -1145,8 +1159,11 @@ static int run_chunk_front(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, 
     ChunkCtx& c = ws->ctx;
     if ((rc = front_prepare(g, ws, d_pairs, n_pairs, hop, flags, res, d_out_pi, d_out_status, d_ids_off, d_out_ids, d_out_f, d_out_n,
                             d_edge_offs, d_out_edges, d_out_m, pi_enabled, s, pipelined)) != TLC_OK) return rc;
+    // (round 6: the early stream's launches submitted AHEAD of the subgraph-list launch, so that the classification is placed before that
+    // launch's 8 192 workgroups ask for every wavefront slot: 0.4872 vs 0.4861 ms per pipelined batch, no difference)
     if ((rc = front_fast(g, ws)) != TLC_OK) return rc;
     if ((rc = front_early_chain(g, ws)) != TLC_OK) return rc;
+    if ((rc = front_join_early(g, ws)) != TLC_OK) return rc;
     if ((rc = front_main_scan(g, ws)) != TLC_OK) return rc;
     if ((rc = front_speculative(g, ws)) != TLC_OK) return rc;
     c.ht_front = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c.ht0).count() * 1e-3;
@@ -1424,6 +1441,7 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
         // serial second kernel behind them and the lane-per-subgraph kernel, no longer the last to finish, only takes LDS from them
         // when it starts alongside (tools/ab_option.py medium_first 0 1: one batch alone 0.7605 -> 0.7325 ms, pipelined batches equal;
         // with the TINY kernel held back 110 us by an explicit sort it was 0.696).
+        // (round 6: MEDIUM / MID first for pipelined chunks too: 0.4884 vs 0.4866 ms, no gain)
         if (!c.pipelined && c.tiny_bins) {
             if ((rc = launch_medium_mid()) != TLC_OK) return rc;
             if ((rc = launch_tiny_small()) != TLC_OK) return rc;
