@@ -150,6 +150,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
                 // (a vicinity with Pos edges enough for the divide and conquer is "wide" whatever its size: only the wide kernels mark
                 // for it, and marking fixes the order of tied descending keys -- a row must not depend on whether its chunk was alone,
                 // where the many-Pos list takes it with the wide kernels, or pipelined)
+                // (round 6: a lower Pos cut for the wide list, for the sake of the compact list's swap kernel -- the last kernel of most batches,
+                // as long as its longest walk -- measured: 160 / 128: -0.5 % per pipelined batch (noise), 96: +2 %.  The cut stays the
+                // divide and conquer's.)
                 const bool wide = n > TLC_C_NMAX || m > TLC_C_MMAX || m - n + 1 >= TLC_DC_MIN_POS_SHARED;
                 const bool split = p.mh_min_pos != 0x7fffffff;
                 if (split && (wide || m - n + 1 >= p.mh_min_pos)) tier = TLC_TIER_MEDHI;
