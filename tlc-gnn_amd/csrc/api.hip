@@ -1430,6 +1430,8 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
                 // (the few vicinities beyond the compact configuration first: the largest of the MEDIUM-sized ones, the longest swaps)
                 if (tc[TLC_TIER_MEDWIDE] > 0 && (r = launch_side(7, TLC_TIER_MEDWIDE, !bumped)) != TLC_OK) return r;
                 if (!spec_done && tc[TLC_TIER_MEDHI] > 0 && (r = launch_side(2, TLC_TIER_MEDHI)) != TLC_OK) return r;
+                // (round 6, again after the first half got shorter and the MEDIUM stream's queue reached 0.82 busy: a workspace's MEDIUM list on
+                // the heavy tiers' stream or on the MEDWIDE stream: +0.7 ... +5 % per pipelined batch in every assignment tried)
                 if (tc[TLC_TIER_MEDIUM] > 0 && (r = launch_side(6, TLC_TIER_MEDIUM, !bumped)) != TLC_OK) return r;
                 if (tc[TLC_TIER_MID] > 0 && (r = launch_side(3, TLC_TIER_MID, !bumped)) != TLC_OK) return r;
             } else {
