@@ -45,6 +45,9 @@ extern "C" int tlc_device_count(void) {
 #define TLC_TIMING_RING 64        /* chunks whose kernel events are kept */
 #define TLC_X_REGION 4096         /* arena entries of the region each workgroup of the extraction starts with (extract.hip) */
 
+// a workspace's control block: [0, 64) control words | [64, 64 + 1024) the scan's per-block flags | 8 ints of statistics | 8 work counters of the
+// general extraction launch, 64 ints apart
+#define TLC_CTL_INTS (64 + 1024 + 8 + 8 * 64)
 struct HostSync {
     long long total_entries;
     int tier_count[TLC_N_TIERS];
@@ -586,7 +589,7 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     const int n_eager = 3;
     for (int i = 0; i < TLC_N_WS; ++i) {
         Workspace* ws = &g->ws[i];
-        CK(hipMalloc(&ws->d_ctl, (64 + 1024 + 8 + 8 * 64) * sizeof(int)));   // counters, the scan's per-block flags, 4 x u64 statistics
+        CK(hipMalloc(&ws->d_ctl, TLC_CTL_INTS * sizeof(int)));   // counters, the scan's per-block flags, 4 x u64 statistics, work counters
         ws->d_stats = reinterpret_cast<unsigned long long*>(ws->d_ctl + 64 + 1024);      // (8-byte aligned: hipMalloc is 256-byte aligned)
         CK(hipMalloc(&ws->d_block_sums, 1024 * sizeof(long long)));
         CK(hipMalloc(&ws->d_totals, 2 * sizeof(long long)));
@@ -732,7 +735,7 @@ static int front_prepare(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, in
     c.s = s; c.n_pairs = n_pairs; c.hop = hop; c.pi_enabled = pi_enabled; c.call_seq = g->call_seq;
     if ((rc = ensure_pairs(g, ws, (size_t)n_pairs)) != TLC_OK) return rc;
     if ((rc = ensure_vic_scratch(g, ws, hop)) != TLC_OK) return rc;
-    TLC_HIP_CHECK(hipMemsetAsync(ws->d_ctl, 0, (64 + 1024 + 8 + 8 * 64) * sizeof(int), s));       // control words, scan flags, statistics
+    TLC_HIP_CHECK(hipMemsetAsync(ws->d_ctl, 0, TLC_CTL_INTS * sizeof(int), s));       // control words, scan flags, statistics, work counters
 
     TlcVicParams& vp = c.vp;
     memset(&vp, 0, sizeof(vp));
@@ -882,6 +885,10 @@ static int front_fast(tlc_graph* g, Workspace* ws) {
         fp.region_base_wg = xgrid + TLC_EARLY_WG;
         fp.scratch_base_slot = 0;                             // (never used: its member lists fit the LDS)
         fp.work_counter = nullptr;
+        // (round 6: its pairs dealt from work counters of its own instead of statically strided -- per-pair times spread from 4 to 21 us and a
+        // workgroup takes 4.6 pairs, so the launch lasts 2.1 x its mean workgroup -- measured: chunks of 1 / 2 / 4 pairs +14 / +6.5 / +3.8 % per
+        // pipelined batch: eight counters do not serve 37 676 dequeues in the 50 us the launch lasts.  What does help is the ORDER of the
+        // pairs: tools/order_probe.py, the batch sorted by vicinity size descending: -3.2 %; the caller's order is the caller's.)
         size_t flds = g->x_lds64f;
         if (g->opt_ball_bits && g->d_bbits) {                 // (no bitmap of N bits in that launch's LDS: nw = 0 in its layout)
             fp.bbits = g->d_bbits; fp.bb_nw = g->nw; fp.nw = 0;
