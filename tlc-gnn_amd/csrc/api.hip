@@ -822,7 +822,7 @@ static int front_prepare(tlc_graph* g, Workspace* ws, const int32_t* d_pairs, in
     // chunk's main stream and runs beside the classification and the early pass, in front of the residency gate.  The general launch
     // behind the gate leaves those pairs alone (TlcVicParams::fast_split).
     const bool fsplit = use_x && g->opt_fast_split && g->opt_ball_edges && g->d_be_ptr != nullptr && !(flags & TLC_INCLUDE_ROOTS);
-    const int xfgrid = fsplit ? std::min(n_pairs, 8192) : 0;        // (2 048 / 4 096 / 8 192 measured: the last by 1 - 2 %)
+    const int xfgrid = fsplit ? std::min(n_pairs, 8192) : 0;        // (2 048 / 4 096 / 8 192 measured: the last by 1 - 2 %; round 6: 12 288 / 16 384 / one per pair: equal)
     long long bump_base = 0;
     if (use_x) {
         // arena = one region per workgroup of the extraction (main pass, then the early pass), then the bump area
