@@ -76,6 +76,7 @@ struct ChunkCtx {
     hipStream_t s;
     int n_pairs, hop, pi_enabled;
     bool bump, use_x, early, spec, count_only, tiny_bins, pipelined;
+    bool mh_front;                 // the scan put the compact list's many-Pos vicinities on the MEDHI list: the front part of the MEDIUM launch
     bool plain, fsplit;            // a plain image batch (no filtration outputs); the subgraph-list pairs have a launch of their own
     int xfgrid;                    // ... of this many workgroups
     long long bump_base;
@@ -1063,6 +1064,15 @@ static int front_main_scan(tlc_graph* g, Workspace* ws) {
     // the fixed batch 0.729 vs 0.734; profiles/r03_threshold_sweep.txt has the curve over the cut).  So a pipelined chunk does not split.
     const bool mh_split = !pipelined;
     sp.mh_min_pos = mh_split ? TLC_MH_MIN_POS : 0x7fffffff;
+    // (Round 6, pipelined plain chunks: the compact list's many-Pos vicinities still get a list of their own -- not for kernels of their own,
+    // but to stand in FRONT of the compact MEDIUM launch (TlcPdParams::tier_list_hi): the swap kernel ends most batches and lasts as long as
+    // its longest walk plus the time that walk's wavefront waited to be placed.  tools/order_probe.py: the MEDIUM list with its most-Pos
+    // vicinities first, -2 % per pipelined batch.)
+#ifndef TLC_MH_FRONT_POS
+#define TLC_MH_FRONT_POS 64      /* (96: -0.9 %, 64: -1.2 ... -1.9 %, 48: about the same, 32 and 128: less; two libraries or four in turn) */
+#endif
+    c.mh_front = !mh_split && plain && TLC_MH_FRONT_POS > 0;
+    if (c.mh_front) { sp.mh_min_pos = TLC_MH_FRONT_POS; sp.mh_compact_only = 1; }
     sp.tiny_ok = (g->opt_tiny && plain && vp.flags == 0u && vp.res == 5) ? 1 : 0;      // (plain: images and none of the filtration outputs)
     sp.dcm_count = ws->d_ctl + 44; sp.h_dcm = const_cast<int*>(&ws->h_sync_dev->pub_dcm);
     // (the TINY list by size class as well: d_ctl[48..63] count, zeroed with the control block; the scan's flags start at 64)
@@ -1241,6 +1251,9 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
     const long long total = ws->h_sync->pub_total;
     int tc[TLC_N_TIERS];
     for (int t = 0; t < TLC_N_TIERS; ++t) tc[t] = ws->h_sync->pub_tier[t];
+    // (the many-Pos part of a pipelined chunk's compact MEDIUM list: one launch with the rest, in front of it)
+    int n_hi = 0;
+    if (c.mh_front) { n_hi = tc[TLC_TIER_MEDHI]; tc[TLC_TIER_MEDIUM] += n_hi; tc[TLC_TIER_MEDHI] = 0; }
     // (COUNT's writes stand unless the chunk overflowed the arena: then everything is laid out by the scan and written by FILL)
     const bool bumped = bump && ws->h_sync->pub_overflow == 0;
     if (use_x) ws->x_entries_hint = std::max(ws->x_entries_hint, (size_t)std::max<long long>(total - (bumped ? bump_base : 0), 0));
@@ -1333,6 +1346,8 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
                 TLC_HIP_CHECK(hipStreamWaitEvent(ws->side[k], ws->ev_fork, 0));
             }
             pp.tier_list = ws->tier_list + (size_t)t * n_pairs; pp.tier_count = tc[t];
+            pp.tier_list_hi = nullptr; pp.n_hi = 0;
+            if (t == TLC_TIER_MEDIUM && n_hi > 0) { pp.tier_list_hi = ws->tier_list + (size_t)TLC_TIER_MEDHI * n_pairs; pp.n_hi = n_hi; }
             const size_t hs = pi_enabled ? tlc_handoff_slot_bytes(t) : 0;       // (0: the tier kernel runs the cycle swap itself -- SMALL, MID)
             pp.handoff = hs ? ws->handoff + hand_base[t] : nullptr;
             pp.handoff_stride = (long long)hs;

@@ -1587,7 +1587,7 @@ __global__ __launch_bounds__(W, (W == 256 && !HUGE ? (NM == TLC_C_NMAX ? 6 : TLC
     int wi = HUGE ? (int)blockIdx.x : p.wi_base + (int)blockIdx.x;
     if (wi >= tier_count) return;
     do {
-        const int i = p.tier_list[wi];
+        const int i = wi < p.n_hi ? p.tier_list_hi[wi] : p.tier_list[wi - p.n_hi];
         // hand-off slot of this subgraph (tiers whose cycle swap runs in tlc_pd_swap_kernel); "nothing pending" until decided
         unsigned char* slot = (!HUGE && p.handoff && wi < p.handoff_cap) ? p.handoff + (size_t)wi * (size_t)p.handoff_stride : nullptr;
         bool deferred = false;
@@ -1924,7 +1924,7 @@ __device__ __forceinline__ void swap_subgraph(const TlcPdParams& p, int wi, unsi
     const int tid = threadIdx.x;
     const Handoff H = carve_handoff(p.handoff + (size_t)wi * (size_t)p.handoff_stride, NM);
     if (H.hdr[0] == 0) return;                                        // finished by the tier kernel itself
-    const int i = p.tier_list[wi];
+    const int i = wi < p.n_hi ? p.tier_list_hi[wi] : p.tier_list[wi - p.n_hi];
     const int n = H.hdr[1], npos = H.hdr[2], np0 = H.hdr[3], n_up = H.hdr[4];
     const bool any_unreached = H.hdr[5] != 0;
     unsigned* pts = (unsigned*)(lds_raw + L.o_pts);
@@ -2037,7 +2037,7 @@ __device__ __forceinline__ void dc_subgraph(const TlcPdParams& p, int wi, unsign
     do {
         const Handoff H = carve_handoff(p.handoff + (size_t)wi * (size_t)p.handoff_stride, NM);
         if (H.hdr[0] == 0 || H.hdr[6] == 0) continue;                 // finished by the tier kernel / not meant for this kernel
-        const int i = p.tier_list[wi];
+        const int i = wi < p.n_hi ? p.tier_list_hi[wi] : p.tier_list[wi - p.n_hi];
         const int n = H.hdr[1], K = H.hdr[2], np0 = H.hdr[3], n_up = H.hdr[4];
         const size_t hin_bytes = al16((size_t)K * 2);
         // what the divide and conquer cannot take (does not fit, or the ranks are no MST order): the serial walk, here

@@ -198,6 +198,8 @@ struct TlcScanParams {
     int* tier_list;   // [TLC_N_TIERS][n_pairs]
     int small_arena;
     int mh_min_pos;         // MEDIUM-sized vicinities with at least this many Pos edges go to the MEDHI list (TLC_MH_MIN_POS; INT_MAX: none)
+    int mh_compact_only;    // 1: ... only those within the compact configuration (the wide ones keep the MEDWIDE list): the MEDHI list is then the
+                            // front part of the compact MEDIUM launch (TlcPdParams::tier_list_hi), pipelined chunks
     int tiny_ok;            // the SMALL-tier vicinities of at most TLC_T_NMAX nodes / TLC_T_MMAX edges get a list of their own
     int* dcm_count;         // device counter (zeroed per chunk): MEDHI / MEDWIDE vicinities with enough Pos edges for the divide and conquer
     int* h_dcm;             // mapped host memory: that count
@@ -226,6 +228,10 @@ struct TlcPdParams {
     // batch mode inputs (arena written by the FILL pass)
     const int* tier_list;  // pair indices of this tier
     int tier_count;
+    // (round 6) list positions [0, n_hi) come from tier_list_hi, the rest from tier_list[wi - n_hi]: the compact MEDIUM list of a pipelined
+    // chunk with its many-Pos vicinities in front (the scan's MEDHI list), so that the longest walks of the swap kernel start first
+    const int* tier_list_hi;
+    int n_hi;
     const int* hdr_n;
     const int* hdr_m2;
     const int* hdr_lu;

@@ -155,7 +155,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tlc_scan_bin(TlcScanParams p) {
                 // divide and conquer's.)
                 const bool wide = n > TLC_C_NMAX || m > TLC_C_MMAX || m - n + 1 >= TLC_DC_MIN_POS_SHARED;
                 const bool split = p.mh_min_pos != 0x7fffffff;
-                if (split && (wide || m - n + 1 >= p.mh_min_pos)) tier = TLC_TIER_MEDHI;
+                if (split && !p.mh_compact_only && (wide || m - n + 1 >= p.mh_min_pos)) tier = TLC_TIER_MEDHI;
+                else if (split && p.mh_compact_only && !wide && m - n + 1 >= p.mh_min_pos) tier = TLC_TIER_MEDHI;   // (same kernels as MEDIUM: the front of its launch)
                 else tier = wide ? TLC_TIER_MEDWIDE : TLC_TIER_MEDIUM;
             }
             else if (n <= TLC_L_NMAX && m <= TLC_L_MMAX) tier = TLC_TIER_LARGE;

@@ -26,6 +26,19 @@ orders = {"as it is": idx,
           "MEDIUM first, fewest Pos first": first(mi[np.argsort(pos[mi], kind="stable")]),
           "MEDIUM last, most Pos first": np.concatenate([np.setdiff1d(idx, mi, assume_unique=True), mi[np.argsort(-pos[mi], kind="stable")]]),
           "all by edges descending": np.argsort(-m, kind="stable")}
+# in place: the pairs of one tier permuted among their own positions (the extraction sees the same mix of sizes along the batch, the
+# tier's LIST comes out in the new order)
+small = (n > 16) & (n <= 64) & (m <= 128) & ~((n <= 16) & (m <= 24))
+mid = ~small & ((n > 64) | (m > 128)) & (n <= 128) & (m <= 256)
+def in_place(sel, key):
+    o = idx.copy(); p_ = idx[sel]; o[p_] = p_[np.argsort(-key[p_], kind="stable")]; return o
+orders["SMALL in place, most edges first"] = in_place(small, m)
+orders["MEDIUM in place, most Pos first"] = in_place(med, pos)
+orders["MEDIUM in place, most edges first"] = in_place(med, m)
+o = in_place(small, m); o2 = idx.copy()
+for sel, key in ((small, m), (mid, m), (med, pos)):
+    p_ = idx[sel]; o2[p_] = p_[np.argsort(-key[p_], kind="stable")]
+orders["SMALL / MID / MEDIUM in place"] = o2
 batches = {k: torch.as_tensor(np.ascontiguousarray(P[o])).cuda() for k, o in orders.items()}
 outs = [torch.empty((E, 25), dtype=torch.float64, device="cuda") for _ in range(3)]
 sts = [torch.empty(E, dtype=torch.uint8, device="cuda") for _ in range(3)]
