@@ -39,6 +39,15 @@ o = in_place(small, m); o2 = idx.copy()
 for sel, key in ((small, m), (mid, m), (med, pos)):
     p_ = idx[sel]; o2[p_] = p_[np.argsort(-key[p_], kind="stable")]
 orders["SMALL / MID / MEDIUM in place"] = o2
+wide = med & ((n > 384) | (m > 512) | (pos >= 320))
+orders = {"as it is": idx,
+          "SMALL in place, most edges first": in_place(small, m),
+          "SMALL in place, two classes (m >= 40 first)": in_place(small, (m >= 40).astype(np.int64)),
+          "MID in place, most Pos first": in_place(mid, pos),
+          "MID in place, most edges first": in_place(mid, m),
+          "MEDWIDE in place, most Pos first": in_place(wide, pos),
+          "compact MEDIUM in place, most Pos first": in_place(med & ~wide, pos),
+          "SMALL / MID / MEDIUM in place": o2}
 batches = {k: torch.as_tensor(np.ascontiguousarray(P[o])).cuda() for k, o in orders.items()}
 outs = [torch.empty((E, 25), dtype=torch.float64, device="cuda") for _ in range(3)]
 sts = [torch.empty(E, dtype=torch.uint8, device="cuda") for _ in range(3)]
