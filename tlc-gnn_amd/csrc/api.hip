@@ -45,9 +45,9 @@ extern "C" int tlc_device_count(void) {
 #define TLC_TIMING_RING 64        /* chunks whose kernel events are kept */
 #define TLC_X_REGION 4096         /* arena entries of the region each workgroup of the extraction starts with (extract.hip) */
 
-// a workspace's control block: [0, 64) control words | [64, 64 + 1024) the scan's per-block flags | 8 ints of statistics | 8 work counters of the
+// a workspace's control block: [0, 64) control words | [64, 64 + TLC_SCAN_MAX_BLOCKS) the scan's per-block flags | 8 ints of statistics | 8 work counters of the
 // general extraction launch, 64 ints apart
-#define TLC_CTL_INTS (64 + 1024 + 8 + 8 * 64)
+#define TLC_CTL_INTS (64 + TLC_SCAN_MAX_BLOCKS + 8 + 8 * 64)
 struct HostSync {
     long long total_entries;
     int tier_count[TLC_N_TIERS];
@@ -591,8 +591,8 @@ extern "C" int tlc_graph_create(int32_t n_nodes, const int32_t* h_rowptr, const 
     for (int i = 0; i < TLC_N_WS; ++i) {
         Workspace* ws = &g->ws[i];
         CK(hipMalloc(&ws->d_ctl, TLC_CTL_INTS * sizeof(int)));   // counters, the scan's per-block flags, 4 x u64 statistics, work counters
-        ws->d_stats = reinterpret_cast<unsigned long long*>(ws->d_ctl + 64 + 1024);      // (8-byte aligned: hipMalloc is 256-byte aligned)
-        CK(hipMalloc(&ws->d_block_sums, 1024 * sizeof(long long)));
+        ws->d_stats = reinterpret_cast<unsigned long long*>(ws->d_ctl + 64 + TLC_SCAN_MAX_BLOCKS);      // (8-byte aligned: hipMalloc is 256-byte aligned)
+        CK(hipMalloc(&ws->d_block_sums, TLC_SCAN_MAX_BLOCKS * sizeof(long long)));
         CK(hipMalloc(&ws->d_totals, 2 * sizeof(long long)));
         CK(hipHostMalloc((void**)&ws->h_sync, sizeof(HostSync), hipHostMallocMapped | hipHostMallocCoherent));
         memset(ws->h_sync, 0, sizeof(HostSync));
@@ -1022,7 +1022,7 @@ static int front_main_scan(tlc_graph* g, Workspace* ws) {
     int* d_early_count = ws->d_ctl + 17;
     unsigned long long* d_bump_top = reinterpret_cast<unsigned long long*>(ws->d_ctl + 20);
     int* d_bump_overflow = ws->d_ctl + 22;
-    vp.work_counter = ws->d_ctl + 64 + 1024 + 8;         // TLC_X_COUNTERS (8) counters, 64 ints apart, behind the statistics
+    vp.work_counter = ws->d_ctl + 64 + TLC_SCAN_MAX_BLOCKS + 8;         // TLC_X_COUNTERS (8) counters, 64 ints apart, behind the statistics
     // (about one chunk per RESIDENT extraction wavefront -- 16 per CU, 4 096 -- when batches are pipelined: the machine is full of
     // other chunks' kernels then and the extraction's own tail costs nothing; twice as many for a lone batch.  In-process A/B,
     // tools/gpu_chunk_ab.sh, x_chunk_div 4096 against 8192 / 16384 / 32768: pipelined batch +0.4 / +2.2 / +2.7 %, latency of one
@@ -1048,7 +1048,7 @@ static int front_main_scan(tlc_graph* g, Workspace* ws) {
     if (early) TLC_HIP_CHECK(hipStreamWaitEvent(s, ws->ev_early, 0));   // the scan reads the early list
 
     // exclusive scan of the induced entry counts + tier binning
-    const int nb = (n_pairs + 1023) / 1024;
+    const int nb = (n_pairs + TLC_SCAN_BLOCK - 1) / TLC_SCAN_BLOCK;
     T0(1, s);
     const unsigned seq = ++ws->pub_seq;
     TlcScanParams sp;
@@ -1090,7 +1090,7 @@ static int front_main_scan(tlc_graph* g, Workspace* ws) {
     sp.h_tier = const_cast<int*>(ws->h_sync_dev->pub_tier);
     sp.h_seq = const_cast<unsigned*>(&ws->h_sync_dev->pub_seq);
     sp.seq = seq;
-    hipLaunchKernelGGL(tlc_scan_bin, dim3(nb), dim3(1024), 0, s, sp);
+    hipLaunchKernelGGL(tlc_scan_bin, dim3(nb), dim3(TLC_SCAN_BLOCK), 0, s, sp);
     T1(1, s);
     TLC_HIP_CHECK(hipGetLastError());
     c.seq = seq;

@@ -32,6 +32,12 @@
 #define TLC_MAX_SUBGRAPH_NODES 65535
 #define TLC_MAX_SUBGRAPH_EDGES ((1 << 24) - 2)
 #define TLC_N_TIERS 8
+/* pairs per block (= threads) of tlc_scan_bin; a chunk has at most 2^20 pairs: TLC_SCAN_MAX_BLOCKS block flags / sums per workspace
+ * (round 6: 512 / 256 -- smaller workgroups are easier to place on a full machine -- measured: pipelined batch equal, one batch alone +1 / +2 %) */
+#ifndef TLC_SCAN_BLOCK
+#define TLC_SCAN_BLOCK 1024
+#endif
+#define TLC_SCAN_MAX_BLOCKS ((1 << 20) / TLC_SCAN_BLOCK)
 /* the TINY list once more, by size class: bin b holds the vicinities with (n + m) / TLC_TINY_BIN_W == TLC_TINY_BINS - 1 - b (largest
    first); the lane-per-subgraph kernel takes 64 consecutive entries of ONE bin per wavefront (it waits for its slowest lane) */
 /* Pos edges from which a vicinity of a 256-thread tier takes the divide and conquer (ext1_dc.h has the measurements); the scan counts them */

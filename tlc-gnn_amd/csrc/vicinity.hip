@@ -62,7 +62,7 @@ template __global__ void tlc_vicinity_kernel<true, 512>(TlcVicParams);
 // block it has to wait for is already running or done), scans its 1024 sizes with wave shuffles, publishes its sum behind
 // a flag and adds up the sums of the blocks before it.  The last block to finish stores the arena size and the tier
 // counts into mapped host memory, fences at system scope and bumps the sequence number the host polls.
-#define SCAN_BLOCK 1024
+#define SCAN_BLOCK TLC_SCAN_BLOCK
 
 // `bumped`: COUNT has written the MID / MEDIUM vicinities already; only the heavy tiers need space
 __device__ __forceinline__ long long arena_entries(int n, int m2, int small_arena, bool bumped) {
