@@ -1528,6 +1528,10 @@ static int acquire_workspace(tlc_graph* g, Workspace** out, bool same) {
         TLC_HIP_CHECK(hipStreamCreateWithPriority(&ws->side[4], hipStreamNonBlocking, prio_hi));
         ws->own_early = 1;
     }
+    // (round 6, measured and not kept: an asynchronous batch that does NOT wait here -- everything it submits is ordered on the GPU behind the
+    // previous chunk's join on the workspace's own main stream anyway, buffers that grow are freed by hipFree, which waits for the device,
+    // and nothing of a finished call is read on the host -- was 1.5 - 2.5 % SLOWER per pipelined batch: the first half's packets then sit in
+    // a hardware queue behind the join's waits, and that queue is shared with a tier stream)
     if (ws->busy) {
         // (development: TLC_HOST_TRACE=1 also prints how long the submitting thread waits here for the workspace's previous chunk)
         static const bool host_trace = getenv("TLC_HOST_TRACE") != nullptr;
