@@ -1454,6 +1454,8 @@ static int run_chunk_back(tlc_graph* g, Workspace* ws) {
                 if (!spec_done && tc[TLC_TIER_MEDHI] > 0 && (r = launch_side(2, TLC_TIER_MEDHI)) != TLC_OK) return r;
                 // (round 6, again after the first half got shorter and the MEDIUM stream's queue reached 0.82 busy: a workspace's MEDIUM list on
                 // the heavy tiers' stream or on the MEDWIDE stream: +0.7 ... +5 % per pipelined batch in every assignment tried)
+                // (round 6: every other pipelined chunk with the MEDIUM list on the MID stream and the MID list on the MEDIUM stream -- the two
+                // queues would then be 0.57 busy each instead of 0.82 / 0.42 -- measured: +3 % per pipelined batch)
                 if (tc[TLC_TIER_MEDIUM] > 0 && (r = launch_side(6, TLC_TIER_MEDIUM, !bumped)) != TLC_OK) return r;
                 if (tc[TLC_TIER_MID] > 0 && (r = launch_side(3, TLC_TIER_MID, !bumped)) != TLC_OK) return r;
             } else {
